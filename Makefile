@@ -1,0 +1,29 @@
+# Top-level build: the gfx950 engine (HIP, C ABI) and the CPU checker under oracle/.
+# hipcc cross-compiles for gfx950 without a GPU.  No FP contraction, no fast-math:
+# the numerics contract depends on it.
+HIPCC   ?= /opt/rocm/bin/hipcc
+ARCH    ?= gfx950
+CSRC    := scl_slam_amd/csrc
+LIBDIR  := scl_slam_amd/lib
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
+            -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-result -Iinclude -I$(CSRC)
+SRCS    := $(CSRC)/engine.hip $(CSRC)/sc_distance.hip $(CSRC)/ringkey_topk.hip $(CSRC)/make_sc.hip $(CSRC)/icp.hip
+OBJS    := $(SRCS:.hip=.o)
+
+all: $(LIBDIR)/libscl_engine.so oracle
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.hpp) include/scl_engine.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/libscl_engine.so: $(OBJS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f $(OBJS) $(LIBDIR)/libscl_engine.so
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

@@ -1,0 +1,191 @@
+/*
+ * scl_engine.h -- C ABI of the MI355X-native Scan Context loop-closure engine.
+ *
+ * This is the drop-in boundary for ONE path of thisparticle/scl_slam (ROS
+ * package dlc_slam): Scan Context place recognition + geometric verification.
+ * Plain pointers and sizes only; no C++/torch types; never throws.
+ *
+ * Each entry point names the reference interface it replaces
+ *   D.h  = include/descriptor.h          (class scan_descriptor, D.h:21-36;
+ *                                          scan_context_descriptor, D.h:1304-1801)
+ *   DM.h = include/distributedMapping.h  (loop-closure driver)
+ * A header-only C++ adapter with the reference's six virtuals lives in
+ * include/scl/scan_context_hip_descriptor.hpp; INTEGRATION.md shows the
+ * one-line change at DM.h:404.
+ *
+ * Conventions
+ *   - every function returns an scl_status (0 = ok, < 0 = error);
+ *   - "values" is the wire format of msg/global_descriptor.msg:8 `float32[]
+ *     values`: R*S floats, ROW-major (ring-major), D.h:1446-1455 / 1576-1582;
+ *   - point clouds are (base pointer, count, stride_bytes) with x,y,z as three
+ *     consecutive floats at the start of each record (pcl::PointXYZI: stride 32);
+ *   - "no loop" is loop_id == -1 exactly as D.h:1615,1678;
+ *   - an engine is internally synchronised: append and detect may be called
+ *     from different threads (the reference calls detect* without mtxSC,
+ *     DM.h:1078,1280, while save() runs under it, DM.h:1001-1003).
+ *   - all compute runs on the GPU; there is no CPU fallback.  Without a HIP
+ *     device scl_create fails with SCL_ERR_NO_DEVICE.
+ */
+#ifndef SCL_ENGINE_H
+#define SCL_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct scl_engine scl_engine;
+
+typedef enum scl_status {
+    SCL_OK               =  0,
+    SCL_ERR_INVALID_ARG  = -1,
+    SCL_ERR_NO_DEVICE    = -2,
+    SCL_ERR_HIP          = -3,
+    SCL_ERR_OUT_OF_RANGE = -4,
+    SCL_ERR_NOMEM        = -5,
+    SCL_ERR_UNSUPPORTED  = -6
+} scl_status;
+
+/* Constructor arguments of scan_context_descriptor, D.h:1307-1316 (same
+ * defaults), plus engine-side knobs. */
+typedef struct scl_config {
+    int    num_ring;            /* PC_NUM_RING              = 20   */
+    int    num_sector;          /* PC_NUM_SECTOR            = 60   */
+    int    num_candidates;      /* NUM_CANDIDATES_FROM_TREE = 3    */
+    double dist_thres;          /* SC_DIST_THRES            = 0.14 */
+    double lidar_height;        /* LIDAR_HEIGHT             = 1.65 */
+    double max_radius;          /* PC_MAX_RADIUS            = 80.0 */
+    int    num_exclude_recent;  /* NUM_EXCLUDE_RECENT       = 100  */
+    int    tree_making_period;  /* TREE_MAKING_PERIOD_      = 10   */
+    double search_ratio;        /* SEARCH_RATIO             = 0.1  */
+    float  knn_exclude_eps;     /* 0 = nanoflann semantics (D.h:1716); FLT_EPSILON =
+                                   libnabo self-match exclusion (D.h:1642)          */
+    int    device;              /* HIP device ordinal                     = 0    */
+    int    initial_capacity;    /* keyframe slots preallocated (grows x2) = 4096 */
+} scl_config;
+
+/* Accumulated device time per kernel family, measured with HIP events on the
+ * engine's own stream while profiling is enabled (scl_profile_enable). */
+typedef struct scl_profile {
+    double   sc_distance_ms;   uint64_t sc_distance_launches;  uint64_t sc_distance_pairs;
+    double   ringkey_topk_ms;  uint64_t ringkey_topk_launches;
+    double   argmin_ms;        uint64_t argmin_launches;
+    double   make_sc_ms;       uint64_t make_sc_launches;      uint64_t make_sc_points;
+    double   ingest_ms;        uint64_t ingest_launches;
+    double   icp_nn_ms;        uint64_t icp_nn_launches;
+    double   icp_reduce_ms;    uint64_t icp_reduce_launches;
+} scl_profile;
+
+const char *scl_status_string(int status);
+const char *scl_last_error(const scl_engine *e);       /* detail of the last failure */
+int  scl_abi_version(void);
+
+int  scl_default_config(scl_config *cfg);
+int  scl_create(const scl_config *cfg, scl_engine **out);     /* ctor, D.h:1307-1344 */
+int  scl_destroy(scl_engine *e);
+
+/* ---- the six virtuals of scan_descriptor (D.h:21-36) ----------------------- */
+
+/* makeAndSaveDescriptorAndKey, D.h:25 / 1604-1611 (called at DM.h:1002).
+ * out_values (R*S floats, may be NULL) receives the vector the reference returns. */
+int  scl_make_and_save(scl_engine *e, const void *points, int n_points, int stride_bytes,
+                       int8_t robot, int index, float *out_values);
+/* saveDescriptorAndKey, D.h:27 / 1572-1585 (called at DM.h:627). */
+int  scl_save_from_wire(scl_engine *e, const float *values, int8_t robot, int index);
+/* detectIntraLoopClosureID, D.h:29 / 1613-1674 (called at DM.h:1078).
+ * shift = ring shift as float (D.h:1665); dist (may be NULL) = the float-narrowed
+ * running minimum of D.h:1655 widened back to double. */
+int  scl_detect_intra(scl_engine *e, int cur, int *loop_id, float *shift, double *dist);
+/* detectInterLoopClosureID, D.h:31 / 1676-1756 (called at DM.h:1280);
+ * yaw_rad as D.h:1752.  Latent defects of the reference are repaired, see DESIGN.md. */
+int  scl_detect_inter(scl_engine *e, int cur, int *loop_id, float *yaw_rad, double *dist);
+/* getIndex, D.h:33 / 1758-1761 */
+int  scl_get_index(const scl_engine *e, int key, int8_t *robot, int *index);
+/* getSize, D.h:35 / 1763-1766: returns the size (>= 0) or a negative status. */
+int  scl_get_size(const scl_engine *e, int id);
+
+/* ---- bulk / building-block entry points ----------------------------------- */
+
+/* makeScancontext only (D.h:1404-1461), nothing is stored. */
+int  scl_make_descriptor(scl_engine *e, const void *points, int n_points, int stride_bytes,
+                         float *out_values);
+/* count descriptors at once; robots/indexs may be NULL (robot 0, index = slot). */
+int  scl_save_bulk(scl_engine *e, const float *values, int count,
+                   const int8_t *robots, const int *indexs);
+/* read back: descriptor in wire format, ring key (D.h:1463-1475, R floats),
+ * sector key (D.h:1477-1489, S doubles) */
+int  scl_get_descriptor(const scl_engine *e, int key, float *values);
+int  scl_get_ringkey(const scl_engine *e, int key, float *ringkey);
+int  scl_get_sectorkey(const scl_engine *e, int key, double *sectorkey);
+
+/* Stage an external query descriptor (wire format) that is NOT stored in the DB;
+ * afterwards pass SCL_QUERY_STAGED as `query`.  Used by the sharded (multi-GPU)
+ * driver, where the query keyframe may live on another rank. */
+#define SCL_QUERY_STAGED (-1)
+int  scl_stage_query(scl_engine *e, const float *values);
+
+/* Exact k nearest ring keys among DB slots [lo, hi): replaces both KD-trees
+ * (libnabo D.h:1631-1642, nanoflann D.h:1699-1716).  Squared L2 in fp32 with
+ * nanoflann's accumulation order (nanoflann.hpp:383-408); ascending distance,
+ * ties -> lower index; unfilled slots idx = -1, d2 = FLT_MAX.
+ * Returns the number found in *found (may be NULL). */
+int  scl_ringkey_topk(scl_engine *e, int query, int lo, int hi, int k,
+                      int *idx, float *d2, int *found);
+/* distanceBtnScanContext (D.h:1538-1569) of `query` against cand[0..n)
+ * (cand == NULL: slots 0..n-1).  dist[i] is bit-identical to the fp64 value of
+ * the sequential CPU evaluation; shift[i] the arg-min ring shift. */
+int  scl_sc_distance_batch(scl_engine *e, int query, const int *cand, int n,
+                           double *dist, int *shift);
+/* BASELINE "full-DB" mode: ring-key top-k AND the shifted SC distance against
+ * every eligible slot [0, hi) with hi = cur - num_exclude_recent (D.h:1627), then
+ * the global arg-min (ties -> lowest slot).  nn_idx/shift/dist describe the best
+ * slot; loop_id = nn_idx iff dist < dist_thres else -1.
+ * With query == SCL_QUERY_STAGED, `hi` is given explicitly via scl_detect_full_range. */
+int  scl_detect_full(scl_engine *e, int cur, int *loop_id, int *nn_idx, int *shift, double *dist);
+int  scl_detect_full_range(scl_engine *e, int query, int lo, int hi,
+                           int *nn_idx, int *shift, double *dist);
+/* Reference-faithful candidates for the sharded driver: local ring-key top-k in
+ * [lo,hi) plus the SC distance/shift of each (one device pass, no host round trip). */
+int  scl_topk_with_distance(scl_engine *e, int query, int lo, int hi, int k,
+                            int *idx, float *d2, double *dist, int *shift, int *found);
+
+/* ---- geometric verification (PCL objects inlined at DM.h:1108-1121, 1211-1230) */
+
+typedef struct scl_icp_params {
+    int    max_iterations;            /* icp.setMaximumIterations(50)        DM.h:1110 */
+    double max_correspondence_dist;   /* icp.setMaxCorrespondenceDistance(100) DM.h:1109 */
+    double transformation_epsilon;    /* icp.setTransformationEpsilon(1e-6)  DM.h:1111 */
+    double euclidean_fitness_epsilon; /* icp.setEuclideanFitnessEpsilon(1e-6) DM.h:1112 */
+    int    estimator;                 /* 0 = point-to-point SVD (reference), 1 = point-to-plane */
+} scl_icp_params;
+
+int  scl_icp_default_params(scl_icp_params *p);
+/* pcl::IterativeClosestPoint::align + getFitnessScore, DM.h:1108-1121.
+ * T = 4x4 row-major final transformation (source -> target). */
+int  scl_icp_align(scl_engine *e, const void *src, int n_src, const void *tgt, int n_tgt,
+                   int stride_bytes, const scl_icp_params *p,
+                   float T[16], float *fitness, int *converged, int *iterations);
+/* CorrespondenceEstimation::determineCorrespondences, DM.h:1211-1215:
+ * exact 1-NN of every source point in the target (ties -> lowest target index). */
+int  scl_nn_correspondences(scl_engine *e, const void *src, int n_src, const void *tgt, int n_tgt,
+                            int stride_bytes, int *nn_index, float *nn_dist2);
+/* TransformationEstimationSVD::estimateRigidTransformation, DM.h:1228-1230,
+ * over correspondence pairs (src_index[i], tgt_index[i]). */
+int  scl_rigid_svd(scl_engine *e, const void *src, int n_src, const void *tgt, int n_tgt,
+                   int stride_bytes, const int *src_index, const int *tgt_index, int n_corr,
+                   float T[16]);
+/* paramsServer::transformPointCloud, DM.h:234-253 (xyz transformed, rest copied) */
+int  scl_transform_cloud(scl_engine *e, const void *in, int n, int stride_bytes,
+                         const float T[16], void *out);
+
+/* ---- measurement ----------------------------------------------------------- */
+int  scl_profile_enable(scl_engine *e, int on);
+int  scl_profile_reset(scl_engine *e);
+int  scl_profile_get(scl_engine *e, scl_profile *out);
+int  scl_device_name(const scl_engine *e, char *buf, int buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCL_ENGINE_H */

@@ -1,0 +1,108 @@
+// device_common.hpp -- shared device helpers for the gfx950 kernels.
+//
+// Numerics contract: every translation unit is built
+// with -ffp-contract=off, so a*b+c is never fused behind our back.  fma() is
+// written explicitly where (and only where) the product is exact in fp64
+// (products of two widened floats), which makes fma(a,b,c) == a*b+c bit for bit.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.hpp"
+
+namespace scl {
+
+constexpr int kWave = 64;                 // gfx950 wavefront
+constexpr int kNoPoint = -1000;           // D.h:1411
+
+// ---- ordered-int encoding of floats: signed-int order == float order -------
+__device__ __forceinline__ int float_to_ordered(float f)
+{
+    int b = __float_as_int(f);
+    return b >= 0 ? b : (b ^ 0x7fffffff);
+}
+__device__ __forceinline__ float ordered_to_float(int o)
+{
+    return __int_as_float(o >= 0 ? o : (o ^ 0x7fffffff));
+}
+
+// ---- deterministic atan (x >= 0): identical operation sequence to the CPU
+// checker's restatement; only + - * / in a fixed order, no libm --------------
+__device__ __forceinline__ double atan_pos(double x)
+{
+    const double hi0 = 4.63647609000806093515e-01, lo0 = 2.26987774529616870924e-17;
+    const double hi1 = 7.85398163397448278999e-01, lo1 = 3.06161699786838301793e-17;
+    const double hi2 = 9.82793723247329054082e-01, lo2 = 1.39033110312309984516e-17;
+    const double hi3 = 1.57079632679489655800e+00, lo3 = 6.12323399573676603587e-17;
+    if (x != x) return x;
+    if (x >= 7.378697629483821e19) return hi3 + lo3;
+    int id;
+    double hi = 0.0, lo = 0.0;
+    if (x < 0.4375) {
+        if (x < 1.862645149230957e-09) return x;
+        id = -1;
+    } else if (x < 1.1875) {
+        if (x < 0.6875) { id = 0; hi = hi0; lo = lo0; x = (2.0 * x - 1.0) / (2.0 + x); }
+        else            { id = 1; hi = hi1; lo = lo1; x = (x - 1.0) / (x + 1.0); }
+    } else {
+        if (x < 2.4375) { id = 2; hi = hi2; lo = lo2; x = (x - 1.5) / (1.0 + 1.5 * x); }
+        else            { id = 3; hi = hi3; lo = lo3; x = -1.0 / x; }
+    }
+    const double z = x * x;
+    const double w = z * z;
+    const double s1 = z * (3.33333333333329318027e-01 + w * (1.42857142725034663711e-01 +
+                      w * (9.09088713343650656196e-02 + w * (6.66107313738753120669e-02 +
+                      w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));
+    const double s2 = w * (-1.99999999998764832476e-01 + w * (-1.11111104054623557880e-01 +
+                      w * (-7.69187620504482999495e-02 + w * (-5.83357013379057348645e-02 +
+                      w * -3.65315727442169155270e-02))));
+    if (id < 0) return x - x * (s1 + s2);
+    return hi - ((x * (s1 + s2) - lo) - x);
+}
+
+__device__ __forceinline__ float atanf_fixed(float x) { return (float)atan_pos((double)x); }
+
+// xy2theta, D.h:1352-1374
+__device__ __forceinline__ float xy2theta(float x, float y)
+{
+    const double k = 180.0 / 3.14159265358979323846;
+    if ((x >= 0) & (y >= 0)) return (float)(k * (double)atanf_fixed(y / x));
+    if ((x < 0) & (y >= 0))  return (float)(180.0 - (k * (double)atanf_fixed(y / (-x))));
+    if ((x < 0) & (y < 0))   return (float)(180.0 + (k * (double)atanf_fixed(y / x)));
+    if ((x >= 0) & (y < 0))  return (float)(360.0 - (k * (double)atanf_fixed((-y) / x)));
+    return __int_as_float(0x7fc00000);
+}
+
+// int(ceil(v)) the way the reference's x86-64 build evaluates it (NaN -> INT_MIN)
+__device__ __forceinline__ int ceil_to_int_x86(double v)
+{
+    const double c = ceil(v);
+    if (!(c >= -2147483648.0 && c <= 2147483647.0)) return (-2147483647 - 1);
+    return (int)c;
+}
+
+// ---- wave-level lexicographic arg-min on (double value, int tag) -----------
+__device__ __forceinline__ void wave_argmin(double &v, int &tag)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(v, off, kWave);
+        const int ot = __shfl_xor(tag, off, kWave);
+        const bool take = (ov < v) | ((ov == v) & (ot < tag));
+        v = take ? ov : v;
+        tag = take ? ot : tag;
+    }
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long k)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(k, off, kWave);
+        k = o < k ? o : k;
+    }
+    return k;
+}
+
+}  // namespace scl

@@ -1,0 +1,843 @@
+// engine.hip -- host side of the C ABI (include/scl_engine.h): keyframe database in
+// HBM, locking, launch orchestration.  No compute happens on the host except the
+// O(k) candidate loop of detectIntra/InterLoopClosureID (descriptor.h:1645-1673,
+// 1721-1755), whose float-narrowing comparison order is part of the contract.
+#include "scl_engine.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "icp.hpp"
+#include "kernels.hpp"
+
+using namespace scl;
+
+namespace {
+
+enum ProfKind { P_SC = 0, P_TOPK, P_ARGMIN, P_MAKESC, P_INGEST, P_ICPNN, P_ICPRED, P_COUNT };
+
+struct PendingEvent { hipEvent_t start, stop; int kind; };
+
+}  // namespace
+
+struct scl_engine {
+    scl_config cfg;
+    int R = 0, S = 0, RG = 0, R4 = 0, SR = 0;
+    int device = 0, num_cu = 256;
+    hipStream_t stream = nullptr;
+    mutable std::mutex mu;
+    mutable std::string last_error;
+
+    // database (layout: kernels.hpp)
+    int n = 0, cap = 0;
+    float4 *d_desc = nullptr; double *d_vkey = nullptr; double *d_norm = nullptr;
+    float *d_rkey = nullptr; float4 *d_rkey4 = nullptr;
+    std::vector<int8_t> robots;
+    std::vector<int> indexs;
+
+    // staged external query (one slot, cap = 1 layout)
+    float4 *q_desc = nullptr; double *q_vkey = nullptr; double *q_norm = nullptr;
+    float *q_rkey = nullptr; float4 *q_rkey4 = nullptr;
+    bool staged = false;
+
+    // scratch
+    float *d_vals = nullptr; size_t vals_cap = 0;          // wire-format staging (floats)
+    unsigned char *d_points = nullptr; size_t points_cap = 0;
+    int *d_tile = nullptr;
+    double *d_dist = nullptr; int *d_shift = nullptr; int *d_cand = nullptr; size_t pair_cap = 0;
+    unsigned long long *d_topk_scratch = nullptr; int *d_topk_idx = nullptr; float *d_topk_d2 = nullptr;
+    double *d_out3 = nullptr;
+    void *h_pinned = nullptr; size_t pinned_cap = 0;       // small result read-back
+
+    // inter-robot tree bookkeeping (descriptor.h:1691-1703, counter initialised: see DESIGN.md)
+    int tree_counter = 0, tree_n = 0;
+
+    // profiling
+    bool prof_on = false;
+    scl_profile prof{};
+    std::vector<PendingEvent> pending;
+    std::vector<hipEvent_t> event_pool;
+
+    IcpWorkspace icp_ws;
+};
+
+namespace {
+
+#define SCL_HIP(e_, call)                                                              \
+    do {                                                                               \
+        hipError_t err__ = (call);                                                     \
+        if (err__ != hipSuccess) {                                                     \
+            (e_)->last_error = std::string(#call) + ": " + hipGetErrorString(err__);   \
+            return err__ == hipErrorOutOfMemory ? SCL_ERR_NOMEM : SCL_ERR_HIP;         \
+        }                                                                              \
+    } while (0)
+
+int fail(const scl_engine *e, int code, const char *msg)
+{
+    if (e) e->last_error = msg;
+    return code;
+}
+
+struct ProfScope {
+    scl_engine *e; int kind; hipEvent_t start = nullptr, stop = nullptr;
+    ProfScope(scl_engine *e_, int kind_) : e(e_), kind(kind_)
+    {
+        if (!e->prof_on) return;
+        auto get = [&]() {
+            hipEvent_t ev = nullptr;
+            if (!e->event_pool.empty()) { ev = e->event_pool.back(); e->event_pool.pop_back(); }
+            else if (hipEventCreate(&ev) != hipSuccess) ev = nullptr;
+            return ev;
+        };
+        start = get(); stop = get();
+        if (start && stop) (void)hipEventRecord(start, e->stream);
+    }
+    ~ProfScope()
+    {
+        if (!e->prof_on || !start || !stop) return;
+        (void)hipEventRecord(stop, e->stream);
+        e->pending.push_back({start, stop, kind});
+    }
+};
+
+void collect_profile(scl_engine *e)
+{   // call after the stream has been synchronised
+    for (auto &p : e->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+            switch (p.kind) {
+            case P_SC:     e->prof.sc_distance_ms += ms;  e->prof.sc_distance_launches++; break;
+            case P_TOPK:   e->prof.ringkey_topk_ms += ms; e->prof.ringkey_topk_launches++; break;
+            case P_ARGMIN: e->prof.argmin_ms += ms;       e->prof.argmin_launches++; break;
+            case P_MAKESC: e->prof.make_sc_ms += ms;      e->prof.make_sc_launches++; break;
+            case P_INGEST: e->prof.ingest_ms += ms;       e->prof.ingest_launches++; break;
+            case P_ICPNN:  e->prof.icp_nn_ms += ms;       e->prof.icp_nn_launches++; break;
+            case P_ICPRED: e->prof.icp_reduce_ms += ms;   e->prof.icp_reduce_launches++; break;
+            default: break;
+            }
+        }
+        e->event_pool.push_back(p.start);
+        e->event_pool.push_back(p.stop);
+    }
+    e->pending.clear();
+}
+
+int sync(scl_engine *e)
+{
+    SCL_HIP(e, hipStreamSynchronize(e->stream));
+    collect_profile(e);
+    return SCL_OK;
+}
+
+template <class T>
+int dev_alloc(scl_engine *e, T **p, size_t count)
+{
+    void *q = nullptr;
+    SCL_HIP(e, hipMalloc(&q, sizeof(T) * (count ? count : 1)));
+    *p = static_cast<T *>(q);
+    return SCL_OK;
+}
+
+template <class T>
+void dev_free(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+DbView db_view(const scl_engine *e)
+{
+    DbView v;
+    v.desc = e->d_desc; v.vkey = e->d_vkey; v.norm = e->d_norm; v.rkey = e->d_rkey; v.rkey4 = e->d_rkey4;
+    v.cap = e->cap; v.R = e->R; v.S = e->S; v.RG = e->RG;
+    return v;
+}
+
+int query_view(const scl_engine *e, int query, QueryView *q)
+{
+    if (query == SCL_QUERY_STAGED) {
+        if (!e->staged) return fail(e, SCL_ERR_INVALID_ARG, "no staged query (call scl_stage_query first)");
+        q->desc = e->q_desc; q->vkey = e->q_vkey; q->norm = e->q_norm; q->rkey = e->q_rkey;
+        return SCL_OK;
+    }
+    if (query < 0 || query >= e->n) return fail(e, SCL_ERR_OUT_OF_RANGE, "query slot out of range");
+    q->desc = e->d_desc + (size_t)query * e->RG * e->S;
+    q->vkey = e->d_vkey + (size_t)query * e->S;
+    q->norm = e->d_norm + (size_t)query * e->S;
+    q->rkey = e->d_rkey + (size_t)query * e->R4;
+    return SCL_OK;
+}
+
+// grow the database to hold at least `need` slots (geometric growth, D2D copies)
+int ensure_capacity(scl_engine *e, int need)
+{
+    if (need <= e->cap) return SCL_OK;
+    int ncap = e->cap > 0 ? e->cap : (e->cfg.initial_capacity > 0 ? e->cfg.initial_capacity : 4096);
+    while (ncap < need) ncap *= 2;
+    const size_t tile = (size_t)e->RG * e->S;
+    float4 *nd = nullptr; double *nv = nullptr; double *nn = nullptr; float *nr = nullptr; float4 *nr4 = nullptr;
+    int rc;
+    if ((rc = dev_alloc(e, &nd, tile * ncap))) return rc;
+    if ((rc = dev_alloc(e, &nv, (size_t)e->S * ncap))) return rc;
+    if ((rc = dev_alloc(e, &nn, (size_t)e->S * ncap))) return rc;
+    if ((rc = dev_alloc(e, &nr, (size_t)e->R4 * ncap))) return rc;
+    if ((rc = dev_alloc(e, &nr4, (size_t)e->RG * ncap))) return rc;
+    SCL_HIP(e, hipMemsetAsync(nr4, 0, sizeof(float4) * (size_t)e->RG * ncap, e->stream));
+    if (e->n > 0) {
+        SCL_HIP(e, hipMemcpyAsync(nd, e->d_desc, sizeof(float4) * tile * e->n, hipMemcpyDeviceToDevice, e->stream));
+        SCL_HIP(e, hipMemcpyAsync(nv, e->d_vkey, sizeof(double) * (size_t)e->S * e->n, hipMemcpyDeviceToDevice, e->stream));
+        SCL_HIP(e, hipMemcpyAsync(nn, e->d_norm, sizeof(double) * (size_t)e->S * e->n, hipMemcpyDeviceToDevice, e->stream));
+        SCL_HIP(e, hipMemcpyAsync(nr, e->d_rkey, sizeof(float) * (size_t)e->R4 * e->n, hipMemcpyDeviceToDevice, e->stream));
+        SCL_HIP(e, hipMemcpy2DAsync(nr4, sizeof(float4) * ncap, e->d_rkey4, sizeof(float4) * e->cap,
+                                    sizeof(float4) * e->n, e->RG, hipMemcpyDeviceToDevice, e->stream));
+    }
+    SCL_HIP(e, hipStreamSynchronize(e->stream));
+    dev_free(e->d_desc); dev_free(e->d_vkey); dev_free(e->d_norm); dev_free(e->d_rkey); dev_free(e->d_rkey4);
+    e->d_desc = nd; e->d_vkey = nv; e->d_norm = nn; e->d_rkey = nr; e->d_rkey4 = nr4;
+    e->cap = ncap;
+    return SCL_OK;
+}
+
+int ensure_vals(scl_engine *e, size_t floats)
+{
+    if (floats <= e->vals_cap) return SCL_OK;
+    dev_free(e->d_vals);
+    int rc = dev_alloc(e, &e->d_vals, floats);
+    if (rc) { e->vals_cap = 0; return rc; }
+    e->vals_cap = floats;
+    return SCL_OK;
+}
+
+int ensure_points(scl_engine *e, size_t bytes)
+{
+    if (bytes <= e->points_cap) return SCL_OK;
+    dev_free(e->d_points);
+    size_t nb = bytes + bytes / 4 + 4096;
+    int rc = dev_alloc(e, &e->d_points, nb);
+    if (rc) { e->points_cap = 0; return rc; }
+    e->points_cap = nb;
+    return SCL_OK;
+}
+
+int ensure_pairs(scl_engine *e, size_t n)
+{
+    if (n <= e->pair_cap) return SCL_OK;
+    dev_free(e->d_dist); dev_free(e->d_shift); dev_free(e->d_cand);
+    size_t nn = n + n / 2 + 64;
+    int rc;
+    if ((rc = dev_alloc(e, &e->d_dist, nn))) return rc;
+    if ((rc = dev_alloc(e, &e->d_shift, nn))) return rc;
+    if ((rc = dev_alloc(e, &e->d_cand, nn))) return rc;
+    e->pair_cap = nn;
+    return SCL_OK;
+}
+
+int ensure_pinned(scl_engine *e, size_t bytes)
+{
+    if (bytes <= e->pinned_cap) return SCL_OK;
+    if (e->h_pinned) { (void)hipHostFree(e->h_pinned); e->h_pinned = nullptr; e->pinned_cap = 0; }
+    SCL_HIP(e, hipHostMalloc(&e->h_pinned, bytes, hipHostMallocDefault));
+    e->pinned_cap = bytes;
+    return SCL_OK;
+}
+
+// ingest `count` wire descriptors already in e->d_vals into slots [first, first+count)
+int ingest_from_vals(scl_engine *e, int count, int first_slot)
+{
+    ProfScope ps(e, P_INGEST);
+    SCL_HIP(e, launch_ingest(e->d_vals, count, first_slot, e->d_desc, e->d_vkey, e->d_norm, e->d_rkey,
+                             e->d_rkey4, e->cap, e->R, e->S, e->stream));
+    return SCL_OK;
+}
+
+int append_meta(scl_engine *e, int8_t robot, int index)
+{
+    e->robots.push_back(robot);
+    e->indexs.push_back(index);
+    e->n++;
+    return SCL_OK;
+}
+
+// points (host) -> e->d_vals[0 .. R*S) on device
+int make_sc_to_vals(scl_engine *e, const void *points, int n_points, int stride_bytes)
+{
+    if (n_points < 0 || stride_bytes < 12 || (stride_bytes & 3)) return fail(e, SCL_ERR_INVALID_ARG, "bad point layout");
+    if (n_points > 0 && !points) return fail(e, SCL_ERR_INVALID_ARG, "null points");
+    int rc;
+    const size_t bytes = (size_t)n_points * (size_t)stride_bytes;
+    if ((rc = ensure_points(e, bytes + 16))) return rc;
+    if ((rc = ensure_vals(e, (size_t)e->R * e->S))) return rc;
+    if (bytes) SCL_HIP(e, hipMemcpyAsync(e->d_points, points, bytes, hipMemcpyHostToDevice, e->stream));
+    {
+        ProfScope ps(e, P_MAKESC);
+        SCL_HIP(e, launch_make_sc(e->d_points, n_points, stride_bytes, e->R, e->S, e->cfg.lidar_height,
+                                  e->cfg.max_radius, e->d_tile, e->d_vals, e->num_cu, e->stream));
+    }
+    e->prof.make_sc_points += e->prof_on ? (uint64_t)n_points : 0;
+    return SCL_OK;
+}
+
+int launch_distance(scl_engine *e, const QueryView &q, const int *d_cand, int slot_base, int n)
+{
+    ProfScope ps(e, P_SC);
+    SCL_HIP(e, launch_sc_distance(db_view(e), q, d_cand, slot_base, n, e->SR, e->d_dist, e->d_shift,
+                                  e->num_cu, e->stream));
+    if (e->prof_on) e->prof.sc_distance_pairs += (uint64_t)n;
+    return SCL_OK;
+}
+
+int launch_topk(scl_engine *e, const QueryView &q, int lo, int hi, int k, float eps)
+{
+    ProfScope ps(e, P_TOPK);
+    SCL_HIP(e, launch_ringkey_topk(db_view(e), q.rkey, lo, hi, k, eps, e->d_topk_scratch,
+                                   e->d_topk_idx, e->d_topk_d2, e->stream));
+    return SCL_OK;
+}
+
+// top-k in [lo,hi) followed by the SC distance of those k candidates; results on host.
+int topk_with_distance_locked(scl_engine *e, int query, int lo, int hi, int k, float eps,
+                              int *idx, float *d2, double *dist, int *shift, int *found)
+{
+    if (k <= 0 || k > kTopkMaxK) return fail(e, SCL_ERR_INVALID_ARG, "k out of range (1..64)");
+    QueryView q;
+    int rc = query_view(e, query, &q);
+    if (rc) return rc;
+    if (lo < 0) lo = 0;
+    if (hi > e->n) hi = e->n;
+    if ((rc = ensure_pairs(e, (size_t)k))) return rc;
+    if ((rc = launch_topk(e, q, lo, hi, k, eps))) return rc;
+    if (hi > lo && (dist || shift)) {
+        if ((rc = launch_distance(e, q, e->d_topk_idx, 0, k))) return rc;
+    }
+    const size_t need = (size_t)k * (sizeof(int) * 2 + sizeof(float) + sizeof(double));
+    if ((rc = ensure_pinned(e, need))) return rc;
+    char *h = static_cast<char *>(e->h_pinned);
+    int *h_idx = reinterpret_cast<int *>(h);
+    float *h_d2 = reinterpret_cast<float *>(h + sizeof(int) * k);
+    double *h_dist = reinterpret_cast<double *>(h + (sizeof(int) + sizeof(float)) * k);
+    int *h_shift = reinterpret_cast<int *>(h + (sizeof(int) + sizeof(float) + sizeof(double)) * k);
+    SCL_HIP(e, hipMemcpyAsync(h_idx, e->d_topk_idx, sizeof(int) * k, hipMemcpyDeviceToHost, e->stream));
+    SCL_HIP(e, hipMemcpyAsync(h_d2, e->d_topk_d2, sizeof(float) * k, hipMemcpyDeviceToHost, e->stream));
+    const bool have_dist = hi > lo && (dist || shift);
+    if (have_dist) {
+        SCL_HIP(e, hipMemcpyAsync(h_dist, e->d_dist, sizeof(double) * k, hipMemcpyDeviceToHost, e->stream));
+        SCL_HIP(e, hipMemcpyAsync(h_shift, e->d_shift, sizeof(int) * k, hipMemcpyDeviceToHost, e->stream));
+    }
+    if ((rc = sync(e))) return rc;
+    int nf = 0;
+    for (int i = 0; i < k; ++i) {
+        if (idx) idx[i] = h_idx[i];
+        if (d2) d2[i] = h_d2[i];
+        if (dist) dist[i] = have_dist ? h_dist[i] : kBigDist;
+        if (shift) shift[i] = have_dist ? h_shift[i] : 0;
+        if (h_idx[i] >= 0) nf++;
+    }
+    if (found) *found = nf;
+    return SCL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *scl_status_string(int status)
+{
+    switch (status) {
+    case SCL_OK: return "ok";
+    case SCL_ERR_INVALID_ARG: return "invalid argument";
+    case SCL_ERR_NO_DEVICE: return "no HIP device";
+    case SCL_ERR_HIP: return "HIP runtime error";
+    case SCL_ERR_OUT_OF_RANGE: return "index out of range";
+    case SCL_ERR_NOMEM: return "out of memory";
+    case SCL_ERR_UNSUPPORTED: return "unsupported";
+    default: return "unknown status";
+    }
+}
+
+const char *scl_last_error(const scl_engine *e) { return e ? e->last_error.c_str() : "null engine"; }
+
+int scl_abi_version(void) { return 1; }
+
+int scl_default_config(scl_config *c)
+{
+    if (!c) return SCL_ERR_INVALID_ARG;
+    c->num_ring = 20; c->num_sector = 60; c->num_candidates = 3;       /* D.h:1308-1310 */
+    c->dist_thres = 0.14; c->lidar_height = 1.65; c->max_radius = 80.0; /* D.h:1311-1313 */
+    c->num_exclude_recent = 100; c->tree_making_period = 10;            /* D.h:1314-1315 */
+    c->search_ratio = 0.1;                                              /* D.h:1316 */
+    c->knn_exclude_eps = 0.0f;
+    c->device = 0;
+    c->initial_capacity = 4096;
+    return SCL_OK;
+}
+
+int scl_create(const scl_config *cfg, scl_engine **out)
+{
+    if (!cfg || !out) return SCL_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (cfg->num_ring < 1 || cfg->num_ring > 256 || cfg->num_sector < 1 || cfg->num_sector > 1024 ||
+        cfg->num_candidates < 1 || cfg->num_candidates > kTopkMaxK || cfg->tree_making_period < 1 ||
+        cfg->num_exclude_recent < 0 || !(cfg->max_radius > 0.0) || !(cfg->search_ratio >= 0.0))
+        return SCL_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SCL_ERR_NO_DEVICE;
+    if (cfg->device < 0 || cfg->device >= ndev) return SCL_ERR_INVALID_ARG;
+    scl_engine *e = new (std::nothrow) scl_engine();
+    if (!e) return SCL_ERR_NOMEM;
+    e->cfg = *cfg;
+    e->R = cfg->num_ring; e->S = cfg->num_sector;
+    e->RG = (e->R + 3) / 4; e->R4 = e->RG * 4;
+    e->SR = (int)std::round(0.5 * cfg->search_ratio * (double)e->S);   /* D.h:1545 */
+    if (e->SR < 0) e->SR = 0;
+    e->device = cfg->device;
+    int rc = SCL_OK;
+    auto bail = [&](int code) { scl_destroy(e); return code; };
+    if (hipSetDevice(e->device) != hipSuccess) return bail(SCL_ERR_HIP);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, e->device) == hipSuccess && prop.multiProcessorCount > 0)
+        e->num_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(SCL_ERR_HIP);
+    if ((rc = ensure_capacity(e, 1))) return bail(rc);
+    const size_t tile = (size_t)e->RG * e->S;
+    if ((rc = dev_alloc(e, &e->q_desc, tile))) return bail(rc);
+    if ((rc = dev_alloc(e, &e->q_vkey, (size_t)e->S))) return bail(rc);
+    if ((rc = dev_alloc(e, &e->q_norm, (size_t)e->S))) return bail(rc);
+    if ((rc = dev_alloc(e, &e->q_rkey, (size_t)e->R4))) return bail(rc);
+    if ((rc = dev_alloc(e, &e->q_rkey4, (size_t)e->RG))) return bail(rc);
+    if ((rc = dev_alloc(e, &e->d_tile, (size_t)e->R * e->S))) return bail(rc);
+    if ((rc = dev_alloc(e, &e->d_topk_scratch, (size_t)kTopkMaxBlocks * kTopkMaxK))) return bail(rc);
+    if ((rc = dev_alloc(e, &e->d_topk_idx, (size_t)kTopkMaxK))) return bail(rc);
+    if ((rc = dev_alloc(e, &e->d_topk_d2, (size_t)kTopkMaxK))) return bail(rc);
+    if ((rc = dev_alloc(e, &e->d_out3, (size_t)4))) return bail(rc);
+    if ((rc = ensure_pairs(e, 1024))) return bail(rc);
+    if ((rc = ensure_pinned(e, 1 << 16))) return bail(rc);
+    if ((rc = ensure_vals(e, (size_t)e->R * e->S))) return bail(rc);
+    *out = e;
+    return SCL_OK;
+}
+
+int scl_destroy(scl_engine *e)
+{
+    if (!e) return SCL_OK;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto &p : e->pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
+    for (auto ev : e->event_pool) (void)hipEventDestroy(ev);
+    icp_workspace_free(&e->icp_ws);
+    dev_free(e->d_desc); dev_free(e->d_vkey); dev_free(e->d_norm); dev_free(e->d_rkey); dev_free(e->d_rkey4);
+    dev_free(e->q_desc); dev_free(e->q_vkey); dev_free(e->q_norm); dev_free(e->q_rkey); dev_free(e->q_rkey4);
+    dev_free(e->d_vals); dev_free(e->d_points); dev_free(e->d_tile);
+    dev_free(e->d_dist); dev_free(e->d_shift); dev_free(e->d_cand);
+    dev_free(e->d_topk_scratch); dev_free(e->d_topk_idx); dev_free(e->d_topk_d2); dev_free(e->d_out3);
+    if (e->h_pinned) (void)hipHostFree(e->h_pinned);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return SCL_OK;
+}
+
+/* ---- the six virtuals ------------------------------------------------------ */
+
+int scl_make_and_save(scl_engine *e, const void *points, int n_points, int stride_bytes,
+                      int8_t robot, int index, float *out_values)
+{
+    if (!e) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    int rc;
+    if ((rc = ensure_capacity(e, e->n + 1))) return rc;
+    if ((rc = make_sc_to_vals(e, points, n_points, stride_bytes))) return rc;
+    if ((rc = ingest_from_vals(e, 1, e->n))) return rc;
+    if (out_values)
+        SCL_HIP(e, hipMemcpyAsync(out_values, e->d_vals, sizeof(float) * (size_t)e->R * e->S,
+                                  hipMemcpyDeviceToHost, e->stream));
+    if ((rc = sync(e))) return rc;
+    return append_meta(e, robot, index);
+}
+
+int scl_make_descriptor(scl_engine *e, const void *points, int n_points, int stride_bytes, float *out_values)
+{
+    if (!e || !out_values) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    int rc;
+    if ((rc = make_sc_to_vals(e, points, n_points, stride_bytes))) return rc;
+    SCL_HIP(e, hipMemcpyAsync(out_values, e->d_vals, sizeof(float) * (size_t)e->R * e->S,
+                              hipMemcpyDeviceToHost, e->stream));
+    return sync(e);
+}
+
+int scl_save_from_wire(scl_engine *e, const float *values, int8_t robot, int index)
+{
+    return scl_save_bulk(e, values, 1, &robot, &index);
+}
+
+int scl_save_bulk(scl_engine *e, const float *values, int count, const int8_t *robots, const int *indexs)
+{
+    if (!e || count < 0 || (count > 0 && !values)) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    int rc;
+    if ((rc = ensure_capacity(e, e->n + count))) return rc;
+    const size_t cells = (size_t)e->R * e->S;
+    const int chunk = 2048;
+    if ((rc = ensure_vals(e, cells * (size_t)(count < chunk ? count : chunk)))) return rc;
+    for (int done = 0; done < count; done += chunk) {
+        const int c = count - done < chunk ? count - done : chunk;
+        SCL_HIP(e, hipMemcpyAsync(e->d_vals, values + (size_t)done * cells, sizeof(float) * cells * c,
+                                  hipMemcpyHostToDevice, e->stream));
+        if ((rc = ingest_from_vals(e, c, e->n + done))) return rc;
+        if ((rc = sync(e))) return rc;     // d_vals is reused by the next chunk
+    }
+    for (int i = 0; i < count; ++i) {
+        e->robots.push_back(robots ? robots[i] : (int8_t)0);
+        e->indexs.push_back(indexs ? indexs[i] : e->n + i);
+    }
+    e->n += count;
+    return SCL_OK;
+}
+
+int scl_stage_query(scl_engine *e, const float *values)
+{
+    if (!e || !values) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    int rc;
+    const size_t cells = (size_t)e->R * e->S;
+    if ((rc = ensure_vals(e, cells))) return rc;
+    SCL_HIP(e, hipMemcpyAsync(e->d_vals, values, sizeof(float) * cells, hipMemcpyHostToDevice, e->stream));
+    {
+        ProfScope ps(e, P_INGEST);
+        SCL_HIP(e, launch_ingest(e->d_vals, 1, 0, e->q_desc, e->q_vkey, e->q_norm, e->q_rkey, e->q_rkey4,
+                                 1, e->R, e->S, e->stream));
+    }
+    if ((rc = sync(e))) return rc;
+    e->staged = true;
+    return SCL_OK;
+}
+
+int scl_detect_intra(scl_engine *e, int cur, int *loop_id, float *shift, double *dist)
+{
+    if (!e || !loop_id || !shift) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    *loop_id = -1; *shift = 0.0f;                                         /* D.h:1615 */
+    if (dist) *dist = kBigDist;
+    if (cur < 0 || cur >= e->n) return fail(e, SCL_ERR_OUT_OF_RANGE, "cur out of range");
+    const int k = e->cfg.num_candidates;
+    if (cur < e->cfg.num_exclude_recent + k + 1) return SCL_OK;           /* D.h:1620-1623 */
+    const int history = cur - e->cfg.num_exclude_recent;                  /* D.h:1627 */
+    int idx[kTopkMaxK]; float d2[kTopkMaxK]; double cd[kTopkMaxK]; int ca[kTopkMaxK];
+    int rc = topk_with_distance_locked(e, cur, 0, history, k, e->cfg.knn_exclude_eps, idx, d2, cd, ca, nullptr);
+    if (rc) return rc;
+    float minDis = 10000000.0f;                                           /* D.h:1637: a float */
+    int minIndex = -1, minBias = 0;
+    for (int i = 0; i < k; ++i) {                                         /* D.h:1645-1659 */
+        if (idx[i] < 0) continue;
+        if (cd[i] < (double)minDis) {                                     /* D.h:1653 */
+            minDis = (float)cd[i];                                        /* D.h:1655 narrowing */
+            minIndex = idx[i];
+            minBias = ca[i];
+        }
+    }
+    if (dist) *dist = (double)minDis;
+    if ((double)minDis < e->cfg.dist_thres) {                             /* D.h:1662 */
+        *loop_id = minIndex;
+        *shift = (float)minBias;                                          /* D.h:1665 */
+    }
+    return SCL_OK;
+}
+
+int scl_detect_inter(scl_engine *e, int cur, int *loop_id, float *yaw_rad, double *dist)
+{
+    if (!e || !loop_id || !yaw_rad) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    *loop_id = -1; *yaw_rad = 0.0f;                                       /* D.h:1678,1686 */
+    if (dist) *dist = kBigDist;
+    if (cur < 0 || cur >= e->n) return fail(e, SCL_ERR_OUT_OF_RANGE, "cur out of range");
+    if (e->n < e->cfg.num_exclude_recent + 1) return SCL_OK;              /* D.h:1684-1688 */
+    if (e->tree_counter % e->cfg.tree_making_period == 0)                 /* D.h:1691-1702 */
+        e->tree_n = e->n - e->cfg.num_exclude_recent;
+    e->tree_counter = e->tree_counter + 1;                                /* D.h:1703 */
+    const int k = e->cfg.num_candidates;
+    int idx[kTopkMaxK]; float d2[kTopkMaxK]; double cd[kTopkMaxK]; int ca[kTopkMaxK];
+    int rc = topk_with_distance_locked(e, cur, 0, e->tree_n, k, 0.0f, idx, d2, cd, ca, nullptr);
+    if (rc) return rc;
+    // slots the search left unfilled read as index 0 in the reference (zero-initialised
+    // candidate_indexes, D.h:1710): score slot 0 for them.
+    bool need0 = false;
+    for (int i = 0; i < k; ++i) need0 |= idx[i] < 0;
+    double cd0 = kBigDist; int ca0 = 0;
+    if (need0 && e->tree_n > 0) {
+        QueryView q;
+        if ((rc = query_view(e, cur, &q))) return rc;
+        if ((rc = launch_distance(e, q, nullptr, 0, 1))) return rc;
+        SCL_HIP(e, hipMemcpyAsync(e->h_pinned, e->d_dist, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        SCL_HIP(e, hipMemcpyAsync((char *)e->h_pinned + 8, e->d_shift, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        if ((rc = sync(e))) return rc;
+        cd0 = *reinterpret_cast<double *>(e->h_pinned);
+        ca0 = *reinterpret_cast<int *>((char *)e->h_pinned + 8);
+    }
+    double min_dist = 10000000;                                           /* D.h:1705 */
+    int nn_align = 0, nn_idx = -1;
+    for (int i = 0; i < k; ++i) {                                         /* D.h:1721-1737 */
+        const int ci = idx[i] < 0 ? 0 : idx[i];
+        const double c = idx[i] < 0 ? cd0 : cd[i];
+        const int al = idx[i] < 0 ? ca0 : ca[i];
+        if (c < min_dist) {
+            if (ci == cur) continue;                                      /* D.h:1731 */
+            min_dist = c; nn_align = al; nn_idx = ci;
+        }
+    }
+    if (min_dist < e->cfg.dist_thres) *loop_id = nn_idx;                  /* D.h:1741-1744 */
+    const double unit_sector_angle = 360.0 / (double)e->S;                /* D.h:1332 */
+    *yaw_rad = (float)(nn_align * unit_sector_angle * M_PI / 180.0);      /* D.h:1752 */
+    if (dist) *dist = min_dist;
+    return SCL_OK;
+}
+
+int scl_get_index(const scl_engine *e, int key, int8_t *robot, int *index)
+{
+    if (!e || !robot || !index) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (key < 0 || key >= e->n) return fail(e, SCL_ERR_OUT_OF_RANGE, "key out of range");
+    *robot = e->robots[key];
+    *index = e->indexs[key];
+    return SCL_OK;
+}
+
+int scl_get_size(const scl_engine *e, int id)
+{
+    (void)id;                                                             /* D.h:1763-1766 ignores idIn */
+    if (!e) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    return e->n;
+}
+
+/* ---- building blocks -------------------------------------------------------- */
+
+int scl_get_descriptor(const scl_engine *ce, int key, float *values)
+{
+    scl_engine *e = const_cast<scl_engine *>(ce);
+    if (!e || !values) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    if (key < 0 || key >= e->n) return fail(e, SCL_ERR_OUT_OF_RANGE, "key out of range");
+    int rc;
+    const size_t cells = (size_t)e->R * e->S;
+    if ((rc = ensure_vals(e, cells))) return rc;
+    SCL_HIP(e, launch_untile(e->d_desc + (size_t)key * e->RG * e->S, e->R, e->S, e->d_vals, e->stream));
+    SCL_HIP(e, hipMemcpyAsync(values, e->d_vals, sizeof(float) * cells, hipMemcpyDeviceToHost, e->stream));
+    return sync(e);
+}
+
+int scl_get_ringkey(const scl_engine *ce, int key, float *ringkey)
+{
+    scl_engine *e = const_cast<scl_engine *>(ce);
+    if (!e || !ringkey) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    if (key < 0 || key >= e->n) return fail(e, SCL_ERR_OUT_OF_RANGE, "key out of range");
+    SCL_HIP(e, hipMemcpyAsync(ringkey, e->d_rkey + (size_t)key * e->R4, sizeof(float) * e->R,
+                              hipMemcpyDeviceToHost, e->stream));
+    return sync(e);
+}
+
+int scl_get_sectorkey(const scl_engine *ce, int key, double *sectorkey)
+{
+    scl_engine *e = const_cast<scl_engine *>(ce);
+    if (!e || !sectorkey) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    if (key < 0 || key >= e->n) return fail(e, SCL_ERR_OUT_OF_RANGE, "key out of range");
+    SCL_HIP(e, hipMemcpyAsync(sectorkey, e->d_vkey + (size_t)key * e->S, sizeof(double) * e->S,
+                              hipMemcpyDeviceToHost, e->stream));
+    return sync(e);
+}
+
+int scl_ringkey_topk(scl_engine *e, int query, int lo, int hi, int k, int *idx, float *d2, int *found)
+{
+    if (!e || !idx || !d2) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    return topk_with_distance_locked(e, query, lo, hi, k, e->cfg.knn_exclude_eps, idx, d2, nullptr, nullptr, found);
+}
+
+int scl_topk_with_distance(scl_engine *e, int query, int lo, int hi, int k,
+                           int *idx, float *d2, double *dist, int *shift, int *found)
+{
+    if (!e || !idx || !d2 || !dist || !shift) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    return topk_with_distance_locked(e, query, lo, hi, k, e->cfg.knn_exclude_eps, idx, d2, dist, shift, found);
+}
+
+int scl_sc_distance_batch(scl_engine *e, int query, const int *cand, int n, double *dist, int *shift)
+{
+    if (!e || n < 0 || !dist || !shift) return SCL_ERR_INVALID_ARG;
+    if (n == 0) return SCL_OK;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    QueryView q;
+    int rc = query_view(e, query, &q);
+    if (rc) return rc;
+    if (cand) {
+        for (int i = 0; i < n; ++i)
+            if (cand[i] >= e->n) return fail(e, SCL_ERR_OUT_OF_RANGE, "candidate slot out of range");
+    } else if (n > e->n) {
+        return fail(e, SCL_ERR_OUT_OF_RANGE, "n exceeds database size");
+    }
+    if ((rc = ensure_pairs(e, (size_t)n))) return rc;
+    if (cand) SCL_HIP(e, hipMemcpyAsync(e->d_cand, cand, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+    if ((rc = launch_distance(e, q, cand ? e->d_cand : nullptr, 0, n))) return rc;
+    SCL_HIP(e, hipMemcpyAsync(dist, e->d_dist, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, e->stream));
+    SCL_HIP(e, hipMemcpyAsync(shift, e->d_shift, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, e->stream));
+    return sync(e);
+}
+
+int scl_detect_full_range(scl_engine *e, int query, int lo, int hi, int *nn_idx, int *shift, double *dist)
+{
+    if (!e || !nn_idx || !shift || !dist) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    *nn_idx = -1; *shift = 0; *dist = kBigDist;
+    QueryView q;
+    int rc = query_view(e, query, &q);
+    if (rc) return rc;
+    if (lo < 0) lo = 0;
+    if (hi > e->n) hi = e->n;
+    const int n = hi - lo;
+    if (n <= 0) return SCL_OK;
+    if ((rc = ensure_pairs(e, (size_t)n))) return rc;
+    // "full ring-key + shifted SC distance per incoming scan": the ring-key scan runs too
+    if ((rc = launch_topk(e, q, lo, hi, e->cfg.num_candidates, e->cfg.knn_exclude_eps))) return rc;
+    if ((rc = launch_distance(e, q, nullptr, lo, n))) return rc;
+    {
+        ProfScope ps(e, P_ARGMIN);
+        SCL_HIP(e, launch_argmin(e->d_dist, e->d_shift, n, e->d_out3, e->stream));
+    }
+    SCL_HIP(e, hipMemcpyAsync(e->h_pinned, e->d_out3, sizeof(double) * 3, hipMemcpyDeviceToHost, e->stream));
+    if ((rc = sync(e))) return rc;
+    const double *o = static_cast<const double *>(e->h_pinned);
+    *dist = o[0];
+    *nn_idx = o[1] < 0 ? -1 : lo + (int)o[1];
+    *shift = (int)o[2];
+    return SCL_OK;
+}
+
+int scl_detect_full(scl_engine *e, int cur, int *loop_id, int *nn_idx, int *shift, double *dist)
+{
+    if (!e || !loop_id || !nn_idx || !shift || !dist) return SCL_ERR_INVALID_ARG;
+    *loop_id = -1;
+    if (cur < 0) return SCL_ERR_OUT_OF_RANGE;
+    const int hi = cur - e->cfg.num_exclude_recent;                       /* D.h:1627 */
+    int rc = scl_detect_full_range(e, cur, 0, hi, nn_idx, shift, dist);
+    if (rc) return rc;
+    if (*nn_idx >= 0 && *dist < e->cfg.dist_thres) *loop_id = *nn_idx;
+    return SCL_OK;
+}
+
+/* ---- geometric verification -------------------------------------------------- */
+
+int scl_icp_default_params(scl_icp_params *p)
+{
+    if (!p) return SCL_ERR_INVALID_ARG;
+    p->max_iterations = 50;               /* DM.h:1110 */
+    p->max_correspondence_dist = 100.0;   /* DM.h:1109 */
+    p->transformation_epsilon = 1e-6;     /* DM.h:1111 */
+    p->euclidean_fitness_epsilon = 1e-6;  /* DM.h:1112 */
+    p->estimator = 0;
+    return SCL_OK;
+}
+
+int scl_icp_align(scl_engine *e, const void *src, int n_src, const void *tgt, int n_tgt,
+                  int stride_bytes, const scl_icp_params *p,
+                  float T[16], float *fitness, int *converged, int *iterations)
+{
+    if (!e || !src || !tgt || !p || !T) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    std::string err;
+    int rc = icp_align(&e->icp_ws, e->stream, e->num_cu, src, n_src, tgt, n_tgt, stride_bytes, *p,
+                       T, fitness, converged, iterations, &err);
+    if (rc) e->last_error = err;
+    return rc;
+}
+
+int scl_nn_correspondences(scl_engine *e, const void *src, int n_src, const void *tgt, int n_tgt,
+                           int stride_bytes, int *nn_index, float *nn_dist2)
+{
+    if (!e || !src || !tgt || !nn_index) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    std::string err;
+    int rc = icp_nn_correspondences(&e->icp_ws, e->stream, e->num_cu, src, n_src, tgt, n_tgt, stride_bytes,
+                                    nn_index, nn_dist2, &err);
+    if (rc) e->last_error = err;
+    return rc;
+}
+
+int scl_rigid_svd(scl_engine *e, const void *src, int n_src, const void *tgt, int n_tgt,
+                  int stride_bytes, const int *src_index, const int *tgt_index, int n_corr, float T[16])
+{
+    if (!e || !src || !tgt || !src_index || !tgt_index || !T) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    std::string err;
+    int rc = icp_rigid_svd(&e->icp_ws, e->stream, e->num_cu, src, n_src, tgt, n_tgt, stride_bytes,
+                           src_index, tgt_index, n_corr, T, &err);
+    if (rc) e->last_error = err;
+    return rc;
+}
+
+int scl_transform_cloud(scl_engine *e, const void *in, int n, int stride_bytes, const float T[16], void *out)
+{
+    if (!e || !in || !out || !T) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    std::string err;
+    int rc = icp_transform_cloud(&e->icp_ws, e->stream, in, n, stride_bytes, T, out, &err);
+    if (rc) e->last_error = err;
+    return rc;
+}
+
+/* ---- measurement ------------------------------------------------------------- */
+
+int scl_profile_enable(scl_engine *e, int on)
+{
+    if (!e) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->prof_on = on != 0;
+    return SCL_OK;
+}
+
+int scl_profile_reset(scl_engine *e)
+{
+    if (!e) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    std::memset(&e->prof, 0, sizeof e->prof);
+    return SCL_OK;
+}
+
+int scl_profile_get(scl_engine *e, scl_profile *out)
+{
+    if (!e || !out) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    *out = e->prof;
+    return SCL_OK;
+}
+
+int scl_device_name(const scl_engine *e, char *buf, int buflen)
+{
+    if (!e || !buf || buflen <= 0) return SCL_ERR_INVALID_ARG;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, e->device) != hipSuccess) return SCL_ERR_HIP;
+    std::snprintf(buf, (size_t)buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return SCL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,33 @@
+// icp.hpp -- geometric verification on the GPU (host-side interface used by engine.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "scl_engine.h"
+
+namespace scl {
+
+struct IcpWorkspace {
+    void *buf[16] = {nullptr};
+    size_t cap[16] = {0};
+    void *pinned = nullptr;
+    size_t pinned_cap = 0;
+};
+
+void icp_workspace_free(IcpWorkspace *ws);
+
+int icp_align(IcpWorkspace *ws, hipStream_t stream, int num_cu, const void *src, int n_src,
+              const void *tgt, int n_tgt, int stride_bytes, const scl_icp_params &p,
+              float T[16], float *fitness, int *converged, int *iterations, std::string *err);
+int icp_nn_correspondences(IcpWorkspace *ws, hipStream_t stream, int num_cu, const void *src, int n_src,
+                           const void *tgt, int n_tgt, int stride_bytes, int *nn_index, float *nn_dist2,
+                           std::string *err);
+int icp_rigid_svd(IcpWorkspace *ws, hipStream_t stream, int num_cu, const void *src, int n_src,
+                  const void *tgt, int n_tgt, int stride_bytes, const int *src_index, const int *tgt_index,
+                  int n_corr, float T[16], std::string *err);
+int icp_transform_cloud(IcpWorkspace *ws, hipStream_t stream, const void *in, int n, int stride_bytes,
+                        const float T[16], void *out, std::string *err);
+
+}  // namespace scl

@@ -1,0 +1,67 @@
+// kernels.hpp -- host-side launch interface of the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace scl {
+
+constexpr double kBigDist = 10000000.0;   // D.h:1494,1556,1637,1705 initial minima
+
+// ---- database layout in HBM (one "slot" per keyframe) -----------------------
+//   desc   float4 [cap][RG][S]   RG = ceil(R/4); element (rg, c) holds rows
+//                                4rg..4rg+3 of column c (rows >= R are 0):
+//                                lane c of a wave reads 16 B, the wave 1 KiB+.
+//   vkey   double [cap][S]       sector key   (D.h:1477-1489), fp64
+//   norm   double [cap][S]       column L2 norms (D.h:1523), fp64
+//   rkey   float  [cap][R4]      ring key, row-major (query side), R4 = 4*RG
+//   rkey4  float4 [RG][cap]      ring key, tiled for the top-k scan
+struct DbView {
+    const float4 *desc;
+    const double *vkey;
+    const double *norm;
+    const float  *rkey;
+    const float4 *rkey4;
+    int cap;     // slot stride of rkey4
+    int R, S, RG;
+};
+
+struct QueryView {          // one descriptor in the same layout (a DB slot or the staged query)
+    const float4 *desc;     // [RG][S]
+    const double *vkey;     // [S]
+    const double *norm;     // [S]
+    const float  *rkey;     // [R4]
+};
+
+// K1: distanceBtnScanContext for n candidates.
+//   slot(i) = cand ? cand[i] : slot_base + i ; slot < 0 -> (1e7, 0) without compute.
+// Returns false when (R,S,SR) has no specialised kernel and the generic one must be used.
+hipError_t launch_sc_distance(const DbView &db, const QueryView &q, const int *cand, int slot_base,
+                              int n, int SR, double *out_dist, int *out_shift, int num_cu,
+                              hipStream_t stream);
+
+// arg-min over (dist[i], i) for i in [0,n): strict <, first wins, NaN never wins,
+// nothing below 1e7 -> idx -1.  out: {dist, (double)idx, (double)shift} packed as 3 doubles.
+hipError_t launch_argmin(const double *dist, const int *shift, int n, double *out3, hipStream_t stream);
+
+// K2: exact ring-key top-k over slots [lo,hi).  out_idx[k], out_d2[k] (device).
+// scratch must hold kTopkMaxBlocks * kTopkMaxK uint64.
+constexpr int kTopkMaxBlocks = 256;
+constexpr int kTopkMaxK = 64;
+hipError_t launch_ringkey_topk(const DbView &db, const float *qkey, int lo, int hi, int k,
+                               float exclude_eps, unsigned long long *scratch,
+                               int *out_idx, float *out_d2, hipStream_t stream);
+
+// ingest: row-major wire descriptors (device) -> DB slots first_slot.. (all derived data)
+hipError_t launch_ingest(const float *values, int count, int first_slot,
+                         float4 *desc, double *vkey, double *norm, float *rkey, float4 *rkey4,
+                         int cap, int R, int S, hipStream_t stream);
+// tiled -> row-major wire format (read back)
+hipError_t launch_untile(const float4 *desc_slot, int R, int S, float *values, hipStream_t stream);
+
+// K3: makeScancontext.  tile = R*S ints (ordered-int max-z image), values = R*S floats.
+hipError_t launch_make_sc(const void *points, int n, int stride_bytes, int R, int S,
+                          double lidar_height, double max_radius, int *tile, float *values,
+                          int num_cu, hipStream_t stream);
+
+}  // namespace scl

@@ -1,0 +1,190 @@
+// make_sc.hip -- K3: Scan Context construction + database ingest.
+//
+//   make_sc_scatter / make_sc_finalize   makeScancontext, include/descriptor.h:1404-1461
+//   ingest                               save(): ring key D.h:1463-1475, sector key
+//                                        D.h:1477-1489, wire decode D.h:1572-1585,
+//                                        plus the column norms of D.h:1523 (hoisted: they
+//                                        depend on one descriptor only)
+//
+// Descriptor construction is a max-z scatter into an R x S polar image.  Taking the
+// maximum is order independent (NaN z never wins `desc < z`, D.h:1438), so the serial
+// loop parallelises exactly: every workgroup streams a contiguous slice of the cloud
+// (one 16-byte load per point record: x,y,z,+pad), bins it with the reference's
+// mixed fp32/fp64 arithmetic, and keeps a private polar tile in LDS updated with
+// integer atomicMax on an order-preserving float encoding; tiles are merged into the
+// global image with one atomicMax per touched cell.  HBM-bound: n*16 B in, R*S*4 out.
+#include "device_common.hpp"
+#include "kernels.hpp"
+
+namespace scl {
+
+namespace {
+
+constexpr int kScThreads = 256;
+
+__global__ __launch_bounds__(kScThreads) void make_sc_scatter_kernel(
+    const unsigned char *points, int n, int stride, int R, int S,
+    double lidar_height, double max_radius, int *gtile)
+{
+    extern __shared__ int tile[];
+    const int cells = R * S;
+    const int init = float_to_ordered((float)kNoPoint);
+    for (int i = threadIdx.x; i < cells; i += blockDim.x) tile[i] = init;
+    __syncthreads();
+
+    const int per_block = (n + gridDim.x - 1) / gridDim.x;
+    const int begin = blockIdx.x * per_block;
+    int end = begin + per_block; end = end > n ? n : end;
+    for (int p = begin + threadIdx.x; p < end; p += blockDim.x) {
+        const unsigned char *rec = points + (size_t)p * (size_t)stride;
+        float px, py, pzraw;
+        if ((stride & 15) == 0) {                       // pcl::PointXYZI and friends: one dwordx4
+            const float4 v = *reinterpret_cast<const float4 *>(rec);
+            px = v.x; py = v.y; pzraw = v.z;
+        } else {
+            const float *f = reinterpret_cast<const float *>(rec);
+            px = f[0]; py = f[1]; pzraw = f[2];
+        }
+        const float pz = (float)((double)pzraw + lidar_height);        // D.h:1422
+        const float azim_range = sqrtf(px * px + py * py);             // D.h:1425
+        const float azim_angle = xy2theta(px, py);                     // D.h:1426
+        if ((double)azim_range > max_radius) continue;                 // D.h:1429
+        const int ring = max(min(R, ceil_to_int_x86(((double)azim_range / max_radius) * R)), 1);   // D.h:1434
+        const int sect = max(min(S, ceil_to_int_x86(((double)azim_angle / 360.0) * S)), 1);        // D.h:1435
+        if (pz != pz) continue;                                        // NaN never passes `<` (D.h:1438)
+        atomicMax(&tile[(ring - 1) * S + (sect - 1)], float_to_ordered(pz));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cells; i += blockDim.x) {
+        const int v = tile[i];
+        if (v != init) atomicMax(&gtile[i], v);
+    }
+}
+
+__global__ void make_sc_init_kernel(int *gtile, int cells)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cells) gtile[i] = float_to_ordered((float)kNoPoint);
+}
+
+__global__ void make_sc_finalize_kernel(const int *gtile, int cells, float *values)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cells) {
+        float v = ordered_to_float(gtile[i]);
+        if (v == (float)kNoPoint) v = 0.0f;                            // D.h:1450-1453
+        values[i] = v;                                                 // row-major == vT order, D.h:1454
+    }
+}
+
+// One workgroup per descriptor.  values: [count][R*S] row-major floats.
+__global__ __launch_bounds__(256) void ingest_kernel(
+    const float *values, int first_slot, float4 *desc, double *vkey, double *norm,
+    float *rkey, float4 *rkey4, int cap, int R, int S)
+{
+    extern __shared__ float sv[];                 // [R][S+1]
+    const int LS = S + 1;                         // odd-ish stride: column walks hit distinct banks
+    const int RG = (R + 3) >> 2;
+    const int slot = first_slot + blockIdx.x;
+    const float *src = values + (size_t)blockIdx.x * R * S;
+    for (int i = threadIdx.x; i < R * S; i += blockDim.x) {
+        const int r = i / S, c = i - r * S;
+        sv[r * LS + c] = src[i];
+    }
+    __syncthreads();
+
+    // tiled copy: element (rg, c) = rows 4rg..4rg+3 of column c
+    float4 *dslot = desc + (size_t)slot * RG * S;
+    for (int i = threadIdx.x; i < RG * S; i += blockDim.x) {
+        const int rg = i / S, c = i - rg * S;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = 4 * rg + k;
+            v[k] = r < R ? sv[r * LS + c] : 0.0f;
+        }
+        dslot[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    // sector key (column mean, D.h:1482-1486) and column norm (D.h:1523), sequential over rings
+    for (int c = threadIdx.x; c < S; c += blockDim.x) {
+        double sum = 0.0, ss = 0.0;
+        for (int r = 0; r < R; ++r) {
+            const double x = (double)sv[r * LS + c];
+            sum = sum + x;
+            ss = ss + x * x;
+        }
+        vkey[(size_t)slot * S + c] = sum / (double)R;
+        norm[(size_t)slot * S + c] = sqrt(ss);
+    }
+    // ring key (row mean narrowed to float, D.h:1468-1472), sequential over sectors
+    for (int r = threadIdx.x; r < 4 * RG; r += blockDim.x) {
+        float key = 0.0f;
+        if (r < R) {
+            double sum = 0.0;
+            for (int c = 0; c < S; ++c) sum = sum + (double)sv[r * LS + c];
+            key = (float)(sum / (double)S);
+        }
+        rkey[(size_t)slot * 4 * RG + r] = key;
+        reinterpret_cast<float *>(rkey4)[((size_t)(r >> 2) * cap + slot) * 4 + (r & 3)] = key;
+    }
+}
+
+__global__ void untile_kernel(const float4 *dslot, int R, int S, float *values)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < R * S) {
+        const int r = i / S, c = i - r * S;
+        const float *f = reinterpret_cast<const float *>(dslot + (size_t)(r >> 2) * S + c);
+        values[i] = f[r & 3];
+    }
+}
+
+}  // namespace
+
+hipError_t launch_make_sc(const void *points, int n, int stride_bytes, int R, int S,
+                          double lidar_height, double max_radius, int *tile, float *values,
+                          int num_cu, hipStream_t stream)
+{
+    const int cells = R * S;
+    hipLaunchKernelGGL(make_sc_init_kernel, dim3((cells + 255) / 256), dim3(256), 0, stream, tile, cells);
+    if (n > 0) {
+        // ~2k points per workgroup keeps the private-tile merge (cells atomics) amortised
+        int blocks = (n + 2047) / 2048;
+        if (blocks > 2 * num_cu) blocks = 2 * num_cu;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(make_sc_scatter_kernel, dim3(blocks), dim3(kScThreads),
+                           sizeof(int) * (size_t)cells, stream,
+                           (const unsigned char *)points, n, stride_bytes, R, S,
+                           lidar_height, max_radius, tile);
+    }
+    hipLaunchKernelGGL(make_sc_finalize_kernel, dim3((cells + 255) / 256), dim3(256), 0, stream,
+                       tile, cells, values);
+    return hipGetLastError();
+}
+
+hipError_t launch_ingest(const float *values, int count, int first_slot,
+                         float4 *desc, double *vkey, double *norm, float *rkey, float4 *rkey4,
+                         int cap, int R, int S, hipStream_t stream)
+{
+    if (count <= 0) return hipSuccess;
+    const size_t lds = sizeof(float) * (size_t)R * (S + 1);
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)ingest_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ingest_kernel, dim3(count), dim3(256), lds, stream,
+                       values, first_slot, desc, vkey, norm, rkey, rkey4, cap, R, S);
+    return hipGetLastError();
+}
+
+hipError_t launch_untile(const float4 *desc_slot, int R, int S, float *values, hipStream_t stream)
+{
+    const int cells = R * S;
+    hipLaunchKernelGGL(untile_kernel, dim3((cells + 255) / 256), dim3(256), 0, stream, desc_slot, R, S, values);
+    return hipGetLastError();
+}
+
+}  // namespace scl

@@ -1,0 +1,175 @@
+// ringkey_topk.hip -- K2: exact brute-force k-nearest ring keys.
+//
+// Replaces both KD-tree searches of the reference: libnabo on the intra path
+// (include/descriptor.h:1631-1642) and nanoflann on the inter path
+// (descriptor.h:1699-1716).  KD-tree search with eps = 0 is exact, so a full scan
+// that reproduces the metric arithmetic returns the same neighbours:
+//   - squared L2 in fp32, four dimensions per step, accumulated exactly as
+//     nanoflann's L2_Adaptor::evalMetric: result += ((d0*d0 + d1*d1) + d2*d2) + d3*d3
+//     then a sequential tail (include/nanoflann.hpp:383-408); no FMA;
+//   - acceptance `dist < worstDist` with worstDist starting at FLT_MAX
+//     (nanoflann.hpp:158-163, 1360): NaN / +inf / FLT_MAX never enter the set;
+//   - result ordered by ascending distance, equal distances by ascending index
+//     (what nanoflann's KNNResultSet yields when points are visited in index order).
+// The scan is HBM-bound by N*R*4 bytes: the ring-key table is stored tiled
+// ([R/4][cap] float4) so lane i reads 16 contiguous bytes of slot lo+i.
+//
+// Selection: every thread packs (distance bits << 32 | slot) into a u64 (distances are
+// >= 0 so the IEEE bits are monotone); each workgroup extracts its k smallest keys by k
+// rounds of block-wide min, a second single-workgroup pass merges the partial lists.
+#include <float.h>
+
+#include "device_common.hpp"
+#include "kernels.hpp"
+
+namespace scl {
+
+namespace {
+
+constexpr unsigned long long kNoKey = ~0ull;
+constexpr int kTopkThreads = 256;
+constexpr int kTopkPerThread = 4;                       // slots per thread per workgroup
+constexpr int kTopkChunk = kTopkThreads * kTopkPerThread;
+
+__device__ __forceinline__ unsigned long long block_min_u64(unsigned long long k, unsigned long long *sred)
+{
+    k = wave_min_u64(k);
+    const int wv = threadIdx.x / kWave;
+    __syncthreads();
+    if ((threadIdx.x & (kWave - 1)) == 0) sred[wv] = k;
+    __syncthreads();
+    unsigned long long m = sred[0];
+#pragma unroll
+    for (int w = 1; w < kTopkThreads / kWave; ++w) m = sred[w] < m ? sred[w] : m;
+    return m;
+}
+
+// k rounds of (block min, remove).  keys[] are this thread's private keys.
+template <int NK>
+__device__ __forceinline__ void extract_topk(unsigned long long (&keys)[NK], int k,
+                                             unsigned long long *out, unsigned long long *sred)
+{
+    for (int round = 0; round < k; ++round) {
+        unsigned long long mine = keys[0];
+#pragma unroll
+        for (int i = 1; i < NK; ++i) mine = keys[i] < mine ? keys[i] : mine;
+        const unsigned long long m = block_min_u64(mine, sred);
+        if (threadIdx.x == 0) out[round] = m;
+        if (m == kNoKey) {               // exhausted: fill the rest and stop (uniform)
+            for (int r2 = round + 1 + (int)threadIdx.x; r2 < k; r2 += blockDim.x) out[r2] = kNoKey;
+            break;
+        }
+#pragma unroll
+        for (int i = 0; i < NK; ++i) keys[i] = (keys[i] == m) ? kNoKey : keys[i];   // slots are unique
+    }
+}
+
+__global__ __launch_bounds__(kTopkThreads) void ringkey_dist_topk_kernel(
+    const float4 *rkey4, int cap, const float *qkey, int R, int lo, int hi, int k,
+    float exclude_eps, unsigned long long *partial)
+{
+    __shared__ unsigned long long sred[kTopkThreads / kWave];
+    __shared__ unsigned long long srun[kTopkMaxK];      // this workgroup's running k best
+    __shared__ float sq[256];
+    for (int r = threadIdx.x; r < R; r += blockDim.x) sq[r] = qkey[r];
+    for (int i = threadIdx.x; i < kTopkMaxK; i += blockDim.x) srun[i] = kNoKey;
+    __syncthreads();
+
+    const int RGfull = R >> 2;          // full groups of four
+    const int tail = R & 3;
+    const int nchunks = (hi - lo + kTopkChunk - 1) / kTopkChunk;
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        unsigned long long keys[kTopkPerThread + 1];
+#pragma unroll
+        for (int u = 0; u < kTopkPerThread; ++u) {
+            const int slot = lo + chunk * kTopkChunk + u * kTopkThreads + threadIdx.x;
+            unsigned long long key = kNoKey;
+            if (slot < hi) {
+                float result = 0.0f;
+                for (int g = 0; g < RGfull; ++g) {
+                    const float4 b = rkey4[(size_t)g * cap + slot];
+                    const float d0 = sq[4 * g + 0] - b.x;
+                    const float d1 = sq[4 * g + 1] - b.y;
+                    const float d2 = sq[4 * g + 2] - b.z;
+                    const float d3 = sq[4 * g + 3] - b.w;
+                    result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+                }
+                if (tail) {
+                    const float4 b = rkey4[(size_t)RGfull * cap + slot];
+                    const float bv[4] = {b.x, b.y, b.z, b.w};
+                    for (int i = 0; i < tail; ++i) {
+                        const float d0 = sq[4 * RGfull + i] - bv[i];
+                        result += d0 * d0;
+                    }
+                }
+                const bool excluded = (exclude_eps > 0.0f) && (result <= exclude_eps);
+                if (!excluded && (result < FLT_MAX))
+                    key = ((unsigned long long)(unsigned)__float_as_int(result) << 32) | (unsigned)slot;
+            }
+            keys[u] = key;
+        }
+        keys[kTopkPerThread] = (int)threadIdx.x < k ? srun[threadIdx.x] : kNoKey;
+        extract_topk(keys, k, srun, sred);   // first write to srun happens behind a barrier
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < k; i += blockDim.x) partial[(size_t)blockIdx.x * k + i] = srun[i];
+}
+
+// merge of the per-workgroup lists; NK keys per thread (4/16/64 by list count)
+template <int NK>
+__global__ __launch_bounds__(kTopkThreads) void topk_merge_small_kernel(
+    const unsigned long long *partial, int count, int k, int *out_idx, float *out_d2)
+{
+    __shared__ unsigned long long sred[kTopkThreads / kWave];
+    __shared__ unsigned long long sout[kTopkMaxK];
+    unsigned long long keys[NK];
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+        const int p = i * kTopkThreads + threadIdx.x;
+        keys[i] = p < count ? partial[p] : kNoKey;
+    }
+    extract_topk(keys, k, sout, sred);
+    __syncthreads();
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        const unsigned long long m = sout[i];
+        if (m == kNoKey) { out_idx[i] = -1; out_d2[i] = FLT_MAX; }
+        else { out_idx[i] = (int)(unsigned)(m & 0xffffffffull); out_d2[i] = __int_as_float((int)(m >> 32)); }
+    }
+}
+
+__global__ void topk_fill_empty_kernel(int k, int *out_idx, float *out_d2)
+{
+    for (int i = threadIdx.x; i < k; i += blockDim.x) { out_idx[i] = -1; out_d2[i] = FLT_MAX; }
+}
+
+}  // namespace
+
+hipError_t launch_ringkey_topk(const DbView &db, const float *qkey, int lo, int hi, int k,
+                               float exclude_eps, unsigned long long *scratch,
+                               int *out_idx, float *out_d2, hipStream_t stream)
+{
+    if (k <= 0 || k > kTopkMaxK || db.R > 256) return hipErrorInvalidValue;
+    const int n = hi - lo;
+    if (n <= 0) {
+        hipLaunchKernelGGL(topk_fill_empty_kernel, dim3(1), dim3(64), 0, stream, k, out_idx, out_d2);
+        return hipGetLastError();
+    }
+    int blocks = (n + kTopkChunk - 1) / kTopkChunk;
+    if (blocks > kTopkMaxBlocks) blocks = kTopkMaxBlocks;    // workgroups stride over the chunks
+    unsigned long long *partial = scratch;
+    hipLaunchKernelGGL(ringkey_dist_topk_kernel, dim3(blocks), dim3(kTopkThreads), 0, stream,
+                       db.rkey4, db.cap, qkey, db.R, lo, hi, k, exclude_eps, partial);
+    const int count = blocks * k;
+    if (count <= 4 * kTopkThreads)
+        hipLaunchKernelGGL((topk_merge_small_kernel<4>), dim3(1), dim3(kTopkThreads), 0, stream,
+                           partial, count, k, out_idx, out_d2);
+    else if (count <= 16 * kTopkThreads)
+        hipLaunchKernelGGL((topk_merge_small_kernel<16>), dim3(1), dim3(kTopkThreads), 0, stream,
+                           partial, count, k, out_idx, out_d2);
+    else
+        hipLaunchKernelGGL((topk_merge_small_kernel<64>), dim3(1), dim3(kTopkThreads), 0, stream,
+                           partial, count, k, out_idx, out_d2);
+    return hipGetLastError();
+}
+
+}  // namespace scl

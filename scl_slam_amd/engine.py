@@ -1,0 +1,377 @@
+"""ctypes binding of include/scl_engine.h + a Python mirror of the reference's plugin class.
+
+``ScanContextEngine`` exposes the C ABI one-to-one (numpy arrays in / out).
+``ScanContextDescriptor`` mirrors ``scan_context_descriptor`` (reference
+include/descriptor.h:1304-1801): same constructor arguments, same six method names,
+same return conventions (``(-1, 0.0)`` = no loop).
+"""
+import ctypes
+from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int8, c_uint64, c_void_p
+
+import numpy as np
+
+from ._native import load_library
+
+QUERY_STAGED = -1
+
+
+class SclConfig(ctypes.Structure):
+    """scl_config; defaults = scan_context_descriptor ctor defaults (D.h:1308-1316)."""
+    _fields_ = [
+        ("num_ring", c_int), ("num_sector", c_int), ("num_candidates", c_int),
+        ("dist_thres", c_double), ("lidar_height", c_double), ("max_radius", c_double),
+        ("num_exclude_recent", c_int), ("tree_making_period", c_int),
+        ("search_ratio", c_double), ("knn_exclude_eps", c_float),
+        ("device", c_int), ("initial_capacity", c_int),
+    ]
+
+
+class IcpParams(ctypes.Structure):
+    """scl_icp_params; defaults = the settings at DM.h:1109-1112."""
+    _fields_ = [
+        ("max_iterations", c_int), ("max_correspondence_dist", c_double),
+        ("transformation_epsilon", c_double), ("euclidean_fitness_epsilon", c_double),
+        ("estimator", c_int),
+    ]
+
+
+class SclProfile(ctypes.Structure):
+    _fields_ = [
+        ("sc_distance_ms", c_double), ("sc_distance_launches", c_uint64), ("sc_distance_pairs", c_uint64),
+        ("ringkey_topk_ms", c_double), ("ringkey_topk_launches", c_uint64),
+        ("argmin_ms", c_double), ("argmin_launches", c_uint64),
+        ("make_sc_ms", c_double), ("make_sc_launches", c_uint64), ("make_sc_points", c_uint64),
+        ("ingest_ms", c_double), ("ingest_launches", c_uint64),
+        ("icp_nn_ms", c_double), ("icp_nn_launches", c_uint64),
+        ("icp_reduce_ms", c_double), ("icp_reduce_launches", c_uint64),
+    ]
+
+
+class SclError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        super().__init__(f"{where}: status {status}" + (f" ({detail})" if detail else ""))
+
+
+_bound = False
+
+
+def _bind(lib):
+    global _bound
+    if _bound:
+        return
+    P = c_void_p
+    fp, dp, ip = POINTER(c_float), POINTER(c_double), POINTER(c_int)
+    sig = {
+        "scl_status_string": (c_char_p, [c_int]),
+        "scl_last_error": (c_char_p, [P]),
+        "scl_abi_version": (c_int, []),
+        "scl_default_config": (c_int, [POINTER(SclConfig)]),
+        "scl_create": (c_int, [POINTER(SclConfig), POINTER(P)]),
+        "scl_destroy": (c_int, [P]),
+        "scl_make_and_save": (c_int, [P, P, c_int, c_int, c_int8, c_int, fp]),
+        "scl_save_from_wire": (c_int, [P, fp, c_int8, c_int]),
+        "scl_detect_intra": (c_int, [P, c_int, ip, fp, dp]),
+        "scl_detect_inter": (c_int, [P, c_int, ip, fp, dp]),
+        "scl_get_index": (c_int, [P, c_int, POINTER(c_int8), ip]),
+        "scl_get_size": (c_int, [P, c_int]),
+        "scl_make_descriptor": (c_int, [P, P, c_int, c_int, fp]),
+        "scl_save_bulk": (c_int, [P, fp, c_int, POINTER(c_int8), ip]),
+        "scl_get_descriptor": (c_int, [P, c_int, fp]),
+        "scl_get_ringkey": (c_int, [P, c_int, fp]),
+        "scl_get_sectorkey": (c_int, [P, c_int, dp]),
+        "scl_stage_query": (c_int, [P, fp]),
+        "scl_ringkey_topk": (c_int, [P, c_int, c_int, c_int, c_int, ip, fp, ip]),
+        "scl_sc_distance_batch": (c_int, [P, c_int, ip, c_int, dp, ip]),
+        "scl_detect_full": (c_int, [P, c_int, ip, ip, ip, dp]),
+        "scl_detect_full_range": (c_int, [P, c_int, c_int, c_int, ip, ip, dp]),
+        "scl_topk_with_distance": (c_int, [P, c_int, c_int, c_int, c_int, ip, fp, dp, ip, ip]),
+        "scl_icp_default_params": (c_int, [POINTER(IcpParams)]),
+        "scl_icp_align": (c_int, [P, P, c_int, P, c_int, c_int, POINTER(IcpParams), fp, fp, ip, ip]),
+        "scl_nn_correspondences": (c_int, [P, P, c_int, P, c_int, c_int, ip, fp]),
+        "scl_rigid_svd": (c_int, [P, P, c_int, P, c_int, c_int, ip, ip, c_int, fp]),
+        "scl_transform_cloud": (c_int, [P, P, c_int, c_int, fp, P]),
+        "scl_profile_enable": (c_int, [P, c_int]),
+        "scl_profile_reset": (c_int, [P]),
+        "scl_profile_get": (c_int, [P, POINTER(SclProfile)]),
+        "scl_device_name": (c_int, [P, c_char_p, c_int]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _bound = True
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a, ctype):
+    return a.ctypes.data_as(POINTER(ctype))
+
+
+def _cloud(points):
+    """Accept (n,3|4|8) float32 arrays; returns (array, n, stride_bytes)."""
+    a = np.ascontiguousarray(points, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] < 3:
+        raise ValueError("point cloud must be (n, >=3) float32")
+    return a, a.shape[0], a.shape[1] * 4
+
+
+class ScanContextEngine:
+    """One engine = one keyframe database resident in one GPU's HBM."""
+
+    def __init__(self, num_ring=20, num_sector=60, num_candidates=3, dist_thres=0.14,
+                 lidar_height=1.65, max_radius=80.0, num_exclude_recent=100,
+                 tree_making_period=10, search_ratio=0.1, knn_exclude_eps=0.0,
+                 device=0, initial_capacity=4096):
+        self._lib = load_library()
+        _bind(self._lib)
+        cfg = SclConfig()
+        self._lib.scl_default_config(byref(cfg))
+        cfg.num_ring, cfg.num_sector, cfg.num_candidates = num_ring, num_sector, num_candidates
+        cfg.dist_thres, cfg.lidar_height, cfg.max_radius = dist_thres, lidar_height, max_radius
+        cfg.num_exclude_recent, cfg.tree_making_period = num_exclude_recent, tree_making_period
+        cfg.search_ratio, cfg.knn_exclude_eps = search_ratio, knn_exclude_eps
+        cfg.device, cfg.initial_capacity = device, initial_capacity
+        self.cfg = cfg
+        self.R, self.S = num_ring, num_sector
+        self._h = c_void_p()
+        rc = self._lib.scl_create(byref(cfg), byref(self._h))
+        if rc != 0:
+            self._h = c_void_p()
+            raise SclError(rc, "scl_create", self._lib.scl_status_string(rc).decode())
+
+    # -- plumbing -----------------------------------------------------------
+    def _check(self, rc, where):
+        if rc != 0:
+            raise SclError(rc, where, self._lib.scl_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.scl_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- the six virtuals -----------------------------------------------------
+    def make_and_save(self, points, robot=0, index=0):
+        a, n, stride = _cloud(points)
+        out = np.empty(self.R * self.S, dtype=np.float32)
+        self._check(self._lib.scl_make_and_save(self._h, a.ctypes.data_as(c_void_p), n, stride,
+                                                robot, index, _ptr(out, c_float)), "scl_make_and_save")
+        return out
+
+    def save_from_wire(self, values, robot=0, index=0):
+        v = _f32(values).reshape(-1)
+        if v.size != self.R * self.S:
+            raise ValueError("values must hold R*S floats")
+        self._check(self._lib.scl_save_from_wire(self._h, _ptr(v, c_float), robot, index), "scl_save_from_wire")
+
+    def detect_intra(self, cur):
+        lid, sh, d = c_int(), c_float(), c_double()
+        self._check(self._lib.scl_detect_intra(self._h, cur, byref(lid), byref(sh), byref(d)), "scl_detect_intra")
+        return lid.value, sh.value, d.value
+
+    def detect_inter(self, cur):
+        lid, yaw, d = c_int(), c_float(), c_double()
+        self._check(self._lib.scl_detect_inter(self._h, cur, byref(lid), byref(yaw), byref(d)), "scl_detect_inter")
+        return lid.value, yaw.value, d.value
+
+    def get_index(self, key):
+        r, i = c_int8(), c_int()
+        self._check(self._lib.scl_get_index(self._h, key, byref(r), byref(i)), "scl_get_index")
+        return r.value, i.value
+
+    def get_size(self, id_in=-1):
+        n = self._lib.scl_get_size(self._h, id_in)
+        if n < 0:
+            raise SclError(n, "scl_get_size")
+        return n
+
+    # -- building blocks -------------------------------------------------------
+    def make_descriptor(self, points):
+        a, n, stride = _cloud(points)
+        out = np.empty(self.R * self.S, dtype=np.float32)
+        self._check(self._lib.scl_make_descriptor(self._h, a.ctypes.data_as(c_void_p), n, stride,
+                                                  _ptr(out, c_float)), "scl_make_descriptor")
+        return out
+
+    def save_bulk(self, values, robots=None, indexs=None):
+        v = _f32(values).reshape(-1, self.R * self.S)
+        count = v.shape[0]
+        rp = ip = None
+        if robots is not None:
+            robots = np.ascontiguousarray(robots, dtype=np.int8); rp = _ptr(robots, c_int8)
+        if indexs is not None:
+            indexs = np.ascontiguousarray(indexs, dtype=np.int32); ip = _ptr(indexs, c_int)
+        self._check(self._lib.scl_save_bulk(self._h, _ptr(v, c_float), count, rp, ip), "scl_save_bulk")
+
+    def get_descriptor(self, key):
+        out = np.empty(self.R * self.S, dtype=np.float32)
+        self._check(self._lib.scl_get_descriptor(self._h, key, _ptr(out, c_float)), "scl_get_descriptor")
+        return out.reshape(self.R, self.S)
+
+    def get_ringkey(self, key):
+        out = np.empty(self.R, dtype=np.float32)
+        self._check(self._lib.scl_get_ringkey(self._h, key, _ptr(out, c_float)), "scl_get_ringkey")
+        return out
+
+    def get_sectorkey(self, key):
+        out = np.empty(self.S, dtype=np.float64)
+        self._check(self._lib.scl_get_sectorkey(self._h, key, _ptr(out, c_double)), "scl_get_sectorkey")
+        return out
+
+    def stage_query(self, values):
+        v = _f32(values).reshape(-1)
+        if v.size != self.R * self.S:
+            raise ValueError("values must hold R*S floats")
+        self._check(self._lib.scl_stage_query(self._h, _ptr(v, c_float)), "scl_stage_query")
+
+    def ringkey_topk(self, query, lo, hi, k):
+        idx = np.empty(k, dtype=np.int32); d2 = np.empty(k, dtype=np.float32); found = c_int()
+        self._check(self._lib.scl_ringkey_topk(self._h, query, lo, hi, k, _ptr(idx, c_int), _ptr(d2, c_float),
+                                               byref(found)), "scl_ringkey_topk")
+        return idx, d2, found.value
+
+    def sc_distance_batch(self, query, cand=None, n=None):
+        if cand is not None:
+            cand = np.ascontiguousarray(cand, dtype=np.int32); n = cand.size; cp = _ptr(cand, c_int)
+        else:
+            cp = None
+            if n is None:
+                raise ValueError("give cand or n")
+        dist = np.empty(n, dtype=np.float64); shift = np.empty(n, dtype=np.int32)
+        self._check(self._lib.scl_sc_distance_batch(self._h, query, cp, n, _ptr(dist, c_double),
+                                                    _ptr(shift, c_int)), "scl_sc_distance_batch")
+        return dist, shift
+
+    def detect_full(self, cur):
+        lid, nn, sh, d = c_int(), c_int(), c_int(), c_double()
+        self._check(self._lib.scl_detect_full(self._h, cur, byref(lid), byref(nn), byref(sh), byref(d)),
+                    "scl_detect_full")
+        return lid.value, nn.value, sh.value, d.value
+
+    def detect_full_range(self, query, lo, hi):
+        nn, sh, d = c_int(), c_int(), c_double()
+        self._check(self._lib.scl_detect_full_range(self._h, query, lo, hi, byref(nn), byref(sh), byref(d)),
+                    "scl_detect_full_range")
+        return nn.value, sh.value, d.value
+
+    def topk_with_distance(self, query, lo, hi, k):
+        idx = np.empty(k, dtype=np.int32); d2 = np.empty(k, dtype=np.float32)
+        dist = np.empty(k, dtype=np.float64); shift = np.empty(k, dtype=np.int32); found = c_int()
+        self._check(self._lib.scl_topk_with_distance(self._h, query, lo, hi, k, _ptr(idx, c_int), _ptr(d2, c_float),
+                                                     _ptr(dist, c_double), _ptr(shift, c_int), byref(found)),
+                    "scl_topk_with_distance")
+        return idx, d2, dist, shift, found.value
+
+    # -- geometric verification ---------------------------------------------------
+    def icp_default_params(self):
+        p = IcpParams()
+        self._lib.scl_icp_default_params(byref(p))
+        return p
+
+    def icp_align(self, src, tgt, params=None):
+        s, ns, stride = _cloud(src)
+        t, nt, stride_t = _cloud(tgt)
+        if stride != stride_t:
+            raise ValueError("source and target must share a record layout")
+        p = params or self.icp_default_params()
+        T = np.empty(16, dtype=np.float32); fit = c_float(); conv = c_int(); it = c_int()
+        self._check(self._lib.scl_icp_align(self._h, s.ctypes.data_as(c_void_p), ns, t.ctypes.data_as(c_void_p), nt,
+                                            stride, byref(p), _ptr(T, c_float), byref(fit), byref(conv), byref(it)),
+                    "scl_icp_align")
+        return T.reshape(4, 4), fit.value, bool(conv.value), it.value
+
+    def nn_correspondences(self, src, tgt):
+        s, ns, stride = _cloud(src)
+        t, nt, stride_t = _cloud(tgt)
+        if stride != stride_t:
+            raise ValueError("source and target must share a record layout")
+        idx = np.empty(ns, dtype=np.int32); d2 = np.empty(ns, dtype=np.float32)
+        self._check(self._lib.scl_nn_correspondences(self._h, s.ctypes.data_as(c_void_p), ns,
+                                                     t.ctypes.data_as(c_void_p), nt, stride,
+                                                     _ptr(idx, c_int), _ptr(d2, c_float)), "scl_nn_correspondences")
+        return idx, d2
+
+    def rigid_svd(self, src, tgt, src_index, tgt_index):
+        s, ns, stride = _cloud(src)
+        t, nt, stride_t = _cloud(tgt)
+        if stride != stride_t:
+            raise ValueError("source and target must share a record layout")
+        si = np.ascontiguousarray(src_index, dtype=np.int32); ti = np.ascontiguousarray(tgt_index, dtype=np.int32)
+        T = np.empty(16, dtype=np.float32)
+        self._check(self._lib.scl_rigid_svd(self._h, s.ctypes.data_as(c_void_p), ns, t.ctypes.data_as(c_void_p), nt,
+                                            stride, _ptr(si, c_int), _ptr(ti, c_int), si.size, _ptr(T, c_float)),
+                    "scl_rigid_svd")
+        return T.reshape(4, 4)
+
+    def transform_cloud(self, cloud, T):
+        a, n, stride = _cloud(cloud)
+        out = np.empty_like(a)
+        Tm = _f32(T).reshape(16)
+        self._check(self._lib.scl_transform_cloud(self._h, a.ctypes.data_as(c_void_p), n, stride, _ptr(Tm, c_float),
+                                                  out.ctypes.data_as(c_void_p)), "scl_transform_cloud")
+        return out
+
+    # -- measurement ------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(self._lib.scl_profile_enable(self._h, 1 if on else 0), "scl_profile_enable")
+
+    def profile_reset(self):
+        self._check(self._lib.scl_profile_reset(self._h), "scl_profile_reset")
+
+    def profile(self):
+        p = SclProfile()
+        self._check(self._lib.scl_profile_get(self._h, byref(p)), "scl_profile_get")
+        return {name: getattr(p, name) for name, _ in SclProfile._fields_}
+
+    def device_name(self):
+        buf = ctypes.create_string_buffer(256)
+        self._check(self._lib.scl_device_name(self._h, buf, 256), "scl_device_name")
+        return buf.value.decode()
+
+
+class ScanContextDescriptor:
+    """Python mirror of ``scan_context_descriptor : scan_descriptor`` (D.h:1304-1801).
+
+    Constructor arguments, method names and return conventions follow the reference;
+    all work is done by the GPU engine behind the C ABI.
+    """
+
+    def __init__(self, numRing=20, numSector=60, numCandidates=3, distThres=0.14, lidarHeight=1.65,
+                 maxRadius=80.0, numExcludeRecent=100, treeMakingPeriod=10, searchRatio=0.1, **engine_kw):
+        self.engine = ScanContextEngine(numRing, numSector, numCandidates, distThres, lidarHeight, maxRadius,
+                                        numExcludeRecent, treeMakingPeriod, searchRatio, **engine_kw)
+
+    def makeAndSaveDescriptorAndKey(self, scan, robot, index):          # D.h:25
+        return self.engine.make_and_save(scan, robot, index)
+
+    def saveDescriptorAndKey(self, descriptorMat, robot, index):       # D.h:27
+        self.engine.save_from_wire(descriptorMat, robot, index)
+
+    def detectIntraLoopClosureID(self, currentPtr):                    # D.h:29
+        lid, shift, _ = self.engine.detect_intra(currentPtr)
+        return lid, shift
+
+    def detectInterLoopClosureID(self, currentPtr):                    # D.h:31
+        lid, yaw, _ = self.engine.detect_inter(currentPtr)
+        return lid, yaw
+
+    def getIndex(self, key):                                           # D.h:33
+        return self.engine.get_index(key)
+
+    def getSize(self, idIn=-1):                                        # D.h:35
+        return self.engine.get_size(idIn)

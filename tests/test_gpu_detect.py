@@ -1,0 +1,75 @@
+"""End-to-end detection parity (detectIntra/InterLoopClosureID + full-DB mode) vs the checker."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from scl_slam_amd import ScanContextEngine, ScanContextDescriptor, SclError
+from scl_slam_amd.synth import synth_descriptors
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c1_plumbing_200_keyframes():
+    """BASELINE configs[0]: 200 VLP-16 keyframes, 20x60, single query at curPtr = 199."""
+    R, S = 20, 60
+    descs, truth = synth_descriptors(200, R, S, seed=1001, revisit_frac=0.03, return_truth=True)
+    sc = ScanContextDescriptor()                       # reference defaults (DM.h:404 passes nothing)
+    db = ob.OracleDB(ob.make_config())
+    for i in range(200):
+        sc.saveDescriptorAndKey(descs[i], 0, i)
+        db.save_wire(descs[i], 0, i)
+    assert sc.getSize() == 200 and sc.getIndex(57) == (0, 57)
+    lid, shift = sc.detectIntraLoopClosureID(199)
+    o_lid, o_shift, o_dist, _ = db.detect_intra(199)
+    assert (lid, shift) == (o_lid, o_shift)
+    assert sc.detectIntraLoopClosureID(103) == (-1, 0.0)     # early-out, D.h:1620
+    sc.engine.close()
+
+
+@pytest.mark.parametrize("R,S,k,n", [(20, 60, 3, 600), (64, 120, 3, 500), (64, 120, 25, 400)])
+def test_detect_intra_inter_full_match_oracle(R, S, k, n):
+    descs, truth = synth_descriptors(n, R, S, seed=50 + k, revisit_frac=0.06, return_truth=True)
+    eng = ScanContextEngine(num_ring=R, num_sector=S, num_candidates=k, initial_capacity=128)
+    db = ob.OracleDB(ob.make_config(R=R, S=S, k=k))
+    eng.save_bulk(descs); db.save_bulk(descs)
+    curs = sorted(set([c for c, _, _ in truth] + [n - 1, 150, 104, 103]))
+    found = 0
+    for cur in curs:
+        lid, shift, dist = eng.detect_intra(cur)
+        o_lid, o_shift, o_dist, _ = db.detect_intra(cur)
+        assert (lid, shift) == (o_lid, o_shift) and dist == o_dist
+        found += lid >= 0
+    assert found >= 1
+    for cur in curs[-12:]:                              # the inter path keeps tree-period state: same call sequence
+        lid, yaw, dist = eng.detect_inter(cur)
+        o_lid, o_yaw, o_dist = db.detect_inter(cur)
+        assert (lid, np.float32(yaw)) == (o_lid, np.float32(o_yaw)) and dist == o_dist
+    for cur in curs[-6:]:
+        lid, nn, sh, dist = eng.detect_full(cur)
+        o_lid, o_nn, o_sh, o_dist = db.detect_full(cur)
+        assert (lid, nn, sh) == (o_lid, o_nn, o_sh) and dist == o_dist
+    eng.close()
+
+
+def test_inter_with_fewer_keys_than_candidates():
+    # tree covers [0, N-100): with N = 101 it holds one key; unfilled candidates read slot 0 (D.h:1710)
+    R, S = 20, 60
+    descs = synth_descriptors(102, R, S, seed=3)
+    eng = ScanContextEngine(num_ring=R, num_sector=S)
+    db = ob.OracleDB(ob.make_config())
+    eng.save_bulk(descs[:101]); db.save_bulk(descs[:101])
+    assert eng.detect_inter(100)[0] == db.detect_inter(100)[0]
+    g = eng.detect_inter(100); o = db.detect_inter(100)
+    assert g[2] == o[2]
+    eng.close()
+
+
+def test_errors_are_status_codes():
+    eng = ScanContextEngine()
+    with pytest.raises(SclError):
+        eng.detect_intra(5)                 # empty DB: out of range
+    with pytest.raises(SclError):
+        eng.sc_distance_batch(-1, n=1)      # no staged query
+    with pytest.raises(ValueError):
+        eng.save_from_wire(np.zeros(7, np.float32))
+    eng.close()

@@ -1,0 +1,61 @@
+"""K3 parity: GPU makeScancontext vs the CPU checker, bit for bit."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from scl_slam_amd import ScanContextEngine
+from scl_slam_amd.synth import synth_scan
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("R,S,n", [(20, 60, 15000), (64, 120, 120000), (80, 180, 240000), (20, 60, 1), (20, 60, 0)])
+def test_descriptor_matches_oracle(R, S, n):
+    cloud = synth_scan(n, seed=R + n)
+    eng = ScanContextEngine(num_ring=R, num_sector=S)
+    cfg = ob.make_config(R=R, S=S)
+    v_gpu = eng.make_descriptor(cloud)
+    v_cpu = ob.make_scancontext(cfg, cloud)
+    assert np.array_equal(v_gpu, v_cpu)
+    eng.close()
+
+
+def test_edge_points_and_strides():
+    R, S = 20, 60
+    pts = np.array([[0, 0, 1.0], [80.0, 0, 2.0], [80.00001, 0, 9.0], [10, 10, -5.0], [10, 10, -2000.0],
+                    [0, 5, 1.0], [-5, 0, 1.0], [0, -5, 1.0], [np.nan, 1, 1], [1, 1, np.nan], [np.inf, 0, 3],
+                    [1e-30, 1e-30, 0.5], [-1e-3, -1e-3, 0.25], [79.999, -0.0001, 4.0]], dtype=np.float32)
+    cfg = ob.make_config(R=R, S=S)
+    for stride in (3, 4, 8):
+        cloud = np.zeros((len(pts), stride), np.float32); cloud[:, :3] = pts
+        eng = ScanContextEngine(num_ring=R, num_sector=S)
+        assert np.array_equal(eng.make_descriptor(cloud), ob.make_scancontext(cfg, cloud))
+        eng.close()
+
+
+def test_sector_edges_bitwise():
+    # points placed on/around sector boundaries: any atan disagreement would flip a bin
+    R, S = 64, 120
+    rs = np.random.RandomState(1)
+    k = np.arange(0, 360, 3.0)
+    ang = np.deg2rad(np.concatenate([k, k + 1e-5, k - 1e-5, rs.uniform(0, 360, 20000)]))
+    rad = rs.uniform(0.1, 79.9, size=ang.size)
+    cloud = np.zeros((ang.size, 8), np.float32)
+    cloud[:, 0] = rad * np.cos(ang); cloud[:, 1] = rad * np.sin(ang); cloud[:, 2] = rs.uniform(-1, 10, ang.size)
+    eng = ScanContextEngine(num_ring=R, num_sector=S)
+    assert np.array_equal(eng.make_descriptor(cloud), ob.make_scancontext(ob.make_config(R=R, S=S), cloud))
+    eng.close()
+
+
+def test_make_and_save_then_detect_keys():
+    R, S = 20, 60
+    eng = ScanContextEngine(num_ring=R, num_sector=S)
+    db = ob.OracleDB(ob.make_config(R=R, S=S))
+    for i in range(5):
+        cloud = synth_scan(8000, seed=i)
+        v_gpu = eng.make_and_save(cloud, robot=1, index=10 + i)
+        v_cpu = db.make_and_save(cloud, robot=1, index=10 + i)
+        assert np.array_equal(v_gpu, v_cpu)
+        assert np.array_equal(eng.get_ringkey(i).view(np.uint32), db.ringkey(i).view(np.uint32))
+    assert eng.get_size() == 5 and eng.get_index(3) == (1, 13) == db.get_index(3)
+    eng.close()
