@@ -38,7 +38,7 @@ def synth_descriptors(n, R, S, seed=1002, n_basis=24, zero_wedge_frac=0.25, revi
     for i in range(n):
         acc = 0.97 * acc + 0.35 * steps[i]
         w[i] = acc
-    field = 3.0 + 2.2 * (w @ basis)                                            # (n, R*S)
+    field = 4.0 + 0.55 * (w @ basis)                                           # (n, R*S)
     field += noise * rs.standard_normal(size=field.shape).astype(np.float32)
     np.clip(field, 0.0, 12.0, out=field)
     field = field.reshape(n, R, S)
