@@ -21,6 +21,11 @@
 // groups of G candidates; a candidate is served by NW = ceil(S/64) waves.
 // Bound: HBM (algorithmic 4*R*S + 8*S bytes per pair) on paper; the LDS read port
 // (one ds_read_b64 per fp64 fma) is what limits v1 -- see DESIGN.md.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
 #include "device_common.hpp"
 #include "kernels.hpp"
 
@@ -44,6 +49,8 @@ struct ScArgs {
     int G;    // candidates per workgroup iteration
     double *out_dist;
     int *out_shift;
+    unsigned long long *stamps;   // diagnostic only (SCL_STAMP=1): per-wave phase cycle sums
+    int ablate;   // diagnostic only (SCL_ABLATE): bit0 skip alignment loop, bit1 skip ring dots, bit2 skip sector sums
 };
 
 __device__ __forceinline__ int wrap(int x, int S)
@@ -199,6 +206,404 @@ __global__ __launch_bounds__(MAXT) void sc_distance_kernel(ScArgs a)
     }
 }
 
+// =================================================================================
+// v2: ONE WAVE PER CANDIDATE, two candidate columns per lane.
+//
+// Why: in the kernel above every fp64 fma needs its own 8-byte LDS operand, so the LDS
+// port (256 B/clk/CU) and not the fp64 pipe sets the pace, and three workgroup barriers
+// per candidate serialise the phases.  Here lane l owns candidate columns 2l and 2l+1:
+// their shift windows overlap in all but one query column, so NSH+2 query values fetched
+// with aligned ds_read_b128 feed 2*NSH fmas (0.57 LDS bytes per fma-byte instead of 1).
+// The window start is rounded down to an even column (NSH = W+1 shifts are evaluated, the
+// surplus one is discarded) so every lane's window is 16-byte aligned.  All per-candidate
+// scratch (doubled sector key, similarity rows) is private to the wave: no workgroup
+// barrier after the query has been staged, waves drift apart and overlap each other's
+// latency-bound phases (alignment chain, sequential sector sum).
+// Arithmetic order is unchanged (ring order dots, sector order sums): results stay
+// bit-identical to the CPU checker.
+// =================================================================================
+__device__ __forceinline__ void wave_fence()
+{   // LDS operations of one wave execute in issue order; only the compiler must not reorder
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Compiler-level ordering point for the ring pipeline of the wave kernel.  An empty asm
+// with a memory clobber orders the LDS reads, and taking every accumulator as a read-write
+// operand orders the fmas: without the latter SelectionDAG is free to emit all fmas of a
+// block after all of its loads (it does), which keeps every ring's window live and spills.
+__device__ __forceinline__ void pin_ring(double (&a)[8], double (&b)[8])
+{
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                      "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7])
+                 :: "memory");
+}
+__device__ __forceinline__ void pin_ring(double (&a)[14], double (&b)[14])
+{
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]),
+                      "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]),
+                      "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]),
+                      "+v"(b[7]), "+v"(b[8]), "+v"(b[9]), "+v"(b[10]), "+v"(b[11]), "+v"(b[12]), "+v"(b[13])
+                 :: "memory");
+}
+
+template <int RG, int NSH, int CH, bool STAMP>
+__global__ __launch_bounds__(512) void sc_distance_wave_kernel(ScArgs a)
+{
+    unsigned long long st_t = 0, st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_real0 = 0, st_cyc0 = 0;
+    auto stamp = [&]() -> unsigned long long {
+        if (!STAMP) return 0ull;
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return t;
+    };
+    if (STAMP) { st_cyc0 = stamp(); st_real0 = __builtin_amdgcn_s_memrealtime(); }
+
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int R4 = RG * 4;
+    constexpr int HSH = NSH / 2;               // shifts summed per phase-D pass
+    constexpr int W = NSH - 1;                 // shifts the reference evaluates (2*SR+1)
+    constexpr int NQ = NSH / 2 + 1;            // ds_read_b128 per ring
+    static_assert(RG % CH == 0, "chunk must divide the ring groups");
+    const int S = a.S, SR = a.SR;
+    const int L = S >> 1;                      // active lanes
+    const int QS = S + NSH + 2;                // extended query row (even)
+    const int SB = S + 2;                      // similarity row stride: even (b128 rows), rows on distinct banks
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+
+    double *Qd = smem;                         // [R4][QS]
+    double *nqe = Qd + R4 * QS;                // [QS] query column norms, extended
+    double *vq = nqe + QS;                     // [S]  query sector key (also the over-read pad of the ring pipeline)
+    const int wsz = 2 * S + HSH * SB;
+    double *vk2 = vq + S + wave * wsz;         // [2S] candidate sector key, doubled
+    double *simbuf = vk2 + 2 * S;              // [HSH][SB]
+
+    for (int idx = threadIdx.x; idx < RG * S; idx += blockDim.x) {
+        const int rg = idx / S, c = idx - rg * S;
+        const float4 v = a.q_desc[idx];
+        double *dst = Qd + (rg * 4) * QS + c;
+        dst[0] = (double)v.x; dst[QS] = (double)v.y; dst[2 * QS] = (double)v.z; dst[3 * QS] = (double)v.w;
+        if (c < NSH + 2) {
+            dst += S;
+            dst[0] = (double)v.x; dst[QS] = (double)v.y; dst[2 * QS] = (double)v.z; dst[3 * QS] = (double)v.w;
+        }
+    }
+    for (int c = threadIdx.x; c < S; c += blockDim.x) {
+        const double nv = a.q_norm[c];
+        nqe[c] = nv;
+        if (c < NSH + 2) nqe[c + S] = nv;
+        vq[c] = a.q_vkey[c];
+    }
+    __syncthreads();                           // the only workgroup barrier
+
+    const bool active = lane < L;
+    const int ll = active ? lane : L - 1;
+    const int j0 = 2 * ll;                     // first of the lane's two QUERY-side columns
+    const double kInf = __longlong_as_double(0x7ff0000000000000LL);
+    // Lane l always works on the query window that starts at column 2l; the candidate is what
+    // rotates: after the alignment has fixed the first evaluated shift s_start, the lane fetches
+    // candidate columns (2l - s_start) mod S and +1.  The window address is the same for every
+    // candidate and never wraps, so the b128 window reads are bank-conflict free.
+    const double2 *qwin = reinterpret_cast<const double2 *>(Qd + j0);
+    const int qstep = QS / 2;
+
+    const int cstride = gridDim.x * nwaves;
+    int ci = blockIdx.x * nwaves + wave;
+    if (ci >= a.n) return;
+
+    // ---- per-candidate state of the software pipeline --------------------------------
+    int slot = a.cand ? a.cand[ci] : a.slot_base + ci;
+    int s_start = 0, t_lo = 0;
+    const float4 *kp = a.desc;
+    double2 nk = make_double2(0.0, 0.0);
+    float4 k0[CH], k1[CH];
+
+    // alignment of one candidate (fastAlignUsingVkey, D.h:1491-1511) + issue of its first loads
+    auto align_and_fetch = [&](int sl_i, const double2 vk, int &o_s_start, int &o_t_lo) {
+        wave_fence();
+        // lanes >= L mirror lane L-1 (same addresses, same values): no divergent stores needed
+        *reinterpret_cast<double2 *>(vk2 + j0) = vk;
+        *reinterpret_cast<double2 *>(vk2 + j0 + S) = vk;
+        wave_fence();
+        double best = kInf;
+        int bshift = 0x7fffffff;
+        {
+            // lane owns shifts 2l and 2l+1:  p[t] = vk[(t - 2l) mod S]; shift 2l+1 reuses p[t-1].
+            // All operands come from LDS (in-order returns => counted waits), one batch of
+            // 8 sectors is in flight while the previous one is being consumed.
+            const double *p = vk2 + S - j0;
+            const double2 *pp = reinterpret_cast<const double2 *>(p);
+            const double2 *qq = reinterpret_cast<const double2 *>(vq);      // wave-uniform address: broadcast
+            double prev = p[-1];
+            double ss0 = 0.0, ss1 = 0.0;
+            const int npair = S >> 1;
+            const int nb = (a.ablate & 1) ? 0 : npair >> 2;                     // batches of 4 pairs = 8 sectors
+            double2 pn[4], qn4[4];
+            if (nb > 0) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { pn[v] = pp[v]; qn4[v] = qq[v]; }
+            }
+#pragma unroll 1
+            for (int bt = 0; bt < nb; ++bt) {
+                double2 pc[4], qc[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { pc[v] = pn[v]; qc[v] = qn4[v]; }
+                if (bt + 1 < nb) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) { pn[v] = pp[(bt + 1) * 4 + v]; qn4[v] = qq[(bt + 1) * 4 + v]; }
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const double d0 = qc[v].x - pc[v].x, d1 = qc[v].x - prev;
+                    ss0 = ss0 + d0 * d0;
+                    ss1 = ss1 + d1 * d1;
+                    const double e0 = qc[v].y - pc[v].y, e1 = qc[v].y - pc[v].x;
+                    ss0 = ss0 + e0 * e0;
+                    ss1 = ss1 + e1 * e1;
+                    prev = pc[v].y;
+                }
+            }
+            for (int i = nb * 4; i < ((a.ablate & 1) ? 1 : npair); ++i) {      // tail (S/2 not a multiple of 4)
+                const double2 pv = pp[i], qv = qq[i];
+                const double d0 = qv.x - pv.x, d1 = qv.x - prev;
+                ss0 = ss0 + d0 * d0;
+                ss1 = ss1 + d1 * d1;
+                const double e0 = qv.y - pv.y, e1 = qv.y - pv.x;
+                ss0 = ss0 + e0 * e0;
+                ss1 = ss1 + e1 * e1;
+                prev = pv.y;
+            }
+            const double n0 = sqrt(ss0), n1 = sqrt(ss1);
+            if (active && n0 < kBigDist) { best = n0; bshift = j0; }
+            if (active && n1 < kBigDist && n1 < best) { best = n1; bshift = j0 + 1; }   // ties keep the lower shift
+        }
+        wave_argmin(best, bshift);
+        const int align = __builtin_amdgcn_readfirstlane(best < kBigDist ? bshift : 0);
+        const int b = wrap(align - SR, S);     // first shift of the reference's search space
+        o_s_start = b & ~1;                    // evaluated shifts: s_start .. s_start+NSH-1 (mod S)
+        o_t_lo = b - o_s_start;                // 0 or 1: which end carries the surplus shift
+        const int kc = wrap(j0 - o_s_start, S);                   // even: the lane's candidate columns
+        const size_t sl = (size_t)sl_i;
+        nk = *reinterpret_cast<const double2 *>(a.norm + sl * S + kc);
+        kp = a.desc + sl * (size_t)(RG * S) + kc;
+#pragma unroll
+        for (int u = 0; u < CH; ++u) { k0[u] = kp[u * S]; k1[u] = kp[u * S + 1]; }
+    };
+
+    if (slot >= 0) {
+        const double2 vk = *reinterpret_cast<const double2 *>(a.vkey + (size_t)slot * S + j0);
+        st_t = stamp();
+        align_and_fetch(slot, vk, s_start, t_lo);
+        st_a += stamp() - st_t;
+    }
+
+    while (true) {
+        const int ci_next = ci + cstride;
+        int slot_next = -1;
+        if (ci_next < a.n) slot_next = a.cand ? a.cand[ci_next] : a.slot_base + ci_next;
+        double2 vk_next = make_double2(0.0, 0.0);
+        if (slot_next >= 0) vk_next = *reinterpret_cast<const double2 *>(a.vkey + (size_t)slot_next * S + j0);
+
+        double acc0[NSH], acc1[NSH];
+        const double2 nk_cur = nk;
+        const int s_start_cur = s_start, t_lo_cur = t_lo;
+        st_t = stamp();
+        if (slot >= 0) {
+            // ---- phase B: 2 x NSH shifted column dots in ring order ------------------
+#pragma unroll
+            for (int t = 0; t < NSH; ++t) { acc0[t] = 0.0; acc1[t] = 0.0; }
+            // Explicit two-stage pipeline over rings: the query window of ring r+1 is requested
+            // before the fmas of ring r; pin_ring() keeps LLVM from batching every ring's LDS
+            // window ahead of all fmas of the block (which it otherwise does -- and spills).
+            const double2 *qp = qwin;
+            double2 qn[NQ];
+#pragma unroll
+            for (int v = 0; v < NQ; ++v) qn[v] = qp[v];
+            // The candidate's two columns stream through a ring of CH ring-groups of registers:
+            // as soon as a group has been widened to fp64 its slot is refilled with the group CH
+            // ahead, so ~CH*32 B per lane stay in flight all through the phase (HBM latency cover).
+            const int nch = (a.ablate & 2) ? 0 : RG / CH;
+#pragma unroll 1
+            for (int ch = 0; ch < nch; ++ch) {
+                const bool more = ch + 1 < RG / CH;
+                const float4 *np = kp + (size_t)(ch + 1) * CH * S;
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const float a0[4] = {k0[u].x, k0[u].y, k0[u].z, k0[u].w};
+                    const float a1[4] = {k1[u].x, k1[u].y, k1[u].z, k1[u].w};
+                    if (more) { k0[u] = np[u * S]; k1[u] = np[u * S + 1]; }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        double q[NSH + 2];
+#pragma unroll
+                        for (int v = 0; v < NQ; ++v) { q[2 * v] = qn[v].x; q[2 * v + 1] = qn[v].y; }
+                        pin_ring(acc0, acc1);
+                        qp += qstep;                        // the last ring over-reads one row: it lands in
+#pragma unroll                                              // nqe/vq (inside the allocation), values unused
+                        for (int v = 0; v < NQ; ++v) qn[v] = qp[v];
+                        const double kd0 = (double)a0[i], kd1 = (double)a1[i];
+#pragma unroll
+                        for (int t = 0; t < NSH; ++t) {
+                            acc0[t] = fma(kd0, q[t], acc0[t]);
+                            acc1[t] = fma(kd1, q[t + 1], acc1[t]);
+                        }
+                    }
+                }
+            }
+        }
+
+        { const unsigned long long t1 = stamp(); st_b += t1 - st_t; st_t = t1; }
+        // ---- next candidate: alignment + first loads, hidden under this one's phases C/D ----
+        if (slot_next >= 0) align_and_fetch(slot_next, vk_next, s_start, t_lo);
+        { const unsigned long long t1 = stamp(); st_a += t1 - st_t; st_t = t1; }
+
+        // ---- phases C/D in two passes of HSH shifts ------------------------------
+        if (slot >= 0) {
+            double dmin = kInf;
+            int smin = 0x7fffffff;
+            // kept rolled on purpose: unrolled, the two passes are interleaved by the scheduler and spill
+            const int nh = (a.ablate & 4) ? 0 : 2;
+#pragma unroll 1
+            for (int h = 0; h < nh; ++h) {
+                wave_fence();
+                int eff = 0;
+#pragma unroll
+                for (int tt = 0; tt < HSH; ++tt) {
+                    const int t = h * HSH + tt;
+                    const int x0 = j0 + t, x1 = x0 + 1;                    // query columns (extended index)
+                    const double nq0 = nqe[x0], nq1 = nqe[x1];
+                    const bool ok0 = !((nq0 == 0.0) | (nk_cur.x == 0.0));  // D.h:1523
+                    const bool ok1 = !((nq1 == 0.0) | (nk_cur.y == 0.0));
+                    const double av0 = h ? acc0[HSH + tt] : acc0[tt];      // static register indices + select
+                    const double av1 = h ? acc1[HSH + tt] : acc1[tt];
+                    const double s0 = av0 / (nq0 * nk_cur.x);
+                    const double s1 = av1 / (nq1 * nk_cur.y);
+                    const int c0 = x0 >= S ? x0 - S : x0;
+                    const int c1 = x1 >= S ? x1 - S : x1;
+                    simbuf[tt * SB + c0] = ok0 ? s0 : 0.0;                 // skipped sectors add +0.0: same bits
+                    simbuf[tt * SB + c1] = ok1 ? s1 : 0.0;                 // (lanes >= L mirror lane L-1)
+                    const int cnt = __popcll(__ballot(active && ok0)) + __popcll(__ballot(active && ok1));
+                    eff = (lane == tt) ? cnt : eff;
+                }
+                wave_fence();
+                { const unsigned long long t1 = stamp(); st_c += t1 - st_t; st_t = t1; }
+                if (lane < HSH) {
+                    const int t = h * HSH + lane;
+                    const double2 *row = reinterpret_cast<const double2 *>(simbuf + lane * SB);
+                    double sum = 0.0;
+                    const int npair = S >> 1;
+                    const int nb = npair >> 2;
+                    double2 rn[4];
+                    if (nb > 0) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) rn[v] = row[v];
+                    }
+#pragma unroll 1
+                    for (int bt = 0; bt < nb; ++bt) {                      // 8 sectors per batch, next batch in flight
+                        double2 rc[4];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) rc[v] = rn[v];
+                        if (bt + 1 < nb) {
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) rn[v] = row[(bt + 1) * 4 + v];
+                        }
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) { sum = sum + rc[v].x; sum = sum + rc[v].y; }
+                    }
+                    for (int i = nb * 4; i < npair; ++i) { const double2 rv = row[i]; sum = sum + rv.x; sum = sum + rv.y; }
+                    const double d = 1.0 - sum / (double)eff;              // 0/0 -> NaN, never wins
+                    const bool in_space = (t >= t_lo_cur) && (t < t_lo_cur + W);
+                    const int st = wrap(s_start_cur + t, S);
+                    if (in_space && d < kBigDist && ((d < dmin) | ((d == dmin) & (st < smin)))) { dmin = d; smin = st; }
+                }
+                { const unsigned long long t1 = stamp(); st_d += t1 - st_t; st_t = t1; }
+            }
+            wave_argmin(dmin, smin);
+            if (lane == 0) {
+                const bool ok = dmin < kBigDist;
+                a.out_dist[ci] = ok ? dmin : kBigDist;
+                a.out_shift[ci] = ok ? smin : 0;
+            }
+        } else if (lane == 0) {
+            a.out_dist[ci] = kBigDist;
+            a.out_shift[ci] = 0;
+        }
+
+        if (ci_next >= a.n) break;
+        ci = ci_next;
+        slot = slot_next;
+    }
+    if (STAMP && a.stamps) {
+        const unsigned long long cyc1 = stamp();
+        const unsigned long long real1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            unsigned long long *o = a.stamps + (size_t)(blockIdx.x * nwaves + wave) * 8;
+            o[0] = cyc1 - st_cyc0; o[1] = real1 - st_real0; o[2] = st_a; o[3] = st_b; o[4] = st_c; o[5] = st_d;
+        }
+    }
+}
+
+template <int RG, int NSH, int CH, bool STAMP = false>
+hipError_t launch_wave(const ScArgs &args_in, int num_cu, hipStream_t stream)
+{
+    ScArgs a = args_in;
+    const int S = a.S;
+    const int QS = S + NSH + 2;
+    const size_t fixed = (size_t)(RG * 4 * QS + QS + S) * sizeof(double);
+    const size_t per_wave = (size_t)(2 * S + (NSH / 2) * (S + 2)) * sizeof(double);
+    const size_t lds_cap = 160 * 1024;
+    int waves = (int)((lds_cap - fixed) / per_wave);
+    if (waves > 8) waves = 8;
+    if (waves < 1) return hipErrorInvalidValue;
+    while (waves > 1 && a.n < num_cu * waves) waves >>= 1;
+    int blocks = (a.n + waves - 1) / waves;
+    if (blocks > num_cu) blocks = num_cu;
+    const size_t lds = fixed + per_wave * waves;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)sc_distance_wave_kernel<RG, NSH, CH, STAMP>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (STAMP) {
+        // diagnostic build of the kernel (SCL_STAMP=1): per-wave cycle sums per phase, printed to stderr
+        const size_t nw = (size_t)blocks * waves;
+        unsigned long long *d = nullptr;
+        if (hipMalloc(&d, nw * 8 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemsetAsync(d, 0, nw * 8 * sizeof(unsigned long long), stream);
+        a.stamps = d;
+        hipLaunchKernelGGL((sc_distance_wave_kernel<RG, NSH, CH, STAMP>), dim3(blocks), dim3(waves * kWave), lds, stream, a);
+        (void)hipStreamSynchronize(stream);
+        std::vector<unsigned long long> h(nw * 8);
+        (void)hipMemcpy(h.data(), d, nw * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        (void)hipFree(d);
+        static int printed = 0;
+        if (printed++ < 3) {
+            auto med = [&](int k) {
+                std::vector<unsigned long long> v;
+                for (size_t w = 0; w < nw; ++w) if (h[w * 8] != 0) v.push_back(h[w * 8 + k]);
+                if (v.empty()) return 0.0;
+                std::sort(v.begin(), v.end());
+                return (double)v[v.size() / 2];
+            };
+            const double cyc = med(0), real = med(1);
+            fprintf(stderr, "[scl stamp] waves=%zu n=%d  wave lifetime: %.0f cycles, %.2f us  => clock %.2f GHz | "
+                            "per wave: align %.0f  dots %.0f  sims %.0f  sums %.0f  other %.0f cycles\n",
+                    nw, a.n, cyc, real / 100.0, real > 0 ? cyc / real * 0.1 : 0.0, med(2), med(3), med(4), med(5),
+                    cyc - med(2) - med(3) - med(4) - med(5));
+        }
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL((sc_distance_wave_kernel<RG, NSH, CH, STAMP>), dim3(blocks), dim3(waves * kWave), lds, stream, a);
+    return hipGetLastError();
+}
+
 // ---- generic fallback: any (R, S, SR).  One workgroup per candidate, one shift at
 // a time, everything read from global/L2.  Correct, not fast; the three BASELINE
 // grids (20x60, 64x120, 80x180 with search ratio 0.1) never take this path. --------
@@ -342,8 +747,17 @@ hipError_t launch_sc_distance(const DbView &db, const QueryView &q, const int *c
     a.q_desc = q.desc; a.q_vkey = q.vkey; a.q_norm = q.norm;
     a.cand = cand; a.slot_base = slot_base; a.n = n; a.S = db.S; a.SR = SR;
     a.NW = (db.S + kWave - 1) / kWave; a.G = 1;
+    static const int ablate = [] { const char *e = getenv("SCL_ABLATE"); return e ? atoi(e) : 0; }();
+    a.ablate = ablate;
+    a.stamps = nullptr;
     a.out_dist = out_dist; a.out_shift = out_shift;
     const int W = 2 * SR + 1;
+    static const bool force_v1 = [] { const char *e = getenv("SCL_SC_KERNEL"); return e && e[0] == 'v' && e[1] == '1'; }();
+    const bool wave_ok = !force_v1 && (db.S % 2 == 0) && (db.S / 2 <= kWave) && (db.S >= W + 3);
+    if (wave_ok && db.RG == 5 && W == 7)   return launch_wave<5, 8, 5>(a, num_cu, stream);
+    static const bool stamp = [] { const char *e = getenv("SCL_STAMP"); return e && e[0] == '1'; }();
+    if (wave_ok && db.RG == 16 && W == 13 && stamp) return launch_wave<16, 14, 4, true>(a, num_cu, stream);
+    if (wave_ok && db.RG == 16 && W == 13) return launch_wave<16, 14, 4>(a, num_cu, stream);
     if (db.RG == 5 && W == 7 && db.S >= W)   return launch_fast<5, 7, 512>(a, num_cu, stream);
     if (db.RG == 16 && W == 13 && db.S >= W) return launch_fast<16, 13, 512>(a, num_cu, stream);
     if (db.RG == 20 && W == 19 && db.S >= W && db.S <= 180) return launch_fast<20, 19, 256>(a, num_cu, stream);
