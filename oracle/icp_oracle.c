@@ -1,0 +1,310 @@
+/*
+ * icp_oracle.c -- CPU restatement of the geometric-verification path (PCL's
+ * published algorithms; see icp_oracle.h: PARITY UNPINNED, test infrastructure only).
+ *
+ * Numerics: points are fp32; nearest-neighbour distances are fp32
+ * ((dx*dx + dy*dy) + dz*dz, no FMA); centroids / cross-covariance / MSE are
+ * accumulated sequentially in fp64; the rotation is the closed-form optimum of
+ * the orthogonal Procrustes problem with det = +1 (what PCL's
+ * TransformationEstimationSVD returns through Eigen::umeyama with its
+ * sign fix), computed here by Horn's quaternion form with a cyclic Jacobi
+ * eigen-solver -- no SVD library needed, no degenerate-rank special cases.
+ */
+#include "icp_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+void icpo_default_params(icpo_params *p)
+{   /* DM.h:1109-1112 */
+    p->max_iterations = 50;
+    p->max_correspondence_dist = 100.0;
+    p->transformation_epsilon = 1e-6;
+    p->euclidean_fitness_epsilon = 1e-6;
+}
+
+static inline const float *pt(const void *base, int i, int stride)
+{
+    return (const float *)((const unsigned char *)base + (size_t)i * (size_t)stride);
+}
+
+static inline float dist2f(const float *a, const float *b)
+{
+    const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+/* ---- exact NN: brute force --------------------------------------------------- */
+static void nn_brute(const void *src, int n_src, const void *tgt, int n_tgt, int stride,
+                     int *nn_index, float *nn_dist2)
+{
+    for (int i = 0; i < n_src; i++) {
+        const float *p = pt(src, i, stride);
+        float best = FLT_MAX; int bi = -1;
+        for (int j = 0; j < n_tgt; j++) {
+            const float d = dist2f(p, pt(tgt, j, stride));
+            if (d < best) { best = d; bi = j; }      /* ascending j: ties keep the lowest index */
+        }
+        nn_index[i] = bi;
+        if (nn_dist2) nn_dist2[i] = best;
+    }
+}
+
+/* ---- exact NN: uniform grid with shell expansion ------------------------------ */
+typedef struct { float mn[3]; float h; int dim[3]; int *start; int *items; } grid_t;
+
+static int cell_of(const grid_t *g, const float *p, int c[3])
+{
+    for (int a = 0; a < 3; a++) {
+        float f = floorf((p[a] - g->mn[a]) / g->h);
+        int ci = (f != f) ? 0 : (f < 0 ? 0 : (f >= (float)g->dim[a] ? g->dim[a] - 1 : (int)f));
+        c[a] = ci;
+    }
+    return (c[2] * g->dim[1] + c[1]) * g->dim[0] + c[0];
+}
+
+static void grid_build(grid_t *g, const void *tgt, int n, int stride)
+{
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = 0; i < n; i++) {
+        const float *p = pt(tgt, i, stride);
+        for (int a = 0; a < 3; a++) { if (p[a] < mn[a]) mn[a] = p[a]; if (p[a] > mx[a]) mx[a] = p[a]; }
+    }
+    float ext = 0; for (int a = 0; a < 3; a++) if (mx[a] - mn[a] > ext) ext = mx[a] - mn[a];
+    float h = ext / 96.0f; if (!(h > 1e-6f)) h = 1.0f;
+    g->h = h;
+    size_t cells = 1;
+    for (int a = 0; a < 3; a++) {
+        g->mn[a] = mn[a];
+        int d = (int)floorf((mx[a] - mn[a]) / h) + 1; if (d < 1) d = 1;
+        g->dim[a] = d; cells *= (size_t)d;
+    }
+    g->start = (int *)calloc(cells + 1, sizeof(int));
+    g->items = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    int c[3];
+    for (int i = 0; i < n; i++) g->start[cell_of(g, pt(tgt, i, stride), c) + 1]++;
+    for (size_t k = 0; k < cells; k++) g->start[k + 1] += g->start[k];
+    int *fill = (int *)malloc(sizeof(int) * cells);
+    memcpy(fill, g->start, sizeof(int) * cells);
+    for (int i = 0; i < n; i++) g->items[fill[cell_of(g, pt(tgt, i, stride), c)]++] = i;   /* ascending i per cell */
+    free(fill);
+}
+
+static void nn_grid(const void *src, int n_src, const void *tgt, int n_tgt, int stride,
+                    int *nn_index, float *nn_dist2)
+{
+    grid_t g; grid_build(&g, tgt, n_tgt, stride);
+    const int maxdim = g.dim[0] > g.dim[1] ? (g.dim[0] > g.dim[2] ? g.dim[0] : g.dim[2])
+                                           : (g.dim[1] > g.dim[2] ? g.dim[1] : g.dim[2]);
+    for (int i = 0; i < n_src; i++) {
+        const float *p = pt(src, i, stride);
+        int c[3]; cell_of(&g, p, c);
+        float best = FLT_MAX; int bi = -1;
+        for (int r = 0; r <= maxdim; r++) {
+            int lo[3], hi[3];
+            for (int a = 0; a < 3; a++) { lo[a] = c[a] - r; hi[a] = c[a] + r; }
+            for (int z = (lo[2] < 0 ? 0 : lo[2]); z <= (hi[2] >= g.dim[2] ? g.dim[2] - 1 : hi[2]); z++)
+            for (int y = (lo[1] < 0 ? 0 : lo[1]); y <= (hi[1] >= g.dim[1] ? g.dim[1] - 1 : hi[1]); y++)
+            for (int x = (lo[0] < 0 ? 0 : lo[0]); x <= (hi[0] >= g.dim[0] ? g.dim[0] - 1 : hi[0]); x++) {
+                const int on_shell = (z == lo[2] || z == hi[2] || y == lo[1] || y == hi[1] || x == lo[0] || x == hi[0]);
+                if (!on_shell) continue;
+                const int cell = (z * g.dim[1] + y) * g.dim[0] + x;
+                for (int k = g.start[cell]; k < g.start[cell + 1]; k++) {
+                    const int j = g.items[k];
+                    const float d = dist2f(p, pt(tgt, j, stride));
+                    if (d < best || (d == best && j < bi)) { best = d; bi = j; }
+                }
+            }
+            /* every unsearched point lies beyond a face of the searched block that still has cells behind it */
+            float bound = FLT_MAX; int open = 0;
+            for (int a = 0; a < 3; a++) {
+                if (lo[a] > 0) { float f = p[a] - (g.mn[a] + (float)lo[a] * g.h); if (f < 0) f = 0; if (f < bound) bound = f; open = 1; }
+                if (hi[a] < g.dim[a] - 1) { float f = (g.mn[a] + (float)(hi[a] + 1) * g.h) - p[a]; if (f < 0) f = 0; if (f < bound) bound = f; open = 1; }
+            }
+            if (!open) break;
+            bound *= 0.9999f;                         /* never over-estimate (fp32 face positions) */
+            if (bi >= 0 && best < bound * bound) break;
+        }
+        nn_index[i] = bi;
+        if (nn_dist2) nn_dist2[i] = best;
+    }
+    free(g.start); free(g.items);
+}
+
+void icpo_nn(const void *src, int n_src, const void *tgt, int n_tgt, int stride_bytes,
+             int use_grid, int *nn_index, float *nn_dist2)
+{
+    if (use_grid && n_tgt > 0) nn_grid(src, n_src, tgt, n_tgt, stride_bytes, nn_index, nn_dist2);
+    else nn_brute(src, n_src, tgt, n_tgt, stride_bytes, nn_index, nn_dist2);
+}
+
+/* ---- rotation from the cross-covariance ----------------------------------------
+ * S[a][b] = sum (p_a - pbar_a)(q_b - qbar_b)   (src x dst).  Horn 1987: the optimal unit
+ * quaternion is the eigenvector of the symmetric 4x4 matrix N(S) with the largest
+ * eigenvalue.  Cyclic Jacobi, fixed sweep budget, fp64. */
+static void jacobi_eig4(double A[4][4], double V[4][4])
+{
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) V[i][j] = (i == j);
+    for (int sweep = 0; sweep < 32; sweep++) {
+        double off = 0;
+        for (int i = 0; i < 4; i++) for (int j = i + 1; j < 4; j++) off += A[i][j] * A[i][j];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 3; p++) for (int q = p + 1; q < 4; q++) {
+            if (A[p][q] == 0.0) continue;
+            const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+            for (int k = 0; k < 4; k++) {            /* A <- A J */
+                const double akp = A[k][p], akq = A[k][q];
+                A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq;
+            }
+            for (int k = 0; k < 4; k++) {            /* A <- J^T A */
+                const double apk = A[p][k], aqk = A[q][k];
+                A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk;
+            }
+            for (int k = 0; k < 4; k++) {
+                const double vkp = V[k][p], vkq = V[k][q];
+                V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq;
+            }
+        }
+    }
+}
+
+static void rotation_from_S(const double S[3][3], double R[3][3])
+{
+    double N[4][4], V[4][4];
+    const double Sxx = S[0][0], Sxy = S[0][1], Sxz = S[0][2];
+    const double Syx = S[1][0], Syy = S[1][1], Syz = S[1][2];
+    const double Szx = S[2][0], Szy = S[2][1], Szz = S[2][2];
+    N[0][0] = Sxx + Syy + Szz; N[0][1] = Syz - Szy;       N[0][2] = Szx - Sxz;        N[0][3] = Sxy - Syx;
+    N[1][1] = Sxx - Syy - Szz; N[1][2] = Sxy + Syx;       N[1][3] = Szx + Sxz;
+    N[2][2] = -Sxx + Syy - Szz; N[2][3] = Syz + Szy;
+    N[3][3] = -Sxx - Syy + Szz;
+    for (int i = 0; i < 4; i++) for (int j = 0; j < i; j++) N[i][j] = N[j][i];
+    jacobi_eig4(N, V);
+    int m = 0;
+    for (int i = 1; i < 4; i++) if (N[i][i] > N[m][m]) m = i;
+    double w = V[0][m], x = V[1][m], y = V[2][m], z = V[3][m];
+    const double n = sqrt(w * w + x * x + y * y + z * z);
+    if (n > 0) { w /= n; x /= n; y /= n; z /= n; } else { w = 1; x = y = z = 0; }
+    R[0][0] = w * w + x * x - y * y - z * z; R[0][1] = 2 * (x * y - w * z);           R[0][2] = 2 * (x * z + w * y);
+    R[1][0] = 2 * (x * y + w * z);           R[1][1] = w * w - x * x + y * y - z * z; R[1][2] = 2 * (y * z - w * x);
+    R[2][0] = 2 * (x * z - w * y);           R[2][1] = 2 * (y * z + w * x);           R[2][2] = w * w - x * x - y * y + z * z;
+}
+
+void icpo_rotation_from_covariance(const double H[9], double R[9])
+{   /* H = dst x src (Umeyama's Sigma * N): S = H^T */
+    double S[3][3], Rm[3][3];
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) S[a][b] = H[b * 3 + a];
+    rotation_from_S(S, Rm);
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) R[a * 3 + b] = Rm[a][b];
+}
+
+/* centroids + cross-covariance (fp64, sequential) -> 4x4 float transform src->dst */
+static int estimate_rigid(const void *src, const void *tgt, int stride,
+                          const int *si, const int *ti, int n, float T[16])
+{
+    if (n < 3) return -1;
+    double pm[3] = {0, 0, 0}, qm[3] = {0, 0, 0};
+    for (int i = 0; i < n; i++) {
+        const float *p = pt(src, si ? si[i] : i, stride), *q = pt(tgt, ti[i], stride);
+        for (int a = 0; a < 3; a++) { pm[a] += (double)p[a]; qm[a] += (double)q[a]; }
+    }
+    for (int a = 0; a < 3; a++) { pm[a] /= (double)n; qm[a] /= (double)n; }
+    double S[3][3] = {{0}};
+    for (int i = 0; i < n; i++) {
+        const float *p = pt(src, si ? si[i] : i, stride), *q = pt(tgt, ti[i], stride);
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++)
+            S[a][b] += ((double)p[a] - pm[a]) * ((double)q[b] - qm[b]);
+    }
+    double R[3][3];
+    rotation_from_S(S, R);
+    for (int a = 0; a < 3; a++) {
+        for (int b = 0; b < 3; b++) T[a * 4 + b] = (float)R[a][b];
+        T[a * 4 + 3] = (float)(qm[a] - (R[a][0] * pm[0] + R[a][1] * pm[1] + R[a][2] * pm[2]));
+    }
+    T[12] = T[13] = T[14] = 0.0f; T[15] = 1.0f;
+    return 0;
+}
+
+int icpo_rigid_svd(const void *src, const void *tgt, int stride_bytes,
+                   const int *src_index, const int *tgt_index, int n_corr, float T[16])
+{
+    return estimate_rigid(src, tgt, stride_bytes, src_index, tgt_index, n_corr, T);
+}
+
+/* DM.h:247-250 */
+void icpo_transform(const void *in, int n, int stride_bytes, const float T[16], void *out)
+{
+    if (out != in) memcpy(out, in, (size_t)n * (size_t)stride_bytes);
+    for (int i = 0; i < n; i++) {
+        const float *p = pt(in, i, stride_bytes);
+        float *o = (float *)((unsigned char *)out + (size_t)i * (size_t)stride_bytes);
+        const float x = p[0], y = p[1], z = p[2];
+        o[0] = T[0] * x + T[1] * y + T[2] * z + T[3];
+        o[1] = T[4] * x + T[5] * y + T[6] * z + T[7];
+        o[2] = T[8] * x + T[9] * y + T[10] * z + T[11];
+    }
+}
+
+static void mat4_mul(const float A[16], const float B[16], float C[16])
+{
+    float r[16];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) {
+        float s = 0.0f;
+        for (int k = 0; k < 4; k++) s += A[i * 4 + k] * B[k * 4 + j];
+        r[i * 4 + j] = s;
+    }
+    memcpy(C, r, sizeof r);
+}
+
+/* pcl::IterativeClosestPoint::align */
+int icpo_icp_align(const void *src, int n_src, const void *tgt, int n_tgt, int stride_bytes,
+                   const icpo_params *p, float T[16], float *fitness, int *converged, int *iterations)
+{
+    const int use_grid = n_tgt > 2048;
+    unsigned char *work = (unsigned char *)malloc((size_t)(n_src > 0 ? n_src : 1) * (size_t)stride_bytes);
+    memcpy(work, src, (size_t)n_src * (size_t)stride_bytes);
+    int *nn = (int *)malloc(sizeof(int) * (size_t)(n_src > 0 ? n_src : 1));
+    float *d2 = (float *)malloc(sizeof(float) * (size_t)(n_src > 0 ? n_src : 1));
+    int *si = (int *)malloc(sizeof(int) * (size_t)(n_src > 0 ? n_src : 1));
+    int *ti = (int *)malloc(sizeof(int) * (size_t)(n_src > 0 ? n_src : 1));
+    float final[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    const float maxd2 = (float)(p->max_correspondence_dist * p->max_correspondence_dist);
+    double mse_prev = DBL_MAX;
+    int iter = 0, conv = 0;
+    while (!conv) {
+        icpo_nn(work, n_src, tgt, n_tgt, stride_bytes, use_grid, nn, d2);
+        int nc = 0; double sum_d2 = 0;
+        for (int i = 0; i < n_src; i++)
+            if (nn[i] >= 0 && d2[i] <= maxd2) { si[nc] = i; ti[nc] = nn[i]; sum_d2 += (double)d2[i]; nc++; }
+        if (nc < 3) { conv = 0; break; }                                  /* not enough correspondences */
+        float Tinc[16];
+        estimate_rigid(work, tgt, stride_bytes, si, ti, nc, Tinc);
+        icpo_transform(work, n_src, stride_bytes, Tinc, work);
+        mat4_mul(Tinc, final, final);
+        iter++;
+        /* DefaultConvergenceCriteria */
+        if (iter >= p->max_iterations) { conv = 1; break; }
+        const double cos_angle = 0.5 * ((double)Tinc[0] + (double)Tinc[5] + (double)Tinc[10] - 1.0);
+        const double tsq = (double)Tinc[3] * Tinc[3] + (double)Tinc[7] * Tinc[7] + (double)Tinc[11] * Tinc[11];
+        if (cos_angle >= 1.0 - p->transformation_epsilon && tsq <= p->transformation_epsilon) { conv = 1; break; }
+        const double mse = sum_d2 / (double)nc;
+        if (fabs(mse - mse_prev) < 1e-12) { conv = 1; break; }
+        if (fabs(mse - mse_prev) / mse_prev < p->euclidean_fitness_epsilon) { conv = 1; break; }
+        mse_prev = mse;
+    }
+    /* getFitnessScore(): original source moved by `final`, mean squared NN distance over all points */
+    icpo_transform(src, n_src, stride_bytes, final, work);
+    icpo_nn(work, n_src, tgt, n_tgt, stride_bytes, use_grid, nn, d2);
+    double fs = 0; int nr = 0;
+    for (int i = 0; i < n_src; i++) if (nn[i] >= 0) { fs += (double)d2[i]; nr++; }
+    if (fitness) *fitness = nr > 0 ? (float)(fs / (double)nr) : FLT_MAX;
+    memcpy(T, final, sizeof final);
+    if (converged) *converged = conv;
+    if (iterations) *iterations = iter;
+    free(work); free(nn); free(d2); free(si); free(ti);
+    return 0;
+}

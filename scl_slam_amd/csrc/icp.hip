@@ -1,7 +1,475 @@
-// icp.hip -- placeholder until the ICP kernels land (next milestone of this round).
+// icp.hip -- geometric verification of loop candidates on the GPU.
+//
+// Replaces the PCL objects the reference uses inline:
+//   pcl::IterativeClosestPoint::align + getFitnessScore   distributedMapping.h:1108-1121
+//   CorrespondenceEstimation::determineCorrespondences     distributedMapping.h:1211-1215
+//   TransformationEstimationSVD::estimateRigidTransformation  distributedMapping.h:1228-1230
+//   paramsServer::transformPointCloud                      distributedMapping.h:234-253
+//
+// Kernels (all HBM-bound; bytes per iteration ~ (n_src + n_tgt) * 16):
+//   K4a grid build   target cloud -> uniform grid (bbox, count, scan, scatter as float4 xyz+index)
+//   K4b nn search    one thread per source point, shell expansion over grid cells until the best
+//                    distance beats every unsearched cell; fp32 distances ((dx*dx+dy*dy)+dz*dz),
+//                    ties -> lowest target index (a total order: the result does not depend on the
+//                    order points were scattered into a cell)
+//   K5  reduce       fp64 sums of the augmented outer product [p;1][q;1]^T over correspondences
+//                    (gives the cross-covariance, both centroids and the count in one pass) + sum d2
+//   K5b solve        one wave: centred covariance, closed-form rotation (Horn quaternion, cyclic
+//                    Jacobi, fp64), incremental transform, PCL's convergence criteria, final = T*final
+//   K6  transform    working source cloud <- T_inc * cloud (fp32, no FMA)
+// The whole ICP loop is enqueued without host round trips: every kernel looks at a device-side
+// `done` flag, the host peeks at it every few iterations.
 #include "icp.hpp"
 
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+#include "device_common.hpp"
+
 namespace scl {
+
+namespace {
+
+constexpr int kGridDiv = 96;             // cells along the longest bbox edge
+constexpr int kMaxCells = 97 * 97 * 97;
+constexpr int kRedBlocks = 256;
+constexpr int kNSum = 17;                // 16 entries of sum [p;1][q;1]^T + sum d2
+
+struct IcpState {
+    float mn[3]; float h; int dim[3]; int cells;         // grid
+    float final_T[16]; float inc_T[16];
+    double mse_prev;
+    double fitness;
+    int iter; int done; int converged; int n_corr;
+    double sums[kNSum];
+};
+
+enum Buf { B_SRC = 0, B_TGT, B_WORK, B_TSORT, B_CSTART, B_CFILL, B_NNI, B_NND, B_PART, B_STATE, B_BBOX, B_SI, B_TI, B_OUT };
+
+int ensure(IcpWorkspace *ws, int k, size_t bytes, std::string *err)
+{
+    if (bytes <= ws->cap[k]) return SCL_OK;
+    if (ws->buf[k]) { (void)hipFree(ws->buf[k]); ws->buf[k] = nullptr; ws->cap[k] = 0; }
+    size_t nb = bytes + bytes / 4 + 256;
+    if (hipMalloc(&ws->buf[k], nb) != hipSuccess) { if (err) *err = "icp: hipMalloc failed"; return SCL_ERR_NOMEM; }
+    ws->cap[k] = nb;
+    return SCL_OK;
+}
+
+#define ICP_HIP(call)                                                                   \
+    do {                                                                                \
+        hipError_t e__ = (call);                                                        \
+        if (e__ != hipSuccess) { if (err) *err = std::string(#call) + ": " + hipGetErrorString(e__); return SCL_ERR_HIP; } \
+    } while (0)
+
+__device__ __forceinline__ float3 load_xyz(const unsigned char *base, int i, int stride)
+{
+    const float *f = reinterpret_cast<const float *>(base + (size_t)i * (size_t)stride);
+    return make_float3(f[0], f[1], f[2]);
+}
+
+// ---- K4a ---------------------------------------------------------------------------
+__global__ void bbox_partial_kernel(const unsigned char *pts, int n, int stride, float *part)
+{
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float3 p = load_xyz(pts, i, stride);
+        mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+        mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+    }
+    __shared__ float s[6][4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, kWave));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, kWave));
+        }
+    }
+    const int wv = threadIdx.x / kWave;
+    if ((threadIdx.x & 63) == 0) for (int a = 0; a < 3; ++a) { s[a][wv] = mn[a]; s[3 + a][wv] = mx[a]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int a = 0; a < 3; ++a) {
+            float m = s[a][0], M = s[3 + a][0];
+            for (int w = 1; w < (int)blockDim.x / kWave; ++w) { m = fminf(m, s[a][w]); M = fmaxf(M, s[3 + a][w]); }
+            part[blockIdx.x * 6 + a] = m; part[blockIdx.x * 6 + 3 + a] = M;
+        }
+    }
+}
+
+__global__ void grid_setup_kernel(const float *part, int nblocks, int n, IcpState *st, int *cell_start)
+{
+    if (threadIdx.x == 0) {
+        float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (int b = 0; b < nblocks; ++b)
+            for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], part[b * 6 + a]); mx[a] = fmaxf(mx[a], part[b * 6 + 3 + a]); }
+        if (n <= 0) { for (int a = 0; a < 3; ++a) { mn[a] = 0.f; mx[a] = 0.f; } }
+        float ext = 0.f;
+        for (int a = 0; a < 3; ++a) ext = fmaxf(ext, mx[a] - mn[a]);
+        float h = ext / (float)kGridDiv;
+        if (!(h > 1e-6f)) h = 1.0f;
+        int cells = 1;
+        for (int a = 0; a < 3; ++a) {
+            int d = (int)floorf((mx[a] - mn[a]) / h) + 1;
+            d = d < 1 ? 1 : (d > kGridDiv + 1 ? kGridDiv + 1 : d);
+            st->dim[a] = d; st->mn[a] = mn[a]; cells *= d;
+        }
+        st->h = h; st->cells = cells;
+    }
+    __syncthreads();
+    const int cells = st->cells;
+    for (int i = threadIdx.x; i <= cells; i += blockDim.x) cell_start[i] = 0;
+}
+
+__device__ __forceinline__ int cell_index(const IcpState *st, float3 p, int c[3])
+{
+    const float v[3] = {p.x, p.y, p.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float f = floorf((v[a] - st->mn[a]) / st->h);
+        int ci = (f != f) ? 0 : (f < 0.f ? 0 : (f >= (float)st->dim[a] ? st->dim[a] - 1 : (int)f));
+        c[a] = ci;
+    }
+    return (c[2] * st->dim[1] + c[1]) * st->dim[0] + c[0];
+}
+
+__global__ void grid_count_kernel(const unsigned char *pts, int n, int stride, const IcpState *st, int *cell_start)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int c[3];
+        const int cell = cell_index(st, load_xyz(pts, i, stride), c);
+        atomicAdd(&cell_start[cell + 1], 1);
+    }
+}
+
+// exclusive scan of cell counts in place (cell_start[0] = 0 already), single workgroup
+__global__ __launch_bounds__(1024) void grid_scan_kernel(const IcpState *st, int *cell_start, int *cell_fill)
+{
+    __shared__ int s_part[1024];
+    const int n = st->cells + 1;
+    const int per = (n + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(lo + per, n);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += cell_start[i];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {                 // Hillis-Steele inclusive scan
+        const int v = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = threadIdx.x ? s_part[threadIdx.x - 1] : 0;
+    for (int i = lo; i < hi; ++i) { run += cell_start[i]; cell_start[i] = run; }   // inclusive of the +1 shift => start offsets
+    __syncthreads();
+    for (int i = threadIdx.x; i < st->cells; i += blockDim.x) cell_fill[i] = cell_start[i];
+}
+
+__global__ void grid_scatter_kernel(const unsigned char *pts, int n, int stride, const IcpState *st,
+                                    int *cell_fill, float4 *sorted)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int c[3];
+        const float3 p = load_xyz(pts, i, stride);
+        const int cell = cell_index(st, p, c);
+        const int pos = atomicAdd(&cell_fill[cell], 1);
+        sorted[pos] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+    }
+}
+
+// ---- K4b ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nn_search_kernel(const float4 *work, int n_src, const IcpState *st,
+                                                        const int *cell_start, const float4 *sorted,
+                                                        int *nn_idx, float *nn_d2, int check_done)
+{
+    if (check_done && st->done) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_src) return;
+    const float4 pw = work[i];
+    const float3 p = make_float3(pw.x, pw.y, pw.z);
+    int c[3];
+    cell_index(st, p, c);
+    const int dx = st->dim[0], dy = st->dim[1], dz = st->dim[2];
+    const float h = st->h;
+    const int maxdim = max(dx, max(dy, dz));
+    float best = FLT_MAX;
+    int bi = -1;
+    for (int r = 0; r <= maxdim; ++r) {
+        const int lo0 = c[0] - r, hi0 = c[0] + r, lo1 = c[1] - r, hi1 = c[1] + r, lo2 = c[2] - r, hi2 = c[2] + r;
+        for (int z = max(lo2, 0); z <= min(hi2, dz - 1); ++z) {
+            const bool zs = (z == lo2) | (z == hi2);
+            for (int y = max(lo1, 0); y <= min(hi1, dy - 1); ++y) {
+                const bool ys = zs | (y == lo1) | (y == hi1);
+                // on a z- or y-face of the shell every x is on the shell; otherwise only the two x-faces
+                const int xs = max(lo0, 0), xe = min(hi0, dx - 1);
+                const int step = ys ? 1 : max(hi0 - lo0, 1);
+                for (int x = ys ? xs : lo0; x <= xe; x += step) {
+                    if (x < 0) continue;
+                    const int cell = (z * dy + y) * dx + x;
+                    const int kb = cell_start[cell], ke = cell_start[cell + 1];
+                    for (int k = kb; k < ke; ++k) {
+                        const float4 q = sorted[k];
+                        const float ex = p.x - q.x, ey = p.y - q.y, ez = p.z - q.z;
+                        const float d = (ex * ex + ey * ey) + ez * ez;
+                        const int j = __float_as_int(q.w);
+                        if ((d < best) | ((d == best) & (j < bi))) { best = d; bi = j; }
+                    }
+                }
+            }
+        }
+        float bound = FLT_MAX;
+        bool open = false;
+        const float pv[3] = {p.x, p.y, p.z};
+        const int lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0, hi1, hi2}, dm[3] = {dx, dy, dz};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (lo[a] > 0) { float f = pv[a] - (st->mn[a] + (float)lo[a] * h); f = f < 0.f ? 0.f : f; bound = fminf(bound, f); open = true; }
+            if (hi[a] < dm[a] - 1) { float f = (st->mn[a] + (float)(hi[a] + 1) * h) - pv[a]; f = f < 0.f ? 0.f : f; bound = fminf(bound, f); open = true; }
+        }
+        if (!open) break;
+        bound *= 0.9999f;
+        if (bi >= 0 && best < bound * bound) break;
+    }
+    nn_idx[i] = bi;
+    nn_d2[i] = best;
+}
+
+// ---- K5 ----------------------------------------------------------------------------
+// sums of [p;1][q;1]^T (16) and of d2 over the accepted correspondences.
+// mode 0: pairs (i, nn_idx[i]) with d2 <= maxd2, p from `work`;  mode 1: explicit pairs (si[k], ti[k]).
+__global__ __launch_bounds__(256) void corr_reduce_kernel(const float4 *work, const unsigned char *src_raw,
+                                                          const unsigned char *tgt_raw, int stride, int n,
+                                                          const int *nn_idx, const float *nn_d2, float maxd2,
+                                                          const int *si, const int *ti, int mode,
+                                                          const IcpState *st, double *partials, int check_done)
+{
+    if (check_done && st->done) return;
+    double acc[kNSum];
+#pragma unroll
+    for (int k = 0; k < kNSum; ++k) acc[k] = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float3 p, q;
+        float d2 = 0.f;
+        if (mode == 0) {
+            const int j = nn_idx[i];
+            d2 = nn_d2[i];
+            if (j < 0 || !(d2 <= maxd2)) continue;
+            const float4 pw = work[i];
+            p = make_float3(pw.x, pw.y, pw.z);
+            q = load_xyz(tgt_raw, j, stride);
+        } else {
+            p = load_xyz(src_raw, si[i], stride);
+            q = load_xyz(tgt_raw, ti[i], stride);
+        }
+        const double pv[4] = {(double)p.x, (double)p.y, (double)p.z, 1.0};
+        const double qv[4] = {(double)q.x, (double)q.y, (double)q.z, 1.0};
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a * 4 + b] = fma(pv[a], qv[b], acc[a * 4 + b]);
+        acc[16] += (double)d2;
+    }
+    __shared__ double s[4][kNSum];
+#pragma unroll
+    for (int k = 0; k < kNSum; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off, kWave);
+    }
+    const int wv = threadIdx.x / kWave;
+    if ((threadIdx.x & 63) == 0) for (int k = 0; k < kNSum; ++k) s[wv][k] = acc[k];
+    __syncthreads();
+    if (threadIdx.x < kNSum)
+        partials[blockIdx.x * kNSum + threadIdx.x] = ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x];
+}
+
+// ---- K5b ---------------------------------------------------------------------------
+__device__ void rotation_from_S(const double S[3][3], double R[3][3])
+{
+    double N[4][4], V[4][4];
+    const double Sxx = S[0][0], Sxy = S[0][1], Sxz = S[0][2];
+    const double Syx = S[1][0], Syy = S[1][1], Syz = S[1][2];
+    const double Szx = S[2][0], Szy = S[2][1], Szz = S[2][2];
+    N[0][0] = Sxx + Syy + Szz; N[0][1] = Syz - Szy;        N[0][2] = Szx - Sxz;        N[0][3] = Sxy - Syx;
+    N[1][1] = Sxx - Syy - Szz; N[1][2] = Sxy + Syx;        N[1][3] = Szx + Sxz;
+    N[2][2] = -Sxx + Syy - Szz; N[2][3] = Syz + Szy;
+    N[3][3] = -Sxx - Syy + Szz;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < i; ++j) N[i][j] = N[j][i];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 32; ++sweep) {
+        double off = 0.0;
+        for (int i = 0; i < 4; ++i) for (int j = i + 1; j < 4; ++j) off += N[i][j] * N[i][j];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 3; ++p) for (int q = p + 1; q < 4; ++q) {
+            if (N[p][q] == 0.0) continue;
+            const double theta = (N[q][q] - N[p][p]) / (2.0 * N[p][q]);
+            const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+            for (int k = 0; k < 4; ++k) { const double a = N[k][p], b = N[k][q]; N[k][p] = c * a - s * b; N[k][q] = s * a + c * b; }
+            for (int k = 0; k < 4; ++k) { const double a = N[p][k], b = N[q][k]; N[p][k] = c * a - s * b; N[q][k] = s * a + c * b; }
+            for (int k = 0; k < 4; ++k) { const double a = V[k][p], b = V[k][q]; V[k][p] = c * a - s * b; V[k][q] = s * a + c * b; }
+        }
+    }
+    int m = 0;
+    for (int i = 1; i < 4; ++i) if (N[i][i] > N[m][m]) m = i;
+    double w = V[0][m], x = V[1][m], y = V[2][m], z = V[3][m];
+    const double n = sqrt(w * w + x * x + y * y + z * z);
+    if (n > 0.0) { w /= n; x /= n; y /= n; z /= n; } else { w = 1.0; x = y = z = 0.0; }
+    R[0][0] = w * w + x * x - y * y - z * z; R[0][1] = 2 * (x * y - w * z);           R[0][2] = 2 * (x * z + w * y);
+    R[1][0] = 2 * (x * y + w * z);           R[1][1] = w * w - x * x + y * y - z * z; R[1][2] = 2 * (y * z - w * x);
+    R[2][0] = 2 * (x * z - w * y);           R[2][1] = 2 * (y * z + w * x);           R[2][2] = w * w - x * x - y * y + z * z;
+}
+
+// mode 0: ICP iteration (convergence bookkeeping); mode 1: one-shot rigid estimate; mode 2: fitness only
+__global__ void icp_solve_kernel(IcpState *st, const double *partials, int nblocks, int mode,
+                                 int max_iter, double trans_eps, double fit_eps)
+{
+    __shared__ double sums[kNSum];
+    if (mode == 0 && st->done) return;
+    if (threadIdx.x < kNSum) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += partials[b * kNSum + threadIdx.x];   // fixed order: deterministic
+        sums[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int k = 0; k < kNSum; ++k) st->sums[k] = sums[k];
+    const double N = sums[15];
+    st->n_corr = (int)N;
+    if (mode == 2) { st->fitness = N > 0.0 ? sums[16] / N : (double)FLT_MAX; return; }
+    if (N < 3.0) { st->done = 1; st->converged = 0; return; }             // not enough correspondences
+    double pm[3], qm[3], S[3][3], R[3][3];
+    for (int a = 0; a < 3; ++a) { pm[a] = sums[a * 4 + 3] / N; qm[a] = sums[12 + a] / N; }
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) S[a][b] = sums[a * 4 + b] - N * pm[a] * qm[b];
+    rotation_from_S(S, R);
+    float T[16];
+    for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) T[a * 4 + b] = (float)R[a][b];
+        T[a * 4 + 3] = (float)(qm[a] - (R[a][0] * pm[0] + R[a][1] * pm[1] + R[a][2] * pm[2]));
+    }
+    T[12] = T[13] = T[14] = 0.f; T[15] = 1.f;
+    for (int k = 0; k < 16; ++k) st->inc_T[k] = T[k];
+    if (mode == 1) { for (int k = 0; k < 16; ++k) st->final_T[k] = T[k]; return; }
+    float F[16];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
+        float s = 0.f;
+        for (int k = 0; k < 4; ++k) s += T[i * 4 + k] * st->final_T[k * 4 + j];
+        F[i * 4 + j] = s;
+    }
+    for (int k = 0; k < 16; ++k) st->final_T[k] = F[k];
+    st->iter += 1;
+    // pcl::registration::DefaultConvergenceCriteria
+    if (st->iter >= max_iter) { st->done = 1; st->converged = 1; return; }
+    const double cos_angle = 0.5 * ((double)T[0] + (double)T[5] + (double)T[10] - 1.0);
+    const double tsq = (double)T[3] * T[3] + (double)T[7] * T[7] + (double)T[11] * T[11];
+    if (cos_angle >= 1.0 - trans_eps && tsq <= trans_eps) { st->done = 1; st->converged = 1; return; }
+    const double mse = sums[16] / N;
+    if (fabs(mse - st->mse_prev) < 1e-12) { st->done = 1; st->converged = 1; return; }
+    if (fabs(mse - st->mse_prev) / st->mse_prev < fit_eps) { st->done = 1; st->converged = 1; return; }
+    st->mse_prev = mse;
+}
+
+// ---- K6 ----------------------------------------------------------------------------
+__global__ void work_init_kernel(const unsigned char *src, int n, int stride, float4 *work)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const float3 p = load_xyz(src, i, stride); work[i] = make_float4(p.x, p.y, p.z, 0.f); }
+}
+
+// which: 0 = inc_T applied to work in place (ICP step); 1 = final_T applied to the raw source into work
+__global__ void work_transform_kernel(float4 *work, const unsigned char *src, int n, int stride,
+                                      const IcpState *st, int which, int expect_iter)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *T = which == 0 ? st->inc_T : st->final_T;
+    float x, y, z;
+    if (which == 0) {
+        if (st->iter != expect_iter) return;      // this iteration's solve did not run (finished earlier / failed)
+        const float4 p = work[i]; x = p.x; y = p.y; z = p.z;
+    } else {
+        const float3 p = load_xyz(src, i, stride); x = p.x; y = p.y; z = p.z;
+    }
+    // distributedMapping.h:247-249 (fp32, left-to-right, no FMA)
+    const float ox = T[0] * x + T[1] * y + T[2] * z + T[3];
+    const float oy = T[4] * x + T[5] * y + T[6] * z + T[7];
+    const float oz = T[8] * x + T[9] * y + T[10] * z + T[11];
+    work[i] = make_float4(ox, oy, oz, 0.f);
+}
+
+__global__ void raw_transform_kernel(const unsigned char *in, unsigned char *out, int n, int stride, const float *T)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned char *pi = in + (size_t)i * stride;
+    unsigned char *po = out + (size_t)i * stride;
+    const float *f = reinterpret_cast<const float *>(pi);
+    const float x = f[0], y = f[1], z = f[2];
+    float *o = reinterpret_cast<float *>(po);
+    for (int k = 3; k < stride / 4; ++k) o[k] = f[k];                        // intensity & padding copied (DM.h:250)
+    o[0] = T[0] * x + T[1] * y + T[2] * z + T[3];
+    o[1] = T[4] * x + T[5] * y + T[6] * z + T[7];
+    o[2] = T[8] * x + T[9] * y + T[10] * z + T[11];
+}
+
+__global__ void state_init_kernel(IcpState *st)
+{
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 16; ++k) { st->final_T[k] = (k % 5 == 0) ? 1.f : 0.f; st->inc_T[k] = (k % 5 == 0) ? 1.f : 0.f; }
+        st->mse_prev = DBL_MAX; st->fitness = (double)FLT_MAX;
+        st->iter = 0; st->done = 0; st->converged = 0; st->n_corr = 0;
+    }
+}
+
+// ---- host helpers -------------------------------------------------------------------
+int upload(IcpWorkspace *ws, int k, const void *host, size_t bytes, hipStream_t stream, std::string *err)
+{
+    int rc = ensure(ws, k, bytes + 16, err);
+    if (rc) return rc;
+    if (bytes) ICP_HIP(hipMemcpyAsync(ws->buf[k], host, bytes, hipMemcpyHostToDevice, stream));
+    return SCL_OK;
+}
+
+int build_grid(IcpWorkspace *ws, hipStream_t stream, int n_tgt, int stride, std::string *err)
+{
+    int rc;
+    if ((rc = ensure(ws, B_TSORT, sizeof(float4) * (size_t)(n_tgt + 1), err))) return rc;
+    if ((rc = ensure(ws, B_CSTART, sizeof(int) * (size_t)(kMaxCells + 2), err))) return rc;
+    if ((rc = ensure(ws, B_CFILL, sizeof(int) * (size_t)(kMaxCells + 2), err))) return rc;
+    if ((rc = ensure(ws, B_BBOX, sizeof(float) * 6 * 256, err))) return rc;
+    if ((rc = ensure(ws, B_STATE, sizeof(IcpState), err))) return rc;
+    const unsigned char *tgt = static_cast<const unsigned char *>(ws->buf[B_TGT]);
+    IcpState *st = static_cast<IcpState *>(ws->buf[B_STATE]);
+    int nb = (n_tgt + 255) / 256; nb = nb < 1 ? 1 : (nb > 256 ? 256 : nb);
+    hipLaunchKernelGGL(bbox_partial_kernel, dim3(nb), dim3(256), 0, stream, tgt, n_tgt, stride, (float *)ws->buf[B_BBOX]);
+    hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(1024), 0, stream, (const float *)ws->buf[B_BBOX], nb, n_tgt, st,
+                       (int *)ws->buf[B_CSTART]);
+    int gb = (n_tgt + 255) / 256; gb = gb < 1 ? 1 : (gb > 2048 ? 2048 : gb);
+    hipLaunchKernelGGL(grid_count_kernel, dim3(gb), dim3(256), 0, stream, tgt, n_tgt, stride, st, (int *)ws->buf[B_CSTART]);
+    hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, stream, st, (int *)ws->buf[B_CSTART], (int *)ws->buf[B_CFILL]);
+    hipLaunchKernelGGL(grid_scatter_kernel, dim3(gb), dim3(256), 0, stream, tgt, n_tgt, stride, st, (int *)ws->buf[B_CFILL],
+                       (float4 *)ws->buf[B_TSORT]);
+    ICP_HIP(hipGetLastError());
+    return SCL_OK;
+}
+
+int pinned(IcpWorkspace *ws, size_t bytes, std::string *err)
+{
+    if (bytes <= ws->pinned_cap) return SCL_OK;
+    if (ws->pinned) { (void)hipHostFree(ws->pinned); ws->pinned = nullptr; ws->pinned_cap = 0; }
+    ICP_HIP(hipHostMalloc(&ws->pinned, bytes, hipHostMallocDefault));
+    ws->pinned_cap = bytes;
+    return SCL_OK;
+}
+
+int check_cloud_args(int n_src, int n_tgt, int stride, std::string *err)
+{
+    if (n_src < 0 || n_tgt < 0 || stride < 12 || (stride & 3)) { if (err) *err = "icp: bad cloud layout"; return SCL_ERR_INVALID_ARG; }
+    return SCL_OK;
+}
+
+}  // namespace
 
 void icp_workspace_free(IcpWorkspace *ws)
 {
@@ -9,16 +477,146 @@ void icp_workspace_free(IcpWorkspace *ws)
     if (ws->pinned) { (void)hipHostFree(ws->pinned); ws->pinned = nullptr; ws->pinned_cap = 0; }
 }
 
-int icp_align(IcpWorkspace *, hipStream_t, int, const void *, int, const void *, int, int, const scl_icp_params &,
-              float *, float *, int *, int *, std::string *err)
-{ if (err) *err = "icp_align: not implemented yet"; return SCL_ERR_UNSUPPORTED; }
-int icp_nn_correspondences(IcpWorkspace *, hipStream_t, int, const void *, int, const void *, int, int, int *, float *,
-                           std::string *err)
-{ if (err) *err = "nn_correspondences: not implemented yet"; return SCL_ERR_UNSUPPORTED; }
-int icp_rigid_svd(IcpWorkspace *, hipStream_t, int, const void *, int, const void *, int, int, const int *, const int *,
-                  int, float *, std::string *err)
-{ if (err) *err = "rigid_svd: not implemented yet"; return SCL_ERR_UNSUPPORTED; }
-int icp_transform_cloud(IcpWorkspace *, hipStream_t, const void *, int, int, const float *, void *, std::string *err)
-{ if (err) *err = "transform_cloud: not implemented yet"; return SCL_ERR_UNSUPPORTED; }
+int icp_align(IcpWorkspace *ws, hipStream_t stream, int num_cu, const void *src, int n_src,
+              const void *tgt, int n_tgt, int stride, const scl_icp_params &p,
+              float T[16], float *fitness, int *converged, int *iterations, std::string *err)
+{
+    (void)num_cu;
+    int rc = check_cloud_args(n_src, n_tgt, stride, err);
+    if (rc) return rc;
+    if (p.estimator != 0) { if (err) *err = "point-to-plane estimator: not implemented in this round"; return SCL_ERR_UNSUPPORTED; }
+    if (p.max_iterations < 1) { if (err) *err = "max_iterations < 1"; return SCL_ERR_INVALID_ARG; }
+    if ((rc = upload(ws, B_SRC, src, (size_t)n_src * stride, stream, err))) return rc;
+    if ((rc = upload(ws, B_TGT, tgt, (size_t)n_tgt * stride, stream, err))) return rc;
+    if ((rc = ensure(ws, B_WORK, sizeof(float4) * (size_t)(n_src + 1), err))) return rc;
+    if ((rc = ensure(ws, B_NNI, sizeof(int) * (size_t)(n_src + 1), err))) return rc;
+    if ((rc = ensure(ws, B_NND, sizeof(float) * (size_t)(n_src + 1), err))) return rc;
+    if ((rc = ensure(ws, B_PART, sizeof(double) * kNSum * kRedBlocks, err))) return rc;
+    if ((rc = build_grid(ws, stream, n_tgt, stride, err))) return rc;
+    if ((rc = pinned(ws, sizeof(IcpState), err))) return rc;
+
+    IcpState *st = static_cast<IcpState *>(ws->buf[B_STATE]);
+    float4 *work = static_cast<float4 *>(ws->buf[B_WORK]);
+    const unsigned char *d_src = static_cast<const unsigned char *>(ws->buf[B_SRC]);
+    const unsigned char *d_tgt = static_cast<const unsigned char *>(ws->buf[B_TGT]);
+    int *nni = static_cast<int *>(ws->buf[B_NNI]);
+    float *nnd = static_cast<float *>(ws->buf[B_NND]);
+    double *part = static_cast<double *>(ws->buf[B_PART]);
+    const int pb = (n_src + 255) / 256 > 0 ? (n_src + 255) / 256 : 1;
+    int rb = pb < kRedBlocks ? pb : kRedBlocks;
+    const float maxd2 = (float)(p.max_correspondence_dist * p.max_correspondence_dist);
+
+    hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(64), 0, stream, st);
+    hipLaunchKernelGGL(work_init_kernel, dim3(pb), dim3(256), 0, stream, d_src, n_src, stride, work);
+    IcpState *h = static_cast<IcpState *>(ws->pinned);
+    for (int it = 0; it < p.max_iterations; ++it) {
+        hipLaunchKernelGGL(nn_search_kernel, dim3(pb), dim3(256), 0, stream, work, n_src, st,
+                           (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], nni, nnd, 1);
+        hipLaunchKernelGGL(corr_reduce_kernel, dim3(rb), dim3(256), 0, stream, work, d_src, d_tgt, stride, n_src,
+                           nni, nnd, maxd2, (const int *)nullptr, (const int *)nullptr, 0, st, part, 1);
+        hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, stream, st, part, rb, 0, p.max_iterations,
+                           p.transformation_epsilon, p.euclidean_fitness_epsilon);
+        // applies inc_T iff the solve of this very iteration ran (also when it just declared convergence)
+        hipLaunchKernelGGL(work_transform_kernel, dim3(pb), dim3(256), 0, stream, work, d_src, n_src, stride, st, 0, it + 1);
+        if ((it & 7) == 7) {                                   // peek at the device flag every 8 iterations
+            ICP_HIP(hipMemcpyAsync(h, st, sizeof(IcpState), hipMemcpyDeviceToHost, stream));
+            ICP_HIP(hipStreamSynchronize(stream));
+            if (h->done) break;
+        }
+    }
+    // fitness: original source moved by the final transform, mean squared NN distance over all points
+    hipLaunchKernelGGL(work_transform_kernel, dim3(pb), dim3(256), 0, stream, work, d_src, n_src, stride, st, 1, 0);
+    hipLaunchKernelGGL(nn_search_kernel, dim3(pb), dim3(256), 0, stream, work, n_src, st,
+                       (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], nni, nnd, 0);
+    hipLaunchKernelGGL(corr_reduce_kernel, dim3(rb), dim3(256), 0, stream, work, d_src, d_tgt, stride, n_src,
+                       nni, nnd, FLT_MAX, (const int *)nullptr, (const int *)nullptr, 0, st, part, 0);
+    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, stream, st, part, rb, 2, 0, 0.0, 0.0);
+    ICP_HIP(hipGetLastError());
+    ICP_HIP(hipMemcpyAsync(h, st, sizeof(IcpState), hipMemcpyDeviceToHost, stream));
+    ICP_HIP(hipStreamSynchronize(stream));
+    std::memcpy(T, h->final_T, sizeof(float) * 16);
+    if (fitness) *fitness = (float)h->fitness;
+    if (converged) *converged = h->converged;
+    if (iterations) *iterations = h->iter;
+    return SCL_OK;
+}
+
+int icp_nn_correspondences(IcpWorkspace *ws, hipStream_t stream, int num_cu, const void *src, int n_src,
+                           const void *tgt, int n_tgt, int stride, int *nn_index, float *nn_dist2, std::string *err)
+{
+    (void)num_cu;
+    int rc = check_cloud_args(n_src, n_tgt, stride, err);
+    if (rc) return rc;
+    if ((rc = upload(ws, B_SRC, src, (size_t)n_src * stride, stream, err))) return rc;
+    if ((rc = upload(ws, B_TGT, tgt, (size_t)n_tgt * stride, stream, err))) return rc;
+    if ((rc = ensure(ws, B_WORK, sizeof(float4) * (size_t)(n_src + 1), err))) return rc;
+    if ((rc = ensure(ws, B_NNI, sizeof(int) * (size_t)(n_src + 1), err))) return rc;
+    if ((rc = ensure(ws, B_NND, sizeof(float) * (size_t)(n_src + 1), err))) return rc;
+    if ((rc = build_grid(ws, stream, n_tgt, stride, err))) return rc;
+    IcpState *st = static_cast<IcpState *>(ws->buf[B_STATE]);
+    const int pb = (n_src + 255) / 256 > 0 ? (n_src + 255) / 256 : 1;
+    hipLaunchKernelGGL(work_init_kernel, dim3(pb), dim3(256), 0, stream, (const unsigned char *)ws->buf[B_SRC], n_src, stride,
+                       (float4 *)ws->buf[B_WORK]);
+    hipLaunchKernelGGL(nn_search_kernel, dim3(pb), dim3(256), 0, stream, (const float4 *)ws->buf[B_WORK], n_src, st,
+                       (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], (int *)ws->buf[B_NNI],
+                       (float *)ws->buf[B_NND], 0);
+    ICP_HIP(hipGetLastError());
+    ICP_HIP(hipMemcpyAsync(nn_index, ws->buf[B_NNI], sizeof(int) * (size_t)n_src, hipMemcpyDeviceToHost, stream));
+    if (nn_dist2) ICP_HIP(hipMemcpyAsync(nn_dist2, ws->buf[B_NND], sizeof(float) * (size_t)n_src, hipMemcpyDeviceToHost, stream));
+    ICP_HIP(hipStreamSynchronize(stream));
+    return SCL_OK;
+}
+
+int icp_rigid_svd(IcpWorkspace *ws, hipStream_t stream, int num_cu, const void *src, int n_src,
+                  const void *tgt, int n_tgt, int stride, const int *src_index, const int *tgt_index,
+                  int n_corr, float T[16], std::string *err)
+{
+    (void)num_cu;
+    int rc = check_cloud_args(n_src, n_tgt, stride, err);
+    if (rc) return rc;
+    if (n_corr < 3) { if (err) *err = "rigid_svd needs >= 3 correspondences"; return SCL_ERR_INVALID_ARG; }
+    for (int i = 0; i < n_corr; ++i)
+        if (src_index[i] < 0 || src_index[i] >= n_src || tgt_index[i] < 0 || tgt_index[i] >= n_tgt) {
+            if (err) *err = "rigid_svd: correspondence index out of range"; return SCL_ERR_OUT_OF_RANGE;
+        }
+    if ((rc = upload(ws, B_SRC, src, (size_t)n_src * stride, stream, err))) return rc;
+    if ((rc = upload(ws, B_TGT, tgt, (size_t)n_tgt * stride, stream, err))) return rc;
+    if ((rc = upload(ws, B_SI, src_index, sizeof(int) * (size_t)n_corr, stream, err))) return rc;
+    if ((rc = upload(ws, B_TI, tgt_index, sizeof(int) * (size_t)n_corr, stream, err))) return rc;
+    if ((rc = ensure(ws, B_PART, sizeof(double) * kNSum * kRedBlocks, err))) return rc;
+    if ((rc = ensure(ws, B_STATE, sizeof(IcpState), err))) return rc;
+    if ((rc = pinned(ws, sizeof(IcpState), err))) return rc;
+    IcpState *st = static_cast<IcpState *>(ws->buf[B_STATE]);
+    int rb = (n_corr + 255) / 256; rb = rb < 1 ? 1 : (rb > kRedBlocks ? kRedBlocks : rb);
+    hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(64), 0, stream, st);
+    hipLaunchKernelGGL(corr_reduce_kernel, dim3(rb), dim3(256), 0, stream, (const float4 *)nullptr,
+                       (const unsigned char *)ws->buf[B_SRC], (const unsigned char *)ws->buf[B_TGT], stride, n_corr,
+                       (const int *)nullptr, (const float *)nullptr, 0.f, (const int *)ws->buf[B_SI], (const int *)ws->buf[B_TI], 1,
+                       st, (double *)ws->buf[B_PART], 0);
+    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, stream, st, (const double *)ws->buf[B_PART], rb, 1, 0, 0.0, 0.0);
+    ICP_HIP(hipGetLastError());
+    IcpState *h = static_cast<IcpState *>(ws->pinned);
+    ICP_HIP(hipMemcpyAsync(h, st, sizeof(IcpState), hipMemcpyDeviceToHost, stream));
+    ICP_HIP(hipStreamSynchronize(stream));
+    std::memcpy(T, h->final_T, sizeof(float) * 16);
+    return SCL_OK;
+}
+
+int icp_transform_cloud(IcpWorkspace *ws, hipStream_t stream, const void *in, int n, int stride,
+                        const float T[16], void *out, std::string *err)
+{
+    int rc = check_cloud_args(n, 0, stride, err);
+    if (rc) return rc;
+    if ((rc = upload(ws, B_SRC, in, (size_t)n * stride, stream, err))) return rc;
+    if ((rc = ensure(ws, B_OUT, (size_t)n * stride + 16, err))) return rc;
+    if ((rc = upload(ws, B_BBOX, T, sizeof(float) * 16, stream, err))) return rc;
+    const int pb = (n + 255) / 256 > 0 ? (n + 255) / 256 : 1;
+    hipLaunchKernelGGL(raw_transform_kernel, dim3(pb), dim3(256), 0, stream, (const unsigned char *)ws->buf[B_SRC],
+                       (unsigned char *)ws->buf[B_OUT], n, stride, (const float *)ws->buf[B_BBOX]);
+    ICP_HIP(hipGetLastError());
+    ICP_HIP(hipMemcpyAsync(out, ws->buf[B_OUT], (size_t)n * stride, hipMemcpyDeviceToHost, stream));
+    ICP_HIP(hipStreamSynchronize(stream));
+    return SCL_OK;
+}
 
 }  // namespace scl

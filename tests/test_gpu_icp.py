@@ -1,0 +1,89 @@
+"""Geometric-verification parity: GPU (through the C ABI) vs the CPU restatement.
+Bar: NN indices bit-exact (incl. the fp32 squared distances), ICP transforms within 1e-5."""
+import numpy as np
+import pytest
+
+import oracle_icp_binding as oi
+from scl_slam_amd import ScanContextEngine
+from scl_slam_amd.synth import rigid_transform, synth_structured_cloud
+from test_oracle_icp_kat import moved_copy
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = ScanContextEngine()
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("n_src,n_tgt", [(1500, 5000), (20000, 30000), (1, 10), (300, 1000)])
+def test_nn_correspondences_bit_exact(eng, n_src, n_tgt):
+    tgt = synth_structured_cloud(n_tgt, seed=2 + n_tgt)
+    src = synth_structured_cloud(n_src, seed=3 + n_src)
+    src[: max(1, n_src // 50), :3] += 250.0                      # points far outside the target's bounding box
+    gi, gd = eng.nn_correspondences(src, tgt)
+    oi_, od = oi.nn(src, tgt, use_grid=True)
+    assert np.array_equal(gi, oi_)
+    assert np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+
+
+def test_nn_ties_lowest_index(eng):
+    tgt = np.zeros((6, 8), np.float32); tgt[:, 0] = [1, 1, 1, 5, 5, 1]
+    src = np.zeros((2, 8), np.float32); src[1, 0] = 5
+    gi, gd = eng.nn_correspondences(src, tgt)
+    assert list(gi) == [0, 3]
+
+
+def test_rigid_svd_matches(eng):
+    tgt = synth_structured_cloud(4000, seed=5)
+    T = rigid_transform(0.2, -0.1, 0.7, 1.5, -2.0, 0.4)
+    src = moved_copy(tgt, T, keep_every=1, noise=0.01)
+    rs = np.random.RandomState(0)
+    si = rs.randint(0, 4000, 1500).astype(np.int32)
+    Tg = eng.rigid_svd(src, tgt, si, si)
+    To = oi.rigid_svd(src, tgt, si, si)
+    assert np.abs(Tg - To).max() < TOL and np.abs(Tg - T).max() < 5e-3
+
+
+def test_transform_cloud_bit_exact(eng):
+    c = synth_structured_cloud(5000, seed=9)
+    T = rigid_transform(0.3, 0.2, -1.0, 4, 5, 6).astype(np.float32)
+    assert np.array_equal(eng.transform_cloud(c, T), oi.transform(c, T))
+
+
+@pytest.mark.parametrize("n_tgt,noise,keep", [(6000, 0.0, 2), (20000, 0.01, 2), (3000, 0.02, 1)])
+def test_icp_align_matches_oracle(eng, n_tgt, noise, keep):
+    tgt = synth_structured_cloud(n_tgt, seed=1 + n_tgt)
+    T = rigid_transform(0.01, -0.02, 0.05, 0.3, -0.2, 0.1)
+    src = moved_copy(tgt, T, keep_every=keep, noise=noise, seed=7)
+    Tg, fg, cg, ig = eng.icp_align(src, tgt)
+    To, fo, co, io = oi.icp_align(src, tgt)
+    assert cg == co and ig == io
+    assert np.abs(Tg - To).max() < TOL
+    assert abs(fg - fo) <= 1e-5 * max(1e-6, abs(fo)) + 1e-12
+    assert np.abs(Tg - T).max() < 5e-3
+
+
+def test_icp_iteration_cap_and_failure(eng):
+    tgt = synth_structured_cloud(3000, seed=4)
+    src = moved_copy(tgt, rigid_transform(0.02, 0.01, 0.08, 0.5, 0.4, -0.1), noise=0.01)
+    p = eng.icp_default_params(); p.max_iterations = 3
+    Tg, fg, cg, ig = eng.icp_align(src, tgt, p)
+    To, fo, co, io = oi.icp_align(src, tgt, oi.default_params(max_iterations=3))
+    assert (cg, ig) == (co, io) == (True, 3) and np.abs(Tg - To).max() < TOL
+    Tg, fg, cg, ig = eng.icp_align(src[:2], tgt)
+    assert (cg, ig) == (False, 0)
+
+
+def test_icp_reference_sizes_100k(eng):
+    """BASELINE configs[2] shape: ~100k x ~100k points; GPU vs CPU restatement end to end."""
+    tgt = synth_structured_cloud(100000, seed=11, extent=60.0)
+    T = rigid_transform(0.004, -0.006, 0.02, 0.25, -0.15, 0.05)
+    src = moved_copy(tgt, T, keep_every=1, noise=0.01, seed=3)
+    p = eng.icp_default_params(); p.max_iterations = 30
+    Tg, fg, cg, ig = eng.icp_align(src, tgt, p)
+    To, fo, co, io = oi.icp_align(src, tgt, oi.default_params(max_iterations=30))
+    assert cg == co and ig == io and np.abs(Tg - To).max() < TOL
