@@ -10,7 +10,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-f
 SRCS    := $(CSRC)/engine.hip $(CSRC)/sc_distance.hip $(CSRC)/ringkey_topk.hip $(CSRC)/make_sc.hip $(CSRC)/icp.hip
 OBJS    := $(SRCS:.hip=.o)
 
-all: $(LIBDIR)/libscl_engine.so oracle
+all: $(LIBDIR)/libscl_engine.so oracle tests/cpp/adapter_check
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.hpp) include/scl_engine.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -22,8 +22,13 @@ $(LIBDIR)/libscl_engine.so: $(OBJS)
 oracle:
 	$(MAKE) -C oracle
 
+# C++ host-side adapter (include/scl/scan_context_hip_descriptor.hpp) type-checked and linked
+# against the C ABI; runs on the GPU box (tests/test_gpu_adapter.py)
+tests/cpp/adapter_check: tests/cpp/adapter_check.cpp tests/cpp/pcl_types_for_adapter_check.h include/scl/scan_context_hip_descriptor.hpp $(LIBDIR)/libscl_engine.so
+	g++ -std=c++14 -O2 -Wall -Iinclude -Itests/cpp -o $@ tests/cpp/adapter_check.cpp -L$(LIBDIR) -lscl_engine -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)'
+
 clean:
-	rm -f $(OBJS) $(LIBDIR)/libscl_engine.so
+	rm -f $(OBJS) $(LIBDIR)/libscl_engine.so tests/cpp/adapter_check
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

@@ -1,0 +1,122 @@
+// scan_context_hip_descriptor.hpp -- header-only adapter that plugs the MI355X engine into
+// the reference's descriptor plugin interface.
+//
+// Include it AFTER the reference's descriptor.h (it needs `class scan_descriptor`,
+// descriptor.h:21-36, and pcl::PointCloud<pcl::PointXYZI>).  It implements the same six
+// virtuals as scan_context_descriptor (descriptor.h:1304-1801) with the same constructor
+// arguments and return conventions, forwarding every call to the C ABI in scl_engine.h:
+//
+//   distributedMapping.h:404   scanDescriptor = std::unique_ptr<scan_descriptor>(new scan_context_descriptor());
+//   becomes                    scanDescriptor = std::unique_ptr<scan_descriptor>(new scan_context_hip_descriptor());
+//
+// The reference reports nothing but "-1 = no loop" (descriptor.h:1615,1678) and logs through
+// ROS; the adapter keeps that: engine errors are written to stderr and mapped to "no loop".
+#pragma once
+
+#include <cstdint>
+#include <cstdio>
+#include <utility>
+#include <vector>
+
+#include "scl_engine.h"
+
+class scan_context_hip_descriptor : public scan_descriptor
+{
+public:
+    // same parameter list and defaults as scan_context_descriptor's ctor, descriptor.h:1307-1316
+    scan_context_hip_descriptor(
+        int numRing            = 20,
+        int numSector          = 60,
+        int numCandidates      = 3,
+        double distThres       = 0.14,
+        double lidarHeight     = 1.65,
+        double maxRadius       = 80.0,
+        int numExcludeRecent   = 100,
+        int treeMakingPeriod   = 10,
+        double searchRatio     = 0.1,
+        int device             = 0)
+    {
+        scl_config cfg;
+        scl_default_config(&cfg);
+        cfg.num_ring = numRing;                 cfg.num_sector = numSector;
+        cfg.num_candidates = numCandidates;     cfg.dist_thres = distThres;
+        cfg.lidar_height = lidarHeight;         cfg.max_radius = maxRadius;
+        cfg.num_exclude_recent = numExcludeRecent;
+        cfg.tree_making_period = treeMakingPeriod;
+        cfg.search_ratio = searchRatio;         cfg.device = device;
+        cells_ = numRing * numSector;
+        const int rc = scl_create(&cfg, &engine_);
+        if (rc != SCL_OK) {
+            std::fprintf(stderr, "[scan_context_hip_descriptor] scl_create failed: %s\n", scl_status_string(rc));
+            engine_ = nullptr;
+        }
+    }
+
+    ~scan_context_hip_descriptor() { scl_destroy(engine_); }
+    scan_context_hip_descriptor(const scan_context_hip_descriptor &) = delete;
+    scan_context_hip_descriptor &operator=(const scan_context_hip_descriptor &) = delete;
+
+    // descriptor.h:25 / 1604-1611; pcl::PointXYZI is a 32-byte record with x,y,z first
+    std::vector<float> makeAndSaveDescriptorAndKey(const pcl::PointCloud<pcl::PointXYZI> &scan,
+                                                   const int8_t robot, const int index) override
+    {
+        std::vector<float> vT(static_cast<size_t>(cells_), 0.0f);
+        report(scl_make_and_save(engine_, scan.points.data(), static_cast<int>(scan.points.size()),
+                                 static_cast<int>(sizeof(pcl::PointXYZI)), robot, index, vT.data()),
+               "makeAndSaveDescriptorAndKey");
+        return vT;
+    }
+
+    // descriptor.h:27 / 1572-1585 (descriptorMat = global_descriptor.values.data(), DM.h:627)
+    void saveDescriptorAndKey(const float *descriptorMat, const int8_t robot, const int index) override
+    {
+        report(scl_save_from_wire(engine_, descriptorMat, robot, index), "saveDescriptorAndKey");
+    }
+
+    // descriptor.h:29 / 1613-1674: {loop index or -1, ring shift as float}
+    std::pair<int, float> detectIntraLoopClosureID(const int currentPtr) override
+    {
+        int loop_id = -1; float shift = 0.0f;
+        if (!report(scl_detect_intra(engine_, currentPtr, &loop_id, &shift, nullptr), "detectIntraLoopClosureID"))
+            return std::pair<int, float>(-1, 0.0f);
+        return std::pair<int, float>(loop_id, shift);
+    }
+
+    // descriptor.h:31 / 1676-1756: {loop index or -1, relative yaw in radians}
+    std::pair<int, float> detectInterLoopClosureID(const int currentPtr) override
+    {
+        int loop_id = -1; float yaw = 0.0f;
+        if (!report(scl_detect_inter(engine_, currentPtr, &loop_id, &yaw, nullptr), "detectInterLoopClosureID"))
+            return std::pair<int, float>(-1, 0.0f);
+        return std::pair<int, float>(loop_id, yaw);
+    }
+
+    // descriptor.h:33 / 1758-1761
+    std::pair<int8_t, int> getIndex(const int key) override
+    {
+        int8_t robot = 0; int index = -1;
+        report(scl_get_index(engine_, key, &robot, &index), "getIndex");
+        return std::pair<int8_t, int>(robot, index);
+    }
+
+    // descriptor.h:35 / 1763-1766
+    int getSize(const int idIn = -1) override
+    {
+        const int n = scl_get_size(engine_, idIn);
+        return n < 0 ? 0 : n;
+    }
+
+    scl_engine *engine() { return engine_; }   // for the geometric-verification calls (scl_icp_align ...)
+
+private:
+    bool report(int rc, const char *where) const
+    {
+        if (rc == SCL_OK) return true;
+        std::fprintf(stderr, "[scan_context_hip_descriptor] %s: %s (%s)\n", where, scl_status_string(rc),
+                     engine_ ? scl_last_error(engine_) : "no engine");
+        return false;
+    }
+
+    scl_engine *engine_ = nullptr;
+    int cells_ = 0;
+};

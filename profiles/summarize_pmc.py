@@ -1,0 +1,36 @@
+"""Condense rocprofv3 --pmc counter_collection CSVs into a small per-kernel summary.
+
+usage: python profiles/summarize_pmc.py <dir with pN/runc/*_counter_collection.csv ...> <out.json> [kernel substring]
+HBM traffic follows MI355X_MICROARCH.md §HBM: FETCH_SIZE (KB) counts 64 B per 128-B request of a wide
+coalesced stream on gfx950 -> doubled; WRITE_SIZE (KB) is exact for 16-B-per-lane stores.  Separate
+passes per counter group, no tracing domains combined with --pmc.
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def main():
+    root, out = sys.argv[1], sys.argv[2]
+    needle = sys.argv[3] if len(sys.argv) > 3 else "sc_distance"
+    agg = collections.defaultdict(list)
+    for f in glob.glob(f"{root}/**/*_counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            if needle in row["Kernel_Name"]:
+                agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
+    summary = {k: {"launches": len(v), "mean_per_launch": sum(v) / len(v)} for k, v in sorted(agg.items())}
+    res = {"kernel_filter": needle, "counters": summary}
+    if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
+        fetch = summary["FETCH_SIZE"]["mean_per_launch"] * 1024.0 * 2.0
+        write = summary["WRITE_SIZE"]["mean_per_launch"] * 1024.0
+        res["hbm_bytes_per_launch"] = fetch + write
+        res["hbm_read_bytes_corrected_x2"] = fetch
+        res["hbm_write_bytes"] = write
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,108 @@
+"""Keyframe database sharded by keyframe index across the GPUs of one node.
+
+One process per GPU (``torch.distributed``; backend "nccl" = RCCL over xGMI on the GPU box,
+"gloo" in the CPU tests).  Global keyframe ``g`` lives on rank ``g % G`` in local slot
+``g // G`` (round robin keeps the shards balanced while the database grows append-only).
+Every (query, keyframe) pair is independent, so scoring needs no data-path collective; the
+only exchange is the reduction of the per-rank winners:
+
+* reference-faithful mode (``detect_intra``, descriptor.h:1613-1674): every rank returns its
+  local ring-key top-k *with* their SC distance/shift, one all-gather of k records per rank,
+  then every rank merges to the global top-k (ascending ring distance, ties -> lowest global
+  index) and applies the reference's candidate loop including its float narrowing
+  (descriptor.h:1645-1659);
+* full-DB mode (``detect_full``): one all-gather of one (distance, index, shift) record per
+  rank, global arg-min with ties -> lowest global index.
+
+Messages are <= k * 32 bytes per rank: latency bound, xGMI bandwidth is irrelevant here.
+The search-range rule ``[0, cur - NUM_EXCLUDE_RECENT)`` (descriptor.h:1627) is applied on
+GLOBAL indices: rank r may use local slots ``l`` with ``l * G + r < cur - exclude``.
+"""
+import numpy as np
+
+BIG_DIST = 10000000.0
+
+
+def local_count(global_hi, rank, world):
+    """number of local slots l with l*world + rank < global_hi"""
+    if global_hi <= rank:
+        return 0
+    return (global_hi - rank + world - 1) // world
+
+
+class ShardedLoopDetector:
+    def __init__(self, engine, rank=0, world=1, group=None, device="cpu", num_candidates=3,
+                 num_exclude_recent=100, dist_thres=0.14):
+        self.engine, self.rank, self.world, self.group = engine, rank, world, group
+        self.device = device
+        self.k, self.exclude, self.thres = num_candidates, num_exclude_recent, dist_thres
+        self.n_global = 0
+        self.index_map = []                  # replicated (robot, index) map, descriptor.h:1758-1761
+
+    # ---- ingest: every rank sees every descriptor (the ROS topic is a broadcast), keeps its share
+    def save(self, values, robot=0, index=0):
+        g = self.n_global
+        if g % self.world == self.rank:
+            self.engine.save_from_wire(values, robot, index)
+        self.index_map.append((robot, index))
+        self.n_global += 1
+        return g
+
+    def get_index(self, g):
+        return self.index_map[g]
+
+    def get_size(self):
+        return self.n_global
+
+    # ---- collectives -----------------------------------------------------------------
+    def _all_gather(self, rec):
+        """rec: float64 array (m, c) -> (world*m, c), same on every rank"""
+        if self.world == 1:
+            return rec
+        import torch
+        import torch.distributed as dist
+        t = torch.from_numpy(np.ascontiguousarray(rec)).to(self.device)
+        out = torch.empty((self.world * t.shape[0], t.shape[1]), dtype=t.dtype, device=self.device)
+        dist.all_gather_into_tensor(out, t, group=self.group)      # concatenated along dim 0, rank order
+        return out.cpu().numpy()
+
+    # ---- detection ---------------------------------------------------------------------
+    def detect_intra(self, cur, values_cur):
+        """detectIntraLoopClosureID on the sharded database; `values_cur` = descriptor of keyframe
+        `cur` (every rank has it: it arrived on the broadcast).  Returns (loop_id, shift, dist)."""
+        k = self.k
+        if cur < self.exclude + k + 1:                                   # descriptor.h:1620-1623
+            return -1, 0.0, BIG_DIST
+        hi = local_count(cur - self.exclude, self.rank, self.world)
+        self.engine.stage_query(values_cur)
+        idx, d2, dist_, shift, found = self.engine.topk_with_distance(-1, 0, hi, k)
+        rec = np.full((k, 4), -1.0, dtype=np.float64)
+        for i in range(k):
+            if idx[i] >= 0:
+                rec[i] = (float(d2[i]), float(int(idx[i]) * self.world + self.rank), dist_[i], float(shift[i]))
+        allr = self._all_gather(rec)
+        allr = allr[allr[:, 1] >= 0]
+        order = np.lexsort((allr[:, 1], allr[:, 0]))[:k]                 # ascending ring distance, ties -> lowest index
+        min_dis = np.float32(BIG_DIST)                                   # descriptor.h:1637 (a float)
+        min_index, min_bias = -1, 0
+        for r in allr[order]:                                            # descriptor.h:1645-1659
+            if r[2] < float(min_dis):
+                min_dis = np.float32(r[2])
+                min_index, min_bias = int(r[1]), int(r[3])
+        if float(min_dis) < self.thres:                                  # descriptor.h:1662
+            return min_index, float(min_bias), float(min_dis)
+        return -1, 0.0, float(min_dis)
+
+    def detect_full(self, cur, values_cur):
+        """full-DB mode: (loop_id, nn_idx, shift, dist) over every eligible keyframe of every shard."""
+        hi = local_count(cur - self.exclude, self.rank, self.world)
+        self.engine.stage_query(values_cur)
+        nn, sh, d = self.engine.detect_full_range(-1, 0, hi)
+        rec = np.array([[d, float(nn * self.world + self.rank) if nn >= 0 else -1.0, float(sh)]], dtype=np.float64)
+        allr = self._all_gather(rec)
+        allr = allr[allr[:, 1] >= 0]
+        if len(allr) == 0:
+            return -1, -1, 0, BIG_DIST
+        best = allr[np.lexsort((allr[:, 1], allr[:, 0]))[0]]
+        d, g, sh = float(best[0]), int(best[1]), int(best[2])
+        return (g if d < self.thres else -1), g, sh, d

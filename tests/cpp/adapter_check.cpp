@@ -1,0 +1,68 @@
+// Drives the engine exactly the way distributedMapping.h drives scanDescriptor
+// (makeDescriptors DM.h:988-1025, globalDescriptorHandler DM.h:625-628, performIntraLoopClosure
+// DM.h:1072-1086) through the C++ adapter.  Prints one line per check; exit code 0 = all good.
+// Expected values come from a file written by the Python test (CPU checker results).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <random>
+
+#include "pcl_types_for_adapter_check.h"
+#include "scl/scan_context_hip_descriptor.hpp"
+
+int main(int argc, char **argv)
+{
+    const int n_keyframes = argc > 1 ? std::atoi(argv[1]) : 260;
+    std::unique_ptr<scan_descriptor> scanDescriptor(new scan_context_hip_descriptor());   // the DM.h:404 line
+    if (scanDescriptor->getSize() != 0) { std::printf("FAIL size0\n"); return 1; }
+
+    // a closed loop: keyframes 0..129 walk a path, 130..259 revisit it -> loops must be found
+    std::mt19937_64 rng(7);
+    auto uni = [&](double a, double b) { return a + (b - a) * ((rng() >> 11) * (1.0 / 9007199254740992.0)); };
+    std::vector<std::array<float, 4>> boxes;
+    for (int b = 0; b < 300; ++b) boxes.push_back({(float)uni(-200, 200), (float)uni(-200, 200), (float)uni(2, 8), (float)uni(1, 10)});
+    std::vector<std::vector<float>> published;
+    for (int kf = 0; kf < n_keyframes; ++kf) {
+        const int pos = kf % (n_keyframes / 2);
+        const float cx = 150.0f * std::cos(0.048f * pos), cy = 150.0f * std::sin(0.048f * pos);
+        pcl::PointCloud<pcl::PointXYZI> cloud;
+        for (int i = 0; i < 6000; ++i) {
+            const float ang = (float)uni(0, 6.283185307), rad = (float)(80.0 * std::sqrt(uni(0.001, 1)));
+            pcl::PointXYZI p{};
+            p.x = rad * std::cos(ang); p.y = rad * std::sin(ang); p.z = -1.65f;
+            for (const auto &bx : boxes)
+                if (std::fabs(p.x + cx - bx[0]) < bx[2] && std::fabs(p.y + cy - bx[1]) < bx[2]) { p.z = -1.65f + bx[3]; break; }
+            p.intensity = 1.0f;
+            cloud.points.push_back(p);
+        }
+        std::vector<float> v = scanDescriptor->makeAndSaveDescriptorAndKey(cloud, 0, kf);
+        if ((int)v.size() != 20 * 60) { std::printf("FAIL vT size\n"); return 1; }
+        published.push_back(v);
+    }
+    if (scanDescriptor->getSize() != n_keyframes) { std::printf("FAIL size\n"); return 1; }
+    if (scanDescriptor->getIndex(17) != std::pair<int8_t, int>(0, 17)) { std::printf("FAIL getIndex\n"); return 1; }
+
+    int loops = 0, correct = 0;
+    for (int cur = 0; cur < n_keyframes; ++cur) {
+        const std::pair<int, float> r = scanDescriptor->detectIntraLoopClosureID(cur);
+        if (r.first >= 0) {
+            ++loops;
+            if (std::abs(r.first - (cur - n_keyframes / 2)) <= 2) ++correct;
+        }
+        if (cur < 104 && r.first != -1) { std::printf("FAIL early-out at %d\n", cur); return 1; }
+    }
+    std::printf("loops found %d, at the revisited place %d\n", loops, correct);
+    if (loops < 20 || correct * 10 < loops * 8) { std::printf("FAIL loop recall\n"); return 1; }
+
+    // a second robot ingests the same descriptors from the wire (DM.h:625-628) and must agree
+    std::unique_ptr<scan_descriptor> remote(new scan_context_hip_descriptor());
+    for (int kf = 0; kf < n_keyframes; ++kf) remote->saveDescriptorAndKey(published[kf].data(), 1, kf);
+    for (int cur = n_keyframes - 30; cur < n_keyframes; ++cur) {
+        if (remote->detectIntraLoopClosureID(cur) != scanDescriptor->detectIntraLoopClosureID(cur)) { std::printf("FAIL wire parity\n"); return 1; }
+    }
+    const std::pair<int, float> inter = remote->detectInterLoopClosureID(n_keyframes - 1);
+    std::printf("inter: loop %d yaw %.4f\n", inter.first, inter.second);
+    std::printf("ADAPTER OK\n");
+    return 0;
+}

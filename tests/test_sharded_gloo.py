@@ -1,0 +1,116 @@
+"""Multi-rank path on CPU: world_size 2 over gloo.  The local scorer is the CPU checker wrapped
+in the engine's interface (tests may use oracle/); what is under test is the sharding arithmetic,
+the exchange and the merge -- they must reproduce the single-database result exactly."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_binding as ob
+from scl_slam_amd.sharded import ShardedLoopDetector, local_count
+from scl_slam_amd.synth import synth_descriptors
+
+R, S, K, N = 20, 60, 3, 420
+
+
+class OracleShardEngine:
+    """Engine-shaped wrapper over the CPU checker (one shard)."""
+
+    def __init__(self, cfg):
+        self.cfg, self.db, self.q = cfg, ob.OracleDB(cfg), None
+        self.R, self.S = cfg.num_ring, cfg.num_sector
+
+    def save_from_wire(self, values, robot=0, index=0):
+        self.db.save_wire(values, robot, index)
+
+    def stage_query(self, values):
+        self.q = np.ascontiguousarray(values, dtype=np.float32).reshape(self.R, self.S)
+        tmp = ob.OracleDB(self.cfg); tmp.save_wire(self.q)
+        self.qkey = tmp.ringkey(0)
+
+    def _dist(self, slot):
+        return ob.distance(self.cfg, self.q, self._desc(slot), fast=True)
+
+    def _desc(self, slot):
+        cm = np.ctypeslib.as_array(self.db.L.sco_db_desc(self.db.h, slot), shape=(self.S, self.R))
+        return cm.T.astype(np.float32)
+
+    def topk_with_distance(self, query, lo, hi, k):
+        assert query == -1
+        idx, d2, found = ob.knn(self.db.ringkeys(hi)[lo:], self.qkey, k) if hi > lo else (np.full(k, -1, np.int32), np.zeros(k, np.float32), 0)
+        dist_ = np.full(k, 1e7); shift = np.zeros(k, np.int32)
+        for i in range(k):
+            if idx[i] >= 0:
+                idx[i] += lo
+                dist_[i], shift[i] = self._dist(int(idx[i]))
+        return idx, d2, dist_, shift, found
+
+    def detect_full_range(self, query, lo, hi):
+        best, bi, bs = 1e7, -1, 0
+        for s in range(lo, hi):
+            d, sh = self._dist(s)
+            if d < best:
+                best, bi, bs = d, s, sh
+        return bi, bs, best
+
+
+def test_local_count():
+    for world in (1, 2, 3, 8):
+        for hi in range(0, 40):
+            for r in range(world):
+                assert local_count(hi, r, world) == len([g for g in range(hi) if g % world == r])
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, curs, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    descs = synth_descriptors(N, R, S, seed=1001, revisit_frac=0.06)
+    cfg = ob.make_config(R=R, S=S, k=K)
+    det = ShardedLoopDetector(OracleShardEngine(cfg), rank, world, num_candidates=K)
+    for i in range(N):
+        det.save(descs[i], 0, i)
+    res = []
+    for cur in curs:
+        res.append((cur, det.detect_intra(cur, descs[cur]), det.detect_full(cur, descs[cur])))
+    out_q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_equals_single_database(world):
+    descs, truth = synth_descriptors(N, R, S, seed=1001, revisit_frac=0.06, return_truth=True)
+    curs = sorted({c for c, _, _ in truth} | {N - 1, 103, 104, 150})
+    ref = ob.OracleDB(ob.make_config(R=R, S=S, k=K)); ref.save_bulk(descs)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, curs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        results = dict(q.get(timeout=120) for _ in range(world))
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.terminate()
+    assert all(p.exitcode == 0 for p in procs)
+    assert results[0] == results[1]                                  # every rank reaches the same verdict
+    hits = 0
+    for cur, intra, full in results[0]:
+        o = ref.detect_intra(cur)
+        assert (intra[0], intra[1]) == (o[0], o[1]) and intra[2] == o[2]
+        of = ref.detect_full(cur)
+        assert full == (of[0], of[1], of[2], of[3])
+        hits += intra[0] >= 0
+    assert hits >= 3
