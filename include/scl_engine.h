@@ -145,6 +145,8 @@ int  scl_sc_distance_batch(scl_engine *e, int query, const int *cand, int n,
 int  scl_detect_full(scl_engine *e, int cur, int *loop_id, int *nn_idx, int *shift, double *dist);
 int  scl_detect_full_range(scl_engine *e, int query, int lo, int hi,
                            int *nn_idx, int *shift, double *dist);
+/* The ring-key top-k (num_candidates entries) computed as part of the last scl_detect_full[_range]. */
+int  scl_get_last_topk(scl_engine *e, int k, int *idx, float *d2);
 /* Reference-faithful candidates for the sharded driver: local ring-key top-k in
  * [lo,hi) plus the SC distance/shift of each (one device pass, no host round trip). */
 int  scl_topk_with_distance(scl_engine *e, int query, int lo, int hi, int k,
@@ -180,7 +182,7 @@ int  scl_transform_cloud(scl_engine *e, const void *in, int n, int stride_bytes,
                          const float T[16], void *out);
 
 /* ---- measurement ----------------------------------------------------------- */
-int  scl_profile_enable(scl_engine *e, int on);
+int  scl_profile_enable(scl_engine *e, int on);   /* 0 off, 1 every kernel family, 2 SC distance only */
 int  scl_profile_reset(scl_engine *e);
 int  scl_profile_get(scl_engine *e, scl_profile *out);
 int  scl_device_name(const scl_engine *e, char *buf, int buflen);

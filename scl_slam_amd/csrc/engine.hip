@@ -33,6 +33,9 @@ struct scl_engine {
     int R = 0, S = 0, RG = 0, R4 = 0, SR = 0;
     int device = 0, num_cu = 256;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;                         // ring-key scan runs beside the SC distance
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    double *h_out3 = nullptr;                              // pinned, device-visible: the arg-min kernel writes it directly
     mutable std::mutex mu;
     mutable std::string last_error;
 
@@ -52,7 +55,7 @@ struct scl_engine {
     float *d_vals = nullptr; size_t vals_cap = 0;          // wire-format staging (floats)
     unsigned char *d_points = nullptr; size_t points_cap = 0;
     int *d_tile = nullptr;
-    double *d_dist = nullptr; int *d_shift = nullptr; int *d_cand = nullptr; size_t pair_cap = 0;
+    double *d_dist = nullptr; int *d_shift = nullptr; int *d_cand = nullptr; float *d_ring_d2 = nullptr; size_t pair_cap = 0;
     unsigned long long *d_topk_scratch = nullptr; int *d_topk_idx = nullptr; float *d_topk_d2 = nullptr;
     double *d_out3 = nullptr;
     void *h_pinned = nullptr; size_t pinned_cap = 0;       // small result read-back
@@ -61,7 +64,7 @@ struct scl_engine {
     int tree_counter = 0, tree_n = 0;
 
     // profiling
-    bool prof_on = false;
+    int prof_on = 0;                                       // 0 off, 1 every kernel family, 2 SC distance only
     scl_profile prof{};
     std::vector<PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;
@@ -87,10 +90,10 @@ int fail(const scl_engine *e, int code, const char *msg)
 }
 
 struct ProfScope {
-    scl_engine *e; int kind; hipEvent_t start = nullptr, stop = nullptr;
-    ProfScope(scl_engine *e_, int kind_) : e(e_), kind(kind_)
+    scl_engine *e; int kind; hipStream_t s; hipEvent_t start = nullptr, stop = nullptr;
+    ProfScope(scl_engine *e_, int kind_, hipStream_t s_ = nullptr) : e(e_), kind(kind_), s(s_ ? s_ : e_->stream)
     {
-        if (!e->prof_on) return;
+        if (!e->prof_on || (e->prof_on == 2 && kind != P_SC)) return;
         auto get = [&]() {
             hipEvent_t ev = nullptr;
             if (!e->event_pool.empty()) { ev = e->event_pool.back(); e->event_pool.pop_back(); }
@@ -98,12 +101,12 @@ struct ProfScope {
             return ev;
         };
         start = get(); stop = get();
-        if (start && stop) (void)hipEventRecord(start, e->stream);
+        if (start && stop) (void)hipEventRecord(start, s);
     }
     ~ProfScope()
     {
         if (!e->prof_on || !start || !stop) return;
-        (void)hipEventRecord(stop, e->stream);
+        (void)hipEventRecord(stop, s);
         e->pending.push_back({start, stop, kind});
     }
 };
@@ -226,9 +229,10 @@ int ensure_points(scl_engine *e, size_t bytes)
 int ensure_pairs(scl_engine *e, size_t n)
 {
     if (n <= e->pair_cap) return SCL_OK;
-    dev_free(e->d_dist); dev_free(e->d_shift); dev_free(e->d_cand);
+    dev_free(e->d_dist); dev_free(e->d_shift); dev_free(e->d_cand); dev_free(e->d_ring_d2);
     size_t nn = n + n / 2 + 64;
     int rc;
+    if ((rc = dev_alloc(e, &e->d_ring_d2, nn))) return rc;
     if ((rc = dev_alloc(e, &e->d_dist, nn))) return rc;
     if ((rc = dev_alloc(e, &e->d_shift, nn))) return rc;
     if ((rc = dev_alloc(e, &e->d_cand, nn))) return rc;
@@ -290,11 +294,12 @@ int launch_distance(scl_engine *e, const QueryView &q, const int *d_cand, int sl
     return SCL_OK;
 }
 
-int launch_topk(scl_engine *e, const QueryView &q, int lo, int hi, int k, float eps)
+int launch_topk(scl_engine *e, const QueryView &q, int lo, int hi, int k, float eps, hipStream_t on = nullptr)
 {
-    ProfScope ps(e, P_TOPK);
+    hipStream_t s = on ? on : e->stream;
+    ProfScope ps(e, P_TOPK, s);
     SCL_HIP(e, launch_ringkey_topk(db_view(e), q.rkey, lo, hi, k, eps, e->d_topk_scratch,
-                                   e->d_topk_idx, e->d_topk_d2, e->stream));
+                                   e->d_topk_idx, e->d_topk_d2, s));
     return SCL_OK;
 }
 
@@ -401,6 +406,14 @@ int scl_create(const scl_config *cfg, scl_engine **out)
     if (hipGetDeviceProperties(&prop, e->device) == hipSuccess && prop.multiProcessorCount > 0)
         e->num_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(SCL_ERR_HIP);
+    {   // the ring-key scan is small: give its queue priority so it slips in beside the SC-distance kernel
+        int lo_p = 0, hi_p = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
+        if (hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, hi_p) != hipSuccess) return bail(SCL_ERR_HIP);
+    }
+    if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) return bail(SCL_ERR_HIP);
+    if (hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) return bail(SCL_ERR_HIP);
+    if (hipHostMalloc((void **)&e->h_out3, 64, hipHostMallocDefault) != hipSuccess) return bail(SCL_ERR_HIP);
     if ((rc = ensure_capacity(e, 1))) return bail(rc);
     const size_t tile = (size_t)e->RG * e->S;
     if ((rc = dev_alloc(e, &e->q_desc, tile))) return bail(rc);
@@ -431,9 +444,13 @@ int scl_destroy(scl_engine *e)
     dev_free(e->d_desc); dev_free(e->d_vkey); dev_free(e->d_norm); dev_free(e->d_rkey); dev_free(e->d_rkey4);
     dev_free(e->q_desc); dev_free(e->q_vkey); dev_free(e->q_norm); dev_free(e->q_rkey); dev_free(e->q_rkey4);
     dev_free(e->d_vals); dev_free(e->d_points); dev_free(e->d_tile);
-    dev_free(e->d_dist); dev_free(e->d_shift); dev_free(e->d_cand);
+    dev_free(e->d_dist); dev_free(e->d_shift); dev_free(e->d_cand); dev_free(e->d_ring_d2);
     dev_free(e->d_topk_scratch); dev_free(e->d_topk_idx); dev_free(e->d_topk_d2); dev_free(e->d_out3);
     if (e->h_pinned) (void)hipHostFree(e->h_pinned);
+    if (e->h_out3) (void)hipHostFree(e->h_out3);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->stream2) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamDestroy(e->stream2); }
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return SCL_OK;
@@ -713,20 +730,51 @@ int scl_detect_full_range(scl_engine *e, int query, int lo, int hi, int *nn_idx,
     const int n = hi - lo;
     if (n <= 0) return SCL_OK;
     if ((rc = ensure_pairs(e, (size_t)n))) return rc;
-    // "full ring-key + shifted SC distance per incoming scan": the ring-key scan runs too
-    if ((rc = launch_topk(e, q, lo, hi, e->cfg.num_candidates, e->cfg.knn_exclude_eps))) return rc;
-    if ((rc = launch_distance(e, q, nullptr, lo, n))) return rc;
+    // "full ring-key + shifted SC distance per incoming scan".  On the two-sectors-per-lane grids the
+    // ring-key metric is evaluated inside the SC-distance kernel (the wave that scores a slot also reads
+    // its ring key) and one epilogue launch does arg-min + top-k; otherwise the stand-alone ring-key
+    // scan runs on a second stream beside the SC kernel.
+    const int k = e->cfg.num_candidates;
+    const bool fuse = k <= 8 && sc_distance_fuses_ring(db_view(e), e->SR);
+    if (!fuse) SCL_HIP(e, hipEventRecord(e->ev_fork, e->stream));
+    bool fused = false;
     {
-        ProfScope ps(e, P_ARGMIN);
-        SCL_HIP(e, launch_argmin(e->d_dist, e->d_shift, n, e->d_out3, e->stream));
+        ProfScope ps(e, P_SC);
+        SCL_HIP(e, launch_sc_distance(db_view(e), q, nullptr, lo, n, e->SR, e->d_dist, e->d_shift, e->num_cu, e->stream,
+                                      fuse ? e->d_ring_d2 : nullptr, &fused));
+        if (e->prof_on) e->prof.sc_distance_pairs += (uint64_t)n;
     }
-    SCL_HIP(e, hipMemcpyAsync(e->h_pinned, e->d_out3, sizeof(double) * 3, hipMemcpyDeviceToHost, e->stream));
+    if (fuse && fused) {
+        ProfScope ps(e, P_ARGMIN);
+        SCL_HIP(e, launch_full_epilogue(e->d_dist, e->d_shift, e->d_ring_d2, n, lo, k, e->cfg.knn_exclude_eps,
+                                        e->h_out3, e->d_topk_idx, e->d_topk_d2, e->stream));
+    } else {
+        if (fuse) return fail(e, SCL_ERR_HIP, "ring-key fusion expected but not provided by the kernel");
+        SCL_HIP(e, hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
+        if ((rc = launch_topk(e, q, lo, hi, k, e->cfg.knn_exclude_eps, e->stream2))) return rc;
+        SCL_HIP(e, hipEventRecord(e->ev_join, e->stream2));
+        {
+            ProfScope ps(e, P_ARGMIN);
+            SCL_HIP(e, launch_argmin(e->d_dist, e->d_shift, n, e->h_out3, e->stream));   // writes pinned host memory
+        }
+        SCL_HIP(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));
+    }
     if ((rc = sync(e))) return rc;
-    const double *o = static_cast<const double *>(e->h_pinned);
+    const volatile double *o = e->h_out3;
     *dist = o[0];
     *nn_idx = o[1] < 0 ? -1 : lo + (int)o[1];
     *shift = (int)o[2];
     return SCL_OK;
+}
+
+int scl_get_last_topk(scl_engine *e, int k, int *idx, float *d2)
+{
+    if (!e || !idx || !d2 || k < 1 || k > kTopkMaxK) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    SCL_HIP(e, hipMemcpyAsync(idx, e->d_topk_idx, sizeof(int) * k, hipMemcpyDeviceToHost, e->stream));
+    SCL_HIP(e, hipMemcpyAsync(d2, e->d_topk_d2, sizeof(float) * k, hipMemcpyDeviceToHost, e->stream));
+    return sync(e);
 }
 
 int scl_detect_full(scl_engine *e, int cur, int *loop_id, int *nn_idx, int *shift, double *dist)
@@ -811,7 +859,7 @@ int scl_profile_enable(scl_engine *e, int on)
 {
     if (!e) return SCL_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(e->mu);
-    e->prof_on = on != 0;
+    e->prof_on = on < 0 ? 0 : (on > 2 ? 1 : on);
     return SCL_OK;
 }
 

@@ -36,13 +36,20 @@ struct QueryView {          // one descriptor in the same layout (a DB slot or t
 // K1: distanceBtnScanContext for n candidates.
 //   slot(i) = cand ? cand[i] : slot_base + i ; slot < 0 -> (1e7, 0) without compute.
 // Returns false when (R,S,SR) has no specialised kernel and the generic one must be used.
+// out_ring_d2 (optional): also write the squared ring-key distance (nanoflann metric) of every scored
+// slot; *ring_fused tells whether the selected kernel supports it (the two-sectors-per-lane grids do).
 hipError_t launch_sc_distance(const DbView &db, const QueryView &q, const int *cand, int slot_base,
                               int n, int SR, double *out_dist, int *out_shift, int num_cu,
-                              hipStream_t stream);
+                              hipStream_t stream, float *out_ring_d2 = nullptr, bool *ring_fused = nullptr);
 
 // arg-min over (dist[i], i) for i in [0,n): strict <, first wins, NaN never wins,
 // nothing below 1e7 -> idx -1.  out: {dist, (double)idx, (double)shift} packed as 3 doubles.
+bool sc_distance_fuses_ring(const DbView &db, int SR);
 hipError_t launch_argmin(const double *dist, const int *shift, int n, double *out3, hipStream_t stream);
+// arg-min + ring-key top-k (from fused distances) in one launch; idx are slot_base-relative inputs
+hipError_t launch_full_epilogue(const double *dist, const int *shift, const float *ring_d2, int n, int slot_base,
+                                int k, float exclude_eps, double *out3, int *topk_idx, float *topk_d2,
+                                hipStream_t stream);
 
 // K2: exact ring-key top-k over slots [lo,hi).  out_idx[k], out_d2[k] (device).
 // scratch must hold kTopkMaxBlocks * kTopkMaxK uint64.

@@ -49,6 +49,8 @@ struct ScArgs {
     int G;    // candidates per workgroup iteration
     double *out_dist;
     int *out_shift;
+    // optional fused ring-key scan (full-DB mode): squared ring-key distance of every scored slot
+    const float4 *rkey4; int rk_cap; const float *q_rkey; float *out_d2;
     unsigned long long *stamps;   // diagnostic only (SCL_STAMP=1): per-wave phase cycle sums
     int ablate;   // diagnostic only (SCL_ABLATE): bit0 skip alignment loop, bit1 skip ring dots, bit2 skip sector sums
 };
@@ -248,12 +250,25 @@ __device__ __forceinline__ void pin_ring(double (&a)[14], double (&b)[14])
                  :: "memory");
 }
 
-template <int RG, int NSH, int CH, bool STAMP>
-__global__ __launch_bounds__(512) void sc_distance_wave_kernel(ScArgs a)
+// value of `v` held by lane `src_lane` (compile-time), delivered through scalar registers
+__device__ __forceinline__ double lane_bcast(double v, int src_lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ void pin3(double &a, double &b, double &c)
+{
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c) :: "memory");
+}
+
+template <int RG, int NSH, int CH, int S, int MAXT, bool STAMP>
+__global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
 {
     unsigned long long st_t = 0, st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_real0 = 0, st_cyc0 = 0;
     auto stamp = [&]() -> unsigned long long {
-        if (!STAMP) return 0ull;
+        if (!STAMP) { __builtin_amdgcn_sched_barrier(0); return 0ull; }   // phase boundaries stay scheduling fences
         unsigned long long t;
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
@@ -268,10 +283,11 @@ __global__ __launch_bounds__(512) void sc_distance_wave_kernel(ScArgs a)
     constexpr int W = NSH - 1;                 // shifts the reference evaluates (2*SR+1)
     constexpr int NQ = NSH / 2 + 1;            // ds_read_b128 per ring
     static_assert(RG % CH == 0, "chunk must divide the ring groups");
-    const int S = a.S, SR = a.SR;
-    const int L = S >> 1;                      // active lanes
-    const int QS = S + NSH + 2;                // extended query row (even)
-    const int SB = S + 2;                      // similarity row stride: even (b128 rows), rows on distinct banks
+    static_assert(S % 2 == 0 && S / 2 <= kWave && S >= NSH + 2, "two sectors per lane, one wave per candidate");
+    const int SR = a.SR;
+    constexpr int L = S >> 1;                  // active lanes
+    constexpr int QS = S + NSH + 2;            // extended query row (even)
+    constexpr int SB = S + 2;                      // similarity row stride: even (b128 rows), rows on distinct banks
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     const int nwaves = blockDim.x >> 6;
@@ -279,9 +295,12 @@ __global__ __launch_bounds__(512) void sc_distance_wave_kernel(ScArgs a)
     double *Qd = smem;                         // [R4][QS]
     double *nqe = Qd + R4 * QS;                // [QS] query column norms, extended
     double *vq = nqe + QS;                     // [S]  query sector key (also the over-read pad of the ring pipeline)
-    const int wsz = 2 * S + HSH * SB;
+    // per-wave scratch: the doubled sector key (alignment of candidate i+1) and the similarity rows
+    // (phases C/D of candidate i) are never live together -> they share the space
+    constexpr int wsz = (2 * S > HSH * SB) ? 2 * S : HSH * SB;
     double *vk2 = vq + S + wave * wsz;         // [2S] candidate sector key, doubled
-    double *simbuf = vk2 + 2 * S;              // [HSH][SB]
+    double *simbuf = vk2;                      // [HSH][SB]
+    int *next_ticket = reinterpret_cast<int *>(vq + S + nwaves * wsz);   // workgroup-wide candidate dispenser
 
     for (int idx = threadIdx.x; idx < RG * S; idx += blockDim.x) {
         const int rg = idx / S, c = idx - rg * S;
@@ -299,6 +318,13 @@ __global__ __launch_bounds__(512) void sc_distance_wave_kernel(ScArgs a)
         if (c < NSH + 2) nqe[c + S] = nv;
         vq[c] = a.q_vkey[c];
     }
+    // Candidates of this workgroup: a contiguous range, handed out wave by wave through an LDS
+    // counter.  The two waves that share a SIMD are not served equally (the older one wins the
+    // VALU arbitration), so a static split leaves waves 4-7 ~25 % behind; first come, first served
+    // evens it out.
+    const int c_lo = (int)(((long long)blockIdx.x * a.n) / gridDim.x);
+    const int c_hi = (int)(((long long)(blockIdx.x + 1) * a.n) / gridDim.x);
+    if (threadIdx.x == 0) *next_ticket = c_lo + nwaves;
     __syncthreads();                           // the only workgroup barrier
 
     const bool active = lane < L;
@@ -310,11 +336,17 @@ __global__ __launch_bounds__(512) void sc_distance_wave_kernel(ScArgs a)
     // candidate columns (2l - s_start) mod S and +1.  The window address is the same for every
     // candidate and never wraps, so the b128 window reads are bank-conflict free.
     const double2 *qwin = reinterpret_cast<const double2 *>(Qd + j0);
-    const int qstep = QS / 2;
+    // the query's sector key lives in registers, two sectors per lane; phase A broadcasts it with
+    // v_readlane (scalar operands of the fp64 subtractions) instead of re-reading it from LDS
+    const double2 vq_own = *reinterpret_cast<const double2 *>(a.q_vkey + j0);
+    // fused ring-key scan: lane g < RG owns ring group g of the query key
+    const bool rk_on = a.out_d2 != nullptr;
+    float4 qrk = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rk_on && lane < RG) qrk = *reinterpret_cast<const float4 *>(a.q_rkey + 4 * lane);
+    constexpr int qstep = QS / 2;
 
-    const int cstride = gridDim.x * nwaves;
-    int ci = blockIdx.x * nwaves + wave;
-    if (ci >= a.n) return;
+    int ci = c_lo + wave;
+    if (ci >= c_hi) return;
 
     // ---- per-candidate state of the software pipeline --------------------------------
     int slot = a.cand ? a.cand[ci] : a.slot_base + ci;
@@ -338,45 +370,40 @@ __global__ __launch_bounds__(512) void sc_distance_wave_kernel(ScArgs a)
             // 8 sectors is in flight while the previous one is being consumed.
             const double *p = vk2 + S - j0;
             const double2 *pp = reinterpret_cast<const double2 *>(p);
-            const double2 *qq = reinterpret_cast<const double2 *>(vq);      // wave-uniform address: broadcast
             double prev = p[-1];
             double ss0 = 0.0, ss1 = 0.0;
-            const int npair = S >> 1;
-            const int nb = (a.ablate & 1) ? 0 : npair >> 2;                     // batches of 4 pairs = 8 sectors
-            double2 pn[4], qn4[4];
-            if (nb > 0) {
+            constexpr int npair = S >> 1;
+            // Batches of BT sector pairs: the LDS reads of batch b+1 are issued before the arithmetic
+            // of batch b (pin3 fixes that order for LLVM), so the two dependent add chains never wait
+            // on LDS; the query key comes from registers by lane broadcast.
+            constexpr int BT = (MAXT > 512) ? 5 : 10;
+            static_assert(npair % BT == 0, "alignment batches must tile the sector pairs");
+            if (!(a.ablate & 1)) {
+                double2 pb[2][BT];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) { pn[v] = pp[v]; qn4[v] = qq[v]; }
-            }
-#pragma unroll 1
-            for (int bt = 0; bt < nb; ++bt) {
-                double2 pc[4], qc[4];
+                for (int v = 0; v < BT; ++v) pb[0][v] = pp[v];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) { pc[v] = pn[v]; qc[v] = qn4[v]; }
-                if (bt + 1 < nb) {
+                for (int bt = 0; bt < npair / BT; ++bt) {
+                    if (bt + 1 < npair / BT) {
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) { pn[v] = pp[(bt + 1) * 4 + v]; qn4[v] = qq[(bt + 1) * 4 + v]; }
+                        for (int v = 0; v < BT; ++v) pb[(bt + 1) & 1][v] = pp[(bt + 1) * BT + v];
+                    }
+                    pin3(ss0, ss1, prev);
+#pragma unroll
+                    for (int v = 0; v < BT; ++v) {
+                        const int i = bt * BT + v;
+                        const double2 pv = pb[bt & 1][v];
+                        const double qx = lane_bcast(vq_own.x, i), qy = lane_bcast(vq_own.y, i);
+                        const double d0 = qx - pv.x, d1 = qx - prev;
+                        ss0 = ss0 + d0 * d0;
+                        ss1 = ss1 + d1 * d1;
+                        const double e0 = qy - pv.y, e1 = qy - pv.x;
+                        ss0 = ss0 + e0 * e0;
+                        ss1 = ss1 + e1 * e1;
+                        prev = pv.y;
+                    }
+                    pin3(ss0, ss1, prev);
                 }
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const double d0 = qc[v].x - pc[v].x, d1 = qc[v].x - prev;
-                    ss0 = ss0 + d0 * d0;
-                    ss1 = ss1 + d1 * d1;
-                    const double e0 = qc[v].y - pc[v].y, e1 = qc[v].y - pc[v].x;
-                    ss0 = ss0 + e0 * e0;
-                    ss1 = ss1 + e1 * e1;
-                    prev = pc[v].y;
-                }
-            }
-            for (int i = nb * 4; i < ((a.ablate & 1) ? 1 : npair); ++i) {      // tail (S/2 not a multiple of 4)
-                const double2 pv = pp[i], qv = qq[i];
-                const double d0 = qv.x - pv.x, d1 = qv.x - prev;
-                ss0 = ss0 + d0 * d0;
-                ss1 = ss1 + d1 * d1;
-                const double e0 = qv.y - pv.y, e1 = qv.y - pv.x;
-                ss0 = ss0 + e0 * e0;
-                ss1 = ss1 + e1 * e1;
-                prev = pv.y;
             }
             const double n0 = sqrt(ss0), n1 = sqrt(ss1);
             if (active && n0 < kBigDist) { best = n0; bshift = j0; }
@@ -403,9 +430,11 @@ __global__ __launch_bounds__(512) void sc_distance_wave_kernel(ScArgs a)
     }
 
     while (true) {
-        const int ci_next = ci + cstride;
+        int ticket = 0;
+        if (lane == 0) ticket = atomicAdd(next_ticket, 1);
+        const int ci_next = __builtin_amdgcn_readfirstlane(ticket);
         int slot_next = -1;
-        if (ci_next < a.n) slot_next = a.cand ? a.cand[ci_next] : a.slot_base + ci_next;
+        if (ci_next < c_hi) slot_next = a.cand ? a.cand[ci_next] : a.slot_base + ci_next;
         double2 vk_next = make_double2(0.0, 0.0);
         if (slot_next >= 0) vk_next = *reinterpret_cast<const double2 *>(a.vkey + (size_t)slot_next * S + j0);
 
@@ -463,6 +492,20 @@ __global__ __launch_bounds__(512) void sc_distance_wave_kernel(ScArgs a)
         { const unsigned long long t1 = stamp(); st_a += t1 - st_t; st_t = t1; }
 
         // ---- phases C/D in two passes of HSH shifts ------------------------------
+        if (slot >= 0 && rk_on) {
+            // nanoflann's metric (nanoflann.hpp:383-408): four dimensions per step, fp32, left to right,
+            // groups accumulated in order -> lane g forms its group, lane-broadcasts feed the serial sum
+            float grp = 0.0f;
+            if (lane < RG) {
+                const float4 b = a.rkey4[(size_t)lane * a.rk_cap + slot];
+                const float d0 = qrk.x - b.x, d1 = qrk.y - b.y, d2 = qrk.z - b.z, d3 = qrk.w - b.w;
+                grp = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            }
+            float result = 0.0f;
+#pragma unroll
+            for (int g = 0; g < RG; ++g) result += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(grp), g));
+            if (lane == 0) a.out_d2[ci] = result;
+        }
         if (slot >= 0) {
             double dmin = kInf;
             int smin = 0x7fffffff;
@@ -496,26 +539,8 @@ __global__ __launch_bounds__(512) void sc_distance_wave_kernel(ScArgs a)
                     const int t = h * HSH + lane;
                     const double2 *row = reinterpret_cast<const double2 *>(simbuf + lane * SB);
                     double sum = 0.0;
-                    const int npair = S >> 1;
-                    const int nb = npair >> 2;
-                    double2 rn[4];
-                    if (nb > 0) {
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) rn[v] = row[v];
-                    }
-#pragma unroll 1
-                    for (int bt = 0; bt < nb; ++bt) {                      // 8 sectors per batch, next batch in flight
-                        double2 rc[4];
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) rc[v] = rn[v];
-                        if (bt + 1 < nb) {
-#pragma unroll
-                            for (int v = 0; v < 4; ++v) rn[v] = row[(bt + 1) * 4 + v];
-                        }
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) { sum = sum + rc[v].x; sum = sum + rc[v].y; }
-                    }
-                    for (int i = nb * 4; i < npair; ++i) { const double2 rv = row[i]; sum = sum + rv.x; sum = sum + rv.y; }
+                    for (int i = 0; i < S / 2; ++i) { const double2 rv = row[i]; sum = sum + rv.x; sum = sum + rv.y; }
                     const double d = 1.0 - sum / (double)eff;              // 0/0 -> NaN, never wins
                     const bool in_space = (t >= t_lo_cur) && (t < t_lo_cur + W);
                     const int st = wrap(s_start_cur + t, S);
@@ -534,7 +559,7 @@ __global__ __launch_bounds__(512) void sc_distance_wave_kernel(ScArgs a)
             a.out_shift[ci] = 0;
         }
 
-        if (ci_next >= a.n) break;
+        if (ci_next >= c_hi) break;
         ci = ci_next;
         slot = slot_next;
     }
@@ -548,25 +573,24 @@ __global__ __launch_bounds__(512) void sc_distance_wave_kernel(ScArgs a)
     }
 }
 
-template <int RG, int NSH, int CH, bool STAMP = false>
+template <int RG, int NSH, int CH, int S, int MAXT = 512, bool STAMP = false>
 hipError_t launch_wave(const ScArgs &args_in, int num_cu, hipStream_t stream)
 {
     ScArgs a = args_in;
-    const int S = a.S;
-    const int QS = S + NSH + 2;
+    constexpr int QS = S + NSH + 2;
     const size_t fixed = (size_t)(RG * 4 * QS + QS + S) * sizeof(double);
-    const size_t per_wave = (size_t)(2 * S + (NSH / 2) * (S + 2)) * sizeof(double);
+    const size_t per_wave = (size_t)((2 * S > (NSH / 2) * (S + 2)) ? 2 * S : (NSH / 2) * (S + 2)) * sizeof(double);
     const size_t lds_cap = 160 * 1024;
-    int waves = (int)((lds_cap - fixed) / per_wave);
-    if (waves > 8) waves = 8;
+    int waves = (int)((lds_cap - fixed - 16) / per_wave);
+    if (waves > MAXT / kWave) waves = MAXT / kWave;
     if (waves < 1) return hipErrorInvalidValue;
-    while (waves > 1 && a.n < num_cu * waves) waves >>= 1;
+    while (waves > 1 && a.n < num_cu * waves) waves = (waves + 1) / 2;
     int blocks = (a.n + waves - 1) / waves;
     if (blocks > num_cu) blocks = num_cu;
-    const size_t lds = fixed + per_wave * waves;
+    const size_t lds = fixed + per_wave * waves + 16;      // + the candidate dispenser
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)sc_distance_wave_kernel<RG, NSH, CH, STAMP>,
+        hipError_t e = hipFuncSetAttribute((const void *)sc_distance_wave_kernel<RG, NSH, CH, S, MAXT, STAMP>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -578,7 +602,7 @@ hipError_t launch_wave(const ScArgs &args_in, int num_cu, hipStream_t stream)
         if (hipMalloc(&d, nw * 8 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(d, 0, nw * 8 * sizeof(unsigned long long), stream);
         a.stamps = d;
-        hipLaunchKernelGGL((sc_distance_wave_kernel<RG, NSH, CH, STAMP>), dim3(blocks), dim3(waves * kWave), lds, stream, a);
+        hipLaunchKernelGGL((sc_distance_wave_kernel<RG, NSH, CH, S, MAXT, STAMP>), dim3(blocks), dim3(waves * kWave), lds, stream, a);
         (void)hipStreamSynchronize(stream);
         std::vector<unsigned long long> h(nw * 8);
         (void)hipMemcpy(h.data(), d, nw * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
@@ -592,6 +616,33 @@ hipError_t launch_wave(const ScArgs &args_in, int num_cu, hipStream_t stream)
                 std::sort(v.begin(), v.end());
                 return (double)v[v.size() / 2];
             };
+            auto pct = [&](int k, double q) {
+                std::vector<unsigned long long> v;
+                for (size_t w = 0; w < nw; ++w) if (h[w * 8] != 0) v.push_back(h[w * 8 + k]);
+                if (v.empty()) return 0.0;
+                std::sort(v.begin(), v.end());
+                return (double)v[(size_t)(q * (v.size() - 1))];
+            };
+            fprintf(stderr, "[scl stamp] wave lifetime us: min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f\n",
+                    pct(1, 0.0) / 100.0, pct(1, 0.1) / 100.0, pct(1, 0.5) / 100.0, pct(1, 0.9) / 100.0, pct(1, 1.0) / 100.0);
+            {   // where do the slow waves sit?  mean lifetime by blockIdx %% 8 (XCD group) and by wave slot
+                double sx[8] = {0}, sw[16] = {0}; int nx[8] = {0}, nwv[16] = {0};
+                for (size_t w = 0; w < nw; ++w) if (h[w * 8] != 0) {
+                    const int blk = (int)(w / waves), wv = (int)(w % waves);
+                    sx[blk & 7] += h[w * 8 + 1] / 100.0; nx[blk & 7]++;
+                    sw[wv & 15] += h[w * 8 + 1] / 100.0; nwv[wv & 15]++;
+                }
+                fprintf(stderr, "[scl stamp] mean us by block%%8:");
+                for (int k = 0; k < 8; ++k) fprintf(stderr, " %.1f", nx[k] ? sx[k] / nx[k] : 0.0);
+                fprintf(stderr, " | by wave slot:");
+                for (int k = 0; k < waves && k < 16; ++k) fprintf(stderr, " %.1f", nwv[k] ? sw[k] / nwv[k] : 0.0);
+                fprintf(stderr, "\n[scl stamp] slowest blocks:");
+                std::vector<std::pair<double, int>> bl;
+                for (int b = 0; b < blocks; ++b) { double m = 0; for (int k = 0; k < waves; ++k) m = std::max(m, h[((size_t)b * waves + k) * 8 + 1] / 100.0); bl.push_back({m, b}); }
+                std::sort(bl.rbegin(), bl.rend());
+                for (int k = 0; k < 24 && k < (int)bl.size(); ++k) fprintf(stderr, " %d:%.0f", bl[k].second, bl[k].first);
+                fprintf(stderr, "\n");
+            }
             const double cyc = med(0), real = med(1);
             fprintf(stderr, "[scl stamp] waves=%zu n=%d  wave lifetime: %.0f cycles, %.2f us  => clock %.2f GHz | "
                             "per wave: align %.0f  dots %.0f  sims %.0f  sums %.0f  other %.0f cycles\n",
@@ -600,7 +651,7 @@ hipError_t launch_wave(const ScArgs &args_in, int num_cu, hipStream_t stream)
         }
         return hipGetLastError();
     }
-    hipLaunchKernelGGL((sc_distance_wave_kernel<RG, NSH, CH, STAMP>), dim3(blocks), dim3(waves * kWave), lds, stream, a);
+    hipLaunchKernelGGL((sc_distance_wave_kernel<RG, NSH, CH, S, MAXT, STAMP>), dim3(blocks), dim3(waves * kWave), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -739,8 +790,9 @@ hipError_t launch_fast(const ScArgs &args_in, int num_cu, hipStream_t stream)
 
 hipError_t launch_sc_distance(const DbView &db, const QueryView &q, const int *cand, int slot_base,
                               int n, int SR, double *out_dist, int *out_shift, int num_cu,
-                              hipStream_t stream)
+                              hipStream_t stream, float *out_ring_d2, bool *ring_fused)
 {
+    if (ring_fused) *ring_fused = false;
     if (n <= 0) return hipSuccess;
     ScArgs a;
     a.desc = db.desc; a.vkey = db.vkey; a.norm = db.norm;
@@ -750,14 +802,20 @@ hipError_t launch_sc_distance(const DbView &db, const QueryView &q, const int *c
     static const int ablate = [] { const char *e = getenv("SCL_ABLATE"); return e ? atoi(e) : 0; }();
     a.ablate = ablate;
     a.stamps = nullptr;
+    a.rkey4 = db.rkey4; a.rk_cap = db.cap; a.q_rkey = q.rkey; a.out_d2 = nullptr;
     a.out_dist = out_dist; a.out_shift = out_shift;
     const int W = 2 * SR + 1;
     static const bool force_v1 = [] { const char *e = getenv("SCL_SC_KERNEL"); return e && e[0] == 'v' && e[1] == '1'; }();
-    const bool wave_ok = !force_v1 && (db.S % 2 == 0) && (db.S / 2 <= kWave) && (db.S >= W + 3);
-    if (wave_ok && db.RG == 5 && W == 7)   return launch_wave<5, 8, 5>(a, num_cu, stream);
+    const bool wave_ok = !force_v1;
+    const bool wave_grid = wave_ok && ((db.RG == 5 && W == 7 && db.S == 60) || (db.RG == 16 && W == 13 && db.S == 120)) && (db.R % 4 == 0);
+    if (wave_grid && out_ring_d2) { a.out_d2 = out_ring_d2; if (ring_fused) *ring_fused = true; }
+    if (wave_ok && db.RG == 5 && W == 7 && db.S == 60)   return launch_wave<5, 8, 5, 60>(a, num_cu, stream);
     static const bool stamp = [] { const char *e = getenv("SCL_STAMP"); return e && e[0] == '1'; }();
-    if (wave_ok && db.RG == 16 && W == 13 && stamp) return launch_wave<16, 14, 4, true>(a, num_cu, stream);
-    if (wave_ok && db.RG == 16 && W == 13) return launch_wave<16, 14, 4>(a, num_cu, stream);
+    static const int occ = [] { const char *e = getenv("SCL_SC_WAVES"); return e ? atoi(e) : 8; }();
+    if (wave_ok && db.RG == 16 && W == 13 && db.S == 120 && stamp && occ > 8) return launch_wave<16, 14, 2, 120, 768, true>(a, num_cu, stream);
+    if (wave_ok && db.RG == 16 && W == 13 && db.S == 120 && stamp) return launch_wave<16, 14, 4, 120, 512, true>(a, num_cu, stream);
+    if (wave_ok && db.RG == 16 && W == 13 && db.S == 120 && occ > 8) return launch_wave<16, 14, 2, 120, 768>(a, num_cu, stream);
+    if (wave_ok && db.RG == 16 && W == 13 && db.S == 120) return launch_wave<16, 14, 4, 120, 512>(a, num_cu, stream);
     if (db.RG == 5 && W == 7 && db.S >= W)   return launch_fast<5, 7, 512>(a, num_cu, stream);
     if (db.RG == 16 && W == 13 && db.S >= W) return launch_fast<16, 13, 512>(a, num_cu, stream);
     if (db.RG == 20 && W == 19 && db.S >= W && db.S <= 180) return launch_fast<20, 19, 256>(a, num_cu, stream);
@@ -767,9 +825,88 @@ hipError_t launch_sc_distance(const DbView &db, const QueryView &q, const int *c
     return hipGetLastError();
 }
 
+bool sc_distance_fuses_ring(const DbView &db, int SR)
+{
+    const int W = 2 * SR + 1;
+    const char *e = getenv("SCL_SC_KERNEL");
+    if (e && e[0] == 'v' && e[1] == '1') return false;
+    return ((db.RG == 5 && W == 7 && db.S == 60) || (db.RG == 16 && W == 13 && db.S == 120)) && (db.R % 4 == 0);
+}
+
 hipError_t launch_argmin(const double *dist, const int *shift, int n, double *out3, hipStream_t stream)
 {
     hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(1024), 0, stream, dist, shift, n, out3);
+    return hipGetLastError();
+}
+
+namespace {
+
+// Full-DB epilogue in one launch: arg-min over the SC distances AND the k nearest ring keys from
+// the squared ring distances the SC kernel produced on the side.  k rounds of "smallest key larger
+// than the previous pick" (keys (d2 bits << 32 | i) are unique), so nothing has to be removed.
+__global__ __launch_bounds__(1024) void full_epilogue_kernel(const double *dist, const int *shift, const float *d2,
+                                                             int n, int slot_base, int k, float exclude_eps,
+                                                             double *out3, int *topk_idx, float *topk_d2)
+{
+    __shared__ double sv[16];
+    __shared__ int si[16];
+    __shared__ unsigned long long sk[16];
+    const int wv = threadIdx.x / kWave;
+    double best = __longlong_as_double(0x7ff0000000000000LL);
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double d = dist[i];
+        if (d < kBigDist && ((d < best) | ((d == best) & (i < bi)))) { best = d; bi = i; }
+    }
+    wave_argmin(best, bi);
+    if ((threadIdx.x & (kWave - 1)) == 0) { sv[wv] = best; si[wv] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)blockDim.x / kWave; ++w)
+            if ((sv[w] < best) | ((sv[w] == best) & (si[w] < bi))) { best = sv[w]; bi = si[w]; }
+        const bool ok = best < kBigDist;
+        out3[0] = ok ? best : kBigDist;
+        out3[1] = ok ? (double)bi : -1.0;
+        out3[2] = ok ? (double)shift[bi] : 0.0;
+    }
+    const unsigned long long none = ~0ull;
+    unsigned long long prev = 0ull;
+    bool first = true;
+    for (int round = 0; round < k; ++round) {
+        unsigned long long mine = none;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const float r = d2[i];
+            const bool excluded = (exclude_eps > 0.0f) && (r <= exclude_eps);
+            if (excluded || !(r < 3.402823466e+38f)) continue;
+            const unsigned long long key = ((unsigned long long)(unsigned)__float_as_int(r) << 32) | (unsigned)i;
+            if ((first || key > prev) && key < mine) mine = key;
+        }
+        mine = wave_min_u64(mine);
+        __syncthreads();
+        if ((threadIdx.x & (kWave - 1)) == 0) sk[wv] = mine;
+        __syncthreads();
+        unsigned long long m = sk[0];
+        for (int w = 1; w < (int)blockDim.x / kWave; ++w) m = sk[w] < m ? sk[w] : m;
+        if (threadIdx.x == 0) {
+            if (m == none) { topk_idx[round] = -1; topk_d2[round] = 3.402823466e+38f; }
+            else { topk_idx[round] = slot_base + (int)(unsigned)(m & 0xffffffffull); topk_d2[round] = __int_as_float((int)(m >> 32)); }
+        }
+        if (m == none) {
+            for (int r2 = round + 1 + (int)threadIdx.x; r2 < k; r2 += blockDim.x) { topk_idx[r2] = -1; topk_d2[r2] = 3.402823466e+38f; }
+            break;
+        }
+        prev = m; first = false;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_full_epilogue(const double *dist, const int *shift, const float *ring_d2, int n, int slot_base,
+                                int k, float exclude_eps, double *out3, int *topk_idx, float *topk_d2,
+                                hipStream_t stream)
+{
+    hipLaunchKernelGGL(full_epilogue_kernel, dim3(1), dim3(1024), 0, stream, dist, shift, ring_d2, n, slot_base, k,
+                       exclude_eps, out3, topk_idx, topk_d2);
     return hipGetLastError();
 }
 

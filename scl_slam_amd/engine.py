@@ -85,6 +85,7 @@ def _bind(lib):
         "scl_sc_distance_batch": (c_int, [P, c_int, ip, c_int, dp, ip]),
         "scl_detect_full": (c_int, [P, c_int, ip, ip, ip, dp]),
         "scl_detect_full_range": (c_int, [P, c_int, c_int, c_int, ip, ip, dp]),
+        "scl_get_last_topk": (c_int, [P, c_int, ip, fp]),
         "scl_topk_with_distance": (c_int, [P, c_int, c_int, c_int, c_int, ip, fp, dp, ip, ip]),
         "scl_icp_default_params": (c_int, [POINTER(IcpParams)]),
         "scl_icp_align": (c_int, [P, P, c_int, P, c_int, c_int, POINTER(IcpParams), fp, fp, ip, ip]),
@@ -269,6 +270,11 @@ class ScanContextEngine:
                     "scl_detect_full_range")
         return nn.value, sh.value, d.value
 
+    def last_topk(self, k):
+        idx = np.empty(k, dtype=np.int32); d2 = np.empty(k, dtype=np.float32)
+        self._check(self._lib.scl_get_last_topk(self._h, k, _ptr(idx, c_int), _ptr(d2, c_float)), "scl_get_last_topk")
+        return idx, d2
+
     def topk_with_distance(self, query, lo, hi, k):
         idx = np.empty(k, dtype=np.int32); d2 = np.empty(k, dtype=np.float32)
         dist = np.empty(k, dtype=np.float64); shift = np.empty(k, dtype=np.int32); found = c_int()
@@ -328,7 +334,8 @@ class ScanContextEngine:
 
     # -- measurement ------------------------------------------------------------
     def profile_enable(self, on=True):
-        self._check(self._lib.scl_profile_enable(self._h, 1 if on else 0), "scl_profile_enable")
+        """0/False off, 1/True every kernel family, 2 the SC-distance kernel only (lightest)"""
+        self._check(self._lib.scl_profile_enable(self._h, int(on)), "scl_profile_enable")
 
     def profile_reset(self):
         self._check(self._lib.scl_profile_reset(self._h), "scl_profile_reset")

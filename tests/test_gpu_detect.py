@@ -73,3 +73,24 @@ def test_errors_are_status_codes():
     with pytest.raises(ValueError):
         eng.save_from_wire(np.zeros(7, np.float32))
     eng.close()
+
+
+@pytest.mark.parametrize("R,S,k", [(64, 120, 3), (20, 60, 5), (64, 120, 25), (80, 180, 3)])
+def test_full_mode_also_delivers_the_ringkey_topk(R, S, k):
+    """full-DB pass = ring-key top-k + SC distance over everything (fused on the 20x60 / 64x120 grids)."""
+    n = 420
+    descs = synth_descriptors(n, R, S, seed=7 + k)
+    eng = ScanContextEngine(num_ring=R, num_sector=S, num_candidates=k, initial_capacity=512)
+    db = ob.OracleDB(ob.make_config(R=R, S=S, k=k))
+    eng.save_bulk(descs); db.save_bulk(descs)
+    for (q, lo, hi) in [(n - 1, 0, n - 100), (n - 7, 13, 250), (5, 0, 2)]:
+        nn, sh, d = eng.detect_full_range(q, lo, hi)
+        idx, d2 = eng.last_topk(k)
+        o_idx, o_d2, o_found = ob.knn(db.ringkeys(hi)[lo:], db.ringkey(q), k)
+        exp = [int(x) + lo if x >= 0 else -1 for x in o_idx]
+        assert list(idx) == exp
+        assert np.array_equal(d2[:o_found].view(np.uint32), o_d2[:o_found].view(np.uint32))
+        dist, shift = db.distance_batch(q, cand=np.arange(lo, hi, dtype=np.int32))
+        j = int(np.lexsort((np.arange(hi - lo), dist))[0])
+        assert (nn, sh) == (lo + j, int(shift[j])) and d == dist[j]
+    eng.close()
