@@ -145,6 +145,11 @@ int  scl_sc_distance_batch(scl_engine *e, int query, const int *cand, int n,
 int  scl_detect_full(scl_engine *e, int cur, int *loop_id, int *nn_idx, int *shift, double *dist);
 int  scl_detect_full_range(scl_engine *e, int query, int lo, int hi,
                            int *nn_idx, int *shift, double *dist);
+/* Pipelined form of scl_detect_full_range for streams of scans: submit enqueues the pass and returns a
+ * ticket at once (up to 8 may be in flight, results are collected in any order); collect blocks until
+ * that pass has finished.  scl_detect_full_range == submit + collect. */
+int  scl_detect_full_submit(scl_engine *e, int query, int lo, int hi, int *ticket);
+int  scl_detect_full_collect(scl_engine *e, int ticket, int *nn_idx, int *shift, double *dist);
 /* The ring-key top-k (num_candidates entries) computed as part of the last scl_detect_full[_range]. */
 int  scl_get_last_topk(scl_engine *e, int k, int *idx, float *d2);
 /* Reference-faithful candidates for the sharded driver: local ring-key top-k in

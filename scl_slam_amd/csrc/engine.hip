@@ -36,6 +36,10 @@ struct scl_engine {
     hipStream_t stream2 = nullptr;                         // ring-key scan runs beside the SC distance
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     double *h_out3 = nullptr;                              // pinned, device-visible: the arg-min kernel writes it directly
+    static constexpr int kSlots = 8;                       // full-DB passes in flight (submit/collect)
+    hipEvent_t ev_done[kSlots] = {nullptr};
+    int slot_lo[kSlots] = {0}; bool slot_busy[kSlots] = {false}; bool slot_empty[kSlots] = {false};
+    unsigned next_slot = 0;
     mutable std::mutex mu;
     mutable std::string last_error;
 
@@ -58,6 +62,7 @@ struct scl_engine {
     double *d_dist = nullptr; int *d_shift = nullptr; int *d_cand = nullptr; float *d_ring_d2 = nullptr; size_t pair_cap = 0;
     unsigned long long *d_topk_scratch = nullptr; int *d_topk_idx = nullptr; float *d_topk_d2 = nullptr;
     double *d_out3 = nullptr;
+    unsigned long long *d_blk_part = nullptr; unsigned int *d_done_counter = nullptr;   // fused full-DB epilogue
     void *h_pinned = nullptr; size_t pinned_cap = 0;       // small result read-back
 
     // inter-robot tree bookkeeping (descriptor.h:1691-1703, counter initialised: see DESIGN.md)
@@ -112,8 +117,10 @@ struct ProfScope {
 };
 
 void collect_profile(scl_engine *e)
-{   // call after the stream has been synchronised
+{   // folds every finished (start, stop) pair into the profile; unfinished ones stay pending
+    std::vector<PendingEvent> keep;
     for (auto &p : e->pending) {
+        if (hipEventQuery(p.stop) != hipSuccess) { keep.push_back(p); continue; }
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
             switch (p.kind) {
@@ -130,7 +137,7 @@ void collect_profile(scl_engine *e)
         e->event_pool.push_back(p.start);
         e->event_pool.push_back(p.stop);
     }
-    e->pending.clear();
+    e->pending.swap(keep);
 }
 
 int sync(scl_engine *e)
@@ -413,7 +420,9 @@ int scl_create(const scl_config *cfg, scl_engine **out)
     }
     if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) return bail(SCL_ERR_HIP);
     if (hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) return bail(SCL_ERR_HIP);
-    if (hipHostMalloc((void **)&e->h_out3, 64, hipHostMallocDefault) != hipSuccess) return bail(SCL_ERR_HIP);
+    if (hipHostMalloc((void **)&e->h_out3, 64 * scl_engine::kSlots, hipHostMallocDefault) != hipSuccess) return bail(SCL_ERR_HIP);
+    for (int i = 0; i < scl_engine::kSlots; ++i)
+        if (hipEventCreateWithFlags(&e->ev_done[i], hipEventDisableTiming) != hipSuccess) return bail(SCL_ERR_HIP);
     if ((rc = ensure_capacity(e, 1))) return bail(rc);
     const size_t tile = (size_t)e->RG * e->S;
     if ((rc = dev_alloc(e, &e->q_desc, tile))) return bail(rc);
@@ -426,6 +435,9 @@ int scl_create(const scl_config *cfg, scl_engine **out)
     if ((rc = dev_alloc(e, &e->d_topk_idx, (size_t)kTopkMaxK))) return bail(rc);
     if ((rc = dev_alloc(e, &e->d_topk_d2, (size_t)kTopkMaxK))) return bail(rc);
     if ((rc = dev_alloc(e, &e->d_out3, (size_t)4))) return bail(rc);
+    if ((rc = dev_alloc(e, &e->d_blk_part, (size_t)1024 * kTailRec))) return bail(rc);
+    if ((rc = dev_alloc(e, &e->d_done_counter, (size_t)4))) return bail(rc);
+    if (hipMemset(e->d_done_counter, 0, 16) != hipSuccess) return bail(SCL_ERR_HIP);
     if ((rc = ensure_pairs(e, 1024))) return bail(rc);
     if ((rc = ensure_pinned(e, 1 << 16))) return bail(rc);
     if ((rc = ensure_vals(e, (size_t)e->R * e->S))) return bail(rc);
@@ -446,8 +458,11 @@ int scl_destroy(scl_engine *e)
     dev_free(e->d_vals); dev_free(e->d_points); dev_free(e->d_tile);
     dev_free(e->d_dist); dev_free(e->d_shift); dev_free(e->d_cand); dev_free(e->d_ring_d2);
     dev_free(e->d_topk_scratch); dev_free(e->d_topk_idx); dev_free(e->d_topk_d2); dev_free(e->d_out3);
+    dev_free(e->d_blk_part); dev_free(e->d_done_counter);
+    dev_free(e->d_blk_part); dev_free(e->d_done_counter);
     if (e->h_pinned) (void)hipHostFree(e->h_pinned);
     if (e->h_out3) (void)hipHostFree(e->h_out3);
+    for (int i = 0; i < scl_engine::kSlots; ++i) if (e->ev_done[i]) (void)hipEventDestroy(e->ev_done[i]);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->stream2) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamDestroy(e->stream2); }
@@ -716,55 +731,104 @@ int scl_sc_distance_batch(scl_engine *e, int query, const int *cand, int n, doub
     return sync(e);
 }
 
+namespace {
+
+// enqueue one full-DB pass; results land in pinned slot `sl` when ev_done[sl] has fired
+int submit_full_locked(scl_engine *e, int query, int lo, int hi, int *ticket)
+{
+    QueryView q;
+    int rc = query_view(e, query, &q);
+    if (rc) return rc;
+    const int sl = (int)(e->next_slot % scl_engine::kSlots);
+    if (e->slot_busy[sl]) return fail(e, SCL_ERR_INVALID_ARG, "too many full-DB passes in flight: collect first");
+    if (lo < 0) lo = 0;
+    if (hi > e->n) hi = e->n;
+    const int n = hi - lo;
+    e->slot_lo[sl] = lo;
+    e->slot_empty[sl] = n <= 0;
+    double *out3 = e->h_out3 + (size_t)sl * 8;
+    if (n > 0) {
+        if ((rc = ensure_pairs(e, (size_t)n))) return rc;
+        // "full ring-key + shifted SC distance per incoming scan".  On the two-sectors-per-lane grids the
+        // ring-key metric is evaluated inside the SC-distance kernel (the wave that scores a slot also reads
+        // its ring key) and one epilogue launch does arg-min + top-k; otherwise the stand-alone ring-key
+        // scan runs on a second stream beside the SC kernel.
+        const int k = e->cfg.num_candidates;
+        const bool fuse = k <= kTailTop && sc_distance_fuses_ring(db_view(e), e->SR);
+        if (!fuse) SCL_HIP(e, hipEventRecord(e->ev_fork, e->stream));
+        bool fused = false;
+        FullTail tail{e->d_blk_part, e->d_done_counter, out3, e->d_topk_idx, e->d_topk_d2, k, e->cfg.knn_exclude_eps};
+        {
+            ProfScope ps(e, P_SC);
+            SCL_HIP(e, launch_sc_distance(db_view(e), q, nullptr, lo, n, e->SR, e->d_dist, e->d_shift, e->num_cu, e->stream,
+                                          fuse ? e->d_ring_d2 : nullptr, &fused, fuse ? &tail : nullptr));
+            if (e->prof_on) e->prof.sc_distance_pairs += (uint64_t)n;
+        }
+        if (fuse && fused) {
+            // arg-min and top-k were reduced inside the kernel (last workgroup)
+        } else {
+            if (fuse) return fail(e, SCL_ERR_HIP, "ring-key fusion expected but not provided by the kernel");
+            SCL_HIP(e, hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
+            if ((rc = launch_topk(e, q, lo, hi, k, e->cfg.knn_exclude_eps, e->stream2))) return rc;
+            SCL_HIP(e, hipEventRecord(e->ev_join, e->stream2));
+            {
+                ProfScope ps(e, P_ARGMIN);
+                SCL_HIP(e, launch_argmin(e->d_dist, e->d_shift, n, out3, e->stream));   // writes pinned host memory
+            }
+            SCL_HIP(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));
+        }
+    }
+    SCL_HIP(e, hipEventRecord(e->ev_done[sl], e->stream));
+    e->slot_busy[sl] = true;
+    e->next_slot++;
+    *ticket = sl;
+    return SCL_OK;
+}
+
+int collect_full_locked(scl_engine *e, int ticket, int *nn_idx, int *shift, double *dist)
+{
+    if (ticket < 0 || ticket >= scl_engine::kSlots || !e->slot_busy[ticket])
+        return fail(e, SCL_ERR_INVALID_ARG, "unknown ticket");
+    SCL_HIP(e, hipEventSynchronize(e->ev_done[ticket]));
+    collect_profile(e);
+    e->slot_busy[ticket] = false;
+    *nn_idx = -1; *shift = 0; *dist = kBigDist;
+    if (e->slot_empty[ticket]) return SCL_OK;
+    const volatile double *o = e->h_out3 + (size_t)ticket * 8;
+    *dist = o[0];
+    *nn_idx = o[1] < 0 ? -1 : e->slot_lo[ticket] + (int)o[1];
+    *shift = (int)o[2];
+    return SCL_OK;
+}
+
+}  // namespace
+
+int scl_detect_full_submit(scl_engine *e, int query, int lo, int hi, int *ticket)
+{
+    if (!e || !ticket) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    return submit_full_locked(e, query, lo, hi, ticket);
+}
+
+int scl_detect_full_collect(scl_engine *e, int ticket, int *nn_idx, int *shift, double *dist)
+{
+    if (!e || !nn_idx || !shift || !dist) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    return collect_full_locked(e, ticket, nn_idx, shift, dist);
+}
+
 int scl_detect_full_range(scl_engine *e, int query, int lo, int hi, int *nn_idx, int *shift, double *dist)
 {
     if (!e || !nn_idx || !shift || !dist) return SCL_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     *nn_idx = -1; *shift = 0; *dist = kBigDist;
-    QueryView q;
-    int rc = query_view(e, query, &q);
+    int ticket = -1;
+    int rc = submit_full_locked(e, query, lo, hi, &ticket);
     if (rc) return rc;
-    if (lo < 0) lo = 0;
-    if (hi > e->n) hi = e->n;
-    const int n = hi - lo;
-    if (n <= 0) return SCL_OK;
-    if ((rc = ensure_pairs(e, (size_t)n))) return rc;
-    // "full ring-key + shifted SC distance per incoming scan".  On the two-sectors-per-lane grids the
-    // ring-key metric is evaluated inside the SC-distance kernel (the wave that scores a slot also reads
-    // its ring key) and one epilogue launch does arg-min + top-k; otherwise the stand-alone ring-key
-    // scan runs on a second stream beside the SC kernel.
-    const int k = e->cfg.num_candidates;
-    const bool fuse = k <= 8 && sc_distance_fuses_ring(db_view(e), e->SR);
-    if (!fuse) SCL_HIP(e, hipEventRecord(e->ev_fork, e->stream));
-    bool fused = false;
-    {
-        ProfScope ps(e, P_SC);
-        SCL_HIP(e, launch_sc_distance(db_view(e), q, nullptr, lo, n, e->SR, e->d_dist, e->d_shift, e->num_cu, e->stream,
-                                      fuse ? e->d_ring_d2 : nullptr, &fused));
-        if (e->prof_on) e->prof.sc_distance_pairs += (uint64_t)n;
-    }
-    if (fuse && fused) {
-        ProfScope ps(e, P_ARGMIN);
-        SCL_HIP(e, launch_full_epilogue(e->d_dist, e->d_shift, e->d_ring_d2, n, lo, k, e->cfg.knn_exclude_eps,
-                                        e->h_out3, e->d_topk_idx, e->d_topk_d2, e->stream));
-    } else {
-        if (fuse) return fail(e, SCL_ERR_HIP, "ring-key fusion expected but not provided by the kernel");
-        SCL_HIP(e, hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
-        if ((rc = launch_topk(e, q, lo, hi, k, e->cfg.knn_exclude_eps, e->stream2))) return rc;
-        SCL_HIP(e, hipEventRecord(e->ev_join, e->stream2));
-        {
-            ProfScope ps(e, P_ARGMIN);
-            SCL_HIP(e, launch_argmin(e->d_dist, e->d_shift, n, e->h_out3, e->stream));   // writes pinned host memory
-        }
-        SCL_HIP(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));
-    }
-    if ((rc = sync(e))) return rc;
-    const volatile double *o = e->h_out3;
-    *dist = o[0];
-    *nn_idx = o[1] < 0 ? -1 : lo + (int)o[1];
-    *shift = (int)o[2];
-    return SCL_OK;
+    return collect_full_locked(e, ticket, nn_idx, shift, dist);
 }
 
 int scl_get_last_topk(scl_engine *e, int k, int *idx, float *d2)

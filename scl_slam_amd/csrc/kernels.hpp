@@ -36,11 +36,21 @@ struct QueryView {          // one descriptor in the same layout (a DB slot or t
 // K1: distanceBtnScanContext for n candidates.
 //   slot(i) = cand ? cand[i] : slot_base + i ; slot < 0 -> (1e7, 0) without compute.
 // Returns false when (R,S,SR) has no specialised kernel and the generic one must be used.
+// FullTail (optional, needs out_ring_d2 and a fusing grid): the kernel also reduces the global arg-min and the
+// ring-key top-k itself (per-workgroup partials + last-workgroup reduction), so no epilogue launch is needed.
+// blk_part: kTailRec u64 per workgroup (>= 1024 workgroups); done_counter: one zeroed u32.
+constexpr int kTailTop = 4;                 // ring-key candidates the fused epilogue can track (k <= kTailTop)
+constexpr int kTailRec = 2 + kTailTop;
+struct FullTail {
+    unsigned long long *blk_part; unsigned int *done_counter; double *out3; int *topk_idx; float *topk_d2;
+    int k; float exclude_eps;
+};
 // out_ring_d2 (optional): also write the squared ring-key distance (nanoflann metric) of every scored
 // slot; *ring_fused tells whether the selected kernel supports it (the two-sectors-per-lane grids do).
 hipError_t launch_sc_distance(const DbView &db, const QueryView &q, const int *cand, int slot_base,
                               int n, int SR, double *out_dist, int *out_shift, int num_cu,
-                              hipStream_t stream, float *out_ring_d2 = nullptr, bool *ring_fused = nullptr);
+                              hipStream_t stream, float *out_ring_d2 = nullptr, bool *ring_fused = nullptr,
+                              const FullTail *tail = nullptr);
 
 // arg-min over (dist[i], i) for i in [0,n): strict <, first wins, NaN never wins,
 // nothing below 1e7 -> idx -1.  out: {dist, (double)idx, (double)shift} packed as 3 doubles.

@@ -51,6 +51,9 @@ struct ScArgs {
     int *out_shift;
     // optional fused ring-key scan (full-DB mode): squared ring-key distance of every scored slot
     const float4 *rkey4; int rk_cap; const float *q_rkey; float *out_d2;
+    // optional fused epilogue (full-DB mode): per-workgroup partials, last workgroup reduces them
+    unsigned long long *blk_part; unsigned int *done_counter; double *out3; int *topk_idx; float *topk_d2;
+    int topk_k; float exclude_eps;
     unsigned long long *stamps;   // diagnostic only (SCL_STAMP=1): per-wave phase cycle sums
     int ablate;   // diagnostic only (SCL_ABLATE): bit0 skip alignment loop, bit1 skip ring dots, bit2 skip sector sums
 };
@@ -346,10 +349,19 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
     constexpr int qstep = QS / 2;
 
     int ci = c_lo + wave;
-    if (ci >= c_hi) return;
+    const bool have_work = ci < c_hi;
+
+    // running results of this wave (wave-uniform): best (distance, position) and the KT nearest ring keys
+    constexpr int KT = kTailTop;               // ring-key candidates tracked by the fused epilogue
+    constexpr unsigned long long kNone = ~0ull;
+    double w_best = kInf;
+    int w_bidx = 0x7fffffff, w_bshift = 0;
+    unsigned long long w_top[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) w_top[t] = kNone;
 
     // ---- per-candidate state of the software pipeline --------------------------------
-    int slot = a.cand ? a.cand[ci] : a.slot_base + ci;
+    int slot = have_work ? (a.cand ? a.cand[ci] : a.slot_base + ci) : -1;
     int s_start = 0, t_lo = 0;
     const float4 *kp = a.desc;
     double2 nk = make_double2(0.0, 0.0);
@@ -429,7 +441,7 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
         st_a += stamp() - st_t;
     }
 
-    while (true) {
+    while (have_work) {
         int ticket = 0;
         if (lane == 0) ticket = atomicAdd(next_ticket, 1);
         const int ci_next = __builtin_amdgcn_readfirstlane(ticket);
@@ -505,6 +517,18 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
 #pragma unroll
             for (int g = 0; g < RG; ++g) result += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(grp), g));
             if (lane == 0) a.out_d2[ci] = result;
+            const int rbits = __builtin_amdgcn_readfirstlane(__float_as_int(result));   // scalar from here on
+            const float rs = __int_as_float(rbits);
+            const bool excluded = (a.exclude_eps > 0.0f) && (rs <= a.exclude_eps);
+            if (!excluded && (rs < 3.402823466e+38f)) {
+                unsigned long long key = ((unsigned long long)(unsigned)rbits << 32) | (unsigned)ci;
+#pragma unroll
+                for (int t = 0; t < KT; ++t) {                   // sorted insert (ascending), wave-uniform
+                    const unsigned long long lo_k = key < w_top[t] ? key : w_top[t];
+                    const unsigned long long hi_k = key < w_top[t] ? w_top[t] : key;
+                    w_top[t] = lo_k; key = hi_k;
+                }
+            }
         }
         if (slot >= 0) {
             double dmin = kInf;
@@ -554,6 +578,12 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
                 a.out_dist[ci] = ok ? dmin : kBigDist;
                 a.out_shift[ci] = ok ? smin : 0;
             }
+            {
+                const double ds = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(dmin)),
+                                                   __builtin_amdgcn_readfirstlane(__double2loint(dmin)));
+                const int ss = __builtin_amdgcn_readfirstlane(smin);
+                if (ds < kBigDist && ((ds < w_best) | ((ds == w_best) & (ci < w_bidx)))) { w_best = ds; w_bidx = ci; w_bshift = ss; }
+            }
         } else if (lane == 0) {
             a.out_dist[ci] = kBigDist;
             a.out_shift[ci] = 0;
@@ -570,6 +600,98 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
             unsigned long long *o = a.stamps + (size_t)(blockIdx.x * nwaves + wave) * 8;
             o[0] = cyc1 - st_cyc0; o[1] = real1 - st_real0; o[2] = st_a; o[3] = st_b; o[4] = st_c; o[5] = st_d;
         }
+    }
+
+    // ---- fused epilogue (full-DB mode): global arg-min and ring-key top-k without another launch ----
+    // wave records -> workgroup record (LDS) -> global partial; the last workgroup to arrive (agent-scope
+    // release on the producers, acquire on the consumer) reduces the partials and resets the counter.
+    if (a.blk_part == nullptr) return;
+    constexpr int REC = 2 + KT;
+    unsigned long long *wrec = reinterpret_cast<unsigned long long *>(vq + S) + (size_t)wave * wsz;   // wave scratch is free now
+    if (lane == 0) {
+        wrec[0] = (unsigned long long)__double_as_longlong(w_best);
+        wrec[1] = ((unsigned long long)(unsigned)w_bidx << 32) | (unsigned)w_bshift;
+#pragma unroll
+        for (int t = 0; t < KT; ++t) wrec[2 + t] = w_top[t];
+    }
+    __syncthreads();
+    unsigned int *s_ticket = reinterpret_cast<unsigned int *>(next_ticket) + 1;
+    if (wave == 0) {
+        // workgroup record: lane w < nwaves holds wave w's best, lane l holds one ring key of wave l / KT
+        const unsigned long long *base = reinterpret_cast<unsigned long long *>(vq + S);
+        unsigned long long b0 = ~0ull, b1 = ~0ull;
+        if (lane < nwaves) { b0 = base[(size_t)lane * wsz]; b1 = base[(size_t)lane * wsz + 1]; }
+        const unsigned long long m0 = wave_min_u64(b0);                       // distance bits order like distances
+        const unsigned long long m1 = wave_min_u64(b0 == m0 ? b1 : ~0ull);    // then the lowest position
+        unsigned long long key = kNone;
+        if (lane < nwaves * KT) key = base[(size_t)(lane / KT) * wsz + 2 + (lane % KT)];
+        unsigned long long *bp = a.blk_part + (size_t)blockIdx.x * REC;
+        unsigned long long prev = 0ull;
+        bool first = true;
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            const unsigned long long m = wave_min_u64((first || key > prev) ? key : kNone);
+            if (lane == 0) bp[2 + t] = m;
+            prev = m; first = false;
+            if (m == kNone) { prev = kNone; }
+        }
+        if (lane == 0) {
+            bp[0] = m0; bp[1] = m1;
+            __threadfence();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            *s_ticket = atomicAdd(a.done_counter, 1u);
+        }
+    }
+    __syncthreads();
+    if (*s_ticket != gridDim.x - 1) return;
+    if (wave != 0) return;
+    __threadfence();                                   // acquire: partials of the other workgroups
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+        unsigned long long best = (unsigned long long)__double_as_longlong(kInf), tag = ~0ull;
+        unsigned long long keys[4 * KT];
+#pragma unroll
+        for (int t = 0; t < 4 * KT; ++t) keys[t] = kNone;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int b = lane + u * kWave;
+            if (b < (int)gridDim.x) {
+                const unsigned long long *bp = a.blk_part + (size_t)b * REC;
+                const unsigned long long r0 = __builtin_nontemporal_load(bp), r1 = __builtin_nontemporal_load(bp + 1);
+                if (r0 < best || (r0 == best && (r1 >> 32) < (tag >> 32))) { best = r0; tag = r1; }
+#pragma unroll
+                for (int t = 0; t < KT; ++t) keys[u * KT + t] = __builtin_nontemporal_load(bp + 2 + t);
+            }
+        }
+        double bd = __longlong_as_double((long long)best);
+        int bpos = (int)(unsigned)(tag >> 32);
+        const int my_shift = (int)(unsigned)(tag & 0xffffffffull);
+        const double my_bd = bd; const int my_pos = bpos;
+        wave_argmin(bd, bpos);
+        if (my_bd == bd && my_pos == bpos && ((lane & 63) == __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(my_bd == bd && my_pos == bpos)) - 1))) {
+            const bool ok = bd < kBigDist;
+            a.out3[0] = ok ? bd : kBigDist;
+            a.out3[1] = ok ? (double)bpos : -1.0;
+            a.out3[2] = ok ? (double)my_shift : 0.0;
+        }
+        unsigned long long prev = 0ull;
+        bool first = true;
+        for (int round = 0; round < a.topk_k; ++round) {
+            unsigned long long mine = kNone;
+#pragma unroll
+            for (int t = 0; t < 4 * KT; ++t) if ((first || keys[t] > prev) && keys[t] < mine) mine = keys[t];
+            const unsigned long long m = wave_min_u64(mine);
+            if (lane == 0) {
+                if (m == kNone) { a.topk_idx[round] = -1; a.topk_d2[round] = 3.402823466e+38f; }
+                else { a.topk_idx[round] = a.slot_base + (int)(unsigned)(m & 0xffffffffull); a.topk_d2[round] = __int_as_float((int)(m >> 32)); }
+            }
+            if (m == kNone) {
+                for (int r2 = round + 1 + lane; r2 < a.topk_k; r2 += kWave) { a.topk_idx[r2] = -1; a.topk_d2[r2] = 3.402823466e+38f; }
+                break;
+            }
+            prev = m; first = false;
+        }
+        if (lane == 0) *a.done_counter = 0u;            // armed for the next launch (stream ordered)
     }
 }
 
@@ -790,7 +912,7 @@ hipError_t launch_fast(const ScArgs &args_in, int num_cu, hipStream_t stream)
 
 hipError_t launch_sc_distance(const DbView &db, const QueryView &q, const int *cand, int slot_base,
                               int n, int SR, double *out_dist, int *out_shift, int num_cu,
-                              hipStream_t stream, float *out_ring_d2, bool *ring_fused)
+                              hipStream_t stream, float *out_ring_d2, bool *ring_fused, const FullTail *tail)
 {
     if (ring_fused) *ring_fused = false;
     if (n <= 0) return hipSuccess;
@@ -803,12 +925,20 @@ hipError_t launch_sc_distance(const DbView &db, const QueryView &q, const int *c
     a.ablate = ablate;
     a.stamps = nullptr;
     a.rkey4 = db.rkey4; a.rk_cap = db.cap; a.q_rkey = q.rkey; a.out_d2 = nullptr;
+    a.blk_part = nullptr; a.done_counter = nullptr; a.out3 = nullptr; a.topk_idx = nullptr; a.topk_d2 = nullptr;
+    a.topk_k = 0; a.exclude_eps = 0.0f;
     a.out_dist = out_dist; a.out_shift = out_shift;
     const int W = 2 * SR + 1;
     static const bool force_v1 = [] { const char *e = getenv("SCL_SC_KERNEL"); return e && e[0] == 'v' && e[1] == '1'; }();
     const bool wave_ok = !force_v1;
     const bool wave_grid = wave_ok && ((db.RG == 5 && W == 7 && db.S == 60) || (db.RG == 16 && W == 13 && db.S == 120)) && (db.R % 4 == 0);
-    if (wave_grid && out_ring_d2) { a.out_d2 = out_ring_d2; if (ring_fused) *ring_fused = true; }
+    if (wave_grid && out_ring_d2) {
+        a.out_d2 = out_ring_d2; if (ring_fused) *ring_fused = true;
+        if (tail && tail->k <= kTailTop) {
+            a.blk_part = tail->blk_part; a.done_counter = tail->done_counter; a.out3 = tail->out3;
+            a.topk_idx = tail->topk_idx; a.topk_d2 = tail->topk_d2; a.topk_k = tail->k; a.exclude_eps = tail->exclude_eps;
+        }
+    }
     if (wave_ok && db.RG == 5 && W == 7 && db.S == 60)   return launch_wave<5, 8, 5, 60>(a, num_cu, stream);
     static const bool stamp = [] { const char *e = getenv("SCL_STAMP"); return e && e[0] == '1'; }();
     static const int occ = [] { const char *e = getenv("SCL_SC_WAVES"); return e ? atoi(e) : 8; }();

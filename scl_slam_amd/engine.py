@@ -86,6 +86,8 @@ def _bind(lib):
         "scl_detect_full": (c_int, [P, c_int, ip, ip, ip, dp]),
         "scl_detect_full_range": (c_int, [P, c_int, c_int, c_int, ip, ip, dp]),
         "scl_get_last_topk": (c_int, [P, c_int, ip, fp]),
+        "scl_detect_full_submit": (c_int, [P, c_int, c_int, c_int, ip]),
+        "scl_detect_full_collect": (c_int, [P, c_int, ip, ip, dp]),
         "scl_topk_with_distance": (c_int, [P, c_int, c_int, c_int, c_int, ip, fp, dp, ip, ip]),
         "scl_icp_default_params": (c_int, [POINTER(IcpParams)]),
         "scl_icp_align": (c_int, [P, P, c_int, P, c_int, c_int, POINTER(IcpParams), fp, fp, ip, ip]),
@@ -268,6 +270,17 @@ class ScanContextEngine:
         nn, sh, d = c_int(), c_int(), c_double()
         self._check(self._lib.scl_detect_full_range(self._h, query, lo, hi, byref(nn), byref(sh), byref(d)),
                     "scl_detect_full_range")
+        return nn.value, sh.value, d.value
+
+    def detect_full_submit(self, query, lo, hi):
+        t = c_int()
+        self._check(self._lib.scl_detect_full_submit(self._h, query, lo, hi, byref(t)), "scl_detect_full_submit")
+        return t.value
+
+    def detect_full_collect(self, ticket):
+        nn, sh, d = c_int(), c_int(), c_double()
+        self._check(self._lib.scl_detect_full_collect(self._h, ticket, byref(nn), byref(sh), byref(d)),
+                    "scl_detect_full_collect")
         return nn.value, sh.value, d.value
 
     def last_topk(self, k):

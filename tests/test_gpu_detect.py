@@ -94,3 +94,24 @@ def test_full_mode_also_delivers_the_ringkey_topk(R, S, k):
         j = int(np.lexsort((np.arange(hi - lo), dist))[0])
         assert (nn, sh) == (lo + j, int(shift[j])) and d == dist[j]
     eng.close()
+
+
+def test_submit_collect_pipeline_matches_blocking_calls():
+    R, S, n = 64, 120, 330
+    descs = synth_descriptors(n, R, S, seed=77)
+    eng = ScanContextEngine(num_ring=R, num_sector=S, initial_capacity=512)
+    eng.save_bulk(descs)
+    qs = [n - 1, n - 2, n - 3, n - 4, n - 5, 200]
+    ref = [eng.detect_full_range(q, 0, n - 100) for q in qs]
+    tickets = [eng.detect_full_submit(q, 0, n - 100) for q in qs]       # six passes in flight
+    got = [eng.detect_full_collect(t) for t in reversed(tickets)][::-1]  # collected out of order
+    assert got == ref
+    empty = eng.detect_full_submit(n - 1, 5, 5)
+    assert eng.detect_full_collect(empty) == (-1, 0, 10000000.0)
+    with pytest.raises(SclError):
+        eng.detect_full_collect(empty)                                    # ticket already consumed
+    for _ in range(8):
+        eng.detect_full_submit(0, 0, 10)
+    with pytest.raises(SclError):
+        eng.detect_full_submit(0, 0, 10)                                  # ring of 8 is full
+    eng.close()
