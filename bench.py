@@ -93,9 +93,18 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    # SCL_BENCH_SHARE_GPU=1: rehearsal of the multi-rank path on a one-GPU box (all ranks on cuda:0, gloo
+    # for the exchange); the real runs use one GPU per rank and RCCL ("nccl").
+    share_gpu = os.environ.get("SCL_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    coll_dev = "cpu" if share_gpu else "cuda"
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from scl_slam_amd import ScanContextEngine
     from scl_slam_amd.synth import synth_descriptors
@@ -113,7 +122,7 @@ def main():
             src = int(rs.randint(0, n_elig))
             queries[i] = np.roll(shard[src], int(rs.randint(0, S)), axis=1)
     if world > 1:
-        qt = torch.from_numpy(queries).cuda()
+        qt = torch.from_numpy(queries).to(coll_dev)
         dist.broadcast(qt, src=0)
         queries = qt.cpu().numpy()
 
@@ -123,8 +132,8 @@ def main():
     eng.save_bulk(queries)
     assert eng.get_size() == n_local
 
-    res_dev = torch.zeros(3, dtype=torch.float64, device="cuda")
-    gather = [torch.zeros(3, dtype=torch.float64, device="cuda") for _ in range(world)] if world > 1 else None
+    res_dev = torch.zeros(3, dtype=torch.float64, device=coll_dev)
+    gather = [torch.zeros(3, dtype=torch.float64, device=coll_dev) for _ in range(world)] if world > 1 else None
 
     def submit(i):
         q = n_elig + (i % n_query)
@@ -171,7 +180,7 @@ def main():
     prof = eng.profile()
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -203,7 +212,7 @@ def main():
             "kernel_ms": {"sc_distance": k1_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "sc_distance_wave_kernel<16,14,4>",
+                         "kernel": "sc_distance_wave_kernel<16,13,4,120,512> (SC distance + fused ring-key metric, arg-min and top-k)",
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PAIR * k1_pairs},
             "device": eng.device_name(),
         }

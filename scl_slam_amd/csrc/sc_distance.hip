@@ -23,6 +23,7 @@
 // (one ds_read_b64 per fp64 fma) is what limits v1 -- see DESIGN.md.
 #include <algorithm>
 #include <cstdio>
+#include <type_traits>
 #include <cstdlib>
 #include <vector>
 
@@ -216,14 +217,14 @@ __global__ __launch_bounds__(MAXT) void sc_distance_kernel(ScArgs a)
 //
 // Why: in the kernel above every fp64 fma needs its own 8-byte LDS operand, so the LDS
 // port (256 B/clk/CU) and not the fp64 pipe sets the pace, and three workgroup barriers
-// per candidate serialise the phases.  Here lane l owns candidate columns 2l and 2l+1:
-// their shift windows overlap in all but one query column, so NSH+2 query values fetched
-// with aligned ds_read_b128 feed 2*NSH fmas (0.57 LDS bytes per fma-byte instead of 1).
-// The window start is rounded down to an even column (NSH = W+1 shifts are evaluated, the
-// surplus one is discarded) so every lane's window is 16-byte aligned.  All per-candidate
-// scratch (doubled sector key, similarity rows) is private to the wave: no workgroup
-// barrier after the query has been staged, waves drift apart and overlap each other's
-// latency-bound phases (alignment chain, sequential sector sum).
+// per candidate serialise the phases.  Here lane l owns QUERY columns 2l and 2l+1 and the
+// candidate rotates under it: with b the first searched shift, the lane takes candidate
+// columns (2l - b) mod S and +1.  The two columns' shift windows overlap in all but one
+// query column, so W+1 query values -- always columns 2l .. 2l+W, a fixed, 16-byte aligned,
+// never wrapping address: (W+1)/2 conflict-free ds_read_b128 -- feed 2*W fmas (0.54 LDS
+// bytes per fma-byte instead of 1).  All per-candidate scratch (doubled sector key,
+// similarity rows) is private to the wave: no workgroup barrier after the query has been
+// staged, waves drift apart and overlap each other's latency-bound phases.
 // Arithmetic order is unchanged (ring order dots, sector order sums): results stay
 // bit-identical to the CPU checker.
 // =================================================================================
@@ -238,18 +239,18 @@ __device__ __forceinline__ void wave_fence()
 // with a memory clobber orders the LDS reads, and taking every accumulator as a read-write
 // operand orders the fmas: without the latter SelectionDAG is free to emit all fmas of a
 // block after all of its loads (it does), which keeps every ring's window live and spills.
-__device__ __forceinline__ void pin_ring(double (&a)[8], double (&b)[8])
-{
-    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
-                      "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7])
-                 :: "memory");
-}
-__device__ __forceinline__ void pin_ring(double (&a)[14], double (&b)[14])
+__device__ __forceinline__ void pin_ring(double (&a)[7], double (&b)[7])
 {
     asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]),
-                      "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]),
+                      "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6])
+                 :: "memory");
+}
+__device__ __forceinline__ void pin_ring(double (&a)[13], double (&b)[13])
+{
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]),
+                      "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]),
                       "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]),
-                      "+v"(b[7]), "+v"(b[8]), "+v"(b[9]), "+v"(b[10]), "+v"(b[11]), "+v"(b[12]), "+v"(b[13])
+                      "+v"(b[7]), "+v"(b[8]), "+v"(b[9]), "+v"(b[10]), "+v"(b[11]), "+v"(b[12])
                  :: "memory");
 }
 
@@ -266,7 +267,7 @@ __device__ __forceinline__ void pin3(double &a, double &b, double &c)
     asm volatile("" : "+v"(a), "+v"(b), "+v"(c) :: "memory");
 }
 
-template <int RG, int NSH, int CH, int S, int MAXT, bool STAMP>
+template <int RG, int W, int CH, int S, int MAXT, bool STAMP>
 __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
 {
     unsigned long long st_t = 0, st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_real0 = 0, st_cyc0 = 0;
@@ -282,14 +283,14 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
 
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int R4 = RG * 4;
-    constexpr int HSH = NSH / 2;               // shifts summed per phase-D pass
-    constexpr int W = NSH - 1;                 // shifts the reference evaluates (2*SR+1)
-    constexpr int NQ = NSH / 2 + 1;            // ds_read_b128 per ring
+    static_assert(W % 2 == 1, "2*SR+1 shifts");
+    constexpr int HSH = (W + 1) / 2;           // shifts summed per phase-D pass (second pass: W - HSH)
+    constexpr int NQ = (W + 1) / 2;            // ds_read_b128 per ring: W+1 query values feed 2*W fmas
     static_assert(RG % CH == 0, "chunk must divide the ring groups");
-    static_assert(S % 2 == 0 && S / 2 <= kWave && S >= NSH + 2, "two sectors per lane, one wave per candidate");
+    static_assert(S % 2 == 0 && S / 2 <= kWave && S >= W + 1, "two sectors per lane, one wave per candidate");
     const int SR = a.SR;
     constexpr int L = S >> 1;                  // active lanes
-    constexpr int QS = S + NSH + 2;            // extended query row (even)
+    constexpr int QS = S + W + 1;              // extended query row (even)
     constexpr int SB = S + 2;                      // similarity row stride: even (b128 rows), rows on distinct banks
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
         const float4 v = a.q_desc[idx];
         double *dst = Qd + (rg * 4) * QS + c;
         dst[0] = (double)v.x; dst[QS] = (double)v.y; dst[2 * QS] = (double)v.z; dst[3 * QS] = (double)v.w;
-        if (c < NSH + 2) {
+        if (c < W + 1) {
             dst += S;
             dst[0] = (double)v.x; dst[QS] = (double)v.y; dst[2 * QS] = (double)v.z; dst[3 * QS] = (double)v.w;
         }
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
     for (int c = threadIdx.x; c < S; c += blockDim.x) {
         const double nv = a.q_norm[c];
         nqe[c] = nv;
-        if (c < NSH + 2) nqe[c + S] = nv;
+        if (c < W + 1) nqe[c + S] = nv;
         vq[c] = a.q_vkey[c];
     }
     // Candidates of this workgroup: a contiguous range, handed out wave by wave through an LDS
@@ -362,13 +363,13 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
 
     // ---- per-candidate state of the software pipeline --------------------------------
     int slot = have_work ? (a.cand ? a.cand[ci] : a.slot_base + ci) : -1;
-    int s_start = 0, t_lo = 0;
-    const float4 *kp = a.desc;
+    int s_start = 0;
+    const float4 *kp0 = a.desc, *kp1 = a.desc;
     double2 nk = make_double2(0.0, 0.0);
     float4 k0[CH], k1[CH];
 
     // alignment of one candidate (fastAlignUsingVkey, D.h:1491-1511) + issue of its first loads
-    auto align_and_fetch = [&](int sl_i, const double2 vk, int &o_s_start, int &o_t_lo) {
+    auto align_and_fetch = [&](int sl_i, const double2 vk, int &o_s_start) {
         wave_fence();
         // lanes >= L mirror lane L-1 (same addresses, same values): no divergent stores needed
         *reinterpret_cast<double2 *>(vk2 + j0) = vk;
@@ -423,21 +424,24 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
         }
         wave_argmin(best, bshift);
         const int align = __builtin_amdgcn_readfirstlane(best < kBigDist ? bshift : 0);
-        const int b = wrap(align - SR, S);     // first shift of the reference's search space
-        o_s_start = b & ~1;                    // evaluated shifts: s_start .. s_start+NSH-1 (mod S)
-        o_t_lo = b - o_s_start;                // 0 or 1: which end carries the surplus shift
-        const int kc = wrap(j0 - o_s_start, S);                   // even: the lane's candidate columns
+        // first shift of the reference's search space; the W evaluated shifts are b .. b+W-1 (mod S)
+        o_s_start = wrap(align - SR, S);
+        // rotation: lane l keeps query columns 2l, 2l+1 and takes the candidate columns that meet them at
+        // shift b; the pair may straddle the sector wrap (kc = S-1), hence two pointers
+        const int kc = wrap(j0 - o_s_start, S);
+        const int kc1 = kc + 1 == S ? 0 : kc + 1;
         const size_t sl = (size_t)sl_i;
-        nk = *reinterpret_cast<const double2 *>(a.norm + sl * S + kc);
-        kp = a.desc + sl * (size_t)(RG * S) + kc;
+        nk = make_double2(a.norm[sl * S + kc], a.norm[sl * S + kc1]);
+        kp0 = a.desc + sl * (size_t)(RG * S) + kc;
+        kp1 = a.desc + sl * (size_t)(RG * S) + kc1;
 #pragma unroll
-        for (int u = 0; u < CH; ++u) { k0[u] = kp[u * S]; k1[u] = kp[u * S + 1]; }
+        for (int u = 0; u < CH; ++u) { k0[u] = kp0[u * S]; k1[u] = kp1[u * S]; }
     };
 
     if (slot >= 0) {
         const double2 vk = *reinterpret_cast<const double2 *>(a.vkey + (size_t)slot * S + j0);
         st_t = stamp();
-        align_and_fetch(slot, vk, s_start, t_lo);
+        align_and_fetch(slot, vk, s_start);
         st_a += stamp() - st_t;
     }
 
@@ -450,14 +454,14 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
         double2 vk_next = make_double2(0.0, 0.0);
         if (slot_next >= 0) vk_next = *reinterpret_cast<const double2 *>(a.vkey + (size_t)slot_next * S + j0);
 
-        double acc0[NSH], acc1[NSH];
+        double acc0[W], acc1[W];
         const double2 nk_cur = nk;
-        const int s_start_cur = s_start, t_lo_cur = t_lo;
+        const int s_start_cur = s_start;
         st_t = stamp();
         if (slot >= 0) {
-            // ---- phase B: 2 x NSH shifted column dots in ring order ------------------
+            // ---- phase B: 2 x W shifted column dots in ring order ---------------------
 #pragma unroll
-            for (int t = 0; t < NSH; ++t) { acc0[t] = 0.0; acc1[t] = 0.0; }
+            for (int t = 0; t < W; ++t) { acc0[t] = 0.0; acc1[t] = 0.0; }
             // Explicit two-stage pipeline over rings: the query window of ring r+1 is requested
             // before the fmas of ring r; pin_ring() keeps LLVM from batching every ring's LDS
             // window ahead of all fmas of the block (which it otherwise does -- and spills).
@@ -472,15 +476,15 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
 #pragma unroll 1
             for (int ch = 0; ch < nch; ++ch) {
                 const bool more = ch + 1 < RG / CH;
-                const float4 *np = kp + (size_t)(ch + 1) * CH * S;
+                const float4 *np0 = kp0 + (size_t)(ch + 1) * CH * S, *np1 = kp1 + (size_t)(ch + 1) * CH * S;
 #pragma unroll
                 for (int u = 0; u < CH; ++u) {
                     const float a0[4] = {k0[u].x, k0[u].y, k0[u].z, k0[u].w};
                     const float a1[4] = {k1[u].x, k1[u].y, k1[u].z, k1[u].w};
-                    if (more) { k0[u] = np[u * S]; k1[u] = np[u * S + 1]; }
+                    if (more) { k0[u] = np0[u * S]; k1[u] = np1[u * S]; }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        double q[NSH + 2];
+                        double q[W + 1];
 #pragma unroll
                         for (int v = 0; v < NQ; ++v) { q[2 * v] = qn[v].x; q[2 * v + 1] = qn[v].y; }
                         pin_ring(acc0, acc1);
@@ -489,7 +493,7 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
                         for (int v = 0; v < NQ; ++v) qn[v] = qp[v];
                         const double kd0 = (double)a0[i], kd1 = (double)a1[i];
 #pragma unroll
-                        for (int t = 0; t < NSH; ++t) {
+                        for (int t = 0; t < W; ++t) {
                             acc0[t] = fma(kd0, q[t], acc0[t]);
                             acc1[t] = fma(kd1, q[t + 1], acc1[t]);
                         }
@@ -500,7 +504,7 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
 
         { const unsigned long long t1 = stamp(); st_b += t1 - st_t; st_t = t1; }
         // ---- next candidate: alignment + first loads, hidden under this one's phases C/D ----
-        if (slot_next >= 0) align_and_fetch(slot_next, vk_next, s_start, t_lo);
+        if (slot_next >= 0) align_and_fetch(slot_next, vk_next, s_start);
         { const unsigned long long t1 = stamp(); st_a += t1 - st_t; st_t = t1; }
 
         // ---- phases C/D in two passes of HSH shifts ------------------------------
@@ -533,44 +537,66 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
         if (slot >= 0) {
             double dmin = kInf;
             int smin = 0x7fffffff;
-            // kept rolled on purpose: unrolled, the two passes are interleaved by the scheduler and spill
-            const int nh = (a.ablate & 4) ? 0 : 2;
-#pragma unroll 1
-            for (int h = 0; h < nh; ++h) {
+            // Two passes (HSH, then W - HSH shifts), each a compile-time instance so the accumulators keep
+            // static register indices; a scheduling fence between them keeps LLVM from interleaving both
+            // (it would, and spill).  Within a pass: all query norms first, then every quotient (independent
+            // division chains the scheduler can interleave), then the stores / effective-sector counts.
+            // Similarity rows are stored de-interleaved (even sectors, then odd sectors) so the 8-byte
+            // stores of consecutive lanes hit consecutive banks.
+            auto cd_pass = [&](auto htag) {
+                constexpr int h = decltype(htag)::value;
+                constexpr int T0 = h * HSH;
+                constexpr int NT = h == 0 ? HSH : W - HSH;
                 wave_fence();
+                double nqv[NT + 1];
+#pragma unroll
+                for (int i = 0; i <= NT; ++i) nqv[i] = nqe[j0 + T0 + i];
+                double s0[NT], s1[NT];
+                bool ok0[NT], ok1[NT];
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) {
+                    ok0[tt] = !((nqv[tt] == 0.0) | (nk_cur.x == 0.0));                  // D.h:1523
+                    ok1[tt] = !((nqv[tt + 1] == 0.0) | (nk_cur.y == 0.0));
+                    s0[tt] = acc0[T0 + tt] / (nqv[tt] * nk_cur.x);
+                    s1[tt] = acc1[T0 + tt] / (nqv[tt + 1] * nk_cur.y);
+                }
                 int eff = 0;
 #pragma unroll
-                for (int tt = 0; tt < HSH; ++tt) {
-                    const int t = h * HSH + tt;
-                    const int x0 = j0 + t, x1 = x0 + 1;                    // query columns (extended index)
-                    const double nq0 = nqe[x0], nq1 = nqe[x1];
-                    const bool ok0 = !((nq0 == 0.0) | (nk_cur.x == 0.0));  // D.h:1523
-                    const bool ok1 = !((nq1 == 0.0) | (nk_cur.y == 0.0));
-                    const double av0 = h ? acc0[HSH + tt] : acc0[tt];      // static register indices + select
-                    const double av1 = h ? acc1[HSH + tt] : acc1[tt];
-                    const double s0 = av0 / (nq0 * nk_cur.x);
-                    const double s1 = av1 / (nq1 * nk_cur.y);
+                for (int tt = 0; tt < NT; ++tt) {
+                    const int x0 = j0 + T0 + tt;                                        // even sector iff T0 + tt is even
                     const int c0 = x0 >= S ? x0 - S : x0;
+                    const int x1 = x0 + 1;
                     const int c1 = x1 >= S ? x1 - S : x1;
-                    simbuf[tt * SB + c0] = ok0 ? s0 : 0.0;                 // skipped sectors add +0.0: same bits
-                    simbuf[tt * SB + c1] = ok1 ? s1 : 0.0;                 // (lanes >= L mirror lane L-1)
-                    const int cnt = __popcll(__ballot(active && ok0)) + __popcll(__ballot(active && ok1));
+                    constexpr int HALF = S / 2;
+                    double *row = simbuf + tt * SB;
+                    row[(c0 >> 1) + (c0 & 1) * HALF] = ok0[tt] ? s0[tt] : 0.0;          // skipped sectors add +0.0: same bits
+                    row[(c1 >> 1) + (c1 & 1) * HALF] = ok1[tt] ? s1[tt] : 0.0;          // (lanes >= L mirror lane L-1)
+                    const int cnt = __popcll(__ballot(active && ok0[tt])) + __popcll(__ballot(active && ok1[tt]));
                     eff = (lane == tt) ? cnt : eff;
                 }
                 wave_fence();
                 { const unsigned long long t1 = stamp(); st_c += t1 - st_t; st_t = t1; }
-                if (lane < HSH) {
-                    const int t = h * HSH + lane;
-                    const double2 *row = reinterpret_cast<const double2 *>(simbuf + lane * SB);
+                if (lane < NT) {
+                    const int t = T0 + lane;
+                    const double2 *ev = reinterpret_cast<const double2 *>(simbuf + lane * SB);
+                    const double2 *od = ev + S / 4;                                     // odd sectors start S/2 doubles in
                     double sum = 0.0;
 #pragma unroll
-                    for (int i = 0; i < S / 2; ++i) { const double2 rv = row[i]; sum = sum + rv.x; sum = sum + rv.y; }
-                    const double d = 1.0 - sum / (double)eff;              // 0/0 -> NaN, never wins
-                    const bool in_space = (t >= t_lo_cur) && (t < t_lo_cur + W);
+                    for (int i = 0; i < S / 4; ++i) {                                   // sectors 4i .. 4i+3 in order
+                        const double2 e = ev[i], o = od[i];
+                        sum = sum + e.x; sum = sum + o.x; sum = sum + e.y; sum = sum + o.y;
+                    }
+                    const double d = 1.0 - sum / (double)eff;                           // 0/0 -> NaN, never wins
                     const int st = wrap(s_start_cur + t, S);
-                    if (in_space && d < kBigDist && ((d < dmin) | ((d == dmin) & (st < smin)))) { dmin = d; smin = st; }
+                    if (d < kBigDist && ((d < dmin) | ((d == dmin) & (st < smin)))) { dmin = d; smin = st; }
                 }
                 { const unsigned long long t1 = stamp(); st_d += t1 - st_t; st_t = t1; }
+            };
+            static_assert(S % 4 == 0, "sector sums read two aligned pairs per step");
+            if (!(a.ablate & 4)) {
+                cd_pass(std::integral_constant<int, 0>{});
+                __builtin_amdgcn_sched_barrier(0);
+                cd_pass(std::integral_constant<int, 1>{});
             }
             wave_argmin(dmin, smin);
             if (lane == 0) {
@@ -695,13 +721,14 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
     }
 }
 
-template <int RG, int NSH, int CH, int S, int MAXT = 512, bool STAMP = false>
+template <int RG, int W, int CH, int S, int MAXT = 512, bool STAMP = false>
 hipError_t launch_wave(const ScArgs &args_in, int num_cu, hipStream_t stream)
 {
     ScArgs a = args_in;
-    constexpr int QS = S + NSH + 2;
+    constexpr int QS = S + W + 1;
+    constexpr int HSH = (W + 1) / 2;
     const size_t fixed = (size_t)(RG * 4 * QS + QS + S) * sizeof(double);
-    const size_t per_wave = (size_t)((2 * S > (NSH / 2) * (S + 2)) ? 2 * S : (NSH / 2) * (S + 2)) * sizeof(double);
+    const size_t per_wave = (size_t)((2 * S > HSH * (S + 2)) ? 2 * S : HSH * (S + 2)) * sizeof(double);
     const size_t lds_cap = 160 * 1024;
     int waves = (int)((lds_cap - fixed - 16) / per_wave);
     if (waves > MAXT / kWave) waves = MAXT / kWave;
@@ -712,7 +739,7 @@ hipError_t launch_wave(const ScArgs &args_in, int num_cu, hipStream_t stream)
     const size_t lds = fixed + per_wave * waves + 16;      // + the candidate dispenser
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)sc_distance_wave_kernel<RG, NSH, CH, S, MAXT, STAMP>,
+        hipError_t e = hipFuncSetAttribute((const void *)sc_distance_wave_kernel<RG, W, CH, S, MAXT, STAMP>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -724,7 +751,7 @@ hipError_t launch_wave(const ScArgs &args_in, int num_cu, hipStream_t stream)
         if (hipMalloc(&d, nw * 8 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(d, 0, nw * 8 * sizeof(unsigned long long), stream);
         a.stamps = d;
-        hipLaunchKernelGGL((sc_distance_wave_kernel<RG, NSH, CH, S, MAXT, STAMP>), dim3(blocks), dim3(waves * kWave), lds, stream, a);
+        hipLaunchKernelGGL((sc_distance_wave_kernel<RG, W, CH, S, MAXT, STAMP>), dim3(blocks), dim3(waves * kWave), lds, stream, a);
         (void)hipStreamSynchronize(stream);
         std::vector<unsigned long long> h(nw * 8);
         (void)hipMemcpy(h.data(), d, nw * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
@@ -773,7 +800,7 @@ hipError_t launch_wave(const ScArgs &args_in, int num_cu, hipStream_t stream)
         }
         return hipGetLastError();
     }
-    hipLaunchKernelGGL((sc_distance_wave_kernel<RG, NSH, CH, S, MAXT, STAMP>), dim3(blocks), dim3(waves * kWave), lds, stream, a);
+    hipLaunchKernelGGL((sc_distance_wave_kernel<RG, W, CH, S, MAXT, STAMP>), dim3(blocks), dim3(waves * kWave), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -939,13 +966,13 @@ hipError_t launch_sc_distance(const DbView &db, const QueryView &q, const int *c
             a.topk_idx = tail->topk_idx; a.topk_d2 = tail->topk_d2; a.topk_k = tail->k; a.exclude_eps = tail->exclude_eps;
         }
     }
-    if (wave_ok && db.RG == 5 && W == 7 && db.S == 60)   return launch_wave<5, 8, 5, 60>(a, num_cu, stream);
+    if (wave_ok && db.RG == 5 && W == 7 && db.S == 60)   return launch_wave<5, 7, 5, 60>(a, num_cu, stream);
     static const bool stamp = [] { const char *e = getenv("SCL_STAMP"); return e && e[0] == '1'; }();
     static const int occ = [] { const char *e = getenv("SCL_SC_WAVES"); return e ? atoi(e) : 8; }();
-    if (wave_ok && db.RG == 16 && W == 13 && db.S == 120 && stamp && occ > 8) return launch_wave<16, 14, 2, 120, 768, true>(a, num_cu, stream);
-    if (wave_ok && db.RG == 16 && W == 13 && db.S == 120 && stamp) return launch_wave<16, 14, 4, 120, 512, true>(a, num_cu, stream);
-    if (wave_ok && db.RG == 16 && W == 13 && db.S == 120 && occ > 8) return launch_wave<16, 14, 2, 120, 768>(a, num_cu, stream);
-    if (wave_ok && db.RG == 16 && W == 13 && db.S == 120) return launch_wave<16, 14, 4, 120, 512>(a, num_cu, stream);
+    if (wave_ok && db.RG == 16 && W == 13 && db.S == 120 && stamp && occ > 8) return launch_wave<16, 13, 2, 120, 768, true>(a, num_cu, stream);
+    if (wave_ok && db.RG == 16 && W == 13 && db.S == 120 && stamp) return launch_wave<16, 13, 4, 120, 512, true>(a, num_cu, stream);
+    if (wave_ok && db.RG == 16 && W == 13 && db.S == 120 && occ > 8) return launch_wave<16, 13, 2, 120, 768>(a, num_cu, stream);
+    if (wave_ok && db.RG == 16 && W == 13 && db.S == 120) return launch_wave<16, 13, 4, 120, 512>(a, num_cu, stream);
     if (db.RG == 5 && W == 7 && db.S >= W)   return launch_fast<5, 7, 512>(a, num_cu, stream);
     if (db.RG == 16 && W == 13 && db.S >= W) return launch_fast<16, 13, 512>(a, num_cu, stream);
     if (db.RG == 20 && W == 19 && db.S >= W && db.S <= 180) return launch_fast<20, 19, 256>(a, num_cu, stream);
