@@ -10,6 +10,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -571,4 +572,34 @@ void sco_db_distance_batch(sco_db *db, int cur, const int *cand, int n,
         if (fast) sco_distance_fast(&db->cfg, sco_db_desc(db, cur), sco_db_desc(db, ci), &dist[i], &shift[i]);
         else      sco_distance(&db->cfg, sco_db_desc(db, cur), sco_db_desc(db, ci), &dist[i], &shift[i]);
     }
+}
+
+/* ---- CPU baseline variant B: the same reference-shaped evaluation, candidates split over threads ---- */
+typedef struct { sco_db *db; int cur; const int *cand; int lo, hi; double *dist; int *shift; int fast; } mt_job;
+
+static void *mt_worker(void *arg)
+{
+    mt_job *j = (mt_job *)arg;
+    for (int i = j->lo; i < j->hi; i++) {
+        int ci = j->cand ? j->cand[i] : i;
+        if (j->fast) sco_distance_fast(&j->db->cfg, sco_db_desc(j->db, j->cur), sco_db_desc(j->db, ci), &j->dist[i], &j->shift[i]);
+        else         sco_distance(&j->db->cfg, sco_db_desc(j->db, j->cur), sco_db_desc(j->db, ci), &j->dist[i], &j->shift[i]);
+    }
+    return NULL;
+}
+
+void sco_db_distance_batch_mt(sco_db *db, int cur, const int *cand, int n,
+                              double *dist, int *shift, int fast, int threads)
+{
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    pthread_t th[256];
+    mt_job jobs[256];
+    for (int t = 0; t < threads; t++) {
+        jobs[t].db = db; jobs[t].cur = cur; jobs[t].cand = cand; jobs[t].dist = dist; jobs[t].shift = shift; jobs[t].fast = fast;
+        jobs[t].lo = (int)((long long)n * t / threads);
+        jobs[t].hi = (int)((long long)n * (t + 1) / threads);
+        pthread_create(&th[t], NULL, mt_worker, &jobs[t]);
+    }
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
 }

@@ -94,6 +94,10 @@ void    sco_db_detect_full(sco_db *db, int cur, int *loop_id, int *nn_idx, int *
 void    sco_db_distance_batch(sco_db *db, int cur, const int *cand, int n,
                               double *dist, int *shift, int fast);
 
+/* the same batch split over `threads` pthreads (CPU baseline on all host cores) */
+void    sco_db_distance_batch_mt(sco_db *db, int cur, const int *cand, int n,
+                                 double *dist, int *shift, int fast, int threads);
+
 #ifdef __cplusplus
 }
 #endif

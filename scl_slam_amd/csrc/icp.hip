@@ -13,7 +13,8 @@
 //                    ties -> lowest target index (a total order: the result does not depend on the
 //                    order points were scattered into a cell)
 //   K5  reduce       fp64 sums of the augmented outer product [p;1][q;1]^T over correspondences
-//                    (gives the cross-covariance, both centroids and the count in one pass) + sum d2
+//                    (gives the cross-covariance, both centroids and the count in one pass) + sum d2;
+//                    on the matrix cores: one v_mfma_f64_4x4x4_4b_f64 per 16 correspondences
 //   K5b solve        one wave: centred covariance, closed-form rotation (Horn quaternion, cyclic
 //                    Jacobi, fp64), incremental transform, PCL's convergence criteria, final = T*final
 //   K6  transform    working source cloud <- T_inc * cloud (fp32, no FMA)
@@ -23,6 +24,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "device_common.hpp"
@@ -284,6 +286,64 @@ __global__ __launch_bounds__(256) void corr_reduce_kernel(const float4 *work, co
         partials[blockIdx.x * kNSum + threadIdx.x] = ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x];
 }
 
+// MFMA form of K5.  v_mfma_f64_4x4x4_4b_f64 computes, in each of its four 16-lane blocks,
+// D[i][j] += sum_k A[i][k] * B[k][j] (k ascending, a plain fma chain -- probed on gfx950, see
+// scripts/probes/probe_mfma_f64.hip).  With A[i][k] = component i of [p;1] and B[k][j] = component j of
+// [q;1] for correspondence k of the block, one instruction adds the augmented outer products of 16
+// correspondences: cross-covariance, both centroids and the count at once.  Operand layout (probed):
+// A[i][k] of block b sits in lane 16k + 4b + i, B[k][j] in lane 16k + 4b + j, D[i][j] in lane 16i + 4b + j.
+__global__ __launch_bounds__(256) void corr_reduce_mfma_kernel(const float4 *work, const unsigned char *src_raw,
+                                                               const unsigned char *tgt_raw, int stride, int n,
+                                                               const int *nn_idx, const float *nn_d2, float maxd2,
+                                                               const int *si, const int *ti, int mode,
+                                                               const IcpState *st, double *partials, int check_done)
+{
+    if (check_done && st->done) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int k = lane >> 4, blk = (lane >> 2) & 3, comp = lane & 3;
+    const int wave_global = blockIdx.x * 4 + wv, nwaves = gridDim.x * 4;
+    double acc0 = 0.0, acc1 = 0.0;
+    double sum_d2 = 0.0;
+    for (int base = wave_global * 32; base < n; base += nwaves * 32) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {                       // two independent accumulator chains
+            const int i = base + half * 16 + 4 * blk + k;            // this lane's correspondence
+            double av = 0.0, bv = 0.0;
+            if (i < n) {
+                bool ok = true;
+                int pi = i, qi;
+                float d2 = 0.f;
+                if (mode == 0) { qi = nn_idx[i]; d2 = nn_d2[i]; ok = qi >= 0 && (d2 <= maxd2); }
+                else { pi = si[i]; qi = ti[i]; }
+                if (ok) {
+                    float pc, qc;
+                    if (comp == 3) { pc = 1.0f; qc = 1.0f; }
+                    else {
+                        pc = mode == 0 ? reinterpret_cast<const float *>(work + pi)[comp]
+                                       : reinterpret_cast<const float *>(src_raw + (size_t)pi * stride)[comp];
+                        qc = reinterpret_cast<const float *>(tgt_raw + (size_t)qi * stride)[comp];
+                    }
+                    av = (double)pc; bv = (double)qc;
+                    if (comp == 0) sum_d2 += (double)d2;
+                }
+            }
+            if (half == 0) acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, acc0, 0, 0, 0);
+            else           acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, acc1, 0, 0, 0);
+        }
+    }
+    double d = acc0 + acc1;                                          // lane 16i + 4b + j holds block b's D[i][j]
+    d += __shfl_xor(d, 4, kWave);                                    // fold the four blocks
+    d += __shfl_xor(d, 8, kWave);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum_d2 += __shfl_xor(sum_d2, off, kWave);
+    __shared__ double s[4][kNSum];
+    if (blk == 0) s[wv][k * 4 + comp] = d;                           // lane 16i + j: entry (i, j); here k == i
+    if (lane == 0) s[wv][16] = sum_d2;
+    __syncthreads();
+    if (threadIdx.x < kNSum)
+        partials[blockIdx.x * kNSum + threadIdx.x] = ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x];
+}
+
 // ---- K5b ---------------------------------------------------------------------------
 __device__ void rotation_from_S(const double S[3][3], double R[3][3])
 {
@@ -423,6 +483,18 @@ __global__ void state_init_kernel(IcpState *st)
 }
 
 // ---- host helpers -------------------------------------------------------------------
+static bool use_mfma_reduce()
+{
+    static const bool v = [] { const char *e = getenv("SCL_ICP_REDUCE"); return !(e && e[0] == 'v'); }();   // SCL_ICP_REDUCE=valu
+    return v;
+}
+
+#define LAUNCH_REDUCE(grid, stream, ...)                                                                  \
+    do {                                                                                                  \
+        if (use_mfma_reduce()) hipLaunchKernelGGL(corr_reduce_mfma_kernel, dim3(grid), dim3(256), 0, stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL(corr_reduce_kernel, dim3(grid), dim3(256), 0, stream, __VA_ARGS__);       \
+    } while (0)
+
 int upload(IcpWorkspace *ws, int k, const void *host, size_t bytes, hipStream_t stream, std::string *err)
 {
     int rc = ensure(ws, k, bytes + 16, err);
@@ -512,8 +584,8 @@ int icp_align(IcpWorkspace *ws, hipStream_t stream, int num_cu, const void *src,
     for (int it = 0; it < p.max_iterations; ++it) {
         hipLaunchKernelGGL(nn_search_kernel, dim3(pb), dim3(256), 0, stream, work, n_src, st,
                            (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], nni, nnd, 1);
-        hipLaunchKernelGGL(corr_reduce_kernel, dim3(rb), dim3(256), 0, stream, work, d_src, d_tgt, stride, n_src,
-                           nni, nnd, maxd2, (const int *)nullptr, (const int *)nullptr, 0, st, part, 1);
+        LAUNCH_REDUCE(rb, stream, work, d_src, d_tgt, stride, n_src,
+                      nni, nnd, maxd2, (const int *)nullptr, (const int *)nullptr, 0, st, part, 1);
         hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, stream, st, part, rb, 0, p.max_iterations,
                            p.transformation_epsilon, p.euclidean_fitness_epsilon);
         // applies inc_T iff the solve of this very iteration ran (also when it just declared convergence)
@@ -528,8 +600,8 @@ int icp_align(IcpWorkspace *ws, hipStream_t stream, int num_cu, const void *src,
     hipLaunchKernelGGL(work_transform_kernel, dim3(pb), dim3(256), 0, stream, work, d_src, n_src, stride, st, 1, 0);
     hipLaunchKernelGGL(nn_search_kernel, dim3(pb), dim3(256), 0, stream, work, n_src, st,
                        (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], nni, nnd, 0);
-    hipLaunchKernelGGL(corr_reduce_kernel, dim3(rb), dim3(256), 0, stream, work, d_src, d_tgt, stride, n_src,
-                       nni, nnd, FLT_MAX, (const int *)nullptr, (const int *)nullptr, 0, st, part, 0);
+    LAUNCH_REDUCE(rb, stream, work, d_src, d_tgt, stride, n_src,
+                  nni, nnd, FLT_MAX, (const int *)nullptr, (const int *)nullptr, 0, st, part, 0);
     hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, stream, st, part, rb, 2, 0, 0.0, 0.0);
     ICP_HIP(hipGetLastError());
     ICP_HIP(hipMemcpyAsync(h, st, sizeof(IcpState), hipMemcpyDeviceToHost, stream));
@@ -589,10 +661,10 @@ int icp_rigid_svd(IcpWorkspace *ws, hipStream_t stream, int num_cu, const void *
     IcpState *st = static_cast<IcpState *>(ws->buf[B_STATE]);
     int rb = (n_corr + 255) / 256; rb = rb < 1 ? 1 : (rb > kRedBlocks ? kRedBlocks : rb);
     hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(64), 0, stream, st);
-    hipLaunchKernelGGL(corr_reduce_kernel, dim3(rb), dim3(256), 0, stream, (const float4 *)nullptr,
-                       (const unsigned char *)ws->buf[B_SRC], (const unsigned char *)ws->buf[B_TGT], stride, n_corr,
-                       (const int *)nullptr, (const float *)nullptr, 0.f, (const int *)ws->buf[B_SI], (const int *)ws->buf[B_TI], 1,
-                       st, (double *)ws->buf[B_PART], 0);
+    LAUNCH_REDUCE(rb, stream, (const float4 *)nullptr,
+                  (const unsigned char *)ws->buf[B_SRC], (const unsigned char *)ws->buf[B_TGT], stride, n_corr,
+                  (const int *)nullptr, (const float *)nullptr, 0.f, (const int *)ws->buf[B_SI], (const int *)ws->buf[B_TI], 1,
+                  st, (double *)ws->buf[B_PART], 0);
     hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, stream, st, (const double *)ws->buf[B_PART], rb, 1, 0, 0.0, 0.0);
     ICP_HIP(hipGetLastError());
     IcpState *h = static_cast<IcpState *>(ws->pinned);

@@ -61,6 +61,7 @@ def load():
     L.sco_db_detect_inter.argtypes = [c_void_p, c_int, ip, fp, dp]
     L.sco_db_detect_full.argtypes = [c_void_p, c_int, ip, ip, ip, dp]
     L.sco_db_distance_batch.argtypes = [c_void_p, c_int, ip, c_int, dp, ip, c_int]
+    L.sco_db_distance_batch_mt.argtypes = [c_void_p, c_int, ip, c_int, dp, ip, c_int, c_int]
     _lib = L
     return L
 
@@ -166,6 +167,13 @@ class OracleDB:
         lid = c_int(); nn = c_int(); sh = c_int(); d = c_double()
         self.L.sco_db_detect_full(self.h, cur, byref(lid), byref(nn), byref(sh), byref(d))
         return lid.value, nn.value, sh.value, d.value
+
+    def distance_batch_mt(self, cur, cand, fast, threads):
+        cand = np.ascontiguousarray(cand, dtype=np.int32); n = cand.size
+        dist = np.empty(n, dtype=np.float64); shift = np.empty(n, dtype=np.int32)
+        self.L.sco_db_distance_batch_mt(self.h, cur, _p(cand, c_int), n, _p(dist, c_double), _p(shift, c_int),
+                                        1 if fast else 0, threads)
+        return dist, shift
 
     def distance_batch(self, cur, cand=None, n=None, fast=True):
         if cand is not None:
