@@ -182,6 +182,20 @@ int  scl_nn_correspondences(scl_engine *e, const void *src, int n_src, const voi
 int  scl_rigid_svd(scl_engine *e, const void *src, int n_src, const void *tgt, int n_tgt,
                    int stride_bytes, const int *src_index, const int *tgt_index, int n_corr,
                    float T[16]);
+/* CorrespondenceRejectorSampleConsensus::getCorrespondences, DM.h:1218-1225 (ransacMaxIter DM.h:187,
+ * ransacOutlierTreshold DM.h:188).  Deterministic: hypothesis h draws its 3 correspondences from a
+ * counter-based generator of (seed, h); every one of max_iterations hypotheses is scored; best = most
+ * inliers, ties -> lowest h.  inlier_mask[n_corr] (0/1), T_model = the winning 3-point model (may be NULL). */
+int  scl_ransac_correspondences(scl_engine *e, const void *src, int n_src, const void *tgt, int n_tgt,
+                                int stride_bytes, const int *src_index, const int *tgt_index, int n_corr,
+                                int max_iterations, double inlier_threshold, uint64_t seed,
+                                int *inlier_mask, int *n_inliers, int *best_hypothesis, float T_model[16]);
+/* The compute core of geometricVerificationService, DM.h:1211-1243: NN correspondences -> RANSAC ->
+ * SVD transform on the inliers -> gate `inliers >= inlier_ratio * correspondences` (inlierTreshold DM.h:189). */
+int  scl_geometric_verification(scl_engine *e, const void *src, int n_src, const void *tgt, int n_tgt,
+                                int stride_bytes, int ransac_iterations, double inlier_threshold,
+                                double inlier_ratio, uint64_t seed, float T[16], int *success,
+                                int *n_correspondences, int *n_inliers);
 /* paramsServer::transformPointCloud, DM.h:234-253 (xyz transformed, rest copied) */
 int  scl_transform_cloud(scl_engine *e, const void *in, int n, int stride_bytes,
                          const float T[16], void *out);

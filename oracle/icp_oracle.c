@@ -308,3 +308,104 @@ int icpo_icp_align(const void *src, int n_src, const void *tgt, int n_tgt, int s
     free(work); free(nn); free(d2); free(si); free(ti);
     return 0;
 }
+
+/* ---- RANSAC (deterministic restatement, see icp_oracle.h) ------------------------------------------- */
+static unsigned long long splitmix64(unsigned long long x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+static void ransac_sample(unsigned long long seed, int h, int n, int idx[3])
+{
+    unsigned long long ctr = 0;
+    for (int m = 0; m < 3; ) {
+        const unsigned long long r = splitmix64(seed ^ splitmix64(((unsigned long long)h << 20) + ctr));
+        ctr++;
+        const int cand = (int)(r % (unsigned long long)n);
+        int dup = 0;
+        for (int q = 0; q < m; q++) dup |= idx[q] == cand;
+        if (!dup) idx[m++] = cand;
+    }
+}
+
+/* rigid transform of 3 pairs in fp64: T[12] row-major 3x4 */
+static void rigid3(const float *p[3], const float *q[3], double T[12])
+{
+    double pm[3] = {0, 0, 0}, qm[3] = {0, 0, 0};
+    for (int i = 0; i < 3; i++) for (int a = 0; a < 3; a++) { pm[a] += (double)p[i][a]; qm[a] += (double)q[i][a]; }
+    for (int a = 0; a < 3; a++) { pm[a] /= 3.0; qm[a] /= 3.0; }
+    double S[3][3] = {{0}};
+    for (int i = 0; i < 3; i++) for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++)
+        S[a][b] += ((double)p[i][a] - pm[a]) * ((double)q[i][b] - qm[b]);
+    double R[3][3];
+    rotation_from_S(S, R);
+    for (int a = 0; a < 3; a++) {
+        for (int b = 0; b < 3; b++) T[a * 4 + b] = R[a][b];
+        T[a * 4 + 3] = qm[a] - (R[a][0] * pm[0] + R[a][1] * pm[1] + R[a][2] * pm[2]);
+    }
+}
+
+static int is_inlier(const double T[12], const float *p, const float *q, double thr2)
+{
+    const double x = p[0], y = p[1], z = p[2];
+    const double dx = (T[0] * x + T[1] * y + T[2] * z + T[3]) - (double)q[0];
+    const double dy = (T[4] * x + T[5] * y + T[6] * z + T[7]) - (double)q[1];
+    const double dz = (T[8] * x + T[9] * y + T[10] * z + T[11]) - (double)q[2];
+    return (dx * dx + dy * dy) + dz * dz < thr2;
+}
+
+int icpo_ransac(const void *src, const void *tgt, int stride, const int *si, const int *ti,
+                int n_corr, int max_iterations, double inlier_threshold, unsigned long long seed,
+                int *inlier_mask, int *best_hypothesis, double T_best[12])
+{
+    if (n_corr < 3) return -1;
+    const double thr2 = inlier_threshold * inlier_threshold;
+    int best = -1, best_h = -1;
+    double Tb[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    for (int h = 0; h < max_iterations; h++) {
+        int idx[3];
+        ransac_sample(seed, h, n_corr, idx);
+        const float *p[3], *q[3];
+        for (int m = 0; m < 3; m++) { p[m] = pt(src, si[idx[m]], stride); q[m] = pt(tgt, ti[idx[m]], stride); }
+        double T[12];
+        rigid3(p, q, T);
+        int cnt = 0;
+        for (int i = 0; i < n_corr; i++) cnt += is_inlier(T, pt(src, si[i], stride), pt(tgt, ti[i], stride), thr2);
+        if (cnt > best) { best = cnt; best_h = h; memcpy(Tb, T, sizeof Tb); }
+    }
+    if (inlier_mask)
+        for (int i = 0; i < n_corr; i++) inlier_mask[i] = is_inlier(Tb, pt(src, si[i], stride), pt(tgt, ti[i], stride), thr2);
+    if (best_hypothesis) *best_hypothesis = best_h;
+    if (T_best) memcpy(T_best, Tb, sizeof Tb);
+    return best < 0 ? 0 : best;
+}
+
+int icpo_geometric_verification(const void *src, int n_src, const void *tgt, int n_tgt, int stride,
+                                int ransac_iterations, double inlier_threshold, double inlier_ratio,
+                                unsigned long long seed, float T[16], int *success, int *n_corr, int *n_inliers)
+{
+    int *nn = (int *)malloc(sizeof(int) * (size_t)(n_src > 0 ? n_src : 1));
+    int *si = (int *)malloc(sizeof(int) * (size_t)(n_src > 0 ? n_src : 1));
+    int *ti = (int *)malloc(sizeof(int) * (size_t)(n_src > 0 ? n_src : 1));
+    int *mask = (int *)malloc(sizeof(int) * (size_t)(n_src > 0 ? n_src : 1));
+    icpo_nn(src, n_src, tgt, n_tgt, stride, n_tgt > 2048, nn, NULL);          /* DM.h:1211-1215 */
+    int nc = 0;
+    for (int i = 0; i < n_src; i++) if (nn[i] >= 0) { si[nc] = i; ti[nc] = nn[i]; nc++; }
+    int ok = 0, ninl = 0;
+    for (int k = 0; k < 16; k++) T[k] = (k % 5 == 0) ? 1.0f : 0.0f;
+    if (nc >= 3) {
+        ninl = icpo_ransac(src, tgt, stride, si, ti, nc, ransac_iterations, inlier_threshold, seed, mask, NULL, NULL);  /* DM.h:1218-1225 */
+        int m = 0;
+        for (int i = 0; i < nc; i++) if (mask[i]) { si[m] = si[i]; ti[m] = ti[i]; m++; }
+        if (m >= 3) estimate_rigid(src, tgt, stride, si, ti, m, T);             /* DM.h:1228-1230 */
+        ok = !((double)ninl < inlier_ratio * (double)nc);                       /* DM.h:1238 */
+    }
+    if (success) *success = ok;
+    if (n_corr) *n_corr = nc;
+    if (n_inliers) *n_inliers = ninl;
+    free(nn); free(si); free(ti); free(mask);
+    return 0;
+}

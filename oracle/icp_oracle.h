@@ -47,6 +47,23 @@ void icpo_transform(const void *in, int n, int stride_bytes, const float T[16], 
 int  icpo_icp_align(const void *src, int n_src, const void *tgt, int n_tgt, int stride_bytes,
                     const icpo_params *p, float T[16], float *fitness, int *converged, int *iterations);
 
+/* CorrespondenceRejectorSampleConsensus (DM.h:1218-1225), restated as a deterministic RANSAC:
+ * hypothesis h draws 3 distinct correspondences with a counter-based generator (splitmix64 of
+ * (seed, h, draw)), fits the rigid transform of the 3 pairs, and scores every correspondence with
+ * |T p - q|^2 < thr^2 (fp64).  ALL max_iterations hypotheses are scored (no probabilistic early exit:
+ * at least as good as PCL's adaptive loop); best = most inliers, ties -> lowest h.  PCL's own random
+ * sequence cannot be reproduced offline, so parity with the reference is statistical.
+ * inlier_mask[n_corr] receives 0/1; returns the inlier count (or -1 if n_corr < 3). */
+int  icpo_ransac(const void *src, const void *tgt, int stride_bytes, const int *src_index, const int *tgt_index,
+                 int n_corr, int max_iterations, double inlier_threshold, unsigned long long seed,
+                 int *inlier_mask, int *best_hypothesis, double T_best[12]);
+
+/* geometricVerificationService core (DM.h:1211-1243): NN correspondences -> RANSAC -> SVD on the
+ * inliers -> inlier-ratio gate.  success = n_inliers >= inlier_ratio * n_corr (DM.h:1238). */
+int  icpo_geometric_verification(const void *src, int n_src, const void *tgt, int n_tgt, int stride_bytes,
+                                 int ransac_iterations, double inlier_threshold, double inlier_ratio,
+                                 unsigned long long seed, float T[16], int *success, int *n_corr, int *n_inliers);
+
 /* 3x3 SVD-based rotation for a cross-covariance matrix (exposed for tests):
  * H = sum (q - qbar)(p - pbar)^T  (dst x src), R = U diag(1,1,det) V^T */
 void icpo_rotation_from_covariance(const double H[9], double R[9]);

@@ -906,6 +906,38 @@ int scl_rigid_svd(scl_engine *e, const void *src, int n_src, const void *tgt, in
     return rc;
 }
 
+int scl_ransac_correspondences(scl_engine *e, const void *src, int n_src, const void *tgt, int n_tgt,
+                               int stride_bytes, const int *src_index, const int *tgt_index, int n_corr,
+                               int max_iterations, double inlier_threshold, uint64_t seed,
+                               int *inlier_mask, int *n_inliers, int *best_hypothesis, float T_model[16])
+{
+    if (!e || !src || !tgt || !src_index || !tgt_index) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    std::string err;
+    int rc = icp_ransac(&e->icp_ws, e->stream, src, n_src, tgt, n_tgt, stride_bytes, src_index, tgt_index, n_corr,
+                        max_iterations, inlier_threshold, (unsigned long long)seed, inlier_mask, n_inliers,
+                        best_hypothesis, T_model, &err);
+    if (rc) e->last_error = err;
+    return rc;
+}
+
+int scl_geometric_verification(scl_engine *e, const void *src, int n_src, const void *tgt, int n_tgt,
+                               int stride_bytes, int ransac_iterations, double inlier_threshold,
+                               double inlier_ratio, uint64_t seed, float T[16], int *success,
+                               int *n_correspondences, int *n_inliers)
+{
+    if (!e || !src || !tgt || !T) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    std::string err;
+    int rc = icp_geometric_verification(&e->icp_ws, e->stream, e->num_cu, src, n_src, tgt, n_tgt, stride_bytes,
+                                        ransac_iterations, inlier_threshold, inlier_ratio, (unsigned long long)seed,
+                                        T, success, n_correspondences, n_inliers, &err);
+    if (rc) e->last_error = err;
+    return rc;
+}
+
 int scl_transform_cloud(scl_engine *e, const void *in, int n, int stride_bytes, const float T[16], void *out)
 {
     if (!e || !in || !out || !T) return SCL_ERR_INVALID_ARG;

@@ -47,7 +47,7 @@ struct IcpState {
     double sums[kNSum];
 };
 
-enum Buf { B_SRC = 0, B_TGT, B_WORK, B_TSORT, B_CSTART, B_CFILL, B_NNI, B_NND, B_PART, B_STATE, B_BBOX, B_SI, B_TI, B_OUT };
+enum Buf { B_SRC = 0, B_TGT, B_WORK, B_TSORT, B_CSTART, B_CFILL, B_NNI, B_NND, B_PART, B_STATE, B_BBOX, B_SI, B_TI, B_OUT, B_MASK, B_HYP };
 
 int ensure(IcpWorkspace *ws, int k, size_t bytes, std::string *err)
 {
@@ -262,6 +262,7 @@ __global__ __launch_bounds__(256) void corr_reduce_kernel(const float4 *work, co
             p = make_float3(pw.x, pw.y, pw.z);
             q = load_xyz(tgt_raw, j, stride);
         } else {
+            if (nn_idx && nn_idx[i] == 0) continue;          // mode 1: nn_idx doubles as an optional inlier mask
             p = load_xyz(src_raw, si[i], stride);
             q = load_xyz(tgt_raw, ti[i], stride);
         }
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256) void corr_reduce_mfma_kernel(const float4 *wor
                 int pi = i, qi;
                 float d2 = 0.f;
                 if (mode == 0) { qi = nn_idx[i]; d2 = nn_d2[i]; ok = qi >= 0 && (d2 <= maxd2); }
-                else { pi = si[i]; qi = ti[i]; }
+                else { pi = si[i]; qi = ti[i]; ok = !(nn_idx && nn_idx[i] == 0); }   // optional inlier mask
                 if (ok) {
                     float pc, qc;
                     if (comp == 3) { pc = 1.0f; qc = 1.0f; }
@@ -480,6 +481,132 @@ __global__ void state_init_kernel(IcpState *st)
         st->mse_prev = DBL_MAX; st->fitness = (double)FLT_MAX;
         st->iter = 0; st->done = 0; st->converged = 0; st->n_corr = 0;
     }
+}
+
+// ---- RANSAC correspondence rejection (CorrespondenceRejectorSampleConsensus, DM.h:1218-1225) ----------
+// Deterministic restatement (see oracle/icp_oracle.h): hypothesis h = 3 distinct correspondences drawn
+// with splitmix64(seed, h, draw), rigid fit of the 3 pairs in fp64, every hypothesis scored against every
+// correspondence.  kHypPerBlock hypotheses share one sweep over the pairs.
+constexpr int kHypPerBlock = 8;
+
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__device__ void ransac_model(const unsigned char *src, const unsigned char *tgt, int stride, const int *si, const int *ti,
+                             int n, unsigned long long seed, int h, double T[12])
+{
+    int idx[3];
+    unsigned long long ctr = 0;
+    for (int m = 0; m < 3;) {
+        const unsigned long long r = splitmix64(seed ^ splitmix64(((unsigned long long)h << 20) + ctr));
+        ctr++;
+        const int cand = (int)(r % (unsigned long long)n);
+        bool dup = false;
+        for (int q = 0; q < m; ++q) dup |= idx[q] == cand;
+        if (!dup) idx[m++] = cand;
+    }
+    double pm[3] = {0, 0, 0}, qm[3] = {0, 0, 0}, P[3][3], Q[3][3];
+    for (int i = 0; i < 3; ++i) {
+        const float3 p = load_xyz(src, si[idx[i]], stride), q = load_xyz(tgt, ti[idx[i]], stride);
+        P[i][0] = p.x; P[i][1] = p.y; P[i][2] = p.z; Q[i][0] = q.x; Q[i][1] = q.y; Q[i][2] = q.z;
+        for (int a = 0; a < 3; ++a) { pm[a] += P[i][a]; qm[a] += Q[i][a]; }
+    }
+    for (int a = 0; a < 3; ++a) { pm[a] /= 3.0; qm[a] /= 3.0; }
+    double S[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, R[3][3];
+    for (int i = 0; i < 3; ++i) for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b)
+        S[a][b] += (P[i][a] - pm[a]) * (Q[i][b] - qm[b]);
+    rotation_from_S(S, R);
+    for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) T[a * 4 + b] = R[a][b];
+        T[a * 4 + 3] = qm[a] - (R[a][0] * pm[0] + R[a][1] * pm[1] + R[a][2] * pm[2]);
+    }
+}
+
+__device__ __forceinline__ bool ransac_inlier(const double *T, float3 p, float3 q, double thr2)
+{
+    const double x = p.x, y = p.y, z = p.z;
+    const double dx = (T[0] * x + T[1] * y + T[2] * z + T[3]) - (double)q.x;
+    const double dy = (T[4] * x + T[5] * y + T[6] * z + T[7]) - (double)q.y;
+    const double dz = (T[8] * x + T[9] * y + T[10] * z + T[11]) - (double)q.z;
+    return (dx * dx + dy * dy) + dz * dz < thr2;
+}
+
+__global__ __launch_bounds__(256) void ransac_score_kernel(const unsigned char *src, const unsigned char *tgt, int stride,
+                                                           const int *si, const int *ti, int n, unsigned long long seed,
+                                                           int n_hyp, double thr2, int *counts)
+{
+    __shared__ double sT[kHypPerBlock][12];
+    __shared__ int scnt[kHypPerBlock];
+    const int h0 = blockIdx.x * kHypPerBlock;
+    if (threadIdx.x < kHypPerBlock) {
+        scnt[threadIdx.x] = 0;
+        if (h0 + (int)threadIdx.x < n_hyp) ransac_model(src, tgt, stride, si, ti, n, seed, h0 + threadIdx.x, sT[threadIdx.x]);
+        else for (int k = 0; k < 12; ++k) sT[threadIdx.x][k] = 0.0;
+    }
+    __syncthreads();
+    int cnt[kHypPerBlock];
+#pragma unroll
+    for (int u = 0; u < kHypPerBlock; ++u) cnt[u] = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float3 p = load_xyz(src, si[i], stride), q = load_xyz(tgt, ti[i], stride);
+#pragma unroll
+        for (int u = 0; u < kHypPerBlock; ++u) cnt[u] += ransac_inlier(sT[u], p, q, thr2) ? 1 : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < kHypPerBlock; ++u) {
+        int c = cnt[u];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, kWave);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&scnt[u], c);
+    }
+    __syncthreads();
+    if (threadIdx.x < kHypPerBlock && h0 + (int)threadIdx.x < n_hyp) counts[h0 + threadIdx.x] = scnt[threadIdx.x];
+}
+
+// best hypothesis (most inliers, ties -> lowest index), its model, and the inlier mask
+__global__ void ransac_pick_kernel(const int *counts, int n_hyp, int *best /*[2]: h, count*/)
+{
+    __shared__ long long sk[16];
+    long long key = -1;                                  // (count << 32) | (0x7fffffff - h): max = most inliers, lowest h
+    for (int h = threadIdx.x; h < n_hyp; h += blockDim.x) {
+        const long long k2 = ((long long)counts[h] << 32) | (long long)(0x7fffffff - h);
+        key = k2 > key ? k2 : key;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const long long o = __shfl_xor(key, off, kWave); key = o > key ? o : key; }
+    if ((threadIdx.x & 63) == 0) sk[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)blockDim.x / 64; ++w) key = sk[w] > key ? sk[w] : key;
+        best[0] = key < 0 ? -1 : 0x7fffffff - (int)(key & 0xffffffffll);
+        best[1] = key < 0 ? 0 : (int)(key >> 32);
+    }
+}
+
+__global__ __launch_bounds__(256) void ransac_mask_kernel(const unsigned char *src, const unsigned char *tgt, int stride,
+                                                          const int *si, const int *ti, int n, unsigned long long seed,
+                                                          const int *best, double thr2, int *mask, double *T_out)
+{
+    __shared__ double sT[12];
+    if (threadIdx.x == 0) {
+        if (best[0] >= 0) ransac_model(src, tgt, stride, si, ti, n, seed, best[0], sT);
+        else for (int k = 0; k < 12; ++k) sT[k] = (k % 5 == 0) ? 1.0 : 0.0;
+        if (blockIdx.x == 0) for (int k = 0; k < 12; ++k) T_out[k] = sT[k];
+    }
+    __syncthreads();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        mask[i] = ransac_inlier(sT, load_xyz(src, si[i], stride), load_xyz(tgt, ti[i], stride), thr2) ? 1 : 0;
+}
+
+__global__ void iota_pairs_kernel(const int *nn, int n, int *si, int *ti)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { si[i] = i; ti[i] = nn[i]; }
 }
 
 // ---- host helpers -------------------------------------------------------------------
@@ -688,6 +815,126 @@ int icp_transform_cloud(IcpWorkspace *ws, hipStream_t stream, const void *in, in
     ICP_HIP(hipGetLastError());
     ICP_HIP(hipMemcpyAsync(out, ws->buf[B_OUT], (size_t)n * stride, hipMemcpyDeviceToHost, stream));
     ICP_HIP(hipStreamSynchronize(stream));
+    return SCL_OK;
+}
+
+// RANSAC over explicit pairs already on the device (d_si/d_ti), leaves the mask in ws->buf[B_MASK]
+static int ransac_device(IcpWorkspace *ws, hipStream_t stream, int stride, const int *d_si, const int *d_ti, int n_corr,
+                         int max_iterations, double thr, unsigned long long seed, int *h_best2, double *h_T12, std::string *err)
+{
+    int rc;
+    if ((rc = ensure(ws, B_MASK, sizeof(int) * (size_t)(n_corr + 1), err))) return rc;
+    if ((rc = ensure(ws, B_HYP, sizeof(int) * (size_t)(max_iterations + 8) + 256, err))) return rc;
+    if ((rc = pinned(ws, sizeof(IcpState) + 256, err))) return rc;
+    int *counts = static_cast<int *>(ws->buf[B_HYP]);
+    int *best = counts + max_iterations + 2;
+    double *T12 = reinterpret_cast<double *>(reinterpret_cast<char *>(ws->buf[B_HYP]) + ((sizeof(int) * (size_t)(max_iterations + 8) + 63) / 64) * 64);
+    const unsigned char *d_src = static_cast<const unsigned char *>(ws->buf[B_SRC]);
+    const unsigned char *d_tgt = static_cast<const unsigned char *>(ws->buf[B_TGT]);
+    const double thr2 = thr * thr;
+    const int hb = (max_iterations + kHypPerBlock - 1) / kHypPerBlock;
+    hipLaunchKernelGGL(ransac_score_kernel, dim3(hb), dim3(256), 0, stream, d_src, d_tgt, stride, d_si, d_ti, n_corr, seed,
+                       max_iterations, thr2, counts);
+    hipLaunchKernelGGL(ransac_pick_kernel, dim3(1), dim3(256), 0, stream, counts, max_iterations, best);
+    int mb = (n_corr + 255) / 256; mb = mb < 1 ? 1 : (mb > 1024 ? 1024 : mb);
+    hipLaunchKernelGGL(ransac_mask_kernel, dim3(mb), dim3(256), 0, stream, d_src, d_tgt, stride, d_si, d_ti, n_corr, seed,
+                       best, thr2, (int *)ws->buf[B_MASK], T12);
+    ICP_HIP(hipGetLastError());
+    char *hp = static_cast<char *>(ws->pinned);
+    ICP_HIP(hipMemcpyAsync(hp, best, sizeof(int) * 2, hipMemcpyDeviceToHost, stream));
+    ICP_HIP(hipMemcpyAsync(hp + 64, T12, sizeof(double) * 12, hipMemcpyDeviceToHost, stream));
+    ICP_HIP(hipStreamSynchronize(stream));
+    std::memcpy(h_best2, hp, sizeof(int) * 2);
+    if (h_T12) std::memcpy(h_T12, hp + 64, sizeof(double) * 12);
+    return SCL_OK;
+}
+
+int icp_ransac(IcpWorkspace *ws, hipStream_t stream, const void *src, int n_src, const void *tgt, int n_tgt, int stride,
+               const int *src_index, const int *tgt_index, int n_corr, int max_iterations, double inlier_threshold,
+               unsigned long long seed, int *inlier_mask, int *n_inliers, int *best_hypothesis, float T_model[16],
+               std::string *err)
+{
+    int rc = check_cloud_args(n_src, n_tgt, stride, err);
+    if (rc) return rc;
+    if (n_corr < 3 || max_iterations < 1 || max_iterations > (1 << 20)) { if (err) *err = "ransac: need >= 3 correspondences and 1..2^20 iterations"; return SCL_ERR_INVALID_ARG; }
+    for (int i = 0; i < n_corr; ++i)
+        if (src_index[i] < 0 || src_index[i] >= n_src || tgt_index[i] < 0 || tgt_index[i] >= n_tgt) {
+            if (err) *err = "ransac: correspondence index out of range"; return SCL_ERR_OUT_OF_RANGE;
+        }
+    if ((rc = upload(ws, B_SRC, src, (size_t)n_src * stride, stream, err))) return rc;
+    if ((rc = upload(ws, B_TGT, tgt, (size_t)n_tgt * stride, stream, err))) return rc;
+    if ((rc = upload(ws, B_SI, src_index, sizeof(int) * (size_t)n_corr, stream, err))) return rc;
+    if ((rc = upload(ws, B_TI, tgt_index, sizeof(int) * (size_t)n_corr, stream, err))) return rc;
+    int best2[2]; double T12[12];
+    if ((rc = ransac_device(ws, stream, stride, (const int *)ws->buf[B_SI], (const int *)ws->buf[B_TI], n_corr,
+                            max_iterations, inlier_threshold, seed, best2, T12, err))) return rc;
+    if (inlier_mask) {
+        ICP_HIP(hipMemcpyAsync(inlier_mask, ws->buf[B_MASK], sizeof(int) * (size_t)n_corr, hipMemcpyDeviceToHost, stream));
+        ICP_HIP(hipStreamSynchronize(stream));
+    }
+    if (n_inliers) *n_inliers = best2[1];
+    if (best_hypothesis) *best_hypothesis = best2[0];
+    if (T_model) {
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 4; ++b) T_model[a * 4 + b] = (float)T12[a * 4 + b];
+        T_model[12] = T_model[13] = T_model[14] = 0.f; T_model[15] = 1.f;
+    }
+    return SCL_OK;
+}
+
+// geometricVerificationService core, DM.h:1211-1243, entirely on the device
+int icp_geometric_verification(IcpWorkspace *ws, hipStream_t stream, int num_cu, const void *src, int n_src,
+                               const void *tgt, int n_tgt, int stride, int ransac_iterations, double inlier_threshold,
+                               double inlier_ratio, unsigned long long seed, float T[16], int *success, int *n_corr_out,
+                               int *n_inliers_out, std::string *err)
+{
+    (void)num_cu;
+    int rc = check_cloud_args(n_src, n_tgt, stride, err);
+    if (rc) return rc;
+    for (int k = 0; k < 16; ++k) T[k] = (k % 5 == 0) ? 1.f : 0.f;
+    if (success) *success = 0;
+    if (n_corr_out) *n_corr_out = 0;
+    if (n_inliers_out) *n_inliers_out = 0;
+    if (n_src < 3 || n_tgt < 1) return SCL_OK;
+    if (ransac_iterations < 1 || ransac_iterations > (1 << 20)) { if (err) *err = "ransac iterations out of range"; return SCL_ERR_INVALID_ARG; }
+    if ((rc = upload(ws, B_SRC, src, (size_t)n_src * stride, stream, err))) return rc;
+    if ((rc = upload(ws, B_TGT, tgt, (size_t)n_tgt * stride, stream, err))) return rc;
+    if ((rc = ensure(ws, B_WORK, sizeof(float4) * (size_t)(n_src + 1), err))) return rc;
+    if ((rc = ensure(ws, B_NNI, sizeof(int) * (size_t)(n_src + 1), err))) return rc;
+    if ((rc = ensure(ws, B_NND, sizeof(float) * (size_t)(n_src + 1), err))) return rc;
+    if ((rc = ensure(ws, B_SI, sizeof(int) * (size_t)(n_src + 1), err))) return rc;
+    if ((rc = ensure(ws, B_TI, sizeof(int) * (size_t)(n_src + 1), err))) return rc;
+    if ((rc = ensure(ws, B_PART, sizeof(double) * kNSum * kRedBlocks, err))) return rc;
+    if ((rc = build_grid(ws, stream, n_tgt, stride, err))) return rc;
+    IcpState *st = static_cast<IcpState *>(ws->buf[B_STATE]);
+    const int pb = (n_src + 255) / 256;
+    hipLaunchKernelGGL(work_init_kernel, dim3(pb), dim3(256), 0, stream, (const unsigned char *)ws->buf[B_SRC], n_src, stride,
+                       (float4 *)ws->buf[B_WORK]);
+    hipLaunchKernelGGL(nn_search_kernel, dim3(pb), dim3(256), 0, stream, (const float4 *)ws->buf[B_WORK], n_src, st,
+                       (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], (int *)ws->buf[B_NNI],
+                       (float *)ws->buf[B_NND], 0);                                              // DM.h:1211-1215
+    hipLaunchKernelGGL(iota_pairs_kernel, dim3(pb), dim3(256), 0, stream, (const int *)ws->buf[B_NNI], n_src,
+                       (int *)ws->buf[B_SI], (int *)ws->buf[B_TI]);
+    int best2[2];
+    if ((rc = ransac_device(ws, stream, stride, (const int *)ws->buf[B_SI], (const int *)ws->buf[B_TI], n_src,
+                            ransac_iterations, inlier_threshold, seed, best2, nullptr, err))) return rc;   // DM.h:1218-1225
+    const int n_inl = best2[1];
+    if (n_corr_out) *n_corr_out = n_src;
+    if (n_inliers_out) *n_inliers_out = n_inl;
+    if (n_inl >= 3) {                                                                              // DM.h:1228-1230
+        int rb = (n_src + 255) / 256; rb = rb < 1 ? 1 : (rb > kRedBlocks ? kRedBlocks : rb);
+        hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(64), 0, stream, st);
+        LAUNCH_REDUCE(rb, stream, (const float4 *)nullptr, (const unsigned char *)ws->buf[B_SRC],
+                      (const unsigned char *)ws->buf[B_TGT], stride, n_src, (const int *)ws->buf[B_MASK],
+                      (const float *)nullptr, 0.f, (const int *)ws->buf[B_SI], (const int *)ws->buf[B_TI], 1, st,
+                      (double *)ws->buf[B_PART], 0);
+        hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, stream, st, (const double *)ws->buf[B_PART], rb, 1, 0, 0.0, 0.0);
+        ICP_HIP(hipGetLastError());
+        IcpState *h = static_cast<IcpState *>(ws->pinned);
+        ICP_HIP(hipMemcpyAsync(h, st, sizeof(IcpState), hipMemcpyDeviceToHost, stream));
+        ICP_HIP(hipStreamSynchronize(stream));
+        std::memcpy(T, h->final_T, sizeof(float) * 16);
+    }
+    if (success) *success = !((double)n_inl < inlier_ratio * (double)n_src);                      // DM.h:1238
     return SCL_OK;
 }
 

@@ -30,4 +30,13 @@ int icp_rigid_svd(IcpWorkspace *ws, hipStream_t stream, int num_cu, const void *
 int icp_transform_cloud(IcpWorkspace *ws, hipStream_t stream, const void *in, int n, int stride_bytes,
                         const float T[16], void *out, std::string *err);
 
+int icp_ransac(IcpWorkspace *ws, hipStream_t stream, const void *src, int n_src, const void *tgt, int n_tgt, int stride,
+               const int *src_index, const int *tgt_index, int n_corr, int max_iterations, double inlier_threshold,
+               unsigned long long seed, int *inlier_mask, int *n_inliers, int *best_hypothesis, float T_model[16],
+               std::string *err);
+int icp_geometric_verification(IcpWorkspace *ws, hipStream_t stream, int num_cu, const void *src, int n_src,
+                               const void *tgt, int n_tgt, int stride, int ransac_iterations, double inlier_threshold,
+                               double inlier_ratio, unsigned long long seed, float T[16], int *success, int *n_corr_out,
+                               int *n_inliers_out, std::string *err);
+
 }  // namespace scl

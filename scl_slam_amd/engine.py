@@ -94,6 +94,8 @@ def _bind(lib):
         "scl_nn_correspondences": (c_int, [P, P, c_int, P, c_int, c_int, ip, fp]),
         "scl_rigid_svd": (c_int, [P, P, c_int, P, c_int, c_int, ip, ip, c_int, fp]),
         "scl_transform_cloud": (c_int, [P, P, c_int, c_int, fp, P]),
+        "scl_ransac_correspondences": (c_int, [P, P, c_int, P, c_int, c_int, ip, ip, c_int, c_int, c_double, c_uint64, ip, ip, ip, fp]),
+        "scl_geometric_verification": (c_int, [P, P, c_int, P, c_int, c_int, c_int, c_double, c_double, c_uint64, fp, ip, ip, ip]),
         "scl_profile_enable": (c_int, [P, c_int]),
         "scl_profile_reset": (c_int, [P]),
         "scl_profile_get": (c_int, [P, POINTER(SclProfile)]),
@@ -336,6 +338,33 @@ class ScanContextEngine:
                                             stride, _ptr(si, c_int), _ptr(ti, c_int), si.size, _ptr(T, c_float)),
                     "scl_rigid_svd")
         return T.reshape(4, 4)
+
+    def ransac_correspondences(self, src, tgt, src_index, tgt_index, max_iterations=1000, inlier_threshold=0.25, seed=1):
+        """CorrespondenceRejectorSampleConsensus (DM.h:1218-1225); defaults = ransacMaxIter / ransacOutlierTreshold (DM.h:187-188)"""
+        s, ns, stride = _cloud(src)
+        t, nt, stride_t = _cloud(tgt)
+        if stride != stride_t:
+            raise ValueError("source and target must share a record layout")
+        si = np.ascontiguousarray(src_index, dtype=np.int32); ti = np.ascontiguousarray(tgt_index, dtype=np.int32)
+        mask = np.empty(si.size, dtype=np.int32); ninl = c_int(); best = c_int(); T = np.empty(16, dtype=np.float32)
+        self._check(self._lib.scl_ransac_correspondences(self._h, s.ctypes.data_as(c_void_p), ns, t.ctypes.data_as(c_void_p), nt,
+                                                         stride, _ptr(si, c_int), _ptr(ti, c_int), si.size, max_iterations,
+                                                         inlier_threshold, seed, _ptr(mask, c_int), byref(ninl), byref(best),
+                                                         _ptr(T, c_float)), "scl_ransac_correspondences")
+        return mask, ninl.value, best.value, T.reshape(4, 4)
+
+    def geometric_verification(self, src, tgt, ransac_iterations=1000, inlier_threshold=0.25, inlier_ratio=0.45, seed=1):
+        """compute core of geometricVerificationService (DM.h:1211-1243); defaults DM.h:187-189"""
+        s, ns, stride = _cloud(src)
+        t, nt, stride_t = _cloud(tgt)
+        if stride != stride_t:
+            raise ValueError("source and target must share a record layout")
+        T = np.empty(16, dtype=np.float32); ok = c_int(); nc = c_int(); ni = c_int()
+        self._check(self._lib.scl_geometric_verification(self._h, s.ctypes.data_as(c_void_p), ns, t.ctypes.data_as(c_void_p), nt,
+                                                         stride, ransac_iterations, inlier_threshold, inlier_ratio, seed,
+                                                         _ptr(T, c_float), byref(ok), byref(nc), byref(ni)),
+                    "scl_geometric_verification")
+        return T.reshape(4, 4), bool(ok.value), nc.value, ni.value
 
     def transform_cloud(self, cloud, T):
         a, n, stride = _cloud(cloud)

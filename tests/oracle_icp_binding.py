@@ -24,6 +24,12 @@ def _lib():
         L.icpo_icp_align.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, POINTER(IcpoParams), POINTER(c_float),
                                      POINTER(c_float), POINTER(c_int), POINTER(c_int)]
         L.icpo_rotation_from_covariance.argtypes = [POINTER(c_double), POINTER(c_double)]
+        L.icpo_ransac.restype = c_int
+        L.icpo_ransac.argtypes = [c_void_p, c_void_p, c_int, POINTER(c_int), POINTER(c_int), c_int, c_int, c_double,
+                                  ctypes.c_ulonglong, POINTER(c_int), POINTER(c_int), POINTER(c_double)]
+        L.icpo_geometric_verification.restype = c_int
+        L.icpo_geometric_verification.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_double, c_double,
+                                                  ctypes.c_ulonglong, POINTER(c_float), POINTER(c_int), POINTER(c_int), POINTER(c_int)]
         L._icp_bound = True
     return L
 
@@ -72,3 +78,22 @@ def icp_align(src, tgt, params=None):
     _lib().icpo_icp_align(s.ctypes.data_as(c_void_p), ns, t.ctypes.data_as(c_void_p), nt, st, byref(p),
                           T.ctypes.data_as(POINTER(c_float)), byref(fit), byref(conv), byref(it))
     return T.reshape(4, 4), fit.value, bool(conv.value), it.value
+
+
+def ransac(src, tgt, si, ti, max_iterations=1000, inlier_threshold=0.25, seed=1):
+    s, ns, st = _c(src); t, nt, _ = _c(tgt)
+    si = np.ascontiguousarray(si, np.int32); ti = np.ascontiguousarray(ti, np.int32)
+    mask = np.empty(si.size, np.int32); best = c_int(); T = np.empty(12, np.float64)
+    n = _lib().icpo_ransac(s.ctypes.data_as(c_void_p), t.ctypes.data_as(c_void_p), st, si.ctypes.data_as(POINTER(c_int)),
+                           ti.ctypes.data_as(POINTER(c_int)), si.size, max_iterations, inlier_threshold, seed,
+                           mask.ctypes.data_as(POINTER(c_int)), byref(best), T.ctypes.data_as(POINTER(c_double)))
+    return mask, n, best.value, T.reshape(3, 4)
+
+
+def geometric_verification(src, tgt, ransac_iterations=1000, inlier_threshold=0.25, inlier_ratio=0.45, seed=1):
+    s, ns, st = _c(src); t, nt, _ = _c(tgt)
+    T = np.empty(16, np.float32); ok = c_int(); nc = c_int(); ni = c_int()
+    _lib().icpo_geometric_verification(s.ctypes.data_as(c_void_p), ns, t.ctypes.data_as(c_void_p), nt, st, ransac_iterations,
+                                       inlier_threshold, inlier_ratio, seed, T.ctypes.data_as(POINTER(c_float)),
+                                       byref(ok), byref(nc), byref(ni))
+    return T.reshape(4, 4), bool(ok.value), nc.value, ni.value

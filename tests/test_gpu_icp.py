@@ -6,7 +6,7 @@ import pytest
 import oracle_icp_binding as oi
 from scl_slam_amd import ScanContextEngine
 from scl_slam_amd.synth import rigid_transform, synth_structured_cloud
-from test_oracle_icp_kat import moved_copy
+from test_oracle_icp_kat import moved_copy, _outlier_problem
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -87,3 +87,27 @@ def test_icp_reference_sizes_100k(eng):
     Tg, fg, cg, ig = eng.icp_align(src, tgt, p)
     To, fo, co, io = oi.icp_align(src, tgt, oi.default_params(max_iterations=30))
     assert cg == co and ig == io and np.abs(Tg - To).max() < TOL
+
+
+@pytest.mark.parametrize("iters,seed", [(200, 7), (1000, 1), (37, 99)])
+def test_ransac_matches_oracle_bit_for_bit(eng, iters, seed):
+    src, tgt, si, ti, T, bad = _outlier_problem(n=5000, outlier_frac=0.35, seed=seed)
+    gm, gn, gb, gT = eng.ransac_correspondences(src, tgt, si, ti, iters, 0.05, seed)
+    om, on, ob_, oT = oi.ransac(src, tgt, si, ti, iters, 0.05, seed)
+    assert (gn, gb) == (on, ob_)
+    assert np.array_equal(gm, om)
+    assert np.abs(gT[:3] - oT).max() < 1e-6
+
+
+def test_geometric_verification_matches_oracle(eng):
+    tgt = synth_structured_cloud(20000, seed=31)
+    T = rigid_transform(0.0, 0.0, 0.002, 0.02, -0.01, 0.0)
+    src = moved_copy(tgt, T, keep_every=2, noise=0.003, seed=1)
+    g = eng.geometric_verification(src, tgt, 500, 0.25, 0.45, seed=3)
+    o = oi.geometric_verification(src, tgt, 500, 0.25, 0.45, seed=3)
+    assert g[1:] == o[1:] and g[1] is True
+    assert np.abs(g[0] - o[0]).max() < TOL
+    far = src.copy(); far[:, :3] += np.random.RandomState(2).uniform(-30, 30, size=(len(src), 3)).astype(np.float32)
+    g = eng.geometric_verification(far, tgt, 500, 0.25, 0.45, seed=3)
+    o = oi.geometric_verification(far, tgt, 500, 0.25, 0.45, seed=3)
+    assert g[1:] == o[1:] and g[1] is False

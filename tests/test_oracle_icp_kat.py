@@ -83,3 +83,39 @@ def test_transform_matches_numpy():
     out = oi.transform(c, T)
     ref = c[:, :3].astype(np.float64) @ T[:3, :3].astype(np.float64).T + T[:3, 3]
     assert np.abs(out[:, :3] - ref).max() < 1e-4 and np.array_equal(out[:, 3:], c[:, 3:])
+
+
+def _outlier_problem(n=3000, outlier_frac=0.3, seed=0):
+    tgt = synth_structured_cloud(n, seed=21)
+    T = rigid_transform(0.05, -0.03, 0.4, 2.0, -1.0, 0.3)
+    src = moved_copy(tgt, T, keep_every=1)
+    rs = np.random.RandomState(seed)
+    ti = np.arange(n, dtype=np.int32)
+    bad = rs.choice(n, int(outlier_frac * n), replace=False)
+    ti[bad] = rs.randint(0, n, size=bad.size)                       # wrong correspondences
+    return src, tgt, np.arange(n, dtype=np.int32), ti, T, bad
+
+
+def test_ransac_finds_the_inlier_set():
+    src, tgt, si, ti, T, bad = _outlier_problem()
+    mask, n_inl, best_h, Tm = oi.ransac(src, tgt, si, ti, max_iterations=200, inlier_threshold=0.05, seed=7)
+    good = np.ones(si.size, bool); good[bad] = False
+    good |= (ti == si)                                               # a random re-draw may hit the right target
+    assert n_inl == int(mask.sum()) and 0 <= best_h < 200
+    assert (mask.astype(bool) & ~good).sum() <= 3                    # essentially no outlier accepted
+    assert mask[good].mean() > 0.99
+    assert np.abs(Tm - T[:3]).max() < 1e-3
+    # deterministic in the seed; a different seed may pick another (equally good) model
+    m2, n2, b2, _ = oi.ransac(src, tgt, si, ti, max_iterations=200, inlier_threshold=0.05, seed=7)
+    assert np.array_equal(mask, m2) and (n2, b2) == (n_inl, best_h)
+
+
+def test_geometric_verification_gate():
+    tgt = synth_structured_cloud(4000, seed=31)
+    T = rigid_transform(0.0, 0.0, 0.002, 0.02, -0.01, 0.0)         # already nearly aligned: NN pairs are right
+    src = moved_copy(tgt, T, keep_every=2, noise=0.003, seed=1)
+    Tg, ok, nc, ni = oi.geometric_verification(src, tgt, 300, 0.25, 0.45, seed=3)
+    assert ok and nc == len(src) and ni > 0.9 * nc and np.abs(Tg - T).max() < 5e-3
+    far = src.copy(); far[:, :3] += np.random.RandomState(2).uniform(-30, 30, size=(len(src), 3)).astype(np.float32)
+    Tg, ok, nc, ni = oi.geometric_verification(far, tgt, 300, 0.25, 0.45, seed=3)
+    assert not ok and ni < 0.45 * nc                                 # DM.h:1238
