@@ -196,6 +196,18 @@ int  scl_geometric_verification(scl_engine *e, const void *src, int n_src, const
                                 int stride_bytes, int ransac_iterations, double inlier_threshold,
                                 double inlier_ratio, uint64_t seed, float T[16], int *success,
                                 int *n_correspondences, int *n_inliers);
+/* pcl::VoxelGrid::filter with one leaf size (DM.h:501,503; DM.h:996-998, 1183-1185, 1200-1201): one point
+ * per occupied voxel = centroid of x, y, z and intensity, ascending voxel index.  out must hold out_capacity
+ * records (n_points always suffices).  When the voxel index range overflows int32 the input is returned
+ * unchanged, as PCL does. */
+int  scl_voxel_grid(scl_engine *e, const void *points, int n_points, int stride_bytes, float leaf,
+                    void *out, int out_capacity, int *n_out);
+/* pcl::getTransformation(x, y, z, roll, pitch, yaw) (DM.h:223,241) as a row-major 4x4; host-side helper */
+int  scl_pose_to_matrix(float x, float y, float z, float roll, float pitch, float yaw, float T[16]);
+/* loopFindNearKeyframes, DM.h:1163-1186: concatenation of transformPointCloud(cloud_i, T_i) (DM.h:234-253)
+ * followed by the voxel filter.  transforms = n_clouds row-major 4x4 matrices. */
+int  scl_assemble_submap(scl_engine *e, const void *const *clouds, const int *counts, const float *transforms,
+                         int n_clouds, int stride_bytes, float leaf, void *out, int out_capacity, int *n_out);
 /* paramsServer::transformPointCloud, DM.h:234-253 (xyz transformed, rest copied) */
 int  scl_transform_cloud(scl_engine *e, const void *in, int n, int stride_bytes,
                          const float T[16], void *out);

@@ -409,3 +409,75 @@ int icpo_geometric_verification(const void *src, int n_src, const void *tgt, int
     free(nn); free(si); free(ti); free(mask);
     return 0;
 }
+
+/* ---- voxel grid ---------------------------------------------------------------------------------------- */
+typedef struct { long long idx; int pt; } vox_key;
+static int cmp_vox(const void *a, const void *b)
+{
+    const vox_key *x = (const vox_key *)a, *y = (const vox_key *)b;
+    if (x->idx != y->idx) return x->idx < y->idx ? -1 : 1;
+    return (x->pt > y->pt) - (x->pt < y->pt);
+}
+
+int icpo_voxel_grid(const void *in, int n, int stride, float leaf, void *out)
+{
+    const float inv = 1.0f / leaf;
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    int nfinite = 0;
+    for (int i = 0; i < n; i++) {
+        const float *p = pt(in, i, stride);
+        if (!(isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]))) continue;
+        for (int a = 0; a < 3; a++) { if (p[a] < mn[a]) mn[a] = p[a]; if (p[a] > mx[a]) mx[a] = p[a]; }
+        nfinite++;
+    }
+    if (nfinite == 0) return 0;
+    long long minb[3], divb[3];
+    for (int a = 0; a < 3; a++) {
+        minb[a] = (long long)floorf(mn[a] * inv);
+        divb[a] = (long long)floorf(mx[a] * inv) - minb[a] + 1;
+    }
+    if (divb[0] * divb[1] * divb[2] > 2147483647LL) return -1;
+    vox_key *keys = (vox_key *)malloc(sizeof(vox_key) * (size_t)nfinite);
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+        const float *p = pt(in, i, stride);
+        if (!(isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]))) continue;
+        const long long i0 = (long long)floorf(p[0] * inv) - minb[0];
+        const long long i1 = (long long)floorf(p[1] * inv) - minb[1];
+        const long long i2 = (long long)floorf(p[2] * inv) - minb[2];
+        keys[m].idx = i0 + i1 * divb[0] + i2 * divb[0] * divb[1];
+        keys[m].pt = i; m++;
+    }
+    qsort(keys, (size_t)m, sizeof(vox_key), cmp_vox);
+    const int has_i = stride >= 20;
+    int nout = 0;
+    for (int a = 0; a < m; ) {
+        int b = a;
+        float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+        while (b < m && keys[b].idx == keys[a].idx) {
+            const float *p = pt(in, keys[b].pt, stride);
+            sx += p[0]; sy += p[1]; sz += p[2];
+            if (has_i) si += p[4];
+            b++;
+        }
+        const float cnt = (float)(b - a);
+        float *o = (float *)((unsigned char *)out + (size_t)nout * (size_t)stride);
+        memset(o, 0, (size_t)stride);
+        o[0] = sx / cnt; o[1] = sy / cnt; o[2] = sz / cnt;
+        if (has_i) o[4] = si / cnt;
+        nout++;
+        a = b;
+    }
+    free(keys);
+    return nout;
+}
+
+void icpo_pose_to_matrix(float x, float y, float z, float roll, float pitch, float yaw, float T[16])
+{
+    const float A = cosf(yaw), B = sinf(yaw), C = cosf(pitch), D = sinf(pitch), E = cosf(roll), F = sinf(roll);
+    const float DE = D * E, DF = D * F;
+    T[0] = A * C; T[1] = A * DF - B * E; T[2] = B * F + A * DE; T[3] = x;
+    T[4] = B * C; T[5] = A * E + B * DF; T[6] = B * DE - A * F; T[7] = y;
+    T[8] = -D;    T[9] = C * F;          T[10] = C * E;         T[11] = z;
+    T[12] = 0.f;  T[13] = 0.f;           T[14] = 0.f;           T[15] = 1.f;
+}

@@ -64,6 +64,19 @@ int  icpo_geometric_verification(const void *src, int n_src, const void *tgt, in
                                  int ransac_iterations, double inlier_threshold, double inlier_ratio,
                                  unsigned long long seed, float T[16], int *success, int *n_corr, int *n_inliers);
 
+/* pcl::VoxelGrid::filter with one leaf size for all axes (DM.h:501,503; call sites DM.h:996-998,
+ * 1183-1185, 1200-1201), restated from PCL's published algorithm (PARITY UNPINNED):
+ * bounding box of the finite points -> voxel coords floor(p * (1/leaf)) - min_b (fp32) -> linear index
+ * (x fastest) -> one output point per occupied voxel = centroid of x, y, z and intensity (the float at
+ * byte offset 16 when the record has one), fp32 sums in ascending input order within the voxel, divided
+ * by the count; output in ascending voxel index; other record bytes are zero.
+ * Returns the number of output points, or -1 when the index range would overflow int32 (PCL then
+ * returns the input unchanged). */
+int  icpo_voxel_grid(const void *in, int n, int stride_bytes, float leaf, void *out);
+
+/* pcl::getTransformation(x, y, z, roll, pitch, yaw) as used at DM.h:223,241: fp32, row-major 4x4 */
+void icpo_pose_to_matrix(float x, float y, float z, float roll, float pitch, float yaw, float T[16]);
+
 /* 3x3 SVD-based rotation for a cross-covariance matrix (exposed for tests):
  * H = sum (q - qbar)(p - pbar)^T  (dst x src), R = U diag(1,1,det) V^T */
 void icpo_rotation_from_covariance(const double H[9], double R[9]);

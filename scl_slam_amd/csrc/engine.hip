@@ -75,6 +75,7 @@ struct scl_engine {
     std::vector<hipEvent_t> event_pool;
 
     IcpWorkspace icp_ws;
+    IcpWorkspace vox_ws;
 };
 
 namespace {
@@ -453,6 +454,7 @@ int scl_destroy(scl_engine *e)
     for (auto &p : e->pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
     for (auto ev : e->event_pool) (void)hipEventDestroy(ev);
     icp_workspace_free(&e->icp_ws);
+    icp_workspace_free(&e->vox_ws);
     dev_free(e->d_desc); dev_free(e->d_vkey); dev_free(e->d_norm); dev_free(e->d_rkey); dev_free(e->d_rkey4);
     dev_free(e->q_desc); dev_free(e->q_vkey); dev_free(e->q_norm); dev_free(e->q_rkey); dev_free(e->q_rkey4);
     dev_free(e->d_vals); dev_free(e->d_points); dev_free(e->d_tile);
@@ -934,6 +936,43 @@ int scl_geometric_verification(scl_engine *e, const void *src, int n_src, const 
     int rc = icp_geometric_verification(&e->icp_ws, e->stream, e->num_cu, src, n_src, tgt, n_tgt, stride_bytes,
                                         ransac_iterations, inlier_threshold, inlier_ratio, (unsigned long long)seed,
                                         T, success, n_correspondences, n_inliers, &err);
+    if (rc) e->last_error = err;
+    return rc;
+}
+
+int scl_voxel_grid(scl_engine *e, const void *points, int n_points, int stride_bytes, float leaf,
+                   void *out, int out_capacity, int *n_out)
+{
+    if (!e || (!points && n_points > 0) || !out || !n_out) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    std::string err;
+    int rc = voxel_grid(&e->vox_ws, e->stream, points, n_points, stride_bytes, leaf, out, out_capacity, n_out, &err);
+    if (rc) e->last_error = err;
+    return rc;
+}
+
+int scl_pose_to_matrix(float x, float y, float z, float roll, float pitch, float yaw, float T[16])
+{
+    if (!T) return SCL_ERR_INVALID_ARG;
+    const float A = std::cos(yaw), B = std::sin(yaw), C = std::cos(pitch), D = std::sin(pitch), E = std::cos(roll), F = std::sin(roll);
+    const float DE = D * E, DF = D * F;
+    T[0] = A * C; T[1] = A * DF - B * E; T[2] = B * F + A * DE; T[3] = x;
+    T[4] = B * C; T[5] = A * E + B * DF; T[6] = B * DE - A * F; T[7] = y;
+    T[8] = -D;    T[9] = C * F;          T[10] = C * E;         T[11] = z;
+    T[12] = 0.f;  T[13] = 0.f;           T[14] = 0.f;           T[15] = 1.f;
+    return SCL_OK;
+}
+
+int scl_assemble_submap(scl_engine *e, const void *const *clouds, const int *counts, const float *transforms,
+                        int n_clouds, int stride_bytes, float leaf, void *out, int out_capacity, int *n_out)
+{
+    if (!e || (n_clouds > 0 && (!clouds || !counts || !transforms)) || !out || !n_out) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    std::string err;
+    int rc = assemble_submap(&e->vox_ws, e->stream, clouds, counts, transforms, n_clouds, stride_bytes, leaf, out,
+                             out_capacity, n_out, &err);
     if (rc) e->last_error = err;
     return rc;
 }

@@ -39,4 +39,11 @@ int icp_geometric_verification(IcpWorkspace *ws, hipStream_t stream, int num_cu,
                                double inlier_ratio, unsigned long long seed, float T[16], int *success, int *n_corr_out,
                                int *n_inliers_out, std::string *err);
 
+// voxel.hip (a separate workspace instance is used: buffer slots differ from icp.hip's)
+int voxel_grid(IcpWorkspace *ws, hipStream_t stream, const void *in, int n, int stride, float leaf,
+               void *out, int out_capacity, int *n_out, std::string *err);
+int assemble_submap(IcpWorkspace *ws, hipStream_t stream, const void *const *clouds, const int *counts,
+                    const float *transforms, int n_clouds, int stride, float leaf, void *out, int out_capacity,
+                    int *n_out, std::string *err);
+
 }  // namespace scl

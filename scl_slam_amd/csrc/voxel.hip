@@ -1,0 +1,281 @@
+// voxel.hip -- pcl::VoxelGrid down-sampling and submap assembly on the GPU.
+//
+//   voxel grid        DM.h:996-998 (descriptor input), 1183-1185 (submap), 1200-1201 (service input)
+//   submap assembly   loopFindNearKeyframes, DM.h:1163-1186: sum of transformPointCloud(keyframe, pose)
+//                     (DM.h:234-253) followed by the voxel filter
+//
+// Algorithm (PCL's, restated in oracle/icp_oracle.c): voxel coordinates floor(p * 1/leaf) - min_b in fp32,
+// linear index with x fastest, one output point per occupied voxel = centroid of x, y, z, intensity, output
+// in ascending voxel index.  GPU form: 64-bit keys (voxel index << 32 | point index) sorted with rocPRIM's
+// radix sort (through hipCUB), run heads flagged and scanned, then ONE thread per voxel adds its points in
+// key order -- i.e. ascending input order, the same fp32 sums as the serial restatement, bit for bit.
+// HBM-bound: n * (stride + 2 * 8) bytes; the sort dominates.
+#include <hipcub/hipcub.hpp>
+
+#include <cfloat>
+#include <cstring>
+
+#include "device_common.hpp"
+#include "icp.hpp"
+
+namespace scl {
+
+namespace {
+
+struct VoxState { float mn[3]; float mx[3]; long long minb[3]; long long divb[3]; int nfinite; int overflow; int nout; };
+
+__device__ __forceinline__ bool finite3(float x, float y, float z)
+{
+    return (fabsf(x) <= FLT_MAX) && (fabsf(y) <= FLT_MAX) && (fabsf(z) <= FLT_MAX);
+}
+
+__global__ void vox_bbox_partial_kernel(const unsigned char *pts, int n, int stride, float *part, int *cnt)
+{
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    int c = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float *f = reinterpret_cast<const float *>(pts + (size_t)i * stride);
+        const float x = f[0], y = f[1], z = f[2];
+        if (!finite3(x, y, z)) continue;
+        mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
+        mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
+        ++c;
+    }
+    __shared__ float s[6][4];
+    __shared__ int sc[4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, kWave));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, kWave));
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, kWave);
+    const int wv = threadIdx.x / kWave;
+    if ((threadIdx.x & 63) == 0) { for (int a = 0; a < 3; ++a) { s[a][wv] = mn[a]; s[3 + a][wv] = mx[a]; } sc[wv] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < 4; ++w) tot += sc[w];
+        for (int a = 0; a < 3; ++a) {
+            float m = s[a][0], M = s[3 + a][0];
+            for (int w = 1; w < 4; ++w) { m = fminf(m, s[a][w]); M = fmaxf(M, s[3 + a][w]); }
+            part[blockIdx.x * 6 + a] = m; part[blockIdx.x * 6 + 3 + a] = M;
+        }
+        cnt[blockIdx.x] = tot;
+    }
+}
+
+__global__ void vox_setup_kernel(const float *part, const int *cnt, int nblocks, float inv, VoxState *st)
+{
+    if (threadIdx.x != 0) return;
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    int tot = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        tot += cnt[b];
+        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], part[b * 6 + a]); mx[a] = fmaxf(mx[a], part[b * 6 + 3 + a]); }
+    }
+    st->nfinite = tot; st->overflow = 0; st->nout = 0;
+    for (int a = 0; a < 3; ++a) {
+        st->mn[a] = mn[a]; st->mx[a] = mx[a];
+        st->minb[a] = tot ? (long long)floorf(mn[a] * inv) : 0;
+        st->divb[a] = tot ? (long long)floorf(mx[a] * inv) - st->minb[a] + 1 : 1;
+    }
+    if (st->divb[0] * st->divb[1] * st->divb[2] > 2147483647LL) st->overflow = 1;
+}
+
+__global__ void vox_keys_kernel(const unsigned char *pts, int n, int stride, float inv, const VoxState *st,
+                                unsigned long long *keys)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *f = reinterpret_cast<const float *>(pts + (size_t)i * stride);
+    const float x = f[0], y = f[1], z = f[2];
+    unsigned long long key = ~0ull;                                   // non-finite points sort to the end
+    if (finite3(x, y, z) && !st->overflow) {
+        const long long i0 = (long long)floorf(x * inv) - st->minb[0];
+        const long long i1 = (long long)floorf(y * inv) - st->minb[1];
+        const long long i2 = (long long)floorf(z * inv) - st->minb[2];
+        const long long idx = i0 + i1 * st->divb[0] + i2 * st->divb[0] * st->divb[1];
+        key = ((unsigned long long)idx << 32) | (unsigned)i;
+    }
+    keys[i] = key;
+}
+
+__global__ void vox_heads_kernel(const unsigned long long *keys, int n, int *head)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long k = keys[i];
+    const bool valid = k != ~0ull;
+    head[i] = (valid && (i == 0 || (keys[i - 1] >> 32) != (k >> 32))) ? 1 : 0;
+}
+
+__global__ void vox_centroid_kernel(const unsigned char *pts, int stride, const unsigned long long *keys, const int *head,
+                                    const int *pos /*exclusive scan of head*/, int n, unsigned char *out, VoxState *st)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !head[i]) return;
+    const unsigned long long vox = keys[i] >> 32;
+    float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+    const bool has_i = stride >= 20;
+    int b = i;
+    while (b < n && (keys[b] >> 32) == vox && keys[b] != ~0ull) {
+        const float *f = reinterpret_cast<const float *>(pts + (size_t)(unsigned)(keys[b] & 0xffffffffull) * stride);
+        sx += f[0]; sy += f[1]; sz += f[2];
+        if (has_i) si += f[4];
+        ++b;
+    }
+    const float cnt = (float)(b - i);
+    float *o = reinterpret_cast<float *>(out + (size_t)pos[i] * stride);
+    for (int k = 0; k < stride / 4; ++k) o[k] = 0.f;
+    o[0] = sx / cnt; o[1] = sy / cnt; o[2] = sz / cnt;
+    if (has_i) o[4] = si / cnt;
+    if (i == 0 || true) { /* the last head also publishes the output count */ }
+    if (b >= n || keys[b] == ~0ull) st->nout = pos[i] + 1;
+}
+
+__global__ void transform_append_kernel(const unsigned char *in, int n, int stride, const float *T, unsigned char *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *f = reinterpret_cast<const float *>(in + (size_t)i * stride);
+    float *o = reinterpret_cast<float *>(out + (size_t)i * stride);
+    const float x = f[0], y = f[1], z = f[2];
+    for (int k = 3; k < stride / 4; ++k) o[k] = f[k];
+    // distributedMapping.h:247-249 (fp32, left to right, no FMA)
+    o[0] = T[0] * x + T[1] * y + T[2] * z + T[3];
+    o[1] = T[4] * x + T[5] * y + T[6] * z + T[7];
+    o[2] = T[8] * x + T[9] * y + T[10] * z + T[11];
+}
+
+enum VBuf { V_IN = 0, V_KEYS, V_KEYS2, V_HEAD, V_POS, V_TMP, V_OUT, V_STATE, V_PART, V_T };
+
+#define VOX_HIP(call)                                                                   \
+    do {                                                                                \
+        hipError_t e__ = (call);                                                        \
+        if (e__ != hipSuccess) { if (err) *err = std::string(#call) + ": " + hipGetErrorString(e__); return SCL_ERR_HIP; } \
+    } while (0)
+
+int vensure(IcpWorkspace *ws, int k, size_t bytes, std::string *err)
+{
+    if (bytes <= ws->cap[k]) return SCL_OK;
+    if (ws->buf[k]) { (void)hipFree(ws->buf[k]); ws->buf[k] = nullptr; ws->cap[k] = 0; }
+    size_t nb = bytes + bytes / 4 + 256;
+    if (hipMalloc(&ws->buf[k], nb) != hipSuccess) { if (err) *err = "voxel: hipMalloc failed"; return SCL_ERR_NOMEM; }
+    ws->cap[k] = nb;
+    return SCL_OK;
+}
+
+// input already in ws->buf[V_IN]; output left in ws->buf[V_OUT]; *n_out on host
+int voxel_device(IcpWorkspace *ws, hipStream_t stream, int n, int stride, float leaf, int *n_out, std::string *err)
+{
+    int rc;
+    *n_out = 0;
+    if (n == 0) return SCL_OK;
+    if ((rc = vensure(ws, V_KEYS, sizeof(unsigned long long) * (size_t)n, err))) return rc;
+    if ((rc = vensure(ws, V_KEYS2, sizeof(unsigned long long) * (size_t)n, err))) return rc;
+    if ((rc = vensure(ws, V_HEAD, sizeof(int) * (size_t)n, err))) return rc;
+    if ((rc = vensure(ws, V_POS, sizeof(int) * (size_t)n, err))) return rc;
+    if ((rc = vensure(ws, V_OUT, (size_t)n * stride + 16, err))) return rc;
+    if ((rc = vensure(ws, V_STATE, sizeof(VoxState), err))) return rc;
+    if ((rc = vensure(ws, V_PART, (sizeof(float) * 6 + sizeof(int)) * 256, err))) return rc;
+    const unsigned char *in = static_cast<const unsigned char *>(ws->buf[V_IN]);
+    unsigned long long *keys = static_cast<unsigned long long *>(ws->buf[V_KEYS]);
+    unsigned long long *keys2 = static_cast<unsigned long long *>(ws->buf[V_KEYS2]);
+    VoxState *st = static_cast<VoxState *>(ws->buf[V_STATE]);
+    float *part = static_cast<float *>(ws->buf[V_PART]);
+    int *pcnt = reinterpret_cast<int *>(part + 6 * 256);
+    const float inv = 1.0f / leaf;
+    int nb = (n + 255) / 256; nb = nb > 256 ? 256 : nb;
+    const int pb = (n + 255) / 256;
+    hipLaunchKernelGGL(vox_bbox_partial_kernel, dim3(nb), dim3(256), 0, stream, in, n, stride, part, pcnt);
+    hipLaunchKernelGGL(vox_setup_kernel, dim3(1), dim3(64), 0, stream, part, pcnt, nb, inv, st);
+    hipLaunchKernelGGL(vox_keys_kernel, dim3(pb), dim3(256), 0, stream, in, n, stride, inv, st, keys);
+    size_t tmp_sort = 0, tmp_scan = 0;
+    VOX_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_sort, keys, keys2, n, 0, 64, stream));
+    VOX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, (int *)ws->buf[V_HEAD], (int *)ws->buf[V_POS], n, stream));
+    const size_t tmp = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
+    if ((rc = vensure(ws, V_TMP, tmp + 256, err))) return rc;
+    VOX_HIP(hipcub::DeviceRadixSort::SortKeys(ws->buf[V_TMP], tmp_sort, keys, keys2, n, 0, 64, stream));
+    hipLaunchKernelGGL(vox_heads_kernel, dim3(pb), dim3(256), 0, stream, keys2, n, (int *)ws->buf[V_HEAD]);
+    VOX_HIP(hipcub::DeviceScan::ExclusiveSum(ws->buf[V_TMP], tmp_scan, (int *)ws->buf[V_HEAD], (int *)ws->buf[V_POS], n, stream));
+    hipLaunchKernelGGL(vox_centroid_kernel, dim3(pb), dim3(256), 0, stream, in, stride, keys2, (const int *)ws->buf[V_HEAD],
+                       (const int *)ws->buf[V_POS], n, (unsigned char *)ws->buf[V_OUT], st);
+    VOX_HIP(hipGetLastError());
+    if (!ws->pinned || ws->pinned_cap < sizeof(VoxState)) {
+        if (ws->pinned) { (void)hipHostFree(ws->pinned); ws->pinned = nullptr; ws->pinned_cap = 0; }
+        VOX_HIP(hipHostMalloc(&ws->pinned, 4096, hipHostMallocDefault));
+        ws->pinned_cap = 4096;
+    }
+    VOX_HIP(hipMemcpyAsync(ws->pinned, st, sizeof(VoxState), hipMemcpyDeviceToHost, stream));
+    VOX_HIP(hipStreamSynchronize(stream));
+    const VoxState *h = static_cast<const VoxState *>(ws->pinned);
+    if (h->overflow) { *n_out = -1; return SCL_OK; }
+    *n_out = h->nout;
+    return SCL_OK;
+}
+
+}  // namespace
+
+int voxel_grid(IcpWorkspace *ws, hipStream_t stream, const void *in, int n, int stride, float leaf,
+               void *out, int out_capacity, int *n_out, std::string *err)
+{
+    if (n < 0 || stride < 12 || (stride & 3) || !(leaf > 0.f)) { if (err) *err = "voxel_grid: bad arguments"; return SCL_ERR_INVALID_ARG; }
+    int rc;
+    if ((rc = vensure(ws, V_IN, (size_t)n * stride + 16, err))) return rc;
+    if (n) VOX_HIP(hipMemcpyAsync(ws->buf[V_IN], in, (size_t)n * stride, hipMemcpyHostToDevice, stream));
+    int m = 0;
+    if ((rc = voxel_device(ws, stream, n, stride, leaf, &m, err))) return rc;
+    if (m < 0) {                                                       // PCL: leaf too small -> input returned unchanged
+        if (n > out_capacity) { if (err) *err = "voxel_grid: output capacity too small"; return SCL_ERR_INVALID_ARG; }
+        std::memcpy(out, in, (size_t)n * stride);
+        *n_out = n;
+        return SCL_OK;
+    }
+    if (m > out_capacity) { if (err) *err = "voxel_grid: output capacity too small"; return SCL_ERR_INVALID_ARG; }
+    if (m) VOX_HIP(hipMemcpyAsync(out, ws->buf[V_OUT], (size_t)m * stride, hipMemcpyDeviceToHost, stream));
+    VOX_HIP(hipStreamSynchronize(stream));
+    *n_out = m;
+    return SCL_OK;
+}
+
+int assemble_submap(IcpWorkspace *ws, hipStream_t stream, const void *const *clouds, const int *counts,
+                    const float *transforms, int n_clouds, int stride, float leaf, void *out, int out_capacity,
+                    int *n_out, std::string *err)
+{
+    if (n_clouds < 0 || stride < 12 || (stride & 3) || !(leaf > 0.f)) { if (err) *err = "assemble_submap: bad arguments"; return SCL_ERR_INVALID_ARG; }
+    size_t total = 0;
+    for (int c = 0; c < n_clouds; ++c) { if (counts[c] < 0) { if (err) *err = "negative count"; return SCL_ERR_INVALID_ARG; } total += (size_t)counts[c]; }
+    if (total > 0x7fffffffull) { if (err) *err = "submap too large"; return SCL_ERR_INVALID_ARG; }
+    int rc;
+    if ((rc = vensure(ws, V_IN, total * stride + 16, err))) return rc;
+    if ((rc = vensure(ws, V_T, sizeof(float) * 16 * (size_t)(n_clouds > 0 ? n_clouds : 1), err))) return rc;
+    if (n_clouds) VOX_HIP(hipMemcpyAsync(ws->buf[V_T], transforms, sizeof(float) * 16 * (size_t)n_clouds, hipMemcpyHostToDevice, stream));
+    // raw clouds are staged behind the concatenated buffer's end in V_OUT (reused as scratch before the filter runs)
+    size_t maxc = 0;
+    for (int c = 0; c < n_clouds; ++c) maxc = maxc > (size_t)counts[c] ? maxc : (size_t)counts[c];
+    if ((rc = vensure(ws, V_OUT, (total > maxc ? total : maxc) * stride + 16, err))) return rc;
+    size_t off = 0;
+    for (int c = 0; c < n_clouds; ++c) {                               // DM.h:1168-1176
+        const int n = counts[c];
+        if (!n) continue;
+        VOX_HIP(hipMemcpyAsync(ws->buf[V_OUT], clouds[c], (size_t)n * stride, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(transform_append_kernel, dim3((n + 255) / 256), dim3(256), 0, stream,
+                           (const unsigned char *)ws->buf[V_OUT], n, stride, (const float *)ws->buf[V_T] + 16 * c,
+                           (unsigned char *)ws->buf[V_IN] + off * stride);
+        off += (size_t)n;
+    }
+    int m = 0;
+    if ((rc = voxel_device(ws, stream, (int)total, stride, leaf, &m, err))) return rc;   // DM.h:1181-1185
+    const void *res = ws->buf[V_OUT];
+    if (m < 0) { m = (int)total; res = ws->buf[V_IN]; }
+    if (m > out_capacity) { if (err) *err = "assemble_submap: output capacity too small"; return SCL_ERR_INVALID_ARG; }
+    if (m) VOX_HIP(hipMemcpyAsync(out, res, (size_t)m * stride, hipMemcpyDeviceToHost, stream));
+    VOX_HIP(hipStreamSynchronize(stream));
+    *n_out = m;
+    return SCL_OK;
+}
+
+}  // namespace scl

@@ -94,6 +94,9 @@ def _bind(lib):
         "scl_nn_correspondences": (c_int, [P, P, c_int, P, c_int, c_int, ip, fp]),
         "scl_rigid_svd": (c_int, [P, P, c_int, P, c_int, c_int, ip, ip, c_int, fp]),
         "scl_transform_cloud": (c_int, [P, P, c_int, c_int, fp, P]),
+        "scl_voxel_grid": (c_int, [P, P, c_int, c_int, c_float, P, c_int, ip]),
+        "scl_pose_to_matrix": (c_int, [c_float, c_float, c_float, c_float, c_float, c_float, fp]),
+        "scl_assemble_submap": (c_int, [P, POINTER(c_void_p), ip, fp, c_int, c_int, c_float, P, c_int, ip]),
         "scl_ransac_correspondences": (c_int, [P, P, c_int, P, c_int, c_int, ip, ip, c_int, c_int, c_double, c_uint64, ip, ip, ip, fp]),
         "scl_geometric_verification": (c_int, [P, P, c_int, P, c_int, c_int, c_int, c_double, c_double, c_uint64, fp, ip, ip, ip]),
         "scl_profile_enable": (c_int, [P, c_int]),
@@ -365,6 +368,32 @@ class ScanContextEngine:
                                                          _ptr(T, c_float), byref(ok), byref(nc), byref(ni)),
                     "scl_geometric_verification")
         return T.reshape(4, 4), bool(ok.value), nc.value, ni.value
+
+    def voxel_grid(self, cloud, leaf):
+        """pcl::VoxelGrid with one leaf size (DM.h:501,503)"""
+        a, n, stride = _cloud(cloud)
+        out = np.empty_like(a); m = c_int()
+        self._check(self._lib.scl_voxel_grid(self._h, a.ctypes.data_as(c_void_p), n, stride, leaf,
+                                             out.ctypes.data_as(c_void_p), n, byref(m)), "scl_voxel_grid")
+        return out[:m.value].copy()
+
+    def pose_to_matrix(self, x, y, z, roll, pitch, yaw):
+        T = np.empty(16, dtype=np.float32)
+        self._check(self._lib.scl_pose_to_matrix(x, y, z, roll, pitch, yaw, _ptr(T, c_float)), "scl_pose_to_matrix")
+        return T.reshape(4, 4)
+
+    def assemble_submap(self, clouds, transforms, leaf):
+        """loopFindNearKeyframes (DM.h:1163-1186): transformed keyframes concatenated, then voxel-filtered"""
+        arrs = [np.ascontiguousarray(c, dtype=np.float32) for c in clouds]
+        stride = arrs[0].shape[1] * 4 if arrs else 32
+        counts = np.array([a.shape[0] for a in arrs], dtype=np.int32)
+        ptrs = (c_void_p * max(1, len(arrs)))(*[a.ctypes.data_as(c_void_p) for a in arrs])
+        Ts = _f32(np.stack(transforms)).reshape(-1, 16) if arrs else np.zeros((1, 16), np.float32)
+        total = int(counts.sum())
+        out = np.empty((max(total, 1), stride // 4), dtype=np.float32); m = c_int()
+        self._check(self._lib.scl_assemble_submap(self._h, ptrs, _ptr(counts, c_int), _ptr(Ts, c_float), len(arrs), stride,
+                                                  leaf, out.ctypes.data_as(c_void_p), total, byref(m)), "scl_assemble_submap")
+        return out[:m.value].copy()
 
     def transform_cloud(self, cloud, T):
         a, n, stride = _cloud(cloud)

@@ -24,6 +24,9 @@ def _lib():
         L.icpo_icp_align.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, POINTER(IcpoParams), POINTER(c_float),
                                      POINTER(c_float), POINTER(c_int), POINTER(c_int)]
         L.icpo_rotation_from_covariance.argtypes = [POINTER(c_double), POINTER(c_double)]
+        L.icpo_voxel_grid.restype = c_int
+        L.icpo_voxel_grid.argtypes = [c_void_p, c_int, c_int, c_float, c_void_p]
+        L.icpo_pose_to_matrix.argtypes = [c_float] * 6 + [POINTER(c_float)]
         L.icpo_ransac.restype = c_int
         L.icpo_ransac.argtypes = [c_void_p, c_void_p, c_int, POINTER(c_int), POINTER(c_int), c_int, c_int, c_double,
                                   ctypes.c_ulonglong, POINTER(c_int), POINTER(c_int), POINTER(c_double)]
@@ -97,3 +100,16 @@ def geometric_verification(src, tgt, ransac_iterations=1000, inlier_threshold=0.
                                        inlier_threshold, inlier_ratio, seed, T.ctypes.data_as(POINTER(c_float)),
                                        byref(ok), byref(nc), byref(ni))
     return T.reshape(4, 4), bool(ok.value), nc.value, ni.value
+
+
+def voxel_grid(cloud, leaf):
+    a, n, st = _c(cloud)
+    out = np.empty_like(a)
+    m = _lib().icpo_voxel_grid(a.ctypes.data_as(c_void_p), n, st, leaf, out.ctypes.data_as(c_void_p))
+    return None if m < 0 else out[:m].copy()
+
+
+def pose_to_matrix(x, y, z, roll, pitch, yaw):
+    T = np.empty(16, np.float32)
+    _lib().icpo_pose_to_matrix(x, y, z, roll, pitch, yaw, T.ctypes.data_as(POINTER(c_float)))
+    return T.reshape(4, 4)

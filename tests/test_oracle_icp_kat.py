@@ -119,3 +119,31 @@ def test_geometric_verification_gate():
     far = src.copy(); far[:, :3] += np.random.RandomState(2).uniform(-30, 30, size=(len(src), 3)).astype(np.float32)
     Tg, ok, nc, ni = oi.geometric_verification(far, tgt, 300, 0.25, 0.45, seed=3)
     assert not ok and ni < 0.45 * nc                                 # DM.h:1238
+
+
+def test_voxel_grid_known_answers():
+    c = np.zeros((6, 8), np.float32)
+    c[:, :3] = [[0.05, 0.05, 0.05], [0.15, 0.02, 0.01], [1.05, 0.0, 0.0], [0.0, 1.05, 0.0], [0.01, 0.03, 0.02], [np.nan, 0, 0]]
+    c[:, 4] = [10, 20, 30, 40, 60, 99]
+    out = oi.voxel_grid(c, 0.2)
+    # points 0, 1, 4 share voxel (0,0,0) -> centroid; NaN point dropped; order = ascending voxel index (x fastest)
+    assert out.shape[0] == 3
+    np.testing.assert_allclose(out[0, :3], c[[0, 1, 4], :3].mean(0), rtol=1e-6)
+    assert out[0, 4] == np.float32((10 + 20 + 60) / 3.0)
+    np.testing.assert_allclose(out[1, :3], [1.05, 0, 0]); np.testing.assert_allclose(out[2, :3], [0, 1.05, 0])
+    assert not out[:, [3, 5, 6, 7]].any()
+    assert oi.voxel_grid(np.zeros((0, 8), np.float32), 0.2).shape[0] == 0
+    huge = np.zeros((2, 8), np.float32); huge[1, :3] = 1e6
+    assert oi.voxel_grid(huge, 0.001) is None              # index range overflows int32: PCL refuses
+
+
+def test_voxel_grid_reduces_and_preserves_mean():
+    c = synth_structured_cloud(20000, seed=5)
+    out = oi.voxel_grid(c, 0.4)
+    assert 100 < out.shape[0] < 20000
+    assert abs(out[:, 0].mean() - c[:, 0].mean()) < 2.0
+
+
+def test_pose_matrix_matches_euler_convention():
+    T = oi.pose_to_matrix(1, 2, 3, 0.1, -0.2, 0.7)
+    np.testing.assert_allclose(T, rigid_transform(0.1, -0.2, 0.7, 1, 2, 3), atol=1e-6)
