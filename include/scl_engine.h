@@ -164,7 +164,9 @@ typedef struct scl_icp_params {
     double max_correspondence_dist;   /* icp.setMaxCorrespondenceDistance(100) DM.h:1109 */
     double transformation_epsilon;    /* icp.setTransformationEpsilon(1e-6)  DM.h:1111 */
     double euclidean_fitness_epsilon; /* icp.setEuclideanFitnessEpsilon(1e-6) DM.h:1112 */
-    int    estimator;                 /* 0 = point-to-point SVD (reference), 1 = point-to-plane */
+    int    estimator;                 /* 0 = point-to-point SVD (reference, DM.h:1108), 1 = point-to-plane LLS
+                                         (BASELINE configs[2]; target normals by PCA within normal_radius) */
+    double normal_radius;             /* neighbourhood radius of the target normals, metres (1.0) */
 } scl_icp_params;
 
 int  scl_icp_default_params(scl_icp_params *p);

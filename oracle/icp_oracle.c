@@ -23,6 +23,8 @@ void icpo_default_params(icpo_params *p)
     p->max_correspondence_dist = 100.0;
     p->transformation_epsilon = 1e-6;
     p->euclidean_fitness_epsilon = 1e-6;
+    p->estimator = 0;
+    p->normal_radius = 1.0;
 }
 
 static inline const float *pt(const void *base, int i, int stride)
@@ -260,6 +262,129 @@ static void mat4_mul(const float A[16], const float B[16], float C[16])
     memcpy(C, r, sizeof r);
 }
 
+/* ---- point-to-plane pieces -------------------------------------------------------------------------- */
+static void jacobi_eig3(double A[3][3], double V[3][3])
+{
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) V[i][j] = (i == j);
+    for (int sweep = 0; sweep < 32; sweep++) {
+        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; p++) for (int q = p + 1; q < 3; q++) {
+            if (A[p][q] == 0.0) continue;
+            const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+            for (int k = 0; k < 3; k++) { const double a = A[k][p], b = A[k][q]; A[k][p] = c * a - s * b; A[k][q] = s * a + c * b; }
+            for (int k = 0; k < 3; k++) { const double a = A[p][k], b = A[q][k]; A[p][k] = c * a - s * b; A[q][k] = s * a + c * b; }
+            for (int k = 0; k < 3; k++) { const double a = V[k][p], b = V[k][q]; V[k][p] = c * a - s * b; V[k][q] = s * a + c * b; }
+        }
+    }
+}
+
+void icpo_normals(const void *tgt, int n_tgt, int stride, double radius, float *normals)
+{
+    /* uniform grid with cell = radius: neighbours live in the 27 surrounding cells */
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = 0; i < n_tgt; i++) { const float *p = pt(tgt, i, stride); for (int a = 0; a < 3; a++) { if (p[a] < mn[a]) mn[a] = p[a]; if (p[a] > mx[a]) mx[a] = p[a]; } }
+    int dim[3]; size_t cells = 1;
+    for (int a = 0; a < 3; a++) { dim[a] = n_tgt ? (int)floor(((double)mx[a] - mn[a]) / radius) + 1 : 1; cells *= (size_t)dim[a]; }
+    int *start = (int *)calloc(cells + 1, sizeof(int));
+    int *items = (int *)malloc(sizeof(int) * (size_t)(n_tgt > 0 ? n_tgt : 1));
+    int *cell = (int *)malloc(sizeof(int) * (size_t)(n_tgt > 0 ? n_tgt : 1));
+    for (int i = 0; i < n_tgt; i++) {
+        const float *p = pt(tgt, i, stride);
+        int c[3];
+        for (int a = 0; a < 3; a++) { c[a] = (int)floor(((double)p[a] - mn[a]) / radius); if (c[a] >= dim[a]) c[a] = dim[a] - 1; if (c[a] < 0) c[a] = 0; }
+        cell[i] = (c[2] * dim[1] + c[1]) * dim[0] + c[0];
+        start[cell[i] + 1]++;
+    }
+    for (size_t k = 0; k < cells; k++) start[k + 1] += start[k];
+    int *fill = (int *)malloc(sizeof(int) * cells);
+    memcpy(fill, start, sizeof(int) * cells);
+    for (int i = 0; i < n_tgt; i++) items[fill[cell[i]]++] = i;
+    const double r2 = radius * radius;
+    for (int i = 0; i < n_tgt; i++) {
+        const float *p = pt(tgt, i, stride);
+        const int cz = cell[i] / (dim[0] * dim[1]), cy = (cell[i] / dim[0]) % dim[1], cx = cell[i] % dim[0];
+        double sum[3] = {0, 0, 0}, sq[6] = {0, 0, 0, 0, 0, 0};
+        int cnt = 0;
+        for (int z = cz - 1; z <= cz + 1; z++) for (int y = cy - 1; y <= cy + 1; y++) for (int x = cx - 1; x <= cx + 1; x++) {
+            if (x < 0 || y < 0 || z < 0 || x >= dim[0] || y >= dim[1] || z >= dim[2]) continue;
+            const int c = (z * dim[1] + y) * dim[0] + x;
+            for (int k = start[c]; k < start[c + 1]; k++) {
+                const float *q = pt(tgt, items[k], stride);
+                const double dx = (double)q[0] - p[0], dy = (double)q[1] - p[1], dz = (double)q[2] - p[2];
+                if (dx * dx + dy * dy + dz * dz > r2) continue;
+                sum[0] += dx; sum[1] += dy; sum[2] += dz;             /* relative to p: well conditioned */
+                sq[0] += dx * dx; sq[1] += dx * dy; sq[2] += dx * dz; sq[3] += dy * dy; sq[4] += dy * dz; sq[5] += dz * dz;
+                cnt++;
+            }
+        }
+        float *n = normals + (size_t)i * 3;
+        n[0] = n[1] = n[2] = 0.0f;
+        if (cnt < 3) continue;
+        const double N = (double)cnt, m0 = sum[0] / N, m1 = sum[1] / N, m2 = sum[2] / N;
+        double C[3][3], V[3][3];
+        C[0][0] = sq[0] / N - m0 * m0; C[0][1] = sq[1] / N - m0 * m1; C[0][2] = sq[2] / N - m0 * m2;
+        C[1][1] = sq[3] / N - m1 * m1; C[1][2] = sq[4] / N - m1 * m2; C[2][2] = sq[5] / N - m2 * m2;
+        C[1][0] = C[0][1]; C[2][0] = C[0][2]; C[2][1] = C[1][2];
+        jacobi_eig3(C, V);
+        int m = 0;
+        for (int a = 1; a < 3; a++) if (C[a][a] < C[m][m]) m = a;
+        n[0] = (float)V[0][m]; n[1] = (float)V[1][m]; n[2] = (float)V[2][m];
+    }
+    free(start); free(items); free(cell); free(fill);
+}
+
+/* 6x6 solve by Gaussian elimination with partial pivoting; returns 0 when singular */
+static int solve6(double A[6][6], double b[6], double x[6])
+{
+    int perm[6];
+    for (int i = 0; i < 6; i++) perm[i] = i;
+    for (int c = 0; c < 6; c++) {
+        int piv = c; double best = fabs(A[c][c]);
+        for (int r = c + 1; r < 6; r++) if (fabs(A[r][c]) > best) { best = fabs(A[r][c]); piv = r; }
+        if (!(best > 1e-300)) return 0;
+        if (piv != c) { for (int k = 0; k < 6; k++) { double t = A[c][k]; A[c][k] = A[piv][k]; A[piv][k] = t; } double t = b[c]; b[c] = b[piv]; b[piv] = t; }
+        for (int r = c + 1; r < 6; r++) {
+            const double f = A[r][c] / A[c][c];
+            for (int k = c; k < 6; k++) A[r][k] -= f * A[c][k];
+            b[r] -= f * b[c];
+        }
+    }
+    for (int r = 5; r >= 0; r--) {
+        double s = b[r];
+        for (int k = r + 1; k < 6; k++) s -= A[r][k] * x[k];
+        x[r] = s / A[r][r];
+    }
+    (void)perm;
+    return 1;
+}
+
+/* TransformationEstimationPointToPlaneLLS: minimise sum(((R p + t - q) . n)^2) linearised in the angles
+ * (Low 2004); the rotation is rebuilt exactly from the three angles (Rz(g) Ry(b) Rx(a)). */
+static int estimate_point_to_plane(const void *src, const void *tgt, int stride, const float *normals,
+                                   const int *si, const int *ti, int n, float T[16])
+{
+    double ATA[6][6] = {{0}}, ATb[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n; i++) {
+        const float *p = pt(src, si[i], stride), *q = pt(tgt, ti[i], stride);
+        const float *nn = normals + (size_t)ti[i] * 3;
+        const double px = p[0], py = p[1], pz = p[2], nx = nn[0], ny = nn[1], nz = nn[2];
+        const double row[6] = {py * nz - pz * ny, pz * nx - px * nz, px * ny - py * nx, nx, ny, nz};
+        const double r = ((double)q[0] - px) * nx + ((double)q[1] - py) * ny + ((double)q[2] - pz) * nz;
+        for (int a = 0; a < 6; a++) { for (int b = 0; b < 6; b++) ATA[a][b] += row[a] * row[b]; ATb[a] += row[a] * r; }
+    }
+    double x[6];
+    if (!solve6(ATA, ATb, x)) return -1;
+    const double ca = cos(x[0]), sa = sin(x[0]), cb = cos(x[1]), sb = sin(x[1]), cg = cos(x[2]), sg = sin(x[2]);
+    T[0] = (float)(cg * cb); T[1] = (float)(-sg * ca + cg * sb * sa); T[2] = (float)(sg * sa + cg * sb * ca);  T[3] = (float)x[3];
+    T[4] = (float)(sg * cb); T[5] = (float)(cg * ca + sg * sb * sa);  T[6] = (float)(-cg * sa + sg * sb * ca); T[7] = (float)x[4];
+    T[8] = (float)(-sb);     T[9] = (float)(cb * sa);                 T[10] = (float)(cb * ca);                T[11] = (float)x[5];
+    T[12] = T[13] = T[14] = 0.0f; T[15] = 1.0f;
+    return 0;
+}
+
 /* pcl::IterativeClosestPoint::align */
 int icpo_icp_align(const void *src, int n_src, const void *tgt, int n_tgt, int stride_bytes,
                    const icpo_params *p, float T[16], float *fitness, int *converged, int *iterations)
@@ -272,6 +397,11 @@ int icpo_icp_align(const void *src, int n_src, const void *tgt, int n_tgt, int s
     int *si = (int *)malloc(sizeof(int) * (size_t)(n_src > 0 ? n_src : 1));
     int *ti = (int *)malloc(sizeof(int) * (size_t)(n_src > 0 ? n_src : 1));
     float final[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    float *normals = NULL;
+    if (p->estimator == 1) {
+        normals = (float *)malloc(sizeof(float) * 3 * (size_t)(n_tgt > 0 ? n_tgt : 1));
+        icpo_normals(tgt, n_tgt, stride_bytes, p->normal_radius, normals);
+    }
     const float maxd2 = (float)(p->max_correspondence_dist * p->max_correspondence_dist);
     double mse_prev = DBL_MAX;
     int iter = 0, conv = 0;
@@ -282,7 +412,11 @@ int icpo_icp_align(const void *src, int n_src, const void *tgt, int n_tgt, int s
             if (nn[i] >= 0 && d2[i] <= maxd2) { si[nc] = i; ti[nc] = nn[i]; sum_d2 += (double)d2[i]; nc++; }
         if (nc < 3) { conv = 0; break; }                                  /* not enough correspondences */
         float Tinc[16];
-        estimate_rigid(work, tgt, stride_bytes, si, ti, nc, Tinc);
+        if (p->estimator == 1) {
+            if (estimate_point_to_plane(work, tgt, stride_bytes, normals, si, ti, nc, Tinc) != 0) { conv = 0; break; }
+        } else {
+            estimate_rigid(work, tgt, stride_bytes, si, ti, nc, Tinc);
+        }
         icpo_transform(work, n_src, stride_bytes, Tinc, work);
         mat4_mul(Tinc, final, final);
         iter++;
@@ -305,7 +439,7 @@ int icpo_icp_align(const void *src, int n_src, const void *tgt, int n_tgt, int s
     memcpy(T, final, sizeof final);
     if (converged) *converged = conv;
     if (iterations) *iterations = iter;
-    free(work); free(nn); free(d2); free(si); free(ti);
+    free(work); free(nn); free(d2); free(si); free(ti); free(normals);
     return 0;
 }
 

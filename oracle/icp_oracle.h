@@ -24,6 +24,8 @@ typedef struct icpo_params {
     double max_correspondence_dist;    /* DM.h:1109  (100)  */
     double transformation_epsilon;     /* DM.h:1111  (1e-6) */
     double euclidean_fitness_epsilon;  /* DM.h:1112  (1e-6) */
+    int    estimator;                  /* 0 point-to-point (reference), 1 point-to-plane (BASELINE configs[2]) */
+    double normal_radius;              /* neighbourhood of the target normals (1.0 m) */
 } icpo_params;
 
 void icpo_default_params(icpo_params *p);
@@ -46,6 +48,11 @@ void icpo_transform(const void *in, int n, int stride_bytes, const float T[16], 
 /* pcl::IterativeClosestPoint::align + getFitnessScore, DM.h:1108-1121 */
 int  icpo_icp_align(const void *src, int n_src, const void *tgt, int n_tgt, int stride_bytes,
                     const icpo_params *p, float T[16], float *fitness, int *converged, int *iterations);
+
+/* Target normals for the point-to-plane estimator: PCA of all target points within `radius` of the point
+ * (itself included), fp64 covariance, eigenvector of the smallest eigenvalue (cyclic Jacobi); fewer than
+ * 3 neighbours -> (0,0,0).  normals: n_tgt x 3 floats. */
+void icpo_normals(const void *tgt, int n_tgt, int stride_bytes, double radius, float *normals);
 
 /* CorrespondenceRejectorSampleConsensus (DM.h:1218-1225), restated as a deterministic RANSAC:
  * hypothesis h draws 3 distinct correspondences with a counter-based generator (splitmix64 of

@@ -373,7 +373,7 @@ const char *scl_status_string(int status)
 
 const char *scl_last_error(const scl_engine *e) { return e ? e->last_error.c_str() : "null engine"; }
 
-int scl_abi_version(void) { return 1; }
+int scl_abi_version(void) { return 2; }
 
 int scl_default_config(scl_config *c)
 {
@@ -865,6 +865,7 @@ int scl_icp_default_params(scl_icp_params *p)
     p->transformation_epsilon = 1e-6;     /* DM.h:1111 */
     p->euclidean_fitness_epsilon = 1e-6;  /* DM.h:1112 */
     p->estimator = 0;
+    p->normal_radius = 1.0;
     return SCL_OK;
 }
 

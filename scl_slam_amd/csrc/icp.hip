@@ -48,6 +48,7 @@ struct IcpState {
 };
 
 enum Buf { B_SRC = 0, B_TGT, B_WORK, B_TSORT, B_CSTART, B_CFILL, B_NNI, B_NND, B_PART, B_STATE, B_BBOX, B_SI, B_TI, B_OUT, B_MASK, B_HYP };
+constexpr int B_NORM = B_OUT;             // target normals share the slot of the raw-transform output (never live together)
 
 int ensure(IcpWorkspace *ws, int k, size_t bytes, std::string *err)
 {
@@ -382,6 +383,28 @@ __device__ void rotation_from_S(const double S[3][3], double R[3][3])
     R[2][0] = 2 * (x * z - w * y);           R[2][1] = 2 * (y * z + w * x);           R[2][2] = w * w - x * x - y * y + z * z;
 }
 
+// final = T_inc * final, ++iter, pcl::registration::DefaultConvergenceCriteria
+__device__ void apply_increment(IcpState *st, const float *T, double sum_d2, double N, int max_iter,
+                                double trans_eps, double fit_eps)
+{
+    float F[16];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
+        float s = 0.f;
+        for (int k = 0; k < 4; ++k) s += T[i * 4 + k] * st->final_T[k * 4 + j];
+        F[i * 4 + j] = s;
+    }
+    for (int k = 0; k < 16; ++k) st->final_T[k] = F[k];
+    st->iter += 1;
+    if (st->iter >= max_iter) { st->done = 1; st->converged = 1; return; }
+    const double cos_angle = 0.5 * ((double)T[0] + (double)T[5] + (double)T[10] - 1.0);
+    const double tsq = (double)T[3] * T[3] + (double)T[7] * T[7] + (double)T[11] * T[11];
+    if (cos_angle >= 1.0 - trans_eps && tsq <= trans_eps) { st->done = 1; st->converged = 1; return; }
+    const double mse = sum_d2 / N;
+    if (fabs(mse - st->mse_prev) < 1e-12) { st->done = 1; st->converged = 1; return; }
+    if (fabs(mse - st->mse_prev) / st->mse_prev < fit_eps) { st->done = 1; st->converged = 1; return; }
+    st->mse_prev = mse;
+}
+
 // mode 0: ICP iteration (convergence bookkeeping); mode 1: one-shot rigid estimate; mode 2: fitness only
 __global__ void icp_solve_kernel(IcpState *st, const double *partials, int nblocks, int mode,
                                  int max_iter, double trans_eps, double fit_eps)
@@ -412,23 +435,154 @@ __global__ void icp_solve_kernel(IcpState *st, const double *partials, int nbloc
     T[12] = T[13] = T[14] = 0.f; T[15] = 1.f;
     for (int k = 0; k < 16; ++k) st->inc_T[k] = T[k];
     if (mode == 1) { for (int k = 0; k < 16; ++k) st->final_T[k] = T[k]; return; }
-    float F[16];
-    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
-        float s = 0.f;
-        for (int k = 0; k < 4; ++k) s += T[i * 4 + k] * st->final_T[k * 4 + j];
-        F[i * 4 + j] = s;
+    apply_increment(st, T, sums[16], N, max_iter, trans_eps, fit_eps);
+}
+
+// ---- point-to-plane estimator (BASELINE configs[2]; the reference itself is point-to-point) ---------
+constexpr int kNPlane = 29;              // 21 (upper triangle of A^T A) + 6 (A^T b) + sum d2 + count
+
+__device__ void jacobi_eig3(double A[3][3], double V[3][3])
+{
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 32; ++sweep) {
+        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; ++p) for (int q = p + 1; q < 3; ++q) {
+            if (A[p][q] == 0.0) continue;
+            const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+            const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+            for (int k = 0; k < 3; ++k) { const double a = A[k][p], b = A[k][q]; A[k][p] = c * a - s * b; A[k][q] = s * a + c * b; }
+            for (int k = 0; k < 3; ++k) { const double a = A[p][k], b = A[q][k]; A[p][k] = c * a - s * b; A[q][k] = s * a + c * b; }
+            for (int k = 0; k < 3; ++k) { const double a = V[k][p], b = V[k][q]; V[k][p] = c * a - s * b; V[k][q] = s * a + c * b; }
+        }
     }
-    for (int k = 0; k < 16; ++k) st->final_T[k] = F[k];
-    st->iter += 1;
-    // pcl::registration::DefaultConvergenceCriteria
-    if (st->iter >= max_iter) { st->done = 1; st->converged = 1; return; }
-    const double cos_angle = 0.5 * ((double)T[0] + (double)T[5] + (double)T[10] - 1.0);
-    const double tsq = (double)T[3] * T[3] + (double)T[7] * T[7] + (double)T[11] * T[11];
-    if (cos_angle >= 1.0 - trans_eps && tsq <= trans_eps) { st->done = 1; st->converged = 1; return; }
-    const double mse = sums[16] / N;
-    if (fabs(mse - st->mse_prev) < 1e-12) { st->done = 1; st->converged = 1; return; }
-    if (fabs(mse - st->mse_prev) / st->mse_prev < fit_eps) { st->done = 1; st->converged = 1; return; }
-    st->mse_prev = mse;
+}
+
+// target normals: PCA of the points within `radius` (searched through the NN grid)
+__global__ __launch_bounds__(256) void normals_kernel(const unsigned char *tgt, int n_tgt, int stride, const IcpState *st,
+                                                      const int *cell_start, const float4 *sorted, double radius, float4 *normals)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tgt) return;
+    const float3 p = load_xyz(tgt, i, stride);
+    const float pv[3] = {p.x, p.y, p.z};
+    int lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) {
+        const double l = floor(((double)pv[a] - radius - (double)st->mn[a]) / (double)st->h) - 1.0;
+        const double h = floor(((double)pv[a] + radius - (double)st->mn[a]) / (double)st->h) + 1.0;
+        lo[a] = l < 0.0 ? 0 : (int)l;
+        hi[a] = h >= (double)st->dim[a] ? st->dim[a] - 1 : (int)h;
+    }
+    const double r2 = radius * radius;
+    double sum[3] = {0, 0, 0}, sq[6] = {0, 0, 0, 0, 0, 0};
+    int cnt = 0;
+    for (int z = lo[2]; z <= hi[2]; ++z) for (int y = lo[1]; y <= hi[1]; ++y) {
+        const int kb = cell_start[(z * st->dim[1] + y) * st->dim[0] + lo[0]];
+        const int ke = cell_start[(z * st->dim[1] + y) * st->dim[0] + hi[0] + 1];       // cells along x are contiguous
+        for (int k = kb; k < ke; ++k) {
+            const float4 q = sorted[k];
+            const double dx = (double)q.x - (double)p.x, dy = (double)q.y - (double)p.y, dz = (double)q.z - (double)p.z;
+            if (dx * dx + dy * dy + dz * dz > r2) continue;
+            sum[0] += dx; sum[1] += dy; sum[2] += dz;
+            sq[0] += dx * dx; sq[1] += dx * dy; sq[2] += dx * dz; sq[3] += dy * dy; sq[4] += dy * dz; sq[5] += dz * dz;
+            ++cnt;
+        }
+    }
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cnt >= 3) {
+        const double N = (double)cnt, m0 = sum[0] / N, m1 = sum[1] / N, m2 = sum[2] / N;
+        double C[3][3], V[3][3];
+        C[0][0] = sq[0] / N - m0 * m0; C[0][1] = sq[1] / N - m0 * m1; C[0][2] = sq[2] / N - m0 * m2;
+        C[1][1] = sq[3] / N - m1 * m1; C[1][2] = sq[4] / N - m1 * m2; C[2][2] = sq[5] / N - m2 * m2;
+        C[1][0] = C[0][1]; C[2][0] = C[0][2]; C[2][1] = C[1][2];
+        jacobi_eig3(C, V);
+        int m = 0;
+        for (int a = 1; a < 3; ++a) if (C[a][a] < C[m][m]) m = a;
+        out = make_float4((float)V[0][m], (float)V[1][m], (float)V[2][m], 0.f);
+    }
+    normals[i] = out;
+}
+
+__global__ __launch_bounds__(256) void plane_reduce_kernel(const float4 *work, const unsigned char *tgt_raw, int stride, int n,
+                                                           const int *nn_idx, const float *nn_d2, float maxd2,
+                                                           const float4 *normals, const IcpState *st, double *partials)
+{
+    if (st->done) return;
+    double acc[kNPlane];
+#pragma unroll
+    for (int k = 0; k < kNPlane; ++k) acc[k] = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int j = nn_idx[i];
+        const float d2 = nn_d2[i];
+        if (j < 0 || !(d2 <= maxd2)) continue;
+        const float4 pw = work[i];
+        const float3 q = load_xyz(tgt_raw, j, stride);
+        const float4 nn = normals[j];
+        const double px = pw.x, py = pw.y, pz = pw.z, nx = nn.x, ny = nn.y, nz = nn.z;
+        const double row[6] = {py * nz - pz * ny, pz * nx - px * nz, px * ny - py * nx, nx, ny, nz};
+        const double r = ((double)q.x - px) * nx + ((double)q.y - py) * ny + ((double)q.z - pz) * nz;
+        int t = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b) acc[t++] += row[a] * row[b];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) acc[21 + a] += row[a] * r;
+        acc[27] += (double)d2;
+        acc[28] += 1.0;
+    }
+    __shared__ double s[4][kNPlane];
+#pragma unroll
+    for (int k = 0; k < kNPlane; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off, kWave);
+    }
+    const int wv = threadIdx.x / kWave;
+    if ((threadIdx.x & 63) == 0) for (int k = 0; k < kNPlane; ++k) s[wv][k] = acc[k];
+    __syncthreads();
+    if (threadIdx.x < kNPlane)
+        partials[blockIdx.x * kNPlane + threadIdx.x] = ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x];
+}
+
+__global__ void plane_solve_kernel(IcpState *st, const double *partials, int nblocks, int max_iter, double trans_eps, double fit_eps)
+{
+    __shared__ double sums[kNPlane];
+    if (st->done) return;
+    if (threadIdx.x < kNPlane) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += partials[b * kNPlane + threadIdx.x];
+        sums[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const double N = sums[28];
+    st->n_corr = (int)N;
+    if (N < 3.0) { st->done = 1; st->converged = 0; return; }
+    double A[6][6], b[6], x[6];
+    int t = 0;
+    for (int a = 0; a < 6; ++a) for (int c = a; c < 6; ++c) { A[a][c] = sums[t]; A[c][a] = sums[t]; ++t; }
+    for (int a = 0; a < 6; ++a) b[a] = sums[21 + a];
+    for (int c = 0; c < 6; ++c) {                                      // Gaussian elimination, partial pivoting
+        int piv = c; double best = fabs(A[c][c]);
+        for (int r = c + 1; r < 6; ++r) if (fabs(A[r][c]) > best) { best = fabs(A[r][c]); piv = r; }
+        if (!(best > 1e-300)) { st->done = 1; st->converged = 0; return; }
+        if (piv != c) { for (int k = 0; k < 6; ++k) { const double tmp = A[c][k]; A[c][k] = A[piv][k]; A[piv][k] = tmp; } const double tmp = b[c]; b[c] = b[piv]; b[piv] = tmp; }
+        for (int r = c + 1; r < 6; ++r) {
+            const double f = A[r][c] / A[c][c];
+            for (int k = c; k < 6; ++k) A[r][k] -= f * A[c][k];
+            b[r] -= f * b[c];
+        }
+    }
+    for (int r = 5; r >= 0; --r) { double sacc = b[r]; for (int k = r + 1; k < 6; ++k) sacc -= A[r][k] * x[k]; x[r] = sacc / A[r][r]; }
+    const double ca = cos(x[0]), sa = sin(x[0]), cb = cos(x[1]), sb = sin(x[1]), cg = cos(x[2]), sg = sin(x[2]);
+    float T[16];
+    T[0] = (float)(cg * cb); T[1] = (float)(-sg * ca + cg * sb * sa); T[2] = (float)(sg * sa + cg * sb * ca);  T[3] = (float)x[3];
+    T[4] = (float)(sg * cb); T[5] = (float)(cg * ca + sg * sb * sa);  T[6] = (float)(-cg * sa + sg * sb * ca); T[7] = (float)x[4];
+    T[8] = (float)(-sb);     T[9] = (float)(cb * sa);                 T[10] = (float)(cb * ca);                T[11] = (float)x[5];
+    T[12] = T[13] = T[14] = 0.f; T[15] = 1.f;
+    for (int k = 0; k < 16; ++k) st->inc_T[k] = T[k];
+    apply_increment(st, T, sums[27], N, max_iter, trans_eps, fit_eps);
 }
 
 // ---- K6 ----------------------------------------------------------------------------
@@ -683,16 +837,24 @@ int icp_align(IcpWorkspace *ws, hipStream_t stream, int num_cu, const void *src,
     (void)num_cu;
     int rc = check_cloud_args(n_src, n_tgt, stride, err);
     if (rc) return rc;
-    if (p.estimator != 0) { if (err) *err = "point-to-plane estimator: not implemented in this round"; return SCL_ERR_UNSUPPORTED; }
+    if (p.estimator != 0 && p.estimator != 1) { if (err) *err = "unknown estimator"; return SCL_ERR_INVALID_ARG; }
+    if (p.estimator == 1 && !(p.normal_radius > 0.0)) { if (err) *err = "normal_radius must be > 0"; return SCL_ERR_INVALID_ARG; }
     if (p.max_iterations < 1) { if (err) *err = "max_iterations < 1"; return SCL_ERR_INVALID_ARG; }
     if ((rc = upload(ws, B_SRC, src, (size_t)n_src * stride, stream, err))) return rc;
     if ((rc = upload(ws, B_TGT, tgt, (size_t)n_tgt * stride, stream, err))) return rc;
     if ((rc = ensure(ws, B_WORK, sizeof(float4) * (size_t)(n_src + 1), err))) return rc;
     if ((rc = ensure(ws, B_NNI, sizeof(int) * (size_t)(n_src + 1), err))) return rc;
     if ((rc = ensure(ws, B_NND, sizeof(float) * (size_t)(n_src + 1), err))) return rc;
-    if ((rc = ensure(ws, B_PART, sizeof(double) * kNSum * kRedBlocks, err))) return rc;
+    if ((rc = ensure(ws, B_PART, sizeof(double) * kNPlane * kRedBlocks, err))) return rc;
     if ((rc = build_grid(ws, stream, n_tgt, stride, err))) return rc;
     if ((rc = pinned(ws, sizeof(IcpState), err))) return rc;
+    if (p.estimator == 1) {
+        if ((rc = ensure(ws, B_NORM, sizeof(float4) * (size_t)(n_tgt + 1), err))) return rc;
+        hipLaunchKernelGGL(normals_kernel, dim3((n_tgt + 255) / 256 > 0 ? (n_tgt + 255) / 256 : 1), dim3(256), 0, stream,
+                           (const unsigned char *)ws->buf[B_TGT], n_tgt, stride, (const IcpState *)ws->buf[B_STATE],
+                           (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], p.normal_radius,
+                           (float4 *)ws->buf[B_NORM]);
+    }
 
     IcpState *st = static_cast<IcpState *>(ws->buf[B_STATE]);
     float4 *work = static_cast<float4 *>(ws->buf[B_WORK]);
@@ -711,10 +873,17 @@ int icp_align(IcpWorkspace *ws, hipStream_t stream, int num_cu, const void *src,
     for (int it = 0; it < p.max_iterations; ++it) {
         hipLaunchKernelGGL(nn_search_kernel, dim3(pb), dim3(256), 0, stream, work, n_src, st,
                            (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], nni, nnd, 1);
-        LAUNCH_REDUCE(rb, stream, work, d_src, d_tgt, stride, n_src,
-                      nni, nnd, maxd2, (const int *)nullptr, (const int *)nullptr, 0, st, part, 1);
-        hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, stream, st, part, rb, 0, p.max_iterations,
-                           p.transformation_epsilon, p.euclidean_fitness_epsilon);
+        if (p.estimator == 1) {
+            hipLaunchKernelGGL(plane_reduce_kernel, dim3(rb), dim3(256), 0, stream, work, d_tgt, stride, n_src, nni, nnd, maxd2,
+                               (const float4 *)ws->buf[B_NORM], st, part);
+            hipLaunchKernelGGL(plane_solve_kernel, dim3(1), dim3(64), 0, stream, st, part, rb, p.max_iterations,
+                               p.transformation_epsilon, p.euclidean_fitness_epsilon);
+        } else {
+            LAUNCH_REDUCE(rb, stream, work, d_src, d_tgt, stride, n_src,
+                          nni, nnd, maxd2, (const int *)nullptr, (const int *)nullptr, 0, st, part, 1);
+            hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, stream, st, part, rb, 0, p.max_iterations,
+                               p.transformation_epsilon, p.euclidean_fitness_epsilon);
+        }
         // applies inc_T iff the solve of this very iteration ran (also when it just declared convergence)
         hipLaunchKernelGGL(work_transform_kernel, dim3(pb), dim3(256), 0, stream, work, d_src, n_src, stride, st, 0, it + 1);
         if ((it & 7) == 7) {                                   // peek at the device flag every 8 iterations

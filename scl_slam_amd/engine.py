@@ -31,7 +31,7 @@ class IcpParams(ctypes.Structure):
     _fields_ = [
         ("max_iterations", c_int), ("max_correspondence_dist", c_double),
         ("transformation_epsilon", c_double), ("euclidean_fitness_epsilon", c_double),
-        ("estimator", c_int),
+        ("estimator", c_int), ("normal_radius", c_double),
     ]
 
 

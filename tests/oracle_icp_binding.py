@@ -9,7 +9,8 @@ import oracle_binding as ob
 
 class IcpoParams(ctypes.Structure):
     _fields_ = [("max_iterations", c_int), ("max_correspondence_dist", c_double),
-                ("transformation_epsilon", c_double), ("euclidean_fitness_epsilon", c_double)]
+                ("transformation_epsilon", c_double), ("euclidean_fitness_epsilon", c_double),
+                ("estimator", c_int), ("normal_radius", c_double)]
 
 
 def _lib():
@@ -24,6 +25,7 @@ def _lib():
         L.icpo_icp_align.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, POINTER(IcpoParams), POINTER(c_float),
                                      POINTER(c_float), POINTER(c_int), POINTER(c_int)]
         L.icpo_rotation_from_covariance.argtypes = [POINTER(c_double), POINTER(c_double)]
+        L.icpo_normals.argtypes = [c_void_p, c_int, c_int, c_double, POINTER(c_float)]
         L.icpo_voxel_grid.restype = c_int
         L.icpo_voxel_grid.argtypes = [c_void_p, c_int, c_int, c_float, c_void_p]
         L.icpo_pose_to_matrix.argtypes = [c_float] * 6 + [POINTER(c_float)]
@@ -42,8 +44,9 @@ def _c(a):
     return a, a.shape[0], a.shape[1] * 4
 
 
-def default_params(max_iterations=50):
+def default_params(max_iterations=50, estimator=0, normal_radius=1.0):
     p = IcpoParams(); _lib().icpo_default_params(byref(p)); p.max_iterations = max_iterations
+    p.estimator = estimator; p.normal_radius = normal_radius
     return p
 
 
@@ -113,3 +116,10 @@ def pose_to_matrix(x, y, z, roll, pitch, yaw):
     T = np.empty(16, np.float32)
     _lib().icpo_pose_to_matrix(x, y, z, roll, pitch, yaw, T.ctypes.data_as(POINTER(c_float)))
     return T.reshape(4, 4)
+
+
+def normals(tgt, radius=1.0):
+    t, nt, st = _c(tgt)
+    out = np.empty((nt, 3), np.float32)
+    _lib().icpo_normals(t.ctypes.data_as(c_void_p), nt, st, radius, out.ctypes.data_as(POINTER(c_float)))
+    return out

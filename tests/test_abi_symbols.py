@@ -56,3 +56,4 @@ def test_status_strings_and_defaults():
     # DM.h:1109-1112
     assert (p.max_iterations, p.max_correspondence_dist) == (50, 100.0)
     assert (p.transformation_epsilon, p.euclidean_fitness_epsilon) == (1e-6, 1e-6)
+    assert (p.estimator, p.normal_radius) == (0, 1.0)

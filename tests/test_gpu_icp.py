@@ -144,3 +144,17 @@ def test_submap_assembly_matches_oracle(eng):
 def test_pose_to_matrix_matches_oracle(eng):
     for args in [(1, 2, 3, 0.1, -0.2, 0.7), (0, 0, 0, 0, 0, 0), (-5, 4, 0.3, 3.0, 1.2, -2.9)]:
         assert np.array_equal(eng.pose_to_matrix(*args), oi.pose_to_matrix(*args))
+
+
+@pytest.mark.parametrize("n_tgt,noise", [(6000, 0.0), (30000, 0.01)])
+def test_point_to_plane_icp_matches_oracle(eng, n_tgt, noise):
+    """BASELINE configs[2] estimator; the reference itself is point-to-point (DM.h:1108)."""
+    tgt = synth_structured_cloud(n_tgt, seed=3 + n_tgt)
+    T = rigid_transform(0.01, -0.02, 0.05, 0.3, -0.2, 0.1)
+    src = moved_copy(tgt, T, keep_every=2, noise=noise, seed=5)
+    p = eng.icp_default_params(); p.max_iterations = 30; p.estimator = 1; p.normal_radius = 1.5
+    Tg, fg, cg, ig = eng.icp_align(src, tgt, p)
+    To, fo, co, io = oi.icp_align(src, tgt, oi.default_params(30, estimator=1, normal_radius=1.5))
+    assert cg == co and ig == io
+    assert np.abs(Tg - To).max() < TOL and np.abs(Tg - T).max() < 5e-3
+    assert abs(fg - fo) <= 1e-4 * max(1e-6, abs(fo)) + 1e-12
