@@ -489,13 +489,20 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
                         for (int v = 0; v < NQ; ++v) { q[2 * v] = qn[v].x; q[2 * v + 1] = qn[v].y; }
                         pin_ring(acc0, acc1);
                         qp += qstep;                        // the last ring over-reads one row: it lands in
-#pragma unroll                                              // nqe/vq (inside the allocation), values unused
-                        for (int v = 0; v < NQ; ++v) qn[v] = qp[v];
+                        if (MAXT <= 512) {                  // nqe/vq (inside the allocation), values unused
+#pragma unroll
+                            for (int v = 0; v < NQ; ++v) qn[v] = qp[v];
+                        }
                         const double kd0 = (double)a0[i], kd1 = (double)a1[i];
 #pragma unroll
                         for (int t = 0; t < W; ++t) {
                             acc0[t] = fma(kd0, q[t], acc0[t]);
                             acc1[t] = fma(kd1, q[t + 1], acc1[t]);
+                        }
+                        if (MAXT > 512) {                   // 3 waves/SIMD build: one window buffer, the partner
+                            pin_ring(acc0, acc1);           // waves cover the LDS latency instead of a prefetch
+#pragma unroll
+                            for (int v = 0; v < NQ; ++v) qn[v] = qp[v];
                         }
                     }
                 }
@@ -548,31 +555,53 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
                 constexpr int T0 = h * HSH;
                 constexpr int NT = h == 0 ? HSH : W - HSH;
                 wave_fence();
-                double nqv[NT + 1];
-#pragma unroll
-                for (int i = 0; i <= NT; ++i) nqv[i] = nqe[j0 + T0 + i];
-                double s0[NT], s1[NT];
-                bool ok0[NT], ok1[NT];
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt) {
-                    ok0[tt] = !((nqv[tt] == 0.0) | (nk_cur.x == 0.0));                  // D.h:1523
-                    ok1[tt] = !((nqv[tt + 1] == 0.0) | (nk_cur.y == 0.0));
-                    s0[tt] = acc0[T0 + tt] / (nqv[tt] * nk_cur.x);
-                    s1[tt] = acc1[T0 + tt] / (nqv[tt + 1] * nk_cur.y);
-                }
                 int eff = 0;
+                constexpr int HALF = S / 2;
+                if (MAXT <= 512) {
+                    // 2 waves/SIMD build: everything of the pass in flight at once (ILP hides the division latency)
+                    double nqv[NT + 1];
 #pragma unroll
-                for (int tt = 0; tt < NT; ++tt) {
-                    const int x0 = j0 + T0 + tt;                                        // even sector iff T0 + tt is even
-                    const int c0 = x0 >= S ? x0 - S : x0;
-                    const int x1 = x0 + 1;
-                    const int c1 = x1 >= S ? x1 - S : x1;
-                    constexpr int HALF = S / 2;
-                    double *row = simbuf + tt * SB;
-                    row[(c0 >> 1) + (c0 & 1) * HALF] = ok0[tt] ? s0[tt] : 0.0;          // skipped sectors add +0.0: same bits
-                    row[(c1 >> 1) + (c1 & 1) * HALF] = ok1[tt] ? s1[tt] : 0.0;          // (lanes >= L mirror lane L-1)
-                    const int cnt = __popcll(__ballot(active && ok0[tt])) + __popcll(__ballot(active && ok1[tt]));
-                    eff = (lane == tt) ? cnt : eff;
+                    for (int i = 0; i <= NT; ++i) nqv[i] = nqe[j0 + T0 + i];
+                    double s0[NT], s1[NT];
+                    bool ok0[NT], ok1[NT];
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) {
+                        ok0[tt] = !((nqv[tt] == 0.0) | (nk_cur.x == 0.0));                  // D.h:1523
+                        ok1[tt] = !((nqv[tt + 1] == 0.0) | (nk_cur.y == 0.0));
+                        s0[tt] = acc0[T0 + tt] / (nqv[tt] * nk_cur.x);
+                        s1[tt] = acc1[T0 + tt] / (nqv[tt + 1] * nk_cur.y);
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) {
+                        const int x0 = j0 + T0 + tt;                                        // even sector iff T0 + tt is even
+                        const int c0 = x0 >= S ? x0 - S : x0;
+                        const int x1 = x0 + 1;
+                        const int c1 = x1 >= S ? x1 - S : x1;
+                        double *row = simbuf + tt * SB;
+                        row[(c0 >> 1) + (c0 & 1) * HALF] = ok0[tt] ? s0[tt] : 0.0;          // skipped sectors add +0.0: same bits
+                        row[(c1 >> 1) + (c1 & 1) * HALF] = ok1[tt] ? s1[tt] : 0.0;          // (lanes >= L mirror lane L-1)
+                        const int cnt = __popcll(__ballot(active && ok0[tt])) + __popcll(__ballot(active && ok1[tt]));
+                        eff = (lane == tt) ? cnt : eff;
+                    }
+                } else {
+                    // 3 waves/SIMD build: one shift at a time (few live registers), the partner waves hide the latency
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) {
+                        const int x0 = j0 + T0 + tt, x1 = x0 + 1;
+                        const double nq0 = nqe[x0], nq1 = nqe[x1];
+                        const bool k0ok = !((nq0 == 0.0) | (nk_cur.x == 0.0));
+                        const bool k1ok = !((nq1 == 0.0) | (nk_cur.y == 0.0));
+                        const double q0 = acc0[T0 + tt] / (nq0 * nk_cur.x);
+                        const double q1 = acc1[T0 + tt] / (nq1 * nk_cur.y);
+                        const int c0 = x0 >= S ? x0 - S : x0;
+                        const int c1 = x1 >= S ? x1 - S : x1;
+                        double *row = simbuf + tt * SB;
+                        row[(c0 >> 1) + (c0 & 1) * HALF] = k0ok ? q0 : 0.0;
+                        row[(c1 >> 1) + (c1 & 1) * HALF] = k1ok ? q1 : 0.0;
+                        const int cnt = __popcll(__ballot(active && k0ok)) + __popcll(__ballot(active && k1ok));
+                        eff = (lane == tt) ? cnt : eff;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 wave_fence();
                 { const unsigned long long t1 = stamp(); st_c += t1 - st_t; st_t = t1; }
