@@ -168,7 +168,9 @@ hipError_t launch_ingest(const float *values, int count, int first_slot,
 {
     if (count <= 0) return hipSuccess;
     const size_t lds = sizeof(float) * (size_t)R * (S + 1);
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {false};   // per device
+    int dev_ = 0; (void)hipGetDevice(&dev_);
+    bool &attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set && lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)ingest_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -766,7 +766,9 @@ hipError_t launch_wave(const ScArgs &args_in, int num_cu, hipStream_t stream)
     int blocks = (a.n + waves - 1) / waves;
     if (blocks > num_cu) blocks = num_cu;
     const size_t lds = fixed + per_wave * waves + 16;      // + the candidate dispenser
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {false};   // per instantiation and per device
+    int dev_ = 0; (void)hipGetDevice(&dev_);
+    bool &attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)sc_distance_wave_kernel<RG, W, CH, S, MAXT, STAMP>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap);
@@ -953,7 +955,9 @@ hipError_t launch_fast(const ScArgs &args_in, int num_cu, hipStream_t stream)
     int blocks = (a.n + G - 1) / G;
     if (blocks > num_cu) blocks = num_cu;
     const size_t lds = fixed + per_group * G;
-    static bool attr_set = false;   // per instantiation
+    static bool attr_set_dev[64] = {false};   // per instantiation and per device (one engine per GPU in a process is allowed)
+    int dev_ = 0; (void)hipGetDevice(&dev_);
+    bool &attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)sc_distance_kernel<RG, W, MAXT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap);
