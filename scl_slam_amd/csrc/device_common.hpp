@@ -95,6 +95,53 @@ __device__ __forceinline__ void wave_argmin(double &v, int &tag)
     }
 }
 
+// Same result without the LDS round trips of __shfl_xor (ds_bpermute): DPP lane exchanges inside each
+// 16-lane row (xor 1, xor 2, half-row mirror, row mirror), then the four row results through scalar
+// registers.  Requires all 64 lanes active and NaN-free values.  Every lane returns the wave result.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int src_lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), src_lane));
+}
+__device__ __forceinline__ double wave_min_f64_dpp(double v)
+{
+    double o;
+    o = dpp_move_f64<0xB1>(v);  v = o < v ? o : v;      // quad_perm [1,0,3,2]
+    o = dpp_move_f64<0x4E>(v);  v = o < v ? o : v;      // quad_perm [2,3,0,1]
+    o = dpp_move_f64<0x141>(v); v = o < v ? o : v;      // row_half_mirror
+    o = dpp_move_f64<0x140>(v); v = o < v ? o : v;      // row_mirror
+    const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+    const double a = r1 < r0 ? r1 : r0, b = r3 < r2 ? r3 : r2;
+    return b < a ? b : a;
+}
+__device__ __forceinline__ int wave_min_i32_dpp(int t)
+{
+    int o;
+    o = __builtin_amdgcn_update_dpp(0, t, 0xB1, 0xf, 0xf, false);  t = o < t ? o : t;
+    o = __builtin_amdgcn_update_dpp(0, t, 0x4E, 0xf, 0xf, false);  t = o < t ? o : t;
+    o = __builtin_amdgcn_update_dpp(0, t, 0x141, 0xf, 0xf, false); t = o < t ? o : t;
+    o = __builtin_amdgcn_update_dpp(0, t, 0x140, 0xf, 0xf, false); t = o < t ? o : t;
+    const int r0 = __builtin_amdgcn_readlane(t, 0), r1 = __builtin_amdgcn_readlane(t, 16);
+    const int r2 = __builtin_amdgcn_readlane(t, 32), r3 = __builtin_amdgcn_readlane(t, 48);
+    const int a = r1 < r0 ? r1 : r0, b = r3 < r2 ? r3 : r2;
+    return b < a ? b : a;
+}
+// lexicographic arg-min on (value, tag): minimum value, lowest tag among the lanes that hold it
+__device__ __forceinline__ void wave_argmin_dpp(double &v, int &tag)
+{
+    const double m = wave_min_f64_dpp(v);
+    const int t = (v == m) ? tag : 0x7fffffff;
+    tag = wave_min_i32_dpp(t);
+    v = m;
+}
+
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long k)
 {
 #pragma unroll

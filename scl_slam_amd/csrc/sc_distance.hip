@@ -254,17 +254,28 @@ __device__ __forceinline__ void pin_ring(double (&a)[13], double (&b)[13])
                  :: "memory");
 }
 
-// value of `v` held by lane `src_lane` (compile-time), delivered through scalar registers
-__device__ __forceinline__ double lane_bcast(double v, int src_lane)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-    return __hiloint2double(hi, lo);
-}
-
 __device__ __forceinline__ void pin3(double &a, double &b, double &c)
 {
     asm volatile("" : "+v"(a), "+v"(b), "+v"(c) :: "memory");
+}
+// a / b for operands whose quotient needs no exponent scaling: v_rcp_f64, two Newton steps on the
+// reciprocal, one on the quotient -- the exact instruction sequence of the compiler's correctly rounded
+// division (v_div_scale / v_div_fmas / v_div_fixup reduce to the identity in that range).
+__device__ __forceinline__ double quot_core(double a, double b)
+{
+    double y = __builtin_amdgcn_rcp(b);
+    double e = fma(-b, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-b, y, 1.0);
+    y = fma(y, e, y);
+    const double q = a * y;
+    const double r = fma(-b, q, a);
+    return fma(r, y, q);
+}
+__device__ __forceinline__ bool is_finite(double x) { return fabs(x) <= 0x1.fffffffffffffp+1023; }
+__device__ __forceinline__ void pin1(double &a)
+{
+    asm volatile("" : "+v"(a) :: "memory");
 }
 
 template <int RG, int W, int CH, int S, int MAXT, bool STAMP>
@@ -340,9 +351,6 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
     // candidate columns (2l - s_start) mod S and +1.  The window address is the same for every
     // candidate and never wraps, so the b128 window reads are bank-conflict free.
     const double2 *qwin = reinterpret_cast<const double2 *>(Qd + j0);
-    // the query's sector key lives in registers, two sectors per lane; phase A broadcasts it with
-    // v_readlane (scalar operands of the fp64 subtractions) instead of re-reading it from LDS
-    const double2 vq_own = *reinterpret_cast<const double2 *>(a.q_vkey + j0);
     // fused ring-key scan: lane g < RG owns ring group g of the query key
     const bool rk_on = a.out_d2 != nullptr;
     float4 qrk = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -351,6 +359,13 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
 
     int ci = c_lo + wave;
     const bool have_work = ci < c_hi;
+    bool q_finite;
+    {
+        bool f = true;
+#pragma unroll
+        for (int i = 0; i <= W; ++i) f &= is_finite(nqe[j0 + i]);
+        q_finite = __all(f);
+    }
 
     // running results of this wave (wave-uniform): best (distance, position) and the KT nearest ring keys
     constexpr int KT = kTailTop;               // ring-key candidates tracked by the fused epilogue
@@ -388,25 +403,27 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
             constexpr int npair = S >> 1;
             // Batches of BT sector pairs: the LDS reads of batch b+1 are issued before the arithmetic
             // of batch b (pin3 fixes that order for LLVM), so the two dependent add chains never wait
-            // on LDS; the query key comes from registers by lane broadcast.
-            constexpr int BT = (MAXT > 512) ? 5 : 10;
+            // on LDS.
+            constexpr int BT = 5;
             static_assert(npair % BT == 0, "alignment batches must tile the sector pairs");
             if (!(a.ablate & 1)) {
-                double2 pb[2][BT];
+                // query key pairs: every lane reads the same 16 bytes (LDS broadcast, one array cycle);
+                // cheaper than four v_readlane per pair, which stall the fp64 pipe on the SGPR hazard
+                const double2 *qq = reinterpret_cast<const double2 *>(vq);
+                double2 pb[2][BT], qb[2][BT];
 #pragma unroll
-                for (int v = 0; v < BT; ++v) pb[0][v] = pp[v];
+                for (int v = 0; v < BT; ++v) { pb[0][v] = pp[v]; qb[0][v] = qq[v]; }
 #pragma unroll
                 for (int bt = 0; bt < npair / BT; ++bt) {
                     if (bt + 1 < npair / BT) {
 #pragma unroll
-                        for (int v = 0; v < BT; ++v) pb[(bt + 1) & 1][v] = pp[(bt + 1) * BT + v];
+                        for (int v = 0; v < BT; ++v) { pb[(bt + 1) & 1][v] = pp[(bt + 1) * BT + v]; qb[(bt + 1) & 1][v] = qq[(bt + 1) * BT + v]; }
                     }
                     pin3(ss0, ss1, prev);
 #pragma unroll
                     for (int v = 0; v < BT; ++v) {
-                        const int i = bt * BT + v;
                         const double2 pv = pb[bt & 1][v];
-                        const double qx = lane_bcast(vq_own.x, i), qy = lane_bcast(vq_own.y, i);
+                        const double qx = qb[bt & 1][v].x, qy = qb[bt & 1][v].y;
                         const double d0 = qx - pv.x, d1 = qx - prev;
                         ss0 = ss0 + d0 * d0;
                         ss1 = ss1 + d1 * d1;
@@ -422,7 +439,7 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
             if (active && n0 < kBigDist) { best = n0; bshift = j0; }
             if (active && n1 < kBigDist && n1 < best) { best = n1; bshift = j0 + 1; }   // ties keep the lower shift
         }
-        wave_argmin(best, bshift);
+        wave_argmin_dpp(best, bshift);
         const int align = __builtin_amdgcn_readfirstlane(best < kBigDist ? bshift : 0);
         // first shift of the reference's search space; the W evaluated shifts are b .. b+W-1 (mod S)
         o_s_start = wrap(align - SR, S);
@@ -453,6 +470,10 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
         if (ci_next < c_hi) slot_next = a.cand ? a.cand[ci_next] : a.slot_base + ci_next;
         double2 vk_next = make_double2(0.0, 0.0);
         if (slot_next >= 0) vk_next = *reinterpret_cast<const double2 *>(a.vkey + (size_t)slot_next * S + j0);
+
+        // the candidate's ring key travels under phase B (consumed by the fused ring-key metric after it)
+        float4 rk_cand = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (slot >= 0 && rk_on && lane < RG) rk_cand = a.rkey4[(size_t)lane * a.rk_cap + slot];
 
         double acc0[W], acc1[W];
         const double2 nk_cur = nk;
@@ -520,7 +541,7 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
             // groups accumulated in order -> lane g forms its group, lane-broadcasts feed the serial sum
             float grp = 0.0f;
             if (lane < RG) {
-                const float4 b = a.rkey4[(size_t)lane * a.rk_cap + slot];
+                const float4 b = rk_cand;
                 const float d0 = qrk.x - b.x, d1 = qrk.y - b.y, d2 = qrk.z - b.z, d3 = qrk.w - b.w;
                 grp = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
             }
@@ -544,6 +565,7 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
         if (slot >= 0) {
             double dmin = kInf;
             int smin = 0x7fffffff;
+            const bool fast_quot = q_finite && __all(is_finite(nk_cur.x) & is_finite(nk_cur.y));
             // Two passes (HSH, then W - HSH shifts), each a compile-time instance so the accumulators keep
             // static register indices; a scheduling fence between them keeps LLVM from interleaving both
             // (it would, and spill).  Within a pass: all query norms first, then every quotient (independent
@@ -564,12 +586,28 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
                     for (int i = 0; i <= NT; ++i) nqv[i] = nqe[j0 + T0 + i];
                     double s0[NT], s1[NT];
                     bool ok0[NT], ok1[NT];
+                    // Descriptor values are widened floats, so for finite inputs every counted quotient has
+                    // dot in {0} u [2^-298, 2^262] over norm product in [2^-298, 2^262]: the scaling steps of the
+                    // compiler's division (v_div_scale / v_div_fmas / v_div_fixup) are the identity there and
+                    // quot_core() -- the same refinement without them -- returns the same bits with three
+                    // instructions less and no serialisation through VCC.  Non-finite norms (query: checked
+                    // once per wave, candidate: per candidate) take the general division.
+                    if (fast_quot) {
 #pragma unroll
-                    for (int tt = 0; tt < NT; ++tt) {
-                        ok0[tt] = !((nqv[tt] == 0.0) | (nk_cur.x == 0.0));                  // D.h:1523
-                        ok1[tt] = !((nqv[tt + 1] == 0.0) | (nk_cur.y == 0.0));
-                        s0[tt] = acc0[T0 + tt] / (nqv[tt] * nk_cur.x);
-                        s1[tt] = acc1[T0 + tt] / (nqv[tt + 1] * nk_cur.y);
+                        for (int tt = 0; tt < NT; ++tt) {
+                            ok0[tt] = !((nqv[tt] == 0.0) | (nk_cur.x == 0.0));              // D.h:1523
+                            ok1[tt] = !((nqv[tt + 1] == 0.0) | (nk_cur.y == 0.0));
+                            s0[tt] = quot_core(acc0[T0 + tt], nqv[tt] * nk_cur.x);
+                            s1[tt] = quot_core(acc1[T0 + tt], nqv[tt + 1] * nk_cur.y);
+                        }
+                    } else {
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt) {
+                            ok0[tt] = !((nqv[tt] == 0.0) | (nk_cur.x == 0.0));
+                            ok1[tt] = !((nqv[tt + 1] == 0.0) | (nk_cur.y == 0.0));
+                            s0[tt] = acc0[T0 + tt] / (nqv[tt] * nk_cur.x);
+                            s1[tt] = acc1[T0 + tt] / (nqv[tt + 1] * nk_cur.y);
+                        }
                     }
 #pragma unroll
                     for (int tt = 0; tt < NT; ++tt) {
@@ -580,7 +618,7 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
                         double *row = simbuf + tt * SB;
                         row[(c0 >> 1) + (c0 & 1) * HALF] = ok0[tt] ? s0[tt] : 0.0;          // skipped sectors add +0.0: same bits
                         row[(c1 >> 1) + (c1 & 1) * HALF] = ok1[tt] ? s1[tt] : 0.0;          // (lanes >= L mirror lane L-1)
-                        const int cnt = __popcll(__ballot(active && ok0[tt])) + __popcll(__ballot(active && ok1[tt]));
+                        const int cnt = __popcll(__builtin_amdgcn_ballot_w64(active && ok0[tt])) + __popcll(__builtin_amdgcn_ballot_w64(active && ok1[tt]));
                         eff = (lane == tt) ? cnt : eff;
                     }
                 } else {
@@ -610,10 +648,27 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
                     const double2 *ev = reinterpret_cast<const double2 *>(simbuf + lane * SB);
                     const double2 *od = ev + S / 4;                                     // odd sectors start S/2 doubles in
                     double sum = 0.0;
+                    // One dependent add chain of S terms per lane: the row is fetched in batches of DB
+                    // steps, batch b+1 requested before the adds of batch b (pin1 fixes that order), so
+                    // the chain never waits on an LDS round trip.
+                    constexpr int DB = 5;
+                    static_assert((S / 4) % DB == 0, "sector-sum batches must tile the row");
+                    double2 eb[2][DB], ob[2][DB];
 #pragma unroll
-                    for (int i = 0; i < S / 4; ++i) {                                   // sectors 4i .. 4i+3 in order
-                        const double2 e = ev[i], o = od[i];
-                        sum = sum + e.x; sum = sum + o.x; sum = sum + e.y; sum = sum + o.y;
+                    for (int v = 0; v < DB; ++v) { eb[0][v] = ev[v]; ob[0][v] = od[v]; }
+#pragma unroll
+                    for (int bt = 0; bt < S / 4 / DB; ++bt) {
+                        if (bt + 1 < S / 4 / DB) {
+#pragma unroll
+                            for (int v = 0; v < DB; ++v) { eb[(bt + 1) & 1][v] = ev[(bt + 1) * DB + v]; ob[(bt + 1) & 1][v] = od[(bt + 1) * DB + v]; }
+                        }
+                        pin1(sum);
+#pragma unroll
+                        for (int v = 0; v < DB; ++v) {                                  // sectors 4i .. 4i+3 in order
+                            const double2 e = eb[bt & 1][v], o = ob[bt & 1][v];
+                            sum = sum + e.x; sum = sum + o.x; sum = sum + e.y; sum = sum + o.y;
+                        }
+                        pin1(sum);
                     }
                     const double d = 1.0 - sum / (double)eff;                           // 0/0 -> NaN, never wins
                     const int st = wrap(s_start_cur + t, S);
@@ -627,7 +682,7 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
                 __builtin_amdgcn_sched_barrier(0);
                 cd_pass(std::integral_constant<int, 1>{});
             }
-            wave_argmin(dmin, smin);
+            wave_argmin_dpp(dmin, smin);
             if (lane == 0) {
                 const bool ok = dmin < kBigDist;
                 a.out_dist[ci] = ok ? dmin : kBigDist;
@@ -761,6 +816,8 @@ hipError_t launch_wave(const ScArgs &args_in, int num_cu, hipStream_t stream)
     const size_t lds_cap = 160 * 1024;
     int waves = (int)((lds_cap - fixed - 16) / per_wave);
     if (waves > MAXT / kWave) waves = MAXT / kWave;
+    static const int wave_cap = [] { const char *e = getenv("SCL_SC_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1 << 20; }();
+    if (waves > wave_cap) waves = wave_cap;               // diagnostic: fewer waves per CU
     if (waves < 1) return hipErrorInvalidValue;
     while (waves > 1 && a.n < num_cu * waves) waves = (waves + 1) / 2;
     int blocks = (a.n + waves - 1) / waves;

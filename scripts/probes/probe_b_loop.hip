@@ -1,0 +1,109 @@
+// Phase-B inner loop of the SC-distance wave kernel in isolation (gfx950): per query ring,
+// W+1 = 14 fp64 window values per lane from LDS (7 x ds_read_b128) feed 26 fp64 fmas + 2 cvt.
+// How many cycles per ring does one wave need, alone and with a partner on the SIMD, as a
+// function of how far ahead the window is requested?  s_memtime (core clock).
+//   MODE 0: fmas only (window loaded once)         MODE 1: window of ring r+1 requested before ring r's fmas
+//   MODE 2: window of ring r+2 requested (2 ahead) MODE 3: as 1, window as 14 x ds_read_b64
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+constexpr int W = 13, NQ = 7, QS = 134, ROWS = 64;
+
+__device__ __forceinline__ void pin_ring(double (&a)[13], double (&b)[13])
+{
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]),
+                      "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]),
+                      "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]),
+                      "+v"(b[7]), "+v"(b[8]), "+v"(b[9]), "+v"(b[10]), "+v"(b[11]), "+v"(b[12])
+                 :: "memory");
+}
+
+template <int MODE>
+__global__ __launch_bounds__(768) void b_loop(double *out, unsigned long long *cyc, int reps, const float *kin)
+{
+    extern __shared__ __attribute__((aligned(16))) double Q[];
+    for (int i = threadIdx.x; i < (ROWS + 2) * QS; i += blockDim.x) Q[i] = 1.0 + 1e-3 * (i % 97);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int ll = lane < 60 ? lane : 59;
+    const double2 *qwin = reinterpret_cast<const double2 *>(Q + 2 * ll);
+    double acc0[W], acc1[W];
+#pragma unroll
+    for (int t = 0; t < W; ++t) { acc0[t] = 0.0; acc1[t] = 0.0; }
+    float kf0 = kin[threadIdx.x], kf1 = kin[threadIdx.x + 768];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int rep = 0; rep < reps; ++rep) {
+        const double2 *qp = qwin;
+        double2 qn[NQ], qn2[NQ];
+#pragma unroll
+        for (int v = 0; v < NQ; ++v) qn[v] = qp[v];
+        if (MODE == 2) {
+#pragma unroll
+            for (int v = 0; v < NQ; ++v) qn2[v] = qp[QS / 2 + v];
+        }
+#pragma unroll 4
+        for (int r = 0; r < ROWS; ++r) {
+            double q[W + 1];
+#pragma unroll
+            for (int v = 0; v < NQ; ++v) { q[2 * v] = qn[v].x; q[2 * v + 1] = qn[v].y; }
+            pin_ring(acc0, acc1);
+            qp += QS / 2;
+            if (MODE == 1) {
+#pragma unroll
+                for (int v = 0; v < NQ; ++v) qn[v] = qp[v];
+            }
+            if (MODE == 2) {
+#pragma unroll
+                for (int v = 0; v < NQ; ++v) { qn[v] = qn2[v]; qn2[v] = qp[QS / 2 + v]; }
+            }
+            if (MODE == 3) {
+                const double *qd = reinterpret_cast<const double *>(qp);
+#pragma unroll
+                for (int v = 0; v < NQ; ++v) { qn[v].x = qd[2 * v]; qn[v].y = qd[2 * v + 1]; }
+            }
+            const double kd0 = (double)kf0, kd1 = (double)kf1;
+            kf0 += 1.0f; kf1 += 0.5f;
+#pragma unroll
+            for (int t = 0; t < W; ++t) {
+                acc0[t] = fma(kd0, q[t], acc0[t]);
+                acc1[t] = fma(kd1, q[t + 1], acc1[t]);
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    double s = 0;
+#pragma unroll
+    for (int t = 0; t < W; ++t) s += acc0[t] + acc1[t];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (lane == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
+template <int MODE>
+void run(const char *name, int threads)
+{
+    double *out; unsigned long long *cyc; float *kin;
+    (void)hipMalloc(&out, 8 * 768 * 256); (void)hipMalloc(&cyc, 8 * 12 * 256); (void)hipMalloc(&kin, 4 * 2048);
+    (void)hipMemset(kin, 0, 4 * 2048);
+    const int reps = 40;
+    const size_t lds = 100 * 1024;                      // > half the CU's LDS: one workgroup per CU
+    (void)hipFuncSetAttribute((const void *)b_loop<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(b_loop<MODE>, dim3(256), dim3(threads), lds, 0, out, cyc, reps, kin);
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> h(256 * threads / 64);
+    (void)hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
+    double m = 0; for (auto x : h) m += (double)x; m /= h.size();
+    printf("%-44s waves/CU %d : %7.1f cycles per ring per wave (fma issue alone = 112)\n", name, threads / 64, m / reps / ROWS);
+    (void)hipFree(out); (void)hipFree(cyc); (void)hipFree(kin);
+}
+
+int main()
+{
+    for (int threads : {64, 256, 512, 768}) {
+        run<0>("fmas only", threads);
+        run<1>("window one ring ahead, 7 x ds_read_b128", threads);
+        run<2>("window two rings ahead, 7 x ds_read_b128", threads);
+        run<3>("window one ring ahead, 14 x ds_read_b64", threads);
+    }
+    return 0;
+}
