@@ -214,6 +214,30 @@ int  scl_assemble_submap(scl_engine *e, const void *const *clouds, const int *co
 int  scl_transform_cloud(scl_engine *e, const void *in, int n, int stride_bytes,
                          const float T[16], void *out);
 
+/* ---- on-device keyframe store ------------------------------------------------
+ * robots[id].keyFrameArray (DM.h:86; filled at DM.h:983-985) kept resident in HBM, so that submap
+ * assembly and the ICP of a loop candidate move only poses across PCIe, not clouds.
+ * Records have one stride per engine (fixed by the first put).  Keyframes are dense per robot
+ * (index = position in keyFrameArray); putting an existing index replaces that cloud. */
+int  scl_keyframe_put(scl_engine *e, int robot, int index, const void *points, int n_points, int stride_bytes);
+/* keyFrameArray.size() of one robot (highest stored index + 1) */
+int  scl_keyframe_count(const scl_engine *e, int robot);
+/* read one stored cloud back (out may be NULL to query the size only) */
+int  scl_keyframe_get(scl_engine *e, int robot, int index, void *out, int out_capacity, int *n_points);
+/* loopFindNearKeyframes(nearKeyframes, key, searchNum), DM.h:1163-1186, from the store: keyframes
+ * key-searchNum .. key+searchNum that exist, each moved by its pose, concatenated in index order and
+ * voxel-filtered with `leaf`.  poses: (2*search_num+1) row-major 4x4 matrices, poses[i] belonging to
+ * keyframe key-search_num+i (entries of keyframes outside [0, count) are ignored). */
+int  scl_submap_from_store(scl_engine *e, int robot, int key, int search_num, const float *poses, float leaf,
+                           void *out, int out_capacity, int *n_out);
+/* performIntraLoopClosure stage 2, DM.h:1104-1121, entirely on the device: source = submap(key_cur, 0),
+ * target = submap(key_pre, search_num), size gate (DM.h:1108: fewer than min_src_points / min_tgt_points
+ * -> no alignment, *converged = 0, T = identity), then scl_icp_align's alignment. */
+int  scl_loop_icp_from_store(scl_engine *e, int robot, int key_cur, const float *pose_cur,
+                             int key_pre, int search_num, const float *poses_pre, float leaf,
+                             const scl_icp_params *p, int min_src_points, int min_tgt_points,
+                             float T[16], float *fitness, int *converged, int *iterations, int *n_src, int *n_tgt);
+
 /* ---- measurement ----------------------------------------------------------- */
 int  scl_profile_enable(scl_engine *e, int on);   /* 0 off, 1 every kernel family, 2 SC distance only */
 int  scl_profile_reset(scl_engine *e);

@@ -76,6 +76,13 @@ struct scl_engine {
 
     IcpWorkspace icp_ws;
     IcpWorkspace vox_ws;
+
+    // on-device keyframe store (robots[id].keyFrameArray, DM.h:86): clouds live in slabs of HBM, bump allocated
+    struct StoredCloud { unsigned char *d = nullptr; int n = -1; size_t cap_bytes = 0; };
+    std::vector<std::vector<StoredCloud>> kf;              // [robot][index]; n < 0: never stored
+    std::vector<void *> kf_slabs;
+    size_t kf_slab_used = 0, kf_slab_cap = 0;
+    int kf_stride = 0;                                     // fixed by the first put
 };
 
 namespace {
@@ -455,6 +462,7 @@ int scl_destroy(scl_engine *e)
     for (auto ev : e->event_pool) (void)hipEventDestroy(ev);
     icp_workspace_free(&e->icp_ws);
     icp_workspace_free(&e->vox_ws);
+    for (void *slab : e->kf_slabs) (void)hipFree(slab);
     dev_free(e->d_desc); dev_free(e->d_vkey); dev_free(e->d_norm); dev_free(e->d_rkey); dev_free(e->d_rkey4);
     dev_free(e->q_desc); dev_free(e->q_vkey); dev_free(e->q_norm); dev_free(e->q_rkey); dev_free(e->q_rkey4);
     dev_free(e->d_vals); dev_free(e->d_points); dev_free(e->d_tile);
@@ -985,6 +993,159 @@ int scl_transform_cloud(scl_engine *e, const void *in, int n, int stride_bytes, 
     (void)hipSetDevice(e->device);
     std::string err;
     int rc = icp_transform_cloud(&e->icp_ws, e->stream, in, n, stride_bytes, T, out, &err);
+    if (rc) e->last_error = err;
+    return rc;
+}
+
+/* ---- on-device keyframe store ------------------------------------------------ */
+
+namespace {
+
+constexpr size_t kKfSlabBytes = (size_t)256 << 20;         // 256 MiB slabs: ~100 keyframes of 100 k points each
+
+int kf_alloc(scl_engine *e, size_t bytes, unsigned char **out)
+{
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (e->kf_slabs.empty() || e->kf_slab_used + bytes > e->kf_slab_cap) {
+        const size_t cap = bytes > kKfSlabBytes ? bytes : kKfSlabBytes;
+        void *slab = nullptr;
+        if (hipMalloc(&slab, cap) != hipSuccess) return fail(e, SCL_ERR_NOMEM, "keyframe store: hipMalloc failed");
+        e->kf_slabs.push_back(slab);
+        e->kf_slab_used = 0;
+        e->kf_slab_cap = cap;
+    }
+    *out = static_cast<unsigned char *>(e->kf_slabs.back()) + e->kf_slab_used;
+    e->kf_slab_used += bytes;
+    return SCL_OK;
+}
+
+// keyframes key-search_num .. key+search_num that exist in the store (DM.h:1168-1176); poses[i] belongs to
+// keyframe key - search_num + i
+int kf_window(scl_engine *e, int robot, int key, int search_num, const float *poses,
+              std::vector<const void *> *clouds, std::vector<int> *counts, std::vector<float> *T)
+{
+    if (robot < 0 || search_num < 0 || !poses) return fail(e, SCL_ERR_INVALID_ARG, "keyframe window: bad arguments");
+    clouds->clear(); counts->clear(); T->clear();
+    if ((size_t)robot >= e->kf.size()) return SCL_OK;
+    const auto &arr = e->kf[robot];
+    for (int i = -search_num; i <= search_num; ++i) {
+        const long long k = (long long)key + i;
+        if (k < 0 || k >= (long long)arr.size()) continue;             // DM.h:1171-1174
+        const auto &c = arr[(size_t)k];
+        if (c.n < 0) return fail(e, SCL_ERR_INVALID_ARG, "keyframe window: a keyframe inside the window was never stored");
+        clouds->push_back(c.d);
+        counts->push_back(c.n);
+        const float *m = poses + 16 * (size_t)(i + search_num);
+        T->insert(T->end(), m, m + 16);
+    }
+    return SCL_OK;
+}
+
+}  // namespace
+
+int scl_keyframe_put(scl_engine *e, int robot, int index, const void *points, int n_points, int stride_bytes)
+{
+    if (!e || robot < 0 || index < 0 || n_points < 0 || (!points && n_points > 0)) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (stride_bytes < 12 || (stride_bytes & 3)) return fail(e, SCL_ERR_INVALID_ARG, "keyframe_put: bad stride");
+    if (e->kf_stride == 0) e->kf_stride = stride_bytes;
+    if (stride_bytes != e->kf_stride) return fail(e, SCL_ERR_INVALID_ARG, "keyframe_put: stride differs from the store's");
+    (void)hipSetDevice(e->device);
+    if ((size_t)robot >= e->kf.size()) e->kf.resize((size_t)robot + 1);
+    auto &arr = e->kf[robot];
+    if ((size_t)index >= arr.size()) arr.resize((size_t)index + 1);
+    auto &c = arr[(size_t)index];
+    const size_t bytes = (size_t)n_points * stride_bytes;
+    if (bytes > c.cap_bytes) {                                         // replacing with a larger cloud: old space is retired
+        unsigned char *d = nullptr;
+        int rc = kf_alloc(e, bytes, &d);
+        if (rc) return rc;
+        c.d = d; c.cap_bytes = (bytes + 255) & ~(size_t)255;
+    }
+    if (bytes) {
+        SCL_HIP(e, hipMemcpyAsync(c.d, points, bytes, hipMemcpyHostToDevice, e->stream));
+        SCL_HIP(e, hipStreamSynchronize(e->stream));                   // the caller's buffer is free on return
+    }
+    c.n = n_points;
+    return SCL_OK;
+}
+
+int scl_keyframe_count(const scl_engine *e, int robot)
+{
+    if (!e || robot < 0) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    return (size_t)robot < e->kf.size() ? (int)e->kf[robot].size() : 0;
+}
+
+int scl_keyframe_get(scl_engine *e, int robot, int index, void *out, int out_capacity, int *n_points)
+{
+    if (!e || robot < 0 || index < 0 || !n_points) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if ((size_t)robot >= e->kf.size() || (size_t)index >= e->kf[robot].size() || e->kf[robot][index].n < 0)
+        return fail(e, SCL_ERR_INVALID_ARG, "keyframe_get: no such keyframe");
+    const auto &c = e->kf[robot][index];
+    *n_points = c.n;
+    if (!out) return SCL_OK;
+    if (c.n > out_capacity) return fail(e, SCL_ERR_INVALID_ARG, "keyframe_get: output capacity too small");
+    (void)hipSetDevice(e->device);
+    if (c.n) {
+        SCL_HIP(e, hipMemcpyAsync(out, c.d, (size_t)c.n * e->kf_stride, hipMemcpyDeviceToHost, e->stream));
+        SCL_HIP(e, hipStreamSynchronize(e->stream));
+    }
+    return SCL_OK;
+}
+
+int scl_submap_from_store(scl_engine *e, int robot, int key, int search_num, const float *poses, float leaf,
+                          void *out, int out_capacity, int *n_out)
+{
+    if (!e || !out || !n_out) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    std::vector<const void *> clouds; std::vector<int> counts; std::vector<float> T;
+    int rc = kf_window(e, robot, key, search_num, poses, &clouds, &counts, &T);
+    if (rc) return rc;
+    std::string err;
+    rc = assemble_submap_ex(&e->vox_ws, e->stream, clouds.data(), counts.data(), T.data(), (int)clouds.size(),
+                            e->kf_stride ? e->kf_stride : 16, leaf, true, out, out_capacity, nullptr, n_out, &err);
+    if (rc) e->last_error = err;
+    return rc;
+}
+
+int scl_loop_icp_from_store(scl_engine *e, int robot, int key_cur, const float *pose_cur,
+                            int key_pre, int search_num, const float *poses_pre, float leaf,
+                            const scl_icp_params *p, int min_src_points, int min_tgt_points,
+                            float T[16], float *fitness, int *converged, int *iterations, int *n_src, int *n_tgt)
+{
+    if (!e || !pose_cur || !poses_pre || !p || !T) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    const int stride = e->kf_stride ? e->kf_stride : 16;
+    std::vector<const void *> clouds; std::vector<int> counts; std::vector<float> Tw;
+    std::string err;
+    int ns = 0, nt = 0;
+    const void *d_res = nullptr;
+    // source: loopFindNearKeyframes(cur, 0), DM.h:1105
+    int rc = kf_window(e, robot, key_cur, 0, pose_cur, &clouds, &counts, &Tw);
+    if (rc) return rc;
+    rc = assemble_submap_ex(&e->vox_ws, e->stream, clouds.data(), counts.data(), Tw.data(), (int)clouds.size(), stride, leaf,
+                            true, nullptr, 0, &d_res, &ns, &err);
+    if (!rc) rc = icp_stage_cloud(&e->icp_ws, e->stream, false, d_res, ns, stride, &err);
+    if (rc) { e->last_error = err; return rc; }
+    // target: loopFindNearKeyframes(pre, historyKeyframeSearchNum), DM.h:1107
+    rc = kf_window(e, robot, key_pre, search_num, poses_pre, &clouds, &counts, &Tw);
+    if (rc) return rc;
+    rc = assemble_submap_ex(&e->vox_ws, e->stream, clouds.data(), counts.data(), Tw.data(), (int)clouds.size(), stride, leaf,
+                            true, nullptr, 0, &d_res, &nt, &err);
+    if (!rc) rc = icp_stage_cloud(&e->icp_ws, e->stream, true, d_res, nt, stride, &err);
+    if (rc) { e->last_error = err; return rc; }
+    if (n_src) *n_src = ns;
+    if (n_tgt) *n_tgt = nt;
+    if (converged) *converged = 0;
+    if (iterations) *iterations = 0;
+    if (fitness) *fitness = 0.0f;
+    for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+    if (ns < min_src_points || nt < min_tgt_points) return SCL_OK;    // DM.h:1108-1111: too small, no alignment attempted
+    rc = icp_align_staged(&e->icp_ws, e->stream, ns, nt, stride, *p, T, fitness, converged, iterations, &err);
     if (rc) e->last_error = err;
     return rc;
 }

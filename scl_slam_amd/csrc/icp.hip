@@ -837,11 +837,31 @@ int icp_align(IcpWorkspace *ws, hipStream_t stream, int num_cu, const void *src,
     (void)num_cu;
     int rc = check_cloud_args(n_src, n_tgt, stride, err);
     if (rc) return rc;
+    if ((rc = upload(ws, B_SRC, src, (size_t)n_src * stride, stream, err))) return rc;
+    if ((rc = upload(ws, B_TGT, tgt, (size_t)n_tgt * stride, stream, err))) return rc;
+    return icp_align_staged(ws, stream, n_src, n_tgt, stride, p, T, fitness, converged, iterations, err);
+}
+
+int icp_stage_cloud(IcpWorkspace *ws, hipStream_t stream, bool target, const void *d_cloud, int n, int stride,
+                    std::string *err)
+{
+    if (n < 0 || stride < 12 || (stride & 3)) { if (err) *err = "icp_stage_cloud: bad arguments"; return SCL_ERR_INVALID_ARG; }
+    const int k = target ? B_TGT : B_SRC;
+    const size_t bytes = (size_t)n * stride;
+    int rc = ensure(ws, k, bytes + 16, err);
+    if (rc) return rc;
+    if (bytes) ICP_HIP(hipMemcpyAsync(ws->buf[k], d_cloud, bytes, hipMemcpyDeviceToDevice, stream));
+    return SCL_OK;
+}
+
+int icp_align_staged(IcpWorkspace *ws, hipStream_t stream, int n_src, int n_tgt, int stride, const scl_icp_params &p,
+                     float T[16], float *fitness, int *converged, int *iterations, std::string *err)
+{
+    int rc = check_cloud_args(n_src, n_tgt, stride, err);
+    if (rc) return rc;
     if (p.estimator != 0 && p.estimator != 1) { if (err) *err = "unknown estimator"; return SCL_ERR_INVALID_ARG; }
     if (p.estimator == 1 && !(p.normal_radius > 0.0)) { if (err) *err = "normal_radius must be > 0"; return SCL_ERR_INVALID_ARG; }
     if (p.max_iterations < 1) { if (err) *err = "max_iterations < 1"; return SCL_ERR_INVALID_ARG; }
-    if ((rc = upload(ws, B_SRC, src, (size_t)n_src * stride, stream, err))) return rc;
-    if ((rc = upload(ws, B_TGT, tgt, (size_t)n_tgt * stride, stream, err))) return rc;
     if ((rc = ensure(ws, B_WORK, sizeof(float4) * (size_t)(n_src + 1), err))) return rc;
     if ((rc = ensure(ws, B_NNI, sizeof(int) * (size_t)(n_src + 1), err))) return rc;
     if ((rc = ensure(ws, B_NND, sizeof(float) * (size_t)(n_src + 1), err))) return rc;

@@ -21,6 +21,13 @@ void icp_workspace_free(IcpWorkspace *ws);
 int icp_align(IcpWorkspace *ws, hipStream_t stream, int num_cu, const void *src, int n_src,
               const void *tgt, int n_tgt, int stride_bytes, const scl_icp_params &p,
               float T[16], float *fitness, int *converged, int *iterations, std::string *err);
+// device-resident clouds: icp_stage_cloud() copies one (device to device) into the workspace, then
+// icp_align_staged() runs the same alignment as icp_align() on what has been staged
+int icp_stage_cloud(IcpWorkspace *ws, hipStream_t stream, bool target, const void *d_cloud, int n, int stride_bytes,
+                    std::string *err);
+int icp_align_staged(IcpWorkspace *ws, hipStream_t stream, int n_src, int n_tgt, int stride_bytes,
+                     const scl_icp_params &p, float T[16], float *fitness, int *converged, int *iterations,
+                     std::string *err);
 int icp_nn_correspondences(IcpWorkspace *ws, hipStream_t stream, int num_cu, const void *src, int n_src,
                            const void *tgt, int n_tgt, int stride_bytes, int *nn_index, float *nn_dist2,
                            std::string *err);
@@ -45,5 +52,9 @@ int voxel_grid(IcpWorkspace *ws, hipStream_t stream, const void *in, int n, int 
 int assemble_submap(IcpWorkspace *ws, hipStream_t stream, const void *const *clouds, const int *counts,
                     const float *transforms, int n_clouds, int stride, float leaf, void *out, int out_capacity,
                     int *n_out, std::string *err);
+
+int assemble_submap_ex(IcpWorkspace *ws, hipStream_t stream, const void *const *clouds, const int *counts,
+                       const float *transforms, int n_clouds, int stride, float leaf, bool clouds_on_device,
+                       void *out, int out_capacity, const void **d_result, int *n_out, std::string *err);
 
 }  // namespace scl

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
             // Batches of BT sector pairs: the LDS reads of batch b+1 are issued before the arithmetic
             // of batch b (pin3 fixes that order for LLVM), so the two dependent add chains never wait
             // on LDS.
-            constexpr int BT = 5;
+            constexpr int BT = (MAXT > 512) ? 3 : 5;
             static_assert(npair % BT == 0, "alignment batches must tile the sector pairs");
             if (!(a.ablate & 1)) {
                 // query key pairs: every lane reads the same 16 bytes (LDS broadcast, one array cycle);
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
                     // One dependent add chain of S terms per lane: the row is fetched in batches of DB
                     // steps, batch b+1 requested before the adds of batch b (pin1 fixes that order), so
                     // the chain never waits on an LDS round trip.
-                    constexpr int DB = 5;
+                    constexpr int DB = (MAXT > 512) ? 3 : 5;
                     static_assert((S / 4) % DB == 0, "sector-sum batches must tile the row");
                     double2 eb[2][DB], ob[2][DB];
 #pragma unroll

@@ -241,9 +241,12 @@ int voxel_grid(IcpWorkspace *ws, hipStream_t stream, const void *in, int n, int 
     return SCL_OK;
 }
 
-int assemble_submap(IcpWorkspace *ws, hipStream_t stream, const void *const *clouds, const int *counts,
-                    const float *transforms, int n_clouds, int stride, float leaf, void *out, int out_capacity,
-                    int *n_out, std::string *err)
+// clouds_on_device: clouds[c] are device pointers (the on-device keyframe store) and are read in place.
+// d_result != nullptr: the filtered submap stays in the workspace (*d_result, valid until the workspace is
+// used again) and nothing crosses PCIe but the 16-float poses and the point count.
+int assemble_submap_ex(IcpWorkspace *ws, hipStream_t stream, const void *const *clouds, const int *counts,
+                       const float *transforms, int n_clouds, int stride, float leaf, bool clouds_on_device,
+                       void *out, int out_capacity, const void **d_result, int *n_out, std::string *err)
 {
     if (n_clouds < 0 || stride < 12 || (stride & 3) || !(leaf > 0.f)) { if (err) *err = "assemble_submap: bad arguments"; return SCL_ERR_INVALID_ARG; }
     size_t total = 0;
@@ -253,7 +256,7 @@ int assemble_submap(IcpWorkspace *ws, hipStream_t stream, const void *const *clo
     if ((rc = vensure(ws, V_IN, total * stride + 16, err))) return rc;
     if ((rc = vensure(ws, V_T, sizeof(float) * 16 * (size_t)(n_clouds > 0 ? n_clouds : 1), err))) return rc;
     if (n_clouds) VOX_HIP(hipMemcpyAsync(ws->buf[V_T], transforms, sizeof(float) * 16 * (size_t)n_clouds, hipMemcpyHostToDevice, stream));
-    // raw clouds are staged behind the concatenated buffer's end in V_OUT (reused as scratch before the filter runs)
+    // host clouds are staged behind the concatenated buffer's end in V_OUT (reused as scratch before the filter runs)
     size_t maxc = 0;
     for (int c = 0; c < n_clouds; ++c) maxc = maxc > (size_t)counts[c] ? maxc : (size_t)counts[c];
     if ((rc = vensure(ws, V_OUT, (total > maxc ? total : maxc) * stride + 16, err))) return rc;
@@ -261,9 +264,13 @@ int assemble_submap(IcpWorkspace *ws, hipStream_t stream, const void *const *clo
     for (int c = 0; c < n_clouds; ++c) {                               // DM.h:1168-1176
         const int n = counts[c];
         if (!n) continue;
-        VOX_HIP(hipMemcpyAsync(ws->buf[V_OUT], clouds[c], (size_t)n * stride, hipMemcpyHostToDevice, stream));
+        const unsigned char *d_cloud = static_cast<const unsigned char *>(clouds[c]);
+        if (!clouds_on_device) {
+            VOX_HIP(hipMemcpyAsync(ws->buf[V_OUT], clouds[c], (size_t)n * stride, hipMemcpyHostToDevice, stream));
+            d_cloud = static_cast<const unsigned char *>(ws->buf[V_OUT]);
+        }
         hipLaunchKernelGGL(transform_append_kernel, dim3((n + 255) / 256), dim3(256), 0, stream,
-                           (const unsigned char *)ws->buf[V_OUT], n, stride, (const float *)ws->buf[V_T] + 16 * c,
+                           d_cloud, n, stride, (const float *)ws->buf[V_T] + 16 * c,
                            (unsigned char *)ws->buf[V_IN] + off * stride);
         off += (size_t)n;
     }
@@ -271,11 +278,22 @@ int assemble_submap(IcpWorkspace *ws, hipStream_t stream, const void *const *clo
     if ((rc = voxel_device(ws, stream, (int)total, stride, leaf, &m, err))) return rc;   // DM.h:1181-1185
     const void *res = ws->buf[V_OUT];
     if (m < 0) { m = (int)total; res = ws->buf[V_IN]; }
-    if (m > out_capacity) { if (err) *err = "assemble_submap: output capacity too small"; return SCL_ERR_INVALID_ARG; }
-    if (m) VOX_HIP(hipMemcpyAsync(out, res, (size_t)m * stride, hipMemcpyDeviceToHost, stream));
+    if (d_result) *d_result = res;
+    if (out) {
+        if (m > out_capacity) { if (err) *err = "assemble_submap: output capacity too small"; return SCL_ERR_INVALID_ARG; }
+        if (m) VOX_HIP(hipMemcpyAsync(out, res, (size_t)m * stride, hipMemcpyDeviceToHost, stream));
+    }
     VOX_HIP(hipStreamSynchronize(stream));
     *n_out = m;
     return SCL_OK;
+}
+
+int assemble_submap(IcpWorkspace *ws, hipStream_t stream, const void *const *clouds, const int *counts,
+                    const float *transforms, int n_clouds, int stride, float leaf, void *out, int out_capacity,
+                    int *n_out, std::string *err)
+{
+    return assemble_submap_ex(ws, stream, clouds, counts, transforms, n_clouds, stride, leaf, false,
+                              out, out_capacity, nullptr, n_out, err);
 }
 
 }  // namespace scl

@@ -99,6 +99,12 @@ def _bind(lib):
         "scl_assemble_submap": (c_int, [P, POINTER(c_void_p), ip, fp, c_int, c_int, c_float, P, c_int, ip]),
         "scl_ransac_correspondences": (c_int, [P, P, c_int, P, c_int, c_int, ip, ip, c_int, c_int, c_double, c_uint64, ip, ip, ip, fp]),
         "scl_geometric_verification": (c_int, [P, P, c_int, P, c_int, c_int, c_int, c_double, c_double, c_uint64, fp, ip, ip, ip]),
+        "scl_keyframe_put": (c_int, [P, c_int, c_int, P, c_int, c_int]),
+        "scl_keyframe_count": (c_int, [P, c_int]),
+        "scl_keyframe_get": (c_int, [P, c_int, c_int, P, c_int, ip]),
+        "scl_submap_from_store": (c_int, [P, c_int, c_int, c_int, fp, c_float, P, c_int, ip]),
+        "scl_loop_icp_from_store": (c_int, [P, c_int, c_int, fp, c_int, c_int, fp, c_float, POINTER(IcpParams), c_int, c_int,
+                                            fp, fp, ip, ip, ip, ip]),
         "scl_profile_enable": (c_int, [P, c_int]),
         "scl_profile_reset": (c_int, [P]),
         "scl_profile_get": (c_int, [P, POINTER(SclProfile)]),
@@ -402,6 +408,44 @@ class ScanContextEngine:
         self._check(self._lib.scl_transform_cloud(self._h, a.ctypes.data_as(c_void_p), n, stride, _ptr(Tm, c_float),
                                                   out.ctypes.data_as(c_void_p)), "scl_transform_cloud")
         return out
+
+    # -- on-device keyframe store (robots[id].keyFrameArray, DM.h:86) -------------
+    def keyframe_put(self, robot, index, cloud):
+        a, n, stride = _cloud(cloud)
+        self._check(self._lib.scl_keyframe_put(self._h, robot, index, a.ctypes.data_as(c_void_p), n, stride), "scl_keyframe_put")
+
+    def keyframe_count(self, robot):
+        return self._lib.scl_keyframe_count(self._h, robot)
+
+    def keyframe_get(self, robot, index, floats_per_point=8):
+        n = c_int()
+        self._check(self._lib.scl_keyframe_get(self._h, robot, index, None, 0, byref(n)), "scl_keyframe_get")
+        out = np.empty((max(n.value, 1), floats_per_point), dtype=np.float32)
+        self._check(self._lib.scl_keyframe_get(self._h, robot, index, out.ctypes.data_as(c_void_p), n.value, byref(n)), "scl_keyframe_get")
+        return out[:n.value].copy()
+
+    def submap_from_store(self, robot, key, search_num, poses, leaf, capacity, floats_per_point=8):
+        """loopFindNearKeyframes (DM.h:1163-1186) on stored keyframes; poses[i] belongs to keyframe key-search_num+i"""
+        Ts = _f32(np.asarray(poses)).reshape(-1, 16)
+        assert Ts.shape[0] == 2 * search_num + 1
+        out = np.empty((max(capacity, 1), floats_per_point), dtype=np.float32); m = c_int()
+        self._check(self._lib.scl_submap_from_store(self._h, robot, key, search_num, _ptr(Ts, c_float), leaf,
+                                                    out.ctypes.data_as(c_void_p), capacity, byref(m)), "scl_submap_from_store")
+        return out[:m.value].copy()
+
+    def loop_icp_from_store(self, robot, key_cur, pose_cur, key_pre, search_num, poses_pre, leaf, params=None,
+                            min_src_points=300, min_tgt_points=1000):
+        """performIntraLoopClosure stage 2 (DM.h:1104-1121) without moving clouds over PCIe"""
+        p = params if params is not None else self.icp_default_params()
+        Tc = _f32(np.asarray(pose_cur)).reshape(16)
+        Tp = _f32(np.asarray(poses_pre)).reshape(-1, 16)
+        assert Tp.shape[0] == 2 * search_num + 1
+        T = np.empty(16, dtype=np.float32); fit = c_float(); conv = c_int(); it = c_int(); ns = c_int(); nt = c_int()
+        self._check(self._lib.scl_loop_icp_from_store(self._h, robot, key_cur, _ptr(Tc, c_float), key_pre, search_num,
+                                                      _ptr(Tp, c_float), leaf, byref(p), min_src_points, min_tgt_points,
+                                                      _ptr(T, c_float), byref(fit), byref(conv), byref(it), byref(ns), byref(nt)),
+                    "scl_loop_icp_from_store")
+        return T.reshape(4, 4), fit.value, bool(conv.value), it.value, ns.value, nt.value
 
     # -- measurement ------------------------------------------------------------
     def profile_enable(self, on=True):
