@@ -380,7 +380,7 @@ const char *scl_status_string(int status)
 
 const char *scl_last_error(const scl_engine *e) { return e ? e->last_error.c_str() : "null engine"; }
 
-int scl_abi_version(void) { return 2; }
+int scl_abi_version(void) { return 3; }
 
 int scl_default_config(scl_config *c)
 {

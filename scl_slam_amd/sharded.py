@@ -15,6 +15,9 @@ only exchange is the reduction of the per-rank winners:
   rank, global arg-min with ties -> lowest global index.
 
 Messages are <= k * 32 bytes per rank: latency bound, xGMI bandwidth is irrelevant here.
+For a stream of scans (``FullScanStream``) the winners of ``merge_every`` scans travel in ONE
+asynchronous all-gather that is awaited a batch later, so the exchange (and the CU the RCCL
+kernel needs while the SC-distance kernel owns every CU) never sits between two scans.
 The search-range rule ``[0, cur - NUM_EXCLUDE_RECENT)`` (descriptor.h:1627) is applied on
 GLOBAL indices: rank r may use local slots ``l`` with ``l * G + r < cur - exclude``.
 """
@@ -106,3 +109,73 @@ class ShardedLoopDetector:
         best = allr[np.lexsort((allr[:, 1], allr[:, 0]))[0]]
         d, g, sh = float(best[0]), int(best[1]), int(best[2])
         return (g if d < self.thres else -1), g, sh, d
+
+
+class FullScanStream:
+    """Full-DB detection for a stream of scans on a sharded database.
+
+    ``submit(query, lo, hi)`` enqueues one scan's pass over this rank's shard
+    (``scl_detect_full_submit``; a few passes are kept in flight).  Local winners are
+    collected in submission order; every ``merge_every`` scans their records go into one
+    asynchronous all-gather, merged one batch later (global arg-min, ties -> lowest global
+    index).  ``drain()`` flushes; ``results`` holds (dist, global_idx, shift) per scan, in
+    order, identical on every rank.
+    """
+
+    def __init__(self, engine, rank=0, world=1, group=None, device="cpu", depth=2, merge_every=16):
+        self.engine, self.rank, self.world, self.group, self.device = engine, rank, world, group, device
+        self.depth, self.merge_every = max(1, depth), max(1, merge_every)
+        self.inflight, self.batch, self.pending, self.results = [], [], None, []
+
+    def submit(self, query, lo, hi):
+        self.inflight.append(self.engine.detect_full_submit(query, lo, hi))
+        if len(self.inflight) >= self.depth:
+            self._collect_one()
+
+    def _collect_one(self):
+        nn, sh, d = self.engine.detect_full_collect(self.inflight.pop(0))
+        self.batch.append((d, float(nn * self.world + self.rank) if nn >= 0 else -1.0, float(sh)))
+        if len(self.batch) >= self.merge_every:
+            self._exchange()
+
+    def _exchange(self):
+        if not self.batch:
+            return
+        rec = np.array(self.batch, dtype=np.float64)
+        self.batch = []
+        if self.world == 1:
+            self._merge(rec[None])
+            return
+        import torch
+        import torch.distributed as dist
+        t = torch.from_numpy(rec).to(self.device)
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=self.device)
+        work = dist.all_gather_into_tensor(out.view(-1, t.shape[1]), t, group=self.group, async_op=True)
+        prev, self.pending = self.pending, (work, out, t)
+        self._finish(prev)
+
+    def _finish(self, pending):
+        if pending is None:
+            return
+        work, out, _ = pending
+        work.wait()
+        self._merge(out.cpu().numpy())
+
+    def _merge(self, allr):
+        """allr: (world, m, 3) records (dist, global index or -1, shift)"""
+        for j in range(allr.shape[1]):
+            r = allr[:, j, :]
+            r = r[r[:, 1] >= 0]
+            if len(r) == 0:
+                self.results.append((BIG_DIST, -1, 0))
+                continue
+            b = r[np.lexsort((r[:, 1], r[:, 0]))[0]]
+            self.results.append((float(b[0]), int(b[1]), int(b[2])))
+
+    def drain(self):
+        while self.inflight:
+            self._collect_one()
+        self._exchange()
+        prev, self.pending = self.pending, None
+        self._finish(prev)
+        return self.results

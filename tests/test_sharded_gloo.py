@@ -49,6 +49,12 @@ class OracleShardEngine:
                 dist_[i], shift[i] = self._dist(int(idx[i]))
         return idx, d2, dist_, shift, found
 
+    def detect_full_submit(self, query, lo, hi):
+        return self.detect_full_range(query, lo, hi)                # the checker has no queue: done at submit
+
+    def detect_full_collect(self, ticket):
+        return ticket
+
     def detect_full_range(self, query, lo, hi):
         best, bi, bs = 1e7, -1, 0
         for s in range(lo, hi):
@@ -81,7 +87,14 @@ def _worker(rank, world, port, curs, out_q):
     res = []
     for cur in curs:
         res.append((cur, det.detect_intra(cur, descs[cur]), det.detect_full(cur, descs[cur])))
-    out_q.put((rank, res))
+    # the same scans as a stream: winners of 4 scans per (asynchronous) all-gather, merged a batch later
+    from scl_slam_amd.sharded import FullScanStream
+    st = FullScanStream(det.engine, rank, world, depth=2, merge_every=4)
+    for cur in curs:
+        det.engine.stage_query(descs[cur])
+        st.submit(-1, 0, local_count(cur - det.exclude, rank, world))
+    stream = st.drain()
+    out_q.put((rank, res, stream))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -98,7 +111,9 @@ def test_sharded_equals_single_database(world):
     for p in procs:
         p.start()
     try:
-        results = dict(q.get(timeout=120) for _ in range(world))
+        got = [q.get(timeout=120) for _ in range(world)]
+        results = {r: a for r, a, _ in got}
+        streams = {r: b for r, _, b in got}
     finally:
         for p in procs:
             p.join(timeout=30)
@@ -106,6 +121,9 @@ def test_sharded_equals_single_database(world):
                 p.terminate()
     assert all(p.exitcode == 0 for p in procs)
     assert results[0] == results[1]                                  # every rank reaches the same verdict
+    assert streams[0] == streams[1] and len(streams[0]) == len(curs)
+    for (cur, _, full), (d, g, sh) in zip(results[0], streams[0]):   # batched exchange == per-scan exchange
+        assert (g, sh, d) == (full[1], full[2], full[3])
     hits = 0
     for cur, intra, full in results[0]:
         o = ref.detect_intra(cur)
