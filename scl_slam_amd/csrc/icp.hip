@@ -183,13 +183,40 @@ __global__ void grid_scatter_kernel(const unsigned char *pts, int n, int stride,
 }
 
 // ---- K4b ---------------------------------------------------------------------------
+// Exact nearest neighbour through the grid, kNnGroup lanes per query.  A query walks cubic shells of cells
+// around its own cell; the (z, y) rows of a shell are dealt round robin to the lanes of its group (a row
+// on a z- or y-face of the shell is one contiguous range of `sorted`, an interior row contributes its two
+// x-face cells), the group's (distance, index) minimum is formed with DPP exchanges, and the walk ends once
+// the nearest face of the shell is farther than the best distance.  One lane per query left ~1.5 waves per
+// SIMD chasing dependent loads; eight lanes per query give the memory system 8x the requests in flight and
+// cut the dependent round trips per shell from (rows) to (rows / 8).  min over (d, index) is order
+// independent: results are bit-identical to the serial walk (ties -> lowest target index).
+constexpr int kNnGroup = 8;
+
+__device__ __forceinline__ void group_min8(float &d, int &j)
+{
+    // xor 1, xor 2 (quad permutes), then mirror inside each half row (lane i <-> 7 - i): all 8 lanes end equal
+#define SCL_GMIN_STEP(CTRL)                                                                        \
+    {                                                                                              \
+        const float od = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), CTRL, 0xf, 0xf, false)); \
+        const int oj = __builtin_amdgcn_update_dpp(0, j, CTRL, 0xf, 0xf, false);                    \
+        const bool take = (od < d) | ((od == d) & (oj < j));                                        \
+        d = take ? od : d; j = take ? oj : j;                                                       \
+    }
+    SCL_GMIN_STEP(0xB1) SCL_GMIN_STEP(0x4E) SCL_GMIN_STEP(0x141)
+#undef SCL_GMIN_STEP
+}
+
 __global__ __launch_bounds__(256) void nn_search_kernel(const float4 *work, int n_src, const IcpState *st,
                                                         const int *cell_start, const float4 *sorted,
                                                         int *nn_idx, float *nn_d2, int check_done)
 {
     if (check_done && st->done) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_src) return;
+    if (n_src <= 0) return;
+    const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / kNnGroup;
+    const int sub = threadIdx.x & (kNnGroup - 1);
+    const bool valid = gid < n_src;
+    const int i = valid ? gid : n_src - 1;                       // surplus groups shadow the last query (all lanes stay in the exchanges)
     const float4 pw = work[i];
     const float3 p = make_float3(pw.x, pw.y, pw.z);
     int c[3];
@@ -201,27 +228,31 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const float4 *work, int 
     int bi = -1;
     for (int r = 0; r <= maxdim; ++r) {
         const int lo0 = c[0] - r, hi0 = c[0] + r, lo1 = c[1] - r, hi1 = c[1] + r, lo2 = c[2] - r, hi2 = c[2] + r;
-        for (int z = max(lo2, 0); z <= min(hi2, dz - 1); ++z) {
-            const bool zs = (z == lo2) | (z == hi2);
-            for (int y = max(lo1, 0); y <= min(hi1, dy - 1); ++y) {
-                const bool ys = zs | (y == lo1) | (y == hi1);
-                // on a z- or y-face of the shell every x is on the shell; otherwise only the two x-faces
-                const int xs = max(lo0, 0), xe = min(hi0, dx - 1);
-                const int step = ys ? 1 : max(hi0 - lo0, 1);
-                for (int x = ys ? xs : lo0; x <= xe; x += step) {
-                    if (x < 0) continue;
-                    const int cell = (z * dy + y) * dx + x;
-                    const int kb = cell_start[cell], ke = cell_start[cell + 1];
-                    for (int k = kb; k < ke; ++k) {
-                        const float4 q = sorted[k];
-                        const float ex = p.x - q.x, ey = p.y - q.y, ez = p.z - q.z;
-                        const float d = (ex * ex + ey * ey) + ez * ez;
-                        const int j = __float_as_int(q.w);
-                        if ((d < best) | ((d == best) & (j < bi))) { best = d; bi = j; }
-                    }
-                }
+        const int z0 = max(lo2, 0), z1 = min(hi2, dz - 1), y0 = max(lo1, 0), y1 = min(hi1, dy - 1);
+        const int ny = y1 - y0 + 1, nrows = (z1 - z0 + 1) * ny;
+        const int xs = max(lo0, 0), xe = min(hi0, dx - 1);
+        auto scan = [&](int kb, int ke) {
+            for (int k = kb; k < ke; ++k) {
+                const float4 q = sorted[k];
+                const float ex = p.x - q.x, ey = p.y - q.y, ez = p.z - q.z;
+                const float d = (ex * ex + ey * ey) + ez * ez;
+                const int j = __float_as_int(q.w);
+                if ((d < best) | ((d == best) & (j < bi))) { best = d; bi = j; }
+            }
+        };
+        for (int t = sub; t < nrows; t += kNnGroup) {
+            const int zz = t / ny;
+            const int z = z0 + zz, y = y0 + (t - zz * ny);
+            const bool face = (z == lo2) | (z == hi2) | (y == lo1) | (y == hi1);
+            const int row = (z * dy + y) * dx;
+            if (face) {
+                scan(cell_start[row + xs], cell_start[row + xe + 1]);
+            } else {
+                if (lo0 >= 0) scan(cell_start[row + lo0], cell_start[row + lo0 + 1]);
+                if (hi0 <= dx - 1) scan(cell_start[row + hi0], cell_start[row + hi0 + 1]);
             }
         }
+        group_min8(best, bi);
         float bound = FLT_MAX;
         bool open = false;
         const float pv[3] = {p.x, p.y, p.z};
@@ -235,8 +266,10 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const float4 *work, int 
         bound *= 0.9999f;
         if (bi >= 0 && best < bound * bound) break;
     }
-    nn_idx[i] = bi;
-    nn_d2[i] = best;
+    if (valid && sub == 0) {
+        nn_idx[i] = bi;
+        nn_d2[i] = best;
+    }
 }
 
 // ---- K5 ----------------------------------------------------------------------------
@@ -347,8 +380,71 @@ __global__ __launch_bounds__(256) void corr_reduce_mfma_kernel(const float4 *wor
 }
 
 // ---- K5b ---------------------------------------------------------------------------
+// Rotation maximising trace(R S) for a well conditioned S with positive determinant (the ICP case:
+// thousands of correspondences): the orthogonal polar factor of S^T by Newton's iteration
+// X <- (g X + X^-T / g) / 2, Frobenius-scaled (Higham) while far from orthogonal.  A handful of 3x3
+// cofactor inverses instead of ~8 sweeps of a 4x4 Jacobi whose dependent fp64 divisions and square
+// roots cost ~40 us on one lane.  Returns false (caller falls back to Horn's quaternion) when S is
+// close to singular or improper -- e.g. the rank-2 matrices of the 3-point RANSAC fits.
+__device__ bool rotation_polar(const double S[3][3], double R[3][3])
+{
+    double X[3][3];
+    double fro = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { X[i][j] = S[j][i]; fro += S[j][i] * S[j][i]; }
+    if (!(fro > 0.0) || !(fro < 1e300)) return false;
+    const double inv_fro = 1.0 / sqrt(fro);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) X[i][j] *= inv_fro;
+    bool scaled = true;
+#pragma unroll 1
+    for (int it = 0; it < 24; ++it) {
+        double C[3][3];                                    // cofactors: X^-T = C / det
+        C[0][0] = X[1][1] * X[2][2] - X[1][2] * X[2][1]; C[0][1] = X[1][2] * X[2][0] - X[1][0] * X[2][2]; C[0][2] = X[1][0] * X[2][1] - X[1][1] * X[2][0];
+        C[1][0] = X[0][2] * X[2][1] - X[0][1] * X[2][2]; C[1][1] = X[0][0] * X[2][2] - X[0][2] * X[2][0]; C[1][2] = X[0][1] * X[2][0] - X[0][0] * X[2][1];
+        C[2][0] = X[0][1] * X[1][2] - X[0][2] * X[1][1]; C[2][1] = X[0][2] * X[1][0] - X[0][0] * X[1][2]; C[2][2] = X[0][0] * X[1][1] - X[0][1] * X[1][0];
+        const double det = X[0][0] * C[0][0] + X[0][1] * C[0][1] + X[0][2] * C[0][2];
+        if (it == 0 && !(det > 1e-5)) return false;         // ||X||_F = 1: smallest singular value >~ 2e-5
+        if (!(det > 0.0)) return false;
+        const double inv_det = 1.0 / det;
+        double a = 0.5, b = 0.5 * inv_det;
+        if (scaled) {
+            double nx = 0.0, nc = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { nx += X[i][j] * X[i][j]; nc += C[i][j] * C[i][j]; }
+            const double g2 = sqrt(nc / nx) * inv_det;      // gamma^2 = ||X^-1||_F / ||X||_F
+            const double g = sqrt(g2);
+            a = 0.5 * g; b = 0.5 * inv_det / g;
+            if (fabs(g2 - 1.0) < 1e-2) scaled = false;      // near orthogonal: plain Newton converges quadratically
+        }
+        double delta = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double xn = a * X[i][j] + b * C[i][j];
+                const double d = xn - X[i][j];
+                delta += d * d;
+                X[i][j] = xn;
+            }
+        if (!scaled && delta < 1e-28) break;               // next step would change nothing above rounding
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) R[i][j] = X[i][j];
+    return true;
+}
+
 __device__ void rotation_from_S(const double S[3][3], double R[3][3])
 {
+    if (rotation_polar(S, R)) return;
     double N[4][4], V[4][4];
     const double Sxx = S[0][0], Sxy = S[0][1], Sxz = S[0][2];
     const double Syx = S[1][0], Syy = S[1][1], Syz = S[1][2];
@@ -357,25 +453,46 @@ __device__ void rotation_from_S(const double S[3][3], double R[3][3])
     N[1][1] = Sxx - Syy - Szz; N[1][2] = Sxy + Syx;        N[1][3] = Szx + Sxz;
     N[2][2] = -Sxx + Syy - Szz; N[2][3] = Syz + Szy;
     N[3][3] = -Sxx - Syy + Szz;
-    for (int i = 0; i < 4; ++i) for (int j = 0; j < i; ++j) N[i][j] = N[j][i];
-    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    // every loop over matrix indices is unrolled: the 4x4 arrays must stay in registers (a dynamically
+    // indexed private array lives in scratch memory, ~0.5 us per access on one lane)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < i; ++j) N[i][j] = N[j][i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+#pragma unroll 1
     for (int sweep = 0; sweep < 32; ++sweep) {
         double off = 0.0;
-        for (int i = 0; i < 4; ++i) for (int j = i + 1; j < 4; ++j) off += N[i][j] * N[i][j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = i + 1; j < 4; ++j) off += N[i][j] * N[i][j];
         if (off < 1e-300) break;
-        for (int p = 0; p < 3; ++p) for (int q = p + 1; q < 4; ++q) {
-            if (N[p][q] == 0.0) continue;
-            const double theta = (N[q][q] - N[p][p]) / (2.0 * N[p][q]);
-            const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-            for (int k = 0; k < 4; ++k) { const double a = N[k][p], b = N[k][q]; N[k][p] = c * a - s * b; N[k][q] = s * a + c * b; }
-            for (int k = 0; k < 4; ++k) { const double a = N[p][k], b = N[q][k]; N[p][k] = c * a - s * b; N[q][k] = s * a + c * b; }
-            for (int k = 0; k < 4; ++k) { const double a = V[k][p], b = V[k][q]; V[k][p] = c * a - s * b; V[k][q] = s * a + c * b; }
-        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 4; ++q) {
+                if (N[p][q] != 0.0) {
+                    const double theta = (N[q][q] - N[p][p]) / (2.0 * N[p][q]);
+                    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { const double a = N[k][p], b = N[k][q]; N[k][p] = c * a - s * b; N[k][q] = s * a + c * b; }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { const double a = N[p][k], b = N[q][k]; N[p][k] = c * a - s * b; N[q][k] = s * a + c * b; }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { const double a = V[k][p], b = V[k][q]; V[k][p] = c * a - s * b; V[k][q] = s * a + c * b; }
+                }
+            }
     }
-    int m = 0;
-    for (int i = 1; i < 4; ++i) if (N[i][i] > N[m][m]) m = i;
-    double w = V[0][m], x = V[1][m], y = V[2][m], z = V[3][m];
+    double best = N[0][0];
+    double w = V[0][0], x = V[1][0], y = V[2][0], z = V[3][0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (N[i][i] > best) { best = N[i][i]; w = V[0][i]; x = V[1][i]; y = V[2][i]; z = V[3][i]; }
     const double n = sqrt(w * w + x * x + y * y + z * z);
     if (n > 0.0) { w /= n; x /= n; y /= n; z /= n; } else { w = 1.0; x = y = z = 0.0; }
     R[0][0] = w * w + x * x - y * y - z * z; R[0][1] = 2 * (x * y - w * z);           R[0][2] = 2 * (x * z + w * y);
@@ -405,18 +522,36 @@ __device__ void apply_increment(IcpState *st, const float *T, double sum_d2, dou
     st->mse_prev = mse;
 }
 
-// mode 0: ICP iteration (convergence bookkeeping); mode 1: one-shot rigid estimate; mode 2: fitness only
-__global__ void icp_solve_kernel(IcpState *st, const double *partials, int nblocks, int mode,
-                                 int max_iter, double trans_eps, double fit_eps)
+// Sum of the per-workgroup partials in a fixed order (deterministic run to run): lane l adds workgroups
+// l, l+64, ... (independent loads, all in flight together), then entry k is summed over the lanes in lane
+// order.  One wave; sums[NS] and tmp[NS][64] in LDS.
+template <int NS>
+__device__ __forceinline__ void reduce_partials(const double *partials, int nblocks, double *sums, double (*tmp)[64])
 {
-    __shared__ double sums[kNSum];
-    if (mode == 0 && st->done) return;
-    if (threadIdx.x < kNSum) {
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
         double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += partials[b * kNSum + threadIdx.x];   // fixed order: deterministic
-        sums[threadIdx.x] = s;
+        for (int b = lane; b < nblocks; b += 64) s += partials[b * NS + k];
+        tmp[k][lane] = s;
     }
     __syncthreads();
+    if (lane < NS) {
+        double s = 0.0;
+        for (int l = 0; l < 64; ++l) s += tmp[lane][l];
+        sums[lane] = s;
+    }
+    __syncthreads();
+}
+
+// mode 0: ICP iteration (convergence bookkeeping); mode 1: one-shot rigid estimate; mode 2: fitness only
+__global__ __launch_bounds__(64) void icp_solve_kernel(IcpState *st, const double *partials, int nblocks, int mode,
+                                                       int max_iter, double trans_eps, double fit_eps)
+{
+    __shared__ double sums[kNSum];
+    __shared__ double tmp[kNSum][64];
+    if (mode == 0 && st->done) return;
+    reduce_partials<kNSum>(partials, nblocks, sums, tmp);
     if (threadIdx.x != 0) return;
     for (int k = 0; k < kNSum; ++k) st->sums[k] = sums[k];
     const double N = sums[15];
@@ -441,21 +576,33 @@ __global__ void icp_solve_kernel(IcpState *st, const double *partials, int nbloc
 // ---- point-to-plane estimator (BASELINE configs[2]; the reference itself is point-to-point) ---------
 constexpr int kNPlane = 29;              // 21 (upper triangle of A^T A) + 6 (A^T b) + sum d2 + count
 
-__device__ void jacobi_eig3(double A[3][3], double V[3][3])
+__device__ __forceinline__ void jacobi_eig3(double (&A)[3][3], double (&V)[3][3])
 {
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    // loops over matrix indices unrolled (registers, not scratch): see rotation_from_S
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+#pragma unroll 1
     for (int sweep = 0; sweep < 32; ++sweep) {
         const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
         if (off < 1e-300) break;
-        for (int p = 0; p < 2; ++p) for (int q = p + 1; q < 3; ++q) {
-            if (A[p][q] == 0.0) continue;
-            const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
-            const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-            for (int k = 0; k < 3; ++k) { const double a = A[k][p], b = A[k][q]; A[k][p] = c * a - s * b; A[k][q] = s * a + c * b; }
-            for (int k = 0; k < 3; ++k) { const double a = A[p][k], b = A[q][k]; A[p][k] = c * a - s * b; A[q][k] = s * a + c * b; }
-            for (int k = 0; k < 3; ++k) { const double a = V[k][p], b = V[k][q]; V[k][p] = c * a - s * b; V[k][q] = s * a + c * b; }
-        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                if (A[p][q] != 0.0) {
+                    const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { const double a = A[k][p], b = A[k][q]; A[k][p] = c * a - s * b; A[k][q] = s * a + c * b; }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { const double a = A[p][k], b = A[q][k]; A[p][k] = c * a - s * b; A[q][k] = s * a + c * b; }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { const double a = V[k][p], b = V[k][q]; V[k][p] = c * a - s * b; V[k][q] = s * a + c * b; }
+                }
+            }
     }
 }
 
@@ -497,9 +644,10 @@ __global__ __launch_bounds__(256) void normals_kernel(const unsigned char *tgt, 
         C[1][1] = sq[3] / N - m1 * m1; C[1][2] = sq[4] / N - m1 * m2; C[2][2] = sq[5] / N - m2 * m2;
         C[1][0] = C[0][1]; C[2][0] = C[0][2]; C[2][1] = C[1][2];
         jacobi_eig3(C, V);
-        int m = 0;
-        for (int a = 1; a < 3; ++a) if (C[a][a] < C[m][m]) m = a;
-        out = make_float4((float)V[0][m], (float)V[1][m], (float)V[2][m], 0.f);
+        double low = C[0][0], n0 = V[0][0], n1 = V[1][0], n2 = V[2][0];
+#pragma unroll
+        for (int a = 1; a < 3; ++a) if (C[a][a] < low) { low = C[a][a]; n0 = V[0][a]; n1 = V[1][a]; n2 = V[2][a]; }
+        out = make_float4((float)n0, (float)n1, (float)n2, 0.f);
     }
     normals[i] = out;
 }
@@ -548,13 +696,9 @@ __global__ __launch_bounds__(256) void plane_reduce_kernel(const float4 *work, c
 __global__ void plane_solve_kernel(IcpState *st, const double *partials, int nblocks, int max_iter, double trans_eps, double fit_eps)
 {
     __shared__ double sums[kNPlane];
+    __shared__ double tmp[kNPlane][64];
     if (st->done) return;
-    if (threadIdx.x < kNPlane) {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += partials[b * kNPlane + threadIdx.x];
-        sums[threadIdx.x] = s;
-    }
-    __syncthreads();
+    reduce_partials<kNPlane>(partials, nblocks, sums, tmp);
     if (threadIdx.x != 0) return;
     const double N = sums[28];
     st->n_corr = (int)N;
@@ -816,6 +960,12 @@ int pinned(IcpWorkspace *ws, size_t bytes, std::string *err)
     return SCL_OK;
 }
 
+int nn_blocks(int n_src)
+{
+    const long long threads = (long long)(n_src > 0 ? n_src : 1) * kNnGroup;
+    return (int)((threads + 255) / 256);
+}
+
 int check_cloud_args(int n_src, int n_tgt, int stride, std::string *err)
 {
     if (n_src < 0 || n_tgt < 0 || stride < 12 || (stride & 3)) { if (err) *err = "icp: bad cloud layout"; return SCL_ERR_INVALID_ARG; }
@@ -891,7 +1041,7 @@ int icp_align_staged(IcpWorkspace *ws, hipStream_t stream, int n_src, int n_tgt,
     hipLaunchKernelGGL(work_init_kernel, dim3(pb), dim3(256), 0, stream, d_src, n_src, stride, work);
     IcpState *h = static_cast<IcpState *>(ws->pinned);
     for (int it = 0; it < p.max_iterations; ++it) {
-        hipLaunchKernelGGL(nn_search_kernel, dim3(pb), dim3(256), 0, stream, work, n_src, st,
+        hipLaunchKernelGGL(nn_search_kernel, dim3(nn_blocks(n_src)), dim3(256), 0, stream, work, n_src, st,
                            (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], nni, nnd, 1);
         if (p.estimator == 1) {
             hipLaunchKernelGGL(plane_reduce_kernel, dim3(rb), dim3(256), 0, stream, work, d_tgt, stride, n_src, nni, nnd, maxd2,
@@ -914,7 +1064,7 @@ int icp_align_staged(IcpWorkspace *ws, hipStream_t stream, int n_src, int n_tgt,
     }
     // fitness: original source moved by the final transform, mean squared NN distance over all points
     hipLaunchKernelGGL(work_transform_kernel, dim3(pb), dim3(256), 0, stream, work, d_src, n_src, stride, st, 1, 0);
-    hipLaunchKernelGGL(nn_search_kernel, dim3(pb), dim3(256), 0, stream, work, n_src, st,
+    hipLaunchKernelGGL(nn_search_kernel, dim3(nn_blocks(n_src)), dim3(256), 0, stream, work, n_src, st,
                        (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], nni, nnd, 0);
     LAUNCH_REDUCE(rb, stream, work, d_src, d_tgt, stride, n_src,
                   nni, nnd, FLT_MAX, (const int *)nullptr, (const int *)nullptr, 0, st, part, 0);
@@ -945,7 +1095,7 @@ int icp_nn_correspondences(IcpWorkspace *ws, hipStream_t stream, int num_cu, con
     const int pb = (n_src + 255) / 256 > 0 ? (n_src + 255) / 256 : 1;
     hipLaunchKernelGGL(work_init_kernel, dim3(pb), dim3(256), 0, stream, (const unsigned char *)ws->buf[B_SRC], n_src, stride,
                        (float4 *)ws->buf[B_WORK]);
-    hipLaunchKernelGGL(nn_search_kernel, dim3(pb), dim3(256), 0, stream, (const float4 *)ws->buf[B_WORK], n_src, st,
+    hipLaunchKernelGGL(nn_search_kernel, dim3(nn_blocks(n_src)), dim3(256), 0, stream, (const float4 *)ws->buf[B_WORK], n_src, st,
                        (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], (int *)ws->buf[B_NNI],
                        (float *)ws->buf[B_NND], 0);
     ICP_HIP(hipGetLastError());
@@ -1098,7 +1248,7 @@ int icp_geometric_verification(IcpWorkspace *ws, hipStream_t stream, int num_cu,
     const int pb = (n_src + 255) / 256;
     hipLaunchKernelGGL(work_init_kernel, dim3(pb), dim3(256), 0, stream, (const unsigned char *)ws->buf[B_SRC], n_src, stride,
                        (float4 *)ws->buf[B_WORK]);
-    hipLaunchKernelGGL(nn_search_kernel, dim3(pb), dim3(256), 0, stream, (const float4 *)ws->buf[B_WORK], n_src, st,
+    hipLaunchKernelGGL(nn_search_kernel, dim3(nn_blocks(n_src)), dim3(256), 0, stream, (const float4 *)ws->buf[B_WORK], n_src, st,
                        (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], (int *)ws->buf[B_NNI],
                        (float *)ws->buf[B_NND], 0);                                              // DM.h:1211-1215
     hipLaunchKernelGGL(iota_pairs_kernel, dim3(pb), dim3(256), 0, stream, (const int *)ws->buf[B_NNI], n_src,
