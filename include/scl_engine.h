@@ -175,6 +175,13 @@ int  scl_icp_default_params(scl_icp_params *p);
 int  scl_icp_align(scl_engine *e, const void *src, int n_src, const void *tgt, int n_tgt,
                    int stride_bytes, const scl_icp_params *p,
                    float T[16], float *fitness, int *converged, int *iterations);
+/* The same alignment for the n_targets loop candidates of one scan (BASELINE configs[2]: ICP on the
+ * top-25 candidates): one source against tgts[c] (n_tgts[c] points), up to four alignments in flight on
+ * internal streams.  T: n_targets x 16 floats; fitness / converged / iterations: n_targets entries
+ * (each may be NULL).  Per-candidate results are those of scl_icp_align. */
+int  scl_icp_align_batch(scl_engine *e, const void *src, int n_src, const void *const *tgts, const int *n_tgts,
+                         int n_targets, int stride_bytes, const scl_icp_params *p,
+                         float *T, float *fitness, int *converged, int *iterations);
 /* CorrespondenceEstimation::determineCorrespondences, DM.h:1211-1215:
  * exact 1-NN of every source point in the target (ties -> lowest target index). */
 int  scl_nn_correspondences(scl_engine *e, const void *src, int n_src, const void *tgt, int n_tgt,

@@ -13,6 +13,8 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "icp.hpp"
@@ -76,6 +78,9 @@ struct scl_engine {
 
     IcpWorkspace icp_ws;
     IcpWorkspace vox_ws;
+    static constexpr int kIcpLanes = 4;                    // concurrent alignments of scl_icp_align_batch
+    IcpWorkspace icp_lane_ws[kIcpLanes];
+    hipStream_t icp_lane_stream[kIcpLanes] = {nullptr};
 
     // on-device keyframe store (robots[id].keyFrameArray, DM.h:86): clouds live in slabs of HBM, bump allocated
     struct StoredCloud { unsigned char *d = nullptr; int n = -1; size_t cap_bytes = 0; };
@@ -463,6 +468,10 @@ int scl_destroy(scl_engine *e)
     icp_workspace_free(&e->icp_ws);
     icp_workspace_free(&e->vox_ws);
     for (void *slab : e->kf_slabs) (void)hipFree(slab);
+    for (int i = 0; i < scl_engine::kIcpLanes; ++i) {
+        icp_workspace_free(&e->icp_lane_ws[i]);
+        if (e->icp_lane_stream[i]) (void)hipStreamDestroy(e->icp_lane_stream[i]);
+    }
     dev_free(e->d_desc); dev_free(e->d_vkey); dev_free(e->d_norm); dev_free(e->d_rkey); dev_free(e->d_rkey4);
     dev_free(e->q_desc); dev_free(e->q_vkey); dev_free(e->q_norm); dev_free(e->q_rkey); dev_free(e->q_rkey4);
     dev_free(e->d_vals); dev_free(e->d_points); dev_free(e->d_tile);
@@ -888,6 +897,52 @@ int scl_icp_align(scl_engine *e, const void *src, int n_src, const void *tgt, in
     int rc = icp_align(&e->icp_ws, e->stream, e->num_cu, src, n_src, tgt, n_tgt, stride_bytes, *p,
                        T, fitness, converged, iterations, &err);
     if (rc) e->last_error = err;
+    return rc;
+}
+
+int scl_icp_align_batch(scl_engine *e, const void *src, int n_src, const void *const *tgts, const int *n_tgts,
+                        int n_targets, int stride_bytes, const scl_icp_params *p,
+                        float *T, float *fitness, int *converged, int *iterations)
+{
+    if (!e || !src || !p || !T || n_targets < 0 || (n_targets > 0 && (!tgts || !n_tgts))) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    const int lanes = n_targets < scl_engine::kIcpLanes ? n_targets : scl_engine::kIcpLanes;
+    for (int l = 0; l < lanes; ++l)
+        if (!e->icp_lane_stream[l]) SCL_HIP(e, hipStreamCreateWithFlags(&e->icp_lane_stream[l], hipStreamNonBlocking));
+    if (n_src < 0 || stride_bytes < 12 || (stride_bytes & 3)) return fail(e, SCL_ERR_INVALID_ARG, "icp_align_batch: bad cloud layout");
+    // the source crosses PCIe once; every lane takes a device-to-device copy of it
+    int rc0 = ensure_points(e, (size_t)n_src * stride_bytes + 16);
+    if (rc0) return rc0;
+    if (n_src) SCL_HIP(e, hipMemcpyAsync(e->d_points, src, (size_t)n_src * stride_bytes, hipMemcpyHostToDevice, e->stream));
+    SCL_HIP(e, hipStreamSynchronize(e->stream));
+    std::atomic<int> next{0};
+    std::atomic<int> first_rc{SCL_OK};
+    std::string errs[scl_engine::kIcpLanes];
+    auto worker = [&](int l) {
+        (void)hipSetDevice(e->device);
+        IcpWorkspace *ws = &e->icp_lane_ws[l];
+        hipStream_t st = e->icp_lane_stream[l];
+        for (;;) {
+            const int c = next.fetch_add(1);
+            if (c >= n_targets) break;
+            if ((!tgts[c] && n_tgts[c] > 0) || n_tgts[c] < 0) { int ok = SCL_OK; first_rc.compare_exchange_strong(ok, SCL_ERR_INVALID_ARG); continue; }
+            int conv = 0, iters = 0; float fit = 0.f;
+            int rc = icp_stage_cloud(ws, st, false, e->d_points, n_src, stride_bytes, &errs[l]);
+            if (!rc) rc = icp_stage_cloud_host(ws, st, true, tgts[c], n_tgts[c], stride_bytes, &errs[l]);
+            if (!rc) rc = icp_align_staged(ws, st, n_src, n_tgts[c], stride_bytes, *p, T + 16 * (size_t)c, &fit, &conv, &iters, &errs[l]);
+            if (rc) { int ok = SCL_OK; first_rc.compare_exchange_strong(ok, rc); continue; }
+            if (fitness) fitness[c] = fit;
+            if (converged) converged[c] = conv;
+            if (iterations) iterations[c] = iters;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int l = 1; l < lanes; ++l) pool.emplace_back(worker, l);
+    if (lanes > 0) worker(0);
+    for (auto &t : pool) t.join();
+    const int rc = first_rc.load();
+    if (rc) { for (auto &m : errs) if (!m.empty()) { e->last_error = m; break; } if (e->last_error.empty()) e->last_error = "icp_align_batch: bad target"; }
     return rc;
 }
 

@@ -22,6 +22,8 @@
 // `done` flag, the host peeks at it every few iterations.
 #include "icp.hpp"
 
+#include <hipcub/hipcub.hpp>
+
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
@@ -104,10 +106,16 @@ __global__ void bbox_partial_kernel(const unsigned char *pts, int n, int stride,
 
 __global__ void grid_setup_kernel(const float *part, int nblocks, int n, IcpState *st, int *cell_start)
 {
+    // one wave: lane l folds the partial boxes l, l+64, ..., then a butterfly (min/max are order independent)
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int b = threadIdx.x; b < nblocks; b += 64)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], part[b * 6 + a]); mx[a] = fmaxf(mx[a], part[b * 6 + 3 + a]); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64)); }
     if (threadIdx.x == 0) {
-        float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-        for (int b = 0; b < nblocks; ++b)
-            for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], part[b * 6 + a]); mx[a] = fmaxf(mx[a], part[b * 6 + 3 + a]); }
         if (n <= 0) { for (int a = 0; a < 3; ++a) { mn[a] = 0.f; mx[a] = 0.f; } }
         float ext = 0.f;
         for (int a = 0; a < 3; ++a) ext = fmaxf(ext, mx[a] - mn[a]);
@@ -121,9 +129,7 @@ __global__ void grid_setup_kernel(const float *part, int nblocks, int n, IcpStat
         }
         st->h = h; st->cells = cells;
     }
-    __syncthreads();
-    const int cells = st->cells;
-    for (int i = threadIdx.x; i <= cells; i += blockDim.x) cell_start[i] = 0;
+    (void)cell_start;                                      // zeroed by the caller (hipMemsetAsync of the whole table)
 }
 
 __device__ __forceinline__ int cell_index(const IcpState *st, float3 p, int c[3])
@@ -145,29 +151,6 @@ __global__ void grid_count_kernel(const unsigned char *pts, int n, int stride, c
         const int cell = cell_index(st, load_xyz(pts, i, stride), c);
         atomicAdd(&cell_start[cell + 1], 1);
     }
-}
-
-// exclusive scan of cell counts in place (cell_start[0] = 0 already), single workgroup
-__global__ __launch_bounds__(1024) void grid_scan_kernel(const IcpState *st, int *cell_start, int *cell_fill)
-{
-    __shared__ int s_part[1024];
-    const int n = st->cells + 1;
-    const int per = (n + 1023) / 1024;
-    const int lo = threadIdx.x * per, hi = min(lo + per, n);
-    int sum = 0;
-    for (int i = lo; i < hi; ++i) sum += cell_start[i];
-    s_part[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {                 // Hillis-Steele inclusive scan
-        const int v = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0;
-        __syncthreads();
-        s_part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    int run = threadIdx.x ? s_part[threadIdx.x - 1] : 0;
-    for (int i = lo; i < hi; ++i) { run += cell_start[i]; cell_start[i] = run; }   // inclusive of the +1 shift => start offsets
-    __syncthreads();
-    for (int i = threadIdx.x; i < st->cells; i += blockDim.x) cell_fill[i] = cell_start[i];
 }
 
 __global__ void grid_scatter_kernel(const unsigned char *pts, int n, int stride, const IcpState *st,
@@ -207,9 +190,12 @@ __device__ __forceinline__ void group_min8(float &d, int &j)
 #undef SCL_GMIN_STEP
 }
 
-__global__ __launch_bounds__(256) void nn_search_kernel(const float4 *work, int n_src, const IcpState *st,
+// apply_iter >= 0: K6 fused in -- the increment of the previous iteration's solve (st->inc_T, valid iff
+// st->iter == apply_iter, i.e. that solve really ran) moves the working point first, and the moved point is
+// written back for the reduction that follows (distributedMapping.h:247-249 arithmetic: fp32, no FMA).
+__global__ __launch_bounds__(256) void nn_search_kernel(float4 *work, int n_src, const IcpState *st,
                                                         const int *cell_start, const float4 *sorted,
-                                                        int *nn_idx, float *nn_d2, int check_done)
+                                                        int *nn_idx, float *nn_d2, int check_done, int apply_iter)
 {
     if (check_done && st->done) return;
     if (n_src <= 0) return;
@@ -217,7 +203,16 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const float4 *work, int 
     const int sub = threadIdx.x & (kNnGroup - 1);
     const bool valid = gid < n_src;
     const int i = valid ? gid : n_src - 1;                       // surplus groups shadow the last query (all lanes stay in the exchanges)
-    const float4 pw = work[i];
+    float4 pw = work[i];
+    if (apply_iter >= 0 && st->iter == apply_iter && valid) {    // (surplus groups would re-apply it to the stored result)
+        const float *T = st->inc_T;
+        const float x = pw.x, y = pw.y, z = pw.z;
+        pw.x = T[0] * x + T[1] * y + T[2] * z + T[3];
+        pw.y = T[4] * x + T[5] * y + T[6] * z + T[7];
+        pw.z = T[8] * x + T[9] * y + T[10] * z + T[11];
+        pw.w = 0.f;
+        if (sub == 0) work[i] = pw;
+    }
     const float3 p = make_float3(pw.x, pw.y, pw.z);
     int c[3];
     cell_index(st, p, c);
@@ -939,12 +934,19 @@ int build_grid(IcpWorkspace *ws, hipStream_t stream, int n_tgt, int stride, std:
     const unsigned char *tgt = static_cast<const unsigned char *>(ws->buf[B_TGT]);
     IcpState *st = static_cast<IcpState *>(ws->buf[B_STATE]);
     int nb = (n_tgt + 255) / 256; nb = nb < 1 ? 1 : (nb > 256 ? 256 : nb);
+    // counts land in cell_start[cell + 1]; an inclusive scan of the whole table (zeros past the used cells) turns
+    // them into start offsets; cell_fill = a copy the scatter advances
+    int *cstart = static_cast<int *>(ws->buf[B_CSTART]);
+    ICP_HIP(hipMemsetAsync(cstart, 0, sizeof(int) * (size_t)(kMaxCells + 2), stream));
     hipLaunchKernelGGL(bbox_partial_kernel, dim3(nb), dim3(256), 0, stream, tgt, n_tgt, stride, (float *)ws->buf[B_BBOX]);
-    hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(1024), 0, stream, (const float *)ws->buf[B_BBOX], nb, n_tgt, st,
-                       (int *)ws->buf[B_CSTART]);
+    hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(64), 0, stream, (const float *)ws->buf[B_BBOX], nb, n_tgt, st, cstart);
     int gb = (n_tgt + 255) / 256; gb = gb < 1 ? 1 : (gb > 2048 ? 2048 : gb);
-    hipLaunchKernelGGL(grid_count_kernel, dim3(gb), dim3(256), 0, stream, tgt, n_tgt, stride, st, (int *)ws->buf[B_CSTART]);
-    hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, stream, st, (int *)ws->buf[B_CSTART], (int *)ws->buf[B_CFILL]);
+    hipLaunchKernelGGL(grid_count_kernel, dim3(gb), dim3(256), 0, stream, tgt, n_tgt, stride, st, cstart);
+    size_t scan_tmp = 0;
+    ICP_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, scan_tmp, cstart, cstart, kMaxCells + 1, stream));
+    if (scan_tmp > ws->cap[B_CFILL]) { if (err) *err = "icp: scan scratch larger than the cell table"; return SCL_ERR_NOMEM; }
+    ICP_HIP(hipcub::DeviceScan::InclusiveSum(ws->buf[B_CFILL], scan_tmp, cstart, cstart, kMaxCells + 1, stream));   // cell_fill doubles as scratch
+    ICP_HIP(hipMemcpyAsync(ws->buf[B_CFILL], cstart, sizeof(int) * (size_t)(kMaxCells + 1), hipMemcpyDeviceToDevice, stream));
     hipLaunchKernelGGL(grid_scatter_kernel, dim3(gb), dim3(256), 0, stream, tgt, n_tgt, stride, st, (int *)ws->buf[B_CFILL],
                        (float4 *)ws->buf[B_TSORT]);
     ICP_HIP(hipGetLastError());
@@ -990,6 +992,13 @@ int icp_align(IcpWorkspace *ws, hipStream_t stream, int num_cu, const void *src,
     if ((rc = upload(ws, B_SRC, src, (size_t)n_src * stride, stream, err))) return rc;
     if ((rc = upload(ws, B_TGT, tgt, (size_t)n_tgt * stride, stream, err))) return rc;
     return icp_align_staged(ws, stream, n_src, n_tgt, stride, p, T, fitness, converged, iterations, err);
+}
+
+int icp_stage_cloud_host(IcpWorkspace *ws, hipStream_t stream, bool target, const void *h_cloud, int n, int stride,
+                         std::string *err)
+{
+    if (n < 0 || stride < 12 || (stride & 3)) { if (err) *err = "icp_stage_cloud_host: bad arguments"; return SCL_ERR_INVALID_ARG; }
+    return upload(ws, target ? B_TGT : B_SRC, h_cloud, (size_t)n * stride, stream, err);
 }
 
 int icp_stage_cloud(IcpWorkspace *ws, hipStream_t stream, bool target, const void *d_cloud, int n, int stride,
@@ -1042,7 +1051,7 @@ int icp_align_staged(IcpWorkspace *ws, hipStream_t stream, int n_src, int n_tgt,
     IcpState *h = static_cast<IcpState *>(ws->pinned);
     for (int it = 0; it < p.max_iterations; ++it) {
         hipLaunchKernelGGL(nn_search_kernel, dim3(nn_blocks(n_src)), dim3(256), 0, stream, work, n_src, st,
-                           (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], nni, nnd, 1);
+                           (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], nni, nnd, 1, it > 0 ? it : -1);
         if (p.estimator == 1) {
             hipLaunchKernelGGL(plane_reduce_kernel, dim3(rb), dim3(256), 0, stream, work, d_tgt, stride, n_src, nni, nnd, maxd2,
                                (const float4 *)ws->buf[B_NORM], st, part);
@@ -1054,8 +1063,7 @@ int icp_align_staged(IcpWorkspace *ws, hipStream_t stream, int n_src, int n_tgt,
             hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, stream, st, part, rb, 0, p.max_iterations,
                                p.transformation_epsilon, p.euclidean_fitness_epsilon);
         }
-        // applies inc_T iff the solve of this very iteration ran (also when it just declared convergence)
-        hipLaunchKernelGGL(work_transform_kernel, dim3(pb), dim3(256), 0, stream, work, d_src, n_src, stride, st, 0, it + 1);
+        // K6 (working cloud <- inc_T * working cloud) is fused into the next iteration's nn_search_kernel
         if ((it & 7) == 7) {                                   // peek at the device flag every 8 iterations
             ICP_HIP(hipMemcpyAsync(h, st, sizeof(IcpState), hipMemcpyDeviceToHost, stream));
             ICP_HIP(hipStreamSynchronize(stream));
@@ -1065,7 +1073,7 @@ int icp_align_staged(IcpWorkspace *ws, hipStream_t stream, int n_src, int n_tgt,
     // fitness: original source moved by the final transform, mean squared NN distance over all points
     hipLaunchKernelGGL(work_transform_kernel, dim3(pb), dim3(256), 0, stream, work, d_src, n_src, stride, st, 1, 0);
     hipLaunchKernelGGL(nn_search_kernel, dim3(nn_blocks(n_src)), dim3(256), 0, stream, work, n_src, st,
-                       (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], nni, nnd, 0);
+                       (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], nni, nnd, 0, -1);
     LAUNCH_REDUCE(rb, stream, work, d_src, d_tgt, stride, n_src,
                   nni, nnd, FLT_MAX, (const int *)nullptr, (const int *)nullptr, 0, st, part, 0);
     hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, stream, st, part, rb, 2, 0, 0.0, 0.0);
@@ -1095,9 +1103,9 @@ int icp_nn_correspondences(IcpWorkspace *ws, hipStream_t stream, int num_cu, con
     const int pb = (n_src + 255) / 256 > 0 ? (n_src + 255) / 256 : 1;
     hipLaunchKernelGGL(work_init_kernel, dim3(pb), dim3(256), 0, stream, (const unsigned char *)ws->buf[B_SRC], n_src, stride,
                        (float4 *)ws->buf[B_WORK]);
-    hipLaunchKernelGGL(nn_search_kernel, dim3(nn_blocks(n_src)), dim3(256), 0, stream, (const float4 *)ws->buf[B_WORK], n_src, st,
+    hipLaunchKernelGGL(nn_search_kernel, dim3(nn_blocks(n_src)), dim3(256), 0, stream, (float4 *)ws->buf[B_WORK], n_src, st,
                        (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], (int *)ws->buf[B_NNI],
-                       (float *)ws->buf[B_NND], 0);
+                       (float *)ws->buf[B_NND], 0, -1);
     ICP_HIP(hipGetLastError());
     ICP_HIP(hipMemcpyAsync(nn_index, ws->buf[B_NNI], sizeof(int) * (size_t)n_src, hipMemcpyDeviceToHost, stream));
     if (nn_dist2) ICP_HIP(hipMemcpyAsync(nn_dist2, ws->buf[B_NND], sizeof(float) * (size_t)n_src, hipMemcpyDeviceToHost, stream));
@@ -1248,9 +1256,9 @@ int icp_geometric_verification(IcpWorkspace *ws, hipStream_t stream, int num_cu,
     const int pb = (n_src + 255) / 256;
     hipLaunchKernelGGL(work_init_kernel, dim3(pb), dim3(256), 0, stream, (const unsigned char *)ws->buf[B_SRC], n_src, stride,
                        (float4 *)ws->buf[B_WORK]);
-    hipLaunchKernelGGL(nn_search_kernel, dim3(nn_blocks(n_src)), dim3(256), 0, stream, (const float4 *)ws->buf[B_WORK], n_src, st,
+    hipLaunchKernelGGL(nn_search_kernel, dim3(nn_blocks(n_src)), dim3(256), 0, stream, (float4 *)ws->buf[B_WORK], n_src, st,
                        (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], (int *)ws->buf[B_NNI],
-                       (float *)ws->buf[B_NND], 0);                                              // DM.h:1211-1215
+                       (float *)ws->buf[B_NND], 0, -1);                                              // DM.h:1211-1215
     hipLaunchKernelGGL(iota_pairs_kernel, dim3(pb), dim3(256), 0, stream, (const int *)ws->buf[B_NNI], n_src,
                        (int *)ws->buf[B_SI], (int *)ws->buf[B_TI]);
     int best2[2];

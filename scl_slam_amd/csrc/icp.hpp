@@ -25,6 +25,8 @@ int icp_align(IcpWorkspace *ws, hipStream_t stream, int num_cu, const void *src,
 // icp_align_staged() runs the same alignment as icp_align() on what has been staged
 int icp_stage_cloud(IcpWorkspace *ws, hipStream_t stream, bool target, const void *d_cloud, int n, int stride_bytes,
                     std::string *err);
+int icp_stage_cloud_host(IcpWorkspace *ws, hipStream_t stream, bool target, const void *h_cloud, int n, int stride_bytes,
+                         std::string *err);
 int icp_align_staged(IcpWorkspace *ws, hipStream_t stream, int n_src, int n_tgt, int stride_bytes,
                      const scl_icp_params &p, float T[16], float *fitness, int *converged, int *iterations,
                      std::string *err);

@@ -91,6 +91,7 @@ def _bind(lib):
         "scl_topk_with_distance": (c_int, [P, c_int, c_int, c_int, c_int, ip, fp, dp, ip, ip]),
         "scl_icp_default_params": (c_int, [POINTER(IcpParams)]),
         "scl_icp_align": (c_int, [P, P, c_int, P, c_int, c_int, POINTER(IcpParams), fp, fp, ip, ip]),
+        "scl_icp_align_batch": (c_int, [P, P, c_int, POINTER(c_void_p), ip, c_int, c_int, POINTER(IcpParams), fp, fp, ip, ip]),
         "scl_nn_correspondences": (c_int, [P, P, c_int, P, c_int, c_int, ip, fp]),
         "scl_rigid_svd": (c_int, [P, P, c_int, P, c_int, c_int, ip, ip, c_int, fp]),
         "scl_transform_cloud": (c_int, [P, P, c_int, c_int, fp, P]),
@@ -324,6 +325,24 @@ class ScanContextEngine:
                                             stride, byref(p), _ptr(T, c_float), byref(fit), byref(conv), byref(it)),
                     "scl_icp_align")
         return T.reshape(4, 4), fit.value, bool(conv.value), it.value
+
+    def icp_align_batch(self, src, tgts, params=None):
+        """one source against several targets (the loop candidates of one scan), alignments overlapped on the device"""
+        s_, ns, stride = _cloud(src)
+        arrs = [_cloud(t) for t in tgts]
+        for a, n, st in arrs:
+            if st != stride:
+                raise ValueError("source and targets must share a record layout")
+        m = len(arrs)
+        p = params or self.icp_default_params()
+        ptrs = (c_void_p * max(1, m))(*[a.ctypes.data_as(c_void_p) for a, _, _ in arrs])
+        counts = np.array([n for _, n, _ in arrs] or [0], dtype=np.int32)
+        T = np.empty((max(1, m), 16), dtype=np.float32); fit = np.zeros(max(1, m), np.float32)
+        conv = np.zeros(max(1, m), np.int32); it = np.zeros(max(1, m), np.int32)
+        self._check(self._lib.scl_icp_align_batch(self._h, s_.ctypes.data_as(c_void_p), ns, ptrs, _ptr(counts, c_int), m, stride,
+                                                  byref(p), _ptr(T, c_float), _ptr(fit, c_float), _ptr(conv, c_int), _ptr(it, c_int)),
+                    "scl_icp_align_batch")
+        return T[:m].reshape(m, 4, 4), fit[:m], conv[:m].astype(bool), it[:m]
 
     def nn_correspondences(self, src, tgt):
         s, ns, stride = _cloud(src)

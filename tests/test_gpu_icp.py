@@ -158,3 +158,20 @@ def test_point_to_plane_icp_matches_oracle(eng, n_tgt, noise):
     assert cg == co and ig == io
     assert np.abs(Tg - To).max() < TOL and np.abs(Tg - T).max() < 5e-3
     assert abs(fg - fo) <= 1e-4 * max(1e-6, abs(fo)) + 1e-12
+
+
+def test_icp_align_batch_equals_one_by_one(eng):
+    """top-k candidates of one scan verified together (BASELINE configs[2]): per-candidate results are
+    exactly those of scl_icp_align, whatever the interleaving of the concurrent alignments"""
+    base = synth_structured_cloud(9000, seed=77)
+    src = moved_copy(base, rigid_transform(0.01, -0.01, 0.03, 0.2, -0.1, 0.05), keep_every=2, noise=0.004)
+    tgts = [base]
+    for c in range(1, 7):                                          # other places: 3 good matches, 3 poor ones
+        tgts.append(synth_structured_cloud(5000 + 700 * c, seed=300 + c) if c % 2 else
+                    moved_copy(base, rigid_transform(0.0, 0.0, 0.01 * c, 0.05 * c, 0.02, 0.0), keep_every=1, noise=0.002, seed=c))
+    Tb, fb, cb, ib = eng.icp_align_batch(src, tgts)
+    for c, t in enumerate(tgts):
+        T1, f1, c1, i1 = eng.icp_align(src, t)
+        assert np.array_equal(Tb[c].view(np.uint32), T1.view(np.uint32)) and fb[c] == f1 and bool(cb[c]) == c1 and ib[c] == i1
+    T0, f0, c0, i0 = eng.icp_align_batch(src, [])
+    assert T0.shape[0] == 0
