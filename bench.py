@@ -42,6 +42,9 @@ def parse_args():
     ap.add_argument("--keyframes", type=int, default=N_KEYFRAMES, help="keyframes per GPU")
     ap.add_argument("--pipeline", type=int, default=2, help="scans in flight (1 = strictly one after another)")
     ap.add_argument("--merge-every", type=int, default=16, help="N > 1: scans whose per-rank winners share one all-gather")
+    ap.add_argument("--scans-per-launch", type=int, default=2,
+                    help="incoming scans scored by one kernel launch (1..4): the second scan's workgroups take over CUs "
+                         "as the first scan's retire, so no CU idles in a launch tail")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU sample (0 = auto ~15 s)")
     return ap.parse_args()
@@ -155,7 +158,8 @@ def main():
         """`count` steps.  Each step = one scan's full pass over this rank's shard (ring-key top-k + SC distance
         + arg-min, one launch); `--pipeline` passes are in flight, and for N > 1 the per-rank winners of
         `--merge-every` scans travel in one asynchronous all-gather (RCCL), merged one batch later."""
-        st = FullScanStream(eng, rank, world, device=coll_dev, depth=args.pipeline, merge_every=args.merge_every)
+        st = FullScanStream(eng, rank, world, device=coll_dev, depth=args.pipeline, merge_every=args.merge_every,
+                            scans_per_launch=args.scans_per_launch)
         for i in range(count):
             st.submit(n_elig + ((first + i) % n_query), 0, n_elig)
         res = st.drain()
@@ -169,7 +173,7 @@ def main():
 
     run(0, args.warmup)
     eng.profile_reset()
-    eng.profile_enable(2)          # HIP events around the dominant kernel only (2 records per step)
+    eng.profile_enable(3)          # HIP events around the dominant kernel, one launch in eight (an event pair per launch costs ~8 us)
     fence()
     t0 = time.perf_counter()
     timed_results = run(args.warmup, args.steps)
@@ -198,7 +202,8 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic_sc_distance.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))                      # PMC run of this same command (profiles/r01/final)
+            traffic = tj["hbm_bytes_per_launch"] / tj["pairs_per_launch"] * k1_pairs
         except Exception:
             traffic = None
 
@@ -211,7 +216,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: 10k synthetic Velodyne-64 keyframes per GPU, 64x120 SC, "
                                    "full ring-key scan + shifted SC distance over the whole DB per incoming scan",
                        "keyframes_per_gpu": n_local, "eligible_per_query": n_elig, "rings": R, "sectors": S,
-                       "shifts_per_pair": 13, "scans_in_flight": args.pipeline, "sharding": f"keyframe-index shards x{world}, one async all-gather of 24 B/rank/scan per {args.merge_every} scans"},
+                       "shifts_per_pair": 13, "scans_per_launch": args.scans_per_launch, "launches_in_flight": args.pipeline, "sharding": f"keyframe-index shards x{world}, one async all-gather of 24 B/rank/scan per {args.merge_every} scans"},
             "sc_distance_GBps": value * ALGO_BYTES_PER_PAIR / 1e9,
             "kernel_ms": {"sc_distance": k1_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -149,6 +149,11 @@ int  scl_detect_full_range(scl_engine *e, int query, int lo, int hi,
  * ticket at once (up to 8 may be in flight, results are collected in any order); collect blocks until
  * that pass has finished.  scl_detect_full_range == submit + collect. */
 int  scl_detect_full_submit(scl_engine *e, int query, int lo, int hi, int *ticket);
+/* Several keyframes of the database as queries in ONE launch (scans of several robots arriving together,
+ * or a backlog): query i = keyframe queries[i] against [lo[i], hi[i]); tickets[i] is collected like a
+ * ticket of scl_detect_full_submit.  Up to 4 queries share a launch (more are split); staged queries
+ * (SCL_QUERY_STAGED) and grids without the fused kernel fall back to one launch per query. */
+int  scl_detect_full_submit_many(scl_engine *e, const int *queries, const int *lo, const int *hi, int n_queries, int *tickets);
 int  scl_detect_full_collect(scl_engine *e, int ticket, int *nn_idx, int *shift, double *dist);
 /* The ring-key top-k (num_candidates entries) computed as part of the last scl_detect_full[_range]. */
 int  scl_get_last_topk(scl_engine *e, int k, int *idx, float *d2);
@@ -246,7 +251,9 @@ int  scl_loop_icp_from_store(scl_engine *e, int robot, int key_cur, const float 
                              float T[16], float *fitness, int *converged, int *iterations, int *n_src, int *n_tgt);
 
 /* ---- measurement ----------------------------------------------------------- */
-int  scl_profile_enable(scl_engine *e, int on);   /* 0 off, 1 every kernel family, 2 SC distance only */
+int  scl_profile_enable(scl_engine *e, int on);   /* 0 off, 1 every kernel family, 2 SC distance only,
+                                                     3 SC distance only, one launch in eight (an event pair
+                                                     between two back-to-back launches costs ~8 us of device time) */
 int  scl_profile_reset(scl_engine *e);
 int  scl_profile_get(scl_engine *e, scl_profile *out);
 int  scl_device_name(const scl_engine *e, char *buf, int buflen);

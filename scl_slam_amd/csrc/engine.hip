@@ -9,6 +9,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -41,6 +42,7 @@ struct scl_engine {
     static constexpr int kSlots = 8;                       // full-DB passes in flight (submit/collect)
     hipEvent_t ev_done[kSlots] = {nullptr};
     int slot_lo[kSlots] = {0}; bool slot_busy[kSlots] = {false}; bool slot_empty[kSlots] = {false};
+    int slot_ev[kSlots] = {0};                             // which slot's event completes this one (batched launches share one)
     unsigned next_slot = 0;
     mutable std::mutex mu;
     mutable std::string last_error;
@@ -65,13 +67,26 @@ struct scl_engine {
     unsigned long long *d_topk_scratch = nullptr; int *d_topk_idx = nullptr; float *d_topk_d2 = nullptr;
     double *d_out3 = nullptr;
     unsigned long long *d_blk_part = nullptr; unsigned int *d_done_counter = nullptr;   // fused full-DB epilogue
+    // Second lane for fused full-DB passes: consecutive passes alternate between `stream` and `stream_alt`
+    // (own epilogue scratch and per-pair outputs), so the next pass's workgroups move onto CUs as the previous
+    // pass's workgroups retire instead of waiting behind its completion packet.
+    hipStream_t stream_alt = nullptr;
+    hipEvent_t ev_db = nullptr;                            // database writes on `stream` the alt lane must see
+    uint64_t db_version = 0, alt_seen_version = 0;
+    unsigned long long *a_blk_part = nullptr; unsigned int *a_done_counter = nullptr;
+    int *a_topk_idx = nullptr; float *a_topk_d2 = nullptr;
+    double *a_dist = nullptr; int *a_shift = nullptr; float *a_ring_d2 = nullptr; size_t a_pair_cap = 0;
+    bool last_pass_alt = false;
+    bool alt_lane = false;                                 // SCL_ALT_LANE=1: lowest latency per scan; kernels of the two lanes overlap,
+                                                           // so per-kernel durations no longer measure one pass (default off)
     void *h_pinned = nullptr; size_t pinned_cap = 0;       // small result read-back
 
     // inter-robot tree bookkeeping (descriptor.h:1691-1703, counter initialised: see DESIGN.md)
     int tree_counter = 0, tree_n = 0;
 
     // profiling
-    int prof_on = 0;                                       // 0 off, 1 every kernel family, 2 SC distance only
+    int prof_on = 0;                                       // 0 off, 1 every kernel family, 2 SC distance only, 3 SC distance sampled 1:8
+    unsigned prof_tick = 0;
     scl_profile prof{};
     std::vector<PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;
@@ -111,7 +126,8 @@ struct ProfScope {
     scl_engine *e; int kind; hipStream_t s; hipEvent_t start = nullptr, stop = nullptr;
     ProfScope(scl_engine *e_, int kind_, hipStream_t s_ = nullptr) : e(e_), kind(kind_), s(s_ ? s_ : e_->stream)
     {
-        if (!e->prof_on || (e->prof_on == 2 && kind != P_SC)) return;
+        if (!e->prof_on || (e->prof_on >= 2 && kind != P_SC)) return;
+        if (e->prof_on == 3 && (e->prof_tick++ & 7) != 0) return;     // sampled: one launch in eight
         auto get = [&]() {
             hipEvent_t ev = nullptr;
             if (!e->event_pool.empty()) { ev = e->event_pool.back(); e->event_pool.pop_back(); }
@@ -121,6 +137,7 @@ struct ProfScope {
         start = get(); stop = get();
         if (start && stop) (void)hipEventRecord(start, s);
     }
+    bool active() const { return start && stop; }
     ~ProfScope()
     {
         if (!e->prof_on || !start || !stop) return;
@@ -219,6 +236,7 @@ int ensure_capacity(scl_engine *e, int need)
                                     sizeof(float4) * e->n, e->RG, hipMemcpyDeviceToDevice, e->stream));
     }
     SCL_HIP(e, hipStreamSynchronize(e->stream));
+    if (e->stream_alt) SCL_HIP(e, hipStreamSynchronize(e->stream_alt));   // passes still reading the old arrays
     dev_free(e->d_desc); dev_free(e->d_vkey); dev_free(e->d_norm); dev_free(e->d_rkey); dev_free(e->d_rkey4);
     e->d_desc = nd; e->d_vkey = nv; e->d_norm = nn; e->d_rkey = nr; e->d_rkey4 = nr4;
     e->cap = ncap;
@@ -275,6 +293,7 @@ int ingest_from_vals(scl_engine *e, int count, int first_slot)
     ProfScope ps(e, P_INGEST);
     SCL_HIP(e, launch_ingest(e->d_vals, count, first_slot, e->d_desc, e->d_vkey, e->d_norm, e->d_rkey,
                              e->d_rkey4, e->cap, e->R, e->S, e->stream));
+    e->db_version++;                                       // the alt lane orders itself behind this write
     return SCL_OK;
 }
 
@@ -310,7 +329,7 @@ int launch_distance(scl_engine *e, const QueryView &q, const int *d_cand, int sl
     ProfScope ps(e, P_SC);
     SCL_HIP(e, launch_sc_distance(db_view(e), q, d_cand, slot_base, n, e->SR, e->d_dist, e->d_shift,
                                   e->num_cu, e->stream));
-    if (e->prof_on) e->prof.sc_distance_pairs += (uint64_t)n;
+    if (ps.active()) e->prof.sc_distance_pairs += (uint64_t)n;
     return SCL_OK;
 }
 
@@ -445,12 +464,21 @@ int scl_create(const scl_config *cfg, scl_engine **out)
     if ((rc = dev_alloc(e, &e->q_rkey4, (size_t)e->RG))) return bail(rc);
     if ((rc = dev_alloc(e, &e->d_tile, (size_t)e->R * e->S))) return bail(rc);
     if ((rc = dev_alloc(e, &e->d_topk_scratch, (size_t)kTopkMaxBlocks * kTopkMaxK))) return bail(rc);
-    if ((rc = dev_alloc(e, &e->d_topk_idx, (size_t)kTopkMaxK))) return bail(rc);
-    if ((rc = dev_alloc(e, &e->d_topk_d2, (size_t)kTopkMaxK))) return bail(rc);
+    if ((rc = dev_alloc(e, &e->d_topk_idx, (size_t)kTopkMaxK * kMaxQueryBatch))) return bail(rc);
+    if ((rc = dev_alloc(e, &e->d_topk_d2, (size_t)kTopkMaxK * kMaxQueryBatch))) return bail(rc);
     if ((rc = dev_alloc(e, &e->d_out3, (size_t)4))) return bail(rc);
-    if ((rc = dev_alloc(e, &e->d_blk_part, (size_t)1024 * kTailRec))) return bail(rc);
+    if ((rc = dev_alloc(e, &e->d_blk_part, (size_t)kTailBlocks * kTailRec * kMaxQueryBatch))) return bail(rc);
+    static_assert(kMaxQueryBatch <= 4, "done_counter holds four counters");
     if ((rc = dev_alloc(e, &e->d_done_counter, (size_t)4))) return bail(rc);
     if (hipMemset(e->d_done_counter, 0, 16) != hipSuccess) return bail(SCL_ERR_HIP);
+    if ((rc = dev_alloc(e, &e->a_blk_part, (size_t)1024 * kTailRec))) return bail(rc);
+    if ((rc = dev_alloc(e, &e->a_done_counter, (size_t)4))) return bail(rc);
+    if (hipMemset(e->a_done_counter, 0, 16) != hipSuccess) return bail(SCL_ERR_HIP);
+    if ((rc = dev_alloc(e, &e->a_topk_idx, (size_t)kTopkMaxK))) return bail(rc);
+    if ((rc = dev_alloc(e, &e->a_topk_d2, (size_t)kTopkMaxK))) return bail(rc);
+    if (hipStreamCreateWithFlags(&e->stream_alt, hipStreamNonBlocking) != hipSuccess) return bail(SCL_ERR_HIP);
+    { const char *env = getenv("SCL_ALT_LANE"); e->alt_lane = env && env[0] == '1'; }
+    if (hipEventCreateWithFlags(&e->ev_db, hipEventDisableTiming) != hipSuccess) return bail(SCL_ERR_HIP);
     if ((rc = ensure_pairs(e, 1024))) return bail(rc);
     if ((rc = ensure_pinned(e, 1 << 16))) return bail(rc);
     if ((rc = ensure_vals(e, (size_t)e->R * e->S))) return bail(rc);
@@ -478,7 +506,10 @@ int scl_destroy(scl_engine *e)
     dev_free(e->d_dist); dev_free(e->d_shift); dev_free(e->d_cand); dev_free(e->d_ring_d2);
     dev_free(e->d_topk_scratch); dev_free(e->d_topk_idx); dev_free(e->d_topk_d2); dev_free(e->d_out3);
     dev_free(e->d_blk_part); dev_free(e->d_done_counter);
-    dev_free(e->d_blk_part); dev_free(e->d_done_counter);
+    dev_free(e->a_blk_part); dev_free(e->a_done_counter); dev_free(e->a_topk_idx); dev_free(e->a_topk_d2);
+    dev_free(e->a_dist); dev_free(e->a_shift); dev_free(e->a_ring_d2);
+    if (e->ev_db) (void)hipEventDestroy(e->ev_db);
+    if (e->stream_alt) { (void)hipStreamSynchronize(e->stream_alt); (void)hipStreamDestroy(e->stream_alt); }
     if (e->h_pinned) (void)hipHostFree(e->h_pinned);
     if (e->h_out3) (void)hipHostFree(e->h_out3);
     for (int i = 0; i < scl_engine::kSlots; ++i) if (e->ev_done[i]) (void)hipEventDestroy(e->ev_done[i]);
@@ -766,6 +797,7 @@ int submit_full_locked(scl_engine *e, int query, int lo, int hi, int *ticket)
     e->slot_lo[sl] = lo;
     e->slot_empty[sl] = n <= 0;
     double *out3 = e->h_out3 + (size_t)sl * 8;
+    bool use_alt = false;
     if (n > 0) {
         if ((rc = ensure_pairs(e, (size_t)n))) return rc;
         // "full ring-key + shifted SC distance per incoming scan".  On the two-sectors-per-lane grids the
@@ -776,13 +808,35 @@ int submit_full_locked(scl_engine *e, int query, int lo, int hi, int *ticket)
         const bool fuse = k <= kTailTop && sc_distance_fuses_ring(db_view(e), e->SR);
         if (!fuse) SCL_HIP(e, hipEventRecord(e->ev_fork, e->stream));
         bool fused = false;
-        FullTail tail{e->d_blk_part, e->d_done_counter, out3, e->d_topk_idx, e->d_topk_d2, k, e->cfg.knn_exclude_eps};
-        {
-            ProfScope ps(e, P_SC);
-            SCL_HIP(e, launch_sc_distance(db_view(e), q, nullptr, lo, n, e->SR, e->d_dist, e->d_shift, e->num_cu, e->stream,
-                                          fuse ? e->d_ring_d2 : nullptr, &fused, fuse ? &tail : nullptr));
-            if (e->prof_on) e->prof.sc_distance_pairs += (uint64_t)n;
+        // every other fused pass on a database-resident query runs on the alt lane (see scl_engine::stream_alt)
+        use_alt = e->alt_lane && fuse && query >= 0 && (e->next_slot & 1u);
+        if (use_alt) {
+            if ((size_t)n > e->a_pair_cap) {
+                dev_free(e->a_dist); dev_free(e->a_shift); dev_free(e->a_ring_d2);
+                const size_t nn = (size_t)n + (size_t)n / 2 + 64;
+                e->a_pair_cap = 0;
+                if ((rc = dev_alloc(e, &e->a_ring_d2, nn))) return rc;
+                if ((rc = dev_alloc(e, &e->a_dist, nn))) return rc;
+                if ((rc = dev_alloc(e, &e->a_shift, nn))) return rc;
+                e->a_pair_cap = nn;
+            }
+            if (e->alt_seen_version != e->db_version) {               // descriptors written on `stream` since the last alt pass
+                SCL_HIP(e, hipEventRecord(e->ev_db, e->stream));
+                SCL_HIP(e, hipStreamWaitEvent(e->stream_alt, e->ev_db, 0));
+                e->alt_seen_version = e->db_version;
+            }
         }
+        hipStream_t ks = use_alt ? e->stream_alt : e->stream;
+        FullTail tail{use_alt ? e->a_blk_part : e->d_blk_part, use_alt ? e->a_done_counter : e->d_done_counter, out3,
+                      use_alt ? e->a_topk_idx : e->d_topk_idx, use_alt ? e->a_topk_d2 : e->d_topk_d2, k, e->cfg.knn_exclude_eps};
+        {
+            ProfScope ps(e, P_SC, ks);
+            SCL_HIP(e, launch_sc_distance(db_view(e), q, nullptr, lo, n, e->SR, use_alt ? e->a_dist : e->d_dist,
+                                          use_alt ? e->a_shift : e->d_shift, e->num_cu, ks,
+                                          fuse ? (use_alt ? e->a_ring_d2 : e->d_ring_d2) : nullptr, &fused, fuse ? &tail : nullptr));
+            if (ps.active()) e->prof.sc_distance_pairs += (uint64_t)n;
+        }
+        if (fuse && fused) e->last_pass_alt = use_alt;
         if (fuse && fused) {
             // arg-min and top-k were reduced inside the kernel (last workgroup)
         } else {
@@ -797,10 +851,57 @@ int submit_full_locked(scl_engine *e, int query, int lo, int hi, int *ticket)
             SCL_HIP(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));
         }
     }
-    SCL_HIP(e, hipEventRecord(e->ev_done[sl], e->stream));
+    SCL_HIP(e, hipEventRecord(e->ev_done[sl], use_alt ? e->stream_alt : e->stream));
+    e->slot_ev[sl] = sl;
     e->slot_busy[sl] = true;
     e->next_slot++;
     *ticket = sl;
+    return SCL_OK;
+}
+
+// nq database-resident queries, one launch (workgroups [i*nb, (i+1)*nb) serve query i); every query gets its own
+// result slot, all of them complete with the one event recorded behind the launch.
+int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, const int *his, int nq, int *tickets)
+{
+    const int k = e->cfg.num_candidates;
+    bool batchable = nq > 1 && nq <= kMaxQueryBatch && k <= kTailTop && sc_distance_fuses_ring(db_view(e), e->SR);
+    for (int i = 0; i < nq && batchable; ++i) batchable = queries[i] >= 0 && queries[i] < e->n;
+    if (!batchable) {                                      // one pass per query
+        for (int i = 0; i < nq; ++i) { int rc = submit_full_locked(e, queries[i], los[i], his[i], &tickets[i]); if (rc) return rc; }
+        return SCL_OK;
+    }
+    for (int i = 0; i < nq; ++i)
+        if (e->slot_busy[(e->next_slot + (unsigned)i) % scl_engine::kSlots])
+            return fail(e, SCL_ERR_INVALID_ARG, "too many full-DB passes in flight: collect first");
+    QueryBatch qb{};
+    int first = -1, nmax = 0;
+    for (int i = 0; i < nq; ++i) {
+        const int sl = (int)((e->next_slot + (unsigned)i) % scl_engine::kSlots);
+        int lo = los[i] < 0 ? 0 : los[i], hi = his[i] > e->n ? e->n : his[i];
+        const int n = hi - lo;
+        tickets[i] = sl;
+        e->slot_lo[sl] = lo;
+        e->slot_empty[sl] = n <= 0;
+        if (first < 0) first = sl;
+        if (n > 0) {
+            const int j = qb.nq++;
+            qb.slot[j] = queries[i]; qb.base[j] = lo; qb.n[j] = n; qb.out3[j] = e->h_out3 + (size_t)sl * 8;
+            nmax = n > nmax ? n : nmax;
+        }
+    }
+    if (qb.nq > 0) {
+        int rc = ensure_pairs(e, (size_t)nmax * qb.nq);
+        if (rc) return rc;
+        qb.pair_stride = (size_t)nmax;
+        FullTail tail{e->d_blk_part, e->d_done_counter, nullptr, e->d_topk_idx, e->d_topk_d2, k, e->cfg.knn_exclude_eps};
+        ProfScope ps(e, P_SC);
+        SCL_HIP(e, launch_sc_distance_batch(db_view(e), qb, e->SR, e->d_dist, e->d_shift, e->d_ring_d2, tail, e->num_cu, e->stream));
+        if (ps.active()) { for (int j = 0; j < qb.nq; ++j) e->prof.sc_distance_pairs += (uint64_t)qb.n[j]; }
+        e->last_pass_alt = false;
+    }
+    SCL_HIP(e, hipEventRecord(e->ev_done[first], e->stream));
+    for (int i = 0; i < nq; ++i) { e->slot_ev[tickets[i]] = first; e->slot_busy[tickets[i]] = true; }
+    e->next_slot += (unsigned)nq;
     return SCL_OK;
 }
 
@@ -808,7 +909,7 @@ int collect_full_locked(scl_engine *e, int ticket, int *nn_idx, int *shift, doub
 {
     if (ticket < 0 || ticket >= scl_engine::kSlots || !e->slot_busy[ticket])
         return fail(e, SCL_ERR_INVALID_ARG, "unknown ticket");
-    SCL_HIP(e, hipEventSynchronize(e->ev_done[ticket]));
+    SCL_HIP(e, hipEventSynchronize(e->ev_done[e->slot_ev[ticket]]));
     collect_profile(e);
     e->slot_busy[ticket] = false;
     *nn_idx = -1; *shift = 0; *dist = kBigDist;
@@ -828,6 +929,19 @@ int scl_detect_full_submit(scl_engine *e, int query, int lo, int hi, int *ticket
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     return submit_full_locked(e, query, lo, hi, ticket);
+}
+
+int scl_detect_full_submit_many(scl_engine *e, const int *queries, const int *lo, const int *hi, int n_queries, int *tickets)
+{
+    if (!e || !queries || !lo || !hi || !tickets || n_queries < 1 || n_queries > scl_engine::kSlots) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    for (int i = 0; i < n_queries; i += kMaxQueryBatch) {
+        const int m = n_queries - i < kMaxQueryBatch ? n_queries - i : kMaxQueryBatch;
+        int rc = submit_full_many_locked(e, queries + i, lo + i, hi + i, m, tickets + i);
+        if (rc) return rc;
+    }
+    return SCL_OK;
 }
 
 int scl_detect_full_collect(scl_engine *e, int ticket, int *nn_idx, int *shift, double *dist)
@@ -855,6 +969,12 @@ int scl_get_last_topk(scl_engine *e, int k, int *idx, float *d2)
     if (!e || !idx || !d2 || k < 1 || k > kTopkMaxK) return SCL_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
+    if (e->last_pass_alt) {                                // the most recent pass ran on the alt lane
+        SCL_HIP(e, hipMemcpyAsync(idx, e->a_topk_idx, sizeof(int) * k, hipMemcpyDeviceToHost, e->stream_alt));
+        SCL_HIP(e, hipMemcpyAsync(d2, e->a_topk_d2, sizeof(float) * k, hipMemcpyDeviceToHost, e->stream_alt));
+        SCL_HIP(e, hipStreamSynchronize(e->stream_alt));
+        return SCL_OK;
+    }
     SCL_HIP(e, hipMemcpyAsync(idx, e->d_topk_idx, sizeof(int) * k, hipMemcpyDeviceToHost, e->stream));
     SCL_HIP(e, hipMemcpyAsync(d2, e->d_topk_d2, sizeof(float) * k, hipMemcpyDeviceToHost, e->stream));
     return sync(e);
@@ -1211,7 +1331,8 @@ int scl_profile_enable(scl_engine *e, int on)
 {
     if (!e) return SCL_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(e->mu);
-    e->prof_on = on < 0 ? 0 : (on > 2 ? 1 : on);
+    e->prof_on = on < 0 ? 0 : (on > 3 ? 1 : on);
+    e->prof_tick = 0;
     return SCL_OK;
 }
 

@@ -41,10 +41,25 @@ struct QueryView {          // one descriptor in the same layout (a DB slot or t
 // blk_part: kTailRec u64 per workgroup (>= 1024 workgroups); done_counter: one zeroed u32.
 constexpr int kTailTop = 4;                 // ring-key candidates the fused epilogue can track (k <= kTailTop)
 constexpr int kTailRec = 2 + kTailTop;
+constexpr int kTailBlocks = 1024;           // workgroup records per blk_part set
+constexpr int kTailTopMaxK = 64;            // entries per topk_idx / topk_d2 set (= kTopkMaxK)
 struct FullTail {
     unsigned long long *blk_part; unsigned int *done_counter; double *out3; int *topk_idx; float *topk_d2;
     int k; float exclude_eps;
 };
+// Several database-resident queries scored by ONE launch of the fused kernel (full-DB mode): query i is
+// slot[i], scored against slots base[i] .. base[i]+n[i]-1, its winner written to out3[i] (3 doubles).
+// Per-query scratch is the single-query scratch repeated: out_dist / out_shift / out_ring_d2 with stride
+// pair_stride, blk_part with stride kTailBlocks*kTailRec, done_counter +1, topk_idx / topk_d2 +kTailTopMaxK.
+constexpr int kMaxQueryBatch = 4;
+struct QueryBatch {
+    int nq;
+    int slot[kMaxQueryBatch], base[kMaxQueryBatch], n[kMaxQueryBatch];
+    double *out3[kMaxQueryBatch];
+    size_t pair_stride;
+};
+hipError_t launch_sc_distance_batch(const struct DbView &db, const QueryBatch &qb, int SR, double *out_dist, int *out_shift,
+                                    float *out_ring_d2, const FullTail &tail, int num_cu, hipStream_t stream);
 // out_ring_d2 (optional): also write the squared ring-key distance (nanoflann metric) of every scored
 // slot; *ring_fused tells whether the selected kernel supports it (the two-sectors-per-lane grids do).
 hipError_t launch_sc_distance(const DbView &db, const QueryView &q, const int *cand, int slot_base,
@@ -65,6 +80,7 @@ hipError_t launch_full_epilogue(const double *dist, const int *shift, const floa
 // scratch must hold kTopkMaxBlocks * kTopkMaxK uint64.
 constexpr int kTopkMaxBlocks = 256;
 constexpr int kTopkMaxK = 64;
+static_assert(kTopkMaxK == kTailTopMaxK, "top-k sets share one size");
 hipError_t launch_ringkey_topk(const DbView &db, const float *qkey, int lo, int hi, int k,
                                float exclude_eps, unsigned long long *scratch,
                                int *out_idx, float *out_d2, hipStream_t stream);

@@ -59,6 +59,14 @@ struct ScArgs {
     int ablate;   // diagnostic only (SCL_ABLATE): bit0 skip alignment loop, bit1 skip ring dots, bit2 skip sector sums
 };
 
+// Kernel argument of the wave kernel: up to kMaxQueryBatch complete argument sets, one per query of the launch.
+// Workgroups [qi*nb, (qi+1)*nb) serve query qi and read q[qi] straight from the kernel-argument segment (scalar,
+// invariant loads the compiler re-issues on demand -- nothing per-query has to stay live in registers).
+struct ScBatchArgs {
+    ScArgs q[kMaxQueryBatch];
+    int nq, nb;
+};
+
 __device__ __forceinline__ int wrap(int x, int S)
 {   // x in (-S, 2S)
     x = x < 0 ? x + S : x;
@@ -279,8 +287,12 @@ __device__ __forceinline__ void pin1(double &a)
 }
 
 template <int RG, int W, int CH, int S, int MAXT, bool STAMP>
-__global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
+__global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScBatchArgs ab)
 {
+    const int nbk = ab.nb;                             // workgroups per query
+    const int qi = ab.nq > 1 ? (int)blockIdx.x / nbk : 0;
+    const int bid = (int)blockIdx.x - qi * nbk;        // workgroup index within its query
+    const ScArgs &a = ab.q[qi];
     unsigned long long st_t = 0, st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_real0 = 0, st_cyc0 = 0;
     auto stamp = [&]() -> unsigned long long {
         if (!STAMP) { __builtin_amdgcn_sched_barrier(0); return 0ull; }   // phase boundaries stay scheduling fences
@@ -337,8 +349,8 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
     // counter.  The two waves that share a SIMD are not served equally (the older one wins the
     // VALU arbitration), so a static split leaves waves 4-7 ~25 % behind; first come, first served
     // evens it out.
-    const int c_lo = (int)(((long long)blockIdx.x * a.n) / gridDim.x);
-    const int c_hi = (int)(((long long)(blockIdx.x + 1) * a.n) / gridDim.x);
+    const int c_lo = (int)(((long long)bid * a.n) / nbk);
+    const int c_hi = (int)(((long long)(bid + 1) * a.n) / nbk);
     if (threadIdx.x == 0) *next_ticket = c_lo + nwaves;
     __syncthreads();                           // the only workgroup barrier
 
@@ -735,7 +747,7 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
         const unsigned long long m1 = wave_min_u64(b0 == m0 ? b1 : ~0ull);    // then the lowest position
         unsigned long long key = kNone;
         if (lane < nwaves * KT) key = base[(size_t)(lane / KT) * wsz + 2 + (lane % KT)];
-        unsigned long long *bp = a.blk_part + (size_t)blockIdx.x * REC;
+        unsigned long long *bp = a.blk_part + (size_t)bid * REC;
         unsigned long long prev = 0ull;
         bool first = true;
 #pragma unroll
@@ -753,7 +765,7 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
         }
     }
     __syncthreads();
-    if (*s_ticket != gridDim.x - 1) return;
+    if (*s_ticket != (unsigned)nbk - 1) return;
     if (wave != 0) return;
     __threadfence();                                   // acquire: partials of the other workgroups
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -765,7 +777,7 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int b = lane + u * kWave;
-            if (b < (int)gridDim.x) {
+            if (b < nbk) {
                 const unsigned long long *bp = a.blk_part + (size_t)b * REC;
                 const unsigned long long r0 = __builtin_nontemporal_load(bp), r1 = __builtin_nontemporal_load(bp + 1);
                 if (r0 < best || (r0 == best && (r1 >> 32) < (tag >> 32))) { best = r0; tag = r1; }
@@ -806,9 +818,11 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScArgs a)
 }
 
 template <int RG, int W, int CH, int S, int MAXT = 512, bool STAMP = false>
-hipError_t launch_wave(const ScArgs &args_in, int num_cu, hipStream_t stream)
+hipError_t launch_wave(const ScBatchArgs &batch_in, int num_cu, hipStream_t stream)
 {
-    ScArgs a = args_in;
+    ScBatchArgs ab = batch_in;
+    ScArgs &a = ab.q[0];                                   // sizes the launch (batch: the largest n, set by the caller)
+    const int n_launch = ab.nq > 1 ? ab.nb : a.n;          // caller passes max n in nb for a batch
     constexpr int QS = S + W + 1;
     constexpr int HSH = (W + 1) / 2;
     const size_t fixed = (size_t)(RG * 4 * QS + QS + S) * sizeof(double);
@@ -819,9 +833,11 @@ hipError_t launch_wave(const ScArgs &args_in, int num_cu, hipStream_t stream)
     static const int wave_cap = [] { const char *e = getenv("SCL_SC_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1 << 20; }();
     if (waves > wave_cap) waves = wave_cap;               // diagnostic: fewer waves per CU
     if (waves < 1) return hipErrorInvalidValue;
-    while (waves > 1 && a.n < num_cu * waves) waves = (waves + 1) / 2;
-    int blocks = (a.n + waves - 1) / waves;
+    while (waves > 1 && n_launch < num_cu * waves) waves = (waves + 1) / 2;
+    int blocks = (n_launch + waves - 1) / waves;
     if (blocks > num_cu) blocks = num_cu;
+    const int grid = blocks * ab.nq;                       // workgroups [qi*blocks, (qi+1)*blocks) serve query qi
+    ab.nb = blocks;
     const size_t lds = fixed + per_wave * waves + 16;      // + the candidate dispenser
     static bool attr_set_dev[64] = {false};   // per instantiation and per device
     int dev_ = 0; (void)hipGetDevice(&dev_);
@@ -839,7 +855,7 @@ hipError_t launch_wave(const ScArgs &args_in, int num_cu, hipStream_t stream)
         if (hipMalloc(&d, nw * 8 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(d, 0, nw * 8 * sizeof(unsigned long long), stream);
         a.stamps = d;
-        hipLaunchKernelGGL((sc_distance_wave_kernel<RG, W, CH, S, MAXT, STAMP>), dim3(blocks), dim3(waves * kWave), lds, stream, a);
+        hipLaunchKernelGGL((sc_distance_wave_kernel<RG, W, CH, S, MAXT, STAMP>), dim3(grid), dim3(waves * kWave), lds, stream, ab);
         (void)hipStreamSynchronize(stream);
         std::vector<unsigned long long> h(nw * 8);
         (void)hipMemcpy(h.data(), d, nw * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
@@ -888,7 +904,7 @@ hipError_t launch_wave(const ScArgs &args_in, int num_cu, hipStream_t stream)
         }
         return hipGetLastError();
     }
-    hipLaunchKernelGGL((sc_distance_wave_kernel<RG, W, CH, S, MAXT, STAMP>), dim3(blocks), dim3(waves * kWave), lds, stream, a);
+    hipLaunchKernelGGL((sc_distance_wave_kernel<RG, W, CH, S, MAXT, STAMP>), dim3(grid), dim3(waves * kWave), lds, stream, ab);
     return hipGetLastError();
 }
 
@@ -1056,13 +1072,15 @@ hipError_t launch_sc_distance(const DbView &db, const QueryView &q, const int *c
             a.topk_idx = tail->topk_idx; a.topk_d2 = tail->topk_d2; a.topk_k = tail->k; a.exclude_eps = tail->exclude_eps;
         }
     }
-    if (wave_ok && db.RG == 5 && W == 7 && db.S == 60)   return launch_wave<5, 7, 5, 60>(a, num_cu, stream);
+    ScBatchArgs one{};
+    one.q[0] = a; one.nq = 1; one.nb = 0;
+    if (wave_ok && db.RG == 5 && W == 7 && db.S == 60)   return launch_wave<5, 7, 5, 60>(one, num_cu, stream);
     static const bool stamp = [] { const char *e = getenv("SCL_STAMP"); return e && e[0] == '1'; }();
     static const int occ = [] { const char *e = getenv("SCL_SC_WAVES"); return e ? atoi(e) : 8; }();
-    if (wave_ok && db.RG == 16 && W == 13 && db.S == 120 && stamp && occ > 8) return launch_wave<16, 13, 2, 120, 768, true>(a, num_cu, stream);
-    if (wave_ok && db.RG == 16 && W == 13 && db.S == 120 && stamp) return launch_wave<16, 13, 4, 120, 512, true>(a, num_cu, stream);
-    if (wave_ok && db.RG == 16 && W == 13 && db.S == 120 && occ > 8) return launch_wave<16, 13, 2, 120, 768>(a, num_cu, stream);
-    if (wave_ok && db.RG == 16 && W == 13 && db.S == 120) return launch_wave<16, 13, 4, 120, 512>(a, num_cu, stream);
+    if (wave_ok && db.RG == 16 && W == 13 && db.S == 120 && stamp && occ > 8) return launch_wave<16, 13, 2, 120, 768, true>(one, num_cu, stream);
+    if (wave_ok && db.RG == 16 && W == 13 && db.S == 120 && stamp) return launch_wave<16, 13, 4, 120, 512, true>(one, num_cu, stream);
+    if (wave_ok && db.RG == 16 && W == 13 && db.S == 120 && occ > 8) return launch_wave<16, 13, 2, 120, 768>(one, num_cu, stream);
+    if (wave_ok && db.RG == 16 && W == 13 && db.S == 120) return launch_wave<16, 13, 4, 120, 512>(one, num_cu, stream);
     if (db.RG == 5 && W == 7 && db.S >= W)   return launch_fast<5, 7, 512>(a, num_cu, stream);
     if (db.RG == 16 && W == 13 && db.S >= W) return launch_fast<16, 13, 512>(a, num_cu, stream);
     if (db.RG == 20 && W == 19 && db.S >= W && db.S <= 180) return launch_fast<20, 19, 256>(a, num_cu, stream);
@@ -1070,6 +1088,40 @@ hipError_t launch_sc_distance(const DbView &db, const QueryView &q, const int *c
     const size_t lds = (size_t)6 * db.S * sizeof(double);
     hipLaunchKernelGGL(sc_distance_generic_kernel, dim3(n), dim3(256), lds, stream, a, db.RG, db.R);
     return hipGetLastError();
+}
+
+hipError_t launch_sc_distance_batch(const DbView &db, const QueryBatch &qb, int SR, double *out_dist, int *out_shift,
+                                    float *out_ring_d2, const FullTail &tail, int num_cu, hipStream_t stream)
+{
+    if (qb.nq < 1 || qb.nq > kMaxQueryBatch || !out_ring_d2 || tail.k > kTailTop || !sc_distance_fuses_ring(db, SR))
+        return hipErrorInvalidValue;
+    ScBatchArgs ab{};
+    ab.nq = qb.nq;
+    int nmax = 0;
+    for (int i = 0; i < qb.nq; ++i) {
+        if (qb.n[i] <= 0) return hipErrorInvalidValue;                 // empty ranges are the caller's business
+        ScArgs &a = ab.q[i];
+        const size_t slot = (size_t)qb.slot[i];
+        a.desc = db.desc; a.vkey = db.vkey; a.norm = db.norm;
+        a.q_desc = db.desc + slot * (size_t)(db.RG * db.S); a.q_vkey = db.vkey + slot * db.S;
+        a.q_norm = db.norm + slot * db.S; a.q_rkey = db.rkey + slot * (size_t)(4 * db.RG);
+        a.cand = nullptr; a.slot_base = qb.base[i]; a.n = qb.n[i]; a.S = db.S; a.SR = SR;
+        a.NW = (db.S + kWave - 1) / kWave; a.G = 1;
+        a.ablate = 0; a.stamps = nullptr;
+        a.rkey4 = db.rkey4; a.rk_cap = db.cap;
+        a.out_dist = out_dist + (size_t)i * qb.pair_stride; a.out_shift = out_shift + (size_t)i * qb.pair_stride;
+        a.out_d2 = out_ring_d2 + (size_t)i * qb.pair_stride;
+        a.blk_part = tail.blk_part + (size_t)i * kTailBlocks * kTailRec; a.done_counter = tail.done_counter + i;
+        a.out3 = qb.out3[i];
+        a.topk_idx = tail.topk_idx + i * kTailTopMaxK; a.topk_d2 = tail.topk_d2 + i * kTailTopMaxK;
+        a.topk_k = tail.k; a.exclude_eps = tail.exclude_eps;
+        nmax = qb.n[i] > nmax ? qb.n[i] : nmax;
+    }
+    for (int i = qb.nq; i < kMaxQueryBatch; ++i) ab.q[i] = ab.q[0];
+    ab.nb = nmax;                                                      // launch_wave sizes the grid from it
+    const int W = 2 * SR + 1;
+    if (db.RG == 5 && W == 7 && db.S == 60) return launch_wave<5, 7, 5, 60>(ab, num_cu, stream);
+    return launch_wave<16, 13, 4, 120, 512>(ab, num_cu, stream);
 }
 
 bool sc_distance_fuses_ring(const DbView &db, int SR)

@@ -88,6 +88,7 @@ def _bind(lib):
         "scl_get_last_topk": (c_int, [P, c_int, ip, fp]),
         "scl_detect_full_submit": (c_int, [P, c_int, c_int, c_int, ip]),
         "scl_detect_full_collect": (c_int, [P, c_int, ip, ip, dp]),
+        "scl_detect_full_submit_many": (c_int, [P, ip, ip, ip, c_int, ip]),
         "scl_topk_with_distance": (c_int, [P, c_int, c_int, c_int, c_int, ip, fp, dp, ip, ip]),
         "scl_icp_default_params": (c_int, [POINTER(IcpParams)]),
         "scl_icp_align": (c_int, [P, P, c_int, P, c_int, c_int, POINTER(IcpParams), fp, fp, ip, ip]),
@@ -288,6 +289,17 @@ class ScanContextEngine:
         t = c_int()
         self._check(self._lib.scl_detect_full_submit(self._h, query, lo, hi, byref(t)), "scl_detect_full_submit")
         return t.value
+
+    def detect_full_submit_many(self, queries, lo, hi):
+        """several database keyframes as queries, up to four per launch; returns one ticket per query"""
+        q = np.ascontiguousarray(queries, dtype=np.int32)
+        m = q.shape[0]
+        lo_ = np.ascontiguousarray(np.broadcast_to(np.asarray(lo, dtype=np.int32), (m,)))
+        hi_ = np.ascontiguousarray(np.broadcast_to(np.asarray(hi, dtype=np.int32), (m,)))
+        t = np.zeros(m, dtype=np.int32)
+        self._check(self._lib.scl_detect_full_submit_many(self._h, _ptr(q, c_int), _ptr(lo_, c_int), _ptr(hi_, c_int), m, _ptr(t, c_int)),
+                    "scl_detect_full_submit_many")
+        return [int(x) for x in t]
 
     def detect_full_collect(self, ticket):
         nn, sh, d = c_int(), c_int(), c_double()

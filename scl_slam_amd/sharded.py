@@ -122,14 +122,35 @@ class FullScanStream:
     order, identical on every rank.
     """
 
-    def __init__(self, engine, rank=0, world=1, group=None, device="cpu", depth=2, merge_every=16):
+    def __init__(self, engine, rank=0, world=1, group=None, device="cpu", depth=2, merge_every=16, scans_per_launch=1):
         self.engine, self.rank, self.world, self.group, self.device = engine, rank, world, group, device
         self.depth, self.merge_every = max(1, depth), max(1, merge_every)
+        self.per_launch = max(1, scans_per_launch)          # database-resident queries sharing one kernel launch
         self.inflight, self.batch, self.pending, self.results = [], [], None, []
+        self.held = []
 
     def submit(self, query, lo, hi):
+        if self.per_launch > 1 and query >= 0:
+            self.held.append((query, lo, hi))
+            if len(self.held) >= self.per_launch:
+                self._launch_held()
+            return
+        self._launch_held()
+        self._make_room(1)
         self.inflight.append(self.engine.detect_full_submit(query, lo, hi))
-        if len(self.inflight) >= self.depth:
+
+    def _launch_held(self):
+        if not self.held:
+            return
+        q, lo, hi = zip(*self.held)
+        self.held = []
+        self._make_room(len(q))
+        self.inflight.extend(self.engine.detect_full_submit_many(q, lo, hi))
+
+    def _make_room(self, incoming):
+        # at most `depth` launches in flight, the new one included (the engine has 8 result slots)
+        limit = min(self.depth * self.per_launch, 8)
+        while self.inflight and len(self.inflight) + incoming > limit:
             self._collect_one()
 
     def _collect_one(self):
@@ -173,6 +194,7 @@ class FullScanStream:
             self.results.append((float(b[0]), int(b[1]), int(b[2])))
 
     def drain(self):
+        self._launch_held()
         while self.inflight:
             self._collect_one()
         self._exchange()
