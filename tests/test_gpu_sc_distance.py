@@ -88,6 +88,33 @@ def test_zero_and_nan_rules():
     eng.close()
 
 
+@pytest.mark.parametrize("R,S", [(20, 60), (64, 120)])
+def test_extreme_and_non_finite_values(R, S):
+    """The wave kernel divides with the scaling-free quotient when every column norm is finite and falls back
+    to the general division otherwise; both must return the checker's bits.  Values at the ends of the float
+    range (products near 2^-298 and 2^256), sign changes with exact cancellation, Inf and NaN cells."""
+    descs = synth_descriptors(12, R, S, seed=19)
+    tiny, huge = np.float32(1e-45), np.float32(3.0e38)            # smallest denormal, just below FLT_MAX
+    descs[1] *= np.float32(1e-30)                                  # norms ~1e-29, dots ~1e-58
+    descs[2][:, :] = tiny                                          # every product = 2^-298
+    descs[3] *= np.float32(1e30)
+    descs[4][:, 5] = huge; descs[4][:, 6] = -huge                  # norm overflows to Inf in fp64? no: 64 * 9e76 is finite
+    descs[5][3, 7] = np.inf                                        # one Inf cell -> that column's norm is Inf
+    descs[6][2, 9] = np.nan
+    descs[7][:, ::3] *= -1.0                                       # negative heights: dots may cancel to exactly 0
+    descs[8][:, :] = 0.0; descs[8][0, 0] = tiny                    # one non-empty column with a denormal
+    descs[9] = -descs[0]
+    eng = ScanContextEngine(num_ring=R, num_sector=S)
+    eng.save_bulk(descs)
+    db = ob.OracleDB(ob.make_config(R=R, S=S)); db.save_bulk(descs)
+    with np.errstate(all="ignore"):
+        for q in range(12):
+            d_gpu, s_gpu = eng.sc_distance_batch(q, n=12)
+            d_cpu, s_cpu = db.distance_batch(q, n=12, fast=True)
+            assert_same(d_gpu, s_gpu, d_cpu, s_cpu)
+    eng.close()
+
+
 def test_staged_query_equals_stored_query():
     R, S, n = 64, 120, 50
     descs, eng, db = build(R, S, n, seed=31)
