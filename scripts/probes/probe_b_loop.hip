@@ -4,6 +4,7 @@
 // function of how far ahead the window is requested?  s_memtime (core clock).
 //   MODE 0: fmas only (window loaded once)         MODE 1: window of ring r+1 requested before ring r's fmas
 //   MODE 2: window of ring r+2 requested (2 ahead) MODE 3: as 1, window as 14 x ds_read_b64
+//   MODE 4: as 1, but the 7 reads interleaved with the fmas (sched_group_barrier: 4 VALU, 1 DS read, ...)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(768) void b_loop(double *out, unsigned long long *c
             for (int v = 0; v < NQ; ++v) { q[2 * v] = qn[v].x; q[2 * v + 1] = qn[v].y; }
             pin_ring(acc0, acc1);
             qp += QS / 2;
-            if (MODE == 1) {
+            if (MODE == 1 || MODE == 4) {
 #pragma unroll
                 for (int v = 0; v < NQ; ++v) qn[v] = qp[v];
             }
@@ -68,6 +69,13 @@ __global__ __launch_bounds__(768) void b_loop(double *out, unsigned long long *c
             for (int t = 0; t < W; ++t) {
                 acc0[t] = fma(kd0, q[t], acc0[t]);
                 acc1[t] = fma(kd1, q[t + 1], acc1[t]);
+            }
+            if (MODE == 4) {
+#pragma unroll
+                for (int v = 0; v < NQ; ++v) {
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // 4 VALU
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                }
             }
         }
     }
@@ -104,6 +112,7 @@ int main()
         run<1>("window one ring ahead, 7 x ds_read_b128", threads);
         run<2>("window two rings ahead, 7 x ds_read_b128", threads);
         run<3>("window one ring ahead, 14 x ds_read_b64", threads);
+        run<4>("one ring ahead, reads interleaved 4 fma : 1 read", threads);
     }
     return 0;
 }
