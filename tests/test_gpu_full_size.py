@@ -1,0 +1,70 @@
+"""BASELINE configs[1] at full size (10 k keyframes, 64x120) on the GPU: size-independent properties plus
+spot checks against the CPU checker (the checker needs ~0.15 ms per pair, so it scores a sample only)."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from scl_slam_amd import ScanContextEngine
+from scl_slam_amd.synth import synth_descriptors
+
+pytestmark = pytest.mark.gpu
+R, S, N = 64, 120, 10000
+
+
+@pytest.fixture(scope="module")
+def world():
+    descs = synth_descriptors(N, R, S, seed=2024)
+    rs = np.random.RandomState(3)
+    planted = {}
+    for q in range(N - 40, N, 4):                                   # queries that revisit an old place, rotated
+        j, sh = int(rs.randint(0, N - 200)), int(rs.randint(0, S))
+        descs[q] = np.roll(descs[j], sh, axis=1)
+        planted[q] = (j, sh)
+    e = ScanContextEngine(num_ring=R, num_sector=S, num_candidates=3, num_exclude_recent=100, initial_capacity=N + 8)
+    e.save_bulk(descs)
+    yield e, descs, planted
+    e.close()
+
+
+def test_planted_revisits_are_found_with_their_rotation(world):
+    e, descs, planted = world
+    for q, (j, sh) in planted.items():
+        nn, shift, d = e.detect_full_range(q, 0, N - 100)
+        assert nn == j and shift == sh and d < 1e-12
+
+
+def test_fused_pass_equals_per_pair_path_and_checker(world):
+    e, descs, planted = world
+    cfg = ob.make_config(R=R, S=S)
+    rs = np.random.RandomState(5)
+    for q in (N - 1, N - 2, N - 40):
+        hi = N - 100
+        nn, shift, d = e.detect_full_range(q, 0, hi)               # one fused launch: arg-min inside the kernel
+        dist, sh = e.sc_distance_batch(q, n=hi)                    # per-pair outputs of the same kernel
+        j = int(np.argmin(dist))                                   # first minimum = lowest index on ties
+        assert (nn, shift) == (j, int(sh[j])) and np.float64(d).view(np.uint64) == dist[j:j + 1].view(np.uint64)[0]
+        assert np.all(np.isfinite(dist)) and dist.min() >= 0.0 and dist.max() <= 2.0
+        for c in [j] + [int(x) for x in rs.randint(0, hi, 24)]:     # checker on the winner and a random sample
+            dc, sc = ob.distance(cfg, descs[q], descs[c], fast=True)
+            assert sc == sh[c] and np.float64(dc).view(np.uint64) == dist[c:c + 1].view(np.uint64)[0]
+
+
+def test_batched_launch_equals_single_launches(world):
+    e, _, _ = world
+    qs = [N - 1, N - 2, N - 3, N - 40]
+    single = [e.detect_full_range(q, 0, N - 100) for q in qs]
+    tickets = e.detect_full_submit_many(qs, 0, N - 100)
+    assert [e.detect_full_collect(t) for t in tickets] == single
+
+
+def test_ring_shift_of_the_query_shifts_the_answer(world):
+    """circshift(query, s) against an unrotated database: the candidate must turn s sectors further (D.h:1559 shifts
+    the candidate), so the best ring shift moves by +s (mod S); same distance"""
+    e, descs, _ = world
+    q = descs[N - 7]
+    e.stage_query(q)
+    nn0, sh0, d0 = e.detect_full_range(-1, 0, N - 100)
+    for s in (1, 17, 60, 119):
+        e.stage_query(np.roll(q, s, axis=1))
+        nn, sh, d = e.detect_full_range(-1, 0, N - 100)
+        assert nn == nn0 and sh == (sh0 + s) % S and abs(d - d0) < 1e-12
