@@ -87,6 +87,70 @@ __global__ __launch_bounds__(768) void b_loop(double *out, unsigned long long *c
     if (lane == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
 }
 
+// fp32 variant of the same loop: 14-float window (3 x ds_read_b128 + 1 x ds_read_b64), packed fp32 fmas
+typedef float f2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(768) void b_loop_f32(float *out, unsigned long long *cyc, int reps, const float *kin)
+{
+    extern __shared__ __attribute__((aligned(16))) float Qf[];
+    constexpr int QSF = 136;                           // floats per row (16-byte aligned rows)
+    for (int i = threadIdx.x; i < (ROWS + 2) * QSF; i += blockDim.x) Qf[i] = 1.0f + 1e-3f * (i % 97);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int ll = lane < 60 ? lane : 59;
+    const float *qwin = Qf + 4 * (ll >> 1);            // 16-byte aligned (the kernel would keep a second, 2-float-shifted copy for odd lanes)
+    f2 acc0[7], acc1[7];                               // shifts (0,1) (2,3) ... (12,13): 14 slots, 13 used
+#pragma unroll
+    for (int t = 0; t < 7; ++t) { acc0[t] = f2{0.f, 0.f}; acc1[t] = f2{0.f, 0.f}; }
+    float kf0 = kin[threadIdx.x], kf1 = kin[threadIdx.x + 768];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int rep = 0; rep < reps; ++rep) {
+        const float *qp = qwin;
+        f2 qn[8];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { const float4 w = *reinterpret_cast<const float4 *>(qp + 4 * v); qn[2 * v] = f2{w.x, w.y}; qn[2 * v + 1] = f2{w.z, w.w}; }
+#pragma unroll 4
+        for (int r = 0; r < ROWS; ++r) {
+            f2 q[8];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) q[v] = qn[v];
+            asm volatile("" ::: "memory");
+            qp += QSF;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { const float4 w = *reinterpret_cast<const float4 *>(qp + 4 * v); qn[2 * v] = f2{w.x, w.y}; qn[2 * v + 1] = f2{w.z, w.w}; }
+            const f2 k0 = f2{kf0, kf0}, k1 = f2{kf1, kf1};
+            kf0 += 1.0f; kf1 += 0.5f;
+#pragma unroll
+            for (int t = 0; t < 7; ++t) {
+                acc0[t] = __builtin_elementwise_fma(k0, q[t], acc0[t]);                       // column 0: q[t] = (w[2t], w[2t+1])
+                const f2 qs = f2{q[t].y, q[t + 1].x};                                        // column 1 sees the window one later
+                acc1[t] = __builtin_elementwise_fma(k1, qs, acc1[t]);
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0;
+#pragma unroll
+    for (int t = 0; t < 7; ++t) s += acc0[t].x + acc0[t].y + acc1[t].x + acc1[t].y;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (lane == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
+void run_f32(int threads)
+{
+    float *out; unsigned long long *cyc; float *kin;
+    (void)hipMalloc(&out, 4 * 768 * 256); (void)hipMalloc(&cyc, 8 * 12 * 256); (void)hipMalloc(&kin, 4 * 2048);
+    (void)hipMemset(kin, 0, 4 * 2048);
+    const int reps = 40;
+    (void)hipFuncSetAttribute((const void *)b_loop_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(b_loop_f32, dim3(256), dim3(threads), 100 * 1024, 0, out, cyc, reps, kin);
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> h(256 * threads / 64);
+    (void)hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
+    double m = 0; for (auto x : h) m += (double)x; m /= h.size();
+    printf("%-44s waves/CU %d : %7.1f cycles per ring per wave\n", "fp32: packed fmas, 16-float window", threads / 64, m / reps / ROWS);
+    (void)hipFree(out); (void)hipFree(cyc); (void)hipFree(kin);
+}
+
 template <int MODE>
 void run(const char *name, int threads)
 {
@@ -113,6 +177,7 @@ int main()
         run<2>("window two rings ahead, 7 x ds_read_b128", threads);
         run<3>("window one ring ahead, 14 x ds_read_b64", threads);
         run<4>("one ring ahead, reads interleaved 4 fma : 1 read", threads);
+        run_f32(threads);
     }
     return 0;
 }
