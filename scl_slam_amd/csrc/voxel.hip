@@ -6,10 +6,10 @@
 //
 // Algorithm (PCL's, restated in oracle/icp_oracle.c): voxel coordinates floor(p * 1/leaf) - min_b in fp32,
 // linear index with x fastest, one output point per occupied voxel = centroid of x, y, z, intensity, output
-// in ascending voxel index.  GPU form: 64-bit keys (voxel index << 32 | point index) sorted with rocPRIM's
-// radix sort (through hipCUB), run heads flagged and scanned, then ONE thread per voxel adds its points in
-// key order -- i.e. ascending input order, the same fp32 sums as the serial restatement, bit for bit.
-// HBM-bound: n * (stride + 2 * 8) bytes; the sort dominates.
+// in ascending voxel index.  GPU form: (voxel index, point index) pairs sorted by the 32-bit voxel index with
+// rocPRIM's radix sort (through hipCUB; LSD radix sort is stable, so the points of a voxel stay in input
+// order), run heads flagged and scanned, then ONE thread per voxel adds its points in that order -- the same
+// fp32 sums as the serial restatement, bit for bit.  HBM-bound: n * (stride + 4 * 4) bytes; the sort dominates.
 #include <hipcub/hipcub.hpp>
 
 #include <cfloat>
@@ -67,15 +67,23 @@ __global__ void vox_bbox_partial_kernel(const unsigned char *pts, int n, int str
     }
 }
 
-__global__ void vox_setup_kernel(const float *part, const int *cnt, int nblocks, float inv, VoxState *st)
+__global__ __launch_bounds__(64) void vox_setup_kernel(const float *part, const int *cnt, int nblocks, float inv, VoxState *st)
 {
-    if (threadIdx.x != 0) return;
+    // one wave: lane l folds the partial boxes l, l+64, ..., then a butterfly (min / max / integer sum: order independent)
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     int tot = 0;
-    for (int b = 0; b < nblocks; ++b) {
+    for (int b = threadIdx.x; b < nblocks; b += 64) {
         tot += cnt[b];
+#pragma unroll
         for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], part[b * 6 + a]); mx[a] = fmaxf(mx[a], part[b * 6 + 3 + a]); }
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        tot += __shfl_xor(tot, off, kWave);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, kWave)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, kWave)); }
+    }
+    if (threadIdx.x != 0) return;
     st->nfinite = tot; st->overflow = 0; st->nout = 0;
     for (int a = 0; a < 3; ++a) {
         st->mn[a] = mn[a]; st->mx[a] = mx[a];
@@ -85,44 +93,45 @@ __global__ void vox_setup_kernel(const float *part, const int *cnt, int nblocks,
     if (st->divb[0] * st->divb[1] * st->divb[2] > 2147483647LL) st->overflow = 1;
 }
 
+constexpr unsigned kNoVoxel = 0xffffffffu;                             // non-finite points sort to the end
+
 __global__ void vox_keys_kernel(const unsigned char *pts, int n, int stride, float inv, const VoxState *st,
-                                unsigned long long *keys)
+                                unsigned *vox, unsigned *idx)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float *f = reinterpret_cast<const float *>(pts + (size_t)i * stride);
     const float x = f[0], y = f[1], z = f[2];
-    unsigned long long key = ~0ull;                                   // non-finite points sort to the end
+    unsigned key = kNoVoxel;
     if (finite3(x, y, z) && !st->overflow) {
         const long long i0 = (long long)floorf(x * inv) - st->minb[0];
         const long long i1 = (long long)floorf(y * inv) - st->minb[1];
         const long long i2 = (long long)floorf(z * inv) - st->minb[2];
-        const long long idx = i0 + i1 * st->divb[0] + i2 * st->divb[0] * st->divb[1];
-        key = ((unsigned long long)idx << 32) | (unsigned)i;
+        key = (unsigned)(i0 + i1 * st->divb[0] + i2 * st->divb[0] * st->divb[1]);   // < 2^31 (overflow is flagged)
     }
-    keys[i] = key;
+    vox[i] = key;
+    idx[i] = (unsigned)i;
 }
 
-__global__ void vox_heads_kernel(const unsigned long long *keys, int n, int *head)
+__global__ void vox_heads_kernel(const unsigned *vox, int n, int *head)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const unsigned long long k = keys[i];
-    const bool valid = k != ~0ull;
-    head[i] = (valid && (i == 0 || (keys[i - 1] >> 32) != (k >> 32))) ? 1 : 0;
+    const unsigned k = vox[i];
+    head[i] = (k != kNoVoxel && (i == 0 || vox[i - 1] != k)) ? 1 : 0;
 }
 
-__global__ void vox_centroid_kernel(const unsigned char *pts, int stride, const unsigned long long *keys, const int *head,
+__global__ void vox_centroid_kernel(const unsigned char *pts, int stride, const unsigned *vox, const unsigned *idx, const int *head,
                                     const int *pos /*exclusive scan of head*/, int n, unsigned char *out, VoxState *st)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !head[i]) return;
-    const unsigned long long vox = keys[i] >> 32;
+    const unsigned v = vox[i];
     float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
     const bool has_i = stride >= 20;
     int b = i;
-    while (b < n && (keys[b] >> 32) == vox && keys[b] != ~0ull) {
-        const float *f = reinterpret_cast<const float *>(pts + (size_t)(unsigned)(keys[b] & 0xffffffffull) * stride);
+    while (b < n && vox[b] == v) {
+        const float *f = reinterpret_cast<const float *>(pts + (size_t)idx[b] * stride);
         sx += f[0]; sy += f[1]; sz += f[2];
         if (has_i) si += f[4];
         ++b;
@@ -132,8 +141,7 @@ __global__ void vox_centroid_kernel(const unsigned char *pts, int stride, const 
     for (int k = 0; k < stride / 4; ++k) o[k] = 0.f;
     o[0] = sx / cnt; o[1] = sy / cnt; o[2] = sz / cnt;
     if (has_i) o[4] = si / cnt;
-    if (i == 0 || true) { /* the last head also publishes the output count */ }
-    if (b >= n || keys[b] == ~0ull) st->nout = pos[i] + 1;
+    if (b >= n || vox[b] == kNoVoxel) st->nout = pos[i] + 1;        // the last head also publishes the output count
 }
 
 __global__ void transform_append_kernel(const unsigned char *in, int n, int stride, const float *T, unsigned char *out)
@@ -182,8 +190,9 @@ int voxel_device(IcpWorkspace *ws, hipStream_t stream, int n, int stride, float 
     if ((rc = vensure(ws, V_STATE, sizeof(VoxState), err))) return rc;
     if ((rc = vensure(ws, V_PART, (sizeof(float) * 6 + sizeof(int)) * 256, err))) return rc;
     const unsigned char *in = static_cast<const unsigned char *>(ws->buf[V_IN]);
-    unsigned long long *keys = static_cast<unsigned long long *>(ws->buf[V_KEYS]);
-    unsigned long long *keys2 = static_cast<unsigned long long *>(ws->buf[V_KEYS2]);
+    // V_KEYS / V_KEYS2 hold (voxel, point) as two 32-bit arrays each: unsorted and sorted
+    unsigned *vox_in = static_cast<unsigned *>(ws->buf[V_KEYS]), *idx_in = vox_in + n;
+    unsigned *vox_out = static_cast<unsigned *>(ws->buf[V_KEYS2]), *idx_out = vox_out + n;
     VoxState *st = static_cast<VoxState *>(ws->buf[V_STATE]);
     float *part = static_cast<float *>(ws->buf[V_PART]);
     int *pcnt = reinterpret_cast<int *>(part + 6 * 256);
@@ -192,16 +201,16 @@ int voxel_device(IcpWorkspace *ws, hipStream_t stream, int n, int stride, float 
     const int pb = (n + 255) / 256;
     hipLaunchKernelGGL(vox_bbox_partial_kernel, dim3(nb), dim3(256), 0, stream, in, n, stride, part, pcnt);
     hipLaunchKernelGGL(vox_setup_kernel, dim3(1), dim3(64), 0, stream, part, pcnt, nb, inv, st);
-    hipLaunchKernelGGL(vox_keys_kernel, dim3(pb), dim3(256), 0, stream, in, n, stride, inv, st, keys);
+    hipLaunchKernelGGL(vox_keys_kernel, dim3(pb), dim3(256), 0, stream, in, n, stride, inv, st, vox_in, idx_in);
     size_t tmp_sort = 0, tmp_scan = 0;
-    VOX_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_sort, keys, keys2, n, 0, 64, stream));
+    VOX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, vox_in, vox_out, idx_in, idx_out, n, 0, 32, stream));
     VOX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, (int *)ws->buf[V_HEAD], (int *)ws->buf[V_POS], n, stream));
     const size_t tmp = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
     if ((rc = vensure(ws, V_TMP, tmp + 256, err))) return rc;
-    VOX_HIP(hipcub::DeviceRadixSort::SortKeys(ws->buf[V_TMP], tmp_sort, keys, keys2, n, 0, 64, stream));
-    hipLaunchKernelGGL(vox_heads_kernel, dim3(pb), dim3(256), 0, stream, keys2, n, (int *)ws->buf[V_HEAD]);
+    VOX_HIP(hipcub::DeviceRadixSort::SortPairs(ws->buf[V_TMP], tmp_sort, vox_in, vox_out, idx_in, idx_out, n, 0, 32, stream));
+    hipLaunchKernelGGL(vox_heads_kernel, dim3(pb), dim3(256), 0, stream, vox_out, n, (int *)ws->buf[V_HEAD]);
     VOX_HIP(hipcub::DeviceScan::ExclusiveSum(ws->buf[V_TMP], tmp_scan, (int *)ws->buf[V_HEAD], (int *)ws->buf[V_POS], n, stream));
-    hipLaunchKernelGGL(vox_centroid_kernel, dim3(pb), dim3(256), 0, stream, in, stride, keys2, (const int *)ws->buf[V_HEAD],
+    hipLaunchKernelGGL(vox_centroid_kernel, dim3(pb), dim3(256), 0, stream, in, stride, vox_out, idx_out, (const int *)ws->buf[V_HEAD],
                        (const int *)ws->buf[V_POS], n, (unsigned char *)ws->buf[V_OUT], st);
     VOX_HIP(hipGetLastError());
     if (!ws->pinned || ws->pinned_cap < sizeof(VoxState)) {
