@@ -122,8 +122,10 @@ class FullScanStream:
     order, identical on every rank.
     """
 
-    def __init__(self, engine, rank=0, world=1, group=None, device="cpu", depth=2, merge_every=16, scans_per_launch=1):
+    def __init__(self, engine, rank=0, world=1, group=None, device="cpu", depth=2, merge_every=16, scans_per_launch=1,
+                 always_exchange=False):
         self.engine, self.rank, self.world, self.group, self.device = engine, rank, world, group, device
+        self.always_exchange = always_exchange              # run the collective even for world == 1 (exercises the backend)
         self.depth, self.merge_every = max(1, depth), max(1, merge_every)
         self.per_launch = max(1, scans_per_launch)          # database-resident queries sharing one kernel launch
         self.inflight, self.batch, self.pending, self.results = [], [], None, []
@@ -164,7 +166,7 @@ class FullScanStream:
             return
         rec = np.array(self.batch, dtype=np.float64)
         self.batch = []
-        if self.world == 1:
+        if self.world == 1 and not self.always_exchange:
             self._merge(rec[None])
             return
         import torch
