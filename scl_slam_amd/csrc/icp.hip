@@ -219,6 +219,17 @@ __global__ __launch_bounds__(256) void nn_search_kernel(float4 *work, int n_src,
     const int dx = st->dim[0], dy = st->dim[1], dz = st->dim[2];
     const float h = st->h;
     const int maxdim = max(dx, max(dy, dz));
+    const float pv[3] = {p.x, p.y, p.z};
+    const int dm[3] = {dx, dy, dz};
+    float dout2[3], dout_sum = 0.f;                              // squared distance from p to the grid's box, per axis
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float below = st->mn[a] - pv[a], above = pv[a] - (st->mn[a] + (float)dm[a] * h);
+        float d = fmaxf(fmaxf(below, above), 0.f);
+        d = (d == d) ? d : 0.f;                                  // NaN coordinates: no help from this axis
+        dout2[a] = d * d;
+        dout_sum += dout2[a];
+    }
     float best = FLT_MAX;
     int bi = -1;
     for (int r = 0; r <= maxdim; ++r) {
@@ -248,18 +259,26 @@ __global__ __launch_bounds__(256) void nn_search_kernel(float4 *work, int n_src,
             }
         }
         group_min8(best, bi);
-        float bound = FLT_MAX;
+        // lower bound on the squared distance to anything not visited yet: such a point lies beyond an open face of
+        // the shell (distance f along that axis) and inside the grid's box (so at least dout[a] away along every axis
+        // on which p lies outside the box -- what ends the walk of a query far outside the target early)
+        float bound2 = FLT_MAX;
         bool open = false;
-        const float pv[3] = {p.x, p.y, p.z};
-        const int lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0, hi1, hi2}, dm[3] = {dx, dy, dz};
+        const int lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0, hi1, hi2};
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            if (lo[a] > 0) { float f = pv[a] - (st->mn[a] + (float)lo[a] * h); f = f < 0.f ? 0.f : f; bound = fminf(bound, f); open = true; }
-            if (hi[a] < dm[a] - 1) { float f = (st->mn[a] + (float)(hi[a] + 1) * h) - pv[a]; f = f < 0.f ? 0.f : f; bound = fminf(bound, f); open = true; }
+            const float others = dout_sum - dout2[a];
+            if (lo[a] > 0) {
+                float f = pv[a] - (st->mn[a] + (float)lo[a] * h); f = f < 0.f ? 0.f : f;
+                bound2 = fminf(bound2, fmaxf(f * f, dout2[a]) + others); open = true;
+            }
+            if (hi[a] < dm[a] - 1) {
+                float f = (st->mn[a] + (float)(hi[a] + 1) * h) - pv[a]; f = f < 0.f ? 0.f : f;
+                bound2 = fminf(bound2, fmaxf(f * f, dout2[a]) + others); open = true;
+            }
         }
         if (!open) break;
-        bound *= 0.9999f;
-        if (bi >= 0 && best < bound * bound) break;
+        if (bi >= 0 && best < bound2 * 0.9998f) break;
     }
     if (valid && sub == 0) {
         nn_idx[i] = bi;
