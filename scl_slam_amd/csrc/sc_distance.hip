@@ -55,6 +55,7 @@ struct ScArgs {
     // optional fused epilogue (full-DB mode): per-workgroup partials, last workgroup reduces them
     unsigned long long *blk_part; unsigned int *done_counter; double *out3; int *topk_idx; float *topk_d2;
     int topk_k; float exclude_eps;
+    int align_filter;             // 1: fp32 correlation filter in front of the exact alignment (SCL_ALIGN_FILTER=0 disables)
     unsigned long long *stamps;   // diagnostic only (SCL_STAMP=1): per-wave phase cycle sums
     int ablate;   // diagnostic only (SCL_ABLATE): bit0 skip alignment loop, bit1 skip ring dots, bit2 skip sector sums
 };
@@ -281,6 +282,11 @@ __device__ __forceinline__ double quot_core(double a, double b)
     return fma(r, y, q);
 }
 __device__ __forceinline__ bool is_finite(double x) { return fabs(x) <= 0x1.fffffffffffffp+1023; }
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pin_f2(f2 &a, f2 &b)
+{
+    asm volatile("" : "+v"(a), "+v"(b) :: "memory");
+}
 __device__ __forceinline__ void pin1(double &a)
 {
     asm volatile("" : "+v"(a) :: "memory");
@@ -325,9 +331,18 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScBatchArgs ab)
     // per-wave scratch: the doubled sector key (alignment of candidate i+1) and the similarity rows
     // (phases C/D of candidate i) are never live together -> they share the space
     constexpr int wsz = (2 * S > HSH * SB) ? 2 * S : HSH * SB;
-    double *vk2 = vq + S + wave * wsz;         // [2S] candidate sector key, doubled
+    // fp32 copies of the query's sector key for the alignment filter: vqf0[t] = q[t], vqf1[t] = q[(t+1) mod S]
+    float *vqf0 = reinterpret_cast<float *>(vq + S);
+    float *vqf1 = vqf0 + S;
+    double *wbase = vq + 2 * S;                // per-wave scratch starts here
+    double *vk2 = wbase + wave * wsz;          // [2S] candidate sector key, doubled
     double *simbuf = vk2;                      // [HSH][SB]
-    int *next_ticket = reinterpret_cast<int *>(vq + S + nwaves * wsz);   // workgroup-wide candidate dispenser
+    // fp32 doubled candidate key, twice: pf[c][t + 2c] = p[t mod S] (c = 0, 1), so that the window of every lane
+    // starts on a 16-byte boundary in one of the two copies; lives behind vk2 inside the wave's scratch
+    constexpr int PFS = 2 * S + 4;             // floats per copy
+    static_assert(2 * S + PFS <= wsz, "alignment filter scratch must fit the wave's scratch");
+    float *pf = reinterpret_cast<float *>(vk2 + 2 * S);
+    int *next_ticket = reinterpret_cast<int *>(wbase + nwaves * wsz);    // workgroup-wide candidate dispenser
 
     for (int idx = threadIdx.x; idx < RG * S; idx += blockDim.x) {
         const int rg = idx / S, c = idx - rg * S;
@@ -343,7 +358,10 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScBatchArgs ab)
         const double nv = a.q_norm[c];
         nqe[c] = nv;
         if (c < W + 1) nqe[c + S] = nv;
-        vq[c] = a.q_vkey[c];
+        const double kv = a.q_vkey[c];
+        vq[c] = kv;
+        vqf0[c] = (float)kv;
+        vqf1[c == 0 ? S - 1 : c - 1] = (float)kv;
     }
     // Candidates of this workgroup: a contiguous range, handed out wave by wave through an LDS
     // counter.  The two waves that share a SIMD are not served equally (the older one wins the
@@ -371,6 +389,13 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScBatchArgs ab)
 
     int ci = c_lo + wave;
     const bool have_work = ci < c_hi;
+    // alignment filter: |q|^2 of the query's sector key in fp32 (any summation order: the bound has 5 % of slack)
+    const bool use_filter = a.align_filter != 0;
+    float qn2 = 0.f;
+    if (use_filter) {
+        const f2 qv = *reinterpret_cast<const f2 *>(vqf0 + j0);
+        qn2 = wave_sum_f32_dpp(active ? qv.x * qv.x + qv.y * qv.y : 0.f);
+    }
     bool q_finite;
     {
         bool f = true;
@@ -401,10 +426,68 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScBatchArgs ab)
         // lanes >= L mirror lane L-1 (same addresses, same values): no divergent stores needed
         *reinterpret_cast<double2 *>(vk2 + j0) = vk;
         *reinterpret_cast<double2 *>(vk2 + j0 + S) = vk;
+        int filtered = -1;                                   // >= 0: the alignment, decided by the filter below
+        if (use_filter) {
+            // ---- alignment filter -------------------------------------------------------------------
+            // argmin_s |q - shift(k, s)|  =  argmax_s c_s,  c_s = sum_t q_t k_(t-s)  (|shift(k, s)| does not depend
+            // on s).  c_s is evaluated in fp32 (packed fmas) for every shift; the absolute error of each value is
+            // at most eps = 65 * 2^-24 * |q| |k| (60-term chains per accumulator, input conversion, final add;
+            // Cauchy-Schwarz on sum |q_t| |k_u|).  Every shift whose c lies more than 4 eps below the maximum is
+            // provably not the reference's minimum (2 eps of margin over the error, far above the fp64 rounding
+            // of the reference's own sums); if exactly one shift remains it is the answer, otherwise -- near
+            // ties, non-finite or huge keys -- the exact fp64 evaluation below decides, as it always did.
+            const f2 kf = f2{(float)vk.x, (float)vk.y};
+            float *pf1 = pf + PFS;
+            *reinterpret_cast<f2 *>(pf + j0) = kf;          *reinterpret_cast<f2 *>(pf + j0 + S) = kf;
+            *reinterpret_cast<f2 *>(pf1 + j0 + 2) = kf;     *reinterpret_cast<f2 *>(pf1 + j0 + S + 2) = kf;
+            wave_fence();
+            const int E = S - j0;                             // doubled-key index of sector 0 at shift 2l
+            const float4 *pw = reinterpret_cast<const float4 *>((ll & 1) ? pf1 + E + 2 : pf + E);
+            const float4 *q0w = reinterpret_cast<const float4 *>(vqf0);
+            const float4 *q1w = reinterpret_cast<const float4 *>(vqf1);
+            constexpr int NG = S / 4, FB = 3;                 // sector groups of four, FB groups per batch
+            static_assert(S % 4 == 0 && NG % FB == 0, "filter batches must tile the sectors");
+            f2 ce = f2{0.f, 0.f}, co = f2{0.f, 0.f};
+            float4 pb[2][FB], qa[2][FB], qb[2][FB];
+#pragma unroll
+            for (int v = 0; v < FB; ++v) { pb[0][v] = pw[v]; qa[0][v] = q0w[v]; qb[0][v] = q1w[v]; }
+#pragma unroll
+            for (int bt = 0; bt < NG / FB; ++bt) {
+                if (bt + 1 < NG / FB) {
+#pragma unroll
+                    for (int v = 0; v < FB; ++v) {
+                        pb[(bt + 1) & 1][v] = pw[(bt + 1) * FB + v];
+                        qa[(bt + 1) & 1][v] = q0w[(bt + 1) * FB + v];
+                        qb[(bt + 1) & 1][v] = q1w[(bt + 1) * FB + v];
+                    }
+                }
+                pin_f2(ce, co);
+#pragma unroll
+                for (int v = 0; v < FB; ++v) {
+                    const float4 pv = pb[bt & 1][v], a0 = qa[bt & 1][v], a1 = qb[bt & 1][v];
+                    ce = __builtin_elementwise_fma(f2{a0.x, a0.y}, f2{pv.x, pv.y}, ce);
+                    ce = __builtin_elementwise_fma(f2{a0.z, a0.w}, f2{pv.z, pv.w}, ce);
+                    co = __builtin_elementwise_fma(f2{a1.x, a1.y}, f2{pv.x, pv.y}, co);
+                    co = __builtin_elementwise_fma(f2{a1.z, a1.w}, f2{pv.z, pv.w}, co);
+                }
+                pin_f2(ce, co);
+            }
+            const float c_even = ce.x + ce.y, c_odd = co.x + co.y;
+            const float kn2 = wave_sum_f32_dpp(active ? kf.x * kf.x + kf.y * kf.y : 0.f);
+            const float nsum = sqrtf(qn2) + sqrtf(kn2);
+            const float eps = 4.07e-6f * sqrtf(qn2) * sqrtf(kn2) + 1e-12f * (qn2 + kn2);   // 65 * 2^-24 * 1.05
+            const float cmax = wave_max_f32_dpp(active ? fmaxf(c_even, c_odd) : -3.0e38f);
+            const float cut = cmax - 4.0f * eps;
+            const bool fe = active && !(c_even < cut), fo = active && !(c_odd < cut);      // NaN counts as "may be the minimum"
+            const unsigned long long me = __builtin_amdgcn_ballot_w64(fe), mo = __builtin_amdgcn_ballot_w64(fo);
+            const bool sane = (qn2 < 3.0e38f) && (kn2 < 3.0e38f) && (nsum * nsum < 0.9e14f);   // every norm finite and below the 1e7 start value
+            if (sane && __popcll(me) + __popcll(mo) == 1)
+                filtered = me ? 2 * (__ffsll((long long)me) - 1) : 2 * (__ffsll((long long)mo) - 1) + 1;
+        }
         wave_fence();
         double best = kInf;
         int bshift = 0x7fffffff;
-        {
+        if (filtered < 0) {
             // lane owns shifts 2l and 2l+1:  p[t] = vk[(t - 2l) mod S]; shift 2l+1 reuses p[t-1].
             // All operands come from LDS (in-order returns => counted waits), one batch of
             // 8 sectors is in flight while the previous one is being consumed.
@@ -451,8 +534,13 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScBatchArgs ab)
             if (active && n0 < kBigDist) { best = n0; bshift = j0; }
             if (active && n1 < kBigDist && n1 < best) { best = n1; bshift = j0 + 1; }   // ties keep the lower shift
         }
-        wave_argmin_dpp(best, bshift);
-        const int align = __builtin_amdgcn_readfirstlane(best < kBigDist ? bshift : 0);
+        int align;
+        if (filtered >= 0) {
+            align = filtered;
+        } else {
+            wave_argmin_dpp(best, bshift);
+            align = __builtin_amdgcn_readfirstlane(best < kBigDist ? bshift : 0);
+        }
         // first shift of the reference's search space; the W evaluated shifts are b .. b+W-1 (mod S)
         o_s_start = wrap(align - SR, S);
         // rotation: lane l keeps query columns 2l, 2l+1 and takes the candidate columns that meet them at
@@ -729,7 +817,7 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScBatchArgs ab)
     // release on the producers, acquire on the consumer) reduces the partials and resets the counter.
     if (a.blk_part == nullptr) return;
     constexpr int REC = 2 + KT;
-    unsigned long long *wrec = reinterpret_cast<unsigned long long *>(vq + S) + (size_t)wave * wsz;   // wave scratch is free now
+    unsigned long long *wrec = reinterpret_cast<unsigned long long *>(wbase) + (size_t)wave * wsz;   // wave scratch is free now
     if (lane == 0) {
         wrec[0] = (unsigned long long)__double_as_longlong(w_best);
         wrec[1] = ((unsigned long long)(unsigned)w_bidx << 32) | (unsigned)w_bshift;
@@ -740,7 +828,7 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScBatchArgs ab)
     unsigned int *s_ticket = reinterpret_cast<unsigned int *>(next_ticket) + 1;
     if (wave == 0) {
         // workgroup record: lane w < nwaves holds wave w's best, lane l holds one ring key of wave l / KT
-        const unsigned long long *base = reinterpret_cast<unsigned long long *>(vq + S);
+        const unsigned long long *base = reinterpret_cast<unsigned long long *>(wbase);
         unsigned long long b0 = ~0ull, b1 = ~0ull;
         if (lane < nwaves) { b0 = base[(size_t)lane * wsz]; b1 = base[(size_t)lane * wsz + 1]; }
         const unsigned long long m0 = wave_min_u64(b0);                       // distance bits order like distances
@@ -825,7 +913,7 @@ hipError_t launch_wave(const ScBatchArgs &batch_in, int num_cu, hipStream_t stre
     const int n_launch = ab.nq > 1 ? ab.nb : a.n;          // caller passes max n in nb for a batch
     constexpr int QS = S + W + 1;
     constexpr int HSH = (W + 1) / 2;
-    const size_t fixed = (size_t)(RG * 4 * QS + QS + S) * sizeof(double);
+    const size_t fixed = (size_t)(RG * 4 * QS + QS + 2 * S) * sizeof(double);   // query rows, norms, sector key (fp64 + two fp32 copies)
     const size_t per_wave = (size_t)((2 * S > HSH * (S + 2)) ? 2 * S : HSH * (S + 2)) * sizeof(double);
     const size_t lds_cap = 160 * 1024;
     int waves = (int)((lds_cap - fixed - 16) / per_wave);
@@ -1043,6 +1131,12 @@ hipError_t launch_fast(const ScArgs &args_in, int num_cu, hipStream_t stream)
 
 }  // namespace
 
+int align_filter_enabled()
+{
+    static const int on = [] { const char *e = getenv("SCL_ALIGN_FILTER"); return (e && e[0] == '0') ? 0 : 1; }();
+    return on;
+}
+
 hipError_t launch_sc_distance(const DbView &db, const QueryView &q, const int *cand, int slot_base,
                               int n, int SR, double *out_dist, int *out_shift, int num_cu,
                               hipStream_t stream, float *out_ring_d2, bool *ring_fused, const FullTail *tail)
@@ -1056,6 +1150,7 @@ hipError_t launch_sc_distance(const DbView &db, const QueryView &q, const int *c
     a.NW = (db.S + kWave - 1) / kWave; a.G = 1;
     static const int ablate = [] { const char *e = getenv("SCL_ABLATE"); return e ? atoi(e) : 0; }();
     a.ablate = ablate;
+    a.align_filter = align_filter_enabled();
     a.stamps = nullptr;
     a.rkey4 = db.rkey4; a.rk_cap = db.cap; a.q_rkey = q.rkey; a.out_d2 = nullptr;
     a.blk_part = nullptr; a.done_counter = nullptr; a.out3 = nullptr; a.topk_idx = nullptr; a.topk_d2 = nullptr;
@@ -1107,7 +1202,7 @@ hipError_t launch_sc_distance_batch(const DbView &db, const QueryBatch &qb, int 
         a.q_norm = db.norm + slot * db.S; a.q_rkey = db.rkey + slot * (size_t)(4 * db.RG);
         a.cand = nullptr; a.slot_base = qb.base[i]; a.n = qb.n[i]; a.S = db.S; a.SR = SR;
         a.NW = (db.S + kWave - 1) / kWave; a.G = 1;
-        a.ablate = 0; a.stamps = nullptr;
+        a.ablate = 0; a.stamps = nullptr; a.align_filter = align_filter_enabled();
         a.rkey4 = db.rkey4; a.rk_cap = db.cap;
         a.out_dist = out_dist + (size_t)i * qb.pair_stride; a.out_shift = out_shift + (size_t)i * qb.pair_stride;
         a.out_d2 = out_ring_d2 + (size_t)i * qb.pair_stride;

@@ -115,6 +115,58 @@ def test_extreme_and_non_finite_values(R, S):
     eng.close()
 
 
+@pytest.mark.parametrize("R,S", [(20, 60), (64, 120)])
+def test_alignment_near_ties(R, S):
+    """The wave kernel screens the S alignment shifts with an fp32 correlation and evaluates exactly only when
+    more than one shift survives the error bound.  Near-tie constructions around that bound: a descriptor that
+    repeats every S/2 sectors makes shifts s and s + S/2 tie exactly (first minimum wins, D.h:1503); a
+    perturbation of relative size 1e-12 .. 1e-2 in one cell breaks the tie one way or the other; constant and
+    almost-constant sector keys make every shift tie."""
+    rs = np.random.RandomState(17)
+    base = synth_descriptors(3, R, S, seed=23)
+    half = S // 2
+    descs = []
+    periodic = base[0].copy(); periodic[:, half:] = periodic[:, :half]
+    descs.append(periodic)
+    for rel in (1e-12, 1e-9, 1e-7, 3e-7, 1e-6, 3e-6, 1e-5, 1e-4, 1e-3, 1e-2):
+        for sign in (+1.0, -1.0):
+            d = periodic.copy()
+            r, c = int(rs.randint(0, R)), int(rs.randint(0, S))
+            d[r, c] = np.float32(d[r, c] * (1.0 + sign * rel) + sign * rel)
+            descs.append(d)
+    flat = np.full((R, S), 3.5, np.float32); descs.append(flat)                       # constant key: every shift ties
+    almost = flat.copy(); almost[0, 7] += np.float32(1e-6); descs.append(almost)
+    descs.append(np.roll(periodic, 7, axis=1)); descs.append(np.roll(base[1], 11, axis=1)); descs.append(base[1]); descs.append(base[2])
+    descs = np.stack(descs).astype(np.float32)
+    n = descs.shape[0]
+    eng = ScanContextEngine(num_ring=R, num_sector=S)
+    eng.save_bulk(descs)
+    db = ob.OracleDB(ob.make_config(R=R, S=S)); db.save_bulk(descs)
+    for q in range(n):
+        d_gpu, s_gpu = eng.sc_distance_batch(q, n=n)
+        d_cpu, s_cpu = db.distance_batch(q, n=n, fast=True)
+        assert_same(d_gpu, s_gpu, d_cpu, s_cpu)
+    eng.close()
+
+
+@pytest.mark.parametrize("amp", [1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1])
+def test_alignment_filter_boundary_sweep(amp):
+    """Sector keys = constant + amp * noise: the gaps between the alignment candidates sweep through the filter's
+    error bound (amp ~ 1e-4 .. 1e-3 at these norms), so decisions by the filter and by the exact fallback mix."""
+    R, S, n = 64, 120, 36
+    rs = np.random.RandomState(int(-np.log10(amp)) + 5)
+    descs = (5.0 + amp * rs.standard_normal((n, R, S))).astype(np.float32)
+    descs[::5] += (amp * 10 * rs.standard_normal((len(descs[::5]), 1, S))).astype(np.float32)   # some with column structure
+    eng = ScanContextEngine(num_ring=R, num_sector=S)
+    eng.save_bulk(descs)
+    db = ob.OracleDB(ob.make_config(R=R, S=S)); db.save_bulk(descs)
+    for q in range(0, n, 3):
+        d_gpu, s_gpu = eng.sc_distance_batch(q, n=n)
+        d_cpu, s_cpu = db.distance_batch(q, n=n, fast=True)
+        assert_same(d_gpu, s_gpu, d_cpu, s_cpu)
+    eng.close()
+
+
 def test_staged_query_equals_stored_query():
     R, S, n = 64, 120, 50
     descs, eng, db = build(R, S, n, seed=31)
