@@ -64,6 +64,47 @@ class OracleShardEngine:
         return bi, bs, best
 
 
+def test_full_scan_stream_orders_and_batches_single_process():
+    """FullScanStream on one rank: every combination of launches in flight, scans per launch and merge batch
+    returns the scans' results in submission order, equal to blocking calls (the checker stands in for the engine)."""
+    from scl_slam_amd.sharded import FullScanStream
+    n = 160
+    descs = synth_descriptors(n, R, S, seed=77, revisit_frac=0.1)
+    cfg = ob.make_config(R=R, S=S, k=K)
+    eng = OracleShardEngine(cfg)
+    for i in range(n):
+        eng.save_from_wire(descs[i], 0, i)
+
+    class SlotEngine:
+        """adds the engine's submit_many and its limit of eight result slots"""
+        def __init__(self, inner):
+            self.inner, self.busy, self.q = inner, 0, None
+        def stage(self, q):
+            self.inner.stage_query(descs[q])
+        def detect_full_submit(self, query, lo, hi):
+            assert self.busy < 8; self.busy += 1
+            self.stage(query)
+            return self.inner.detect_full_range(-1, lo, hi)
+        def detect_full_submit_many(self, qs, los, his):
+            return [self.detect_full_submit(q, lo, hi) for q, lo, hi in zip(qs, los, his)]
+        def detect_full_collect(self, t):
+            self.busy -= 1
+            return t
+
+    queries = list(range(n - 1, n - 24, -1))
+    blocking = []
+    for q in queries:
+        eng.stage_query(descs[q]); blocking.append(eng.detect_full_range(-1, 0, q - 30))
+    for depth in (1, 2, 3):
+        for per_launch in (1, 2, 3, 4):
+            for merge_every in (1, 5, 16):
+                st = FullScanStream(SlotEngine(eng), depth=depth, merge_every=merge_every, scans_per_launch=per_launch)
+                for q in queries:
+                    st.submit(q, 0, q - 30)
+                res = st.drain()
+                assert [(g, sh, d) for d, g, sh in res] == [(nn, sh, d) for nn, sh, d in blocking], (depth, per_launch, merge_every)
+
+
 def test_local_count():
     for world in (1, 2, 3, 8):
         for hi in range(0, 40):
