@@ -451,6 +451,7 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScBatchArgs ab)
             float4 pb[2][FB], qa[2][FB], qb[2][FB];
 #pragma unroll
             for (int v = 0; v < FB; ++v) { pb[0][v] = pw[v]; qa[0][v] = q0w[v]; qb[0][v] = q1w[v]; }
+            if (!(a.ablate & 1)) {
 #pragma unroll
             for (int bt = 0; bt < NG / FB; ++bt) {
                 if (bt + 1 < NG / FB) {
@@ -471,6 +472,7 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScBatchArgs ab)
                     co = __builtin_elementwise_fma(f2{a1.z, a1.w}, f2{pv.z, pv.w}, co);
                 }
                 pin_f2(ce, co);
+            }
             }
             const float c_even = ce.x + ce.y, c_odd = co.x + co.y;
             const float kn2 = wave_sum_f32_dpp(active ? kf.x * kf.x + kf.y * kf.y : 0.f);
@@ -1131,6 +1133,12 @@ hipError_t launch_fast(const ScArgs &args_in, int num_cu, hipStream_t stream)
 
 }  // namespace
 
+int ablate_flags()
+{
+    static const int f = [] { const char *e = getenv("SCL_ABLATE"); return e ? atoi(e) : 0; }();
+    return f;
+}
+
 int align_filter_enabled()
 {
     static const int on = [] { const char *e = getenv("SCL_ALIGN_FILTER"); return (e && e[0] == '0') ? 0 : 1; }();
@@ -1148,8 +1156,7 @@ hipError_t launch_sc_distance(const DbView &db, const QueryView &q, const int *c
     a.q_desc = q.desc; a.q_vkey = q.vkey; a.q_norm = q.norm;
     a.cand = cand; a.slot_base = slot_base; a.n = n; a.S = db.S; a.SR = SR;
     a.NW = (db.S + kWave - 1) / kWave; a.G = 1;
-    static const int ablate = [] { const char *e = getenv("SCL_ABLATE"); return e ? atoi(e) : 0; }();
-    a.ablate = ablate;
+    a.ablate = ablate_flags();
     a.align_filter = align_filter_enabled();
     a.stamps = nullptr;
     a.rkey4 = db.rkey4; a.rk_cap = db.cap; a.q_rkey = q.rkey; a.out_d2 = nullptr;
@@ -1202,7 +1209,7 @@ hipError_t launch_sc_distance_batch(const DbView &db, const QueryBatch &qb, int 
         a.q_norm = db.norm + slot * db.S; a.q_rkey = db.rkey + slot * (size_t)(4 * db.RG);
         a.cand = nullptr; a.slot_base = qb.base[i]; a.n = qb.n[i]; a.S = db.S; a.SR = SR;
         a.NW = (db.S + kWave - 1) / kWave; a.G = 1;
-        a.ablate = 0; a.stamps = nullptr; a.align_filter = align_filter_enabled();
+        a.ablate = ablate_flags(); a.stamps = nullptr; a.align_filter = align_filter_enabled();
         a.rkey4 = db.rkey4; a.rk_cap = db.cap;
         a.out_dist = out_dist + (size_t)i * qb.pair_stride; a.out_shift = out_shift + (size_t)i * qb.pair_stride;
         a.out_d2 = out_ring_d2 + (size_t)i * qb.pair_stride;
