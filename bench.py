@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--scans-per-launch", type=int, default=2,
                     help="incoming scans scored by one kernel launch (1..4): the second scan's workgroups take over CUs "
                          "as the first scan's retire, so no CU idles in a launch tail")
+    ap.add_argument("--native-chunk", type=int, default=64,
+                    help="scans handed to the engine's native submit/collect pipeline per call (0: drive every scan from Python)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU sample (0 = auto ~15 s)")
     return ap.parse_args()
@@ -161,7 +163,7 @@ def main():
         + arg-min, one launch); `--pipeline` passes are in flight, and for N > 1 the per-rank winners of
         `--merge-every` scans travel in one asynchronous all-gather (RCCL), merged one batch later."""
         st = FullScanStream(eng, rank, world, device=coll_dev, depth=args.pipeline, merge_every=args.merge_every,
-                            scans_per_launch=args.scans_per_launch)
+                            scans_per_launch=args.scans_per_launch, native_chunk=args.native_chunk)
         for i in range(count):
             st.submit(n_elig + ((first + i) % n_query), 0, n_elig)
         res = st.drain()
@@ -220,7 +222,8 @@ def main():
             "config": {"workload": "BASELINE configs[1]: 10k synthetic Velodyne-64 keyframes per GPU, 64x120 SC, "
                                    "full ring-key scan + shifted SC distance over the whole DB per incoming scan",
                        "keyframes_per_gpu": n_local, "eligible_per_query": n_elig, "rings": R, "sectors": S,
-                       "shifts_per_pair": 13, "scans_per_launch": args.scans_per_launch, "launches_in_flight": args.pipeline, "sharding": f"keyframe-index shards x{world}, one async all-gather of 24 B/rank/scan per {args.merge_every} scans"},
+                       "shifts_per_pair": 13, "scans_per_launch": args.scans_per_launch, "launches_in_flight": args.pipeline, "native_chunk": args.native_chunk,
+                       "sharding": f"keyframe-index shards x{world}, one async all-gather of 24 B/rank/scan per {args.native_chunk or args.merge_every} scans"},
             "sc_distance_GBps": value * ALGO_BYTES_PER_PAIR / 1e9,
             "kernel_ms": {"sc_distance": k1_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -154,6 +154,11 @@ int  scl_detect_full_submit(scl_engine *e, int query, int lo, int hi, int *ticke
  * ticket of scl_detect_full_submit.  Up to 4 queries share a launch (more are split); staged queries
  * (SCL_QUERY_STAGED) and grids without the fused kernel fall back to one launch per query. */
 int  scl_detect_full_submit_many(scl_engine *e, const int *queries, const int *lo, const int *hi, int n_queries, int *tickets);
+/* A backlog of n_queries scans in one call: the submit / collect pipeline of the two calls above run natively
+ * (scans_per_launch queries per kernel launch, launches_in_flight launches enqueued ahead), results in
+ * submission order.  Blocks until the last scan is done; no other pass may be in flight. */
+int  scl_detect_full_stream(scl_engine *e, const int *queries, const int *lo, const int *hi, int n_queries,
+                            int scans_per_launch, int launches_in_flight, int *nn_idx, int *shift, double *dist);
 int  scl_detect_full_collect(scl_engine *e, int ticket, int *nn_idx, int *shift, double *dist);
 /* The ring-key top-k (num_candidates entries) computed as part of the last scl_detect_full[_range]. */
 int  scl_get_last_topk(scl_engine *e, int k, int *idx, float *d2);

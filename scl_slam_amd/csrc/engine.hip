@@ -944,6 +944,34 @@ int scl_detect_full_submit_many(scl_engine *e, const int *queries, const int *lo
     return SCL_OK;
 }
 
+int scl_detect_full_stream(scl_engine *e, const int *queries, const int *lo, const int *hi, int n_queries,
+                           int scans_per_launch, int launches_in_flight, int *nn_idx, int *shift, double *dist)
+{
+    if (!e || !queries || !lo || !hi || !nn_idx || !shift || !dist || n_queries < 0) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    for (int i = 0; i < scl_engine::kSlots; ++i)
+        if (e->slot_busy[i]) return fail(e, SCL_ERR_INVALID_ARG, "detect_full_stream: collect the passes in flight first");
+    const int spl = scans_per_launch < 1 ? 1 : (scans_per_launch > kMaxQueryBatch ? kMaxQueryBatch : scans_per_launch);
+    int depth = launches_in_flight < 1 ? 1 : launches_in_flight;
+    if (depth * spl > scl_engine::kSlots) depth = scl_engine::kSlots / spl;
+    std::vector<int> tk((size_t)n_queries);
+    int submitted = 0, collected = 0;
+    while (collected < n_queries) {
+        while (submitted < n_queries) {                       // keep `depth` launches enqueued
+            const int m = n_queries - submitted < spl ? n_queries - submitted : spl;
+            if ((submitted - collected) + m > depth * spl) break;
+            const int rc = submit_full_many_locked(e, queries + submitted, lo + submitted, hi + submitted, m, tk.data() + submitted);
+            if (rc) return rc;
+            submitted += m;
+        }
+        const int rc = collect_full_locked(e, tk[(size_t)collected], nn_idx + collected, shift + collected, dist + collected);
+        if (rc) return rc;
+        ++collected;
+    }
+    return SCL_OK;
+}
+
 int scl_detect_full_collect(scl_engine *e, int ticket, int *nn_idx, int *shift, double *dist)
 {
     if (!e || !nn_idx || !shift || !dist) return SCL_ERR_INVALID_ARG;

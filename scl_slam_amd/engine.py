@@ -89,6 +89,7 @@ def _bind(lib):
         "scl_detect_full_submit": (c_int, [P, c_int, c_int, c_int, ip]),
         "scl_detect_full_collect": (c_int, [P, c_int, ip, ip, dp]),
         "scl_detect_full_submit_many": (c_int, [P, ip, ip, ip, c_int, ip]),
+        "scl_detect_full_stream": (c_int, [P, ip, ip, ip, c_int, c_int, c_int, ip, ip, dp]),
         "scl_topk_with_distance": (c_int, [P, c_int, c_int, c_int, c_int, ip, fp, dp, ip, ip]),
         "scl_icp_default_params": (c_int, [POINTER(IcpParams)]),
         "scl_icp_align": (c_int, [P, P, c_int, P, c_int, c_int, POINTER(IcpParams), fp, fp, ip, ip]),
@@ -300,6 +301,18 @@ class ScanContextEngine:
         self._check(self._lib.scl_detect_full_submit_many(self._h, _ptr(q, c_int), _ptr(lo_, c_int), _ptr(hi_, c_int), m, _ptr(t, c_int)),
                     "scl_detect_full_submit_many")
         return [int(x) for x in t]
+
+    def detect_full_stream(self, queries, lo, hi, scans_per_launch=2, launches_in_flight=2):
+        """a backlog of scans through the native submit / collect pipeline; returns (nn_idx, shift, dist) arrays"""
+        q = np.ascontiguousarray(queries, dtype=np.int32)
+        m = q.shape[0]
+        lo_ = np.ascontiguousarray(np.broadcast_to(np.asarray(lo, dtype=np.int32), (m,)))
+        hi_ = np.ascontiguousarray(np.broadcast_to(np.asarray(hi, dtype=np.int32), (m,)))
+        nn = np.empty(max(m, 1), np.int32); sh = np.empty(max(m, 1), np.int32); d = np.empty(max(m, 1), np.float64)
+        self._check(self._lib.scl_detect_full_stream(self._h, _ptr(q, c_int), _ptr(lo_, c_int), _ptr(hi_, c_int), m,
+                                                     scans_per_launch, launches_in_flight, _ptr(nn, c_int), _ptr(sh, c_int),
+                                                     _ptr(d, c_double)), "scl_detect_full_stream")
+        return nn[:m], sh[:m], d[:m]
 
     def detect_full_collect(self, ticket):
         nn, sh, d = c_int(), c_int(), c_double()

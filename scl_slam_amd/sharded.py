@@ -123,15 +123,24 @@ class FullScanStream:
     """
 
     def __init__(self, engine, rank=0, world=1, group=None, device="cpu", depth=2, merge_every=16, scans_per_launch=1,
-                 always_exchange=False):
+                 always_exchange=False, native_chunk=0):
         self.engine, self.rank, self.world, self.group, self.device = engine, rank, world, group, device
         self.always_exchange = always_exchange              # run the collective even for world == 1 (exercises the backend)
+        # native_chunk > 0: database-resident queries are handed to scl_detect_full_stream in chunks of that many
+        # scans (the submit / collect pipeline runs in the engine, the Python loop pays once per chunk); each
+        # chunk's winners form one exchange batch
+        self.native_chunk = native_chunk if hasattr(engine, "detect_full_stream") else 0
         self.depth, self.merge_every = max(1, depth), max(1, merge_every)
         self.per_launch = max(1, scans_per_launch)          # database-resident queries sharing one kernel launch
         self.inflight, self.batch, self.pending, self.results = [], [], None, []
         self.held = []
 
     def submit(self, query, lo, hi):
+        if self.native_chunk > 0 and query >= 0:
+            self.held.append((query, lo, hi))
+            if len(self.held) >= self.native_chunk:
+                self._run_native()
+            return
         if self.per_launch > 1 and query >= 0:
             self.held.append((query, lo, hi))
             if len(self.held) >= self.per_launch:
@@ -141,7 +150,20 @@ class FullScanStream:
         self._make_room(1)
         self.inflight.append(self.engine.detect_full_submit(query, lo, hi))
 
+    def _run_native(self):
+        if not self.held:
+            return
+        q, lo, hi = zip(*self.held)
+        self.held = []
+        nn, sh, d = self.engine.detect_full_stream(q, lo, hi, self.per_launch, self.depth)
+        g = np.where(nn >= 0, nn.astype(np.float64) * self.world + self.rank, -1.0)
+        self.batch.extend(zip(d.tolist(), g.tolist(), sh.astype(np.float64).tolist()))
+        self._exchange()
+
     def _launch_held(self):
+        if self.native_chunk > 0:
+            self._run_native()
+            return
         if not self.held:
             return
         q, lo, hi = zip(*self.held)

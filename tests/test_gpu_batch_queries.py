@@ -37,5 +37,15 @@ def test_batched_queries_equal_single_launches(R, S):
         res = st.drain()
         for a, (d, g, sh) in zip(single, res):
             assert (a[0], a[1]) == (g, sh) and a[2] == d
+        # the native pipeline (scl_detect_full_stream) and the stream front end on top of it
+        for spl, depth in ((1, 1), (2, 2), (3, 2), (4, 2), (2, 4)):
+            nn, sh, d = e.detect_full_stream(queries, 0, his, spl, depth)
+            for a, b in zip(single, zip(nn.tolist(), sh.tolist(), d.tolist())):
+                assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2]
+        st = FullScanStream(e, depth=2, merge_every=3, scans_per_launch=2, native_chunk=3)
+        for q, hi in zip(queries, his):
+            st.submit(q, 0, hi)
+        for a, (d, g, sh) in zip(single, st.drain()):
+            assert (a[0], a[1]) == (g, sh) and a[2] == d
     finally:
         e.close()
