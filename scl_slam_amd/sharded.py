@@ -225,3 +225,34 @@ class FullScanStream:
         prev, self.pending = self.pending, None
         self._finish(prev)
         return self.results
+
+
+def verify_candidates_sharded(engine, src, tgts, rank=0, world=1, group=None, device="cpu", params=None):
+    """Geometric verification of the loop candidates of one scan across the GPUs of a node:
+    the alignments are independent, so rank r verifies candidates r, r + G, r + 2G, ... with
+    ``icp_align_batch`` and one all-gather of 19 floats per candidate (4x4 transform, fitness, converged,
+    iterations) gives every rank the whole table.  Returns (T[m,4,4], fitness[m], converged[m], iterations[m])."""
+    m = len(tgts)
+    mine = list(range(rank, m, world))
+    per = (m + world - 1) // world
+    rec = np.zeros((per, 19), dtype=np.float64)
+    rec[:, 17] = -1.0                                                  # padding rows: converged = -1
+    if mine:
+        T, fit, conv, it = engine.icp_align_batch(src, [tgts[c] for c in mine], params)
+        for k in range(len(mine)):
+            rec[k, :16] = np.asarray(T[k], dtype=np.float64).reshape(16)
+            rec[k, 16], rec[k, 17], rec[k, 18] = float(fit[k]), float(bool(conv[k])), float(it[k])
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        t = torch.from_numpy(rec).to(device)
+        out = torch.empty((world * per, 19), dtype=t.dtype, device=device)
+        dist.all_gather_into_tensor(out, t, group=group)
+        allr = out.cpu().numpy().reshape(world, per, 19)
+    else:
+        allr = rec[None]
+    Tm = np.zeros((m, 4, 4), np.float32); fit = np.zeros(m, np.float32); conv = np.zeros(m, bool); it = np.zeros(m, np.int32)
+    for c in range(m):
+        r = allr[c % world, c // world]
+        Tm[c] = r[:16].reshape(4, 4); fit[c] = r[16]; conv[c] = r[17] > 0.5; it[c] = int(r[18])
+    return Tm, fit, conv, it

@@ -105,6 +105,54 @@ def test_full_scan_stream_orders_and_batches_single_process():
                 assert [(g, sh, d) for d, g, sh in res] == [(nn, sh, d) for nn, sh, d in blocking], (depth, per_launch, merge_every)
 
 
+class OracleIcpEngine:
+    """engine-shaped wrapper over the CPU ICP checker (tests may use oracle/)"""
+    def icp_align_batch(self, src, tgts, params=None):
+        import oracle_icp_binding as oi
+        res = [oi.icp_align(src, t) for t in tgts]
+        return (np.stack([r[0] for r in res]), np.array([r[1] for r in res], np.float32),
+                np.array([r[2] for r in res]), np.array([r[3] for r in res], np.int32))
+
+
+def _icp_worker(rank, world, port, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scl_slam_amd.sharded import verify_candidates_sharded
+    from scl_slam_amd.synth import synth_structured_cloud
+    tgts = [synth_structured_cloud(600 + 40 * c, seed=50 + c) for c in range(5)]
+    src = tgts[2][::2].copy(); src[:, 0] += 0.02
+    T, fit, conv, it = verify_candidates_sharded(OracleIcpEngine(), src, tgts, rank, world)
+    out_q.put((rank, T.tobytes(), fit.tobytes(), conv.tolist(), it.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_candidate_verification_sharded_over_ranks():
+    """5 candidates over 2 ranks: every rank ends with the table a single rank computes"""
+    from scl_slam_amd.sharded import verify_candidates_sharded
+    from scl_slam_amd.synth import synth_structured_cloud
+    tgts = [synth_structured_cloud(600 + 40 * c, seed=50 + c) for c in range(5)]
+    src = tgts[2][::2].copy(); src[:, 0] += 0.02
+    T1, f1, c1, i1 = verify_candidates_sharded(OracleIcpEngine(), src, tgts)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_icp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        got = [q.get(timeout=180) for _ in range(2)]
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.terminate()
+    assert all(p.exitcode == 0 for p in procs)
+    for _, Tb, fb, conv, it in got:
+        assert Tb == T1.tobytes() and fb == f1.tobytes() and conv == c1.tolist() and it == i1.tolist()
+    assert c1[2] and i1[2] >= 1
+
+
 def test_local_count():
     for world in (1, 2, 3, 8):
         for hi in range(0, 40):
