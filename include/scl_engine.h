@@ -107,6 +107,11 @@ int  scl_get_size(const scl_engine *e, int id);
 
 /* ---- bulk / building-block entry points ----------------------------------- */
 
+/* makeDescriptors (DM.h:996-1002) in one call: pcl::VoxelGrid with leaf `leaf` (descriptLeafSize) on the raw scan,
+ * then makeAndSaveDescriptorAndKey on the filtered cloud, which stays on the device.  *n_filtered (optional) =
+ * points after the filter.  Same descriptor, key and database state as scl_voxel_grid + scl_make_and_save. */
+int  scl_make_and_save_filtered(scl_engine *e, const void *points, int n_points, int stride_bytes, float leaf,
+                                int8_t robot, int index, float *out_values, int *n_filtered);
 /* makeScancontext only (D.h:1404-1461), nothing is stored. */
 int  scl_make_descriptor(scl_engine *e, const void *points, int n_points, int stride_bytes,
                          float *out_values);

@@ -540,6 +540,38 @@ int scl_make_and_save(scl_engine *e, const void *points, int n_points, int strid
     return append_meta(e, robot, index);
 }
 
+int scl_make_and_save_filtered(scl_engine *e, const void *points, int n_points, int stride_bytes, float leaf,
+                               int8_t robot, int index, float *out_values, int *n_filtered)
+{
+    if (!e) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    if (n_points < 0 || stride_bytes < 12 || (stride_bytes & 3)) return fail(e, SCL_ERR_INVALID_ARG, "bad point layout");
+    if (n_points > 0 && !points) return fail(e, SCL_ERR_INVALID_ARG, "null points");
+    int rc;
+    if ((rc = ensure_capacity(e, e->n + 1))) return rc;
+    if ((rc = ensure_vals(e, (size_t)e->R * e->S))) return rc;
+    // makeDescriptors, DM.h:996-1002: VoxelGrid(descriptLeafSize) then makeAndSaveDescriptorAndKey -- the filtered cloud
+    // never leaves the device
+    std::string err;
+    const void *d_cloud = nullptr;
+    int m = 0;
+    if ((rc = voxel_grid_to_device(&e->vox_ws, e->stream, points, n_points, stride_bytes, leaf, &d_cloud, &m, &err))) { e->last_error = err; return rc; }
+    {
+        ProfScope ps(e, P_MAKESC);
+        SCL_HIP(e, launch_make_sc(d_cloud, m, stride_bytes, e->R, e->S, e->cfg.lidar_height,
+                                  e->cfg.max_radius, e->d_tile, e->d_vals, e->num_cu, e->stream));
+    }
+    e->prof.make_sc_points += e->prof_on ? (uint64_t)m : 0;
+    if ((rc = ingest_from_vals(e, 1, e->n))) return rc;
+    if (out_values)
+        SCL_HIP(e, hipMemcpyAsync(out_values, e->d_vals, sizeof(float) * (size_t)e->R * e->S,
+                                  hipMemcpyDeviceToHost, e->stream));
+    if ((rc = sync(e))) return rc;
+    if (n_filtered) *n_filtered = m;
+    return append_meta(e, robot, index);
+}
+
 int scl_make_descriptor(scl_engine *e, const void *points, int n_points, int stride_bytes, float *out_values)
 {
     if (!e || !out_values) return SCL_ERR_INVALID_ARG;

@@ -51,6 +51,8 @@ int icp_geometric_verification(IcpWorkspace *ws, hipStream_t stream, int num_cu,
 // voxel.hip (a separate workspace instance is used: buffer slots differ from icp.hip's)
 int voxel_grid(IcpWorkspace *ws, hipStream_t stream, const void *in, int n, int stride, float leaf,
                void *out, int out_capacity, int *n_out, std::string *err);
+int voxel_grid_to_device(IcpWorkspace *ws, hipStream_t stream, const void *in, int n, int stride, float leaf,
+                         const void **d_result, int *n_out, std::string *err);
 int assemble_submap(IcpWorkspace *ws, hipStream_t stream, const void *const *clouds, const int *counts,
                     const float *transforms, int n_clouds, int stride, float leaf, void *out, int out_capacity,
                     int *n_out, std::string *err);

@@ -228,6 +228,22 @@ int voxel_device(IcpWorkspace *ws, hipStream_t stream, int n, int stride, float 
 
 }  // namespace
 
+// host cloud in, filtered cloud left on the device (*d_result, valid until the workspace is used again);
+// *n_out = -1 when PCL would return the input unchanged (index overflow): *d_result is then the unfiltered copy
+int voxel_grid_to_device(IcpWorkspace *ws, hipStream_t stream, const void *in, int n, int stride, float leaf,
+                         const void **d_result, int *n_out, std::string *err)
+{
+    if (n < 0 || stride < 12 || (stride & 3) || !(leaf > 0.f)) { if (err) *err = "voxel_grid: bad arguments"; return SCL_ERR_INVALID_ARG; }
+    int rc;
+    if ((rc = vensure(ws, V_IN, (size_t)n * stride + 16, err))) return rc;
+    if (n) VOX_HIP(hipMemcpyAsync(ws->buf[V_IN], in, (size_t)n * stride, hipMemcpyHostToDevice, stream));
+    int m = 0;
+    if ((rc = voxel_device(ws, stream, n, stride, leaf, &m, err))) return rc;
+    *d_result = m < 0 ? ws->buf[V_IN] : ws->buf[V_OUT];
+    *n_out = m < 0 ? n : m;
+    return SCL_OK;
+}
+
 int voxel_grid(IcpWorkspace *ws, hipStream_t stream, const void *in, int n, int stride, float leaf,
                void *out, int out_capacity, int *n_out, std::string *err)
 {

@@ -71,6 +71,7 @@ def _bind(lib):
         "scl_destroy": (c_int, [P]),
         "scl_make_and_save": (c_int, [P, P, c_int, c_int, c_int8, c_int, fp]),
         "scl_save_from_wire": (c_int, [P, fp, c_int8, c_int]),
+        "scl_make_and_save_filtered": (c_int, [P, P, c_int, c_int, c_float, c_int8, c_int, fp, ip]),
         "scl_detect_intra": (c_int, [P, c_int, ip, fp, dp]),
         "scl_detect_inter": (c_int, [P, c_int, ip, fp, dp]),
         "scl_get_index": (c_int, [P, c_int, POINTER(c_int8), ip]),
@@ -189,6 +190,14 @@ class ScanContextEngine:
         self._check(self._lib.scl_make_and_save(self._h, a.ctypes.data_as(c_void_p), n, stride,
                                                 robot, index, _ptr(out, c_float)), "scl_make_and_save")
         return out
+
+    def make_and_save_filtered(self, points, leaf, robot=0, index=0):
+        """makeDescriptors (DM.h:996-1002): voxel filter + descriptor + append, the filtered cloud stays on the device"""
+        a, n, stride = _cloud(points)
+        out = np.empty(self.R * self.S, dtype=np.float32); m = c_int()
+        self._check(self._lib.scl_make_and_save_filtered(self._h, a.ctypes.data_as(c_void_p), n, stride, leaf,
+                                                         robot, index, _ptr(out, c_float), byref(m)), "scl_make_and_save_filtered")
+        return out, m.value
 
     def save_from_wire(self, values, robot=0, index=0):
         v = _f32(values).reshape(-1)

@@ -24,13 +24,12 @@ Tinv = np.linalg.inv(rigid_transform(0.004, -0.006, 0.02, 0.25, -0.15, 0.05))
 src_moved = submap[::2].copy()
 src_moved[:, :3] = (submap[::2, :3].astype(np.float64) @ Tinv[:3, :3].T + Tinv[:3, 3]).astype(np.float32)
 p = eng.icp_default_params(); p.max_iterations = 30
-lat, parts = [], {"voxel": [], "descriptor+append": [], "detect": [], "icp": []}
+lat, parts = [], {"(merged)": [], "voxel+descriptor+append": [], "detect": [], "icp": []}
 for i in range(n_scans):
     scan = scans[i % len(scans)]
     t0 = time.perf_counter()
-    ds = eng.voxel_grid(scan, 0.4)                                         # descriptLeafSize, DM.h:185
-    t1 = time.perf_counter()
-    eng.make_and_save(ds, 0, n0 + i)
+    t1 = t0
+    eng.make_and_save_filtered(scan, 0.4, 0, n0 + i)                       # makeDescriptors, DM.h:996-1002 (descriptLeafSize, DM.h:185)
     t2 = time.perf_counter()
     lid, shift, dist = eng.detect_intra(n0 + i)
     t3 = time.perf_counter()

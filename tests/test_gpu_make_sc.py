@@ -59,3 +59,21 @@ def test_make_and_save_then_detect_keys():
         assert np.array_equal(eng.get_ringkey(i).view(np.uint32), db.ringkey(i).view(np.uint32))
     assert eng.get_size() == 5 and eng.get_index(3) == (1, 13) == db.get_index(3)
     eng.close()
+
+
+def test_filtered_make_and_save_equals_two_calls():
+    """makeDescriptors in one call (voxel filter + descriptor on the device) == scl_voxel_grid followed by
+    scl_make_and_save: same wire values, same keys, same database entry; also the leaf-too-small case in which
+    PCL returns the input unchanged."""
+    from scl_slam_amd.synth import synth_scan
+    R, S = 64, 120
+    for n, leaf in ((60000, 0.4), (240000, 0.2), (5000, 0.001), (0, 0.4)):
+        cloud = synth_scan(n, seed=7 + n) if n else np.zeros((0, 8), np.float32)
+        e1 = ScanContextEngine(num_ring=R, num_sector=S); e2 = ScanContextEngine(num_ring=R, num_sector=S)
+        v1 = e1.make_and_save(e1.voxel_grid(cloud, leaf) if n else cloud, 0, 0)
+        v2, m = e2.make_and_save_filtered(cloud, leaf, 0, 0)
+        assert np.array_equal(v1.view(np.uint32), v2.view(np.uint32))
+        assert m == (e1.voxel_grid(cloud, leaf).shape[0] if n else 0)
+        assert np.array_equal(e1.get_ringkey(0).view(np.uint32), e2.get_ringkey(0).view(np.uint32))
+        assert np.array_equal(e1.get_sectorkey(0).view(np.uint64), e2.get_sectorkey(0).view(np.uint64))
+        e1.close(); e2.close()
