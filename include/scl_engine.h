@@ -260,6 +260,17 @@ int  scl_loop_icp_from_store(scl_engine *e, int robot, int key_cur, const float 
                              const scl_icp_params *p, int min_src_points, int min_tgt_points,
                              float T[16], float *fitness, int *converged, int *iterations, int *n_src, int *n_tgt);
 
+/* geometricVerificationService (DM.h:1189-1268) with the submap taken from the keyframe store: voxel filter of
+ * the received cloud (src_leaf), submap(key_pre, search_num) from stored keyframes (leaf), size gate
+ * (DM.h:1204), then exactly scl_geometric_verification's correspondences -> RANSAC -> SVD -> inlier gate;
+ * no cloud but the received one crosses PCIe. */
+int  scl_geometric_verification_from_store(scl_engine *e, const void *src, int n_src, int stride_bytes, float src_leaf,
+                                           int robot, int key_pre, int search_num, const float *poses_pre, float leaf,
+                                           int min_src_points, int min_tgt_points,
+                                           int ransac_iterations, double inlier_threshold, double inlier_ratio, uint64_t seed,
+                                           float T[16], int *success, int *n_src_filtered, int *n_tgt,
+                                           int *n_correspondences, int *n_inliers);
+
 /* ---- measurement ----------------------------------------------------------- */
 int  scl_profile_enable(scl_engine *e, int on);   /* 0 off, 1 every kernel family, 2 SC distance only,
                                                      3 SC distance only, one launch in eight (an event pair

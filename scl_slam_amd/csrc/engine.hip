@@ -1385,6 +1385,46 @@ int scl_loop_icp_from_store(scl_engine *e, int robot, int key_cur, const float *
     return rc;
 }
 
+int scl_geometric_verification_from_store(scl_engine *e, const void *src, int n_src, int stride_bytes, float src_leaf,
+                                          int robot, int key_pre, int search_num, const float *poses_pre, float leaf,
+                                          int min_src_points, int min_tgt_points,
+                                          int ransac_iterations, double inlier_threshold, double inlier_ratio, uint64_t seed,
+                                          float T[16], int *success, int *n_src_filtered, int *n_tgt,
+                                          int *n_correspondences, int *n_inliers)
+{
+    if (!e || (!src && n_src > 0) || !poses_pre || !T) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    const int stride = e->kf_stride ? e->kf_stride : stride_bytes;
+    if (stride != stride_bytes) return fail(e, SCL_ERR_INVALID_ARG, "geometric_verification_from_store: stride differs from the store's");
+    std::string err;
+    int ns = 0, nt = 0, rc;
+    const void *d_res = nullptr;
+    // received cloud: downSizeFilterICP (DM.h:1199-1201), stays on the device
+    rc = voxel_grid_to_device(&e->vox_ws, e->stream, src, n_src, stride, src_leaf, &d_res, &ns, &err);
+    if (!rc) rc = icp_stage_cloud(&e->icp_ws, e->stream, false, d_res, ns, stride, &err);
+    if (rc) { e->last_error = err; return rc; }
+    // submap around the matched keyframe (DM.h:1202) from the keyframe store
+    std::vector<const void *> clouds; std::vector<int> counts; std::vector<float> Tw;
+    rc = kf_window(e, robot, key_pre, search_num, poses_pre, &clouds, &counts, &Tw);
+    if (rc) return rc;
+    rc = assemble_submap_ex(&e->vox_ws, e->stream, clouds.data(), counts.data(), Tw.data(), (int)clouds.size(), stride, leaf,
+                            true, nullptr, 0, &d_res, &nt, &err);
+    if (!rc) rc = icp_stage_cloud(&e->icp_ws, e->stream, true, d_res, nt, stride, &err);
+    if (rc) { e->last_error = err; return rc; }
+    if (n_src_filtered) *n_src_filtered = ns;
+    if (n_tgt) *n_tgt = nt;
+    for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+    if (success) *success = 0;
+    if (n_correspondences) *n_correspondences = 0;
+    if (n_inliers) *n_inliers = 0;
+    if (ns < min_src_points || nt < min_tgt_points) return SCL_OK;    // DM.h:1204: clouds too small
+    rc = icp_geometric_verification_staged(&e->icp_ws, e->stream, ns, nt, stride, ransac_iterations, inlier_threshold,
+                                           inlier_ratio, (unsigned long long)seed, T, success, n_correspondences, n_inliers, &err);
+    if (rc) e->last_error = err;
+    return rc;
+}
+
 /* ---- measurement ------------------------------------------------------------- */
 
 int scl_profile_enable(scl_engine *e, int on)

@@ -1256,14 +1256,28 @@ int icp_geometric_verification(IcpWorkspace *ws, hipStream_t stream, int num_cu,
     (void)num_cu;
     int rc = check_cloud_args(n_src, n_tgt, stride, err);
     if (rc) return rc;
+    if (n_src >= 3 && n_tgt >= 1) {
+        if ((rc = upload(ws, B_SRC, src, (size_t)n_src * stride, stream, err))) return rc;
+        if ((rc = upload(ws, B_TGT, tgt, (size_t)n_tgt * stride, stream, err))) return rc;
+    }
+    return icp_geometric_verification_staged(ws, stream, n_src, n_tgt, stride, ransac_iterations, inlier_threshold,
+                                             inlier_ratio, seed, T, success, n_corr_out, n_inliers_out, err);
+}
+
+// the same on clouds already staged in the workspace (icp_stage_cloud / icp_stage_cloud_host)
+int icp_geometric_verification_staged(IcpWorkspace *ws, hipStream_t stream, int n_src, int n_tgt, int stride,
+                                      int ransac_iterations, double inlier_threshold, double inlier_ratio,
+                                      unsigned long long seed, float T[16], int *success, int *n_corr_out,
+                                      int *n_inliers_out, std::string *err)
+{
+    int rc = check_cloud_args(n_src, n_tgt, stride, err);
+    if (rc) return rc;
     for (int k = 0; k < 16; ++k) T[k] = (k % 5 == 0) ? 1.f : 0.f;
     if (success) *success = 0;
     if (n_corr_out) *n_corr_out = 0;
     if (n_inliers_out) *n_inliers_out = 0;
     if (n_src < 3 || n_tgt < 1) return SCL_OK;
     if (ransac_iterations < 1 || ransac_iterations > (1 << 20)) { if (err) *err = "ransac iterations out of range"; return SCL_ERR_INVALID_ARG; }
-    if ((rc = upload(ws, B_SRC, src, (size_t)n_src * stride, stream, err))) return rc;
-    if ((rc = upload(ws, B_TGT, tgt, (size_t)n_tgt * stride, stream, err))) return rc;
     if ((rc = ensure(ws, B_WORK, sizeof(float4) * (size_t)(n_src + 1), err))) return rc;
     if ((rc = ensure(ws, B_NNI, sizeof(int) * (size_t)(n_src + 1), err))) return rc;
     if ((rc = ensure(ws, B_NND, sizeof(float) * (size_t)(n_src + 1), err))) return rc;

@@ -48,6 +48,11 @@ int icp_geometric_verification(IcpWorkspace *ws, hipStream_t stream, int num_cu,
                                double inlier_ratio, unsigned long long seed, float T[16], int *success, int *n_corr_out,
                                int *n_inliers_out, std::string *err);
 
+int icp_geometric_verification_staged(IcpWorkspace *ws, hipStream_t stream, int n_src, int n_tgt, int stride,
+                                      int ransac_iterations, double inlier_threshold, double inlier_ratio,
+                                      unsigned long long seed, float T[16], int *success, int *n_corr_out,
+                                      int *n_inliers_out, std::string *err);
+
 // voxel.hip (a separate workspace instance is used: buffer slots differ from icp.hip's)
 int voxel_grid(IcpWorkspace *ws, hipStream_t stream, const void *in, int n, int stride, float leaf,
                void *out, int out_capacity, int *n_out, std::string *err);

@@ -109,6 +109,8 @@ def _bind(lib):
         "scl_submap_from_store": (c_int, [P, c_int, c_int, c_int, fp, c_float, P, c_int, ip]),
         "scl_loop_icp_from_store": (c_int, [P, c_int, c_int, fp, c_int, c_int, fp, c_float, POINTER(IcpParams), c_int, c_int,
                                             fp, fp, ip, ip, ip, ip]),
+        "scl_geometric_verification_from_store": (c_int, [P, P, c_int, c_int, c_float, c_int, c_int, c_int, fp, c_float, c_int, c_int,
+                                                          c_int, c_double, c_double, c_uint64, fp, ip, ip, ip, ip, ip]),
         "scl_profile_enable": (c_int, [P, c_int]),
         "scl_profile_reset": (c_int, [P]),
         "scl_profile_get": (c_int, [P, POINTER(SclProfile)]),
@@ -499,6 +501,20 @@ class ScanContextEngine:
                                                       _ptr(T, c_float), byref(fit), byref(conv), byref(it), byref(ns), byref(nt)),
                     "scl_loop_icp_from_store")
         return T.reshape(4, 4), fit.value, bool(conv.value), it.value, ns.value, nt.value
+
+    def geometric_verification_from_store(self, src, src_leaf, robot, key_pre, search_num, poses_pre, leaf,
+                                          ransac_iterations=1000, inlier_threshold=0.25, inlier_ratio=0.45, seed=1,
+                                          min_src_points=300, min_tgt_points=1000):
+        """geometricVerificationService (DM.h:1189-1268) against a submap of stored keyframes"""
+        a, n, stride = _cloud(src)
+        Tp = _f32(np.asarray(poses_pre)).reshape(-1, 16)
+        assert Tp.shape[0] == 2 * search_num + 1
+        T = np.empty(16, dtype=np.float32); ok = c_int(); ns = c_int(); nt = c_int(); nc = c_int(); ni = c_int()
+        self._check(self._lib.scl_geometric_verification_from_store(
+            self._h, a.ctypes.data_as(c_void_p), n, stride, src_leaf, robot, key_pre, search_num, _ptr(Tp, c_float), leaf,
+            min_src_points, min_tgt_points, ransac_iterations, inlier_threshold, inlier_ratio, seed,
+            _ptr(T, c_float), byref(ok), byref(ns), byref(nt), byref(nc), byref(ni)), "scl_geometric_verification_from_store")
+        return T.reshape(4, 4), bool(ok.value), ns.value, nt.value, nc.value, ni.value
 
     # -- measurement ------------------------------------------------------------
     def profile_enable(self, on=True):

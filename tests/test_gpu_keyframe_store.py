@@ -102,3 +102,29 @@ def test_loop_icp_from_store_equals_icp_on_submaps():
         assert not conv3 and it3 == 0 and np.array_equal(T3, ident)
     finally:
         e.close()
+
+
+def test_service_verification_from_store_equals_stepwise():
+    """geometricVerificationService with the submap from the store == voxel filter + submap + scl_geometric_verification"""
+    e = ScanContextEngine()
+    try:
+        base = synth_structured_cloud(30000, seed=13)
+        ident = np.eye(4, dtype=np.float32)
+        for k in range(7):
+            e.keyframe_put(0, k, base[k::3][:8000].copy())
+        T = rigid_transform(0.02, -0.01, 0.03, 0.3, -0.2, 0.05)
+        received = moved_copy(base, T, keep_every=3, noise=0.01)
+        received[::9, :3] += 2.5                                      # outliers for the RANSAC stage
+        sn = 2
+        poses = [ident] * (2 * sn + 1)
+        Tg, ok, ns, nt, nc, ni = e.geometric_verification_from_store(received, 0.2, 0, 3, sn, poses, 0.3, 1000, 0.25, 0.45, 7)
+        src = e.voxel_grid(received, 0.2)
+        tgt = e.submap_from_store(0, 3, sn, poses, 0.3, 60000)
+        Ts, oks, ncs, nis = e.geometric_verification(src, tgt, 1000, 0.25, 0.45, 7)
+        assert (ns, nt) == (src.shape[0], tgt.shape[0]) and (ok, nc, ni) == (oks, ncs, nis)
+        assert np.array_equal(Tg.view(np.uint32), Ts.view(np.uint32)) and ni > 100
+        # size gate (DM.h:1204)
+        T2, ok2, *_ = e.geometric_verification_from_store(received, 0.2, 0, 3, sn, poses, 0.3, min_src_points=10 ** 7)
+        assert not ok2 and np.array_equal(T2, ident)
+    finally:
+        e.close()
