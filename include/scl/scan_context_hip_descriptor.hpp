@@ -108,6 +108,19 @@ public:
 
     scl_engine *engine() { return engine_; }   // for the geometric-verification calls (scl_icp_align ...)
 
+    // Not part of scan_descriptor: makeDescriptors' filter + descriptor + append (DM.h:996-1002) in one call; the
+    // filtered cloud never leaves the device.  Same return value as makeAndSaveDescriptorAndKey on the
+    // VoxelGrid(leaf)-filtered scan.
+    std::vector<float> makeAndSaveDescriptorAndKeyFiltered(const pcl::PointCloud<pcl::PointXYZI> &rawScan, float leaf,
+                                                           const int8_t robot, const int index)
+    {
+        std::vector<float> vT(static_cast<size_t>(cells_), 0.0f);
+        report(scl_make_and_save_filtered(engine_, rawScan.points.data(), static_cast<int>(rawScan.points.size()),
+                                          static_cast<int>(sizeof(pcl::PointXYZI)), leaf, robot, index, vT.data(), nullptr),
+               "makeAndSaveDescriptorAndKeyFiltered");
+        return vT;
+    }
+
 private:
     bool report(int rc, const char *where) const
     {

@@ -61,6 +61,25 @@ int main(int argc, char **argv)
     for (int cur = n_keyframes - 30; cur < n_keyframes; ++cur) {
         if (remote->detectIntraLoopClosureID(cur) != scanDescriptor->detectIntraLoopClosureID(cur)) { std::printf("FAIL wire parity\n"); return 1; }
     }
+    // makeDescriptors in one call (filter + descriptor on the device) == scl_voxel_grid followed by the virtual
+    {
+        scan_context_hip_descriptor a, b;
+        pcl::PointCloud<pcl::PointXYZI> raw;
+        for (int i = 0; i < 30000; ++i) {
+            pcl::PointXYZI p;
+            p.x = (float)uni(-60, 60); p.y = (float)uni(-60, 60); p.z = (float)uni(-1.5, 6.0); p.intensity = (float)uni(0, 1);
+            raw.points.push_back(p);
+        }
+        pcl::PointCloud<pcl::PointXYZI> filtered;
+        filtered.points.resize(raw.points.size());
+        int m = 0;
+        if (scl_voxel_grid(a.engine(), raw.points.data(), (int)raw.points.size(), (int)sizeof(pcl::PointXYZI), 0.4f,
+                           filtered.points.data(), (int)filtered.points.size(), &m) != SCL_OK) { std::printf("FAIL voxel\n"); return 1; }
+        filtered.points.resize((size_t)m);
+        const std::vector<float> two_calls = a.makeAndSaveDescriptorAndKey(filtered, 0, 0);
+        const std::vector<float> one_call = b.makeAndSaveDescriptorAndKeyFiltered(raw, 0.4f, 0, 0);
+        if (two_calls != one_call) { std::printf("FAIL filtered descriptor\n"); return 1; }
+    }
     const std::pair<int, float> inter = remote->detectInterLoopClosureID(n_keyframes - 1);
     std::printf("inter: loop %d yaw %.4f\n", inter.first, inter.second);
     std::printf("ADAPTER OK\n");
