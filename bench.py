@@ -44,9 +44,10 @@ def parse_args():
     ap.add_argument("--keyframes", type=int, default=N_KEYFRAMES, help="keyframes per GPU")
     ap.add_argument("--pipeline", type=int, default=2, help="scans in flight (1 = strictly one after another)")
     ap.add_argument("--merge-every", type=int, default=16, help="N > 1: scans whose per-rank winners share one all-gather")
-    ap.add_argument("--scans-per-launch", type=int, default=2,
-                    help="incoming scans scored by one kernel launch (1..4): the second scan's workgroups take over CUs "
-                         "as the first scan's retire, so no CU idles in a launch tail")
+    ap.add_argument("--scans-per-launch", type=int, default=4,
+                    help="incoming scans scored by one kernel launch (1..4; the reference runs several robots, whose scans "
+                         "arrive together): the next scan's workgroups take over CUs as the previous scan's retire, so "
+                         "no CU idles in a launch tail")
     ap.add_argument("--native-chunk", type=int, default=64,
                     help="scans handed to the engine's native submit/collect pipeline per call (0: drive every scan from Python)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
