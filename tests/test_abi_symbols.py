@@ -57,3 +57,16 @@ def test_status_strings_and_defaults():
     assert (p.max_iterations, p.max_correspondence_dist) == (50, 100.0)
     assert (p.transformation_epsilon, p.euclidean_fitness_epsilon) == (1e-6, 1e-6)
     assert (p.estimator, p.normal_radius) == (0, 1.0)
+
+
+def test_header_is_plain_c99(tmp_path):
+    """the boundary is a C ABI: the header must compile as C99 with no C++ or torch types in it"""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "cabi.c"
+    src.write_text('#include "scl_engine.h"\nint main(void) { scl_config c; scl_icp_params p; (void)p; return scl_default_config(&c) == SCL_OK ? 0 : 1; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        "-fsyntax-only", str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
