@@ -11,10 +11,14 @@ distance per incoming scan").  `value` counts (query, keyframe) pairs scored per
 Multi-GPU (`--gpus N`, launched by torch.distributed.run, one rank per GPU): the keyframe
 database is sharded by keyframe index, every rank scores its own 10k-keyframe shard (weak
 scaling: N x 10k keyframes in total) with no data-path collective, and the per-query
-(distance, index, shift) minimum is exchanged with one RCCL all-gather of 24 bytes per rank.
+(distance, index, shift) minima are exchanged with one asynchronous RCCL all-gather of
+24 bytes per rank and scan per chunk of scans.
 
 Inputs are resident in HBM when the timed region starts (database shard + the query
-keyframes); only the 24-byte result leaves the device per step.
+keyframes); only the 24-byte result leaves the device per step.  Scans are handed to the
+engine in chunks (`--native-chunk`, 64): its C++ submit / collect pipeline puts
+`--scans-per-launch` (4) scans into one kernel launch and keeps `--pipeline` (2) launches
+enqueued, so the Python loop costs one call per chunk and a slow host does not starve the GPU.
 """
 import argparse
 import json
@@ -42,7 +46,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--keyframes", type=int, default=N_KEYFRAMES, help="keyframes per GPU")
-    ap.add_argument("--pipeline", type=int, default=2, help="scans in flight (1 = strictly one after another)")
+    ap.add_argument("--pipeline", type=int, default=2, help="kernel launches enqueued ahead (1 = strictly one after another)")
     ap.add_argument("--merge-every", type=int, default=16, help="N > 1: scans whose per-rank winners share one all-gather")
     ap.add_argument("--scans-per-launch", type=int, default=4,
                     help="incoming scans scored by one kernel launch (1..4; the reference runs several robots, whose scans "
