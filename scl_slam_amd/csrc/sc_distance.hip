@@ -380,7 +380,10 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScBatchArgs ab)
     // rotates: after the alignment has fixed the first evaluated shift s_start, the lane fetches
     // candidate columns (2l - s_start) mod S and +1.  The window address is the same for every
     // candidate and never wraps, so the b128 window reads are bank-conflict free.
-    const double2 *qwin = reinterpret_cast<const double2 *>(Qd + j0);
+    // (the idle lanes 60..63 read at their own 2 * lane, not at lane L-1's address: four lanes on lane 59's
+    // address put a second access on banks 44..47 of their ds_read_b128 lane group -- one extra LDS cycle on
+    // every window read, 20 % of the array's cycles in phase B.  What they read and accumulate is never stored.)
+    const double2 *qwin = reinterpret_cast<const double2 *>(Qd + 2 * lane);
     // fused ring-key scan: lane g < RG owns ring group g of the query key
     const bool rk_on = a.out_d2 != nullptr;
     float4 qrk = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -718,8 +721,9 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScBatchArgs ab)
                         const int x1 = x0 + 1;
                         const int c1 = x1 >= S ? x1 - S : x1;
                         double *row = simbuf + tt * SB;
-                        row[(c0 >> 1) + (c0 & 1) * HALF] = ok0[tt] ? s0[tt] : 0.0;          // skipped sectors add +0.0: same bits
-                        row[(c1 >> 1) + (c1 & 1) * HALF] = ok1[tt] ? s1[tt] : 0.0;          // (lanes >= L mirror lane L-1)
+                        // idle lanes hold no sectors: their stores go to the two spare doubles at the end of the row
+                        row[active ? (c0 >> 1) + (c0 & 1) * HALF : S] = ok0[tt] ? s0[tt] : 0.0;     // skipped sectors add +0.0: same bits
+                        row[active ? (c1 >> 1) + (c1 & 1) * HALF : S + 1] = ok1[tt] ? s1[tt] : 0.0;
                         const int cnt = __popcll(__builtin_amdgcn_ballot_w64(active && ok0[tt])) + __popcll(__builtin_amdgcn_ballot_w64(active && ok1[tt]));
                         eff = (lane == tt) ? cnt : eff;
                     }
@@ -736,8 +740,8 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScBatchArgs ab)
                         const int c0 = x0 >= S ? x0 - S : x0;
                         const int c1 = x1 >= S ? x1 - S : x1;
                         double *row = simbuf + tt * SB;
-                        row[(c0 >> 1) + (c0 & 1) * HALF] = k0ok ? q0 : 0.0;
-                        row[(c1 >> 1) + (c1 & 1) * HALF] = k1ok ? q1 : 0.0;
+                        row[active ? (c0 >> 1) + (c0 & 1) * HALF : S] = k0ok ? q0 : 0.0;
+                        row[active ? (c1 >> 1) + (c1 & 1) * HALF : S + 1] = k1ok ? q1 : 0.0;
                         const int cnt = __popcll(__ballot(active && k0ok)) + __popcll(__ballot(active && k1ok));
                         eff = (lane == tt) ? cnt : eff;
                         __builtin_amdgcn_sched_barrier(0);
