@@ -339,8 +339,12 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScBatchArgs ab)
     double *simbuf = vk2;                      // [HSH][SB]
     // fp32 doubled candidate key, twice: pf[c][t + 2c] = p[t mod S] (c = 0, 1), so that the window of every lane
     // starts on a 16-byte boundary in one of the two copies; lives behind vk2 inside the wave's scratch
-    constexpr int PFS = 2 * S + 4;             // floats per copy
-    static_assert(2 * S + PFS <= wsz, "alignment filter scratch must fit the wave's scratch");
+    // copy 1 starts PFS floats after copy 0.  Even lanes read copy 0 and odd lanes copy 1, both in 16-byte steps
+    // of -16 B per lane pair; with the copies 128 B apart modulo 256 the two streams fall on complementary banks
+    // inside every ds_read_b128 lane group (the first fit, 2S + 4 floats, made them collide: 1.5 extra LDS cycles
+    // per window read of the filter).  The small grid has no room for the padding.
+    constexpr int PFS = (2 * S + 4 <= 288 && 2 * S + (288 + 2 * S + 4 + 1) / 2 <= wsz) ? 288 : 2 * S + 4;
+    static_assert(2 * S + (PFS + 2 * S + 4 + 1) / 2 <= wsz, "alignment filter scratch must fit the wave's scratch");
     float *pf = reinterpret_cast<float *>(vk2 + 2 * S);
     int *next_ticket = reinterpret_cast<int *>(wbase + nwaves * wsz);    // workgroup-wide candidate dispenser
 
@@ -444,8 +448,9 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScBatchArgs ab)
             *reinterpret_cast<f2 *>(pf + j0) = kf;          *reinterpret_cast<f2 *>(pf + j0 + S) = kf;
             *reinterpret_cast<f2 *>(pf1 + j0 + 2) = kf;     *reinterpret_cast<f2 *>(pf1 + j0 + S + 2) = kf;
             wave_fence();
-            const int E = S - j0;                             // doubled-key index of sector 0 at shift 2l
-            const float4 *pw = reinterpret_cast<const float4 *>((ll & 1) ? pf1 + E + 2 : pf + E);
+            const int E = S - 2 * lane;                       // doubled-key index of sector 0 at shift 2l (idle lanes 60..63:
+                                                              // their own, unused address -- lane 59's would conflict)
+            const float4 *pw = reinterpret_cast<const float4 *>((lane & 1) ? pf1 + E + 2 : pf + E);
             const float4 *q0w = reinterpret_cast<const float4 *>(vqf0);
             const float4 *q1w = reinterpret_cast<const float4 *>(vqf1);
             constexpr int NG = S / 4, FB = 3;                 // sector groups of four, FB groups per batch
