@@ -11,8 +11,14 @@ only exchange is the reduction of the per-rank winners:
   then every rank merges to the global top-k (ascending ring distance, ties -> lowest global
   index) and applies the reference's candidate loop including its float narrowing
   (descriptor.h:1645-1659);
-* full-DB mode (``detect_full``): one all-gather of one (distance, index, shift) record per
-  rank, global arg-min with ties -> lowest global index.
+* full-DB mode (``detect_full``, ``FullScanStream``): the min all-reduce north_star names, on
+  packed 64-bit keys.  fp64 distance + index + shift do not fit one 64-bit key without rounding
+  the distance (which would change near-tie winners), so the exact reduction takes two 8-byte
+  ``all_reduce(MIN)`` per scan: (1) the order-preserving integer image of the fp64 distance,
+  (2) ``global_index << 16 | shift`` contributed only by ranks whose local minimum equals the
+  global one (everyone else sends INT64_MAX) -> ties go to the lowest global index, exactly the
+  single-database rule.  ``exchange="allgather"`` keeps the round-1 all-gather + host merge as a
+  fallback to measure the collective's cost against.
 
 Messages are <= k * 32 bytes per rank: latency bound, xGMI bandwidth is irrelevant here.
 For a stream of scans (``FullScanStream``) the winners of ``merge_every`` scans travel in ONE
@@ -24,6 +30,41 @@ GLOBAL indices: rank r may use local slots ``l`` with ``l * G + r < cur - exclud
 import numpy as np
 
 BIG_DIST = 10000000.0
+I64_MAX = np.iinfo(np.int64).max
+
+
+def dist_to_key(d):
+    """fp64 distances -> int64 keys with the same order (IEEE bits; negative values have their
+    magnitude bits flipped).  Self-inverse up to the view: ``key_to_dist(dist_to_key(d)) == d``."""
+    b = np.ascontiguousarray(d, dtype=np.float64).view(np.int64)
+    return np.where(b >= 0, b, b ^ I64_MAX)
+
+
+def key_to_dist(k):
+    k = np.ascontiguousarray(k, dtype=np.int64)
+    return np.where(k >= 0, k, k ^ I64_MAX).view(np.float64)
+
+
+def pack_winner_keys(rec):
+    """rec: (m, 3) float64 rows (dist, global index or -1, shift) -> (key1, key2) int64 arrays.
+    key1 orders by distance (INT64_MAX = this rank has no candidate), key2 = index << 16 | shift."""
+    rec = np.asarray(rec, dtype=np.float64).reshape(-1, 3)
+    have = rec[:, 1] >= 0
+    k1 = np.where(have, dist_to_key(rec[:, 0]), I64_MAX)
+    k2 = np.where(have, (rec[:, 1].astype(np.int64) << 16) | (rec[:, 2].astype(np.int64) & 0xFFFF), I64_MAX)
+    return k1, k2
+
+
+def unpack_winner_keys(m1, m2):
+    """reduced keys -> list of (dist, global index, shift); no candidate anywhere -> (BIG_DIST, -1, 0)"""
+    out = []
+    d = key_to_dist(np.where(m1 == I64_MAX, 0, m1))
+    for j in range(len(m1)):
+        if m1[j] == I64_MAX or m2[j] == I64_MAX:
+            out.append((BIG_DIST, -1, 0))
+        else:
+            out.append((float(d[j]), int(m2[j] >> 16), int(m2[j] & 0xFFFF)))
+    return out
 
 
 def local_count(global_hi, rank, world):
@@ -35,9 +76,10 @@ def local_count(global_hi, rank, world):
 
 class ShardedLoopDetector:
     def __init__(self, engine, rank=0, world=1, group=None, device="cpu", num_candidates=3,
-                 num_exclude_recent=100, dist_thres=0.14):
+                 num_exclude_recent=100, dist_thres=0.14, exchange="allreduce"):
         self.engine, self.rank, self.world, self.group = engine, rank, world, group
         self.device = device
+        self.exchange = exchange
         self.k, self.exclude, self.thres = num_candidates, num_exclude_recent, dist_thres
         self.n_global = 0
         self.index_map = []                  # replicated (robot, index) map, descriptor.h:1758-1761
@@ -68,6 +110,16 @@ class ShardedLoopDetector:
         out = torch.empty((self.world * t.shape[0], t.shape[1]), dtype=t.dtype, device=self.device)
         dist.all_gather_into_tensor(out, t, group=self.group)      # concatenated along dim 0, rank order
         return out.cpu().numpy()
+
+    def _all_reduce_min(self, keys):
+        """int64 array -> element-wise minimum over the ranks (RCCL / gloo ``all_reduce(MIN)``)"""
+        if self.world == 1:
+            return keys
+        import torch
+        import torch.distributed as dist
+        t = torch.from_numpy(np.array(keys, dtype=np.int64, copy=True)).to(self.device)   # copy: the reduction is in place
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return t.cpu().numpy()
 
     # ---- detection ---------------------------------------------------------------------
     def detect_intra(self, cur, values_cur):
@@ -102,6 +154,14 @@ class ShardedLoopDetector:
         self.engine.stage_query(values_cur)
         nn, sh, d = self.engine.detect_full_range(-1, 0, hi)
         rec = np.array([[d, float(nn * self.world + self.rank) if nn >= 0 else -1.0, float(sh)]], dtype=np.float64)
+        if self.exchange == "allreduce":
+            k1, k2 = pack_winner_keys(rec)
+            m1 = self._all_reduce_min(k1)
+            m2 = self._all_reduce_min(np.where(k1 == m1, k2, I64_MAX))
+            d, g, sh = unpack_winner_keys(m1, m2)[0]
+            if g < 0:
+                return -1, -1, 0, BIG_DIST
+            return (g if d < self.thres else -1), g, sh, d
         allr = self._all_gather(rec)
         allr = allr[allr[:, 1] >= 0]
         if len(allr) == 0:
@@ -123,8 +183,10 @@ class FullScanStream:
     """
 
     def __init__(self, engine, rank=0, world=1, group=None, device="cpu", depth=2, merge_every=16, scans_per_launch=1,
-                 always_exchange=False, native_chunk=0):
+                 always_exchange=False, native_chunk=0, exchange="allreduce"):
         self.engine, self.rank, self.world, self.group, self.device = engine, rank, world, group, device
+        self.exchange = exchange                            # "allreduce": two min all-reduces on packed keys; "allgather": host merge
+        self.stage1 = self.stage2 = None                    # all-reduce pipeline: batch b in phase 1, batch b-1 in phase 2
         self.always_exchange = always_exchange              # run the collective even for world == 1 (exercises the backend)
         # native_chunk > 0: database-resident queries are handed to scl_detect_full_stream in chunks of that many
         # scans (the submit / collect pipeline runs in the engine, the Python loop pays once per chunk); each
@@ -193,11 +255,39 @@ class FullScanStream:
             return
         import torch
         import torch.distributed as dist
+        if self.exchange == "allreduce":
+            # phase 1 of this batch starts now; phase 1 of the previous batch is awaited and its phase 2 started;
+            # phase 2 of the batch before that is awaited and delivered.  Nothing blocks on a collective that was
+            # enqueued in this call.
+            k1, k2 = pack_winner_keys(rec)
+            t1 = torch.from_numpy(k1.copy()).to(self.device)
+            w1 = dist.all_reduce(t1, op=dist.ReduceOp.MIN, group=self.group, async_op=True)
+            prev1, self.stage1 = self.stage1, (w1, t1, k1, k2)
+            self._advance(prev1)
+            return
         t = torch.from_numpy(rec).to(self.device)
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=self.device)
         work = dist.all_gather_into_tensor(out.view(-1, t.shape[1]), t, group=self.group, async_op=True)
         prev, self.pending = self.pending, (work, out, t)
         self._finish(prev)
+
+    def _advance(self, prev1):
+        """prev1 = a batch whose phase 1 (distance keys) is in flight: await it, start its phase 2 (index | shift of
+        the ranks that hold the minimum); the batch that was in phase 2 is awaited and delivered first (order)."""
+        import torch
+        import torch.distributed as dist
+        prev2, self.stage2 = self.stage2, None
+        if prev2 is not None:
+            w2, t2, m1 = prev2
+            w2.wait()
+            self.results.extend(unpack_winner_keys(m1, t2.cpu().numpy()))
+        if prev1 is not None:
+            w1, t1, k1, k2 = prev1
+            w1.wait()
+            m1 = t1.cpu().numpy()
+            t2 = torch.from_numpy(np.where(k1 == m1, k2, I64_MAX)).to(self.device)
+            w2 = dist.all_reduce(t2, op=dist.ReduceOp.MIN, group=self.group, async_op=True)
+            self.stage2 = (w2, t2, m1)
 
     def _finish(self, pending):
         if pending is None:
@@ -224,6 +314,9 @@ class FullScanStream:
         self._exchange()
         prev, self.pending = self.pending, None
         self._finish(prev)
+        while self.stage1 is not None or self.stage2 is not None:      # flush the all-reduce pipeline
+            prev1, self.stage1 = self.stage1, None
+            self._advance(prev1)
         return self.results
 
 

@@ -153,6 +153,35 @@ def test_candidate_verification_sharded_over_ranks():
     assert c1[2] and i1[2] >= 1
 
 
+def test_packed_winner_keys_order_and_ties():
+    """the two-phase min all-reduce on packed keys == lexicographic (distance, global index) arg-min, including
+    negative distances (1 - mean cosine can round below zero), exact ties and ranks without a candidate"""
+    from scl_slam_amd.sharded import BIG_DIST, I64_MAX, dist_to_key, key_to_dist, pack_winner_keys, unpack_winner_keys
+    d = np.array([-3e-16, -1e-300, 0.0, 5e-324, 1e-9, 0.1399999999999, 0.14, 1.0, 2.0, 1e7])
+    k = dist_to_key(d)
+    assert np.all(np.diff(k) > 0) and np.array_equal(key_to_dist(k).view(np.uint64), d.view(np.uint64))
+    rs = np.random.RandomState(3)
+    for world in (2, 3, 8):
+        m = 64
+        rec = np.zeros((world, m, 3))
+        rec[:, :, 0] = rs.choice([0.0, 0.05, 0.05 + 1e-17, 0.3, -2e-16, 1.0 - 2 ** -53], size=(world, m))
+        rec[:, :, 1] = rs.randint(0, 100000, size=(world, m)) * world + np.arange(world)[:, None]
+        rec[:, :, 2] = rs.randint(0, 120, size=(world, m))
+        rec[rs.random_sample((world, m)) < 0.2, 1] = -1.0
+        rec[:, 0, 1] = -1.0                                              # a scan no rank has a candidate for
+        keys = [pack_winner_keys(rec[r]) for r in range(world)]
+        m1 = np.min(np.stack([k1 for k1, _ in keys]), axis=0)
+        m2 = np.min(np.stack([np.where(k1 == m1, k2, I64_MAX) for k1, k2 in keys]), axis=0)
+        got = unpack_winner_keys(m1, m2)
+        for j in range(m):
+            r = rec[:, j, :]; r = r[r[:, 1] >= 0]
+            if len(r) == 0:
+                assert got[j] == (BIG_DIST, -1, 0)
+                continue
+            b = r[np.lexsort((r[:, 1], r[:, 0]))[0]]
+            assert got[j][1:] == (int(b[1]), int(b[2])) and np.float64(got[j][0]).view(np.uint64) == np.float64(b[0]).view(np.uint64)
+
+
 def test_local_count():
     for world in (1, 2, 3, 8):
         for hi in range(0, 40):
@@ -165,12 +194,12 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, curs, out_q):
+def _worker(rank, world, port, curs, exchange, out_q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     descs = synth_descriptors(N, R, S, seed=1001, revisit_frac=0.06)
     cfg = ob.make_config(R=R, S=S, k=K)
-    det = ShardedLoopDetector(OracleShardEngine(cfg), rank, world, num_candidates=K)
+    det = ShardedLoopDetector(OracleShardEngine(cfg), rank, world, num_candidates=K, exchange=exchange)
     for i in range(N):
         det.save(descs[i], 0, i)
     res = []
@@ -178,7 +207,7 @@ def _worker(rank, world, port, curs, out_q):
         res.append((cur, det.detect_intra(cur, descs[cur]), det.detect_full(cur, descs[cur])))
     # the same scans as a stream: winners of 4 scans per (asynchronous) all-gather, merged a batch later
     from scl_slam_amd.sharded import FullScanStream
-    st = FullScanStream(det.engine, rank, world, depth=2, merge_every=4)
+    st = FullScanStream(det.engine, rank, world, depth=2, merge_every=4, exchange=exchange)
     for cur in curs:
         det.engine.stage_query(descs[cur])
         st.submit(-1, 0, local_count(cur - det.exclude, rank, world))
@@ -188,15 +217,15 @@ def _worker(rank, world, port, curs, out_q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_equals_single_database(world):
+@pytest.mark.parametrize("world,exchange", [(2, "allreduce"), (3, "allreduce"), (2, "allgather")])
+def test_sharded_equals_single_database(world, exchange):
     descs, truth = synth_descriptors(N, R, S, seed=1001, revisit_frac=0.06, return_truth=True)
     curs = sorted({c for c, _, _ in truth} | {N - 1, 103, 104, 150})
     ref = ob.OracleDB(ob.make_config(R=R, S=S, k=K)); ref.save_bulk(descs)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, curs, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, curs, exchange, q)) for r in range(world)]
     for p in procs:
         p.start()
     try:
