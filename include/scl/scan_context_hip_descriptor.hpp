@@ -11,8 +11,20 @@
 //
 // The reference reports nothing but "-1 = no loop" (descriptor.h:1615,1678) and logs through
 // ROS; the adapter keeps that: engine errors are written to stderr and mapped to "no loop".
+//
+// Multi-GPU: pass the device ordinals of the node -- the keyframe database is then sharded by keyframe index over
+// them behind the same six virtuals (scl_create_sharded):
+//                              scanDescriptor = std::unique_ptr<scan_descriptor>(new scan_context_hip_descriptor({0, 1, 2, 3, 4, 5, 6, 7}));
+//
+// Lifetime: `scan_descriptor` has NO virtual destructor (descriptor.h:21-36) and distributedMapping.h owns the object
+// as std::unique_ptr<scan_descriptor> (DM.h:333), so deleting through that pointer never runs
+// ~scan_context_hip_descriptor(): the engine and its HBM (the whole keyframe database) would stay allocated until the
+// process ends -- which is also when the reference destroys the object, so nothing leaks at run time, but a host
+// that re-creates descriptors must call close() first (or give scan_descriptor a virtual destructor, one line at
+// descriptor.h:23).  close() is idempotent; every call after it reports "no engine" and returns "no loop".
 #pragma once
 
+#include <cfloat>
 #include <cstdint>
 #include <cstdio>
 #include <utility>
@@ -34,25 +46,42 @@ public:
         int numExcludeRecent   = 100,
         int treeMakingPeriod   = 10,
         double searchRatio     = 0.1,
-        int device             = 0)
+        int device             = 0,
+        // The live intra-robot search is libnabo's knn with optionFlags = 0 (descriptor.h:1631-1642), which skips
+        // neighbours whose squared ring-key distance is <= FLT_EPSILON (no self match): a yaw-only revisit has the
+        // SAME ring key as the query, and libnabo does not return it.  0 selects nanoflann's behaviour (every key
+        // counts), which the inter-robot path uses regardless of this value (descriptor.h:1710-1716).
+        float knnExcludeEps    = FLT_EPSILON)
     {
-        scl_config cfg;
-        scl_default_config(&cfg);
-        cfg.num_ring = numRing;                 cfg.num_sector = numSector;
-        cfg.num_candidates = numCandidates;     cfg.dist_thres = distThres;
-        cfg.lidar_height = lidarHeight;         cfg.max_radius = maxRadius;
-        cfg.num_exclude_recent = numExcludeRecent;
-        cfg.tree_making_period = treeMakingPeriod;
-        cfg.search_ratio = searchRatio;         cfg.device = device;
-        cells_ = numRing * numSector;
-        const int rc = scl_create(&cfg, &engine_);
-        if (rc != SCL_OK) {
-            std::fprintf(stderr, "[scan_context_hip_descriptor] scl_create failed: %s\n", scl_status_string(rc));
-            engine_ = nullptr;
-        }
+        init(numRing, numSector, numCandidates, distThres, lidarHeight, maxRadius, numExcludeRecent, treeMakingPeriod,
+             searchRatio, knnExcludeEps, &device, 1, false);
     }
 
-    ~scan_context_hip_descriptor() { scl_destroy(engine_); }
+    // the same database sharded by keyframe index over several GPUs (keyframe g on devices[g % devices.size()])
+    explicit scan_context_hip_descriptor(
+        const std::vector<int> &devices,
+        int numRing            = 20,
+        int numSector          = 60,
+        int numCandidates      = 3,
+        double distThres       = 0.14,
+        double lidarHeight     = 1.65,
+        double maxRadius       = 80.0,
+        int numExcludeRecent   = 100,
+        int treeMakingPeriod   = 10,
+        double searchRatio     = 0.1,
+        float knnExcludeEps    = FLT_EPSILON)
+    {
+        init(numRing, numSector, numCandidates, distThres, lidarHeight, maxRadius, numExcludeRecent, treeMakingPeriod,
+             searchRatio, knnExcludeEps, devices.data(), static_cast<int>(devices.size()), true);
+    }
+
+    ~scan_context_hip_descriptor() { close(); }
+    // releases the engine and its HBM; see "Lifetime" above
+    void close()
+    {
+        if (engine_) scl_destroy(engine_);
+        engine_ = nullptr;
+    }
     scan_context_hip_descriptor(const scan_context_hip_descriptor &) = delete;
     scan_context_hip_descriptor &operator=(const scan_context_hip_descriptor &) = delete;
 
@@ -122,8 +151,33 @@ public:
     }
 
 private:
+    void init(int numRing, int numSector, int numCandidates, double distThres, double lidarHeight, double maxRadius,
+              int numExcludeRecent, int treeMakingPeriod, double searchRatio, float knnExcludeEps,
+              const int *devices, int n_devices, bool sharded)
+    {
+        scl_config cfg;
+        scl_default_config(&cfg);
+        cfg.num_ring = numRing;                 cfg.num_sector = numSector;
+        cfg.num_candidates = numCandidates;     cfg.dist_thres = distThres;
+        cfg.lidar_height = lidarHeight;         cfg.max_radius = maxRadius;
+        cfg.num_exclude_recent = numExcludeRecent;
+        cfg.tree_making_period = treeMakingPeriod;
+        cfg.search_ratio = searchRatio;         cfg.device = n_devices > 0 ? devices[0] : 0;
+        cfg.knn_exclude_eps = knnExcludeEps;
+        cells_ = numRing * numSector;
+        const int rc = sharded ? scl_create_sharded(&cfg, devices, n_devices, 0, &engine_) : scl_create(&cfg, &engine_);
+        if (rc != SCL_OK) {
+            std::fprintf(stderr, "[scan_context_hip_descriptor] engine creation failed: %s\n", scl_status_string(rc));
+            engine_ = nullptr;
+        }
+    }
+
     bool report(int rc, const char *where) const
     {
+        if (!engine_) {
+            std::fprintf(stderr, "[scan_context_hip_descriptor] %s: no engine (creation failed or close() was called)\n", where);
+            return false;
+        }
         if (rc == SCL_OK) return true;
         std::fprintf(stderr, "[scan_context_hip_descriptor] %s: %s (%s)\n", where, scl_status_string(rc),
                      engine_ ? scl_last_error(engine_) : "no engine");

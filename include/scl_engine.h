@@ -84,6 +84,19 @@ int  scl_abi_version(void);
 int  scl_default_config(scl_config *cfg);
 int  scl_create(const scl_config *cfg, scl_engine **out);     /* ctor, D.h:1307-1344 */
 int  scl_destroy(scl_engine *e);
+/* The same constructor for ONE keyframe database sharded over the GPUs of a node (BASELINE configs[3]): one
+ * process, one engine state per entry of devices[], keyframe g on shard g % n_devices; every entry point of this
+ * header works on the returned engine exactly as on a one-GPU engine (same results, bit for bit: the search
+ * range of D.h:1627 is applied on global indices, ties go to the lowest global index).  Scoring needs no
+ * exchange; the per-shard winners of the full-DB mode are reduced with two RCCL min all-reduces on packed 64-bit
+ * keys (exchange = 2; needs every shard on its own device), or on the host from pinned memory (exchange = 1);
+ * exchange = 0 picks RCCL when n_devices > 1 and the devices are distinct, else the host merge.  The same device
+ * may be listed more than once (several shards on one GPU: rehearsal of the multi-GPU path on a one-GPU box).
+ * Geometric verification of one scan's candidates (scl_icp_align_batch) is spread over the shards by candidate;
+ * other geometry calls and the keyframe store live on devices[0].  cfg->device is ignored. */
+int  scl_create_sharded(const scl_config *cfg, const int *devices, int n_devices, int exchange, scl_engine **out);
+/* number of shards (1 for scl_create) and the exchange in use (0 none, 1 host merge, 2 RCCL); either may be NULL */
+int  scl_shard_info(const scl_engine *e, int *n_shards, int *exchange);
 
 /* ---- the six virtuals of scan_descriptor (D.h:21-36) ----------------------- */
 

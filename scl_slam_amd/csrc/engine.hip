@@ -18,92 +18,9 @@
 #include <thread>
 #include <vector>
 
-#include "icp.hpp"
-#include "kernels.hpp"
+#include "engine_internal.hpp"
 
 using namespace scl;
-
-namespace {
-
-enum ProfKind { P_SC = 0, P_TOPK, P_ARGMIN, P_MAKESC, P_INGEST, P_ICPNN, P_ICPRED, P_COUNT };
-
-struct PendingEvent { hipEvent_t start, stop; int kind; };
-
-}  // namespace
-
-struct scl_engine {
-    scl_config cfg;
-    int R = 0, S = 0, RG = 0, R4 = 0, SR = 0;
-    int device = 0, num_cu = 256;
-    hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;                         // ring-key scan runs beside the SC distance
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    double *h_out3 = nullptr;                              // pinned, device-visible: the arg-min kernel writes it directly
-    static constexpr int kSlots = 8;                       // full-DB passes in flight (submit/collect)
-    hipEvent_t ev_done[kSlots] = {nullptr};
-    int slot_lo[kSlots] = {0}; bool slot_busy[kSlots] = {false}; bool slot_empty[kSlots] = {false};
-    int slot_ev[kSlots] = {0};                             // which slot's event completes this one (batched launches share one)
-    unsigned next_slot = 0;
-    mutable std::mutex mu;
-    mutable std::string last_error;
-
-    // database (layout: kernels.hpp)
-    int n = 0, cap = 0;
-    float4 *d_desc = nullptr; double *d_vkey = nullptr; double *d_norm = nullptr;
-    float *d_rkey = nullptr; float4 *d_rkey4 = nullptr;
-    std::vector<int8_t> robots;
-    std::vector<int> indexs;
-
-    // staged external query (one slot, cap = 1 layout)
-    float4 *q_desc = nullptr; double *q_vkey = nullptr; double *q_norm = nullptr;
-    float *q_rkey = nullptr; float4 *q_rkey4 = nullptr;
-    bool staged = false;
-
-    // scratch
-    float *d_vals = nullptr; size_t vals_cap = 0;          // wire-format staging (floats)
-    unsigned char *d_points = nullptr; size_t points_cap = 0;
-    int *d_tile = nullptr;
-    double *d_dist = nullptr; int *d_shift = nullptr; int *d_cand = nullptr; float *d_ring_d2 = nullptr; size_t pair_cap = 0;
-    unsigned long long *d_topk_scratch = nullptr; int *d_topk_idx = nullptr; float *d_topk_d2 = nullptr;
-    double *d_out3 = nullptr;
-    unsigned long long *d_blk_part = nullptr; unsigned int *d_done_counter = nullptr;   // fused full-DB epilogue
-    // Second lane for fused full-DB passes: consecutive passes alternate between `stream` and `stream_alt`
-    // (own epilogue scratch and per-pair outputs), so the next pass's workgroups move onto CUs as the previous
-    // pass's workgroups retire instead of waiting behind its completion packet.
-    hipStream_t stream_alt = nullptr;
-    hipEvent_t ev_db = nullptr;                            // database writes on `stream` the alt lane must see
-    uint64_t db_version = 0, alt_seen_version = 0;
-    unsigned long long *a_blk_part = nullptr; unsigned int *a_done_counter = nullptr;
-    int *a_topk_idx = nullptr; float *a_topk_d2 = nullptr;
-    double *a_dist = nullptr; int *a_shift = nullptr; float *a_ring_d2 = nullptr; size_t a_pair_cap = 0;
-    bool last_pass_alt = false;
-    bool alt_lane = false;                                 // SCL_ALT_LANE=1: lowest latency per scan; kernels of the two lanes overlap,
-                                                           // so per-kernel durations no longer measure one pass (default off)
-    void *h_pinned = nullptr; size_t pinned_cap = 0;       // small result read-back
-
-    // inter-robot tree bookkeeping (descriptor.h:1691-1703, counter initialised: see DESIGN.md)
-    int tree_counter = 0, tree_n = 0;
-
-    // profiling
-    int prof_on = 0;                                       // 0 off, 1 every kernel family, 2 SC distance only, 3 SC distance sampled 1:8
-    unsigned prof_tick = 0;
-    scl_profile prof{};
-    std::vector<PendingEvent> pending;
-    std::vector<hipEvent_t> event_pool;
-
-    IcpWorkspace icp_ws;
-    IcpWorkspace vox_ws;
-    static constexpr int kIcpLanes = 4;                    // concurrent alignments of scl_icp_align_batch
-    IcpWorkspace icp_lane_ws[kIcpLanes];
-    hipStream_t icp_lane_stream[kIcpLanes] = {nullptr};
-
-    // on-device keyframe store (robots[id].keyFrameArray, DM.h:86): clouds live in slabs of HBM, bump allocated
-    struct StoredCloud { unsigned char *d = nullptr; int n = -1; size_t cap_bytes = 0; };
-    std::vector<std::vector<StoredCloud>> kf;              // [robot][index]; n < 0: never stored
-    std::vector<void *> kf_slabs;
-    size_t kf_slab_used = 0, kf_slab_cap = 0;
-    int kf_stride = 0;                                     // fixed by the first put
-};
 
 namespace {
 
@@ -199,12 +116,11 @@ DbView db_view(const scl_engine *e)
 
 int query_view(const scl_engine *e, int query, QueryView *q)
 {
-    if (query == SCL_QUERY_STAGED) {
-        if (!e->staged) return fail(e, SCL_ERR_INVALID_ARG, "no staged query (call scl_stage_query first)");
-        q->desc = e->q_desc; q->vkey = e->q_vkey; q->norm = e->q_norm; q->rkey = e->q_rkey;
-        return SCL_OK;
-    }
-    if (query < 0 || query >= e->n) return fail(e, SCL_ERR_OUT_OF_RANGE, "query slot out of range");
+    if (query < 0) {                                       // staging slot j = -1 - query
+        const int j = -1 - query;
+        if (j >= scl_engine::kStage || !e->staged[j]) return fail(e, SCL_ERR_INVALID_ARG, "no staged query (call scl_stage_query first)");
+        query = e->cap + j;
+    } else if (query >= e->n) return fail(e, SCL_ERR_OUT_OF_RANGE, "query slot out of range");
     q->desc = e->d_desc + (size_t)query * e->RG * e->S;
     q->vkey = e->d_vkey + (size_t)query * e->S;
     q->norm = e->d_norm + (size_t)query * e->S;
@@ -221,10 +137,11 @@ int ensure_capacity(scl_engine *e, int need)
     const size_t tile = (size_t)e->RG * e->S;
     float4 *nd = nullptr; double *nv = nullptr; double *nn = nullptr; float *nr = nullptr; float4 *nr4 = nullptr;
     int rc;
-    if ((rc = dev_alloc(e, &nd, tile * ncap))) return rc;
-    if ((rc = dev_alloc(e, &nv, (size_t)e->S * ncap))) return rc;
-    if ((rc = dev_alloc(e, &nn, (size_t)e->S * ncap))) return rc;
-    if ((rc = dev_alloc(e, &nr, (size_t)e->R4 * ncap))) return rc;
+    const size_t nst = (size_t)ncap + scl_engine::kStage;     // database slots + the staging slots behind them
+    if ((rc = dev_alloc(e, &nd, tile * nst))) return rc;
+    if ((rc = dev_alloc(e, &nv, (size_t)e->S * nst))) return rc;
+    if ((rc = dev_alloc(e, &nn, (size_t)e->S * nst))) return rc;
+    if ((rc = dev_alloc(e, &nr, (size_t)e->R4 * nst))) return rc;
     if ((rc = dev_alloc(e, &nr4, (size_t)e->RG * ncap))) return rc;
     SCL_HIP(e, hipMemsetAsync(nr4, 0, sizeof(float4) * (size_t)e->RG * ncap, e->stream));
     if (e->n > 0) {
@@ -234,6 +151,13 @@ int ensure_capacity(scl_engine *e, int need)
         SCL_HIP(e, hipMemcpyAsync(nr, e->d_rkey, sizeof(float) * (size_t)e->R4 * e->n, hipMemcpyDeviceToDevice, e->stream));
         SCL_HIP(e, hipMemcpy2DAsync(nr4, sizeof(float4) * ncap, e->d_rkey4, sizeof(float4) * e->cap,
                                     sizeof(float4) * e->n, e->RG, hipMemcpyDeviceToDevice, e->stream));
+    }
+    if (e->cap > 0) {                                      // staged queries move with the arrays
+        const size_t k = scl_engine::kStage;
+        SCL_HIP(e, hipMemcpyAsync(nd + tile * ncap, e->d_desc + tile * e->cap, sizeof(float4) * tile * k, hipMemcpyDeviceToDevice, e->stream));
+        SCL_HIP(e, hipMemcpyAsync(nv + (size_t)e->S * ncap, e->d_vkey + (size_t)e->S * e->cap, sizeof(double) * e->S * k, hipMemcpyDeviceToDevice, e->stream));
+        SCL_HIP(e, hipMemcpyAsync(nn + (size_t)e->S * ncap, e->d_norm + (size_t)e->S * e->cap, sizeof(double) * e->S * k, hipMemcpyDeviceToDevice, e->stream));
+        SCL_HIP(e, hipMemcpyAsync(nr + (size_t)e->R4 * ncap, e->d_rkey + (size_t)e->R4 * e->cap, sizeof(float) * e->R4 * k, hipMemcpyDeviceToDevice, e->stream));
     }
     SCL_HIP(e, hipStreamSynchronize(e->stream));
     if (e->stream_alt) SCL_HIP(e, hipStreamSynchronize(e->stream_alt));   // passes still reading the old arrays
@@ -342,9 +266,10 @@ int launch_topk(scl_engine *e, const QueryView &q, int lo, int hi, int k, float 
     return SCL_OK;
 }
 
-// top-k in [lo,hi) followed by the SC distance of those k candidates; results on host.
-int topk_with_distance_locked(scl_engine *e, int query, int lo, int hi, int k, float eps,
-                              int *idx, float *d2, double *dist, int *shift, int *found)
+// top-k in [lo,hi) followed by the SC distance of those k candidates; enqueue puts the launches and the copies
+// into pinned memory on the engine's stream, finish waits for them and unpacks (the sharded front enqueues on
+// every device before it waits on any).
+int topk_enqueue_locked(scl_engine *e, int query, int lo, int hi, int k, float eps, bool want_dist, bool *have_dist)
 {
     if (k <= 0 || k > kTopkMaxK) return fail(e, SCL_ERR_INVALID_ARG, "k out of range (1..64)");
     QueryView q;
@@ -354,7 +279,8 @@ int topk_with_distance_locked(scl_engine *e, int query, int lo, int hi, int k, f
     if (hi > e->n) hi = e->n;
     if ((rc = ensure_pairs(e, (size_t)k))) return rc;
     if ((rc = launch_topk(e, q, lo, hi, k, eps))) return rc;
-    if (hi > lo && (dist || shift)) {
+    *have_dist = hi > lo && want_dist;
+    if (*have_dist) {
         if ((rc = launch_distance(e, q, e->d_topk_idx, 0, k))) return rc;
     }
     const size_t need = (size_t)k * (sizeof(int) * 2 + sizeof(float) + sizeof(double));
@@ -366,12 +292,22 @@ int topk_with_distance_locked(scl_engine *e, int query, int lo, int hi, int k, f
     int *h_shift = reinterpret_cast<int *>(h + (sizeof(int) + sizeof(float) + sizeof(double)) * k);
     SCL_HIP(e, hipMemcpyAsync(h_idx, e->d_topk_idx, sizeof(int) * k, hipMemcpyDeviceToHost, e->stream));
     SCL_HIP(e, hipMemcpyAsync(h_d2, e->d_topk_d2, sizeof(float) * k, hipMemcpyDeviceToHost, e->stream));
-    const bool have_dist = hi > lo && (dist || shift);
-    if (have_dist) {
+    if (*have_dist) {
         SCL_HIP(e, hipMemcpyAsync(h_dist, e->d_dist, sizeof(double) * k, hipMemcpyDeviceToHost, e->stream));
         SCL_HIP(e, hipMemcpyAsync(h_shift, e->d_shift, sizeof(int) * k, hipMemcpyDeviceToHost, e->stream));
     }
+    return SCL_OK;
+}
+
+int topk_finish_locked(scl_engine *e, int k, bool have_dist, int *idx, float *d2, double *dist, int *shift, int *found)
+{
+    int rc;
     if ((rc = sync(e))) return rc;
+    char *h = static_cast<char *>(e->h_pinned);
+    const int *h_idx = reinterpret_cast<int *>(h);
+    const float *h_d2 = reinterpret_cast<float *>(h + sizeof(int) * k);
+    const double *h_dist = reinterpret_cast<double *>(h + (sizeof(int) + sizeof(float)) * k);
+    const int *h_shift = reinterpret_cast<int *>(h + (sizeof(int) + sizeof(float) + sizeof(double)) * k);
     int nf = 0;
     for (int i = 0; i < k; ++i) {
         if (idx) idx[i] = h_idx[i];
@@ -382,6 +318,15 @@ int topk_with_distance_locked(scl_engine *e, int query, int lo, int hi, int k, f
     }
     if (found) *found = nf;
     return SCL_OK;
+}
+
+int topk_with_distance_locked(scl_engine *e, int query, int lo, int hi, int k, float eps,
+                              int *idx, float *d2, double *dist, int *shift, int *found)
+{
+    bool have_dist = false;
+    int rc = topk_enqueue_locked(e, query, lo, hi, k, eps, dist || shift, &have_dist);
+    if (rc) return rc;
+    return topk_finish_locked(e, k, have_dist, idx, d2, dist, shift, found);
 }
 
 }  // namespace
@@ -404,7 +349,7 @@ const char *scl_status_string(int status)
 
 const char *scl_last_error(const scl_engine *e) { return e ? e->last_error.c_str() : "null engine"; }
 
-int scl_abi_version(void) { return 3; }
+int scl_abi_version(void) { return 4; }
 
 int scl_default_config(scl_config *c)
 {
@@ -456,12 +401,6 @@ int scl_create(const scl_config *cfg, scl_engine **out)
     for (int i = 0; i < scl_engine::kSlots; ++i)
         if (hipEventCreateWithFlags(&e->ev_done[i], hipEventDisableTiming) != hipSuccess) return bail(SCL_ERR_HIP);
     if ((rc = ensure_capacity(e, 1))) return bail(rc);
-    const size_t tile = (size_t)e->RG * e->S;
-    if ((rc = dev_alloc(e, &e->q_desc, tile))) return bail(rc);
-    if ((rc = dev_alloc(e, &e->q_vkey, (size_t)e->S))) return bail(rc);
-    if ((rc = dev_alloc(e, &e->q_norm, (size_t)e->S))) return bail(rc);
-    if ((rc = dev_alloc(e, &e->q_rkey, (size_t)e->R4))) return bail(rc);
-    if ((rc = dev_alloc(e, &e->q_rkey4, (size_t)e->RG))) return bail(rc);
     if ((rc = dev_alloc(e, &e->d_tile, (size_t)e->R * e->S))) return bail(rc);
     if ((rc = dev_alloc(e, &e->d_topk_scratch, (size_t)kTopkMaxBlocks * kTopkMaxK))) return bail(rc);
     if ((rc = dev_alloc(e, &e->d_topk_idx, (size_t)kTopkMaxK * kMaxQueryBatch))) return bail(rc);
@@ -489,6 +428,7 @@ int scl_create(const scl_config *cfg, scl_engine **out)
 int scl_destroy(scl_engine *e)
 {
     if (!e) return SCL_OK;
+    if (e->front) return front_destroy(e);
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto &p : e->pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
@@ -501,7 +441,6 @@ int scl_destroy(scl_engine *e)
         if (e->icp_lane_stream[i]) (void)hipStreamDestroy(e->icp_lane_stream[i]);
     }
     dev_free(e->d_desc); dev_free(e->d_vkey); dev_free(e->d_norm); dev_free(e->d_rkey); dev_free(e->d_rkey4);
-    dev_free(e->q_desc); dev_free(e->q_vkey); dev_free(e->q_norm); dev_free(e->q_rkey); dev_free(e->q_rkey4);
     dev_free(e->d_vals); dev_free(e->d_points); dev_free(e->d_tile);
     dev_free(e->d_dist); dev_free(e->d_shift); dev_free(e->d_cand); dev_free(e->d_ring_d2);
     dev_free(e->d_topk_scratch); dev_free(e->d_topk_idx); dev_free(e->d_topk_d2); dev_free(e->d_out3);
@@ -527,6 +466,7 @@ int scl_make_and_save(scl_engine *e, const void *points, int n_points, int strid
                       int8_t robot, int index, float *out_values)
 {
     if (!e) return SCL_ERR_INVALID_ARG;
+    if (e->front) return front_make_and_save(e, points, n_points, stride_bytes, robot, index, out_values, false, 0.f, nullptr);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     int rc;
@@ -544,6 +484,7 @@ int scl_make_and_save_filtered(scl_engine *e, const void *points, int n_points, 
                                int8_t robot, int index, float *out_values, int *n_filtered)
 {
     if (!e) return SCL_ERR_INVALID_ARG;
+    if (e->front) return front_make_and_save(e, points, n_points, stride_bytes, robot, index, out_values, true, leaf, n_filtered);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     if (n_points < 0 || stride_bytes < 12 || (stride_bytes & 3)) return fail(e, SCL_ERR_INVALID_ARG, "bad point layout");
@@ -575,6 +516,7 @@ int scl_make_and_save_filtered(scl_engine *e, const void *points, int n_points, 
 int scl_make_descriptor(scl_engine *e, const void *points, int n_points, int stride_bytes, float *out_values)
 {
     if (!e || !out_values) return SCL_ERR_INVALID_ARG;
+    if (e->front) e = front_primary(e);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     int rc;
@@ -592,6 +534,7 @@ int scl_save_from_wire(scl_engine *e, const float *values, int8_t robot, int ind
 int scl_save_bulk(scl_engine *e, const float *values, int count, const int8_t *robots, const int *indexs)
 {
     if (!e || count < 0 || (count > 0 && !values)) return SCL_ERR_INVALID_ARG;
+    if (e->front) return front_save_bulk(e, values, count, robots, indexs);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     int rc;
@@ -617,6 +560,7 @@ int scl_save_bulk(scl_engine *e, const float *values, int count, const int8_t *r
 int scl_stage_query(scl_engine *e, const float *values)
 {
     if (!e || !values) return SCL_ERR_INVALID_ARG;
+    if (e->front) return front_stage_query(e, values);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     int rc;
@@ -625,17 +569,19 @@ int scl_stage_query(scl_engine *e, const float *values)
     SCL_HIP(e, hipMemcpyAsync(e->d_vals, values, sizeof(float) * cells, hipMemcpyHostToDevice, e->stream));
     {
         ProfScope ps(e, P_INGEST);
-        SCL_HIP(e, launch_ingest(e->d_vals, 1, 0, e->q_desc, e->q_vkey, e->q_norm, e->q_rkey, e->q_rkey4,
-                                 1, e->R, e->S, e->stream));
+        // staging slot 0 = database index cap; no tiled ring key for staged queries (rkey4 == nullptr)
+        SCL_HIP(e, launch_ingest(e->d_vals, 1, e->cap, e->d_desc, e->d_vkey, e->d_norm, e->d_rkey, nullptr,
+                                 e->cap, e->R, e->S, e->stream));
     }
     if ((rc = sync(e))) return rc;
-    e->staged = true;
+    e->staged[0] = true;
     return SCL_OK;
 }
 
 int scl_detect_intra(scl_engine *e, int cur, int *loop_id, float *shift, double *dist)
 {
     if (!e || !loop_id || !shift) return SCL_ERR_INVALID_ARG;
+    if (e->front) return front_detect_intra(e, cur, loop_id, shift, dist);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     *loop_id = -1; *shift = 0.0f;                                         /* D.h:1615 */
@@ -668,6 +614,7 @@ int scl_detect_intra(scl_engine *e, int cur, int *loop_id, float *shift, double 
 int scl_detect_inter(scl_engine *e, int cur, int *loop_id, float *yaw_rad, double *dist)
 {
     if (!e || !loop_id || !yaw_rad) return SCL_ERR_INVALID_ARG;
+    if (e->front) return front_detect_inter(e, cur, loop_id, yaw_rad, dist);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     *loop_id = -1; *yaw_rad = 0.0f;                                       /* D.h:1678,1686 */
@@ -717,6 +664,7 @@ int scl_detect_inter(scl_engine *e, int cur, int *loop_id, float *yaw_rad, doubl
 int scl_get_index(const scl_engine *e, int key, int8_t *robot, int *index)
 {
     if (!e || !robot || !index) return SCL_ERR_INVALID_ARG;
+    if (e->front) return front_get_index(e, key, robot, index);
     std::lock_guard<std::mutex> lk(e->mu);
     if (key < 0 || key >= e->n) return fail(e, SCL_ERR_OUT_OF_RANGE, "key out of range");
     *robot = e->robots[key];
@@ -728,6 +676,7 @@ int scl_get_size(const scl_engine *e, int id)
 {
     (void)id;                                                             /* D.h:1763-1766 ignores idIn */
     if (!e) return SCL_ERR_INVALID_ARG;
+    if (e->front) return front_get_size(e);
     std::lock_guard<std::mutex> lk(e->mu);
     return e->n;
 }
@@ -738,6 +687,7 @@ int scl_get_descriptor(const scl_engine *ce, int key, float *values)
 {
     scl_engine *e = const_cast<scl_engine *>(ce);
     if (!e || !values) return SCL_ERR_INVALID_ARG;
+    if (e->front) { scl_engine *child = nullptr; int slot = 0; const int rc = front_get_slot(e, key, &child, &slot); return rc ? rc : scl_get_descriptor(child, slot, values); }
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     if (key < 0 || key >= e->n) return fail(e, SCL_ERR_OUT_OF_RANGE, "key out of range");
@@ -753,6 +703,7 @@ int scl_get_ringkey(const scl_engine *ce, int key, float *ringkey)
 {
     scl_engine *e = const_cast<scl_engine *>(ce);
     if (!e || !ringkey) return SCL_ERR_INVALID_ARG;
+    if (e->front) { scl_engine *child = nullptr; int slot = 0; const int rc = front_get_slot(e, key, &child, &slot); return rc ? rc : scl_get_ringkey(child, slot, ringkey); }
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     if (key < 0 || key >= e->n) return fail(e, SCL_ERR_OUT_OF_RANGE, "key out of range");
@@ -765,6 +716,7 @@ int scl_get_sectorkey(const scl_engine *ce, int key, double *sectorkey)
 {
     scl_engine *e = const_cast<scl_engine *>(ce);
     if (!e || !sectorkey) return SCL_ERR_INVALID_ARG;
+    if (e->front) { scl_engine *child = nullptr; int slot = 0; const int rc = front_get_slot(e, key, &child, &slot); return rc ? rc : scl_get_sectorkey(child, slot, sectorkey); }
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     if (key < 0 || key >= e->n) return fail(e, SCL_ERR_OUT_OF_RANGE, "key out of range");
@@ -776,6 +728,7 @@ int scl_get_sectorkey(const scl_engine *ce, int key, double *sectorkey)
 int scl_ringkey_topk(scl_engine *e, int query, int lo, int hi, int k, int *idx, float *d2, int *found)
 {
     if (!e || !idx || !d2) return SCL_ERR_INVALID_ARG;
+    if (e->front) return front_topk(e, query, lo, hi, k, idx, d2, nullptr, nullptr, found);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     return topk_with_distance_locked(e, query, lo, hi, k, e->cfg.knn_exclude_eps, idx, d2, nullptr, nullptr, found);
@@ -785,6 +738,7 @@ int scl_topk_with_distance(scl_engine *e, int query, int lo, int hi, int k,
                            int *idx, float *d2, double *dist, int *shift, int *found)
 {
     if (!e || !idx || !d2 || !dist || !shift) return SCL_ERR_INVALID_ARG;
+    if (e->front) return front_topk(e, query, lo, hi, k, idx, d2, dist, shift, found);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     return topk_with_distance_locked(e, query, lo, hi, k, e->cfg.knn_exclude_eps, idx, d2, dist, shift, found);
@@ -794,6 +748,7 @@ int scl_sc_distance_batch(scl_engine *e, int query, const int *cand, int n, doub
 {
     if (!e || n < 0 || !dist || !shift) return SCL_ERR_INVALID_ARG;
     if (n == 0) return SCL_OK;
+    if (e->front) return front_sc_distance_batch(e, query, cand, n, dist, shift);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     QueryView q;
@@ -883,6 +838,7 @@ int submit_full_locked(scl_engine *e, int query, int lo, int hi, int *ticket)
             SCL_HIP(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));
         }
     }
+    e->last_pass_empty = n <= 0;                            // nothing ran: the top-k buffers still hold an older pass
     SCL_HIP(e, hipEventRecord(e->ev_done[sl], use_alt ? e->stream_alt : e->stream));
     e->slot_ev[sl] = sl;
     e->slot_busy[sl] = true;
@@ -897,7 +853,12 @@ int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, c
 {
     const int k = e->cfg.num_candidates;
     bool batchable = nq > 1 && nq <= kMaxQueryBatch && k <= kTailTop && sc_distance_fuses_ring(db_view(e), e->SR);
-    for (int i = 0; i < nq && batchable; ++i) batchable = queries[i] >= 0 && queries[i] < e->n;
+    int qslot[kMaxQueryBatch] = {0};                       // database index of every query (staging slot j = cap + j)
+    for (int i = 0; i < nq && batchable; ++i) {
+        const int q = queries[i];
+        if (q >= 0) { batchable = q < e->n; qslot[i] = q; }
+        else { const int j = -1 - q; batchable = j < scl_engine::kStage && e->staged[j]; qslot[i] = e->cap + j; }
+    }
     if (!batchable) {                                      // one pass per query
         for (int i = 0; i < nq; ++i) { int rc = submit_full_locked(e, queries[i], los[i], his[i], &tickets[i]); if (rc) return rc; }
         return SCL_OK;
@@ -907,17 +868,17 @@ int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, c
             return fail(e, SCL_ERR_INVALID_ARG, "too many full-DB passes in flight: collect first");
     QueryBatch qb{};
     int first = -1, nmax = 0;
+    int lo_of[kMaxQueryBatch]; bool empty_of[kMaxQueryBatch];
     for (int i = 0; i < nq; ++i) {
         const int sl = (int)((e->next_slot + (unsigned)i) % scl_engine::kSlots);
         int lo = los[i] < 0 ? 0 : los[i], hi = his[i] > e->n ? e->n : his[i];
         const int n = hi - lo;
         tickets[i] = sl;
-        e->slot_lo[sl] = lo;
-        e->slot_empty[sl] = n <= 0;
+        lo_of[i] = lo; empty_of[i] = n <= 0;
         if (first < 0) first = sl;
         if (n > 0) {
             const int j = qb.nq++;
-            qb.slot[j] = queries[i]; qb.base[j] = lo; qb.n[j] = n; qb.out3[j] = e->h_out3 + (size_t)sl * 8;
+            qb.slot[j] = qslot[i]; qb.base[j] = lo; qb.n[j] = n; qb.out3[j] = e->h_out3 + (size_t)sl * 8;
             nmax = n > nmax ? n : nmax;
         }
     }
@@ -931,8 +892,13 @@ int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, c
         if (ps.active()) { for (int j = 0; j < qb.nq; ++j) e->prof.sc_distance_pairs += (uint64_t)qb.n[j]; }
         e->last_pass_alt = false;
     }
+    e->last_pass_empty = qb.nq == 0 || empty_of[0];
     SCL_HIP(e, hipEventRecord(e->ev_done[first], e->stream));
-    for (int i = 0; i < nq; ++i) { e->slot_ev[tickets[i]] = first; e->slot_busy[tickets[i]] = true; }
+    // slot state changes only now that the launch and its event are enqueued (an error above leaves every slot free)
+    for (int i = 0; i < nq; ++i) {
+        e->slot_lo[tickets[i]] = lo_of[i]; e->slot_empty[tickets[i]] = empty_of[i];
+        e->slot_ev[tickets[i]] = first; e->slot_busy[tickets[i]] = true;
+    }
     e->next_slot += (unsigned)nq;
     return SCL_OK;
 }
@@ -958,6 +924,7 @@ int collect_full_locked(scl_engine *e, int ticket, int *nn_idx, int *shift, doub
 int scl_detect_full_submit(scl_engine *e, int query, int lo, int hi, int *ticket)
 {
     if (!e || !ticket) return SCL_ERR_INVALID_ARG;
+    if (e->front) return front_submit_many(e, &query, &lo, &hi, 1, ticket);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     return submit_full_locked(e, query, lo, hi, ticket);
@@ -966,6 +933,14 @@ int scl_detect_full_submit(scl_engine *e, int query, int lo, int hi, int *ticket
 int scl_detect_full_submit_many(scl_engine *e, const int *queries, const int *lo, const int *hi, int n_queries, int *tickets)
 {
     if (!e || !queries || !lo || !hi || !tickets || n_queries < 1 || n_queries > scl_engine::kSlots) return SCL_ERR_INVALID_ARG;
+    if (e->front) {
+        for (int i = 0; i < n_queries; i += kMaxQueryBatch) {
+            const int m = n_queries - i < kMaxQueryBatch ? n_queries - i : kMaxQueryBatch;
+            const int rc = front_submit_many(e, queries + i, lo + i, hi + i, m, tickets + i);
+            if (rc) return rc;
+        }
+        return SCL_OK;
+    }
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     for (int i = 0; i < n_queries; i += kMaxQueryBatch) {
@@ -980,6 +955,7 @@ int scl_detect_full_stream(scl_engine *e, const int *queries, const int *lo, con
                            int scans_per_launch, int launches_in_flight, int *nn_idx, int *shift, double *dist)
 {
     if (!e || !queries || !lo || !hi || !nn_idx || !shift || !dist || n_queries < 0) return SCL_ERR_INVALID_ARG;
+    if (e->front) return front_detect_full_stream(e, queries, lo, hi, n_queries, scans_per_launch, launches_in_flight, nn_idx, shift, dist);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     for (int i = 0; i < scl_engine::kSlots; ++i)
@@ -989,17 +965,25 @@ int scl_detect_full_stream(scl_engine *e, const int *queries, const int *lo, con
     if (depth * spl > scl_engine::kSlots) depth = scl_engine::kSlots / spl;
     std::vector<int> tk((size_t)n_queries);
     int submitted = 0, collected = 0;
+    // error path: the passes already enqueued are waited for and their slots released, so the engine's pipeline is
+    // usable again afterwards (their results are dropped; last_error keeps the first failure)
+    auto drain = [&]() {
+        const std::string first_error = e->last_error;
+        (void)hipStreamSynchronize(e->stream);
+        for (int i = collected; i < submitted; ++i) e->slot_busy[tk[(size_t)i]] = false;
+        e->last_error = first_error;
+    };
     while (collected < n_queries) {
         while (submitted < n_queries) {                       // keep `depth` launches enqueued
             const int m = n_queries - submitted < spl ? n_queries - submitted : spl;
             if ((submitted - collected) + m > depth * spl) break;
             const int rc = submit_full_many_locked(e, queries + submitted, lo + submitted, hi + submitted, m, tk.data() + submitted);
-            if (rc) return rc;
+            if (rc) { drain(); return rc; }
             submitted += m;
         }
         const int rc = collect_full_locked(e, tk[(size_t)collected], nn_idx + collected, shift + collected, dist + collected);
-        if (rc) return rc;
         ++collected;
+        if (rc) { drain(); return rc; }
     }
     return SCL_OK;
 }
@@ -1007,6 +991,7 @@ int scl_detect_full_stream(scl_engine *e, const int *queries, const int *lo, con
 int scl_detect_full_collect(scl_engine *e, int ticket, int *nn_idx, int *shift, double *dist)
 {
     if (!e || !nn_idx || !shift || !dist) return SCL_ERR_INVALID_ARG;
+    if (e->front) return front_collect(e, ticket, nn_idx, shift, dist);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     return collect_full_locked(e, ticket, nn_idx, shift, dist);
@@ -1015,6 +1000,11 @@ int scl_detect_full_collect(scl_engine *e, int ticket, int *nn_idx, int *shift, 
 int scl_detect_full_range(scl_engine *e, int query, int lo, int hi, int *nn_idx, int *shift, double *dist)
 {
     if (!e || !nn_idx || !shift || !dist) return SCL_ERR_INVALID_ARG;
+    if (e->front) {
+        int t = -1;
+        const int rc = front_submit_many(e, &query, &lo, &hi, 1, &t);
+        return rc ? rc : front_collect(e, t, nn_idx, shift, dist);
+    }
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     *nn_idx = -1; *shift = 0; *dist = kBigDist;
@@ -1027,8 +1017,13 @@ int scl_detect_full_range(scl_engine *e, int query, int lo, int hi, int *nn_idx,
 int scl_get_last_topk(scl_engine *e, int k, int *idx, float *d2)
 {
     if (!e || !idx || !d2 || k < 1 || k > kTopkMaxK) return SCL_ERR_INVALID_ARG;
+    if (e->front) return front_get_last_topk(e, k, idx, d2);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
+    if (e->last_pass_empty) {                              // the last pass had an empty range: no neighbours
+        for (int i = 0; i < k; ++i) { idx[i] = -1; d2[i] = FLT_MAX; }
+        return SCL_OK;
+    }
     if (e->last_pass_alt) {                                // the most recent pass ran on the alt lane
         SCL_HIP(e, hipMemcpyAsync(idx, e->a_topk_idx, sizeof(int) * k, hipMemcpyDeviceToHost, e->stream_alt));
         SCL_HIP(e, hipMemcpyAsync(d2, e->a_topk_d2, sizeof(float) * k, hipMemcpyDeviceToHost, e->stream_alt));
@@ -1071,6 +1066,7 @@ int scl_icp_align(scl_engine *e, const void *src, int n_src, const void *tgt, in
                   float T[16], float *fitness, int *converged, int *iterations)
 {
     if (!e || !src || !tgt || !p || !T) return SCL_ERR_INVALID_ARG;
+    if (e->front) e = front_primary(e);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     std::string err;
@@ -1085,6 +1081,7 @@ int scl_icp_align_batch(scl_engine *e, const void *src, int n_src, const void *c
                         float *T, float *fitness, int *converged, int *iterations)
 {
     if (!e || !src || !p || !T || n_targets < 0 || (n_targets > 0 && (!tgts || !n_tgts))) return SCL_ERR_INVALID_ARG;
+    if (e->front) return front_icp_align_batch(e, src, n_src, tgts, n_tgts, n_targets, stride_bytes, p, T, fitness, converged, iterations);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     const int lanes = n_targets < scl_engine::kIcpLanes ? n_targets : scl_engine::kIcpLanes;
@@ -1130,6 +1127,7 @@ int scl_nn_correspondences(scl_engine *e, const void *src, int n_src, const void
                            int stride_bytes, int *nn_index, float *nn_dist2)
 {
     if (!e || !src || !tgt || !nn_index) return SCL_ERR_INVALID_ARG;
+    if (e->front) e = front_primary(e);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     std::string err;
@@ -1143,6 +1141,7 @@ int scl_rigid_svd(scl_engine *e, const void *src, int n_src, const void *tgt, in
                   int stride_bytes, const int *src_index, const int *tgt_index, int n_corr, float T[16])
 {
     if (!e || !src || !tgt || !src_index || !tgt_index || !T) return SCL_ERR_INVALID_ARG;
+    if (e->front) e = front_primary(e);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     std::string err;
@@ -1158,6 +1157,7 @@ int scl_ransac_correspondences(scl_engine *e, const void *src, int n_src, const 
                                int *inlier_mask, int *n_inliers, int *best_hypothesis, float T_model[16])
 {
     if (!e || !src || !tgt || !src_index || !tgt_index) return SCL_ERR_INVALID_ARG;
+    if (e->front) e = front_primary(e);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     std::string err;
@@ -1174,6 +1174,7 @@ int scl_geometric_verification(scl_engine *e, const void *src, int n_src, const 
                                int *n_correspondences, int *n_inliers)
 {
     if (!e || !src || !tgt || !T) return SCL_ERR_INVALID_ARG;
+    if (e->front) e = front_primary(e);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     std::string err;
@@ -1188,6 +1189,7 @@ int scl_voxel_grid(scl_engine *e, const void *points, int n_points, int stride_b
                    void *out, int out_capacity, int *n_out)
 {
     if (!e || (!points && n_points > 0) || !out || !n_out) return SCL_ERR_INVALID_ARG;
+    if (e->front) e = front_primary(e);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     std::string err;
@@ -1212,6 +1214,7 @@ int scl_assemble_submap(scl_engine *e, const void *const *clouds, const int *cou
                         int n_clouds, int stride_bytes, float leaf, void *out, int out_capacity, int *n_out)
 {
     if (!e || (n_clouds > 0 && (!clouds || !counts || !transforms)) || !out || !n_out) return SCL_ERR_INVALID_ARG;
+    if (e->front) e = front_primary(e);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     std::string err;
@@ -1224,6 +1227,7 @@ int scl_assemble_submap(scl_engine *e, const void *const *clouds, const int *cou
 int scl_transform_cloud(scl_engine *e, const void *in, int n, int stride_bytes, const float T[16], void *out)
 {
     if (!e || !in || !out || !T) return SCL_ERR_INVALID_ARG;
+    if (e->front) e = front_primary(e);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     std::string err;
@@ -1281,6 +1285,7 @@ int kf_window(scl_engine *e, int robot, int key, int search_num, const float *po
 int scl_keyframe_put(scl_engine *e, int robot, int index, const void *points, int n_points, int stride_bytes)
 {
     if (!e || robot < 0 || index < 0 || n_points < 0 || (!points && n_points > 0)) return SCL_ERR_INVALID_ARG;
+    if (e->front) e = front_primary(e);
     std::lock_guard<std::mutex> lk(e->mu);
     if (stride_bytes < 12 || (stride_bytes & 3)) return fail(e, SCL_ERR_INVALID_ARG, "keyframe_put: bad stride");
     if (e->kf_stride == 0) e->kf_stride = stride_bytes;
@@ -1308,6 +1313,7 @@ int scl_keyframe_put(scl_engine *e, int robot, int index, const void *points, in
 int scl_keyframe_count(const scl_engine *e, int robot)
 {
     if (!e || robot < 0) return SCL_ERR_INVALID_ARG;
+    if (e->front) e = front_primary(e);
     std::lock_guard<std::mutex> lk(e->mu);
     return (size_t)robot < e->kf.size() ? (int)e->kf[robot].size() : 0;
 }
@@ -1315,6 +1321,7 @@ int scl_keyframe_count(const scl_engine *e, int robot)
 int scl_keyframe_get(scl_engine *e, int robot, int index, void *out, int out_capacity, int *n_points)
 {
     if (!e || robot < 0 || index < 0 || !n_points) return SCL_ERR_INVALID_ARG;
+    if (e->front) e = front_primary(e);
     std::lock_guard<std::mutex> lk(e->mu);
     if ((size_t)robot >= e->kf.size() || (size_t)index >= e->kf[robot].size() || e->kf[robot][index].n < 0)
         return fail(e, SCL_ERR_INVALID_ARG, "keyframe_get: no such keyframe");
@@ -1334,6 +1341,7 @@ int scl_submap_from_store(scl_engine *e, int robot, int key, int search_num, con
                           void *out, int out_capacity, int *n_out)
 {
     if (!e || !out || !n_out) return SCL_ERR_INVALID_ARG;
+    if (e->front) e = front_primary(e);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     std::vector<const void *> clouds; std::vector<int> counts; std::vector<float> T;
@@ -1352,6 +1360,7 @@ int scl_loop_icp_from_store(scl_engine *e, int robot, int key_cur, const float *
                             float T[16], float *fitness, int *converged, int *iterations, int *n_src, int *n_tgt)
 {
     if (!e || !pose_cur || !poses_pre || !p || !T) return SCL_ERR_INVALID_ARG;
+    if (e->front) e = front_primary(e);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     const int stride = e->kf_stride ? e->kf_stride : 16;
@@ -1393,6 +1402,7 @@ int scl_geometric_verification_from_store(scl_engine *e, const void *src, int n_
                                           int *n_correspondences, int *n_inliers)
 {
     if (!e || (!src && n_src > 0) || !poses_pre || !T) return SCL_ERR_INVALID_ARG;
+    if (e->front) e = front_primary(e);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     const int stride = e->kf_stride ? e->kf_stride : stride_bytes;
@@ -1430,6 +1440,7 @@ int scl_geometric_verification_from_store(scl_engine *e, const void *src, int n_
 int scl_profile_enable(scl_engine *e, int on)
 {
     if (!e) return SCL_ERR_INVALID_ARG;
+    if (e->front) return front_profile_enable(e, on);
     std::lock_guard<std::mutex> lk(e->mu);
     e->prof_on = on < 0 ? 0 : (on > 3 ? 1 : on);
     e->prof_tick = 0;
@@ -1439,6 +1450,7 @@ int scl_profile_enable(scl_engine *e, int on)
 int scl_profile_reset(scl_engine *e)
 {
     if (!e) return SCL_ERR_INVALID_ARG;
+    if (e->front) return front_profile_reset(e);
     std::lock_guard<std::mutex> lk(e->mu);
     std::memset(&e->prof, 0, sizeof e->prof);
     return SCL_OK;
@@ -1447,6 +1459,7 @@ int scl_profile_reset(scl_engine *e)
 int scl_profile_get(scl_engine *e, scl_profile *out)
 {
     if (!e || !out) return SCL_ERR_INVALID_ARG;
+    if (e->front) return front_profile_get(e, out);
     std::lock_guard<std::mutex> lk(e->mu);
     *out = e->prof;
     return SCL_OK;
@@ -1455,6 +1468,7 @@ int scl_profile_get(scl_engine *e, scl_profile *out)
 int scl_device_name(const scl_engine *e, char *buf, int buflen)
 {
     if (!e || !buf || buflen <= 0) return SCL_ERR_INVALID_ARG;
+    if (e->front) e = front_primary(e);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, e->device) != hipSuccess) return SCL_ERR_HIP;
     std::snprintf(buf, (size_t)buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
@@ -1462,3 +1476,93 @@ int scl_device_name(const scl_engine *e, char *buf, int buflen)
 }
 
 }  // extern "C"
+
+// ---- hooks for the sharded front (engine_internal.hpp) ---------------------------------------------------------
+namespace scl {
+
+int eng_stage_from_peer(scl_engine *dst, int j, scl_engine *src, int src_slot)
+{
+    if (!dst || !src || j < 0 || j >= scl_engine::kStage) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(dst->mu);
+    if (src_slot < 0 || src_slot >= src->n) return fail(dst, SCL_ERR_OUT_OF_RANGE, "stage_from_peer: source slot out of range");
+    (void)hipSetDevice(dst->device);
+    const size_t tile = (size_t)dst->RG * dst->S, S = (size_t)dst->S, R4 = (size_t)dst->R4;
+    const size_t d = (size_t)dst->cap + (size_t)j, s = (size_t)src_slot;
+    SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_desc + d * tile, dst->device, src->d_desc + s * tile, src->device, sizeof(float4) * tile, dst->stream));
+    SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_vkey + d * S, dst->device, src->d_vkey + s * S, src->device, sizeof(double) * S, dst->stream));
+    SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_norm + d * S, dst->device, src->d_norm + s * S, src->device, sizeof(double) * S, dst->stream));
+    SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_rkey + d * R4, dst->device, src->d_rkey + s * R4, src->device, sizeof(float) * R4, dst->stream));
+    dst->staged[j] = true;
+    return SCL_OK;
+}
+
+int eng_stage_values(scl_engine *e, int j, const float *values)
+{
+    if (!e || !values || j < 0 || j >= scl_engine::kStage) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    int rc;
+    const size_t cells = (size_t)e->R * e->S;
+    if ((rc = ensure_vals(e, cells))) return rc;
+    SCL_HIP(e, hipMemcpyAsync(e->d_vals, values, sizeof(float) * cells, hipMemcpyHostToDevice, e->stream));
+    {
+        ProfScope ps(e, P_INGEST);
+        SCL_HIP(e, launch_ingest(e->d_vals, 1, e->cap + j, e->d_desc, e->d_vkey, e->d_norm, e->d_rkey, nullptr,
+                                 e->cap, e->R, e->S, e->stream));
+    }
+    if ((rc = sync(e))) return rc;
+    e->staged[j] = true;
+    return SCL_OK;
+}
+
+int eng_topk_enqueue(scl_engine *e, int query, int lo, int hi, int k, float eps, bool want_dist, bool *have_dist)
+{
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    return topk_enqueue_locked(e, query, lo, hi, k, eps, want_dist, have_dist);
+}
+
+int eng_topk_finish(scl_engine *e, int k, bool have_dist, int *idx, float *d2, double *dist, int *shift, int *found)
+{
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    return topk_finish_locked(e, k, have_dist, idx, d2, dist, shift, found);
+}
+
+int eng_sync_streams(scl_engine *e)
+{
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    SCL_HIP(e, hipStreamSynchronize(e->stream));
+    if (e->stream_alt) SCL_HIP(e, hipStreamSynchronize(e->stream_alt));
+    if (e->stream2) SCL_HIP(e, hipStreamSynchronize(e->stream2));
+    return SCL_OK;
+}
+
+bool eng_would_regrow(const scl_engine *e, int count)
+{
+    std::lock_guard<std::mutex> lk(e->mu);
+    return e->n + count > e->cap;
+}
+
+const double *eng_ticket_record(const scl_engine *e, int ticket, int *slot_lo, bool *empty)
+{
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (ticket < 0 || ticket >= scl_engine::kSlots || !e->slot_busy[ticket]) return nullptr;
+    *slot_lo = e->slot_lo[ticket];
+    *empty = e->slot_empty[ticket];
+    return e->h_out3 + (size_t)ticket * 8;
+}
+
+hipStream_t eng_stream(const scl_engine *e) { return e->stream; }
+
+int eng_release_ticket(scl_engine *e, int ticket)
+{
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (ticket < 0 || ticket >= scl_engine::kSlots || !e->slot_busy[ticket]) return fail(e, SCL_ERR_INVALID_ARG, "unknown ticket");
+    e->slot_busy[ticket] = false;
+    collect_profile(e);
+    return SCL_OK;
+}
+
+}  // namespace scl

@@ -1,0 +1,154 @@
+// engine_internal.hpp -- the engine object behind the C ABI, shared by engine.hip (one database on one GPU)
+// and sharded_front.hip (one database spread over several GPUs, include/scl_engine.h scl_create_sharded).
+#pragma once
+
+#include "scl_engine.h"
+
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "icp.hpp"
+#include "kernels.hpp"
+
+namespace scl {
+
+enum ProfKind { P_SC = 0, P_TOPK, P_ARGMIN, P_MAKESC, P_INGEST, P_ICPNN, P_ICPRED, P_COUNT };
+
+struct PendingEvent { hipEvent_t start, stop; int kind; };
+
+struct ShardedFront;                                       // sharded_front.hip
+
+}  // namespace scl
+
+struct scl_engine {
+    scl_config cfg;
+    scl::ShardedFront *front = nullptr;                    // != nullptr: this object is the front of a sharded database
+                                                           // (no device state of its own; every call is forwarded)
+    int R = 0, S = 0, RG = 0, R4 = 0, SR = 0;
+    int device = 0, num_cu = 256;
+    hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;                         // ring-key scan runs beside the SC distance
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    double *h_out3 = nullptr;                              // pinned, device-visible: the arg-min kernel writes it directly
+    static constexpr int kSlots = 8;                       // full-DB passes in flight (submit/collect)
+    hipEvent_t ev_done[kSlots] = {nullptr};
+    int slot_lo[kSlots] = {0}; bool slot_busy[kSlots] = {false}; bool slot_empty[kSlots] = {false};
+    int slot_ev[kSlots] = {0};                             // which slot's event completes this one (batched launches share one)
+    unsigned next_slot = 0;
+    mutable std::mutex mu;
+    mutable std::string last_error;
+
+    // database (layout: kernels.hpp)
+    int n = 0, cap = 0;
+    float4 *d_desc = nullptr; double *d_vkey = nullptr; double *d_norm = nullptr;
+    float *d_rkey = nullptr; float4 *d_rkey4 = nullptr;
+    std::vector<int8_t> robots;
+    std::vector<int> indexs;
+
+    // staged external queries: kStage slots BEHIND the database slots of desc / vkey / norm / rkey (indices
+    // cap .. cap+kStage-1; rkey4 has no staging rows), so a staged query is addressed like a keyframe of the
+    // database by every kernel, the multi-query launches included.  Query id -1-j = staging slot j
+    // (SCL_QUERY_STAGED = -1 = slot 0, the public one; the sharded front uses the others for keyframes that
+    // live on another device).
+    static constexpr int kStage = 12;
+    bool staged[kStage] = {false};
+
+    // scratch
+    float *d_vals = nullptr; size_t vals_cap = 0;          // wire-format staging (floats)
+    unsigned char *d_points = nullptr; size_t points_cap = 0;
+    int *d_tile = nullptr;
+    double *d_dist = nullptr; int *d_shift = nullptr; int *d_cand = nullptr; float *d_ring_d2 = nullptr; size_t pair_cap = 0;
+    unsigned long long *d_topk_scratch = nullptr; int *d_topk_idx = nullptr; float *d_topk_d2 = nullptr;
+    double *d_out3 = nullptr;
+    unsigned long long *d_blk_part = nullptr; unsigned int *d_done_counter = nullptr;   // fused full-DB epilogue
+    // Second lane for fused full-DB passes: consecutive passes alternate between `stream` and `stream_alt`
+    // (own epilogue scratch and per-pair outputs), so the next pass's workgroups move onto CUs as the previous
+    // pass's workgroups retire instead of waiting behind its completion packet.
+    hipStream_t stream_alt = nullptr;
+    hipEvent_t ev_db = nullptr;                            // database writes on `stream` the alt lane must see
+    uint64_t db_version = 0, alt_seen_version = 0;
+    unsigned long long *a_blk_part = nullptr; unsigned int *a_done_counter = nullptr;
+    int *a_topk_idx = nullptr; float *a_topk_d2 = nullptr;
+    double *a_dist = nullptr; int *a_shift = nullptr; float *a_ring_d2 = nullptr; size_t a_pair_cap = 0;
+    bool last_pass_alt = false;
+    bool last_pass_empty = false;                          // the most recent full-DB pass had nothing to score
+    bool alt_lane = false;                                 // SCL_ALT_LANE=1: lowest latency per scan; kernels of the two lanes overlap,
+                                                           // so per-kernel durations no longer measure one pass (default off)
+    void *h_pinned = nullptr; size_t pinned_cap = 0;       // small result read-back
+
+    // inter-robot tree bookkeeping (descriptor.h:1691-1703, counter initialised: see DESIGN.md)
+    int tree_counter = 0, tree_n = 0;
+
+    // profiling
+    int prof_on = 0;                                       // 0 off, 1 every kernel family, 2 SC distance only, 3 SC distance sampled 1:8
+    unsigned prof_tick = 0;
+    scl_profile prof{};
+    std::vector<scl::PendingEvent> pending;
+    std::vector<hipEvent_t> event_pool;
+
+    scl::IcpWorkspace icp_ws;
+    scl::IcpWorkspace vox_ws;
+    static constexpr int kIcpLanes = 4;                    // concurrent alignments of scl_icp_align_batch
+    scl::IcpWorkspace icp_lane_ws[kIcpLanes];
+    hipStream_t icp_lane_stream[kIcpLanes] = {nullptr};
+
+    // on-device keyframe store (robots[id].keyFrameArray, DM.h:86): clouds live in slabs of HBM, bump allocated
+    struct StoredCloud { unsigned char *d = nullptr; int n = -1; size_t cap_bytes = 0; };
+    std::vector<std::vector<StoredCloud>> kf;              // [robot][index]; n < 0: never stored
+    std::vector<void *> kf_slabs;
+    size_t kf_slab_used = 0, kf_slab_cap = 0;
+    int kf_stride = 0;                                     // fixed by the first put
+};
+
+
+// ---- hooks for the sharded front (sharded_front.hip); each takes the engine's own lock ---------------------------
+namespace scl {
+
+// copy keyframe `src_slot` of `src` (descriptor tile, sector key, norms, ring key) into staging slot j of `dst`
+// (query id -1-j); device-to-device, ordered on dst's stream.  src == dst is allowed.
+int eng_stage_from_peer(scl_engine *dst, int j, scl_engine *src, int src_slot);
+// wire descriptor -> staging slot j
+int eng_stage_values(scl_engine *e, int j, const float *values);
+// ring-key top-k in [lo, hi) + SC distance of those k: enqueue on the engine's stream / wait and unpack
+int eng_topk_enqueue(scl_engine *e, int query, int lo, int hi, int k, float eps, bool want_dist, bool *have_dist);
+int eng_topk_finish(scl_engine *e, int k, bool have_dist, int *idx, float *d2, double *dist, int *shift, int *found);
+// wait for everything enqueued on the engine's streams (before another device's arrays may move)
+int eng_sync_streams(scl_engine *e);
+// true when appending `count` keyframes would move the database arrays
+bool eng_would_regrow(const scl_engine *e, int count);
+// device-side exchange of full-DB winners: the pinned (device-visible) result record of a ticket, its range start,
+// the stream the pass runs on; release = free the ticket without reading it (the exchange has delivered it)
+const double *eng_ticket_record(const scl_engine *e, int ticket, int *slot_lo, bool *empty);
+hipStream_t eng_stream(const scl_engine *e);
+int eng_release_ticket(scl_engine *e, int ticket);
+
+// the front's side of every public entry point (same arguments)
+int front_destroy(scl_engine *e);
+int front_make_and_save(scl_engine *e, const void *points, int n_points, int stride_bytes, int8_t robot, int index, float *out_values,
+                        bool filtered, float leaf, int *n_filtered);
+int front_save_bulk(scl_engine *e, const float *values, int count, const int8_t *robots, const int *indexs);
+int front_stage_query(scl_engine *e, const float *values);
+int front_detect_intra(scl_engine *e, int cur, int *loop_id, float *shift, double *dist);
+int front_detect_inter(scl_engine *e, int cur, int *loop_id, float *yaw_rad, double *dist);
+int front_get_index(const scl_engine *e, int key, int8_t *robot, int *index);
+int front_get_size(const scl_engine *e);
+int front_get_slot(const scl_engine *e, int key, scl_engine **child, int *slot);     // owner of global keyframe `key`
+int front_topk(scl_engine *e, int query, int lo, int hi, int k, int *idx, float *d2, double *dist, int *shift, int *found);
+int front_sc_distance_batch(scl_engine *e, int query, const int *cand, int n, double *dist, int *shift);
+int front_submit_many(scl_engine *e, const int *queries, const int *lo, const int *hi, int nq, int *tickets);
+int front_collect(scl_engine *e, int ticket, int *nn_idx, int *shift, double *dist);
+int front_detect_full_stream(scl_engine *e, const int *queries, const int *lo, const int *hi, int n_queries,
+                             int scans_per_launch, int launches_in_flight, int *nn_idx, int *shift, double *dist);
+int front_get_last_topk(scl_engine *e, int k, int *idx, float *d2);
+int front_icp_align_batch(scl_engine *e, const void *src, int n_src, const void *const *tgts, const int *n_tgts,
+                          int n_targets, int stride_bytes, const scl_icp_params *p,
+                          float *T, float *fitness, int *converged, int *iterations);
+int front_profile_enable(scl_engine *e, int on);
+int front_profile_reset(scl_engine *e);
+int front_profile_get(scl_engine *e, scl_profile *out);
+scl_engine *front_primary(const scl_engine *e);            // the shard that runs unsharded work (geometry, keyframe store)
+
+}  // namespace scl

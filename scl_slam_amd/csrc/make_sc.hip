@@ -13,6 +13,8 @@
 // mixed fp32/fp64 arithmetic, and keeps a private polar tile in LDS updated with
 // integer atomicMax on an order-preserving float encoding; tiles are merged into the
 // global image with one atomicMax per touched cell.  HBM-bound: n*16 B in, R*S*4 out.
+#include <atomic>
+
 #include "device_common.hpp"
 #include "kernels.hpp"
 
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(
             key = (float)(sum / (double)S);
         }
         rkey[(size_t)slot * 4 * RG + r] = key;
-        reinterpret_cast<float *>(rkey4)[((size_t)(r >> 2) * cap + slot) * 4 + (r & 3)] = key;
+        if (rkey4) reinterpret_cast<float *>(rkey4)[((size_t)(r >> 2) * cap + slot) * 4 + (r & 3)] = key;   // nullptr: staging slot
     }
 }
 
@@ -168,14 +170,14 @@ hipError_t launch_ingest(const float *values, int count, int first_slot,
 {
     if (count <= 0) return hipSuccess;
     const size_t lds = sizeof(float) * (size_t)R * (S + 1);
-    static bool attr_set_dev[64] = {false};   // per device
-    int dev_ = 0; (void)hipGetDevice(&dev_);
-    bool &attr_set = attr_set_dev[dev_ & 63];
-    if (!attr_set && lds > 48 * 1024) {
+    static std::atomic<bool> attr_set_dev[64];   // per device; engines on different threads may race here: atomic flag,
+    int dev_ = 0; (void)hipGetDevice(&dev_);     // and setting the attribute twice is harmless
+    std::atomic<bool> &attr_set = attr_set_dev[dev_ & 63];
+    if (!attr_set.load(std::memory_order_acquire) && lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)ingest_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set.store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(ingest_kernel, dim3(count), dim3(256), lds, stream,
                        values, first_slot, desc, vkey, norm, rkey, rkey4, cap, R, S);

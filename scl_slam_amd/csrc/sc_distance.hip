@@ -22,6 +22,7 @@
 // Bound: HBM (algorithmic 4*R*S + 8*S bytes per pair) on paper; the LDS read port
 // (one ds_read_b64 per fp64 fma) is what limits v1 -- see DESIGN.md.
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <type_traits>
 #include <cstdlib>
@@ -938,14 +939,14 @@ hipError_t launch_wave(const ScBatchArgs &batch_in, int num_cu, hipStream_t stre
     const int grid = blocks * ab.nq;                       // workgroups [qi*blocks, (qi+1)*blocks) serve query qi
     ab.nb = blocks;
     const size_t lds = fixed + per_wave * waves + 16;      // + the candidate dispenser
-    static bool attr_set_dev[64] = {false};   // per instantiation and per device
+    static std::atomic<bool> attr_set_dev[64];   // per instantiation and per device (engines on other threads may race: atomic)
     int dev_ = 0; (void)hipGetDevice(&dev_);
-    bool &attr_set = attr_set_dev[dev_ & 63];
-    if (!attr_set) {
+    std::atomic<bool> &attr_set = attr_set_dev[dev_ & 63];
+    if (!attr_set.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void *)sc_distance_wave_kernel<RG, W, CH, S, MAXT, STAMP>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set.store(true, std::memory_order_release);
     }
     if (STAMP) {
         // diagnostic build of the kernel (SCL_STAMP=1): per-wave cycle sums per phase, printed to stderr
@@ -1127,14 +1128,14 @@ hipError_t launch_fast(const ScArgs &args_in, int num_cu, hipStream_t stream)
     int blocks = (a.n + G - 1) / G;
     if (blocks > num_cu) blocks = num_cu;
     const size_t lds = fixed + per_group * G;
-    static bool attr_set_dev[64] = {false};   // per instantiation and per device (one engine per GPU in a process is allowed)
+    static std::atomic<bool> attr_set_dev[64];   // per instantiation and per device (one engine per GPU in a process is allowed)
     int dev_ = 0; (void)hipGetDevice(&dev_);
-    bool &attr_set = attr_set_dev[dev_ & 63];
-    if (!attr_set) {
+    std::atomic<bool> &attr_set = attr_set_dev[dev_ & 63];
+    if (!attr_set.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void *)sc_distance_kernel<RG, W, MAXT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set.store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((sc_distance_kernel<RG, W, MAXT>), dim3(blocks), dim3(G * a.NW * kWave), lds, stream, a);
     return hipGetLastError();

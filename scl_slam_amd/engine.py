@@ -68,6 +68,8 @@ def _bind(lib):
         "scl_abi_version": (c_int, []),
         "scl_default_config": (c_int, [POINTER(SclConfig)]),
         "scl_create": (c_int, [POINTER(SclConfig), POINTER(P)]),
+        "scl_create_sharded": (c_int, [POINTER(SclConfig), ip, c_int, c_int, POINTER(P)]),
+        "scl_shard_info": (c_int, [P, ip, ip]),
         "scl_destroy": (c_int, [P]),
         "scl_make_and_save": (c_int, [P, P, c_int, c_int, c_int8, c_int, fp]),
         "scl_save_from_wire": (c_int, [P, fp, c_int8, c_int]),
@@ -140,12 +142,14 @@ def _cloud(points):
 
 
 class ScanContextEngine:
-    """One engine = one keyframe database resident in one GPU's HBM."""
+    """One engine = one keyframe database resident in one GPU's HBM, or -- with ``devices=[...]`` -- ONE database
+    sharded over several GPUs behind the same interface (``scl_create_sharded``: keyframe g on shard g % len(devices);
+    ``exchange`` 0 auto, 1 host merge, 2 RCCL min all-reduce of the full-DB winners)."""
 
     def __init__(self, num_ring=20, num_sector=60, num_candidates=3, dist_thres=0.14,
                  lidar_height=1.65, max_radius=80.0, num_exclude_recent=100,
                  tree_making_period=10, search_ratio=0.1, knn_exclude_eps=0.0,
-                 device=0, initial_capacity=4096):
+                 device=0, initial_capacity=4096, devices=None, exchange=0):
         self._lib = load_library()
         _bind(self._lib)
         cfg = SclConfig()
@@ -158,10 +162,20 @@ class ScanContextEngine:
         self.cfg = cfg
         self.R, self.S = num_ring, num_sector
         self._h = c_void_p()
-        rc = self._lib.scl_create(byref(cfg), byref(self._h))
+        if devices is not None:
+            devs = np.ascontiguousarray(devices, dtype=np.int32)
+            rc = self._lib.scl_create_sharded(byref(cfg), _ptr(devs, c_int), devs.size, exchange, byref(self._h))
+        else:
+            rc = self._lib.scl_create(byref(cfg), byref(self._h))
         if rc != 0:
             self._h = c_void_p()
             raise SclError(rc, "scl_create", self._lib.scl_status_string(rc).decode())
+
+    def shard_info(self):
+        """(number of shards, exchange in use: 0 none, 1 host merge, 2 RCCL)"""
+        n, x = c_int(), c_int()
+        self._check(self._lib.scl_shard_info(self._h, byref(n), byref(x)), "scl_shard_info")
+        return n.value, x.value
 
     # -- plumbing -----------------------------------------------------------
     def _check(self, rc, where):

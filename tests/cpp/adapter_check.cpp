@@ -14,7 +14,15 @@
 int main(int argc, char **argv)
 {
     const int n_keyframes = argc > 1 ? std::atoi(argv[1]) : 260;
-    std::unique_ptr<scan_descriptor> scanDescriptor(new scan_context_hip_descriptor());   // the DM.h:404 line
+    // argv[2] = number of shards: 0 = the one-GPU constructor, G > 0 = the sharded constructor with G shards, all on
+    // device 0 (a one-GPU box; on a node the list would be {0, 1, ..., 7})
+    const int shards = argc > 2 ? std::atoi(argv[2]) : 0;
+    auto make = [&]() -> scan_context_hip_descriptor * {
+        if (shards > 0) return new scan_context_hip_descriptor(std::vector<int>((size_t)shards, 0));
+        return new scan_context_hip_descriptor();
+    };
+    scan_context_hip_descriptor *local_impl = make();
+    std::unique_ptr<scan_descriptor> scanDescriptor(local_impl);   // the DM.h:404 line
     if (scanDescriptor->getSize() != 0) { std::printf("FAIL size0\n"); return 1; }
 
     // a closed loop: keyframes 0..129 walk a path, 130..259 revisit it -> loops must be found
@@ -44,8 +52,11 @@ int main(int argc, char **argv)
     if (scanDescriptor->getIndex(17) != std::pair<int8_t, int>(0, 17)) { std::printf("FAIL getIndex\n"); return 1; }
 
     int loops = 0, correct = 0;
+    unsigned long long digest = 1469598103934665603ull;    // every detection folded in: sharded and unsharded runs must print the same
     for (int cur = 0; cur < n_keyframes; ++cur) {
         const std::pair<int, float> r = scanDescriptor->detectIntraLoopClosureID(cur);
+        digest = (digest ^ (unsigned long long)(unsigned)r.first) * 1099511628211ull;
+        digest = (digest ^ (unsigned long long)(int)r.second) * 1099511628211ull;
         if (r.first >= 0) {
             ++loops;
             if (std::abs(r.first - (cur - n_keyframes / 2)) <= 2) ++correct;
@@ -56,7 +67,8 @@ int main(int argc, char **argv)
     if (loops < 20 || correct * 10 < loops * 8) { std::printf("FAIL loop recall\n"); return 1; }
 
     // a second robot ingests the same descriptors from the wire (DM.h:625-628) and must agree
-    std::unique_ptr<scan_descriptor> remote(new scan_context_hip_descriptor());
+    scan_context_hip_descriptor *remote_impl = make();
+    std::unique_ptr<scan_descriptor> remote(remote_impl);
     for (int kf = 0; kf < n_keyframes; ++kf) remote->saveDescriptorAndKey(published[kf].data(), 1, kf);
     for (int cur = n_keyframes - 30; cur < n_keyframes; ++cur) {
         if (remote->detectIntraLoopClosureID(cur) != scanDescriptor->detectIntraLoopClosureID(cur)) { std::printf("FAIL wire parity\n"); return 1; }
@@ -82,6 +94,12 @@ int main(int argc, char **argv)
     }
     const std::pair<int, float> inter = remote->detectInterLoopClosureID(n_keyframes - 1);
     std::printf("inter: loop %d yaw %.4f\n", inter.first, inter.second);
+    std::printf("detections digest %016llx\n", digest);
+    // scan_descriptor has no virtual destructor (descriptor.h:21-36): deleting through unique_ptr<scan_descriptor> would
+    // not run the adapter's destructor, so a host that wants the HBM back closes explicitly first
+    local_impl->close(); remote_impl->close();
+    if (scanDescriptor->getSize() != 0 || scanDescriptor->detectIntraLoopClosureID(n_keyframes - 1).first != -1) { std::printf("FAIL closed adapter\n"); return 1; }
+    local_impl->close();                                   // idempotent
     std::printf("ADAPTER OK\n");
     return 0;
 }
