@@ -146,14 +146,17 @@ def cpu_baseline(descs, n_pairs_hint, budget_s=10.0):
         return done, time.perf_counter() - t0
 
     def sample_mt(db, fast, budget):
-        cand = np.arange(0, n_hist, dtype=np.int32)
+        # one call = the history scored against several queries' worth of candidates, so that every thread of the pool
+        # gets >= ~100 pairs per call and thread start-up does not dominate on a 256-core host
+        tiles = max(1, (128 * threads + n_hist - 1) // n_hist)
+        cand = np.tile(np.arange(0, n_hist, dtype=np.int32), tiles)
         reps, t0 = 0, time.perf_counter()
         while True:
             db.distance_batch_mt(n_db - 1 - (reps % N_EXCLUDE), cand, fast, threads)
             reps += 1
             if time.perf_counter() - t0 >= budget:
                 break
-        return reps * n_hist, time.perf_counter() - t0
+        return reps * cand.size, time.perf_counter() - t0
 
     db = ob.OracleDB(cfg)
     db.save_bulk(descs[:n_db])
