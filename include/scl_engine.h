@@ -178,6 +178,14 @@ int  scl_detect_full_submit_many(scl_engine *e, const int *queries, const int *l
 int  scl_detect_full_stream(scl_engine *e, const int *queries, const int *lo, const int *hi, int n_queries,
                             int scans_per_launch, int launches_in_flight, int *nn_idx, int *shift, double *dist);
 int  scl_detect_full_collect(scl_engine *e, int ticket, int *nn_idx, int *shift, double *dist);
+/* Diagnostic view of the screening pass behind the full-DB mode on the 64x120 grid (scl_slam_amd/csrc/sc_screen.hip):
+ * approx[i] = the reduced-precision (fp16 matrix-core) evaluation of distanceBtnScanContext (D.h:1538-1569) of
+ * `query` against slot lo + i -- the reference's own alignment, its 13 shifts -- guaranteed within *eps of the fp64
+ * value (-inf: the keyframe is always scored exactly); survivors[0 .. *n_survivors) = the slots (ascending) that can
+ * still hold the minimum and are re-scored by the exact fp64 kernel.  The full-DB entry points return the exact
+ * winner; this call exists so that tests can check the bound on the hardware.  survivors (n entries), n_survivors
+ * and eps may be NULL.  SCL_ERR_UNSUPPORTED on other grids. */
+int  scl_screen_distances(scl_engine *e, int query, int lo, int hi, float *approx, int *survivors, int *n_survivors, float *eps);
 /* The ring-key top-k (num_candidates entries) computed as part of the last scl_detect_full[_range]. */
 int  scl_get_last_topk(scl_engine *e, int k, int *idx, float *d2);
 /* Reference-faithful candidates for the sharded driver: local ring-key top-k in

@@ -109,7 +109,7 @@ void dev_free(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
 DbView db_view(const scl_engine *e)
 {
     DbView v;
-    v.desc = e->d_desc; v.vkey = e->d_vkey; v.norm = e->d_norm; v.rkey = e->d_rkey; v.rkey4 = e->d_rkey4;
+    v.desc = e->d_desc; v.vkey = e->d_vkey; v.norm = e->d_norm; v.rkey = e->d_rkey; v.rkey4 = e->d_rkey4; v.inv = e->d_inv;
     v.cap = e->cap; v.R = e->R; v.S = e->S; v.RG = e->RG;
     return v;
 }
@@ -125,6 +125,7 @@ int query_view(const scl_engine *e, int query, QueryView *q)
     q->vkey = e->d_vkey + (size_t)query * e->S;
     q->norm = e->d_norm + (size_t)query * e->S;
     q->rkey = e->d_rkey + (size_t)query * e->R4;
+    q->inv = e->d_inv + (size_t)query * e->S;
     return SCL_OK;
 }
 
@@ -135,13 +136,14 @@ int ensure_capacity(scl_engine *e, int need)
     int ncap = e->cap > 0 ? e->cap : (e->cfg.initial_capacity > 0 ? e->cfg.initial_capacity : 4096);
     while (ncap < need) ncap *= 2;
     const size_t tile = (size_t)e->RG * e->S;
-    float4 *nd = nullptr; double *nv = nullptr; double *nn = nullptr; float *nr = nullptr; float4 *nr4 = nullptr;
+    float4 *nd = nullptr; double *nv = nullptr; double *nn = nullptr; float *nr = nullptr; float4 *nr4 = nullptr; float *ni = nullptr;
     int rc;
     const size_t nst = (size_t)ncap + scl_engine::kStage;     // database slots + the staging slots behind them
     if ((rc = dev_alloc(e, &nd, tile * nst))) return rc;
     if ((rc = dev_alloc(e, &nv, (size_t)e->S * nst))) return rc;
     if ((rc = dev_alloc(e, &nn, (size_t)e->S * nst))) return rc;
     if ((rc = dev_alloc(e, &nr, (size_t)e->R4 * nst))) return rc;
+    if ((rc = dev_alloc(e, &ni, (size_t)e->S * nst))) return rc;
     if ((rc = dev_alloc(e, &nr4, (size_t)e->RG * ncap))) return rc;
     SCL_HIP(e, hipMemsetAsync(nr4, 0, sizeof(float4) * (size_t)e->RG * ncap, e->stream));
     if (e->n > 0) {
@@ -149,6 +151,7 @@ int ensure_capacity(scl_engine *e, int need)
         SCL_HIP(e, hipMemcpyAsync(nv, e->d_vkey, sizeof(double) * (size_t)e->S * e->n, hipMemcpyDeviceToDevice, e->stream));
         SCL_HIP(e, hipMemcpyAsync(nn, e->d_norm, sizeof(double) * (size_t)e->S * e->n, hipMemcpyDeviceToDevice, e->stream));
         SCL_HIP(e, hipMemcpyAsync(nr, e->d_rkey, sizeof(float) * (size_t)e->R4 * e->n, hipMemcpyDeviceToDevice, e->stream));
+        SCL_HIP(e, hipMemcpyAsync(ni, e->d_inv, sizeof(float) * (size_t)e->S * e->n, hipMemcpyDeviceToDevice, e->stream));
         SCL_HIP(e, hipMemcpy2DAsync(nr4, sizeof(float4) * ncap, e->d_rkey4, sizeof(float4) * e->cap,
                                     sizeof(float4) * e->n, e->RG, hipMemcpyDeviceToDevice, e->stream));
     }
@@ -158,11 +161,12 @@ int ensure_capacity(scl_engine *e, int need)
         SCL_HIP(e, hipMemcpyAsync(nv + (size_t)e->S * ncap, e->d_vkey + (size_t)e->S * e->cap, sizeof(double) * e->S * k, hipMemcpyDeviceToDevice, e->stream));
         SCL_HIP(e, hipMemcpyAsync(nn + (size_t)e->S * ncap, e->d_norm + (size_t)e->S * e->cap, sizeof(double) * e->S * k, hipMemcpyDeviceToDevice, e->stream));
         SCL_HIP(e, hipMemcpyAsync(nr + (size_t)e->R4 * ncap, e->d_rkey + (size_t)e->R4 * e->cap, sizeof(float) * e->R4 * k, hipMemcpyDeviceToDevice, e->stream));
+        SCL_HIP(e, hipMemcpyAsync(ni + (size_t)e->S * ncap, e->d_inv + (size_t)e->S * e->cap, sizeof(float) * e->S * k, hipMemcpyDeviceToDevice, e->stream));
     }
     SCL_HIP(e, hipStreamSynchronize(e->stream));
     if (e->stream_alt) SCL_HIP(e, hipStreamSynchronize(e->stream_alt));   // passes still reading the old arrays
-    dev_free(e->d_desc); dev_free(e->d_vkey); dev_free(e->d_norm); dev_free(e->d_rkey); dev_free(e->d_rkey4);
-    e->d_desc = nd; e->d_vkey = nv; e->d_norm = nn; e->d_rkey = nr; e->d_rkey4 = nr4;
+    dev_free(e->d_desc); dev_free(e->d_vkey); dev_free(e->d_norm); dev_free(e->d_rkey); dev_free(e->d_rkey4); dev_free(e->d_inv);
+    e->d_desc = nd; e->d_vkey = nv; e->d_norm = nn; e->d_rkey = nr; e->d_rkey4 = nr4; e->d_inv = ni;
     e->cap = ncap;
     return SCL_OK;
 }
@@ -192,8 +196,12 @@ int ensure_pairs(scl_engine *e, size_t n)
 {
     if (n <= e->pair_cap) return SCL_OK;
     dev_free(e->d_dist); dev_free(e->d_shift); dev_free(e->d_cand); dev_free(e->d_ring_d2);
+    dev_free(e->d_approx); dev_free(e->d_surv);
     size_t nn = n + n / 2 + 64;
     int rc;
+    e->pair_cap = 0;
+    if ((rc = dev_alloc(e, &e->d_approx, nn))) return rc;
+    if ((rc = dev_alloc(e, &e->d_surv, nn))) return rc;
     if ((rc = dev_alloc(e, &e->d_ring_d2, nn))) return rc;
     if ((rc = dev_alloc(e, &e->d_dist, nn))) return rc;
     if ((rc = dev_alloc(e, &e->d_shift, nn))) return rc;
@@ -216,7 +224,7 @@ int ingest_from_vals(scl_engine *e, int count, int first_slot)
 {
     ProfScope ps(e, P_INGEST);
     SCL_HIP(e, launch_ingest(e->d_vals, count, first_slot, e->d_desc, e->d_vkey, e->d_norm, e->d_rkey,
-                             e->d_rkey4, e->cap, e->R, e->S, e->stream));
+                             e->d_rkey4, e->d_inv, e->cap, e->R, e->S, e->stream));
     e->db_version++;                                       // the alt lane orders itself behind this write
     return SCL_OK;
 }
@@ -410,6 +418,10 @@ int scl_create(const scl_config *cfg, scl_engine **out)
     static_assert(kMaxQueryBatch <= 4, "done_counter holds four counters");
     if ((rc = dev_alloc(e, &e->d_done_counter, (size_t)4))) return bail(rc);
     if (hipMemset(e->d_done_counter, 0, 16) != hipSuccess) return bail(SCL_ERR_HIP);
+    if ((rc = dev_alloc(e, &e->d_nsurv, (size_t)kMaxQueryBatch))) return bail(rc);
+    if ((rc = dev_alloc(e, &e->d_tmin, (size_t)kMaxQueryBatch))) return bail(rc);
+    if (hipMemset(e->d_nsurv, 0, sizeof(int) * kMaxQueryBatch) != hipSuccess) return bail(SCL_ERR_HIP);
+    if (hipMemset(e->d_tmin, 0xff, sizeof(unsigned int) * kMaxQueryBatch) != hipSuccess) return bail(SCL_ERR_HIP);
     if ((rc = dev_alloc(e, &e->a_blk_part, (size_t)1024 * kTailRec))) return bail(rc);
     if ((rc = dev_alloc(e, &e->a_done_counter, (size_t)4))) return bail(rc);
     if (hipMemset(e->a_done_counter, 0, 16) != hipSuccess) return bail(SCL_ERR_HIP);
@@ -419,6 +431,7 @@ int scl_create(const scl_config *cfg, scl_engine **out)
     { const char *env = getenv("SCL_ALT_LANE"); e->alt_lane = env && env[0] == '1'; }
     if (hipEventCreateWithFlags(&e->ev_db, hipEventDisableTiming) != hipSuccess) return bail(SCL_ERR_HIP);
     if ((rc = ensure_pairs(e, 1024))) return bail(rc);
+    e->screen = sc_screen_supported(db_view(e), e->SR) && cfg->num_candidates <= kTailTopMaxK;
     if ((rc = ensure_pinned(e, 1 << 16))) return bail(rc);
     if ((rc = ensure_vals(e, (size_t)e->R * e->S))) return bail(rc);
     *out = e;
@@ -440,9 +453,10 @@ int scl_destroy(scl_engine *e)
         icp_workspace_free(&e->icp_lane_ws[i]);
         if (e->icp_lane_stream[i]) (void)hipStreamDestroy(e->icp_lane_stream[i]);
     }
-    dev_free(e->d_desc); dev_free(e->d_vkey); dev_free(e->d_norm); dev_free(e->d_rkey); dev_free(e->d_rkey4);
+    dev_free(e->d_desc); dev_free(e->d_vkey); dev_free(e->d_norm); dev_free(e->d_rkey); dev_free(e->d_rkey4); dev_free(e->d_inv);
     dev_free(e->d_vals); dev_free(e->d_points); dev_free(e->d_tile);
     dev_free(e->d_dist); dev_free(e->d_shift); dev_free(e->d_cand); dev_free(e->d_ring_d2);
+    dev_free(e->d_approx); dev_free(e->d_surv); dev_free(e->d_nsurv); dev_free(e->d_tmin);
     dev_free(e->d_topk_scratch); dev_free(e->d_topk_idx); dev_free(e->d_topk_d2); dev_free(e->d_out3);
     dev_free(e->d_blk_part); dev_free(e->d_done_counter);
     dev_free(e->a_blk_part); dev_free(e->a_done_counter); dev_free(e->a_topk_idx); dev_free(e->a_topk_d2);
@@ -570,7 +584,7 @@ int scl_stage_query(scl_engine *e, const float *values)
     {
         ProfScope ps(e, P_INGEST);
         // staging slot 0 = database index cap; no tiled ring key for staged queries (rkey4 == nullptr)
-        SCL_HIP(e, launch_ingest(e->d_vals, 1, e->cap, e->d_desc, e->d_vkey, e->d_norm, e->d_rkey, nullptr,
+        SCL_HIP(e, launch_ingest(e->d_vals, 1, e->cap, e->d_desc, e->d_vkey, e->d_norm, e->d_rkey, nullptr, e->d_inv,
                                  e->cap, e->R, e->S, e->stream));
     }
     if ((rc = sync(e))) return rc;
@@ -771,8 +785,16 @@ int scl_sc_distance_batch(scl_engine *e, int query, const int *cand, int n, doub
 namespace {
 
 // enqueue one full-DB pass; results land in pinned slot `sl` when ev_done[sl] has fired
+int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, const int *his, int nq, int *tickets);
+
 int submit_full_locked(scl_engine *e, int query, int lo, int hi, int *ticket)
 {
+    if (e->screen && !e->in_single_fallback) {             // one query through the screening pipeline of the batched form
+        e->in_single_fallback = true;
+        const int rc = submit_full_many_locked(e, &query, &lo, &hi, 1, ticket);
+        e->in_single_fallback = false;
+        return rc;
+    }
     QueryView q;
     int rc = query_view(e, query, &q);
     if (rc) return rc;
@@ -852,7 +874,7 @@ int submit_full_locked(scl_engine *e, int query, int lo, int hi, int *ticket)
 int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, const int *his, int nq, int *tickets)
 {
     const int k = e->cfg.num_candidates;
-    bool batchable = nq > 1 && nq <= kMaxQueryBatch && k <= kTailTop && sc_distance_fuses_ring(db_view(e), e->SR);
+    bool batchable = (nq > 1 || e->screen) && nq <= kMaxQueryBatch && (k <= kTailTop || e->screen) && sc_distance_fuses_ring(db_view(e), e->SR);
     int qslot[kMaxQueryBatch] = {0};                       // database index of every query (staging slot j = cap + j)
     for (int i = 0; i < nq && batchable; ++i) {
         const int q = queries[i];
@@ -887,9 +909,30 @@ int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, c
         if (rc) return rc;
         qb.pair_stride = (size_t)nmax;
         FullTail tail{e->d_blk_part, e->d_done_counter, nullptr, e->d_topk_idx, e->d_topk_d2, k, e->cfg.knn_exclude_eps};
-        ProfScope ps(e, P_SC);
-        SCL_HIP(e, launch_sc_distance_batch(db_view(e), qb, e->SR, e->d_dist, e->d_shift, e->d_ring_d2, tail, e->num_cu, e->stream));
-        if (ps.active()) { for (int j = 0; j < qb.nq; ++j) e->prof.sc_distance_pairs += (uint64_t)qb.n[j]; }
+        if (e->screen) {
+            // screening pass (fp16 matrix-core bounds around every reference distance) -> survivors -> exact fp64 kernel
+            // on the survivors only; the winner is the reference's, bit for bit (sc_screen.hip)
+            ScreenBatch sb{};
+            sb.nq = qb.nq;
+            for (int j = 0; j < qb.nq; ++j) { sb.slot[j] = qb.slot[j]; sb.base[j] = qb.base[j]; sb.n[j] = qb.n[j]; }
+            sb.pair_stride = qb.pair_stride;
+            sb.approx = e->d_approx; sb.ring_d2 = e->d_ring_d2; sb.survivors = e->d_surv; sb.n_surv = e->d_nsurv; sb.t_min = e->d_tmin;
+            sb.k = k; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
+            {
+                ProfScope ps(e, P_SC);
+                SCL_HIP(e, launch_sc_screen_batch(db_view(e), sb, e->SR, sc_align_filter_enabled(), e->num_cu, e->stream));
+                if (ps.active()) { for (int j = 0; j < qb.nq; ++j) e->prof.sc_distance_pairs += (uint64_t)qb.n[j]; }
+            }
+            SCL_HIP(e, launch_sc_select_batch(sb, e->stream));
+            {
+                ProfScope ps(e, P_ARGMIN);
+                SCL_HIP(e, launch_sc_distance_survivors(db_view(e), qb, e->SR, e->d_surv, e->d_nsurv, e->d_dist, e->d_shift, tail, e->num_cu, e->stream));
+            }
+        } else {
+            ProfScope ps(e, P_SC);
+            SCL_HIP(e, launch_sc_distance_batch(db_view(e), qb, e->SR, e->d_dist, e->d_shift, e->d_ring_d2, tail, e->num_cu, e->stream));
+            if (ps.active()) { for (int j = 0; j < qb.nq; ++j) e->prof.sc_distance_pairs += (uint64_t)qb.n[j]; }
+        }
         e->last_pass_alt = false;
     }
     e->last_pass_empty = qb.nq == 0 || empty_of[0];
@@ -1012,6 +1055,42 @@ int scl_detect_full_range(scl_engine *e, int query, int lo, int hi, int *nn_idx,
     int rc = submit_full_locked(e, query, lo, hi, &ticket);
     if (rc) return rc;
     return collect_full_locked(e, ticket, nn_idx, shift, dist);
+}
+
+int scl_screen_distances(scl_engine *e, int query, int lo, int hi, float *approx, int *survivors, int *n_survivors, float *eps)
+{
+    if (!e || !approx) return SCL_ERR_INVALID_ARG;
+    if (e->front) return fail(e, SCL_ERR_UNSUPPORTED, "screen_distances: call it on a one-GPU engine");
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    if (eps) *eps = sc_screen_eps();
+    if (!e->screen) return fail(e, SCL_ERR_UNSUPPORTED, "no screening pass for this grid (64x120, search ratio 0.1 only)");
+    int qslot;
+    if (query >= 0) { if (query >= e->n) return fail(e, SCL_ERR_OUT_OF_RANGE, "query slot out of range"); qslot = query; }
+    else { const int j = -1 - query; if (j >= scl_engine::kStage || !e->staged[j]) return fail(e, SCL_ERR_INVALID_ARG, "no staged query"); qslot = e->cap + j; }
+    if (lo < 0) lo = 0;
+    if (hi > e->n) hi = e->n;
+    const int n = hi - lo;
+    if (n_survivors) *n_survivors = 0;
+    if (n <= 0) return SCL_OK;
+    int rc;
+    if ((rc = ensure_pairs(e, (size_t)n))) return rc;
+    ScreenBatch sb{};
+    sb.nq = 1; sb.slot[0] = qslot; sb.base[0] = lo; sb.n[0] = n; sb.pair_stride = (size_t)n;
+    sb.approx = e->d_approx; sb.ring_d2 = e->d_ring_d2; sb.survivors = e->d_surv; sb.n_surv = e->d_nsurv; sb.t_min = e->d_tmin;
+    sb.k = e->cfg.num_candidates; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
+    SCL_HIP(e, launch_sc_screen_batch(db_view(e), sb, e->SR, sc_align_filter_enabled(), e->num_cu, e->stream));
+    SCL_HIP(e, launch_sc_select_batch(sb, e->stream));
+    SCL_HIP(e, hipMemcpyAsync(approx, e->d_approx, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, e->stream));
+    int ns = 0;
+    SCL_HIP(e, hipMemcpyAsync(&ns, e->d_nsurv, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    if ((rc = sync(e))) return rc;
+    if (n_survivors) *n_survivors = ns;
+    if (survivors && ns > 0) {
+        SCL_HIP(e, hipMemcpyAsync(survivors, e->d_surv, sizeof(int) * (size_t)ns, hipMemcpyDeviceToHost, e->stream));
+        if ((rc = sync(e))) return rc;
+    }
+    return SCL_OK;
 }
 
 int scl_get_last_topk(scl_engine *e, int k, int *idx, float *d2)
@@ -1492,6 +1571,7 @@ int eng_stage_from_peer(scl_engine *dst, int j, scl_engine *src, int src_slot)
     SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_vkey + d * S, dst->device, src->d_vkey + s * S, src->device, sizeof(double) * S, dst->stream));
     SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_norm + d * S, dst->device, src->d_norm + s * S, src->device, sizeof(double) * S, dst->stream));
     SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_rkey + d * R4, dst->device, src->d_rkey + s * R4, src->device, sizeof(float) * R4, dst->stream));
+    SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_inv + d * S, dst->device, src->d_inv + s * S, src->device, sizeof(float) * S, dst->stream));
     dst->staged[j] = true;
     return SCL_OK;
 }
@@ -1507,7 +1587,7 @@ int eng_stage_values(scl_engine *e, int j, const float *values)
     SCL_HIP(e, hipMemcpyAsync(e->d_vals, values, sizeof(float) * cells, hipMemcpyHostToDevice, e->stream));
     {
         ProfScope ps(e, P_INGEST);
-        SCL_HIP(e, launch_ingest(e->d_vals, 1, e->cap + j, e->d_desc, e->d_vkey, e->d_norm, e->d_rkey, nullptr,
+        SCL_HIP(e, launch_ingest(e->d_vals, 1, e->cap + j, e->d_desc, e->d_vkey, e->d_norm, e->d_rkey, nullptr, e->d_inv,
                                  e->cap, e->R, e->S, e->stream));
     }
     if ((rc = sync(e))) return rc;

@@ -44,7 +44,7 @@ struct scl_engine {
     // database (layout: kernels.hpp)
     int n = 0, cap = 0;
     float4 *d_desc = nullptr; double *d_vkey = nullptr; double *d_norm = nullptr;
-    float *d_rkey = nullptr; float4 *d_rkey4 = nullptr;
+    float *d_rkey = nullptr; float4 *d_rkey4 = nullptr; float *d_inv = nullptr;
     std::vector<int8_t> robots;
     std::vector<int> indexs;
 
@@ -61,6 +61,10 @@ struct scl_engine {
     unsigned char *d_points = nullptr; size_t points_cap = 0;
     int *d_tile = nullptr;
     double *d_dist = nullptr; int *d_shift = nullptr; int *d_cand = nullptr; float *d_ring_d2 = nullptr; size_t pair_cap = 0;
+    // screening pass of the full-DB mode (sc_screen.hip): approximate distances, survivors, their counts, min d~ words
+    float *d_approx = nullptr; int *d_surv = nullptr; int *d_nsurv = nullptr; unsigned int *d_tmin = nullptr;
+    bool screen = false;                                   // grid supported and not switched off (SCL_SCREEN=0)
+    bool in_single_fallback = false;                       // submit_full_locked <-> submit_full_many_locked recursion guard
     unsigned long long *d_topk_scratch = nullptr; int *d_topk_idx = nullptr; float *d_topk_d2 = nullptr;
     double *d_out3 = nullptr;
     unsigned long long *d_blk_part = nullptr; unsigned int *d_done_counter = nullptr;   // fused full-DB epilogue

@@ -16,10 +16,14 @@ constexpr double kBigDist = 10000000.0;   // D.h:1494,1556,1637,1705 initial min
 //   norm   double [cap][S]       column L2 norms (D.h:1523), fp64
 //   rkey   float  [cap][R4]      ring key, row-major (query side), R4 = 4*RG
 //   rkey4  float4 [RG][cap]      ring key, tiled for the top-k scan
+//   inv    float  [cap][S]       1 / column norm in fp32 for the fp16 screening pass (sc_screen.hip): 0 for an
+//                                all-zero column (D.h:1523 skips it), NaN when the norm is not in [2^-60, 2^60]
+//                                (non-finite or extreme values: such keyframes are always scored exactly)
 struct DbView {
     const float4 *desc;
     const double *vkey;
     const double *norm;
+    const float  *inv;
     const float  *rkey;
     const float4 *rkey4;
     int cap;     // slot stride of rkey4
@@ -31,6 +35,7 @@ struct QueryView {          // one descriptor in the same layout (a DB slot or t
     const double *vkey;     // [S]
     const double *norm;     // [S]
     const float  *rkey;     // [R4]
+    const float  *inv;      // [S]
 };
 
 // K1: distanceBtnScanContext for n candidates.
@@ -60,6 +65,29 @@ struct QueryBatch {
 };
 hipError_t launch_sc_distance_batch(const struct DbView &db, const QueryBatch &qb, int SR, double *out_dist, int *out_shift,
                                     float *out_ring_d2, const FullTail &tail, int num_cu, hipStream_t stream);
+// ---- screening pass of the full-DB mode (sc_screen.hip; 64x120 grid) --------------------------------------------
+// Per query i: every keyframe of [base, base+n) gets approx[i*pair_stride + pos] = its reference distance within
+// +- sc_screen_eps() (fp16 matrix-core evaluation of the reference's own 13 shifts; -inf = must be scored exactly),
+// ring_d2 = its ring-key metric; then, in a second small launch, survivors[i*pair_stride ..] = the database slots
+// (ascending) that can still hold the minimum, n_surv[i] their number, and the ring-key top-k of the range.
+// t_min: one word per query, 0xffffffff before the first launch (the select launch re-arms it).
+struct ScreenBatch {
+    int nq;
+    int slot[kMaxQueryBatch], base[kMaxQueryBatch], n[kMaxQueryBatch];
+    size_t pair_stride;
+    float *approx; float *ring_d2; int *survivors; int *n_surv; unsigned int *t_min;
+    int k; float exclude_eps; int *topk_idx; float *topk_d2;
+};
+bool sc_screen_supported(const struct DbView &db, int SR);
+float sc_screen_eps();
+hipError_t launch_sc_screen_batch(const struct DbView &db, const ScreenBatch &sb, int SR, int align_filter, int num_cu, hipStream_t stream);
+hipError_t launch_sc_select_batch(const ScreenBatch &sb, hipStream_t stream);
+// Exact distances of the survivors: query i = slot[i] against the slots survivors[i*pair_stride .. + n_surv[i]) (count
+// read on the device), winner (distance, position relative to base[i], shift) into qb.out3[i] by the fused tail.
+hipError_t launch_sc_distance_survivors(const struct DbView &db, const QueryBatch &qb, int SR, const int *survivors, const int *n_surv,
+                                        double *out_dist, int *out_shift, const FullTail &tail, int num_cu, hipStream_t stream);
+int sc_align_filter_enabled();
+
 // out_ring_d2 (optional): also write the squared ring-key distance (nanoflann metric) of every scored
 // slot; *ring_fused tells whether the selected kernel supports it (the two-sectors-per-lane grids do).
 hipError_t launch_sc_distance(const DbView &db, const QueryView &q, const int *cand, int slot_base,
@@ -87,7 +115,7 @@ hipError_t launch_ringkey_topk(const DbView &db, const float *qkey, int lo, int 
 
 // ingest: row-major wire descriptors (device) -> DB slots first_slot.. (all derived data)
 hipError_t launch_ingest(const float *values, int count, int first_slot,
-                         float4 *desc, double *vkey, double *norm, float *rkey, float4 *rkey4,
+                         float4 *desc, double *vkey, double *norm, float *rkey, float4 *rkey4, float *inv,
                          int cap, int R, int S, hipStream_t stream);
 // tiled -> row-major wire format (read back)
 hipError_t launch_untile(const float4 *desc_slot, int R, int S, float *values, hipStream_t stream);

@@ -82,7 +82,7 @@ __global__ void make_sc_finalize_kernel(const int *gtile, int cells, float *valu
 // One workgroup per descriptor.  values: [count][R*S] row-major floats.
 __global__ __launch_bounds__(256) void ingest_kernel(
     const float *values, int first_slot, float4 *desc, double *vkey, double *norm,
-    float *rkey, float4 *rkey4, int cap, int R, int S)
+    float *rkey, float4 *rkey4, float *inv, int cap, int R, int S)
 {
     extern __shared__ float sv[];                 // [R][S+1]
     const int LS = S + 1;                         // odd-ish stride: column walks hit distinct banks
@@ -116,7 +116,13 @@ __global__ __launch_bounds__(256) void ingest_kernel(
             ss = ss + x * x;
         }
         vkey[(size_t)slot * S + c] = sum / (double)R;
-        norm[(size_t)slot * S + c] = sqrt(ss);
+        const double nrm = sqrt(ss);
+        norm[(size_t)slot * S + c] = nrm;
+        // screening pass operand (sc_screen.hip): fp32 reciprocal norm; 0 = all-zero column, NaN = score this keyframe exactly
+        float iv = __int_as_float(0x7fc00000);
+        if (nrm == 0.0) iv = 0.0f;
+        else if (nrm >= 0x1p-60 && nrm <= 0x1p60) iv = (float)(1.0 / nrm);
+        inv[(size_t)slot * S + c] = iv;
     }
     // ring key (row mean narrowed to float, D.h:1468-1472), sequential over sectors
     for (int r = threadIdx.x; r < 4 * RG; r += blockDim.x) {
@@ -165,7 +171,7 @@ hipError_t launch_make_sc(const void *points, int n, int stride_bytes, int R, in
 }
 
 hipError_t launch_ingest(const float *values, int count, int first_slot,
-                         float4 *desc, double *vkey, double *norm, float *rkey, float4 *rkey4,
+                         float4 *desc, double *vkey, double *norm, float *rkey, float4 *rkey4, float *inv,
                          int cap, int R, int S, hipStream_t stream)
 {
     if (count <= 0) return hipSuccess;
@@ -180,7 +186,7 @@ hipError_t launch_ingest(const float *values, int count, int first_slot,
         attr_set.store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(ingest_kernel, dim3(count), dim3(256), lds, stream,
-                       values, first_slot, desc, vkey, norm, rkey, rkey4, cap, R, S);
+                       values, first_slot, desc, vkey, norm, rkey, rkey4, inv, cap, R, S);
     return hipGetLastError();
 }
 

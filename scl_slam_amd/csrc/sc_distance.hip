@@ -45,6 +45,7 @@ struct ScArgs {
     const int *cand;
     int slot_base;
     int n;
+    const int *n_dev;         // != nullptr: the number of candidates is read on the device (survivors of the screening pass)
     int S;
     int SR;
     int NW;   // waves per candidate
@@ -349,7 +350,12 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScBatchArgs ab)
     float *pf = reinterpret_cast<float *>(vk2 + 2 * S);
     int *next_ticket = reinterpret_cast<int *>(wbase + nwaves * wsz);    // workgroup-wide candidate dispenser
 
-    for (int idx = threadIdx.x; idx < RG * S; idx += blockDim.x) {
+    // Candidates of this workgroup: a contiguous range, handed out wave by wave through an LDS counter (below).
+    // A workgroup without candidates (few survivors of the screening pass) skips the query staging altogether.
+    const int n_cand = a.n_dev ? *a.n_dev : a.n;
+    const int c_lo = (int)(((long long)bid * n_cand) / nbk);
+    const int c_hi = (int)(((long long)(bid + 1) * n_cand) / nbk);
+    for (int idx = threadIdx.x; idx < (c_lo < c_hi ? RG * S : 0); idx += blockDim.x) {
         const int rg = idx / S, c = idx - rg * S;
         const float4 v = a.q_desc[idx];
         double *dst = Qd + (rg * 4) * QS + c;
@@ -359,7 +365,7 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScBatchArgs ab)
             dst[0] = (double)v.x; dst[QS] = (double)v.y; dst[2 * QS] = (double)v.z; dst[3 * QS] = (double)v.w;
         }
     }
-    for (int c = threadIdx.x; c < S; c += blockDim.x) {
+    for (int c = threadIdx.x; c < (c_lo < c_hi ? S : 0); c += blockDim.x) {
         const double nv = a.q_norm[c];
         nqe[c] = nv;
         if (c < W + 1) nqe[c + S] = nv;
@@ -372,8 +378,6 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScBatchArgs ab)
     // counter.  The two waves that share a SIMD are not served equally (the older one wins the
     // VALU arbitration), so a static split leaves waves 4-7 ~25 % behind; first come, first served
     // evens it out.
-    const int c_lo = (int)(((long long)bid * a.n) / nbk);
-    const int c_hi = (int)(((long long)(bid + 1) * a.n) / nbk);
     if (threadIdx.x == 0) *next_ticket = c_lo + nwaves;
     __syncthreads();                           // the only workgroup barrier
 
@@ -893,7 +897,8 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScBatchArgs ab)
         if (my_bd == bd && my_pos == bpos && ((lane & 63) == __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(my_bd == bd && my_pos == bpos)) - 1))) {
             const bool ok = bd < kBigDist;
             a.out3[0] = ok ? bd : kBigDist;
-            a.out3[1] = ok ? (double)bpos : -1.0;
+            // explicit candidate list: report the winner's slot relative to the range start, like the contiguous form
+            a.out3[1] = ok ? (double)(a.cand ? a.cand[bpos] - a.slot_base : bpos) : -1.0;
             a.out3[2] = ok ? (double)my_shift : 0.0;
         }
         unsigned long long prev = 0ull;
@@ -918,7 +923,7 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScBatchArgs ab)
 }
 
 template <int RG, int W, int CH, int S, int MAXT = 512, bool STAMP = false>
-hipError_t launch_wave(const ScBatchArgs &batch_in, int num_cu, hipStream_t stream)
+hipError_t launch_wave(const ScBatchArgs &batch_in, int num_cu, hipStream_t stream, int fixed_blocks = 0)
 {
     ScBatchArgs ab = batch_in;
     ScArgs &a = ab.q[0];                                   // sizes the launch (batch: the largest n, set by the caller)
@@ -933,9 +938,10 @@ hipError_t launch_wave(const ScBatchArgs &batch_in, int num_cu, hipStream_t stre
     static const int wave_cap = [] { const char *e = getenv("SCL_SC_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1 << 20; }();
     if (waves > wave_cap) waves = wave_cap;               // diagnostic: fewer waves per CU
     if (waves < 1) return hipErrorInvalidValue;
-    while (waves > 1 && n_launch < num_cu * waves) waves = (waves + 1) / 2;
+    if (!fixed_blocks) while (waves > 1 && n_launch < num_cu * waves) waves = (waves + 1) / 2;
     int blocks = (n_launch + waves - 1) / waves;
     if (blocks > num_cu) blocks = num_cu;
+    if (fixed_blocks) blocks = fixed_blocks;               // candidate count known only on the device: full-width workgroups
     const int grid = blocks * ab.nq;                       // workgroups [qi*blocks, (qi+1)*blocks) serve query qi
     ab.nb = blocks;
     const size_t lds = fixed + per_wave * waves + 16;      // + the candidate dispenser
@@ -1164,7 +1170,7 @@ hipError_t launch_sc_distance(const DbView &db, const QueryView &q, const int *c
     ScArgs a;
     a.desc = db.desc; a.vkey = db.vkey; a.norm = db.norm;
     a.q_desc = q.desc; a.q_vkey = q.vkey; a.q_norm = q.norm;
-    a.cand = cand; a.slot_base = slot_base; a.n = n; a.S = db.S; a.SR = SR;
+    a.cand = cand; a.slot_base = slot_base; a.n = n; a.n_dev = nullptr; a.S = db.S; a.SR = SR;
     a.NW = (db.S + kWave - 1) / kWave; a.G = 1;
     a.ablate = ablate_flags();
     a.align_filter = align_filter_enabled();
@@ -1217,7 +1223,7 @@ hipError_t launch_sc_distance_batch(const DbView &db, const QueryBatch &qb, int 
         a.desc = db.desc; a.vkey = db.vkey; a.norm = db.norm;
         a.q_desc = db.desc + slot * (size_t)(db.RG * db.S); a.q_vkey = db.vkey + slot * db.S;
         a.q_norm = db.norm + slot * db.S; a.q_rkey = db.rkey + slot * (size_t)(4 * db.RG);
-        a.cand = nullptr; a.slot_base = qb.base[i]; a.n = qb.n[i]; a.S = db.S; a.SR = SR;
+        a.cand = nullptr; a.slot_base = qb.base[i]; a.n = qb.n[i]; a.n_dev = nullptr; a.S = db.S; a.SR = SR;
         a.NW = (db.S + kWave - 1) / kWave; a.G = 1;
         a.ablate = ablate_flags(); a.stamps = nullptr; a.align_filter = align_filter_enabled();
         a.rkey4 = db.rkey4; a.rk_cap = db.cap;
@@ -1235,6 +1241,37 @@ hipError_t launch_sc_distance_batch(const DbView &db, const QueryBatch &qb, int 
     if (db.RG == 5 && W == 7 && db.S == 60) return launch_wave<5, 7, 5, 60>(ab, num_cu, stream);
     return launch_wave<16, 13, 4, 120, 512>(ab, num_cu, stream);
 }
+
+hipError_t launch_sc_distance_survivors(const DbView &db, const QueryBatch &qb, int SR, const int *survivors, const int *n_surv,
+                                        double *out_dist, int *out_shift, const FullTail &tail, int num_cu, hipStream_t stream)
+{
+    if (qb.nq < 1 || qb.nq > kMaxQueryBatch || !(db.RG == 16 && db.S == 120 && SR == 6)) return hipErrorInvalidValue;
+    ScBatchArgs ab{};
+    ab.nq = qb.nq;
+    for (int i = 0; i < qb.nq; ++i) {
+        ScArgs &a = ab.q[i];
+        const size_t slot = (size_t)qb.slot[i];
+        a.desc = db.desc; a.vkey = db.vkey; a.norm = db.norm;
+        a.q_desc = db.desc + slot * (size_t)(db.RG * db.S); a.q_vkey = db.vkey + slot * db.S;
+        a.q_norm = db.norm + slot * db.S; a.q_rkey = db.rkey + slot * (size_t)(4 * db.RG);
+        a.cand = survivors + (size_t)i * qb.pair_stride; a.slot_base = qb.base[i]; a.n = qb.n[i]; a.n_dev = n_surv + i;
+        a.S = db.S; a.SR = SR; a.NW = (db.S + kWave - 1) / kWave; a.G = 1;
+        a.ablate = ablate_flags(); a.stamps = nullptr; a.align_filter = align_filter_enabled();
+        a.rkey4 = db.rkey4; a.rk_cap = db.cap;
+        a.out_dist = out_dist + (size_t)i * qb.pair_stride; a.out_shift = out_shift + (size_t)i * qb.pair_stride;
+        a.out_d2 = nullptr;                                            // the ring-key top-k came from the screening pass
+        a.blk_part = tail.blk_part + (size_t)i * kTailBlocks * kTailRec; a.done_counter = tail.done_counter + i;
+        a.out3 = qb.out3[i];
+        a.topk_idx = nullptr; a.topk_d2 = nullptr; a.topk_k = 0; a.exclude_eps = 0.0f;
+    }
+    for (int i = qb.nq; i < kMaxQueryBatch; ++i) ab.q[i] = ab.q[0];
+    ab.nb = 1;
+    // the survivor counts live on the device: 64 full-width workgroups per query cover any count; a workgroup whose
+    // share is empty leaves before staging the query
+    return launch_wave<16, 13, 4, 120, 512>(ab, num_cu, stream, 64);
+}
+
+int sc_align_filter_enabled() { return align_filter_enabled(); }
 
 bool sc_distance_fuses_ring(const DbView &db, int SR)
 {

@@ -1,0 +1,583 @@
+// sc_screen.hip -- K1s: the screening pass of the full-DB mode (64x120 grid).
+//
+// Full-DB detection needs the ARG-MIN over the database of distanceBtnScanContext (descriptor.h:1538-1569), not
+// every distance.  This pass gives every keyframe a guaranteed interval around its reference distance; only the
+// keyframes whose interval reaches below the smallest upper bound are then scored by the exact fp64 kernel
+// (sc_distance.hip), so the winner -- index, shift and fp64 distance -- is the reference's, bit for bit.
+//
+// Per keyframe:
+//   1. the reference's own alignment, exactly (fastAlignUsingVkey, D.h:1491-1511: fp32 correlation filter with the
+//      exact fp64 evaluation as fallback -- the same code path as sc_distance.hip);
+//   2. the 13 shifted cosine distances of D.h:1545-1566 in reduced precision on the matrix cores: both descriptors
+//      with unit columns (x / |column|, fp32) rounded to fp16, products exact, fp32 accumulation:
+//        sim[t] = sum over query sectors x and rings r of  Qh[r][x + t] * Kh[r][(x - b) mod S],   b = first shift
+//      which is ONE matrix product per 16 keyframes: M = 16 shift rows (13 used), N = 16 keyframes, K = 7 680
+//      = (ring group, sector, ring) -- v_mfma_f32_16x16x32_f16, 240 per 16 keyframes.  The effective-sector counts
+//      (D.h:1523-1526) come from the same product on 0/1 indicators (15 more MFMAs), exact;
+//   3. d~ = min_t (1 - sim[t] / n_eff[t]).
+// Error of d~ against the reference distance of the same shift: each cosine is off by at most
+//   2u + u^2 (u = 2^-11, fp16 rounding of both unit vectors, Cauchy-Schwarz) + 16 * 2^-25 (fp16 subnormals)
+//   + 3 * 2^-23 (fp32 scaling by the reciprocal norms) < 9.78e-4,
+// the accumulation (chains of 60 MFMAs = 1 920 products per wave, then 4 partials) adds at most 1 924 * 2^-23 =
+// 2.3e-4 even if every addition truncated; the mean over the effective sectors keeps that bound.  kScreenEps = 1.5e-3
+// leaves 20 % on top.  A keyframe can hold the minimum only if d~ <= min(d~) + 2 * kScreenEps.
+// Keyframes (or queries) with a column norm outside [2^-60, 2^60] or non-finite are never screened out.
+//
+// Mapping: workgroup = 4 waves, 16 keyframes per step.  Wave w aligns keyframes 4w..4w+3, then streams ring groups
+// 4w..4w+3 of all 16: lane (n, j) = (lane & 15, lane >> 4) reads keyframe n's columns (x - b_n) mod S for
+// x = 8 xb + 2j, +1 as two float4 (4 rings each) -- the MFMA's B fragment after scaling and conversion -- through
+// a ring of D k-steps; the A fragment is 16 bytes of the fp16 query in LDS.  Partial sums meet in LDS, wave 0
+// finishes.  Bound: HBM (4 R S + 8 S + 4 S bytes per keyframe actually read; SURVEY 8(d) counts 4 R S + 8 S).
+#include <atomic>
+
+#include "device_common.hpp"
+#include "kernels.hpp"
+
+namespace scl {
+
+namespace {
+
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+struct ScreenArgs {
+    const float4 *desc; const double *vkey; const float *inv;
+    const float4 *q_desc; const double *q_vkey; const float *q_inv; const float *q_rkey;
+    const float4 *rkey4; int rk_cap;
+    int slot_base, n;
+    float *out_approx;        // [n] d~ ; -inf = must be scored exactly, +inf = no finite distance
+    float *out_d2;            // [n] squared ring-key distance (nanoflann's metric), for the top-k
+    unsigned int *t_min;      // ordered image of min d~ over the screened keyframes (atomicMin; reset by the select kernel)
+    int align_filter;
+};
+
+struct ScreenBatchArgs { ScreenArgs q[kMaxQueryBatch]; int nq, nb; };
+
+__device__ __forceinline__ int wrapS(int x, int S)
+{   // x in (-S, 2S)
+    x = x < 0 ? x + S : x;
+    return x >= S ? x - S : x;
+}
+
+__device__ __forceinline__ void wave_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void pin3(double &a, double &b, double &c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c) :: "memory"); }
+__device__ __forceinline__ void pin_f2(f2 &a, f2 &b) { asm volatile("" : "+v"(a), "+v"(b) :: "memory"); }
+
+__device__ __forceinline__ unsigned int float_to_ordered_u(float f)
+{
+    const unsigned int b = (unsigned int)__float_as_int(f);
+    return (b >> 31) ? ~b : (b | 0x80000000u);
+}
+
+// fastAlignUsingVkey (D.h:1491-1511) for one keyframe, wave-wide; returns the reference's arg-min shift.
+// vk = the keyframe's sector key at sectors 2*ll, 2*ll+1 (ll = min(lane, S/2 - 1)).  Same arithmetic as the
+// alignment phase of sc_distance_wave_kernel (filter bound, exact fallback, tie rules).
+template <int S>
+__device__ __forceinline__ int align_keyframe(const double2 vk, int lane, bool use_filter, float qn2,
+                                              double *vk2, float *pf, const double *vq, const float *vqf0, const float *vqf1)
+{
+    constexpr int L = S >> 1;
+    constexpr int PFS = 288;
+    const bool active = lane < L;
+    const int ll = active ? lane : L - 1;
+    const int j0 = 2 * ll;
+    const double kInf = __longlong_as_double(0x7ff0000000000000LL);
+    wave_fence();
+    *reinterpret_cast<double2 *>(vk2 + j0) = vk;
+    *reinterpret_cast<double2 *>(vk2 + j0 + S) = vk;
+    int filtered = -1;
+    if (use_filter) {
+        const f2 kf = f2{(float)vk.x, (float)vk.y};
+        float *pf1 = pf + PFS;
+        *reinterpret_cast<f2 *>(pf + j0) = kf;          *reinterpret_cast<f2 *>(pf + j0 + S) = kf;
+        *reinterpret_cast<f2 *>(pf1 + j0 + 2) = kf;     *reinterpret_cast<f2 *>(pf1 + j0 + S + 2) = kf;
+        wave_fence();
+        const int E = S - 2 * lane;
+        const float4 *pw = reinterpret_cast<const float4 *>((lane & 1) ? pf1 + E + 2 : pf + E);
+        const float4 *q0w = reinterpret_cast<const float4 *>(vqf0);
+        const float4 *q1w = reinterpret_cast<const float4 *>(vqf1);
+        constexpr int NG = S / 4, FB = 3;
+        static_assert(S % 4 == 0 && NG % FB == 0, "filter batches must tile the sectors");
+        f2 ce = f2{0.f, 0.f}, co = f2{0.f, 0.f};
+        float4 pb[2][FB], qa[2][FB], qb[2][FB];
+#pragma unroll
+        for (int v = 0; v < FB; ++v) { pb[0][v] = pw[v]; qa[0][v] = q0w[v]; qb[0][v] = q1w[v]; }
+#pragma unroll
+        for (int bt = 0; bt < NG / FB; ++bt) {
+            if (bt + 1 < NG / FB) {
+#pragma unroll
+                for (int v = 0; v < FB; ++v) {
+                    pb[(bt + 1) & 1][v] = pw[(bt + 1) * FB + v];
+                    qa[(bt + 1) & 1][v] = q0w[(bt + 1) * FB + v];
+                    qb[(bt + 1) & 1][v] = q1w[(bt + 1) * FB + v];
+                }
+            }
+            pin_f2(ce, co);
+#pragma unroll
+            for (int v = 0; v < FB; ++v) {
+                const float4 pv = pb[bt & 1][v], a0 = qa[bt & 1][v], a1 = qb[bt & 1][v];
+                ce = __builtin_elementwise_fma(f2{a0.x, a0.y}, f2{pv.x, pv.y}, ce);
+                ce = __builtin_elementwise_fma(f2{a0.z, a0.w}, f2{pv.z, pv.w}, ce);
+                co = __builtin_elementwise_fma(f2{a1.x, a1.y}, f2{pv.x, pv.y}, co);
+                co = __builtin_elementwise_fma(f2{a1.z, a1.w}, f2{pv.z, pv.w}, co);
+            }
+            pin_f2(ce, co);
+        }
+        const float c_even = ce.x + ce.y, c_odd = co.x + co.y;
+        const float kn2 = wave_sum_f32_dpp(active ? kf.x * kf.x + kf.y * kf.y : 0.f);
+        const float nsum = sqrtf(qn2) + sqrtf(kn2);
+        const float eps = 4.07e-6f * sqrtf(qn2) * sqrtf(kn2) + 1e-12f * (qn2 + kn2);
+        const float cmax = wave_max_f32_dpp(active ? fmaxf(c_even, c_odd) : -3.0e38f);
+        const float cut = cmax - 4.0f * eps;
+        const bool fe = active && !(c_even < cut), fo = active && !(c_odd < cut);
+        const unsigned long long me = __builtin_amdgcn_ballot_w64(fe), mo = __builtin_amdgcn_ballot_w64(fo);
+        const bool sane = (qn2 < 3.0e38f) && (kn2 < 3.0e38f) && (nsum * nsum < 0.9e14f);
+        if (sane && __popcll(me) + __popcll(mo) == 1)
+            filtered = me ? 2 * (__ffsll((long long)me) - 1) : 2 * (__ffsll((long long)mo) - 1) + 1;
+    }
+    wave_fence();
+    if (filtered >= 0) return filtered;
+    double best = kInf;
+    int bshift = 0x7fffffff;
+    {
+        const double *p = vk2 + S - j0;
+        const double2 *pp = reinterpret_cast<const double2 *>(p);
+        double prev = p[-1];
+        double ss0 = 0.0, ss1 = 0.0;
+        constexpr int npair = S >> 1;
+        constexpr int BT = 3;                              // (5 in sc_distance.hip; this kernel runs three waves per SIMD)
+        static_assert(npair % BT == 0, "alignment batches must tile the sector pairs");
+        const double2 *qq = reinterpret_cast<const double2 *>(vq);
+        double2 pb[2][BT], qb[2][BT];
+#pragma unroll
+        for (int v = 0; v < BT; ++v) { pb[0][v] = pp[v]; qb[0][v] = qq[v]; }
+#pragma unroll
+        for (int bt = 0; bt < npair / BT; ++bt) {
+            if (bt + 1 < npair / BT) {
+#pragma unroll
+                for (int v = 0; v < BT; ++v) { pb[(bt + 1) & 1][v] = pp[(bt + 1) * BT + v]; qb[(bt + 1) & 1][v] = qq[(bt + 1) * BT + v]; }
+            }
+            pin3(ss0, ss1, prev);
+#pragma unroll
+            for (int v = 0; v < BT; ++v) {
+                const double2 pv = pb[bt & 1][v];
+                const double qx = qb[bt & 1][v].x, qy = qb[bt & 1][v].y;
+                const double d0 = qx - pv.x, d1 = qx - prev;
+                ss0 = ss0 + d0 * d0;
+                ss1 = ss1 + d1 * d1;
+                const double e0 = qy - pv.y, e1 = qy - pv.x;
+                ss0 = ss0 + e0 * e0;
+                ss1 = ss1 + e1 * e1;
+                prev = pv.y;
+            }
+            pin3(ss0, ss1, prev);
+        }
+        const double n0 = sqrt(ss0), n1 = sqrt(ss1);
+        if (active && n0 < kBigDist) { best = n0; bshift = j0; }
+        if (active && n1 < kBigDist && n1 < best) { best = n1; bshift = j0 + 1; }
+    }
+    wave_argmin_dpp(best, bshift);
+    return __builtin_amdgcn_readfirstlane(best < kBigDist ? bshift : 0);
+}
+
+constexpr float kScreenEps = 1.5e-3f;          // see the error budget at the top of this file
+constexpr int kScreenWaves = 4;
+constexpr int kGroup = 16;                     // keyframes per matrix product (the MFMA's N)
+
+// D = k-steps of loads in flight per wave; OCC = waves per SIMD the register allocation is held to
+// (3: 168 registers, three workgroups per CU; 2: 256 registers, two workgroups per CU)
+template <int RG, int S, int W, int D, int OCC>
+__global__ __launch_bounds__(kScreenWaves * kWave, OCC) void sc_screen_kernel(ScreenBatchArgs ab)
+{
+    constexpr int NWV = kScreenWaves;
+    constexpr int RPW = RG / NWV;                      // ring groups per wave
+    constexpr int QSX = S + 16;                        // extended query row (sectors)
+    constexpr int NXB = S / 8;                         // k-steps per ring group (8 sectors x 4 rings = K 32)
+    constexpr int L = S >> 1;
+    constexpr int PFS = 288;
+    static_assert(RG % NWV == 0 && S % 8 == 0 && NXB % D == 0 && W <= 16, "tiling");
+    static_assert(S / 2 <= kWave && S % 4 == 0, "alignment phase: two sectors per lane");
+
+    const int nbk = ab.nb;
+    const int qi = ab.nq > 1 ? (int)blockIdx.x / nbk : 0;
+    const int bid = (int)blockIdx.x - qi * nbk;
+    const ScreenArgs &a = ab.q[qi];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: wave-derived addresses stay in SGPRs
+    const int SR = (W - 1) / 2;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    _Float16 *Qh = reinterpret_cast<_Float16 *>(smem_raw);                       // [RG + 1][QSX][4]
+    double *vq = reinterpret_cast<double *>(Qh + (size_t)(RG + 1) * QSX * 4);    // [S]
+    float *vqf0 = reinterpret_cast<float *>(vq + S);                             // [S]
+    float *vqf1 = vqf0 + S;                                                      // [S]
+    constexpr int kAlignBytes = 2 * S * 8 + (PFS + 2 * S + 8) * 4;               // vk2 + the two fp32 key copies
+    constexpr int kAlignStride = (kAlignBytes + 15) & ~15;
+    unsigned char *wscratch = reinterpret_cast<unsigned char *>(vqf1 + S) + (size_t)wave * kAlignStride;
+    double *vk2 = reinterpret_cast<double *>(wscratch);
+    float *pf = reinterpret_cast<float *>(vk2 + 2 * S);
+    unsigned char *shared_tail = reinterpret_cast<unsigned char *>(vqf1 + S) + (size_t)NWV * kAlignStride;
+    f4v *part = reinterpret_cast<f4v *>(shared_tail);                            // [NWV][64] partial sums
+    f4v *npart = part + NWV * kWave;                                             // [64] effective-sector counts
+    int *s_start = reinterpret_cast<int *>(npart + kWave);                       // [16]
+    int *bad_flag = s_start + kGroup;                                            // [16]
+    int *q_bad_flag = bad_flag + kGroup;                                         // [1]
+
+    // ---- stage the query: unit columns in fp16, extended by 16 sectors; indicator row; sector-key copies ----
+    if (threadIdx.x == 0) *q_bad_flag = 0;
+    for (int i = threadIdx.x; i < kGroup; i += blockDim.x) bad_flag[i] = 0;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < RG * S; idx += blockDim.x) {
+        const int rg = idx / S, c = idx - rg * S;
+        const float4 v = a.q_desc[idx];
+        const float iv = a.q_inv[c];
+        if (iv != iv) *q_bad_flag = 1;                                           // benign race: everyone writes 1
+        h4 hv;
+        hv[0] = (_Float16)(v.x * iv); hv[1] = (_Float16)(v.y * iv); hv[2] = (_Float16)(v.z * iv); hv[3] = (_Float16)(v.w * iv);
+        *reinterpret_cast<h4 *>(Qh + ((size_t)rg * QSX + c) * 4) = hv;
+        if (c < 16) *reinterpret_cast<h4 *>(Qh + ((size_t)rg * QSX + c + S) * 4) = hv;
+    }
+    for (int c = threadIdx.x; c < S; c += blockDim.x) {
+        h4 ind; ind[0] = (_Float16)(a.q_inv[c] != 0.0f ? 1.0f : 0.0f); ind[1] = ind[2] = ind[3] = (_Float16)0.0f;
+        *reinterpret_cast<h4 *>(Qh + ((size_t)RG * QSX + c) * 4) = ind;
+        if (c < 16) *reinterpret_cast<h4 *>(Qh + ((size_t)RG * QSX + c + S) * 4) = ind;
+        const double kv = a.q_vkey[c];
+        vq[c] = kv;
+        vqf0[c] = (float)kv;
+        vqf1[c == 0 ? S - 1 : c - 1] = (float)kv;
+    }
+    __syncthreads();
+    const bool q_bad = *q_bad_flag != 0;
+
+    const bool active = lane < L;
+    const int ll = active ? lane : L - 1;
+    const int j0 = 2 * ll;
+    const bool use_filter = a.align_filter != 0;
+    float qn2 = 0.f;
+    if (use_filter) {
+        const f2 qv = *reinterpret_cast<const f2 *>(vqf0 + j0);
+        qn2 = wave_sum_f32_dpp(active ? qv.x * qv.x + qv.y * qv.y : 0.f);
+    }
+    float4 qrk = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < RG) qrk = *reinterpret_cast<const float4 *>(a.q_rkey + 4 * lane);
+
+    const int n16 = lane & 15, j4 = lane >> 4;
+    const int ngroups = (a.n + kGroup - 1) / kGroup;
+    float run_min = __int_as_float(0x7f800000);                                  // wave 0: min d~ over screened keyframes
+
+    for (int g = bid; g < ngroups; g += nbk) {
+        const int c_base = g * kGroup;
+        // ---- phase A: this wave aligns keyframes 4w .. 4w+3 of the group (and forms their ring-key metric) ----
+        // (one keyframe at a time, the next one's sector key and ring key requested before the current one is aligned:
+        // four inlined copies of the alignment with every operand live at once do not fit the register file)
+        auto fetch = [&](int u, double2 &vk_o, float4 &rk_o) {
+            const int ci = c_base + wave * (kGroup / NWV) + u;
+            const int slot = a.slot_base + (ci < a.n ? ci : a.n - 1);
+            vk_o = *reinterpret_cast<const double2 *>(a.vkey + (size_t)slot * S + j0);
+            rk_o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lane < RG) rk_o = a.rkey4[(size_t)lane * a.rk_cap + slot];
+        };
+        double2 vk_cur; float4 rk_cur;
+        fetch(0, vk_cur, rk_cur);
+#pragma unroll 1
+        for (int u = 0; u < kGroup / NWV; ++u) {
+            const int ci = c_base + wave * (kGroup / NWV) + u;
+            double2 vk_nxt = vk_cur; float4 rk_nxt = rk_cur;
+            if (u + 1 < kGroup / NWV) fetch(u + 1, vk_nxt, rk_nxt);
+            const int al = align_keyframe<S>(vk_cur, lane, use_filter, qn2, vk2, pf, vq, vqf0, vqf1);
+            if (lane == 0) s_start[wave * (kGroup / NWV) + u] = wrapS(al - SR, S);
+            // nanoflann's metric (nanoflann.hpp:383-408): four dimensions per step, fp32, groups accumulated in order
+            float grp = 0.0f;
+            if (lane < RG) {
+                const float4 b = rk_cur;
+                const float d0 = qrk.x - b.x, d1 = qrk.y - b.y, d2 = qrk.z - b.z, d3 = qrk.w - b.w;
+                grp = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            }
+            float result = 0.0f;
+#pragma unroll
+            for (int r = 0; r < RG; ++r) result += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(grp), r));
+            if (lane == 0 && ci < a.n) a.out_d2[ci] = result;
+            vk_cur = vk_nxt; rk_cur = rk_nxt;
+        }
+        __syncthreads();                                                         // B1: the 16 first shifts are known
+
+        // ---- phase G: ring groups 4w .. 4w+3 of all 16 keyframes ------------------------------------------------
+        const int ci_n = c_base + n16;
+        const int slot_n = a.slot_base + (ci_n < a.n ? ci_n : a.n - 1);
+        const int b_n = s_start[n16];
+        const int col0 = wrapS(2 * j4 - b_n, S);                                 // keyframe column that meets query sector 2j at shift b
+        // Addresses = one wave-uniform 64-bit base per group + 32-bit per-lane byte offsets (the 16 keyframes of a group
+        // are consecutive slots: < 16 * 30 KB apart), so the 30 column addresses of a row cost 30 registers, not 60.
+        const int first_slot = a.slot_base + c_base;
+        const unsigned int rel_n = (unsigned int)(slot_n - first_slot);
+        const char *inv_base = reinterpret_cast<const char *>(a.inv + (size_t)first_slot * S);
+        const unsigned int inv_off = rel_n * (unsigned int)(S * 4);
+        float iv0[NXB], iv1[NXB];
+        bool bad = false;
+        {
+            int c = col0;
+#pragma unroll
+            for (int xb = 0; xb < NXB; ++xb) {
+                const int c1 = c + 1 == S ? 0 : c + 1;
+                iv0[xb] = *reinterpret_cast<const float *>(inv_base + (inv_off + (unsigned int)c * 4u));
+                iv1[xb] = *reinterpret_cast<const float *>(inv_base + (inv_off + (unsigned int)c1 * 4u));
+                c += 8; c = c >= S ? c - S : c;
+            }
+#pragma unroll
+            for (int xb = 0; xb < NXB; ++xb) bad |= (iv0[xb] != iv0[xb]) | (iv1[xb] != iv1[xb]);
+        }
+        if (bad) bad_flag[n16] = 1;
+        const char *desc_base = reinterpret_cast<const char *>(a.desc + (size_t)first_slot * (RG * S) + (size_t)(wave * RPW) * S);
+        const unsigned int desc_off = rel_n * (unsigned int)(RG * S * 16);
+        float4 ra[D], rb[D];
+        int c_iss = col0, xb_iss = 0, r_iss = 0;
+        auto issue = [&](int sl) {
+            if (r_iss < RPW) {
+                const unsigned int row = desc_off + (unsigned int)r_iss * (unsigned int)(S * 16);
+                const int c1 = c_iss + 1 == S ? 0 : c_iss + 1;
+                ra[sl] = *reinterpret_cast<const float4 *>(desc_base + (row + (unsigned int)c_iss * 16u));
+                rb[sl] = *reinterpret_cast<const float4 *>(desc_base + (row + (unsigned int)c1 * 16u));
+            }
+            c_iss += 8; c_iss = c_iss >= S ? c_iss - S : c_iss;
+            if (++xb_iss == NXB) { xb_iss = 0; ++r_iss; c_iss = col0; }
+        };
+#pragma unroll
+        for (int sl = 0; sl < D; ++sl) issue(sl);
+        f4v acc = {0.f, 0.f, 0.f, 0.f};
+        const _Float16 *qrow = Qh + ((size_t)(wave * RPW) * QSX + 2 * j4 + n16) * 4;   // A fragment: row t = lane & 15
+        // One k-step = 2 global loads (issued D steps ahead), 8 VALU (scale, convert), 1 LDS read of the A fragment
+        // (requested one step ahead), 1 MFMA.  The scheduling fences keep LLVM from hoisting every step's loads and
+        // conversions to the top of the unrolled row (which it does, and then needs > 256 registers).
+        auto load_a = [&](const _Float16 *ap) -> h8 {
+            const h4 alo = *reinterpret_cast<const h4 *>(ap), ahi = *reinterpret_cast<const h4 *>(ap + 4);
+            return __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        h8 a_nxt = load_a(qrow);
+#pragma unroll 1
+        for (int r = 0; r < RPW; ++r) {
+#pragma unroll
+            for (int xb = 0; xb < NXB; ++xb) {
+                const int sl = xb % D;
+                const float4 u = ra[sl], v = rb[sl];
+                issue(sl);
+                const h8 afrag = a_nxt;
+                // next step's A fragment (the step after the row's last one is the next row's first; past the end it
+                // re-reads inside the staged query, values unused)
+                a_nxt = load_a(xb + 1 < NXB ? qrow + (size_t)(8 * (xb + 1)) * 4 : qrow + (size_t)(r + 1 < RPW ? QSX : 0) * 4);
+                h8 bfrag;
+                bfrag[0] = (_Float16)(u.x * iv0[xb]); bfrag[1] = (_Float16)(u.y * iv0[xb]);
+                bfrag[2] = (_Float16)(u.z * iv0[xb]); bfrag[3] = (_Float16)(u.w * iv0[xb]);
+                bfrag[4] = (_Float16)(v.x * iv1[xb]); bfrag[5] = (_Float16)(v.y * iv1[xb]);
+                bfrag[6] = (_Float16)(v.z * iv1[xb]); bfrag[7] = (_Float16)(v.w * iv1[xb]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag, acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            qrow += (size_t)QSX * 4;
+        }
+        part[wave * kWave + lane] = acc;
+        if (wave == 1 % NWV) {
+            // effective-sector counts (D.h:1523-1526): the same product on 0/1 indicators (exact in fp16 / fp32)
+            f4v nacc = {0.f, 0.f, 0.f, 0.f};
+            const _Float16 *irow = Qh + ((size_t)RG * QSX + 2 * j4 + n16) * 4;
+#pragma unroll
+            for (int xb = 0; xb < NXB; ++xb) {
+                h8 bfrag;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bfrag[e] = (_Float16)0.0f;
+                bfrag[0] = (_Float16)(iv0[xb] != 0.0f ? 1.0f : 0.0f);
+                bfrag[4] = (_Float16)(iv1[xb] != 0.0f ? 1.0f : 0.0f);
+                const _Float16 *ap = irow + (size_t)(8 * xb) * 4;
+                const h4 alo = *reinterpret_cast<const h4 *>(ap), ahi = *reinterpret_cast<const h4 *>(ap + 4);
+                const h8 afrag = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+                nacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag, nacc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            npart[lane] = nacc;
+        }
+        __syncthreads();                                                         // B2: partial sums are in LDS
+
+        // ---- epilogue (wave 0): lane (n, q) holds shifts 4q .. 4q+3 of keyframe n ----------------------------
+        if (wave == 0) {
+            f4v s = part[lane];
+#pragma unroll
+            for (int w = 1; w < NWV; ++w) s += part[w * kWave + lane];
+            const f4v ne = npart[lane];
+            float dmin = __int_as_float(0x7f800000);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = 4 * j4 + r;
+                const float d = 1.0f - s[r] / ne[r];
+                if (t < W && ne[r] > 0.5f && d < dmin) dmin = d;                 // n_eff = 0: 0/0 in the reference, never wins
+            }
+            dmin = fminf(dmin, __shfl_xor(dmin, 16, kWave));
+            dmin = fminf(dmin, __shfl_xor(dmin, 32, kWave));
+            const bool mine = lane < kGroup && ci_n < a.n;
+            const bool exact_only = q_bad || bad_flag[n16] != 0 || !(dmin == dmin);
+            if (mine) a.out_approx[ci_n] = exact_only ? __int_as_float(0xff800000) : dmin;
+            float contrib = (mine && !exact_only) ? dmin : __int_as_float(0x7f800000);
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) contrib = fminf(contrib, __shfl_xor(contrib, off, kWave));
+            run_min = fminf(run_min, __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(contrib))));
+            if (lane < kGroup) bad_flag[lane] = 0;
+        }
+    }
+    if (wave == 0 && lane == 0 && run_min < __int_as_float(0x7f800000)) atomicMin(a.t_min, float_to_ordered_u(run_min));
+}
+
+// ---- select: survivors of the screening (ascending slot order) + the ring-key top-k ----------------------------
+// One workgroup per query.  survivors[i] = database slots (ascending) whose d~ <= min d~ + 2 eps, or flagged
+// "score exactly"; *n_surv their number.  Also the k nearest ring keys from the metric the screening pass produced
+// (k rounds of "smallest key larger than the previous pick"; keys (d2 bits << 32 | position) are unique).
+struct SelectArgs {
+    const float *approx; const float *d2; int n; int slot_base;
+    unsigned int *t_min; int *survivors; int *n_surv;
+    int k; float exclude_eps; int *topk_idx; float *topk_d2;
+};
+struct SelectBatchArgs { SelectArgs q[kMaxQueryBatch]; };
+
+__global__ __launch_bounds__(1024) void sc_select_kernel(SelectBatchArgs sb)
+{
+    const SelectArgs &a = sb.q[blockIdx.x];
+    __shared__ int wcount[16];
+    __shared__ int base_s;
+    __shared__ unsigned long long sk[16];
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+    const unsigned int tm = *a.t_min;
+    float thr;
+    {
+        const unsigned int b = (tm >> 31) ? (tm & 0x7fffffffu) : ~tm;            // inverse of float_to_ordered_u
+        thr = tm == 0xffffffffu ? __int_as_float(0xff800000) : __int_as_float((int)b) + 2.0f * kScreenEps;
+    }
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < a.n; i0 += blockDim.x) {
+        const int i = i0 + threadIdx.x;
+        bool keep = false;
+        if (i < a.n) { const float d = a.approx[i]; keep = d <= thr; }           // -inf (score exactly) always passes
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        if (lane == 0) wcount[wv] = __popcll(m);
+        __syncthreads();
+        int before = base_s;
+        for (int w = 0; w < wv; ++w) before += wcount[w];
+        if (keep) a.survivors[before + __popcll(m & ((1ull << lane) - 1ull))] = a.slot_base + i;
+        __syncthreads();
+        if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < (int)blockDim.x / kWave; ++w) t += wcount[w]; base_s += t; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { *a.n_surv = base_s; *a.t_min = 0xffffffffu; }        // armed for the next launch (stream ordered)
+
+    const unsigned long long none = ~0ull;
+    unsigned long long prev = 0ull;
+    bool first = true;
+    for (int round = 0; round < a.k; ++round) {
+        unsigned long long mine = none;
+        for (int i = threadIdx.x; i < a.n; i += blockDim.x) {
+            const float r = a.d2[i];
+            const bool excluded = (a.exclude_eps > 0.0f) && (r <= a.exclude_eps);
+            if (excluded || !(r < 3.402823466e+38f)) continue;
+            const unsigned long long key = ((unsigned long long)(unsigned)__float_as_int(r) << 32) | (unsigned)i;
+            if ((first || key > prev) && key < mine) mine = key;
+        }
+        mine = wave_min_u64(mine);
+        __syncthreads();
+        if (lane == 0) sk[wv] = mine;
+        __syncthreads();
+        unsigned long long m = sk[0];
+        for (int w = 1; w < (int)blockDim.x / kWave; ++w) m = sk[w] < m ? sk[w] : m;
+        if (threadIdx.x == 0) {
+            if (m == none) { a.topk_idx[round] = -1; a.topk_d2[round] = 3.402823466e+38f; }
+            else { a.topk_idx[round] = a.slot_base + (int)(unsigned)(m & 0xffffffffull); a.topk_d2[round] = __int_as_float((int)(m >> 32)); }
+        }
+        if (m == none) {
+            for (int r2 = round + 1 + (int)threadIdx.x; r2 < a.k; r2 += blockDim.x) { a.topk_idx[r2] = -1; a.topk_d2[r2] = 3.402823466e+38f; }
+            break;
+        }
+        prev = m; first = false;
+    }
+}
+
+}  // namespace
+
+bool sc_screen_supported(const DbView &db, int SR)
+{
+    static const bool off = [] { const char *e = getenv("SCL_SCREEN"); return e && e[0] == '0'; }();
+    return !off && db.RG == 16 && db.R == 64 && db.S == 120 && SR == 6;
+}
+
+float sc_screen_eps() { return kScreenEps; }
+
+hipError_t launch_sc_select_batch(const ScreenBatch &sb, hipStream_t stream)
+{
+    if (sb.nq < 1 || sb.nq > kMaxQueryBatch) return hipErrorInvalidValue;
+    SelectBatchArgs sel{};
+    for (int i = 0; i < sb.nq; ++i) {
+        SelectArgs &s = sel.q[i];
+        s.approx = sb.approx + (size_t)i * sb.pair_stride; s.d2 = sb.ring_d2 + (size_t)i * sb.pair_stride;
+        s.n = sb.n[i]; s.slot_base = sb.base[i]; s.t_min = sb.t_min + i;
+        s.survivors = sb.survivors + (size_t)i * sb.pair_stride; s.n_surv = sb.n_surv + i;
+        s.k = sb.k; s.exclude_eps = sb.exclude_eps; s.topk_idx = sb.topk_idx + i * kTailTopMaxK; s.topk_d2 = sb.topk_d2 + i * kTailTopMaxK;
+    }
+    hipLaunchKernelGGL(sc_select_kernel, dim3(sb.nq), dim3(1024), 0, stream, sel);
+    return hipGetLastError();
+}
+
+hipError_t launch_sc_screen_batch(const DbView &db, const ScreenBatch &sb, int SR, int align_filter, int num_cu, hipStream_t stream)
+{
+    if (sb.nq < 1 || sb.nq > kMaxQueryBatch || !sc_screen_supported(db, SR)) return hipErrorInvalidValue;
+    constexpr int RG = 16, S = 120, W = 13;
+    ScreenBatchArgs ab{};
+    ab.nq = sb.nq;
+    int nmax = 0;
+    for (int i = 0; i < sb.nq; ++i) {
+        if (sb.n[i] <= 0) return hipErrorInvalidValue;
+        ScreenArgs &a = ab.q[i];
+        const size_t q = (size_t)sb.slot[i];
+        a.desc = db.desc; a.vkey = db.vkey; a.inv = db.inv;
+        a.q_desc = db.desc + q * (size_t)(db.RG * db.S); a.q_vkey = db.vkey + q * db.S; a.q_inv = db.inv + q * db.S;
+        a.q_rkey = db.rkey + q * (size_t)(4 * db.RG);
+        a.rkey4 = db.rkey4; a.rk_cap = db.cap;
+        a.slot_base = sb.base[i]; a.n = sb.n[i];
+        a.out_approx = sb.approx + (size_t)i * sb.pair_stride; a.out_d2 = sb.ring_d2 + (size_t)i * sb.pair_stride;
+        a.t_min = sb.t_min + i; a.align_filter = align_filter;
+        nmax = sb.n[i] > nmax ? sb.n[i] : nmax;
+    }
+    for (int i = sb.nq; i < kMaxQueryBatch; ++i) ab.q[i] = ab.q[0];
+    constexpr int QSX = S + 16, PFS = 288;
+    constexpr int kAlignStride = ((2 * S * 8 + (PFS + 2 * S + 8) * 4) + 15) & ~15;
+    const size_t lds = (size_t)(RG + 1) * QSX * 4 * 2 + (size_t)S * 8 + (size_t)S * 4 * 2 + (size_t)kScreenWaves * kAlignStride +
+                       (size_t)(kScreenWaves + 1) * kWave * 16 + (size_t)(2 * kGroup + 4) * 4;
+    const int ngroups = (nmax + kGroup - 1) / kGroup;
+    // variants (SCL_SCREEN_VARIANT): 0 = 5 k-steps in flight, 2 waves/SIMD; 1 = 3 in flight, 3 waves/SIMD; 2 = 5 in flight, 3 waves/SIMD
+    static const int variant = [] { const char *e = getenv("SCL_SCREEN_VARIANT"); return e ? atoi(e) : 0; }();
+    const int occ = variant == 0 ? 2 : 3;
+    int wg_per_cu = (int)((160 * 1024) / (lds + 256));
+    if (wg_per_cu > occ) wg_per_cu = occ;
+    if (wg_per_cu < 1) return hipErrorInvalidValue;
+    int blocks = num_cu * wg_per_cu;
+    if (blocks > ngroups) blocks = ngroups;
+    ab.nb = blocks;
+    auto launch = [&](auto kernel) -> hipError_t {
+        static std::atomic<bool> attr_set_dev[64];             // per instantiation (the lambda's static) and per device
+        int dev_ = 0; (void)hipGetDevice(&dev_);
+        std::atomic<bool> &attr_set = attr_set_dev[dev_ & 63];
+        if (!attr_set.load(std::memory_order_acquire)) {
+            hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_set.store(true, std::memory_order_release);
+        }
+        hipLaunchKernelGGL(kernel, dim3(blocks * sb.nq), dim3(kScreenWaves * kWave), lds, stream, ab);
+        return hipGetLastError();
+    };
+    if (variant == 1) return launch(sc_screen_kernel<RG, S, W, 3, 3>);
+    if (variant == 2) return launch(sc_screen_kernel<RG, S, W, 5, 3>);
+    return launch(sc_screen_kernel<RG, S, W, 5, 2>);
+}
+
+}  // namespace scl

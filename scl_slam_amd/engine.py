@@ -89,6 +89,7 @@ def _bind(lib):
         "scl_detect_full": (c_int, [P, c_int, ip, ip, ip, dp]),
         "scl_detect_full_range": (c_int, [P, c_int, c_int, c_int, ip, ip, dp]),
         "scl_get_last_topk": (c_int, [P, c_int, ip, fp]),
+        "scl_screen_distances": (c_int, [P, c_int, c_int, c_int, fp, ip, ip, fp]),
         "scl_detect_full_submit": (c_int, [P, c_int, c_int, c_int, ip]),
         "scl_detect_full_collect": (c_int, [P, c_int, ip, ip, dp]),
         "scl_detect_full_submit_many": (c_int, [P, ip, ip, ip, c_int, ip]),
@@ -344,6 +345,14 @@ class ScanContextEngine:
         self._check(self._lib.scl_detect_full_collect(self._h, ticket, byref(nn), byref(sh), byref(d)),
                     "scl_detect_full_collect")
         return nn.value, sh.value, d.value
+
+    def screen_distances(self, query, lo, hi):
+        """diagnostic: (approximate distances of slots lo..hi-1, surviving slots, eps) of the screening pass"""
+        n = max(0, min(hi, self.get_size()) - max(lo, 0))
+        approx = np.empty(max(n, 1), np.float32); surv = np.empty(max(n, 1), np.int32); ns = c_int(); eps = c_float()
+        self._check(self._lib.scl_screen_distances(self._h, query, lo, hi, _ptr(approx, c_float), _ptr(surv, c_int), byref(ns), byref(eps)),
+                    "scl_screen_distances")
+        return approx[:n], surv[:ns.value].copy(), eps.value
 
     def last_topk(self, k):
         idx = np.empty(k, dtype=np.int32); d2 = np.empty(k, dtype=np.float32)

@@ -1,0 +1,83 @@
+"""The screening pass of the full-DB mode (scl_slam_amd/csrc/sc_screen.hip) on the hardware: its reduced-precision
+distances must stay inside the stated bound around the exact fp64 distances (the CPU checker's), the survivor set must
+contain every keyframe that can hold the minimum, and the full-DB winner must be the checker's bit for bit -- also on
+inputs built to stress the bound (near ties, zero sectors, tiny / huge / non-finite values)."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from scl_slam_amd import ScanContextEngine
+from scl_slam_amd.synth import synth_descriptors
+
+pytestmark = pytest.mark.gpu
+R, S = 64, 120
+
+
+def _check(eng, db, query, lo, hi):
+    approx, surv, eps = eng.screen_distances(query, lo, hi)
+    d_ref, s_ref = db.distance_batch(query, cand=np.arange(lo, hi, dtype=np.int32))
+    finite = np.isfinite(approx)
+    ok = d_ref < 1e7                                          # 1e7 = the reference's "no finite distance"
+    assert np.all(approx[~ok & ~np.isneginf(approx)] == np.inf)
+    err = np.abs(approx[finite & ok].astype(np.float64) - d_ref[finite & ok])
+    assert err.size == 0 or err.max() <= eps, (err.max(), eps)
+    if ok.any():
+        best = int(np.flatnonzero(ok)[np.argmin(d_ref[ok])]) + lo        # first minimum = lowest slot
+        assert best in surv
+        assert np.all(np.diff(surv) > 0)
+        # everything that is not a survivor is provably worse than the best upper bound
+        mask = np.ones(hi - lo, bool); mask[surv - lo] = False
+        assert np.all(d_ref[mask] > d_ref[best - lo])
+    nn, sh, d = eng.detect_full_range(query, lo, hi)
+    if ok.any():
+        assert nn == best and sh == s_ref[best - lo] and np.float64(d).view(np.uint64) == d_ref[best - lo].view(np.uint64)
+    else:
+        assert nn == -1
+    return err.max() if err.size else 0.0, len(surv)
+
+
+def test_screening_bound_and_survivors_on_the_bench_database():
+    n = 3000
+    descs = synth_descriptors(n, R, S, seed=1002, revisit_frac=0.02)
+    eng = ScanContextEngine(num_ring=R, num_sector=S, initial_capacity=n)
+    db = ob.OracleDB(ob.make_config(R=R, S=S))
+    eng.save_bulk(descs); db.save_bulk(descs)
+    worst, most = 0.0, 0
+    for q, lo, hi in ((n - 1, 0, n - 100), (n - 2, 7, n - 101), (1500, 0, 1400), (n - 3, 0, 16), (n - 4, 0, 17), (n - 5, 33, 34)):
+        e, m = _check(eng, db, q, lo, hi)
+        worst, most = max(worst, e), max(most, m)
+    print(f"screening: worst |d~ - d| = {worst:.3e}, most survivors = {most}")
+    assert worst < 3e-4                                        # observed error is far inside the a-priori bound
+    eng.close()
+
+
+def test_screening_with_adversarial_descriptors():
+    rs = np.random.RandomState(11)
+    n = 700
+    descs = synth_descriptors(n, R, S, seed=5, revisit_frac=0.0)
+    q = n - 1
+    base = descs[q].copy()
+    # near ties around the minimum: copies of the query with perturbations from 1e-7 to 1e-2, rolled
+    for i, mag in enumerate([0.0, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3, 3e-3, 1e-2, 0.0, 1e-6]):
+        d = np.roll(base, int(rs.randint(0, S)), axis=1)
+        descs[10 + 7 * i] = np.clip(d + mag * rs.standard_normal(d.shape).astype(np.float32) * (d > 0), 0, None)
+    descs[100] = 0.0                                           # all-zero keyframe: NaN distance in the reference
+    descs[101][:, ::2] = 0.0                                   # half the sectors empty
+    descs[102] = base * np.float32(1e-30)                      # tiny values: norms ~1e-29 (still inside the fp32 reciprocal range)
+    descs[103] = base * np.float32(1e25)                       # huge values: norm outside [2^-60, 2^60] -> exact only
+    descs[104] = base * np.float32(1e-38)                      # subnormal products
+    descs[105][3, 5] = np.inf
+    descs[106][0, 0] = np.nan
+    descs[107] = np.where(rs.random_sample(base.shape) < 0.98, 0.0, base)    # almost empty
+    descs[108][:] = 0.0; descs[108][17, 40] = 3.5              # a single non-zero cell
+    descs[109] = -base                                         # negative heights: cosine -1
+    eng = ScanContextEngine(num_ring=R, num_sector=S, initial_capacity=n)
+    db = ob.OracleDB(ob.make_config(R=R, S=S))
+    eng.save_bulk(descs); db.save_bulk(descs)
+    _check(eng, db, q, 0, n - 100)
+    for qq in (100, 101, 103, 105, 106, 108, 109, 17):         # degenerate queries as well
+        _check(eng, db, qq, 0, n - 1 if qq != n - 1 else n - 100)
+    # every candidate flagged for the exact path
+    approx, surv, _ = eng.screen_distances(103, 0, 300)
+    assert np.all(np.isneginf(approx)) and len(surv) == 300
+    eng.close()
