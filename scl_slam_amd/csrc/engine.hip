@@ -210,6 +210,17 @@ int ensure_pairs(scl_engine *e, size_t n)
     return SCL_OK;
 }
 
+// screening buffers: kScreenSets sets of at least n entries each
+int ensure_sets(scl_engine *e, size_t n)
+{
+    if (n <= e->set_stride && e->pair_cap >= e->set_stride * scl_engine::kScreenSets) return SCL_OK;
+    const size_t stride = n + n / 4 + 64;
+    int rc = ensure_pairs(e, stride * scl_engine::kScreenSets);
+    if (rc) { e->set_stride = 0; return rc; }
+    e->set_stride = stride;
+    return SCL_OK;
+}
+
 int ensure_pinned(scl_engine *e, size_t bytes)
 {
     if (bytes <= e->pinned_cap) return SCL_OK;
@@ -411,17 +422,30 @@ int scl_create(const scl_config *cfg, scl_engine **out)
     if ((rc = ensure_capacity(e, 1))) return bail(rc);
     if ((rc = dev_alloc(e, &e->d_tile, (size_t)e->R * e->S))) return bail(rc);
     if ((rc = dev_alloc(e, &e->d_topk_scratch, (size_t)kTopkMaxBlocks * kTopkMaxK))) return bail(rc);
-    if ((rc = dev_alloc(e, &e->d_topk_idx, (size_t)kTopkMaxK * kMaxQueryBatch))) return bail(rc);
-    if ((rc = dev_alloc(e, &e->d_topk_d2, (size_t)kTopkMaxK * kMaxQueryBatch))) return bail(rc);
+    if ((rc = dev_alloc(e, &e->d_topk_idx, (size_t)kTopkMaxK * scl_engine::kScreenSets))) return bail(rc);
+    if ((rc = dev_alloc(e, &e->d_topk_d2, (size_t)kTopkMaxK * scl_engine::kScreenSets))) return bail(rc);
     if ((rc = dev_alloc(e, &e->d_out3, (size_t)4))) return bail(rc);
     if ((rc = dev_alloc(e, &e->d_blk_part, (size_t)kTailBlocks * kTailRec * kMaxQueryBatch))) return bail(rc);
     static_assert(kMaxQueryBatch <= 4, "done_counter holds four counters");
     if ((rc = dev_alloc(e, &e->d_done_counter, (size_t)4))) return bail(rc);
     if (hipMemset(e->d_done_counter, 0, 16) != hipSuccess) return bail(SCL_ERR_HIP);
-    if ((rc = dev_alloc(e, &e->d_nsurv, (size_t)kMaxQueryBatch))) return bail(rc);
-    if ((rc = dev_alloc(e, &e->d_tmin, (size_t)kMaxQueryBatch))) return bail(rc);
-    if (hipMemset(e->d_nsurv, 0, sizeof(int) * kMaxQueryBatch) != hipSuccess) return bail(SCL_ERR_HIP);
-    if (hipMemset(e->d_tmin, 0xff, sizeof(unsigned int) * kMaxQueryBatch) != hipSuccess) return bail(SCL_ERR_HIP);
+    {
+        constexpr int NS = scl_engine::kScreenSets;
+        if ((rc = dev_alloc(e, &e->d_nsurv, (size_t)NS))) return bail(rc);
+        if ((rc = dev_alloc(e, &e->d_tmin, (size_t)NS))) return bail(rc);
+        if (hipMemset(e->d_nsurv, 0, sizeof(int) * NS) != hipSuccess) return bail(SCL_ERR_HIP);
+        if (hipMemset(e->d_tmin, 0xff, sizeof(unsigned int) * NS) != hipSuccess) return bail(SCL_ERR_HIP);
+        if ((rc = dev_alloc(e, &e->d_scr_part, (size_t)kMaxQueryBatch * kScreenTopkWords))) return bail(rc);
+        if ((rc = dev_alloc(e, &e->d_scr_done, (size_t)kMaxQueryBatch))) return bail(rc);
+        if (hipMemset(e->d_scr_done, 0, sizeof(unsigned int) * kMaxQueryBatch) != hipSuccess) return bail(SCL_ERR_HIP);
+        if ((rc = dev_alloc(e, &e->d_surv_part, (size_t)NS * kSurvivorBlocks * kTailRec))) return bail(rc);
+        if ((rc = dev_alloc(e, &e->d_surv_done, (size_t)NS))) return bail(rc);
+        if (hipMemset(e->d_surv_done, 0, sizeof(unsigned int) * NS) != hipSuccess) return bail(SCL_ERR_HIP);
+        if (hipMalloc(&e->d_surv_args, (size_t)8 * NS * kSurvivorArgBytes) != hipSuccess) return bail(SCL_ERR_NOMEM);
+        if (hipHostMalloc(&e->h_surv_args, (size_t)8 * NS * kSurvivorArgBytes, hipHostMallocDefault) != hipSuccess) return bail(SCL_ERR_HIP);
+        if (hipHostMalloc((void **)&e->h_stream_out, (size_t)2 * NS * 64, hipHostMallocDefault) != hipSuccess) return bail(SCL_ERR_HIP);
+        for (auto &ev : e->ev_chunk) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return bail(SCL_ERR_HIP);
+    }
     if ((rc = dev_alloc(e, &e->a_blk_part, (size_t)1024 * kTailRec))) return bail(rc);
     if ((rc = dev_alloc(e, &e->a_done_counter, (size_t)4))) return bail(rc);
     if (hipMemset(e->a_done_counter, 0, 16) != hipSuccess) return bail(SCL_ERR_HIP);
@@ -457,6 +481,11 @@ int scl_destroy(scl_engine *e)
     dev_free(e->d_vals); dev_free(e->d_points); dev_free(e->d_tile);
     dev_free(e->d_dist); dev_free(e->d_shift); dev_free(e->d_cand); dev_free(e->d_ring_d2);
     dev_free(e->d_approx); dev_free(e->d_surv); dev_free(e->d_nsurv); dev_free(e->d_tmin);
+    dev_free(e->d_scr_part); dev_free(e->d_scr_done); dev_free(e->d_surv_part); dev_free(e->d_surv_done);
+    if (e->d_surv_args) (void)hipFree(e->d_surv_args);
+    if (e->h_surv_args) (void)hipHostFree(e->h_surv_args);
+    if (e->h_stream_out) (void)hipHostFree(e->h_stream_out);
+    for (auto ev : e->ev_chunk) if (ev) (void)hipEventDestroy(ev);
     dev_free(e->d_topk_scratch); dev_free(e->d_topk_idx); dev_free(e->d_topk_d2); dev_free(e->d_out3);
     dev_free(e->d_blk_part); dev_free(e->d_done_counter);
     dev_free(e->a_blk_part); dev_free(e->a_done_counter); dev_free(e->a_topk_idx); dev_free(e->a_topk_d2);
@@ -787,6 +816,43 @@ namespace {
 // enqueue one full-DB pass; results land in pinned slot `sl` when ev_done[sl] has fired
 int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, const int *his, int nq, int *tickets);
 
+// ---- screened full-DB passes (64x120 grid; sc_screen.hip) --------------------------------------------------------
+// One screening launch for up to four queries: slots qslot[i] against [lo[i], lo[i] + n[i]), results in buffer sets
+// set0 + i.  The event pair of the profile brackets this launch: it is the dominant kernel of a pass.
+int launch_screen_group(scl_engine *e, const int *qslot, const int *lo, const int *n, int nq, int set0)
+{
+    ScreenBatch sb{};
+    sb.nq = nq;
+    for (int j = 0; j < nq; ++j) { sb.slot[j] = qslot[j]; sb.base[j] = lo[j]; sb.n[j] = n[j]; sb.buf[j] = set0 + j; }
+    sb.pair_stride = e->set_stride;
+    sb.approx = e->d_approx; sb.ring_d2 = e->d_ring_d2; sb.survivors = nullptr; sb.n_surv = nullptr; sb.t_min = e->d_tmin;
+    sb.k = e->cfg.num_candidates; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
+    sb.blk_part = nullptr; sb.done_counter = e->d_scr_done;   // (the ring-key top-k is formed by the exact pass's first workgroup)
+    {
+        ProfScope ps(e, P_SC);
+        SCL_HIP(e, launch_sc_screen_batch(db_view(e), sb, e->SR, sc_align_filter_enabled(), e->num_cu, e->stream));
+        if (ps.active()) { for (int j = 0; j < nq; ++j) e->prof.sc_distance_pairs += (uint64_t)n[j]; }
+    }
+    return SCL_OK;
+}
+
+// The exact pass over the survivors of nq screened queries (buffer sets set0 .. set0 + nq - 1); winners to out3[i].
+int launch_survivor_pass(scl_engine *e, const int *qslot, const int *lo, const int *n, int nq, int set0, double *const *out3)
+{
+    SurvivorPass sp{};
+    sp.nq = nq;
+    for (int j = 0; j < nq; ++j) { sp.slot[j] = qslot[j]; sp.base[j] = lo[j]; sp.n[j] = n[j]; sp.buf[j] = set0 + j; sp.out3[j] = out3[j]; }
+    sp.pair_stride = e->set_stride;
+    sp.approx = e->d_approx; sp.survivors = e->d_surv; sp.t_min = e->d_tmin; sp.out_dist = e->d_dist; sp.out_shift = e->d_shift;
+    sp.blk_part = e->d_surv_part; sp.done_counter = e->d_surv_done;
+    sp.ring_d2 = e->d_ring_d2; sp.k = e->cfg.num_candidates; sp.exclude_eps = e->cfg.knn_exclude_eps; sp.topk_idx = e->d_topk_idx; sp.topk_d2 = e->d_topk_d2;
+    const size_t region = (size_t)(e->surv_arg_tick++ & 7u) * scl_engine::kScreenSets * kSurvivorArgBytes;   // 8 passes may be in flight
+    sp.d_args = static_cast<char *>(e->d_surv_args) + region; sp.h_args = static_cast<char *>(e->h_surv_args) + region;
+    ProfScope ps(e, P_ARGMIN);
+    SCL_HIP(e, launch_sc_distance_survivors(db_view(e), sp, e->SR, e->num_cu, e->stream));
+    return SCL_OK;
+}
+
 int submit_full_locked(scl_engine *e, int query, int lo, int hi, int *ticket)
 {
     if (e->screen && !e->in_single_fallback) {             // one query through the screening pipeline of the batched form
@@ -905,29 +971,16 @@ int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, c
         }
     }
     if (qb.nq > 0) {
-        int rc = ensure_pairs(e, (size_t)nmax * qb.nq);
+        int rc = e->screen ? SCL_OK : ensure_pairs(e, (size_t)nmax * qb.nq);
         if (rc) return rc;
         qb.pair_stride = (size_t)nmax;
         FullTail tail{e->d_blk_part, e->d_done_counter, nullptr, e->d_topk_idx, e->d_topk_d2, k, e->cfg.knn_exclude_eps};
         if (e->screen) {
-            // screening pass (fp16 matrix-core bounds around every reference distance) -> survivors -> exact fp64 kernel
-            // on the survivors only; the winner is the reference's, bit for bit (sc_screen.hip)
-            ScreenBatch sb{};
-            sb.nq = qb.nq;
-            for (int j = 0; j < qb.nq; ++j) { sb.slot[j] = qb.slot[j]; sb.base[j] = qb.base[j]; sb.n[j] = qb.n[j]; }
-            sb.pair_stride = qb.pair_stride;
-            sb.approx = e->d_approx; sb.ring_d2 = e->d_ring_d2; sb.survivors = e->d_surv; sb.n_surv = e->d_nsurv; sb.t_min = e->d_tmin;
-            sb.k = k; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
-            {
-                ProfScope ps(e, P_SC);
-                SCL_HIP(e, launch_sc_screen_batch(db_view(e), sb, e->SR, sc_align_filter_enabled(), e->num_cu, e->stream));
-                if (ps.active()) { for (int j = 0; j < qb.nq; ++j) e->prof.sc_distance_pairs += (uint64_t)qb.n[j]; }
-            }
-            SCL_HIP(e, launch_sc_select_batch(sb, e->stream));
-            {
-                ProfScope ps(e, P_ARGMIN);
-                SCL_HIP(e, launch_sc_distance_survivors(db_view(e), qb, e->SR, e->d_surv, e->d_nsurv, e->d_dist, e->d_shift, tail, e->num_cu, e->stream));
-            }
+            // screening pass (fp16 matrix-core bounds around every reference distance) -> the exact fp64 kernel on the
+            // survivors only; the winner is the reference's, bit for bit (sc_screen.hip)
+            if ((rc = ensure_sets(e, (size_t)nmax))) return rc;
+            if ((rc = launch_screen_group(e, qb.slot, qb.base, qb.n, qb.nq, 0))) return rc;
+            if ((rc = launch_survivor_pass(e, qb.slot, qb.base, qb.n, qb.nq, 0, qb.out3))) return rc;
         } else {
             ProfScope ps(e, P_SC);
             SCL_HIP(e, launch_sc_distance_batch(db_view(e), qb, e->SR, e->d_dist, e->d_shift, e->d_ring_d2, tail, e->num_cu, e->stream));
@@ -994,6 +1047,95 @@ int scl_detect_full_submit_many(scl_engine *e, const int *queries, const int *lo
     return SCL_OK;
 }
 
+namespace {
+
+// The stream form on the screened grid: a chunk of up to kScreenSets scans = its screening launches back to back
+// (spl scans per launch, one buffer set per scan), then ONE exact pass over the survivors of the whole chunk, one
+// event.  Two chunks are kept enqueued (their results land in the two halves of h_stream_out), so the device never
+// waits for the host between chunks.
+int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, const int *hi, int n_queries, int spl,
+                           int *nn_idx, int *shift, double *dist)
+{
+    constexpr int NS = scl_engine::kScreenSets;
+    struct Chunk { int first = 0, count = 0; bool busy = false; std::vector<int> lo, empty; };
+    Chunk ch[2];
+    int nmax = 1;
+    for (int i = 0; i < n_queries; ++i) {
+        const int l = lo[i] < 0 ? 0 : lo[i], h = hi[i] > e->n ? e->n : hi[i];
+        if (h - l > nmax) nmax = h - l;
+    }
+    int rc = ensure_sets(e, (size_t)nmax);
+    if (rc) return rc;
+    auto submit = [&](int c, int first, int count) -> int {
+        Chunk &k = ch[c];
+        k.first = first; k.count = count; k.lo.assign((size_t)count, 0); k.empty.assign((size_t)count, 1);
+        int qslot[NS], qlo[NS], qn[NS], set_of[NS]; double *out3[NS];
+        int m = 0;                                           // scans of the chunk that have something to score
+        for (int i = 0; i < count; ++i) {
+            const int q = queries[first + i];
+            int slot;
+            if (q >= 0) { if (q >= e->n) return fail(e, SCL_ERR_OUT_OF_RANGE, "query slot out of range"); slot = q; }
+            else { const int j = -1 - q; if (j >= scl_engine::kStage || !e->staged[j]) return fail(e, SCL_ERR_INVALID_ARG, "no staged query"); slot = e->cap + j; }
+            const int l = lo[first + i] < 0 ? 0 : lo[first + i], h = hi[first + i] > e->n ? e->n : hi[first + i];
+            k.lo[(size_t)i] = l;
+            if (h - l <= 0) continue;
+            k.empty[(size_t)i] = 0;
+            qslot[m] = slot; qlo[m] = l; qn[m] = h - l; set_of[m] = i;
+            out3[m] = e->h_stream_out + ((size_t)c * NS + (size_t)i) * 8;
+            ++m;
+        }
+        // buffer set = position among the non-empty scans (sets must be consecutive within a launch)
+        for (int g = 0; g < m; g += spl) {
+            const int w = m - g < spl ? m - g : spl;
+            if ((rc = launch_screen_group(e, qslot + g, qlo + g, qn + g, w, g))) return rc;
+        }
+        if (m > 0 && (rc = launch_survivor_pass(e, qslot, qlo, qn, m, 0, out3))) return rc;
+        (void)set_of;
+        SCL_HIP(e, hipEventRecord(e->ev_chunk[c], e->stream));
+        k.busy = true;
+        e->last_pass_empty = m == 0;
+        e->last_pass_alt = false;
+        return SCL_OK;
+    };
+    auto collect = [&](int c) -> int {
+        Chunk &k = ch[c];
+        SCL_HIP(e, hipEventSynchronize(e->ev_chunk[c]));
+        collect_profile(e);
+        for (int i = 0; i < k.count; ++i) {
+            const int o_i = k.first + i;
+            nn_idx[o_i] = -1; shift[o_i] = 0; dist[o_i] = kBigDist;
+            if (k.empty[(size_t)i]) continue;
+            const volatile double *o = e->h_stream_out + ((size_t)c * NS + (size_t)i) * 8;
+            dist[o_i] = o[0];
+            nn_idx[o_i] = o[1] < 0 ? -1 : k.lo[(size_t)i] + (int)o[1];
+            shift[o_i] = (int)o[2];
+        }
+        k.busy = false;
+        return SCL_OK;
+    };
+    int next = 0, c = 0;
+    while (next < n_queries || ch[0].busy || ch[1].busy) {
+        if (next < n_queries && !ch[c].busy) {
+            const int count = n_queries - next < NS ? n_queries - next : NS;
+            if ((rc = submit(c, next, count))) {
+                const std::string first_error = e->last_error;
+                (void)hipStreamSynchronize(e->stream);
+                e->last_error = first_error;
+                return rc;
+            }
+            next += count;
+            c ^= 1;
+            continue;
+        }
+        // both halves enqueued (or nothing left to submit): wait for the older one
+        const int older = ch[c].busy ? c : c ^ 1;
+        if ((rc = collect(older))) return rc;
+    }
+    return SCL_OK;
+}
+
+}  // namespace
+
 int scl_detect_full_stream(scl_engine *e, const int *queries, const int *lo, const int *hi, int n_queries,
                            int scans_per_launch, int launches_in_flight, int *nn_idx, int *shift, double *dist)
 {
@@ -1004,6 +1146,8 @@ int scl_detect_full_stream(scl_engine *e, const int *queries, const int *lo, con
     for (int i = 0; i < scl_engine::kSlots; ++i)
         if (e->slot_busy[i]) return fail(e, SCL_ERR_INVALID_ARG, "detect_full_stream: collect the passes in flight first");
     const int spl = scans_per_launch < 1 ? 1 : (scans_per_launch > kMaxQueryBatch ? kMaxQueryBatch : scans_per_launch);
+    if (e->screen && sc_distance_fuses_ring(db_view(e), e->SR))
+        return stream_screened_locked(e, queries, lo, hi, n_queries, spl, nn_idx, shift, dist);
     int depth = launches_in_flight < 1 ? 1 : launches_in_flight;
     if (depth * spl > scl_engine::kSlots) depth = scl_engine::kSlots / spl;
     std::vector<int> tk((size_t)n_queries);

@@ -62,7 +62,16 @@ struct scl_engine {
     int *d_tile = nullptr;
     double *d_dist = nullptr; int *d_shift = nullptr; int *d_cand = nullptr; float *d_ring_d2 = nullptr; size_t pair_cap = 0;
     // screening pass of the full-DB mode (sc_screen.hip): approximate distances, survivors, their counts, min d~ words
+    // Buffers come in kScreenSets sets of `set_stride` entries (one set per query of a chunk of the stream form; the
+    // submit / collect form uses sets 0..3): approx, ring_d2, survivors, dist, shift at set * set_stride.
+    static constexpr int kScreenSets = 64;
     float *d_approx = nullptr; int *d_surv = nullptr; int *d_nsurv = nullptr; unsigned int *d_tmin = nullptr;
+    size_t set_stride = 0;
+    unsigned long long *d_scr_part = nullptr; unsigned int *d_scr_done = nullptr;          // fused top-k of the screening launches
+    unsigned long long *d_surv_part = nullptr; unsigned int *d_surv_done = nullptr;        // tail of the exact pass
+    void *d_surv_args = nullptr; void *h_surv_args = nullptr; unsigned surv_arg_tick = 0;   // argument sets of the exact pass (ring of 8 regions)
+    double *h_stream_out = nullptr;                        // pinned: 2 x kScreenSets result records of the stream form
+    hipEvent_t ev_chunk[2] = {nullptr, nullptr};
     bool screen = false;                                   // grid supported and not switched off (SCL_SCREEN=0)
     bool in_single_fallback = false;                       // submit_full_locked <-> submit_full_many_locked recursion guard
     unsigned long long *d_topk_scratch = nullptr; int *d_topk_idx = nullptr; float *d_topk_d2 = nullptr;

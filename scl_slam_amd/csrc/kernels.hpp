@@ -68,24 +68,46 @@ hipError_t launch_sc_distance_batch(const struct DbView &db, const QueryBatch &q
 // ---- screening pass of the full-DB mode (sc_screen.hip; 64x120 grid) --------------------------------------------
 // Per query i: every keyframe of [base, base+n) gets approx[i*pair_stride + pos] = its reference distance within
 // +- sc_screen_eps() (fp16 matrix-core evaluation of the reference's own 13 shifts; -inf = must be scored exactly),
-// ring_d2 = its ring-key metric; then, in a second small launch, survivors[i*pair_stride ..] = the database slots
-// (ascending) that can still hold the minimum, n_surv[i] their number, and the ring-key top-k of the range.
+// ring_d2 = its ring-key metric, and the ring-key top-k of the range (fused for k <= kTailTop).  launch_sc_select_batch
+// (diagnostics, and the top-k for larger k): survivors = the database slots (ascending) that can still hold the minimum.
 // t_min: one word per query, 0xffffffff before the first launch (the select launch re-arms it).
 struct ScreenBatch {
     int nq;
     int slot[kMaxQueryBatch], base[kMaxQueryBatch], n[kMaxQueryBatch];
+    int buf[kMaxQueryBatch];                    // buffer set of query i: approx / ring_d2 / survivors at buf * pair_stride, t_min[buf], top-k set buf
     size_t pair_stride;
     float *approx; float *ring_d2; int *survivors; int *n_surv; unsigned int *t_min;
     int k; float exclude_eps; int *topk_idx; float *topk_d2;
+    // fused ring-key top-k of the screening launch (k <= kTailTop): kMaxQueryBatch * kScreenTopkWords words, kMaxQueryBatch zeroed counters;
+    // blk_part == nullptr (or k > kTailTop): call launch_sc_select_batch with survivors == nullptr for the top-k
+    unsigned long long *blk_part; unsigned int *done_counter;
 };
+constexpr int kScreenTopkWords = 768 * kTailTop;
 bool sc_screen_supported(const struct DbView &db, int SR);
 float sc_screen_eps();
 hipError_t launch_sc_screen_batch(const struct DbView &db, const ScreenBatch &sb, int SR, int align_filter, int num_cu, hipStream_t stream);
 hipError_t launch_sc_select_batch(const ScreenBatch &sb, hipStream_t stream);
-// Exact distances of the survivors: query i = slot[i] against the slots survivors[i*pair_stride .. + n_surv[i]) (count
-// read on the device), winner (distance, position relative to base[i], shift) into qb.out3[i] by the fused tail.
-hipError_t launch_sc_distance_survivors(const struct DbView &db, const QueryBatch &qb, int SR, const int *survivors, const int *n_surv,
-                                        double *out_dist, int *out_shift, const FullTail &tail, int num_cu, hipStream_t stream);
+// Exact pass over the survivors of nq screened queries (any number: the argument sets travel through device memory).
+// Query i: keyframe slot[i] against the range [base[i], base[i] + n[i]); its screening results live in buffer set
+// buf[i] (approx / survivors / out_dist / out_shift at buf[i] * pair_stride, t_min[buf[i]]).  Every workgroup builds
+// the survivor list itself (approx <= min + 2 eps, ascending slots), scores its share with the fp64 wave program, and
+// the last workgroup of the query writes the winner (distance, position relative to base[i], shift) to out3[i] and
+// re-arms t_min.  blk_part: nq * kSurvivorBlocks * kTailRec words, done_counter: nq zeroed words,
+// d_args / h_args (pinned): nq * kSurvivorArgBytes bytes.
+constexpr int kSurvivorBlocks = 4;          // workgroups (of 8 waves) per query
+constexpr int kSurvivorArgBytes = 384;
+constexpr int kMaxSurvivorQueries = 64;
+struct SurvivorPass {
+    int nq;
+    int slot[kMaxSurvivorQueries], base[kMaxSurvivorQueries], n[kMaxSurvivorQueries], buf[kMaxSurvivorQueries];
+    double *out3[kMaxSurvivorQueries];
+    size_t pair_stride;
+    const float *approx; int *survivors; unsigned int *t_min; double *out_dist; int *out_shift;
+    const float *ring_d2; int k; float exclude_eps; int *topk_idx; float *topk_d2;   // ring-key top-k of every range (workgroup 0 of the query)
+    unsigned long long *blk_part; unsigned int *done_counter;
+    void *d_args; void *h_args;
+};
+hipError_t launch_sc_distance_survivors(const struct DbView &db, const SurvivorPass &sp, int SR, int num_cu, hipStream_t stream);
 int sc_align_filter_enabled();
 
 // out_ring_d2 (optional): also write the squared ring-key distance (nanoflann metric) of every scored

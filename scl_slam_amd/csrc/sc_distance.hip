@@ -46,6 +46,12 @@ struct ScArgs {
     int slot_base;
     int n;
     const int *n_dev;         // != nullptr: the number of candidates is read on the device (survivors of the screening pass)
+    // survivors of the screening pass (sc_distance_survivors_kernel): every workgroup selects them itself from the
+    // approximate distances of the range [slot_base, slot_base + range_n): approx[i] <= min + 2 eps (t_min = ordered
+    // image of the minimum, re-armed by the last workgroup), slots written to `cand` in ascending order
+    const float *approx; unsigned int *t_min; int range_n; float two_eps;
+    const float *ring_d2;     // survivors pass: the ring-key metric of the range (from the screening pass), for the top-k
+    int *sel_topk_idx; float *sel_topk_d2; int sel_topk_k; float sel_exclude_eps;
     int S;
     int SR;
     int NW;   // waves per candidate
@@ -294,13 +300,11 @@ __device__ __forceinline__ void pin1(double &a)
     asm volatile("" : "+v"(a) :: "memory");
 }
 
+// The whole workgroup program of the wave kernel: `a` = the argument set of this workgroup's query, bid / nbk = its
+// index among / the number of workgroups that serve the query.
 template <int RG, int W, int CH, int S, int MAXT, bool STAMP>
-__global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScBatchArgs ab)
+__device__ __forceinline__ void sc_wave_body(const ScArgs &a, const int bid, const int nbk)
 {
-    const int nbk = ab.nb;                             // workgroups per query
-    const int qi = ab.nq > 1 ? (int)blockIdx.x / nbk : 0;
-    const int bid = (int)blockIdx.x - qi * nbk;        // workgroup index within its query
-    const ScArgs &a = ab.q[qi];
     unsigned long long st_t = 0, st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_real0 = 0, st_cyc0 = 0;
     auto stamp = [&]() -> unsigned long long {
         if (!STAMP) { __builtin_amdgcn_sched_barrier(0); return 0ull; }   // phase boundaries stay scheduling fences
@@ -919,7 +923,93 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScBatchArgs ab)
             prev = m; first = false;
         }
         if (lane == 0) *a.done_counter = 0u;            // armed for the next launch (stream ordered)
+        if (lane == 0 && a.t_min) *a.t_min = 0xffffffffu;   // survivors pass: every workgroup has read the minimum by now
     }
+}
+
+template <int RG, int W, int CH, int S, int MAXT, bool STAMP>
+__global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScBatchArgs ab)
+{
+    const int nbk = ab.nb;                             // workgroups per query
+    const int qi = ab.nq > 1 ? (int)blockIdx.x / nbk : 0;
+    const int bid = (int)blockIdx.x - qi * nbk;        // workgroup index within its query
+    sc_wave_body<RG, W, CH, S, MAXT, STAMP>(ab.q[qi], bid, nbk);
+}
+
+// Exact pass behind the screening pass (sc_screen.hip): query qi = qargs[qi] (any number of queries: the argument sets
+// live in device memory), nb workgroups per query.  Every workgroup first builds the survivor list of its query --
+// the slots whose approximate distance lies within 2 eps of the minimum, ascending, written to a.cand (all nb
+// workgroups write the same values) -- and then runs the wave program on its share of that list.
+template <int RG, int W, int CH, int S, int MAXT>
+__global__ __launch_bounds__(MAXT) void sc_distance_survivors_kernel(const ScArgs *qargs, int nb)
+{
+    const int qi = (int)blockIdx.x / nb;
+    const int bid = (int)blockIdx.x - qi * nb;
+    ScArgs a = qargs[qi];
+    __shared__ int wave_total[MAXT / kWave];
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+    const unsigned int tm = *a.t_min;
+    float thr = __int_as_float(0xff800000);                                      // nothing screened: only the "score exactly" marks pass
+    if (tm != 0xffffffffu) {
+        const unsigned int b = (tm >> 31) ? (tm & 0x7fffffffu) : ~tm;            // inverse of the ordered image
+        thr = __int_as_float((int)b) + a.two_eps;
+    }
+    const int chunk = (a.range_n + (int)blockDim.x - 1) / (int)blockDim.x;
+    const int lo = (int)threadIdx.x * chunk;
+    const int hi = lo + chunk < a.range_n ? lo + chunk : a.range_n;
+    int cnt = 0;
+    for (int i = lo; i < hi; ++i) cnt += a.approx[i] <= thr ? 1 : 0;             // -inf (score exactly) always passes
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const int o = __shfl_up(incl, off, kWave);
+        if (lane >= off) incl += o;
+    }
+    if (lane == kWave - 1) wave_total[wv] = incl;
+    __syncthreads();
+    int before = incl - cnt, total = 0;
+    for (int w = 0; w < (int)blockDim.x / kWave; ++w) { const int t = wave_total[w]; if (w < wv) before += t; total += t; }
+    int *list = const_cast<int *>(a.cand);
+    for (int i = lo; i < hi; ++i)
+        if (a.approx[i] <= thr) list[before++] = a.slot_base + i;
+    __threadfence_block();
+    __syncthreads();
+    // The ring-key top-k of the range (workgroup 0 of the query): k rounds of "smallest key larger than the previous
+    // pick" over the metric the screening pass stored; keys (d2 bits << 32 | position) are unique.
+    if (bid == 0 && a.sel_topk_k > 0) {
+        __shared__ unsigned long long wave_key[MAXT / kWave];
+        const unsigned long long none = ~0ull;
+        unsigned long long prev = 0ull;
+        bool first = true;
+        for (int round = 0; round < a.sel_topk_k; ++round) {
+            unsigned long long mine = none;
+            for (int i = lo; i < hi; ++i) {
+                const float r = a.ring_d2[i];
+                const bool excluded = (a.sel_exclude_eps > 0.0f) && (r <= a.sel_exclude_eps);
+                if (excluded || !(r < 3.402823466e+38f)) continue;
+                const unsigned long long key = ((unsigned long long)(unsigned)__float_as_int(r) << 32) | (unsigned)i;
+                if ((first || key > prev) && key < mine) mine = key;
+            }
+            mine = wave_min_u64(mine);
+            __syncthreads();
+            if (lane == 0) wave_key[wv] = mine;
+            __syncthreads();
+            unsigned long long m = wave_key[0];
+            for (int w = 1; w < (int)blockDim.x / kWave; ++w) m = wave_key[w] < m ? wave_key[w] : m;
+            if (threadIdx.x == 0) {
+                if (m == none) { a.sel_topk_idx[round] = -1; a.sel_topk_d2[round] = 3.402823466e+38f; }
+                else { a.sel_topk_idx[round] = a.slot_base + (int)(unsigned)(m & 0xffffffffull); a.sel_topk_d2[round] = __int_as_float((int)(m >> 32)); }
+            }
+            if (m == none) {
+                for (int r2 = round + 1 + (int)threadIdx.x; r2 < a.sel_topk_k; r2 += blockDim.x) { a.sel_topk_idx[r2] = -1; a.sel_topk_d2[r2] = 3.402823466e+38f; }
+                break;
+            }
+            prev = m; first = false;
+        }
+        __syncthreads();
+    }
+    a.n = total; a.n_dev = nullptr;
+    sc_wave_body<RG, W, CH, S, MAXT, false>(a, bid, nb);
 }
 
 template <int RG, int W, int CH, int S, int MAXT = 512, bool STAMP = false>
@@ -1170,7 +1260,7 @@ hipError_t launch_sc_distance(const DbView &db, const QueryView &q, const int *c
     ScArgs a;
     a.desc = db.desc; a.vkey = db.vkey; a.norm = db.norm;
     a.q_desc = q.desc; a.q_vkey = q.vkey; a.q_norm = q.norm;
-    a.cand = cand; a.slot_base = slot_base; a.n = n; a.n_dev = nullptr; a.S = db.S; a.SR = SR;
+    a.cand = cand; a.slot_base = slot_base; a.n = n; a.n_dev = nullptr; a.approx = nullptr; a.t_min = nullptr; a.range_n = 0; a.two_eps = 0.f; a.ring_d2 = nullptr; a.sel_topk_idx = nullptr; a.sel_topk_d2 = nullptr; a.sel_topk_k = 0; a.sel_exclude_eps = 0.f; a.S = db.S; a.SR = SR;
     a.NW = (db.S + kWave - 1) / kWave; a.G = 1;
     a.ablate = ablate_flags();
     a.align_filter = align_filter_enabled();
@@ -1223,7 +1313,7 @@ hipError_t launch_sc_distance_batch(const DbView &db, const QueryBatch &qb, int 
         a.desc = db.desc; a.vkey = db.vkey; a.norm = db.norm;
         a.q_desc = db.desc + slot * (size_t)(db.RG * db.S); a.q_vkey = db.vkey + slot * db.S;
         a.q_norm = db.norm + slot * db.S; a.q_rkey = db.rkey + slot * (size_t)(4 * db.RG);
-        a.cand = nullptr; a.slot_base = qb.base[i]; a.n = qb.n[i]; a.n_dev = nullptr; a.S = db.S; a.SR = SR;
+        a.cand = nullptr; a.slot_base = qb.base[i]; a.n = qb.n[i]; a.n_dev = nullptr; a.approx = nullptr; a.t_min = nullptr; a.range_n = 0; a.two_eps = 0.f; a.ring_d2 = nullptr; a.sel_topk_idx = nullptr; a.sel_topk_d2 = nullptr; a.sel_topk_k = 0; a.sel_exclude_eps = 0.f; a.S = db.S; a.SR = SR;
         a.NW = (db.S + kWave - 1) / kWave; a.G = 1;
         a.ablate = ablate_flags(); a.stamps = nullptr; a.align_filter = align_filter_enabled();
         a.rkey4 = db.rkey4; a.rk_cap = db.cap;
@@ -1242,33 +1332,51 @@ hipError_t launch_sc_distance_batch(const DbView &db, const QueryBatch &qb, int 
     return launch_wave<16, 13, 4, 120, 512>(ab, num_cu, stream);
 }
 
-hipError_t launch_sc_distance_survivors(const DbView &db, const QueryBatch &qb, int SR, const int *survivors, const int *n_surv,
-                                        double *out_dist, int *out_shift, const FullTail &tail, int num_cu, hipStream_t stream)
+hipError_t launch_sc_distance_survivors(const DbView &db, const SurvivorPass &sp, int SR, int num_cu, hipStream_t stream)
 {
-    if (qb.nq < 1 || qb.nq > kMaxQueryBatch || !(db.RG == 16 && db.S == 120 && SR == 6)) return hipErrorInvalidValue;
-    ScBatchArgs ab{};
-    ab.nq = qb.nq;
-    for (int i = 0; i < qb.nq; ++i) {
-        ScArgs &a = ab.q[i];
-        const size_t slot = (size_t)qb.slot[i];
+    if (sp.nq < 1 || !(db.RG == 16 && db.S == 120 && SR == 6) || !sp.d_args || !sp.h_args) return hipErrorInvalidValue;
+    constexpr int RG = 16, W = 13, CH = 4, S = 120, MAXT = 512;
+    ScArgs *h = reinterpret_cast<ScArgs *>(sp.h_args);
+    static_assert(sizeof(ScArgs) <= kSurvivorArgBytes, "argument set must fit the slot the engine reserves");
+    for (int i = 0; i < sp.nq; ++i) {
+        ScArgs &a = h[i];
+        const size_t slot = (size_t)sp.slot[i];
         a.desc = db.desc; a.vkey = db.vkey; a.norm = db.norm;
         a.q_desc = db.desc + slot * (size_t)(db.RG * db.S); a.q_vkey = db.vkey + slot * db.S;
         a.q_norm = db.norm + slot * db.S; a.q_rkey = db.rkey + slot * (size_t)(4 * db.RG);
-        a.cand = survivors + (size_t)i * qb.pair_stride; a.slot_base = qb.base[i]; a.n = qb.n[i]; a.n_dev = n_surv + i;
+        a.cand = sp.survivors + (size_t)sp.buf[i] * sp.pair_stride; a.slot_base = sp.base[i]; a.n = 0; a.n_dev = nullptr;
+        a.approx = sp.approx + (size_t)sp.buf[i] * sp.pair_stride; a.t_min = sp.t_min + sp.buf[i]; a.range_n = sp.n[i]; a.two_eps = 2.0f * sc_screen_eps();
         a.S = db.S; a.SR = SR; a.NW = (db.S + kWave - 1) / kWave; a.G = 1;
         a.ablate = ablate_flags(); a.stamps = nullptr; a.align_filter = align_filter_enabled();
         a.rkey4 = db.rkey4; a.rk_cap = db.cap;
-        a.out_dist = out_dist + (size_t)i * qb.pair_stride; a.out_shift = out_shift + (size_t)i * qb.pair_stride;
-        a.out_d2 = nullptr;                                            // the ring-key top-k came from the screening pass
-        a.blk_part = tail.blk_part + (size_t)i * kTailBlocks * kTailRec; a.done_counter = tail.done_counter + i;
-        a.out3 = qb.out3[i];
+        a.out_dist = sp.out_dist + (size_t)sp.buf[i] * sp.pair_stride; a.out_shift = sp.out_shift + (size_t)sp.buf[i] * sp.pair_stride;
+        a.out_d2 = nullptr;                                            // the ring-key top-k comes from the screening pass
+        a.blk_part = sp.blk_part + (size_t)i * kSurvivorBlocks * kTailRec; a.done_counter = sp.done_counter + i;
+        a.out3 = sp.out3[i];
         a.topk_idx = nullptr; a.topk_d2 = nullptr; a.topk_k = 0; a.exclude_eps = 0.0f;
+        a.ring_d2 = sp.ring_d2 + (size_t)sp.buf[i] * sp.pair_stride;
+        a.sel_topk_idx = sp.topk_idx + sp.buf[i] * kTailTopMaxK; a.sel_topk_d2 = sp.topk_d2 + sp.buf[i] * kTailTopMaxK;
+        a.sel_topk_k = sp.k; a.sel_exclude_eps = sp.exclude_eps;
     }
-    for (int i = qb.nq; i < kMaxQueryBatch; ++i) ab.q[i] = ab.q[0];
-    ab.nb = 1;
-    // the survivor counts live on the device: 64 full-width workgroups per query cover any count; a workgroup whose
-    // share is empty leaves before staging the query
-    return launch_wave<16, 13, 4, 120, 512>(ab, num_cu, stream, 64);
+    hipError_t e = hipMemcpyAsync(sp.d_args, sp.h_args, sizeof(ScArgs) * (size_t)sp.nq, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
+    constexpr int QS = S + W + 1, HSH = (W + 1) / 2;
+    const size_t fixed = (size_t)(RG * 4 * QS + QS + 2 * S) * sizeof(double);
+    const size_t per_wave = (size_t)((2 * S > HSH * (S + 2)) ? 2 * S : HSH * (S + 2)) * sizeof(double);
+    const int waves = MAXT / kWave;
+    const size_t lds = fixed + per_wave * waves + 16;
+    static std::atomic<bool> attr_set_dev[64];
+    int dev_ = 0; (void)hipGetDevice(&dev_);
+    std::atomic<bool> &attr_set = attr_set_dev[dev_ & 63];
+    if (!attr_set.load(std::memory_order_acquire)) {
+        e = hipFuncSetAttribute((const void *)sc_distance_survivors_kernel<RG, W, CH, S, MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (the kernel also has a few static words)
+        if (e != hipSuccess) return e;
+        attr_set.store(true, std::memory_order_release);
+    }
+    (void)num_cu;
+    hipLaunchKernelGGL((sc_distance_survivors_kernel<RG, W, CH, S, MAXT>), dim3(sp.nq * kSurvivorBlocks), dim3(waves * kWave), lds, stream,
+                       reinterpret_cast<const ScArgs *>(sp.d_args), kSurvivorBlocks);
+    return hipGetLastError();
 }
 
 int sc_align_filter_enabled() { return align_filter_enabled(); }
