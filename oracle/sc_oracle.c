@@ -603,3 +603,121 @@ void sco_db_distance_batch_mt(sco_db *db, int cur, const int *cand, int n,
     }
     for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
 }
+
+/* ---- Envelope of the parts that cannot be pinned offline (tests only) ------------------------------------------
+ * Eigen's .mean() / .norm() / .dot() (D.h:1470-1471, 1484-1485, 1500-1502, 1523, 1528) are packet-vectorised:
+ * `lanes` interleaved partial sums (2 with SSE2, 4 with AVX, 8 with AVX-512 or Eigen's 4 x unrolled SSE2 packets),
+ * combined pairwise at the end, then a scalar tail.  sco_distance_lanes is sco_distance_fast with every such
+ * reduction evaluated in that shape; everything the reference writes as a scalar loop (the sum over sectors in
+ * distDirectSC, D.h:1518-1532, and the arg-min scans) stays sequential.  lanes = 1 reproduces sco_distance_fast. */
+static double lanes_sum(const double *v, int n, int stride, int lanes)
+{
+    double p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int body = (n / lanes) * lanes;
+    for (int i = 0; i < body; i++) p[i % lanes] += v[(size_t)i * stride];
+    for (int w = lanes; w > 1; w >>= 1)
+        for (int k = 0; k < w / 2; k++) p[k] = p[k] + p[k + w / 2];
+    double s = p[0];
+    for (int i = body; i < n; i++) s += v[(size_t)i * stride];
+    return s;
+}
+
+static double lanes_dot(const double *a, const double *b, int n, int lanes)
+{
+    double p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int body = (n / lanes) * lanes;
+    for (int i = 0; i < body; i++) p[i % lanes] += a[i] * b[i];
+    for (int w = lanes; w > 1; w >>= 1)
+        for (int k = 0; k < w / 2; k++) p[k] = p[k] + p[k + w / 2];
+    double s = p[0];
+    for (int i = body; i < n; i++) s += a[i] * b[i];
+    return s;
+}
+
+void sco_ringkey_lanes(int R, int S, const double *desc, int lanes, float *key)
+{
+    for (int r = 0; r < R; r++) key[r] = (float)(lanes_sum(desc + r, S, R, lanes) / (double)S);
+}
+
+void sco_distance_lanes(const sco_config *c, const double *sc1, const double *sc2, int lanes,
+                        double *dist, int *shift)
+{
+    const int R = c->num_ring, S = c->num_sector;
+    if (lanes < 1) lanes = 1;
+    if (lanes > 8) lanes = 8;
+    double *buf = (double *)malloc(sizeof(double) * 5 * (size_t)S);
+    double *vk1 = buf, *vk2 = buf + S, *n1 = buf + 2 * S, *n2 = buf + 3 * S, *diff = buf + 4 * S;
+    for (int s = 0; s < S; s++) {
+        vk1[s] = lanes_sum(sc1 + (size_t)s * R, R, 1, lanes) / (double)R;
+        vk2[s] = lanes_sum(sc2 + (size_t)s * R, R, 1, lanes) / (double)R;
+        n1[s] = sqrt(lanes_dot(sc1 + (size_t)s * R, sc1 + (size_t)s * R, R, lanes));
+        n2[s] = sqrt(lanes_dot(sc2 + (size_t)s * R, sc2 + (size_t)s * R, R, lanes));
+    }
+    int a = 0;
+    double best = 10000000;
+    for (int sh = 0; sh < S; sh++) {
+        for (int j = 0; j < S; j++) { int src = j - sh; if (src < 0) src += S; diff[j] = vk1[j] - vk2[src]; }
+        double cur = sqrt(lanes_dot(diff, diff, S, lanes));
+        if (cur < best) { a = sh; best = cur; }
+    }
+    const int SR = search_radius(c);
+    int nsp = 1 + 2 * (SR > 0 ? SR : 0);
+    int *space = (int *)malloc(sizeof(int) * (size_t)nsp);
+    int m = 0;
+    space[m++] = a;
+    for (int ii = 1; ii < SR + 1; ii++) { space[m++] = (a + ii + S) % S; space[m++] = (a - ii + S) % S; }
+    qsort(space, (size_t)m, sizeof(int), cmp_int);
+    int argmin_shift = 0;
+    double min_sc_dist = 10000000;
+    for (int t = 0; t < m; t++) {
+        int sh = space[t], eff = 0;
+        double sum = 0;
+        for (int col = 0; col < S; col++) {
+            int src = (col - sh) % S; if (src < 0) src += S;
+            if ((n1[col] == 0) | (n2[src] == 0)) continue;
+            sum = sum + lanes_dot(sc1 + (size_t)col * R, sc2 + (size_t)src * R, R, lanes) / (n1[col] * n2[src]);
+            eff++;
+        }
+        double cur = 1.0 - sum / eff;
+        if (cur < min_sc_dist) { argmin_shift = sh; min_sc_dist = cur; }
+    }
+    free(space);
+    free(buf);
+    *dist = min_sc_dist;
+    *shift = argmin_shift;
+}
+
+/* Census of sector-bin differences between the fixed atan used on both sides of the parity tests (sco_atanf) and
+ * this platform's libm atanf, which is what the reference calls (D.h:1357-1372).  n points, uniform in the square
+ * [-range, range]^2, xorshift64* stream of `seed`.  Returns the number of points whose sector index
+ * (D.h:1435) differs; *theta_diff (optional) = how many xy2theta results differ in any bit. */
+static float xy2theta_libm(float x, float y)
+{
+    const double k = 180 / M_PI;
+    if ((x >= 0) & (y >= 0)) return (float)(k * (double)atanf(y / x));
+    if ((x < 0) & (y >= 0))  return (float)(180 - (k * (double)atanf(y / (-x))));
+    if ((x < 0) & (y < 0))   return (float)(180 + (k * (double)atanf(y / x)));
+    if ((x >= 0) & (y < 0))  return (float)(360 - (k * (double)atanf((-y) / x)));
+    return NAN;
+}
+
+long long sco_theta_census(long long n, unsigned long long seed, double range, int S, long long *theta_diff)
+{
+    unsigned long long s = seed ? seed : 0x9E3779B97F4A7C15ull;
+    long long flips = 0, tdiff = 0;
+    for (long long i = 0; i < n; i++) {
+        s ^= s >> 12; s ^= s << 25; s ^= s >> 27;
+        const unsigned long long r = s * 0x2545F4914F6CDD1Dull;
+        const float x = (float)(((double)(r >> 40) * (1.0 / 16777216.0) * 2.0 - 1.0) * range);
+        const float y = (float)(((double)((r >> 16) & 0xFFFFFF) * (1.0 / 16777216.0) * 2.0 - 1.0) * range);
+        const float a = sco_xy2theta(x, y), b = xy2theta_libm(x, y);
+        if (memcmp(&a, &b, sizeof a) != 0) {
+            tdiff++;
+            const int ia = imax(imin(S, ceil_to_int_x86(((double)a / 360.0) * S)), 1);
+            const int ib = imax(imin(S, ceil_to_int_x86(((double)b / 360.0) * S)), 1);
+            if (ia != ib) flips++;
+        }
+    }
+    if (theta_diff) *theta_diff = tdiff;
+    return flips;
+}

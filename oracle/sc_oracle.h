@@ -98,6 +98,11 @@ void    sco_db_distance_batch(sco_db *db, int cur, const int *cand, int n,
 void    sco_db_distance_batch_mt(sco_db *db, int cur, const int *cand, int n,
                                  double *dist, int *shift, int fast, int threads);
 
+/* envelope of what cannot be pinned offline (tests only; see sc_oracle.c) */
+void sco_ringkey_lanes(int R, int S, const double *desc, int lanes, float *key);
+void sco_distance_lanes(const sco_config *c, const double *sc1, const double *sc2, int lanes, double *dist, int *shift);
+long long sco_theta_census(long long n, unsigned long long seed, double range, int S, long long *theta_diff);
+
 #ifdef __cplusplus
 }
 #endif
