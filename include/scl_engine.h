@@ -137,6 +137,18 @@ int  scl_get_descriptor(const scl_engine *e, int key, float *values);
 int  scl_get_ringkey(const scl_engine *e, int key, float *ringkey);
 int  scl_get_sectorkey(const scl_engine *e, int key, double *sectorkey);
 
+/* `count` descriptors first .. first+count-1 in wire format (count * R*S floats) */
+int  scl_get_descriptors(const scl_engine *e, int first, int count, float *values);
+/* Reverse of getIndex (D.h:1758-1761): the database key of keyframe `index` of robot `robot`, or -1 (*key) when it
+ * is not in the database -- the index mapping of performInterLoopClosure, DM.h:1281-1284. */
+int  scl_find_key(const scl_engine *e, int8_t robot, int index, int *key);
+/* The whole keyframe database as a flat file: header {magic, version, R, S, N}, float32[N][R*S] descriptors in
+ * wire order (D.h:1446-1455), then N x {int32 robot, int32 index} (the map of D.h:1758-1761).  Keys, norms and the
+ * tiled layouts are derived data and are rebuilt on load.  load appends to the engine's database (an empty engine
+ * reproduces the dumped one exactly: same keys, same detections); the grid must match. */
+int  scl_db_dump_file(scl_engine *e, const char *path);
+int  scl_db_load_file(scl_engine *e, const char *path, int *n_loaded);
+
 /* Stage an external query descriptor (wire format) that is NOT stored in the DB;
  * afterwards pass SCL_QUERY_STAGED as `query`.  Used by the sharded (multi-GPU)
  * driver, where the query keyframe may live on another rank. */
@@ -249,6 +261,14 @@ int  scl_voxel_grid(scl_engine *e, const void *points, int n_points, int stride_
                     void *out, int out_capacity, int *n_out);
 /* pcl::getTransformation(x, y, z, roll, pitch, yaw) (DM.h:223,241) as a row-major 4x4; host-side helper */
 int  scl_pose_to_matrix(float x, float y, float z, float roll, float pitch, float yaw, float T[16]);
+/* pcl::getTranslationAndEulerAngles (DM.h:1133, 1139): roll = atan2(R21, R22), pitch = asin(-R20), yaw = atan2(R10, R00) */
+int  scl_matrix_to_pose(const float T[16], float *x, float *y, float *z, float *roll, float *pitch, float *yaw);
+/* The tail of the ICP block, DM.h:1130-1141 (and DM.h:1249-1259 with the SVD transform): tfCorrect = T_icp * tfWrong
+ * (pose_cur = x, y, z, roll, pitch, yaw of the current keyframe, float like Affine3f), poseFrom = its Euler pose,
+ * poseTo = pose_pre, result = poseFrom.between(poseTo) in double: between_xyz_q = translation x, y, z and the unit
+ * quaternion x, y, z, w (w >= 0) -- the fields of loop_info.betPose / poseBetween --, between_rpy (optional) =
+ * roll, pitch, yaw of the same rotation. */
+int  scl_loop_pose_between(const float T_icp[16], const float pose_cur[6], const float pose_pre[6], double between_xyz_q[7], double between_rpy[3]);
 /* loopFindNearKeyframes, DM.h:1163-1186: concatenation of transformPointCloud(cloud_i, T_i) (DM.h:234-253)
  * followed by the voxel filter.  transforms = n_clouds row-major 4x4 matrices. */
 int  scl_assemble_submap(scl_engine *e, const void *const *clouds, const int *counts, const float *transforms,

@@ -1270,6 +1270,183 @@ int scl_detect_full(scl_engine *e, int cur, int *loop_id, int *nn_idx, int *shif
     return SCL_OK;
 }
 
+/* ---- database dump / load, index map ----------------------------------------------- */
+
+int scl_get_descriptors(const scl_engine *ce, int first, int count, float *values)
+{
+    scl_engine *e = const_cast<scl_engine *>(ce);
+    if (!e || !values || first < 0 || count < 0) return SCL_ERR_INVALID_ARG;
+    const size_t cells = (size_t)e->R * e->S;
+    if (e->front) {                                         // sharded: keyframe by keyframe through the owners
+        for (int i = 0; i < count; ++i) { const int rc = scl_get_descriptor(e, first + i, values + (size_t)i * cells); if (rc) return rc; }
+        return SCL_OK;
+    }
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    if (first + count > e->n) return fail(e, SCL_ERR_OUT_OF_RANGE, "get_descriptors: range exceeds the database");
+    const int chunk = 512;
+    int rc;
+    if ((rc = ensure_vals(e, cells * (size_t)(count < chunk ? (count > 0 ? count : 1) : chunk)))) return rc;
+    for (int done = 0; done < count; done += chunk) {
+        const int c = count - done < chunk ? count - done : chunk;
+        for (int i = 0; i < c; ++i)
+            SCL_HIP(e, launch_untile(e->d_desc + (size_t)(first + done + i) * e->RG * e->S, e->R, e->S, e->d_vals + (size_t)i * cells, e->stream));
+        SCL_HIP(e, hipMemcpyAsync(values + (size_t)done * cells, e->d_vals, sizeof(float) * cells * (size_t)c, hipMemcpyDeviceToHost, e->stream));
+        if ((rc = sync(e))) return rc;
+    }
+    return SCL_OK;
+}
+
+int scl_find_key(const scl_engine *e, int8_t robot, int index, int *key)
+{
+    if (!e || !key) return SCL_ERR_INVALID_ARG;
+    *key = -1;
+    const int n = scl_get_size(e, -1);
+    if (n < 0) return n;
+    // newest first: the callers of DM.h:1281-1284 ask about recent keyframes
+    for (int k = n - 1; k >= 0; --k) {
+        int8_t r = 0; int idx = 0;
+        const int rc = scl_get_index(e, k, &r, &idx);
+        if (rc) return rc;
+        if (r == robot && idx == index) { *key = k; break; }
+    }
+    return SCL_OK;
+}
+
+namespace {
+struct DbFileHeader {
+    char magic[8];                                          // "SCLDB\0\0\1"
+    int32_t version, num_ring, num_sector, count;
+    int32_t reserved[4];
+};
+const char kDbMagic[8] = {'S', 'C', 'L', 'D', 'B', 0, 0, 1};
+}  // namespace
+
+int scl_db_dump_file(scl_engine *e, const char *path)
+{
+    if (!e || !path) return SCL_ERR_INVALID_ARG;
+    const int n = scl_get_size(e, -1);
+    if (n < 0) return n;
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return fail(e, SCL_ERR_INVALID_ARG, "db_dump: cannot open the file for writing");
+    DbFileHeader h{};
+    std::memcpy(h.magic, kDbMagic, 8);
+    h.version = 1; h.num_ring = e->R; h.num_sector = e->S; h.count = n;
+    int rc = SCL_OK;
+    if (std::fwrite(&h, sizeof h, 1, f) != 1) rc = SCL_ERR_INVALID_ARG;
+    const size_t cells = (size_t)e->R * e->S;
+    const int chunk = 512;
+    std::vector<float> buf(cells * (size_t)chunk);
+    for (int done = 0; done < n && !rc; done += chunk) {    // float32[N][R*S], wire order (D.h:1446-1455)
+        const int c = n - done < chunk ? n - done : chunk;
+        rc = scl_get_descriptors(e, done, c, buf.data());
+        if (!rc && std::fwrite(buf.data(), sizeof(float) * cells, (size_t)c, f) != (size_t)c) rc = fail(e, SCL_ERR_INVALID_ARG, "db_dump: short write");
+    }
+    for (int k = 0; k < n && !rc; ++k) {                    // (robot, index) map, D.h:1758-1761
+        int8_t r = 0; int32_t idx = 0;
+        rc = scl_get_index(e, k, &r, &idx);
+        const int32_t rec[2] = {(int32_t)r, idx};
+        if (!rc && std::fwrite(rec, sizeof rec, 1, f) != 1) rc = fail(e, SCL_ERR_INVALID_ARG, "db_dump: short write");
+    }
+    if (std::fclose(f) != 0 && !rc) rc = fail(e, SCL_ERR_INVALID_ARG, "db_dump: close failed");
+    return rc;
+}
+
+int scl_db_load_file(scl_engine *e, const char *path, int *n_loaded)
+{
+    if (!e || !path) return SCL_ERR_INVALID_ARG;
+    if (n_loaded) *n_loaded = 0;
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return fail(e, SCL_ERR_INVALID_ARG, "db_load: cannot open the file");
+    DbFileHeader h{};
+    int rc = SCL_OK;
+    if (std::fread(&h, sizeof h, 1, f) != 1 || std::memcmp(h.magic, kDbMagic, 8) != 0 || h.version != 1) rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: not a database dump of this engine");
+    else if (h.num_ring != e->R || h.num_sector != e->S) rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: the dump was made for another grid (rings x sectors)");
+    else if (h.count < 0) rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: corrupt header");
+    const size_t cells = (size_t)e->R * e->S;
+    std::vector<int8_t> robots; std::vector<int> indexs;
+    if (!rc) {
+        // the index map sits behind the descriptors: read it first, then stream the descriptors in chunks
+        robots.resize((size_t)h.count); indexs.resize((size_t)h.count);
+        if (std::fseek(f, (long)(sizeof h + sizeof(float) * cells * (size_t)h.count), SEEK_SET) != 0) rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: truncated file");
+        for (int k = 0; k < h.count && !rc; ++k) {
+            int32_t rec[2];
+            if (std::fread(rec, sizeof rec, 1, f) != 1) { rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: truncated index map"); break; }
+            robots[(size_t)k] = (int8_t)rec[0]; indexs[(size_t)k] = rec[1];
+        }
+        if (!rc && std::fseek(f, (long)sizeof h, SEEK_SET) != 0) rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: seek failed");
+    }
+    const int chunk = 512;
+    std::vector<float> buf(cells * (size_t)chunk);
+    for (int done = 0; !rc && done < h.count; done += chunk) {
+        const int c = h.count - done < chunk ? h.count - done : chunk;
+        if (std::fread(buf.data(), sizeof(float) * cells, (size_t)c, f) != (size_t)c) { rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: truncated descriptors"); break; }
+        rc = scl_save_bulk(e, buf.data(), c, robots.data() + done, indexs.data() + done);
+        if (!rc && n_loaded) *n_loaded += c;
+    }
+    std::fclose(f);
+    return rc;
+}
+
+/* ---- pose algebra behind the ICP block (DM.h:1130-1141, 1249-1259) ------------------------ */
+
+int scl_matrix_to_pose(const float T[16], float *x, float *y, float *z, float *roll, float *pitch, float *yaw)
+{
+    if (!T || !x || !y || !z || !roll || !pitch || !yaw) return SCL_ERR_INVALID_ARG;
+    *x = T[3]; *y = T[7]; *z = T[11];                       /* pcl::getTranslationAndEulerAngles, float like the reference */
+    *roll = std::atan2(T[9], T[10]);
+    *pitch = std::asin(-T[8]);
+    *yaw = std::atan2(T[4], T[0]);
+    return SCL_OK;
+}
+
+int scl_loop_pose_between(const float T_icp[16], const float pose_cur[6], const float pose_pre[6], double between_xyz_q[7], double between_rpy[3])
+{
+    if (!T_icp || !pose_cur || !pose_pre || !between_xyz_q) return SCL_ERR_INVALID_ARG;
+    float Tw[16], Tc[16];
+    scl_pose_to_matrix(pose_cur[0], pose_cur[1], pose_cur[2], pose_cur[3], pose_cur[4], pose_cur[5], Tw);   /* tfWrong, DM.h:1137 */
+    for (int r = 0; r < 4; ++r)                                                                              /* tfCorrect = tfICP * tfWrong (Affine3f), DM.h:1138 */
+        for (int c = 0; c < 4; ++c) {
+            float s = 0.0f;
+            for (int k = 0; k < 4; ++k) s += T_icp[4 * r + k] * Tw[4 * k + c];
+            Tc[4 * r + c] = s;
+        }
+    float x, y, z, roll, pitch, yaw;
+    scl_matrix_to_pose(Tc, &x, &y, &z, &roll, &pitch, &yaw);                                                 /* DM.h:1139 */
+    auto rzryrx = [](double ro, double pi, double ya, double R[9]) {                                         /* gtsam::Rot3::RzRyRx */
+        const double cr = std::cos(ro), sr = std::sin(ro), cp = std::cos(pi), sp = std::sin(pi), cy = std::cos(ya), sy = std::sin(ya);
+        R[0] = cy * cp; R[1] = cy * sp * sr - sy * cr; R[2] = cy * sp * cr + sy * sr;
+        R[3] = sy * cp; R[4] = sy * sp * sr + cy * cr; R[5] = sy * sp * cr - cy * sr;
+        R[6] = -sp;     R[7] = cp * sr;                R[8] = cp * cr;
+    };
+    double Rf[9], Rt[9];
+    rzryrx((double)roll, (double)pitch, (double)yaw, Rf);                                                    /* poseFrom, DM.h:1140 */
+    rzryrx((double)pose_pre[3], (double)pose_pre[4], (double)pose_pre[5], Rt);                               /* poseTo, DM.h:1141 + 214-218 */
+    const double tf[3] = {(double)x, (double)y, (double)z}, tt[3] = {(double)pose_pre[0], (double)pose_pre[1], (double)pose_pre[2]};
+    double Rb[9], tb[3];                                                                                     /* poseFrom.between(poseTo) = poseFrom^-1 * poseTo */
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) { double s = 0; for (int k = 0; k < 3; ++k) s += Rf[3 * k + r] * Rt[3 * k + c]; Rb[3 * r + c] = s; }
+        double s = 0; for (int k = 0; k < 3; ++k) s += Rf[3 * k + r] * (tt[k] - tf[k]);
+        tb[r] = s;
+    }
+    between_xyz_q[0] = tb[0]; between_xyz_q[1] = tb[1]; between_xyz_q[2] = tb[2];
+    // rotation matrix -> unit quaternion with w >= 0 (q and -q are the same rotation; the sign GTSAM / Eigen pick is not pinned)
+    double qw, qx, qy, qz;
+    const double tr = Rb[0] + Rb[4] + Rb[8];
+    if (tr > 0) { const double s = std::sqrt(tr + 1.0) * 2; qw = 0.25 * s; qx = (Rb[7] - Rb[5]) / s; qy = (Rb[2] - Rb[6]) / s; qz = (Rb[3] - Rb[1]) / s; }
+    else if (Rb[0] > Rb[4] && Rb[0] > Rb[8]) { const double s = std::sqrt(1.0 + Rb[0] - Rb[4] - Rb[8]) * 2; qw = (Rb[7] - Rb[5]) / s; qx = 0.25 * s; qy = (Rb[1] + Rb[3]) / s; qz = (Rb[2] + Rb[6]) / s; }
+    else if (Rb[4] > Rb[8]) { const double s = std::sqrt(1.0 + Rb[4] - Rb[0] - Rb[8]) * 2; qw = (Rb[2] - Rb[6]) / s; qx = (Rb[1] + Rb[3]) / s; qy = 0.25 * s; qz = (Rb[5] + Rb[7]) / s; }
+    else { const double s = std::sqrt(1.0 + Rb[8] - Rb[0] - Rb[4]) * 2; qw = (Rb[3] - Rb[1]) / s; qx = (Rb[2] + Rb[6]) / s; qy = (Rb[5] + Rb[7]) / s; qz = 0.25 * s; }
+    if (qw < 0) { qw = -qw; qx = -qx; qy = -qy; qz = -qz; }
+    between_xyz_q[3] = qx; between_xyz_q[4] = qy; between_xyz_q[5] = qz; between_xyz_q[6] = qw;
+    if (between_rpy) {                                                                                       /* Rot3::roll/pitch/yaw (DM.h:1258) */
+        between_rpy[0] = std::atan2(Rb[7], Rb[8]);
+        between_rpy[1] = std::asin(-Rb[6] > 1 ? 1 : (-Rb[6] < -1 ? -1 : -Rb[6]));
+        between_rpy[2] = std::atan2(Rb[3], Rb[0]);
+    }
+    return SCL_OK;
+}
+
 /* ---- geometric verification -------------------------------------------------- */
 
 int scl_icp_default_params(scl_icp_params *p)

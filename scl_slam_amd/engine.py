@@ -6,6 +6,7 @@ include/descriptor.h:1304-1801): same constructor arguments, same six method nam
 same return conventions (``(-1, 0.0)`` = no loop).
 """
 import ctypes
+import os
 from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int8, c_uint64, c_void_p
 
 import numpy as np
@@ -83,6 +84,12 @@ def _bind(lib):
         "scl_get_descriptor": (c_int, [P, c_int, fp]),
         "scl_get_ringkey": (c_int, [P, c_int, fp]),
         "scl_get_sectorkey": (c_int, [P, c_int, dp]),
+        "scl_get_descriptors": (c_int, [P, c_int, c_int, fp]),
+        "scl_find_key": (c_int, [P, c_int8, c_int, ip]),
+        "scl_db_dump_file": (c_int, [P, c_char_p]),
+        "scl_db_load_file": (c_int, [P, c_char_p, ip]),
+        "scl_matrix_to_pose": (c_int, [fp, fp, fp, fp, fp, fp, fp]),
+        "scl_loop_pose_between": (c_int, [fp, fp, fp, dp, dp]),
         "scl_stage_query": (c_int, [P, fp]),
         "scl_ringkey_topk": (c_int, [P, c_int, c_int, c_int, c_int, ip, fp, ip]),
         "scl_sc_distance_batch": (c_int, [P, c_int, ip, c_int, dp, ip]),
@@ -275,6 +282,39 @@ class ScanContextEngine:
         out = np.empty(self.S, dtype=np.float64)
         self._check(self._lib.scl_get_sectorkey(self._h, key, _ptr(out, c_double)), "scl_get_sectorkey")
         return out
+
+    def get_descriptors(self, first, count):
+        out = np.empty((max(count, 1), self.R * self.S), dtype=np.float32)
+        self._check(self._lib.scl_get_descriptors(self._h, first, count, _ptr(out, c_float)), "scl_get_descriptors")
+        return out[:count].reshape(count, self.R, self.S)
+
+    def find_key(self, robot, index):
+        """reverse of get_index: database key of (robot, index) or -1 (DM.h:1281-1284)"""
+        k = c_int()
+        self._check(self._lib.scl_find_key(self._h, robot, index, byref(k)), "scl_find_key")
+        return k.value
+
+    def db_dump(self, path):
+        self._check(self._lib.scl_db_dump_file(self._h, os.fsencode(path)), "scl_db_dump_file")
+
+    def db_load(self, path):
+        n = c_int()
+        self._check(self._lib.scl_db_load_file(self._h, os.fsencode(path), byref(n)), "scl_db_load_file")
+        return n.value
+
+    def matrix_to_pose(self, T):
+        Tm = _f32(T).reshape(16)
+        v = [c_float() for _ in range(6)]
+        self._check(self._lib.scl_matrix_to_pose(_ptr(Tm, c_float), *[byref(x) for x in v]), "scl_matrix_to_pose")
+        return tuple(x.value for x in v)
+
+    def loop_pose_between(self, T_icp, pose_cur, pose_pre):
+        """DM.h:1130-1141: (translation xyz + quaternion xyzw, roll/pitch/yaw) of poseFrom.between(poseTo)"""
+        Tm = _f32(T_icp).reshape(16); pc = _f32(pose_cur).reshape(6); pp = _f32(pose_pre).reshape(6)
+        out = np.empty(7, np.float64); rpy = np.empty(3, np.float64)
+        self._check(self._lib.scl_loop_pose_between(_ptr(Tm, c_float), _ptr(pc, c_float), _ptr(pp, c_float), _ptr(out, c_double), _ptr(rpy, c_double)),
+                    "scl_loop_pose_between")
+        return out, rpy
 
     def stage_query(self, values):
         v = _f32(values).reshape(-1)

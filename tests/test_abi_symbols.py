@@ -6,13 +6,15 @@ import re
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = os.path.join(ROOT, "include", "scl_engine.h")
+HEADERS = [os.path.join(ROOT, "include", "scl_engine.h"), os.path.join(ROOT, "include", "scl_messages.h")]
 
 
 def declared_symbols():
-    text = open(HEADER).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = set(re.findall(r"\b(scl_[a-z0-9_]+)\s*\(", text))
+    names = set()
+    for header in HEADERS:
+        text = open(header).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(scl_[a-z0-9_]+)\s*\(", text))
     return sorted(names)
 
 
@@ -66,7 +68,7 @@ def test_header_is_plain_c99(tmp_path):
     if not shutil.which("gcc"):
         pytest.skip("no gcc")
     src = tmp_path / "cabi.c"
-    src.write_text('#include "scl_engine.h"\nint main(void) { scl_config c; scl_icp_params p; (void)p; return scl_default_config(&c) == SCL_OK ? 0 : 1; }\n')
+    src.write_text('#include "scl_engine.h"\n#include "scl_messages.h"\nint main(void) { scl_config c; scl_icp_params p; (void)p; return scl_default_config(&c) == SCL_OK ? 0 : 1; }\n')
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
                         "-fsyntax-only", str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
