@@ -3,10 +3,13 @@
 # the numerics contract depends on it.
 HIPCC   ?= /opt/rocm/bin/hipcc
 ARCH    ?= gfx950
+# EXTRA=-DSCL_DIAGNOSTICS builds the SC-distance kernels' phase ablation / stamps / occupancy overrides in
+# (scripts/ablate_k1.sh); the product build has none of them
+EXTRA   ?=
 CSRC    := scl_slam_amd/csrc
 LIBDIR  := scl_slam_amd/lib
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
-            -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-result -Iinclude -I$(CSRC)
+            -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-result -Iinclude -I$(CSRC) $(EXTRA)
 SRCS    := $(CSRC)/engine.hip $(CSRC)/sc_distance.hip $(CSRC)/ringkey_topk.hip $(CSRC)/make_sc.hip $(CSRC)/icp.hip $(CSRC)/voxel.hip $(CSRC)/sharded_front.hip $(CSRC)/sc_screen.hip $(CSRC)/messages.hip
 OBJS    := $(SRCS:.hip=.o)
 

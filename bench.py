@@ -216,24 +216,38 @@ def secondary_icp(eng, n_cand=25, n_pts=100000):
             src0 = tgt.copy()
             p = tgt[:, :3].astype(np.float64) @ T[:3, :3].T + T[:3, 3]
             src0[:, :3] = (p + 0.01 * rs.standard_normal(p.shape)).astype(np.float32)
-    out = {"workload": f"BASELINE configs[2]: one scan vs its {n_cand} loop candidates, {n_pts} points per cloud, "
-                       f"max 30 iterations, clouds handed over as host buffers (PCIe inclusive)"}
+    out = {"workload": f"BASELINE configs[2]: one scan vs its {n_cand} loop candidates, {n_pts} points per cloud, max 30 iterations; "
+                       f"'from_store': clouds resident in the on-device keyframe store (scl_loop_icp_batch_from_store: submap assembly + "
+                       f"fused ICP loops, nothing but poses crosses PCIe); 'host_buffers': the same alignments with every cloud handed "
+                       f"over as a pageable host buffer (scl_icp_align_batch, PCIe inclusive)"}
+    ident = np.eye(4, dtype=np.float32)
+    for c in range(n_cand):
+        eng.keyframe_put(0, c, tgts[c])
+    eng.keyframe_put(0, n_cand, src0)
+    keys = np.arange(n_cand, dtype=np.int32)
+    poses = np.tile(ident.reshape(1, 1, 16), (n_cand, 1, 1))
     for est, name in ((1, "point_to_plane"), (0, "point_to_point")):
         pp = eng.icp_default_params(); pp.max_iterations = 30; pp.estimator = est; pp.normal_radius = 1.0
-        eng.icp_align_batch(src0, tgts[:2], pp)               # warm-up (workspaces, streams)
-        eng.profile_reset(); eng.profile_enable(1)
-        t0 = time.perf_counter()
-        Tb, fb, cb, ib = eng.icp_align_batch(src0, tgts, pp)
-        dt = time.perf_counter() - t0
-        eng.profile_enable(0)
-        iters = float(np.sum(ib))
-        algo_bytes = iters * (n_pts + n_pts) * 16.0
-        out[name] = {"value": n_cand / dt, "unit": "ICP problems/s", "ms_per_query": dt * 1e3,
-                     "ms_per_candidate": dt * 1e3 / n_cand, "iterations_mean": float(np.mean(ib)),
-                     "converged": int(np.sum(cb)), "matching_candidate_fitness": float(fb[0]),
-                     "roofline": {"bound": "hbm", "achieved": algo_bytes / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": algo_bytes / dt / 1e9 / HBM_PEAK_GBS,
-                                  "algorithmic_bytes": algo_bytes, "note": "wall time of the whole batch incl. H2D of 25 targets"}}
+        res = {}
+        for mode in ("from_store", "host_buffers"):
+            def run():
+                if mode == "from_store":                      # leaf 0.02 m: the voxel filter of loopFindNearKeyframes keeps ~all points
+                    T, f, cv, it, ns, nt = eng.loop_icp_batch_from_store(0, n_cand, ident, keys, 0, poses, 0.02, pp)
+                    return f, cv, it, ns, float(np.mean(nt))
+                T, f, cv, it = eng.icp_align_batch(src0, tgts, pp)
+                return f, cv, it, src0.shape[0], float(n_pts)
+            run()                                             # warm-up (workspaces, streams)
+            t0 = time.perf_counter()
+            fb, cb, ib, ns, nt = run()
+            dt = time.perf_counter() - t0
+            algo_bytes = float(np.sum(ib)) * (ns + nt) * 16.0
+            res[mode] = {"value": n_cand / dt, "unit": "ICP problems/s", "ms_per_query": dt * 1e3, "ms_per_candidate": dt * 1e3 / n_cand,
+                         "iterations_mean": float(np.mean(ib)), "converged": int(np.sum(cb)), "matching_candidate_fitness": float(fb[0]),
+                         "points_src": int(ns), "points_tgt_mean": nt,
+                         "roofline": {"bound": "hbm", "achieved": algo_bytes / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": algo_bytes / dt / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": algo_bytes,
+                                      "note": "SURVEY 8(d): (n_src + n_tgt) * 16 B per iteration; wall time of the whole call"}}
+        out[name] = res
     return out
 
 

@@ -300,6 +300,15 @@ int  scl_loop_icp_from_store(scl_engine *e, int robot, int key_cur, const float 
                              int key_pre, int search_num, const float *poses_pre, float leaf,
                              const scl_icp_params *p, int min_src_points, int min_tgt_points,
                              float T[16], float *fitness, int *converged, int *iterations, int *n_src, int *n_tgt);
+/* The same stage for the n_candidates loop candidates of ONE scan (BASELINE configs[2]: ICP on the top-25 candidates):
+ * the source submap is built once, every candidate's target submap comes from the store (keys_pre[c], its window of
+ * 2 * search_num + 1 poses at poses_pre + c * (2 * search_num + 1) * 16), and the ICP loops of all candidates run fused
+ * -- every loop step is one launch for the whole batch.  Outputs are per candidate (T: n_candidates x 16); candidates
+ * that fail the size gate keep T = identity, converged = 0.  Per-candidate results equal scl_loop_icp_from_store's. */
+int  scl_loop_icp_batch_from_store(scl_engine *e, int robot, int key_cur, const float *pose_cur,
+                                   int n_candidates, const int *keys_pre, int search_num, const float *poses_pre, float leaf,
+                                   const scl_icp_params *p, int min_src_points, int min_tgt_points,
+                                   float *T, float *fitness, int *converged, int *iterations, int *n_src, int *n_tgts);
 
 /* geometricVerificationService (DM.h:1189-1268) with the submap taken from the keyframe store: voxel filter of
  * the received cloud (src_leaf), submap(key_pre, search_num) from stored keyframes (leaf), size gate

@@ -435,9 +435,6 @@ int scl_create(const scl_config *cfg, scl_engine **out)
         if ((rc = dev_alloc(e, &e->d_tmin, (size_t)NS))) return bail(rc);
         if (hipMemset(e->d_nsurv, 0, sizeof(int) * NS) != hipSuccess) return bail(SCL_ERR_HIP);
         if (hipMemset(e->d_tmin, 0xff, sizeof(unsigned int) * NS) != hipSuccess) return bail(SCL_ERR_HIP);
-        if ((rc = dev_alloc(e, &e->d_scr_part, (size_t)kMaxQueryBatch * kScreenTopkWords))) return bail(rc);
-        if ((rc = dev_alloc(e, &e->d_scr_done, (size_t)kMaxQueryBatch))) return bail(rc);
-        if (hipMemset(e->d_scr_done, 0, sizeof(unsigned int) * kMaxQueryBatch) != hipSuccess) return bail(SCL_ERR_HIP);
         if ((rc = dev_alloc(e, &e->d_surv_part, (size_t)NS * kSurvivorBlocks * kTailRec))) return bail(rc);
         if ((rc = dev_alloc(e, &e->d_surv_done, (size_t)NS))) return bail(rc);
         if (hipMemset(e->d_surv_done, 0, sizeof(unsigned int) * NS) != hipSuccess) return bail(SCL_ERR_HIP);
@@ -473,7 +470,10 @@ int scl_destroy(scl_engine *e)
     icp_workspace_free(&e->icp_ws);
     icp_workspace_free(&e->vox_ws);
     for (void *slab : e->kf_slabs) (void)hipFree(slab);
+    for (int i = 0; i < scl_engine::kIcpBatch; ++i) icp_workspace_free(&e->icp_batch_ws[i]);
+    icp_workspace_free(&e->icp_batch_ctl);
     for (int i = 0; i < scl_engine::kIcpLanes; ++i) {
+        if (e->ev_lane[i]) (void)hipEventDestroy(e->ev_lane[i]);
         icp_workspace_free(&e->icp_lane_ws[i]);
         if (e->icp_lane_stream[i]) (void)hipStreamDestroy(e->icp_lane_stream[i]);
     }
@@ -481,7 +481,7 @@ int scl_destroy(scl_engine *e)
     dev_free(e->d_vals); dev_free(e->d_points); dev_free(e->d_tile);
     dev_free(e->d_dist); dev_free(e->d_shift); dev_free(e->d_cand); dev_free(e->d_ring_d2);
     dev_free(e->d_approx); dev_free(e->d_surv); dev_free(e->d_nsurv); dev_free(e->d_tmin);
-    dev_free(e->d_scr_part); dev_free(e->d_scr_done); dev_free(e->d_surv_part); dev_free(e->d_surv_done);
+    dev_free(e->d_surv_part); dev_free(e->d_surv_done);
     if (e->d_surv_args) (void)hipFree(e->d_surv_args);
     if (e->h_surv_args) (void)hipHostFree(e->h_surv_args);
     if (e->h_stream_out) (void)hipHostFree(e->h_stream_out);
@@ -827,7 +827,6 @@ int launch_screen_group(scl_engine *e, const int *qslot, const int *lo, const in
     sb.pair_stride = e->set_stride;
     sb.approx = e->d_approx; sb.ring_d2 = e->d_ring_d2; sb.survivors = nullptr; sb.n_surv = nullptr; sb.t_min = e->d_tmin;
     sb.k = e->cfg.num_candidates; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
-    sb.blk_part = nullptr; sb.done_counter = e->d_scr_done;   // (the ring-key top-k is formed by the exact pass's first workgroup)
     {
         ProfScope ps(e, P_SC);
         SCL_HIP(e, launch_sc_screen_batch(db_view(e), sb, e->SR, sc_align_filter_enabled(), e->num_cu, e->stream));
@@ -1485,42 +1484,55 @@ int scl_icp_align_batch(scl_engine *e, const void *src, int n_src, const void *c
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     const int lanes = n_targets < scl_engine::kIcpLanes ? n_targets : scl_engine::kIcpLanes;
-    for (int l = 0; l < lanes; ++l)
+    for (int l = 0; l < lanes; ++l) {
         if (!e->icp_lane_stream[l]) SCL_HIP(e, hipStreamCreateWithFlags(&e->icp_lane_stream[l], hipStreamNonBlocking));
+        if (!e->ev_lane[l]) SCL_HIP(e, hipEventCreateWithFlags(&e->ev_lane[l], hipEventDisableTiming));
+    }
     if (n_src < 0 || stride_bytes < 12 || (stride_bytes & 3)) return fail(e, SCL_ERR_INVALID_ARG, "icp_align_batch: bad cloud layout");
-    // the source crosses PCIe once; every lane takes a device-to-device copy of it
+    for (int c = 0; c < n_targets; ++c)
+        if ((!tgts[c] && n_tgts[c] > 0) || n_tgts[c] < 0) return fail(e, SCL_ERR_INVALID_ARG, "icp_align_batch: bad target");
+    // the source crosses PCIe once; every alignment's working cloud is made from it on the device
     int rc0 = ensure_points(e, (size_t)n_src * stride_bytes + 16);
     if (rc0) return rc0;
     if (n_src) SCL_HIP(e, hipMemcpyAsync(e->d_points, src, (size_t)n_src * stride_bytes, hipMemcpyHostToDevice, e->stream));
     SCL_HIP(e, hipStreamSynchronize(e->stream));
-    std::atomic<int> next{0};
-    std::atomic<int> first_rc{SCL_OK};
-    std::string errs[scl_engine::kIcpLanes];
-    auto worker = [&](int l) {
-        (void)hipSetDevice(e->device);
-        IcpWorkspace *ws = &e->icp_lane_ws[l];
-        hipStream_t st = e->icp_lane_stream[l];
-        for (;;) {
-            const int c = next.fetch_add(1);
-            if (c >= n_targets) break;
-            if ((!tgts[c] && n_tgts[c] > 0) || n_tgts[c] < 0) { int ok = SCL_OK; first_rc.compare_exchange_strong(ok, SCL_ERR_INVALID_ARG); continue; }
-            int conv = 0, iters = 0; float fit = 0.f;
-            int rc = icp_stage_cloud(ws, st, false, e->d_points, n_src, stride_bytes, &errs[l]);
-            if (!rc) rc = icp_stage_cloud_host(ws, st, true, tgts[c], n_tgts[c], stride_bytes, &errs[l]);
-            if (!rc) rc = icp_align_staged(ws, st, n_src, n_tgts[c], stride_bytes, *p, T + 16 * (size_t)c, &fit, &conv, &iters, &errs[l]);
-            if (rc) { int ok = SCL_OK; first_rc.compare_exchange_strong(ok, rc); continue; }
-            if (fitness) fitness[c] = fit;
-            if (converged) converged[c] = conv;
-            if (iterations) iterations[c] = iters;
-        }
-    };
-    std::vector<std::thread> pool;
-    for (int l = 1; l < lanes; ++l) pool.emplace_back(worker, l);
-    if (lanes > 0) worker(0);
-    for (auto &t : pool) t.join();
-    const int rc = first_rc.load();
-    if (rc) { for (auto &m : errs) if (!m.empty()) { e->last_error = m; break; } if (e->last_error.empty()) e->last_error = "icp_align_batch: bad target"; }
-    return rc;
+    for (int first = 0; first < n_targets; first += scl_engine::kIcpBatch) {
+        const int m = n_targets - first < scl_engine::kIcpBatch ? n_targets - first : scl_engine::kIcpBatch;
+        // stage the targets and build their search grids (normals): independent per candidate, issued from a few host
+        // threads onto the lane streams
+        std::atomic<int> next{0};
+        std::atomic<int> first_rc{SCL_OK};
+        std::string errs[scl_engine::kIcpLanes];
+        auto worker = [&](int l) {
+            (void)hipSetDevice(e->device);
+            hipStream_t st = e->icp_lane_stream[l];
+            for (;;) {
+                const int c = next.fetch_add(1);
+                if (c >= m) break;
+                IcpWorkspace *ws = &e->icp_batch_ws[c];
+                int rc = icp_stage_cloud_host(ws, st, true, tgts[first + c], n_tgts[first + c], stride_bytes, &errs[l]);
+                if (!rc) rc = icp_batch_prepare(ws, st, e->d_points, n_src, n_tgts[first + c], stride_bytes, *p, &errs[l]);
+                if (rc) { int ok = SCL_OK; first_rc.compare_exchange_strong(ok, rc); }
+            }
+            (void)hipEventRecord(e->ev_lane[l], st);
+        };
+        const int nl = m < lanes ? m : lanes;
+        std::vector<std::thread> pool;
+        for (int l = 1; l < nl; ++l) pool.emplace_back(worker, l);
+        worker(0);
+        for (auto &t : pool) t.join();
+        int rc = first_rc.load();
+        if (rc) { for (auto &msg : errs) if (!msg.empty()) { e->last_error = msg; break; } (void)hipDeviceSynchronize(); return rc; }
+        for (int l = 0; l < nl; ++l) SCL_HIP(e, hipStreamWaitEvent(e->stream, e->ev_lane[l], 0));
+        IcpWorkspace *wss[scl_engine::kIcpBatch];
+        for (int c = 0; c < m; ++c) wss[c] = &e->icp_batch_ws[c];
+        std::string err;
+        rc = icp_batch_run(wss, m, &e->icp_batch_ctl, e->stream, e->d_points, n_src, stride_bytes, *p, T + 16 * (size_t)first,
+                           fitness ? fitness + first : nullptr, converged ? converged + first : nullptr,
+                           iterations ? iterations + first : nullptr, &err);
+        if (rc) { e->last_error = err; return rc; }
+    }
+    return SCL_OK;
 }
 
 int scl_nn_correspondences(scl_engine *e, const void *src, int n_src, const void *tgt, int n_tgt,
@@ -1792,6 +1804,70 @@ int scl_loop_icp_from_store(scl_engine *e, int robot, int key_cur, const float *
     rc = icp_align_staged(&e->icp_ws, e->stream, ns, nt, stride, *p, T, fitness, converged, iterations, &err);
     if (rc) e->last_error = err;
     return rc;
+}
+
+int scl_loop_icp_batch_from_store(scl_engine *e, int robot, int key_cur, const float *pose_cur,
+                                  int n_candidates, const int *keys_pre, int search_num, const float *poses_pre, float leaf,
+                                  const scl_icp_params *p, int min_src_points, int min_tgt_points,
+                                  float *T, float *fitness, int *converged, int *iterations, int *n_src, int *n_tgts)
+{
+    if (!e || !pose_cur || !p || !T || n_candidates < 0 || (n_candidates > 0 && (!keys_pre || !poses_pre))) return SCL_ERR_INVALID_ARG;
+    if (e->front) e = front_primary(e);
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    const int stride = e->kf_stride ? e->kf_stride : 16;
+    std::vector<const void *> clouds; std::vector<int> counts; std::vector<float> Tw;
+    std::string err;
+    int ns = 0;
+    const void *d_res = nullptr;
+    // source: loopFindNearKeyframes(cur, 0), DM.h:1105 -- once for all candidates
+    int rc = kf_window(e, robot, key_cur, 0, pose_cur, &clouds, &counts, &Tw);
+    if (rc) return rc;
+    rc = assemble_submap_ex(&e->vox_ws, e->stream, clouds.data(), counts.data(), Tw.data(), (int)clouds.size(), stride, leaf,
+                            true, nullptr, 0, &d_res, &ns, &err);
+    if (rc) { e->last_error = err; return rc; }
+    if ((rc = ensure_points(e, (size_t)ns * stride + 16))) return rc;
+    if (ns) SCL_HIP(e, hipMemcpyAsync(e->d_points, d_res, (size_t)ns * stride, hipMemcpyDeviceToDevice, e->stream));
+    if (n_src) *n_src = ns;
+    const int win = 2 * search_num + 1;
+    for (int c = 0; c < n_candidates; ++c) {
+        for (int i = 0; i < 16; ++i) T[16 * (size_t)c + i] = (i % 5 == 0) ? 1.0f : 0.0f;
+        if (fitness) fitness[c] = 0.0f;
+        if (converged) converged[c] = 0;
+        if (iterations) iterations[c] = 0;
+        if (n_tgts) n_tgts[c] = 0;
+    }
+    for (int first = 0; first < n_candidates; first += scl_engine::kIcpBatch) {
+        const int m = n_candidates - first < scl_engine::kIcpBatch ? n_candidates - first : scl_engine::kIcpBatch;
+        IcpWorkspace *wss[scl_engine::kIcpBatch]; int which[scl_engine::kIcpBatch]; int live = 0;
+        for (int c = 0; c < m; ++c) {
+            // target: loopFindNearKeyframes(pre, historyKeyframeSearchNum), DM.h:1107, from the store
+            int nt = 0;
+            rc = kf_window(e, robot, keys_pre[first + c], search_num, poses_pre + (size_t)(first + c) * win * 16, &clouds, &counts, &Tw);
+            if (rc) return rc;
+            rc = assemble_submap_ex(&e->vox_ws, e->stream, clouds.data(), counts.data(), Tw.data(), (int)clouds.size(), stride, leaf,
+                                    true, nullptr, 0, &d_res, &nt, &err);
+            if (rc) { e->last_error = err; return rc; }
+            if (n_tgts) n_tgts[first + c] = nt;
+            if (ns < min_src_points || nt < min_tgt_points) continue;                   // DM.h:1108: too small, no alignment attempted
+            IcpWorkspace *ws = &e->icp_batch_ws[live];
+            rc = icp_stage_cloud(ws, e->stream, true, d_res, nt, stride, &err);
+            if (!rc) rc = icp_batch_prepare(ws, e->stream, e->d_points, ns, nt, stride, *p, &err);
+            if (rc) { e->last_error = err; return rc; }
+            wss[live] = ws; which[live] = first + c; ++live;
+        }
+        if (live == 0) continue;
+        std::vector<float> Tl(16 * (size_t)live), fl((size_t)live); std::vector<int> cl((size_t)live), il((size_t)live);
+        rc = icp_batch_run(wss, live, &e->icp_batch_ctl, e->stream, e->d_points, ns, stride, *p, Tl.data(), fl.data(), cl.data(), il.data(), &err);
+        if (rc) { e->last_error = err; return rc; }
+        for (int j = 0; j < live; ++j) {
+            std::memcpy(T + 16 * (size_t)which[j], Tl.data() + 16 * (size_t)j, 16 * sizeof(float));
+            if (fitness) fitness[which[j]] = fl[(size_t)j];
+            if (converged) converged[which[j]] = cl[(size_t)j];
+            if (iterations) iterations[which[j]] = il[(size_t)j];
+        }
+    }
+    return SCL_OK;
 }
 
 int scl_geometric_verification_from_store(scl_engine *e, const void *src, int n_src, int stride_bytes, float src_leaf,

@@ -67,7 +67,6 @@ struct scl_engine {
     static constexpr int kScreenSets = 64;
     float *d_approx = nullptr; int *d_surv = nullptr; int *d_nsurv = nullptr; unsigned int *d_tmin = nullptr;
     size_t set_stride = 0;
-    unsigned long long *d_scr_part = nullptr; unsigned int *d_scr_done = nullptr;          // fused top-k of the screening launches
     unsigned long long *d_surv_part = nullptr; unsigned int *d_surv_done = nullptr;        // tail of the exact pass
     void *d_surv_args = nullptr; void *h_surv_args = nullptr; unsigned surv_arg_tick = 0;   // argument sets of the exact pass (ring of 8 regions)
     double *h_stream_out = nullptr;                        // pinned: 2 x kScreenSets result records of the stream form
@@ -106,6 +105,12 @@ struct scl_engine {
     scl::IcpWorkspace vox_ws;
     static constexpr int kIcpLanes = 4;                    // concurrent alignments of scl_icp_align_batch
     scl::IcpWorkspace icp_lane_ws[kIcpLanes];
+    // scl_icp_align_batch: one workspace per loop candidate (their ICP loops run fused, every step one launch for the
+    // whole batch), prepared on the lane streams; candidates beyond kIcpBatch go in further rounds
+    static constexpr int kIcpBatch = 32;
+    scl::IcpWorkspace icp_batch_ws[kIcpBatch];
+    scl::IcpWorkspace icp_batch_ctl;
+    hipEvent_t ev_lane[kIcpLanes] = {nullptr};
     hipStream_t icp_lane_stream[kIcpLanes] = {nullptr};
 
     // on-device keyframe store (robots[id].keyFrameArray, DM.h:86): clouds live in slabs of HBM, bump allocated

@@ -176,7 +176,8 @@ __global__ void grid_scatter_kernel(const unsigned char *pts, int n, int stride,
 // independent: results are bit-identical to the serial walk (ties -> lowest target index).
 constexpr int kNnGroup = 8;
 
-__device__ __forceinline__ void group_min8(float &d, int &j)
+template <int G>
+__device__ __forceinline__ void group_min(float &d, int &j)
 {
     // xor 1, xor 2 (quad permutes), then mirror inside each half row (lane i <-> 7 - i): all 8 lanes end equal
 #define SCL_GMIN_STEP(CTRL)                                                                        \
@@ -186,25 +187,40 @@ __device__ __forceinline__ void group_min8(float &d, int &j)
         const bool take = (od < d) | ((od == d) & (oj < j));                                        \
         d = take ? od : d; j = take ? oj : j;                                                       \
     }
-    SCL_GMIN_STEP(0xB1) SCL_GMIN_STEP(0x4E) SCL_GMIN_STEP(0x141)
+    SCL_GMIN_STEP(0xB1)
+    if (G >= 4) SCL_GMIN_STEP(0x4E)
+    if (G >= 8) SCL_GMIN_STEP(0x141)
 #undef SCL_GMIN_STEP
 }
 
-// apply_iter >= 0: K6 fused in -- the increment of the previous iteration's solve (st->inc_T, valid iff
-// st->iter == apply_iter, i.e. that solve really ran) moves the working point first, and the moved point is
-// written back for the reduction that follows (distributedMapping.h:247-249 arithmetic: fp32, no FMA).
-__global__ __launch_bounds__(256) void nn_search_kernel(float4 *work, int n_src, const IcpState *st,
-                                                        const int *cell_start, const float4 *sorted,
-                                                        int *nn_idx, float *nn_d2, int check_done, int apply_iter)
+// apply_iter >= 0: K6 fused in -- the increment of the previous iteration's solve (st->inc_T) moves the working point
+// first, and the moved point is written back for the reduction that follows (distributedMapping.h:247-249
+// arithmetic: fp32, no FMA).  Every search of the loop follows exactly one solve; a solve that fails or converges sets
+// st->done, on which this kernel returns at once -- so no iteration number has to travel with the launch, and the same
+// launch serves every iteration, of one alignment or of a whole batch of them.
+// warm != 0: nn_idx[i] still holds the query's neighbour of the previous iteration.  Its distance to the moved query is
+// an upper bound on the new minimum, and every cell (row) of a shell whose box lies strictly farther away than the
+// best distance known so far is skipped: after the first iteration a query typically looks at its own cell and the
+// one or two neighbours its small ball reaches into, not at the 26 cells of the first shell.  Exactness is untouched:
+// a skipped box cannot hold a point at a smaller or equal distance (ties -> lowest index are decided among the points
+// at exactly the minimum distance, whose boxes are never skipped).
+// G = lanes per query: 8 for a cold search (whole shells to look at), 2 once the previous neighbour bounds the ball
+// (most queries are done after their own cell; eight lanes would mostly idle and only a quarter of the queries
+// would be resident at a time).
+template <int G>
+__device__ __forceinline__ void nn_search_kernel_t_body(float4 *work, int n_src, const IcpState *st,
+                                                          const int *cell_start, const float4 *sorted,
+                                                          int *nn_idx, float *nn_d2, int check_done, int apply_iter,
+                                                          const unsigned char *tgt_raw, int stride, int warm)
 {
     if (check_done && st->done) return;
     if (n_src <= 0) return;
-    const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / kNnGroup;
-    const int sub = threadIdx.x & (kNnGroup - 1);
+    const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int sub = threadIdx.x & (G - 1);
     const bool valid = gid < n_src;
     const int i = valid ? gid : n_src - 1;                       // surplus groups shadow the last query (all lanes stay in the exchanges)
     float4 pw = work[i];
-    if (apply_iter >= 0 && st->iter == apply_iter && valid) {    // (surplus groups would re-apply it to the stored result)
+    if (apply_iter >= 0 && valid) {                              // (surplus groups would re-apply it to the stored result)
         const float *T = st->inc_T;
         const float x = pw.x, y = pw.y, z = pw.z;
         pw.x = T[0] * x + T[1] * y + T[2] * z + T[3];
@@ -232,33 +248,75 @@ __global__ __launch_bounds__(256) void nn_search_kernel(float4 *work, int n_src,
     }
     float best = FLT_MAX;
     int bi = -1;
+    if (warm) {
+        const int j = nn_idx[i];
+        if (j >= 0) {
+            const float3 q = load_xyz(tgt_raw, j, stride);
+            const float ex = p.x - q.x, ey = p.y - q.y, ez = p.z - q.z;
+            const float d = (ex * ex + ey * ey) + ez * ez;       // the expression the scan uses: the same bits when the scan meets j again
+            if (d == d) { best = d; bi = j; }
+        }
+    }
+    const float gx0 = st->mn[0], gy0 = st->mn[1], gz0 = st->mn[2];
     for (int r = 0; r <= maxdim; ++r) {
         const int lo0 = c[0] - r, hi0 = c[0] + r, lo1 = c[1] - r, hi1 = c[1] + r, lo2 = c[2] - r, hi2 = c[2] + r;
         const int z0 = max(lo2, 0), z1 = min(hi2, dz - 1), y0 = max(lo1, 0), y1 = min(hi1, dy - 1);
         const int ny = y1 - y0 + 1, nrows = (z1 - z0 + 1) * ny;
         const int xs = max(lo0, 0), xe = min(hi0, dx - 1);
+        // four points per step, their loads issued together (a load per step and a wait behind it left the lane
+        // chasing one L2 latency per point); the last step re-reads the range's final point, which cannot change
+        // a (distance, index) minimum
         auto scan = [&](int kb, int ke) {
-            for (int k = kb; k < ke; ++k) {
-                const float4 q = sorted[k];
-                const float ex = p.x - q.x, ey = p.y - q.y, ez = p.z - q.z;
-                const float d = (ex * ex + ey * ey) + ez * ez;
-                const int j = __float_as_int(q.w);
-                if ((d < best) | ((d == best) & (j < bi))) { best = d; bi = j; }
+            for (int k = kb; k < ke; k += 4) {
+                float4 q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q[u] = sorted[k + u < ke ? k + u : ke - 1];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float ex = p.x - q[u].x, ey = p.y - q[u].y, ez = p.z - q[u].z;
+                    const float d = (ex * ex + ey * ey) + ez * ez;
+                    const int j = __float_as_int(q[u].w);
+                    if ((d < best) | ((d == best) & (j < bi))) { best = d; bi = j; }
+                }
             }
         };
-        for (int t = sub; t < nrows; t += kNnGroup) {
+        for (int t = sub; t < nrows; t += G) {
             const int zz = t / ny;
             const int z = z0 + zz, y = y0 + (t - zz * ny);
             const bool face = (z == lo2) | (z == hi2) | (y == lo1) | (y == hi1);
             const int row = (z * dy + y) * dx;
+            // squared distance from p to the row's (y, z) cell interval; boxes are taken a hair smaller than the cells
+            // (0.9995 on the squared distance) so that rounding in the box arithmetic can never skip a cell that
+            // holds a point at distance <= best
+            const float ylo = gy0 + (float)y * h, zlo = gz0 + (float)z * h;
+            const float ddy = fmaxf(fmaxf(ylo - p.y, p.y - (ylo + h)), 0.f), ddz = fmaxf(fmaxf(zlo - p.z, p.z - (zlo + h)), 0.f);
+            const float dyz2 = (ddy * ddy + ddz * ddz) * 0.9995f;
+            if (dyz2 > best) continue;                           // NaN coordinates never skip
             if (face) {
-                scan(cell_start[row + xs], cell_start[row + xe + 1]);
+                int xa = xs, xb = xe;
+                if (best < FLT_MAX) {                            // trim the row to the cells the ball reaches
+                    const float reach = sqrtf(best - dyz2) * 1.0005f + 1e-6f * h;
+                    const float fa = floorf((p.x - reach - gx0) / h), fb = floorf((p.x + reach - gx0) / h);
+                    if (fa == fa && fb == fb) {
+                        const int ia = fa < -1.0e9f ? xs : (fa > 1.0e9f ? xe + 1 : (int)fa), ib = fb < -1.0e9f ? xs - 1 : (fb > 1.0e9f ? xe : (int)fb);
+                        xa = max(xa, ia); xb = min(xb, ib);
+                    }
+                }
+                if (xa <= xb) scan(cell_start[row + xa], cell_start[row + xb + 1]);
             } else {
-                if (lo0 >= 0) scan(cell_start[row + lo0], cell_start[row + lo0 + 1]);
-                if (hi0 <= dx - 1) scan(cell_start[row + hi0], cell_start[row + hi0 + 1]);
+                if (lo0 >= 0) {
+                    const float xhi = gx0 + (float)(lo0 + 1) * h;
+                    const float ddx = fmaxf(p.x - xhi, 0.f);
+                    if (!((ddx * ddx) * 0.9995f + dyz2 > best)) scan(cell_start[row + lo0], cell_start[row + lo0 + 1]);
+                }
+                if (hi0 <= dx - 1) {
+                    const float xlo = gx0 + (float)hi0 * h;
+                    const float ddx = fmaxf(xlo - p.x, 0.f);
+                    if (!((ddx * ddx) * 0.9995f + dyz2 > best)) scan(cell_start[row + hi0], cell_start[row + hi0 + 1]);
+                }
             }
         }
-        group_min8(best, bi);
+        group_min<G>(best, bi);
         // lower bound on the squared distance to anything not visited yet: such a point lies beyond an open face of
         // the shell (distance f along that axis) and inside the grid's box (so at least dout[a] away along every axis
         // on which p lies outside the box -- what ends the walk of a query far outside the target early)
@@ -286,10 +344,19 @@ __global__ __launch_bounds__(256) void nn_search_kernel(float4 *work, int n_src,
     }
 }
 
+template <int G>
+__global__ __launch_bounds__(256) void nn_search_kernel_t(float4 *work, int n_src, const IcpState *st,
+                                                          const int *cell_start, const float4 *sorted,
+                                                          int *nn_idx, float *nn_d2, int check_done, int apply_iter,
+                                                          const unsigned char *tgt_raw, int stride, int warm)
+{
+    nn_search_kernel_t_body<G>(work, n_src, st, cell_start, sorted, nn_idx, nn_d2, check_done, apply_iter, tgt_raw, stride, warm);
+}
+
 // ---- K5 ----------------------------------------------------------------------------
 // sums of [p;1][q;1]^T (16) and of d2 over the accepted correspondences.
 // mode 0: pairs (i, nn_idx[i]) with d2 <= maxd2, p from `work`;  mode 1: explicit pairs (si[k], ti[k]).
-__global__ __launch_bounds__(256) void corr_reduce_kernel(const float4 *work, const unsigned char *src_raw,
+__device__ __forceinline__ void corr_reduce_kernel_body(const float4 *work, const unsigned char *src_raw,
                                                           const unsigned char *tgt_raw, int stride, int n,
                                                           const int *nn_idx, const float *nn_d2, float maxd2,
                                                           const int *si, const int *ti, int mode,
@@ -335,13 +402,22 @@ __global__ __launch_bounds__(256) void corr_reduce_kernel(const float4 *work, co
         partials[blockIdx.x * kNSum + threadIdx.x] = ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x];
 }
 
+__global__ __launch_bounds__(256) void corr_reduce_kernel(const float4 *work, const unsigned char *src_raw,
+                                                          const unsigned char *tgt_raw, int stride, int n,
+                                                          const int *nn_idx, const float *nn_d2, float maxd2,
+                                                          const int *si, const int *ti, int mode,
+                                                          const IcpState *st, double *partials, int check_done)
+{
+    corr_reduce_kernel_body(work, src_raw, tgt_raw, stride, n, nn_idx, nn_d2, maxd2, si, ti, mode, st, partials, check_done);
+}
+
 // MFMA form of K5.  v_mfma_f64_4x4x4_4b_f64 computes, in each of its four 16-lane blocks,
 // D[i][j] += sum_k A[i][k] * B[k][j] (k ascending, a plain fma chain -- probed on gfx950, see
 // scripts/probes/probe_mfma_f64.hip).  With A[i][k] = component i of [p;1] and B[k][j] = component j of
 // [q;1] for correspondence k of the block, one instruction adds the augmented outer products of 16
 // correspondences: cross-covariance, both centroids and the count at once.  Operand layout (probed):
 // A[i][k] of block b sits in lane 16k + 4b + i, B[k][j] in lane 16k + 4b + j, D[i][j] in lane 16i + 4b + j.
-__global__ __launch_bounds__(256) void corr_reduce_mfma_kernel(const float4 *work, const unsigned char *src_raw,
+__device__ __forceinline__ void corr_reduce_mfma_kernel_body(const float4 *work, const unsigned char *src_raw,
                                                                const unsigned char *tgt_raw, int stride, int n,
                                                                const int *nn_idx, const float *nn_d2, float maxd2,
                                                                const int *si, const int *ti, int mode,
@@ -391,6 +467,15 @@ __global__ __launch_bounds__(256) void corr_reduce_mfma_kernel(const float4 *wor
     __syncthreads();
     if (threadIdx.x < kNSum)
         partials[blockIdx.x * kNSum + threadIdx.x] = ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void corr_reduce_mfma_kernel(const float4 *work, const unsigned char *src_raw,
+                                                               const unsigned char *tgt_raw, int stride, int n,
+                                                               const int *nn_idx, const float *nn_d2, float maxd2,
+                                                               const int *si, const int *ti, int mode,
+                                                               const IcpState *st, double *partials, int check_done)
+{
+    corr_reduce_mfma_kernel_body(work, src_raw, tgt_raw, stride, n, nn_idx, nn_d2, maxd2, si, ti, mode, st, partials, check_done);
 }
 
 // ---- K5b ---------------------------------------------------------------------------
@@ -559,7 +644,7 @@ __device__ __forceinline__ void reduce_partials(const double *partials, int nblo
 }
 
 // mode 0: ICP iteration (convergence bookkeeping); mode 1: one-shot rigid estimate; mode 2: fitness only
-__global__ __launch_bounds__(64) void icp_solve_kernel(IcpState *st, const double *partials, int nblocks, int mode,
+__device__ __forceinline__ void icp_solve_kernel_body(IcpState *st, const double *partials, int nblocks, int mode,
                                                        int max_iter, double trans_eps, double fit_eps)
 {
     __shared__ double sums[kNSum];
@@ -585,6 +670,12 @@ __global__ __launch_bounds__(64) void icp_solve_kernel(IcpState *st, const doubl
     for (int k = 0; k < 16; ++k) st->inc_T[k] = T[k];
     if (mode == 1) { for (int k = 0; k < 16; ++k) st->final_T[k] = T[k]; return; }
     apply_increment(st, T, sums[16], N, max_iter, trans_eps, fit_eps);
+}
+
+__global__ __launch_bounds__(64) void icp_solve_kernel(IcpState *st, const double *partials, int nblocks, int mode,
+                                                       int max_iter, double trans_eps, double fit_eps)
+{
+    icp_solve_kernel_body(st, partials, nblocks, mode, max_iter, trans_eps, fit_eps);
 }
 
 // ---- point-to-plane estimator (BASELINE configs[2]; the reference itself is point-to-point) ---------
@@ -641,13 +732,19 @@ __global__ __launch_bounds__(256) void normals_kernel(const unsigned char *tgt, 
     for (int z = lo[2]; z <= hi[2]; ++z) for (int y = lo[1]; y <= hi[1]; ++y) {
         const int kb = cell_start[(z * st->dim[1] + y) * st->dim[0] + lo[0]];
         const int ke = cell_start[(z * st->dim[1] + y) * st->dim[0] + hi[0] + 1];       // cells along x are contiguous
-        for (int k = kb; k < ke; ++k) {
-            const float4 q = sorted[k];
-            const double dx = (double)q.x - (double)p.x, dy = (double)q.y - (double)p.y, dz = (double)q.z - (double)p.z;
-            if (dx * dx + dy * dy + dz * dz > r2) continue;
-            sum[0] += dx; sum[1] += dy; sum[2] += dz;
-            sq[0] += dx * dx; sq[1] += dx * dy; sq[2] += dx * dz; sq[3] += dy * dy; sq[4] += dy * dz; sq[5] += dz * dz;
-            ++cnt;
+        for (int k = kb; k < ke; k += 4) {                     // four loads in flight per step; sums stay in index order
+            float4 qq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) qq[u] = sorted[k + u < ke ? k + u : ke - 1];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 q = qq[u];
+                const double dx = (double)q.x - (double)p.x, dy = (double)q.y - (double)p.y, dz = (double)q.z - (double)p.z;
+                if (k + u >= ke || dx * dx + dy * dy + dz * dz > r2) continue;
+                sum[0] += dx; sum[1] += dy; sum[2] += dz;
+                sq[0] += dx * dx; sq[1] += dx * dy; sq[2] += dx * dz; sq[3] += dy * dy; sq[4] += dy * dz; sq[5] += dz * dz;
+                ++cnt;
+            }
         }
     }
     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -666,7 +763,7 @@ __global__ __launch_bounds__(256) void normals_kernel(const unsigned char *tgt, 
     normals[i] = out;
 }
 
-__global__ __launch_bounds__(256) void plane_reduce_kernel(const float4 *work, const unsigned char *tgt_raw, int stride, int n,
+__device__ __forceinline__ void plane_reduce_kernel_body(const float4 *work, const unsigned char *tgt_raw, int stride, int n,
                                                            const int *nn_idx, const float *nn_d2, float maxd2,
                                                            const float4 *normals, const IcpState *st, double *partials)
 {
@@ -707,7 +804,14 @@ __global__ __launch_bounds__(256) void plane_reduce_kernel(const float4 *work, c
         partials[blockIdx.x * kNPlane + threadIdx.x] = ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x];
 }
 
-__global__ void plane_solve_kernel(IcpState *st, const double *partials, int nblocks, int max_iter, double trans_eps, double fit_eps)
+__global__ __launch_bounds__(256) void plane_reduce_kernel(const float4 *work, const unsigned char *tgt_raw, int stride, int n,
+                                                           const int *nn_idx, const float *nn_d2, float maxd2,
+                                                           const float4 *normals, const IcpState *st, double *partials)
+{
+    plane_reduce_kernel_body(work, tgt_raw, stride, n, nn_idx, nn_d2, maxd2, normals, st, partials);
+}
+
+__device__ __forceinline__ void plane_solve_kernel_body(IcpState *st, const double *partials, int nblocks, int max_iter, double trans_eps, double fit_eps)
 {
     __shared__ double sums[kNPlane];
     __shared__ double tmp[kNPlane][64];
@@ -743,6 +847,11 @@ __global__ void plane_solve_kernel(IcpState *st, const double *partials, int nbl
     apply_increment(st, T, sums[27], N, max_iter, trans_eps, fit_eps);
 }
 
+__global__ void plane_solve_kernel(IcpState *st, const double *partials, int nblocks, int max_iter, double trans_eps, double fit_eps)
+{
+    plane_solve_kernel_body(st, partials, nblocks, max_iter, trans_eps, fit_eps);
+}
+
 // ---- K6 ----------------------------------------------------------------------------
 __global__ void work_init_kernel(const unsigned char *src, int n, int stride, float4 *work)
 {
@@ -751,7 +860,7 @@ __global__ void work_init_kernel(const unsigned char *src, int n, int stride, fl
 }
 
 // which: 0 = inc_T applied to work in place (ICP step); 1 = final_T applied to the raw source into work
-__global__ void work_transform_kernel(float4 *work, const unsigned char *src, int n, int stride,
+__device__ __forceinline__ void work_transform_kernel_body(float4 *work, const unsigned char *src, int n, int stride,
                                       const IcpState *st, int which, int expect_iter)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -769,6 +878,12 @@ __global__ void work_transform_kernel(float4 *work, const unsigned char *src, in
     const float oy = T[4] * x + T[5] * y + T[6] * z + T[7];
     const float oz = T[8] * x + T[9] * y + T[10] * z + T[11];
     work[i] = make_float4(ox, oy, oz, 0.f);
+}
+
+__global__ void work_transform_kernel(float4 *work, const unsigned char *src, int n, int stride,
+                                      const IcpState *st, int which, int expect_iter)
+{
+    work_transform_kernel_body(work, src, n, stride, st, which, expect_iter);
 }
 
 __global__ void raw_transform_kernel(const unsigned char *in, unsigned char *out, int n, int stride, const float *T)
@@ -921,6 +1036,55 @@ __global__ void iota_pairs_kernel(const int *nn, int n, int *si, int *ti)
     if (i < n) { si[i] = i; ti[i] = nn[i]; }
 }
 
+// ---- batched forms: one launch serves the same step of many alignments (blockIdx.y = alignment) -------------------
+// The loop of ONE alignment is a chain of three dependent, latency-bound launches per iteration (search 35 us with the
+// chip a quarter full, reduction 8 us, a single-wave solve 15 us); the loop candidates of one scan (BASELINE configs[2]:
+// 25) are independent, so their chains run side by side inside the same launches.  A finished alignment's workgroups
+// leave at once (st->done).
+struct IcpProblem {
+    float4 *work; IcpState *st; const int *cell_start; const float4 *sorted; int *nni; float *nnd; double *part;
+    const unsigned char *tgt; const float4 *normals;
+};
+
+template <int G>
+__global__ __launch_bounds__(256) void nn_search_batch_kernel(const IcpProblem *pr, int n_src, int check_done, int apply_iter, int stride, int warm)
+{
+    const IcpProblem p = pr[blockIdx.y];
+    nn_search_kernel_t_body<G>(p.work, n_src, p.st, p.cell_start, p.sorted, p.nni, p.nnd, check_done, apply_iter, p.tgt, stride, warm);
+}
+
+__global__ __launch_bounds__(256) void corr_reduce_batch_kernel(const IcpProblem *pr, const unsigned char *src_raw, int stride, int n, float maxd2,
+                                                                int check_done, int mfma)
+{
+    const IcpProblem p = pr[blockIdx.y];
+    if (mfma) corr_reduce_mfma_kernel_body(p.work, src_raw, p.tgt, stride, n, p.nni, p.nnd, maxd2, nullptr, nullptr, 0, p.st, p.part, check_done);
+    else corr_reduce_kernel_body(p.work, src_raw, p.tgt, stride, n, p.nni, p.nnd, maxd2, nullptr, nullptr, 0, p.st, p.part, check_done);
+}
+
+__global__ __launch_bounds__(64) void icp_solve_batch_kernel(const IcpProblem *pr, int nblocks, int mode, int max_iter, double trans_eps, double fit_eps)
+{
+    const IcpProblem p = pr[blockIdx.x];
+    icp_solve_kernel_body(p.st, p.part, nblocks, mode, max_iter, trans_eps, fit_eps);
+}
+
+__global__ __launch_bounds__(256) void plane_reduce_batch_kernel(const IcpProblem *pr, int stride, int n, float maxd2)
+{
+    const IcpProblem p = pr[blockIdx.y];
+    plane_reduce_kernel_body(p.work, p.tgt, stride, n, p.nni, p.nnd, maxd2, p.normals, p.st, p.part);
+}
+
+__global__ void plane_solve_batch_kernel(const IcpProblem *pr, int nblocks, int max_iter, double trans_eps, double fit_eps)
+{
+    const IcpProblem p = pr[blockIdx.x];
+    plane_solve_kernel_body(p.st, p.part, nblocks, max_iter, trans_eps, fit_eps);
+}
+
+__global__ void work_transform_batch_kernel(const IcpProblem *pr, const unsigned char *src, int n, int stride, int which)
+{
+    const IcpProblem p = pr[blockIdx.y];
+    work_transform_kernel_body(p.work, src, n, stride, p.st, which, 0);
+}
+
 // ---- host helpers -------------------------------------------------------------------
 static bool use_mfma_reduce()
 {
@@ -981,10 +1145,21 @@ int pinned(IcpWorkspace *ws, size_t bytes, std::string *err)
     return SCL_OK;
 }
 
-int nn_blocks(int n_src)
+constexpr int kNnWarmGroup = 2;
+
+void launch_nn_search(hipStream_t stream, float4 *work, int n_src, const IcpState *st, const int *cell_start, const float4 *sorted,
+                      int *nn_idx, float *nn_d2, int check_done, int apply_iter, const unsigned char *tgt_raw, int stride, int warm)
 {
-    const long long threads = (long long)(n_src > 0 ? n_src : 1) * kNnGroup;
-    return (int)((threads + 255) / 256);
+    const long long q = n_src > 0 ? n_src : 1;
+    if (warm) {
+        const int blocks = (int)((q * kNnWarmGroup + 255) / 256);
+        hipLaunchKernelGGL(nn_search_kernel_t<kNnWarmGroup>, dim3(blocks), dim3(256), 0, stream, work, n_src, st, cell_start, sorted,
+                           nn_idx, nn_d2, check_done, apply_iter, tgt_raw, stride, warm);
+    } else {
+        const int blocks = (int)((q * kNnGroup + 255) / 256);
+        hipLaunchKernelGGL(nn_search_kernel_t<kNnGroup>, dim3(blocks), dim3(256), 0, stream, work, n_src, st, cell_start, sorted,
+                           nn_idx, nn_d2, check_done, apply_iter, tgt_raw, stride, warm);
+    }
 }
 
 int check_cloud_args(int n_src, int n_tgt, int stride, std::string *err)
@@ -997,6 +1172,7 @@ int check_cloud_args(int n_src, int n_tgt, int stride, std::string *err)
 
 void icp_workspace_free(IcpWorkspace *ws)
 {
+
     for (int i = 0; i < 16; ++i) if (ws->buf[i]) { (void)hipFree(ws->buf[i]); ws->buf[i] = nullptr; ws->cap[i] = 0; }
     if (ws->pinned) { (void)hipHostFree(ws->pinned); ws->pinned = nullptr; ws->pinned_cap = 0; }
 }
@@ -1068,9 +1244,10 @@ int icp_align_staged(IcpWorkspace *ws, hipStream_t stream, int n_src, int n_tgt,
     hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(64), 0, stream, st);
     hipLaunchKernelGGL(work_init_kernel, dim3(pb), dim3(256), 0, stream, d_src, n_src, stride, work);
     IcpState *h = static_cast<IcpState *>(ws->pinned);
-    for (int it = 0; it < p.max_iterations; ++it) {
-        hipLaunchKernelGGL(nn_search_kernel, dim3(nn_blocks(n_src)), dim3(256), 0, stream, work, n_src, st,
-                           (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], nni, nnd, 1, it > 0 ? it : -1);
+    // one iteration = neighbour search (K6 of the previous iteration fused in) + reduction + solve
+    auto enqueue_iteration = [&](bool cold) {
+        launch_nn_search(stream, work, n_src, st, (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], nni, nnd, 1,
+                         cold ? -1 : 1, d_tgt, stride, cold ? 0 : 1);
         if (p.estimator == 1) {
             hipLaunchKernelGGL(plane_reduce_kernel, dim3(rb), dim3(256), 0, stream, work, d_tgt, stride, n_src, nni, nnd, maxd2,
                                (const float4 *)ws->buf[B_NORM], st, part);
@@ -1082,8 +1259,11 @@ int icp_align_staged(IcpWorkspace *ws, hipStream_t stream, int n_src, int n_tgt,
             hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, stream, st, part, rb, 0, p.max_iterations,
                                p.transformation_epsilon, p.euclidean_fitness_epsilon);
         }
-        // K6 (working cloud <- inc_T * working cloud) is fused into the next iteration's nn_search_kernel
-        if ((it & 7) == 7) {                                   // peek at the device flag every 8 iterations
+    };
+    enqueue_iteration(true);
+    for (int it = 1; it < p.max_iterations; ++it) {
+        enqueue_iteration(false);
+        if ((it & 7) == 7 && it + 1 < p.max_iterations) {      // peek at the device flag every 8 iterations
             ICP_HIP(hipMemcpyAsync(h, st, sizeof(IcpState), hipMemcpyDeviceToHost, stream));
             ICP_HIP(hipStreamSynchronize(stream));
             if (h->done) break;
@@ -1091,8 +1271,8 @@ int icp_align_staged(IcpWorkspace *ws, hipStream_t stream, int n_src, int n_tgt,
     }
     // fitness: original source moved by the final transform, mean squared NN distance over all points
     hipLaunchKernelGGL(work_transform_kernel, dim3(pb), dim3(256), 0, stream, work, d_src, n_src, stride, st, 1, 0);
-    hipLaunchKernelGGL(nn_search_kernel, dim3(nn_blocks(n_src)), dim3(256), 0, stream, work, n_src, st,
-                       (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], nni, nnd, 0, -1);
+    launch_nn_search(stream, work, n_src, st,
+                       (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], nni, nnd, 0, -1, d_tgt, stride, 1);
     LAUNCH_REDUCE(rb, stream, work, d_src, d_tgt, stride, n_src,
                   nni, nnd, FLT_MAX, (const int *)nullptr, (const int *)nullptr, 0, st, part, 0);
     hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, stream, st, part, rb, 2, 0, 0.0, 0.0);
@@ -1103,6 +1283,114 @@ int icp_align_staged(IcpWorkspace *ws, hipStream_t stream, int n_src, int n_tgt,
     if (fitness) *fitness = (float)h->fitness;
     if (converged) *converged = h->converged;
     if (iterations) *iterations = h->iter;
+    return SCL_OK;
+}
+
+// ---- the alignments of one scan's loop candidates, fused (BASELINE configs[2]) -----------------------------------------
+// icp_batch_prepare: everything an alignment needs before its first iteration, for the target staged in ws (B_TGT) and
+// the batch's shared source d_src: buffers, NN grid, normals (point-to-plane), state and working cloud.
+int icp_batch_prepare(IcpWorkspace *ws, hipStream_t stream, const void *d_src, int n_src, int n_tgt, int stride,
+                      const scl_icp_params &p, std::string *err)
+{
+    int rc = check_cloud_args(n_src, n_tgt, stride, err);
+    if (rc) return rc;
+    if (p.estimator != 0 && p.estimator != 1) { if (err) *err = "unknown estimator"; return SCL_ERR_INVALID_ARG; }
+    if (p.estimator == 1 && !(p.normal_radius > 0.0)) { if (err) *err = "normal_radius must be > 0"; return SCL_ERR_INVALID_ARG; }
+    if (p.max_iterations < 1) { if (err) *err = "max_iterations < 1"; return SCL_ERR_INVALID_ARG; }
+    if ((rc = ensure(ws, B_WORK, sizeof(float4) * (size_t)(n_src + 1), err))) return rc;
+    if ((rc = ensure(ws, B_NNI, sizeof(int) * (size_t)(n_src + 1), err))) return rc;
+    if ((rc = ensure(ws, B_NND, sizeof(float) * (size_t)(n_src + 1), err))) return rc;
+    if ((rc = ensure(ws, B_PART, sizeof(double) * kNPlane * kRedBlocks, err))) return rc;
+    if ((rc = build_grid(ws, stream, n_tgt, stride, err))) return rc;
+    if (p.estimator == 1) {
+        if ((rc = ensure(ws, B_NORM, sizeof(float4) * (size_t)(n_tgt + 1), err))) return rc;
+        hipLaunchKernelGGL(normals_kernel, dim3((n_tgt + 255) / 256 > 0 ? (n_tgt + 255) / 256 : 1), dim3(256), 0, stream,
+                           (const unsigned char *)ws->buf[B_TGT], n_tgt, stride, (const IcpState *)ws->buf[B_STATE],
+                           (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], p.normal_radius,
+                           (float4 *)ws->buf[B_NORM]);
+    }
+    const int pb = (n_src + 255) / 256 > 0 ? (n_src + 255) / 256 : 1;
+    hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(64), 0, stream, (IcpState *)ws->buf[B_STATE]);
+    hipLaunchKernelGGL(work_init_kernel, dim3(pb), dim3(256), 0, stream, (const unsigned char *)d_src, n_src, stride, (float4 *)ws->buf[B_WORK]);
+    ICP_HIP(hipGetLastError());
+    return SCL_OK;
+}
+
+// icp_batch_run: the ICP loops and the fitness passes of nprob prepared alignments, every step one launch for all of
+// them.  ctl keeps the problem table (device) and the pinned read-back area.  Per-alignment results are those of
+// icp_align_staged on the same clouds.
+int icp_batch_run(IcpWorkspace *const *wss, int nprob, IcpWorkspace *ctl, hipStream_t stream, const void *d_src, int n_src,
+                  int stride, const scl_icp_params &p, float *T, float *fitness, int *converged, int *iterations, std::string *err)
+{
+    if (nprob <= 0) return SCL_OK;
+    int rc;
+    if ((rc = ensure(ctl, B_MASK, sizeof(IcpProblem) * (size_t)nprob, err))) return rc;
+    if ((rc = pinned(ctl, (sizeof(IcpProblem) + sizeof(IcpState)) * (size_t)nprob, err))) return rc;
+    IcpProblem *hp = static_cast<IcpProblem *>(ctl->pinned);
+    IcpState *hs = reinterpret_cast<IcpState *>(hp + nprob);
+    for (int c = 0; c < nprob; ++c) {
+        IcpWorkspace *ws = wss[c];
+        hp[c].work = (float4 *)ws->buf[B_WORK]; hp[c].st = (IcpState *)ws->buf[B_STATE];
+        hp[c].cell_start = (const int *)ws->buf[B_CSTART]; hp[c].sorted = (const float4 *)ws->buf[B_TSORT];
+        hp[c].nni = (int *)ws->buf[B_NNI]; hp[c].nnd = (float *)ws->buf[B_NND]; hp[c].part = (double *)ws->buf[B_PART];
+        hp[c].tgt = (const unsigned char *)ws->buf[B_TGT]; hp[c].normals = p.estimator == 1 ? (const float4 *)ws->buf[B_NORM] : nullptr;
+    }
+    const IcpProblem *dp = static_cast<const IcpProblem *>(ctl->buf[B_MASK]);
+    ICP_HIP(hipMemcpyAsync(ctl->buf[B_MASK], hp, sizeof(IcpProblem) * (size_t)nprob, hipMemcpyHostToDevice, stream));
+    const unsigned char *src = static_cast<const unsigned char *>(d_src);
+    const long long q = n_src > 0 ? n_src : 1;
+    const int pb = (int)((q + 255) / 256);
+    const int rb = pb < kRedBlocks ? pb : kRedBlocks;
+    const float maxd2 = (float)(p.max_correspondence_dist * p.max_correspondence_dist);
+    const int mfma = use_mfma_reduce() ? 1 : 0;
+    auto search = [&](bool cold, int check_done) {
+        if (cold) hipLaunchKernelGGL(nn_search_batch_kernel<kNnGroup>, dim3((unsigned)((q * kNnGroup + 255) / 256), nprob), dim3(256), 0, stream,
+                                     dp, n_src, check_done, -1, stride, 0);
+        else hipLaunchKernelGGL(nn_search_batch_kernel<kNnWarmGroup>, dim3((unsigned)((q * kNnWarmGroup + 255) / 256), nprob), dim3(256), 0, stream,
+                                dp, n_src, check_done, 1, stride, 1);
+    };
+    auto iteration = [&](bool cold) {
+        search(cold, 1);
+        if (p.estimator == 1) {
+            hipLaunchKernelGGL(plane_reduce_batch_kernel, dim3(rb, nprob), dim3(256), 0, stream, dp, stride, n_src, maxd2);
+            hipLaunchKernelGGL(plane_solve_batch_kernel, dim3(nprob), dim3(64), 0, stream, dp, rb, p.max_iterations, p.transformation_epsilon,
+                               p.euclidean_fitness_epsilon);
+        } else {
+            hipLaunchKernelGGL(corr_reduce_batch_kernel, dim3(rb, nprob), dim3(256), 0, stream, dp, src, stride, n_src, maxd2, 1, mfma);
+            hipLaunchKernelGGL(icp_solve_batch_kernel, dim3(nprob), dim3(64), 0, stream, dp, rb, 0, p.max_iterations, p.transformation_epsilon,
+                               p.euclidean_fitness_epsilon);
+        }
+    };
+    auto read_states = [&]() -> int {
+        for (int c = 0; c < nprob; ++c) ICP_HIP(hipMemcpyAsync(&hs[c], hp[c].st, sizeof(IcpState), hipMemcpyDeviceToHost, stream));
+        ICP_HIP(hipStreamSynchronize(stream));
+        return SCL_OK;
+    };
+    iteration(true);
+    for (int it = 1; it < p.max_iterations; ++it) {
+        iteration(false);
+        if ((it & 7) == 7 && it + 1 < p.max_iterations) {      // peek at the done flags every 8 iterations
+            if ((rc = read_states())) return rc;
+            bool all = true;
+            for (int c = 0; c < nprob; ++c) all &= hs[c].done != 0;
+            if (all) break;
+        }
+    }
+    // fitness: the original source moved by each final transform, mean squared NN distance over all points (warm: the
+    // last neighbour bounds the search)
+    hipLaunchKernelGGL(work_transform_batch_kernel, dim3(pb, nprob), dim3(256), 0, stream, dp, src, n_src, stride, 1);
+    hipLaunchKernelGGL(nn_search_batch_kernel<kNnWarmGroup>, dim3((unsigned)((q * kNnWarmGroup + 255) / 256), nprob), dim3(256), 0, stream,
+                       dp, n_src, 0, -1, stride, 1);
+    hipLaunchKernelGGL(corr_reduce_batch_kernel, dim3(rb, nprob), dim3(256), 0, stream, dp, src, stride, n_src, FLT_MAX, 0, mfma);
+    hipLaunchKernelGGL(icp_solve_batch_kernel, dim3(nprob), dim3(64), 0, stream, dp, rb, 2, 0, 0.0, 0.0);
+    ICP_HIP(hipGetLastError());
+    if ((rc = read_states())) return rc;
+    for (int c = 0; c < nprob; ++c) {
+        std::memcpy(T + 16 * (size_t)c, hs[c].final_T, sizeof(float) * 16);
+        if (fitness) fitness[c] = (float)hs[c].fitness;
+        if (converged) converged[c] = hs[c].converged;
+        if (iterations) iterations[c] = hs[c].iter;
+    }
     return SCL_OK;
 }
 
@@ -1122,9 +1410,9 @@ int icp_nn_correspondences(IcpWorkspace *ws, hipStream_t stream, int num_cu, con
     const int pb = (n_src + 255) / 256 > 0 ? (n_src + 255) / 256 : 1;
     hipLaunchKernelGGL(work_init_kernel, dim3(pb), dim3(256), 0, stream, (const unsigned char *)ws->buf[B_SRC], n_src, stride,
                        (float4 *)ws->buf[B_WORK]);
-    hipLaunchKernelGGL(nn_search_kernel, dim3(nn_blocks(n_src)), dim3(256), 0, stream, (float4 *)ws->buf[B_WORK], n_src, st,
+    launch_nn_search(stream, (float4 *)ws->buf[B_WORK], n_src, st,
                        (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], (int *)ws->buf[B_NNI],
-                       (float *)ws->buf[B_NND], 0, -1);
+                       (float *)ws->buf[B_NND], 0, -1, (const unsigned char *)ws->buf[B_TGT], stride, 0);
     ICP_HIP(hipGetLastError());
     ICP_HIP(hipMemcpyAsync(nn_index, ws->buf[B_NNI], sizeof(int) * (size_t)n_src, hipMemcpyDeviceToHost, stream));
     if (nn_dist2) ICP_HIP(hipMemcpyAsync(nn_dist2, ws->buf[B_NND], sizeof(float) * (size_t)n_src, hipMemcpyDeviceToHost, stream));
@@ -1289,9 +1577,9 @@ int icp_geometric_verification_staged(IcpWorkspace *ws, hipStream_t stream, int 
     const int pb = (n_src + 255) / 256;
     hipLaunchKernelGGL(work_init_kernel, dim3(pb), dim3(256), 0, stream, (const unsigned char *)ws->buf[B_SRC], n_src, stride,
                        (float4 *)ws->buf[B_WORK]);
-    hipLaunchKernelGGL(nn_search_kernel, dim3(nn_blocks(n_src)), dim3(256), 0, stream, (float4 *)ws->buf[B_WORK], n_src, st,
+    launch_nn_search(stream, (float4 *)ws->buf[B_WORK], n_src, st,
                        (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], (int *)ws->buf[B_NNI],
-                       (float *)ws->buf[B_NND], 0, -1);                                              // DM.h:1211-1215
+                       (float *)ws->buf[B_NND], 0, -1, (const unsigned char *)ws->buf[B_TGT], stride, 0);   // DM.h:1211-1215
     hipLaunchKernelGGL(iota_pairs_kernel, dim3(pb), dim3(256), 0, stream, (const int *)ws->buf[B_NNI], n_src,
                        (int *)ws->buf[B_SI], (int *)ws->buf[B_TI]);
     int best2[2];

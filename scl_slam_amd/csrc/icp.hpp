@@ -30,6 +30,11 @@ int icp_stage_cloud_host(IcpWorkspace *ws, hipStream_t stream, bool target, cons
 int icp_align_staged(IcpWorkspace *ws, hipStream_t stream, int n_src, int n_tgt, int stride_bytes,
                      const scl_icp_params &p, float T[16], float *fitness, int *converged, int *iterations,
                      std::string *err);
+// the alignments of one scan's loop candidates, every loop step one launch for all of them (icp.hip)
+int icp_batch_prepare(IcpWorkspace *ws, hipStream_t stream, const void *d_src, int n_src, int n_tgt, int stride,
+                      const scl_icp_params &p, std::string *err);
+int icp_batch_run(IcpWorkspace *const *wss, int nprob, IcpWorkspace *ctl, hipStream_t stream, const void *d_src, int n_src,
+                  int stride, const scl_icp_params &p, float *T, float *fitness, int *converged, int *iterations, std::string *err);
 int icp_nn_correspondences(IcpWorkspace *ws, hipStream_t stream, int num_cu, const void *src, int n_src,
                            const void *tgt, int n_tgt, int stride_bytes, int *nn_index, float *nn_dist2,
                            std::string *err);

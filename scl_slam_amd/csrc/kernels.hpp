@@ -68,8 +68,8 @@ hipError_t launch_sc_distance_batch(const struct DbView &db, const QueryBatch &q
 // ---- screening pass of the full-DB mode (sc_screen.hip; 64x120 grid) --------------------------------------------
 // Per query i: every keyframe of [base, base+n) gets approx[i*pair_stride + pos] = its reference distance within
 // +- sc_screen_eps() (fp16 matrix-core evaluation of the reference's own 13 shifts; -inf = must be scored exactly),
-// ring_d2 = its ring-key metric, and the ring-key top-k of the range (fused for k <= kTailTop).  launch_sc_select_batch
-// (diagnostics, and the top-k for larger k): survivors = the database slots (ascending) that can still hold the minimum.
+// ring_d2 = its ring-key metric (the exact pass forms the top-k from it).  launch_sc_select_batch (diagnostics only):
+// survivors = the database slots (ascending) that can still hold the minimum.
 // t_min: one word per query, 0xffffffff before the first launch (the select launch re-arms it).
 struct ScreenBatch {
     int nq;
@@ -78,11 +78,7 @@ struct ScreenBatch {
     size_t pair_stride;
     float *approx; float *ring_d2; int *survivors; int *n_surv; unsigned int *t_min;
     int k; float exclude_eps; int *topk_idx; float *topk_d2;
-    // fused ring-key top-k of the screening launch (k <= kTailTop): kMaxQueryBatch * kScreenTopkWords words, kMaxQueryBatch zeroed counters;
-    // blk_part == nullptr (or k > kTailTop): call launch_sc_select_batch with survivors == nullptr for the top-k
-    unsigned long long *blk_part; unsigned int *done_counter;
 };
-constexpr int kScreenTopkWords = 768 * kTailTop;
 bool sc_screen_supported(const struct DbView &db, int SR);
 float sc_screen_eps();
 hipError_t launch_sc_screen_batch(const struct DbView &db, const ScreenBatch &sb, int SR, int align_filter, int num_cu, hipStream_t stream);

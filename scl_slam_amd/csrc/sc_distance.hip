@@ -1012,6 +1012,8 @@ __global__ __launch_bounds__(MAXT) void sc_distance_survivors_kernel(const ScArg
     sc_wave_body<RG, W, CH, S, MAXT, false>(a, bid, nb);
 }
 
+constexpr int kTailReadable = 4 * kWave;        // partial records the last workgroup of the fused epilogue merges (u < 4 x 64 lanes)
+
 template <int RG, int W, int CH, int S, int MAXT = 512, bool STAMP = false>
 hipError_t launch_wave(const ScBatchArgs &batch_in, int num_cu, hipStream_t stream, int fixed_blocks = 0)
 {
@@ -1025,13 +1027,18 @@ hipError_t launch_wave(const ScBatchArgs &batch_in, int num_cu, hipStream_t stre
     const size_t lds_cap = 160 * 1024;
     int waves = (int)((lds_cap - fixed - 16) / per_wave);
     if (waves > MAXT / kWave) waves = MAXT / kWave;
+#ifdef SCL_DIAGNOSTICS
     static const int wave_cap = [] { const char *e = getenv("SCL_SC_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1 << 20; }();
     if (waves > wave_cap) waves = wave_cap;               // diagnostic: fewer waves per CU
+#endif
     if (waves < 1) return hipErrorInvalidValue;
     if (!fixed_blocks) while (waves > 1 && n_launch < num_cu * waves) waves = (waves + 1) / 2;
     int blocks = (n_launch + waves - 1) / waves;
     if (blocks > num_cu) blocks = num_cu;
     if (fixed_blocks) blocks = fixed_blocks;               // candidate count known only on the device: full-width workgroups
+    // the fused epilogue's last workgroup reads at most kTailReadable partials (4 per lane): never launch more
+    // workgroups per query than it can merge (a device with more than 256 CUs would otherwise lose partials silently)
+    if (a.blk_part && blocks > kTailReadable) blocks = kTailReadable;
     const int grid = blocks * ab.nq;                       // workgroups [qi*blocks, (qi+1)*blocks) serve query qi
     ab.nb = blocks;
     const size_t lds = fixed + per_wave * waves + 16;      // + the candidate dispenser
@@ -1239,10 +1246,16 @@ hipError_t launch_fast(const ScArgs &args_in, int num_cu, hipStream_t stream)
 
 }  // namespace
 
+// Phase ablation / in-kernel stamps / occupancy overrides change results or timing on purpose: they exist only in
+// builds made with -DSCL_DIAGNOSTICS (scripts/ablate_k1.sh); the product library ignores the environment.
 int ablate_flags()
 {
+#ifdef SCL_DIAGNOSTICS
     static const int f = [] { const char *e = getenv("SCL_ABLATE"); return e ? atoi(e) : 0; }();
     return f;
+#else
+    return 0;
+#endif
 }
 
 int align_filter_enabled()
@@ -1283,8 +1296,13 @@ hipError_t launch_sc_distance(const DbView &db, const QueryView &q, const int *c
     ScBatchArgs one{};
     one.q[0] = a; one.nq = 1; one.nb = 0;
     if (wave_ok && db.RG == 5 && W == 7 && db.S == 60)   return launch_wave<5, 7, 5, 60>(one, num_cu, stream);
+#ifdef SCL_DIAGNOSTICS
     static const bool stamp = [] { const char *e = getenv("SCL_STAMP"); return e && e[0] == '1'; }();
     static const int occ = [] { const char *e = getenv("SCL_SC_WAVES"); return e ? atoi(e) : 8; }();
+#else
+    constexpr bool stamp = false;
+    constexpr int occ = 8;
+#endif
     if (wave_ok && db.RG == 16 && W == 13 && db.S == 120 && stamp && occ > 8) return launch_wave<16, 13, 2, 120, 768, true>(one, num_cu, stream);
     if (wave_ok && db.RG == 16 && W == 13 && db.S == 120 && stamp) return launch_wave<16, 13, 4, 120, 512, true>(one, num_cu, stream);
     if (wave_ok && db.RG == 16 && W == 13 && db.S == 120 && occ > 8) return launch_wave<16, 13, 2, 120, 768>(one, num_cu, stream);

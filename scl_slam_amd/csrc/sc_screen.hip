@@ -51,8 +51,6 @@ struct ScreenArgs {
     float *out_d2;            // [n] squared ring-key distance (nanoflann's metric), for the top-k
     unsigned int *t_min;      // ordered image of min d~ over the screened keyframes (atomicMin; re-armed by the exact pass)
     int align_filter;
-    // fused ring-key top-k (k <= kTailTop): per-workgroup partials, the last workgroup of the query merges them
-    unsigned long long *blk_part; unsigned int *done_counter; int *topk_idx; float *topk_d2; int topk_k; float exclude_eps;
 };
 
 struct ScreenBatchArgs { ScreenArgs q[kMaxQueryBatch]; int nq, nb; };
@@ -192,7 +190,7 @@ __device__ __forceinline__ int align_keyframe(const double2 vk, int lane, bool u
 constexpr float kScreenEps = 1.5e-3f;          // see the error budget at the top of this file
 constexpr int kScreenWaves = 4;
 constexpr int kGroup = 16;                     // keyframes per matrix product (the MFMA's N)
-constexpr int kScreenMaxBlocks = 768;          // workgroups per query (3 per CU at most): sizes the top-k partials
+constexpr int kScreenMaxBlocks = 768;          // workgroups per query (3 per CU at most)
 
 // D = k-steps of loads in flight per wave; OCC = waves per SIMD the register allocation is held to
 // (3: 168 registers, three workgroups per CU; 2: 256 registers, two workgroups per CU)
@@ -274,11 +272,6 @@ __global__ __launch_bounds__(kScreenWaves * kWave, OCC) void sc_screen_kernel(Sc
     const int n16 = lane & 15, j4 = lane >> 4;
     const int ngroups = (a.n + kGroup - 1) / kGroup;
     float run_min = __int_as_float(0x7f800000);                                  // wave 0: min d~ over screened keyframes
-    constexpr int KT = kTailTop;
-    constexpr unsigned long long kNone = ~0ull;
-    unsigned long long w_top[KT];                                                // this wave's KT nearest ring keys (wave-uniform)
-#pragma unroll
-    for (int t = 0; t < KT; ++t) w_top[t] = kNone;
 
     for (int g = bid; g < ngroups; g += nbk) {
         const int c_base = g * kGroup;
@@ -312,20 +305,6 @@ __global__ __launch_bounds__(kScreenWaves * kWave, OCC) void sc_screen_kernel(Sc
 #pragma unroll
             for (int r = 0; r < RG; ++r) result += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(grp), r));
             if (lane == 0 && ci < a.n) a.out_d2[ci] = result;
-            if (a.blk_part && ci < a.n) {
-                const int rbits = __builtin_amdgcn_readfirstlane(__float_as_int(result));   // scalar from here on
-                const float rs = __int_as_float(rbits);
-                const bool excluded = (a.exclude_eps > 0.0f) && (rs <= a.exclude_eps);
-                if (!excluded && (rs < 3.402823466e+38f)) {
-                    unsigned long long key = ((unsigned long long)(unsigned)rbits << 32) | (unsigned)ci;
-#pragma unroll
-                    for (int t = 0; t < KT; ++t) {                               // sorted insert (ascending), wave-uniform
-                        const unsigned long long lo_k = key < w_top[t] ? key : w_top[t];
-                        const unsigned long long hi_k = key < w_top[t] ? w_top[t] : key;
-                        w_top[t] = lo_k; key = hi_k;
-                    }
-                }
-            }
             vk_cur = vk_nxt; rk_cur = rk_nxt;
         }
         __syncthreads();                                                         // B1: the 16 first shifts are known
@@ -451,65 +430,6 @@ __global__ __launch_bounds__(kScreenWaves * kWave, OCC) void sc_screen_kernel(Sc
         }
     }
     if (wave == 0 && lane == 0 && run_min < __int_as_float(0x7f800000)) atomicMin(a.t_min, float_to_ordered_u(run_min));
-
-    // ---- fused ring-key top-k: wave lists -> workgroup list -> global partial; the last workgroup of the query merges ----
-    if (a.blk_part == nullptr) return;
-    __syncthreads();                                                             // everyone is done with the partial-sum buffers
-    unsigned long long *wl = reinterpret_cast<unsigned long long *>(part);       // [NWV][KT]
-    unsigned int *s_ticket = reinterpret_cast<unsigned int *>(s_start);
-    if (lane == 0) {
-#pragma unroll
-        for (int t = 0; t < KT; ++t) wl[wave * KT + t] = w_top[t];
-    }
-    __syncthreads();
-    if (wave == 0) {
-        unsigned long long key = lane < NWV * KT ? wl[lane] : kNone;
-        unsigned long long *bp = a.blk_part + (size_t)bid * KT;
-        unsigned long long prev = 0ull;
-        bool first = true;
-#pragma unroll
-        for (int t = 0; t < KT; ++t) {
-            const unsigned long long m = wave_min_u64((first || key > prev) ? key : kNone);
-            if (lane == 0) bp[t] = m;
-            prev = m; first = false;
-        }
-        if (lane == 0) {
-            __threadfence();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            *s_ticket = atomicAdd(a.done_counter, 1u);
-        }
-    }
-    __syncthreads();
-    if (*s_ticket != (unsigned)nbk - 1 || wave != 0) return;
-    __threadfence();                                                             // acquire: partials of the other workgroups
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    {
-        constexpr int PER = (kScreenMaxBlocks * KT + kWave - 1) / kWave;         // keys per lane
-        unsigned long long keys[PER];
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int i = lane + u * kWave;
-            keys[u] = i < nbk * KT ? __builtin_nontemporal_load(a.blk_part + i) : kNone;
-        }
-        unsigned long long prev = 0ull;
-        bool first = true;
-        for (int round = 0; round < a.topk_k; ++round) {
-            unsigned long long mine = kNone;
-#pragma unroll
-            for (int u = 0; u < PER; ++u) if ((first || keys[u] > prev) && keys[u] < mine) mine = keys[u];
-            const unsigned long long m = wave_min_u64(mine);
-            if (lane == 0) {
-                if (m == kNone) { a.topk_idx[round] = -1; a.topk_d2[round] = 3.402823466e+38f; }
-                else { a.topk_idx[round] = a.slot_base + (int)(unsigned)(m & 0xffffffffull); a.topk_d2[round] = __int_as_float((int)(m >> 32)); }
-            }
-            if (m == kNone) {
-                for (int r2 = round + 1 + lane; r2 < a.topk_k; r2 += kWave) { a.topk_idx[r2] = -1; a.topk_d2[r2] = 3.402823466e+38f; }
-                break;
-            }
-            prev = m; first = false;
-        }
-        if (lane == 0) *a.done_counter = 0u;                                     // armed for the next launch (stream ordered)
-    }
 }
 
 // ---- select: survivors of the screening (ascending slot order) + the ring-key top-k ----------------------------
@@ -627,12 +547,6 @@ hipError_t launch_sc_screen_batch(const DbView &db, const ScreenBatch &sb, int S
         a.slot_base = sb.base[i]; a.n = sb.n[i];
         a.out_approx = sb.approx + (size_t)sb.buf[i] * sb.pair_stride; a.out_d2 = sb.ring_d2 + (size_t)sb.buf[i] * sb.pair_stride;
         a.t_min = sb.t_min + sb.buf[i]; a.align_filter = align_filter;
-        static const bool topk_off = [] { const char *e = getenv("SCL_SCREEN_TOPK"); return e && e[0] == '0'; }();   // diagnostic A/B
-        const bool fused_topk = sb.k <= kTailTop && sb.blk_part != nullptr && !topk_off;
-        a.blk_part = fused_topk ? sb.blk_part + (size_t)i * kScreenMaxBlocks * kTailTop : nullptr;
-        a.done_counter = sb.done_counter + i;
-        a.topk_idx = sb.topk_idx + sb.buf[i] * kTailTopMaxK; a.topk_d2 = sb.topk_d2 + sb.buf[i] * kTailTopMaxK;
-        a.topk_k = sb.k; a.exclude_eps = sb.exclude_eps;
         nmax = sb.n[i] > nmax ? sb.n[i] : nmax;
     }
     for (int i = sb.nq; i < kMaxQueryBatch; ++i) ab.q[i] = ab.q[0];

@@ -119,6 +119,8 @@ def _bind(lib):
         "scl_submap_from_store": (c_int, [P, c_int, c_int, c_int, fp, c_float, P, c_int, ip]),
         "scl_loop_icp_from_store": (c_int, [P, c_int, c_int, fp, c_int, c_int, fp, c_float, POINTER(IcpParams), c_int, c_int,
                                             fp, fp, ip, ip, ip, ip]),
+        "scl_loop_icp_batch_from_store": (c_int, [P, c_int, c_int, fp, c_int, ip, c_int, fp, c_float, POINTER(IcpParams), c_int, c_int,
+                                                  fp, fp, ip, ip, ip, ip]),
         "scl_geometric_verification_from_store": (c_int, [P, P, c_int, c_int, c_float, c_int, c_int, c_int, fp, c_float, c_int, c_int,
                                                           c_int, c_double, c_double, c_uint64, fp, ip, ip, ip, ip, ip]),
         "scl_profile_enable": (c_int, [P, c_int]),
@@ -564,6 +566,21 @@ class ScanContextEngine:
                                                       _ptr(T, c_float), byref(fit), byref(conv), byref(it), byref(ns), byref(nt)),
                     "scl_loop_icp_from_store")
         return T.reshape(4, 4), fit.value, bool(conv.value), it.value, ns.value, nt.value
+
+    def loop_icp_batch_from_store(self, robot, key_cur, pose_cur, keys_pre, search_num, poses_pre, leaf, params=None,
+                                  min_src_points=300, min_tgt_points=1000):
+        """stage 2 of performIntraLoopClosure for all loop candidates of one scan, ICP loops fused (BASELINE configs[2])"""
+        p = params if params is not None else self.icp_default_params()
+        keys = np.ascontiguousarray(keys_pre, dtype=np.int32); m = keys.size
+        Tc = _f32(np.asarray(pose_cur)).reshape(16)
+        Tp = _f32(np.asarray(poses_pre)).reshape(m, 2 * search_num + 1, 16)
+        T = np.empty((max(m, 1), 16), np.float32); fit = np.zeros(max(m, 1), np.float32)
+        conv = np.zeros(max(m, 1), np.int32); it = np.zeros(max(m, 1), np.int32); ns = c_int(); nt = np.zeros(max(m, 1), np.int32)
+        self._check(self._lib.scl_loop_icp_batch_from_store(self._h, robot, key_cur, _ptr(Tc, c_float), m, _ptr(keys, c_int), search_num,
+                                                            _ptr(Tp, c_float), leaf, byref(p), min_src_points, min_tgt_points,
+                                                            _ptr(T, c_float), _ptr(fit, c_float), _ptr(conv, c_int), _ptr(it, c_int),
+                                                            byref(ns), _ptr(nt, c_int)), "scl_loop_icp_batch_from_store")
+        return T[:m].reshape(m, 4, 4), fit[:m], conv[:m].astype(bool), it[:m], ns.value, nt[:m]
 
     def geometric_verification_from_store(self, src, src_leaf, robot, key_pre, search_num, poses_pre, leaf,
                                           ransac_iterations=1000, inlier_threshold=0.25, inlier_ratio=0.45, seed=1,

@@ -115,3 +115,28 @@ def test_submit_collect_pipeline_matches_blocking_calls():
     with pytest.raises(SclError):
         eng.detect_full_submit(0, 0, 10)                                  # ring of 8 is full
     eng.close()
+
+
+def test_duplicate_ring_key_in_history_under_both_knn_rules():
+    """A yaw-only revisit has the query's ring key bit for bit (the key is rotation invariant).  libnabo, the tree of
+    the live intra-robot path (D.h:1631-1642, optionFlags = 0), skips neighbours at squared distance <= FLT_EPSILON;
+    nanoflann (D.h:1710-1716) returns them.  knn_exclude_eps selects the rule; the C++ adapter defaults to libnabo's."""
+    R, S, n = 20, 60, 400
+    descs = synth_descriptors(n, R, S, seed=77, revisit_frac=0.0)
+    descs[n - 1] = np.roll(descs[57], 23, axis=1)               # pure rotation of keyframe 57: identical ring key
+    eps = float(np.finfo(np.float32).eps)
+    for rule in (0.0, eps):
+        eng = ScanContextEngine(num_ring=R, num_sector=S, knn_exclude_eps=rule)
+        db = ob.OracleDB(ob.make_config(R=R, S=S, knn_exclude_eps=rule))
+        eng.save_bulk(descs); db.save_bulk(descs)
+        assert np.array_equal(eng.get_ringkey(n - 1).view(np.uint32), eng.get_ringkey(57).view(np.uint32))
+        got, want = eng.detect_intra(n - 1), db.detect_intra(n - 1)
+        assert got[:2] == want[:2] and got[2] == want[2]
+        idx, d2, found = eng.ringkey_topk(n - 1, 0, n - 100, 3)
+        if rule == 0.0:
+            assert got[0] == 57 and got[1] == 23.0 and idx[0] == 57 and d2[0] == 0.0      # nanoflann: the twin is candidate no. 1
+        else:
+            assert 57 not in idx and got[0] != 57                                          # libnabo: the twin is never proposed
+        # the inter-robot path uses nanoflann's rule regardless (D.h:1710-1716)
+        assert eng.detect_inter(n - 1)[0] == db.detect_inter(n - 1)[0] == 57
+        eng.close()

@@ -128,3 +128,30 @@ def test_service_verification_from_store_equals_stepwise():
         assert not ok2 and np.array_equal(T2, ident)
     finally:
         e.close()
+
+
+def test_loop_icp_batch_from_store_equals_one_by_one():
+    """the fused ICP loops of a scan's candidates (BASELINE configs[2]) return what scl_loop_icp_from_store returns per candidate"""
+    e = ScanContextEngine()
+    try:
+        base = synth_structured_cloud(24000, seed=3)
+        ident = np.eye(4, dtype=np.float32)
+        for k in range(12):
+            e.keyframe_put(0, k, (base if k < 9 else synth_structured_cloud(24000, seed=40 + k))[k % 3::3][:6000].copy())
+        drift = rigid_transform(0.01, -0.015, 0.04, 0.25, -0.2, 0.05)
+        e.keyframe_put(0, 12, moved_copy(base, drift, keep_every=4, noise=0.005))
+        sn, leaf = 1, 0.3
+        keys = [3, 6, 10, 1, 11]                                 # matching places and unrelated ones
+        poses = np.stack([np.stack(_window([ident] * 13, k, sn)) for k in keys])
+        pp = e.icp_default_params(); pp.max_iterations = 30
+        Tb, fb, cb, ib, ns, ntb = e.loop_icp_batch_from_store(0, 12, ident, keys, sn, poses, leaf, pp)
+        for c, k in enumerate(keys):
+            T1, f1, c1, i1, ns1, nt1 = e.loop_icp_from_store(0, 12, ident, k, sn, _window([ident] * 13, k, sn), leaf, pp)
+            assert (ns, ntb[c]) == (ns1, nt1) and cb[c] == c1 and ib[c] == i1
+            assert np.array_equal(Tb[c].view(np.uint32), T1.view(np.uint32)) and fb[c] == np.float32(f1)
+        assert cb.all()
+        # size gate: nothing attempted
+        T0, f0, c0, i0, _, _ = e.loop_icp_batch_from_store(0, 12, ident, keys[:2], sn, poses[:2], leaf, pp, min_tgt_points=10 ** 7)
+        assert not c0.any() and not i0.any() and np.array_equal(T0[1], ident)
+    finally:
+        e.close()
