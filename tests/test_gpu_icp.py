@@ -175,3 +175,23 @@ def test_icp_align_batch_equals_one_by_one(eng):
         assert np.array_equal(Tb[c].view(np.uint32), T1.view(np.uint32)) and fb[c] == f1 and bool(cb[c]) == c1 and ib[c] == i1
     T0, f0, c0, i0 = eng.icp_align_batch(src, [])
     assert T0.shape[0] == 0
+
+
+def test_configs2_point_to_plane_batch_25_candidates_of_100k_points(eng):
+    """BASELINE configs[2] at full size: one scan against 25 loop candidates of 100 k points, point-to-plane, 30
+    iterations max, verified together (fused ICP loops); the matching candidate and an unrelated one are checked
+    against the CPU restatement, every candidate against the one-by-one call on a sample."""
+    n_pts, n_cand = 100000, 25
+    tgts = [synth_structured_cloud(n_pts, seed=100 + c, extent=60.0) for c in range(n_cand)]
+    T = rigid_transform(0.004, -0.006, 0.02, 0.25, -0.15, 0.05)
+    src = moved_copy(tgts[0], T, keep_every=1, noise=0.01, seed=3)
+    p = eng.icp_default_params(); p.max_iterations = 30; p.estimator = 1; p.normal_radius = 1.0
+    Tb, fb, cb, ib = eng.icp_align_batch(src, tgts, p)
+    assert cb.all() and np.abs(Tb[0] - T).max() < 5e-3 and fb[0] < 1e-3
+    for c in (0, 13):                                               # vs the CPU restatement (seconds each)
+        To, fo, co, io = oi.icp_align(src, tgts[c], oi.default_params(30, estimator=1, normal_radius=1.0))
+        assert co == bool(cb[c]) and io == ib[c], (c, io, ib[c])
+        assert np.abs(Tb[c] - To).max() < TOL and abs(fb[c] - fo) <= 1e-4 * max(1e-6, abs(fo)) + 1e-12
+    for c in (0, 5, 24):                                            # fused == one by one, bit for bit
+        T1, f1, c1, i1 = eng.icp_align(src, tgts[c], p)
+        assert np.array_equal(Tb[c].view(np.uint32), T1.view(np.uint32)) and fb[c] == f1 and bool(cb[c]) == c1 and ib[c] == i1
