@@ -939,7 +939,8 @@ int submit_full_locked(scl_engine *e, int query, int lo, int hi, int *ticket)
 int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, const int *his, int nq, int *tickets)
 {
     const int k = e->cfg.num_candidates;
-    bool batchable = (nq > 1 || e->screen) && nq <= kMaxQueryBatch && (k <= kTailTop || e->screen) && sc_distance_fuses_ring(db_view(e), e->SR);
+    const bool wide = e->screen && sc_screen_is_wide(db_view(e), e->SR);      // 80 x 180
+    bool batchable = (nq > 1 || e->screen) && nq <= kMaxQueryBatch && (k <= kTailTop || e->screen) && (sc_distance_fuses_ring(db_view(e), e->SR) || wide);
     int qslot[kMaxQueryBatch] = {0};                       // database index of every query (staging slot j = cap + j)
     for (int i = 0; i < nq && batchable; ++i) {
         const int q = queries[i];
@@ -979,7 +980,23 @@ int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, c
             // survivors only; the winner is the reference's, bit for bit (sc_screen.hip)
             if ((rc = ensure_sets(e, (size_t)nmax))) return rc;
             if ((rc = launch_screen_group(e, qb.slot, qb.base, qb.n, qb.nq, 0))) return rc;
-            if ((rc = launch_survivor_pass(e, qb.slot, qb.base, qb.n, qb.nq, 0, qb.out3))) return rc;
+            if (wide) {
+                // 80 x 180: survivors (+ ring-key top-k) by the select launch, then per query the exact one-sector-per-lane
+                // kernel on its survivors and the arg-min
+                ScreenBatch sb{};
+                sb.nq = qb.nq;
+                for (int j = 0; j < qb.nq; ++j) { sb.slot[j] = qb.slot[j]; sb.base[j] = qb.base[j]; sb.n[j] = qb.n[j]; sb.buf[j] = j; }
+                sb.pair_stride = e->set_stride;
+                sb.approx = e->d_approx; sb.ring_d2 = e->d_ring_d2; sb.survivors = e->d_surv; sb.n_surv = e->d_nsurv; sb.t_min = e->d_tmin;
+                sb.k = k; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
+                SCL_HIP(e, launch_sc_select_batch(sb, e->stream));
+                ProfScope ps(e, P_ARGMIN);
+                for (int j = 0; j < qb.nq; ++j)
+                    SCL_HIP(e, launch_sc_distance_survivors_wide(db_view(e), qb.slot[j], qb.base[j], qb.n[j], e->SR,
+                                                                 e->d_surv + (size_t)j * e->set_stride, e->d_nsurv + j,
+                                                                 e->d_dist + (size_t)j * e->set_stride, e->d_shift + (size_t)j * e->set_stride,
+                                                                 qb.out3[j], e->num_cu, e->stream));
+            } else if ((rc = launch_survivor_pass(e, qb.slot, qb.base, qb.n, qb.nq, 0, qb.out3))) return rc;
         } else {
             ProfScope ps(e, P_SC);
             SCL_HIP(e, launch_sc_distance_batch(db_view(e), qb, e->SR, e->d_dist, e->d_shift, e->d_ring_d2, tail, e->num_cu, e->stream));
@@ -1207,7 +1224,7 @@ int scl_screen_distances(scl_engine *e, int query, int lo, int hi, float *approx
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     if (eps) *eps = sc_screen_eps();
-    if (!e->screen) return fail(e, SCL_ERR_UNSUPPORTED, "no screening pass for this grid (64x120, search ratio 0.1 only)");
+    if (!e->screen) return fail(e, SCL_ERR_UNSUPPORTED, "no screening pass for this grid (64x120 and 80x180 at search ratio 0.1 only)");
     int qslot;
     if (query >= 0) { if (query >= e->n) return fail(e, SCL_ERR_OUT_OF_RANGE, "query slot out of range"); qslot = query; }
     else { const int j = -1 - query; if (j >= scl_engine::kStage || !e->staged[j]) return fail(e, SCL_ERR_INVALID_ARG, "no staged query"); qslot = e->cap + j; }

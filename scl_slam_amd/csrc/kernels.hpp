@@ -80,6 +80,7 @@ struct ScreenBatch {
     int k; float exclude_eps; int *topk_idx; float *topk_d2;
 };
 bool sc_screen_supported(const struct DbView &db, int SR);
+bool sc_screen_is_wide(const struct DbView &db, int SR);      // 80 x 180: screening by sc_screen_wide_kernel, exact pass by the one-sector-per-lane kernel
 float sc_screen_eps();
 hipError_t launch_sc_screen_batch(const struct DbView &db, const ScreenBatch &sb, int SR, int align_filter, int num_cu, hipStream_t stream);
 hipError_t launch_sc_select_batch(const ScreenBatch &sb, hipStream_t stream);
@@ -104,6 +105,8 @@ struct SurvivorPass {
     void *d_args; void *h_args;
 };
 hipError_t launch_sc_distance_survivors(const struct DbView &db, const SurvivorPass &sp, int SR, int num_cu, hipStream_t stream);
+hipError_t launch_sc_distance_survivors_wide(const struct DbView &db, int query_slot, int slot_base, int range_n, int SR, const int *survivors,
+                                             const int *n_surv, double *out_dist, int *out_shift, double *out3, int num_cu, hipStream_t stream);
 int sc_align_filter_enabled();
 
 // out_ring_d2 (optional): also write the squared ring-key distance (nanoflann metric) of every scored

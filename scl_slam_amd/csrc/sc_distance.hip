@@ -123,11 +123,12 @@ __global__ __launch_bounds__(MAXT) void sc_distance_kernel(ScArgs a)
     for (int c = threadIdx.x; c < S; c += blockDim.x) { nq[c] = a.q_norm[c]; vq[c] = a.q_vkey[c]; }
 
     const int per_iter = gridDim.x * a.G;
-    const int iters = (a.n + per_iter - 1) / per_iter;
+    const int n_cand = a.n_dev ? *a.n_dev : a.n;          // survivors of the screening pass: counted on the device
+    const int iters = (n_cand + per_iter - 1) / per_iter;
     for (int it = 0; it < iters; ++it) {
         const int ci = (it * gridDim.x + blockIdx.x) * a.G + g;
         int slot = -1;
-        if (ci < a.n) slot = a.cand ? a.cand[ci] : a.slot_base + ci;
+        if (ci < n_cand) slot = a.cand ? a.cand[ci] : a.slot_base + ci;
         const bool valid = slot >= 0;
         const size_t sl = valid ? (size_t)slot : 0;
 
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(MAXT) void sc_distance_kernel(ScArgs a)
         }
         if (wv == 0) {
             wave_argmin(dmin, smin);
-            if (j == 0 && ci < a.n) {
+            if (j == 0 && ci < n_cand) {
                 const bool ok = valid && (dmin < kBigDist);
                 a.out_dist[ci] = ok ? dmin : kBigDist;
                 a.out_shift[ci] = ok ? smin : 0;
@@ -1212,6 +1213,34 @@ __global__ void argmin_kernel(const double *dist, const int *shift, int n, doubl
     }
 }
 
+// arg-min over the exact distances of a survivor list (count on the device); out3[1] = the winner's slot relative to
+// slot_base (ties -> lowest position = lowest slot: the list is ascending)
+__global__ void argmin_survivors_kernel(const double *dist, const int *shift, const int *n_dev, const int *cand, int slot_base, double *out3)
+{
+    __shared__ double sv[16];
+    __shared__ int si[16];
+    const int n = *n_dev;
+    double best = __longlong_as_double(0x7ff0000000000000LL);
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double d = dist[i];
+        if (d < kBigDist && ((d < best) | ((d == best) & (i < bi)))) { best = d; bi = i; }
+    }
+    wave_argmin(best, bi);
+    const int wv = threadIdx.x / kWave;
+    if ((threadIdx.x & (kWave - 1)) == 0) { sv[wv] = best; si[wv] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = blockDim.x / kWave;
+        for (int w = 1; w < nw; ++w)
+            if ((sv[w] < best) | ((sv[w] == best) & (si[w] < bi))) { best = sv[w]; bi = si[w]; }
+        const bool ok = best < kBigDist;
+        out3[0] = ok ? best : kBigDist;
+        out3[1] = ok ? (double)(cand[bi] - slot_base) : -1.0;
+        out3[2] = ok ? (double)shift[bi] : 0.0;
+    }
+}
+
 template <int RG, int W, int MAXT>
 hipError_t launch_fast(const ScArgs &args_in, int num_cu, hipStream_t stream)
 {
@@ -1394,6 +1423,30 @@ hipError_t launch_sc_distance_survivors(const DbView &db, const SurvivorPass &sp
     (void)num_cu;
     hipLaunchKernelGGL((sc_distance_survivors_kernel<RG, W, CH, S, MAXT>), dim3(sp.nq * kSurvivorBlocks), dim3(waves * kWave), lds, stream,
                        reinterpret_cast<const ScArgs *>(sp.d_args), kSurvivorBlocks);
+    return hipGetLastError();
+}
+
+// 80 x 180: exact distances of the survivor list by the one-sector-per-lane kernel, then the arg-min (two launches)
+hipError_t launch_sc_distance_survivors_wide(const DbView &db, int query_slot, int slot_base, int range_n, int SR, const int *survivors,
+                                             const int *n_surv, double *out_dist, int *out_shift, double *out3, int num_cu, hipStream_t stream)
+{
+    if (!(db.RG == 20 && db.S == 180 && SR == 9)) return hipErrorInvalidValue;
+    ScArgs a{};
+    const size_t slot = (size_t)query_slot;
+    a.desc = db.desc; a.vkey = db.vkey; a.norm = db.norm;
+    a.q_desc = db.desc + slot * (size_t)(db.RG * db.S); a.q_vkey = db.vkey + slot * db.S; a.q_norm = db.norm + slot * db.S;
+    a.q_rkey = db.rkey + slot * (size_t)(4 * db.RG);
+    a.cand = survivors; a.slot_base = slot_base; a.n = range_n < 256 ? range_n : 256;   // sizes the launch; the kernel loops over *n_dev
+    a.n_dev = n_surv; a.approx = nullptr; a.t_min = nullptr; a.range_n = 0; a.two_eps = 0.f;
+    a.ring_d2 = nullptr; a.sel_topk_idx = nullptr; a.sel_topk_d2 = nullptr; a.sel_topk_k = 0; a.sel_exclude_eps = 0.f;
+    a.S = db.S; a.SR = SR; a.NW = (db.S + kWave - 1) / kWave; a.G = 1;
+    a.ablate = 0; a.align_filter = 0; a.stamps = nullptr;
+    a.rkey4 = db.rkey4; a.rk_cap = db.cap; a.out_d2 = nullptr;
+    a.blk_part = nullptr; a.done_counter = nullptr; a.out3 = nullptr; a.topk_idx = nullptr; a.topk_d2 = nullptr; a.topk_k = 0; a.exclude_eps = 0.f;
+    a.out_dist = out_dist; a.out_shift = out_shift;
+    hipError_t e = launch_fast<20, 19, 256>(a, num_cu, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(argmin_survivors_kernel, dim3(1), dim3(1024), 0, stream, out_dist, out_shift, n_surv, survivors, slot_base, out3);
     return hipGetLastError();
 }
 

@@ -432,6 +432,274 @@ __global__ __launch_bounds__(kScreenWaves * kWave, OCC) void sc_screen_kernel(Sc
     if (wave == 0 && lane == 0 && run_min < __int_as_float(0x7f800000)) atomicMin(a.t_min, float_to_ordered_u(run_min));
 }
 
+// =====================================================================================================================
+// The same pass for grids whose sector count is not a multiple of 8 or whose search window exceeds 16 shifts
+// (80 x 180, search ratio 0.1: W = 19): k-steps of 8 sectors with the last one partly empty (B fragment zero, no load),
+// two M tiles of shift rows, every ring group's k-steps fully unrolled (23 per row has no common divisor with the load
+// ring), and an exact fp64 alignment with three shifts per lane (the two-sectors-per-lane filter of the narrow grids
+// needs S / 2 <= 64).  Error budget as above (K = R * S = 14 400 products per shift: the accumulation term grows to
+// 3 604 * 2^-23 = 4.3e-4, still inside kScreenEps).
+// =====================================================================================================================
+template <int S>
+__device__ __forceinline__ int align_keyframe_wide(const double (&vk)[(S + kWave - 1) / kWave], int lane, double *vk2, const double *vq)
+{
+    constexpr int SPL = (S + kWave - 1) / kWave;           // shifts (and sectors) per lane
+    constexpr int LA = S / SPL;                            // active lanes
+    static_assert(S % SPL == 0 && LA <= kWave, "shifts must tile the lanes");
+    const double kInf = __longlong_as_double(0x7ff0000000000000LL);
+    wave_fence();
+    if (lane < LA) {
+#pragma unroll
+        for (int u = 0; u < SPL; ++u) { vk2[SPL * lane + u] = vk[u]; vk2[SPL * lane + u + S] = vk[u]; }
+    }
+    if (lane == 0) { vk2[2 * S] = vk[0]; }                 // one past the doubled key: read by the last slide, never used
+    wave_fence();
+    // lane owns shifts s_k = SPL * lane + k; the key shifted by s at sector t is vk[(t - s) mod S] = p[t - k], p = vk2 + S - SPL * lane
+    const int ll = lane < LA ? lane : LA - 1;
+    const double *p = vk2 + S - SPL * ll;
+    double ss[SPL], w[SPL];
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) { ss[k] = 0.0; w[k] = p[-k]; }
+#pragma unroll 4
+    for (int t = 0; t < S; ++t) {                          // sector order, as the reference's norm (D.h:1500-1502)
+        const double q = vq[t];
+        const double nxt = p[t + 1];
+#pragma unroll
+        for (int k = 0; k < SPL; ++k) { const double d = q - w[k]; ss[k] = ss[k] + d * d; }
+#pragma unroll
+        for (int k = SPL - 1; k > 0; --k) w[k] = w[k - 1];
+        w[0] = nxt;
+    }
+    double best = kInf;
+    int bshift = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {                        // ascending shifts, strict <: ties keep the lower shift
+        const double nk = sqrt(ss[k]);
+        if (lane < LA && nk < kBigDist && nk < best) { best = nk; bshift = SPL * lane + k; }
+    }
+    wave_argmin_dpp(best, bshift);
+    return __builtin_amdgcn_readfirstlane(best < kBigDist ? bshift : 0);
+}
+
+template <int RG, int S, int W, int D>
+__global__ __launch_bounds__(kScreenWaves * kWave, 2) void sc_screen_wide_kernel(ScreenBatchArgs ab)
+{
+    constexpr int NWV = kScreenWaves;
+    constexpr int RPW = RG / NWV;
+    constexpr int NXB = (S + 7) / 8;                       // k-steps per ring group; the last one may be partly empty
+    constexpr int MT = (W + 15) / 16;                      // M tiles of 16 shift rows
+    constexpr int QSX = NXB * 8 + 16 * MT;                 // query row: sectors, padding to the k-step grid, the wrap
+    constexpr int SPL = (S + kWave - 1) / kWave;
+    constexpr int NKS = RPW * NXB;
+    static_assert(RG % NWV == 0 && D <= NXB && RG <= kWave, "tiling");
+
+    const int nbk = ab.nb;
+    const int qi = ab.nq > 1 ? (int)blockIdx.x / nbk : 0;
+    const int bid = (int)blockIdx.x - qi * nbk;
+    const ScreenArgs &a = ab.q[qi];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int SR = (W - 1) / 2;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    _Float16 *Qh = reinterpret_cast<_Float16 *>(smem_raw);                       // [RG + 1][QSX][4]
+    double *vq = reinterpret_cast<double *>(Qh + (size_t)(RG + 1) * QSX * 4);    // [S]
+    constexpr int kAlignDoubles = (2 * S + 2 + 1) & ~1;
+    double *vk2 = vq + S + (size_t)wave * kAlignDoubles;                         // per wave: the doubled sector key
+    f4v *part = reinterpret_cast<f4v *>(vq + S + (size_t)NWV * kAlignDoubles);   // [MT][NWV][64]
+    f4v *npart = part + MT * NWV * kWave;                                        // [MT][64]
+    int *s_start = reinterpret_cast<int *>(npart + MT * kWave);                  // [16]
+    int *bad_flag = s_start + kGroup;
+    int *q_bad_flag = bad_flag + kGroup;
+
+    if (threadIdx.x == 0) *q_bad_flag = 0;
+    for (int i = threadIdx.x; i < kGroup; i += blockDim.x) bad_flag[i] = 0;
+    for (int i = threadIdx.x; i < (RG + 1) * QSX; i += blockDim.x) {            // padding must be finite: B is zero there, 0 * x must stay 0
+        h4 z; z[0] = z[1] = z[2] = z[3] = (_Float16)0.0f;
+        *reinterpret_cast<h4 *>(Qh + (size_t)i * 4) = z;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < RG * S; idx += blockDim.x) {
+        const int rg = idx / S, c = idx - rg * S;
+        const float4 v = a.q_desc[idx];
+        const float iv = a.q_inv[c];
+        if (iv != iv) *q_bad_flag = 1;
+        h4 hv;
+        hv[0] = (_Float16)(v.x * iv); hv[1] = (_Float16)(v.y * iv); hv[2] = (_Float16)(v.z * iv); hv[3] = (_Float16)(v.w * iv);
+        *reinterpret_cast<h4 *>(Qh + ((size_t)rg * QSX + c) * 4) = hv;
+        if (c + S < QSX) *reinterpret_cast<h4 *>(Qh + ((size_t)rg * QSX + c + S) * 4) = hv;
+    }
+    for (int c = threadIdx.x; c < S; c += blockDim.x) {
+        h4 ind; ind[0] = (_Float16)(a.q_inv[c] != 0.0f ? 1.0f : 0.0f); ind[1] = ind[2] = ind[3] = (_Float16)0.0f;
+        *reinterpret_cast<h4 *>(Qh + ((size_t)RG * QSX + c) * 4) = ind;
+        if (c + S < QSX) *reinterpret_cast<h4 *>(Qh + ((size_t)RG * QSX + c + S) * 4) = ind;
+        vq[c] = a.q_vkey[c];
+    }
+    __syncthreads();
+    const bool q_bad = *q_bad_flag != 0;
+
+    float4 qrk = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < RG) qrk = *reinterpret_cast<const float4 *>(a.q_rkey + 4 * lane);
+    const int n16 = lane & 15, j4 = lane >> 4;
+    const int ngroups = (a.n + kGroup - 1) / kGroup;
+    float run_min = __int_as_float(0x7f800000);
+    constexpr int LA = S / SPL;
+    const int la = lane < LA ? lane : LA - 1;
+
+    for (int g = bid; g < ngroups; g += nbk) {
+        const int c_base = g * kGroup;
+        // ---- phase A: exact alignment of keyframes 4w .. 4w+3 (three shifts per lane) + their ring-key metric ----
+        auto fetch = [&](int u, double (&vk_o)[SPL], float4 &rk_o) {
+            const int ci = c_base + wave * (kGroup / NWV) + u;
+            const int slot = a.slot_base + (ci < a.n ? ci : a.n - 1);
+#pragma unroll
+            for (int k = 0; k < SPL; ++k) vk_o[k] = a.vkey[(size_t)slot * S + SPL * la + k];
+            rk_o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lane < RG) rk_o = a.rkey4[(size_t)lane * a.rk_cap + slot];
+        };
+        double vk_cur[SPL]; float4 rk_cur;
+        fetch(0, vk_cur, rk_cur);
+#pragma unroll 1
+        for (int u = 0; u < kGroup / NWV; ++u) {
+            const int ci = c_base + wave * (kGroup / NWV) + u;
+            double vk_nxt[SPL]; float4 rk_nxt = rk_cur;
+#pragma unroll
+            for (int k = 0; k < SPL; ++k) vk_nxt[k] = vk_cur[k];
+            if (u + 1 < kGroup / NWV) fetch(u + 1, vk_nxt, rk_nxt);
+            const int al = align_keyframe_wide<S>(vk_cur, lane, vk2, vq);
+            if (lane == 0) s_start[wave * (kGroup / NWV) + u] = wrapS(al - SR, S);
+            float grp = 0.0f;
+            if (lane < RG) {
+                const float4 b = rk_cur;
+                const float d0 = qrk.x - b.x, d1 = qrk.y - b.y, d2 = qrk.z - b.z, d3 = qrk.w - b.w;
+                grp = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            }
+            float result = 0.0f;
+#pragma unroll
+            for (int r = 0; r < RG; ++r) result += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(grp), r));
+            if (lane == 0 && ci < a.n) a.out_d2[ci] = result;
+#pragma unroll
+            for (int k = 0; k < SPL; ++k) vk_cur[k] = vk_nxt[k];
+            rk_cur = rk_nxt;
+        }
+        __syncthreads();                                                         // B1
+
+        // ---- phase G ------------------------------------------------------------------------------------------------
+        const int ci_n = c_base + n16;
+        const int slot_n = a.slot_base + (ci_n < a.n ? ci_n : a.n - 1);
+        const int b_n = s_start[n16];
+        const int col0 = wrapS(2 * j4 - b_n, S);
+        const int first_slot = a.slot_base + c_base;
+        const unsigned int rel_n = (unsigned int)(slot_n - first_slot);
+        const char *inv_base = reinterpret_cast<const char *>(a.inv + (size_t)first_slot * S);
+        const unsigned int inv_off = rel_n * (unsigned int)(S * 4);
+        auto col_of = [&](int xb) { int c = col0 + 8 * xb; return c >= S ? c - S : c; };   // col0 < S, 8 xb < S
+        auto in_grid = [&](int xb, int e) { return 8 * xb + 2 * j4 + e < S; };            // the last k-step is partly empty
+        float iv0[NXB], iv1[NXB];
+        bool bad = false;
+#pragma unroll
+        for (int xb = 0; xb < NXB; ++xb) {
+            const int c = col_of(xb), c1 = c + 1 == S ? 0 : c + 1;
+            iv0[xb] = in_grid(xb, 0) ? *reinterpret_cast<const float *>(inv_base + (inv_off + (unsigned int)c * 4u)) : 0.0f;
+            iv1[xb] = in_grid(xb, 1) ? *reinterpret_cast<const float *>(inv_base + (inv_off + (unsigned int)c1 * 4u)) : 0.0f;
+        }
+#pragma unroll
+        for (int xb = 0; xb < NXB; ++xb) bad |= (iv0[xb] != iv0[xb]) | (iv1[xb] != iv1[xb]);
+        if (bad) bad_flag[n16] = 1;
+        const char *desc_base = reinterpret_cast<const char *>(a.desc + (size_t)first_slot * (RG * S) + (size_t)(wave * RPW) * S);
+        const unsigned int desc_off = rel_n * (unsigned int)(RG * S * 16);
+        float4 ra[D], rb[D];
+        auto issue = [&](int sl, int r_i, int xb_i) {      // r_i, xb_i are compile-time after unrolling
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            const unsigned int row = desc_off + (unsigned int)r_i * (unsigned int)(S * 16);
+            const int c = col_of(xb_i), c1 = c + 1 == S ? 0 : c + 1;
+            ra[sl] = in_grid(xb_i, 0) ? *reinterpret_cast<const float4 *>(desc_base + (row + (unsigned int)c * 16u)) : z;
+            rb[sl] = in_grid(xb_i, 1) ? *reinterpret_cast<const float4 *>(desc_base + (row + (unsigned int)c1 * 16u)) : z;
+        };
+#pragma unroll
+        for (int sl = 0; sl < D; ++sl) issue(sl, sl / NXB, sl % NXB);
+        f4v acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = f4v{0.f, 0.f, 0.f, 0.f};
+        const _Float16 *qbase = Qh + ((size_t)(wave * RPW) * QSX + 2 * j4 + n16) * 4;
+        auto load_a = [&](const _Float16 *ap) -> h8 {
+            const h4 alo = *reinterpret_cast<const h4 *>(ap), ahi = *reinterpret_cast<const h4 *>(ap + 4);
+            return __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int r = ks / NXB, xb = ks % NXB, sl = ks % D;
+            const float4 u = ra[sl], v = rb[sl];
+            if (ks + D < NKS) issue(sl, (ks + D) / NXB, (ks + D) % NXB);
+            h8 bfrag;
+            bfrag[0] = (_Float16)(u.x * iv0[xb]); bfrag[1] = (_Float16)(u.y * iv0[xb]);
+            bfrag[2] = (_Float16)(u.z * iv0[xb]); bfrag[3] = (_Float16)(u.w * iv0[xb]);
+            bfrag[4] = (_Float16)(v.x * iv1[xb]); bfrag[5] = (_Float16)(v.y * iv1[xb]);
+            bfrag[6] = (_Float16)(v.z * iv1[xb]); bfrag[7] = (_Float16)(v.w * iv1[xb]);
+            const _Float16 *ap = qbase + ((size_t)r * QSX + 8 * xb) * 4;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const h8 afrag = load_a(ap + (size_t)(16 * m) * 4);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag, acc[m], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) part[(m * NWV + wave) * kWave + lane] = acc[m];
+        if (wave == 1 % NWV) {
+            f4v nacc[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) nacc[m] = f4v{0.f, 0.f, 0.f, 0.f};
+            const _Float16 *irow = Qh + ((size_t)RG * QSX + 2 * j4 + n16) * 4;
+#pragma unroll
+            for (int xb = 0; xb < NXB; ++xb) {
+                h8 bfrag;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bfrag[e] = (_Float16)0.0f;
+                bfrag[0] = (_Float16)(iv0[xb] != 0.0f ? 1.0f : 0.0f);
+                bfrag[4] = (_Float16)(iv1[xb] != 0.0f ? 1.0f : 0.0f);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const h8 afrag = load_a(irow + (size_t)(8 * xb + 16 * m) * 4);
+                    nacc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag, nacc[m], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) npart[m * kWave + lane] = nacc[m];
+        }
+        __syncthreads();                                                         // B2
+
+        if (wave == 0) {
+            float dmin = __int_as_float(0x7f800000);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                f4v s = part[(m * NWV) * kWave + lane];
+#pragma unroll
+                for (int w = 1; w < NWV; ++w) s += part[(m * NWV + w) * kWave + lane];
+                const f4v ne = npart[m * kWave + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = 16 * m + 4 * j4 + r;
+                    const float d = 1.0f - s[r] / ne[r];
+                    if (t < W && ne[r] > 0.5f && d < dmin) dmin = d;
+                }
+            }
+            dmin = fminf(dmin, __shfl_xor(dmin, 16, kWave));
+            dmin = fminf(dmin, __shfl_xor(dmin, 32, kWave));
+            const bool mine = lane < kGroup && ci_n < a.n;
+            const bool exact_only = q_bad || bad_flag[n16] != 0 || !(dmin == dmin);
+            if (mine) a.out_approx[ci_n] = exact_only ? __int_as_float(0xff800000) : dmin;
+            float contrib = (mine && !exact_only) ? dmin : __int_as_float(0x7f800000);
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) contrib = fminf(contrib, __shfl_xor(contrib, off, kWave));
+            run_min = fminf(run_min, __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(contrib))));
+            if (lane < kGroup) bad_flag[lane] = 0;
+        }
+    }
+    if (wave == 0 && lane == 0 && run_min < __int_as_float(0x7f800000)) atomicMin(a.t_min, float_to_ordered_u(run_min));
+}
+
 // ---- select: survivors of the screening (ascending slot order) + the ring-key top-k ----------------------------
 // One workgroup per query.  survivors[i] = database slots (ascending) whose d~ <= min d~ + 2 eps, or flagged
 // "score exactly"; *n_surv their number.  Also the k nearest ring keys from the metric the screening pass produced
@@ -509,8 +777,11 @@ __global__ __launch_bounds__(1024) void sc_select_kernel(SelectBatchArgs sb)
 bool sc_screen_supported(const DbView &db, int SR)
 {
     static const bool off = [] { const char *e = getenv("SCL_SCREEN"); return e && e[0] == '0'; }();
-    return !off && db.RG == 16 && db.R == 64 && db.S == 120 && SR == 6;
+    if (off) return false;
+    return (db.RG == 16 && db.R == 64 && db.S == 120 && SR == 6) || sc_screen_is_wide(db, SR);
 }
+
+bool sc_screen_is_wide(const DbView &db, int SR) { return db.RG == 20 && db.R == 80 && db.S == 180 && SR == 9; }
 
 float sc_screen_eps() { return kScreenEps; }
 
@@ -532,6 +803,7 @@ hipError_t launch_sc_select_batch(const ScreenBatch &sb, hipStream_t stream)
 hipError_t launch_sc_screen_batch(const DbView &db, const ScreenBatch &sb, int SR, int align_filter, int num_cu, hipStream_t stream)
 {
     if (sb.nq < 1 || sb.nq > kMaxQueryBatch || !sc_screen_supported(db, SR)) return hipErrorInvalidValue;
+    const bool wide = sc_screen_is_wide(db, SR);
     constexpr int RG = 16, S = 120, W = 13;
     ScreenBatchArgs ab{};
     ab.nq = sb.nq;
@@ -550,11 +822,31 @@ hipError_t launch_sc_screen_batch(const DbView &db, const ScreenBatch &sb, int S
         nmax = sb.n[i] > nmax ? sb.n[i] : nmax;
     }
     for (int i = sb.nq; i < kMaxQueryBatch; ++i) ab.q[i] = ab.q[0];
+    const int ngroups = (nmax + kGroup - 1) / kGroup;
+    if (wide) {
+        constexpr int RGw = 20, Sw = 180, Ww = 19, Dw = 5;
+        constexpr int NXB = (Sw + 7) / 8, MT = (Ww + 15) / 16, QSXw = NXB * 8 + 16 * MT, kAlignDoubles = (2 * Sw + 2 + 1) & ~1;
+        const size_t ldsw = (size_t)(RGw + 1) * QSXw * 4 * 2 + (size_t)Sw * 8 + (size_t)kScreenWaves * kAlignDoubles * 8 +
+                            (size_t)MT * (kScreenWaves + 1) * kWave * 16 + (size_t)(2 * kGroup + 4) * 4;
+        int blocks = num_cu * 2;
+        if (blocks > ngroups) blocks = ngroups;
+        if (blocks > kScreenMaxBlocks) blocks = kScreenMaxBlocks;
+        ab.nb = blocks;
+        static std::atomic<bool> attr_set_dev[64];
+        int dev_ = 0; (void)hipGetDevice(&dev_);
+        std::atomic<bool> &attr_set = attr_set_dev[dev_ & 63];
+        if (!attr_set.load(std::memory_order_acquire)) {
+            hipError_t e = hipFuncSetAttribute((const void *)sc_screen_wide_kernel<RGw, Sw, Ww, Dw>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_set.store(true, std::memory_order_release);
+        }
+        hipLaunchKernelGGL((sc_screen_wide_kernel<RGw, Sw, Ww, Dw>), dim3(blocks * sb.nq), dim3(kScreenWaves * kWave), ldsw, stream, ab);
+        return hipGetLastError();
+    }
     constexpr int QSX = S + 16, PFS = 288;
     constexpr int kAlignStride = ((2 * S * 8 + (PFS + 2 * S + 8) * 4) + 15) & ~15;
     const size_t lds = (size_t)(RG + 1) * QSX * 4 * 2 + (size_t)S * 8 + (size_t)S * 4 * 2 + (size_t)kScreenWaves * kAlignStride +
                        (size_t)(kScreenWaves + 1) * kWave * 16 + (size_t)(2 * kGroup + 4) * 4;
-    const int ngroups = (nmax + kGroup - 1) / kGroup;
     // variants (SCL_SCREEN_VARIANT): 0 = 5 k-steps in flight, 2 waves/SIMD; 1 = 3 in flight, 3 waves/SIMD; 2 = 5 in flight, 3 waves/SIMD
     static const int variant = [] { const char *e = getenv("SCL_SCREEN_VARIANT"); return e ? atoi(e) : 0; }();
     const int occ = variant == 0 ? 2 : 3;

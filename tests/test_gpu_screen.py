@@ -13,6 +13,34 @@ pytestmark = pytest.mark.gpu
 R, S = 64, 120
 
 
+def test_screening_on_the_80x180_grid():
+    """BASELINE configs[4]'s grid: W = 19 shifts (two M tiles), 23 k-steps per ring group with the last one partly empty,
+    exact three-shifts-per-lane alignment, exact pass by the one-sector-per-lane kernel"""
+    R2, S2, n = 80, 180, 1300
+    descs = synth_descriptors(n, R2, S2, seed=1005, revisit_frac=0.03)
+    rs = np.random.RandomState(2)
+    descs[40] = 0.0; descs[41][:, ::3] = 0.0; descs[42] = descs[n - 1] * np.float32(1e25); descs[43][5, 7] = np.nan
+    for i, mag in enumerate([0.0, 1e-6, 1e-4, 1e-3, 3e-3]):
+        d = np.roll(descs[n - 1], int(rs.randint(0, S2)), axis=1)
+        descs[60 + 9 * i] = np.clip(d + mag * rs.standard_normal(d.shape).astype(np.float32) * (d > 0), 0, None)
+    eng = ScanContextEngine(num_ring=R2, num_sector=S2, initial_capacity=n)
+    db = ob.OracleDB(ob.make_config(R=R2, S=S2))
+    eng.save_bulk(descs); db.save_bulk(descs)
+    worst = 0.0
+    for q, lo, hi in ((n - 1, 0, n - 100), (n - 2, 3, n - 101), (700, 0, 600), (n - 3, 0, 17), (40, 0, 300), (42, 0, 200)):
+        e, m = _check(eng, db, q, lo, hi)
+        worst = max(worst, e)
+    print(f"screening 80x180: worst |d~ - d| = {worst:.3e}")
+    assert worst < 3e-4
+    # the stream / batched forms go through the same path one query at a time
+    qs = np.arange(n - 1, n - 9, -1, dtype=np.int32)
+    nn, sh, dd = eng.detect_full_stream(qs, 0, qs - 100, 4, 2)
+    for i, q in enumerate(qs):
+        o = db.detect_full(int(q))
+        assert (nn[i], sh[i]) == (o[1], o[2]) and dd[i].view(np.uint64) == np.float64(o[3]).view(np.uint64)
+    eng.close()
+
+
 def _check(eng, db, query, lo, hi):
     approx, surv, eps = eng.screen_distances(query, lo, hi)
     d_ref, s_ref = db.distance_batch(query, cand=np.arange(lo, hi, dtype=np.int32))
