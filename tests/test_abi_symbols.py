@@ -6,7 +6,7 @@ import re
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADERS = [os.path.join(ROOT, "include", "scl_engine.h"), os.path.join(ROOT, "include", "scl_messages.h")]
+HEADERS = [os.path.join(ROOT, "include", h) for h in ("scl_engine.h", "scl_messages.h", "scl_iris.h")]
 
 
 def declared_symbols():
@@ -68,7 +68,7 @@ def test_header_is_plain_c99(tmp_path):
     if not shutil.which("gcc"):
         pytest.skip("no gcc")
     src = tmp_path / "cabi.c"
-    src.write_text('#include "scl_engine.h"\n#include "scl_messages.h"\nint main(void) { scl_config c; scl_icp_params p; (void)p; return scl_default_config(&c) == SCL_OK ? 0 : 1; }\n')
+    src.write_text('#include "scl_engine.h"\n#include "scl_messages.h"\n#include "scl_iris.h"\nint main(void) { scl_config c; scl_icp_params p; (void)p; return scl_default_config(&c) == SCL_OK ? 0 : 1; }\n')
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
                         "-fsyntax-only", str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
