@@ -82,13 +82,14 @@ __global__ void make_sc_finalize_kernel(const int *gtile, int cells, float *valu
 // One workgroup per descriptor.  values: [count][R*S] row-major floats.
 __global__ __launch_bounds__(256) void ingest_kernel(
     const float *values, int first_slot, float4 *desc, double *vkey, double *norm,
-    float *rkey, float4 *rkey4, float *inv, int cap, int R, int S)
+    float *rkey, float4 *rkey4, float *inv, uint2 *hdesc, unsigned int *kmask, int hstride, int cap, int R, int S)
 {
-    extern __shared__ float sv[];                 // [R][S+1]
+    extern __shared__ float sv[];                 // [R][S+1], then the S reciprocal norms
     const int LS = S + 1;                         // odd-ish stride: column walks hit distinct banks
     const int RG = (R + 3) >> 2;
     const int slot = first_slot + blockIdx.x;
     const float *src = values + (size_t)blockIdx.x * R * S;
+    float *siv = sv + R * LS;
     for (int i = threadIdx.x; i < R * S; i += blockDim.x) {
         const int r = i / S, c = i - r * S;
         sv[r * LS + c] = src[i];
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(
         if (nrm == 0.0) iv = 0.0f;
         else if (nrm >= 0x1p-60 && nrm <= 0x1p60) iv = (float)(1.0 / nrm);
         inv[(size_t)slot * S + c] = iv;
+        siv[c] = iv;
     }
     // ring key (row mean narrowed to float, D.h:1468-1472), sequential over sectors
     for (int r = threadIdx.x; r < 4 * RG; r += blockDim.x) {
@@ -134,6 +136,33 @@ __global__ __launch_bounds__(256) void ingest_kernel(
         }
         rkey[(size_t)slot * 4 * RG + r] = key;
         if (rkey4) reinterpret_cast<float *>(rkey4)[((size_t)(r >> 2) * cap + slot) * 4 + (r & 3)] = key;   // nullptr: staging slot
+    }
+    // the screening pass's copy (sc_screen.hip): x * inv in fp32, rounded to nearest fp16; sector-major
+    __syncthreads();
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h4 *hslot = reinterpret_cast<h4 *>(hdesc + (size_t)slot * hstride);
+    for (int i = threadIdx.x; i < S * RG; i += blockDim.x) {
+        const int c = i / RG, rg = i - c * RG;
+        const float iv = siv[c];
+        h4 hv;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = 4 * rg + k;
+            hv[k] = (_Float16)((r < R ? sv[r * LS + c] : 0.0f) * iv);
+        }
+        hslot[i] = hv;
+    }
+    if (threadIdx.x < 8) {
+        unsigned int w = 0;
+        if (threadIdx.x < 7) {
+            for (int b = 0; b < 32; ++b) {
+                const int c = 32 * (int)threadIdx.x + b;
+                if (c < S && siv[c] != 0.0f) w |= 1u << b;               // NaN counts as non-zero
+            }
+        } else {
+            for (int c = 0; c < S; ++c) if (siv[c] != siv[c]) w = 1u;
+        }
+        kmask[(size_t)slot * 8 + threadIdx.x] = w;
     }
 }
 
@@ -172,10 +201,12 @@ hipError_t launch_make_sc(const void *points, int n, int stride_bytes, int R, in
 
 hipError_t launch_ingest(const float *values, int count, int first_slot,
                          float4 *desc, double *vkey, double *norm, float *rkey, float4 *rkey4, float *inv,
+                         uint2 *hdesc, unsigned int *kmask, int hstride,
                          int cap, int R, int S, hipStream_t stream)
 {
     if (count <= 0) return hipSuccess;
-    const size_t lds = sizeof(float) * (size_t)R * (S + 1);
+    if (S > 224) return hipErrorInvalidValue;              // kmask holds 7 words of sector bits
+    const size_t lds = sizeof(float) * ((size_t)R * (S + 1) + S);
     static std::atomic<bool> attr_set_dev[64];   // per device; engines on different threads may race here: atomic flag,
     int dev_ = 0; (void)hipGetDevice(&dev_);     // and setting the attribute twice is harmless
     std::atomic<bool> &attr_set = attr_set_dev[dev_ & 63];
@@ -186,7 +217,7 @@ hipError_t launch_ingest(const float *values, int count, int first_slot,
         attr_set.store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(ingest_kernel, dim3(count), dim3(256), lds, stream,
-                       values, first_slot, desc, vkey, norm, rkey, rkey4, inv, cap, R, S);
+                       values, first_slot, desc, vkey, norm, rkey, rkey4, inv, hdesc, kmask, hstride, cap, R, S);
     return hipGetLastError();
 }
 

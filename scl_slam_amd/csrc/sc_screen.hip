@@ -29,6 +29,7 @@
 // a ring of D k-steps; the A fragment is 16 bytes of the fp16 query in LDS.  Partial sums meet in LDS, wave 0
 // finishes.  Bound: HBM (4 R S + 8 S + 4 S bytes per keyframe actually read; SURVEY 8(d) counts 4 R S + 8 S).
 #include <atomic>
+#include <type_traits>
 
 #include "device_common.hpp"
 #include "kernels.hpp"
@@ -41,10 +42,14 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 __attribute__((aligned(8))) u32x4_a8;   // 16 B at an 8-byte boundary (hdesc windows start at any sector)
 
 struct ScreenArgs {
     const float4 *desc; const double *vkey; const float *inv;
+    const uint2 *hdesc; const unsigned int *kmask;
     const float4 *q_desc; const double *q_vkey; const float *q_inv; const float *q_rkey;
+    const uint2 *q_hdesc; const unsigned int *q_kmask;
     const float4 *rkey4; int rk_cap;
     int slot_base, n;
     float *out_approx;        // [n] d~ ; -inf = must be scored exactly, +inf = no finite distance
@@ -190,20 +195,30 @@ __device__ __forceinline__ int align_keyframe(const double2 vk, int lane, bool u
 constexpr float kScreenEps = 1.5e-3f;          // see the error budget at the top of this file
 constexpr int kScreenWaves = 4;
 constexpr int kGroup = 16;                     // keyframes per matrix product (the MFMA's N)
+constexpr int kTileStride = 96;                // bytes per keyframe in a wave's transposition tile (32 fp16 + 32 B of padding: conflict-free reads)
 constexpr int kScreenMaxBlocks = 768;          // workgroups per query (3 per CU at most)
 
-// D = k-steps of loads in flight per wave; OCC = waves per SIMD the register allocation is held to
-// (3: 168 registers, three workgroups per CU; 2: 256 registers, two workgroups per CU)
-template <int RG, int S, int W, int D, int OCC>
+// D = k-steps of loads in flight per wave (1 KB each); OCC = waves per SIMD the register allocation is held to.
+// PROBE (diagnostic builds only, -DSCL_DIAGNOSTICS + SCL_SCREEN_PROBE): 1 = no alignment (first shift 0), 2 = no alignment and
+// no staging / MFMA (the loads are summed): what the access pattern alone costs, 3 = alignment only (no loads, no products),
+// 4 = neither.  Results are wrong on purpose.
+template <int RG, int S, int W, int D, int OCC, int PROBE = 0>
 __global__ __launch_bounds__(kScreenWaves * kWave, OCC) void sc_screen_kernel(ScreenBatchArgs ab)
 {
     constexpr int NWV = kScreenWaves;
     constexpr int RPW = RG / NWV;                      // ring groups per wave
-    constexpr int QSX = S + 16;                        // extended query row (sectors)
-    constexpr int NXB = S / 8;                         // k-steps per ring group (8 sectors x 4 rings = K 32)
+    constexpr int QSX = S + 16;                        // sectors of the extended query
+    constexpr int SB = RG * 8;                         // bytes of one sector in hdesc (all rings, fp16)
+    constexpr int KH = SB / 64;                        // k-steps per sector (32 rings = 64 B each)
+    constexpr int QST = SB + 32;                       // bytes of one sector of the staged query (the padding keeps the A reads conflict-free)
+    constexpr int HS = RG * S;                         // a keyframe's slot in hdesc (elements of 8 B)
+    constexpr int SPW = S / NWV;                       // query sectors per wave
+    constexpr int NROW = 4;                            // a wave's k-steps come in NROW runs of NXB (one alignment after each run)
+    constexpr int NXB = SPW * KH / NROW;               // k-steps per run
     constexpr int L = S >> 1;
     constexpr int PFS = 288;
-    static_assert(RG % NWV == 0 && S % 8 == 0 && NXB % D == 0 && W <= 16, "tiling");
+    static_assert(S % NWV == 0 && SB % 64 == 0 && (SPW * KH) % NROW == 0 && NXB % D == 0 && W <= 16 && S <= 128, "tiling");
+    static_assert(NROW == kGroup / NWV, "one alignment per run");
     static_assert(S / 2 <= kWave && S % 4 == 0, "alignment phase: two sectors per lane");
 
     const int nbk = ab.nb;
@@ -215,47 +230,44 @@ __global__ __launch_bounds__(kScreenWaves * kWave, OCC) void sc_screen_kernel(Sc
     const int SR = (W - 1) / 2;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    _Float16 *Qh = reinterpret_cast<_Float16 *>(smem_raw);                       // [RG + 1][QSX][4]
-    double *vq = reinterpret_cast<double *>(Qh + (size_t)(RG + 1) * QSX * 4);    // [S]
+    unsigned char *Qs = smem_raw;                                                // [QSX][QST]: sector-major fp16 query, 16 sectors repeated
+    uint4 *rotq = reinterpret_cast<uint4 *>(Qs + (size_t)QSX * QST);             // [S] the query's sector mask rotated right by s
+    double *vq = reinterpret_cast<double *>(rotq + S);                           // [S]
     float *vqf0 = reinterpret_cast<float *>(vq + S);                             // [S]
     float *vqf1 = vqf0 + S;                                                      // [S]
     constexpr int kAlignBytes = 2 * S * 8 + (PFS + 2 * S + 8) * 4;               // vk2 + the two fp32 key copies
-    constexpr int kAlignStride = (kAlignBytes + 15) & ~15;
+    constexpr int kTileOff = (kAlignBytes + 15) & ~15;                           // the wave's transposition tile follows
+    constexpr int kAlignStride = kTileOff + kGroup * kTileStride;
     unsigned char *wscratch = reinterpret_cast<unsigned char *>(vqf1 + S) + (size_t)wave * kAlignStride;
     double *vk2 = reinterpret_cast<double *>(wscratch);
     float *pf = reinterpret_cast<float *>(vk2 + 2 * S);
     unsigned char *shared_tail = reinterpret_cast<unsigned char *>(vqf1 + S) + (size_t)NWV * kAlignStride;
-    f4v *part = reinterpret_cast<f4v *>(shared_tail);                            // [NWV][64] partial sums
-    f4v *npart = part + NWV * kWave;                                             // [64] effective-sector counts
-    int *s_start = reinterpret_cast<int *>(npart + kWave);                       // [16]
-    int *bad_flag = s_start + kGroup;                                            // [16]
-    int *q_bad_flag = bad_flag + kGroup;                                         // [1]
+    f4v *part = reinterpret_cast<f4v *>(shared_tail);                            // [2][NWV][64] partial sums
+    int *s_start = reinterpret_cast<int *>(part + 2 * NWV * kWave);              // [2][16]
 
-    // ---- stage the query: unit columns in fp16, extended by 16 sectors; indicator row; sector-key copies ----
-    if (threadIdx.x == 0) *q_bad_flag = 0;
-    for (int i = threadIdx.x; i < kGroup; i += blockDim.x) bad_flag[i] = 0;
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < RG * S; idx += blockDim.x) {
-        const int rg = idx / S, c = idx - rg * S;
-        const float4 v = a.q_desc[idx];
-        const float iv = a.q_inv[c];
-        if (iv != iv) *q_bad_flag = 1;                                           // benign race: everyone writes 1
-        h4 hv;
-        hv[0] = (_Float16)(v.x * iv); hv[1] = (_Float16)(v.y * iv); hv[2] = (_Float16)(v.z * iv); hv[3] = (_Float16)(v.w * iv);
-        *reinterpret_cast<h4 *>(Qh + ((size_t)rg * QSX + c) * 4) = hv;
-        if (c < 16) *reinterpret_cast<h4 *>(Qh + ((size_t)rg * QSX + c + S) * 4) = hv;
+    // ---- stage the query: its fp16 unit columns extended by 16 sectors, its rotated sector masks, sector-key copies ----
+    for (int idx = threadIdx.x; idx < QSX * (SB / 16); idx += blockDim.x) {
+        const int cx = idx / (SB / 16), ch = idx - cx * (SB / 16);
+        const int c = cx < S ? cx : cx - S;
+        *reinterpret_cast<uint4 *>(Qs + (size_t)cx * QST + ch * 16) =
+            *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(a.q_hdesc) + (size_t)c * SB + ch * 16);
+    }
+    const uint4 qm4 = *reinterpret_cast<const uint4 *>(a.q_kmask);
+    const bool q_bad = a.q_kmask[7] != 0;
+    for (int sft = threadIdx.x; sft < S; sft += blockDim.x) {                    // bit x of rotq[s] = query sector (x + s) mod S
+        const unsigned __int128 m = ((unsigned __int128)qm4.w << 96) | ((unsigned __int128)qm4.z << 64) |
+                                    ((unsigned __int128)qm4.y << 32) | (unsigned __int128)qm4.x;
+        unsigned __int128 rr = (m >> sft) | (m << (S - sft));
+        if (S < 128) rr &= (((unsigned __int128)1) << (S & 127)) - 1;
+        rotq[sft] = make_uint4((unsigned int)rr, (unsigned int)(rr >> 32), (unsigned int)(rr >> 64), (unsigned int)(rr >> 96));
     }
     for (int c = threadIdx.x; c < S; c += blockDim.x) {
-        h4 ind; ind[0] = (_Float16)(a.q_inv[c] != 0.0f ? 1.0f : 0.0f); ind[1] = ind[2] = ind[3] = (_Float16)0.0f;
-        *reinterpret_cast<h4 *>(Qh + ((size_t)RG * QSX + c) * 4) = ind;
-        if (c < 16) *reinterpret_cast<h4 *>(Qh + ((size_t)RG * QSX + c + S) * 4) = ind;
         const double kv = a.q_vkey[c];
         vq[c] = kv;
         vqf0[c] = (float)kv;
         vqf1[c == 0 ? S - 1 : c - 1] = (float)kv;
     }
     __syncthreads();
-    const bool q_bad = *q_bad_flag != 0;
 
     const bool active = lane < L;
     const int ll = active ? lane : L - 1;
@@ -269,164 +281,176 @@ __global__ __launch_bounds__(kScreenWaves * kWave, OCC) void sc_screen_kernel(Sc
     float4 qrk = make_float4(0.f, 0.f, 0.f, 0.f);
     if (lane < RG) qrk = *reinterpret_cast<const float4 *>(a.q_rkey + 4 * lane);
 
-    const int n16 = lane & 15, j4 = lane >> 4;
+    const int n16 = lane & 15, j4 = lane >> 4;           // MFMA layout: lane = (keyframe n, k-chunk j)
+    const int n4 = lane >> 2, jl = lane & 3;             // load layout: four consecutive lanes = 64 consecutive bytes of keyframe n
     const int ngroups = (a.n + kGroup - 1) / kGroup;
     float run_min = __int_as_float(0x7f800000);                                  // wave 0: min d~ over screened keyframes
 
-    for (int g = bid; g < ngroups; g += nbk) {
-        const int c_base = g * kGroup;
-        // ---- phase A: this wave aligns keyframes 4w .. 4w+3 of the group (and forms their ring-key metric) ----
-        // (one keyframe at a time, the next one's sector key and ring key requested before the current one is aligned:
-        // four inlined copies of the alignment with every operand live at once do not fit the register file)
-        auto fetch = [&](int u, double2 &vk_o, float4 &rk_o) {
-            const int ci = c_base + wave * (kGroup / NWV) + u;
-            const int slot = a.slot_base + (ci < a.n ? ci : a.n - 1);
-            vk_o = *reinterpret_cast<const double2 *>(a.vkey + (size_t)slot * S + j0);
-            rk_o = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (lane < RG) rk_o = a.rkey4[(size_t)lane * a.rk_cap + slot];
-        };
+    // ---- phase A: a wave aligns keyframes 4w .. 4w+3 of a group (and forms their ring-key metric), one at a time: four
+    // inlined copies of the alignment with every operand live at once do not fit the register file.  Only the first group
+    // of a workgroup is aligned ahead of its products; every later one is aligned inside the previous group's phase G
+    // (one keyframe after each ring group's k-steps, while that phase's loads are in flight), its sector and ring key
+    // requested a ring group earlier.  First shifts and partial sums are double-buffered by group parity, so one barrier
+    // per group (B2) orders everything.
+    // (unconditional loads only: a load behind a branch makes the compiler's s_waitcnt counting give up on every load
+    // issued before it -- the k-loop then drains its ring)
+    auto fetch = [&](int cb, int u, double2 &vk_o, float4 &rk_o) {
+        const int ci = cb + wave * (kGroup / NWV) + u;
+        const int slot = a.slot_base + (ci < a.n ? ci : a.n - 1);
+        vk_o = *reinterpret_cast<const double2 *>(a.vkey + (size_t)slot * S + j0);
+        rk_o = a.rkey4[(size_t)(lane < RG ? lane : RG - 1) * a.rk_cap + slot];
+    };
+    auto align_one = [&](int cb, int u, int *starts, const double2 &vk_c, const float4 &rk_c) {
+        const int ci = cb + wave * (kGroup / NWV) + u;
+        const int al = (PROBE == 1 || PROBE == 2 || PROBE == 4) ? 0 : align_keyframe<S>(vk_c, lane, use_filter, qn2, vk2, pf, vq, vqf0, vqf1);
+        if (lane == 0) starts[wave * (kGroup / NWV) + u] = wrapS(al - SR, S);
+        // nanoflann's metric (nanoflann.hpp:383-408): four dimensions per step, fp32, groups accumulated in order
+        float grp = 0.0f;
+        if (lane < RG) {
+            const float4 b = rk_c;
+            const float d0 = qrk.x - b.x, d1 = qrk.y - b.y, d2 = qrk.z - b.z, d3 = qrk.w - b.w;
+            grp = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        }
+        float result = 0.0f;
+#pragma unroll
+        for (int r = 0; r < RG; ++r) result += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(grp), r));
+        if (lane == 0 && ci < a.n) a.out_d2[ci] = result;
+    };
+    if (bid < ngroups) {
         double2 vk_cur; float4 rk_cur;
-        fetch(0, vk_cur, rk_cur);
+        fetch(bid * kGroup, 0, vk_cur, rk_cur);
 #pragma unroll 1
         for (int u = 0; u < kGroup / NWV; ++u) {
-            const int ci = c_base + wave * (kGroup / NWV) + u;
             double2 vk_nxt = vk_cur; float4 rk_nxt = rk_cur;
-            if (u + 1 < kGroup / NWV) fetch(u + 1, vk_nxt, rk_nxt);
-            const int al = align_keyframe<S>(vk_cur, lane, use_filter, qn2, vk2, pf, vq, vqf0, vqf1);
-            if (lane == 0) s_start[wave * (kGroup / NWV) + u] = wrapS(al - SR, S);
-            // nanoflann's metric (nanoflann.hpp:383-408): four dimensions per step, fp32, groups accumulated in order
-            float grp = 0.0f;
-            if (lane < RG) {
-                const float4 b = rk_cur;
-                const float d0 = qrk.x - b.x, d1 = qrk.y - b.y, d2 = qrk.z - b.z, d3 = qrk.w - b.w;
-                grp = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-            }
-            float result = 0.0f;
-#pragma unroll
-            for (int r = 0; r < RG; ++r) result += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(grp), r));
-            if (lane == 0 && ci < a.n) a.out_d2[ci] = result;
+            if (u + 1 < kGroup / NWV) fetch(bid * kGroup, u + 1, vk_nxt, rk_nxt);
+            align_one(bid * kGroup, u, s_start, vk_cur, rk_cur);
             vk_cur = vk_nxt; rk_cur = rk_nxt;
         }
-        __syncthreads();                                                         // B1: the 16 first shifts are known
+    }
+    __syncthreads();                                                             // the first group's 16 first shifts are known
 
-        // ---- phase G: ring groups 4w .. 4w+3 of all 16 keyframes ------------------------------------------------
+    if (PROBE == 5 || PROBE == 6) {                      // stagger the workgroups' phases (diagnostic)
+        const int steps = PROBE == 5 ? (bid >= nbk / 2 ? 4 : 0) : (bid >= nbk / 2 ? 2 : 0) + (bid & 1);
+        for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(30);
+    }
+    int par = 0;
+    for (int g = bid; g < ngroups; g += nbk, par ^= 1) {
+        const int c_base = g * kGroup;
+        const int nxt_base = (g + nbk) * kGroup;
+        const bool has_next = g + nbk < ngroups;
+        int *s_cur = s_start + par * kGroup, *s_nxt = s_start + (par ^ 1) * kGroup;
+        f4v *part_cur = part + par * (NWV * kWave);
+
+        // ---- phase G: query sectors SPW*w .. SPW*w + SPW-1 against all 16 keyframes ---------------------------------
+        // hdesc is sector-major: the 64 rings of one sector are one 128-byte line, so the keyframe's ring shift is a
+        // rotation of whole lines, every line is fetched once, and a wave walks SPW consecutive lines of each keyframe.
+        // One k-step = 32 rings of one sector.  Load layout: lane 4n + j fetches rings 8j .. 8j+7 (16 B) of keyframe n, so
+        // four consecutive lanes read 64 consecutive bytes and one instruction is one k-step of all 16 keyframes.  (The
+        // texture path coalesces per group of four lanes: in the MFMA's own layout, keyframe = lane & 15, every such group
+        // touches four lines, which costs a quarter of the kernel.)  The step passes through a 1.5 KB tile of LDS owned by
+        // this wave and comes back in the MFMA's B layout, lane (n, j) = lane 16j + n.
         const int ci_n = c_base + n16;
-        const int slot_n = a.slot_base + (ci_n < a.n ? ci_n : a.n - 1);
-        const int b_n = s_start[n16];
-        const int col0 = wrapS(2 * j4 - b_n, S);                                 // keyframe column that meets query sector 2j at shift b
-        // Addresses = one wave-uniform 64-bit base per group + 32-bit per-lane byte offsets (the 16 keyframes of a group
-        // are consecutive slots: < 16 * 30 KB apart), so the 30 column addresses of a row cost 30 registers, not 60.
         const int first_slot = a.slot_base + c_base;
-        const unsigned int rel_n = (unsigned int)(slot_n - first_slot);
-        const char *inv_base = reinterpret_cast<const char *>(a.inv + (size_t)first_slot * S);
-        const unsigned int inv_off = rel_n * (unsigned int)(S * 4);
-        float iv0[NXB], iv1[NXB];
-        bool bad = false;
-        {
-            int c = col0;
-#pragma unroll
-            for (int xb = 0; xb < NXB; ++xb) {
-                const int c1 = c + 1 == S ? 0 : c + 1;
-                iv0[xb] = *reinterpret_cast<const float *>(inv_base + (inv_off + (unsigned int)c * 4u));
-                iv1[xb] = *reinterpret_cast<const float *>(inv_base + (inv_off + (unsigned int)c1 * 4u));
-                c += 8; c = c >= S ? c - S : c;
-            }
-#pragma unroll
-            for (int xb = 0; xb < NXB; ++xb) bad |= (iv0[xb] != iv0[xb]) | (iv1[xb] != iv1[xb]);
+        const int last_rel = a.n - 1 - c_base;                                   // groups are consecutive slots: < 16 * 15 KB apart
+        // the keyframe sector that meets query sector x at first shift b is (x - b) mod S
+        const int cw0 = wrapS(wave * SPW - s_cur[n4], S) * SB;
+        // Addresses = one wave-uniform 64-bit base per group + 32-bit per-lane byte offsets.
+        const char *hbase = reinterpret_cast<const char *>(a.hdesc + (size_t)first_slot * HS);
+        const unsigned int hoff = (unsigned int)(n4 < last_rel ? n4 : last_rel) * (unsigned int)(HS * 8) + (unsigned int)jl * 16u;
+        uint4 km = make_uint4(0u, 0u, 0u, 0u);
+        unsigned int kflag = 0;
+        if (wave == 0) {                                                         // the epilogue's operands: sector mask and flag of keyframe n
+            const unsigned int *kp = a.kmask + (size_t)(first_slot + (n16 < last_rel ? n16 : last_rel)) * 8;
+            km = *reinterpret_cast<const uint4 *>(kp);
+            kflag = kp[7];
         }
-        if (bad) bad_flag[n16] = 1;
-        const char *desc_base = reinterpret_cast<const char *>(a.desc + (size_t)first_slot * (RG * S) + (size_t)(wave * RPW) * S);
-        const unsigned int desc_off = rel_n * (unsigned int)(RG * S * 16);
-        float4 ra[D], rb[D];
-        int c_iss = col0, xb_iss = 0, r_iss = 0;
-        auto issue = [&](int sl) {
-            if (r_iss < RPW) {
-                const unsigned int row = desc_off + (unsigned int)r_iss * (unsigned int)(S * 16);
-                const int c1 = c_iss + 1 == S ? 0 : c_iss + 1;
-                ra[sl] = *reinterpret_cast<const float4 *>(desc_base + (row + (unsigned int)c_iss * 16u));
-                rb[sl] = *reinterpret_cast<const float4 *>(desc_base + (row + (unsigned int)c1 * 16u));
-            }
-            c_iss += 8; c_iss = c_iss >= S ? c_iss - S : c_iss;
-            if (++xb_iss == NXB) { xb_iss = 0; ++r_iss; c_iss = col0; }
+        u32x4 ring[D];
+        int cw_iss = cw0;                                                        // byte offset of the next step inside the keyframe
+        const char *qbase = reinterpret_cast<const char *>(a.q_hdesc);
+        auto issue = [&](int sl, bool real) {
+            if (PROBE == 3 || PROBE == 4) return;
+            const char *bsel = real ? hbase : qbase;
+            const unsigned int osel = real ? hoff + (unsigned int)cw_iss : (unsigned int)jl * 16u;
+            ring[sl] = *reinterpret_cast<const u32x4 *>(bsel + osel);
+            cw_iss += 64; cw_iss = cw_iss >= S * SB ? cw_iss - S * SB : cw_iss;
         };
 #pragma unroll
-        for (int sl = 0; sl < D; ++sl) issue(sl);
+        for (int sl = 0; sl < D; ++sl) issue(sl, true);
+        unsigned char *tile_wr = wscratch + kTileOff + n4 * kTileStride + jl * 16;
+        const unsigned char *tile_rd = wscratch + kTileOff + n16 * kTileStride + j4 * 16;
         f4v acc = {0.f, 0.f, 0.f, 0.f};
-        const _Float16 *qrow = Qh + ((size_t)(wave * RPW) * QSX + 2 * j4 + n16) * 4;   // A fragment: row t = lane & 15
-        // One k-step = 2 global loads (issued D steps ahead), 8 VALU (scale, convert), 1 LDS read of the A fragment
-        // (requested one step ahead), 1 MFMA.  The scheduling fences keep LLVM from hoisting every step's loads and
-        // conversions to the top of the unrolled row (which it does, and then needs > 256 registers).
-        auto load_a = [&](const _Float16 *ap) -> h8 {
-            const h4 alo = *reinterpret_cast<const h4 *>(ap), ahi = *reinterpret_cast<const h4 *>(ap + 4);
-            return __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
-        };
-        h8 a_nxt = load_a(qrow);
+        // A fragment of step g (sector x = SPW*w + g / KH, rings 32 (g % KH) ..): row t = lane & 15 is the query at sector x + t
+        const unsigned char *qlane = Qs + (size_t)(wave * SPW + n16) * QST + j4 * 16;
+        auto a_off = [&](int g) { return (g / KH) * QST + (g % KH) * 64; };      // wave-uniform
+        // One k-step = 1 global load (issued D steps ahead), 1 LDS write + 1 LDS read through the tile (the step after
+        // this one is staged while this one's read is in flight: LDS operations of a wave execute in order, one tile is
+        // enough), 1 LDS read of the A fragment (requested one step ahead), 1 MFMA.  The scheduling fences keep LLVM from
+        // hoisting every step's loads to the top of the unrolled run.
+        h8 a_nxt = *reinterpret_cast<const h8 *>(qlane);
+        if (PROBE < 2) *reinterpret_cast<u32x4 *>(tile_wr) = ring[0];
+        issue(0, NROW * NXB > D);
+        // Every step refills its ring slot with the step D later; past the group's last step the refill reads 16 bytes of
+        // the query's own copy instead (cache-resident, never used): a load behind a branch would make the compiler's
+        // s_waitcnt counting give up on every load issued before it, and the ring would drain once per run.
 #pragma unroll 1
-        for (int r = 0; r < RPW; ++r) {
+        for (int r = 0; r < NROW; ++r) {
+            double2 vk_n; float4 rk_n;
+            fetch(has_next ? nxt_base : c_base, r, vk_n, rk_n);
 #pragma unroll
             for (int xb = 0; xb < NXB; ++xb) {
-                const int sl = xb % D;
-                const float4 u = ra[sl], v = rb[sl];
-                issue(sl);
+                const int xn = xb + 1 < NXB ? xb + 1 : 0;                        // the step after this one (the next run's first)
+                const int sn = xn % D;
+                const int g = r * NXB + xb;                                      // wave-uniform
+                const bool more = (g + 1 + D) < NROW * NXB;
+                if (PROBE == 3 || PROBE == 4) continue;
+                if (PROBE == 2) {
+                    acc[0] += __uint_as_float(ring[sn][0] ^ ring[sn][1] ^ ring[sn][2] ^ ring[sn][3]);
+                    issue(sn, more);
+                    __builtin_amdgcn_sched_barrier(0);
+                    continue;
+                }
+                const h8 bfrag = *reinterpret_cast<const h8 *>(tile_rd);         // this step, staged one step ago
+                // (the slot is staged before it is refilled: the old value is dead when the load is issued, so the load
+                // returns into the same registers and the ring never has to be copied)
+                *reinterpret_cast<u32x4 *>(tile_wr) = ring[sn];
+                issue(sn, more);
                 const h8 afrag = a_nxt;
-                // next step's A fragment (the step after the row's last one is the next row's first; past the end it
-                // re-reads inside the staged query, values unused)
-                a_nxt = load_a(xb + 1 < NXB ? qrow + (size_t)(8 * (xb + 1)) * 4 : qrow + (size_t)(r + 1 < RPW ? QSX : 0) * 4);
-                h8 bfrag;
-                bfrag[0] = (_Float16)(u.x * iv0[xb]); bfrag[1] = (_Float16)(u.y * iv0[xb]);
-                bfrag[2] = (_Float16)(u.z * iv0[xb]); bfrag[3] = (_Float16)(u.w * iv0[xb]);
-                bfrag[4] = (_Float16)(v.x * iv1[xb]); bfrag[5] = (_Float16)(v.y * iv1[xb]);
-                bfrag[6] = (_Float16)(v.z * iv1[xb]); bfrag[7] = (_Float16)(v.w * iv1[xb]);
+                // next step's A fragment (past the end it re-reads inside the staged query, values unused)
+                a_nxt = *reinterpret_cast<const h8 *>(qlane + a_off(g + 1 < NROW * NXB ? g + 1 : 0));
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag, acc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            qrow += (size_t)QSX * 4;
+            if (has_next) align_one(nxt_base, r, s_nxt, vk_n, rk_n);            // keyframe 4w + r of the workgroup's next group
         }
-        part[wave * kWave + lane] = acc;
-        if (wave == 1 % NWV) {
-            // effective-sector counts (D.h:1523-1526): the same product on 0/1 indicators (exact in fp16 / fp32)
-            f4v nacc = {0.f, 0.f, 0.f, 0.f};
-            const _Float16 *irow = Qh + ((size_t)RG * QSX + 2 * j4 + n16) * 4;
-#pragma unroll
-            for (int xb = 0; xb < NXB; ++xb) {
-                h8 bfrag;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bfrag[e] = (_Float16)0.0f;
-                bfrag[0] = (_Float16)(iv0[xb] != 0.0f ? 1.0f : 0.0f);
-                bfrag[4] = (_Float16)(iv1[xb] != 0.0f ? 1.0f : 0.0f);
-                const _Float16 *ap = irow + (size_t)(8 * xb) * 4;
-                const h4 alo = *reinterpret_cast<const h4 *>(ap), ahi = *reinterpret_cast<const h4 *>(ap + 4);
-                const h8 afrag = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
-                nacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag, nacc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            npart[lane] = nacc;
-        }
+        part_cur[wave * kWave + lane] = acc;
         __syncthreads();                                                         // B2: partial sums are in LDS
 
         // ---- epilogue (wave 0): lane (n, q) holds shifts 4q .. 4q+3 of keyframe n ----------------------------
         if (wave == 0) {
-            f4v s = part[lane];
+            f4v s = part_cur[lane];
 #pragma unroll
-            for (int w = 1; w < NWV; ++w) s += part[w * kWave + lane];
-            const f4v ne = npart[lane];
+            for (int w = 1; w < NWV; ++w) s += part_cur[w * kWave + lane];
+            const int b_n = s_cur[n16];
             float dmin = __int_as_float(0x7f800000);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int t = 4 * j4 + r;
-                const float d = 1.0f - s[r] / ne[r];
-                if (t < W && ne[r] > 0.5f && d < dmin) dmin = d;                 // n_eff = 0: 0/0 in the reference, never wins
+                // effective sectors (D.h:1523-1526): both columns non-zero; keyframe sector y meets query sector y + b + t
+                int ri = b_n + t; ri = ri >= S ? ri - S : ri;
+                const uint4 rq = rotq[ri];
+                const int ne = __popc(rq.x & km.x) + __popc(rq.y & km.y) + __popc(rq.z & km.z) + __popc(rq.w & km.w);
+                const float d = 1.0f - s[r] / (float)ne;
+                if (t < W && ne > 0 && d < dmin) dmin = d;                       // n_eff = 0: 0/0 in the reference, never wins
             }
             dmin = fminf(dmin, __shfl_xor(dmin, 16, kWave));
             dmin = fminf(dmin, __shfl_xor(dmin, 32, kWave));
             const bool mine = lane < kGroup && ci_n < a.n;
-            const bool exact_only = q_bad || bad_flag[n16] != 0 || !(dmin == dmin);
+            const bool exact_only = q_bad || kflag != 0 || !(dmin == dmin);
             if (mine) a.out_approx[ci_n] = exact_only ? __int_as_float(0xff800000) : dmin;
             float contrib = (mine && !exact_only) ? dmin : __int_as_float(0x7f800000);
 #pragma unroll
             for (int off = 8; off > 0; off >>= 1) contrib = fminf(contrib, __shfl_xor(contrib, off, kWave));
             run_min = fminf(run_min, __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(contrib))));
-            if (lane < kGroup) bad_flag[lane] = 0;
         }
     }
     if (wave == 0 && lane == 0 && run_min < __int_as_float(0x7f800000)) atomicMin(a.t_min, float_to_ordered_u(run_min));
@@ -815,6 +839,7 @@ hipError_t launch_sc_screen_batch(const DbView &db, const ScreenBatch &sb, int S
         a.desc = db.desc; a.vkey = db.vkey; a.inv = db.inv;
         a.q_desc = db.desc + q * (size_t)(db.RG * db.S); a.q_vkey = db.vkey + q * db.S; a.q_inv = db.inv + q * db.S;
         a.q_rkey = db.rkey + q * (size_t)(4 * db.RG);
+        a.hdesc = db.hdesc; a.kmask = db.kmask; a.q_hdesc = db.hdesc + q * (size_t)db.hstride; a.q_kmask = db.kmask + q * 8;
         a.rkey4 = db.rkey4; a.rk_cap = db.cap;
         a.slot_base = sb.base[i]; a.n = sb.n[i];
         a.out_approx = sb.approx + (size_t)sb.buf[i] * sb.pair_stride; a.out_d2 = sb.ring_d2 + (size_t)sb.buf[i] * sb.pair_stride;
@@ -843,13 +868,14 @@ hipError_t launch_sc_screen_batch(const DbView &db, const ScreenBatch &sb, int S
         hipLaunchKernelGGL((sc_screen_wide_kernel<RGw, Sw, Ww, Dw>), dim3(blocks * sb.nq), dim3(kScreenWaves * kWave), ldsw, stream, ab);
         return hipGetLastError();
     }
+    if (db.hstride != RG * S) return hipErrorInvalidValue;
     constexpr int QSX = S + 16, PFS = 288;
-    constexpr int kAlignStride = ((2 * S * 8 + (PFS + 2 * S + 8) * 4) + 15) & ~15;
-    const size_t lds = (size_t)(RG + 1) * QSX * 4 * 2 + (size_t)S * 8 + (size_t)S * 4 * 2 + (size_t)kScreenWaves * kAlignStride +
-                       (size_t)(kScreenWaves + 1) * kWave * 16 + (size_t)(2 * kGroup + 4) * 4;
-    // variants (SCL_SCREEN_VARIANT): 0 = 5 k-steps in flight, 2 waves/SIMD; 1 = 3 in flight, 3 waves/SIMD; 2 = 5 in flight, 3 waves/SIMD
+    constexpr int kAlignStride = (((2 * S * 8 + (PFS + 2 * S + 8) * 4) + 15) & ~15) + kGroup * kTileStride;
+    const size_t lds = (size_t)QSX * (RG * 8 + 32) + (size_t)S * 16 + (size_t)S * 8 + (size_t)S * 4 * 2 + (size_t)kScreenWaves * kAlignStride +
+                       (size_t)(2 * kScreenWaves) * kWave * 16 + (size_t)(2 * kGroup) * 4;
+    // variants (SCL_SCREEN_VARIANT): 0 = 15 k-steps in flight, 2 waves/SIMD; 1 = 5 in flight, 2 waves/SIMD; 2 = 5 in flight, 3 waves/SIMD
     static const int variant = [] { const char *e = getenv("SCL_SCREEN_VARIANT"); return e ? atoi(e) : 0; }();
-    const int occ = variant == 0 ? 2 : 3;
+    const int occ = variant == 2 ? 3 : 2;
     int wg_per_cu = (int)((160 * 1024) / (lds + 256));
     if (wg_per_cu > occ) wg_per_cu = occ;
     if (wg_per_cu < 1) return hipErrorInvalidValue;
@@ -869,9 +895,19 @@ hipError_t launch_sc_screen_batch(const DbView &db, const ScreenBatch &sb, int S
         hipLaunchKernelGGL(kernel, dim3(blocks * sb.nq), dim3(kScreenWaves * kWave), lds, stream, ab);
         return hipGetLastError();
     };
-    if (variant == 1) return launch(sc_screen_kernel<RG, S, W, 3, 3>);
+#ifdef SCL_DIAGNOSTICS
+    static const int probe = [] { const char *e = getenv("SCL_SCREEN_PROBE"); return e ? atoi(e) : 0; }();
+    if (probe == 1) return launch(sc_screen_kernel<RG, S, W, 15, 2, 1>);
+    if (probe == 2) return launch(sc_screen_kernel<RG, S, W, 15, 2, 2>);
+    if (probe == 3) return launch(sc_screen_kernel<RG, S, W, 15, 2, 3>);
+    if (probe == 4) return launch(sc_screen_kernel<RG, S, W, 15, 2, 4>);
+    if (probe == 5) return launch(sc_screen_kernel<RG, S, W, 15, 2, 5>);
+    if (probe == 6) return launch(sc_screen_kernel<RG, S, W, 15, 2, 6>);
+    if (probe == 7) return launch(sc_screen_kernel<RG, S, W, 15, 2, 7>);
+#endif
+    if (variant == 1) return launch(sc_screen_kernel<RG, S, W, 5, 2>);
     if (variant == 2) return launch(sc_screen_kernel<RG, S, W, 5, 3>);
-    return launch(sc_screen_kernel<RG, S, W, 5, 2>);
+    return launch(sc_screen_kernel<RG, S, W, 15, 2>);
 }
 
 }  // namespace scl
