@@ -49,7 +49,7 @@ HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=2048)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--repeats", type=int, default=5, help="repetitions of the timed block of --steps steps (median reported)")
     ap.add_argument("--keyframes", type=int, default=0, help="keyframes per GPU (0: 10 000 at N = 1, 12 500 at N > 1)")
@@ -61,7 +61,7 @@ def parse_args():
                     help="incoming scans scored by one kernel launch (1..4; the reference runs several robots, whose scans "
                          "arrive together): the next scan's workgroups take over CUs as the previous scan's retire, so "
                          "no CU idles in a launch tail")
-    ap.add_argument("--native-chunk", type=int, default=64,
+    ap.add_argument("--native-chunk", type=int, default=256,
                     help="scans handed to the engine's native submit/collect pipeline per call (0: drive every scan from Python)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] geometric-verification measurement")
@@ -351,8 +351,7 @@ def main():
         of scans travel in one asynchronous exchange (RCCL), merged one batch later."""
         st = FullScanStream(eng, rank, world, device=coll_dev, depth=args.pipeline, merge_every=args.merge_every,
                             scans_per_launch=args.scans_per_launch, native_chunk=args.native_chunk, exchange=args.exchange)
-        for i in range(count):
-            st.submit(n_elig + ((first + i) % n_query), 0, n_elig)
+        st.submit_many(n_elig + ((first + np.arange(count)) % n_query), 0, n_elig)
         res = st.drain()
         assert len(res) == count
         return res

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <string>
@@ -44,7 +45,7 @@ struct ProfScope {
     ProfScope(scl_engine *e_, int kind_, hipStream_t s_ = nullptr) : e(e_), kind(kind_), s(s_ ? s_ : e_->stream)
     {
         if (!e->prof_on || (e->prof_on >= 2 && kind != P_SC)) return;
-        if (e->prof_on == 3 && (e->prof_tick++ & 7) != 0) return;     // sampled: one launch in eight
+        if (e->prof_on == 3 && (e->prof_tick++ % 7) != 0) return;     // sampled: one launch in seven (not a divisor of the launches per chunk)
         auto get = [&]() {
             hipEvent_t ev = nullptr;
             if (!e->event_pool.empty()) { ev = e->event_pool.back(); e->event_pool.pop_back(); }
@@ -208,11 +209,12 @@ int ensure_pairs(scl_engine *e, size_t n)
 {
     if (n <= e->pair_cap) return SCL_OK;
     dev_free(e->d_dist); dev_free(e->d_shift); dev_free(e->d_cand); dev_free(e->d_ring_d2);
-    dev_free(e->d_approx); dev_free(e->d_surv);
+    dev_free(e->d_approx); dev_free(e->d_surv); dev_free(e->d_starts);
     size_t nn = n + n / 2 + 64;
     int rc;
     e->pair_cap = 0;
     if ((rc = dev_alloc(e, &e->d_approx, nn))) return rc;
+    if ((rc = dev_alloc(e, &e->d_starts, nn))) return rc;
     if ((rc = dev_alloc(e, &e->d_surv, nn))) return rc;
     if ((rc = dev_alloc(e, &e->d_ring_d2, nn))) return rc;
     if ((rc = dev_alloc(e, &e->d_dist, nn))) return rc;
@@ -455,6 +457,13 @@ int scl_create(const scl_config *cfg, scl_engine **out)
         if (hipHostMalloc(&e->h_surv_args, (size_t)8 * NS * kSurvivorArgBytes, hipHostMallocDefault) != hipSuccess) return bail(SCL_ERR_HIP);
         if (hipHostMalloc((void **)&e->h_stream_out, (size_t)2 * NS * 64, hipHostMallocDefault) != hipSuccess) return bail(SCL_ERR_HIP);
         for (auto &ev : e->ev_chunk) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return bail(SCL_ERR_HIP);
+        for (auto &ev : e->ev_k1) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return bail(SCL_ERR_HIP);
+        if (hipEventCreateWithFlags(&e->ev_align_gate, hipEventDisableTiming) != hipSuccess) return bail(SCL_ERR_HIP);
+        {   // lowest priority: its workgroups take the slots the products leave, not the other way round
+            int lo_p = 0, hi_p = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
+            if (hipStreamCreateWithPriority(&e->stream_surv, hipStreamNonBlocking, lo_p) != hipSuccess) return bail(SCL_ERR_HIP);
+        }
     }
     if ((rc = dev_alloc(e, &e->a_blk_part, (size_t)1024 * kTailRec))) return bail(rc);
     if ((rc = dev_alloc(e, &e->a_done_counter, (size_t)4))) return bail(rc);
@@ -494,12 +503,15 @@ int scl_destroy(scl_engine *e)
     dev_free(e->d_hdesc); dev_free(e->d_kmask);
     dev_free(e->d_vals); dev_free(e->d_points); dev_free(e->d_tile);
     dev_free(e->d_dist); dev_free(e->d_shift); dev_free(e->d_cand); dev_free(e->d_ring_d2);
-    dev_free(e->d_approx); dev_free(e->d_surv); dev_free(e->d_nsurv); dev_free(e->d_tmin);
+    dev_free(e->d_approx); dev_free(e->d_starts); dev_free(e->d_surv); dev_free(e->d_nsurv); dev_free(e->d_tmin);
     dev_free(e->d_surv_part); dev_free(e->d_surv_done);
     if (e->d_surv_args) (void)hipFree(e->d_surv_args);
     if (e->h_surv_args) (void)hipHostFree(e->h_surv_args);
     if (e->h_stream_out) (void)hipHostFree(e->h_stream_out);
     for (auto ev : e->ev_chunk) if (ev) (void)hipEventDestroy(ev);
+    if (e->stream_surv) { (void)hipStreamSynchronize(e->stream_surv); (void)hipStreamDestroy(e->stream_surv); }
+    for (auto ev : e->ev_k1) if (ev) (void)hipEventDestroy(ev);
+    if (e->ev_align_gate) (void)hipEventDestroy(e->ev_align_gate);
     dev_free(e->d_topk_scratch); dev_free(e->d_topk_idx); dev_free(e->d_topk_d2); dev_free(e->d_out3);
     dev_free(e->d_blk_part); dev_free(e->d_done_counter);
     dev_free(e->a_blk_part); dev_free(e->a_done_counter); dev_free(e->a_topk_idx); dev_free(e->a_topk_d2);
@@ -833,25 +845,36 @@ int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, c
 // ---- screened full-DB passes (64x120 grid; sc_screen.hip) --------------------------------------------------------
 // One screening launch for up to four queries: slots qslot[i] against [lo[i], lo[i] + n[i]), results in buffer sets
 // set0 + i.  The event pair of the profile brackets this launch: it is the dominant kernel of a pass.
-int launch_screen_group(scl_engine *e, const int *qslot, const int *lo, const int *n, int nq, int set0)
+// nq_next > 0: the nq_next queries behind the nq of this launch (same arrays, buffer sets set0 + nq ...) are the next launch;
+// their alignment rides in this one (phases of the next call: kScreenProducts only).
+int launch_screen_group(scl_engine *e, const int *qslot, const int *lo, const int *n, int nq, int set0,
+                        int phases = kScreenAlign | kScreenProducts, int nq_next = 0, hipStream_t stream = nullptr)
 {
-    ScreenBatch sb{};
-    sb.nq = nq;
-    for (int j = 0; j < nq; ++j) { sb.slot[j] = qslot[j]; sb.base[j] = lo[j]; sb.n[j] = n[j]; sb.buf[j] = set0 + j; }
-    sb.pair_stride = e->set_stride;
-    sb.approx = e->d_approx; sb.ring_d2 = e->d_ring_d2; sb.survivors = nullptr; sb.n_surv = nullptr; sb.t_min = e->d_tmin;
-    sb.k = e->cfg.num_candidates; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
-    {
-        ProfScope ps(e, P_SC);
-        SCL_HIP(e, launch_sc_screen_batch(db_view(e), sb, e->SR, sc_align_filter_enabled(), e->num_cu, e->stream));
-        if (ps.active()) { for (int j = 0; j < nq; ++j) e->prof.sc_distance_pairs += (uint64_t)n[j]; }
+    if (!stream) stream = e->stream;
+    auto fill = [&](ScreenBatch &sb, int first, int count) {
+        sb.nq = count;
+        for (int j = 0; j < count; ++j) { sb.slot[j] = qslot[first + j]; sb.base[j] = lo[first + j]; sb.n[j] = n[first + j]; sb.buf[j] = set0 + first + j; }
+        sb.pair_stride = e->set_stride;
+        sb.approx = e->d_approx; sb.starts = e->d_starts; sb.ring_d2 = e->d_ring_d2; sb.survivors = nullptr; sb.n_surv = nullptr; sb.t_min = e->d_tmin;
+        sb.k = e->cfg.num_candidates; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
+    };
+    ScreenBatch sb{}, nx{};
+    fill(sb, 0, nq);
+    if (nq_next > 0) fill(nx, nq, nq_next);
+    if ((phases & kScreenAlign) && (phases & kScreenProducts) && nq_next > 0) {   // a sequence's first launch: its own alignment outside the
+        SCL_HIP(e, launch_sc_screen_batch(db_view(e), sb, e->SR, sc_align_filter_enabled(), e->num_cu, stream, kScreenAlign, nullptr));   // event pair
+        phases = kScreenProducts;
     }
+    ProfScope ps(e, P_SC, stream);
+    SCL_HIP(e, launch_sc_screen_batch(db_view(e), sb, e->SR, sc_align_filter_enabled(), e->num_cu, stream, phases, nq_next > 0 ? &nx : nullptr));
+    if (ps.active()) { for (int j = 0; j < nq; ++j) e->prof.sc_distance_pairs += (uint64_t)n[j]; }
     return SCL_OK;
 }
 
 // The exact pass over the survivors of nq screened queries (buffer sets set0 .. set0 + nq - 1); winners to out3[i].
-int launch_survivor_pass(scl_engine *e, const int *qslot, const int *lo, const int *n, int nq, int set0, double *const *out3)
+int launch_survivor_pass(scl_engine *e, const int *qslot, const int *lo, const int *n, int nq, int set0, double *const *out3, hipStream_t stream = nullptr)
 {
+    if (!stream) stream = e->stream;
     SurvivorPass sp{};
     sp.nq = nq;
     for (int j = 0; j < nq; ++j) { sp.slot[j] = qslot[j]; sp.base[j] = lo[j]; sp.n[j] = n[j]; sp.buf[j] = set0 + j; sp.out3[j] = out3[j]; }
@@ -861,8 +884,8 @@ int launch_survivor_pass(scl_engine *e, const int *qslot, const int *lo, const i
     sp.ring_d2 = e->d_ring_d2; sp.k = e->cfg.num_candidates; sp.exclude_eps = e->cfg.knn_exclude_eps; sp.topk_idx = e->d_topk_idx; sp.topk_d2 = e->d_topk_d2;
     const size_t region = (size_t)(e->surv_arg_tick++ & 7u) * scl_engine::kScreenSets * kSurvivorArgBytes;   // 8 passes may be in flight
     sp.d_args = static_cast<char *>(e->d_surv_args) + region; sp.h_args = static_cast<char *>(e->h_surv_args) + region;
-    ProfScope ps(e, P_ARGMIN);
-    SCL_HIP(e, launch_sc_distance_survivors(db_view(e), sp, e->SR, e->num_cu, e->stream));
+    ProfScope ps(e, P_ARGMIN, stream);
+    SCL_HIP(e, launch_sc_distance_survivors(db_view(e), sp, e->SR, e->num_cu, stream));
     return SCL_OK;
 }
 
@@ -1001,7 +1024,7 @@ int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, c
                 sb.nq = qb.nq;
                 for (int j = 0; j < qb.nq; ++j) { sb.slot[j] = qb.slot[j]; sb.base[j] = qb.base[j]; sb.n[j] = qb.n[j]; sb.buf[j] = j; }
                 sb.pair_stride = e->set_stride;
-                sb.approx = e->d_approx; sb.ring_d2 = e->d_ring_d2; sb.survivors = e->d_surv; sb.n_surv = e->d_nsurv; sb.t_min = e->d_tmin;
+                sb.approx = e->d_approx; sb.starts = e->d_starts; sb.ring_d2 = e->d_ring_d2; sb.survivors = e->d_surv; sb.n_surv = e->d_nsurv; sb.t_min = e->d_tmin;
                 sb.k = k; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
                 SCL_HIP(e, launch_sc_select_batch(sb, e->stream));
                 ProfScope ps(e, P_ARGMIN);
@@ -1087,6 +1110,7 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
                            int *nn_idx, int *shift, double *dist)
 {
     constexpr int NS = scl_engine::kScreenSets;
+    constexpr int CH = NS / 2;                               // scans per chunk: the two chunks in flight use the two halves of the buffer sets
     struct Chunk { int first = 0, count = 0; bool busy = false; std::vector<int> lo, empty; };
     Chunk ch[2];
     int nmax = 1;
@@ -1096,6 +1120,9 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
     }
     int rc = ensure_sets(e, (size_t)nmax);
     if (rc) return rc;
+    // the side streams start behind everything the main stream holds (ingests wrote the arrays they read)
+    SCL_HIP(e, hipEventRecord(e->ev_align_gate, e->stream));
+    SCL_HIP(e, hipStreamWaitEvent(e->stream_surv, e->ev_align_gate, 0));
     auto submit = [&](int c, int first, int count) -> int {
         Chunk &k = ch[c];
         k.first = first; k.count = count; k.lo.assign((size_t)count, 0); k.empty.assign((size_t)count, 1);
@@ -1114,14 +1141,21 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
             out3[m] = e->h_stream_out + ((size_t)c * NS + (size_t)i) * 8;
             ++m;
         }
-        // buffer set = position among the non-empty scans (sets must be consecutive within a launch)
+        // buffer set = first set of this half + position among the non-empty scans (consecutive within a launch).
+        // The two halves alternate, and a chunk is submitted only after the chunk two before it was collected, so nothing
+        // still reads or writes these sets.
+        const int set0 = c * CH;
+        // Every launch carries the alignment of the launch behind it; only the chunk's first one aligns for itself.
         for (int g = 0; g < m; g += spl) {
             const int w = m - g < spl ? m - g : spl;
-            if ((rc = launch_screen_group(e, qslot + g, qlo + g, qn + g, w, g))) return rc;
+            const int wn = m - g - w < spl ? m - g - w : spl;
+            if ((rc = launch_screen_group(e, qslot + g, qlo + g, qn + g, w, set0 + g, g == 0 ? (kScreenAlign | kScreenProducts) : kScreenProducts, wn))) return rc;
         }
-        if (m > 0 && (rc = launch_survivor_pass(e, qslot, qlo, qn, m, 0, out3))) return rc;
+        SCL_HIP(e, hipEventRecord(e->ev_k1[c], e->stream));
+        SCL_HIP(e, hipStreamWaitEvent(e->stream_surv, e->ev_k1[c], 0));
+        if (m > 0 && (rc = launch_survivor_pass(e, qslot, qlo, qn, m, set0, out3, e->stream_surv))) return rc;
         (void)set_of;
-        SCL_HIP(e, hipEventRecord(e->ev_chunk[c], e->stream));
+        SCL_HIP(e, hipEventRecord(e->ev_chunk[c], e->stream_surv));
         k.busy = true;
         e->last_pass_empty = m == 0;
         e->last_pass_alt = false;
@@ -1144,12 +1178,17 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
         return SCL_OK;
     };
     int next = 0, c = 0;
+    double t_sub = 0, t_col = 0; int n_sub = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     while (next < n_queries || ch[0].busy || ch[1].busy) {
         if (next < n_queries && !ch[c].busy) {
-            const int count = n_queries - next < NS ? n_queries - next : NS;
-            if ((rc = submit(c, next, count))) {
+            const int count = n_queries - next < CH ? n_queries - next : CH;
+            const double t0 = now();
+            rc = submit(c, next, count);
+            t_sub += now() - t0; ++n_sub;
+            if (rc) {
                 const std::string first_error = e->last_error;
-                (void)hipStreamSynchronize(e->stream);
+                (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream_surv);
                 e->last_error = first_error;
                 return rc;
             }
@@ -1159,8 +1198,11 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
         }
         // both halves enqueued (or nothing left to submit): wait for the older one
         const int older = ch[c].busy ? c : c ^ 1;
+        const double t0 = now();
         if ((rc = collect(older))) return rc;
+        t_col += now() - t0;
     }
+    if (getenv("SCL_STREAM_TIMING")) fprintf(stderr, "stream: %d chunks, submit %.1f us each, collect wait %.1f us each\n", n_sub, t_sub / n_sub * 1e6, t_col / n_sub * 1e6);
     return SCL_OK;
 }
 
@@ -1251,7 +1293,7 @@ int scl_screen_distances(scl_engine *e, int query, int lo, int hi, float *approx
     if ((rc = ensure_pairs(e, (size_t)n))) return rc;
     ScreenBatch sb{};
     sb.nq = 1; sb.slot[0] = qslot; sb.base[0] = lo; sb.n[0] = n; sb.pair_stride = (size_t)n;
-    sb.approx = e->d_approx; sb.ring_d2 = e->d_ring_d2; sb.survivors = e->d_surv; sb.n_surv = e->d_nsurv; sb.t_min = e->d_tmin;
+    sb.approx = e->d_approx; sb.starts = e->d_starts; sb.ring_d2 = e->d_ring_d2; sb.survivors = e->d_surv; sb.n_surv = e->d_nsurv; sb.t_min = e->d_tmin;
     sb.k = e->cfg.num_candidates; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
     SCL_HIP(e, launch_sc_screen_batch(db_view(e), sb, e->SR, sc_align_filter_enabled(), e->num_cu, e->stream));
     SCL_HIP(e, launch_sc_select_batch(sb, e->stream));

@@ -66,12 +66,17 @@ struct scl_engine {
     // Buffers come in kScreenSets sets of `set_stride` entries (one set per query of a chunk of the stream form; the
     // submit / collect form uses sets 0..3): approx, ring_d2, survivors, dist, shift at set * set_stride.
     static constexpr int kScreenSets = 64;
-    float *d_approx = nullptr; int *d_surv = nullptr; int *d_nsurv = nullptr; unsigned int *d_tmin = nullptr;
+    float *d_approx = nullptr; int *d_starts = nullptr; int *d_surv = nullptr; int *d_nsurv = nullptr; unsigned int *d_tmin = nullptr;
     size_t set_stride = 0;
     unsigned long long *d_surv_part = nullptr; unsigned int *d_surv_done = nullptr;        // tail of the exact pass
     void *d_surv_args = nullptr; void *h_surv_args = nullptr; unsigned surv_arg_tick = 0;   // argument sets of the exact pass (ring of 8 regions)
     double *h_stream_out = nullptr;                        // pinned: 2 x kScreenSets result records of the stream form
     hipEvent_t ev_chunk[2] = {nullptr, nullptr};
+    // stream form: the exact pass over a chunk's survivors (small, latency bound) runs on its own low-priority stream
+    // beside the screening products of the next chunk; the main stream carries the products back to back.
+    hipStream_t stream_surv = nullptr;
+    hipEvent_t ev_k1[2] = {nullptr, nullptr};
+    hipEvent_t ev_align_gate = nullptr;
     bool screen = false;                                   // grid supported and not switched off (SCL_SCREEN=0)
     bool in_single_fallback = false;                       // submit_full_locked <-> submit_full_many_locked recursion guard
     unsigned long long *d_topk_scratch = nullptr; int *d_topk_idx = nullptr; float *d_topk_d2 = nullptr;

@@ -82,7 +82,7 @@ __global__ void iris_rowkey_kernel(const int *zmax, const unsigned int *cells, i
     }
 }
 
-constexpr int kIrisWords = 20;                 // 640 template rows (2 * 4 scales * 80 rows) as 20 words per column
+// (kIrisWords = 20)                 // 640 template rows (2 * 4 scales * 80 rows) as 20 words per column
 
 // one workgroup per image column n
 __global__ __launch_bounds__(256) void iris_encode_kernel(const unsigned char *image, const double2 *h, int rows, int N, int nscale,

@@ -88,12 +88,19 @@ struct ScreenBatch {
     int buf[kMaxQueryBatch];                    // buffer set of query i: approx / ring_d2 / survivors at buf * pair_stride, t_min[buf], top-k set buf
     size_t pair_stride;
     float *approx; float *ring_d2; int *survivors; int *n_surv; unsigned int *t_min;
+    int *starts;                                // first shifts (alignment kernel -> screening kernel), like approx
     int k; float exclude_eps; int *topk_idx; float *topk_d2;
 };
 bool sc_screen_supported(const struct DbView &db, int SR);
 bool sc_screen_is_wide(const struct DbView &db, int SR);      // 80 x 180: screening by sc_screen_wide_kernel, exact pass by the one-sector-per-lane kernel
 float sc_screen_eps();
-hipError_t launch_sc_screen_batch(const struct DbView &db, const ScreenBatch &sb, int SR, int align_filter, int num_cu, hipStream_t stream);
+// phases: 1 = the alignment kernel (first shifts + ring-key metric into sb.starts / sb.ring_d2), 2 = the screening products
+// (which read sb.starts), 3 = both, one after the other on `stream`.  next (optional): the batch that follows; its
+// alignment rides in the launch of this batch's products (further workgroups of the same grid: one is matrix-core bound,
+// the other HBM bound), so the next call needs phase 2 only.
+constexpr int kScreenAlign = 1, kScreenProducts = 2;
+hipError_t launch_sc_screen_batch(const struct DbView &db, const ScreenBatch &sb, int SR, int align_filter, int num_cu, hipStream_t stream,
+                                  int phases = kScreenAlign | kScreenProducts, const ScreenBatch *next = nullptr);
 hipError_t launch_sc_select_batch(const ScreenBatch &sb, hipStream_t stream);
 // Exact pass over the survivors of nq screened queries (any number: the argument sets travel through device memory).
 // Query i: keyframe slot[i] against the range [base[i], base[i] + n[i]); its screening results live in buffer set

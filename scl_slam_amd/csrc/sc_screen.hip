@@ -52,6 +52,7 @@ struct ScreenArgs {
     const uint2 *q_hdesc; const unsigned int *q_kmask;
     const float4 *rkey4; int rk_cap;
     int slot_base, n;
+    int *starts;              // [n] first shifts: written by sc_align_kernel, read by sc_screen_kernel
     float *out_approx;        // [n] d~ ; -inf = must be scored exactly, +inf = no finite distance
     float *out_d2;            // [n] squared ring-key distance (nanoflann's metric), for the top-k
     unsigned int *t_min;      // ordered image of min d~ over the screened keyframes (atomicMin; re-armed by the exact pass)
@@ -73,7 +74,6 @@ __device__ __forceinline__ void wave_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 __device__ __forceinline__ void pin3(double &a, double &b, double &c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c) :: "memory"); }
-__device__ __forceinline__ void pin_f2(f2 &a, f2 &b) { asm volatile("" : "+v"(a), "+v"(b) :: "memory"); }
 
 __device__ __forceinline__ unsigned int float_to_ordered_u(float f)
 {
@@ -81,15 +81,13 @@ __device__ __forceinline__ unsigned int float_to_ordered_u(float f)
     return (b >> 31) ? ~b : (b | 0x80000000u);
 }
 
-// fastAlignUsingVkey (D.h:1491-1511) for one keyframe, wave-wide; returns the reference's arg-min shift.
-// vk = the keyframe's sector key at sectors 2*ll, 2*ll+1 (ll = min(lane, S/2 - 1)).  Same arithmetic as the
-// alignment phase of sc_distance_wave_kernel (filter bound, exact fallback, tie rules).
+// fastAlignUsingVkey (D.h:1491-1511) for one keyframe, wave-wide, in the reference's own fp64 arithmetic; returns the
+// reference's arg-min shift.  vk = the keyframe's sector key at sectors 2*ll, 2*ll+1 (ll = min(lane, S/2 - 1)).  Same
+// arithmetic as the exact evaluation in the alignment phase of sc_distance_wave_kernel (tie rules included).
 template <int S>
-__device__ __forceinline__ int align_keyframe(const double2 vk, int lane, bool use_filter, float qn2,
-                                              double *vk2, float *pf, const double *vq, const float *vqf0, const float *vqf1)
+__device__ __forceinline__ int align_keyframe_exact(const double2 vk, int lane, double *vk2, const double *vq)
 {
     constexpr int L = S >> 1;
-    constexpr int PFS = 288;
     const bool active = lane < L;
     const int ll = active ? lane : L - 1;
     const int j0 = 2 * ll;
@@ -97,58 +95,7 @@ __device__ __forceinline__ int align_keyframe(const double2 vk, int lane, bool u
     wave_fence();
     *reinterpret_cast<double2 *>(vk2 + j0) = vk;
     *reinterpret_cast<double2 *>(vk2 + j0 + S) = vk;
-    int filtered = -1;
-    if (use_filter) {
-        const f2 kf = f2{(float)vk.x, (float)vk.y};
-        float *pf1 = pf + PFS;
-        *reinterpret_cast<f2 *>(pf + j0) = kf;          *reinterpret_cast<f2 *>(pf + j0 + S) = kf;
-        *reinterpret_cast<f2 *>(pf1 + j0 + 2) = kf;     *reinterpret_cast<f2 *>(pf1 + j0 + S + 2) = kf;
-        wave_fence();
-        const int E = S - 2 * lane;
-        const float4 *pw = reinterpret_cast<const float4 *>((lane & 1) ? pf1 + E + 2 : pf + E);
-        const float4 *q0w = reinterpret_cast<const float4 *>(vqf0);
-        const float4 *q1w = reinterpret_cast<const float4 *>(vqf1);
-        constexpr int NG = S / 4, FB = 3;
-        static_assert(S % 4 == 0 && NG % FB == 0, "filter batches must tile the sectors");
-        f2 ce = f2{0.f, 0.f}, co = f2{0.f, 0.f};
-        float4 pb[2][FB], qa[2][FB], qb[2][FB];
-#pragma unroll
-        for (int v = 0; v < FB; ++v) { pb[0][v] = pw[v]; qa[0][v] = q0w[v]; qb[0][v] = q1w[v]; }
-#pragma unroll
-        for (int bt = 0; bt < NG / FB; ++bt) {
-            if (bt + 1 < NG / FB) {
-#pragma unroll
-                for (int v = 0; v < FB; ++v) {
-                    pb[(bt + 1) & 1][v] = pw[(bt + 1) * FB + v];
-                    qa[(bt + 1) & 1][v] = q0w[(bt + 1) * FB + v];
-                    qb[(bt + 1) & 1][v] = q1w[(bt + 1) * FB + v];
-                }
-            }
-            pin_f2(ce, co);
-#pragma unroll
-            for (int v = 0; v < FB; ++v) {
-                const float4 pv = pb[bt & 1][v], a0 = qa[bt & 1][v], a1 = qb[bt & 1][v];
-                ce = __builtin_elementwise_fma(f2{a0.x, a0.y}, f2{pv.x, pv.y}, ce);
-                ce = __builtin_elementwise_fma(f2{a0.z, a0.w}, f2{pv.z, pv.w}, ce);
-                co = __builtin_elementwise_fma(f2{a1.x, a1.y}, f2{pv.x, pv.y}, co);
-                co = __builtin_elementwise_fma(f2{a1.z, a1.w}, f2{pv.z, pv.w}, co);
-            }
-            pin_f2(ce, co);
-        }
-        const float c_even = ce.x + ce.y, c_odd = co.x + co.y;
-        const float kn2 = wave_sum_f32_dpp(active ? kf.x * kf.x + kf.y * kf.y : 0.f);
-        const float nsum = sqrtf(qn2) + sqrtf(kn2);
-        const float eps = 4.07e-6f * sqrtf(qn2) * sqrtf(kn2) + 1e-12f * (qn2 + kn2);
-        const float cmax = wave_max_f32_dpp(active ? fmaxf(c_even, c_odd) : -3.0e38f);
-        const float cut = cmax - 4.0f * eps;
-        const bool fe = active && !(c_even < cut), fo = active && !(c_odd < cut);
-        const unsigned long long me = __builtin_amdgcn_ballot_w64(fe), mo = __builtin_amdgcn_ballot_w64(fo);
-        const bool sane = (qn2 < 3.0e38f) && (kn2 < 3.0e38f) && (nsum * nsum < 0.9e14f);
-        if (sane && __popcll(me) + __popcll(mo) == 1)
-            filtered = me ? 2 * (__ffsll((long long)me) - 1) : 2 * (__ffsll((long long)mo) - 1) + 1;
-    }
     wave_fence();
-    if (filtered >= 0) return filtered;
     double best = kInf;
     int bshift = 0x7fffffff;
     {
@@ -157,7 +104,7 @@ __device__ __forceinline__ int align_keyframe(const double2 vk, int lane, bool u
         double prev = p[-1];
         double ss0 = 0.0, ss1 = 0.0;
         constexpr int npair = S >> 1;
-        constexpr int BT = 3;                              // (5 in sc_distance.hip; this kernel runs three waves per SIMD)
+        constexpr int BT = 3;                              // (5 in sc_distance.hip; here the path is rare and registers are short)
         static_assert(npair % BT == 0, "alignment batches must tile the sector pairs");
         const double2 *qq = reinterpret_cast<const double2 *>(vq);
         double2 pb[2][BT], qb[2][BT];
@@ -198,54 +145,187 @@ constexpr int kGroup = 16;                     // keyframes per matrix product (
 constexpr int kTileStride = 96;                // bytes per keyframe in a wave's transposition tile (32 fp16 + 32 B of padding: conflict-free reads)
 constexpr int kScreenMaxBlocks = 768;          // workgroups per query (3 per CU at most)
 
-// D = k-steps of loads in flight per wave (1 KB each); OCC = waves per SIMD the register allocation is held to.
-// PROBE (diagnostic builds only, -DSCL_DIAGNOSTICS + SCL_SCREEN_PROBE): 1 = no alignment (first shift 0), 2 = no alignment and
-// no staging / MFMA (the loads are summed): what the access pattern alone costs, 3 = alignment only (no loads, no products),
-// 4 = neither.  Results are wrong on purpose.
-template <int RG, int S, int W, int D, int OCC, int PROBE = 0>
-__global__ __launch_bounds__(kScreenWaves * kWave, OCC) void sc_screen_kernel(ScreenBatchArgs ab)
+// ---------------------------------------------------------------------------------------------------------------------
+// K0: the first shift of every (query, keyframe) pair -- fastAlignUsingVkey (D.h:1491-1511) -- and nanoflann's ring-key
+// metric, ahead of the screening products.  One wave per 16 keyframes.
+//
+// The arg-min over shifts s of |vq - shift(vk, s)| is the arg-max of the circular correlation
+//   c[s] = sum_u vq[(u + s) mod S] * vk[u],
+// a matrix product: M = shifts, N = 16 keyframes, K = sectors, in fp32 on the matrix cores (v_mfma_f32_16x16x4_f32).
+// It is a FILTER, as in sc_distance.hip: |c~ - c| <= eps = 4.07e-6 |vq| |vk| for any summation order (K + 2 roundings
+// of 2^-24 relative, Cauchy-Schwarz; truncating accumulation would still fit), so a shift whose c~ leads every other by
+// more than 4 eps is the exact arg-max of the fp64 distances as well; anything else -- two shifts within 4 eps (ties
+// included), norms that are not finite or so large that products could overflow -- is decided by the reference's own
+// fp64 evaluation (align_keyframe_exact, the same code as the exact kernel's).
+// Lane (m, k) = (lane & 15, lane >> 4) owns A[s = 16t + m][u = 16b + 4k + e] = vq[(16 (b + t) + 4k + m + e) mod S],
+// read from a repeated fp32 copy of the query's key in LDS; B comes from a per-wave LDS image of the 16 sector keys
+// in fp32.  Results: starts[i] = (shift - SR) mod S, out_d2[i].
+template <int RG, int S, int W>
+__device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const int block, unsigned char *smem_raw)
 {
     constexpr int NWV = kScreenWaves;
-    constexpr int RPW = RG / NWV;                      // ring groups per wave
+    constexpr int L = S >> 1;
+    constexpr int MT = (S + 15) / 16;                  // tiles of 16 shifts
+    constexpr int KB = (S + 15) / 16;                  // blocks of 16 sectors
+    constexpr int BST = 16 * KB + 4;                   // floats per keyframe in the B image (the 4 keep its reads spread over the banks)
+    constexpr int QX = 16 * (MT + KB);                 // the query key, repeated
+    static_assert(S % 4 == 0 && S / 2 <= kWave && (kGroup * L) % kWave == 0, "sector keys of a group tile the wave");
+    const int SR = (W - 1) / 2;
+
+    const int nbk = ab.nb;
+    const int qi = ab.nq > 1 ? block / nbk : 0;
+    const int bid = block - qi * nbk;
+    const ScreenArgs &a = ab.q[qi];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+
+    double *vq = reinterpret_cast<double *>(smem_raw);                           // [S]
+    float *qx = reinterpret_cast<float *>(vq + S);                               // [QX]
+    unsigned char *wbase = reinterpret_cast<unsigned char *>(qx + QX) + (size_t)wave * ((2 * S + 2) * 8 + kGroup * BST * 4);
+    double *vk2 = reinterpret_cast<double *>(wbase);                             // [2S + 2] scratch of the exact evaluation
+    float *Bs = reinterpret_cast<float *>(vk2 + 2 * S + 2);                      // [16][BST]
+
+    for (int c = threadIdx.x; c < S; c += blockDim.x) vq[c] = a.q_vkey[c];
+    for (int i = threadIdx.x; i < QX; i += blockDim.x) qx[i] = (float)a.q_vkey[i % S];
+    for (int i = lane; i < kGroup * (BST - S); i += kWave) {                     // the K padding of the B image stays zero
+        const int n = i / (BST - S), u = S + i - n * (BST - S);
+        Bs[n * BST + u] = 0.0f;
+    }
+    __syncthreads();
+
+    const int m16 = lane & 15, k4 = lane >> 4;
+    const float *qa = qx + 4 * k4 + m16;                                         // A[s = 16t + m][u = 16b + 4k + e] = qa[16 (b + t) + e]
+    float qn2;
+    {
+        const bool act = lane < L;
+        const int ll = act ? lane : L - 1;
+        const float q0 = qx[2 * ll], q1 = qx[2 * ll + 1];
+        qn2 = wave_sum_f32_dpp(act ? q0 * q0 + q1 * q1 : 0.f);
+    }
+    const bool use_filter = a.align_filter != 0;
+
+    const int ngroups = (a.n + kGroup - 1) / kGroup;
+    for (int g = bid * NWV + wave; g < ngroups; g += nbk * NWV) {
+        const int c_base = g * kGroup;
+        const int first_slot = a.slot_base + c_base;
+        const int last_rel = a.n - 1 - c_base;
+        // ---- the 16 sector keys: 16 * S / 2 double2, consecutive in memory, narrowed to fp32 into the B image ----
+        const double2 *src = reinterpret_cast<const double2 *>(a.vkey + (size_t)first_slot * S);
+        wave_fence();
+#pragma unroll 5
+        for (int it = 0; it < kGroup * L / kWave; ++it) {
+            const int f = it * kWave + lane;
+            const int n = f / L, u2 = f - n * L;
+            const double2 v = src[(size_t)(n < last_rel ? n : last_rel) * L + u2];
+            *reinterpret_cast<f2 *>(Bs + n * BST + 2 * u2) = f2{(float)v.x, (float)v.y};
+        }
+        wave_fence();
+        // ---- c~[s][n] for all shifts: MT tiles x KB blocks x 4 steps of K = 4 ----
+        f4v acc[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t] = f4v{0.f, 0.f, 0.f, 0.f};
+        float kn2 = 0.f;
+#pragma unroll
+        for (int b = 0; b < KB; ++b) {
+            const f4v b4 = *reinterpret_cast<const f4v *>(Bs + m16 * BST + 16 * b + 4 * k4);
+            kn2 += (b4[0] * b4[0] + b4[1] * b4[1]) + (b4[2] * b4[2] + b4[3] * b4[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[16 * (b + t) + e], b4[e], acc[t], 0, 0, 0);
+            }
+        }
+        kn2 += __shfl_xor(kn2, 16, kWave);
+        kn2 += __shfl_xor(kn2, 32, kWave);
+        // ---- per keyframe (column n = lane & 15): the largest and the second largest c~ over all shifts ----
+        const float kNegInf = __int_as_float(0xff800000);
+        float v1 = kNegInf, v2 = kNegInf;
+        int a1 = 0;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int sft = 16 * t + 4 * k4 + i;
+                const float c = sft < S ? acc[t][i] : kNegInf;
+                const bool gt = c > v1;
+                v2 = gt ? v1 : fmaxf(v2, c);
+                a1 = gt ? sft : a1;
+                v1 = gt ? c : v1;
+            }
+        }
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            const float o1 = __shfl_xor(v1, off, kWave), o2 = __shfl_xor(v2, off, kWave);
+            const int oa = __shfl_xor(a1, off, kWave);
+            const bool gt = o1 > v1;
+            v2 = fmaxf(gt ? v1 : o1, fmaxf(v2, o2));
+            a1 = gt ? oa : a1;
+            v1 = gt ? o1 : v1;
+        }
+        // ---- decide (every lane of column n holds the same numbers; lanes 0..15 write) ----
+        const float nsum = sqrtf(qn2) + sqrtf(kn2);
+        const float eps = 4.07e-6f * sqrtf(qn2) * sqrtf(kn2) + 1e-12f * (qn2 + kn2);
+        const bool sane = (qn2 < 3.0e38f) && (kn2 < 3.0e38f) && (nsum * nsum < 0.9e14f);
+        const bool mine = lane < kGroup && c_base + lane < a.n;
+        const bool uniq = use_filter && sane && (v2 < v1 - 4.0f * eps);
+        if (mine && uniq) a.starts[c_base + lane] = wrapS(a1 - SR, S);
+        unsigned long long amb = __builtin_amdgcn_ballot_w64(mine && !uniq);
+        while (amb) {                                                            // the reference's own evaluation, one keyframe at a time
+            const int n = __ffsll((long long)amb) - 1;
+            amb &= amb - 1;
+            const int ll = lane < L ? lane : L - 1;
+            const double2 vk = *reinterpret_cast<const double2 *>(a.vkey + (size_t)(first_slot + n) * S + 2 * ll);
+            const int al = align_keyframe_exact<S>(vk, lane, vk2, vq);
+            if (lane == 0) a.starts[c_base + n] = wrapS(al - SR, S);
+        }
+        // ---- nanoflann's metric (nanoflann.hpp:383-408): four dimensions per step, fp32, groups accumulated in order ----
+        if (mine) {
+            const int slot = first_slot + lane;
+            float result = 0.0f;
+#pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                const float4 bk = a.rkey4[(size_t)r * a.rk_cap + slot];
+                const float4 qk = *reinterpret_cast<const float4 *>(a.q_rkey + 4 * r);   // uniform: scalar loads
+                const float d0 = qk.x - bk.x, d1 = qk.y - bk.y, d2 = qk.z - bk.z, d3 = qk.w - bk.w;
+                const float grp = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+                result += grp;
+            }
+            a.out_d2[c_base + lane] = result;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K1s: the screening products.
+// D = k-steps of loads in flight per wave (1 KB each); OCC = waves per SIMD the register allocation is held to.
+// PROBE (diagnostic builds only, -DSCL_DIAGNOSTICS + SCL_SCREEN_PROBE): 2 = no staging / MFMA (the loads are summed): what
+// the access pattern alone costs.  Results are wrong on purpose.
+template <int RG, int S, int W, int D, int PROBE>
+__device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const int block, unsigned char *smem_raw)
+{
+    constexpr int NWV = kScreenWaves;
     constexpr int QSX = S + 16;                        // sectors of the extended query
     constexpr int SB = RG * 8;                         // bytes of one sector in hdesc (all rings, fp16)
     constexpr int KH = SB / 64;                        // k-steps per sector (32 rings = 64 B each)
     constexpr int QST = SB + 32;                       // bytes of one sector of the staged query (the padding keeps the A reads conflict-free)
     constexpr int HS = RG * S;                         // a keyframe's slot in hdesc (elements of 8 B)
     constexpr int SPW = S / NWV;                       // query sectors per wave
-    constexpr int NROW = 4;                            // a wave's k-steps come in NROW runs of NXB (one alignment after each run)
-    constexpr int NXB = SPW * KH / NROW;               // k-steps per run
-    constexpr int L = S >> 1;
-    constexpr int PFS = 288;
-    static_assert(S % NWV == 0 && SB % 64 == 0 && (SPW * KH) % NROW == 0 && NXB % D == 0 && W <= 16 && S <= 128, "tiling");
-    static_assert(NROW == kGroup / NWV, "one alignment per run");
-    static_assert(S / 2 <= kWave && S % 4 == 0, "alignment phase: two sectors per lane");
+    constexpr int NST = SPW * KH;                      // k-steps per wave and group
+    static_assert(S % NWV == 0 && SB % 64 == 0 && NST % D == 0 && W <= 16 && S <= 128, "tiling");
 
     const int nbk = ab.nb;
-    const int qi = ab.nq > 1 ? (int)blockIdx.x / nbk : 0;
-    const int bid = (int)blockIdx.x - qi * nbk;
+    const int qi = ab.nq > 1 ? block / nbk : 0;
+    const int bid = block - qi * nbk;
     const ScreenArgs &a = ab.q[qi];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: wave-derived addresses stay in SGPRs
-    const int SR = (W - 1) / 2;
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char *Qs = smem_raw;                                                // [QSX][QST]: sector-major fp16 query, 16 sectors repeated
     uint4 *rotq = reinterpret_cast<uint4 *>(Qs + (size_t)QSX * QST);             // [S] the query's sector mask rotated right by s
-    double *vq = reinterpret_cast<double *>(rotq + S);                           // [S]
-    float *vqf0 = reinterpret_cast<float *>(vq + S);                             // [S]
-    float *vqf1 = vqf0 + S;                                                      // [S]
-    constexpr int kAlignBytes = 2 * S * 8 + (PFS + 2 * S + 8) * 4;               // vk2 + the two fp32 key copies
-    constexpr int kTileOff = (kAlignBytes + 15) & ~15;                           // the wave's transposition tile follows
-    constexpr int kAlignStride = kTileOff + kGroup * kTileStride;
-    unsigned char *wscratch = reinterpret_cast<unsigned char *>(vqf1 + S) + (size_t)wave * kAlignStride;
-    double *vk2 = reinterpret_cast<double *>(wscratch);
-    float *pf = reinterpret_cast<float *>(vk2 + 2 * S);
-    unsigned char *shared_tail = reinterpret_cast<unsigned char *>(vqf1 + S) + (size_t)NWV * kAlignStride;
-    f4v *part = reinterpret_cast<f4v *>(shared_tail);                            // [2][NWV][64] partial sums
-    int *s_start = reinterpret_cast<int *>(part + 2 * NWV * kWave);              // [2][16]
+    unsigned char *tile = reinterpret_cast<unsigned char *>(rotq + S) + (size_t)wave * (kGroup * kTileStride);   // this wave's transposition tile
+    f4v *part = reinterpret_cast<f4v *>(reinterpret_cast<unsigned char *>(rotq + S) + (size_t)NWV * (kGroup * kTileStride));   // [2][NWV][64] partial sums
 
-    // ---- stage the query: its fp16 unit columns extended by 16 sectors, its rotated sector masks, sector-key copies ----
+    // ---- stage the query: its fp16 unit columns extended by 16 sectors, its rotated sector masks ----
     for (int idx = threadIdx.x; idx < QSX * (SB / 16); idx += blockDim.x) {
         const int cx = idx / (SB / 16), ch = idx - cx * (SB / 16);
         const int c = cx < S ? cx : cx - S;
@@ -261,87 +341,27 @@ __global__ __launch_bounds__(kScreenWaves * kWave, OCC) void sc_screen_kernel(Sc
         if (S < 128) rr &= (((unsigned __int128)1) << (S & 127)) - 1;
         rotq[sft] = make_uint4((unsigned int)rr, (unsigned int)(rr >> 32), (unsigned int)(rr >> 64), (unsigned int)(rr >> 96));
     }
-    for (int c = threadIdx.x; c < S; c += blockDim.x) {
-        const double kv = a.q_vkey[c];
-        vq[c] = kv;
-        vqf0[c] = (float)kv;
-        vqf1[c == 0 ? S - 1 : c - 1] = (float)kv;
-    }
-    __syncthreads();
-
-    const bool active = lane < L;
-    const int ll = active ? lane : L - 1;
-    const int j0 = 2 * ll;
-    const bool use_filter = a.align_filter != 0;
-    float qn2 = 0.f;
-    if (use_filter) {
-        const f2 qv = *reinterpret_cast<const f2 *>(vqf0 + j0);
-        qn2 = wave_sum_f32_dpp(active ? qv.x * qv.x + qv.y * qv.y : 0.f);
-    }
-    float4 qrk = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < RG) qrk = *reinterpret_cast<const float4 *>(a.q_rkey + 4 * lane);
 
     const int n16 = lane & 15, j4 = lane >> 4;           // MFMA layout: lane = (keyframe n, k-chunk j)
     const int n4 = lane >> 2, jl = lane & 3;             // load layout: four consecutive lanes = 64 consecutive bytes of keyframe n
     const int ngroups = (a.n + kGroup - 1) / kGroup;
     float run_min = __int_as_float(0x7f800000);                                  // wave 0: min d~ over screened keyframes
-
-    // ---- phase A: a wave aligns keyframes 4w .. 4w+3 of a group (and forms their ring-key metric), one at a time: four
-    // inlined copies of the alignment with every operand live at once do not fit the register file.  Only the first group
-    // of a workgroup is aligned ahead of its products; every later one is aligned inside the previous group's phase G
-    // (one keyframe after each ring group's k-steps, while that phase's loads are in flight), its sector and ring key
-    // requested a ring group earlier.  First shifts and partial sums are double-buffered by group parity, so one barrier
-    // per group (B2) orders everything.
-    // (unconditional loads only: a load behind a branch makes the compiler's s_waitcnt counting give up on every load
-    // issued before it -- the k-loop then drains its ring)
-    auto fetch = [&](int cb, int u, double2 &vk_o, float4 &rk_o) {
-        const int ci = cb + wave * (kGroup / NWV) + u;
-        const int slot = a.slot_base + (ci < a.n ? ci : a.n - 1);
-        vk_o = *reinterpret_cast<const double2 *>(a.vkey + (size_t)slot * S + j0);
-        rk_o = a.rkey4[(size_t)(lane < RG ? lane : RG - 1) * a.rk_cap + slot];
+    // first shifts (K0's output) of this group's keyframe n4, and of the next group's: requested one group ahead
+    auto start_of = [&](int grp) {
+        const int ci = grp * kGroup + n4;
+        return a.starts[ci < a.n ? ci : a.n - 1];
     };
-    auto align_one = [&](int cb, int u, int *starts, const double2 &vk_c, const float4 &rk_c) {
-        const int ci = cb + wave * (kGroup / NWV) + u;
-        const int al = (PROBE == 1 || PROBE == 2 || PROBE == 4) ? 0 : align_keyframe<S>(vk_c, lane, use_filter, qn2, vk2, pf, vq, vqf0, vqf1);
-        if (lane == 0) starts[wave * (kGroup / NWV) + u] = wrapS(al - SR, S);
-        // nanoflann's metric (nanoflann.hpp:383-408): four dimensions per step, fp32, groups accumulated in order
-        float grp = 0.0f;
-        if (lane < RG) {
-            const float4 b = rk_c;
-            const float d0 = qrk.x - b.x, d1 = qrk.y - b.y, d2 = qrk.z - b.z, d3 = qrk.w - b.w;
-            grp = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-        }
-        float result = 0.0f;
-#pragma unroll
-        for (int r = 0; r < RG; ++r) result += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(grp), r));
-        if (lane == 0 && ci < a.n) a.out_d2[ci] = result;
-    };
-    if (bid < ngroups) {
-        double2 vk_cur; float4 rk_cur;
-        fetch(bid * kGroup, 0, vk_cur, rk_cur);
-#pragma unroll 1
-        for (int u = 0; u < kGroup / NWV; ++u) {
-            double2 vk_nxt = vk_cur; float4 rk_nxt = rk_cur;
-            if (u + 1 < kGroup / NWV) fetch(bid * kGroup, u + 1, vk_nxt, rk_nxt);
-            align_one(bid * kGroup, u, s_start, vk_cur, rk_cur);
-            vk_cur = vk_nxt; rk_cur = rk_nxt;
-        }
-    }
-    __syncthreads();                                                             // the first group's 16 first shifts are known
+    int b_nxt = start_of(bid < ngroups ? bid : 0);
+    __syncthreads();
 
-    if (PROBE == 5 || PROBE == 6) {                      // stagger the workgroups' phases (diagnostic)
-        const int steps = PROBE == 5 ? (bid >= nbk / 2 ? 4 : 0) : (bid >= nbk / 2 ? 2 : 0) + (bid & 1);
-        for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(30);
-    }
     int par = 0;
     for (int g = bid; g < ngroups; g += nbk, par ^= 1) {
         const int c_base = g * kGroup;
-        const int nxt_base = (g + nbk) * kGroup;
-        const bool has_next = g + nbk < ngroups;
-        int *s_cur = s_start + par * kGroup, *s_nxt = s_start + (par ^ 1) * kGroup;
         f4v *part_cur = part + par * (NWV * kWave);
+        const int b_cur = b_nxt;
+        b_nxt = start_of(g + nbk < ngroups ? g + nbk : g);
 
-        // ---- phase G: query sectors SPW*w .. SPW*w + SPW-1 against all 16 keyframes ---------------------------------
+        // ---- query sectors SPW*w .. SPW*w + SPW-1 against all 16 keyframes ---------------------------------
         // hdesc is sector-major: the 64 rings of one sector are one 128-byte line, so the keyframe's ring shift is a
         // rotation of whole lines, every line is fetched once, and a wave walks SPW consecutive lines of each keyframe.
         // One k-step = 32 rings of one sector.  Load layout: lane 4n + j fetches rings 8j .. 8j+7 (16 B) of keyframe n, so
@@ -353,7 +373,7 @@ __global__ __launch_bounds__(kScreenWaves * kWave, OCC) void sc_screen_kernel(Sc
         const int first_slot = a.slot_base + c_base;
         const int last_rel = a.n - 1 - c_base;                                   // groups are consecutive slots: < 16 * 15 KB apart
         // the keyframe sector that meets query sector x at first shift b is (x - b) mod S
-        const int cw0 = wrapS(wave * SPW - s_cur[n4], S) * SB;
+        const int cw0 = wrapS(wave * SPW - b_cur, S) * SB;
         // Addresses = one wave-uniform 64-bit base per group + 32-bit per-lane byte offsets.
         const char *hbase = reinterpret_cast<const char *>(a.hdesc + (size_t)first_slot * HS);
         const unsigned int hoff = (unsigned int)(n4 < last_rel ? n4 : last_rel) * (unsigned int)(HS * 8) + (unsigned int)jl * 16u;
@@ -367,8 +387,10 @@ __global__ __launch_bounds__(kScreenWaves * kWave, OCC) void sc_screen_kernel(Sc
         u32x4 ring[D];
         int cw_iss = cw0;                                                        // byte offset of the next step inside the keyframe
         const char *qbase = reinterpret_cast<const char *>(a.q_hdesc);
+        // Every step refills its ring slot with the step D later; past the group's last step the refill reads 16 bytes of
+        // the query's own copy instead (cache-resident, never used): a load behind a branch would make the compiler's
+        // s_waitcnt counting give up on every load issued before it, and the ring would drain.
         auto issue = [&](int sl, bool real) {
-            if (PROBE == 3 || PROBE == 4) return;
             const char *bsel = real ? hbase : qbase;
             const unsigned int osel = real ? hoff + (unsigned int)cw_iss : (unsigned int)jl * 16u;
             ring[sl] = *reinterpret_cast<const u32x4 *>(bsel + osel);
@@ -376,33 +398,25 @@ __global__ __launch_bounds__(kScreenWaves * kWave, OCC) void sc_screen_kernel(Sc
         };
 #pragma unroll
         for (int sl = 0; sl < D; ++sl) issue(sl, true);
-        unsigned char *tile_wr = wscratch + kTileOff + n4 * kTileStride + jl * 16;
-        const unsigned char *tile_rd = wscratch + kTileOff + n16 * kTileStride + j4 * 16;
+        unsigned char *tile_wr = tile + n4 * kTileStride + jl * 16;
+        const unsigned char *tile_rd = tile + n16 * kTileStride + j4 * 16;
         f4v acc = {0.f, 0.f, 0.f, 0.f};
         // A fragment of step g (sector x = SPW*w + g / KH, rings 32 (g % KH) ..): row t = lane & 15 is the query at sector x + t
         const unsigned char *qlane = Qs + (size_t)(wave * SPW + n16) * QST + j4 * 16;
-        auto a_off = [&](int g) { return (g / KH) * QST + (g % KH) * 64; };      // wave-uniform
         // One k-step = 1 global load (issued D steps ahead), 1 LDS write + 1 LDS read through the tile (the step after
         // this one is staged while this one's read is in flight: LDS operations of a wave execute in order, one tile is
         // enough), 1 LDS read of the A fragment (requested one step ahead), 1 MFMA.  The scheduling fences keep LLVM from
         // hoisting every step's loads to the top of the unrolled run.
         h8 a_nxt = *reinterpret_cast<const h8 *>(qlane);
         if (PROBE < 2) *reinterpret_cast<u32x4 *>(tile_wr) = ring[0];
-        issue(0, NROW * NXB > D);
-        // Every step refills its ring slot with the step D later; past the group's last step the refill reads 16 bytes of
-        // the query's own copy instead (cache-resident, never used): a load behind a branch would make the compiler's
-        // s_waitcnt counting give up on every load issued before it, and the ring would drain once per run.
+        issue(0, NST > D);
 #pragma unroll 1
-        for (int r = 0; r < NROW; ++r) {
-            double2 vk_n; float4 rk_n;
-            fetch(has_next ? nxt_base : c_base, r, vk_n, rk_n);
+        for (int r = 0; r < NST / D; ++r) {
 #pragma unroll
-            for (int xb = 0; xb < NXB; ++xb) {
-                const int xn = xb + 1 < NXB ? xb + 1 : 0;                        // the step after this one (the next run's first)
-                const int sn = xn % D;
-                const int g = r * NXB + xb;                                      // wave-uniform
-                const bool more = (g + 1 + D) < NROW * NXB;
-                if (PROBE == 3 || PROBE == 4) continue;
+            for (int xb = 0; xb < D; ++xb) {
+                const int sn = (xb + 1) % D;                                     // slot of the step after this one
+                const int st = r * D + xb;                                       // wave-uniform
+                const bool more = (st + 1 + D) < NST;
                 if (PROBE == 2) {
                     acc[0] += __uint_as_float(ring[sn][0] ^ ring[sn][1] ^ ring[sn][2] ^ ring[sn][3]);
                     issue(sn, more);
@@ -416,21 +430,21 @@ __global__ __launch_bounds__(kScreenWaves * kWave, OCC) void sc_screen_kernel(Sc
                 issue(sn, more);
                 const h8 afrag = a_nxt;
                 // next step's A fragment (past the end it re-reads inside the staged query, values unused)
-                a_nxt = *reinterpret_cast<const h8 *>(qlane + a_off(g + 1 < NROW * NXB ? g + 1 : 0));
+                const int sa = st + 1 < NST ? st + 1 : 0;
+                a_nxt = *reinterpret_cast<const h8 *>(qlane + ((sa / KH) * QST + (sa % KH) * 64));
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag, acc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (has_next) align_one(nxt_base, r, s_nxt, vk_n, rk_n);            // keyframe 4w + r of the workgroup's next group
         }
         part_cur[wave * kWave + lane] = acc;
-        __syncthreads();                                                         // B2: partial sums are in LDS
+        __syncthreads();                                                         // partial sums are in LDS (double-buffered: one barrier per group)
 
         // ---- epilogue (wave 0): lane (n, q) holds shifts 4q .. 4q+3 of keyframe n ----------------------------
         if (wave == 0) {
             f4v s = part_cur[lane];
 #pragma unroll
             for (int w = 1; w < NWV; ++w) s += part_cur[w * kWave + lane];
-            const int b_n = s_cur[n16];
+            const int b_n = __shfl(b_cur, 4 * n16, kWave);                       // lane 4n holds keyframe n's first shift
             float dmin = __int_as_float(0x7f800000);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -454,6 +468,28 @@ __global__ __launch_bounds__(kScreenWaves * kWave, OCC) void sc_screen_kernel(Sc
         }
     }
     if (wave == 0 && lane == 0 && run_min < __int_as_float(0x7f800000)) atomicMin(a.t_min, float_to_ordered_u(run_min));
+}
+
+// One launch = the screening products of a batch of scans and, in further workgroups of the same grid, the alignment of
+// the NEXT batch (fa.next.nq = 0: none): the products are HBM bound, the alignment matrix-core bound, and the workgroups
+// of the second take the third wave slot per SIMD the first leaves free.  (Two kernels on two streams do the same in
+// principle; measured, the dispatcher then lets the alignment crowd out the products.)  Workgroups of the products come
+// first in the grid, so they are dispatched first.
+struct ScreenFusedArgs { ScreenBatchArgs prod; ScreenBatchArgs next; int prod_blocks; };
+
+template <int RG, int S, int W, int D, int OCC, int PROBE = 0>
+__global__ __launch_bounds__(kScreenWaves * kWave, OCC) void sc_screen_kernel(ScreenFusedArgs fa)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_fused[];
+    if ((int)blockIdx.x < fa.prod_blocks) sc_screen_role<RG, S, W, D, PROBE>(fa.prod, (int)blockIdx.x, smem_fused);
+    else sc_align_role<RG, S, W>(fa.next, (int)blockIdx.x - fa.prod_blocks, smem_fused);
+}
+
+template <int RG, int S, int W>
+__global__ __launch_bounds__(kScreenWaves * kWave, 2) void sc_align_kernel(ScreenBatchArgs ab)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_align[];
+    sc_align_role<RG, S, W>(ab, (int)blockIdx.x, smem_align);
 }
 
 // =====================================================================================================================
@@ -824,17 +860,14 @@ hipError_t launch_sc_select_batch(const ScreenBatch &sb, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_sc_screen_batch(const DbView &db, const ScreenBatch &sb, int SR, int align_filter, int num_cu, hipStream_t stream)
+// argument block of one batch; returns the largest range or -1
+static int fill_screen_args(const DbView &db, const ScreenBatch &sb, int align_filter, ScreenBatchArgs *ab)
 {
-    if (sb.nq < 1 || sb.nq > kMaxQueryBatch || !sc_screen_supported(db, SR)) return hipErrorInvalidValue;
-    const bool wide = sc_screen_is_wide(db, SR);
-    constexpr int RG = 16, S = 120, W = 13;
-    ScreenBatchArgs ab{};
-    ab.nq = sb.nq;
+    ab->nq = sb.nq;
     int nmax = 0;
     for (int i = 0; i < sb.nq; ++i) {
-        if (sb.n[i] <= 0) return hipErrorInvalidValue;
-        ScreenArgs &a = ab.q[i];
+        if (sb.n[i] <= 0) return -1;
+        ScreenArgs &a = ab->q[i];
         const size_t q = (size_t)sb.slot[i];
         a.desc = db.desc; a.vkey = db.vkey; a.inv = db.inv;
         a.q_desc = db.desc + q * (size_t)(db.RG * db.S); a.q_vkey = db.vkey + q * db.S; a.q_inv = db.inv + q * db.S;
@@ -842,11 +875,24 @@ hipError_t launch_sc_screen_batch(const DbView &db, const ScreenBatch &sb, int S
         a.hdesc = db.hdesc; a.kmask = db.kmask; a.q_hdesc = db.hdesc + q * (size_t)db.hstride; a.q_kmask = db.kmask + q * 8;
         a.rkey4 = db.rkey4; a.rk_cap = db.cap;
         a.slot_base = sb.base[i]; a.n = sb.n[i];
+        a.starts = sb.starts + (size_t)sb.buf[i] * sb.pair_stride;
         a.out_approx = sb.approx + (size_t)sb.buf[i] * sb.pair_stride; a.out_d2 = sb.ring_d2 + (size_t)sb.buf[i] * sb.pair_stride;
         a.t_min = sb.t_min + sb.buf[i]; a.align_filter = align_filter;
         nmax = sb.n[i] > nmax ? sb.n[i] : nmax;
     }
-    for (int i = sb.nq; i < kMaxQueryBatch; ++i) ab.q[i] = ab.q[0];
+    for (int i = sb.nq; i < kMaxQueryBatch; ++i) ab->q[i] = ab->q[0];
+    return nmax;
+}
+
+hipError_t launch_sc_screen_batch(const DbView &db, const ScreenBatch &sb, int SR, int align_filter, int num_cu, hipStream_t stream, int phases,
+                                  const ScreenBatch *next)
+{
+    if (sb.nq < 1 || sb.nq > kMaxQueryBatch || !sc_screen_supported(db, SR)) return hipErrorInvalidValue;
+    const bool wide = sc_screen_is_wide(db, SR);
+    constexpr int RG = 16, S = 120, W = 13;
+    ScreenBatchArgs ab{};
+    const int nmax = fill_screen_args(db, sb, align_filter, &ab);
+    if (nmax < 0) return hipErrorInvalidValue;
     const int ngroups = (nmax + kGroup - 1) / kGroup;
     if (wide) {
         constexpr int RGw = 20, Sw = 180, Ww = 19, Dw = 5;
@@ -868,46 +914,68 @@ hipError_t launch_sc_screen_batch(const DbView &db, const ScreenBatch &sb, int S
         hipLaunchKernelGGL((sc_screen_wide_kernel<RGw, Sw, Ww, Dw>), dim3(blocks * sb.nq), dim3(kScreenWaves * kWave), ldsw, stream, ab);
         return hipGetLastError();
     }
-    if (db.hstride != RG * S) return hipErrorInvalidValue;
-    constexpr int QSX = S + 16, PFS = 288;
-    constexpr int kAlignStride = (((2 * S * 8 + (PFS + 2 * S + 8) * 4) + 15) & ~15) + kGroup * kTileStride;
-    const size_t lds = (size_t)QSX * (RG * 8 + 32) + (size_t)S * 16 + (size_t)S * 8 + (size_t)S * 4 * 2 + (size_t)kScreenWaves * kAlignStride +
-                       (size_t)(2 * kScreenWaves) * kWave * 16 + (size_t)(2 * kGroup) * 4;
-    // variants (SCL_SCREEN_VARIANT): 0 = 15 k-steps in flight, 2 waves/SIMD; 1 = 5 in flight, 2 waves/SIMD; 2 = 5 in flight, 3 waves/SIMD
+    if (db.hstride != RG * S || !sb.starts) return hipErrorInvalidValue;
+    static std::atomic<bool> attr_set_dev[64];                 // per device
+    int dev_ = 0; (void)hipGetDevice(&dev_);
+    std::atomic<bool> &attr_set = attr_set_dev[dev_ & 63];
+    // variants (SCL_SCREEN_VARIANT): 0 = 15 k-steps in flight, 3 waves/SIMD; 1 = 15 in flight, 2 waves/SIMD; 2 = 5 in flight, 3 waves/SIMD
     static const int variant = [] { const char *e = getenv("SCL_SCREEN_VARIANT"); return e ? atoi(e) : 0; }();
-    const int occ = variant == 2 ? 3 : 2;
-    int wg_per_cu = (int)((160 * 1024) / (lds + 256));
-    if (wg_per_cu > occ) wg_per_cu = occ;
-    if (wg_per_cu < 1) return hipErrorInvalidValue;
-    int blocks = num_cu * wg_per_cu;
-    if (blocks > ngroups) blocks = ngroups;
-    if (blocks > kScreenMaxBlocks) blocks = kScreenMaxBlocks;
-    ab.nb = blocks;
-    auto launch = [&](auto kernel) -> hipError_t {
-        static std::atomic<bool> attr_set_dev[64];             // per instantiation (the lambda's static) and per device
-        int dev_ = 0; (void)hipGetDevice(&dev_);
-        std::atomic<bool> &attr_set = attr_set_dev[dev_ & 63];
-        if (!attr_set.load(std::memory_order_acquire)) {
-            hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            attr_set.store(true, std::memory_order_release);
-        }
-        hipLaunchKernelGGL(kernel, dim3(blocks * sb.nq), dim3(kScreenWaves * kWave), lds, stream, ab);
-        return hipGetLastError();
-    };
+    void (*kern)(ScreenFusedArgs) = sc_screen_kernel<RG, S, W, 15, 3>;
+    if (variant == 1) kern = sc_screen_kernel<RG, S, W, 15, 2>;
+    if (variant == 2) kern = sc_screen_kernel<RG, S, W, 5, 3>;
 #ifdef SCL_DIAGNOSTICS
     static const int probe = [] { const char *e = getenv("SCL_SCREEN_PROBE"); return e ? atoi(e) : 0; }();
-    if (probe == 1) return launch(sc_screen_kernel<RG, S, W, 15, 2, 1>);
-    if (probe == 2) return launch(sc_screen_kernel<RG, S, W, 15, 2, 2>);
-    if (probe == 3) return launch(sc_screen_kernel<RG, S, W, 15, 2, 3>);
-    if (probe == 4) return launch(sc_screen_kernel<RG, S, W, 15, 2, 4>);
-    if (probe == 5) return launch(sc_screen_kernel<RG, S, W, 15, 2, 5>);
-    if (probe == 6) return launch(sc_screen_kernel<RG, S, W, 15, 2, 6>);
-    if (probe == 7) return launch(sc_screen_kernel<RG, S, W, 15, 2, 7>);
+    if (probe == 2) kern = sc_screen_kernel<RG, S, W, 15, 3, 2>;
+#else
+    const int probe = 0;
 #endif
-    if (variant == 1) return launch(sc_screen_kernel<RG, S, W, 5, 2>);
-    if (variant == 2) return launch(sc_screen_kernel<RG, S, W, 5, 3>);
-    return launch(sc_screen_kernel<RG, S, W, 15, 2>);
+    constexpr int MT = (S + 15) / 16, BST = 16 * MT + 4, QSX = S + 16;
+    const size_t lds0 = (size_t)S * 8 + (size_t)(32 * MT) * 4 + (size_t)kScreenWaves * ((2 * S + 2) * 8 + kGroup * BST * 4);
+    const size_t lds1 = (size_t)QSX * (RG * 8 + 32) + (size_t)S * 16 + (size_t)kScreenWaves * kGroup * kTileStride + (size_t)(2 * kScreenWaves) * kWave * 16;
+    if (!attr_set.load(std::memory_order_acquire)) {
+        for (auto k : {(void (*)(ScreenFusedArgs))sc_screen_kernel<RG, S, W, 15, 3>, (void (*)(ScreenFusedArgs))sc_screen_kernel<RG, S, W, 15, 2>,
+                       (void (*)(ScreenFusedArgs))sc_screen_kernel<RG, S, W, 5, 3>}) {
+            hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (e != hipSuccess) return e;
+        }
+        hipError_t e = hipFuncSetAttribute((const void *)sc_align_kernel<RG, S, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return e;
+#ifdef SCL_DIAGNOSTICS
+        (void)hipFuncSetAttribute((const void *)sc_screen_kernel<RG, S, W, 15, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+#endif
+        attr_set.store(true, std::memory_order_release);
+    }
+    auto align_blocks = [&](int groups) {                      // one wave per 16 keyframes, at most one workgroup per CU and query beside the products
+        int b = (groups + kScreenWaves - 1) / kScreenWaves;
+        return b > num_cu ? num_cu : b;
+    };
+    // the alignment of this batch, on its own (the first launch of a sequence, or a caller that has only one)
+    if ((phases & kScreenAlign) && probe != 3) {
+        ab.nb = align_blocks(ngroups);
+        hipLaunchKernelGGL((sc_align_kernel<RG, S, W>), dim3(ab.nb * sb.nq), dim3(kScreenWaves * kWave), lds0, stream, ab);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    if (probe == 4 || !(phases & kScreenProducts)) return hipSuccess;
+    // the products of this batch + the alignment of the next one
+    ScreenFusedArgs fa{};
+    fa.prod = ab;
+    int blocks = num_cu * 2;
+    if (blocks > ngroups) blocks = ngroups;
+    if (blocks > kScreenMaxBlocks) blocks = kScreenMaxBlocks;
+    fa.prod.nb = blocks;
+    fa.prod_blocks = blocks * sb.nq;
+    int extra = 0;
+    if (next && probe != 3) {
+        if (next->nq < 1 || next->nq > kMaxQueryBatch) return hipErrorInvalidValue;
+        const int nmax2 = fill_screen_args(db, *next, align_filter, &fa.next);
+        if (nmax2 < 0) return hipErrorInvalidValue;
+        fa.next.nb = align_blocks((nmax2 + kGroup - 1) / kGroup);
+        extra = fa.next.nb * next->nq;
+    }
+    const size_t lds = extra && lds0 > lds1 ? lds0 : lds1;
+    hipLaunchKernelGGL(kern, dim3(fa.prod_blocks + extra), dim3(kScreenWaves * kWave), lds, stream, fa);
+    return hipGetLastError();
 }
 
 }  // namespace scl

@@ -217,10 +217,27 @@ class FullScanStream:
             return
         q, lo, hi = zip(*self.held)
         self.held = []
+        self._native_call(np.asarray(q, dtype=np.int32), np.asarray(lo, dtype=np.int32), np.asarray(hi, dtype=np.int32))
+
+    def _native_call(self, q, lo, hi):
         nn, sh, d = self.engine.detect_full_stream(q, lo, hi, self.per_launch, self.depth)
         g = np.where(nn >= 0, nn.astype(np.float64) * self.world + self.rank, -1.0)
-        self.batch.extend(zip(d.tolist(), g.tolist(), sh.astype(np.float64).tolist()))
-        self._exchange()
+        self._exchange(np.stack([np.asarray(d, dtype=np.float64), g, sh.astype(np.float64)], axis=1))
+
+    def submit_many(self, queries, lo, hi):
+        """Array form of ``submit`` for database-resident queries (``lo`` / ``hi`` scalars or arrays): the scans go to
+        the engine's native pipeline ``native_chunk`` at a time, with no per-scan work in Python."""
+        q = np.ascontiguousarray(queries, dtype=np.int32)
+        lo = np.ascontiguousarray(np.broadcast_to(np.asarray(lo, dtype=np.int32), q.shape))
+        hi = np.ascontiguousarray(np.broadcast_to(np.asarray(hi, dtype=np.int32), q.shape))
+        if self.native_chunk <= 0 or (q < 0).any():
+            for a, b, c in zip(q.tolist(), lo.tolist(), hi.tolist()):
+                self.submit(a, b, c)
+            return
+        self._launch_held()
+        for s0 in range(0, len(q), self.native_chunk):
+            s1 = min(len(q), s0 + self.native_chunk)
+            self._native_call(q[s0:s1], lo[s0:s1], hi[s0:s1])
 
     def _launch_held(self):
         if self.native_chunk > 0:
@@ -245,11 +262,14 @@ class FullScanStream:
         if len(self.batch) >= self.merge_every:
             self._exchange()
 
-    def _exchange(self):
-        if not self.batch:
-            return
-        rec = np.array(self.batch, dtype=np.float64)
-        self.batch = []
+    def _exchange(self, rec=None):
+        if rec is None:
+            if not self.batch:
+                return
+            rec = np.array(self.batch, dtype=np.float64)
+            self.batch = []
+        elif self.batch:                                    # per-scan submissions collected so far go first (order)
+            self._exchange()
         if self.world == 1 and not self.always_exchange:
             self._merge(rec[None])
             return
@@ -297,15 +317,22 @@ class FullScanStream:
         self._merge(out.cpu().numpy())
 
     def _merge(self, allr):
-        """allr: (world, m, 3) records (dist, global index or -1, shift)"""
-        for j in range(allr.shape[1]):
-            r = allr[:, j, :]
-            r = r[r[:, 1] >= 0]
-            if len(r) == 0:
-                self.results.append((BIG_DIST, -1, 0))
-                continue
-            b = r[np.lexsort((r[:, 1], r[:, 0]))[0]]
-            self.results.append((float(b[0]), int(b[1]), int(b[2])))
+        """allr: (world, m, 3) records (dist, global index or -1, shift): per scan the smallest distance, ties to the
+        lowest global index (vectorised: no per-scan work in Python beyond building the tuples)"""
+        allr = np.asarray(allr, dtype=np.float64)
+        valid = allr[:, :, 1] >= 0
+        d = np.where(valid, allr[:, :, 0], np.inf)
+        dmin = d.min(axis=0)
+        cand = valid & (d == dmin[None, :])
+        g = np.where(cand, allr[:, :, 1], np.inf)
+        gmin = g.min(axis=0)
+        win = np.argmax(cand & (g == gmin[None, :]), axis=0)
+        cols = np.arange(allr.shape[1])
+        any_valid = valid.any(axis=0)
+        out_d = np.where(any_valid, allr[win, cols, 0], BIG_DIST)
+        out_g = np.where(any_valid, allr[win, cols, 1], -1.0).astype(np.int64)
+        out_s = np.where(any_valid, allr[win, cols, 2], 0.0).astype(np.int64)
+        self.results.extend(zip(out_d.tolist(), out_g.tolist(), out_s.tolist()))
 
     def drain(self):
         self._launch_held()
