@@ -685,7 +685,7 @@ __device__ __forceinline__ void sc_wave_body(const ScArgs &a, const int bid, con
         if (slot >= 0) {
             double dmin = kInf;
             int smin = 0x7fffffff;
-            const bool fast_quot = q_finite && __all(is_finite(nk_cur.x) & is_finite(nk_cur.y));
+            const bool fast_quot = q_finite && __all((int)is_finite(nk_cur.x) & (int)is_finite(nk_cur.y));
             // Two passes (HSH, then W - HSH shifts), each a compile-time instance so the accumulators keep
             // static register indices; a scheduling fence between them keeps LLVM from interleaving both
             // (it would, and spill).  Within a pass: all query norms first, then every quotient (independent

@@ -109,3 +109,46 @@ def test_screening_with_adversarial_descriptors():
     approx, surv, _ = eng.screen_distances(103, 0, 300)
     assert np.all(np.isneginf(approx)) and len(surv) == 300
     eng.close()
+
+
+def test_alignment_kernel_on_ties_and_near_ties():
+    """The first shift comes from the fp32 matrix-core correlation of sc_align_kernel only when it leads every other shift
+    by more than the filter's margin; ties (the reference keeps the lowest shift), near ties, flat and periodic sector
+    keys, extreme magnitudes and non-finite values must fall through to the reference's own fp64 evaluation -- any wrong
+    first shift moves the 13-shift window and shows as a distance outside the bound."""
+    n = 700
+    rs = np.random.RandomState(7)
+    descs = synth_descriptors(n, R, S, seed=1011, revisit_frac=0.02)
+    base = descs[n - 1].copy()
+    k = 20
+    descs[k + 0] = np.tile(base[:, :1], (1, S))                               # flat sector key: every shift ties
+    descs[k + 1] = np.tile(base[:, :60], (1, 2))                              # period 60: two exact ties
+    descs[k + 2] = np.tile(base[:, :2], (1, 60))                              # period 2
+    descs[k + 3] = np.tile(base[:, :60], (1, 2)); descs[k + 3][0, 61] += np.float32(1e-6)     # ... broken in the last bits
+    descs[k + 4] = np.tile(base[:, :60], (1, 2)); descs[k + 4][3, 7] *= np.float32(1.0 + 1e-7)
+    descs[k + 5] = np.roll(base, 17, axis=1) * np.float32(1e18)               # huge: the filter's norm guard
+    descs[k + 6] = np.roll(base, 33, axis=1) * np.float32(1e-18)              # tiny
+    descs[k + 7] = np.roll(base, 5, axis=1); descs[k + 7][2, 9] = np.nan
+    descs[k + 8] = np.roll(base, 5, axis=1); descs[k + 8][2, 9] = np.inf
+    descs[k + 9] = 0.0
+    for i in range(10):                                                       # near copies of the query at every kind of shift
+        d = np.roll(base, int(rs.randint(0, S)), axis=1)
+        descs[k + 10 + i] = np.clip(d + np.float32(10.0 ** -(i % 5 + 3)) * rs.standard_normal(d.shape).astype(np.float32) * (d > 0), 0, None)
+    eng = ScanContextEngine(num_ring=R, num_sector=S, initial_capacity=n)
+    db = ob.OracleDB(ob.make_config(R=R, S=S))
+    eng.save_bulk(descs); db.save_bulk(descs)
+    for q in (n - 1, k + 0, k + 1, k + 3, k + 5, k + 7, k + 9, n - 2):         # the stress rows as queries as well
+        _check(eng, db, q, 0, n - 100 if q >= n - 100 else k + 20)
+    qs = np.array([n - 1, k + 1, k + 3, k + 0, n - 2, k + 5, k + 7, n - 3], dtype=np.int32)
+    nn, sh, dd = eng.detect_full_stream(qs, 0, np.full(len(qs), 300, np.int32), 4, 2)
+    for i, q in enumerate(qs):
+        o = db.detect_full_range(int(q), 0, 300) if hasattr(db, "detect_full_range") else None
+        if o is None:
+            d_ref, s_ref = db.distance_batch(int(q), cand=np.arange(0, 300, dtype=np.int32))
+            ok = d_ref < 1e7
+            if not ok.any():
+                assert nn[i] == -1
+                continue
+            b = int(np.flatnonzero(ok)[np.argmin(d_ref[ok])])
+            assert (nn[i], sh[i]) == (b, s_ref[b]) and dd[i].view(np.uint64) == d_ref[b].view(np.uint64), (q, nn[i], b)
+    eng.close()
