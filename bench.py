@@ -390,6 +390,7 @@ def main():
                 assert d < 1e-6 and g >= 0 and g % world == 0, (i, d, g, sh)
     eng.profile_enable(False)
     prof = eng.profile()
+    al_pairs, al_fallbacks = eng.alignment_stats()
     elapsed = float(np.median(times))
 
     pairs_per_step = n_elig * world
@@ -428,6 +429,8 @@ def main():
                                     f"per scan, batched over {args.native_chunk or args.merge_every} scans, asynchronous)") if world > 1 else "none (one GPU)"},
             "screening_GBps": value * KERNEL_BYTES_PER_PAIR / 1e9,           # whole job, priced like roofline.achieved
             "kernel_ms": {"sc_distance": k1_ms},
+            # fastAlignUsingVkey: pairs whose first shift the fp32 matrix-core filter left to the exact fp64 evaluation
+            "alignment": {"pairs": al_pairs, "exact_fallbacks": al_fallbacks, "fallback_rate": al_fallbacks / max(1, al_pairs)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "sc_screen_kernel (one launch = screening products of 4 scans x 10k keyframes on the fp16 copy "

@@ -327,6 +327,11 @@ int  scl_profile_enable(scl_engine *e, int on);   /* 0 off, 1 every kernel famil
                                                      between two back-to-back launches costs ~8 us of device time) */
 int  scl_profile_reset(scl_engine *e);
 int  scl_profile_get(scl_engine *e, scl_profile *out);
+/* The full-database pass aligns every (scan, keyframe) pair (fastAlignUsingVkey, D.h:1491-1511) with an fp32 correlation
+ * filter on the matrix cores and falls back to the reference's own fp64 evaluation wherever two shifts are closer than the
+ * filter's error margin.  pairs = pairs aligned since the last reset, fallbacks = those decided by the fp64 evaluation (the
+ * rate depends on the data: flat or periodic sector keys fall back).  Either pointer may be NULL; reset != 0 clears both. */
+int  scl_alignment_stats(scl_engine *e, uint64_t *pairs, uint64_t *fallbacks, int reset);
 int  scl_device_name(const scl_engine *e, char *buf, int buflen);
 
 #ifdef __cplusplus

@@ -382,7 +382,7 @@ const char *scl_status_string(int status)
 
 const char *scl_last_error(const scl_engine *e) { return e ? e->last_error.c_str() : "null engine"; }
 
-int scl_abi_version(void) { return 4; }
+int scl_abi_version(void) { return 5; }
 
 int scl_default_config(scl_config *c)
 {
@@ -473,6 +473,8 @@ int scl_create(const scl_config *cfg, scl_engine **out)
     if (hipStreamCreateWithFlags(&e->stream_alt, hipStreamNonBlocking) != hipSuccess) return bail(SCL_ERR_HIP);
     { const char *env = getenv("SCL_ALT_LANE"); e->alt_lane = env && env[0] == '1'; }
     if (hipEventCreateWithFlags(&e->ev_db, hipEventDisableTiming) != hipSuccess) return bail(SCL_ERR_HIP);
+    if ((rc = dev_alloc(e, &e->d_align_fallbacks, (size_t)1))) return bail(rc);
+    if (hipMemset(e->d_align_fallbacks, 0, sizeof(unsigned long long)) != hipSuccess) return bail(SCL_ERR_HIP);
     if ((rc = ensure_pairs(e, 1024))) return bail(rc);
     e->screen = sc_screen_supported(db_view(e), e->SR) && cfg->num_candidates <= kTailTopMaxK;
     if ((rc = ensure_pinned(e, 1 << 16))) return bail(rc);
@@ -504,6 +506,7 @@ int scl_destroy(scl_engine *e)
     dev_free(e->d_vals); dev_free(e->d_points); dev_free(e->d_tile);
     dev_free(e->d_dist); dev_free(e->d_shift); dev_free(e->d_cand); dev_free(e->d_ring_d2);
     dev_free(e->d_approx); dev_free(e->d_starts); dev_free(e->d_surv); dev_free(e->d_nsurv); dev_free(e->d_tmin);
+    dev_free(e->d_align_fallbacks);
     dev_free(e->d_surv_part); dev_free(e->d_surv_done);
     if (e->d_surv_args) (void)hipFree(e->d_surv_args);
     if (e->h_surv_args) (void)hipHostFree(e->h_surv_args);
@@ -855,12 +858,14 @@ int launch_screen_group(scl_engine *e, const int *qslot, const int *lo, const in
         sb.nq = count;
         for (int j = 0; j < count; ++j) { sb.slot[j] = qslot[first + j]; sb.base[j] = lo[first + j]; sb.n[j] = n[first + j]; sb.buf[j] = set0 + first + j; }
         sb.pair_stride = e->set_stride;
-        sb.approx = e->d_approx; sb.starts = e->d_starts; sb.ring_d2 = e->d_ring_d2; sb.survivors = nullptr; sb.n_surv = nullptr; sb.t_min = e->d_tmin;
+        sb.approx = e->d_approx; sb.starts = e->d_starts; sb.align_fallbacks = e->d_align_fallbacks; sb.ring_d2 = e->d_ring_d2; sb.survivors = nullptr; sb.n_surv = nullptr; sb.t_min = e->d_tmin;
         sb.k = e->cfg.num_candidates; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
     };
     ScreenBatch sb{}, nx{};
     fill(sb, 0, nq);
     if (nq_next > 0) fill(nx, nq, nq_next);
+    if (phases & kScreenAlign) for (int j = 0; j < nq; ++j) e->align_pairs += (uint64_t)n[j];
+    for (int j = 0; j < nq_next; ++j) e->align_pairs += (uint64_t)n[nq + j];
     if ((phases & kScreenAlign) && (phases & kScreenProducts) && nq_next > 0) {   // a sequence's first launch: its own alignment outside the
         SCL_HIP(e, launch_sc_screen_batch(db_view(e), sb, e->SR, sc_align_filter_enabled(), e->num_cu, stream, kScreenAlign, nullptr));   // event pair
         phases = kScreenProducts;
@@ -1024,7 +1029,7 @@ int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, c
                 sb.nq = qb.nq;
                 for (int j = 0; j < qb.nq; ++j) { sb.slot[j] = qb.slot[j]; sb.base[j] = qb.base[j]; sb.n[j] = qb.n[j]; sb.buf[j] = j; }
                 sb.pair_stride = e->set_stride;
-                sb.approx = e->d_approx; sb.starts = e->d_starts; sb.ring_d2 = e->d_ring_d2; sb.survivors = e->d_surv; sb.n_surv = e->d_nsurv; sb.t_min = e->d_tmin;
+                sb.approx = e->d_approx; sb.starts = e->d_starts; sb.align_fallbacks = e->d_align_fallbacks; sb.ring_d2 = e->d_ring_d2; sb.survivors = e->d_surv; sb.n_surv = e->d_nsurv; sb.t_min = e->d_tmin;
                 sb.k = k; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
                 SCL_HIP(e, launch_sc_select_batch(sb, e->stream));
                 ProfScope ps(e, P_ARGMIN);
@@ -1293,7 +1298,7 @@ int scl_screen_distances(scl_engine *e, int query, int lo, int hi, float *approx
     if ((rc = ensure_pairs(e, (size_t)n))) return rc;
     ScreenBatch sb{};
     sb.nq = 1; sb.slot[0] = qslot; sb.base[0] = lo; sb.n[0] = n; sb.pair_stride = (size_t)n;
-    sb.approx = e->d_approx; sb.starts = e->d_starts; sb.ring_d2 = e->d_ring_d2; sb.survivors = e->d_surv; sb.n_surv = e->d_nsurv; sb.t_min = e->d_tmin;
+    sb.approx = e->d_approx; sb.starts = e->d_starts; sb.align_fallbacks = e->d_align_fallbacks; sb.ring_d2 = e->d_ring_d2; sb.survivors = e->d_surv; sb.n_surv = e->d_nsurv; sb.t_min = e->d_tmin;
     sb.k = e->cfg.num_candidates; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
     SCL_HIP(e, launch_sc_screen_batch(db_view(e), sb, e->SR, sc_align_filter_enabled(), e->num_cu, e->stream));
     SCL_HIP(e, launch_sc_select_batch(sb, e->stream));
@@ -2011,6 +2016,24 @@ int scl_profile_get(scl_engine *e, scl_profile *out)
     if (e->front) return front_profile_get(e, out);
     std::lock_guard<std::mutex> lk(e->mu);
     *out = e->prof;
+    return SCL_OK;
+}
+
+int scl_alignment_stats(scl_engine *e, uint64_t *pairs, uint64_t *fallbacks, int reset)
+{
+    if (!e) return SCL_ERR_INVALID_ARG;
+    if (e->front) return front_alignment_stats(e, pairs, fallbacks, reset);
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    unsigned long long f = 0;
+    SCL_HIP(e, hipStreamSynchronize(e->stream));
+    SCL_HIP(e, hipMemcpy(&f, e->d_align_fallbacks, sizeof f, hipMemcpyDeviceToHost));
+    if (pairs) *pairs = e->align_pairs;
+    if (fallbacks) *fallbacks = (uint64_t)f;
+    if (reset) {
+        SCL_HIP(e, hipMemset(e->d_align_fallbacks, 0, sizeof f));
+        e->align_pairs = 0;
+    }
     return SCL_OK;
 }
 

@@ -66,7 +66,9 @@ struct scl_engine {
     // Buffers come in kScreenSets sets of `set_stride` entries (one set per query of a chunk of the stream form; the
     // submit / collect form uses sets 0..3): approx, ring_d2, survivors, dist, shift at set * set_stride.
     static constexpr int kScreenSets = 64;
-    float *d_approx = nullptr; int *d_starts = nullptr; int *d_surv = nullptr; int *d_nsurv = nullptr; unsigned int *d_tmin = nullptr;
+    float *d_approx = nullptr; int *d_starts = nullptr; int *d_surv = nullptr;
+    int *d_nsurv = nullptr; unsigned int *d_tmin = nullptr;
+    unsigned long long *d_align_fallbacks = nullptr; uint64_t align_pairs = 0;   // statistics of the alignment kernel (scl_alignment_stats)
     size_t set_stride = 0;
     unsigned long long *d_surv_part = nullptr; unsigned int *d_surv_done = nullptr;        // tail of the exact pass
     void *d_surv_args = nullptr; void *h_surv_args = nullptr; unsigned surv_arg_tick = 0;   // argument sets of the exact pass (ring of 8 regions)
@@ -101,7 +103,7 @@ struct scl_engine {
     int tree_counter = 0, tree_n = 0;
 
     // profiling
-    int prof_on = 0;                                       // 0 off, 1 every kernel family, 2 SC distance only, 3 SC distance sampled 1:8
+    int prof_on = 0;                                       // 0 off, 1 every kernel family, 2 SC distance only, 3 SC distance sampled 1:7
     unsigned prof_tick = 0;
     scl_profile prof{};
     std::vector<scl::PendingEvent> pending;
@@ -173,6 +175,7 @@ int front_icp_align_batch(scl_engine *e, const void *src, int n_src, const void 
 int front_profile_enable(scl_engine *e, int on);
 int front_profile_reset(scl_engine *e);
 int front_profile_get(scl_engine *e, scl_profile *out);
+int front_alignment_stats(scl_engine *e, uint64_t *pairs, uint64_t *fallbacks, int reset);
 scl_engine *front_primary(const scl_engine *e);            // the shard that runs unsharded work (geometry, keyframe store)
 
 }  // namespace scl

@@ -89,6 +89,7 @@ struct ScreenBatch {
     size_t pair_stride;
     float *approx; float *ring_d2; int *survivors; int *n_surv; unsigned int *t_min;
     int *starts;                                // first shifts (alignment kernel -> screening kernel), like approx
+    unsigned long long *align_fallbacks;        // optional counter: keyframes aligned by the exact evaluation
     int k; float exclude_eps; int *topk_idx; float *topk_d2;
 };
 bool sc_screen_supported(const struct DbView &db, int SR);

@@ -53,6 +53,7 @@ struct ScreenArgs {
     const float4 *rkey4; int rk_cap;
     int slot_base, n;
     int *starts;              // [n] first shifts: written by sc_align_kernel, read by sc_screen_kernel
+    unsigned long long *fallbacks;   // keyframes whose first shift the filter could not decide (statistics; may be null)
     float *out_approx;        // [n] d~ ; -inf = must be scored exactly, +inf = no finite distance
     float *out_d2;            // [n] squared ring-key distance (nanoflann's metric), for the top-k
     unsigned int *t_min;      // ordered image of min d~ over the screened keyframes (atomicMin; re-armed by the exact pass)
@@ -270,6 +271,7 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
         const bool uniq = use_filter && sane && (v2 < v1 - 4.0f * eps);
         if (mine && uniq) a.starts[c_base + lane] = wrapS(a1 - SR, S);
         unsigned long long amb = __builtin_amdgcn_ballot_w64(mine && !uniq);
+        if (amb && lane == 0 && a.fallbacks) atomicAdd(a.fallbacks, (unsigned long long)__popcll(amb));
         while (amb) {                                                            // the reference's own evaluation, one keyframe at a time
             const int n = __ffsll((long long)amb) - 1;
             amb &= amb - 1;
@@ -878,6 +880,7 @@ static int fill_screen_args(const DbView &db, const ScreenBatch &sb, int align_f
         a.starts = sb.starts + (size_t)sb.buf[i] * sb.pair_stride;
         a.out_approx = sb.approx + (size_t)sb.buf[i] * sb.pair_stride; a.out_d2 = sb.ring_d2 + (size_t)sb.buf[i] * sb.pair_stride;
         a.t_min = sb.t_min + sb.buf[i]; a.align_filter = align_filter;
+        a.fallbacks = sb.align_fallbacks;
         nmax = sb.n[i] > nmax ? sb.n[i] : nmax;
     }
     for (int i = sb.nq; i < kMaxQueryBatch; ++i) ab->q[i] = ab->q[0];

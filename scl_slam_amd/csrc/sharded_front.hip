@@ -801,6 +801,20 @@ int front_profile_reset(scl_engine *e)
     return SCL_OK;
 }
 
+int front_alignment_stats(scl_engine *e, uint64_t *pairs, uint64_t *fallbacks, int reset)
+{
+    uint64_t p = 0, f = 0;
+    for (int c = 0; c < e->front->G; ++c) {
+        uint64_t pc = 0, fc = 0;
+        const int rc = scl_alignment_stats(e->front->sh[c], &pc, &fc, reset);
+        if (rc) return rc;
+        p += pc; f += fc;
+    }
+    if (pairs) *pairs = p;
+    if (fallbacks) *fallbacks = f;
+    return SCL_OK;
+}
+
 int front_profile_get(scl_engine *e, scl_profile *out)
 {
     std::memset(out, 0, sizeof *out);

@@ -126,6 +126,7 @@ def _bind(lib):
         "scl_profile_enable": (c_int, [P, c_int]),
         "scl_profile_reset": (c_int, [P]),
         "scl_profile_get": (c_int, [P, POINTER(SclProfile)]),
+        "scl_alignment_stats": (c_int, [P, POINTER(ctypes.c_uint64), POINTER(ctypes.c_uint64), c_int]),
         "scl_device_name": (c_int, [P, c_char_p, c_int]),
     }
     for name, (res, args) in sig.items():
@@ -608,6 +609,12 @@ class ScanContextEngine:
         p = SclProfile()
         self._check(self._lib.scl_profile_get(self._h, byref(p)), "scl_profile_get")
         return {name: getattr(p, name) for name, _ in SclProfile._fields_}
+
+    def alignment_stats(self, reset=False):
+        """(pairs aligned by the full-database pass, pairs whose first shift needed the exact fp64 evaluation)"""
+        a, b = c_uint64(0), c_uint64(0)
+        self._check(self._lib.scl_alignment_stats(self._h, byref(a), byref(b), int(bool(reset))), "scl_alignment_stats")
+        return int(a.value), int(b.value)
 
     def device_name(self):
         buf = ctypes.create_string_buffer(256)

@@ -137,8 +137,15 @@ def test_alignment_kernel_on_ties_and_near_ties():
     eng = ScanContextEngine(num_ring=R, num_sector=S, initial_capacity=n)
     db = ob.OracleDB(ob.make_config(R=R, S=S))
     eng.save_bulk(descs); db.save_bulk(descs)
-    for q in (n - 1, k + 0, k + 1, k + 3, k + 5, k + 7, k + 9, n - 2):         # the stress rows as queries as well
+    eng.alignment_stats(reset=True)
+    _check(eng, db, n - 1, 0, n - 100)
+    pairs, fallbacks = eng.alignment_stats(reset=True)
+    # the flat / periodic / huge / non-finite / all-zero rows must have gone to the exact evaluation, ordinary ones must not
+    assert pairs >= n - 100 and 6 <= fallbacks <= 40, (pairs, fallbacks)
+    for q in (k + 0, k + 1, k + 3, k + 5, k + 7, k + 9, n - 2):               # the stress rows as queries as well
         _check(eng, db, q, 0, n - 100 if q >= n - 100 else k + 20)
+    pairs, fallbacks = eng.alignment_stats()
+    assert fallbacks >= 3 * (k + 20)                                          # a flat / periodic / all-zero query ties against everything
     qs = np.array([n - 1, k + 1, k + 3, k + 0, n - 2, k + 5, k + 7, n - 3], dtype=np.int32)
     nn, sh, dd = eng.detect_full_stream(qs, 0, np.full(len(qs), 300, np.int32), 4, 2)
     for i, q in enumerate(qs):
