@@ -110,7 +110,7 @@ void dev_free(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
 DbView db_view(const scl_engine *e)
 {
     DbView v;
-    v.desc = e->d_desc; v.vkey = e->d_vkey; v.norm = e->d_norm; v.rkey = e->d_rkey; v.rkey4 = e->d_rkey4; v.inv = e->d_inv;
+    v.desc = e->d_desc; v.vkey = e->d_vkey; v.norm = e->d_norm; v.rkey = e->d_rkey; v.rkey4 = e->d_rkey4;
     v.hdesc = e->d_hdesc; v.kmask = e->d_kmask; v.hstride = e->hstride;
     v.cap = e->cap; v.R = e->R; v.S = e->S; v.RG = e->RG;
     return v;
@@ -127,7 +127,6 @@ int query_view(const scl_engine *e, int query, QueryView *q)
     q->vkey = e->d_vkey + (size_t)query * e->S;
     q->norm = e->d_norm + (size_t)query * e->S;
     q->rkey = e->d_rkey + (size_t)query * e->R4;
-    q->inv = e->d_inv + (size_t)query * e->S;
     q->hdesc = e->d_hdesc + (size_t)query * e->hstride;
     q->kmask = e->d_kmask + (size_t)query * 8;
     return SCL_OK;
@@ -140,7 +139,7 @@ int ensure_capacity(scl_engine *e, int need)
     int ncap = e->cap > 0 ? e->cap : (e->cfg.initial_capacity > 0 ? e->cfg.initial_capacity : 4096);
     while (ncap < need) ncap *= 2;
     const size_t tile = (size_t)e->RG * e->S;
-    float4 *nd = nullptr; double *nv = nullptr; double *nn = nullptr; float *nr = nullptr; float4 *nr4 = nullptr; float *ni = nullptr;
+    float4 *nd = nullptr; double *nv = nullptr; double *nn = nullptr; float *nr = nullptr; float4 *nr4 = nullptr;
     uint2 *nh = nullptr; unsigned int *nk = nullptr;
     int rc;
     const size_t nst = (size_t)ncap + scl_engine::kStage;     // database slots + the staging slots behind them
@@ -148,7 +147,6 @@ int ensure_capacity(scl_engine *e, int need)
     if ((rc = dev_alloc(e, &nv, (size_t)e->S * nst))) return rc;
     if ((rc = dev_alloc(e, &nn, (size_t)e->S * nst))) return rc;
     if ((rc = dev_alloc(e, &nr, (size_t)e->R4 * nst))) return rc;
-    if ((rc = dev_alloc(e, &ni, (size_t)e->S * nst))) return rc;
     if ((rc = dev_alloc(e, &nh, (size_t)e->hstride * nst))) return rc;
     if ((rc = dev_alloc(e, &nk, (size_t)8 * nst))) return rc;
     if ((rc = dev_alloc(e, &nr4, (size_t)e->RG * ncap))) return rc;
@@ -158,7 +156,6 @@ int ensure_capacity(scl_engine *e, int need)
         SCL_HIP(e, hipMemcpyAsync(nv, e->d_vkey, sizeof(double) * (size_t)e->S * e->n, hipMemcpyDeviceToDevice, e->stream));
         SCL_HIP(e, hipMemcpyAsync(nn, e->d_norm, sizeof(double) * (size_t)e->S * e->n, hipMemcpyDeviceToDevice, e->stream));
         SCL_HIP(e, hipMemcpyAsync(nr, e->d_rkey, sizeof(float) * (size_t)e->R4 * e->n, hipMemcpyDeviceToDevice, e->stream));
-        SCL_HIP(e, hipMemcpyAsync(ni, e->d_inv, sizeof(float) * (size_t)e->S * e->n, hipMemcpyDeviceToDevice, e->stream));
         SCL_HIP(e, hipMemcpyAsync(nh, e->d_hdesc, sizeof(uint2) * (size_t)e->hstride * e->n, hipMemcpyDeviceToDevice, e->stream));
         SCL_HIP(e, hipMemcpyAsync(nk, e->d_kmask, sizeof(unsigned int) * (size_t)8 * e->n, hipMemcpyDeviceToDevice, e->stream));
         SCL_HIP(e, hipMemcpy2DAsync(nr4, sizeof(float4) * ncap, e->d_rkey4, sizeof(float4) * e->cap,
@@ -170,15 +167,14 @@ int ensure_capacity(scl_engine *e, int need)
         SCL_HIP(e, hipMemcpyAsync(nv + (size_t)e->S * ncap, e->d_vkey + (size_t)e->S * e->cap, sizeof(double) * e->S * k, hipMemcpyDeviceToDevice, e->stream));
         SCL_HIP(e, hipMemcpyAsync(nn + (size_t)e->S * ncap, e->d_norm + (size_t)e->S * e->cap, sizeof(double) * e->S * k, hipMemcpyDeviceToDevice, e->stream));
         SCL_HIP(e, hipMemcpyAsync(nr + (size_t)e->R4 * ncap, e->d_rkey + (size_t)e->R4 * e->cap, sizeof(float) * e->R4 * k, hipMemcpyDeviceToDevice, e->stream));
-        SCL_HIP(e, hipMemcpyAsync(ni + (size_t)e->S * ncap, e->d_inv + (size_t)e->S * e->cap, sizeof(float) * e->S * k, hipMemcpyDeviceToDevice, e->stream));
         SCL_HIP(e, hipMemcpyAsync(nh + (size_t)e->hstride * ncap, e->d_hdesc + (size_t)e->hstride * e->cap, sizeof(uint2) * e->hstride * k, hipMemcpyDeviceToDevice, e->stream));
         SCL_HIP(e, hipMemcpyAsync(nk + (size_t)8 * ncap, e->d_kmask + (size_t)8 * e->cap, sizeof(unsigned int) * 8 * k, hipMemcpyDeviceToDevice, e->stream));
     }
     SCL_HIP(e, hipStreamSynchronize(e->stream));
     if (e->stream_alt) SCL_HIP(e, hipStreamSynchronize(e->stream_alt));   // passes still reading the old arrays
-    dev_free(e->d_desc); dev_free(e->d_vkey); dev_free(e->d_norm); dev_free(e->d_rkey); dev_free(e->d_rkey4); dev_free(e->d_inv);
+    dev_free(e->d_desc); dev_free(e->d_vkey); dev_free(e->d_norm); dev_free(e->d_rkey); dev_free(e->d_rkey4);
     dev_free(e->d_hdesc); dev_free(e->d_kmask);
-    e->d_desc = nd; e->d_vkey = nv; e->d_norm = nn; e->d_rkey = nr; e->d_rkey4 = nr4; e->d_inv = ni;
+    e->d_desc = nd; e->d_vkey = nv; e->d_norm = nn; e->d_rkey = nr; e->d_rkey4 = nr4;
     e->d_hdesc = nh; e->d_kmask = nk;
     e->cap = ncap;
     return SCL_OK;
@@ -249,7 +245,7 @@ int ingest_from_vals(scl_engine *e, int count, int first_slot)
 {
     ProfScope ps(e, P_INGEST);
     SCL_HIP(e, launch_ingest(e->d_vals, count, first_slot, e->d_desc, e->d_vkey, e->d_norm, e->d_rkey,
-                             e->d_rkey4, e->d_inv, e->d_hdesc, e->d_kmask, e->hstride, e->cap, e->R, e->S, e->stream));
+                             e->d_rkey4, e->d_hdesc, e->d_kmask, e->hstride, e->cap, e->R, e->S, e->stream));
     e->db_version++;                                       // the alt lane orders itself behind this write
     return SCL_OK;
 }
@@ -501,7 +497,7 @@ int scl_destroy(scl_engine *e)
         icp_workspace_free(&e->icp_lane_ws[i]);
         if (e->icp_lane_stream[i]) (void)hipStreamDestroy(e->icp_lane_stream[i]);
     }
-    dev_free(e->d_desc); dev_free(e->d_vkey); dev_free(e->d_norm); dev_free(e->d_rkey); dev_free(e->d_rkey4); dev_free(e->d_inv);
+    dev_free(e->d_desc); dev_free(e->d_vkey); dev_free(e->d_norm); dev_free(e->d_rkey); dev_free(e->d_rkey4);
     dev_free(e->d_hdesc); dev_free(e->d_kmask);
     dev_free(e->d_vals); dev_free(e->d_points); dev_free(e->d_tile);
     dev_free(e->d_dist); dev_free(e->d_shift); dev_free(e->d_cand); dev_free(e->d_ring_d2);
@@ -642,7 +638,7 @@ int scl_stage_query(scl_engine *e, const float *values)
     {
         ProfScope ps(e, P_INGEST);
         // staging slot 0 = database index cap; no tiled ring key for staged queries (rkey4 == nullptr)
-        SCL_HIP(e, launch_ingest(e->d_vals, 1, e->cap, e->d_desc, e->d_vkey, e->d_norm, e->d_rkey, nullptr, e->d_inv, e->d_hdesc, e->d_kmask, e->hstride,
+        SCL_HIP(e, launch_ingest(e->d_vals, 1, e->cap, e->d_desc, e->d_vkey, e->d_norm, e->d_rkey, nullptr, e->d_hdesc, e->d_kmask, e->hstride,
                                  e->cap, e->R, e->S, e->stream));
     }
     if ((rc = sync(e))) return rc;
@@ -2064,7 +2060,6 @@ int eng_stage_from_peer(scl_engine *dst, int j, scl_engine *src, int src_slot)
     SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_vkey + d * S, dst->device, src->d_vkey + s * S, src->device, sizeof(double) * S, dst->stream));
     SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_norm + d * S, dst->device, src->d_norm + s * S, src->device, sizeof(double) * S, dst->stream));
     SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_rkey + d * R4, dst->device, src->d_rkey + s * R4, src->device, sizeof(float) * R4, dst->stream));
-    SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_inv + d * S, dst->device, src->d_inv + s * S, src->device, sizeof(float) * S, dst->stream));
     SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_hdesc + d * dst->hstride, dst->device, src->d_hdesc + s * src->hstride, src->device, sizeof(uint2) * src->hstride, dst->stream));
     SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_kmask + d * 8, dst->device, src->d_kmask + s * 8, src->device, sizeof(unsigned int) * 8, dst->stream));
     dst->staged[j] = true;
@@ -2082,7 +2077,7 @@ int eng_stage_values(scl_engine *e, int j, const float *values)
     SCL_HIP(e, hipMemcpyAsync(e->d_vals, values, sizeof(float) * cells, hipMemcpyHostToDevice, e->stream));
     {
         ProfScope ps(e, P_INGEST);
-        SCL_HIP(e, launch_ingest(e->d_vals, 1, e->cap + j, e->d_desc, e->d_vkey, e->d_norm, e->d_rkey, nullptr, e->d_inv, e->d_hdesc, e->d_kmask, e->hstride,
+        SCL_HIP(e, launch_ingest(e->d_vals, 1, e->cap + j, e->d_desc, e->d_vkey, e->d_norm, e->d_rkey, nullptr, e->d_hdesc, e->d_kmask, e->hstride,
                                  e->cap, e->R, e->S, e->stream));
     }
     if ((rc = sync(e))) return rc;

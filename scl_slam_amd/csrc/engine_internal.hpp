@@ -44,7 +44,7 @@ struct scl_engine {
     // database (layout: kernels.hpp)
     int n = 0, cap = 0;
     float4 *d_desc = nullptr; double *d_vkey = nullptr; double *d_norm = nullptr;
-    float *d_rkey = nullptr; float4 *d_rkey4 = nullptr; float *d_inv = nullptr;
+    float *d_rkey = nullptr; float4 *d_rkey4 = nullptr;
     uint2 *d_hdesc = nullptr; unsigned int *d_kmask = nullptr; int hstride = 0;   // the screening pass's fp16 copy + sector masks
     std::vector<int8_t> robots;
     std::vector<int> indexs;

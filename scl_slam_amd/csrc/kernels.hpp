@@ -7,7 +7,8 @@
 namespace scl {
 
 constexpr double kBigDist = 10000000.0;   // D.h:1494,1556,1637,1705 initial minima
-inline int hdesc_stride(int RG, int S) { return RG * S; }   // 8-byte elements per slot of hdesc
+constexpr int hdesc_sector(int RG) { return ((RG * 8 + 63) / 64) * 8; }   // 8-byte elements per sector of hdesc: ring groups padded to whole 64-byte k-steps
+constexpr int hdesc_stride(int RG, int S) { return hdesc_sector(RG) * S; }  // ... per slot
 
 // ---- database layout in HBM (one "slot" per keyframe) -----------------------
 //   desc   float4 [cap][RG][S]   RG = ceil(R/4); element (rg, c) holds rows
@@ -17,19 +18,15 @@ inline int hdesc_stride(int RG, int S) { return RG * S; }   // 8-byte elements p
 //   norm   double [cap][S]       column L2 norms (D.h:1523), fp64
 //   rkey   float  [cap][R4]      ring key, row-major (query side), R4 = 4*RG
 //   rkey4  float4 [RG][cap]      ring key, tiled for the top-k scan
-//   inv    float  [cap][S]       1 / column norm in fp32 for the fp16 screening pass (sc_screen.hip): 0 for an
-//                                all-zero column (D.h:1523 skips it), NaN when the norm is not in [2^-60, 2^60]
-//                                (non-finite or extreme values: such keyframes are always scored exactly)
-//   hdesc  half   [cap][S][4*RG]  the screening pass's own copy: unit columns (x * inv, fp32) rounded to fp16, sector-major:
+//   hdesc  half   [cap][S][4*RGH] the screening pass's own copy (RGH = ring groups padded to whole 64-byte steps: 16 at R = 64, 24 at R = 80): unit columns (x * (float)(1 / norm), fp32) rounded to fp16; an all-zero column stays zero, a norm outside [2^-60, 2^60] or non-finite makes the column NaN, sector-major:
 //                                all rings of one sector are consecutive (128 B = one cache line on the 64 x 120 grid), so
 //                                a ring shift is a rotation of whole lines and every line is read once.  Half the bytes of
-//                                desc.  hstride = S * RG elements of 8 B.
-//   kmask  u32    [cap][8]       bit c of words 0..6 = column c has a non-zero norm; word 7 bit 0 = some inv is NaN
+//                                desc.  hstride = S * RGH elements of 8 B.
+//   kmask  u32    [cap][8]       bit c of words 0..6 = column c has a non-zero norm; word 7 bit 0 = some column norm is outside [2^-60, 2^60] or non-finite (such keyframes are always scored exactly)
 struct DbView {
     const float4 *desc;
     const double *vkey;
     const double *norm;
-    const float  *inv;
     const uint2  *hdesc;
     const unsigned int *kmask;
     int hstride;
@@ -44,7 +41,6 @@ struct QueryView {          // one descriptor in the same layout (a DB slot or t
     const double *vkey;     // [S]
     const double *norm;     // [S]
     const float  *rkey;     // [R4]
-    const float  *inv;      // [S]
     const uint2  *hdesc;    // [hstride]
     const unsigned int *kmask;   // [8]
 };
@@ -155,7 +151,7 @@ hipError_t launch_ringkey_topk(const DbView &db, const float *qkey, int lo, int 
 
 // ingest: row-major wire descriptors (device) -> DB slots first_slot.. (all derived data)
 hipError_t launch_ingest(const float *values, int count, int first_slot,
-                         float4 *desc, double *vkey, double *norm, float *rkey, float4 *rkey4, float *inv,
+                         float4 *desc, double *vkey, double *norm, float *rkey, float4 *rkey4,
                          uint2 *hdesc, unsigned int *kmask, int hstride,
                          int cap, int R, int S, hipStream_t stream);
 // tiled -> row-major wire format (read back)

@@ -82,7 +82,7 @@ __global__ void make_sc_finalize_kernel(const int *gtile, int cells, float *valu
 // One workgroup per descriptor.  values: [count][R*S] row-major floats.
 __global__ __launch_bounds__(256) void ingest_kernel(
     const float *values, int first_slot, float4 *desc, double *vkey, double *norm,
-    float *rkey, float4 *rkey4, float *inv, uint2 *hdesc, unsigned int *kmask, int hstride, int cap, int R, int S)
+    float *rkey, float4 *rkey4, uint2 *hdesc, unsigned int *kmask, int hstride, int cap, int R, int S)
 {
     extern __shared__ float sv[];                 // [R][S+1], then the S reciprocal norms
     const int LS = S + 1;                         // odd-ish stride: column walks hit distinct banks
@@ -123,7 +123,6 @@ __global__ __launch_bounds__(256) void ingest_kernel(
         float iv = __int_as_float(0x7fc00000);
         if (nrm == 0.0) iv = 0.0f;
         else if (nrm >= 0x1p-60 && nrm <= 0x1p60) iv = (float)(1.0 / nrm);
-        inv[(size_t)slot * S + c] = iv;
         siv[c] = iv;
     }
     // ring key (row mean narrowed to float, D.h:1468-1472), sequential over sectors
@@ -141,8 +140,9 @@ __global__ __launch_bounds__(256) void ingest_kernel(
     __syncthreads();
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     h4 *hslot = reinterpret_cast<h4 *>(hdesc + (size_t)slot * hstride);
-    for (int i = threadIdx.x; i < S * RG; i += blockDim.x) {
-        const int c = i / RG, rg = i - c * RG;
+    const int RGH = hdesc_sector(RG);                        // ring groups of the copy: rows >= R are zero
+    for (int i = threadIdx.x; i < S * RGH; i += blockDim.x) {
+        const int c = i / RGH, rg = i - c * RGH;
         const float iv = siv[c];
         h4 hv;
 #pragma unroll
@@ -200,7 +200,7 @@ hipError_t launch_make_sc(const void *points, int n, int stride_bytes, int R, in
 }
 
 hipError_t launch_ingest(const float *values, int count, int first_slot,
-                         float4 *desc, double *vkey, double *norm, float *rkey, float4 *rkey4, float *inv,
+                         float4 *desc, double *vkey, double *norm, float *rkey, float4 *rkey4,
                          uint2 *hdesc, unsigned int *kmask, int hstride,
                          int cap, int R, int S, hipStream_t stream)
 {
@@ -217,7 +217,7 @@ hipError_t launch_ingest(const float *values, int count, int first_slot,
         attr_set.store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(ingest_kernel, dim3(count), dim3(256), lds, stream,
-                       values, first_slot, desc, vkey, norm, rkey, rkey4, inv, hdesc, kmask, hstride, cap, R, S);
+                       values, first_slot, desc, vkey, norm, rkey, rkey4, hdesc, kmask, hstride, cap, R, S);
     return hipGetLastError();
 }
 

@@ -46,9 +46,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 __attribute__((aligned(8))) u32x4_a8;   // 16 B at an 8-byte boundary (hdesc windows start at any sector)
 
 struct ScreenArgs {
-    const float4 *desc; const double *vkey; const float *inv;
+    const double *vkey;
     const uint2 *hdesc; const unsigned int *kmask;
-    const float4 *q_desc; const double *q_vkey; const float *q_inv; const float *q_rkey;
+    const double *q_vkey; const float *q_rkey;
     const uint2 *q_hdesc; const unsigned int *q_kmask;
     const float4 *rkey4; int rk_cap;
     int slot_base, n;
@@ -146,6 +146,49 @@ constexpr int kGroup = 16;                     // keyframes per matrix product (
 constexpr int kTileStride = 96;                // bytes per keyframe in a wave's transposition tile (32 fp16 + 32 B of padding: conflict-free reads)
 constexpr int kScreenMaxBlocks = 768;          // workgroups per query (3 per CU at most)
 
+// The same evaluation for grids with more than two sectors per lane (80 x 180: three shifts per lane).
+template <int S>
+__device__ __forceinline__ int align_keyframe_wide(const double (&vk)[(S + kWave - 1) / kWave], int lane, double *vk2, const double *vq)
+{
+    constexpr int SPL = (S + kWave - 1) / kWave;           // shifts (and sectors) per lane
+    constexpr int LA = S / SPL;                            // active lanes
+    static_assert(S % SPL == 0 && LA <= kWave, "shifts must tile the lanes");
+    const double kInf = __longlong_as_double(0x7ff0000000000000LL);
+    wave_fence();
+    if (lane < LA) {
+#pragma unroll
+        for (int u = 0; u < SPL; ++u) { vk2[SPL * lane + u] = vk[u]; vk2[SPL * lane + u + S] = vk[u]; }
+    }
+    if (lane == 0) { vk2[2 * S] = vk[0]; }                 // one past the doubled key: read by the last slide, never used
+    wave_fence();
+    // lane owns shifts s_k = SPL * lane + k; the key shifted by s at sector t is vk[(t - s) mod S] = p[t - k], p = vk2 + S - SPL * lane
+    const int ll = lane < LA ? lane : LA - 1;
+    const double *p = vk2 + S - SPL * ll;
+    double ss[SPL], w[SPL];
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) { ss[k] = 0.0; w[k] = p[-k]; }
+#pragma unroll 4
+    for (int t = 0; t < S; ++t) {                          // sector order, as the reference's norm (D.h:1500-1502)
+        const double q = vq[t];
+        const double nxt = p[t + 1];
+#pragma unroll
+        for (int k = 0; k < SPL; ++k) { const double d = q - w[k]; ss[k] = ss[k] + d * d; }
+#pragma unroll
+        for (int k = SPL - 1; k > 0; --k) w[k] = w[k - 1];
+        w[0] = nxt;
+    }
+    double best = kInf;
+    int bshift = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {                        // ascending shifts, strict <: ties keep the lower shift
+        const double nk = sqrt(ss[k]);
+        if (lane < LA && nk < kBigDist && nk < best) { best = nk; bshift = SPL * lane + k; }
+    }
+    wave_argmin_dpp(best, bshift);
+    return __builtin_amdgcn_readfirstlane(best < kBigDist ? bshift : 0);
+}
+
+
 // ---------------------------------------------------------------------------------------------------------------------
 // K0: the first shift of every (query, keyframe) pair -- fastAlignUsingVkey (D.h:1491-1511) -- and nanoflann's ring-key
 // metric, ahead of the screening products.  One wave per 16 keyframes.
@@ -170,7 +213,7 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
     constexpr int KB = (S + 15) / 16;                  // blocks of 16 sectors
     constexpr int BST = 16 * KB + 4;                   // floats per keyframe in the B image (the 4 keep its reads spread over the banks)
     constexpr int QX = 16 * (MT + KB);                 // the query key, repeated
-    static_assert(S % 4 == 0 && S / 2 <= kWave && (kGroup * L) % kWave == 0, "sector keys of a group tile the wave");
+    static_assert(S % 4 == 0, "sector keys are read in pairs, the B image in fours");
     const int SR = (W - 1) / 2;
 
     const int nbk = ab.nb;
@@ -196,13 +239,9 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
 
     const int m16 = lane & 15, k4 = lane >> 4;
     const float *qa = qx + 4 * k4 + m16;                                         // A[s = 16t + m][u = 16b + 4k + e] = qa[16 (b + t) + e]
-    float qn2;
-    {
-        const bool act = lane < L;
-        const int ll = act ? lane : L - 1;
-        const float q0 = qx[2 * ll], q1 = qx[2 * ll + 1];
-        qn2 = wave_sum_f32_dpp(act ? q0 * q0 + q1 * q1 : 0.f);
-    }
+    float qn2 = 0.f;
+    for (int i = lane; i < S; i += kWave) qn2 += qx[i] * qx[i];
+    qn2 = wave_sum_f32_dpp(qn2);
     const bool use_filter = a.align_filter != 0;
 
     const int ngroups = (a.n + kGroup - 1) / kGroup;
@@ -214,9 +253,10 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
         const double2 *src = reinterpret_cast<const double2 *>(a.vkey + (size_t)first_slot * S);
         wave_fence();
 #pragma unroll 5
-        for (int it = 0; it < kGroup * L / kWave; ++it) {
+        for (int it = 0; it < (kGroup * L + kWave - 1) / kWave; ++it) {
             const int f = it * kWave + lane;
-            const int n = f / L, u2 = f - n * L;
+            const int fc = f < kGroup * L ? f : kGroup * L - 1;                  // (the last round of a grid whose keys do not tile the wave)
+            const int n = fc / L, u2 = fc - n * L;
             const double2 v = src[(size_t)(n < last_rel ? n : last_rel) * L + u2];
             *reinterpret_cast<f2 *>(Bs + n * BST + 2 * u2) = f2{(float)v.x, (float)v.y};
         }
@@ -275,9 +315,19 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
         while (amb) {                                                            // the reference's own evaluation, one keyframe at a time
             const int n = __ffsll((long long)amb) - 1;
             amb &= amb - 1;
-            const int ll = lane < L ? lane : L - 1;
-            const double2 vk = *reinterpret_cast<const double2 *>(a.vkey + (size_t)(first_slot + n) * S + 2 * ll);
-            const int al = align_keyframe_exact<S>(vk, lane, vk2, vq);
+            int al;
+            if constexpr (S / 2 <= kWave) {
+                const int ll = lane < L ? lane : L - 1;
+                const double2 vk = *reinterpret_cast<const double2 *>(a.vkey + (size_t)(first_slot + n) * S + 2 * ll);
+                al = align_keyframe_exact<S>(vk, lane, vk2, vq);
+            } else {                                                             // more than two sectors per lane
+                constexpr int SPL = (S + kWave - 1) / kWave, LA = S / SPL;
+                const int ll = lane < LA ? lane : LA - 1;
+                double vk[SPL];
+#pragma unroll
+                for (int u = 0; u < SPL; ++u) vk[u] = a.vkey[(size_t)(first_slot + n) * S + SPL * ll + u];
+                al = align_keyframe_wide<S>(vk, lane, vk2, vq);
+            }
             if (lane == 0) a.starts[c_base + n] = wrapS(al - SR, S);
         }
         // ---- nanoflann's metric (nanoflann.hpp:383-408): four dimensions per step, fp32, groups accumulated in order ----
@@ -299,21 +349,59 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
 
 // ---------------------------------------------------------------------------------------------------------------------
 // K1s: the screening products.
-// D = k-steps of loads in flight per wave (1 KB each); OCC = waves per SIMD the register allocation is held to.
+// RGH = 8-byte elements per sector of hdesc (ring groups padded to whole k-steps: 16 at R = 64, 24 at R = 80);
+// D = k-steps of loads in flight per wave (1 KB each).
 // PROBE (diagnostic builds only, -DSCL_DIAGNOSTICS + SCL_SCREEN_PROBE): 2 = no staging / MFMA (the loads are summed): what
 // the access pattern alone costs.  Results are wrong on purpose.
-template <int RG, int S, int W, int D, int PROBE>
+
+// the S-bit sector mask m (64-bit words, bits >= S zero) rotated right by s: bit x of the result = bit (x + s) mod S of m
+template <int S>
+__device__ __forceinline__ void rotate_mask(const unsigned long long (&m)[(S + 63) / 64], int s, unsigned long long (&out)[(S + 63) / 64])
+{
+    constexpr int NW = (S + 63) / 64;
+    auto shr = [&](int k, unsigned long long (&o)[NW]) {       // logical shift right by k in [0, 64 NW)
+        const int w = k >> 6, b = k & 63;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const unsigned long long lo = i + w < NW ? m[i + w] : 0ull, hi = i + w + 1 < NW ? m[i + w + 1] : 0ull;
+            o[i] = b ? (lo >> b) | (hi << (64 - b)) : lo;
+        }
+    };
+    auto shl = [&](int k, unsigned long long (&o)[NW]) {       // logical shift left by k in [0, 64 NW]
+        const int w = k >> 6, b = k & 63;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const unsigned long long hi = i - w >= 0 && i - w < NW ? m[i - w] : 0ull, lo = i - w - 1 >= 0 && i - w - 1 < NW ? m[i - w - 1] : 0ull;
+            o[i] = b ? (hi << b) | (lo >> (64 - b)) : hi;
+        }
+    };
+    unsigned long long r1[NW], r2[NW];
+    shr(s, r1);
+    shl(S - s, r2);
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        unsigned long long v = r1[i] | r2[i];
+        const int top = S - 64 * i;                             // valid bits of word i
+        if (top < 64) v &= top > 0 ? ((1ull << (top & 63)) - 1ull) : 0ull;
+        out[i] = v;
+    }
+}
+
+template <int RGH, int S, int W, int D, int PROBE>
 __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const int block, unsigned char *smem_raw)
 {
     constexpr int NWV = kScreenWaves;
-    constexpr int QSX = S + 16;                        // sectors of the extended query
-    constexpr int SB = RG * 8;                         // bytes of one sector in hdesc (all rings, fp16)
+    constexpr int MT = (W + 15) / 16;                  // tiles of 16 shift rows
+    constexpr int QSX = S + 16 * MT;                   // sectors of the extended query
+    constexpr int SB = RGH * 8;                        // bytes of one sector in hdesc (all rings, fp16)
     constexpr int KH = SB / 64;                        // k-steps per sector (32 rings = 64 B each)
     constexpr int QST = SB + 32;                       // bytes of one sector of the staged query (the padding keeps the A reads conflict-free)
-    constexpr int HS = RG * S;                         // a keyframe's slot in hdesc (elements of 8 B)
+    constexpr int HS = RGH * S;                        // a keyframe's slot in hdesc (elements of 8 B)
     constexpr int SPW = S / NWV;                       // query sectors per wave
     constexpr int NST = SPW * KH;                      // k-steps per wave and group
-    static_assert(S % NWV == 0 && SB % 64 == 0 && NST % D == 0 && W <= 16 && S <= 128, "tiling");
+    constexpr int NW64 = (S + 63) / 64;                // 64-bit words of a sector mask
+    constexpr int MW = (NW64 + 1) / 2;                 // ... stored as MW x 16 bytes
+    static_assert(S % NWV == 0 && SB % 64 == 0 && NST % D == 0 && W <= 32 && S <= 224, "tiling");
 
     const int nbk = ab.nb;
     const int qi = ab.nq > 1 ? block / nbk : 0;
@@ -322,26 +410,32 @@ __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const 
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: wave-derived addresses stay in SGPRs
 
-    unsigned char *Qs = smem_raw;                                                // [QSX][QST]: sector-major fp16 query, 16 sectors repeated
-    uint4 *rotq = reinterpret_cast<uint4 *>(Qs + (size_t)QSX * QST);             // [S] the query's sector mask rotated right by s
-    unsigned char *tile = reinterpret_cast<unsigned char *>(rotq + S) + (size_t)wave * (kGroup * kTileStride);   // this wave's transposition tile
-    f4v *part = reinterpret_cast<f4v *>(reinterpret_cast<unsigned char *>(rotq + S) + (size_t)NWV * (kGroup * kTileStride));   // [2][NWV][64] partial sums
+    unsigned char *Qs = smem_raw;                                                // [QSX][QST]: sector-major fp16 query, 16 MT sectors repeated
+    uint4 *rotq = reinterpret_cast<uint4 *>(Qs + (size_t)QSX * QST);             // [S][MW] the query's sector mask rotated right by s
+    unsigned char *tile = reinterpret_cast<unsigned char *>(rotq + S * MW) + (size_t)wave * (kGroup * kTileStride);   // this wave's transposition tile
+    f4v *part = reinterpret_cast<f4v *>(reinterpret_cast<unsigned char *>(rotq + S * MW) + (size_t)NWV * (kGroup * kTileStride));   // [2][NWV][MT][64] partial sums
 
-    // ---- stage the query: its fp16 unit columns extended by 16 sectors, its rotated sector masks ----
+    // ---- stage the query: its fp16 unit columns extended by 16 MT sectors, its rotated sector masks ----
     for (int idx = threadIdx.x; idx < QSX * (SB / 16); idx += blockDim.x) {
         const int cx = idx / (SB / 16), ch = idx - cx * (SB / 16);
         const int c = cx < S ? cx : cx - S;
         *reinterpret_cast<uint4 *>(Qs + (size_t)cx * QST + ch * 16) =
             *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(a.q_hdesc) + (size_t)c * SB + ch * 16);
     }
-    const uint4 qm4 = *reinterpret_cast<const uint4 *>(a.q_kmask);
     const bool q_bad = a.q_kmask[7] != 0;
-    for (int sft = threadIdx.x; sft < S; sft += blockDim.x) {                    // bit x of rotq[s] = query sector (x + s) mod S
-        const unsigned __int128 m = ((unsigned __int128)qm4.w << 96) | ((unsigned __int128)qm4.z << 64) |
-                                    ((unsigned __int128)qm4.y << 32) | (unsigned __int128)qm4.x;
-        unsigned __int128 rr = (m >> sft) | (m << (S - sft));
-        if (S < 128) rr &= (((unsigned __int128)1) << (S & 127)) - 1;
-        rotq[sft] = make_uint4((unsigned int)rr, (unsigned int)(rr >> 32), (unsigned int)(rr >> 64), (unsigned int)(rr >> 96));
+    {
+        unsigned long long qm[NW64];
+#pragma unroll
+        for (int i = 0; i < NW64; ++i) qm[i] = (unsigned long long)a.q_kmask[2 * i] | ((unsigned long long)(2 * i + 1 < 7 ? a.q_kmask[2 * i + 1] : 0u) << 32);
+        for (int sft = threadIdx.x; sft < S; sft += blockDim.x) {                // bit x of rotq[s] = query sector (x + s) mod S
+            unsigned long long rr[NW64];
+            rotate_mask<S>(qm, sft, rr);
+#pragma unroll
+            for (int i = 0; i < MW; ++i) {
+                const unsigned long long lo = rr[2 * i], hi = 2 * i + 1 < NW64 ? rr[2 * i + 1] : 0ull;
+                rotq[sft * MW + i] = make_uint4((unsigned int)lo, (unsigned int)(lo >> 32), (unsigned int)hi, (unsigned int)(hi >> 32));
+            }
+        }
     }
 
     const int n16 = lane & 15, j4 = lane >> 4;           // MFMA layout: lane = (keyframe n, k-chunk j)
@@ -359,32 +453,36 @@ __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const 
     int par = 0;
     for (int g = bid; g < ngroups; g += nbk, par ^= 1) {
         const int c_base = g * kGroup;
-        f4v *part_cur = part + par * (NWV * kWave);
+        f4v *part_cur = part + par * (NWV * MT * kWave);
         const int b_cur = b_nxt;
         b_nxt = start_of(g + nbk < ngroups ? g + nbk : g);
 
         // ---- query sectors SPW*w .. SPW*w + SPW-1 against all 16 keyframes ---------------------------------
-        // hdesc is sector-major: the 64 rings of one sector are one 128-byte line, so the keyframe's ring shift is a
-        // rotation of whole lines, every line is fetched once, and a wave walks SPW consecutive lines of each keyframe.
-        // One k-step = 32 rings of one sector.  Load layout: lane 4n + j fetches rings 8j .. 8j+7 (16 B) of keyframe n, so
-        // four consecutive lanes read 64 consecutive bytes and one instruction is one k-step of all 16 keyframes.  (The
-        // texture path coalesces per group of four lanes: in the MFMA's own layout, keyframe = lane & 15, every such group
-        // touches four lines, which costs a quarter of the kernel.)  The step passes through a 1.5 KB tile of LDS owned by
-        // this wave and comes back in the MFMA's B layout, lane (n, j) = lane 16j + n.
+        // hdesc is sector-major: the rings of one sector are consecutive (one 128-byte line at R = 64), so the keyframe's
+        // ring shift is a rotation of whole sectors, every line is fetched once, and a wave walks SPW consecutive sectors
+        // of each keyframe.  One k-step = 32 rings of one sector.  Load layout: lane 4n + j fetches rings 8j .. 8j+7 (16 B)
+        // of keyframe n, so four consecutive lanes read 64 consecutive bytes and one instruction is one k-step of all 16
+        // keyframes.  (The texture path coalesces per group of four lanes: in the MFMA's own layout, keyframe = lane & 15,
+        // every such group touches four lines, which costs a quarter of the kernel.)  The step passes through a 1.5 KB tile
+        // of LDS owned by this wave and comes back in the MFMA's B layout, lane (n, j) = lane 16j + n.
         const int ci_n = c_base + n16;
         const int first_slot = a.slot_base + c_base;
-        const int last_rel = a.n - 1 - c_base;                                   // groups are consecutive slots: < 16 * 15 KB apart
+        const int last_rel = a.n - 1 - c_base;                                   // groups are consecutive slots: < 16 * 34 KB apart
         // the keyframe sector that meets query sector x at first shift b is (x - b) mod S
         const int cw0 = wrapS(wave * SPW - b_cur, S) * SB;
         // Addresses = one wave-uniform 64-bit base per group + 32-bit per-lane byte offsets.
         const char *hbase = reinterpret_cast<const char *>(a.hdesc + (size_t)first_slot * HS);
         const unsigned int hoff = (unsigned int)(n4 < last_rel ? n4 : last_rel) * (unsigned int)(HS * 8) + (unsigned int)jl * 16u;
-        uint4 km = make_uint4(0u, 0u, 0u, 0u);
+        uint4 km[MW];
+#pragma unroll
+        for (int i = 0; i < MW; ++i) km[i] = make_uint4(0u, 0u, 0u, 0u);
         unsigned int kflag = 0;
         if (wave == 0) {                                                         // the epilogue's operands: sector mask and flag of keyframe n
             const unsigned int *kp = a.kmask + (size_t)(first_slot + (n16 < last_rel ? n16 : last_rel)) * 8;
-            km = *reinterpret_cast<const uint4 *>(kp);
             kflag = kp[7];
+#pragma unroll
+            for (int i = 0; i < MW; ++i) km[i] = *reinterpret_cast<const uint4 *>(kp + 4 * i);
+            if (MW == 2) km[1].w = 0u;                                           // word 7 is the flag, not sector bits
         }
         u32x4 ring[D];
         int cw_iss = cw0;                                                        // byte offset of the next step inside the keyframe
@@ -402,14 +500,19 @@ __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const 
         for (int sl = 0; sl < D; ++sl) issue(sl, true);
         unsigned char *tile_wr = tile + n4 * kTileStride + jl * 16;
         const unsigned char *tile_rd = tile + n16 * kTileStride + j4 * 16;
-        f4v acc = {0.f, 0.f, 0.f, 0.f};
-        // A fragment of step g (sector x = SPW*w + g / KH, rings 32 (g % KH) ..): row t = lane & 15 is the query at sector x + t
+        f4v acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = f4v{0.f, 0.f, 0.f, 0.f};
+        // A fragment of step g (sector x = SPW*w + g / KH, rings 32 (g % KH) ..): row t = lane & 15 of tile m is the query
+        // at sector x + 16 m + t
         const unsigned char *qlane = Qs + (size_t)(wave * SPW + n16) * QST + j4 * 16;
         // One k-step = 1 global load (issued D steps ahead), 1 LDS write + 1 LDS read through the tile (the step after
         // this one is staged while this one's read is in flight: LDS operations of a wave execute in order, one tile is
-        // enough), 1 LDS read of the A fragment (requested one step ahead), 1 MFMA.  The scheduling fences keep LLVM from
-        // hoisting every step's loads to the top of the unrolled run.
-        h8 a_nxt = *reinterpret_cast<const h8 *>(qlane);
+        // enough), MT LDS reads of the A fragments (requested one step ahead), MT MFMAs.  The scheduling fences keep LLVM
+        // from hoisting every step's loads to the top of the unrolled run.
+        h8 a_nxt[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a_nxt[m] = *reinterpret_cast<const h8 *>(qlane + (size_t)(16 * m) * QST);
         if (PROBE < 2) *reinterpret_cast<u32x4 *>(tile_wr) = ring[0];
         issue(0, NST > D);
 #pragma unroll 1
@@ -420,7 +523,7 @@ __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const 
                 const int st = r * D + xb;                                       // wave-uniform
                 const bool more = (st + 1 + D) < NST;
                 if (PROBE == 2) {
-                    acc[0] += __uint_as_float(ring[sn][0] ^ ring[sn][1] ^ ring[sn][2] ^ ring[sn][3]);
+                    acc[0][0] += __uint_as_float(ring[sn][0] ^ ring[sn][1] ^ ring[sn][2] ^ ring[sn][3]);
                     issue(sn, more);
                     __builtin_amdgcn_sched_barrier(0);
                     continue;
@@ -430,33 +533,45 @@ __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const 
                 // returns into the same registers and the ring never has to be copied)
                 *reinterpret_cast<u32x4 *>(tile_wr) = ring[sn];
                 issue(sn, more);
-                const h8 afrag = a_nxt;
-                // next step's A fragment (past the end it re-reads inside the staged query, values unused)
+                // next step's A fragments (past the end they re-read inside the staged query, values unused)
                 const int sa = st + 1 < NST ? st + 1 : 0;
-                a_nxt = *reinterpret_cast<const h8 *>(qlane + ((sa / KH) * QST + (sa % KH) * 64));
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag, acc, 0, 0, 0);
+                const unsigned char *qn = qlane + ((sa / KH) * QST + (sa % KH) * 64);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const h8 afrag = a_nxt[m];
+                    a_nxt[m] = *reinterpret_cast<const h8 *>(qn + (size_t)(16 * m) * QST);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag, acc[m], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        part_cur[wave * kWave + lane] = acc;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) part_cur[(wave * MT + m) * kWave + lane] = acc[m];
         __syncthreads();                                                         // partial sums are in LDS (double-buffered: one barrier per group)
 
-        // ---- epilogue (wave 0): lane (n, q) holds shifts 4q .. 4q+3 of keyframe n ----------------------------
+        // ---- epilogue (wave 0): lane (n, q) holds shifts 16m + 4q .. 16m + 4q+3 of keyframe n ----------------------------
         if (wave == 0) {
-            f4v s = part_cur[lane];
-#pragma unroll
-            for (int w = 1; w < NWV; ++w) s += part_cur[w * kWave + lane];
             const int b_n = __shfl(b_cur, 4 * n16, kWave);                       // lane 4n holds keyframe n's first shift
             float dmin = __int_as_float(0x7f800000);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int t = 4 * j4 + r;
-                // effective sectors (D.h:1523-1526): both columns non-zero; keyframe sector y meets query sector y + b + t
-                int ri = b_n + t; ri = ri >= S ? ri - S : ri;
-                const uint4 rq = rotq[ri];
-                const int ne = __popc(rq.x & km.x) + __popc(rq.y & km.y) + __popc(rq.z & km.z) + __popc(rq.w & km.w);
-                const float d = 1.0f - s[r] / (float)ne;
-                if (t < W && ne > 0 && d < dmin) dmin = d;                       // n_eff = 0: 0/0 in the reference, never wins
+            for (int m = 0; m < MT; ++m) {
+                f4v s = part_cur[m * kWave + lane];
+#pragma unroll
+                for (int w = 1; w < NWV; ++w) s += part_cur[(w * MT + m) * kWave + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = 16 * m + 4 * j4 + r;
+                    // effective sectors (D.h:1523-1526): both columns non-zero; keyframe sector y meets query sector y + b + t
+                    int ri = b_n + t; ri = ri >= S ? ri - S : ri;
+                    int ne = 0;
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) {
+                        const uint4 rq = rotq[ri * MW + i];
+                        ne += __popc(rq.x & km[i].x) + __popc(rq.y & km[i].y) + __popc(rq.z & km[i].z) + __popc(rq.w & km[i].w);
+                    }
+                    const float d = 1.0f - s[r] / (float)ne;
+                    if (t < W && ne > 0 && d < dmin) dmin = d;                   // n_eff = 0: 0/0 in the reference, never wins
+                }
             }
             dmin = fminf(dmin, __shfl_xor(dmin, 16, kWave));
             dmin = fminf(dmin, __shfl_xor(dmin, 32, kWave));
@@ -479,11 +594,13 @@ __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const 
 // first in the grid, so they are dispatched first.
 struct ScreenFusedArgs { ScreenBatchArgs prod; ScreenBatchArgs next; int prod_blocks; };
 
+constexpr int hdesc_rgh(int RG) { return ((RG * 8 + 63) / 64) * 8; }   // 8-byte elements per sector of hdesc: whole k-steps of 64 B
+
 template <int RG, int S, int W, int D, int OCC, int PROBE = 0>
 __global__ __launch_bounds__(kScreenWaves * kWave, OCC) void sc_screen_kernel(ScreenFusedArgs fa)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_fused[];
-    if ((int)blockIdx.x < fa.prod_blocks) sc_screen_role<RG, S, W, D, PROBE>(fa.prod, (int)blockIdx.x, smem_fused);
+    if ((int)blockIdx.x < fa.prod_blocks) sc_screen_role<hdesc_rgh(RG), S, W, D, PROBE>(fa.prod, (int)blockIdx.x, smem_fused);
     else sc_align_role<RG, S, W>(fa.next, (int)blockIdx.x - fa.prod_blocks, smem_fused);
 }
 
@@ -494,273 +611,6 @@ __global__ __launch_bounds__(kScreenWaves * kWave, 2) void sc_align_kernel(Scree
     sc_align_role<RG, S, W>(ab, (int)blockIdx.x, smem_align);
 }
 
-// =====================================================================================================================
-// The same pass for grids whose sector count is not a multiple of 8 or whose search window exceeds 16 shifts
-// (80 x 180, search ratio 0.1: W = 19): k-steps of 8 sectors with the last one partly empty (B fragment zero, no load),
-// two M tiles of shift rows, every ring group's k-steps fully unrolled (23 per row has no common divisor with the load
-// ring), and an exact fp64 alignment with three shifts per lane (the two-sectors-per-lane filter of the narrow grids
-// needs S / 2 <= 64).  Error budget as above (K = R * S = 14 400 products per shift: the accumulation term grows to
-// 3 604 * 2^-23 = 4.3e-4, still inside kScreenEps).
-// =====================================================================================================================
-template <int S>
-__device__ __forceinline__ int align_keyframe_wide(const double (&vk)[(S + kWave - 1) / kWave], int lane, double *vk2, const double *vq)
-{
-    constexpr int SPL = (S + kWave - 1) / kWave;           // shifts (and sectors) per lane
-    constexpr int LA = S / SPL;                            // active lanes
-    static_assert(S % SPL == 0 && LA <= kWave, "shifts must tile the lanes");
-    const double kInf = __longlong_as_double(0x7ff0000000000000LL);
-    wave_fence();
-    if (lane < LA) {
-#pragma unroll
-        for (int u = 0; u < SPL; ++u) { vk2[SPL * lane + u] = vk[u]; vk2[SPL * lane + u + S] = vk[u]; }
-    }
-    if (lane == 0) { vk2[2 * S] = vk[0]; }                 // one past the doubled key: read by the last slide, never used
-    wave_fence();
-    // lane owns shifts s_k = SPL * lane + k; the key shifted by s at sector t is vk[(t - s) mod S] = p[t - k], p = vk2 + S - SPL * lane
-    const int ll = lane < LA ? lane : LA - 1;
-    const double *p = vk2 + S - SPL * ll;
-    double ss[SPL], w[SPL];
-#pragma unroll
-    for (int k = 0; k < SPL; ++k) { ss[k] = 0.0; w[k] = p[-k]; }
-#pragma unroll 4
-    for (int t = 0; t < S; ++t) {                          // sector order, as the reference's norm (D.h:1500-1502)
-        const double q = vq[t];
-        const double nxt = p[t + 1];
-#pragma unroll
-        for (int k = 0; k < SPL; ++k) { const double d = q - w[k]; ss[k] = ss[k] + d * d; }
-#pragma unroll
-        for (int k = SPL - 1; k > 0; --k) w[k] = w[k - 1];
-        w[0] = nxt;
-    }
-    double best = kInf;
-    int bshift = 0x7fffffff;
-#pragma unroll
-    for (int k = 0; k < SPL; ++k) {                        // ascending shifts, strict <: ties keep the lower shift
-        const double nk = sqrt(ss[k]);
-        if (lane < LA && nk < kBigDist && nk < best) { best = nk; bshift = SPL * lane + k; }
-    }
-    wave_argmin_dpp(best, bshift);
-    return __builtin_amdgcn_readfirstlane(best < kBigDist ? bshift : 0);
-}
-
-template <int RG, int S, int W, int D>
-__global__ __launch_bounds__(kScreenWaves * kWave, 2) void sc_screen_wide_kernel(ScreenBatchArgs ab)
-{
-    constexpr int NWV = kScreenWaves;
-    constexpr int RPW = RG / NWV;
-    constexpr int NXB = (S + 7) / 8;                       // k-steps per ring group; the last one may be partly empty
-    constexpr int MT = (W + 15) / 16;                      // M tiles of 16 shift rows
-    constexpr int QSX = NXB * 8 + 16 * MT;                 // query row: sectors, padding to the k-step grid, the wrap
-    constexpr int SPL = (S + kWave - 1) / kWave;
-    constexpr int NKS = RPW * NXB;
-    static_assert(RG % NWV == 0 && D <= NXB && RG <= kWave, "tiling");
-
-    const int nbk = ab.nb;
-    const int qi = ab.nq > 1 ? (int)blockIdx.x / nbk : 0;
-    const int bid = (int)blockIdx.x - qi * nbk;
-    const ScreenArgs &a = ab.q[qi];
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int SR = (W - 1) / 2;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    _Float16 *Qh = reinterpret_cast<_Float16 *>(smem_raw);                       // [RG + 1][QSX][4]
-    double *vq = reinterpret_cast<double *>(Qh + (size_t)(RG + 1) * QSX * 4);    // [S]
-    constexpr int kAlignDoubles = (2 * S + 2 + 1) & ~1;
-    double *vk2 = vq + S + (size_t)wave * kAlignDoubles;                         // per wave: the doubled sector key
-    f4v *part = reinterpret_cast<f4v *>(vq + S + (size_t)NWV * kAlignDoubles);   // [MT][NWV][64]
-    f4v *npart = part + MT * NWV * kWave;                                        // [MT][64]
-    int *s_start = reinterpret_cast<int *>(npart + MT * kWave);                  // [16]
-    int *bad_flag = s_start + kGroup;
-    int *q_bad_flag = bad_flag + kGroup;
-
-    if (threadIdx.x == 0) *q_bad_flag = 0;
-    for (int i = threadIdx.x; i < kGroup; i += blockDim.x) bad_flag[i] = 0;
-    for (int i = threadIdx.x; i < (RG + 1) * QSX; i += blockDim.x) {            // padding must be finite: B is zero there, 0 * x must stay 0
-        h4 z; z[0] = z[1] = z[2] = z[3] = (_Float16)0.0f;
-        *reinterpret_cast<h4 *>(Qh + (size_t)i * 4) = z;
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < RG * S; idx += blockDim.x) {
-        const int rg = idx / S, c = idx - rg * S;
-        const float4 v = a.q_desc[idx];
-        const float iv = a.q_inv[c];
-        if (iv != iv) *q_bad_flag = 1;
-        h4 hv;
-        hv[0] = (_Float16)(v.x * iv); hv[1] = (_Float16)(v.y * iv); hv[2] = (_Float16)(v.z * iv); hv[3] = (_Float16)(v.w * iv);
-        *reinterpret_cast<h4 *>(Qh + ((size_t)rg * QSX + c) * 4) = hv;
-        if (c + S < QSX) *reinterpret_cast<h4 *>(Qh + ((size_t)rg * QSX + c + S) * 4) = hv;
-    }
-    for (int c = threadIdx.x; c < S; c += blockDim.x) {
-        h4 ind; ind[0] = (_Float16)(a.q_inv[c] != 0.0f ? 1.0f : 0.0f); ind[1] = ind[2] = ind[3] = (_Float16)0.0f;
-        *reinterpret_cast<h4 *>(Qh + ((size_t)RG * QSX + c) * 4) = ind;
-        if (c + S < QSX) *reinterpret_cast<h4 *>(Qh + ((size_t)RG * QSX + c + S) * 4) = ind;
-        vq[c] = a.q_vkey[c];
-    }
-    __syncthreads();
-    const bool q_bad = *q_bad_flag != 0;
-
-    float4 qrk = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < RG) qrk = *reinterpret_cast<const float4 *>(a.q_rkey + 4 * lane);
-    const int n16 = lane & 15, j4 = lane >> 4;
-    const int ngroups = (a.n + kGroup - 1) / kGroup;
-    float run_min = __int_as_float(0x7f800000);
-    constexpr int LA = S / SPL;
-    const int la = lane < LA ? lane : LA - 1;
-
-    for (int g = bid; g < ngroups; g += nbk) {
-        const int c_base = g * kGroup;
-        // ---- phase A: exact alignment of keyframes 4w .. 4w+3 (three shifts per lane) + their ring-key metric ----
-        auto fetch = [&](int u, double (&vk_o)[SPL], float4 &rk_o) {
-            const int ci = c_base + wave * (kGroup / NWV) + u;
-            const int slot = a.slot_base + (ci < a.n ? ci : a.n - 1);
-#pragma unroll
-            for (int k = 0; k < SPL; ++k) vk_o[k] = a.vkey[(size_t)slot * S + SPL * la + k];
-            rk_o = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (lane < RG) rk_o = a.rkey4[(size_t)lane * a.rk_cap + slot];
-        };
-        double vk_cur[SPL]; float4 rk_cur;
-        fetch(0, vk_cur, rk_cur);
-#pragma unroll 1
-        for (int u = 0; u < kGroup / NWV; ++u) {
-            const int ci = c_base + wave * (kGroup / NWV) + u;
-            double vk_nxt[SPL]; float4 rk_nxt = rk_cur;
-#pragma unroll
-            for (int k = 0; k < SPL; ++k) vk_nxt[k] = vk_cur[k];
-            if (u + 1 < kGroup / NWV) fetch(u + 1, vk_nxt, rk_nxt);
-            const int al = align_keyframe_wide<S>(vk_cur, lane, vk2, vq);
-            if (lane == 0) s_start[wave * (kGroup / NWV) + u] = wrapS(al - SR, S);
-            float grp = 0.0f;
-            if (lane < RG) {
-                const float4 b = rk_cur;
-                const float d0 = qrk.x - b.x, d1 = qrk.y - b.y, d2 = qrk.z - b.z, d3 = qrk.w - b.w;
-                grp = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-            }
-            float result = 0.0f;
-#pragma unroll
-            for (int r = 0; r < RG; ++r) result += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(grp), r));
-            if (lane == 0 && ci < a.n) a.out_d2[ci] = result;
-#pragma unroll
-            for (int k = 0; k < SPL; ++k) vk_cur[k] = vk_nxt[k];
-            rk_cur = rk_nxt;
-        }
-        __syncthreads();                                                         // B1
-
-        // ---- phase G ------------------------------------------------------------------------------------------------
-        const int ci_n = c_base + n16;
-        const int slot_n = a.slot_base + (ci_n < a.n ? ci_n : a.n - 1);
-        const int b_n = s_start[n16];
-        const int col0 = wrapS(2 * j4 - b_n, S);
-        const int first_slot = a.slot_base + c_base;
-        const unsigned int rel_n = (unsigned int)(slot_n - first_slot);
-        const char *inv_base = reinterpret_cast<const char *>(a.inv + (size_t)first_slot * S);
-        const unsigned int inv_off = rel_n * (unsigned int)(S * 4);
-        auto col_of = [&](int xb) { int c = col0 + 8 * xb; return c >= S ? c - S : c; };   // col0 < S, 8 xb < S
-        auto in_grid = [&](int xb, int e) { return 8 * xb + 2 * j4 + e < S; };            // the last k-step is partly empty
-        float iv0[NXB], iv1[NXB];
-        bool bad = false;
-#pragma unroll
-        for (int xb = 0; xb < NXB; ++xb) {
-            const int c = col_of(xb), c1 = c + 1 == S ? 0 : c + 1;
-            iv0[xb] = in_grid(xb, 0) ? *reinterpret_cast<const float *>(inv_base + (inv_off + (unsigned int)c * 4u)) : 0.0f;
-            iv1[xb] = in_grid(xb, 1) ? *reinterpret_cast<const float *>(inv_base + (inv_off + (unsigned int)c1 * 4u)) : 0.0f;
-        }
-#pragma unroll
-        for (int xb = 0; xb < NXB; ++xb) bad |= (iv0[xb] != iv0[xb]) | (iv1[xb] != iv1[xb]);
-        if (bad) bad_flag[n16] = 1;
-        const char *desc_base = reinterpret_cast<const char *>(a.desc + (size_t)first_slot * (RG * S) + (size_t)(wave * RPW) * S);
-        const unsigned int desc_off = rel_n * (unsigned int)(RG * S * 16);
-        float4 ra[D], rb[D];
-        auto issue = [&](int sl, int r_i, int xb_i) {      // r_i, xb_i are compile-time after unrolling
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            const unsigned int row = desc_off + (unsigned int)r_i * (unsigned int)(S * 16);
-            const int c = col_of(xb_i), c1 = c + 1 == S ? 0 : c + 1;
-            ra[sl] = in_grid(xb_i, 0) ? *reinterpret_cast<const float4 *>(desc_base + (row + (unsigned int)c * 16u)) : z;
-            rb[sl] = in_grid(xb_i, 1) ? *reinterpret_cast<const float4 *>(desc_base + (row + (unsigned int)c1 * 16u)) : z;
-        };
-#pragma unroll
-        for (int sl = 0; sl < D; ++sl) issue(sl, sl / NXB, sl % NXB);
-        f4v acc[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = f4v{0.f, 0.f, 0.f, 0.f};
-        const _Float16 *qbase = Qh + ((size_t)(wave * RPW) * QSX + 2 * j4 + n16) * 4;
-        auto load_a = [&](const _Float16 *ap) -> h8 {
-            const h4 alo = *reinterpret_cast<const h4 *>(ap), ahi = *reinterpret_cast<const h4 *>(ap + 4);
-            return __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
-        };
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            const int r = ks / NXB, xb = ks % NXB, sl = ks % D;
-            const float4 u = ra[sl], v = rb[sl];
-            if (ks + D < NKS) issue(sl, (ks + D) / NXB, (ks + D) % NXB);
-            h8 bfrag;
-            bfrag[0] = (_Float16)(u.x * iv0[xb]); bfrag[1] = (_Float16)(u.y * iv0[xb]);
-            bfrag[2] = (_Float16)(u.z * iv0[xb]); bfrag[3] = (_Float16)(u.w * iv0[xb]);
-            bfrag[4] = (_Float16)(v.x * iv1[xb]); bfrag[5] = (_Float16)(v.y * iv1[xb]);
-            bfrag[6] = (_Float16)(v.z * iv1[xb]); bfrag[7] = (_Float16)(v.w * iv1[xb]);
-            const _Float16 *ap = qbase + ((size_t)r * QSX + 8 * xb) * 4;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const h8 afrag = load_a(ap + (size_t)(16 * m) * 4);
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag, acc[m], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int m = 0; m < MT; ++m) part[(m * NWV + wave) * kWave + lane] = acc[m];
-        if (wave == 1 % NWV) {
-            f4v nacc[MT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) nacc[m] = f4v{0.f, 0.f, 0.f, 0.f};
-            const _Float16 *irow = Qh + ((size_t)RG * QSX + 2 * j4 + n16) * 4;
-#pragma unroll
-            for (int xb = 0; xb < NXB; ++xb) {
-                h8 bfrag;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bfrag[e] = (_Float16)0.0f;
-                bfrag[0] = (_Float16)(iv0[xb] != 0.0f ? 1.0f : 0.0f);
-                bfrag[4] = (_Float16)(iv1[xb] != 0.0f ? 1.0f : 0.0f);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const h8 afrag = load_a(irow + (size_t)(8 * xb + 16 * m) * 4);
-                    nacc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag, nacc[m], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int m = 0; m < MT; ++m) npart[m * kWave + lane] = nacc[m];
-        }
-        __syncthreads();                                                         // B2
-
-        if (wave == 0) {
-            float dmin = __int_as_float(0x7f800000);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                f4v s = part[(m * NWV) * kWave + lane];
-#pragma unroll
-                for (int w = 1; w < NWV; ++w) s += part[(m * NWV + w) * kWave + lane];
-                const f4v ne = npart[m * kWave + lane];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int t = 16 * m + 4 * j4 + r;
-                    const float d = 1.0f - s[r] / ne[r];
-                    if (t < W && ne[r] > 0.5f && d < dmin) dmin = d;
-                }
-            }
-            dmin = fminf(dmin, __shfl_xor(dmin, 16, kWave));
-            dmin = fminf(dmin, __shfl_xor(dmin, 32, kWave));
-            const bool mine = lane < kGroup && ci_n < a.n;
-            const bool exact_only = q_bad || bad_flag[n16] != 0 || !(dmin == dmin);
-            if (mine) a.out_approx[ci_n] = exact_only ? __int_as_float(0xff800000) : dmin;
-            float contrib = (mine && !exact_only) ? dmin : __int_as_float(0x7f800000);
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) contrib = fminf(contrib, __shfl_xor(contrib, off, kWave));
-            run_min = fminf(run_min, __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(contrib))));
-            if (lane < kGroup) bad_flag[lane] = 0;
-        }
-    }
-    if (wave == 0 && lane == 0 && run_min < __int_as_float(0x7f800000)) atomicMin(a.t_min, float_to_ordered_u(run_min));
-}
 
 // ---- select: survivors of the screening (ascending slot order) + the ring-key top-k ----------------------------
 // One workgroup per query.  survivors[i] = database slots (ascending) whose d~ <= min d~ + 2 eps, or flagged
@@ -871,8 +721,7 @@ static int fill_screen_args(const DbView &db, const ScreenBatch &sb, int align_f
         if (sb.n[i] <= 0) return -1;
         ScreenArgs &a = ab->q[i];
         const size_t q = (size_t)sb.slot[i];
-        a.desc = db.desc; a.vkey = db.vkey; a.inv = db.inv;
-        a.q_desc = db.desc + q * (size_t)(db.RG * db.S); a.q_vkey = db.vkey + q * db.S; a.q_inv = db.inv + q * db.S;
+        a.vkey = db.vkey; a.q_vkey = db.vkey + q * db.S;
         a.q_rkey = db.rkey + q * (size_t)(4 * db.RG);
         a.hdesc = db.hdesc; a.kmask = db.kmask; a.q_hdesc = db.hdesc + q * (size_t)db.hstride; a.q_kmask = db.kmask + q * 8;
         a.rkey4 = db.rkey4; a.rk_cap = db.cap;
@@ -887,64 +736,45 @@ static int fill_screen_args(const DbView &db, const ScreenBatch &sb, int align_f
     return nmax;
 }
 
-hipError_t launch_sc_screen_batch(const DbView &db, const ScreenBatch &sb, int SR, int align_filter, int num_cu, hipStream_t stream, int phases,
-                                  const ScreenBatch *next)
+// one grid: RG ring groups, S sectors, W shifts; OCC0 / OCC1 = waves per SIMD of the default kernel / of variant 1
+template <int RG, int S, int W, int OCC0, int OCC1>
+static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, int align_filter, int num_cu, hipStream_t stream, int phases,
+                                     const ScreenBatch *next)
 {
-    if (sb.nq < 1 || sb.nq > kMaxQueryBatch || !sc_screen_supported(db, SR)) return hipErrorInvalidValue;
-    const bool wide = sc_screen_is_wide(db, SR);
-    constexpr int RG = 16, S = 120, W = 13;
+    constexpr int RGH = hdesc_rgh(RG);
     ScreenBatchArgs ab{};
     const int nmax = fill_screen_args(db, sb, align_filter, &ab);
     if (nmax < 0) return hipErrorInvalidValue;
     const int ngroups = (nmax + kGroup - 1) / kGroup;
-    if (wide) {
-        constexpr int RGw = 20, Sw = 180, Ww = 19, Dw = 5;
-        constexpr int NXB = (Sw + 7) / 8, MT = (Ww + 15) / 16, QSXw = NXB * 8 + 16 * MT, kAlignDoubles = (2 * Sw + 2 + 1) & ~1;
-        const size_t ldsw = (size_t)(RGw + 1) * QSXw * 4 * 2 + (size_t)Sw * 8 + (size_t)kScreenWaves * kAlignDoubles * 8 +
-                            (size_t)MT * (kScreenWaves + 1) * kWave * 16 + (size_t)(2 * kGroup + 4) * 4;
-        int blocks = num_cu * 2;
-        if (blocks > ngroups) blocks = ngroups;
-        if (blocks > kScreenMaxBlocks) blocks = kScreenMaxBlocks;
-        ab.nb = blocks;
-        static std::atomic<bool> attr_set_dev[64];
-        int dev_ = 0; (void)hipGetDevice(&dev_);
-        std::atomic<bool> &attr_set = attr_set_dev[dev_ & 63];
-        if (!attr_set.load(std::memory_order_acquire)) {
-            hipError_t e = hipFuncSetAttribute((const void *)sc_screen_wide_kernel<RGw, Sw, Ww, Dw>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            attr_set.store(true, std::memory_order_release);
-        }
-        hipLaunchKernelGGL((sc_screen_wide_kernel<RGw, Sw, Ww, Dw>), dim3(blocks * sb.nq), dim3(kScreenWaves * kWave), ldsw, stream, ab);
-        return hipGetLastError();
-    }
-    if (db.hstride != RG * S || !sb.starts) return hipErrorInvalidValue;
-    static std::atomic<bool> attr_set_dev[64];                 // per device
+    if (db.hstride != RGH * S || !sb.starts) return hipErrorInvalidValue;
+    static std::atomic<bool> attr_set_dev[64];                 // per grid (template instance) and device
     int dev_ = 0; (void)hipGetDevice(&dev_);
     std::atomic<bool> &attr_set = attr_set_dev[dev_ & 63];
-    // variants (SCL_SCREEN_VARIANT): 0 = 15 k-steps in flight, 3 waves/SIMD; 1 = 15 in flight, 2 waves/SIMD; 2 = 5 in flight, 3 waves/SIMD
+    // variants (SCL_SCREEN_VARIANT): 0 = 15 k-steps in flight; 1 = the other register budget; 2 = 5 k-steps in flight
     static const int variant = [] { const char *e = getenv("SCL_SCREEN_VARIANT"); return e ? atoi(e) : 0; }();
-    void (*kern)(ScreenFusedArgs) = sc_screen_kernel<RG, S, W, 15, 3>;
-    if (variant == 1) kern = sc_screen_kernel<RG, S, W, 15, 2>;
-    if (variant == 2) kern = sc_screen_kernel<RG, S, W, 5, 3>;
+    void (*kern)(ScreenFusedArgs) = sc_screen_kernel<RG, S, W, 15, OCC0>;
+    if (variant == 1) kern = sc_screen_kernel<RG, S, W, 15, OCC1>;
+    if (variant == 2) kern = sc_screen_kernel<RG, S, W, 5, OCC0>;
 #ifdef SCL_DIAGNOSTICS
     static const int probe = [] { const char *e = getenv("SCL_SCREEN_PROBE"); return e ? atoi(e) : 0; }();
-    if (probe == 2) kern = sc_screen_kernel<RG, S, W, 15, 3, 2>;
+    if (probe == 2) kern = sc_screen_kernel<RG, S, W, 15, OCC0, 2>;
 #else
     const int probe = 0;
 #endif
-    constexpr int MT = (S + 15) / 16, BST = 16 * MT + 4, QSX = S + 16;
-    const size_t lds0 = (size_t)S * 8 + (size_t)(32 * MT) * 4 + (size_t)kScreenWaves * ((2 * S + 2) * 8 + kGroup * BST * 4);
-    const size_t lds1 = (size_t)QSX * (RG * 8 + 32) + (size_t)S * 16 + (size_t)kScreenWaves * kGroup * kTileStride + (size_t)(2 * kScreenWaves) * kWave * 16;
+    constexpr int MTA = (S + 15) / 16, BST = 16 * MTA + 4, MT = (W + 15) / 16, QSX = S + 16 * MT, MW = ((S + 63) / 64 + 1) / 2;
+    const size_t lds0 = (size_t)S * 8 + (size_t)(32 * MTA) * 4 + (size_t)kScreenWaves * ((2 * S + 2) * 8 + kGroup * BST * 4);
+    const size_t lds1 = (size_t)QSX * (RGH * 8 + 32) + (size_t)S * MW * 16 + (size_t)kScreenWaves * kGroup * kTileStride +
+                        (size_t)(2 * kScreenWaves * MT) * kWave * 16;
     if (!attr_set.load(std::memory_order_acquire)) {
-        for (auto k : {(void (*)(ScreenFusedArgs))sc_screen_kernel<RG, S, W, 15, 3>, (void (*)(ScreenFusedArgs))sc_screen_kernel<RG, S, W, 15, 2>,
-                       (void (*)(ScreenFusedArgs))sc_screen_kernel<RG, S, W, 5, 3>}) {
-            hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        for (auto k : {(void (*)(ScreenFusedArgs))sc_screen_kernel<RG, S, W, 15, OCC0>, (void (*)(ScreenFusedArgs))sc_screen_kernel<RG, S, W, 15, OCC1>,
+                       (void (*)(ScreenFusedArgs))sc_screen_kernel<RG, S, W, 5, OCC0>}) {
+            hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             if (e != hipSuccess) return e;
         }
-        hipError_t e = hipFuncSetAttribute((const void *)sc_align_kernel<RG, S, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void *)sc_align_kernel<RG, S, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (e != hipSuccess) return e;
 #ifdef SCL_DIAGNOSTICS
-        (void)hipFuncSetAttribute((const void *)sc_screen_kernel<RG, S, W, 15, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void *)sc_screen_kernel<RG, S, W, 15, OCC0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
 #endif
         attr_set.store(true, std::memory_order_release);
     }
@@ -979,6 +809,14 @@ hipError_t launch_sc_screen_batch(const DbView &db, const ScreenBatch &sb, int S
     const size_t lds = extra && lds0 > lds1 ? lds0 : lds1;
     hipLaunchKernelGGL(kern, dim3(fa.prod_blocks + extra), dim3(kScreenWaves * kWave), lds, stream, fa);
     return hipGetLastError();
+}
+
+hipError_t launch_sc_screen_batch(const DbView &db, const ScreenBatch &sb, int SR, int align_filter, int num_cu, hipStream_t stream, int phases,
+                                  const ScreenBatch *next)
+{
+    if (sb.nq < 1 || sb.nq > kMaxQueryBatch || !sc_screen_supported(db, SR)) return hipErrorInvalidValue;
+    if (sc_screen_is_wide(db, SR)) return launch_screen_grid<20, 180, 19, 2, 2>(db, sb, align_filter, num_cu, stream, phases, next);   // 80 x 180
+    return launch_screen_grid<16, 120, 13, 3, 2>(db, sb, align_filter, num_cu, stream, phases, next);                                   // 64 x 120
 }
 
 }  // namespace scl
