@@ -252,6 +252,9 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
         // ---- the 16 sector keys: 16 * S / 2 double2, consecutive in memory, narrowed to fp32 into the B image ----
         const double2 *src = reinterpret_cast<const double2 *>(a.vkey + (size_t)first_slot * S);
         wave_fence();
+#ifdef SCL_DIAGNOSTICS
+        if (a.align_filter != 3)                                                 // probe 3: no sector-key reads (stale B image)
+#endif
 #pragma unroll 5
         for (int it = 0; it < (kGroup * L + kWave - 1) / kWave; ++it) {
             const int f = it * kWave + lane;
@@ -261,6 +264,9 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
             *reinterpret_cast<f2 *>(Bs + n * BST + 2 * u2) = f2{(float)v.x, (float)v.y};
         }
         wave_fence();
+#ifdef SCL_DIAGNOSTICS
+        if (a.align_filter == 2) continue;                                       // probe: the role's sector-key reads alone
+#endif
         // ---- c~[s][n] for all shifts: MT tiles x KB blocks x 4 steps of K = 4 ----
         f4v acc[MT];
 #pragma unroll
@@ -311,6 +317,9 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
         const bool uniq = use_filter && sane && (v2 < v1 - 4.0f * eps);
         if (mine && uniq) a.starts[c_base + lane] = wrapS(a1 - SR, S);
         unsigned long long amb = __builtin_amdgcn_ballot_w64(mine && !uniq);
+#ifdef SCL_DIAGNOSTICS
+        if (a.align_filter == 3) { amb = 0; if (mine) a.starts[c_base + lane] = 0; }
+#endif
         if (amb && lane == 0 && a.fallbacks) atomicAdd(a.fallbacks, (unsigned long long)__popcll(amb));
         while (amb) {                                                            // the reference's own evaluation, one keyframe at a time
             const int n = __ffsll((long long)amb) - 1;
@@ -590,9 +599,8 @@ __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const 
 // One launch = the screening products of a batch of scans and, in further workgroups of the same grid, the alignment of
 // the NEXT batch (fa.next.nq = 0: none): the products are HBM bound, the alignment matrix-core bound, and the workgroups
 // of the second take the third wave slot per SIMD the first leaves free.  (Two kernels on two streams do the same in
-// principle; measured, the dispatcher then lets the alignment crowd out the products.)  Workgroups of the products come
-// first in the grid, so they are dispatched first.
-struct ScreenFusedArgs { ScreenBatchArgs prod; ScreenBatchArgs next; int prod_blocks; };
+// principle; measured, the dispatcher then lets the alignment crowd out the products.)
+struct ScreenFusedArgs { ScreenBatchArgs prod; ScreenBatchArgs next; int prod_blocks, align_blocks, period; };
 
 constexpr int hdesc_rgh(int RG) { return ((RG * 8 + 63) / 64) * 8; }   // 8-byte elements per sector of hdesc: whole k-steps of 64 B
 
@@ -600,8 +608,13 @@ template <int RG, int S, int W, int D, int OCC, int PROBE = 0>
 __global__ __launch_bounds__(kScreenWaves * kWave, OCC) void sc_screen_kernel(ScreenFusedArgs fa)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_fused[];
-    if ((int)blockIdx.x < fa.prod_blocks) sc_screen_role<hdesc_rgh(RG), S, W, D, PROBE>(fa.prod, (int)blockIdx.x, smem_fused);
-    else sc_align_role<RG, S, W>(fa.next, (int)blockIdx.x - fa.prod_blocks, smem_fused);
+    // every period-th workgroup of the grid belongs to the alignment, as long as it has any: the dispatcher hands out
+    // workgroups in index order, so the (short) alignment workgroups run beside the products from the start of the launch
+    // instead of queueing behind all of them
+    const int b = (int)blockIdx.x, j = b / fa.period;
+    const int before = j < fa.align_blocks ? j : fa.align_blocks;               // alignment workgroups with a smaller index
+    if (b - j * fa.period == fa.period - 1 && j < fa.align_blocks) sc_align_role<RG, S, W>(fa.next, j, smem_fused);
+    else sc_screen_role<hdesc_rgh(RG), S, W, D, PROBE>(fa.prod, b - before, smem_fused);
 }
 
 template <int RG, int S, int W>
@@ -778,13 +791,18 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
 #endif
         attr_set.store(true, std::memory_order_release);
     }
-    auto align_blocks = [&](int groups) {                      // one wave per 16 keyframes, at most one workgroup per CU and query beside the products
+    // workgroups of the alignment per query: one wave per 16 keyframes, at most two workgroups per CU over all queries of the
+    // batch (measured beside the products: 128 per query for four queries on 256 CUs is the best point; 136 and more cost 5 %)
+    auto align_blocks = [&](int groups, int nq) {
         int b = (groups + kScreenWaves - 1) / kScreenWaves;
-        return b > num_cu ? num_cu : b;
+        static const int cap_env = [] { const char *e = getenv("SCL_ALIGN_WGS"); return e ? atoi(e) : 0; }();
+        int cap = cap_env > 0 ? cap_env : 2 * num_cu / (nq > 0 ? nq : 1);
+        if (cap < 1) cap = 1;
+        return b > cap ? cap : b;
     };
     // the alignment of this batch, on its own (the first launch of a sequence, or a caller that has only one)
     if ((phases & kScreenAlign) && probe != 3) {
-        ab.nb = align_blocks(ngroups);
+        ab.nb = align_blocks(ngroups, sb.nq);
         hipLaunchKernelGGL((sc_align_kernel<RG, S, W>), dim3(ab.nb * sb.nq), dim3(kScreenWaves * kWave), lds0, stream, ab);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -803,10 +821,16 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
         if (next->nq < 1 || next->nq > kMaxQueryBatch) return hipErrorInvalidValue;
         const int nmax2 = fill_screen_args(db, *next, align_filter, &fa.next);
         if (nmax2 < 0) return hipErrorInvalidValue;
-        fa.next.nb = align_blocks((nmax2 + kGroup - 1) / kGroup);
+        fa.next.nb = align_blocks((nmax2 + kGroup - 1) / kGroup, next->nq);
         extra = fa.next.nb * next->nq;
+#ifdef SCL_DIAGNOSTICS
+        if (probe == 5 || probe == 6) for (int i = 0; i < kMaxQueryBatch; ++i) fa.next.q[i].align_filter = probe == 5 ? 2 : 3;
+#endif
     }
     const size_t lds = extra && lds0 > lds1 ? lds0 : lds1;
+    fa.align_blocks = extra;
+    fa.period = extra > 0 ? (fa.prod_blocks + extra) / extra : 1;
+    if (fa.period < 1) fa.period = 1;
     hipLaunchKernelGGL(kern, dim3(fa.prod_blocks + extra), dim3(kScreenWaves * kWave), lds, stream, fa);
     return hipGetLastError();
 }
