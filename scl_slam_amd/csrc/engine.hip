@@ -11,7 +11,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <chrono>
 #include <mutex>
 #include <new>
 #include <string>
@@ -844,31 +843,35 @@ int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, c
 // ---- screened full-DB passes (64x120 grid; sc_screen.hip) --------------------------------------------------------
 // One screening launch for up to four queries: slots qslot[i] against [lo[i], lo[i] + n[i]), results in buffer sets
 // set0 + i.  The event pair of the profile brackets this launch: it is the dominant kernel of a pass.
-// nq_next > 0: the nq_next queries behind the nq of this launch (same arrays, buffer sets set0 + nq ...) are the next launch;
-// their alignment rides in this one (phases of the next call: kScreenProducts only).
-int launch_screen_group(scl_engine *e, const int *qslot, const int *lo, const int *n, int nq, int set0,
-                        int phases = kScreenAlign | kScreenProducts, int nq_next = 0, hipStream_t stream = nullptr)
+// One screening launch group: queries qslot[0..nq) against [lo[i], lo[i] + n[i]), buffer sets set0 + i.
+struct ScreenGroup { const int *qslot, *lo, *n; int nq, set0; };
+// next (optional, nq > 0): the launch that will follow; its alignment rides in this one (the next call then passes
+// kScreenProducts only).
+int launch_screen_group(scl_engine *e, const ScreenGroup &cur, int phases = kScreenAlign | kScreenProducts,
+                        const ScreenGroup *next = nullptr, hipStream_t stream = nullptr)
 {
     if (!stream) stream = e->stream;
-    auto fill = [&](ScreenBatch &sb, int first, int count) {
-        sb.nq = count;
-        for (int j = 0; j < count; ++j) { sb.slot[j] = qslot[first + j]; sb.base[j] = lo[first + j]; sb.n[j] = n[first + j]; sb.buf[j] = set0 + first + j; }
+    auto fill = [&](ScreenBatch &sb, const ScreenGroup &g) {
+        sb.nq = g.nq;
+        for (int j = 0; j < g.nq; ++j) { sb.slot[j] = g.qslot[j]; sb.base[j] = g.lo[j]; sb.n[j] = g.n[j]; sb.buf[j] = g.set0 + j; }
         sb.pair_stride = e->set_stride;
-        sb.approx = e->d_approx; sb.starts = e->d_starts; sb.align_fallbacks = e->d_align_fallbacks; sb.ring_d2 = e->d_ring_d2; sb.survivors = nullptr; sb.n_surv = nullptr; sb.t_min = e->d_tmin;
+        sb.approx = e->d_approx; sb.starts = e->d_starts; sb.align_fallbacks = e->d_align_fallbacks; sb.ring_d2 = e->d_ring_d2;
+        sb.survivors = nullptr; sb.n_surv = nullptr; sb.t_min = e->d_tmin;
         sb.k = e->cfg.num_candidates; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
     };
     ScreenBatch sb{}, nx{};
-    fill(sb, 0, nq);
-    if (nq_next > 0) fill(nx, nq, nq_next);
-    if (phases & kScreenAlign) for (int j = 0; j < nq; ++j) e->align_pairs += (uint64_t)n[j];
-    for (int j = 0; j < nq_next; ++j) e->align_pairs += (uint64_t)n[nq + j];
-    if ((phases & kScreenAlign) && (phases & kScreenProducts) && nq_next > 0) {   // a sequence's first launch: its own alignment outside the
+    fill(sb, cur);
+    const bool has_next = next && next->nq > 0;
+    if (has_next) fill(nx, *next);
+    if (phases & kScreenAlign) for (int j = 0; j < cur.nq; ++j) e->align_pairs += (uint64_t)cur.n[j];
+    if (has_next) for (int j = 0; j < next->nq; ++j) e->align_pairs += (uint64_t)next->n[j];
+    if ((phases & kScreenAlign) && (phases & kScreenProducts) && has_next) {   // a sequence's first launch: its own alignment outside the
         SCL_HIP(e, launch_sc_screen_batch(db_view(e), sb, e->SR, sc_align_filter_enabled(), e->num_cu, stream, kScreenAlign, nullptr));   // event pair
         phases = kScreenProducts;
     }
     ProfScope ps(e, P_SC, stream);
-    SCL_HIP(e, launch_sc_screen_batch(db_view(e), sb, e->SR, sc_align_filter_enabled(), e->num_cu, stream, phases, nq_next > 0 ? &nx : nullptr));
-    if (ps.active()) { for (int j = 0; j < nq; ++j) e->prof.sc_distance_pairs += (uint64_t)n[j]; }
+    SCL_HIP(e, launch_sc_screen_batch(db_view(e), sb, e->SR, sc_align_filter_enabled(), e->num_cu, stream, phases, has_next ? &nx : nullptr));
+    if (ps.active()) { for (int j = 0; j < cur.nq; ++j) e->prof.sc_distance_pairs += (uint64_t)cur.n[j]; }
     return SCL_OK;
 }
 
@@ -1017,7 +1020,7 @@ int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, c
             // screening pass (fp16 matrix-core bounds around every reference distance) -> the exact fp64 kernel on the
             // survivors only; the winner is the reference's, bit for bit (sc_screen.hip)
             if ((rc = ensure_sets(e, (size_t)nmax))) return rc;
-            if ((rc = launch_screen_group(e, qb.slot, qb.base, qb.n, qb.nq, 0))) return rc;
+            if ((rc = launch_screen_group(e, ScreenGroup{qb.slot, qb.base, qb.n, qb.nq, 0}))) return rc;
             if (wide) {
                 // 80 x 180: survivors (+ ring-key top-k) by the select launch, then per query the exact one-sector-per-lane
                 // kernel on its survivors and the arg-min
@@ -1112,7 +1115,8 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
 {
     constexpr int NS = scl_engine::kScreenSets;
     constexpr int CH = NS / 2;                               // scans per chunk: the two chunks in flight use the two halves of the buffer sets
-    struct Chunk { int first = 0, count = 0; bool busy = false; std::vector<int> lo, empty; };
+    struct List { int qslot[CH], qlo[CH], qn[CH], pos[CH], m = 0; };     // the scans of a chunk that have something to score
+    struct Chunk { int first = 0, count = 0; bool busy = false, aligned = false; std::vector<int> lo, empty; };
     Chunk ch[2];
     int nmax = 1;
     for (int i = 0; i < n_queries; ++i) {
@@ -1121,44 +1125,65 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
     }
     int rc = ensure_sets(e, (size_t)nmax);
     if (rc) return rc;
-    // the side streams start behind everything the main stream holds (ingests wrote the arrays they read)
+    // the side stream starts behind everything the main stream holds (ingests wrote the arrays it reads)
     SCL_HIP(e, hipEventRecord(e->ev_align_gate, e->stream));
     SCL_HIP(e, hipStreamWaitEvent(e->stream_surv, e->ev_align_gate, 0));
-    auto submit = [&](int c, int first, int count) -> int {
-        Chunk &k = ch[c];
-        k.first = first; k.count = count; k.lo.assign((size_t)count, 0); k.empty.assign((size_t)count, 1);
-        int qslot[NS], qlo[NS], qn[NS], set_of[NS]; double *out3[NS];
-        int m = 0;                                           // scans of the chunk that have something to score
+    auto build = [&](int first, int count, List &L, Chunk *k) -> int {
+        L.m = 0;
         for (int i = 0; i < count; ++i) {
             const int q = queries[first + i];
             int slot;
             if (q >= 0) { if (q >= e->n) return fail(e, SCL_ERR_OUT_OF_RANGE, "query slot out of range"); slot = q; }
             else { const int j = -1 - q; if (j >= scl_engine::kStage || !e->staged[j]) return fail(e, SCL_ERR_INVALID_ARG, "no staged query"); slot = e->cap + j; }
             const int l = lo[first + i] < 0 ? 0 : lo[first + i], h = hi[first + i] > e->n ? e->n : hi[first + i];
-            k.lo[(size_t)i] = l;
+            if (k) k->lo[(size_t)i] = l;
             if (h - l <= 0) continue;
-            k.empty[(size_t)i] = 0;
-            qslot[m] = slot; qlo[m] = l; qn[m] = h - l; set_of[m] = i;
-            out3[m] = e->h_stream_out + ((size_t)c * NS + (size_t)i) * 8;
-            ++m;
+            if (k) k->empty[(size_t)i] = 0;
+            L.qslot[L.m] = slot; L.qlo[L.m] = l; L.qn[L.m] = h - l; L.pos[L.m] = i;
+            ++L.m;
         }
-        // buffer set = first set of this half + position among the non-empty scans (consecutive within a launch).
-        // The two halves alternate, and a chunk is submitted only after the chunk two before it was collected, so nothing
-        // still reads or writes these sets.
-        const int set0 = c * CH;
-        // Every launch carries the alignment of the launch behind it; only the chunk's first one aligns for itself.
-        for (int g = 0; g < m; g += spl) {
-            const int w = m - g < spl ? m - g : spl;
-            const int wn = m - g - w < spl ? m - g - w : spl;
-            if ((rc = launch_screen_group(e, qslot + g, qlo + g, qn + g, w, set0 + g, g == 0 ? (kScreenAlign | kScreenProducts) : kScreenProducts, wn))) return rc;
+        return SCL_OK;
+    };
+    // c = half of the buffer sets; first / count = this chunk; nfirst / ncount = the chunk behind it (ncount = 0: none)
+    auto submit = [&](int c, int first, int count, int nfirst, int ncount) -> int {
+        Chunk &k = ch[c];
+        k.first = first; k.count = count; k.lo.assign((size_t)count, 0); k.empty.assign((size_t)count, 1);
+        List cur, nxt;
+        if ((rc = build(first, count, cur, &k))) return rc;
+        if (ncount > 0 && (rc = build(nfirst, ncount, nxt, nullptr))) return rc;
+        double *out3[CH];
+        for (int j = 0; j < cur.m; ++j) out3[j] = e->h_stream_out + ((size_t)c * NS + (size_t)cur.pos[j]) * 8;
+        // buffer set = first set of this half + position among the non-empty scans (consecutive within a launch).  The two
+        // halves alternate, and a chunk is submitted only after the chunk two before it was collected.
+        const int set0 = c * CH, nset0 = (c ^ 1) * CH;
+        // Every launch carries the alignment of the launch behind it -- the chunk's last one that of the next chunk's first
+        // launch, whose buffer sets the exact pass of the chunk before this one may still be reading: the main stream waits
+        // for it there (it finished long ago).  Only the very first launch aligns for itself.
+        bool next_aligned = false;
+        for (int g = 0; g < cur.m; g += spl) {
+            const int w = cur.m - g < spl ? cur.m - g : spl;
+            const ScreenGroup grp{cur.qslot + g, cur.qlo + g, cur.qn + g, w, set0 + g};
+            ScreenGroup nx{nullptr, nullptr, nullptr, 0, 0};
+            if (g + w < cur.m) {
+                const int wn = cur.m - g - w < spl ? cur.m - g - w : spl;
+                nx = ScreenGroup{cur.qslot + g + w, cur.qlo + g + w, cur.qn + g + w, wn, set0 + g + w};
+            } else if (ncount > 0 && nxt.m > 0) {
+                const int wn = nxt.m < spl ? nxt.m : spl;
+                nx = ScreenGroup{nxt.qslot, nxt.qlo, nxt.qn, wn, nset0};
+                if (ch[c ^ 1].busy) SCL_HIP(e, hipStreamWaitEvent(e->stream, e->ev_chunk[c ^ 1], 0));
+                next_aligned = true;
+            }
+            const int phases = (g == 0 && !k.aligned) ? (kScreenAlign | kScreenProducts) : kScreenProducts;
+            if ((rc = launch_screen_group(e, grp, phases, nx.nq > 0 ? &nx : nullptr))) return rc;
         }
         SCL_HIP(e, hipEventRecord(e->ev_k1[c], e->stream));
         SCL_HIP(e, hipStreamWaitEvent(e->stream_surv, e->ev_k1[c], 0));
-        if (m > 0 && (rc = launch_survivor_pass(e, qslot, qlo, qn, m, set0, out3, e->stream_surv))) return rc;
-        (void)set_of;
+        if (cur.m > 0 && (rc = launch_survivor_pass(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, e->stream_surv))) return rc;
         SCL_HIP(e, hipEventRecord(e->ev_chunk[c], e->stream_surv));
         k.busy = true;
-        e->last_pass_empty = m == 0;
+        k.aligned = false;
+        ch[c ^ 1].aligned = next_aligned;                    // the next chunk's first launch needs no alignment of its own
+        e->last_pass_empty = cur.m == 0;
         e->last_pass_alt = false;
         return SCL_OK;
     };
@@ -1179,15 +1204,12 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
         return SCL_OK;
     };
     int next = 0, c = 0;
-    double t_sub = 0, t_col = 0; int n_sub = 0;
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     while (next < n_queries || ch[0].busy || ch[1].busy) {
         if (next < n_queries && !ch[c].busy) {
             const int count = n_queries - next < CH ? n_queries - next : CH;
-            const double t0 = now();
-            rc = submit(c, next, count);
-            t_sub += now() - t0; ++n_sub;
-            if (rc) {
+            const int nfirst = next + count;
+            const int ncount = n_queries - nfirst < CH ? n_queries - nfirst : CH;
+            if ((rc = submit(c, next, count, nfirst, ncount > 0 ? ncount : 0))) {
                 const std::string first_error = e->last_error;
                 (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream_surv);
                 e->last_error = first_error;
@@ -1199,11 +1221,8 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
         }
         // both halves enqueued (or nothing left to submit): wait for the older one
         const int older = ch[c].busy ? c : c ^ 1;
-        const double t0 = now();
         if ((rc = collect(older))) return rc;
-        t_col += now() - t0;
     }
-    if (getenv("SCL_STREAM_TIMING")) fprintf(stderr, "stream: %d chunks, submit %.1f us each, collect wait %.1f us each\n", n_sub, t_sub / n_sub * 1e6, t_col / n_sub * 1e6);
     return SCL_OK;
 }
 
