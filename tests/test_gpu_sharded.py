@@ -188,9 +188,20 @@ def _rank_main(rank, world, port, out_q):
     for c in curs:
         eng.stage_query(descs[c])
         st.submit(-1, 0, local_count(c - 100, rank, world))
-    out_q.put((rank, res, st.drain()))
+    staged = st.drain()
+    # bench.py's layout for N > 1: every rank holds its shard of the database followed by ALL query keyframes, and hands the
+    # scans to the native pipeline as arrays (FullScanStream.submit_many), winners merged by the packed-key all-reduces
+    n_db, n_q = 3000, 12
+    eng2 = ScanContextEngine(num_ring=R, num_sector=S, initial_capacity=n_db // world + n_q + 8)
+    eng2.save_bulk(descs[rank:n_db:world])
+    n_local = eng2.get_size()
+    eng2.save_bulk(descs[n - n_q:])
+    st2 = FullScanStream(eng2, rank, world, depth=2, scans_per_launch=4, native_chunk=5)
+    st2.submit_many(n_local + np.arange(n_q, dtype=np.int32), 0, n_local)
+    arrays = st2.drain()
+    out_q.put((rank, res, staged, arrays))
     dist.barrier(); dist.destroy_process_group()
-    eng.close()
+    eng.close(); eng2.close()
 
 
 def test_two_processes_share_the_database_over_gloo():
@@ -203,6 +214,11 @@ def test_two_processes_share_the_database_over_gloo():
     one.save_bulk(descs)
     curs = list(range(n - 1, n - 13, -1))
     want = [(one.detect_intra(c), one.detect_full(c)) for c in curs]
+    one.close()
+    n_db, n_q = 3000, 12
+    one = ScanContextEngine(num_ring=R, num_sector=S, initial_capacity=n_db + n_q)
+    one.save_bulk(descs[:n_db]); one.save_bulk(descs[n - n_q:])
+    want_arrays = [one.detect_full_range(n_db + i, 0, n_db) for i in range(n_q)]
     one.close()
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
@@ -218,7 +234,10 @@ def test_two_processes_share_the_database_over_gloo():
             if p.is_alive():
                 p.terminate()
     assert all(p.exitcode == 0 for p in procs)
-    for _, res, stream in got:
+    for _, res, stream, arrays in got:
         for (intra, full), (w_intra, w_full), (d, g, shf) in zip(res, want, stream):
             assert intra == w_intra and full == w_full
             assert (g, shf) == (w_full[1], w_full[2]) and _same_bits(d, w_full[3])
+        assert len(arrays) == len(want_arrays)
+        for (d, g, shf), w in zip(arrays, want_arrays):
+            assert (g, shf) == (w[0], w[1]) and _same_bits(d, w[2])
