@@ -1032,11 +1032,12 @@ int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, c
                 sb.k = k; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
                 SCL_HIP(e, launch_sc_select_batch(sb, e->stream));
                 ProfScope ps(e, P_ARGMIN);
-                for (int j = 0; j < qb.nq; ++j)
-                    SCL_HIP(e, launch_sc_distance_survivors_wide(db_view(e), qb.slot[j], qb.base[j], qb.n[j], e->SR,
-                                                                 e->d_surv + (size_t)j * e->set_stride, e->d_nsurv + j,
-                                                                 e->d_dist + (size_t)j * e->set_stride, e->d_shift + (size_t)j * e->set_stride,
-                                                                 qb.out3[j], e->num_cu, e->stream));
+                const int *sv[kMaxQueryBatch]; const int *ns[kMaxQueryBatch]; double *od[kMaxQueryBatch]; int *os[kMaxQueryBatch];
+                for (int j = 0; j < qb.nq; ++j) {
+                    sv[j] = e->d_surv + (size_t)j * e->set_stride; ns[j] = e->d_nsurv + j;
+                    od[j] = e->d_dist + (size_t)j * e->set_stride; os[j] = e->d_shift + (size_t)j * e->set_stride;
+                }
+                SCL_HIP(e, launch_sc_distance_survivors_wide(db_view(e), qb.nq, qb.slot, qb.base, e->SR, sv, ns, od, os, qb.out3, e->num_cu, e->stream));
             } else if ((rc = launch_survivor_pass(e, qb.slot, qb.base, qb.n, qb.nq, 0, qb.out3))) return rc;
         } else {
             ProfScope ps(e, P_SC);

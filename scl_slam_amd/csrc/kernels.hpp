@@ -120,8 +120,9 @@ struct SurvivorPass {
     void *d_args; void *h_args;
 };
 hipError_t launch_sc_distance_survivors(const struct DbView &db, const SurvivorPass &sp, int SR, int num_cu, hipStream_t stream);
-hipError_t launch_sc_distance_survivors_wide(const struct DbView &db, int query_slot, int slot_base, int range_n, int SR, const int *survivors,
-                                             const int *n_surv, double *out_dist, int *out_shift, double *out3, int num_cu, hipStream_t stream);
+hipError_t launch_sc_distance_survivors_wide(const struct DbView &db, int nq, const int *query_slot, const int *slot_base, int SR,
+                                             const int *const *survivors, const int *const *n_surv, double *const *out_dist, int *const *out_shift,
+                                             double *const *out3, int num_cu, hipStream_t stream);
 int sc_align_filter_enabled();
 
 // out_ring_d2 (optional): also write the squared ring-key distance (nanoflann metric) of every scored

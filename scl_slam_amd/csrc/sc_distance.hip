@@ -85,9 +85,8 @@ __device__ __forceinline__ int wrap(int x, int S)
 // MAXT bounds the workgroup: 512 threads = 2 waves/SIMD leaves 256 VGPRs per lane, 256 threads
 // (one wave per SIMD) the whole 512-entry file.
 template <int RG, int W, int MAXT>
-__global__ __launch_bounds__(MAXT) void sc_distance_kernel(ScArgs a)
+__device__ __forceinline__ void sc_distance_body(const ScArgs &a, double *smem)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     const int S = a.S, SR = a.SR;
     constexpr int R4 = RG * 4;
     const int QS = S + W - 1;                 // extended query row
@@ -228,6 +227,22 @@ __global__ __launch_bounds__(MAXT) void sc_distance_kernel(ScArgs a)
             }
         }
     }
+}
+
+template <int RG, int W, int MAXT>
+__global__ __launch_bounds__(MAXT) void sc_distance_kernel(ScArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    sc_distance_body<RG, W, MAXT>(a, smem);
+}
+
+// the same program for the survivor lists of up to four queries in one launch: blockIdx.y = query
+struct ScArgsBatch { ScArgs q[kMaxQueryBatch]; };
+template <int RG, int W, int MAXT>
+__global__ __launch_bounds__(MAXT) void sc_distance_batch4_kernel(ScArgsBatch ab)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem_b[];
+    sc_distance_body<RG, W, MAXT>(ab.q[blockIdx.y], smem_b);
 }
 
 // =================================================================================
@@ -1213,13 +1228,17 @@ __global__ void argmin_kernel(const double *dist, const int *shift, int n, doubl
     }
 }
 
-// arg-min over the exact distances of a survivor list (count on the device); out3[1] = the winner's slot relative to
-// slot_base (ties -> lowest position = lowest slot: the list is ascending)
-__global__ void argmin_survivors_kernel(const double *dist, const int *shift, const int *n_dev, const int *cand, int slot_base, double *out3)
+// arg-min over the exact distances of the survivor lists of up to four queries (counts on the device); out3[1] = the
+// winner's slot relative to slot_base (ties -> lowest position = lowest slot: the lists are ascending)
+struct ArgminBatch { const double *dist[kMaxQueryBatch]; const int *shift[kMaxQueryBatch]; const int *n_dev[kMaxQueryBatch];
+                     const int *cand[kMaxQueryBatch]; int slot_base[kMaxQueryBatch]; double *out3[kMaxQueryBatch]; };
+__global__ __launch_bounds__(1024) void argmin_survivors_batch_kernel(ArgminBatch b)
 {
+    const int q = blockIdx.x;
     __shared__ double sv[16];
     __shared__ int si[16];
-    const int n = *n_dev;
+    const double *dist = b.dist[q]; const int *shift = b.shift[q]; const int *cand = b.cand[q];
+    const int n = *b.n_dev[q];
     double best = __longlong_as_double(0x7ff0000000000000LL);
     int bi = 0x7fffffff;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -1235,8 +1254,9 @@ __global__ void argmin_survivors_kernel(const double *dist, const int *shift, co
         for (int w = 1; w < nw; ++w)
             if ((sv[w] < best) | ((sv[w] == best) & (si[w] < bi))) { best = sv[w]; bi = si[w]; }
         const bool ok = best < kBigDist;
+        double *out3 = b.out3[q];
         out3[0] = ok ? best : kBigDist;
-        out3[1] = ok ? (double)(cand[bi] - slot_base) : -1.0;
+        out3[1] = ok ? (double)(cand[bi] - b.slot_base[q]) : -1.0;
         out3[2] = ok ? (double)shift[bi] : 0.0;
     }
 }
@@ -1427,26 +1447,50 @@ hipError_t launch_sc_distance_survivors(const DbView &db, const SurvivorPass &sp
 }
 
 // 80 x 180: exact distances of the survivor list by the one-sector-per-lane kernel, then the arg-min (two launches)
-hipError_t launch_sc_distance_survivors_wide(const DbView &db, int query_slot, int slot_base, int range_n, int SR, const int *survivors,
-                                             const int *n_surv, double *out_dist, int *out_shift, double *out3, int num_cu, hipStream_t stream)
+// Exact pass of the 80 x 180 grid over the survivor lists of nq <= 4 queries: ONE launch of the one-sector-per-lane program
+// (blockIdx.y = query, the survivor counts stay on the device) and ONE arg-min launch; winners to out3[i].
+hipError_t launch_sc_distance_survivors_wide(const DbView &db, int nq, const int *query_slot, const int *slot_base, int SR,
+                                             const int *const *survivors, const int *const *n_surv, double *const *out_dist, int *const *out_shift,
+                                             double *const *out3, int num_cu, hipStream_t stream)
 {
-    if (!(db.RG == 20 && db.S == 180 && SR == 9)) return hipErrorInvalidValue;
-    ScArgs a{};
-    const size_t slot = (size_t)query_slot;
-    a.desc = db.desc; a.vkey = db.vkey; a.norm = db.norm;
-    a.q_desc = db.desc + slot * (size_t)(db.RG * db.S); a.q_vkey = db.vkey + slot * db.S; a.q_norm = db.norm + slot * db.S;
-    a.q_rkey = db.rkey + slot * (size_t)(4 * db.RG);
-    a.cand = survivors; a.slot_base = slot_base; a.n = range_n < 256 ? range_n : 256;   // sizes the launch; the kernel loops over *n_dev
-    a.n_dev = n_surv; a.approx = nullptr; a.t_min = nullptr; a.range_n = 0; a.two_eps = 0.f;
-    a.ring_d2 = nullptr; a.sel_topk_idx = nullptr; a.sel_topk_d2 = nullptr; a.sel_topk_k = 0; a.sel_exclude_eps = 0.f;
-    a.S = db.S; a.SR = SR; a.NW = (db.S + kWave - 1) / kWave; a.G = 1;
-    a.ablate = 0; a.align_filter = 0; a.stamps = nullptr;
-    a.rkey4 = db.rkey4; a.rk_cap = db.cap; a.out_d2 = nullptr;
-    a.blk_part = nullptr; a.done_counter = nullptr; a.out3 = nullptr; a.topk_idx = nullptr; a.topk_d2 = nullptr; a.topk_k = 0; a.exclude_eps = 0.f;
-    a.out_dist = out_dist; a.out_shift = out_shift;
-    hipError_t e = launch_fast<20, 19, 256>(a, num_cu, stream);
+    if (!(db.RG == 20 && db.S == 180 && SR == 9) || nq < 1 || nq > kMaxQueryBatch) return hipErrorInvalidValue;
+    constexpr int RG = 20, W = 19, MAXT = 256;
+    ScArgsBatch ab{};
+    ArgminBatch mb{};
+    for (int i = 0; i < kMaxQueryBatch; ++i) {
+        const int j = i < nq ? i : 0;
+        ScArgs &a = ab.q[i];
+        const size_t slot = (size_t)query_slot[j];
+        a.desc = db.desc; a.vkey = db.vkey; a.norm = db.norm;
+        a.q_desc = db.desc + slot * (size_t)(db.RG * db.S); a.q_vkey = db.vkey + slot * db.S; a.q_norm = db.norm + slot * db.S;
+        a.q_rkey = db.rkey + slot * (size_t)(4 * db.RG);
+        a.cand = survivors[j]; a.slot_base = slot_base[j]; a.n = 256;        // sizes nothing here; the kernel loops over *n_dev
+        a.n_dev = n_surv[j]; a.approx = nullptr; a.t_min = nullptr; a.range_n = 0; a.two_eps = 0.f;
+        a.ring_d2 = nullptr; a.sel_topk_idx = nullptr; a.sel_topk_d2 = nullptr; a.sel_topk_k = 0; a.sel_exclude_eps = 0.f;
+        a.S = db.S; a.SR = SR; a.NW = (db.S + kWave - 1) / kWave; a.G = 1;
+        a.ablate = 0; a.align_filter = 0; a.stamps = nullptr;
+        a.rkey4 = db.rkey4; a.rk_cap = db.cap; a.out_d2 = nullptr;
+        a.blk_part = nullptr; a.done_counter = nullptr; a.out3 = nullptr; a.topk_idx = nullptr; a.topk_d2 = nullptr; a.topk_k = 0; a.exclude_eps = 0.f;
+        a.out_dist = out_dist[j]; a.out_shift = out_shift[j];
+        mb.dist[i] = out_dist[j]; mb.shift[i] = out_shift[j]; mb.n_dev[i] = n_surv[j]; mb.cand[i] = survivors[j];
+        mb.slot_base[i] = slot_base[j]; mb.out3[i] = out3[j];
+    }
+    const int S = db.S, QS = S + W - 1;
+    const size_t lds = (size_t)(RG * 4 * QS + 2 * S) * sizeof(double) + (size_t)(4 * S + W * S + 8) * sizeof(double);   // G = 1
+    static std::atomic<bool> attr_set_dev[64];
+    int dev_ = 0; (void)hipGetDevice(&dev_);
+    std::atomic<bool> &attr_set = attr_set_dev[dev_ & 63];
+    if (!attr_set.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute((const void *)sc_distance_batch4_kernel<RG, W, MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set.store(true, std::memory_order_release);
+    }
+    (void)num_cu;
+    // survivors are few (one to a handful per query): 16 workgroups per query cover 16 of them at once, more loop
+    hipLaunchKernelGGL((sc_distance_batch4_kernel<RG, W, MAXT>), dim3(16, nq), dim3(ab.q[0].NW * kWave), lds, stream, ab);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(argmin_survivors_kernel, dim3(1), dim3(1024), 0, stream, out_dist, out_shift, n_surv, survivors, slot_base, out3);
+    hipLaunchKernelGGL(argmin_survivors_batch_kernel, dim3(nq), dim3(1024), 0, stream, mb);
     return hipGetLastError();
 }
 
