@@ -876,7 +876,11 @@ int launch_screen_group(scl_engine *e, const ScreenGroup &cur, int phases = kScr
 }
 
 // The exact pass over the survivors of nq screened queries (buffer sets set0 .. set0 + nq - 1); winners to out3[i].
-int launch_survivor_pass(scl_engine *e, const int *qslot, const int *lo, const int *n, int nq, int set0, double *const *out3, hipStream_t stream = nullptr)
+// phases / region: see launch_sc_distance_survivors; a caller that splits the pass passes the same region (from
+// survivor_arg_region) to both halves
+unsigned survivor_arg_region(scl_engine *e) { return e->surv_arg_tick++ & 7u; }
+int launch_survivor_pass(scl_engine *e, const int *qslot, const int *lo, const int *n, int nq, int set0, double *const *out3, hipStream_t stream = nullptr,
+                         int phases = kSurvivorArgs | kSurvivorKernel, int region_in = -1)
 {
     if (!stream) stream = e->stream;
     SurvivorPass sp{};
@@ -886,10 +890,14 @@ int launch_survivor_pass(scl_engine *e, const int *qslot, const int *lo, const i
     sp.approx = e->d_approx; sp.survivors = e->d_surv; sp.t_min = e->d_tmin; sp.out_dist = e->d_dist; sp.out_shift = e->d_shift;
     sp.blk_part = e->d_surv_part; sp.done_counter = e->d_surv_done;
     sp.ring_d2 = e->d_ring_d2; sp.k = e->cfg.num_candidates; sp.exclude_eps = e->cfg.knn_exclude_eps; sp.topk_idx = e->d_topk_idx; sp.topk_d2 = e->d_topk_d2;
-    const size_t region = (size_t)(e->surv_arg_tick++ & 7u) * scl_engine::kScreenSets * kSurvivorArgBytes;   // 8 passes may be in flight
+    const size_t region = (size_t)(region_in >= 0 ? (unsigned)region_in : survivor_arg_region(e)) * scl_engine::kScreenSets * kSurvivorArgBytes;   // 8 passes may be in flight
     sp.d_args = static_cast<char *>(e->d_surv_args) + region; sp.h_args = static_cast<char *>(e->h_surv_args) + region;
+    if (!(phases & kSurvivorKernel)) {
+        SCL_HIP(e, launch_sc_distance_survivors(db_view(e), sp, e->SR, e->num_cu, stream, phases));
+        return SCL_OK;
+    }
     ProfScope ps(e, P_ARGMIN, stream);
-    SCL_HIP(e, launch_sc_distance_survivors(db_view(e), sp, e->SR, e->num_cu, stream));
+    SCL_HIP(e, launch_sc_distance_survivors(db_view(e), sp, e->SR, e->num_cu, stream, phases));
     return SCL_OK;
 }
 
@@ -1160,6 +1168,9 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
         // Every launch carries the alignment of the launch behind it -- the chunk's last one that of the next chunk's first
         // launch, whose buffer sets the exact pass of the chunk before this one may still be reading: the main stream waits
         // for it there (it finished long ago).  Only the very first launch aligns for itself.
+        // the exact pass's argument sets go to the device now, ahead of the products it has to wait for
+        const int region = cur.m > 0 ? (int)survivor_arg_region(e) : 0;
+        if (cur.m > 0 && (rc = launch_survivor_pass(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, e->stream_surv, kSurvivorArgs, region))) return rc;
         bool next_aligned = false;
         for (int g = 0; g < cur.m; g += spl) {
             const int w = cur.m - g < spl ? cur.m - g : spl;
@@ -1179,7 +1190,7 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
         }
         SCL_HIP(e, hipEventRecord(e->ev_k1[c], e->stream));
         SCL_HIP(e, hipStreamWaitEvent(e->stream_surv, e->ev_k1[c], 0));
-        if (cur.m > 0 && (rc = launch_survivor_pass(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, e->stream_surv))) return rc;
+        if (cur.m > 0 && (rc = launch_survivor_pass(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, e->stream_surv, kSurvivorKernel, region))) return rc;
         SCL_HIP(e, hipEventRecord(e->ev_chunk[c], e->stream_surv));
         k.busy = true;
         k.aligned = false;

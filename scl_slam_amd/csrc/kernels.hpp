@@ -119,7 +119,11 @@ struct SurvivorPass {
     unsigned long long *blk_part; unsigned int *done_counter;
     void *d_args; void *h_args;
 };
-hipError_t launch_sc_distance_survivors(const struct DbView &db, const SurvivorPass &sp, int SR, int num_cu, hipStream_t stream);
+// phases: kSurvivorArgs = fill the argument sets and enqueue their copy to the device (may be done ahead of the event the
+// kernel has to wait for), kSurvivorKernel = the kernel; both by default
+constexpr int kSurvivorArgs = 1, kSurvivorKernel = 2;
+hipError_t launch_sc_distance_survivors(const struct DbView &db, const SurvivorPass &sp, int SR, int num_cu, hipStream_t stream,
+                                        int phases = kSurvivorArgs | kSurvivorKernel);
 hipError_t launch_sc_distance_survivors_wide(const struct DbView &db, int nq, const int *query_slot, const int *slot_base, int SR,
                                              const int *const *survivors, const int *const *n_surv, double *const *out_dist, int *const *out_shift,
                                              double *const *out3, int num_cu, hipStream_t stream);

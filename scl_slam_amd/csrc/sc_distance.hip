@@ -1399,13 +1399,13 @@ hipError_t launch_sc_distance_batch(const DbView &db, const QueryBatch &qb, int 
     return launch_wave<16, 13, 4, 120, 512>(ab, num_cu, stream);
 }
 
-hipError_t launch_sc_distance_survivors(const DbView &db, const SurvivorPass &sp, int SR, int num_cu, hipStream_t stream)
+hipError_t launch_sc_distance_survivors(const DbView &db, const SurvivorPass &sp, int SR, int num_cu, hipStream_t stream, int phases)
 {
     if (sp.nq < 1 || !(db.RG == 16 && db.S == 120 && SR == 6) || !sp.d_args || !sp.h_args) return hipErrorInvalidValue;
     constexpr int RG = 16, W = 13, CH = 4, S = 120, MAXT = 512;
     ScArgs *h = reinterpret_cast<ScArgs *>(sp.h_args);
     static_assert(sizeof(ScArgs) <= kSurvivorArgBytes, "argument set must fit the slot the engine reserves");
-    for (int i = 0; i < sp.nq; ++i) {
+    for (int i = 0; (phases & kSurvivorArgs) && i < sp.nq; ++i) {
         ScArgs &a = h[i];
         const size_t slot = (size_t)sp.slot[i];
         a.desc = db.desc; a.vkey = db.vkey; a.norm = db.norm;
@@ -1425,8 +1425,12 @@ hipError_t launch_sc_distance_survivors(const DbView &db, const SurvivorPass &sp
         a.sel_topk_idx = sp.topk_idx + sp.buf[i] * kTailTopMaxK; a.sel_topk_d2 = sp.topk_d2 + sp.buf[i] * kTailTopMaxK;
         a.sel_topk_k = sp.k; a.sel_exclude_eps = sp.exclude_eps;
     }
-    hipError_t e = hipMemcpyAsync(sp.d_args, sp.h_args, sizeof(ScArgs) * (size_t)sp.nq, hipMemcpyHostToDevice, stream);
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;
+    if (phases & kSurvivorArgs) {
+        e = hipMemcpyAsync(sp.d_args, sp.h_args, sizeof(ScArgs) * (size_t)sp.nq, hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) return e;
+    }
+    if (!(phases & kSurvivorKernel)) return hipSuccess;
     constexpr int QS = S + W + 1, HSH = (W + 1) / 2;
     const size_t fixed = (size_t)(RG * 4 * QS + QS + 2 * S) * sizeof(double);
     const size_t per_wave = (size_t)((2 * S > HSH * (S + 2)) ? 2 * S : HSH * (S + 2)) * sizeof(double);

@@ -793,16 +793,16 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
     }
     // workgroups of the alignment per query: one wave per 16 keyframes, at most two workgroups per CU over all queries of the
     // batch (measured beside the products: 128 per query for four queries on 256 CUs is the best point; 136 and more cost 5 %)
-    auto align_blocks = [&](int groups, int nq) {
+    auto align_blocks = [&](int groups, int nq, bool beside_products) {
         int b = (groups + kScreenWaves - 1) / kScreenWaves;
         static const int cap_env = [] { const char *e = getenv("SCL_ALIGN_WGS"); return e ? atoi(e) : 0; }();
-        int cap = cap_env > 0 ? cap_env : 2 * num_cu / (nq > 0 ? nq : 1);
+        int cap = cap_env > 0 ? cap_env : (beside_products ? 2 * num_cu / (nq > 0 ? nq : 1) : num_cu);   // on its own: one wave per group
         if (cap < 1) cap = 1;
         return b > cap ? cap : b;
     };
     // the alignment of this batch, on its own (the first launch of a sequence, or a caller that has only one)
     if ((phases & kScreenAlign) && probe != 3) {
-        ab.nb = align_blocks(ngroups, sb.nq);
+        ab.nb = align_blocks(ngroups, sb.nq, false);
         hipLaunchKernelGGL((sc_align_kernel<RG, S, W>), dim3(ab.nb * sb.nq), dim3(kScreenWaves * kWave), lds0, stream, ab);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -821,7 +821,7 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
         if (next->nq < 1 || next->nq > kMaxQueryBatch) return hipErrorInvalidValue;
         const int nmax2 = fill_screen_args(db, *next, align_filter, &fa.next);
         if (nmax2 < 0) return hipErrorInvalidValue;
-        fa.next.nb = align_blocks((nmax2 + kGroup - 1) / kGroup, next->nq);
+        fa.next.nb = align_blocks((nmax2 + kGroup - 1) / kGroup, next->nq, true);
         extra = fa.next.nb * next->nq;
 #ifdef SCL_DIAGNOSTICS
         if (probe == 5 || probe == 6) for (int i = 0; i < kMaxQueryBatch; ++i) fa.next.q[i].align_filter = probe == 5 ? 2 : 3;
