@@ -970,24 +970,31 @@ __global__ __launch_bounds__(MAXT) void sc_distance_survivors_kernel(const ScArg
         const unsigned int b = (tm >> 31) ? (tm & 0x7fffffffu) : ~tm;            // inverse of the ordered image
         thr = __int_as_float((int)b) + a.two_eps;
     }
-    const int chunk = (a.range_n + (int)blockDim.x - 1) / (int)blockDim.x;
-    const int lo = (int)threadIdx.x * chunk;
-    const int hi = lo + chunk < a.range_n ? lo + chunk : a.range_n;
+    // Every wave owns a contiguous part of the range and walks it 64 entries at a time (coalesced reads; a thread-owned
+    // chunk made every load a 64-line gather): count, prefix over the waves, then the same walk writes the list --
+    // iteration-major, lane-minor = ascending slots.
+    const int nwv = (int)blockDim.x / kWave;
+    const int per_wave = (((a.range_n + nwv - 1) / nwv) + kWave - 1) / kWave * kWave;
+    const int wlo = wv * per_wave;
+    const int whi = wlo + per_wave < a.range_n ? wlo + per_wave : a.range_n;
     int cnt = 0;
-    for (int i = lo; i < hi; ++i) cnt += a.approx[i] <= thr ? 1 : 0;             // -inf (score exactly) always passes
-    int incl = cnt;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const int o = __shfl_up(incl, off, kWave);
-        if (lane >= off) incl += o;
+    for (int base = wlo; base < whi; base += kWave) {
+        const int i = base + lane;
+        const bool pass = i < whi && a.approx[i] <= thr;                         // -inf (score exactly) always passes
+        cnt += __popcll(__builtin_amdgcn_ballot_w64(pass));
     }
-    if (lane == kWave - 1) wave_total[wv] = incl;
+    if (lane == 0) wave_total[wv] = cnt;
     __syncthreads();
-    int before = incl - cnt, total = 0;
-    for (int w = 0; w < (int)blockDim.x / kWave; ++w) { const int t = wave_total[w]; if (w < wv) before += t; total += t; }
+    int before = 0, total = 0;
+    for (int w = 0; w < nwv; ++w) { const int t = wave_total[w]; if (w < wv) before += t; total += t; }
     int *list = const_cast<int *>(a.cand);
-    for (int i = lo; i < hi; ++i)
-        if (a.approx[i] <= thr) list[before++] = a.slot_base + i;
+    for (int base = wlo; base < whi; base += kWave) {
+        const int i = base + lane;
+        const bool pass = i < whi && a.approx[i] <= thr;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+        if (pass) list[before + __popcll(m & ((1ull << lane) - 1ull))] = a.slot_base + i;
+        before += __popcll(m);
+    }
     __threadfence_block();
     __syncthreads();
     // The ring-key top-k of the range (workgroup 0 of the query): k rounds of "smallest key larger than the previous
@@ -999,7 +1006,7 @@ __global__ __launch_bounds__(MAXT) void sc_distance_survivors_kernel(const ScArg
         bool first = true;
         for (int round = 0; round < a.sel_topk_k; ++round) {
             unsigned long long mine = none;
-            for (int i = lo; i < hi; ++i) {
+            for (int i = (int)threadIdx.x; i < a.range_n; i += (int)blockDim.x) {
                 const float r = a.ring_d2[i];
                 const bool excluded = (a.sel_exclude_eps > 0.0f) && (r <= a.sel_exclude_eps);
                 if (excluded || !(r < 3.402823466e+38f)) continue;
