@@ -1188,10 +1188,19 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
             const int phases = (g == 0 && !k.aligned) ? (kScreenAlign | kScreenProducts) : kScreenProducts;
             if ((rc = launch_screen_group(e, grp, phases, nx.nq > 0 ? &nx : nullptr))) return rc;
         }
-        SCL_HIP(e, hipEventRecord(e->ev_k1[c], e->stream));
-        SCL_HIP(e, hipStreamWaitEvent(e->stream_surv, e->ev_k1[c], 0));
-        if (cur.m > 0 && (rc = launch_survivor_pass(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, e->stream_surv, kSurvivorKernel, region))) return rc;
-        SCL_HIP(e, hipEventRecord(e->ev_chunk[c], e->stream_surv));
+        // The exact pass of a chunk runs beside the next chunk's products, on the side stream -- except the call's last one,
+        // which nothing follows: it stays on the main stream (no hop between streams in front of it; its argument sets are
+        // already on the device: wait for their copy only).
+        hipStream_t xs = ncount > 0 ? e->stream_surv : e->stream;
+        if (ncount > 0) {
+            SCL_HIP(e, hipEventRecord(e->ev_k1[c], e->stream));
+            SCL_HIP(e, hipStreamWaitEvent(e->stream_surv, e->ev_k1[c], 0));
+        } else if (cur.m > 0) {
+            SCL_HIP(e, hipEventRecord(e->ev_k1[c], e->stream_surv));         // behind the copy of the argument sets
+            SCL_HIP(e, hipStreamWaitEvent(e->stream, e->ev_k1[c], 0));
+        }
+        if (cur.m > 0 && (rc = launch_survivor_pass(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, xs, kSurvivorKernel, region))) return rc;
+        SCL_HIP(e, hipEventRecord(e->ev_chunk[c], xs));
         k.busy = true;
         k.aligned = false;
         ch[c ^ 1].aligned = next_aligned;                    // the next chunk's first launch needs no alignment of its own
@@ -1201,7 +1210,11 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
     };
     auto collect = [&](int c) -> int {
         Chunk &k = ch[c];
-        SCL_HIP(e, hipEventSynchronize(e->ev_chunk[c]));
+        {   // the caller waits for nothing else: poll (a blocking wait wakes up tens of microseconds late)
+            hipError_t q;
+            while ((q = hipEventQuery(e->ev_chunk[c])) == hipErrorNotReady) { }
+            SCL_HIP(e, q);
+        }
         collect_profile(e);
         for (int i = 0; i < k.count; ++i) {
             const int o_i = k.first + i;

@@ -221,6 +221,11 @@ class FullScanStream:
 
     def _native_call(self, q, lo, hi):
         nn, sh, d = self.engine.detect_full_stream(q, lo, hi, self.per_launch, self.depth)
+        if self.world == 1 and not self.always_exchange and not self.batch and self.pending is None and self.stage1 is None and self.stage2 is None:
+            # one shard, nothing in flight: the engine's winners are the result (what _merge would return)
+            ok = nn >= 0
+            self.results.extend(zip(np.where(ok, d, BIG_DIST).tolist(), np.where(ok, nn, -1).tolist(), np.where(ok, sh, 0).tolist()))
+            return
         g = np.where(nn >= 0, nn.astype(np.float64) * self.world + self.rank, -1.0)
         self._exchange(np.stack([np.asarray(d, dtype=np.float64), g, sh.astype(np.float64)], axis=1))
 
