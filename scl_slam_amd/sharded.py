@@ -57,14 +57,12 @@ def pack_winner_keys(rec):
 
 def unpack_winner_keys(m1, m2):
     """reduced keys -> list of (dist, global index, shift); no candidate anywhere -> (BIG_DIST, -1, 0)"""
-    out = []
-    d = key_to_dist(np.where(m1 == I64_MAX, 0, m1))
-    for j in range(len(m1)):
-        if m1[j] == I64_MAX or m2[j] == I64_MAX:
-            out.append((BIG_DIST, -1, 0))
-        else:
-            out.append((float(d[j]), int(m2[j] >> 16), int(m2[j] & 0xFFFF)))
-    return out
+    m1 = np.asarray(m1, dtype=np.int64); m2 = np.asarray(m2, dtype=np.int64)
+    none = (m1 == I64_MAX) | (m2 == I64_MAX)
+    d = np.where(none, BIG_DIST, key_to_dist(np.where(m1 == I64_MAX, 0, m1)))
+    g = np.where(none, -1, m2 >> 16)
+    sh = np.where(none, 0, m2 & 0xFFFF)
+    return list(zip(d.tolist(), g.tolist(), sh.tolist()))
 
 
 def local_count(global_hi, rank, world):
@@ -285,9 +283,10 @@ class FullScanStream:
             # phase 2 of the batch before that is awaited and delivered.  Nothing blocks on a collective that was
             # enqueued in this call.
             k1, k2 = pack_winner_keys(rec)
-            t1 = torch.from_numpy(k1.copy()).to(self.device)
+            both = torch.from_numpy(np.stack([k1, k2])).to(self.device)       # one copy to the device for both phases
+            t1 = both[0].clone()                                              # reduced in place; both[0] keeps this rank's keys
             w1 = dist.all_reduce(t1, op=dist.ReduceOp.MIN, group=self.group, async_op=True)
-            prev1, self.stage1 = self.stage1, (w1, t1, k1, k2)
+            prev1, self.stage1 = self.stage1, (w1, t1, both)
             self._advance(prev1)
             return
         t = torch.from_numpy(rec).to(self.device)
@@ -298,21 +297,22 @@ class FullScanStream:
 
     def _advance(self, prev1):
         """prev1 = a batch whose phase 1 (distance keys) is in flight: await it, start its phase 2 (index | shift of
-        the ranks that hold the minimum); the batch that was in phase 2 is awaited and delivered first (order)."""
+        the ranks that hold the minimum; masked on the device, no trip to the host between the phases); the batch that
+        was in phase 2 is awaited and delivered first (order)."""
         import torch
         import torch.distributed as dist
         prev2, self.stage2 = self.stage2, None
         if prev2 is not None:
             w2, t2, m1 = prev2
             w2.wait()
-            self.results.extend(unpack_winner_keys(m1, t2.cpu().numpy()))
+            both = torch.stack([m1, t2]).cpu().numpy()                          # one copy back for both reduced keys
+            self.results.extend(unpack_winner_keys(both[0], both[1]))
         if prev1 is not None:
-            w1, t1, k1, k2 = prev1
+            w1, t1, both = prev1
             w1.wait()
-            m1 = t1.cpu().numpy()
-            t2 = torch.from_numpy(np.where(k1 == m1, k2, I64_MAX)).to(self.device)
+            t2 = torch.where(both[0] == t1, both[1], torch.full_like(both[1], I64_MAX))
             w2 = dist.all_reduce(t2, op=dist.ReduceOp.MIN, group=self.group, async_op=True)
-            self.stage2 = (w2, t2, m1)
+            self.stage2 = (w2, t2, t1)
 
     def _finish(self, pending):
         if pending is None:
