@@ -490,6 +490,7 @@ int scl_destroy(scl_engine *e)
     icp_workspace_free(&e->vox_ws);
     for (void *slab : e->kf_slabs) (void)hipFree(slab);
     for (int i = 0; i < scl_engine::kIcpBatch; ++i) icp_workspace_free(&e->icp_batch_ws[i]);
+    for (int i = 0; i < scl_engine::kIcpLanes; ++i) icp_workspace_free(&e->vox_lane_ws[i]);
     icp_workspace_free(&e->icp_batch_ctl);
     for (int i = 0; i < scl_engine::kIcpLanes; ++i) {
         if (e->ev_lane[i]) (void)hipEventDestroy(e->ev_lane[i]);
@@ -1955,24 +1956,57 @@ int scl_loop_icp_batch_from_store(scl_engine *e, int robot, int key_cur, const f
         if (iterations) iterations[c] = 0;
         if (n_tgts) n_tgts[c] = 0;
     }
+    const int lanes = n_candidates < scl_engine::kIcpLanes ? n_candidates : scl_engine::kIcpLanes;
+    for (int l = 0; l < lanes; ++l) {
+        if (!e->icp_lane_stream[l]) SCL_HIP(e, hipStreamCreateWithFlags(&e->icp_lane_stream[l], hipStreamNonBlocking));
+        if (!e->ev_lane[l]) SCL_HIP(e, hipEventCreateWithFlags(&e->ev_lane[l], hipEventDisableTiming));
+    }
+    SCL_HIP(e, hipStreamSynchronize(e->stream));                                     // the source is in d_points
     for (int first = 0; first < n_candidates; first += scl_engine::kIcpBatch) {
         const int m = n_candidates - first < scl_engine::kIcpBatch ? n_candidates - first : scl_engine::kIcpBatch;
+        // targets: loopFindNearKeyframes(pre, historyKeyframeSearchNum), DM.h:1107, from the store -- submap assembly (voxel
+        // filter: a radix sort per candidate), staging and search-grid build are independent per candidate: a few host
+        // threads issue them onto the lane streams, each with its own filter workspace
+        std::atomic<int> next{0};
+        std::atomic<int> first_rc{SCL_OK};
+        std::string errs[scl_engine::kIcpLanes];
+        int nts[scl_engine::kIcpBatch]; bool ok[scl_engine::kIcpBatch];
+        auto worker = [&](int l) {
+            (void)hipSetDevice(e->device);
+            hipStream_t st = e->icp_lane_stream[l];
+            std::vector<const void *> cl; std::vector<int> cn; std::vector<float> tw;
+            for (;;) {
+                const int c = next.fetch_add(1);
+                if (c >= m) break;
+                nts[c] = 0; ok[c] = false;
+                const void *d_sub = nullptr;
+                int nt = 0;
+                int rc2 = kf_window(e, robot, keys_pre[first + c], search_num, poses_pre + (size_t)(first + c) * win * 16, &cl, &cn, &tw);
+                if (!rc2) rc2 = assemble_submap_ex(&e->vox_lane_ws[l], st, cl.data(), cn.data(), tw.data(), (int)cl.size(), stride, leaf,
+                                                   true, nullptr, 0, &d_sub, &nt, &errs[l]);
+                nts[c] = nt;
+                if (!rc2 && !(ns < min_src_points || nt < min_tgt_points)) {        // DM.h:1108: too small, no alignment attempted
+                    IcpWorkspace *ws = &e->icp_batch_ws[c];
+                    rc2 = icp_stage_cloud(ws, st, true, d_sub, nt, stride, &errs[l]);
+                    if (!rc2) rc2 = icp_batch_prepare(ws, st, e->d_points, ns, nt, stride, *p, &errs[l]);
+                    ok[c] = !rc2;
+                }
+                if (rc2) { int expect = SCL_OK; first_rc.compare_exchange_strong(expect, rc2); }
+            }
+            (void)hipEventRecord(e->ev_lane[l], st);
+        };
+        const int nl = m < lanes ? m : lanes;
+        std::vector<std::thread> pool;
+        for (int l = 1; l < nl; ++l) pool.emplace_back(worker, l);
+        worker(0);
+        for (auto &t : pool) t.join();
+        rc = first_rc.load();
+        if (rc) { for (auto &msg : errs) if (!msg.empty()) { e->last_error = msg; break; } (void)hipDeviceSynchronize(); return rc; }
+        for (int l = 0; l < nl; ++l) SCL_HIP(e, hipStreamWaitEvent(e->stream, e->ev_lane[l], 0));
         IcpWorkspace *wss[scl_engine::kIcpBatch]; int which[scl_engine::kIcpBatch]; int live = 0;
         for (int c = 0; c < m; ++c) {
-            // target: loopFindNearKeyframes(pre, historyKeyframeSearchNum), DM.h:1107, from the store
-            int nt = 0;
-            rc = kf_window(e, robot, keys_pre[first + c], search_num, poses_pre + (size_t)(first + c) * win * 16, &clouds, &counts, &Tw);
-            if (rc) return rc;
-            rc = assemble_submap_ex(&e->vox_ws, e->stream, clouds.data(), counts.data(), Tw.data(), (int)clouds.size(), stride, leaf,
-                                    true, nullptr, 0, &d_res, &nt, &err);
-            if (rc) { e->last_error = err; return rc; }
-            if (n_tgts) n_tgts[first + c] = nt;
-            if (ns < min_src_points || nt < min_tgt_points) continue;                   // DM.h:1108: too small, no alignment attempted
-            IcpWorkspace *ws = &e->icp_batch_ws[live];
-            rc = icp_stage_cloud(ws, e->stream, true, d_res, nt, stride, &err);
-            if (!rc) rc = icp_batch_prepare(ws, e->stream, e->d_points, ns, nt, stride, *p, &err);
-            if (rc) { e->last_error = err; return rc; }
-            wss[live] = ws; which[live] = first + c; ++live;
+            if (n_tgts) n_tgts[first + c] = nts[c];
+            if (ok[c]) { wss[live] = &e->icp_batch_ws[c]; which[live] = first + c; ++live; }
         }
         if (live == 0) continue;
         std::vector<float> Tl(16 * (size_t)live), fl((size_t)live); std::vector<int> cl((size_t)live), il((size_t)live);

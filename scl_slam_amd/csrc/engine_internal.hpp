@@ -113,6 +113,7 @@ struct scl_engine {
     scl::IcpWorkspace vox_ws;
     static constexpr int kIcpLanes = 4;                    // concurrent alignments of scl_icp_align_batch
     scl::IcpWorkspace icp_lane_ws[kIcpLanes];
+    scl::IcpWorkspace vox_lane_ws[kIcpLanes];              // submap assembly (voxel filter) of the candidates of a batch, one per lane
     // scl_icp_align_batch: one workspace per loop candidate (their ICP loops run fused, every step one launch for the
     // whole batch), prepared on the lane streams; candidates beyond kIcpBatch go in further rounds
     static constexpr int kIcpBatch = 32;
