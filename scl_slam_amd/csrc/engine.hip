@@ -1209,12 +1209,14 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
         e->last_pass_alt = false;
         return SCL_OK;
     };
-    auto collect = [&](int c) -> int {
+    auto collect = [&](int c, bool last) -> int {
         Chunk &k = ch[c];
-        {   // the caller waits for nothing else: poll (a blocking wait wakes up tens of microseconds late)
+        if (last) {   // nothing left to submit, the caller waits for this: poll (a blocking wait wakes up tens of microseconds late)
             hipError_t q;
             while ((q = hipEventQuery(e->ev_chunk[c])) == hipErrorNotReady) { }
             SCL_HIP(e, q);
+        } else {
+            SCL_HIP(e, hipEventSynchronize(e->ev_chunk[c]));
         }
         collect_profile(e);
         for (int i = 0; i < k.count; ++i) {
@@ -1247,7 +1249,7 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
         }
         // both halves enqueued (or nothing left to submit): wait for the older one
         const int older = ch[c].busy ? c : c ^ 1;
-        if ((rc = collect(older))) return rc;
+        if ((rc = collect(older, next >= n_queries))) return rc;
     }
     return SCL_OK;
 }
