@@ -258,28 +258,67 @@ __device__ __forceinline__ void nn_search_kernel_t_body(float4 *work, int n_src,
         }
     }
     const float gx0 = st->mn[0], gy0 = st->mn[1], gz0 = st->mn[2];
+    // four points per step, their loads issued together (a load per step and a wait behind it left the lane
+    // chasing one L2 latency per point); the last step re-reads the range's final point, which cannot change
+    // a (distance, index) minimum
+    auto scan = [&](int kb, int ke) {
+        for (int k = kb; k < ke; k += 4) {
+            float4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = sorted[k + u < ke ? k + u : ke - 1];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float ex = p.x - q[u].x, ey = p.y - q[u].y, ez = p.z - q[u].z;
+                const float d = (ex * ex + ey * ey) + ez * ez;
+                const int j = __float_as_int(q[u].w);
+                if ((d < best) | ((d == best) & (j < bi))) { best = d; bi = j; }
+            }
+        }
+    };
+    // cells [a, b] of one axis that the interval [v - reach, v + reach] meets, clamped to the grid (empty: a > b)
+    auto reach_cells = [&](float v, float g0, int dim, float reach, int &a, int &b) {
+        const float fa = floorf((v - reach - g0) / h), fb = floorf((v + reach - g0) / h);
+        a = 0; b = dim - 1;
+        if (fa == fa && fb == fb) {
+            const int ia = fa < -1.0e9f ? 0 : (fa > 1.0e9f ? dim : (int)fa), ib = fb < -1.0e9f ? -1 : (fb > 1.0e9f ? dim - 1 : (int)fb);
+            a = max(a, ia); b = min(b, ib);
+        }
+    };
+    if (warm && bi >= 0) {
+        // The previous neighbour bounds the ball: one pass over the (z, y) rows of the ball's bounding box, every row ONE
+        // contiguous range of `sorted` trimmed to the cells the ball reaches -- O(R^2) rows, each O(1) when empty.  (The shell
+        // walk below meets a row once per shell: O(R^3) row visits for a neighbour R cells away, which is what a
+        // candidate that does not match costs.)  Every cell that meets the closed ball is visited; the lanes' minima
+        // only shrink the ball further.
+        const float reach0 = sqrtf(best) * 1.0005f + 1e-6f * h;
+        int z0, z1, y0, y1;
+        reach_cells(p.z, gz0, dz, reach0, z0, z1);
+        reach_cells(p.y, gy0, dy, reach0, y0, y1);
+        const int ny = y1 - y0 + 1, nrows = (z1 >= z0 && ny > 0) ? (z1 - z0 + 1) * ny : 0;
+        for (int t = sub; t < nrows; t += G) {
+            const int zz = t / ny;
+            const int z = z0 + zz, y = y0 + (t - zz * ny);
+            const int row = (z * dy + y) * dx;
+            const float ylo = gy0 + (float)y * h, zlo = gz0 + (float)z * h;
+            const float ddy = fmaxf(fmaxf(ylo - p.y, p.y - (ylo + h)), 0.f), ddz = fmaxf(fmaxf(zlo - p.z, p.z - (zlo + h)), 0.f);
+            const float dyz2 = (ddy * ddy + ddz * ddz) * 0.9995f;
+            if (dyz2 > best) continue;
+            int xa, xb;
+            reach_cells(p.x, gx0, dx, sqrtf(best - dyz2) * 1.0005f + 1e-6f * h, xa, xb);
+            if (xa <= xb) scan(cell_start[row + xa], cell_start[row + xb + 1]);
+        }
+        group_min<G>(best, bi);
+        if (valid && sub == 0) {
+            nn_idx[i] = bi;
+            nn_d2[i] = best;
+        }
+        return;
+    }
     for (int r = 0; r <= maxdim; ++r) {
         const int lo0 = c[0] - r, hi0 = c[0] + r, lo1 = c[1] - r, hi1 = c[1] + r, lo2 = c[2] - r, hi2 = c[2] + r;
         const int z0 = max(lo2, 0), z1 = min(hi2, dz - 1), y0 = max(lo1, 0), y1 = min(hi1, dy - 1);
         const int ny = y1 - y0 + 1, nrows = (z1 - z0 + 1) * ny;
         const int xs = max(lo0, 0), xe = min(hi0, dx - 1);
-        // four points per step, their loads issued together (a load per step and a wait behind it left the lane
-        // chasing one L2 latency per point); the last step re-reads the range's final point, which cannot change
-        // a (distance, index) minimum
-        auto scan = [&](int kb, int ke) {
-            for (int k = kb; k < ke; k += 4) {
-                float4 q[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) q[u] = sorted[k + u < ke ? k + u : ke - 1];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float ex = p.x - q[u].x, ey = p.y - q[u].y, ez = p.z - q[u].z;
-                    const float d = (ex * ex + ey * ey) + ez * ez;
-                    const int j = __float_as_int(q[u].w);
-                    if ((d < best) | ((d == best) & (j < bi))) { best = d; bi = j; }
-                }
-            }
-        };
         for (int t = sub; t < nrows; t += G) {
             const int zz = t / ny;
             const int z = z0 + zz, y = y0 + (t - zz * ny);
