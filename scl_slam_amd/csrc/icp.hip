@@ -750,28 +750,68 @@ __device__ __forceinline__ void jacobi_eig3(double (&A)[3][3], double (&V)[3][3]
     }
 }
 
-// target normals: PCA of the points within `radius` (searched through the NN grid)
+// target normals: PCA of the points within `radius` (searched through the NN grid).  Eight lanes per point: the (z, y) rows of
+// the ball's bounding box are dealt round robin to the lanes (one thread per point left 1.5 waves per SIMD chasing dependent
+// loads row after row), the ten fp64 sums meet by DPP exchanges in a fixed order.
+constexpr int kNormGroup = 8;
+__device__ __forceinline__ double group_sum8(double v)
+{
+    // xor 1, xor 2 (quad permutes), then mirror inside each half row (lane i <-> 7 - i): all 8 lanes end with the same sum
+#define SCL_GSUM_STEP(CTRL)                                                                                  \
+    {                                                                                                        \
+        const long long b = __double_as_longlong(v);                                                         \
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);       \
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);                \
+        v += __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);                                 \
+    }
+    SCL_GSUM_STEP(0xB1)
+    SCL_GSUM_STEP(0x4E)
+    SCL_GSUM_STEP(0x141)
+#undef SCL_GSUM_STEP
+    return v;
+}
+
 __global__ __launch_bounds__(256) void normals_kernel(const unsigned char *tgt, int n_tgt, int stride, const IcpState *st,
                                                       const int *cell_start, const float4 *sorted, double radius, float4 *normals)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_tgt) return;
+    if (n_tgt <= 0) return;
+    const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / kNormGroup;
+    const int sub = threadIdx.x & (kNormGroup - 1);
+    const bool valid = gid < n_tgt;
+    const int i = valid ? gid : n_tgt - 1;                    // surplus groups shadow the last point (all lanes stay in the exchanges)
     const float3 p = load_xyz(tgt, i, stride);
     const float pv[3] = {p.x, p.y, p.z};
+    // Cells the ball can reach, per axis: a point within `radius` of p lies in [p - radius, p + radius]; the grid bins points
+    // with an fp32 division (cell_index), which can be off by ~1e-4 of a cell for grids of a thousand cells per axis -- the
+    // interval is widened by a hundredth of a cell, not by a whole cell on either side (that box held 18 x the ball's volume).
+    const double hh = (double)st->h, kCellSlack = 0.01;
+    auto cells = [&](double v, double reach, int a, int &c0, int &c1) {
+        const double l = floor((v - reach - (double)st->mn[a]) / hh - kCellSlack);
+        const double h = floor((v + reach - (double)st->mn[a]) / hh + kCellSlack);
+        c0 = !(l >= 0.0) ? 0 : (l >= (double)st->dim[a] ? st->dim[a] : (int)l);
+        c1 = !(h < (double)st->dim[a]) ? st->dim[a] - 1 : (h < 0.0 ? -1 : (int)h);
+    };
     int lo[3], hi[3];
-    for (int a = 0; a < 3; ++a) {
-        const double l = floor(((double)pv[a] - radius - (double)st->mn[a]) / (double)st->h) - 1.0;
-        const double h = floor(((double)pv[a] + radius - (double)st->mn[a]) / (double)st->h) + 1.0;
-        lo[a] = l < 0.0 ? 0 : (int)l;
-        hi[a] = h >= (double)st->dim[a] ? st->dim[a] - 1 : (int)h;
-    }
+    for (int a = 1; a < 3; ++a) cells((double)pv[a], radius, a, lo[a], hi[a]);
     const double r2 = radius * radius;
     double sum[3] = {0, 0, 0}, sq[6] = {0, 0, 0, 0, 0, 0};
     int cnt = 0;
-    for (int z = lo[2]; z <= hi[2]; ++z) for (int y = lo[1]; y <= hi[1]; ++y) {
-        const int kb = cell_start[(z * st->dim[1] + y) * st->dim[0] + lo[0]];
-        const int ke = cell_start[(z * st->dim[1] + y) * st->dim[0] + hi[0] + 1];       // cells along x are contiguous
-        for (int k = kb; k < ke; k += 4) {                     // four loads in flight per step; sums stay in index order
+    const int ny = hi[1] - lo[1] + 1, nrows = (hi[2] >= lo[2] && ny > 0) ? (hi[2] - lo[2] + 1) * ny : 0;
+    for (int t = sub; t < nrows; t += kNormGroup) {
+        const int zz = t / ny;
+        const int z = lo[2] + zz, y = lo[1] + (t - zz * ny);
+        // the row's cells along x that the ball reaches: distance from p to the row's (y, z) box, taken a hair smaller
+        const double ylo = (double)st->mn[1] + (double)y * hh, zlo = (double)st->mn[2] + (double)z * hh;
+        const double ddy = fmax(fmax(ylo - (double)p.y, (double)p.y - (ylo + hh)), 0.0) - kCellSlack * hh;
+        const double ddz = fmax(fmax(zlo - (double)p.z, (double)p.z - (zlo + hh)), 0.0) - kCellSlack * hh;
+        const double dyz2 = (ddy > 0.0 ? ddy * ddy : 0.0) + (ddz > 0.0 ? ddz * ddz : 0.0);
+        if (dyz2 > r2) continue;
+        int xa, xb;
+        cells((double)p.x, sqrt(r2 - dyz2), 0, xa, xb);
+        if (xa > xb) continue;
+        const int kb = cell_start[(z * st->dim[1] + y) * st->dim[0] + xa];
+        const int ke = cell_start[(z * st->dim[1] + y) * st->dim[0] + xb + 1];          // cells along x are contiguous
+        for (int k = kb; k < ke; k += 4) {                     // four loads in flight per step
             float4 qq[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) qq[u] = sorted[k + u < ke ? k + u : ke - 1];
@@ -786,6 +826,12 @@ __global__ __launch_bounds__(256) void normals_kernel(const unsigned char *tgt, 
             }
         }
     }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) sum[a] = group_sum8(sum[a]);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) sq[a] = group_sum8(sq[a]);
+    cnt = (int)group_sum8((double)cnt);
+    if (!valid || sub != 0) return;
     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
     if (cnt >= 3) {
         const double N = (double)cnt, m0 = sum[0] / N, m1 = sum[1] / N, m2 = sum[2] / N;
@@ -1263,7 +1309,7 @@ int icp_align_staged(IcpWorkspace *ws, hipStream_t stream, int n_src, int n_tgt,
     if ((rc = pinned(ws, sizeof(IcpState), err))) return rc;
     if (p.estimator == 1) {
         if ((rc = ensure(ws, B_NORM, sizeof(float4) * (size_t)(n_tgt + 1), err))) return rc;
-        hipLaunchKernelGGL(normals_kernel, dim3((n_tgt + 255) / 256 > 0 ? (n_tgt + 255) / 256 : 1), dim3(256), 0, stream,
+        hipLaunchKernelGGL(normals_kernel, dim3(((size_t)n_tgt * kNormGroup + 255) / 256 > 0 ? (unsigned)(((size_t)n_tgt * kNormGroup + 255) / 256) : 1u), dim3(256), 0, stream,
                            (const unsigned char *)ws->buf[B_TGT], n_tgt, stride, (const IcpState *)ws->buf[B_STATE],
                            (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], p.normal_radius,
                            (float4 *)ws->buf[B_NORM]);
@@ -1343,7 +1389,7 @@ int icp_batch_prepare(IcpWorkspace *ws, hipStream_t stream, const void *d_src, i
     if ((rc = build_grid(ws, stream, n_tgt, stride, err))) return rc;
     if (p.estimator == 1) {
         if ((rc = ensure(ws, B_NORM, sizeof(float4) * (size_t)(n_tgt + 1), err))) return rc;
-        hipLaunchKernelGGL(normals_kernel, dim3((n_tgt + 255) / 256 > 0 ? (n_tgt + 255) / 256 : 1), dim3(256), 0, stream,
+        hipLaunchKernelGGL(normals_kernel, dim3(((size_t)n_tgt * kNormGroup + 255) / 256 > 0 ? (unsigned)(((size_t)n_tgt * kNormGroup + 255) / 256) : 1u), dim3(256), 0, stream,
                            (const unsigned char *)ws->buf[B_TGT], n_tgt, stride, (const IcpState *)ws->buf[B_STATE],
                            (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], p.normal_radius,
                            (float4 *)ws->buf[B_NORM]);
