@@ -284,12 +284,11 @@ __device__ __forceinline__ void nn_search_kernel_t_body(float4 *work, int n_src,
             a = max(a, ia); b = min(b, ib);
         }
     };
-    if (warm && bi >= 0) {
-        // The previous neighbour bounds the ball: one pass over the (z, y) rows of the ball's bounding box, every row ONE
-        // contiguous range of `sorted` trimmed to the cells the ball reaches -- O(R^2) rows, each O(1) when empty.  (The shell
-        // walk below meets a row once per shell: O(R^3) row visits for a neighbour R cells away, which is what a
-        // candidate that does not match costs.)  Every cell that meets the closed ball is visited; the lanes' minima
-        // only shrink the ball further.
+    // One pass over the ball of the best distance known so far: the (z, y) rows of its bounding box, every row ONE contiguous
+    // range of `sorted` trimmed to the cells the ball reaches -- O(R^2) rows, each O(1) when empty.  (The shell walk below
+    // meets a row once per shell: O(R^3) row visits for a neighbour R cells away, which is what a candidate that does not
+    // match costs.)  Every cell that meets the closed ball is visited; the lanes' minima only shrink the ball further.
+    auto ball_pass = [&]() {
         const float reach0 = sqrtf(best) * 1.0005f + 1e-6f * h;
         int z0, z1, y0, y1;
         reach_cells(p.z, gz0, dz, reach0, z0, z1);
@@ -308,12 +307,16 @@ __device__ __forceinline__ void nn_search_kernel_t_body(float4 *work, int n_src,
             if (xa <= xb) scan(cell_start[row + xa], cell_start[row + xb + 1]);
         }
         group_min<G>(best, bi);
+    };
+    if (warm && bi >= 0) {                                       // the previous neighbour bounds the ball
+        ball_pass();
         if (valid && sub == 0) {
             nn_idx[i] = bi;
             nn_d2[i] = best;
         }
         return;
     }
+    // Cold search: shells until the first one that holds a point (its distance bounds the ball), then the ball once.
     for (int r = 0; r <= maxdim; ++r) {
         const int lo0 = c[0] - r, hi0 = c[0] + r, lo1 = c[1] - r, hi1 = c[1] + r, lo2 = c[2] - r, hi2 = c[2] + r;
         const int z0 = max(lo2, 0), z1 = min(hi2, dz - 1), y0 = max(lo1, 0), y1 = min(hi1, dy - 1);
@@ -376,6 +379,7 @@ __device__ __forceinline__ void nn_search_kernel_t_body(float4 *work, int n_src,
         }
         if (!open) break;
         if (bi >= 0 && best < bound2 * 0.9998f) break;
+        if (bi >= 0 && best < FLT_MAX) { ball_pass(); break; }   // (every lane of the group holds the same best and bi here)
     }
     if (valid && sub == 0) {
         nn_idx[i] = bi;
