@@ -111,7 +111,8 @@ def test_screening_with_adversarial_descriptors():
     eng.close()
 
 
-def test_alignment_kernel_on_ties_and_near_ties():
+@pytest.mark.parametrize("R,S", [(64, 120), (80, 180)])
+def test_alignment_kernel_on_ties_and_near_ties(R, S):
     """The first shift comes from the fp32 matrix-core correlation of sc_align_kernel only when it leads every other shift
     by more than the filter's margin; ties (the reference keeps the lowest shift), near ties, flat and periodic sector
     keys, extreme magnitudes and non-finite values must fall through to the reference's own fp64 evaluation -- any wrong
@@ -122,10 +123,10 @@ def test_alignment_kernel_on_ties_and_near_ties():
     base = descs[n - 1].copy()
     k = 20
     descs[k + 0] = np.tile(base[:, :1], (1, S))                               # flat sector key: every shift ties
-    descs[k + 1] = np.tile(base[:, :60], (1, 2))                              # period 60: two exact ties
-    descs[k + 2] = np.tile(base[:, :2], (1, 60))                              # period 2
-    descs[k + 3] = np.tile(base[:, :60], (1, 2)); descs[k + 3][0, 61] += np.float32(1e-6)     # ... broken in the last bits
-    descs[k + 4] = np.tile(base[:, :60], (1, 2)); descs[k + 4][3, 7] *= np.float32(1.0 + 1e-7)
+    descs[k + 1] = np.tile(base[:, :S // 2], (1, 2))                          # period S/2: two exact ties
+    descs[k + 2] = np.tile(base[:, :2], (1, S // 2))                          # period 2
+    descs[k + 3] = np.tile(base[:, :S // 2], (1, 2)); descs[k + 3][0, S // 2 + 1] += np.float32(1e-6)     # ... broken in the last bits
+    descs[k + 4] = np.tile(base[:, :S // 2], (1, 2)); descs[k + 4][3, 7] *= np.float32(1.0 + 1e-7)
     descs[k + 5] = np.roll(base, 17, axis=1) * np.float32(1e18)               # huge: the filter's norm guard
     descs[k + 6] = np.roll(base, 33, axis=1) * np.float32(1e-18)              # tiny
     descs[k + 7] = np.roll(base, 5, axis=1); descs[k + 7][2, 9] = np.nan
