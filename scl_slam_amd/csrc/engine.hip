@@ -902,6 +902,32 @@ int launch_survivor_pass(scl_engine *e, const int *qslot, const int *lo, const i
     return SCL_OK;
 }
 
+// The exact pass of the 80 x 180 grid over the screened queries of buffer sets set0 .. set0 + nq - 1: per group of up to four
+// queries the select launch (survivor lists + ring-key top-k), the one-sector-per-lane program on the survivors and the arg-min.
+int launch_survivor_pass_wide(scl_engine *e, const int *qslot, const int *lo, const int *n, int nq, int set0, double *const *out3, hipStream_t stream)
+{
+    ProfScope ps(e, P_ARGMIN, stream);
+    for (int g = 0; g < nq; g += kMaxQueryBatch) {
+        const int w = nq - g < kMaxQueryBatch ? nq - g : kMaxQueryBatch;
+        ScreenBatch sb{};
+        sb.nq = w;
+        for (int j = 0; j < w; ++j) { sb.slot[j] = qslot[g + j]; sb.base[j] = lo[g + j]; sb.n[j] = n[g + j]; sb.buf[j] = set0 + g + j; }
+        sb.pair_stride = e->set_stride;
+        sb.approx = e->d_approx; sb.starts = e->d_starts; sb.align_fallbacks = e->d_align_fallbacks; sb.ring_d2 = e->d_ring_d2;
+        sb.survivors = e->d_surv; sb.n_surv = e->d_nsurv; sb.t_min = e->d_tmin;
+        sb.k = e->cfg.num_candidates; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
+        SCL_HIP(e, launch_sc_select_batch(sb, stream));
+        const int *sv[kMaxQueryBatch]; const int *ns[kMaxQueryBatch]; double *od[kMaxQueryBatch]; int *os[kMaxQueryBatch];
+        for (int j = 0; j < w; ++j) {
+            const size_t set = (size_t)(set0 + g + j);
+            sv[j] = e->d_surv + set * e->set_stride; ns[j] = e->d_nsurv + set;
+            od[j] = e->d_dist + set * e->set_stride; os[j] = e->d_shift + set * e->set_stride;
+        }
+        SCL_HIP(e, launch_sc_distance_survivors_wide(db_view(e), w, qslot + g, lo + g, e->SR, sv, ns, od, os, out3 + g, e->num_cu, stream));
+    }
+    return SCL_OK;
+}
+
 int submit_full_locked(scl_engine *e, int query, int lo, int hi, int *ticket)
 {
     if (e->screen && !e->in_single_fallback) {             // one query through the screening pipeline of the batched form
@@ -1031,22 +1057,7 @@ int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, c
             if ((rc = ensure_sets(e, (size_t)nmax))) return rc;
             if ((rc = launch_screen_group(e, ScreenGroup{qb.slot, qb.base, qb.n, qb.nq, 0}))) return rc;
             if (wide) {
-                // 80 x 180: survivors (+ ring-key top-k) by the select launch, then per query the exact one-sector-per-lane
-                // kernel on its survivors and the arg-min
-                ScreenBatch sb{};
-                sb.nq = qb.nq;
-                for (int j = 0; j < qb.nq; ++j) { sb.slot[j] = qb.slot[j]; sb.base[j] = qb.base[j]; sb.n[j] = qb.n[j]; sb.buf[j] = j; }
-                sb.pair_stride = e->set_stride;
-                sb.approx = e->d_approx; sb.starts = e->d_starts; sb.align_fallbacks = e->d_align_fallbacks; sb.ring_d2 = e->d_ring_d2; sb.survivors = e->d_surv; sb.n_surv = e->d_nsurv; sb.t_min = e->d_tmin;
-                sb.k = k; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
-                SCL_HIP(e, launch_sc_select_batch(sb, e->stream));
-                ProfScope ps(e, P_ARGMIN);
-                const int *sv[kMaxQueryBatch]; const int *ns[kMaxQueryBatch]; double *od[kMaxQueryBatch]; int *os[kMaxQueryBatch];
-                for (int j = 0; j < qb.nq; ++j) {
-                    sv[j] = e->d_surv + (size_t)j * e->set_stride; ns[j] = e->d_nsurv + j;
-                    od[j] = e->d_dist + (size_t)j * e->set_stride; os[j] = e->d_shift + (size_t)j * e->set_stride;
-                }
-                SCL_HIP(e, launch_sc_distance_survivors_wide(db_view(e), qb.nq, qb.slot, qb.base, e->SR, sv, ns, od, os, qb.out3, e->num_cu, e->stream));
+                if ((rc = launch_survivor_pass_wide(e, qb.slot, qb.base, qb.n, qb.nq, 0, qb.out3, e->stream))) return rc;
             } else if ((rc = launch_survivor_pass(e, qb.slot, qb.base, qb.n, qb.nq, 0, qb.out3))) return rc;
         } else {
             ProfScope ps(e, P_SC);
@@ -1125,6 +1136,7 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
 {
     constexpr int NS = scl_engine::kScreenSets;
     constexpr int CH = NS / 2;                               // scans per chunk: the two chunks in flight use the two halves of the buffer sets
+    const bool wide = sc_screen_is_wide(db_view(e), e->SR);  // 80 x 180: same launches, its own exact pass
     struct List { int qslot[CH], qlo[CH], qn[CH], pos[CH], m = 0; };     // the scans of a chunk that have something to score
     struct Chunk { int first = 0, count = 0; bool busy = false, aligned = false; std::vector<int> lo, empty; };
     Chunk ch[2];
@@ -1170,8 +1182,8 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
         // launch, whose buffer sets the exact pass of the chunk before this one may still be reading: the main stream waits
         // for it there (it finished long ago).  Only the very first launch aligns for itself.
         // the exact pass's argument sets go to the device now, ahead of the products it has to wait for
-        const int region = cur.m > 0 ? (int)survivor_arg_region(e) : 0;
-        if (cur.m > 0 && (rc = launch_survivor_pass(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, e->stream_surv, kSurvivorArgs, region))) return rc;
+        const int region = (cur.m > 0 && !wide) ? (int)survivor_arg_region(e) : 0;
+        if (cur.m > 0 && !wide && (rc = launch_survivor_pass(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, e->stream_surv, kSurvivorArgs, region))) return rc;
         bool next_aligned = false;
         for (int g = 0; g < cur.m; g += spl) {
             const int w = cur.m - g < spl ? cur.m - g : spl;
@@ -1200,7 +1212,8 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
             SCL_HIP(e, hipEventRecord(e->ev_k1[c], e->stream_surv));         // behind the copy of the argument sets
             SCL_HIP(e, hipStreamWaitEvent(e->stream, e->ev_k1[c], 0));
         }
-        if (cur.m > 0 && (rc = launch_survivor_pass(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, xs, kSurvivorKernel, region))) return rc;
+        if (cur.m > 0 && (rc = wide ? launch_survivor_pass_wide(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, xs)
+                                    : launch_survivor_pass(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, xs, kSurvivorKernel, region))) return rc;
         SCL_HIP(e, hipEventRecord(e->ev_chunk[c], xs));
         k.busy = true;
         k.aligned = false;
@@ -1266,7 +1279,7 @@ int scl_detect_full_stream(scl_engine *e, const int *queries, const int *lo, con
     for (int i = 0; i < scl_engine::kSlots; ++i)
         if (e->slot_busy[i]) return fail(e, SCL_ERR_INVALID_ARG, "detect_full_stream: collect the passes in flight first");
     const int spl = scans_per_launch < 1 ? 1 : (scans_per_launch > kMaxQueryBatch ? kMaxQueryBatch : scans_per_launch);
-    if (e->screen && sc_distance_fuses_ring(db_view(e), e->SR))
+    if (e->screen && (sc_distance_fuses_ring(db_view(e), e->SR) || sc_screen_is_wide(db_view(e), e->SR)))
         return stream_screened_locked(e, queries, lo, hi, n_queries, spl, nn_idx, shift, dist);
     int depth = launches_in_flight < 1 ? 1 : launches_in_flight;
     if (depth * spl > scl_engine::kSlots) depth = scl_engine::kSlots / spl;
