@@ -319,7 +319,9 @@ __device__ __forceinline__ void pin1(double &a)
 // The whole workgroup program of the wave kernel: `a` = the argument set of this workgroup's query, bid / nbk = its
 // index among / the number of workgroups that serve the query.
 template <int RG, int W, int CH, int S, int MAXT, bool STAMP>
-__device__ __forceinline__ void sc_wave_body(const ScArgs &a, const int bid, const int nbk)
+// sbid / snb: this workgroup's share of the candidates is part sbid of snb (normally bid of nbk; the survivors' pass keeps one
+// workgroup free of candidates: it forms the ring-key top-k meanwhile and only takes part in the tail)
+__device__ __forceinline__ void sc_wave_body(const ScArgs &a, const int bid, const int nbk, const int sbid, const int snb)
 {
     unsigned long long st_t = 0, st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_real0 = 0, st_cyc0 = 0;
     auto stamp = [&]() -> unsigned long long {
@@ -373,8 +375,8 @@ __device__ __forceinline__ void sc_wave_body(const ScArgs &a, const int bid, con
     // Candidates of this workgroup: a contiguous range, handed out wave by wave through an LDS counter (below).
     // A workgroup without candidates (few survivors of the screening pass) skips the query staging altogether.
     const int n_cand = a.n_dev ? *a.n_dev : a.n;
-    const int c_lo = (int)(((long long)bid * n_cand) / nbk);
-    const int c_hi = (int)(((long long)(bid + 1) * n_cand) / nbk);
+    const int c_lo = (int)(((long long)sbid * n_cand) / snb);
+    const int c_hi = (int)(((long long)(sbid + 1) * n_cand) / snb);
     for (int idx = threadIdx.x; idx < (c_lo < c_hi ? RG * S : 0); idx += blockDim.x) {
         const int rg = idx / S, c = idx - rg * S;
         const float4 v = a.q_desc[idx];
@@ -949,7 +951,7 @@ __global__ __launch_bounds__(MAXT) void sc_distance_wave_kernel(ScBatchArgs ab)
     const int nbk = ab.nb;                             // workgroups per query
     const int qi = ab.nq > 1 ? (int)blockIdx.x / nbk : 0;
     const int bid = (int)blockIdx.x - qi * nbk;        // workgroup index within its query
-    sc_wave_body<RG, W, CH, S, MAXT, STAMP>(ab.q[qi], bid, nbk);
+    sc_wave_body<RG, W, CH, S, MAXT, STAMP>(ab.q[qi], bid, nbk, bid, nbk);
 }
 
 // Exact pass behind the screening pass (sc_screen.hip): query qi = qargs[qi] (any number of queries: the argument sets
@@ -999,7 +1001,9 @@ __global__ __launch_bounds__(MAXT) void sc_distance_survivors_kernel(const ScArg
     __syncthreads();
     // The ring-key top-k of the range (workgroup 0 of the query): k rounds of "smallest key larger than the previous
     // pick" over the metric the screening pass stored; keys (d2 bits << 32 | position) are unique.
-    if (bid == 0 && a.sel_topk_k > 0) {
+    // (the query's LAST workgroup: it scores nothing, so the top-k runs beside the others' scoring, not in front of it)
+    const bool topk_block = nb > 1 && bid == nb - 1;
+    if ((nb > 1 ? topk_block : bid == 0) && a.sel_topk_k > 0) {
         __shared__ unsigned long long wave_key[MAXT / kWave];
         const unsigned long long none = ~0ull;
         unsigned long long prev = 0ull;
@@ -1031,8 +1035,9 @@ __global__ __launch_bounds__(MAXT) void sc_distance_survivors_kernel(const ScArg
         }
         __syncthreads();
     }
-    a.n = total; a.n_dev = nullptr;
-    sc_wave_body<RG, W, CH, S, MAXT, false>(a, bid, nb);
+    a.n = topk_block ? 0 : total; a.n_dev = nullptr;
+    if (nb > 1) sc_wave_body<RG, W, CH, S, MAXT, false>(a, bid, nb, topk_block ? 0 : bid, topk_block ? 1 : nb - 1);
+    else sc_wave_body<RG, W, CH, S, MAXT, false>(a, bid, nb, bid, nb);
 }
 
 constexpr int kTailReadable = 4 * kWave;        // partial records the last workgroup of the fused epilogue merges (u < 4 x 64 lanes)
