@@ -160,3 +160,37 @@ def test_alignment_kernel_on_ties_and_near_ties(R, S):
             b = int(np.flatnonzero(ok)[np.argmin(d_ref[ok])])
             assert (nn[i], sh[i]) == (b, s_ref[b]) and dd[i].view(np.uint64) == d_ref[b].view(np.uint64), (q, nn[i], b)
     eng.close()
+
+
+@pytest.mark.parametrize("R,S,n", [(64, 120, 777), (80, 180, 401)])
+def test_random_ranges_against_the_checker(R, S, n):
+    """Ranges of every size around the kernels' granularity (groups of 16 keyframes, four waves, 64-entry walks of the
+    selection), starting anywhere, queries anywhere: the winner of the screened pass is the checker's, bit for bit."""
+    descs = synth_descriptors(n, R, S, seed=4242, revisit_frac=0.08)
+    rs = np.random.RandomState(99)
+    descs[5] = 0.0; descs[6][:, ::2] = 0.0; descs[7][1, 1] = np.nan
+    eng = ScanContextEngine(num_ring=R, num_sector=S, initial_capacity=n)
+    db = ob.OracleDB(ob.make_config(R=R, S=S))
+    eng.save_bulk(descs); db.save_bulk(descs)
+    sizes = [1, 2, 3, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 127, 128, 129, 255, 256, 257]
+    cases = []
+    for sz in sizes:
+        for _ in range(2):
+            lo = int(rs.randint(0, n - sz))
+            cases.append((int(rs.randint(0, n)), lo, lo + sz))
+    for _ in range(20):
+        lo = int(rs.randint(0, n - 1)); hi = int(rs.randint(lo + 1, n + 1))
+        cases.append((int(rs.randint(0, n)), lo, hi))
+    qs = np.array([c[0] for c in cases], np.int32); los = np.array([c[1] for c in cases], np.int32); his = np.array([c[2] for c in cases], np.int32)
+    nn, sh, dd = eng.detect_full_stream(qs, los, his, 4, 2)
+    for i, (q, lo, hi) in enumerate(cases):
+        d_ref, s_ref = db.distance_batch(q, cand=np.arange(lo, hi, dtype=np.int32))
+        ok = d_ref < 1e7
+        one = eng.detect_full_range(q, lo, hi)
+        if not ok.any():
+            assert nn[i] == -1 and one[0] == -1, (q, lo, hi)
+            continue
+        b = int(np.flatnonzero(ok)[np.argmin(d_ref[ok])])
+        assert (nn[i], sh[i]) == (lo + b, s_ref[b]) and dd[i].view(np.uint64) == d_ref[b].view(np.uint64), (q, lo, hi, nn[i], lo + b)
+        assert one[0] == lo + b and one[1] == s_ref[b] and np.float64(one[2]).view(np.uint64) == d_ref[b].view(np.uint64)
+    eng.close()
