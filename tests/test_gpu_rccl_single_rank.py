@@ -34,6 +34,13 @@ def test_full_scan_stream_over_rccl_one_rank():
         assert len(res) == len(queries)
         for (nn, sh, d), (d2, g, sh2) in zip(single, res):
             assert (nn, sh) == (g, sh2) and d == d2
+        # bench.py's form: arrays through the native pipeline, one exchange per chunk of scans
+        st = FullScanStream(e, rank=0, world=1, device="cuda", depth=2, scans_per_launch=4, native_chunk=4, always_exchange=True)
+        st.submit_many(np.array(queries, np.int32), 0, np.array(queries, np.int32) - 50)
+        res = st.drain()
+        assert len(res) == len(queries)
+        for (nn, sh, d), (d2, g, sh2) in zip(single, res):
+            assert (nn, sh) == (g, sh2) and d == d2
         e.close()
     finally:
         dist.destroy_process_group()
