@@ -187,7 +187,7 @@ __device__ __forceinline__ void group_min(float &d, int &j)
         const bool take = (od < d) | ((od == d) & (oj < j));                                        \
         d = take ? od : d; j = take ? oj : j;                                                       \
     }
-    SCL_GMIN_STEP(0xB1)
+    if (G >= 2) SCL_GMIN_STEP(0xB1)
     if (G >= 4) SCL_GMIN_STEP(0x4E)
     if (G >= 8) SCL_GMIN_STEP(0x141)
 #undef SCL_GMIN_STEP
