@@ -46,8 +46,6 @@ ALGO_BYTES_PER_PAIR = R * S * 4 + S * 4 + S * 4      # 31 680 
 # fraction is priced on THIS figure (16 608 B), not on SURVEY's 31 680 B: the kernel must not get credit for bytes it
 # does not move; the SURVEY-priced rate is reported beside it as `survey_equivalent`.
 KERNEL_BYTES_PER_PAIR = R * S * 2 + S * 8 + 4 * 4 * ((R + 3) // 4) + 32
-ALGO_FLOP_PER_PAIR = 3 * S * S + 13 * S * 2 * R      # 3 S^2 + (2 SR + 1) S 2R = 242 880 at 64x120
-FP64_VECTOR_PEAK_TFLOPS = 78.6                       # MI355X fp64 vector peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 
@@ -444,13 +442,7 @@ def main():
                          "algorithmic_bytes_per_launch": KERNEL_BYTES_PER_PAIR * k1_pairs,
                          "survey_equivalent": {"bytes_per_pair": ALGO_BYTES_PER_PAIR, "achieved": survey_equiv, "frac": survey_equiv / HBM_PEAK_GBS,
                                                "note": "SURVEY 8(d) prices the fp32 descriptor; the kernel reads a half-size fp16 copy, "
-                                                       "the exact fp64 kernel re-scores the survivors"},
-                         # at 64x120 the arithmetic intensity (7.7 flop/B) sits just under the fp64 ridge, so
-                         # the fp64-vector fraction is reported beside the HBM one (same launches, same event times)
-                         "fp64_vector": {"achieved": ALGO_FLOP_PER_PAIR * k1_pairs / (k1_ms * 1e-3) / 1e12 if k1_ms > 0 else 0.0,
-                                         "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                         "frac": (ALGO_FLOP_PER_PAIR * k1_pairs / (k1_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS) if k1_ms > 0 else 0.0,
-                                         "algorithmic_flop_per_pair": ALGO_FLOP_PER_PAIR}},
+                                                       "the exact fp64 kernel re-scores the survivors"}},
             "device": eng.device_name(),
         }
         if world == 1 and not args.no_secondary:
