@@ -1,7 +1,7 @@
 #!/bin/bash
 # What bounds the screening pass?  Diagnostic build (-DSCL_DIAGNOSTICS), SCL_SCREEN_PROBE: 0 = the product kernels,
 # 2 = the screening kernel without staging and MFMA (its loads alone), 3 = without the alignment kernel (stale first shifts),
-# 4 = the alignment kernel alone, 5 / 6 = the alignment role inside the products' launch reduced to its sector-key reads /
+# 4 = the first launch's own alignment kernel alone (outside the event pair: see rocprofv3), 5 / 6 = the alignment role inside the products' launch reduced to its sector-key reads /
 # to its matrix products on stale keys.  Results are wrong on purpose.
 set -e
 cd "$(dirname "$0")/.."
