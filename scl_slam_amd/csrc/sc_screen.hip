@@ -397,7 +397,7 @@ __device__ __forceinline__ void rotate_mask(const unsigned long long (&m)[(S + 6
 }
 
 template <int RGH, int S, int W, int D, int PROBE>
-__device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const int block, unsigned char *smem_raw)
+__device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const int qi, const int bid, unsigned char *smem_raw)
 {
     constexpr int NWV = kScreenWaves;
     constexpr int MT = (W + 15) / 16;                  // tiles of 16 shift rows
@@ -413,8 +413,6 @@ __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const 
     static_assert(S % NWV == 0 && SB % 64 == 0 && NST % D == 0 && W <= 32 && S <= 224, "tiling");
 
     const int nbk = ab.nb;
-    const int qi = ab.nq > 1 ? block / nbk : 0;
-    const int bid = block - qi * nbk;
     const ScreenArgs &a = ab.q[qi];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: wave-derived addresses stay in SGPRs
@@ -597,24 +595,39 @@ __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const 
 }
 
 // One launch = the screening products of a batch of scans and, in further workgroups of the same grid, the alignment of
-// the NEXT batch (fa.next.nq = 0: none): the products are HBM bound, the alignment matrix-core bound, and the workgroups
+// the NEXT batch (fa.align_blocks = 0: none): the products are HBM bound, the alignment matrix-core bound, and the workgroups
 // of the second take the third wave slot per SIMD the first leaves free.  (Two kernels on two streams do the same in
 // principle; measured, the dispatcher then lets the alignment crowd out the products.)
-struct ScreenFusedArgs { ScreenBatchArgs prod; ScreenBatchArgs next; int prod_blocks, align_blocks, period; };
+//
+// Order of the workgroups -- the dispatcher hands them out by index, round robin over the 8 XCDs (index & 7), each with
+// its own 4 MB L2.  Along one XCD's sequence (index >> 3) the pattern is: the nq workgroups that walk the SAME keyframe
+// groups for the nq queries of the batch, then one workgroup of the alignment.  The nq start together and read the same
+// lines within microseconds of each other, so all but the first find them in that XCD's L2: the products' time drops from
+// 92 to 56 us per four scans (the same workgroups query-major: every query streams the copy from HBM / the Infinity Cache
+// on its own).  The short alignment workgroups are spread over the whole launch.  Slots past either role's count exit.
+struct ScreenFusedArgs { ScreenBatchArgs prod; ScreenBatchArgs next; int align_blocks; };
 
 constexpr int hdesc_rgh(int RG) { return ((RG * 8 + 63) / 64) * 8; }   // 8-byte elements per sector of hdesc: whole k-steps of 64 B
+
+__host__ __device__ inline int fused_patterned_blocks(int nq, int nbk, int align_blocks) { return 8 * ((nbk + 7) >> 3) * (nq + (align_blocks > 0 ? 1 : 0)); }
 
 template <int RG, int S, int W, int D, int OCC, int PROBE = 0>
 __global__ __launch_bounds__(kScreenWaves * kWave, OCC) void sc_screen_kernel(ScreenFusedArgs fa)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_fused[];
-    // every period-th workgroup of the grid belongs to the alignment, as long as it has any: the dispatcher hands out
-    // workgroups in index order, so the (short) alignment workgroups run beside the products from the start of the launch
-    // instead of queueing behind all of them
-    const int b = (int)blockIdx.x, j = b / fa.period;
-    const int before = j < fa.align_blocks ? j : fa.align_blocks;               // alignment workgroups with a smaller index
-    if (b - j * fa.period == fa.period - 1 && j < fa.align_blocks) sc_align_role<RG, S, W>(fa.next, j, smem_fused);
-    else sc_screen_role<hdesc_rgh(RG), S, W, D, PROBE>(fa.prod, b - before, smem_fused);
+    const int b = (int)blockIdx.x, nq = fa.prod.nq, nbk = fa.prod.nb, X = fa.align_blocks;
+    const int cyc_len = nq + (X > 0 ? 1 : 0);
+    const int patterned = fused_patterned_blocks(nq, nbk, X);
+    if (b < patterned) {
+        const int xcd = b & 7, j = b >> 3;
+        const int grp = j / cyc_len, cyc = j - grp * cyc_len;
+        const int idx = grp * 8 + xcd;
+        if (cyc < nq) { if (idx < nbk) sc_screen_role<hdesc_rgh(RG), S, W, D, PROBE>(fa.prod, cyc, idx, smem_fused); }
+        else if (idx < X) sc_align_role<RG, S, W>(fa.next, idx, smem_fused);
+    } else {
+        const int idx = 8 * ((nbk + 7) >> 3) + (b - patterned);             // more alignment workgroups than pattern slots
+        if (idx < X) sc_align_role<RG, S, W>(fa.next, idx, smem_fused);
+    }
 }
 
 template <int RG, int S, int W>
@@ -815,7 +828,6 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
     if (blocks > ngroups) blocks = ngroups;
     if (blocks > kScreenMaxBlocks) blocks = kScreenMaxBlocks;
     fa.prod.nb = blocks;
-    fa.prod_blocks = blocks * sb.nq;
     int extra = 0;
     if (next && probe != 3) {
         if (next->nq < 1 || next->nq > kMaxQueryBatch) return hipErrorInvalidValue;
@@ -829,9 +841,10 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
     }
     const size_t lds = extra && lds0 > lds1 ? lds0 : lds1;
     fa.align_blocks = extra;
-    fa.period = extra > 0 ? (fa.prod_blocks + extra) / extra : 1;
-    if (fa.period < 1) fa.period = 1;
-    hipLaunchKernelGGL(kern, dim3(fa.prod_blocks + extra), dim3(kScreenWaves * kWave), lds, stream, fa);
+    const int patterned = fused_patterned_blocks(sb.nq, blocks, extra);
+    const int slots = 8 * ((blocks + 7) >> 3);                               // alignment slots inside the pattern
+    const int grid = patterned + (extra > slots ? extra - slots : 0);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kScreenWaves * kWave), lds, stream, fa);
     return hipGetLastError();
 }
 
