@@ -60,10 +60,10 @@ def parse_args():
     ap.add_argument("--merge-every", type=int, default=16, help="N > 1, --native-chunk 0: scans whose per-rank winners share one exchange")
     ap.add_argument("--exchange", choices=("allreduce", "allgather"), default="allreduce",
                     help="N > 1: min all-reduce on packed keys (default) or all-gather + host merge (fallback, for comparison)")
-    ap.add_argument("--scans-per-launch", type=int, default=4,
-                    help="incoming scans scored by one kernel launch (1..4; the reference runs several robots, whose scans "
-                         "arrive together): the next scan's workgroups take over CUs as the previous scan's retire, so "
-                         "no CU idles in a launch tail")
+    ap.add_argument("--scans-per-launch", type=int, default=16,
+                    help="incoming scans scored by one kernel launch (1..16; the reference runs several robots, whose scans "
+                         "arrive together): the workgroups that walk the same keyframes for the scans of a launch share "
+                         "them through an XCD's L2, so the database crosses HBM once per launch, not once per scan")
     ap.add_argument("--native-chunk", type=int, default=256,
                     help="scans handed to the engine's native submit/collect pipeline per call (0: drive every scan from Python)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -269,10 +269,10 @@ def secondary_80x180(device, n=10000, steps=512):
     del descs
     n_elig = n - N_EXCLUDE
     qs = (n_elig + (np.arange(steps) % N_EXCLUDE)).astype(np.int32)
-    eng.detect_full_stream(qs[:8], 0, n_elig, 4, 2)
+    eng.detect_full_stream(qs[:8], 0, n_elig, 16, 2)
     eng.profile_reset(); eng.profile_enable(3)
     t0 = time.perf_counter()
-    nn, sh, dd = eng.detect_full_stream(qs, 0, n_elig, 4, 2)
+    nn, sh, dd = eng.detect_full_stream(qs, 0, n_elig, 16, 2)
     dt = time.perf_counter() - t0
     eng.profile_enable(0)
     prof = eng.profile()

@@ -1278,9 +1278,13 @@ int scl_detect_full_stream(scl_engine *e, const int *queries, const int *lo, con
     (void)hipSetDevice(e->device);
     for (int i = 0; i < scl_engine::kSlots; ++i)
         if (e->slot_busy[i]) return fail(e, SCL_ERR_INVALID_ARG, "detect_full_stream: collect the passes in flight first");
+    if (e->screen && (sc_distance_fuses_ring(db_view(e), e->SR) || sc_screen_is_wide(db_view(e), e->SR))) {
+        // the screened grids take up to kMaxScreenBatch scans per launch: the workgroups of a launch's queries share every
+        // keyframe line through the L2 (sc_screen.hip), so more scans per launch read less per scan from HBM
+        const int spl_s = scans_per_launch < 1 ? 1 : (scans_per_launch > kMaxScreenBatch ? kMaxScreenBatch : scans_per_launch);
+        return stream_screened_locked(e, queries, lo, hi, n_queries, spl_s, nn_idx, shift, dist);
+    }
     const int spl = scans_per_launch < 1 ? 1 : (scans_per_launch > kMaxQueryBatch ? kMaxQueryBatch : scans_per_launch);
-    if (e->screen && (sc_distance_fuses_ring(db_view(e), e->SR) || sc_screen_is_wide(db_view(e), e->SR)))
-        return stream_screened_locked(e, queries, lo, hi, n_queries, spl, nn_idx, shift, dist);
     int depth = launches_in_flight < 1 ? 1 : launches_in_flight;
     if (depth * spl > scl_engine::kSlots) depth = scl_engine::kSlots / spl;
     std::vector<int> tk((size_t)n_queries);

@@ -78,10 +78,11 @@ hipError_t launch_sc_distance_batch(const struct DbView &db, const QueryBatch &q
 // ring_d2 = its ring-key metric (the exact pass forms the top-k from it).  launch_sc_select_batch (diagnostics only):
 // survivors = the database slots (ascending) that can still hold the minimum.
 // t_min: one word per query, 0xffffffff before the first launch (the select launch re-arms it).
+constexpr int kMaxScreenBatch = 16;         // scans per screening launch (the fused exact kernel of the 20 x 60 grid keeps kMaxQueryBatch)
 struct ScreenBatch {
     int nq;
-    int slot[kMaxQueryBatch], base[kMaxQueryBatch], n[kMaxQueryBatch];
-    int buf[kMaxQueryBatch];                    // buffer set of query i: approx / ring_d2 / survivors at buf * pair_stride, t_min[buf], top-k set buf
+    int slot[kMaxScreenBatch], base[kMaxScreenBatch], n[kMaxScreenBatch];
+    int buf[kMaxScreenBatch];                    // buffer set of query i: approx / ring_d2 / survivors at buf * pair_stride, t_min[buf], top-k set buf
     size_t pair_stride;
     float *approx; float *ring_d2; int *survivors; int *n_surv; unsigned int *t_min;
     int *starts;                                // first shifts (alignment kernel -> screening kernel), like approx

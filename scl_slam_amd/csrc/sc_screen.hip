@@ -60,7 +60,32 @@ struct ScreenArgs {
     int align_filter;
 };
 
-struct ScreenBatchArgs { ScreenArgs q[kMaxQueryBatch]; int nq, nb; };
+// The argument block of a batch: what the queries share, and four words per query (a kernel's arguments end at 4 KB; the
+// launch takes two batches).  A role rebuilds its query's ScreenArgs from it (wave-uniform: scalar registers).
+struct ScreenQuery { int slot, base, n, buf; };
+struct ScreenBatchArgs {
+    const double *vkey; const float *rkey; const uint2 *hdesc; const unsigned int *kmask; const float4 *rkey4;
+    int *starts; float *approx; float *ring_d2; unsigned int *t_min; unsigned long long *fallbacks;
+    unsigned long long pair_stride;
+    int S, R4, hstride, rk_cap, align_filter;
+    int nq, nb;
+    ScreenQuery q[kMaxScreenBatch];
+};
+__device__ __forceinline__ ScreenArgs screen_args_of(const ScreenBatchArgs &ab, int qi)
+{
+    const ScreenQuery sq = ab.q[qi];
+    ScreenArgs a;
+    const size_t slot = (size_t)sq.slot, off = (size_t)sq.buf * (size_t)ab.pair_stride;
+    a.vkey = ab.vkey; a.hdesc = ab.hdesc; a.kmask = ab.kmask;
+    a.q_vkey = ab.vkey + slot * ab.S; a.q_rkey = ab.rkey + slot * ab.R4;
+    a.q_hdesc = ab.hdesc + slot * ab.hstride; a.q_kmask = ab.kmask + slot * 8;
+    a.rkey4 = ab.rkey4; a.rk_cap = ab.rk_cap;
+    a.slot_base = sq.base; a.n = sq.n;
+    a.starts = ab.starts + off; a.fallbacks = ab.fallbacks;
+    a.out_approx = ab.approx + off; a.out_d2 = ab.ring_d2 + off;
+    a.t_min = ab.t_min + sq.buf; a.align_filter = ab.align_filter;
+    return a;
+}
 
 __device__ __forceinline__ int wrapS(int x, int S)
 {   // x in (-S, 2S)
@@ -219,7 +244,7 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
     const int nbk = ab.nb;
     const int qi = ab.nq > 1 ? block / nbk : 0;
     const int bid = block - qi * nbk;
-    const ScreenArgs &a = ab.q[qi];
+    const ScreenArgs a = screen_args_of(ab, qi);
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 
@@ -413,7 +438,7 @@ __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const 
     static_assert(S % NWV == 0 && SB % 64 == 0 && NST % D == 0 && W <= 32 && S <= 224, "tiling");
 
     const int nbk = ab.nb;
-    const ScreenArgs &a = ab.q[qi];
+    const ScreenArgs a = screen_args_of(ab, qi);
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: wave-derived addresses stay in SGPRs
 
@@ -741,24 +766,18 @@ hipError_t launch_sc_select_batch(const ScreenBatch &sb, hipStream_t stream)
 // argument block of one batch; returns the largest range or -1
 static int fill_screen_args(const DbView &db, const ScreenBatch &sb, int align_filter, ScreenBatchArgs *ab)
 {
+    ab->vkey = db.vkey; ab->rkey = db.rkey; ab->hdesc = db.hdesc; ab->kmask = db.kmask; ab->rkey4 = db.rkey4;
+    ab->starts = sb.starts; ab->approx = sb.approx; ab->ring_d2 = sb.ring_d2; ab->t_min = sb.t_min; ab->fallbacks = sb.align_fallbacks;
+    ab->pair_stride = (unsigned long long)sb.pair_stride;
+    ab->S = db.S; ab->R4 = 4 * db.RG; ab->hstride = db.hstride; ab->rk_cap = db.cap; ab->align_filter = align_filter;
     ab->nq = sb.nq;
     int nmax = 0;
     for (int i = 0; i < sb.nq; ++i) {
         if (sb.n[i] <= 0) return -1;
-        ScreenArgs &a = ab->q[i];
-        const size_t q = (size_t)sb.slot[i];
-        a.vkey = db.vkey; a.q_vkey = db.vkey + q * db.S;
-        a.q_rkey = db.rkey + q * (size_t)(4 * db.RG);
-        a.hdesc = db.hdesc; a.kmask = db.kmask; a.q_hdesc = db.hdesc + q * (size_t)db.hstride; a.q_kmask = db.kmask + q * 8;
-        a.rkey4 = db.rkey4; a.rk_cap = db.cap;
-        a.slot_base = sb.base[i]; a.n = sb.n[i];
-        a.starts = sb.starts + (size_t)sb.buf[i] * sb.pair_stride;
-        a.out_approx = sb.approx + (size_t)sb.buf[i] * sb.pair_stride; a.out_d2 = sb.ring_d2 + (size_t)sb.buf[i] * sb.pair_stride;
-        a.t_min = sb.t_min + sb.buf[i]; a.align_filter = align_filter;
-        a.fallbacks = sb.align_fallbacks;
+        ab->q[i] = ScreenQuery{sb.slot[i], sb.base[i], sb.n[i], sb.buf[i]};
         nmax = sb.n[i] > nmax ? sb.n[i] : nmax;
     }
-    for (int i = sb.nq; i < kMaxQueryBatch; ++i) ab->q[i] = ab->q[0];
+    for (int i = sb.nq; i < kMaxScreenBatch; ++i) ab->q[i] = ab->q[0];
     return nmax;
 }
 
@@ -830,13 +849,13 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
     fa.prod.nb = blocks;
     int extra = 0;
     if (next && probe != 3) {
-        if (next->nq < 1 || next->nq > kMaxQueryBatch) return hipErrorInvalidValue;
+        if (next->nq < 1 || next->nq > kMaxScreenBatch) return hipErrorInvalidValue;
         const int nmax2 = fill_screen_args(db, *next, align_filter, &fa.next);
         if (nmax2 < 0) return hipErrorInvalidValue;
         fa.next.nb = align_blocks((nmax2 + kGroup - 1) / kGroup, next->nq, true);
         extra = fa.next.nb * next->nq;
 #ifdef SCL_DIAGNOSTICS
-        if (probe == 5 || probe == 6) for (int i = 0; i < kMaxQueryBatch; ++i) fa.next.q[i].align_filter = probe == 5 ? 2 : 3;
+        if (probe == 5 || probe == 6) fa.next.align_filter = probe == 5 ? 2 : 3;
 #endif
     }
     const size_t lds = extra && lds0 > lds1 ? lds0 : lds1;
@@ -851,7 +870,7 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
 hipError_t launch_sc_screen_batch(const DbView &db, const ScreenBatch &sb, int SR, int align_filter, int num_cu, hipStream_t stream, int phases,
                                   const ScreenBatch *next)
 {
-    if (sb.nq < 1 || sb.nq > kMaxQueryBatch || !sc_screen_supported(db, SR)) return hipErrorInvalidValue;
+    if (sb.nq < 1 || sb.nq > kMaxScreenBatch || !sc_screen_supported(db, SR)) return hipErrorInvalidValue;
     if (sc_screen_is_wide(db, SR)) return launch_screen_grid<20, 180, 19, 2, 2>(db, sb, align_filter, num_cu, stream, phases, next);   // 80 x 180
     return launch_screen_grid<16, 120, 13, 3, 2>(db, sb, align_filter, num_cu, stream, phases, next);                                   // 64 x 120
 }
