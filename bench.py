@@ -46,6 +46,11 @@ ALGO_BYTES_PER_PAIR = R * S * 4 + S * 4 + S * 4      # 31 680 
 # fraction is priced on THIS figure (16 608 B), not on SURVEY's 31 680 B: the kernel must not get credit for bytes it
 # does not move; the SURVEY-priced rate is reported beside it as `survey_equivalent`.
 KERNEL_BYTES_PER_PAIR = R * S * 2 + S * 8 + 4 * 4 * ((R + 3) // 4) + 32
+# The scans of one launch share every keyframe line through an XCD's L2 (the workgroups that walk the same keyframes sit on one
+# XCD): those bytes reach the CUs once per pair, but cross HBM once per LAUNCH.  `roofline.achieved` (bytes per pair x pairs /
+# time) therefore exceeds the HBM peak; the same rate against the L2's measured rate (MI355X_MICROARCH.md, rows served from an
+# XCD's L2: 16.8-18.8 TB/s chip-wide) and the bytes that must cross HBM are reported beside it.
+L2_RATE_GBS = 17800.0
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 
@@ -402,6 +407,8 @@ def main():
     k1_pairs = prof["sc_distance_pairs"] / max(1, prof["sc_distance_launches"])
     achieved = (KERNEL_BYTES_PER_PAIR * k1_pairs) / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
     survey_equiv = (ALGO_BYTES_PER_PAIR * k1_pairs) / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+    # bytes that must cross HBM per launch: the eligible keyframes' copy, keys and masks, once
+    compulsory = float(n_elig * KERNEL_BYTES_PER_PAIR)
 
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_sc_distance.json")
@@ -436,13 +443,21 @@ def main():
             "alignment": {"pairs": al_pairs, "exact_fallbacks": al_fallbacks, "fallback_rate": al_fallbacks / max(1, al_pairs)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "sc_screen_kernel (one launch = screening products of 4 scans x 10k keyframes on the fp16 copy "
-                                   "+ alignment and ring-key metric of the next 4 scans)",
+                         "kernel": f"sc_screen_kernel (one launch = screening products of {args.scans_per_launch} scans x 10k keyframes on the fp16 "
+                                   f"copy + alignment and ring-key metric of the next {args.scans_per_launch} scans)",
                          "algorithmic_bytes_per_pair": KERNEL_BYTES_PER_PAIR,
                          "algorithmic_bytes_per_launch": KERNEL_BYTES_PER_PAIR * k1_pairs,
+                         "note": "frac > 1: the scans of a launch share every keyframe line through an XCD's L2, so the bytes each pair needs "
+                                 "reach the CUs at more than the HBM rate while `traffic` (what leaves the L2, PMC) is a fraction of them",
+                         "l2": {"achieved": achieved, "peak": L2_RATE_GBS, "unit": "GB/s", "frac": achieved / L2_RATE_GBS,
+                                "note": "the same bytes against the measured rate of rows served from the XCDs' L2 (16.8-18.8 TB/s chip-wide): "
+                                        "the bound of this kernel"},
+                         "hbm_compulsory": {"bytes_per_launch": compulsory, "achieved": compulsory / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0,
+                                            "frac": (compulsory / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k1_ms > 0 else 0.0,
+                                            "note": "the keyframes' fp16 copy, sector keys, ring keys and masks once per launch (compare `traffic`)"},
                          "survey_equivalent": {"bytes_per_pair": ALGO_BYTES_PER_PAIR, "achieved": survey_equiv, "frac": survey_equiv / HBM_PEAK_GBS,
-                                               "note": "SURVEY 8(d) prices the fp32 descriptor; the kernel reads a half-size fp16 copy, "
-                                                       "the exact fp64 kernel re-scores the survivors"}},
+                                               "note": "SURVEY 8(d) prices the fp32 descriptor per pair; the kernel reads a half-size fp16 copy, "
+                                                       "shared by the scans of a launch; the exact fp64 kernel re-scores the survivors"}},
             "device": eng.device_name(),
         }
         if world == 1 and not args.no_secondary:
