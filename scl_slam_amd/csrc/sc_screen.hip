@@ -168,7 +168,8 @@ __device__ __forceinline__ int align_keyframe_exact(const double2 vk, int lane, 
 constexpr float kScreenEps = 1.5e-3f;          // see the error budget at the top of this file
 constexpr int kScreenWaves = 4;
 constexpr int kGroup = 16;                     // keyframes per matrix product (the MFMA's N)
-constexpr int kTileStride = 96;                // bytes per keyframe in a wave's transposition tile (32 fp16 + 32 B of padding: conflict-free reads)
+constexpr int kTileStride = 64;                // bytes per keyframe in a wave's transposition tile (32 fp16); the 16-byte chunk j of keyframe n
+                                               // sits at chunk j ^ ((n >> 1) & 2): stores and loads both conflict-free
 constexpr int kScreenMaxBlocks = 768;          // workgroups per query (3 per CU at most)
 
 // The same evaluation for grids with more than two sectors per lane (80 x 180: three shifts per lane).
@@ -530,8 +531,8 @@ __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const 
         };
 #pragma unroll
         for (int sl = 0; sl < D; ++sl) issue(sl, true);
-        unsigned char *tile_wr = tile + n4 * kTileStride + jl * 16;
-        const unsigned char *tile_rd = tile + n16 * kTileStride + j4 * 16;
+        unsigned char *tile_wr = tile + n4 * kTileStride + ((jl ^ ((n4 >> 1) & 2)) * 16);
+        const unsigned char *tile_rd = tile + n16 * kTileStride + ((j4 ^ ((n16 >> 1) & 2)) * 16);
         f4v acc[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m] = f4v{0.f, 0.f, 0.f, 0.f};
