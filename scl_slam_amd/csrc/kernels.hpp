@@ -8,7 +8,9 @@ namespace scl {
 
 constexpr double kBigDist = 10000000.0;   // D.h:1494,1556,1637,1705 initial minima
 constexpr int hdesc_sector(int RG) { return ((RG * 8 + 63) / 64) * 8; }   // 8-byte elements per sector of hdesc: ring groups padded to whole 64-byte k-steps
-constexpr int hdesc_stride(int RG, int S) { return hdesc_sector(RG) * S; }  // ... per slot
+constexpr int hkey_halfs(int S) { return ((S + 31) / 32) * 32; }         // the unit-norm fp16 sector key behind the copy, zero padded to whole k-steps
+constexpr int hkey_store_halfs(int S) { return hkey_halfs(S) + 8; }      // ... followed by the key's norm as a float (and 12 spare bytes)
+constexpr int hdesc_stride(int RG, int S) { return hdesc_sector(RG) * S + hkey_store_halfs(S) / 4; }  // ... per slot
 
 // ---- database layout in HBM (one "slot" per keyframe) -----------------------
 //   desc   float4 [cap][RG][S]   RG = ceil(R/4); element (rg, c) holds rows
@@ -21,7 +23,9 @@ constexpr int hdesc_stride(int RG, int S) { return hdesc_sector(RG) * S; }  // .
 //   hdesc  half   [cap][S][4*RGH] the screening pass's own copy (RGH = ring groups padded to whole 64-byte steps: 16 at R = 64, 24 at R = 80): unit columns (x * (float)(1 / norm), fp32) rounded to fp16; an all-zero column stays zero, a norm outside [2^-60, 2^60] or non-finite makes the column NaN, sector-major:
 //                                all rings of one sector are consecutive (128 B = one cache line on the 64 x 120 grid), so
 //                                a ring shift is a rotation of whole lines and every line is read once.  Half the bytes of
-//                                desc.  hstride = S * RGH elements of 8 B.
+//                                desc.  Behind it the sector key as a unit vector in fp16 (vkey / |vkey|, zero padded to a multiple of 32; all zero when the
+//                                norm is zero or not finite) and its norm as a float: the first stage of the alignment filter.  hstride = S * RGH + hkey_store_halfs(S) / 4
+//                                elements of 8 B.
 //   kmask  u32    [cap][8]       bit c of words 0..6 = column c has a non-zero norm; word 7 bit 0 = some column norm is outside [2^-60, 2^60] or non-finite (such keyframes are always scored exactly)
 struct DbView {
     const float4 *desc;

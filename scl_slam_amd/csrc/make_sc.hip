@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(
     const int slot = first_slot + blockIdx.x;
     const float *src = values + (size_t)blockIdx.x * R * S;
     float *siv = sv + R * LS;
+    double *svk = reinterpret_cast<double *>(sv + ((R * LS + S + 1) & ~1));     // [S] the sector key, for its norm
     for (int i = threadIdx.x; i < R * S; i += blockDim.x) {
         const int r = i / S, c = i - r * S;
         sv[r * LS + c] = src[i];
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(
             ss = ss + x * x;
         }
         vkey[(size_t)slot * S + c] = sum / (double)R;
+        svk[c] = sum / (double)R;
         const double nrm = sqrt(ss);
         norm[(size_t)slot * S + c] = nrm;
         // screening pass operand (sc_screen.hip): fp32 reciprocal norm; 0 = all-zero column, NaN = score this keyframe exactly
@@ -151,6 +153,18 @@ __global__ __launch_bounds__(256) void ingest_kernel(
             hv[k] = (_Float16)((r < R ? sv[r * LS + c] : 0.0f) * iv);
         }
         hslot[i] = hv;
+    }
+    // the sector key as a unit vector in fp16, behind the copy (first stage of the alignment filter, sc_screen.hip)
+    {
+        const int SK = hkey_halfs(S);
+        _Float16 *hk = reinterpret_cast<_Float16 *>(hdesc + (size_t)slot * hstride + (size_t)RGH * S);
+        double n2 = 0.0;
+        for (int c = 0; c < S; ++c) n2 = n2 + svk[c] * svk[c];            // every thread the same sequential sum
+        const double nrm = sqrt(n2);
+        const bool usable = nrm > 0.0 && nrm < 1.0e300;                   // zero, NaN, inf: all zero -> every shift ties -> exact evaluation
+        for (int c = threadIdx.x; c < SK; c += blockDim.x)
+            hk[c] = (c < S && usable) ? (_Float16)(float)(svk[c] / nrm) : (_Float16)0.0f;
+        if (threadIdx.x == 0) *reinterpret_cast<float *>(hk + SK) = usable ? (float)nrm : -1.0f;   // the filter's range check (negative: no decision)
     }
     if (threadIdx.x < 8) {
         unsigned int w = 0;
@@ -206,7 +220,7 @@ hipError_t launch_ingest(const float *values, int count, int first_slot,
 {
     if (count <= 0) return hipSuccess;
     if (S > 224) return hipErrorInvalidValue;              // kmask holds 7 words of sector bits
-    const size_t lds = sizeof(float) * ((size_t)R * (S + 1) + S);
+    const size_t lds = sizeof(float) * ((size_t)R * (S + 1) + S + 2) + sizeof(double) * (size_t)S;
     static std::atomic<bool> attr_set_dev[64];   // per device; engines on different threads may race here: atomic flag,
     int dev_ = 0; (void)hipGetDevice(&dev_);     // and setting the attribute twice is harmless
     std::atomic<bool> &attr_set = attr_set_dev[dev_ & 63];

@@ -221,25 +221,40 @@ __device__ __forceinline__ int align_keyframe_wide(const double (&vk)[(S + kWave
 //
 // The arg-min over shifts s of |vq - shift(vk, s)| is the arg-max of the circular correlation
 //   c[s] = sum_u vq[(u + s) mod S] * vk[u],
-// a matrix product: M = shifts, N = 16 keyframes, K = sectors, in fp32 on the matrix cores (v_mfma_f32_16x16x4_f32).
-// It is a FILTER, as in sc_distance.hip: |c~ - c| <= eps = 4.07e-6 |vq| |vk| for any summation order (K + 2 roundings
-// of 2^-24 relative, Cauchy-Schwarz; truncating accumulation would still fit), so a shift whose c~ leads every other by
-// more than 4 eps is the exact arg-max of the fp64 distances as well; anything else -- two shifts within 4 eps (ties
-// included), norms that are not finite or so large that products could overflow -- is decided by the reference's own
-// fp64 evaluation (align_keyframe_exact, the same code as the exact kernel's).
-// Lane (m, k) = (lane & 15, lane >> 4) owns A[s = 16t + m][u = 16b + 4k + e] = vq[(16 (b + t) + 4k + m + e) mod S],
-// read from a repeated fp32 copy of the query's key in LDS; B comes from a per-wave LDS image of the 16 sector keys
-// in fp32.  Results: starts[i] = (shift - SR) mod S, out_d2[i].
+// a matrix product: M = shifts, N = 16 keyframes, K = sectors.  It is evaluated as a FILTER in two stages on the matrix
+// cores, and only what neither stage can decide goes to the reference's own fp64 evaluation (align_keyframe_exact, the code
+// of the exact kernel; ties included, so the reference's "lowest shift wins" is kept):
+//   stage 1, always: both keys as unit vectors in fp16 (written at ingest behind the screening copy), v_mfma_f32_16x16x32_f16
+//     (MT x SK/32 of them: 32 at 64 x 120).  |c~ - c^| <= 9.9e-4 (fp16 rounding of two unit vectors, Cauchy-Schwarz;
+//     subnormal elements; fp32 accumulation): a shift leading every other by more than 3e-3 is the exact arg-max.  On the
+//     bench database 96 % of the pairs are decided here.
+//   stage 2, for a group with three or more open keyframes: the keys in fp32, v_mfma_f32_16x16x4_f32 (256 per group):
+//     |c~ - c| <= 4.07e-6 |vq| |vk| for any summation order (K + 2 roundings of 2^-24 relative; truncating accumulation
+//     would still fit); a lead of more than 4 eps decides.  Norms that are not finite or so large that products could
+//     overflow decide nothing.
+// Lane (m, k) = (lane & 15, lane >> 4) owns A[s = 16t + m][...] read from repeated copies of the query's key in LDS; B comes
+// from a per-wave LDS image of the 16 sector keys.  Results: starts[i] = (shift - SR) mod S, out_d2[i].
+constexpr int hdesc_rgh(int RG) { return ((RG * 8 + 63) / 64) * 8; }   // 8-byte elements per sector of hdesc: whole k-steps of 64 B
+constexpr float kAlign16Margin = 3.0e-3f;      // lead the fp16 stage demands of the best shift (normalised correlation; bound below: 2 x 9.9e-4)
+constexpr int kAlignFp32From = 3;              // ambiguous keyframes in a group from which the fp32 stage runs before the exact evaluation
+
 template <int RG, int S, int W>
 __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const int block, unsigned char *smem_raw)
 {
     constexpr int NWV = kScreenWaves;
     constexpr int L = S >> 1;
     constexpr int MT = (S + 15) / 16;                  // tiles of 16 shifts
-    constexpr int KB = (S + 15) / 16;                  // blocks of 16 sectors
-    constexpr int BST = 16 * KB + 4;                   // floats per keyframe in the B image (the 4 keep its reads spread over the banks)
+    constexpr int KB = (S + 15) / 16;                  // blocks of 16 sectors (fp32 stage)
+    constexpr int BST = 16 * KB + 4;                   // floats per keyframe in the fp32 B image (the 4 keep its reads spread over the banks)
     constexpr int QX = 16 * (MT + KB);                 // the query key, repeated
+    constexpr int SK = hkey_halfs(S);                  // fp16 stage: K padded to whole steps of 32
+    constexpr int KS = SK / 32;                        // ... its k-steps
+    constexpr int QH = 16 * MT + SK + 8;               // halfs of the repeated fp16 query key
+    constexpr int BSH = SK + 8;                        // halfs per keyframe in the fp16 B image
+    constexpr int RGH = hdesc_rgh(RG);
+    constexpr int HS = RGH * S + hkey_store_halfs(S) / 4;   // a keyframe's slot in hdesc (elements of 8 B)
     static_assert(S % 4 == 0, "sector keys are read in pairs, the B image in fours");
+    static_assert(kGroup * BSH * 2 <= kGroup * BST * 4, "the fp16 B image shares the fp32 image's storage");
     const int SR = (W - 1) / 2;
 
     const int nbk = ab.nb;
@@ -251,69 +266,37 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
 
     double *vq = reinterpret_cast<double *>(smem_raw);                           // [S]
     float *qx = reinterpret_cast<float *>(vq + S);                               // [QX]
-    unsigned char *wbase = reinterpret_cast<unsigned char *>(qx + QX) + (size_t)wave * ((2 * S + 2) * 8 + kGroup * BST * 4);
+    _Float16 *qh0 = reinterpret_cast<_Float16 *>(qx + QX);                       // [QH] the unit fp16 query key, repeated; qh1[i] = qh0[i + 1]
+    _Float16 *qh1 = qh0 + QH;
+    unsigned char *wbase = reinterpret_cast<unsigned char *>(qh1 + QH) + (size_t)wave * ((2 * S + 2) * 8 + kGroup * BST * 4);
     double *vk2 = reinterpret_cast<double *>(wbase);                             // [2S + 2] scratch of the exact evaluation
-    float *Bs = reinterpret_cast<float *>(vk2 + 2 * S + 2);                      // [16][BST]
+    float *Bs = reinterpret_cast<float *>(vk2 + 2 * S + 2);                      // [16][BST] fp32 image / [16][BSH] fp16 image
+    _Float16 *Bh = reinterpret_cast<_Float16 *>(Bs);
 
     for (int c = threadIdx.x; c < S; c += blockDim.x) vq[c] = a.q_vkey[c];
     for (int i = threadIdx.x; i < QX; i += blockDim.x) qx[i] = (float)a.q_vkey[i % S];
-    for (int i = lane; i < kGroup * (BST - S); i += kWave) {                     // the K padding of the B image stays zero
-        const int n = i / (BST - S), u = S + i - n * (BST - S);
-        Bs[n * BST + u] = 0.0f;
+    {
+        const _Float16 *qk = reinterpret_cast<const _Float16 *>(a.q_hdesc + (size_t)RGH * S);
+        for (int i = threadIdx.x; i < QH; i += blockDim.x) { qh0[i] = qk[i % S]; qh1[i] = qk[(i + 1) % S]; }
     }
     __syncthreads();
 
     const int m16 = lane & 15, k4 = lane >> 4;
     const float *qa = qx + 4 * k4 + m16;                                         // A[s = 16t + m][u = 16b + 4k + e] = qa[16 (b + t) + e]
+    // fp16 stage: A[s = 16t + m][u = 32kk + 8k + i] = q^[(32kk + 16t + (8k + m) + i) mod S]: eight consecutive halfs from an
+    // arbitrary index -- from the copy shifted by one when that index is odd, so that the reads stay dword aligned
+    const int lc = 8 * k4 + m16;
+    const unsigned int *qha = reinterpret_cast<const unsigned int *>(((lc & 1) ? qh1 : qh0) + (lc & ~1));
     float qn2 = 0.f;
     for (int i = lane; i < S; i += kWave) qn2 += qx[i] * qx[i];
     qn2 = wave_sum_f32_dpp(qn2);
     const bool use_filter = a.align_filter != 0;
+    const float kNegInf = __int_as_float(0xff800000);
+    const float qnorm = *reinterpret_cast<const float *>(reinterpret_cast<const _Float16 *>(a.q_hdesc + (size_t)RGH * S) + SK);
 
-    const int ngroups = (a.n + kGroup - 1) / kGroup;
-    for (int g = bid * NWV + wave; g < ngroups; g += nbk * NWV) {
-        const int c_base = g * kGroup;
-        const int first_slot = a.slot_base + c_base;
-        const int last_rel = a.n - 1 - c_base;
-        // ---- the 16 sector keys: 16 * S / 2 double2, consecutive in memory, narrowed to fp32 into the B image ----
-        const double2 *src = reinterpret_cast<const double2 *>(a.vkey + (size_t)first_slot * S);
-        wave_fence();
-#ifdef SCL_DIAGNOSTICS
-        if (a.align_filter != 3)                                                 // probe 3: no sector-key reads (stale B image)
-#endif
-#pragma unroll 5
-        for (int it = 0; it < (kGroup * L + kWave - 1) / kWave; ++it) {
-            const int f = it * kWave + lane;
-            const int fc = f < kGroup * L ? f : kGroup * L - 1;                  // (the last round of a grid whose keys do not tile the wave)
-            const int n = fc / L, u2 = fc - n * L;
-            const double2 v = src[(size_t)(n < last_rel ? n : last_rel) * L + u2];
-            *reinterpret_cast<f2 *>(Bs + n * BST + 2 * u2) = f2{(float)v.x, (float)v.y};
-        }
-        wave_fence();
-#ifdef SCL_DIAGNOSTICS
-        if (a.align_filter == 2) continue;                                       // probe: the role's sector-key reads alone
-#endif
-        // ---- c~[s][n] for all shifts: MT tiles x KB blocks x 4 steps of K = 4 ----
-        f4v acc[MT];
-#pragma unroll
-        for (int t = 0; t < MT; ++t) acc[t] = f4v{0.f, 0.f, 0.f, 0.f};
-        float kn2 = 0.f;
-#pragma unroll
-        for (int b = 0; b < KB; ++b) {
-            const f4v b4 = *reinterpret_cast<const f4v *>(Bs + m16 * BST + 16 * b + 4 * k4);
-            kn2 += (b4[0] * b4[0] + b4[1] * b4[1]) + (b4[2] * b4[2] + b4[3] * b4[3]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[16 * (b + t) + e], b4[e], acc[t], 0, 0, 0);
-            }
-        }
-        kn2 += __shfl_xor(kn2, 16, kWave);
-        kn2 += __shfl_xor(kn2, 32, kWave);
-        // ---- per keyframe (column n = lane & 15): the largest and the second largest c~ over all shifts ----
-        const float kNegInf = __int_as_float(0xff800000);
-        float v1 = kNegInf, v2 = kNegInf;
-        int a1 = 0;
+    // per keyframe (column n = lane & 15): the largest and the second largest value over all shifts, and the largest's shift
+    auto top2 = [&](const f4v (&acc)[MT], float &v1, float &v2, int &a1) {
+        v1 = kNegInf; v2 = kNegInf; a1 = 0;
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
 #pragma unroll
@@ -335,14 +318,109 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
             a1 = gt ? oa : a1;
             v1 = gt ? o1 : v1;
         }
-        // ---- decide (every lane of column n holds the same numbers; lanes 0..15 write) ----
-        const float nsum = sqrtf(qn2) + sqrtf(kn2);
-        const float eps = 4.07e-6f * sqrtf(qn2) * sqrtf(kn2) + 1e-12f * (qn2 + kn2);
-        const bool sane = (qn2 < 3.0e38f) && (kn2 < 3.0e38f) && (nsum * nsum < 0.9e14f);
+    };
+
+    const int ngroups = (a.n + kGroup - 1) / kGroup;
+    for (int g = bid * NWV + wave; g < ngroups; g += nbk * NWV) {
+        const int c_base = g * kGroup;
+        const int first_slot = a.slot_base + c_base;
+        const int last_rel = a.n - 1 - c_base;
         const bool mine = lane < kGroup && c_base + lane < a.n;
-        const bool uniq = use_filter && sane && (v2 < v1 - 4.0f * eps);
-        if (mine && uniq) a.starts[c_base + lane] = wrapS(a1 - SR, S);
+        // ---- stage 1: the normalised correlation in fp16 on the matrix cores (v_mfma_f32_16x16x32_f16, MT x KS of them).
+        // Unit vectors rounded to fp16 are off by <= 2^-11 of themselves (+ 2^-25 per subnormal element), their products are
+        // exact, the fp32 accumulation of SK terms adds <= SK 2^-24: |c~ - c^| <= 9.9e-4 for every shift, so a shift that leads
+        // every other by more than kAlign16Margin = 3e-3 is the arg-max of the exact correlation, i.e. the reference's arg-min.
+        wave_fence();
+#ifdef SCL_DIAGNOSTICS
+        if (a.align_filter != 3)
+#endif
+        for (int it = 0; it < (kGroup * (SK / 8) + kWave - 1) / kWave; ++it) {   // 16 keyframes x SK/8 chunks of 16 bytes
+            const int f = it * kWave + lane;
+            const int fc = f < kGroup * (SK / 8) ? f : kGroup * (SK / 8) - 1;
+            const int n = fc / (SK / 8), ch = fc - n * (SK / 8);
+            const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(
+                a.hdesc + (size_t)(first_slot + (n < last_rel ? n : last_rel)) * HS + (size_t)RGH * S) + ch * 16);
+            *reinterpret_cast<uint4 *>(Bh + n * BSH + 8 * ch) = v;
+        }
+        wave_fence();
+#ifdef SCL_DIAGNOSTICS
+        if (a.align_filter == 2) continue;                                       // probe: the role's key reads alone
+#endif
+        float v1, v2;
+        int a1;
+        {
+            f4v acc[MT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t] = f4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const h8 bfrag = *reinterpret_cast<const h8 *>(Bh + m16 * BSH + 32 * kk + 8 * k4);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const unsigned int *ap = qha + (32 * kk + 16 * t) / 2;
+                    u32x4 aw;
+                    aw[0] = ap[0]; aw[1] = ap[1]; aw[2] = ap[2]; aw[3] = ap[3];
+                    h8 afrag;
+                    __builtin_memcpy(&afrag, &aw, 16);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag, acc[t], 0, 0, 0);
+                }
+            }
+            top2(acc, v1, v2, a1);
+        }
+        // The exact arg-max of the correlation is the reference's arg-min only while its fp64 distances resolve the lead: their
+        // rounding noise is ~1e-13 (|vq|^2 + |vk|^2), a lead of 3e-3 |vq| |vk| stands clear of it for norm ratios up to 1e4;
+        // distances of 1e7 and more never win in the reference (D.h:1494), so the norms stay below 4e6; tiny norms stay
+        // above 1e-30 (no fp64 underflow).  Anything else is left to the exact evaluation.
+        const float knorm = *reinterpret_cast<const float *>(reinterpret_cast<const _Float16 *>(
+            a.hdesc + (size_t)(first_slot + (m16 < last_rel ? m16 : last_rel)) * HS + (size_t)RGH * S) + SK);
+        const bool in_range = qnorm >= 1e-30f && qnorm <= 4.0e6f && knorm >= 1e-30f && knorm <= 4.0e6f &&
+                              qnorm <= 1.0e4f * knorm && knorm <= 1.0e4f * qnorm;
+        bool uniq = use_filter && in_range && (v1 == v1) && (v2 < v1 - kAlign16Margin);
         unsigned long long amb = __builtin_amdgcn_ballot_w64(mine && !uniq);
+        // ---- stage 2 (a group with several keyframes the first stage left open): the correlation in fp32 ----
+        if (use_filter && __popcll(amb) >= kAlignFp32From) {
+            const double2 *src = reinterpret_cast<const double2 *>(a.vkey + (size_t)first_slot * S);
+            wave_fence();
+#pragma unroll 5
+            for (int it = 0; it < (kGroup * L + kWave - 1) / kWave; ++it) {
+                const int f = it * kWave + lane;
+                const int fc = f < kGroup * L ? f : kGroup * L - 1;              // (the last round of a grid whose keys do not tile the wave)
+                const int n = fc / L, u2 = fc - n * L;
+                const double2 v = src[(size_t)(n < last_rel ? n : last_rel) * L + u2];
+                *reinterpret_cast<f2 *>(Bs + n * BST + 2 * u2) = f2{(float)v.x, (float)v.y};
+            }
+            for (int i = lane; i < kGroup * (BST - S); i += kWave) {             // the K padding of the image
+                const int n = i / (BST - S), u = S + i - n * (BST - S);
+                Bs[n * BST + u] = 0.0f;
+            }
+            wave_fence();
+            f4v acc[MT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t] = f4v{0.f, 0.f, 0.f, 0.f};
+            float kn2 = 0.f;
+#pragma unroll
+            for (int b = 0; b < KB; ++b) {
+                const f4v b4 = *reinterpret_cast<const f4v *>(Bs + m16 * BST + 16 * b + 4 * k4);
+                kn2 += (b4[0] * b4[0] + b4[1] * b4[1]) + (b4[2] * b4[2] + b4[3] * b4[3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[16 * (b + t) + e], b4[e], acc[t], 0, 0, 0);
+                }
+            }
+            kn2 += __shfl_xor(kn2, 16, kWave);
+            kn2 += __shfl_xor(kn2, 32, kWave);
+            float w1, w2;
+            int b1;
+            top2(acc, w1, w2, b1);
+            const float nsum = sqrtf(qn2) + sqrtf(kn2);
+            const float eps = 4.07e-6f * sqrtf(qn2) * sqrtf(kn2) + 1e-12f * (qn2 + kn2);
+            const bool sane = (qn2 < 3.0e38f) && (kn2 < 3.0e38f) && (nsum * nsum < 0.9e14f);
+            if (!uniq && sane && (w2 < w1 - 4.0f * eps)) { uniq = true; a1 = b1; }
+            amb = __builtin_amdgcn_ballot_w64(mine && !uniq);
+        }
+        // ---- decide (every lane of column n holds the same numbers; lanes 0..15 write) ----
+        if (mine && uniq) a.starts[c_base + lane] = wrapS(a1 - SR, S);
 #ifdef SCL_DIAGNOSTICS
         if (a.align_filter == 3) { amb = 0; if (mine) a.starts[c_base + lane] = 0; }
 #endif
@@ -431,7 +509,7 @@ __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const 
     constexpr int SB = RGH * 8;                        // bytes of one sector in hdesc (all rings, fp16)
     constexpr int KH = SB / 64;                        // k-steps per sector (32 rings = 64 B each)
     constexpr int QST = SB + 32;                       // bytes of one sector of the staged query (the padding keeps the A reads conflict-free)
-    constexpr int HS = RGH * S;                        // a keyframe's slot in hdesc (elements of 8 B)
+    constexpr int HS = RGH * S + hkey_store_halfs(S) / 4;   // a keyframe's slot in hdesc (elements of 8 B): the copy, then the fp16 sector key
     constexpr int SPW = S / NWV;                       // query sectors per wave
     constexpr int NST = SPW * KH;                      // k-steps per wave and group
     constexpr int NW64 = (S + 63) / 64;                // 64-bit words of a sector mask
@@ -633,8 +711,6 @@ __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const 
 // on its own).  The short alignment workgroups are spread over the whole launch.  Slots past either role's count exit.
 struct ScreenFusedArgs { ScreenBatchArgs prod; ScreenBatchArgs next; int align_blocks; };
 
-constexpr int hdesc_rgh(int RG) { return ((RG * 8 + 63) / 64) * 8; }   // 8-byte elements per sector of hdesc: whole k-steps of 64 B
-
 __host__ __device__ inline int fused_patterned_blocks(int nq, int nbk, int align_blocks) { return 8 * ((nbk + 7) >> 3) * (nq + (align_blocks > 0 ? 1 : 0)); }
 
 template <int RG, int S, int W, int D, int OCC, int PROBE = 0>
@@ -792,7 +868,7 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
     const int nmax = fill_screen_args(db, sb, align_filter, &ab);
     if (nmax < 0) return hipErrorInvalidValue;
     const int ngroups = (nmax + kGroup - 1) / kGroup;
-    if (db.hstride != RGH * S || !sb.starts) return hipErrorInvalidValue;
+    if (db.hstride != hdesc_stride(RG, S) || !sb.starts) return hipErrorInvalidValue;
     static std::atomic<bool> attr_set_dev[64];                 // per grid (template instance) and device
     int dev_ = 0; (void)hipGetDevice(&dev_);
     std::atomic<bool> &attr_set = attr_set_dev[dev_ & 63];
@@ -808,7 +884,8 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
     const int probe = 0;
 #endif
     constexpr int MTA = (S + 15) / 16, BST = 16 * MTA + 4, MT = (W + 15) / 16, QSX = S + 16 * MT, MW = ((S + 63) / 64 + 1) / 2;
-    const size_t lds0 = (size_t)S * 8 + (size_t)(32 * MTA) * 4 + (size_t)kScreenWaves * ((2 * S + 2) * 8 + kGroup * BST * 4);
+    const size_t lds0 = (size_t)S * 8 + (size_t)(32 * MTA) * 4 + (size_t)2 * (16 * MTA + hkey_halfs(S) + 8) * 2 +
+                        (size_t)kScreenWaves * ((2 * S + 2) * 8 + kGroup * BST * 4);
     const size_t lds1 = (size_t)QSX * (RGH * 8 + 32) + (size_t)S * MW * 16 + (size_t)kScreenWaves * kGroup * kTileStride +
                         (size_t)(2 * kScreenWaves * MT) * kWave * 16;
     if (!attr_set.load(std::memory_order_acquire)) {

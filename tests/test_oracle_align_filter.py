@@ -83,3 +83,35 @@ def test_filter_error_is_inside_half_the_margin_and_accepted_shifts_are_the_refe
             assert int(order[0]) == ref, (model, int(order[0]), ref)
     print(f"{model}: worst error {worst:.3e} of |vq||vk| (half margin {2 * EPS:.3e}), {accepted} of {total} pairs accepted by the filter")
     assert accepted > total // 2
+
+
+def test_fp16_stage_error_and_accepted_shifts():
+    """Stage 1 of the alignment filter: both keys as unit vectors rounded to fp16, products exact, fp32 accumulation (here one
+    rounding per product: the worst order).  The error of the normalised correlation must stay below half the lead the kernel
+    demands (kAlign16Margin = 3e-3), and a shift it accepts -- norms inside the kernel's range check -- must be the checker's."""
+    L = ob.load()
+    margin = np.float32(3.0e-3)
+    worst, accepted, total = 0.0, 0, 0
+    for q, k in cases():
+        nq, nk = np.linalg.norm(q), np.linalg.norm(k)
+        if not (nq > 0 and nk > 0):
+            continue
+        qh = (q / nq).astype(np.float32).astype(np.float16).astype(np.float32)
+        kh = (k / nk).astype(np.float32).astype(np.float16).astype(np.float32)
+        s = np.arange(S)
+        acc = np.zeros(S, np.float32)
+        for u in range(S):
+            acc = (acc + (qh[(u + s) % S] * kh[u]).astype(np.float32)).astype(np.float32)
+        ce = corr_exact(q, k) / (np.longdouble(nq) * np.longdouble(nk))
+        err = float(np.max(np.abs(acc.astype(np.longdouble) - ce)))
+        worst = max(worst, err)
+        assert err < 1.5e-3, err
+        total += 1
+        in_range = 1e-30 <= nq <= 4e6 and 1e-30 <= nk <= 4e6 and nq <= 1e4 * nk and nk <= 1e4 * nq
+        order = np.argsort(-acc, kind="stable")
+        if in_range and acc[order[1]] < acc[order[0]] - margin:
+            accepted += 1
+            ref = L.sco_fast_align(S, ob._p(np.ascontiguousarray(q, np.float64), ob.c_double), ob._p(np.ascontiguousarray(k, np.float64), ob.c_double))
+            assert int(order[0]) == ref, (int(order[0]), ref)
+    print(f"fp16 stage: worst error {worst:.3e} (half margin 1.5e-3), {accepted} of {total} pairs accepted")
+    assert accepted > total // 3
