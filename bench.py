@@ -41,15 +41,14 @@ N_KEYFRAMES_1GPU = 10000           # configs[1]
 N_KEYFRAMES_SHARD = 12500          # configs[3]: 100k keyframes over 8 GPUs
 N_EXCLUDE = 100                    # NUM_EXCLUDE_RECENT, descriptor.h:1314
 ALGO_BYTES_PER_PAIR = R * S * 4 + S * 4 + S * 4      # 31 680 B at 64x120 (fp32 descriptor + fp64 sector key)
-# What the dominant kernel has to read per pair by design: the fp16 screening copy of the descriptor
-# (2 R S), the fp64 sector key (8 S), the tiled ring key (4 * 4 ceil(R/4)) and the 32-byte sector mask.  The roofline
-# fraction is priced on THIS figure (16 608 B), not on SURVEY's 31 680 B: the kernel must not get credit for bytes it
-# does not move; the SURVEY-priced rate is reported beside it as `survey_equivalent`.
+# What the dominant kernel reads per keyframe by design: the fp16 screening copy of the descriptor
+# (2 R S), the fp64 sector key (8 S), the tiled ring key (4 * 4 ceil(R/4)) and the 32-byte sector mask = 16 608 B, not SURVEY's
+# 31 680 B (fp32 descriptor): the kernel must not get credit for bytes it does not move.
 KERNEL_BYTES_PER_PAIR = R * S * 2 + S * 8 + 4 * 4 * ((R + 3) // 4) + 32
 # The scans of one launch share every keyframe line through an XCD's L2 (the workgroups that walk the same keyframes sit on one
-# XCD): those bytes reach the CUs once per pair, but cross HBM once per LAUNCH.  `roofline.achieved` (bytes per pair x pairs /
-# time) therefore exceeds the HBM peak; the same rate against the L2's measured rate (MI355X_MICROARCH.md, rows served from an
-# XCD's L2: 16.8-18.8 TB/s chip-wide) and the bytes that must cross HBM are reported beside it.
+# XCD): those bytes reach the CUs once per pair, but cross HBM once per LAUNCH.  `roofline.achieved` follows SURVEY 8(d)'s rule
+# for Q scans per pass (database bytes once per launch + per-scan bytes); the per-pair delivery rate is reported beside it
+# against the measured rate of rows served from the XCDs' L2s (MI355X_MICROARCH.md: 16.8-18.8 TB/s chip-wide).
 L2_RATE_GBS = 17800.0
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
@@ -288,15 +287,20 @@ def secondary_80x180(device, n=10000, steps=512):
     bytes_pair = 96 * S2 * 2 + S2 * 8 + 4 * 4 * ((R2 + 3) // 4) + 32
     k_ms = prof["sc_distance_ms"] / max(1, prof["sc_distance_launches"])
     k_pairs = prof["sc_distance_pairs"] / max(1, prof["sc_distance_launches"])
-    ach = bytes_pair * k_pairs / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    k_scans = k_pairs / n_elig
+    per_launch = n_elig * bytes_pair + k_scans * bytes_pair + k_pairs * 12.0      # DB once per launch + per-scan bytes + outputs
+    ach = per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    deliv = bytes_pair * k_pairs / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     return {"workload": f"{n} synthetic keyframes, 80x180 SC (BASELINE configs[4]'s grid), full ring-key + shifted SC distance (19 shifts) "
                         f"over the whole DB per scan, {steps} scans",
             "value": n_elig * steps / dt, "unit": "pairs/s", "ms_per_scan": dt / steps * 1e3,
             "kernel_ms": {"screening_launch_group": k_ms},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_pair": bytes_pair, "survey_bytes_per_pair": survey_pair,
-                         "kernel": "sc_screen_kernel<20,180,19> (screening products of four scans on the fp16 copy + alignment of the next "
-                                   "four; one launch in seven sampled)"}}
+                         "algorithmic_bytes_per_launch": per_launch, "scans_per_launch": k_scans,
+                         "bytes_per_keyframe": bytes_pair, "survey_bytes_per_pair": survey_pair,
+                         "delivery": {"achieved": deliv, "peak": L2_RATE_GBS, "unit": "GB/s", "frac": deliv / L2_RATE_GBS},
+                         "kernel": "sc_screen_kernel<20,180,19> (screening products of a launch group's scans on the fp16 copy + alignment of "
+                                   "the next group; one launch in seven sampled)"}}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -405,17 +409,25 @@ def main():
     value = pairs_per_step * args.steps / elapsed
     k1_ms = prof["sc_distance_ms"] / max(1, prof["sc_distance_launches"])
     k1_pairs = prof["sc_distance_pairs"] / max(1, prof["sc_distance_launches"])
-    achieved = (KERNEL_BYTES_PER_PAIR * k1_pairs) / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+    k1_scans = k1_pairs / n_elig                          # scans whose products one launch holds
+    # Algorithmic bytes of one launch by SURVEY 8(d)'s rule for Q scans per database pass ("DB_bytes / Q + per-query bytes:
+    # never count bytes that were not moved"): every eligible keyframe's screening rows once, + per scan its own rows, + what
+    # the launch writes per pair (bound d~ 4 B, first shift 4 B and ring-key metric 4 B of the next batch).
+    per_launch = n_elig * KERNEL_BYTES_PER_PAIR + k1_scans * KERNEL_BYTES_PER_PAIR + k1_pairs * 12.0
+    achieved = per_launch / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+    # the same launch priced per pair (what the CUs pull in, from HBM or from an XCD's L2)
+    delivered = (KERNEL_BYTES_PER_PAIR * k1_pairs) / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
     survey_equiv = (ALGO_BYTES_PER_PAIR * k1_pairs) / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
-    # bytes that must cross HBM per launch: the eligible keyframes' copy, keys and masks, once
-    compulsory = float(n_elig * KERNEL_BYTES_PER_PAIR)
 
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_sc_distance.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))                      # PMC run of this same command (scripts/profile_k1.sh)
-            traffic = tj["hbm_bytes_per_launch"] / tj["pairs_per_launch"] * k1_pairs
+            # HBM bytes of a launch follow the database (read once per launch), not the pair count: valid for the profiled
+            # launch shape only
+            if abs(k1_scans - tj.get("scans_per_launch", 0)) < 0.5:
+                traffic = tj["hbm_bytes_per_launch"] * n_elig / tj["eligible_keyframes"]
         except Exception:
             traffic = None
 
@@ -437,27 +449,35 @@ def main():
                        "sharding": (f"keyframe-index shards x{world}; exchange = {args.exchange} "
                                     f"({'two 8-byte min all-reduces' if args.exchange == 'allreduce' else 'one 24-byte all-gather'} "
                                     f"per scan, batched over {args.native_chunk or args.merge_every} scans, asynchronous)") if world > 1 else "none (one GPU)"},
-            "screening_GBps": value * KERNEL_BYTES_PER_PAIR / 1e9,           # whole job, priced like roofline.achieved
+            # BASELINE's second figure, "SC-distance GB/s": bytes that crossed HBM by design (the database once per
+            # launch) and, beside it, the bytes the pairs consumed (each pair's rows, from HBM or L2) per second of the whole job
+            "sc_distance_GBps": value * per_launch / max(1.0, k1_pairs) / 1e9,
+            "sc_distance_GBps_consumed_per_pair": value * KERNEL_BYTES_PER_PAIR / 1e9,
             "kernel_ms": {"sc_distance": k1_ms},
-            # fastAlignUsingVkey: pairs whose first shift the fp32 matrix-core filter left to the exact fp64 evaluation
+            # fastAlignUsingVkey: pairs whose first shift the matrix-core filters left to the exact fp64 evaluation
             "alignment": {"pairs": al_pairs, "exact_fallbacks": al_fallbacks, "fallback_rate": al_fallbacks / max(1, al_pairs)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": f"sc_screen_kernel (one launch = screening products of {args.scans_per_launch} scans x 10k keyframes on the fp16 "
-                                   f"copy + alignment and ring-key metric of the next {args.scans_per_launch} scans)",
-                         "algorithmic_bytes_per_pair": KERNEL_BYTES_PER_PAIR,
-                         "algorithmic_bytes_per_launch": KERNEL_BYTES_PER_PAIR * k1_pairs,
-                         "note": "frac > 1: the scans of a launch share every keyframe line through an XCD's L2, so the bytes each pair needs "
-                                 "reach the CUs at more than the HBM rate while `traffic` (what leaves the L2, PMC) is a fraction of them",
-                         "l2": {"achieved": achieved, "peak": L2_RATE_GBS, "unit": "GB/s", "frac": achieved / L2_RATE_GBS,
-                                "note": "the same bytes against the measured rate of rows served from the XCDs' L2 (16.8-18.8 TB/s chip-wide): "
-                                        "the bound of this kernel"},
-                         "hbm_compulsory": {"bytes_per_launch": compulsory, "achieved": compulsory / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0,
-                                            "frac": (compulsory / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k1_ms > 0 else 0.0,
-                                            "note": "the keyframes' fp16 copy, sector keys, ring keys and masks once per launch (compare `traffic`)"},
-                         "survey_equivalent": {"bytes_per_pair": ALGO_BYTES_PER_PAIR, "achieved": survey_equiv, "frac": survey_equiv / HBM_PEAK_GBS,
-                                               "note": "SURVEY 8(d) prices the fp32 descriptor per pair; the kernel reads a half-size fp16 copy, "
-                                                       "shared by the scans of a launch; the exact fp64 kernel re-scores the survivors"}},
+                         "kernel": f"sc_screen_kernel (one launch = screening products of {k1_scans:.0f} scans x {n_elig} keyframes on the fp16 "
+                                   f"copy + alignment and ring-key metric of the next batch)",
+                         "algorithmic_bytes_per_launch": per_launch,
+                         "scans_per_launch": k1_scans, "pairs_per_launch": k1_pairs,
+                         "pricing": "SURVEY 8(d), Q scans per database pass: DB bytes once per launch + per-scan bytes + outputs "
+                                    f"({KERNEL_BYTES_PER_PAIR} B per keyframe: fp16 screening copy, fp64 sector key, tiled ring key, mask)",
+                         "note": "with Q scans per launch the kernel is no longer bound by HBM: the database crosses HBM once per launch and "
+                                 "reaches the CUs Q times from the XCDs' L2s -- `delivery` is the binding rate.  One scan per launch "
+                                 "(--scans-per-launch 1) is the HBM-bound form; `single_scan_hbm_floor` is its ceiling",
+                         "delivery": {"achieved": delivered, "peak": L2_RATE_GBS, "unit": "GB/s", "frac": delivered / L2_RATE_GBS,
+                                      "bytes_per_pair": KERNEL_BYTES_PER_PAIR,
+                                      "note": "bytes every pair pulls into its CU / launch time, against the measured rate of rows served "
+                                              "from the XCDs' L2 (MI355X_MICROARCH.md: 16.8-18.8 TB/s chip-wide)"},
+                         "single_scan_hbm_floor": {"pairs_per_s": HBM_PEAK_GBS * 1e9 / KERNEL_BYTES_PER_PAIR,
+                                                   "pairs_per_s_survey_bytes": HBM_PEAK_GBS * 1e9 / ALGO_BYTES_PER_PAIR,
+                                                   "value_over_floor": value / world / (HBM_PEAK_GBS * 1e9 / KERNEL_BYTES_PER_PAIR),
+                                                   "note": "what a kernel streaming the database once per scan reaches at 100 % of 8 TB/s"},
+                         "survey_equivalent": {"bytes_per_pair": ALGO_BYTES_PER_PAIR, "achieved": survey_equiv,
+                                               "note": "SURVEY 8(d)'s single-scan price (fp32 descriptor per pair) x pairs / time, for "
+                                                       "comparison with round 1's figures; not a rate of moved bytes"}},
             "device": eng.device_name(),
         }
         if world == 1 and not args.no_secondary:
