@@ -27,7 +27,7 @@ oracle:
 
 # C++ host-side adapter (include/scl/scan_context_hip_descriptor.hpp) type-checked and linked
 # against the C ABI; runs on the GPU box (tests/test_gpu_adapter.py)
-tests/cpp/adapter_check: tests/cpp/adapter_check.cpp tests/cpp/pcl_types_for_adapter_check.h include/scl/scan_context_hip_descriptor.hpp $(LIBDIR)/libscl_engine.so
+tests/cpp/adapter_check: tests/cpp/adapter_check.cpp tests/cpp/pcl_types_for_adapter_check.h include/scl/scan_context_hip_descriptor.hpp include/scl/lidar_iris_hip_descriptor.hpp $(LIBDIR)/libscl_engine.so
 	g++ -std=c++14 -O2 -Wall -Iinclude -Itests/cpp -o $@ tests/cpp/adapter_check.cpp -L$(LIBDIR) -lscl_engine -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)'
 
 clean:

@@ -1,13 +1,19 @@
 /*
- * scl_iris.h -- C ABI of the LiDAR-Iris building blocks (SURVEY.md 8(f)-4 part 2): the second descriptor of the
- * reference (class lidar_iris_descriptor, include/descriptor.h:462-1302; selected by config/dlc_lio_sam_params.yaml:23).
+ * scl_iris.h -- C ABI of the LiDAR-Iris descriptor (SURVEY.md 8(f)-4 part 2): the second descriptor of the reference
+ * (class lidar_iris_descriptor, include/descriptor.h:462-1302; selected by config/dlc_lio_sam_params.yaml:23).
  *
  * On the GPU: the Iris image and row key of a scan (getIris, D.h:532-598), the log-Gabor binary templates T / M of an
- * image (logGaborFilter + logFeatureEncode, D.h:608-680), and the Hamming matching of two keyframes' templates over
- * column shifts (getHammingDistance, D.h:932-964).  NOT here: the shift estimate in front of the matching
- * (logPolarFFTTemplateMatch, D.h:793-925 -- a chain of OpenCV calls whose arithmetic cannot be restated bit for bit
- * without OpenCV); scl_iris_hamming takes the estimate as an argument, scl_iris_hamming_all_shifts searches every
- * column shift instead (a superset of the reference's +-2 window around the estimate).
+ * image (logGaborFilter + logFeatureEncode, D.h:608-680), the Hamming matching of two keyframes' templates over column
+ * shifts (getHammingDistance, D.h:932-964), the row-key distances of the candidate search, and on top of them the six
+ * virtuals of the plugin (D.h:1026-1271: per-robot feature lists, local -> global index maps, intra- and inter-robot
+ * detection).  The C++ adapter is include/scl/lidar_iris_hip_descriptor.hpp.
+ *
+ * NOT here: the shift estimate in front of the matching (logPolarFFTTemplateMatch, D.h:793-925 -- a chain of OpenCV
+ * calls whose arithmetic cannot be restated bit for bit without OpenCV).  compare() (D.h:966-1022) evaluates the
+ * Hamming distance in windows of five column shifts around that estimate (and around the estimate for the candidate
+ * turned by half a revolution); the detection entry points here search EVERY column shift instead -- a superset of
+ * both windows, so the distance is <= the reference's and equal to it whenever the reference's estimate is within two
+ * columns of the best shift.  scl_iris_hamming takes an estimate from the caller for hosts that keep OpenCV's.
  * Parity: bit-identical to the CPU restatement under oracle/ (tests/test_gpu_iris.py); against the reference's binaries
  * the templates are unpinned (OpenCV's float FFT) -- see oracle/iris_oracle.h.
  * Conventions as in scl_engine.h (status codes, point clouds as pointer / count / stride, no CPU fallback).
@@ -35,6 +41,19 @@ typedef struct scl_iris_config {
     float  mult;                /* 1.6  */
     float  sigma_onf;           /* 0.75 */
     int    device;
+    /* the plugin layer */
+    double dist_thres;          /* 0.32: loop accepted below it (D.h:1140, 1245)            */
+    int    num_exclude_recent;  /* 30:   newest keyframes of this robot kept out (D.h:1097)  */
+    int    match_num;           /* 2:    which windows compare() evaluates (D.h:968-1021); kept for the constructor's
+                                         signature -- the exhaustive shift search covers all three settings          */
+    int    num_candidates;      /* 10:   row-key neighbours compared (D.h:1109)              */
+    int    robot_num;           /* 1  */
+    int    this_id;             /* 0  */
+    float  knn_exclude_eps;     /* FLT_EPSILON: libnabo's knn with optionFlags = 0 skips neighbours whose squared row-key
+                                   distance is <= this (no self match), D.h:1109, 1215; 0 = every key counts          */
+    int    wire_decode;         /* 0: saveDescriptorAndKey's own indexing iris[row*(cols+1)+col+1] (D.h:1030-1037: reads
+                                      the image sheared by one more column per row, stays inside the buffer);
+                                   1: the layout makeAndSaveDescriptorAndKey emits (row*cols+col, D.h:1067-1074)       */
 } scl_iris_config;
 
 int  scl_iris_default_config(scl_iris_config *cfg);
@@ -49,12 +68,27 @@ int  scl_iris_make_image(scl_iris *h, const void *points, int n_points, int stri
  * out_values (rows*cols + rows floats, may be NULL) = the vector the reference returns (image values row-major, then
  * the row key). */
 int  scl_iris_make_and_save(scl_iris *h, const void *points, int n_points, int stride_bytes, int8_t robot, int index, float *out_values);
-/* save (D.h:1046-1060) from an image and its row key, e.g. decoded from the wire by the caller.  (The reference's own
- * decoder, D.h:1026-1044, reads iris[row*(cols+1)+col+1] from a buffer laid out with stride cols -- a defect that
- * shears the image; it is not replicated.) */
+/* save (D.h:1046-1060) from an image and its row key, e.g. decoded from the wire by the caller */
 int  scl_iris_save_image(scl_iris *h, const uint8_t *image, const float *rowkey, int8_t robot, int index);
+/* saveDescriptorAndKey(const float*), D.h:1026-1044: `values` = rows*cols + rows floats as emitted by
+ * scl_iris_make_and_save / the reference's makeAndSaveDescriptorAndKey; decoded as cfg.wire_decode says (float ->
+ * uint8 like the reference's implicit conversion on x86: truncation, then the low 8 bits). */
+int  scl_iris_save_from_wire(scl_iris *h, const float *values, int8_t robot, int index);
+/* getSize(idIn), D.h:1260-1270: id = -1 -> keyframes of all robots, else those of robot `id` */
 int  scl_iris_get_size(const scl_iris *h);
+int  scl_iris_get_size_of(const scl_iris *h, int id);
+/* getIndex(key), D.h:1255-1258: global key -> (robot, index) */
 int  scl_iris_get_index(const scl_iris *h, int key, int8_t *robot, int *index);
+/* global key of robot `robot`'s local keyframe `local` (local2Global, D.h:1055) */
+int  scl_iris_local_to_global(const scl_iris *h, int robot, int local, int *key);
+/* detectIntraLoopClosureID(curPtr), D.h:1085-1151: cur = LOCAL index among this_id's keyframes; candidates = the
+ * num_candidates nearest row keys among this robot's keyframes [0, cur - num_exclude_recent); *loop_id = LOCAL index
+ * of the best candidate if its distance < dist_thres, else -1; *bias = its column shift; *dist = the smallest
+ * distance seen (10000000 if none), loop or not. */
+int  scl_iris_detect_intra(scl_iris *h, int cur, int *loop_id, float *bias, float *dist);
+/* detectInterLoopClosureID(curPtr), D.h:1153-1253: cur = GLOBAL key; a keyframe of this robot is searched among all
+ * other robots' keyframes, a received one among this robot's; *loop_id = GLOBAL key or -1. */
+int  scl_iris_detect_inter(scl_iris *h, int cur, int *loop_id, float *bias, float *dist);
 /* the stored image / row key / templates of keyframe `key`: T and M are (2*nscale*rows) x cols bytes, 0 or 255, in the
  * row order of cv::vconcat at D.h:669-678 (real parts of the scales, then imaginary parts) */
 int  scl_iris_get_image(scl_iris *h, int key, uint8_t *image, float *rowkey);

@@ -17,6 +17,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cfloat>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -146,6 +147,26 @@ __global__ __launch_bounds__(64) void iris_hamming_kernel(const unsigned int *T,
     if (threadIdx.x == 0) { bits_diff[job] = diff; total_bits[job] = trows * N - masked; }
 }
 
+
+// Row-key candidate search (libnabo's exact knn, D.h:1103-1109 / 1209-1215): squared L2 in fp32 between keyframe q's
+// row key and those of list[0..n), accumulated four dimensions at a time and unfused -- the metric order the engine
+// uses for every KD-tree search of the reference (ringkey_topk.hip; oracle nf_l2).  The k smallest are picked on the host.
+__global__ void iris_rowkey_d2_kernel(const float *rowkeys, int rows, int q, const int *list, int n, float *d2)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *a = rowkeys + (size_t)q * rows, *b = rowkeys + (size_t)list[i] * rows;
+    float result = 0.0f;
+    int r = 0;
+    for (; r + 3 < rows; r += 4) {
+        const float d0 = __fsub_rn(a[r], b[r]), d1 = __fsub_rn(a[r + 1], b[r + 1]), d2v = __fsub_rn(a[r + 2], b[r + 2]), d3 = __fsub_rn(a[r + 3], b[r + 3]);
+        const float t = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2v, d2v)), __fmul_rn(d3, d3));
+        result = __fadd_rn(result, t);
+    }
+    for (; r < rows; ++r) { const float d0 = __fsub_rn(a[r], b[r]); result = __fadd_rn(result, __fmul_rn(d0, d0)); }
+    d2[i] = result;
+}
+
 }  // namespace
 
 struct scl_iris {
@@ -162,6 +183,9 @@ struct scl_iris {
     unsigned char *d_img1 = nullptr; float *d_key1 = nullptr; unsigned char *d_unpack = nullptr;
     int *d_cand = nullptr, *d_shifts = nullptr, *d_diff = nullptr, *d_total = nullptr; size_t job_cap = 0;
     std::vector<int8_t> robots; std::vector<int> indexs;
+    // the plugin layer (D.h:1289-1292): per robot the global keys of its keyframes in arrival order
+    std::vector<std::vector<int>> local2global;
+    int *d_list = nullptr; float *d_d2 = nullptr; size_t list_cap = 0;
 };
 
 namespace {
@@ -238,6 +262,7 @@ int make_image_locked(scl_iris *h, const void *points, int n_points, int stride)
 // d_img1 / d_key1 -> database slot n (image, row key, templates)
 int append_locked(scl_iris *h, int8_t robot, int index)
 {
+    if (robot < 0 || robot >= h->cfg.robot_num) return ifail(h, SCL_ERR_INVALID_ARG, "robot id outside [0, robot_num)");
     int rc = grow(h, h->n + 1);
     if (rc) return rc;
     const int rows = h->cfg.rows, cols = h->cfg.cols;
@@ -248,7 +273,8 @@ int append_locked(scl_iris *h, int8_t robot, int index)
                        h->d_img1, h->d_h, rows, cols, h->cfg.nscale, h->d_T + fw * h->n, h->d_M + fw * h->n, h->words);
     IRIS_HIP(h, hipGetLastError());
     IRIS_HIP(h, hipStreamSynchronize(h->stream));
-    h->robots.push_back(robot); h->indexs.push_back(index); h->n++;
+    h->local2global[(size_t)robot].push_back(h->n);                                // D.h:1055
+    h->robots.push_back(robot); h->indexs.push_back(index); h->n++;            // D.h:1057
     return SCL_OK;
 }
 
@@ -287,6 +313,56 @@ int hamming_jobs_locked(scl_iris *h, int key1, const int *cand, const int *shift
     return SCL_OK;
 }
 
+// Candidate search + pairwise comparison shared by the two detections (D.h:1100-1137 / 1205-1242).  `list` = global keys of
+// the search set in the order the reference concatenates them (the KD-tree's point order); `cur` = global key of the query.
+// Returns the position in `list` of the best candidate (-1: none), its distance and shift.
+int detect_core_locked(scl_iris *h, int cur, const std::vector<int> &list, int *best_pos, float *best_dis, int *best_bias)
+{
+    *best_pos = -1; *best_dis = 10000000.0f; *best_bias = 0;                  // D.h:1104-1106
+    const int n = (int)list.size(), k = h->cfg.num_candidates;
+    if (n <= 0 || k <= 0) return SCL_OK;
+    if ((size_t)n > h->list_cap) {
+        if (h->d_list) (void)hipFree(h->d_list);
+        if (h->d_d2) (void)hipFree(h->d_d2);
+        h->d_list = nullptr; h->d_d2 = nullptr; h->list_cap = 0;
+        const size_t cap = (size_t)n + (size_t)n / 2 + 256;
+        int rc;
+        if ((rc = ialloc(h, &h->d_list, cap)) || (rc = ialloc(h, &h->d_d2, cap))) return rc;
+        h->list_cap = cap;
+    }
+    IRIS_HIP(h, hipMemcpyAsync(h->d_list, list.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(iris_rowkey_d2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_rowkeys, h->cfg.rows, cur, h->d_list, n, h->d_d2);
+    IRIS_HIP(h, hipGetLastError());
+    std::vector<float> d2((size_t)n);
+    IRIS_HIP(h, hipMemcpyAsync(d2.data(), h->d_d2, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    IRIS_HIP(h, hipStreamSynchronize(h->stream));
+    // the k nearest: ascending distance, equal distances by ascending position; libnabo without ALLOW_SELF_MATCH skips
+    // d2 <= eps; NaN / inf never enter (insertion like the engine's ring-key search)
+    std::vector<int> pos; std::vector<float> pd;
+    pos.reserve((size_t)k + 1); pd.reserve((size_t)k + 1);
+    const float eps = h->cfg.knn_exclude_eps;
+    for (int i = 0; i < n; ++i) {
+        const float d = d2[(size_t)i];
+        if (eps > 0.0f && d <= eps) continue;
+        if (!(d < FLT_MAX)) continue;
+        if ((int)pos.size() == k && !(d < pd.back())) continue;
+        size_t j = pos.size();
+        while (j > 0 && pd[j - 1] > d) --j;
+        pos.insert(pos.begin() + (long)j, i); pd.insert(pd.begin() + (long)j, d);
+        if ((int)pos.size() > k) { pos.pop_back(); pd.pop_back(); }
+    }
+    if (pos.empty()) return SCL_OK;
+    const int m = (int)pos.size(), N = h->cfg.cols;
+    std::vector<int> cand((size_t)m), shifts((size_t)m * N), bias((size_t)m);
+    std::vector<float> dis((size_t)m);
+    for (int c = 0; c < m; ++c) { cand[(size_t)c] = list[(size_t)pos[(size_t)c]]; for (int j = 0; j < N; ++j) shifts[(size_t)c * N + j] = j; }
+    int rc = hamming_jobs_locked(h, cur, cand.data(), shifts.data(), m, N, dis.data(), bias.data(), false);
+    if (rc) return rc;
+    for (int c = 0; c < m; ++c)                                              // D.h:1112-1131: strict <, NaN never wins
+        if (dis[(size_t)c] < *best_dis) { *best_dis = dis[(size_t)c]; *best_pos = pos[(size_t)c]; *best_bias = bias[(size_t)c]; }
+    return SCL_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -295,6 +371,8 @@ int scl_iris_default_config(scl_iris_config *c)
 {
     if (!c) return SCL_ERR_INVALID_ARG;
     c->rows = 80; c->cols = 360; c->nscan = 64; c->nscale = 4; c->min_wavelength = 18; c->mult = 1.6f; c->sigma_onf = 0.75f; c->device = 0;
+    c->dist_thres = 0.32; c->num_exclude_recent = 30; c->match_num = 2; c->num_candidates = 10; c->robot_num = 1; c->this_id = 0;
+    c->knn_exclude_eps = FLT_EPSILON; c->wire_decode = 0;
     return SCL_OK;
 }
 
@@ -305,13 +383,17 @@ int scl_iris_create(const scl_iris_config *cfg, scl_iris **out)
     if (!cfg || !out) return SCL_ERR_INVALID_ARG;
     *out = nullptr;
     if (cfg->rows < 1 || cfg->rows > 512 || cfg->cols < 2 || cfg->cols > 2048 || cfg->nscale < 1 || cfg->nscale > 8 ||
-        cfg->min_wavelength < 1 || !(cfg->mult > 0.f) || !(cfg->sigma_onf > 0.f) || cfg->sigma_onf == 1.0f) return SCL_ERR_INVALID_ARG;
+        cfg->min_wavelength < 1 || !(cfg->mult > 0.f) || !(cfg->sigma_onf > 0.f) || cfg->sigma_onf == 1.0f ||
+        cfg->robot_num < 1 || cfg->robot_num > 127 || cfg->this_id < 0 || cfg->this_id >= cfg->robot_num || cfg->num_candidates < 1 ||
+        cfg->num_candidates > 4096 || cfg->num_exclude_recent < 0 || cfg->match_num < 0 || cfg->match_num > 2 || !(cfg->knn_exclude_eps >= 0.0f))
+        return SCL_ERR_INVALID_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SCL_ERR_NO_DEVICE;
     if (cfg->device < 0 || cfg->device >= ndev) return SCL_ERR_INVALID_ARG;
     scl_iris *h = new (std::nothrow) scl_iris();
     if (!h) return SCL_ERR_NOMEM;
     h->cfg = *cfg; h->device = cfg->device;
+    h->local2global.resize((size_t)cfg->robot_num);                             // D.h:501-509
     h->trows = 2 * cfg->nscale * cfg->rows; h->words = (h->trows + 31) / 32;
     auto bail = [&](int code) { scl_iris_destroy(h); return code; };
     if (hipSetDevice(h->device) != hipSuccess) return bail(SCL_ERR_HIP);
@@ -366,7 +448,7 @@ int scl_iris_destroy(scl_iris *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void *p : {(void *)h->d_images, (void *)h->d_rowkeys, (void *)h->d_T, (void *)h->d_M, (void *)h->d_h, (void *)h->d_cells, (void *)h->d_zmax,
                     (void *)h->d_points, (void *)h->d_img1, (void *)h->d_key1, (void *)h->d_unpack, (void *)h->d_cand, (void *)h->d_shifts,
-                    (void *)h->d_diff, (void *)h->d_total})
+                    (void *)h->d_diff, (void *)h->d_total, (void *)h->d_list, (void *)h->d_d2})
         if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -413,6 +495,92 @@ int scl_iris_save_image(scl_iris *h, const uint8_t *image, const float *rowkey, 
     IRIS_HIP(h, hipMemcpyAsync(h->d_img1, image, (size_t)h->cfg.rows * h->cfg.cols, hipMemcpyHostToDevice, h->stream));
     IRIS_HIP(h, hipMemcpyAsync(h->d_key1, rowkey, sizeof(float) * h->cfg.rows, hipMemcpyHostToDevice, h->stream));
     return append_locked(h, robot, index);
+}
+
+int scl_iris_save_from_wire(scl_iris *h, const float *values, int8_t robot, int index)
+{
+    if (!h || !values) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    (void)hipSetDevice(h->device);
+    const int rows = h->cfg.rows, cols = h->cfg.cols;
+    std::vector<uint8_t> img((size_t)rows * cols);
+    auto to_u8 = [](float f) -> uint8_t {                                     // float -> uchar as x86 does it: cvttss2si, low byte
+        if (!(f > -2147483904.0f && f < 2147483648.0f)) return 0;              // (out of int range / NaN -> 0x80000000 -> 0)
+        return (uint8_t)(int32_t)f;
+    };
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c)
+            img[(size_t)r * cols + c] = to_u8(h->cfg.wire_decode ? values[(size_t)r * cols + c]             // D.h:1067-1074's layout
+                                                               : values[(size_t)r * (cols + 1) + c + 1]);   // D.h:1035
+    IRIS_HIP(h, hipMemcpyAsync(h->d_img1, img.data(), img.size(), hipMemcpyHostToDevice, h->stream));
+    IRIS_HIP(h, hipMemcpyAsync(h->d_key1, values + (size_t)rows * cols, sizeof(float) * rows, hipMemcpyHostToDevice, h->stream));   // D.h:1039-1042
+    return append_locked(h, robot, index);                                    // synchronises before `img` goes away
+}
+
+int scl_iris_get_size_of(const scl_iris *h, int id)
+{
+    if (!h) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (id == -1) return h->n;                                                // D.h:1262-1265
+    if (id < 0 || id >= h->cfg.robot_num) return ifail(h, SCL_ERR_OUT_OF_RANGE, "robot id outside [0, robot_num)");
+    return (int)h->local2global[(size_t)id].size();                           // D.h:1268
+}
+
+int scl_iris_local_to_global(const scl_iris *h, int robot, int local, int *key)
+{
+    if (!h || !key) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (robot < 0 || robot >= h->cfg.robot_num) return ifail(h, SCL_ERR_OUT_OF_RANGE, "robot id outside [0, robot_num)");
+    const std::vector<int> &l2g = h->local2global[(size_t)robot];
+    if (local < 0 || local >= (int)l2g.size()) return ifail(h, SCL_ERR_OUT_OF_RANGE, "local index out of range");
+    *key = l2g[(size_t)local];
+    return SCL_OK;
+}
+
+int scl_iris_detect_intra(scl_iris *h, int cur, int *loop_id, float *bias, float *dist)
+{
+    if (!h || !loop_id || !bias) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    (void)hipSetDevice(h->device);
+    *loop_id = -1; *bias = 0.0f;
+    if (dist) *dist = 10000000.0f;
+    const std::vector<int> &mine = h->local2global[(size_t)h->cfg.this_id];
+    if (cur < 0 || cur >= (int)mine.size()) return ifail(h, SCL_ERR_OUT_OF_RANGE, "detect_intra: no such keyframe of this robot");
+    if (cur < h->cfg.num_exclude_recent + h->cfg.num_candidates + 1) return SCL_OK;     // D.h:1092-1095
+    const int history = cur - h->cfg.num_exclude_recent;                                 // D.h:1097-1101
+    std::vector<int> list(mine.begin(), mine.begin() + history);
+    int pos, b; float d;
+    int rc = detect_core_locked(h, mine[(size_t)cur], list, &pos, &d, &b);
+    if (rc) return rc;
+    if (dist) *dist = d;
+    if ((double)d < h->cfg.dist_thres) { *loop_id = pos; *bias = (float)b; }             // D.h:1140-1144: the LOCAL index
+    return SCL_OK;
+}
+
+int scl_iris_detect_inter(scl_iris *h, int cur, int *loop_id, float *bias, float *dist)
+{
+    if (!h || !loop_id || !bias) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    (void)hipSetDevice(h->device);
+    *loop_id = -1; *bias = 0.0f;
+    if (dist) *dist = 10000000.0f;
+    if (cur < 0 || cur >= h->n) return ifail(h, SCL_ERR_OUT_OF_RANGE, "detect_inter: key out of range");
+    const int cur_robot = h->robots[(size_t)cur];                                        // D.h:1156
+    std::vector<int> list;                                                               // newLocal2Global, D.h:1167-1195
+    if (cur_robot == h->cfg.this_id) {
+        for (int i = 0; i < h->cfg.robot_num; ++i)
+            if (i != h->cfg.this_id) list.insert(list.end(), h->local2global[(size_t)i].begin(), h->local2global[(size_t)i].end());
+    } else {
+        const std::vector<int> &mine = h->local2global[(size_t)h->cfg.this_id];
+        list.assign(mine.begin(), mine.end());
+    }
+    if ((int)list.size() < h->cfg.num_candidates + 1) return SCL_OK;                     // D.h:1198-1201
+    int pos, b; float d;
+    int rc = detect_core_locked(h, cur, list, &pos, &d, &b);
+    if (rc) return rc;
+    if (dist) *dist = d;
+    if ((double)d < h->cfg.dist_thres && pos >= 0) { *loop_id = list[(size_t)pos]; *bias = (float)b; }   // D.h:1236, 1245-1248: the GLOBAL key
+    return SCL_OK;
 }
 
 int scl_iris_get_size(const scl_iris *h)

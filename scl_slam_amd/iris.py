@@ -1,6 +1,6 @@
 """ctypes binding of include/scl_iris.h: the LiDAR-Iris building blocks (image, templates, Hamming matching) on the GPU."""
 import ctypes
-from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_int8, c_uint8, c_void_p
+from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int8, c_uint8, c_void_p
 
 import numpy as np
 
@@ -10,7 +10,9 @@ from ._native import load_library
 class IrisConfig(ctypes.Structure):
     """scl_iris_config; defaults = lidar_iris_descriptor's constructor defaults (descriptor.h:473-486)"""
     _fields_ = [("rows", c_int), ("cols", c_int), ("nscan", c_int), ("nscale", c_int), ("min_wavelength", c_int),
-                ("mult", c_float), ("sigma_onf", c_float), ("device", c_int)]
+                ("mult", c_float), ("sigma_onf", c_float), ("device", c_int),
+                ("dist_thres", c_double), ("num_exclude_recent", c_int), ("match_num", c_int), ("num_candidates", c_int),
+                ("robot_num", c_int), ("this_id", c_int), ("knn_exclude_eps", c_float), ("wire_decode", c_int)]
 
 
 _bound = None
@@ -30,7 +32,12 @@ def _lib():
         "scl_iris_make_image": (c_int, [P, P, c_int, c_int, u8, fp]),
         "scl_iris_make_and_save": (c_int, [P, P, c_int, c_int, c_int8, c_int, fp]),
         "scl_iris_save_image": (c_int, [P, u8, fp, c_int8, c_int]),
+        "scl_iris_save_from_wire": (c_int, [P, fp, c_int8, c_int]),
         "scl_iris_get_size": (c_int, [P]),
+        "scl_iris_get_size_of": (c_int, [P, c_int]),
+        "scl_iris_local_to_global": (c_int, [P, c_int, c_int, ip]),
+        "scl_iris_detect_intra": (c_int, [P, c_int, ip, fp, fp]),
+        "scl_iris_detect_inter": (c_int, [P, c_int, ip, fp, fp]),
         "scl_iris_get_index": (c_int, [P, c_int, POINTER(c_int8), ip]),
         "scl_iris_get_image": (c_int, [P, c_int, u8, fp]),
         "scl_iris_get_feature": (c_int, [P, c_int, u8, u8]),
@@ -45,9 +52,21 @@ def _lib():
 
 
 class IrisEngine:
-    def __init__(self, rows=80, cols=360, nscan=64, nscale=4, min_wavelength=18, mult=1.6, sigma_onf=0.75, device=0):
+    """Mirror of lidar_iris_descriptor (descriptor.h:462-1302): same constructor arguments and defaults, the six plugin
+    calls (make_and_save, save_from_wire, detect_intra, detect_inter, get_index, get_size) and the building blocks."""
+
+    def __init__(self, rows=80, cols=360, nscan=64, dist_thres=0.32, num_exclude_recent=30, match_num=2, num_candidates=10,
+                 nscale=4, min_wavelength=18, mult=1.6, sigma_onf=0.75, robot_num=1, this_id=0, device=0,
+                 knn_exclude_eps=None, wire_decode=0):
         self.L = _lib()
-        cfg = IrisConfig(rows, cols, nscan, nscale, min_wavelength, mult, sigma_onf, device)
+        cfg = IrisConfig()
+        self._check_rc(self.L.scl_iris_default_config(byref(cfg)))
+        cfg.rows, cfg.cols, cfg.nscan, cfg.nscale, cfg.min_wavelength = rows, cols, nscan, nscale, min_wavelength
+        cfg.mult, cfg.sigma_onf, cfg.device = mult, sigma_onf, device
+        cfg.dist_thres, cfg.num_exclude_recent, cfg.match_num, cfg.num_candidates = dist_thres, num_exclude_recent, match_num, num_candidates
+        cfg.robot_num, cfg.this_id, cfg.wire_decode = robot_num, this_id, wire_decode
+        if knn_exclude_eps is not None:
+            cfg.knn_exclude_eps = knn_exclude_eps
         self.cfg = cfg
         self.h = c_void_p()
         rc = self.L.scl_iris_create(byref(cfg), byref(self.h))
@@ -55,6 +74,11 @@ class IrisEngine:
             self.h = c_void_p()
             raise RuntimeError(f"scl_iris_create: status {rc}")
         self.rows, self.cols, self.trows = rows, cols, 2 * nscale * rows
+
+    @staticmethod
+    def _check_rc(rc):
+        if rc != 0:
+            raise RuntimeError(f"scl_iris: status {rc}")
 
     def _check(self, rc, where):
         if rc != 0:
@@ -94,8 +118,34 @@ class IrisEngine:
         self._check(self.L.scl_iris_save_image(self.h, img.ctypes.data_as(POINTER(c_uint8)), key.ctypes.data_as(POINTER(c_float)), robot, index),
                     "scl_iris_save_image")
 
-    def get_size(self):
-        return self.L.scl_iris_get_size(self.h)
+    def save_from_wire(self, values, robot=0, index=0):
+        v = np.ascontiguousarray(values, np.float32)
+        assert v.size == self.rows * self.cols + self.rows
+        self._check(self.L.scl_iris_save_from_wire(self.h, v.ctypes.data_as(POINTER(c_float)), robot, index), "scl_iris_save_from_wire")
+
+    def get_size(self, robot=-1):
+        n = self.L.scl_iris_get_size_of(self.h, robot)
+        if n < 0:
+            self._check(n, "scl_iris_get_size_of")
+        return n
+
+    def local_to_global(self, robot, local):
+        k = c_int()
+        self._check(self.L.scl_iris_local_to_global(self.h, robot, local, byref(k)), "scl_iris_local_to_global")
+        return k.value
+
+    def _detect(self, fn, name, cur):
+        loop, bias, dist = c_int(), c_float(), c_float()
+        self._check(fn(self.h, cur, byref(loop), byref(bias), byref(dist)), name)
+        return loop.value, bias.value, dist.value
+
+    def detect_intra(self, cur):
+        """(loop local index or -1, column shift, smallest distance seen) -- detectIntraLoopClosureID, D.h:1085-1151"""
+        return self._detect(self.L.scl_iris_detect_intra, "scl_iris_detect_intra", cur)
+
+    def detect_inter(self, cur):
+        """(loop global key or -1, column shift, smallest distance seen) -- detectInterLoopClosureID, D.h:1153-1253"""
+        return self._detect(self.L.scl_iris_detect_inter, "scl_iris_detect_inter", cur)
 
     def get_index(self, key):
         r, i = c_int8(), c_int()

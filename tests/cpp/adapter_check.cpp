@@ -10,6 +10,7 @@
 
 #include "pcl_types_for_adapter_check.h"
 #include "scl/scan_context_hip_descriptor.hpp"
+#include "scl/lidar_iris_hip_descriptor.hpp"
 
 int main(int argc, char **argv)
 {
@@ -91,6 +92,60 @@ int main(int argc, char **argv)
         const std::vector<float> two_calls = a.makeAndSaveDescriptorAndKey(filtered, 0, 0);
         const std::vector<float> one_call = b.makeAndSaveDescriptorAndKeyFiltered(raw, 0.4f, 0, 0);
         if (two_calls != one_call) { std::printf("FAIL filtered descriptor\n"); return 1; }
+    }
+    // the second descriptor of the reference through its adapter, constructed like DM.h:408 for two robots: robot 0 walks the
+    // path twice (intra-robot loops), robot 1 receives robot 0's keyframes over the wire and has three of its own at revisited
+    // places (inter-robot loops both ways)
+    {
+        const int n_iris = 100, half = 50;
+        // the same rays at every visit of a place (a polar grid in the world frame: 360 azimuths x 41 ranges away from the
+        // bin edges), seen under the visit's heading; `noise` > 0 perturbs ranges and heights like a second pass would --
+        // without it the row key of a revisit equals the first visit's and libnabo's self-match rule drops the candidate
+        auto make_cloud = [&](int pos, int yaw_deg, float noise) {
+            const float cx = 150.0f * std::cos(0.048f * pos), cy = 150.0f * std::sin(0.048f * pos);
+            pcl::PointCloud<pcl::PointXYZI> cloud;
+            for (int a = 0; a < 360; ++a)
+                for (int j = 0; j < 41; ++j) {
+                    const double az = (a + 0.25) * 3.14159265358979323846 / 180.0, azs = (a + 0.25 - yaw_deg) * 3.14159265358979323846 / 180.0;
+                    const float rad = 1.45f + 1.93f * j + noise * (float)uni(0.0, 0.02);
+                    const float wx = rad * (float)std::cos(az), wy = rad * (float)std::sin(az);
+                    pcl::PointXYZI p{};
+                    p.x = rad * (float)std::cos(azs); p.y = rad * (float)std::sin(azs); p.z = -1.65f;
+                    for (const auto &bx : boxes)
+                        if (std::fabs(wx + cx - bx[0]) < bx[2] && std::fabs(wy + cy - bx[1]) < bx[2]) { p.z = -1.65f + bx[3] + noise * (float)uni(0.0, 0.05); break; }
+                    cloud.points.push_back(p);
+                }
+            return cloud;
+        };
+        lidar_iris_hip_descriptor *i0 = new lidar_iris_hip_descriptor(80, 360, 64, 0.32, 30, 2, 10, 4, 18, 1.6f, 0.75f, 2, 0, 0, 1);
+        lidar_iris_hip_descriptor *i1 = new lidar_iris_hip_descriptor(80, 360, 64, 0.32, 30, 2, 10, 4, 18, 1.6f, 0.75f, 2, 1, 0, 1);
+        std::unique_ptr<scan_descriptor> iris0(i0), iris1(i1);
+        for (int kf = 0; kf < n_iris; ++kf) {
+            const std::vector<float> v = iris0->makeAndSaveDescriptorAndKey(make_cloud(kf % half, kf < half ? 0 : 40, kf < half ? 0.0f : 1.0f), 0, kf);
+            if ((int)v.size() != 80 * 360 + 80) { std::printf("FAIL iris vT size\n"); return 1; }
+            iris1->saveDescriptorAndKey(v.data(), 0, kf);
+        }
+        int iloops = 0, icorrect = 0;
+        for (int cur = 0; cur < n_iris; ++cur) {
+            const std::pair<int, float> r = iris0->detectIntraLoopClosureID(cur);
+            if (cur < 41 && r.first != -1) { std::printf("FAIL iris early-out\n"); return 1; }
+            if (r.first >= 0) { ++iloops; if (std::abs(r.first - (cur - half)) <= 1 && std::fabs(r.second - 40.0f) <= 1.0f) ++icorrect; }   // heading + 40 degrees = 40 columns
+        }
+        std::printf("iris: intra loops %d, at the revisited place and heading %d\n", iloops, icorrect);
+        if (iloops < 20 || icorrect * 10 < iloops * 8) { std::printf("FAIL iris loop recall\n"); return 1; }
+        int inter_ok = 0;
+        for (int k = 0; k < 3; ++k) {
+            const std::vector<float> v = iris1->makeAndSaveDescriptorAndKey(make_cloud(10 + 7 * k, 69, 1.0f), 1, k);
+            iris0->saveDescriptorAndKey(v.data(), 1, k);
+            const std::pair<int, float> mine = iris1->detectInterLoopClosureID(n_iris + k);       // own keyframe among robot 0's
+            const std::pair<int, float> theirs = iris0->detectInterLoopClosureID(n_iris + k);     // received keyframe among robot 0's own
+            if (mine.first >= 0 && mine.first == theirs.first && iris1->getIndex(mine.first).first == 0 &&
+                iris1->getIndex(mine.first).second % half == 10 + 7 * k) ++inter_ok;
+        }
+        std::printf("iris: inter-robot loops agreed on %d of 3\n", inter_ok);
+        if (inter_ok < 3 || iris0->getSize() != n_iris + 3 || iris0->getSize(0) != n_iris || iris0->getSize(1) != 3 || iris1->getSize(1) != 3) { std::printf("FAIL iris inter\n"); return 1; }
+        i0->close(); i1->close();
+        if (iris0->getSize() != 0 || iris0->detectInterLoopClosureID(0).first != -1) { std::printf("FAIL closed iris adapter\n"); return 1; }
     }
     const std::pair<int, float> inter = remote->detectInterLoopClosureID(n_keyframes - 1);
     std::printf("inter: loop %d yaw %.4f\n", inter.first, inter.second);

@@ -65,7 +65,7 @@ def test_iris_templates_and_hamming_properties():
 @pytest.mark.gpu
 def test_iris_on_the_gpu_equals_the_restatement():
     from scl_slam_amd.iris import IrisEngine
-    eng = IrisEngine()
+    eng = IrisEngine(robot_num=3)
     cfg = oi.config()
     rs = np.random.RandomState(5)
     clouds = [synth_scan(60000, seed=70 + k, max_range=85.0) for k in range(5)]
