@@ -227,6 +227,12 @@ int ensure_sets(scl_engine *e, size_t n)
     int rc = ensure_pairs(e, stride * scl_engine::kScreenSets);
     if (rc) { e->set_stride = 0; return rc; }
     e->set_stride = stride;
+    const size_t need = stride * (size_t)kMaxScreenBatch * 32;          // floats: two ring halves x 16 shifts per pair of a launch
+    if (need > e->part_cap) {
+        dev_free(e->d_part); e->part_cap = 0;
+        if ((rc = dev_alloc(e, &e->d_part, need))) { e->set_stride = 0; return rc; }
+        e->part_cap = need;
+    }
     return SCL_OK;
 }
 
@@ -501,7 +507,7 @@ int scl_destroy(scl_engine *e)
     dev_free(e->d_hdesc); dev_free(e->d_kmask);
     dev_free(e->d_vals); dev_free(e->d_points); dev_free(e->d_tile);
     dev_free(e->d_dist); dev_free(e->d_shift); dev_free(e->d_cand); dev_free(e->d_ring_d2);
-    dev_free(e->d_approx); dev_free(e->d_starts); dev_free(e->d_surv); dev_free(e->d_nsurv); dev_free(e->d_tmin);
+    dev_free(e->d_approx); dev_free(e->d_starts); dev_free(e->d_surv); dev_free(e->d_nsurv); dev_free(e->d_tmin); dev_free(e->d_part);
     dev_free(e->d_align_fallbacks);
     dev_free(e->d_surv_part); dev_free(e->d_surv_done);
     if (e->d_surv_args) (void)hipFree(e->d_surv_args);
@@ -857,7 +863,7 @@ int launch_screen_group(scl_engine *e, const ScreenGroup &cur, int phases = kScr
         for (int j = 0; j < g.nq; ++j) { sb.slot[j] = g.qslot[j]; sb.base[j] = g.lo[j]; sb.n[j] = g.n[j]; sb.buf[j] = g.set0 + j; }
         sb.pair_stride = e->set_stride;
         sb.approx = e->d_approx; sb.starts = e->d_starts; sb.align_fallbacks = e->d_align_fallbacks; sb.ring_d2 = e->d_ring_d2;
-        sb.survivors = nullptr; sb.n_surv = nullptr; sb.t_min = e->d_tmin;
+        sb.survivors = nullptr; sb.n_surv = nullptr; sb.t_min = e->d_tmin; sb.part = e->d_part;
         sb.k = e->cfg.num_candidates; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
     };
     ScreenBatch sb{}, nx{};

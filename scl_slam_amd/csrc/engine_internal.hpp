@@ -67,6 +67,7 @@ struct scl_engine {
     // submit / collect form uses sets 0..3): approx, ring_d2, survivors, dist, shift at set * set_stride.
     static constexpr int kScreenSets = 64;
     float *d_approx = nullptr; int *d_starts = nullptr; int *d_surv = nullptr;
+    float *d_part = nullptr; size_t part_cap = 0;       // partial sums of the screening products' second form (one launch at a time)
     int *d_nsurv = nullptr; unsigned int *d_tmin = nullptr;
     unsigned long long *d_align_fallbacks = nullptr; uint64_t align_pairs = 0;   // statistics of the alignment kernel (scl_alignment_stats)
     size_t set_stride = 0;

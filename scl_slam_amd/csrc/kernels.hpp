@@ -10,7 +10,17 @@ constexpr double kBigDist = 10000000.0;   // D.h:1494,1556,1637,1705 initial min
 constexpr int hdesc_sector(int RG) { return ((RG * 8 + 63) / 64) * 8; }   // 8-byte elements per sector of hdesc: ring groups padded to whole 64-byte k-steps
 constexpr int hkey_halfs(int S) { return ((S + 31) / 32) * 32; }         // the unit-norm fp16 sector key behind the copy, zero padded to whole k-steps
 constexpr int hkey_store_halfs(int S) { return hkey_halfs(S) + 8; }      // ... followed by the key's norm as a float (and 12 spare bytes)
-constexpr int hdesc_stride(int RG, int S) { return hdesc_sector(RG) * S + hkey_store_halfs(S) / 4; }  // ... per slot
+// Grids with 64 rings carry a second image of the copy behind the key, for the second form of the screening products
+// (sc_screen.hip): chunk-major -- [ring half h][16-byte chunk j][sector 0 .. S+15] x 16 B (rings 32h + 8j .. + 7 of sector s mod S), so
+// that the 16 consecutive sectors a matrix-core fragment needs per chunk are 256 consecutive bytes; offsets in 8-byte elements,
+// 128-byte aligned
+constexpr int hdesc2_offset_rgh(int RGH, int S) { return ((RGH * S + hkey_store_halfs(S) / 4 + 15) / 16) * 16; }
+constexpr int hdesc2_elems_rgh(int RGH, int S) { return RGH == 16 ? 2 * 8 * (S + 16) : 0; }
+constexpr int hdesc_stride_rgh(int RGH, int S) { return hdesc2_elems_rgh(RGH, S) ? ((hdesc2_offset_rgh(RGH, S) + hdesc2_elems_rgh(RGH, S) + 15) / 16) * 16
+                                                                                 : RGH * S + hkey_store_halfs(S) / 4; }
+constexpr int hdesc2_offset(int RG, int S) { return hdesc2_offset_rgh(hdesc_sector(RG), S); }
+constexpr int hdesc2_elems(int RG, int S) { return hdesc2_elems_rgh(hdesc_sector(RG), S); }
+constexpr int hdesc_stride(int RG, int S) { return hdesc_stride_rgh(hdesc_sector(RG), S); }  // ... per slot
 
 // ---- database layout in HBM (one "slot" per keyframe) -----------------------
 //   desc   float4 [cap][RG][S]   RG = ceil(R/4); element (rg, c) holds rows
@@ -92,6 +102,7 @@ struct ScreenBatch {
     int *starts;                                // first shifts (alignment kernel -> screening kernel), like approx
     unsigned long long *align_fallbacks;        // optional counter: keyframes aligned by the exact evaluation
     int k; float exclude_eps; int *topk_idx; float *topk_d2;
+    float *part;                                // scratch of the second form of the 64 x 120 products: nq * pair_stride * 32 floats (nullptr: first form)
 };
 bool sc_screen_supported(const struct DbView &db, int SR);
 bool sc_screen_is_wide(const struct DbView &db, int SR);      // 80 x 180: screening by sc_screen_wide_kernel, exact pass by the one-sector-per-lane kernel

@@ -154,6 +154,23 @@ __global__ __launch_bounds__(256) void ingest_kernel(
         }
         hslot[i] = hv;
     }
+    // the chunk-major image of the same values (64-ring grids): [half][chunk][sector 0 .. S+15], 8 rings = 16 B per entry
+    if (hdesc2_elems(RG, S)) {
+        typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+        h8v *h2 = reinterpret_cast<h8v *>(hdesc + (size_t)slot * hstride + (size_t)hdesc2_offset(RG, S));
+        for (int i = threadIdx.x; i < 8 * (S + 16); i += blockDim.x) {
+            const int hj = i / (S + 16), sx = i - hj * (S + 16);
+            const int c = sx < S ? sx : sx - S;
+            const float iv = siv[c];
+            h8v hv;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = 8 * hj + k;
+                hv[k] = (_Float16)((r < R ? sv[r * LS + c] : 0.0f) * iv);
+            }
+            h2[i] = hv;
+        }
+    }
     // the sector key as a unit vector in fp16, behind the copy (first stage of the alignment filter, sc_screen.hip)
     {
         const int SK = hkey_halfs(S);
