@@ -41,15 +41,18 @@ N_KEYFRAMES_1GPU = 10000           # configs[1]
 N_KEYFRAMES_SHARD = 12500          # configs[3]: 100k keyframes over 8 GPUs
 N_EXCLUDE = 100                    # NUM_EXCLUDE_RECENT, descriptor.h:1314
 ALGO_BYTES_PER_PAIR = R * S * 4 + S * 4 + S * 4      # 31 680 B at 64x120 (fp32 descriptor + fp64 sector key)
-# What the dominant kernel reads per keyframe by design: the fp16 screening copy of the descriptor
-# (2 R S), the fp64 sector key (8 S), the tiled ring key (4 * 4 ceil(R/4)) and the 32-byte sector mask = 16 608 B, not SURVEY's
-# 31 680 B (fp32 descriptor): the kernel must not get credit for bytes it does not move.
-KERNEL_BYTES_PER_PAIR = R * S * 2 + S * 8 + 4 * 4 * ((R + 3) // 4) + 32
-# The scans of one launch share every keyframe line through an XCD's L2 (the workgroups that walk the same keyframes sit on one
-# XCD): those bytes reach the CUs once per pair, but cross HBM once per LAUNCH.  `roofline.achieved` follows SURVEY 8(d)'s rule
-# for Q scans per pass (database bytes once per launch + per-scan bytes); the per-pair delivery rate is reported beside it
-# against the measured rate of rows served from the XCDs' L2s (MI355X_MICROARCH.md: 16.8-18.8 TB/s chip-wide).
-L2_RATE_GBS = 17800.0
+# What the screening launch group (products in their second form + finishing kernel + the next batch's alignment) reads per
+# KEYFRAME by design, once per launch whatever the number of scans: the chunk-major fp16 image of the
+# descriptor (2 halves x 4 chunks x (S + 16) sectors x 16 B = 17 408 B at 64x120: 13 % padding so that no fragment wraps), the unit
+# fp16 sector key + its norm (2 * 128 + 16), the tiled ring key (4 * 4 ceil(R/4)) and the 32-byte sector mask = 17 968 B -- not
+# SURVEY's 31 680 B (fp32 descriptor): the kernels must not get credit for bytes they do not move.
+KERNEL_BYTES_PER_KEYFRAME = 2 * 4 * (S + 16) * 16 + (2 * 128 + 16) + 4 * 4 * ((R + 3) // 4) + 32
+# ... and per PAIR, whatever stays on the chip or not: first shift (4 B written by the alignment, read by products and finish),
+# the two ring halves' partial sums (2 x 64 B written, read once), the bound d~ and the ring-key metric (4 B each)
+KERNEL_BYTES_PER_PAIR_IO = 4 + 2 * 4 + 2 * 128 + 4 + 4
+# A kernel that streams the database once per SCAN reads at least the fp16 copy, keys and mask per pair (the first form's figure):
+SINGLE_SCAN_BYTES_PER_PAIR = R * S * 2 + S * 8 + 4 * 4 * ((R + 3) // 4) + 32
+L2_RATE_GBS = 17800.0              # rows served from the XCDs' L2s (MI355X_MICROARCH.md): bounds the first form of the products (80x180 still uses it)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 
@@ -453,15 +456,14 @@ def main():
     value = pairs_per_step * args.steps / elapsed
     k1_ms = prof["sc_distance_ms"] / max(1, prof["sc_distance_launches"])
     k1_pairs = prof["sc_distance_pairs"] / max(1, prof["sc_distance_launches"])
-    k1_scans = k1_pairs / n_elig                          # scans whose products one launch holds
-    # Algorithmic bytes of one launch by SURVEY 8(d)'s rule for Q scans per database pass ("DB_bytes / Q + per-query bytes:
-    # never count bytes that were not moved"): every eligible keyframe's screening rows once, + per scan its own rows, + what
-    # the launch writes per pair (bound d~ 4 B, first shift 4 B and ring-key metric 4 B of the next batch).
-    per_launch = n_elig * KERNEL_BYTES_PER_PAIR + k1_scans * KERNEL_BYTES_PER_PAIR + k1_pairs * 12.0
+    k1_scans = k1_pairs / n_elig                          # scans whose products one launch group holds
+    # Algorithmic bytes of one launch group by SURVEY 8(d)'s rule for Q scans per database pass ("DB_bytes / Q + per-query bytes:
+    # never count bytes that were not moved"): every eligible keyframe's screening image and keys once, + per scan its own
+    # images, + what the group writes and re-reads per pair (first shifts, partial sums, bound, ring-key metric).
+    per_launch = (n_elig + k1_scans) * KERNEL_BYTES_PER_KEYFRAME + k1_pairs * KERNEL_BYTES_PER_PAIR_IO
     achieved = per_launch / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
-    # the same launch priced per pair (what the CUs pull in, from HBM or from an XCD's L2)
-    delivered = (KERNEL_BYTES_PER_PAIR * k1_pairs) / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
     survey_equiv = (ALGO_BYTES_PER_PAIR * k1_pairs) / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+    single_floor = HBM_PEAK_GBS * 1e9 / SINGLE_SCAN_BYTES_PER_PAIR
 
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_sc_distance.json")
@@ -493,32 +495,28 @@ def main():
                        "sharding": (f"keyframe-index shards x{world}; exchange = {args.exchange} "
                                     f"({'two 8-byte min all-reduces' if args.exchange == 'allreduce' else 'one 24-byte all-gather'} "
                                     f"per scan, batched over {args.native_chunk or args.merge_every} scans, asynchronous)") if world > 1 else "none (one GPU)"},
-            # BASELINE's second figure, "SC-distance GB/s": bytes that crossed HBM by design (the database once per
-            # launch) and, beside it, the bytes the pairs consumed (each pair's rows, from HBM or L2) per second of the whole job
+            # BASELINE's second figure, "SC-distance GB/s": algorithmic bytes of the launch groups (the database once per
+            # launch) per second of the whole job
             "sc_distance_GBps": value * per_launch / max(1.0, k1_pairs) / 1e9,
-            "sc_distance_GBps_consumed_per_pair": value * KERNEL_BYTES_PER_PAIR / 1e9,
             "kernel_ms": {"sc_distance": k1_ms},
             # fastAlignUsingVkey: pairs whose first shift the matrix-core filters left to the exact fp64 evaluation
             "alignment": {"pairs": al_pairs, "exact_fallbacks": al_fallbacks, "fallback_rate": al_fallbacks / max(1, al_pairs)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": f"sc_screen_kernel (one launch = screening products of {k1_scans:.0f} scans x {n_elig} keyframes on the fp16 "
-                                   f"copy + alignment and ring-key metric of the next batch)",
+                         "kernel": f"screening launch group of {k1_scans:.0f} scans x {n_elig} keyframes: sc_screen2_kernel (products: one keyframe "
+                                   f"against the launch's scans per matrix-core tile) + sc_screen2_finish_kernel + sc_align_kernel of the next batch; "
+                                   f"HIP events around the group",
                          "algorithmic_bytes_per_launch": per_launch,
                          "scans_per_launch": k1_scans, "pairs_per_launch": k1_pairs,
-                         "pricing": "SURVEY 8(d), Q scans per database pass: DB bytes once per launch + per-scan bytes + outputs "
-                                    f"({KERNEL_BYTES_PER_PAIR} B per keyframe: fp16 screening copy, fp64 sector key, tiled ring key, mask)",
-                         "note": "with Q scans per launch the kernel is no longer bound by HBM: the database crosses HBM once per launch and "
-                                 "reaches the CUs Q times from the XCDs' L2s -- `delivery` is the binding rate.  One scan per launch "
-                                 "(--scans-per-launch 1) is the HBM-bound form; `single_scan_hbm_floor` is its ceiling",
-                         "delivery": {"achieved": delivered, "peak": L2_RATE_GBS, "unit": "GB/s", "frac": delivered / L2_RATE_GBS,
-                                      "bytes_per_pair": KERNEL_BYTES_PER_PAIR,
-                                      "note": "bytes every pair pulls into its CU / launch time, against the measured rate of rows served "
-                                              "from the XCDs' L2 (MI355X_MICROARCH.md: 16.8-18.8 TB/s chip-wide)"},
-                         "single_scan_hbm_floor": {"pairs_per_s": HBM_PEAK_GBS * 1e9 / KERNEL_BYTES_PER_PAIR,
+                         "pricing": "SURVEY 8(d), Q scans per database pass: DB bytes once per launch + per-scan bytes + per-pair intermediates "
+                                    f"({KERNEL_BYTES_PER_KEYFRAME} B per keyframe: chunk-major fp16 image, fp16 sector key, tiled ring key, mask; "
+                                    f"{KERNEL_BYTES_PER_PAIR_IO} B per pair: first shift, partial sums, bound, ring-key metric)",
+                         "note": "the database crosses HBM once per launch of Q scans; the per-pair operand (the scan rotated by the pair's first "
+                                 "shift) comes out of LDS.  `single_scan_hbm_floor`: what any kernel that streams the database once per scan "
+                                 "could reach at 100 % of the HBM peak",
+                         "single_scan_hbm_floor": {"pairs_per_s": single_floor, "bytes_per_pair": SINGLE_SCAN_BYTES_PER_PAIR,
                                                    "pairs_per_s_survey_bytes": HBM_PEAK_GBS * 1e9 / ALGO_BYTES_PER_PAIR,
-                                                   "value_over_floor": value / world / (HBM_PEAK_GBS * 1e9 / KERNEL_BYTES_PER_PAIR),
-                                                   "note": "what a kernel streaming the database once per scan reaches at 100 % of 8 TB/s"},
+                                                   "value_over_floor": value / world / single_floor},
                          "survey_equivalent": {"bytes_per_pair": ALGO_BYTES_PER_PAIR, "achieved": survey_equiv,
                                                "note": "SURVEY 8(d)'s single-scan price (fp32 descriptor per pair) x pairs / time, for "
                                                        "comparison with round 1's figures; not a rate of moved bytes"}},

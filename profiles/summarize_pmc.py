@@ -1,6 +1,6 @@
 """Condense rocprofv3 --pmc counter_collection CSVs into a small per-kernel summary.
 
-usage: python profiles/summarize_pmc.py <dir with pN/runc/*_counter_collection.csv ...> <out.json> [kernel substring]
+usage: python profiles/summarize_pmc.py <dir with pN/runc/*_counter_collection.csv ...> <out.json> [kernel substring[,kernel substring...]]
 HBM traffic follows MI355X_MICROARCH.md §HBM: FETCH_SIZE (KB) counts 64 B per 128-B request of a wide
 coalesced stream on gfx950 -> doubled; WRITE_SIZE (KB) is exact for 16-B-per-lane stores.  Separate
 passes per counter group, no tracing domains combined with --pmc.
@@ -12,9 +12,7 @@ import json
 import sys
 
 
-def main():
-    root, out = sys.argv[1], sys.argv[2]
-    needle = sys.argv[3] if len(sys.argv) > 3 else "sc_distance"
+def summarize(root, needle):
     agg = collections.defaultdict(list)
     for f in glob.glob(f"{root}/**/*_counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
@@ -28,6 +26,21 @@ def main():
         res["hbm_bytes_per_launch"] = fetch + write
         res["hbm_read_bytes_corrected_x2"] = fetch
         res["hbm_write_bytes"] = write
+    return res
+
+
+def main():
+    root, out = sys.argv[1], sys.argv[2]
+    needles = (sys.argv[3] if len(sys.argv) > 3 else "sc_distance").split(",")
+    if len(needles) == 1:
+        res = summarize(root, needles[0])
+    else:       # a launch group of several kernels (one launch of each per group): per kernel, and the HBM bytes summed
+        parts = [summarize(root, n) for n in needles]
+        res = {"kernel_filter": needles, "kernels": parts}
+        if all("hbm_bytes_per_launch" in p for p in parts):
+            res["hbm_bytes_per_launch"] = sum(p["hbm_bytes_per_launch"] for p in parts)
+            res["hbm_read_bytes_corrected_x2"] = sum(p["hbm_read_bytes_corrected_x2"] for p in parts)
+            res["hbm_write_bytes"] = sum(p["hbm_write_bytes"] for p in parts)
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

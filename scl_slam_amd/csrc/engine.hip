@@ -464,6 +464,8 @@ int scl_create(const scl_config *cfg, scl_engine **out)
             int lo_p = 0, hi_p = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
             if (hipStreamCreateWithPriority(&e->stream_surv, hipStreamNonBlocking, lo_p) != hipSuccess) return bail(SCL_ERR_HIP);
+            if (hipStreamCreateWithPriority(&e->stream_align, hipStreamNonBlocking, lo_p) != hipSuccess) return bail(SCL_ERR_HIP);
+            if (hipEventCreateWithFlags(&e->ev_afork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_ajoin, hipEventDisableTiming) != hipSuccess) return bail(SCL_ERR_HIP);
         }
     }
     if ((rc = dev_alloc(e, &e->a_blk_part, (size_t)1024 * kTailRec))) return bail(rc);
@@ -515,6 +517,9 @@ int scl_destroy(scl_engine *e)
     if (e->h_stream_out) (void)hipHostFree(e->h_stream_out);
     for (auto ev : e->ev_chunk) if (ev) (void)hipEventDestroy(ev);
     if (e->stream_surv) { (void)hipStreamSynchronize(e->stream_surv); (void)hipStreamDestroy(e->stream_surv); }
+    if (e->stream_align) { (void)hipStreamSynchronize(e->stream_align); (void)hipStreamDestroy(e->stream_align); }
+    if (e->ev_afork) (void)hipEventDestroy(e->ev_afork);
+    if (e->ev_ajoin) (void)hipEventDestroy(e->ev_ajoin);
     for (auto ev : e->ev_k1) if (ev) (void)hipEventDestroy(ev);
     if (e->ev_align_gate) (void)hipEventDestroy(e->ev_align_gate);
     dev_free(e->d_topk_scratch); dev_free(e->d_topk_idx); dev_free(e->d_topk_d2); dev_free(e->d_out3);
@@ -864,6 +869,7 @@ int launch_screen_group(scl_engine *e, const ScreenGroup &cur, int phases = kScr
         sb.pair_stride = e->set_stride;
         sb.approx = e->d_approx; sb.starts = e->d_starts; sb.align_fallbacks = e->d_align_fallbacks; sb.ring_d2 = e->d_ring_d2;
         sb.survivors = nullptr; sb.n_surv = nullptr; sb.t_min = e->d_tmin; sb.part = e->d_part;
+        sb.side = stream == e->stream ? e->stream_align : nullptr; sb.ev_fork = e->ev_afork; sb.ev_join = e->ev_ajoin;
         sb.k = e->cfg.num_candidates; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
     };
     ScreenBatch sb{}, nx{};

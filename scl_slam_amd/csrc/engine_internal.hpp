@@ -80,6 +80,9 @@ struct scl_engine {
     hipStream_t stream_surv = nullptr;
     hipEvent_t ev_k1[2] = {nullptr, nullptr};
     hipEvent_t ev_align_gate = nullptr;
+    // second form of the screening products: the next batch's alignment runs as its own kernel on a low-priority stream beside them
+    hipStream_t stream_align = nullptr;
+    hipEvent_t ev_afork = nullptr, ev_ajoin = nullptr;
     bool screen = false;                                   // grid supported and not switched off (SCL_SCREEN=0)
     bool in_single_fallback = false;                       // submit_full_locked <-> submit_full_many_locked recursion guard
     unsigned long long *d_topk_scratch = nullptr; int *d_topk_idx = nullptr; float *d_topk_d2 = nullptr;

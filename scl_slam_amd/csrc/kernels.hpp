@@ -102,6 +102,7 @@ struct ScreenBatch {
     int *starts;                                // first shifts (alignment kernel -> screening kernel), like approx
     unsigned long long *align_fallbacks;        // optional counter: keyframes aligned by the exact evaluation
     int k; float exclude_eps; int *topk_idx; float *topk_d2;
+    hipStream_t side; hipEvent_t ev_fork, ev_join;   // second form: stream and events for the next batch's alignment beside the products (nullptr: in line)
     float *part;                                // scratch of the second form of the 64 x 120 products: nq * pair_stride * 32 floats (nullptr: first form)
 };
 bool sc_screen_supported(const struct DbView &db, int SR);

@@ -69,6 +69,7 @@ struct ScreenBatchArgs {
     unsigned long long pair_stride;
     int S, R4, hstride, rk_cap, align_filter;
     int nq, nb;
+    int skip_d2;              // the alignment role leaves the ring-key metric to sc_screen2_finish_kernel
     ScreenQuery q[kMaxScreenBatch];
 };
 __device__ __forceinline__ ScreenArgs screen_args_of(const ScreenBatchArgs &ab, int qi)
@@ -238,10 +239,9 @@ constexpr int hdesc_rgh(int RG) { return ((RG * 8 + 63) / 64) * 8; }   // 8-byte
 constexpr float kAlign16Margin = 3.0e-3f;      // lead the fp16 stage demands of the best shift (normalised correlation; bound below: 2 x 9.9e-4)
 constexpr int kAlignFp32From = 3;              // ambiguous keyframes in a group from which the fp32 stage runs before the exact evaluation
 
-template <int RG, int S, int W>
+template <int RG, int S, int W, int NWV = kScreenWaves>
 __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const int block, unsigned char *smem_raw)
 {
-    constexpr int NWV = kScreenWaves;
     constexpr int L = S >> 1;
     constexpr int MT = (S + 15) / 16;                  // tiles of 16 shifts
     constexpr int KB = (S + 15) / 16;                  // blocks of 16 sectors (fp32 stage)
@@ -321,7 +321,27 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
     };
 
     const int ngroups = (a.n + kGroup - 1) / kGroup;
-    for (int g = bid * NWV + wave; g < ngroups; g += nbk * NWV) {
+    // The keys of a group (16 keyframes x SK halfs, their norms) are fetched into registers one group ahead: a wave's groups are a
+    // chain of short phases, and the fetch was a whole memory round trip at the head of every one of them.
+    constexpr int NCH = (kGroup * (SK / 8) + kWave - 1) / kWave;                 // 16-byte chunks per lane and group
+    uint4 pre[NCH];
+    float knorm_pre = 0.f;
+    auto fetch = [&](int g) {
+        const int fs = a.slot_base + g * kGroup, lr = a.n - 1 - g * kGroup;
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) {
+            const int f = it * kWave + lane;
+            const int fc = f < kGroup * (SK / 8) ? f : kGroup * (SK / 8) - 1;
+            const int n = fc / (SK / 8), ch = fc - n * (SK / 8);
+            pre[it] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(
+                a.hdesc + (size_t)(fs + (n < lr ? n : lr)) * HS + (size_t)RGH * S) + ch * 16);
+        }
+        knorm_pre = *reinterpret_cast<const float *>(reinterpret_cast<const _Float16 *>(
+            a.hdesc + (size_t)(fs + (m16 < lr ? m16 : lr)) * HS + (size_t)RGH * S) + SK);
+    };
+    const int g_first = bid * NWV + wave;
+    if (g_first < ngroups) fetch(g_first);
+    for (int g = g_first; g < ngroups; g += nbk * NWV) {
         const int c_base = g * kGroup;
         const int first_slot = a.slot_base + c_base;
         const int last_rel = a.n - 1 - c_base;
@@ -334,15 +354,16 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
 #ifdef SCL_DIAGNOSTICS
         if (a.align_filter != 3)
 #endif
-        for (int it = 0; it < (kGroup * (SK / 8) + kWave - 1) / kWave; ++it) {   // 16 keyframes x SK/8 chunks of 16 bytes
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) {                                       // 16 keyframes x SK/8 chunks of 16 bytes
             const int f = it * kWave + lane;
             const int fc = f < kGroup * (SK / 8) ? f : kGroup * (SK / 8) - 1;
             const int n = fc / (SK / 8), ch = fc - n * (SK / 8);
-            const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(
-                a.hdesc + (size_t)(first_slot + (n < last_rel ? n : last_rel)) * HS + (size_t)RGH * S) + ch * 16);
-            *reinterpret_cast<uint4 *>(Bh + n * BSH + 8 * ch) = v;
+            *reinterpret_cast<uint4 *>(Bh + n * BSH + 8 * ch) = pre[it];
         }
+        const float knorm = knorm_pre;
         wave_fence();
+        if (g + nbk * NWV < ngroups) fetch(g + nbk * NWV);                       // in flight under this group's products and decisions
 #ifdef SCL_DIAGNOSTICS
         if (a.align_filter == 2) continue;                                       // probe: the role's key reads alone
 #endif
@@ -371,8 +392,6 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
         // rounding noise is ~1e-13 (|vq|^2 + |vk|^2), a lead of 3e-3 |vq| |vk| stands clear of it for norm ratios up to 1e4;
         // distances of 1e7 and more never win in the reference (D.h:1494), so the norms stay below 4e6; tiny norms stay
         // above 1e-30 (no fp64 underflow).  Anything else is left to the exact evaluation.
-        const float knorm = *reinterpret_cast<const float *>(reinterpret_cast<const _Float16 *>(
-            a.hdesc + (size_t)(first_slot + (m16 < last_rel ? m16 : last_rel)) * HS + (size_t)RGH * S) + SK);
         const bool in_range = qnorm >= 1e-30f && qnorm <= 4.0e6f && knorm >= 1e-30f && knorm <= 4.0e6f &&
                               qnorm <= 1.0e4f * knorm && knorm <= 1.0e4f * qnorm;
         bool uniq = use_filter && in_range && (v1 == v1) && (v2 < v1 - kAlign16Margin);
@@ -444,7 +463,7 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
             if (lane == 0) a.starts[c_base + n] = wrapS(al - SR, S);
         }
         // ---- nanoflann's metric (nanoflann.hpp:383-408): four dimensions per step, fp32, groups accumulated in order ----
-        if (mine) {
+        if (mine && !ab.skip_d2) {
             const int slot = first_slot + lane;
             float result = 0.0f;
 #pragma unroll
@@ -739,6 +758,14 @@ __global__ __launch_bounds__(kScreenWaves * kWave, 2) void sc_align_kernel(Scree
     sc_align_role<RG, S, W>(ab, (int)blockIdx.x, smem_align);
 }
 
+// the same with NWV waves per workgroup: 3 waves need 34 KB of LDS and fit a CU beside the 126 KB of the second form's products
+template <int RG, int S, int W, int NWV>
+__global__ __launch_bounds__(NWV * kWave) void sc_align_kernel_w(ScreenBatchArgs ab)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_align_w[];
+    sc_align_role<RG, S, W, NWV>(ab, (int)blockIdx.x, smem_align_w);
+}
+
 
 // ---- select: survivors of the screening (ascending slot order) + the ring-key top-k ----------------------------
 // One workgroup per query.  survivors[i] = database slots (ascending) whose d~ <= min d~ + 2 eps, or flagged
@@ -997,7 +1024,7 @@ __global__ __launch_bounds__(kS2Waves * kWave, 1) void sc_screen2_kernel(Screen2
 }
 
 // the two ring halves of every pair meet: d~ = min_t (1 - sim[t] / n_eff[t]), flags, the launch's smallest d~ per scan
-template <int S, int W>
+template <int RG, int S, int W>
 __global__ __launch_bounds__(256) void sc_screen2_finish_kernel(Screen2Args fa)
 {
     constexpr int NW64 = (S + 63) / 64, MW = (NW64 + 1) / 2;
@@ -1048,6 +1075,19 @@ __global__ __launch_bounds__(256) void sc_screen2_finish_kernel(Screen2Args fa)
         const bool exact_only = q_bad || kflag != 0 || !(dmin == dmin);
         a.out_approx[ci] = exact_only ? __int_as_float(0xff800000) : dmin;
         contrib = exact_only ? kInf : dmin;
+        // nanoflann's metric (nanoflann.hpp:383-408) for the ring-key top-k: four dimensions per step, fp32, groups accumulated in
+        // order -- the arithmetic of sc_align_role, here with consecutive threads on consecutive slots of the tiled key table
+        const int slot = a.slot_base + ci;
+        float result = 0.0f;
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            const float4 bk = a.rkey4[(size_t)r * a.rk_cap + slot];
+            const float4 qk = *reinterpret_cast<const float4 *>(a.q_rkey + 4 * r);
+            const float d0 = qk.x - bk.x, d1 = qk.y - bk.y, d2 = qk.z - bk.z, d3 = qk.w - bk.w;
+            const float grp = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            result += grp;
+        }
+        a.out_d2[ci] = result;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) contrib = fminf(contrib, __shfl_xor(contrib, off, kWave));
@@ -1129,6 +1169,14 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
         if (cap < 1) cap = 1;
         return b > cap ? cap : b;
     };
+    // second form of the products (64 x 120: the keyframe as the shared operand, the launch's scans as columns): needs the
+    // partial-sum scratch; SCL_SCREEN_FORM=1 keeps the first form.  Its finishing kernel also forms the ring-key metric.
+    bool use_v2 = false;
+    if constexpr (RG == 16 && S == 120) {
+        static const int form = [] { const char *e = getenv("SCL_SCREEN_FORM"); return e ? atoi(e) : 2; }();
+        use_v2 = form != 1 && sb.part && probe == 0 && variant == 0;
+    }
+    ab.skip_d2 = use_v2 ? 1 : 0;
     // the alignment of this batch, on its own (the first launch of a sequence, or a caller that has only one)
     if ((phases & kScreenAlign) && probe != 3) {
         ab.nb = align_blocks(ngroups, sb.nq, false);
@@ -1138,10 +1186,7 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
     }
     if (probe == 4 || !(phases & kScreenProducts)) return hipSuccess;
     if constexpr (RG == 16 && S == 120) {
-        // second form of the products (the keyframe as the shared operand, the launch's scans as columns): needs the partial-sum
-        // scratch; SCL_SCREEN_FORM=1 keeps the first form
-        static const int form = [] { const char *e = getenv("SCL_SCREEN_FORM"); return e ? atoi(e) : 2; }();
-        if (form != 1 && sb.part && probe == 0 && variant == 0) {
+        if (use_v2) {
             static std::atomic<bool> attr2_dev[64];
             std::atomic<bool> &attr2 = attr2_dev[dev_ & 63];
             if (!attr2.load(std::memory_order_acquire)) {
@@ -1160,18 +1205,49 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
             hipLaunchKernelGGL((sc_screen2_kernel<RG, S, W>), dim3(nwg), dim3(kS2Waves * kWave), kS2Lds, stream, f2);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((sc_screen2_finish_kernel<S, W>), dim3((nmax + 255) / 256, sb.nq), dim3(256), 0, stream, f2);
+            hipLaunchKernelGGL((sc_screen2_finish_kernel<RG, S, W>), dim3((nmax + 255) / 256, sb.nq), dim3(256), 0, stream, f2);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
-            if (next) {                                                          // the next batch's alignment, behind this batch's products
+            if (next) {
+                // the next batch's alignment: its own kernel on the low-priority side stream, beside this batch's products (three
+                // waves per workgroup: 34 KB of LDS, one such workgroup fits every CU next to the products' 126 KB); the main
+                // stream goes on when it is done.  Without a side stream: in line, behind the products.
                 if (next->nq < 1 || next->nq > kMaxScreenBatch) return hipErrorInvalidValue;
+                constexpr int NWA = 3;
                 ScreenBatchArgs nb{};
                 const int nmax2 = fill_screen_args(db, *next, align_filter, &nb);
                 if (nmax2 < 0) return hipErrorInvalidValue;
-                nb.nb = align_blocks((nmax2 + kGroup - 1) / kGroup, next->nq, false);
-                hipLaunchKernelGGL((sc_align_kernel<RG, S, W>), dim3(nb.nb * next->nq), dim3(kScreenWaves * kWave), lds0, stream, nb);
+                nb.skip_d2 = 1;
+                const int ng2 = (nmax2 + kGroup - 1) / kGroup;
+                int wgs = (ng2 + NWA - 1) / NWA;
+                const int cap = num_cu / (next->nq > 0 ? next->nq : 1) > 0 ? num_cu / next->nq : 1;   // one workgroup per CU over the batch
+                nb.nb = wgs > cap ? cap : wgs;
+                const size_t lds_a = (size_t)S * 8 + (size_t)(32 * MTA) * 4 + (size_t)2 * (16 * MTA + hkey_halfs(S) + 8) * 2 + (size_t)NWA * ((2 * S + 2) * 8 + kGroup * BST * 4);
+                static const int side_on = [] { const char *e = getenv("SCL_ALIGN_SIDE"); return e ? atoi(e) : 0; }();
+                const bool side = sb.side && side_on;
+                hipStream_t as = side ? sb.side : stream;
+                if (side) {
+                    e = hipEventRecord(sb.ev_fork, stream);
+                    if (e == hipSuccess) e = hipStreamWaitEvent(sb.side, sb.ev_fork, 0);
+                    if (e != hipSuccess) return e;
+                }
+                if (side) hipLaunchKernelGGL((sc_align_kernel_w<RG, S, W, NWA>), dim3(nb.nb * next->nq), dim3(NWA * kWave), lds_a, as, nb);
+                else {
+                    // persistent workgroups: three per CU (their LDS) over the whole batch, every wave walks several groups with the
+                    // next group's keys in flight (one group per wave pays the workgroup's set-up for every 16 keyframes)
+                    int per_q = 3 * num_cu / next->nq;
+                    per_q = per_q < 1 ? 1 : per_q;
+                    nb.nb = (ng2 + kScreenWaves - 1) / kScreenWaves;
+                    nb.nb = nb.nb > per_q ? per_q : nb.nb;
+                    hipLaunchKernelGGL((sc_align_kernel<RG, S, W>), dim3(nb.nb * next->nq), dim3(kScreenWaves * kWave), lds0, stream, nb);
+                }
                 e = hipGetLastError();
                 if (e != hipSuccess) return e;
+                if (side) {
+                    e = hipEventRecord(sb.ev_join, sb.side);
+                    if (e == hipSuccess) e = hipStreamWaitEvent(stream, sb.ev_join, 0);
+                    if (e != hipSuccess) return e;
+                }
             }
             return hipSuccess;
         }
