@@ -245,16 +245,13 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
     constexpr int L = S >> 1;
     constexpr int MT = (S + 15) / 16;                  // tiles of 16 shifts
     constexpr int KB = (S + 15) / 16;                  // blocks of 16 sectors (fp32 stage)
-    constexpr int BST = 16 * KB + 4;                   // floats per keyframe in the fp32 B image (the 4 keep its reads spread over the banks)
     constexpr int QX = 16 * (MT + KB);                 // the query key, repeated
     constexpr int SK = hkey_halfs(S);                  // fp16 stage: K padded to whole steps of 32
     constexpr int KS = SK / 32;                        // ... its k-steps
     constexpr int QH = 16 * MT + SK + 8;               // halfs of the repeated fp16 query key
-    constexpr int BSH = SK + 8;                        // halfs per keyframe in the fp16 B image
     constexpr int RGH = hdesc_rgh(RG);
     constexpr int HS = hdesc_stride(RG, S);                 // a keyframe's slot in hdesc (elements of 8 B)
     static_assert(S % 4 == 0, "sector keys are read in pairs, the B image in fours");
-    static_assert(kGroup * BSH * 2 <= kGroup * BST * 4, "the fp16 B image shares the fp32 image's storage");
     const int SR = (W - 1) / 2;
 
     const int nbk = ab.nb;
@@ -268,10 +265,8 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
     float *qx = reinterpret_cast<float *>(vq + S);                               // [QX]
     _Float16 *qh0 = reinterpret_cast<_Float16 *>(qx + QX);                       // [QH] the unit fp16 query key, repeated; qh1[i] = qh0[i + 1]
     _Float16 *qh1 = qh0 + QH;
-    unsigned char *wbase = reinterpret_cast<unsigned char *>(qh1 + QH) + (size_t)wave * ((2 * S + 2) * 8 + kGroup * BST * 4);
+    unsigned char *wbase = reinterpret_cast<unsigned char *>(qh1 + QH) + (size_t)wave * ((2 * S + 2) * 8);
     double *vk2 = reinterpret_cast<double *>(wbase);                             // [2S + 2] scratch of the exact evaluation
-    float *Bs = reinterpret_cast<float *>(vk2 + 2 * S + 2);                      // [16][BST] fp32 image / [16][BSH] fp16 image
-    _Float16 *Bh = reinterpret_cast<_Float16 *>(Bs);
 
     for (int c = threadIdx.x; c < S; c += blockDim.x) vq[c] = a.q_vkey[c];
     for (int i = threadIdx.x; i < QX; i += blockDim.x) qx[i] = (float)a.q_vkey[i % S];
@@ -323,21 +318,17 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
     const int ngroups = (a.n + kGroup - 1) / kGroup;
     // The keys of a group (16 keyframes x SK halfs, their norms) are fetched into registers one group ahead: a wave's groups are a
     // chain of short phases, and the fetch was a whole memory round trip at the head of every one of them.
-    constexpr int NCH = (kGroup * (SK / 8) + kWave - 1) / kWave;                 // 16-byte chunks per lane and group
-    uint4 pre[NCH];
+    static_assert(kGroup * (SK / 8) == KS * kWave, "one 16-byte chunk per lane and k-step");
+    // ... in the matrix cores' B layout: lane (n, j) = (lane & 15, lane >> 4) holds halfs 32 kk + 8 j .. + 7 of keyframe n's key for
+    // k-step kk -- the fragments go from memory to the MFMAs without a trip through LDS
+    uint4 pre[KS];
     float knorm_pre = 0.f;
     auto fetch = [&](int g) {
         const int fs = a.slot_base + g * kGroup, lr = a.n - 1 - g * kGroup;
+        const unsigned char *kp = reinterpret_cast<const unsigned char *>(a.hdesc + (size_t)(fs + (m16 < lr ? m16 : lr)) * HS + (size_t)RGH * S);
 #pragma unroll
-        for (int it = 0; it < NCH; ++it) {
-            const int f = it * kWave + lane;
-            const int fc = f < kGroup * (SK / 8) ? f : kGroup * (SK / 8) - 1;
-            const int n = fc / (SK / 8), ch = fc - n * (SK / 8);
-            pre[it] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(
-                a.hdesc + (size_t)(fs + (n < lr ? n : lr)) * HS + (size_t)RGH * S) + ch * 16);
-        }
-        knorm_pre = *reinterpret_cast<const float *>(reinterpret_cast<const _Float16 *>(
-            a.hdesc + (size_t)(fs + (m16 < lr ? m16 : lr)) * HS + (size_t)RGH * S) + SK);
+        for (int kk = 0; kk < KS; ++kk) pre[kk] = *reinterpret_cast<const uint4 *>(kp + (4 * kk + k4) * 16);
+        knorm_pre = *reinterpret_cast<const float *>(reinterpret_cast<const _Float16 *>(kp) + SK);
     };
     const int g_first = bid * NWV + wave;
     if (g_first < ngroups) fetch(g_first);
@@ -350,19 +341,10 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
         // Unit vectors rounded to fp16 are off by <= 2^-11 of themselves (+ 2^-25 per subnormal element), their products are
         // exact, the fp32 accumulation of SK terms adds <= SK 2^-24: |c~ - c^| <= 9.9e-4 for every shift, so a shift that leads
         // every other by more than kAlign16Margin = 3e-3 is the arg-max of the exact correlation, i.e. the reference's arg-min.
-        wave_fence();
-#ifdef SCL_DIAGNOSTICS
-        if (a.align_filter != 3)
-#endif
+        h8 bcur[KS];
 #pragma unroll
-        for (int it = 0; it < NCH; ++it) {                                       // 16 keyframes x SK/8 chunks of 16 bytes
-            const int f = it * kWave + lane;
-            const int fc = f < kGroup * (SK / 8) ? f : kGroup * (SK / 8) - 1;
-            const int n = fc / (SK / 8), ch = fc - n * (SK / 8);
-            *reinterpret_cast<uint4 *>(Bh + n * BSH + 8 * ch) = pre[it];
-        }
+        for (int kk = 0; kk < KS; ++kk) bcur[kk] = __builtin_bit_cast(h8, pre[kk]);
         const float knorm = knorm_pre;
-        wave_fence();
         if (g + nbk * NWV < ngroups) fetch(g + nbk * NWV);                       // in flight under this group's products and decisions
 #ifdef SCL_DIAGNOSTICS
         if (a.align_filter == 2) continue;                                       // probe: the role's key reads alone
@@ -375,7 +357,7 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
             for (int t = 0; t < MT; ++t) acc[t] = f4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
-                const h8 bfrag = *reinterpret_cast<const h8 *>(Bh + m16 * BSH + 32 * kk + 8 * k4);
+                const h8 bfrag = bcur[kk];
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
                     const unsigned int *ap = qha + (32 * kk + 16 * t) / 2;
@@ -398,28 +380,20 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
         unsigned long long amb = __builtin_amdgcn_ballot_w64(mine && !uniq);
         // ---- stage 2 (a group with several keyframes the first stage left open): the correlation in fp32 ----
         if (use_filter && __popcll(amb) >= kAlignFp32From) {
-            const double2 *src = reinterpret_cast<const double2 *>(a.vkey + (size_t)first_slot * S);
-            wave_fence();
-#pragma unroll 5
-            for (int it = 0; it < (kGroup * L + kWave - 1) / kWave; ++it) {
-                const int f = it * kWave + lane;
-                const int fc = f < kGroup * L ? f : kGroup * L - 1;              // (the last round of a grid whose keys do not tile the wave)
-                const int n = fc / L, u2 = fc - n * L;
-                const double2 v = src[(size_t)(n < last_rel ? n : last_rel) * L + u2];
-                *reinterpret_cast<f2 *>(Bs + n * BST + 2 * u2) = f2{(float)v.x, (float)v.y};
-            }
-            for (int i = lane; i < kGroup * (BST - S); i += kWave) {             // the K padding of the image
-                const int n = i / (BST - S), u = S + i - n * (BST - S);
-                Bs[n * BST + u] = 0.0f;
-            }
-            wave_fence();
+            // (rare: the keys come straight from the fp64 table, four sectors per lane and block, zero past the last sector)
+            const double *src = a.vkey + (size_t)(first_slot + (m16 < last_rel ? m16 : last_rel)) * S;
             f4v acc[MT];
 #pragma unroll
             for (int t = 0; t < MT; ++t) acc[t] = f4v{0.f, 0.f, 0.f, 0.f};
             float kn2 = 0.f;
 #pragma unroll
             for (int b = 0; b < KB; ++b) {
-                const f4v b4 = *reinterpret_cast<const f4v *>(Bs + m16 * BST + 16 * b + 4 * k4);
+                const int u0 = 16 * b + 4 * k4;
+                f4v b4 = {0.f, 0.f, 0.f, 0.f};
+                if (u0 < S) {                                                    // S % 4 == 0: a block of four is whole or absent
+                    const double2 p0 = *reinterpret_cast<const double2 *>(src + u0), p1 = *reinterpret_cast<const double2 *>(src + u0 + 2);
+                    b4 = f4v{(float)p0.x, (float)p0.y, (float)p1.x, (float)p1.y};
+                }
                 kn2 += (b4[0] * b4[0] + b4[1] * b4[1]) + (b4[2] * b4[2] + b4[3] * b4[3]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -1142,9 +1116,9 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
 #else
     const int probe = 0;
 #endif
-    constexpr int MTA = (S + 15) / 16, BST = 16 * MTA + 4, MT = (W + 15) / 16, QSX = S + 16 * MT, MW = ((S + 63) / 64 + 1) / 2;
+    constexpr int MTA = (S + 15) / 16, MT = (W + 15) / 16, QSX = S + 16 * MT, MW = ((S + 63) / 64 + 1) / 2;
     const size_t lds0 = (size_t)S * 8 + (size_t)(32 * MTA) * 4 + (size_t)2 * (16 * MTA + hkey_halfs(S) + 8) * 2 +
-                        (size_t)kScreenWaves * ((2 * S + 2) * 8 + kGroup * BST * 4);
+                        (size_t)kScreenWaves * ((2 * S + 2) * 8);
     const size_t lds1 = (size_t)QSX * (RGH * 8 + 32) + (size_t)S * MW * 16 + (size_t)kScreenWaves * kGroup * kTileStride +
                         (size_t)(2 * kScreenWaves * MT) * kWave * 16;
     if (!attr_set.load(std::memory_order_acquire)) {
@@ -1222,7 +1196,7 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
                 int wgs = (ng2 + NWA - 1) / NWA;
                 const int cap = num_cu / (next->nq > 0 ? next->nq : 1) > 0 ? num_cu / next->nq : 1;   // one workgroup per CU over the batch
                 nb.nb = wgs > cap ? cap : wgs;
-                const size_t lds_a = (size_t)S * 8 + (size_t)(32 * MTA) * 4 + (size_t)2 * (16 * MTA + hkey_halfs(S) + 8) * 2 + (size_t)NWA * ((2 * S + 2) * 8 + kGroup * BST * 4);
+                const size_t lds_a = (size_t)S * 8 + (size_t)(32 * MTA) * 4 + (size_t)2 * (16 * MTA + hkey_halfs(S) + 8) * 2 + (size_t)NWA * ((2 * S + 2) * 8);
                 static const int side_on = [] { const char *e = getenv("SCL_ALIGN_SIDE"); return e ? atoi(e) : 0; }();
                 const bool side = sb.side && side_on;
                 hipStream_t as = side ? sb.side : stream;
@@ -1235,7 +1209,7 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
                 else {
                     // persistent workgroups: three per CU (their LDS) over the whole batch, every wave walks several groups with the
                     // next group's keys in flight (one group per wave pays the workgroup's set-up for every 16 keyframes)
-                    int per_q = 3 * num_cu / next->nq;
+                    int per_q = 3 * num_cu / next->nq;                              // (167 registers: three waves per SIMD; 128 spill and double the time)
                     per_q = per_q < 1 ? 1 : per_q;
                     nb.nb = (ng2 + kScreenWaves - 1) / kScreenWaves;
                     nb.nb = nb.nb > per_q ? per_q : nb.nb;
