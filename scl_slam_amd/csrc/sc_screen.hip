@@ -732,14 +732,6 @@ __global__ __launch_bounds__(kScreenWaves * kWave, 2) void sc_align_kernel(Scree
     sc_align_role<RG, S, W>(ab, (int)blockIdx.x, smem_align);
 }
 
-// the same with NWV waves per workgroup: 3 waves need 34 KB of LDS and fit a CU beside the 126 KB of the second form's products
-template <int RG, int S, int W, int NWV>
-__global__ __launch_bounds__(NWV * kWave) void sc_align_kernel_w(ScreenBatchArgs ab)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_align_w[];
-    sc_align_role<RG, S, W, NWV>(ab, (int)blockIdx.x, smem_align_w);
-}
-
 
 // ---- select: survivors of the screening (ascending slot order) + the ring-key top-k ----------------------------
 // One workgroup per query.  survivors[i] = database slots (ascending) whose d~ <= min d~ + 2 eps, or flagged
@@ -1176,53 +1168,44 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
             int nwg = (num_cu / 16) * 16;
             if (nwg < 16) nwg = 16;
             f2.nwg = nwg;
-            hipLaunchKernelGGL((sc_screen2_kernel<RG, S, W>), dim3(nwg), dim3(kS2Waves * kWave), kS2Lds, stream, f2);
-            hipError_t e = hipGetLastError();
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((sc_screen2_finish_kernel<RG, S, W>), dim3((nmax + 255) / 256, sb.nq), dim3(256), 0, stream, f2);
-            e = hipGetLastError();
-            if (e != hipSuccess) return e;
-            if (next) {
-                // the next batch's alignment: its own kernel on the low-priority side stream, beside this batch's products (three
-                // waves per workgroup: 34 KB of LDS, one such workgroup fits every CU next to the products' 126 KB); the main
-                // stream goes on when it is done.  Without a side stream: in line, behind the products.
+            // SCL_ALIGN_SIDE: where the next batch's alignment runs -- 0 (default): in line on the main stream, behind the finishing
+            // kernel; 1: on the low-priority side stream from the end of this batch's products, beside the finishing kernel; 2: from
+            // the start of the products.  Measured: 1.45 G pairs/s in line, 0.51 G (1) and 0.67 G (2) -- the two event hops between
+            // the queues per launch cost more than the alignment itself.
+            static const int side_env = [] { const char *e = getenv("SCL_ALIGN_SIDE"); return e ? atoi(e) : 0; }();
+            const int side = (next && sb.side) ? side_env : 0;
+            hipError_t e = hipSuccess;
+            auto launch_align = [&](hipStream_t as) -> hipError_t {
                 if (next->nq < 1 || next->nq > kMaxScreenBatch) return hipErrorInvalidValue;
-                constexpr int NWA = 3;
                 ScreenBatchArgs nb{};
                 const int nmax2 = fill_screen_args(db, *next, align_filter, &nb);
                 if (nmax2 < 0) return hipErrorInvalidValue;
                 nb.skip_d2 = 1;
                 const int ng2 = (nmax2 + kGroup - 1) / kGroup;
-                int wgs = (ng2 + NWA - 1) / NWA;
-                const int cap = num_cu / (next->nq > 0 ? next->nq : 1) > 0 ? num_cu / next->nq : 1;   // one workgroup per CU over the batch
-                nb.nb = wgs > cap ? cap : wgs;
-                const size_t lds_a = (size_t)S * 8 + (size_t)(32 * MTA) * 4 + (size_t)2 * (16 * MTA + hkey_halfs(S) + 8) * 2 + (size_t)NWA * ((2 * S + 2) * 8);
-                static const int side_on = [] { const char *e = getenv("SCL_ALIGN_SIDE"); return e ? atoi(e) : 0; }();
-                const bool side = sb.side && side_on;
-                hipStream_t as = side ? sb.side : stream;
-                if (side) {
-                    e = hipEventRecord(sb.ev_fork, stream);
-                    if (e == hipSuccess) e = hipStreamWaitEvent(sb.side, sb.ev_fork, 0);
-                    if (e != hipSuccess) return e;
-                }
-                if (side) hipLaunchKernelGGL((sc_align_kernel_w<RG, S, W, NWA>), dim3(nb.nb * next->nq), dim3(NWA * kWave), lds_a, as, nb);
-                else {
-                    // persistent workgroups: three per CU (their LDS) over the whole batch, every wave walks several groups with the
-                    // next group's keys in flight (one group per wave pays the workgroup's set-up for every 16 keyframes)
-                    int per_q = 3 * num_cu / next->nq;                              // (167 registers: three waves per SIMD; 128 spill and double the time)
-                    per_q = per_q < 1 ? 1 : per_q;
-                    nb.nb = (ng2 + kScreenWaves - 1) / kScreenWaves;
-                    nb.nb = nb.nb > per_q ? per_q : nb.nb;
-                    hipLaunchKernelGGL((sc_align_kernel<RG, S, W>), dim3(nb.nb * next->nq), dim3(kScreenWaves * kWave), lds0, stream, nb);
-                }
-                e = hipGetLastError();
-                if (e != hipSuccess) return e;
-                if (side) {
-                    e = hipEventRecord(sb.ev_join, sb.side);
-                    if (e == hipSuccess) e = hipStreamWaitEvent(stream, sb.ev_join, 0);
-                    if (e != hipSuccess) return e;
-                }
-            }
+                // persistent workgroups: three per CU (167 registers: three waves per SIMD; 128 spill and double the time) over the
+                // whole batch, every wave walks several groups with the next group's keys in flight
+                int per_q = 3 * num_cu / next->nq;
+                per_q = per_q < 1 ? 1 : per_q;
+                nb.nb = (ng2 + kScreenWaves - 1) / kScreenWaves;
+                nb.nb = nb.nb > per_q ? per_q : nb.nb;
+                hipLaunchKernelGGL((sc_align_kernel<RG, S, W>), dim3(nb.nb * next->nq), dim3(kScreenWaves * kWave), lds0, as, nb);
+                return hipGetLastError();
+            };
+            auto fork = [&]() -> hipError_t {
+                hipError_t r = hipEventRecord(sb.ev_fork, stream);
+                if (r == hipSuccess) r = hipStreamWaitEvent(sb.side, sb.ev_fork, 0);
+                if (r == hipSuccess) r = launch_align(sb.side);
+                if (r == hipSuccess) r = hipEventRecord(sb.ev_join, sb.side);
+                return r;
+            };
+            if (side == 2 && (e = fork()) != hipSuccess) return e;
+            hipLaunchKernelGGL((sc_screen2_kernel<RG, S, W>), dim3(nwg), dim3(kS2Waves * kWave), kS2Lds, stream, f2);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            if (side == 1 && (e = fork()) != hipSuccess) return e;
+            hipLaunchKernelGGL((sc_screen2_finish_kernel<RG, S, W>), dim3((nmax + 255) / 256, sb.nq), dim3(256), 0, stream, f2);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            if (next && side == 0 && (e = launch_align(stream)) != hipSuccess) return e;
+            if (side != 0 && (e = hipStreamWaitEvent(stream, sb.ev_join, 0)) != hipSuccess) return e;
             return hipSuccess;
         }
     }
