@@ -1368,7 +1368,13 @@ int scl_screen_distances(scl_engine *e, int query, int lo, int hi, float *approx
     if (n <= 0) return SCL_OK;
     int rc;
     if ((rc = ensure_pairs(e, (size_t)n))) return rc;
+    if ((size_t)n * 32 > e->part_cap) {                    // scratch of the products' second form: 32 floats per pair
+        dev_free(e->d_part); e->part_cap = 0;
+        if ((rc = dev_alloc(e, &e->d_part, (size_t)n * 32 + 1024))) return rc;
+        e->part_cap = (size_t)n * 32 + 1024;
+    }
     ScreenBatch sb{};
+    sb.part = e->d_part;
     sb.nq = 1; sb.slot[0] = qslot; sb.base[0] = lo; sb.n[0] = n; sb.pair_stride = (size_t)n;
     sb.approx = e->d_approx; sb.starts = e->d_starts; sb.align_fallbacks = e->d_align_fallbacks; sb.ring_d2 = e->d_ring_d2; sb.survivors = e->d_surv; sb.n_surv = e->d_nsurv; sb.t_min = e->d_tmin;
     sb.k = e->cfg.num_candidates; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;

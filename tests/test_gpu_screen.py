@@ -194,3 +194,14 @@ def test_random_ranges_against_the_checker(R, S, n):
         assert (nn[i], sh[i]) == (lo + b, s_ref[b]) and dd[i].view(np.uint64) == d_ref[b].view(np.uint64), (q, lo, hi, nn[i], lo + b)
         assert one[0] == lo + b and one[1] == s_ref[b] and np.float64(one[2]).view(np.uint64) == d_ref[b].view(np.uint64)
     eng.close()
+
+
+def test_first_form_of_the_products_still_meets_the_bound():
+    """SCL_SCREEN_FORM is read once per process: the same bound / survivor / winner checks with the 64x120 products in their
+    first form (keyframe rows per pair; the default is the second form) in a child interpreter"""
+    import os, subprocess, sys
+    env = dict(os.environ, SCL_SCREEN_FORM="1")
+    here = os.path.abspath(__file__)
+    out = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-m", "gpu", "-x", "-k",
+                          "bench_database or adversarial or random_ranges"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
