@@ -36,6 +36,8 @@ constexpr int hdesc_stride(int RG, int S) { return hdesc_stride_rgh(hdesc_sector
 //                                desc.  Behind it the sector key as a unit vector in fp16 (vkey / |vkey|, zero padded to a multiple of 32; all zero when the
 //                                norm is zero or not finite) and its norm as a float: the first stage of the alignment filter.  hstride = S * RGH + hkey_store_halfs(S) / 4
 //                                elements of 8 B.
+//   hkey   half   [cap][hkey_store_halfs(S)]  the fp16 sector key and its norm as stored behind hdesc's copy, in a table of its own: the alignment reads
+//                                nothing else of a keyframe, and 272 B at a stride of 33 KB cost it a DRAM page and a TLB entry per keyframe
 //   kmask  u32    [cap][8]       bit c of words 0..6 = column c has a non-zero norm; word 7 bit 0 = some column norm is outside [2^-60, 2^60] or non-finite (such keyframes are always scored exactly)
 struct DbView {
     const float4 *desc;
@@ -43,6 +45,7 @@ struct DbView {
     const double *norm;
     const uint2  *hdesc;
     const unsigned int *kmask;
+    const unsigned short *hkey;   // [cap][hkey_store_halfs(S)] the unit fp16 sector keys + norms once more, DENSE (272 B per keyframe at S = 120): what the alignment reads
     int hstride;
     const float  *rkey;
     const float4 *rkey4;
@@ -174,7 +177,7 @@ hipError_t launch_ringkey_topk(const DbView &db, const float *qkey, int lo, int 
 // ingest: row-major wire descriptors (device) -> DB slots first_slot.. (all derived data)
 hipError_t launch_ingest(const float *values, int count, int first_slot,
                          float4 *desc, double *vkey, double *norm, float *rkey, float4 *rkey4,
-                         uint2 *hdesc, unsigned int *kmask, int hstride,
+                         uint2 *hdesc, unsigned int *kmask, unsigned short *hkey, int hstride,
                          int cap, int R, int S, hipStream_t stream);
 // tiled -> row-major wire format (read back)
 hipError_t launch_untile(const float4 *desc_slot, int R, int S, float *values, hipStream_t stream);

@@ -82,7 +82,7 @@ __global__ void make_sc_finalize_kernel(const int *gtile, int cells, float *valu
 // One workgroup per descriptor.  values: [count][R*S] row-major floats.
 __global__ __launch_bounds__(256) void ingest_kernel(
     const float *values, int first_slot, float4 *desc, double *vkey, double *norm,
-    float *rkey, float4 *rkey4, uint2 *hdesc, unsigned int *kmask, int hstride, int cap, int R, int S)
+    float *rkey, float4 *rkey4, uint2 *hdesc, unsigned int *kmask, unsigned short *hkey, int hstride, int cap, int R, int S)
 {
     extern __shared__ float sv[];                 // [R][S+1], then the S reciprocal norms
     const int LS = S + 1;                         // odd-ish stride: column walks hit distinct banks
@@ -179,9 +179,15 @@ __global__ __launch_bounds__(256) void ingest_kernel(
         for (int c = 0; c < S; ++c) n2 = n2 + svk[c] * svk[c];            // every thread the same sequential sum
         const double nrm = sqrt(n2);
         const bool usable = nrm > 0.0 && nrm < 1.0e300;                   // zero, NaN, inf: all zero -> every shift ties -> exact evaluation
-        for (int c = threadIdx.x; c < SK; c += blockDim.x)
-            hk[c] = (c < S && usable) ? (_Float16)(float)(svk[c] / nrm) : (_Float16)0.0f;
-        if (threadIdx.x == 0) *reinterpret_cast<float *>(hk + SK) = usable ? (float)nrm : -1.0f;   // the filter's range check (negative: no decision)
+        _Float16 *hd = reinterpret_cast<_Float16 *>(hkey + (size_t)slot * hkey_store_halfs(S));   // the dense table of the same keys
+        for (int c = threadIdx.x; c < SK; c += blockDim.x) {
+            const _Float16 v = (c < S && usable) ? (_Float16)(float)(svk[c] / nrm) : (_Float16)0.0f;
+            hk[c] = v; hd[c] = v;
+        }
+        if (threadIdx.x == 0) {
+            *reinterpret_cast<float *>(hk + SK) = usable ? (float)nrm : -1.0f;   // the filter's range check (negative: no decision)
+            *reinterpret_cast<float *>(hd + SK) = usable ? (float)nrm : -1.0f;
+        }
     }
     if (threadIdx.x < 8) {
         unsigned int w = 0;
@@ -232,7 +238,7 @@ hipError_t launch_make_sc(const void *points, int n, int stride_bytes, int R, in
 
 hipError_t launch_ingest(const float *values, int count, int first_slot,
                          float4 *desc, double *vkey, double *norm, float *rkey, float4 *rkey4,
-                         uint2 *hdesc, unsigned int *kmask, int hstride,
+                         uint2 *hdesc, unsigned int *kmask, unsigned short *hkey, int hstride,
                          int cap, int R, int S, hipStream_t stream)
 {
     if (count <= 0) return hipSuccess;
@@ -248,7 +254,7 @@ hipError_t launch_ingest(const float *values, int count, int first_slot,
         attr_set.store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(ingest_kernel, dim3(count), dim3(256), lds, stream,
-                       values, first_slot, desc, vkey, norm, rkey, rkey4, hdesc, kmask, hstride, cap, R, S);
+                       values, first_slot, desc, vkey, norm, rkey, rkey4, hdesc, kmask, hkey, hstride, cap, R, S);
     return hipGetLastError();
 }
 

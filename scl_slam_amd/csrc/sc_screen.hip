@@ -50,6 +50,7 @@ struct ScreenArgs {
     const uint2 *hdesc; const unsigned int *kmask;
     const double *q_vkey; const float *q_rkey;
     const uint2 *q_hdesc; const unsigned int *q_kmask;
+    const _Float16 *hkey; const _Float16 *q_hkey; int hkw;   // dense fp16 sector keys (+ norm), hkw halfs per slot
     const float4 *rkey4; int rk_cap;
     int slot_base, n;
     int *starts;              // [n] first shifts: written by sc_align_kernel, read by sc_screen_kernel
@@ -64,10 +65,10 @@ struct ScreenArgs {
 // launch takes two batches).  A role rebuilds its query's ScreenArgs from it (wave-uniform: scalar registers).
 struct ScreenQuery { int slot, base, n, buf; };
 struct ScreenBatchArgs {
-    const double *vkey; const float *rkey; const uint2 *hdesc; const unsigned int *kmask; const float4 *rkey4;
+    const double *vkey; const float *rkey; const uint2 *hdesc; const unsigned int *kmask; const float4 *rkey4; const unsigned short *hkey;
     int *starts; float *approx; float *ring_d2; unsigned int *t_min; unsigned long long *fallbacks;
     unsigned long long pair_stride;
-    int S, R4, hstride, rk_cap, align_filter;
+    int S, R4, hstride, rk_cap, align_filter, hkw;
     int nq, nb;
     int skip_d2;              // the alignment role leaves the ring-key metric to sc_screen2_finish_kernel
     ScreenQuery q[kMaxScreenBatch];
@@ -80,6 +81,7 @@ __device__ __forceinline__ ScreenArgs screen_args_of(const ScreenBatchArgs &ab, 
     a.vkey = ab.vkey; a.hdesc = ab.hdesc; a.kmask = ab.kmask;
     a.q_vkey = ab.vkey + slot * ab.S; a.q_rkey = ab.rkey + slot * ab.R4;
     a.q_hdesc = ab.hdesc + slot * ab.hstride; a.q_kmask = ab.kmask + slot * 8;
+    a.hkey = reinterpret_cast<const _Float16 *>(ab.hkey); a.q_hkey = a.hkey + slot * (size_t)ab.hkw; a.hkw = ab.hkw;
     a.rkey4 = ab.rkey4; a.rk_cap = ab.rk_cap;
     a.slot_base = sq.base; a.n = sq.n;
     a.starts = ab.starts + off; a.fallbacks = ab.fallbacks;
@@ -249,8 +251,6 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
     constexpr int SK = hkey_halfs(S);                  // fp16 stage: K padded to whole steps of 32
     constexpr int KS = SK / 32;                        // ... its k-steps
     constexpr int QH = 16 * MT + SK + 8;               // halfs of the repeated fp16 query key
-    constexpr int RGH = hdesc_rgh(RG);
-    constexpr int HS = hdesc_stride(RG, S);                 // a keyframe's slot in hdesc (elements of 8 B)
     static_assert(S % 4 == 0, "sector keys are read in pairs, the B image in fours");
     const int SR = (W - 1) / 2;
 
@@ -271,7 +271,7 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
     for (int c = threadIdx.x; c < S; c += blockDim.x) vq[c] = a.q_vkey[c];
     for (int i = threadIdx.x; i < QX; i += blockDim.x) qx[i] = (float)a.q_vkey[i % S];
     {
-        const _Float16 *qk = reinterpret_cast<const _Float16 *>(a.q_hdesc + (size_t)RGH * S);
+        const _Float16 *qk = a.q_hkey;
         for (int i = threadIdx.x; i < QH; i += blockDim.x) { qh0[i] = qk[i % S]; qh1[i] = qk[(i + 1) % S]; }
     }
     __syncthreads();
@@ -287,7 +287,7 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
     qn2 = wave_sum_f32_dpp(qn2);
     const bool use_filter = a.align_filter != 0;
     const float kNegInf = __int_as_float(0xff800000);
-    const float qnorm = *reinterpret_cast<const float *>(reinterpret_cast<const _Float16 *>(a.q_hdesc + (size_t)RGH * S) + SK);
+    const float qnorm = *reinterpret_cast<const float *>(a.q_hkey + SK);
 
     // per keyframe (column n = lane & 15): the largest and the second largest value over all shifts, and the largest's shift
     auto top2 = [&](const f4v (&acc)[MT], float &v1, float &v2, int &a1) {
@@ -325,7 +325,7 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
     float knorm_pre = 0.f;
     auto fetch = [&](int g) {
         const int fs = a.slot_base + g * kGroup, lr = a.n - 1 - g * kGroup;
-        const unsigned char *kp = reinterpret_cast<const unsigned char *>(a.hdesc + (size_t)(fs + (m16 < lr ? m16 : lr)) * HS + (size_t)RGH * S);
+        const unsigned char *kp = reinterpret_cast<const unsigned char *>(a.hkey + (size_t)(fs + (m16 < lr ? m16 : lr)) * (size_t)a.hkw);   // the dense key table
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) pre[kk] = *reinterpret_cast<const uint4 *>(kp + (4 * kk + k4) * 16);
         knorm_pre = *reinterpret_cast<const float *>(reinterpret_cast<const _Float16 *>(kp) + SK);
@@ -368,7 +368,31 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag, acc[t], 0, 0, 0);
                 }
             }
-            top2(acc, v1, v2, a1);
+            // the largest value, how many values come within the margin of it, and where it sits: "the second largest is more
+            // than the margin below the largest" <=> exactly one value is >= largest - margin.  Unlike a running (largest, second
+            // largest) pair these are reductions without a serial dependence through the 32 values a lane holds.
+            float mx = kNegInf;
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { if (16 * t + 4 * 3 + i < S || 16 * t + i < S) mx = fmaxf(mx, (16 * t + 4 * k4 + i) < S ? acc[t][i] : kNegInf); }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, kWave));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+            const float thr = mx - kAlign16Margin;
+            int cnt = 0, arg = 0;
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int sft = 16 * t + 4 * k4 + i;
+                    const float c = sft < S ? acc[t][i] : kNegInf;
+                    cnt += (c >= thr) ? 1 : 0;
+                    arg = max(arg, (c == mx) ? sft : 0);
+                }
+            cnt += __shfl_xor(cnt, 16, kWave); cnt += __shfl_xor(cnt, 32, kWave);
+            arg = max(arg, __shfl_xor(arg, 16, kWave)); arg = max(arg, __shfl_xor(arg, 32, kWave));
+            v1 = mx; a1 = arg;
+            v2 = cnt == 1 ? kNegInf : mx;                                        // (only "v2 < v1 - margin" is asked below)
         }
         // The exact arg-max of the correlation is the reference's arg-min only while its fp64 distances resolve the lead: their
         // rounding noise is ~1e-13 (|vq|^2 + |vk|^2), a lead of 3e-3 |vq| |vk| stands clear of it for norm ratios up to 1e4;
@@ -1068,7 +1092,7 @@ __global__ __launch_bounds__(256) void sc_screen2_finish_kernel(Screen2Args fa)
 // argument block of one batch; returns the largest range or -1
 static int fill_screen_args(const DbView &db, const ScreenBatch &sb, int align_filter, ScreenBatchArgs *ab)
 {
-    ab->vkey = db.vkey; ab->rkey = db.rkey; ab->hdesc = db.hdesc; ab->kmask = db.kmask; ab->rkey4 = db.rkey4;
+    ab->vkey = db.vkey; ab->rkey = db.rkey; ab->hdesc = db.hdesc; ab->kmask = db.kmask; ab->rkey4 = db.rkey4; ab->hkey = db.hkey; ab->hkw = hkey_store_halfs(db.S);
     ab->starts = sb.starts; ab->approx = sb.approx; ab->ring_d2 = sb.ring_d2; ab->t_min = sb.t_min; ab->fallbacks = sb.align_fallbacks;
     ab->pair_stride = (unsigned long long)sb.pair_stride;
     ab->S = db.S; ab->R4 = 4 * db.RG; ab->hstride = db.hstride; ab->rk_cap = db.cap; ab->align_filter = align_filter;
@@ -1184,7 +1208,7 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
                 const int ng2 = (nmax2 + kGroup - 1) / kGroup;
                 // persistent workgroups: three per CU (167 registers: three waves per SIMD; 128 spill and double the time) over the
                 // whole batch, every wave walks several groups with the next group's keys in flight
-                int per_q = 3 * num_cu / next->nq;
+                int per_q = 3 * num_cu / next->nq;                                   // (two to nine per CU measure the same 29 us)
                 per_q = per_q < 1 ? 1 : per_q;
                 nb.nb = (ng2 + kScreenWaves - 1) / kScreenWaves;
                 nb.nb = nb.nb > per_q ? per_q : nb.nb;
