@@ -285,25 +285,26 @@ def secondary_80x180(device, n=10000, steps=512):
     prof = eng.profile()
     eng.close()
     survey_pair = R2 * S2 * 4 + S2 * 4 + S2 * 4                                 # 59 040 B at 80x180
-    # what the launch reads by design: the fp16 copy (96 rings per sector: 80 padded to whole 64-byte steps), the fp64 sector
-    # key, the tiled ring key, the sector mask
-    bytes_pair = 96 * S2 * 2 + S2 * 8 + 4 * 4 * ((R2 + 3) // 4) + 32
+    # what the launch group (products in their second form + finish + next alignment) reads per keyframe by design, once per
+    # launch of 12 scans: the chunk-major fp16 image (3 ring thirds x 4 chunks x (S + 16) sectors x 16 B), the fp16 sector key + norm,
+    # the tiled ring key, the sector mask; per pair: first shift, the three thirds' two-pass partial sums (written and read), bound,
+    # ring-key metric
+    bytes_kf = 3 * 4 * (S2 + 16) * 16 + (2 * 192 + 16) + 4 * 4 * ((R2 + 3) // 4) + 32
+    bytes_pair_io = 4 + 2 * 4 + 2 * (3 * 2 * 16 * 4) + 4 + 4
     k_ms = prof["sc_distance_ms"] / max(1, prof["sc_distance_launches"])
     k_pairs = prof["sc_distance_pairs"] / max(1, prof["sc_distance_launches"])
     k_scans = k_pairs / n_elig
-    per_launch = n_elig * bytes_pair + k_scans * bytes_pair + k_pairs * 12.0      # DB once per launch + per-scan bytes + outputs
+    per_launch = (n_elig + k_scans) * bytes_kf + k_pairs * bytes_pair_io        # DB once per launch + per-scan bytes + per-pair intermediates
     ach = per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    deliv = bytes_pair * k_pairs / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     return {"workload": f"{n} synthetic keyframes, 80x180 SC (BASELINE configs[4]'s grid), full ring-key + shifted SC distance (19 shifts) "
                         f"over the whole DB per scan, {steps} scans",
             "value": n_elig * steps / dt, "unit": "pairs/s", "ms_per_scan": dt / steps * 1e3,
             "kernel_ms": {"screening_launch_group": k_ms},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": per_launch, "scans_per_launch": k_scans,
-                         "bytes_per_keyframe": bytes_pair, "survey_bytes_per_pair": survey_pair,
-                         "delivery": {"achieved": deliv, "peak": L2_RATE_GBS, "unit": "GB/s", "frac": deliv / L2_RATE_GBS},
-                         "kernel": "sc_screen_kernel<20,180,19> (screening products of a launch group's scans on the fp16 copy + alignment of "
-                                   "the next group; one launch in seven sampled)"}}
+                         "bytes_per_keyframe": bytes_kf, "bytes_per_pair_intermediates": bytes_pair_io, "survey_bytes_per_pair": survey_pair,
+                         "kernel": "screening launch group of the 80x180 grid: sc_screen2_kernel<20,180,19> (three ring thirds, 19 shifts in two "
+                                   "passes, 12 scans per launch) + finish + alignment of the next group; one group in seven sampled"}}
 
 
 # ------------------------------------------------------------------------------------------------

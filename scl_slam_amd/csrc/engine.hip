@@ -230,7 +230,7 @@ int ensure_sets(scl_engine *e, size_t n)
     int rc = ensure_pairs(e, stride * scl_engine::kScreenSets);
     if (rc) { e->set_stride = 0; return rc; }
     e->set_stride = stride;
-    const size_t need = stride * (size_t)kMaxScreenBatch * 32;          // floats: two ring halves x 16 shifts per pair of a launch
+    const size_t need = stride * sc_screen_scratch_floats(db_view(e), e->SR);   // floats: ring parts x passes x 16 shifts per pair of a launch
     if (need > e->part_cap) {
         dev_free(e->d_part); e->part_cap = 0;
         if ((rc = dev_alloc(e, &e->d_part, need))) { e->set_stride = 0; return rc; }
@@ -1297,7 +1297,8 @@ int scl_detect_full_stream(scl_engine *e, const int *queries, const int *lo, con
     if (e->screen && (sc_distance_fuses_ring(db_view(e), e->SR) || sc_screen_is_wide(db_view(e), e->SR))) {
         // the screened grids take up to kMaxScreenBatch scans per launch: the workgroups of a launch's queries share every
         // keyframe line through the L2 (sc_screen.hip), so more scans per launch read less per scan from HBM
-        const int spl_s = scans_per_launch < 1 ? 1 : (scans_per_launch > kMaxScreenBatch ? kMaxScreenBatch : scans_per_launch);
+        const int mb = sc_screen_max_batch(db_view(e), e->SR);
+        const int spl_s = scans_per_launch < 1 ? 1 : (scans_per_launch > mb ? mb : scans_per_launch);
         return stream_screened_locked(e, queries, lo, hi, n_queries, spl_s, nn_idx, shift, dist);
     }
     const int spl = scans_per_launch < 1 ? 1 : (scans_per_launch > kMaxQueryBatch ? kMaxQueryBatch : scans_per_launch);
@@ -1372,10 +1373,13 @@ int scl_screen_distances(scl_engine *e, int query, int lo, int hi, float *approx
     if (n <= 0) return SCL_OK;
     int rc;
     if ((rc = ensure_pairs(e, (size_t)n))) return rc;
-    if ((size_t)n * 32 > e->part_cap) {                    // scratch of the products' second form: 32 floats per pair
-        dev_free(e->d_part); e->part_cap = 0;
-        if ((rc = dev_alloc(e, &e->d_part, (size_t)n * 32 + 1024))) return rc;
-        e->part_cap = (size_t)n * 32 + 1024;
+    {   // scratch of the products' second form: ring parts x passes x 16 floats per pair
+        const size_t per_pair = sc_screen_scratch_floats(db_view(e), e->SR) / (size_t)sc_screen_max_batch(db_view(e), e->SR);
+        if ((size_t)n * per_pair > e->part_cap) {
+            dev_free(e->d_part); e->part_cap = 0;
+            if ((rc = dev_alloc(e, &e->d_part, (size_t)n * per_pair + 1024))) return rc;
+            e->part_cap = (size_t)n * per_pair + 1024;
+        }
     }
     ScreenBatch sb{};
     sb.part = e->d_part;

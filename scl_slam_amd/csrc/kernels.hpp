@@ -10,12 +10,12 @@ constexpr double kBigDist = 10000000.0;   // D.h:1494,1556,1637,1705 initial min
 constexpr int hdesc_sector(int RG) { return ((RG * 8 + 63) / 64) * 8; }   // 8-byte elements per sector of hdesc: ring groups padded to whole 64-byte k-steps
 constexpr int hkey_halfs(int S) { return ((S + 31) / 32) * 32; }         // the unit-norm fp16 sector key behind the copy, zero padded to whole k-steps
 constexpr int hkey_store_halfs(int S) { return hkey_halfs(S) + 8; }      // ... followed by the key's norm as a float (and 12 spare bytes)
-// Grids with 64 rings carry a second image of the copy behind the key, for the second form of the screening products
-// (sc_screen.hip): chunk-major -- [ring half h][16-byte chunk j][sector 0 .. S+15] x 16 B (rings 32h + 8j .. + 7 of sector s mod S), so
+// A second image of the copy sits behind the key, for the second form of the screening products (sc_screen.hip):
+// chunk-major -- [ring part h of 32 rings][16-byte chunk j][sector 0 .. S+15] x 16 B (rings 32h + 8j .. + 7 of sector s mod S), so
 // that the 16 consecutive sectors a matrix-core fragment needs per chunk are 256 consecutive bytes; offsets in 8-byte elements,
 // 128-byte aligned
 constexpr int hdesc2_offset_rgh(int RGH, int S) { return ((RGH * S + hkey_store_halfs(S) / 4 + 15) / 16) * 16; }
-constexpr int hdesc2_elems_rgh(int RGH, int S) { return RGH == 16 ? 2 * 8 * (S + 16) : 0; }
+constexpr int hdesc2_elems_rgh(int RGH, int S) { return RGH % 8 == 0 ? (RGH / 8) * 8 * (S + 16) : 0; }   // (RGH / 8 ring parts of 32) x 4 chunks x (S + 16) sectors x 16 B
 constexpr int hdesc_stride_rgh(int RGH, int S) { return hdesc2_elems_rgh(RGH, S) ? ((hdesc2_offset_rgh(RGH, S) + hdesc2_elems_rgh(RGH, S) + 15) / 16) * 16
                                                                                  : RGH * S + hkey_store_halfs(S) / 4; }
 constexpr int hdesc2_offset(int RG, int S) { return hdesc2_offset_rgh(hdesc_sector(RG), S); }
@@ -111,6 +111,8 @@ struct ScreenBatch {
 bool sc_screen_supported(const struct DbView &db, int SR);
 bool sc_screen_is_wide(const struct DbView &db, int SR);      // 80 x 180: screening by sc_screen_wide_kernel, exact pass by the one-sector-per-lane kernel
 float sc_screen_eps();
+int sc_screen_max_batch(const struct DbView &db, int SR);            // scans per screening launch on this grid (16; 12 on 80 x 180)
+size_t sc_screen_scratch_floats(const struct DbView &db, int SR);   // partial-sum scratch of the second form per keyframe of a buffer set
 // phases: 1 = the alignment kernel (first shifts + ring-key metric into sb.starts / sb.ring_d2), 2 = the screening products
 // (which read sb.starts), 3 = both, one after the other on `stream`.  next (optional): the batch that follows; its
 // alignment rides in the launch of this batch's products (further workgroups of the same grid: one is matrix-core bound,

@@ -154,11 +154,12 @@ __global__ __launch_bounds__(256) void ingest_kernel(
         }
         hslot[i] = hv;
     }
-    // the chunk-major image of the same values (64-ring grids): [half][chunk][sector 0 .. S+15], 8 rings = 16 B per entry
+    // the chunk-major image of the same values: [ring part][chunk][sector 0 .. S+15], 8 rings = 16 B per entry
     if (hdesc2_elems(RG, S)) {
         typedef _Float16 h8v __attribute__((ext_vector_type(8)));
         h8v *h2 = reinterpret_cast<h8v *>(hdesc + (size_t)slot * hstride + (size_t)hdesc2_offset(RG, S));
-        for (int i = threadIdx.x; i < 8 * (S + 16); i += blockDim.x) {
+        const int n2 = hdesc2_elems(RG, S) / 2;                                 // entries of 16 B: ring parts x 4 chunks x (S + 16) sectors
+        for (int i = threadIdx.x; i < n2; i += blockDim.x) {
             const int hj = i / (S + 16), sx = i - hj * (S + 16);
             const int c = sx < S ? sx : sx - S;
             const float iv = siv[c];

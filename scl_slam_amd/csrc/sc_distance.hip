@@ -108,6 +108,9 @@ __device__ __forceinline__ void sc_distance_body(const ScArgs &a, double *smem)
     double *redv = simbuf + W * S;            // [4]
     int *redi = (int *)(redv + 4);            // [4] + [4]: the agreed alignment shift
 
+    // a survivor list shorter than the grid (the usual case: one to five survivors, 16 workgroups per query): the workgroups
+    // without a candidate leave before they stage 126 KB of query
+    if (a.n_dev && (int)blockIdx.x * a.G >= *a.n_dev) return;
     // ---- stage the query once per (persistent) workgroup ----------------------
     for (int idx = threadIdx.x; idx < RG * S; idx += blockDim.x) {
         const int rg = idx / S, c = idx - rg * S;

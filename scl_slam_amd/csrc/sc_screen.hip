@@ -880,23 +880,31 @@ hipError_t launch_sc_select_batch(const ScreenBatch &sb, hipStream_t stream)
 // first form (1 924 x 2^-23 for 8 partial sums).
 // One wave per keyframe; the waves of a launch take keyframes gw, gw + W, ... of the union of the scans' ranges.
 // LDS image of the scans: four scans share a 256-byte row per sector -- row (p, s) = sector s of scans 4p .. 4p+3, 64 B each --
-// so a lane's address is p * kS2Quad + 256 s + 64 (q & 3) + 16 j and its 16-byte slot in the 256-byte bank row does not
+// so a lane's address is p * QUAD + 256 s + 64 (q & 3) + 16 j and its 16-byte slot in the 256-byte bank row does not
 // depend on the sector: whatever the 16 first shifts are, the 16 lanes of every ds_read_b128 group (MI355X_MICROARCH.md,
 // LDS: {0-3, 12-15, 20-27}, ...: all 16 scans, eight with chunk j and eight with j + 1) hit 16 different slots when
-// kS2Quad / 16 = 2 mod 4.  (Scan-major rows of 64 B put the eight same-chunk lanes of a group on two slots: 4-way conflicts,
+// QUAD / 16 = 2 mod 4.  (Scan-major rows of 64 B put the eight same-chunk lanes of a group on two slots: 4-way conflicts,
 // 99 us per launch instead of ...)
-constexpr int kS2Rows = 123;                       // sectors per scan in LDS (120 + 3: the four reads of an iteration never wrap)
-constexpr int kS2Quad = kS2Rows * 256 + 32;        // bytes per quad of scans (the 32 make the stride 2 mod 4 slots)
+// Shapes of the second form.  64 x 120: two ring halves, 13 shifts in one pass, four k-steps per fragment load (13 + 3 rows),
+// 16 scans per launch.  80 x 180 (96 padded rings, 19 shifts): three ring thirds, the shifts in two passes of 13 and 6 rows that
+// share the keyframe's fragment (pass p reads the scan 13 p sectors further back), three k-steps per load, 12 scans per launch
+// (12 x 182 sectors x 64 B = 140 KB of LDS).
+template <int RG, int S, int W> struct S2Cfg;
+template <> struct S2Cfg<16, 120, 13> { static constexpr int NP = 2, NPASS = 1, STEPS = 4, NQ = 16; };
+template <> struct S2Cfg<20, 180, 19> { static constexpr int NP = 3, NPASS = 2, STEPS = 3, NQ = 12; };
+constexpr int kS2PassRows = 13;                    // shift rows per pass: row m of pass p = shift W - 1 - 13 p - m
 constexpr int kS2Waves = 8;                        // waves per workgroup of the second form (one workgroup per CU: LDS)
-constexpr int kS2DA = 9;                           // A loads in flight per wave (iterations of four k-steps); the ring has one slot more
-constexpr size_t kS2Lds = (size_t)(kMaxScreenBatch / 4) * kS2Quad;
-static_assert((kS2Quad / 16) % 4 == 2, "bank slots of the four quads");
+constexpr int kS2DA = 9;                           // A loads in flight per wave (iterations of STEPS k-steps); the ring has one slot more
+// LDS image of the scans (see above): quad stride in bytes, 2 mod 4 sixteen-byte slots
+constexpr int s2_quad(int S, int STEPS) { return (((S + STEPS - 1) * 256 / 16) % 4 == 2) ? (S + STEPS - 1) * 256 : (S + STEPS - 1) * 256 + 32; }
+template <int RG, int S, int W> constexpr size_t s2_lds() { return (size_t)(S2Cfg<RG, S, W>::NQ / 4) * s2_quad(S, S2Cfg<RG, S, W>::STEPS); }
+template <int RG, int S, int W> constexpr int s2_part_floats() { return S2Cfg<RG, S, W>::NP * S2Cfg<RG, S, W>::NPASS * 16; }   // partial sums per pair
 
 struct Screen2Args {
     ScreenBatchArgs prod;
-    float *part;                                   // [nq][pair_stride][2 halves][16] partial sums (scratch of one launch)
+    float *part;                                   // [nq][pair_stride][ring parts][passes][16] partial sums (scratch of one launch)
     int u_lo, u_n;                                 // union of the scans' ranges (database slots)
-    int nwg;                                       // workgroups of the products (a multiple of 16)
+    int nwg;                                       // workgroups of the products (a multiple of 8 x ring parts)
 };
 
 __device__ __forceinline__ unsigned int ror1_u32(unsigned int v)
@@ -908,79 +916,98 @@ __device__ __forceinline__ u32x4 ror1_frag(const u32x4 v) { return u32x4{ror1_u3
 template <int RG, int S, int W>
 __global__ __launch_bounds__(kS2Waves * kWave, 1) void sc_screen2_kernel(Screen2Args fa)
 {
+    using C = S2Cfg<RG, S, W>;
+    constexpr int NP = C::NP, NPASS = C::NPASS, STEPS = C::STEPS, NQ = C::NQ;
     constexpr int RGH = hdesc_rgh(RG);
     constexpr int SB = RGH * 8;                        // bytes of one sector in hdesc (all rings, fp16)
     constexpr int HS = hdesc_stride(RG, S);
-    constexpr int NIT = S / 4;                         // iterations (of four k-steps) per keyframe
-    static_assert(SB == 128 && S % 4 == 0 && W <= 13, "second form: 64 rings, 13 shifts");
+    constexpr int NIT = S / STEPS;                     // iterations (of STEPS k-steps) per keyframe
+    constexpr int ROWS = S + STEPS - 1;                // sectors per scan in LDS: the reads of an iteration never wrap
+    constexpr int QUAD = s2_quad(S, STEPS);
+    static_assert(SB == 64 * NP && S % STEPS == 0 && kS2PassRows + STEPS - 1 <= 16 && W <= NPASS * kS2PassRows && NQ % 4 == 0 && NQ <= kMaxScreenBatch, "second form");
+    static_assert((QUAD / 16) % 4 == 2, "bank slots of the quads");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
     const ScreenBatchArgs &ab = fa.prod;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // workgroup -> (XCD, ring half, index): the two halves of index i sit next to each other on one XCD
+    // workgroup -> (XCD, ring part, index): the parts of index i sit next to each other on one XCD
     const int b = (int)blockIdx.x, xcd = b & 7, jx = b >> 3;
-    const int half = jx & 1;
-    const int gi = (jx >> 1) * 8 + xcd;                // 0 .. nwg / 2 - 1
-    const int waves_half = (fa.nwg >> 1) * kS2Waves;
+    const int part = jx % NP;
+    const int gi = (jx / NP) * 8 + xcd;                // 0 .. nwg / NP - 1
+    const int waves_part = (fa.nwg / NP) * kS2Waves;
     const int gw = gi * kS2Waves + wave;
 
-    // ---- stage the scans' ring half (sectors 120 .. 122 repeat 0 .. 2) ----
-    for (int idx = threadIdx.x; idx < kMaxScreenBatch * kS2Rows * 4; idx += blockDim.x) {
-        const int q = idx / (kS2Rows * 4), rem = idx - q * (kS2Rows * 4);
+    // ---- stage the scans' ring part (the last STEPS - 1 sectors repeat the first) ----
+    for (int idx = threadIdx.x; idx < NQ * ROWS * 4; idx += blockDim.x) {
+        const int q = idx / (ROWS * 4), rem = idx - q * (ROWS * 4);
         const int sx = rem >> 2, ch = rem & 3;
         const int sct = sx < S ? sx : sx - S;
-        const unsigned char *src = reinterpret_cast<const unsigned char *>(ab.hdesc + (size_t)ab.q[q].slot * HS) + (size_t)sct * SB + half * 64 + ch * 16;
-        *reinterpret_cast<uint4 *>(smem2 + (size_t)(q >> 2) * kS2Quad + sx * 256 + (q & 3) * 64 + ch * 16) = *reinterpret_cast<const uint4 *>(src);
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(ab.hdesc + (size_t)ab.q[q].slot * HS) + (size_t)sct * SB + part * 64 + ch * 16;
+        *reinterpret_cast<uint4 *>(smem2 + (size_t)(q >> 2) * QUAD + sx * 256 + (q & 3) * 64 + ch * 16) = *reinterpret_cast<const uint4 *>(src);
     }
     __syncthreads();
     if (gw >= fa.u_n) return;
 
     const int c16 = lane & 15, j4 = lane >> 4;         // A: row m = c16; B / output: scan q = c16
-    const ScreenQuery sq = ab.q[c16];                  // (entries past nq copy entry 0: valid memory, never stored)
+    const int cq = c16 < NQ ? c16 : c16 - 4;           // (columns past the launch's scans shadow a live column: same address, no bank conflict)
+    const ScreenQuery sq = ab.q[cq];                   // (entries past nq copy entry 0: valid memory, never stored)
     const int *starts_q = ab.starts + (size_t)sq.buf * (size_t)ab.pair_stride;
-    const bool q_live = c16 < ab.nq;
+    const bool q_live = c16 < ab.nq && c16 < NQ;
     // A side: row m of the fragment of step y is sector y + m of the chunk-major image (no wrap: 16 sectors repeat at its end)
-    const unsigned int a_lane = (unsigned int)(hdesc2_offset(RG, S) * 8 + ((half * 4 + j4) * (S + 16) + c16) * 16);
+    const unsigned int a_lane = (unsigned int)(hdesc2_offset(RG, S) * 8 + ((part * 4 + j4) * (S + 16) + c16) * 16);
     const unsigned char *hd = reinterpret_cast<const unsigned char *>(ab.hdesc);
     auto kf_base = [&](int k) -> const unsigned char * {
-        int idx = gw + k * waves_half;
+        int idx = gw + k * waves_part;
         idx = idx < fa.u_n ? idx : fa.u_n - 1;
         return hd + (size_t)(fa.u_lo + idx) * (size_t)(HS * 8);
     };
     auto first_shift = [&](int k) -> int {             // scan q's first shift for the wave's k-th keyframe (0 where it has none)
-        int idx = gw + k * waves_half;
+        int idx = gw + k * waves_part;
         idx = idx < fa.u_n ? idx : fa.u_n - 1;
         const int ci = fa.u_lo + idx - sq.base;
         const bool ok = ci >= 0 && ci < sq.n;
         return starts_q[ok ? ci : 0];
     };
-    const int nk = (fa.u_n - gw + waves_half - 1) / waves_half;
+    const int nk = (fa.u_n - gw + waves_part - 1) / waves_part;
     constexpr int RS = kS2DA + 1;                      // ring slots: iteration i consumes slot i % RS and refills slot (i - 1) % RS,
     static_assert(NIT % RS == 0 && RS % 2 == 0, "");   // whose value died an iteration ago -- no register copies
     u32x4 ringA[RS];
     const unsigned char *base_cur = kf_base(0), *base_nxt = kf_base(1);
-    const unsigned char *pA = base_cur;                // wave-uniform: the keyframe's base + 64 B per iteration issued
+    const unsigned char *pA = base_cur;                // wave-uniform: the keyframe's base + 16 STEPS bytes per iteration issued
     auto issueA = [&](int sl) {
         ringA[sl] = *reinterpret_cast<const u32x4 *>(pA + a_lane);
-        pA += 64;
+        pA += 16 * STEPS;
     };
 #pragma unroll
     for (int sl = 0; sl < kS2DA; ++sl) issueA(sl);
     int b_cur = first_shift(0), b_nxt = first_shift(1);
-    const unsigned int q_lds = (unsigned int)((c16 >> 2) * kS2Quad + (c16 & 3) * 64 + j4 * 16);
+    const unsigned int q_lds = (unsigned int)((cq >> 2) * QUAD + (cq & 3) * 64 + j4 * 16);
     for (int k = 0; k < nk; ++k) {
-        const int c0 = b_cur + (W - 1) >= S ? b_cur + (W - 1) - S : b_cur + (W - 1);
-        unsigned int offB = q_lds + (unsigned int)c0 * 256u;                     // scan sector that meets keyframe sector 0: first shift + 12
-        auto readB = [&](h8 (&dst)[4]) {
-            const unsigned char *qp = smem2 + offB;
+        // scan sector that meets keyframe sector 0 in pass p: first shift + W - 1 - 13 p
+        unsigned int offB[NPASS];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) dst[u] = *reinterpret_cast<const h8 *>(qp + 256 * u);
-            offB += 4u * 256u;
-            const unsigned int t = offB - (unsigned int)(S * 256);
-            offB = (int)t >= (int)q_lds ? t : offB;
+        for (int p = 0; p < NPASS; ++p) {
+            int c0 = b_cur + (W - 1) - kS2PassRows * p;
+            c0 = c0 >= S ? c0 - S : c0;
+            offB[p] = q_lds + (unsigned int)c0 * 256u;
+        }
+        auto readB = [&](h8 (&dst)[NPASS][STEPS]) {
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) {
+                const unsigned char *qp = smem2 + offB[p];
+#pragma unroll
+                for (int u = 0; u < STEPS; ++u) dst[p][u] = *reinterpret_cast<const h8 *>(qp + 256 * u);
+                offB[p] += (unsigned int)STEPS * 256u;
+                const unsigned int t = offB[p] - (unsigned int)(S * 256);
+                offB[p] = (int)t >= (int)q_lds ? t : offB[p];
+            }
         };
-        f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-        h8 bfr[2][4];
+        f4v acc[NPASS][STEPS];
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+            for (int u = 0; u < STEPS; ++u) acc[p][u] = f4v{0.f, 0.f, 0.f, 0.f};
+        h8 bfr[2][NPASS][STEPS];
         readB(bfr[0]);
 #pragma unroll 1
         for (int r = 0; r < NIT / RS; ++r) {
@@ -990,39 +1017,47 @@ __global__ __launch_bounds__(kS2Waves * kWave, 1) void sc_screen2_kernel(Screen2
                 if (xb == RS - kS2DA) pA = (r == NIT / RS - 1) ? base_nxt : pA;
                 issueA((xb + RS - 1) % RS);
                 readB(bfr[(xb + 1) & 1]);                                        // the next iteration's B fragments (past the end: unused)
-                const u32x4 a0 = ringA[xb];
-                const u32x4 a1 = ror1_frag(a0), a2 = ror1_frag(a1), a3 = ror1_frag(a2);
-                const h8 (&bc)[4] = bfr[xb & 1];
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a0), bc[0], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a1), bc[1], acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a2), bc[2], acc2, 0, 0, 0);
-                acc3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a3), bc[3], acc3, 0, 0, 0);
+                u32x4 af[STEPS];
+                af[0] = ringA[xb];
+#pragma unroll
+                for (int u = 1; u < STEPS; ++u) af[u] = ror1_frag(af[u - 1]);
+#pragma unroll
+                for (int u = 0; u < STEPS; ++u)
+#pragma unroll
+                    for (int p = 0; p < NPASS; ++p)
+                        acc[p][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, af[u]), bfr[xb & 1][p][u], acc[p][u], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // ---- this keyframe's 16 x 16 tile: lane (q, j) holds shifts 4j .. 4j+3 of scan q ----
-        const f4v sum = (acc0 + acc1) + (acc2 + acc3);
+        // ---- this keyframe's 16 x 16 tiles: lane (q, j) holds rows 4j .. 4j+3 of scan q ----
         {
-            const int idx = gw + k * waves_half;
+            const int idx = gw + k * waves_part;
             const int ci = fa.u_lo + idx - sq.base;
-            if (q_live && ci >= 0 && ci < sq.n)
-                *reinterpret_cast<f4v *>(fa.part + (((size_t)c16 * (size_t)ab.pair_stride + (size_t)ci) * 2 + half) * 16 + 4 * j4) = sum;
+            const bool ok = q_live && ci >= 0 && ci < sq.n;
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) {
+                f4v sum = acc[p][0];
+#pragma unroll
+                for (int u = 1; u < STEPS; ++u) sum += acc[p][u];
+                if (ok) *reinterpret_cast<f4v *>(fa.part + ((((size_t)c16 * (size_t)ab.pair_stride + (size_t)ci) * NP + part) * NPASS + p) * 16 + 4 * j4) = sum;
+            }
         }
         base_cur = base_nxt; base_nxt = kf_base(k + 2);
         b_cur = b_nxt; b_nxt = first_shift(k + 2);
     }
 }
 
-// the two ring halves of every pair meet: d~ = min_t (1 - sim[t] / n_eff[t]), flags, the launch's smallest d~ per scan
+// the ring parts of every pair meet: d~ = min_t (1 - sim[t] / n_eff[t]), flags, the launch's smallest d~ per scan
 template <int RG, int S, int W>
 __global__ __launch_bounds__(256) void sc_screen2_finish_kernel(Screen2Args fa)
 {
+    using C = S2Cfg<RG, S, W>;
+    constexpr int NP = C::NP, NPASS = C::NPASS;
     constexpr int NW64 = (S + 63) / 64, MW = (NW64 + 1) / 2;
-    static_assert(MW == 1, "sector masks of up to 128 bits");
     const ScreenBatchArgs &ab = fa.prod;
     const int qi = (int)blockIdx.y;
     const ScreenArgs a = screen_args_of(ab, qi);
-    __shared__ uint4 rotq[S];
+    __shared__ uint4 rotq[S * MW];
     __shared__ float wmin[4];
     {
         unsigned long long qm[NW64];
@@ -1031,8 +1066,11 @@ __global__ __launch_bounds__(256) void sc_screen2_finish_kernel(Screen2Args fa)
         for (int sft = threadIdx.x; sft < S; sft += blockDim.x) {
             unsigned long long rr[NW64];
             rotate_mask<S>(qm, sft, rr);
-            const unsigned long long lo = rr[0], hi = NW64 > 1 ? rr[1] : 0ull;
-            rotq[sft] = make_uint4((unsigned int)lo, (unsigned int)(lo >> 32), (unsigned int)hi, (unsigned int)(hi >> 32));
+#pragma unroll
+            for (int i = 0; i < MW; ++i) {
+                const unsigned long long lo = rr[2 * i], hi = 2 * i + 1 < NW64 ? rr[2 * i + 1] : 0ull;
+                rotq[sft * MW + i] = make_uint4((unsigned int)lo, (unsigned int)(lo >> 32), (unsigned int)hi, (unsigned int)(hi >> 32));
+            }
         }
     }
     const bool q_bad = a.q_kmask[7] != 0;
@@ -1042,24 +1080,36 @@ __global__ __launch_bounds__(256) void sc_screen2_finish_kernel(Screen2Args fa)
     float contrib = kInf;
     if (ci < a.n) {
         const unsigned int *kp = a.kmask + (size_t)(a.slot_base + ci) * 8;
-        const uint4 km = *reinterpret_cast<const uint4 *>(kp);
+        uint4 km[MW];
+#pragma unroll
+        for (int i = 0; i < MW; ++i) km[i] = *reinterpret_cast<const uint4 *>(kp + 4 * i);
         const unsigned int kflag = kp[7];
+        if (MW == 2) km[MW - 1].w = 0u;                                          // word 7 is the flag, not sector bits
         const int b0 = a.starts[ci];
-        const f4v *pp = reinterpret_cast<const f4v *>(fa.part + ((size_t)qi * (size_t)ab.pair_stride + (size_t)ci) * 32);
+        const f4v *pp = reinterpret_cast<const f4v *>(fa.part + ((size_t)qi * (size_t)ab.pair_stride + (size_t)ci) * (NP * NPASS * 16));
         float dmin = kInf;
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const f4v s0 = pp[g4], s1 = pp[4 + g4];
+        for (int p = 0; p < NPASS; ++p) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = 4 * g4 + r;                                        // row m of the tile = shift W - 1 - m
-                if (m >= W) continue;
-                const int t = W - 1 - m;
-                int ri = b0 + t; ri = ri >= S ? ri - S : ri;
-                const uint4 rq = rotq[ri];
-                const int ne = __popc(rq.x & km.x) + __popc(rq.y & km.y) + __popc(rq.z & km.z) + __popc(rq.w & km.w);   // (km.w: the flag word is 0 when it counts)
-                const float d = 1.0f - (s0[r] + s1[r]) / (float)ne;
-                if (ne > 0 && d < dmin) dmin = d;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f4v sm = pp[p * 4 + g4];                                         // part 0
+#pragma unroll
+                for (int h = 1; h < NP; ++h) sm += pp[(h * NPASS + p) * 4 + g4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 4 * g4 + r;                                    // row m of pass p = shift W - 1 - 13 p - m
+                    const int t = W - 1 - kS2PassRows * p - m;
+                    if (m >= kS2PassRows || t < 0) continue;
+                    int ri = b0 + t; ri = ri >= S ? ri - S : ri;
+                    int ne = 0;
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) {
+                        const uint4 rq = rotq[ri * MW + i];
+                        ne += __popc(rq.x & km[i].x) + __popc(rq.y & km[i].y) + __popc(rq.z & km[i].z) + __popc(rq.w & km[i].w);
+                    }
+                    const float d = 1.0f - sm[r] / (float)ne;
+                    if (ne > 0 && d < dmin) dmin = d;
+                }
             }
         }
         const bool exact_only = q_bad || kflag != 0 || !(dmin == dmin);
@@ -1087,6 +1137,20 @@ __global__ __launch_bounds__(256) void sc_screen2_finish_kernel(Screen2Args fa)
         const float m = fminf(fminf(wmin[0], wmin[1]), fminf(wmin[2], wmin[3]));
         if (m < kInf) atomicMin(a.t_min, float_to_ordered_u(m));
     }
+}
+
+static bool screen_second_form()
+{   // SCL_SCREEN_FORM=1 keeps the products' first form (keyframe rows per pair through the L2, alignment riding in the launch)
+    static const int form = [] { const char *e = getenv("SCL_SCREEN_FORM"); return e ? atoi(e) : 2; }();
+    return form != 1;
+}
+int sc_screen_max_batch(const DbView &db, int SR)
+{
+    return (sc_screen_is_wide(db, SR) && screen_second_form()) ? S2Cfg<20, 180, 19>::NQ : kMaxScreenBatch;
+}
+size_t sc_screen_scratch_floats(const DbView &db, int SR)
+{
+    return sc_screen_is_wide(db, SR) ? (size_t)S2Cfg<20, 180, 19>::NQ * s2_part_floats<20, 180, 19>() : (size_t)S2Cfg<16, 120, 13>::NQ * s2_part_floats<16, 120, 13>();
 }
 
 // argument block of one batch; returns the largest range or -1
@@ -1161,11 +1225,8 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
     };
     // second form of the products (64 x 120: the keyframe as the shared operand, the launch's scans as columns): needs the
     // partial-sum scratch; SCL_SCREEN_FORM=1 keeps the first form.  Its finishing kernel also forms the ring-key metric.
-    bool use_v2 = false;
-    if constexpr (RG == 16 && S == 120) {
-        static const int form = [] { const char *e = getenv("SCL_SCREEN_FORM"); return e ? atoi(e) : 2; }();
-        use_v2 = form != 1 && sb.part && probe == 0 && variant == 0;
-    }
+    const bool use_v2 = screen_second_form() && sb.part && probe == 0 && variant == 0 && sb.nq <= S2Cfg<RG, S, W>::NQ &&
+                        (!next || next->nq <= S2Cfg<RG, S, W>::NQ);
     ab.skip_d2 = use_v2 ? 1 : 0;
     // the alignment of this batch, on its own (the first launch of a sequence, or a caller that has only one)
     if ((phases & kScreenAlign) && probe != 3) {
@@ -1175,12 +1236,12 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
         if (e != hipSuccess) return e;
     }
     if (probe == 4 || !(phases & kScreenProducts)) return hipSuccess;
-    if constexpr (RG == 16 && S == 120) {
+    {
         if (use_v2) {
             static std::atomic<bool> attr2_dev[64];
             std::atomic<bool> &attr2 = attr2_dev[dev_ & 63];
             if (!attr2.load(std::memory_order_acquire)) {
-                hipError_t e = hipFuncSetAttribute((const void *)sc_screen2_kernel<RG, S, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kS2Lds);
+                hipError_t e = hipFuncSetAttribute((const void *)sc_screen2_kernel<RG, S, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(s2_lds<RG, S, W>()));
                 if (e != hipSuccess) return e;
                 attr2.store(true, std::memory_order_release);
             }
@@ -1189,8 +1250,9 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
             int lo = sb.base[0], hi = sb.base[0] + sb.n[0];
             for (int i = 1; i < sb.nq; ++i) { lo = sb.base[i] < lo ? sb.base[i] : lo; hi = sb.base[i] + sb.n[i] > hi ? sb.base[i] + sb.n[i] : hi; }
             f2.u_lo = lo; f2.u_n = hi - lo;
-            int nwg = (num_cu / 16) * 16;
-            if (nwg < 16) nwg = 16;
+            constexpr int WGU = 8 * S2Cfg<RG, S, W>::NP;                           // the ring parts of an index on one XCD
+            int nwg = (num_cu / WGU) * WGU;
+            if (nwg < WGU) nwg = WGU;
             f2.nwg = nwg;
             // SCL_ALIGN_SIDE: where the next batch's alignment runs -- 0 (default): in line on the main stream, behind the finishing
             // kernel; 1: on the low-priority side stream from the end of this batch's products, beside the finishing kernel; 2: from
@@ -1223,7 +1285,8 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
                 return r;
             };
             if (side == 2 && (e = fork()) != hipSuccess) return e;
-            hipLaunchKernelGGL((sc_screen2_kernel<RG, S, W>), dim3(nwg), dim3(kS2Waves * kWave), kS2Lds, stream, f2);
+            constexpr size_t lds2 = s2_lds<RG, S, W>();
+            hipLaunchKernelGGL((sc_screen2_kernel<RG, S, W>), dim3(nwg), dim3(kS2Waves * kWave), lds2, stream, f2);
             if ((e = hipGetLastError()) != hipSuccess) return e;
             if (side == 1 && (e = fork()) != hipSuccess) return e;
             hipLaunchKernelGGL((sc_screen2_finish_kernel<RG, S, W>), dim3((nmax + 255) / 256, sb.nq), dim3(256), 0, stream, f2);
