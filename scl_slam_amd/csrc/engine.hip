@@ -923,8 +923,8 @@ int launch_survivor_pass(scl_engine *e, const int *qslot, const int *lo, const i
 int launch_survivor_pass_wide(scl_engine *e, const int *qslot, const int *lo, const int *n, int nq, int set0, double *const *out3, hipStream_t stream)
 {
     ProfScope ps(e, P_ARGMIN, stream);
-    for (int g = 0; g < nq; g += kMaxQueryBatch) {
-        const int w = nq - g < kMaxQueryBatch ? nq - g : kMaxQueryBatch;
+    for (int g = 0; g < nq; g += kWideExactBatch) {
+        const int w = nq - g < kWideExactBatch ? nq - g : kWideExactBatch;
         ScreenBatch sb{};
         sb.nq = w;
         for (int j = 0; j < w; ++j) { sb.slot[j] = qslot[g + j]; sb.base[j] = lo[g + j]; sb.n[j] = n[g + j]; sb.buf[j] = set0 + g + j; }
@@ -933,7 +933,7 @@ int launch_survivor_pass_wide(scl_engine *e, const int *qslot, const int *lo, co
         sb.survivors = e->d_surv; sb.n_surv = e->d_nsurv; sb.t_min = e->d_tmin;
         sb.k = e->cfg.num_candidates; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
         SCL_HIP(e, launch_sc_select_batch(sb, stream));
-        const int *sv[kMaxQueryBatch]; const int *ns[kMaxQueryBatch]; double *od[kMaxQueryBatch]; int *os[kMaxQueryBatch];
+        const int *sv[kWideExactBatch]; const int *ns[kWideExactBatch]; double *od[kWideExactBatch]; int *os[kWideExactBatch];
         for (int j = 0; j < w; ++j) {
             const size_t set = (size_t)(set0 + g + j);
             sv[j] = e->d_surv + set * e->set_stride; ns[j] = e->d_nsurv + set;

@@ -239,8 +239,9 @@ __global__ __launch_bounds__(MAXT) void sc_distance_kernel(ScArgs a)
     sc_distance_body<RG, W, MAXT>(a, smem);
 }
 
-// the same program for the survivor lists of up to four queries in one launch: blockIdx.y = query
-struct ScArgsBatch { ScArgs q[kMaxQueryBatch]; };
+// the same program for the survivor lists of up to kWideExactBatch queries in one launch: blockIdx.y = query
+struct ScArgsBatch { ScArgs q[kWideExactBatch]; };
+static_assert(sizeof(ScArgsBatch) <= 4096, "kernel arguments end at 4 KB");
 template <int RG, int W, int MAXT>
 __global__ __launch_bounds__(MAXT) void sc_distance_batch4_kernel(ScArgsBatch ab)
 {
@@ -1245,8 +1246,8 @@ __global__ void argmin_kernel(const double *dist, const int *shift, int n, doubl
 
 // arg-min over the exact distances of the survivor lists of up to four queries (counts on the device); out3[1] = the
 // winner's slot relative to slot_base (ties -> lowest position = lowest slot: the lists are ascending)
-struct ArgminBatch { const double *dist[kMaxQueryBatch]; const int *shift[kMaxQueryBatch]; const int *n_dev[kMaxQueryBatch];
-                     const int *cand[kMaxQueryBatch]; int slot_base[kMaxQueryBatch]; double *out3[kMaxQueryBatch]; };
+struct ArgminBatch { const double *dist[kWideExactBatch]; const int *shift[kWideExactBatch]; const int *n_dev[kWideExactBatch];
+                     const int *cand[kWideExactBatch]; int slot_base[kWideExactBatch]; double *out3[kWideExactBatch]; };
 __global__ __launch_bounds__(1024) void argmin_survivors_batch_kernel(ArgminBatch b)
 {
     const int q = blockIdx.x;
@@ -1472,11 +1473,11 @@ hipError_t launch_sc_distance_survivors_wide(const DbView &db, int nq, const int
                                              const int *const *survivors, const int *const *n_surv, double *const *out_dist, int *const *out_shift,
                                              double *const *out3, int num_cu, hipStream_t stream)
 {
-    if (!(db.RG == 20 && db.S == 180 && SR == 9) || nq < 1 || nq > kMaxQueryBatch) return hipErrorInvalidValue;
+    if (!(db.RG == 20 && db.S == 180 && SR == 9) || nq < 1 || nq > kWideExactBatch) return hipErrorInvalidValue;
     constexpr int RG = 20, W = 19, MAXT = 256;
     ScArgsBatch ab{};
     ArgminBatch mb{};
-    for (int i = 0; i < kMaxQueryBatch; ++i) {
+    for (int i = 0; i < kWideExactBatch; ++i) {
         const int j = i < nq ? i : 0;
         ScArgs &a = ab.q[i];
         const size_t slot = (size_t)query_slot[j];

@@ -766,7 +766,7 @@ struct SelectArgs {
     unsigned int *t_min; int *survivors; int *n_surv;       // survivors == nullptr: ring-key top-k only
     int k; float exclude_eps; int *topk_idx; float *topk_d2;
 };
-struct SelectBatchArgs { SelectArgs q[kMaxQueryBatch]; };
+struct SelectBatchArgs { SelectArgs q[kMaxScreenBatch]; };
 
 __global__ __launch_bounds__(1024) void sc_select_kernel(SelectBatchArgs sb)
 {
@@ -844,7 +844,7 @@ float sc_screen_eps() { return kScreenEps; }
 
 hipError_t launch_sc_select_batch(const ScreenBatch &sb, hipStream_t stream)
 {
-    if (sb.nq < 1 || sb.nq > kMaxQueryBatch) return hipErrorInvalidValue;
+    if (sb.nq < 1 || sb.nq > kMaxScreenBatch) return hipErrorInvalidValue;
     SelectBatchArgs sel{};
     for (int i = 0; i < sb.nq; ++i) {
         SelectArgs &s = sel.q[i];
