@@ -41,7 +41,7 @@ N_KEYFRAMES_1GPU = 10000           # configs[1]
 N_KEYFRAMES_SHARD = 12500          # configs[3]: 100k keyframes over 8 GPUs
 N_EXCLUDE = 100                    # NUM_EXCLUDE_RECENT, descriptor.h:1314
 ALGO_BYTES_PER_PAIR = R * S * 4 + S * 4 + S * 4      # 31 680 B at 64x120 (fp32 descriptor + fp64 sector key)
-# What the screening launch group (products in their second form + finishing kernel + the next batch's alignment) reads per
+# What the screening launch group (products in their second form + the tail launch: finishing beside the next batch's alignment) reads per
 # KEYFRAME by design, once per launch whatever the number of scans: the chunk-major fp16 image of the
 # descriptor (2 halves x 4 chunks x (S + 16) sectors x 16 B = 17 408 B at 64x120: 13 % padding so that no fragment wraps), the unit
 # fp16 sector key + its norm (2 * 128 + 16), the tiled ring key (4 * 4 ceil(R/4)) and the 32-byte sector mask = 17 968 B -- not
@@ -505,7 +505,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": f"screening launch group of {k1_scans:.0f} scans x {n_elig} keyframes: sc_screen2_kernel (products: one keyframe "
-                                   f"against the launch's scans per matrix-core tile) + sc_screen2_finish_kernel + sc_align_kernel of the next batch; "
+                                   f"against the launch's scans per matrix-core tile) + sc_screen2_tail_kernel (finishing beside the next batch's alignment); "
                                    f"HIP events around the group",
                          "algorithmic_bytes_per_launch": per_launch,
                          "scans_per_launch": k1_scans, "pairs_per_launch": k1_pairs,

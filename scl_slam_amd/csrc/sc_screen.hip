@@ -268,11 +268,23 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
     unsigned char *wbase = reinterpret_cast<unsigned char *>(qh1 + QH) + (size_t)wave * ((2 * S + 2) * 8);
     double *vk2 = reinterpret_cast<double *>(wbase);                             // [2S + 2] scratch of the exact evaluation
 
-    for (int c = threadIdx.x; c < S; c += blockDim.x) vq[c] = a.q_vkey[c];
-    for (int i = threadIdx.x; i < QX; i += blockDim.x) qx[i] = (float)a.q_vkey[i % S];
-    {
+    {   // every global read of the set-up first, then the LDS stores: three loops of load -> store were three memory round trips
+        constexpr int T = NWV * kWave;
+        constexpr int N1 = (S + T - 1) / T, N2 = (QX + T - 1) / T, N3 = (QH + T - 1) / T;
         const _Float16 *qk = a.q_hkey;
-        for (int i = threadIdx.x; i < QH; i += blockDim.x) { qh0[i] = qk[i % S]; qh1[i] = qk[(i + 1) % S]; }
+        double r1[N1]; double r2[N2]; _Float16 r3a[N3], r3b[N3];
+#pragma unroll
+        for (int u = 0; u < N1; ++u) { const int c = threadIdx.x + u * T; r1[u] = c < S ? a.q_vkey[c] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < N2; ++u) { const int i = threadIdx.x + u * T; r2[u] = i < QX ? a.q_vkey[i % S] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < N3; ++u) { const int i = threadIdx.x + u * T; r3a[u] = i < QH ? qk[i % S] : (_Float16)0.f; r3b[u] = i < QH ? qk[(i + 1) % S] : (_Float16)0.f; }
+#pragma unroll
+        for (int u = 0; u < N1; ++u) { const int c = threadIdx.x + u * T; if (c < S) vq[c] = r1[u]; }
+#pragma unroll
+        for (int u = 0; u < N2; ++u) { const int i = threadIdx.x + u * T; if (i < QX) qx[i] = (float)r2[u]; }
+#pragma unroll
+        for (int u = 0; u < N3; ++u) { const int i = threadIdx.x + u * T; if (i < QH) { qh0[i] = r3a[u]; qh1[i] = r3b[u]; } }
     }
     __syncthreads();
 
