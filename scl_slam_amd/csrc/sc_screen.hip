@@ -899,14 +899,13 @@ hipError_t launch_sc_select_batch(const ScreenBatch &sb, hipStream_t stream)
 // 99 us per launch instead of ...)
 // Shapes of the second form.  64 x 120: two ring halves, 13 shifts in one pass, four k-steps per fragment load (13 + 3 rows),
 // 16 scans per launch.  80 x 180 (96 padded rings, 19 shifts): three ring thirds, the shifts in two passes of 13 and 6 rows that
-// share the keyframe's fragment (pass p reads the scan 13 p sectors further back), three k-steps per load, 12 scans per launch
-// (12 x 182 sectors x 64 B = 140 KB of LDS).
+// share the keyframe's fragment (pass p reads the scan 13 p sectors further back), 12 scans per launch (12 x 183 sectors x 64 B =
+// 141 KB of LDS).
 template <int RG, int S, int W> struct S2Cfg;
-template <> struct S2Cfg<16, 120, 13> { static constexpr int NP = 2, NPASS = 1, STEPS = 4, NQ = 16; };
-template <> struct S2Cfg<20, 180, 19> { static constexpr int NP = 3, NPASS = 2, STEPS = 3, NQ = 12; };
+template <> struct S2Cfg<16, 120, 13> { static constexpr int NP = 2, NPASS = 1, STEPS = 4, NQ = 16, RS = 10; };   // RS: ring slots of fragment loads (RS - 1 in flight);
+template <> struct S2Cfg<20, 180, 19> { static constexpr int NP = 3, NPASS = 2, STEPS = 4, NQ = 12, RS = 9; };    // S / STEPS iterations per keyframe = a multiple of RS
 constexpr int kS2PassRows = 13;                    // shift rows per pass: row m of pass p = shift W - 1 - 13 p - m
 constexpr int kS2Waves = 8;                        // waves per workgroup of the second form (one workgroup per CU: LDS)
-constexpr int kS2DA = 9;                           // A loads in flight per wave (iterations of STEPS k-steps); the ring has one slot more
 // LDS image of the scans (see above): quad stride in bytes, 2 mod 4 sixteen-byte slots
 constexpr int s2_quad(int S, int STEPS) { return (((S + STEPS - 1) * 256 / 16) % 4 == 2) ? (S + STEPS - 1) * 256 : (S + STEPS - 1) * 256 + 32; }
 template <int RG, int S, int W> constexpr size_t s2_lds() { return (size_t)(S2Cfg<RG, S, W>::NQ / 4) * s2_quad(S, S2Cfg<RG, S, W>::STEPS); }
@@ -961,7 +960,10 @@ __global__ __launch_bounds__(kS2Waves * kWave, 1) void sc_screen2_kernel(Screen2
     if (gw >= fa.u_n) return;
 
     const int c16 = lane & 15, j4 = lane >> 4;         // A: row m = c16; B / output: scan q = c16
-    const int cq = c16 < NQ ? c16 : c16 - 4;           // (columns past the launch's scans shadow a live column: same address, no bank conflict)
+    // columns past the launch's scans shadow the column 12 below: the SAME address as a lane of the same ds_read_b128 group
+    // (lanes 12-15 beside 0-3, 28-31 beside 16-19, ...): a broadcast.  (Shadowing column c - 4 put them on the slots of
+    // columns 0-3: 2-way conflicts on every read, half of the LDS cycles.)
+    const int cq = c16 < NQ ? c16 : c16 - 12;
     const ScreenQuery sq = ab.q[cq];                   // (entries past nq copy entry 0: valid memory, never stored)
     const int *starts_q = ab.starts + (size_t)sq.buf * (size_t)ab.pair_stride;
     const bool q_live = c16 < ab.nq && c16 < NQ;
@@ -981,8 +983,9 @@ __global__ __launch_bounds__(kS2Waves * kWave, 1) void sc_screen2_kernel(Screen2
         return starts_q[ok ? ci : 0];
     };
     const int nk = (fa.u_n - gw + waves_part - 1) / waves_part;
-    constexpr int RS = kS2DA + 1;                      // ring slots: iteration i consumes slot i % RS and refills slot (i - 1) % RS,
-    static_assert(NIT % RS == 0 && RS % 2 == 0, "");   // whose value died an iteration ago -- no register copies
+    constexpr int RS = C::RS, DA = RS - 1;             // ring slots: iteration i consumes slot i % RS and refills slot (i - 1) % RS,
+    constexpr int NB = RS % 2 == 0 ? 2 : 3;            // whose value died an iteration ago -- no register copies; B fragments one
+    static_assert(NIT % RS == 0 && RS % NB == 0, "");  // iteration ahead in NB buffers that the unrolled ring indexes statically
     u32x4 ringA[RS];
     const unsigned char *base_cur = kf_base(0), *base_nxt = kf_base(1);
     const unsigned char *pA = base_cur;                // wave-uniform: the keyframe's base + 16 STEPS bytes per iteration issued
@@ -991,7 +994,7 @@ __global__ __launch_bounds__(kS2Waves * kWave, 1) void sc_screen2_kernel(Screen2
         pA += 16 * STEPS;
     };
 #pragma unroll
-    for (int sl = 0; sl < kS2DA; ++sl) issueA(sl);
+    for (int sl = 0; sl < DA; ++sl) issueA(sl);
     int b_cur = first_shift(0), b_nxt = first_shift(1);
     const unsigned int q_lds = (unsigned int)((cq >> 2) * QUAD + (cq & 3) * 64 + j4 * 16);
     for (int k = 0; k < nk; ++k) {
@@ -1019,16 +1022,16 @@ __global__ __launch_bounds__(kS2Waves * kWave, 1) void sc_screen2_kernel(Screen2
         for (int p = 0; p < NPASS; ++p)
 #pragma unroll
             for (int u = 0; u < STEPS; ++u) acc[p][u] = f4v{0.f, 0.f, 0.f, 0.f};
-        h8 bfr[2][NPASS][STEPS];
+        h8 bfr[NB][NPASS][STEPS];
         readB(bfr[0]);
 #pragma unroll 1
         for (int r = 0; r < NIT / RS; ++r) {
 #pragma unroll
             for (int xb = 0; xb < RS; ++xb) {
-                // the load kS2DA iterations ahead: from the next keyframe for the last kS2DA iterations of this one
-                if (xb == RS - kS2DA) pA = (r == NIT / RS - 1) ? base_nxt : pA;
+                // the load DA iterations ahead: from the next keyframe for the last DA iterations of this one
+                if (xb == RS - DA) pA = (r == NIT / RS - 1) ? base_nxt : pA;
                 issueA((xb + RS - 1) % RS);
-                readB(bfr[(xb + 1) & 1]);                                        // the next iteration's B fragments (past the end: unused)
+                readB(bfr[(xb + 1) % NB]);                                       // the next iteration's B fragments (past the end: unused)
                 u32x4 af[STEPS];
                 af[0] = ringA[xb];
 #pragma unroll
@@ -1037,7 +1040,7 @@ __global__ __launch_bounds__(kS2Waves * kWave, 1) void sc_screen2_kernel(Screen2
                 for (int u = 0; u < STEPS; ++u)
 #pragma unroll
                     for (int p = 0; p < NPASS; ++p)
-                        acc[p][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, af[u]), bfr[xb & 1][p][u], acc[p][u], 0, 0, 0);
+                        acc[p][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, af[u]), bfr[xb % NB][p][u], acc[p][u], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
