@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Randomised parity soak (GPU vs the CPU checker): many seeds, both wave-kernel grids, random exclusion
+"""Randomised parity soak (GPU vs the CPU checker): many seeds, the three tuned grids (64x120, 20x60, 80x180), random exclusion
 ranges and planted rotations; every sampled (query, keyframe) pair must agree bit for bit and every full-DB
 winner must be the checker's winner over the sampled set's superset property (winner distance <= every
-sampled distance, and equal to the checker's value for that pair).  Usage: soak_parity.py [seconds]"""
+sampled distance, and equal to the checker's value for that pair); the stream form (launches of up to 16 scans with ragged
+ranges: the second form of the screening products) must return what the one-scan calls return.  Usage: soak_parity.py [seconds]"""
 import os
 import sys
 import time
@@ -16,12 +17,12 @@ from scl_slam_amd.synth import synth_descriptors  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 t_end = time.time() + budget
-seed, pairs, wins = 0, 0, 0
+seed, pairs, wins, streams = 0, 0, 0, 0
 while time.time() < t_end:
     seed += 1
     rs = np.random.RandomState(seed)
-    R, S = [(64, 120), (20, 60)][seed % 2]
-    n = int(rs.randint(300, 1500))
+    R, S = [(64, 120), (20, 60), (80, 180), (64, 120)][seed % 4]
+    n = int(rs.randint(300, 1500)) if S != 180 else int(rs.randint(300, 800))
     contrast = float(rs.choice([1.0, 0.1, 0.01]))                      # low contrast -> alignment near ties
     descs = synth_descriptors(n, R, S, seed=1000 + seed, revisit_frac=0.05)
     if contrast != 1.0:
@@ -45,6 +46,16 @@ while time.time() < t_end:
             assert sc == sh[c] and np.float64(dc).view(np.uint64) == dist[c:c + 1].view(np.uint64)[0], (seed, q, c, dc, dist[c], sc, sh[c])
             pairs += 1
         wins += 1
+    # the stream form: 5 to 40 scans, every one with its own range (some empty, some one keyframe long)
+    m = int(rs.randint(5, 41))
+    qs = rs.randint(n // 2, n, size=m).astype(np.int32)
+    los = np.array([int(rs.randint(0, max(1, q // 2))) for q in qs], np.int32)
+    his = np.array([int(rs.randint(lo, q)) if rs.random_sample() > 0.1 else lo + int(rs.randint(0, 2)) for lo, q in zip(los, qs)], np.int32)
+    nn_s, sh_s, d_s = eng.detect_full_stream(qs, los, his, 16, 2)
+    for i in range(m):
+        nn1, sh1, d1 = eng.detect_full_range(int(qs[i]), int(los[i]), int(his[i]))
+        assert (int(nn_s[i]), int(sh_s[i])) == (nn1, sh1) and np.float64(d_s[i]).view(np.uint64) == np.float64(d1).view(np.uint64), (seed, i, qs[i], los[i], his[i])
+        streams += 1
     eng.close()
-    print(f"seed {seed}: {R}x{S} n={n} contrast={contrast}: ok ({pairs} pairs, {wins} winners so far)", flush=True)
-print(f"soak done: {seed} databases, {pairs} pairs bit-identical, {wins} full-DB winners consistent")
+    print(f"seed {seed}: {R}x{S} n={n} contrast={contrast}: ok ({pairs} pairs, {wins} winners, {streams} streamed scans so far)", flush=True)
+print(f"soak done: {seed} databases, {pairs} pairs bit-identical, {wins} full-DB winners consistent, {streams} streamed scans equal to their one-scan calls")
