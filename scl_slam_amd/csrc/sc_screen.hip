@@ -1,4 +1,4 @@
-// sc_screen.hip -- K1s: the screening pass of the full-DB mode (64x120 grid).
+// sc_screen.hip -- K0 + K1s: the screening pass of the full-DB mode (64x120 and 80x180 grids).
 //
 // Full-DB detection needs the ARG-MIN over the database of distanceBtnScanContext (descriptor.h:1538-1569), not
 // every distance.  This pass gives every keyframe a guaranteed interval around its reference distance; only the
@@ -6,28 +6,36 @@
 // (sc_distance.hip), so the winner -- index, shift and fp64 distance -- is the reference's, bit for bit.
 //
 // Per keyframe:
-//   1. the reference's own alignment, exactly (fastAlignUsingVkey, D.h:1491-1511: fp32 correlation filter with the
+//   1. the reference's own alignment, exactly (fastAlignUsingVkey, D.h:1491-1511: matrix-core correlation filter with the
 //      exact fp64 evaluation as fallback -- the same code path as sc_distance.hip);
 //   2. the 13 shifted cosine distances of D.h:1545-1566 in reduced precision on the matrix cores: both descriptors
 //      with unit columns (x / |column|, fp32) rounded to fp16, products exact, fp32 accumulation:
 //        sim[t] = sum over query sectors x and rings r of  Qh[r][x + t] * Kh[r][(x - b) mod S],   b = first shift
 //      which is ONE matrix product per 16 keyframes: M = 16 shift rows (13 used), N = 16 keyframes, K = 7 680
-//      = (ring group, sector, ring) -- v_mfma_f32_16x16x32_f16, 240 per 16 keyframes.  The effective-sector counts
-//      (D.h:1523-1526) come from the same product on 0/1 indicators (15 more MFMAs), exact;
+//      = (ring group, sector, ring) -- v_mfma_f32_16x16x32_f16, 240 per 16 keyframes (first form; the second form turns the
+//      product round: one keyframe against 16 scans).  The effective-sector counts (D.h:1523-1526) are popcounts of the
+//      rotated sector masks, exact;
 //   3. d~ = min_t (1 - sim[t] / n_eff[t]).
 // Error of d~ against the reference distance of the same shift: each cosine is off by at most
 //   2u + u^2 (u = 2^-11, fp16 rounding of both unit vectors, Cauchy-Schwarz) + 16 * 2^-25 (fp16 subnormals)
 //   + 3 * 2^-23 (fp32 scaling by the reciprocal norms) < 9.78e-4,
-// the accumulation (chains of 60 MFMAs = 1 920 products per wave, then 4 partials) adds at most 1 924 * 2^-23 =
-// 2.3e-4 even if every addition truncated; the mean over the effective sectors keeps that bound.  kScreenEps = 1.5e-3
+// the accumulation (first form: chains of 60 MFMAs = 1 920 products per wave, then 4 partials; second form: chains of 30 MFMAs
+// = 960 products, then 8 partials) adds at most 1 924 * 2^-23 = 2.3e-4 even if every addition truncated; the mean over the effective sectors keeps that bound.  kScreenEps = 1.5e-3
 // leaves 20 % on top.  A keyframe can hold the minimum only if d~ <= min(d~) + 2 * kScreenEps.
 // Keyframes (or queries) with a column norm outside [2^-60, 2^60] or non-finite are never screened out.
 //
-// Mapping: workgroup = 4 waves, 16 keyframes per step.  Wave w aligns keyframes 4w..4w+3, then streams ring groups
-// 4w..4w+3 of all 16: lane (n, j) = (lane & 15, lane >> 4) reads keyframe n's columns (x - b_n) mod S for
-// x = 8 xb + 2j, +1 as two float4 (4 rings each) -- the MFMA's B fragment after scaling and conversion -- through
-// a ring of D k-steps; the A fragment is 16 bytes of the fp16 query in LDS.  Partial sums meet in LDS, wave 0
-// finishes.  Bound: HBM (4 R S + 8 S + 4 S bytes per keyframe actually read; SURVEY 8(d) counts 4 R S + 8 S).
+// What is in this file:
+//   sc_align_role / sc_align_kernel         K0: the first shift of every (scan, keyframe) pair -- the reference's alignment exactly,
+//                                           as a two-stage matrix-core correlation filter with the fp64 evaluation as fallback
+//   sc_screen_role / sc_screen_kernel       K1s, FIRST form: one scan against 16 keyframes per matrix-core tile, the keyframes' rows
+//                                           fetched per pair (rotated by the pair's first shift) -- bound by what the L2s deliver;
+//                                           the next batch's alignment rides in the same grid (SCL_SCREEN_FORM=1; probes)
+//   sc_screen2_kernel                       K1s, SECOND form (default on 64 x 120 and 80 x 180): one KEYFRAME against the launch's
+//                                           scans per tile, the scans rotated out of LDS, ring parts in separate workgroups
+//   sc_screen2_finish_body / _tail_kernel   the ring parts of a pair meet: bound d~, flags, ring-key metric -- in one launch with the
+//                                           next batch's alignment
+//   sc_select_kernel                        survivors + ring-key top-k (80 x 180's exact pass; scl_screen_distances)
+//   launch_sc_screen_batch                  the launch group of a batch
 #include <atomic>
 #include <type_traits>
 
