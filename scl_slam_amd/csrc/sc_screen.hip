@@ -1266,8 +1266,17 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
     };
     // second form of the products (64 x 120: the keyframe as the shared operand, the launch's scans as columns): needs the
     // partial-sum scratch; SCL_SCREEN_FORM=1 keeps the first form.  Its finishing kernel also forms the ring-key metric.
-    const bool use_v2 = screen_second_form() && sb.part && probe == 0 && variant == 0 && sb.nq <= S2Cfg<RG, S, W>::NQ &&
-                        (!next || next->nq <= S2Cfg<RG, S, W>::NQ);
+    // Which form scores a batch: the second form's cost does not depend on the number of scans (54 us for one or sixteen on
+    // 64 x 120, 175 us on 80 x 180), the first form's grows with it (13 / 107 us per scan): batches of up to three scans
+    // (one on 80 x 180) -- blocking single-scan calls, short remainders -- take the first form.  A batch's alignment is
+    // launched by the batch in front of it and leaves the ring-key metric to the second form's finishing kernel, so the
+    // decision is made per batch from its own size.
+    static const int v2_min = [] { const char *e = getenv("SCL_SCREEN_V2_MIN"); return e ? atoi(e) : (S <= 128 ? 4 : 2); }();   // (tests: 1 = always the second form)
+    auto second_form_for = [&](const ScreenBatch &b) {
+        return screen_second_form() && b.part && probe == 0 && variant == 0 && b.nq >= v2_min && b.nq <= S2Cfg<RG, S, W>::NQ;
+    };
+    const bool use_v2 = second_form_for(sb);
+    const bool next_v2 = next && second_form_for(*next);
     ab.skip_d2 = use_v2 ? 1 : 0;
     // the alignment of this batch, on its own (the first launch of a sequence, or a caller that has only one)
     if ((phases & kScreenAlign) && probe != 3) {
@@ -1307,7 +1316,7 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
                 ScreenBatchArgs nb{};
                 const int nmax2 = fill_screen_args(db, *next, align_filter, &nb);
                 if (nmax2 < 0) return hipErrorInvalidValue;
-                nb.skip_d2 = 1;
+                nb.skip_d2 = next_v2 ? 1 : 0;
                 const int ng2 = (nmax2 + kGroup - 1) / kGroup;
                 // persistent workgroups: three per CU (167 registers: three waves per SIMD; 128 spill and double the time) over the
                 // whole batch, every wave walks several groups with the next group's keys in flight
@@ -1336,7 +1345,7 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
                 ScreenBatchArgs nb{};
                 const int nmax2 = fill_screen_args(db, *next, align_filter, &nb);
                 if (nmax2 < 0) return hipErrorInvalidValue;
-                nb.skip_d2 = 1;
+                nb.skip_d2 = next_v2 ? 1 : 0;
                 const int ng2 = (nmax2 + kGroup - 1) / kGroup;
                 int per_q = 3 * num_cu / next->nq;
                 per_q = per_q < 1 ? 1 : per_q;
@@ -1366,6 +1375,7 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
         if (next->nq < 1 || next->nq > kMaxScreenBatch) return hipErrorInvalidValue;
         const int nmax2 = fill_screen_args(db, *next, align_filter, &fa.next);
         if (nmax2 < 0) return hipErrorInvalidValue;
+        fa.next.skip_d2 = next_v2 ? 1 : 0;
         fa.next.nb = align_blocks((nmax2 + kGroup - 1) / kGroup, next->nq, true);
         extra = fa.next.nb * next->nq;
 #ifdef SCL_DIAGNOSTICS

@@ -196,12 +196,14 @@ def test_random_ranges_against_the_checker(R, S, n):
     eng.close()
 
 
-def test_first_form_of_the_products_still_meets_the_bound():
-    """SCL_SCREEN_FORM is read once per process: the same bound / survivor / winner checks with the 64x120 products in their
-    first form (keyframe rows per pair; the default is the second form) in a child interpreter"""
+@pytest.mark.parametrize("env", [{"SCL_SCREEN_FORM": "1"}, {"SCL_SCREEN_V2_MIN": "1"}])
+def test_both_forms_of_the_products_meet_the_bound_for_every_batch_size(env):
+    """The form of the screening products is chosen per batch (second form from four scans on, two on 80x180) and the switches
+    are read once per process: the bound / survivor / winner checks of this file -- single-scan probes and streams -- once with the
+    first form on every batch and once with the second form on every batch, in a child interpreter"""
     import os, subprocess, sys
-    env = dict(os.environ, SCL_SCREEN_FORM="1")
     here = os.path.abspath(__file__)
     out = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-m", "gpu", "-x", "-k",
-                          "bench_database or adversarial or random_ranges"], env=env, capture_output=True, text=True, timeout=900)
+                          "bench_database or adversarial or random_ranges or 80x180"], env=dict(os.environ, **env),
+                         capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
