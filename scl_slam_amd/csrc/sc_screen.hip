@@ -276,6 +276,26 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
     unsigned char *wbase = reinterpret_cast<unsigned char *>(qh1 + QH) + (size_t)wave * ((2 * S + 2) * 8);
     double *vk2 = reinterpret_cast<double *>(wbase);                             // [2S + 2] scratch of the exact evaluation
 
+    const int m16 = lane & 15, k4 = lane >> 4;
+    // (the first group's keys and the query's norm are requested before the set-up's own reads: one memory round trip for all)
+    const float qnorm = *reinterpret_cast<const float *>(a.q_hkey + SK);
+    const int ngroups = (a.n + kGroup - 1) / kGroup;
+    // The keys of a group (16 keyframes x SK halfs, their norms) are fetched into registers one group ahead: a wave's groups are a
+    // chain of short phases, and the fetch was a whole memory round trip at the head of every one of them.
+    static_assert(kGroup * (SK / 8) == KS * kWave, "one 16-byte chunk per lane and k-step");
+    // ... in the matrix cores' B layout: lane (n, j) = (lane & 15, lane >> 4) holds halfs 32 kk + 8 j .. + 7 of keyframe n's key for
+    // k-step kk -- the fragments go from memory to the MFMAs without a trip through LDS
+    uint4 pre[KS];
+    float knorm_pre = 0.f;
+    auto fetch = [&](int g) {
+        const int fs = a.slot_base + g * kGroup, lr = a.n - 1 - g * kGroup;
+        const unsigned char *kp = reinterpret_cast<const unsigned char *>(a.hkey + (size_t)(fs + (m16 < lr ? m16 : lr)) * (size_t)a.hkw);   // the dense key table
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) pre[kk] = *reinterpret_cast<const uint4 *>(kp + (4 * kk + k4) * 16);
+        knorm_pre = *reinterpret_cast<const float *>(reinterpret_cast<const _Float16 *>(kp) + SK);
+    };
+    const int g_first = bid * NWV + wave;
+    if (g_first < ngroups) fetch(g_first);
     {   // every global read of the set-up first, then the LDS stores: three loops of load -> store were three memory round trips
         constexpr int T = NWV * kWave;
         constexpr int N1 = (S + T - 1) / T, N2 = (QX + T - 1) / T, N3 = (QH + T - 1) / T;
@@ -296,7 +316,6 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
     }
     __syncthreads();
 
-    const int m16 = lane & 15, k4 = lane >> 4;
     const float *qa = qx + 4 * k4 + m16;                                         // A[s = 16t + m][u = 16b + 4k + e] = qa[16 (b + t) + e]
     // fp16 stage: A[s = 16t + m][u = 32kk + 8k + i] = q^[(32kk + 16t + (8k + m) + i) mod S]: eight consecutive halfs from an
     // arbitrary index -- from the copy shifted by one when that index is odd, so that the reads stay dword aligned
@@ -307,7 +326,6 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
     qn2 = wave_sum_f32_dpp(qn2);
     const bool use_filter = a.align_filter != 0;
     const float kNegInf = __int_as_float(0xff800000);
-    const float qnorm = *reinterpret_cast<const float *>(a.q_hkey + SK);
 
     // per keyframe (column n = lane & 15): the largest and the second largest value over all shifts, and the largest's shift
     auto top2 = [&](const f4v (&acc)[MT], float &v1, float &v2, int &a1) {
@@ -335,23 +353,6 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
         }
     };
 
-    const int ngroups = (a.n + kGroup - 1) / kGroup;
-    // The keys of a group (16 keyframes x SK halfs, their norms) are fetched into registers one group ahead: a wave's groups are a
-    // chain of short phases, and the fetch was a whole memory round trip at the head of every one of them.
-    static_assert(kGroup * (SK / 8) == KS * kWave, "one 16-byte chunk per lane and k-step");
-    // ... in the matrix cores' B layout: lane (n, j) = (lane & 15, lane >> 4) holds halfs 32 kk + 8 j .. + 7 of keyframe n's key for
-    // k-step kk -- the fragments go from memory to the MFMAs without a trip through LDS
-    uint4 pre[KS];
-    float knorm_pre = 0.f;
-    auto fetch = [&](int g) {
-        const int fs = a.slot_base + g * kGroup, lr = a.n - 1 - g * kGroup;
-        const unsigned char *kp = reinterpret_cast<const unsigned char *>(a.hkey + (size_t)(fs + (m16 < lr ? m16 : lr)) * (size_t)a.hkw);   // the dense key table
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) pre[kk] = *reinterpret_cast<const uint4 *>(kp + (4 * kk + k4) * 16);
-        knorm_pre = *reinterpret_cast<const float *>(reinterpret_cast<const _Float16 *>(kp) + SK);
-    };
-    const int g_first = bid * NWV + wave;
-    if (g_first < ngroups) fetch(g_first);
     for (int g = g_first; g < ngroups; g += nbk * NWV) {
         const int c_base = g * kGroup;
         const int first_slot = a.slot_base + c_base;
