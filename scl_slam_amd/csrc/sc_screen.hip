@@ -389,31 +389,30 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag, acc[t], 0, 0, 0);
                 }
             }
-            // the largest value, how many values come within the margin of it, and where it sits: "the second largest is more
-            // than the margin below the largest" <=> exactly one value is >= largest - margin.  Unlike a running (largest, second
-            // largest) pair these are reductions without a serial dependence through the 32 values a lane holds.
-            float mx = kNegInf;
+            // The largest and the second largest of the S correlation values of a keyframe (the filter asks whether they are more
+            // than the margin apart) and the largest's shift, at 2.5 instructions per value: the shift is written into the low 8
+            // mantissa bits of its value (values are normalised correlations in [-1, 1]: a perturbation of < 1.6e-5, which the
+            // margin test below allows for), so the maximum carries its own arg-max; pairs of values enter a running (hi, lo)
+            // through max3 / med3 (the second largest of {hi, lo, x, y} is max(lo, med3(hi, x, y))), two independent chains.
+            static_assert(S <= 256, "8 bits of shift");
+            auto tag = [&](float c, int sft) { return sft < S ? __uint_as_float((__float_as_uint(c) & ~255u) | (unsigned int)sft) : kNegInf; };
+            float hi[2] = {kNegInf, kNegInf}, lo[2] = {kNegInf, kNegInf};
 #pragma unroll
-            for (int t = 0; t < MT; ++t)
+            for (int t = 0; t < MT; ++t) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { if (16 * t + 4 * 3 + i < S || 16 * t + i < S) mx = fmaxf(mx, (16 * t + 4 * k4 + i) < S ? acc[t][i] : kNegInf); }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, kWave));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
-            const float thr = mx - kAlign16Margin;
-            int cnt = 0, arg = 0;
-#pragma unroll
-            for (int t = 0; t < MT; ++t)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int sft = 16 * t + 4 * k4 + i;
-                    const float c = sft < S ? acc[t][i] : kNegInf;
-                    cnt += (c >= thr) ? 1 : 0;
-                    arg = max(arg, (c == mx) ? sft : 0);
+                for (int i = 0; i < 4; i += 2) {
+                    const float x = tag(acc[t][i], 16 * t + 4 * k4 + i), y = tag(acc[t][i + 1], 16 * t + 4 * k4 + i + 1);
+                    const int ch = (t & 1);
+                    lo[ch] = fmaxf(lo[ch], __builtin_amdgcn_fmed3f(hi[ch], x, y));
+                    hi[ch] = fmaxf(fmaxf(hi[ch], x), y);
                 }
-            cnt += __shfl_xor(cnt, 16, kWave); cnt += __shfl_xor(cnt, 32, kWave);
-            arg = max(arg, __shfl_xor(arg, 16, kWave)); arg = max(arg, __shfl_xor(arg, 32, kWave));
-            v1 = mx; a1 = arg;
-            v2 = cnt == 1 ? kNegInf : mx;                                        // (only "v2 < v1 - margin" is asked below)
+            }
+            auto merge = [](float &h, float &l, float oh, float ol) { l = fmaxf(fmaxf(l, ol), fminf(h, oh)); h = fmaxf(h, oh); };
+            merge(hi[0], lo[0], hi[1], lo[1]);
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) merge(hi[0], lo[0], __shfl_xor(hi[0], off, kWave), __shfl_xor(lo[0], off, kWave));
+            v1 = hi[0]; v2 = lo[0] + 4.0e-5f;                                   // (the tags moved either value by < 1.6e-5)
+            a1 = (int)(__float_as_uint(hi[0]) & 255u);
         }
         // The exact arg-max of the correlation is the reference's arg-min only while its fp64 distances resolve the lead: their
         // rounding noise is ~1e-13 (|vq|^2 + |vk|^2), a lead of 3e-3 |vq| |vk| stands clear of it for norm ratios up to 1e4;
