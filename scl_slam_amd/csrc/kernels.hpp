@@ -34,8 +34,8 @@ constexpr int hdesc_stride(int RG, int S) { return hdesc_stride_rgh(hdesc_sector
 //                                all rings of one sector are consecutive (128 B = one cache line on the 64 x 120 grid), so
 //                                a ring shift is a rotation of whole lines and every line is read once.  Half the bytes of
 //                                desc.  Behind it the sector key as a unit vector in fp16 (vkey / |vkey|, zero padded to a multiple of 32; all zero when the
-//                                norm is zero or not finite) and its norm as a float: the first stage of the alignment filter.  hstride = S * RGH + hkey_store_halfs(S) / 4
-//                                elements of 8 B.
+//                                norm is zero or not finite) and its norm as a float: the first stage of the alignment filter; behind that, 128-byte aligned, the
+//                                chunk-major image of the same values (hdesc2_offset / hdesc2_elems above).  hstride = hdesc_stride(RG, S) elements of 8 B.
 //   hkey   half   [cap][hkey_store_halfs(S)]  the fp16 sector key and its norm as stored behind hdesc's copy, in a table of its own: the alignment reads
 //                                nothing else of a keyframe, and 272 B at a stride of 33 KB cost it a DRAM page and a TLB entry per keyframe
 //   kmask  u32    [cap][8]       bit c of words 0..6 = column c has a non-zero norm; word 7 bit 0 = some column norm is outside [2^-60, 2^60] or non-finite (such keyframes are always scored exactly)
