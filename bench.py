@@ -2,9 +2,13 @@
 """bench.py -- headline benchmark of the Scan Context loop-closure hot path on MI355X.
 
 Metric (BASELINE.json): loop-closure candidates/sec (+ SC-distance GB/s).  One "step" = one
-incoming scan's place-recognition pass over the resident database: full ring-key scan (exact
-top-k) + column-shifted SC distance against EVERY eligible keyframe + global arg-min.
-`value` counts (query, keyframe) pairs scored per second.
+batch of incoming scans -- `--scans-per-launch` of them (16: the scans of a robot team that
+arrive together, one launch group of the engine) -- and for each scan of the batch the
+place-recognition pass over the resident database: full ring-key scan (exact top-k) +
+column-shifted SC distance against EVERY eligible keyframe + global arg-min.  `value` counts
+(query, keyframe) pairs scored per second; `ms_per_scan` is the step time over the scans of a
+step.  (Up to round 1 a step was a single scan: `--steps 20` then timed 20 scans = two launch
+groups, a region of 0.3 ms that measured the pipeline's fill and drain, not its rate.)
 
 Workloads
   N = 1  BASELINE configs[1]: 10 000 synthetic Velodyne-64 keyframes, 64x120 SC.
@@ -59,8 +63,8 @@ HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2048)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=128, help="timed steps; a step = one batch of --scans-per-launch incoming scans")
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--repeats", type=int, default=5, help="repetitions of the timed block of --steps steps (median reported)")
     ap.add_argument("--keyframes", type=int, default=0, help="keyframes per GPU (0: 10 000 at N = 1, 12 500 at N > 1)")
     ap.add_argument("--pipeline", type=int, default=2, help="kernel launches enqueued ahead (1 = strictly one after another)")
@@ -426,14 +430,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(0, args.warmup)
+    spl = max(1, args.scans_per_launch)                      # scans of one step (= of one launch group)
+    warm_scans, timed_scans = args.warmup * spl, args.steps * spl
+    run(0, warm_scans)
     eng.profile_reset()
     eng.profile_enable(3)          # HIP events around the dominant kernel, one launch in eight (an event pair per launch costs ~8 us)
     times = []
     for rep in range(max(1, args.repeats)):
         fence()
         t0 = time.perf_counter()
-        timed_results = run(args.warmup, args.steps)
+        timed_results = run(warm_scans, timed_scans)
         fence()
         elapsed = time.perf_counter() - t0
         if world > 1:
@@ -446,14 +452,14 @@ def main():
         for i, (d, g, sh) in enumerate(timed_results):
             if os.environ.get("SCL_ABLATE"):             # diagnostic build with phases switched off: results are wrong on purpose
                 break
-            if ((args.warmup + i) % n_query) % 4 == 0:
+            if ((warm_scans + i) % n_query) % 4 == 0:
                 assert d < 1e-6 and g >= 0 and g % world == 0, (i, d, g, sh)
     eng.profile_enable(False)
     prof = eng.profile()
     al_pairs, al_fallbacks = eng.alignment_stats()
     elapsed = float(np.median(times))
 
-    pairs_per_step = n_elig * world
+    pairs_per_step = n_elig * world * spl
     value = pairs_per_step * args.steps / elapsed
     k1_ms = prof["sc_distance_ms"] / max(1, prof["sc_distance_launches"])
     k1_pairs = prof["sc_distance_pairs"] / max(1, prof["sc_distance_launches"])
@@ -487,10 +493,12 @@ def main():
         out = {
             "metric": "loop-closure candidates/sec (SC-distance pairs scored per second), 10k-keyframe DB per GPU",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "ms_per_scan": elapsed / timed_scans * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "repeats": len(times), "ms_per_step_min": min(times) / args.steps * 1e3, "ms_per_step_max": max(times) / args.steps * 1e3,
             "config": {"workload": workload,
+                       "step": f"one batch of {spl} incoming scans, each scored against the whole database (one launch group)",
+                       "scans_per_step": spl, "scans_timed": timed_scans,
                        "keyframes_per_gpu": n_local, "eligible_per_query": n_elig, "rings": R, "sectors": S,
                        "shifts_per_pair": 13, "scans_per_launch": args.scans_per_launch, "launches_in_flight": args.pipeline, "native_chunk": args.native_chunk,
                        "sharding": (f"keyframe-index shards x{world}; exchange = {args.exchange} "
