@@ -1151,7 +1151,11 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
                            int *nn_idx, int *shift, double *dist)
 {
     constexpr int NS = scl_engine::kScreenSets;
-    constexpr int CH = NS / 2;                               // scans per chunk: the two chunks in flight use the two halves of the buffer sets
+    constexpr int CH = NS / 2;                               // scans per chunk at most: the two chunks in flight use the two halves of the buffer sets
+    // ... and a whole number of launches (80 x 180 takes 12 scans per launch: 64 would end every chunk with a launch of four,
+    // which costs the same pass over the database as one of twelve)
+    const int chn = spl >= 1 && spl <= CH ? (CH / spl) * spl : CH;
+    static_assert(CH <= kMaxSurvivorQueries, "one exact pass takes the survivors of a whole chunk");
     const bool wide = sc_screen_is_wide(db_view(e), e->SR);  // 80 x 180: same launches, its own exact pass
     struct List { int qslot[CH], qlo[CH], qn[CH], pos[CH], m = 0; };     // the scans of a chunk that have something to score
     struct Chunk { int first = 0, count = 0; bool busy = false, aligned = false; std::vector<int> lo, empty; };
@@ -1263,9 +1267,9 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
     int next = 0, c = 0;
     while (next < n_queries || ch[0].busy || ch[1].busy) {
         if (next < n_queries && !ch[c].busy) {
-            const int count = n_queries - next < CH ? n_queries - next : CH;
+            const int count = n_queries - next < chn ? n_queries - next : chn;
             const int nfirst = next + count;
-            const int ncount = n_queries - nfirst < CH ? n_queries - nfirst : CH;
+            const int ncount = n_queries - nfirst < chn ? n_queries - nfirst : chn;
             if ((rc = submit(c, next, count, nfirst, ncount > 0 ? ncount : 0))) {
                 const std::string first_error = e->last_error;
                 (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream_surv);

@@ -66,7 +66,9 @@ struct scl_engine {
     // screening pass of the full-DB mode (sc_screen.hip): approximate distances, survivors, their counts, min d~ words
     // Buffers come in kScreenSets sets of `set_stride` entries (one set per query of a chunk of the stream form; the
     // submit / collect form uses sets 0..3): approx, ring_d2, survivors, dist, shift at set * set_stride.
-    static constexpr int kScreenSets = 64;
+    // (128: chunks of 64 scans = four launches of 16, five of 12 on 80 x 180 -- with chunks of 32 the 80 x 180 products waited 85 us at
+    // every chunk end for the exact pass of the chunk before, whose buffers the next alignment writes; 256 measured no better)
+    static constexpr int kScreenSets = 128;
     float *d_approx = nullptr; int *d_starts = nullptr; int *d_surv = nullptr;
     float *d_part = nullptr; size_t part_cap = 0;       // partial sums of the screening products' second form (one launch at a time)
     int *d_nsurv = nullptr; unsigned int *d_tmin = nullptr;

@@ -1417,7 +1417,7 @@ hipError_t launch_sc_distance_batch(const DbView &db, const QueryBatch &qb, int 
 
 hipError_t launch_sc_distance_survivors(const DbView &db, const SurvivorPass &sp, int SR, int num_cu, hipStream_t stream, int phases)
 {
-    if (sp.nq < 1 || !(db.RG == 16 && db.S == 120 && SR == 6) || !sp.d_args || !sp.h_args) return hipErrorInvalidValue;
+    if (sp.nq < 1 || sp.nq > kMaxSurvivorQueries || !(db.RG == 16 && db.S == 120 && SR == 6) || !sp.d_args || !sp.h_args) return hipErrorInvalidValue;
     constexpr int RG = 16, W = 13, CH = 4, S = 120, MAXT = 512;
     ScArgs *h = reinterpret_cast<ScArgs *>(sp.h_args);
     static_assert(sizeof(ScArgs) <= kSurvivorArgBytes, "argument set must fit the slot the engine reserves");

@@ -792,7 +792,6 @@ __global__ __launch_bounds__(1024) void sc_select_kernel(SelectBatchArgs sb)
 {
     const SelectArgs &a = sb.q[blockIdx.x];
     __shared__ int wcount[16];
-    __shared__ int base_s;
     __shared__ unsigned long long sk[16];
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
     const unsigned int tm = *a.t_min;
@@ -801,23 +800,41 @@ __global__ __launch_bounds__(1024) void sc_select_kernel(SelectBatchArgs sb)
         const unsigned int b = (tm >> 31) ? (tm & 0x7fffffffu) : ~tm;            // inverse of float_to_ordered_u
         thr = tm == 0xffffffffu ? __int_as_float(0xff800000) : __int_as_float((int)b) + 2.0f * kScreenEps;
     }
-    if (threadIdx.x == 0) base_s = 0;
-    __syncthreads();
-    for (int i0 = 0; i0 < (a.survivors ? a.n : 0); i0 += blockDim.x) {
-        const int i = i0 + threadIdx.x;
-        bool keep = false;
-        if (i < a.n) { const float d = a.approx[i]; keep = d <= thr; }           // -inf (score exactly) always passes
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
-        if (lane == 0) wcount[wv] = __popcll(m);
+    // Every wave owns a contiguous part of the range and walks it 4 x 64 entries at a time (four independent loads in flight,
+    // one barrier in all: the walk in steps of the whole workgroup paid a load's latency and three barriers per step): count,
+    // prefix over the waves, then the same walk writes the list -- ascending slots.
+    {
+        const int n_s = a.survivors ? a.n : 0;
+        const int nwv = (int)blockDim.x / kWave;
+        const int per_wave = (((n_s + nwv - 1) / nwv) + kWave - 1) / kWave * kWave;
+        const int wlo = wv * per_wave;
+        const int whi = wlo + per_wave < n_s ? wlo + per_wave : n_s;
+        int cnt = 0;
+        for (int base = wlo; base < whi; base += 4 * kWave) {
+            float d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = base + u * kWave + lane; d[u] = i < whi ? a.approx[i] : __int_as_float(0x7fc00000); }   // NaN: never passes
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cnt += __popcll(__builtin_amdgcn_ballot_w64(d[u] <= thr));      // -inf (score exactly) always passes
+        }
+        if (lane == 0) wcount[wv] = cnt;
         __syncthreads();
-        int before = base_s;
-        for (int w = 0; w < wv; ++w) before += wcount[w];
-        if (keep) a.survivors[before + __popcll(m & ((1ull << lane) - 1ull))] = a.slot_base + i;
-        __syncthreads();
-        if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < (int)blockDim.x / kWave; ++w) t += wcount[w]; base_s += t; }
-        __syncthreads();
+        int before = 0, total = 0;
+        for (int w = 0; w < nwv; ++w) { const int t = wcount[w]; if (w < wv) before += t; total += t; }
+        for (int base = wlo; base < whi; base += 4 * kWave) {
+            float d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = base + u * kWave + lane; d[u] = i < whi ? a.approx[i] : __int_as_float(0x7fc00000); }   // NaN: never passes
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool keep = d[u] <= thr;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+                if (keep) a.survivors[before + __popcll(m & ((1ull << lane) - 1ull))] = a.slot_base + base + u * kWave + lane;
+                before += __popcll(m);
+            }
+        }
+        if (threadIdx.x == 0 && a.survivors) { *a.n_surv = total; *a.t_min = 0xffffffffu; }   // armed for the next launch (stream ordered)
     }
-    if (threadIdx.x == 0 && a.survivors) { *a.n_surv = base_s; *a.t_min = 0xffffffffu; }   // armed for the next launch (stream ordered)
 
     const unsigned long long none = ~0ull;
     unsigned long long prev = 0ull;
