@@ -75,7 +75,7 @@ def parse_args():
                     help="incoming scans scored by one kernel launch (1..16; the reference runs several robots, whose scans "
                          "arrive together): the workgroups that walk the same keyframes for the scans of a launch share "
                          "them through an XCD's L2, so the database crosses HBM once per launch, not once per scan")
-    ap.add_argument("--native-chunk", type=int, default=256,
+    ap.add_argument("--native-chunk", type=int, default=1024,
                     help="scans handed to the engine's native submit/collect pipeline per call (0: drive every scan from Python)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] geometric-verification measurement")

@@ -129,7 +129,11 @@ hipError_t launch_sc_select_batch(const ScreenBatch &sb, hipStream_t stream);
 // the last workgroup of the query writes the winner (distance, position relative to base[i], shift) to out3[i] and
 // re-arms t_min.  blk_part: nq * kSurvivorBlocks * kTailRec words, done_counter: nq zeroed words,
 // d_args / h_args (pinned): nq * kSurvivorArgBytes bytes.
-constexpr int kSurvivorBlocks = 4;          // workgroups (of 8 waves) per query
+// workgroups (of 8 waves) per query: one scores the survivors (one to five as a rule, a wave each), one forms the ring-key top-k
+// beside it.  The pass needs 126 KB of LDS per workgroup and cannot share a CU with the screening products (138 KB): every
+// CU it holds is a CU the main stream waits for -- 4 per query (256 for a chunk of 64 scans) cost 7 % of the stream's rate, 1 loses
+// the overlap of top-k and scoring.
+constexpr int kSurvivorBlocks = 2;
 constexpr int kSurvivorArgBytes = 384;
 constexpr int kMaxSurvivorQueries = 64;
 struct SurvivorPass {

@@ -52,7 +52,8 @@ def test_batched_queries_equal_single_launches(R, S):
 
 
 def test_long_stream_crosses_chunks_with_empty_and_ragged_ranges():
-    """scl_detect_full_stream on the screened grid works in chunks of 32 scans on alternating halves of its buffers; every
+    """scl_detect_full_stream on the screened grid works in chunks of up to 64 scans (a whole number of launches: 64, 60 at 12 or 10 scans per launch,
+    63 at three) on alternating halves of its buffers; every
     launch carries the alignment of the launch behind it, the chunk's last one that of the next chunk's first.  Scans with
     an empty range, ranges that differ per scan, a last chunk of one scan and every scans-per-launch setting must give what
     each scan's own pass gives, bit for bit; the array form of the Python stream front end as well."""
@@ -62,14 +63,14 @@ def test_long_stream_crosses_chunks_with_empty_and_ragged_ranges():
     try:
         e.save_bulk(descs)
         rs = np.random.RandomState(5)
-        for count in (97, 65, 33):
+        for count in (150, 129, 65):
             qs = rs.randint(0, n, count).astype(np.int32)
             lo = rs.randint(0, 40, count).astype(np.int32)
             hi = np.maximum(qs - 50, 0).astype(np.int32)
-            hi[::11] = lo[::11]                                        # empty ranges, also as the first scan of a chunk (index 0, 33, 66 ...)
-            hi[32] = lo[32]; hi[31] = lo[31]
+            hi[::11] = lo[::11]                                        # empty ranges, also as the first or last scan of a chunk
+            for k in (59, 60, 62, 63, 64): hi[k] = lo[k]
             single = [e.detect_full_range(int(q), int(a), int(b)) if b > a else (-1, 0, 1e7) for q, a, b in zip(qs, lo, hi)]
-            for spl in (4, 3, 1):
+            for spl in (16, 12, 10, 4, 3, 1):
                 nn, sh, d = e.detect_full_stream(qs, lo, hi, spl, 2)
                 for i, a in enumerate(single):
                     assert (a[0], a[1]) == (nn[i], sh[i]) and np.float64(a[2]).view(np.uint64) == d[i].view(np.uint64), (count, spl, i)
