@@ -2175,22 +2175,24 @@ int scl_device_name(const scl_engine *e, char *buf, int buflen)
 // ---- hooks for the sharded front (engine_internal.hpp) ---------------------------------------------------------
 namespace scl {
 
-int eng_stage_from_peer(scl_engine *dst, int j, scl_engine *src, int src_slot)
+int eng_stage_from_peer(scl_engine *dst, int j, scl_engine *src, int src_slot, int count)
 {
-    if (!dst || !src || j < 0 || j >= scl_engine::kStage) return SCL_ERR_INVALID_ARG;
+    if (!dst || !src || count < 1 || j < 0 || j + count > scl_engine::kStage) return SCL_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(dst->mu);
-    if (src_slot < 0 || src_slot >= src->n) return fail(dst, SCL_ERR_OUT_OF_RANGE, "stage_from_peer: source slot out of range");
+    if (src_slot < 0 || src_slot + count > src->n) return fail(dst, SCL_ERR_OUT_OF_RANGE, "stage_from_peer: source slot out of range");
     (void)hipSetDevice(dst->device);
-    const size_t tile = (size_t)dst->RG * dst->S, S = (size_t)dst->S, R4 = (size_t)dst->R4;
+    const size_t tile = (size_t)dst->RG * dst->S, S = (size_t)dst->S, R4 = (size_t)dst->R4, m = (size_t)count;
     const size_t d = (size_t)dst->cap + (size_t)j, s = (size_t)src_slot;
-    SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_desc + d * tile, dst->device, src->d_desc + s * tile, src->device, sizeof(float4) * tile, dst->stream));
-    SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_vkey + d * S, dst->device, src->d_vkey + s * S, src->device, sizeof(double) * S, dst->stream));
-    SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_norm + d * S, dst->device, src->d_norm + s * S, src->device, sizeof(double) * S, dst->stream));
-    SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_rkey + d * R4, dst->device, src->d_rkey + s * R4, src->device, sizeof(float) * R4, dst->stream));
-    SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_hdesc + d * dst->hstride, dst->device, src->d_hdesc + s * src->hstride, src->device, sizeof(uint2) * src->hstride, dst->stream));
-    SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_kmask + d * 8, dst->device, src->d_kmask + s * 8, src->device, sizeof(unsigned int) * 8, dst->stream));
-    SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_hkey + d * dst->hkw, dst->device, src->d_hkey + s * src->hkw, src->device, sizeof(unsigned short) * src->hkw, dst->stream));
-    dst->staged[j] = true;
+    // consecutive slots are consecutive rows of every array on both sides (the strides agree: same grid): one copy per array
+    if (dst->hstride != src->hstride || dst->hkw != src->hkw) return fail(dst, SCL_ERR_INVALID_ARG, "stage_from_peer: the shards' layouts differ");
+    SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_desc + d * tile, dst->device, src->d_desc + s * tile, src->device, sizeof(float4) * tile * m, dst->stream));
+    SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_vkey + d * S, dst->device, src->d_vkey + s * S, src->device, sizeof(double) * S * m, dst->stream));
+    SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_norm + d * S, dst->device, src->d_norm + s * S, src->device, sizeof(double) * S * m, dst->stream));
+    SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_rkey + d * R4, dst->device, src->d_rkey + s * R4, src->device, sizeof(float) * R4 * m, dst->stream));
+    SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_hdesc + d * dst->hstride, dst->device, src->d_hdesc + s * src->hstride, src->device, sizeof(uint2) * src->hstride * m, dst->stream));
+    SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_kmask + d * 8, dst->device, src->d_kmask + s * 8, src->device, sizeof(unsigned int) * 8 * m, dst->stream));
+    SCL_HIP(dst, hipMemcpyPeerAsync(dst->d_hkey + d * dst->hkw, dst->device, src->d_hkey + s * src->hkw, src->device, sizeof(unsigned short) * src->hkw * m, dst->stream));
+    for (int i = 0; i < count; ++i) dst->staged[j + i] = true;
     return SCL_OK;
 }
 

@@ -55,7 +55,9 @@ struct scl_engine {
     // database by every kernel, the multi-query launches included.  Query id -1-j = staging slot j
     // (SCL_QUERY_STAGED = -1 = slot 0, the public one; the sharded front uses the others for keyframes that
     // live on another device).
-    static constexpr int kStage = 12;
+    // (0: the public staged query; 1..9: the sharded front's passes in flight and blocking calls; 12..75: the front's stream form, one
+    // block of 64 scans whose keyframes live on another shard)
+    static constexpr int kStage = 76;
     bool staged[kStage] = {false};
 
     // scratch
@@ -143,7 +145,7 @@ namespace scl {
 
 // copy keyframe `src_slot` of `src` (descriptor tile, sector key, norms, ring key) into staging slot j of `dst`
 // (query id -1-j); device-to-device, ordered on dst's stream.  src == dst is allowed.
-int eng_stage_from_peer(scl_engine *dst, int j, scl_engine *src, int src_slot);
+int eng_stage_from_peer(scl_engine *dst, int j, scl_engine *src, int src_slot, int count = 1);   // count consecutive rows: slots src_slot.. to staging rows j..
 // wire descriptor -> staging slot j
 int eng_stage_values(scl_engine *e, int j, const float *values);
 // ring-key top-k in [lo, hi) + SC distance of those k: enqueue on the engine's stream / wait and unpack

@@ -42,6 +42,8 @@ constexpr int kMaxShards = 16;
 constexpr int kFrontSlots = 8;                             // full-DB passes in flight at the front (= the shards' slots)
 constexpr unsigned long long kNoKey = ~0ull;
 static_assert(1 + kFrontSlots < scl_engine::kStage, "staging slots: 0 public, 1..8 passes in flight, 9 blocking calls");
+constexpr int kStreamStage0 = 12, kStreamBlock = 64;       // staging rows of the stream form's block
+static_assert(kStreamStage0 > 1 + kFrontSlots && kStreamStage0 + kStreamBlock <= scl_engine::kStage, "staging rows of the stream form");
 
 int local_count(int global_hi, int c, int G)
 {   // number of local slots l of shard c with l * G + c < global_hi
@@ -710,27 +712,78 @@ int front_detect_full_stream(scl_engine *e, const int *queries, const int *lo, c
     ShardedFront *f = e->front;
     for (int t = 0; t < kFrontSlots; ++t)
         if (f->pass[t].busy) return ffail(e, SCL_ERR_INVALID_ARG, "detect_full_stream: collect the passes in flight first");
-    const int spl = scans_per_launch < 1 ? 1 : (scans_per_launch > kMaxQueryBatch ? kMaxQueryBatch : scans_per_launch);
-    int depth = launches_in_flight < 1 ? 1 : launches_in_flight;
-    if (depth * spl > kFrontSlots) depth = kFrontSlots / spl;
-    std::vector<int> tk((size_t)n_queries);
-    int submitted = 0, collected = 0;
-    auto drain = [&]() {
-        const std::string first_error = e->last_error;
-        for (int i = collected; i < submitted; ++i) { int a, b; double x; (void)collect_locked(e, tk[(size_t)i], &a, &b, &x); }
-        e->last_error = first_error;
-    };
-    while (collected < n_queries) {
-        while (submitted < n_queries) {
-            const int m = n_queries - submitted < spl ? n_queries - submitted : spl;
-            if ((submitted - collected) + m > depth * spl) break;
-            const int rc = submit_many_locked(e, queries + submitted, lo + submitted, hi + submitted, m, tk.data() + submitted);
-            if (rc) { drain(); return rc; }
-            submitted += m;
+    // Block form (winners merged on the host whatever the exchange mode of the single passes: the results of a stream go to host arrays
+    // anyway): the scans go to the shards in blocks of 64 -- the keyframes of a block are copied to the
+    // staging rows of the shards that do not hold them, then every shard runs its own stream form over the block (up to 16 scans per
+    // launch, one exact pass per chunk: scl_detect_full_stream of the shard, one host thread per shard), and the per-shard winners of
+    // the block are merged as one database's arg-min would (smallest distance, ties to the lowest global index).
+    const int G = f->G;
+    const int spl_s = scans_per_launch < 1 ? 1 : scans_per_launch;              // the shard clamps it to what its grid takes per launch
+    std::vector<int> q((size_t)G * kStreamBlock), l((size_t)G * kStreamBlock), h((size_t)G * kStreamBlock);
+    std::vector<int> nn((size_t)G * kStreamBlock), sh((size_t)G * kStreamBlock);
+    std::vector<double> dd((size_t)G * kStreamBlock);
+    for (int b0 = 0; b0 < n_queries; b0 += kStreamBlock) {
+        const int m = n_queries - b0 < kStreamBlock ? n_queries - b0 : kStreamBlock;
+        // Staging rows in the order (owner shard, position in the block): keyframes that follow each other on their owner -- the
+        // usual case, a backlog of the newest keyframes: global slots g, g + 1, ... are slots s, s + 1 on each owner -- land in
+        // consecutive rows, and a run of them travels to a shard in one copy per array instead of one per keyframe.
+        int row_of[kStreamBlock], next_row = kStreamStage0;
+        for (int o = 0; o < G; ++o) {
+            int run_row = -1, run_slot = -1, run_len = 0;
+            auto flush = [&]() -> int {
+                for (int c = 0; c < G && run_len > 0; ++c) {
+                    if (c == o) continue;
+                    const int rc = eng_stage_from_peer(f->sh[c], run_row, f->sh[o], run_slot, run_len);
+                    if (rc) return child_fail(e, f->sh[c], rc, "stage queries on shard");
+                }
+                run_len = 0;
+                return SCL_OK;
+            };
+            for (int i = 0; i < m; ++i) {
+                const int g = queries[b0 + i];
+                if (g < 0 || g % G != o) continue;
+                if (g >= f->n) return ffail(e, SCL_ERR_OUT_OF_RANGE, "query keyframe out of range");
+                const int slot = g / G;
+                row_of[i] = next_row++;
+                if (run_len > 0 && slot == run_slot + run_len) { ++run_len; continue; }
+                int rc = flush();
+                if (rc) return rc;
+                run_row = row_of[i]; run_slot = slot; run_len = 1;
+            }
+            const int rc = flush();
+            if (rc) return rc;
         }
-        const int rc = collect_locked(e, tk[(size_t)collected], nn_idx + collected, shift + collected, dist + collected);
-        ++collected;
-        if (rc) { drain(); return rc; }
+        for (int i = 0; i < m; ++i) {
+            const int g = queries[b0 + i];
+            if (g < 0 && (g != SCL_QUERY_STAGED || !f->staged0)) return ffail(e, SCL_ERR_INVALID_ARG, "no staged query (call scl_stage_query first)");
+            const int glo = lo[b0 + i] < 0 ? 0 : lo[b0 + i], ghi = hi[b0 + i] > f->n ? f->n : hi[b0 + i];
+            for (int c = 0; c < G; ++c) {
+                const size_t k = (size_t)c * kStreamBlock + (size_t)i;
+                q[k] = g < 0 ? SCL_QUERY_STAGED : (c == g % G ? g / G : -1 - row_of[i]);
+                l[k] = local_count(glo, c, G); h[k] = local_count(ghi, c, G);
+            }
+        }
+        int rcs[kMaxShards] = {0};
+        auto run = [&](int c) {
+            const size_t k = (size_t)c * kStreamBlock;
+            rcs[c] = scl_detect_full_stream(f->sh[c], q.data() + k, l.data() + k, h.data() + k, m, spl_s, launches_in_flight,
+                                            nn.data() + k, sh.data() + k, dd.data() + k);
+        };
+        std::vector<std::thread> pool;
+        for (int c = 1; c < G; ++c) pool.emplace_back(run, c);
+        run(0);
+        for (auto &t : pool) t.join();
+        for (int c = 0; c < G; ++c) if (rcs[c]) return child_fail(e, f->sh[c], rcs[c], "stream on shard");
+        for (int i = 0; i < m; ++i) {
+            int bi = -1, bs = 0; double bd = kBigDist;
+            for (int c = 0; c < G; ++c) {
+                const size_t k = (size_t)c * kStreamBlock + (size_t)i;
+                if (nn[k] < 0) continue;
+                const int g = nn[k] * G + c;
+                if (dd[k] < bd || (dd[k] == bd && (bi < 0 || g < bi))) { bd = dd[k]; bi = g; bs = sh[k]; }
+            }
+            nn_idx[b0 + i] = bi; shift[b0 + i] = bs; dist[b0 + i] = bd;
+        }
     }
     return SCL_OK;
 }
