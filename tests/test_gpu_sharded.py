@@ -82,6 +82,12 @@ def test_sharded_engine_equals_single_engine_and_oracle(G):
     for spl, depth in ((1, 1), (2, 2), (4, 2), (3, 1)):
         a = sh.detect_full_stream(qs, lo, hi, spl, depth); b = one.detect_full_stream(qs, lo, hi, spl, depth)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2].view(np.uint64), b[2].view(np.uint64))
+    # a backlog in ascending order across three blocks of the front's stream form (runs of keyframes that follow each other on their
+    # owner are staged with one copy per array), the staged external query in the middle of it, a keyframe asked for twice
+    qb = np.concatenate([np.arange(n - 150, n - 80), [-1], np.arange(n - 80, n), [n - 3, n - 3]]).astype(np.int32)
+    hb = np.where(qb >= 0, qb - 100, n - 7).astype(np.int32)
+    a = sh.detect_full_stream(qb, 0, hb, 16, 2); b = one.detect_full_stream(qb, 0, hb, 16, 2)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2].view(np.uint64), b[2].view(np.uint64))
     tk = sh.detect_full_submit_many(qs[:6], lo[:6], hi[:6]); tk1 = one.detect_full_submit_many(qs[:6], lo[:6], hi[:6])
     for t, t1 in reversed(list(zip(tk, tk1))):              # collected in any order
         a = sh.detect_full_collect(t); b = one.detect_full_collect(t1)
