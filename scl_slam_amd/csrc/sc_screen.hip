@@ -926,11 +926,23 @@ hipError_t launch_sc_select_batch(const ScreenBatch &sb, hipStream_t stream)
 // 16 scans per launch.  80 x 180 (96 padded rings, 19 shifts): three ring thirds, the shifts in two passes of 13 and 6 rows that
 // share the keyframe's fragment (pass p reads the scan 13 p sectors further back), 12 scans per launch (12 x 183 sectors x 64 B =
 // 141 KB of LDS).
+// Waves per workgroup (one workgroup per CU: the scans fill the LDS) and ring slots of the fragment loads; -D overrides for experiments.
+// 64 x 120: 113 registers -> 16 waves (four per SIMD) hide the chains that two per SIMD left open (products 54 -> 48 us per 16 scans;
+// six ring slots instead of ten: 1 us slower).  80 x 180: 156 registers; twelve waves measured the same as eight.
+#ifndef S2RS_A
+#define S2RS_A 10
+#endif
+#ifndef S2WV_B
+#define S2WV_B 8
+#endif
+#ifndef S2WV_A
+#define S2WV_A 16
+#endif
 template <int RG, int S, int W> struct S2Cfg;
-template <> struct S2Cfg<16, 120, 13> { static constexpr int NP = 2, NPASS = 1, STEPS = 4, NQ = 16, RS = 10; };   // RS: ring slots of fragment loads (RS - 1 in flight);
-template <> struct S2Cfg<20, 180, 19> { static constexpr int NP = 3, NPASS = 2, STEPS = 4, NQ = 12, RS = 9; };    // S / STEPS iterations per keyframe = a multiple of RS
+template <> struct S2Cfg<16, 120, 13> { static constexpr int NP = 2, NPASS = 1, STEPS = 4, NQ = 16, RS = S2RS_A, WV = S2WV_A; };   // RS: ring slots of fragment loads (RS - 1 in flight);
+template <> struct S2Cfg<20, 180, 19> { static constexpr int NP = 3, NPASS = 2, STEPS = 4, NQ = 12, RS = 9, WV = 8; };    // S / STEPS iterations per keyframe = a multiple of RS
 constexpr int kS2PassRows = 13;                    // shift rows per pass: row m of pass p = shift W - 1 - 13 p - m
-constexpr int kS2Waves = 8;                        // waves per workgroup of the second form (one workgroup per CU: LDS)
+
 // LDS image of the scans (see above): quad stride in bytes, 2 mod 4 sixteen-byte slots
 constexpr int s2_quad(int S, int STEPS) { return (((S + STEPS - 1) * 256 / 16) % 4 == 2) ? (S + STEPS - 1) * 256 : (S + STEPS - 1) * 256 + 32; }
 template <int RG, int S, int W> constexpr size_t s2_lds() { return (size_t)(S2Cfg<RG, S, W>::NQ / 4) * s2_quad(S, S2Cfg<RG, S, W>::STEPS); }
@@ -950,7 +962,7 @@ __device__ __forceinline__ unsigned int ror1_u32(unsigned int v)
 __device__ __forceinline__ u32x4 ror1_frag(const u32x4 v) { return u32x4{ror1_u32(v[0]), ror1_u32(v[1]), ror1_u32(v[2]), ror1_u32(v[3])}; }
 
 template <int RG, int S, int W>
-__global__ __launch_bounds__(kS2Waves * kWave, 1) void sc_screen2_kernel(Screen2Args fa)
+__global__ __launch_bounds__((S2Cfg<RG, S, W>::WV * kWave), 1) void sc_screen2_kernel(Screen2Args fa)
 {
     using C = S2Cfg<RG, S, W>;
     constexpr int NP = C::NP, NPASS = C::NPASS, STEPS = C::STEPS, NQ = C::NQ;
@@ -970,8 +982,8 @@ __global__ __launch_bounds__(kS2Waves * kWave, 1) void sc_screen2_kernel(Screen2
     const int b = (int)blockIdx.x, xcd = b & 7, jx = b >> 3;
     const int part = jx % NP;
     const int gi = (jx / NP) * 8 + xcd;                // 0 .. nwg / NP - 1
-    const int waves_part = (fa.nwg / NP) * kS2Waves;
-    const int gw = gi * kS2Waves + wave;
+    const int waves_part = (fa.nwg / NP) * C::WV;
+    const int gw = gi * C::WV + wave;
 
     // ---- stage the scans' ring part (the last STEPS - 1 sectors repeat the first) ----
     for (int idx = threadIdx.x; idx < NQ * ROWS * 4; idx += blockDim.x) {
@@ -1353,7 +1365,7 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
             };
             if (side == 2 && (e = fork()) != hipSuccess) return e;
             constexpr size_t lds2 = s2_lds<RG, S, W>();
-            hipLaunchKernelGGL((sc_screen2_kernel<RG, S, W>), dim3(nwg), dim3(kS2Waves * kWave), lds2, stream, f2);
+            hipLaunchKernelGGL((sc_screen2_kernel<RG, S, W>), dim3(nwg), dim3(S2Cfg<RG, S, W>::WV * kWave), lds2, stream, f2);
             if ((e = hipGetLastError()) != hipSuccess) return e;
             if (side == 1 && (e = fork()) != hipSuccess) return e;
             static const int tail_env = [] { const char *e = getenv("SCL_SCREEN_TAIL"); return e ? atoi(e) : 1; }();   // 0: finish and alignment as two launches
