@@ -1034,6 +1034,7 @@ __global__ __launch_bounds__((S2Cfg<RG, S, W>::WV * kWave), 1) void sc_screen2_k
     for (int sl = 0; sl < DA; ++sl) issueA(sl);
     int b_cur = first_shift(0), b_nxt = first_shift(1);
     const unsigned int q_lds = (unsigned int)((cq >> 2) * QUAD + (cq & 3) * 64 + j4 * 16);
+    const int up16 = ((lane + 16) & 63) * 4;           // ds_bpermute address of the lane that holds the next four rows of this column
     for (int k = 0; k < nk; ++k) {
         // scan sector that meets keyframe sector 0 in pass p: first shift + W - 1 - 13 p
         unsigned int offB[NPASS];
@@ -1069,15 +1070,16 @@ __global__ __launch_bounds__((S2Cfg<RG, S, W>::WV * kWave), 1) void sc_screen2_k
                 if (xb == RS - DA) pA = (r == NIT / RS - 1) ? base_nxt : pA;
                 issueA((xb + RS - 1) % RS);
                 readB(bfr[(xb + 1) % NB]);                                       // the next iteration's B fragments (past the end: unused)
-                u32x4 af[STEPS];
-                af[0] = ringA[xb];
-#pragma unroll
-                for (int u = 1; u < STEPS; ++u) af[u] = ror1_frag(af[u - 1]);
+                // The fragment is NOT rotated between the k-steps of an iteration: k-step u (scan sector 4 t + u) meets fragment row m =
+                // keyframe sector 4 t + m, so row m of acc[.][u] collects what the rotated fragment would have put in row m - u -- the
+                // same products in the same order, in another row; the rows are shifted back once per keyframe (below) instead of
+                // twelve DPP moves per iteration.
+                const h8 af = __builtin_bit_cast(h8, ringA[xb]);
 #pragma unroll
                 for (int u = 0; u < STEPS; ++u)
 #pragma unroll
                     for (int p = 0; p < NPASS; ++p)
-                        acc[p][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, af[u]), bfr[xb % NB][p][u], acc[p][u], 0, 0, 0);
+                        acc[p][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfr[xb % NB][p][u], acc[p][u], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -1088,9 +1090,18 @@ __global__ __launch_bounds__((S2Cfg<RG, S, W>::WV * kWave), 1) void sc_screen2_k
             const bool ok = q_live && ci >= 0 && ci < sq.n;
 #pragma unroll
             for (int p = 0; p < NPASS; ++p) {
+                // row s of the tile = sum over u of row s + u of acc[p][u]: rows 4 j + i + u of this lane while i + u <= 3, of the lane
+                // 16 further on (rows 4 (j + 1) ..) beyond; rows 13 .. 15 are not shifts (W - 1 - 13 p - m < 0 there) and take whatever comes
                 f4v sum = acc[p][0];
 #pragma unroll
-                for (int u = 1; u < STEPS; ++u) sum += acc[p][u];
+                for (int u = 1; u < STEPS; ++u) {
+                    float nx[STEPS - 1];
+#pragma unroll
+                    for (int e2 = 0; e2 < u; ++e2)
+                        nx[e2] = __int_as_float(__builtin_amdgcn_ds_bpermute(up16, __float_as_int(acc[p][u][e2])));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sum[i] += (i + u <= 3) ? acc[p][u][(i + u) & 3] : nx[(i + u - 4) & 3];
+                }
                 if (ok) *reinterpret_cast<f4v *>(fa.part + ((((size_t)c16 * (size_t)ab.pair_stride + (size_t)ci) * NP + part) * NPASS + p) * 16 + 4 * j4) = sum;
             }
         }
