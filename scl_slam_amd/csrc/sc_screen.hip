@@ -908,7 +908,11 @@ hipError_t launch_sc_select_batch(const ScreenBatch &sb, hipStream_t stream)
 // line: the second finds the line in that XCD's L2); the two partial sums of a pair meet in sc_screen2_finish_kernel.
 // With the rows counted the other way -- row m <-> shift t = 12 - m, A[m][(y, r)] = K[r][(y + m) mod S], the scan rotated by
 // b_q + 12 -- the fragment of step y is SIXTEEN CONSECUTIVE SECTORS y .. y+15 of the keyframe (rows 13 .. 15 are spare), and
-// rotating its rows by one (DPP row_ror:15, four moves) gives the fragment of step y + 1: ONE load serves FOUR k-steps.  The
+// the fragment of step y + u is the same sixteen sectors one row further on: ONE load serves FOUR k-steps.  The rows are not even
+// moved: step y + u multiplies the UNROTATED fragment, so row m of accumulator u collects what belongs to row m - u (the same
+// products in the same order), and the four accumulators are joined once per keyframe with their rows shifted back (row s =
+// sum over u of row s + u: three of the sixteen lane groups' values come from the lane 16 further on, ds_bpermute) -- until then
+// twelve DPP row rotations per iteration made the VALU the busiest unit of the kernel.  The
 // load reads the keyframe's chunk-major image (kernels.hpp, hdesc2: [half][chunk j][sector] x 16 B, 16 sectors repeated at the
 // end), where lane (m, j) = (lane & 15, lane >> 4) finds rings 8j .. 8j+7 of sector y + m at 16 (y + m): the 16 lanes of a
 // chunk read 256 consecutive bytes, no wrap, no address arithmetic (scalar base + 64 B per iteration).  (From the
@@ -954,12 +958,6 @@ struct Screen2Args {
     int u_lo, u_n;                                 // union of the scans' ranges (database slots)
     int nwg;                                       // workgroups of the products (a multiple of 8 x ring parts)
 };
-
-__device__ __forceinline__ unsigned int ror1_u32(unsigned int v)
-{   // rotate the 16 lanes of every row LEFT by one (row_ror:15): lane i <- lane (i + 1) & 15
-    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x12F, 0xf, 0xf, true);   // every lane has a source: `old` is never read
-}
-__device__ __forceinline__ u32x4 ror1_frag(const u32x4 v) { return u32x4{ror1_u32(v[0]), ror1_u32(v[1]), ror1_u32(v[2]), ror1_u32(v[3])}; }
 
 template <int RG, int S, int W>
 __global__ __launch_bounds__((S2Cfg<RG, S, W>::WV * kWave), 1) void sc_screen2_kernel(Screen2Args fa)
