@@ -533,7 +533,7 @@ def main():
         }
         if world == 1 and not args.no_secondary:
             out["secondary"] = {}
-            for name, fn in (("icp_verification", lambda: secondary_icp(eng)), ("sc_distance_80x180", lambda: secondary_80x180(local_rank)),
+            for name, fn in (("sc_distance_80x180", lambda: secondary_80x180(local_rank)), ("icp_verification", lambda: secondary_icp(eng)),
                                  ("livox_stream_80x180", lambda: secondary_livox_stream(local_rank))):
                 try:
                     out["secondary"][name] = fn()
