@@ -936,6 +936,9 @@ hipError_t launch_sc_select_batch(const ScreenBatch &sb, hipStream_t stream)
 #ifndef S2RS_A
 #define S2RS_A 10
 #endif
+#ifndef S2RS_B
+#define S2RS_B 9
+#endif
 #ifndef S2WV_B
 #define S2WV_B 8
 #endif
