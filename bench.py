@@ -129,7 +129,7 @@ def _native_oracle():
         return None
 
 
-def cpu_baseline(descs, n_pairs_hint, budget_s=10.0):
+def cpu_baseline(descs, n_pairs_hint, budget_s=8.0):
     """Reference-shaped CPU path (oracle/sc_oracle.c: copy per shift, norms twice, descriptor.h:1538-1569,
     + the ring-key scan) on this box's host cores.  Headline `value`: 1 thread, like the reference (all omp
     pragmas of the SC code are commented out, descriptor.h:1417-1517).  Variants: every core this process may
@@ -159,18 +159,37 @@ def cpu_baseline(descs, n_pairs_hint, budget_s=10.0):
                 break
         return done, time.perf_counter() - t0
 
-    def sample_mt(db, fast, budget):
-        # one call = the history scored against several queries' worth of candidates, so that every thread of the pool
-        # gets >= ~100 pairs per call and thread start-up does not dominate on a 256-core host
-        tiles = max(1, (128 * threads + n_hist - 1) // n_hist)
+    def sample_mt(db, fast, nthreads, budget):
+        # one call = the history scored against several queries' worth of candidates: every thread of the (persistent) pool
+        # gets >= 2 000 pairs per call, so that waking the team is noise on a 256-core host
+        tiles = max(1, (2000 * nthreads + n_hist - 1) // n_hist)
         cand = np.tile(np.arange(0, n_hist, dtype=np.int32), tiles)
+        db.distance_batch_mt(n_db - 1, cand[:max(64 * nthreads, 1024)], fast, nthreads)      # makes / resizes the pool, warms the scratch
         reps, t0 = 0, time.perf_counter()
         while True:
-            db.distance_batch_mt(n_db - 1 - (reps % N_EXCLUDE), cand, fast, threads)
+            db.distance_batch_mt(n_db - 1 - (reps % N_EXCLUDE), cand, fast, nthreads)
             reps += 1
             if time.perf_counter() - t0 >= budget:
                 break
         return reps * cand.size, time.perf_counter() - t0
+
+    def sweep(db, budget_each):
+        """reference-shaped evaluation on 64 / 128 / 256 threads (and every core of the affinity mask): the best count is the
+        all-core figure; the copy-free restatement at that count."""
+        counts = sorted({c for c in (64, 128, 256, threads) if c <= threads} or {threads})
+        tried, best = {}, None
+        for c in counts:
+            pairs, dtm = sample_mt(db, False, c, budget_each)
+            tried[str(c)] = pairs / dtm
+            if best is None or pairs / dtm > best[1]:
+                best = (c, pairs / dtm, pairs, dtm)
+        c = best[0]
+        pf, dtf = sample_mt(db, True, c, budget_each)
+        return ({"value": best[1], "unit": "pairs/s", "cores": c, "threads_tried": tried,
+                 "sample": f"{best[2]} pairs in {best[3]:.1f} s on {c} threads (persistent pool, >= 2000 pairs per thread and call, "
+                           f"per-thread scratch: no allocation per pair / shift / column; the per-shift matrix copy is kept)"},
+                {"value": pf / dtf, "unit": "pairs/s", "cores": c,
+                 "sample": f"{pf} pairs in {dtf:.1f} s on {c} threads, copy-free restatement (norms and keys once, shifts by index)"})
 
     db = ob.OracleDB(cfg)
     db.save_bulk(descs[:n_db])
@@ -180,12 +199,10 @@ def cpu_baseline(descs, n_pairs_hint, budget_s=10.0):
                      f"reference-shaped sco_distance (per-shift matrix copy, double norm evaluation) "
                      f"+ ring-key scan per query, single thread, -O3 (no -march, as the reference builds)",
            "cpu_model": _cpu_model(), "host_cores_available": os.cpu_count(), "affinity_cores": threads}
-    for name, fast in (("all_cores_reference_shaped", False), ("all_cores_copy_free", True)):
-        pairs, dtm = sample_mt(db, fast, 3.0)
-        res[name] = {"value": pairs / dtm, "unit": "pairs/s", "cores": threads,
-                     "sample": f"{pairs} pairs in {dtm:.1f} s on {threads} threads (std::thread-style pool over candidates)"}
+    res["all_cores_reference_shaped"], res["all_cores_copy_free"] = sweep(db, 2.0)
+    res["all_cores_over_one_thread"] = res["all_cores_reference_shaped"]["value"] / res["value"]
     db.close()
-    # the same three figures from a -march=native build made on this host (BASELINE.md §2's flags)
+    # the same figures from a -march=native build made on this host (BASELINE.md §2's flags)
     native = _native_oracle()
     if native:
         saved_lib, saved_path = ob._lib, ob.LIB
@@ -193,14 +210,12 @@ def cpu_baseline(descs, n_pairs_hint, budget_s=10.0):
             ob._lib, ob.LIB = None, native
             dbn = ob.OracleDB(cfg)
             dbn.save_bulk(descs[:n_db])
-            done, dt = sample_1thread(dbn, 4.0)
+            done, dt = sample_1thread(dbn, 3.0)
             res["march_native_1thread"] = {"value": done / dt, "unit": "pairs/s", "cores": 1,
                                            "sample": f"{done} pairs in {dt:.1f} s, gcc -O3 -march=native -ffp-contract=off"}
-            for name, fast in (("march_native_all_cores_reference_shaped", False), ("march_native_all_cores_copy_free", True)):
-                pairs, dtm = sample_mt(dbn, fast, 3.0)
-                res[name] = {"value": pairs / dtm, "unit": "pairs/s", "cores": threads,
-                             "sample": f"{pairs} pairs in {dtm:.1f} s on {threads} threads"}
+            res["march_native_all_cores_reference_shaped"], res["march_native_all_cores_copy_free"] = sweep(dbn, 1.5)
             dbn.close()
+            ob._lib.sco_pool_shutdown()
         finally:
             ob._lib, ob.LIB = saved_lib, saved_path
             try:
@@ -263,6 +278,80 @@ def secondary_icp(eng, n_cand=25, n_pts=100000):
                                       "note": "SURVEY 8(d): (n_src + n_tgt) * 16 B per iteration; wall time of the whole call"}}
         out[name] = res
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# secondary: the EXACT all-pairs distance matrix (every pair through the fp64 kernel), one blocking scan, survivors
+# ------------------------------------------------------------------------------------------------
+def secondary_exact_all_pairs(eng, n_elig, n_query, queries=32):
+    """north_star's "column-shifted SC distance matrix over the keyframe database": every (scan, keyframe) pair gets the
+    reference's fp64 distance and shift (descriptor.h:1538-1569) from the exact wave kernel -- no screening.  Bit-identical
+    to the checker (tests/test_gpu_sc_distance.py compares uint64 views).  Priced at SURVEY 8(d)'s 31 680 B per pair."""
+    eng.sc_distance_matrix(n_elig + np.arange(4, dtype=np.int32), 0, n_elig)               # warm-up
+    eng.profile_reset(); eng.profile_enable(2)
+    qs = (n_elig + (np.arange(queries) % n_query)).astype(np.int32)
+    t0 = time.perf_counter()
+    dist, shift = eng.sc_distance_matrix(qs, 0, n_elig)
+    dt = time.perf_counter() - t0
+    eng.profile_enable(0)
+    prof = eng.profile()
+    pairs = queries * n_elig
+    k_ms = prof["sc_distance_ms"] / max(1, prof["sc_distance_launches"])
+    k_pairs = prof["sc_distance_pairs"] / max(1, prof["sc_distance_launches"])
+    ach = k_pairs * ALGO_BYTES_PER_PAIR / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    flops = 3 * S * S + 13 * S * 2 * R                                                      # SURVEY 8(d): 242 880 per pair
+    return {"workload": f"{queries} scans x {n_elig} keyframes, 64x120: the fp64 distance and shift of EVERY pair (scl_sc_distance_matrix, "
+                        f"results copied to the host)",
+            "value": pairs / dt, "unit": "pairs/s", "ms_per_scan": dt / queries * 1e3, "dtype": "f64",
+            "finite_distances": int(np.isfinite(dist).sum()),
+            "kernel_ms": {"sc_distance_wave_kernel_launch": k_ms, "pairs_per_launch": k_pairs},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "bytes_per_pair": ALGO_BYTES_PER_PAIR, "kernel": "sc_distance_wave_kernel<16,13,4,120> (exact fp64, one wave per pair); HIP events around every launch",
+                         "fp64_vector_frac": (k_pairs * flops / (k_ms * 1e-3) / 1e12 / 78.6) if k_ms > 0 else 0.0,
+                         "note": "SURVEY 8(d): 4 R S + 8 S bytes per pair, one scan per database pass; fp64_vector_frac = the reference's "
+                                 "242 880 flop per pair against 78.6 TFLOP/s"}}
+
+
+def secondary_blocking_scan(eng, n_elig, n_query, scans=300):
+    """one incoming scan, blocking: scl_detect_full_range call -> result on the host (ring-key top-k + screening + exact pass)"""
+    lat = []
+    for i in range(scans + 20):
+        t0 = time.perf_counter()
+        eng.detect_full_range(int(n_elig + i % n_query), 0, n_elig)
+        if i >= 20:
+            lat.append((time.perf_counter() - t0) * 1e6)
+    lat = np.array(lat)
+    return {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)), "mean": float(lat.mean()), "scans": scans,
+            "pairs_per_s_at_p50": n_elig / (float(np.percentile(lat, 50)) * 1e-6),
+            "note": "microseconds per blocking one-scan call over the whole database (no batch to share the database pass with)"}
+
+
+def secondary_adversarial_survivors(device, shard, queries, n_elig, frac=0.05, scans=256):
+    """The headline rate holds while few keyframes survive the screening.  Here `frac` of the database are noisy rolled copies
+    of the incoming scan -- all within the screening margin (2 x 1.5e-3) of the winner -- so the exact pass scores that many
+    keyframes per scan.  Same pass, same bit-exact winner; the rate is what a place with many near-identical views costs."""
+    from scl_slam_amd import ScanContextEngine
+    rs = np.random.RandomState(23)
+    db = shard.copy()
+    base = queries[1].copy()                                              # (query 1 is not a planted revisit)
+    planted = rs.choice(n_elig, size=int(n_elig * frac), replace=False)
+    for j in planted:
+        d = np.roll(base, int(rs.randint(0, S)), axis=1)
+        db[j] = np.clip(d + np.float32(rs.uniform(1e-4, 2e-3)) * rs.standard_normal(d.shape).astype(np.float32) * (d > 0), 0, None)
+    eng = ScanContextEngine(num_ring=R, num_sector=S, num_candidates=3, num_exclude_recent=N_EXCLUDE, device=device, initial_capacity=n_elig + 64)
+    eng.save_bulk(db); eng.save_bulk(queries[:N_EXCLUDE])
+    del db
+    qs = np.full(scans, n_elig + 1, dtype=np.int32)
+    eng.detect_full_stream(qs[:32], 0, n_elig, 16, 2)
+    eng.survivor_stats(reset=True)
+    t0 = time.perf_counter()
+    nn, sh, dd = eng.detect_full_stream(qs, 0, n_elig, 16, 2)
+    dt = time.perf_counter() - t0
+    q, tot, mx = eng.survivor_stats()
+    eng.close()
+    return {"workload": f"{int(frac * 100)} % of the {n_elig} keyframes within 2 eps of the winner ({len(planted)} planted near-copies of the scan), {scans} scans",
+            "value": n_elig * scans / dt, "unit": "pairs/s", "ms_per_scan": dt / scans * 1e3,
+            "survivors_per_scan": {"mean": tot / max(1, q), "max": mx}, "winner_distance": float(dd[0]), "winner_is_planted": bool(int(nn[0]) in set(planted.tolist()))}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -434,6 +523,7 @@ def main():
     warm_scans, timed_scans = args.warmup * spl, args.steps * spl
     run(0, warm_scans)
     eng.profile_reset()
+    eng.survivor_stats(reset=True)
     eng.profile_enable(3)          # HIP events around the dominant kernel, one launch in eight (an event pair per launch costs ~8 us)
     times = []
     for rep in range(max(1, args.repeats)):
@@ -457,6 +547,7 @@ def main():
     eng.profile_enable(False)
     prof = eng.profile()
     al_pairs, al_fallbacks = eng.alignment_stats()
+    sv_q, sv_sum, sv_max = eng.survivor_stats()
     elapsed = float(np.median(times))
 
     pairs_per_step = n_elig * world * spl
@@ -491,10 +582,12 @@ def main():
                     f"GPU ({n_local * world} in total; 100k at 8 GPUs), 64x120 SC, full ring-key scan + shifted SC distance over "
                     f"every shard per incoming scan, RCCL min all-reduce on the per-scan (distance, index, shift) winners")
         out = {
-            "metric": "loop-closure candidates/sec (SC-distance pairs scored per second), 10k-keyframe DB per GPU",
+            "metric": "loop-closure candidates/sec: (scan, keyframe) pairs taken through full-database ARG-MIN detection per second "
+                      "(every pair aligned exactly and bounded by the f16 matrix-core screening; only the survivors get the f64 distance), "
+                      "batches of 16 scans, 10k-keyframe DB per GPU",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "ms_per_scan": elapsed / timed_scans * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64 results; f16-operand / f32-accumulate MFMA screening + f64 exact pass on the survivors", "data": "synthetic",
             "repeats": len(times), "ms_per_step_min": min(times) / args.steps * 1e3, "ms_per_step_max": max(times) / args.steps * 1e3,
             "config": {"workload": workload,
                        "step": f"one batch of {spl} incoming scans, each scored against the whole database (one launch group)",
@@ -510,6 +603,13 @@ def main():
             "kernel_ms": {"sc_distance": k1_ms},
             # fastAlignUsingVkey: pairs whose first shift the matrix-core filters left to the exact fp64 evaluation
             "alignment": {"pairs": al_pairs, "exact_fallbacks": al_fallbacks, "fallback_rate": al_fallbacks / max(1, al_pairs)},
+            # what the exact fp64 pass scored: the rate above depends on it (worst case -- every keyframe survives -- is
+            # secondary.exact_all_pairs' rate; secondary.adversarial_survivors is a database with 5 % of the keyframes inside the margin)
+            "survivors_per_scan": {"mean": sv_sum / max(1, sv_q), "max": sv_max, "scans": sv_q,
+                                   "screening_margin": "d~ <= min d~ + 2 x 1.5e-3"},
+            "semantics": "value = pairs through arg-min detection (winner index / shift / f64 distance bit-identical to the CPU restatement); "
+                         "NOT every pair's f64 distance -- that is secondary.exact_all_pairs; a step is 16 scans that arrive together, "
+                         "secondary.detect_full_blocking_us is one scan on its own",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": f"screening launch group of {k1_scans:.0f} scans x {n_elig} keyframes: sc_screen2_kernel (products: one keyframe "
@@ -533,7 +633,11 @@ def main():
         }
         if world == 1 and not args.no_secondary:
             out["secondary"] = {}
-            for name, fn in (("sc_distance_80x180", lambda: secondary_80x180(local_rank)), ("icp_verification", lambda: secondary_icp(eng)),
+            for name, fn in (("exact_all_pairs", lambda: secondary_exact_all_pairs(eng, n_elig, n_query)),
+                             ("detect_full_blocking_us", lambda: secondary_blocking_scan(eng, n_elig, n_query)),
+                             ("sc_distance_80x180", lambda: secondary_80x180(local_rank)),
+                             ("adversarial_survivors", lambda: secondary_adversarial_survivors(local_rank, shard, queries, n_elig)),
+                             ("icp_verification", lambda: secondary_icp(eng)),
                                  ("livox_stream_80x180", lambda: secondary_livox_stream(local_rank))):
                 try:
                     out["secondary"][name] = fn()

@@ -92,10 +92,13 @@ int  scl_destroy(scl_engine *e);
  * keys (exchange = 2; needs every shard on its own device), or on the host from pinned memory (exchange = 1);
  * exchange = 0 picks RCCL when n_devices > 1 and the devices are distinct, else the host merge.  The same device
  * may be listed more than once (several shards on one GPU: rehearsal of the multi-GPU path on a one-GPU box).
+ * exchange = 3 is for tests: the control flow of exchange = 2 (pack kernels, grouped all-reduce, select kernels, second
+ * all-reduce, one device-to-host copy) with a stand-in for the collective that forms the ranks' element-wise minimum on the
+ * host -- RCCL refuses two ranks on one device, so this is how the G > 1 flow runs on a one-GPU box.
  * Geometric verification of one scan's candidates (scl_icp_align_batch) is spread over the shards by candidate;
  * other geometry calls and the keyframe store live on devices[0].  cfg->device is ignored. */
 int  scl_create_sharded(const scl_config *cfg, const int *devices, int n_devices, int exchange, scl_engine **out);
-/* number of shards (1 for scl_create) and the exchange in use (0 none, 1 host merge, 2 RCCL); either may be NULL */
+/* number of shards (1 for scl_create) and the exchange in use (0 none, 1 host merge, 2 RCCL, 3 the tests' stand-in); either may be NULL */
 int  scl_shard_info(const scl_engine *e, int *n_shards, int *exchange);
 
 /* ---- the six virtuals of scan_descriptor (D.h:21-36) ----------------------- */
@@ -144,8 +147,12 @@ int  scl_get_descriptors(const scl_engine *e, int first, int count, float *value
 int  scl_find_key(const scl_engine *e, int8_t robot, int index, int *key);
 /* The whole keyframe database as a flat file: header {magic, version, R, S, N}, float32[N][R*S] descriptors in
  * wire order (D.h:1446-1455), then N x {int32 robot, int32 index} (the map of D.h:1758-1761).  Keys, norms and the
- * tiled layouts are derived data and are rebuilt on load.  load appends to the engine's database (an empty engine
- * reproduces the dumped one exactly: same keys, same detections); the grid must match. */
+ * tiled layouts are derived data and are rebuilt on load.  load appends to the engine's database (an empty one-GPU engine
+ * reproduces the dumped one exactly: same keys, same detections -- the header's reserved words carry the counter and range
+ * of detectInterLoopClosureID's periodic tree, D.h:1691-1703; a sharded engine restarts that period); the grid must match.
+ * load checks the file's length against its header before sizing anything by it and fails with SCL_ERR_INVALID_ARG /
+ * SCL_ERR_NOMEM, never by an exception; a load that fails midway (I/O error, device memory) leaves the keyframes appended
+ * so far in the database: *n_loaded says how many. */
 int  scl_db_dump_file(scl_engine *e, const char *path);
 int  scl_db_load_file(scl_engine *e, const char *path, int *n_loaded);
 
@@ -167,6 +174,12 @@ int  scl_ringkey_topk(scl_engine *e, int query, int lo, int hi, int k,
  * the sequential CPU evaluation; shift[i] the arg-min ring shift. */
 int  scl_sc_distance_batch(scl_engine *e, int query, const int *cand, int n,
                            double *dist, int *shift);
+/* The distance MATRIX of north_star ("the column-shifted SC distance matrix over the keyframe database"): row r =
+ * distanceBtnScanContext (D.h:1538-1569) of keyframe queries[r] (or a staged query, -1 - slot) against the keyframes
+ * lo .. hi-1; dist / shift are nq x (hi - lo), row-major.  Every entry is the exact fp64 evaluation (bit-identical to the
+ * sequential CPU evaluation, as scl_sc_distance_batch): no screening.  Several rows share a launch and a launch's results
+ * travel to the host while the next one runs. */
+int  scl_sc_distance_matrix(scl_engine *e, const int *queries, int nq, int lo, int hi, double *dist, int *shift);
 /* BASELINE "full-DB" mode: ring-key top-k AND the shifted SC distance against
  * every eligible slot [0, hi) with hi = cur - num_exclude_recent (D.h:1627), then
  * the global arg-min (ties -> lowest slot).  nn_idx/shift/dist describe the best
@@ -332,6 +345,12 @@ int  scl_profile_get(scl_engine *e, scl_profile *out);
  * filter's error margin.  pairs = pairs aligned since the last reset, fallbacks = those decided by the fp64 evaluation (the
  * rate depends on the data: flat or periodic sector keys fall back).  Either pointer may be NULL; reset != 0 clears both. */
 int  scl_alignment_stats(scl_engine *e, uint64_t *pairs, uint64_t *fallbacks, int reset);
+/* The full-database pass scores exactly (fp64, D.h:1538-1569) only the keyframes whose screening bound reaches the smallest
+ * bound of their scan (sc_screen.hip): queries = scans that went through an exact pass since the last reset, survivors = keyframes
+ * scored exactly for them, max_survivors = the largest such count of one scan.  The rate of the pass depends on it: a database
+ * where every keyframe survives runs at the exact kernel's rate.  On a sharded engine a scan counts once per shard.  Any
+ * pointer may be NULL; reset != 0 clears the counters. */
+int  scl_survivor_stats(scl_engine *e, uint64_t *queries, uint64_t *survivors, uint64_t *max_survivors, int reset);
 int  scl_device_name(const scl_engine *e, char *buf, int buflen);
 
 #ifdef __cplusplus

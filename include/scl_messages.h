@@ -85,8 +85,12 @@ int scl_msg_geometric_verification_response_decode(const uint8_t *buf, size_t le
 /* The record layout pcl::toROSMsg gives a pcl::PointCloud<pcl::PointXYZI> (x, y, z float32 at 0 / 4 / 8, intensity at
  * 16, point_step 32): fills `cloud` so that it describes `n_points` records at `points` (borrowed). */
 int scl_msg_cloud_from_xyzi(const void *points, uint32_t n_points, scl_msg_cloud *cloud, scl_msg_point_field fields_out[4]);
-/* Where the x, y, z float32 fields of a decoded cloud sit: byte offsets inside a record, or SCL_ERR_UNSUPPORTED when
- * x, y, z are not three consecutive float32 (the engine's point layout). */
+/* Where the x, y, z float32 fields of a decoded cloud sit: byte offsets inside a record.  The cloud comes from a peer, so the
+ * layout is checked, not trusted: SCL_ERR_UNSUPPORTED when x, y, z are not three consecutive single float32 fields that end
+ * inside the record (a duplicate x / y / z field, count != 1, another datatype, big-endian data, z past point_step), when
+ * rows are padded (row_step != point_step * width), or when reading width * height whole records from data + xyz_offset --
+ * what the engine's (pointer, count, stride) entry points do -- would pass the end of `data` (a record whose x is not at
+ * offset 0 in a buffer without slack: repack it); SCL_ERR_INVALID_ARG when `data` is shorter than the records it declares. */
 int scl_msg_cloud_xyz_layout(const scl_msg_cloud *cloud, int *stride_bytes, int *xyz_offset);
 
 /* pose helpers of the path: geometry_msgs/Transform <-> (x, y, z, roll, pitch, yaw) with the conventions of

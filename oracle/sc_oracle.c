@@ -14,6 +14,18 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* Per-thread scratch of the reference-shaped evaluation.  The reference allocates a fresh Eigen matrix / vector at each
+ * of these places (D.h:1498, 1520-1521, 1541-1542, 1559); the COPIES are kept here -- they are what the CPU baseline
+ * prices -- but the allocator is not called per pair, per shift and per column: one buffer per call site and thread,
+ * grown on demand and kept for the thread's life. */
+#define SCO_TLS(name) static __thread double *name; static __thread size_t name##_cap
+static double *tls_grow(double **p, size_t *cap, size_t n)
+{
+    if (*cap < n) { free(*p); *p = (double *)malloc(sizeof(double) * n); *cap = *p ? n : 0; }
+    return *p;
+}
+SCO_TLS(tls_align); SCO_TLS(tls_cols); SCO_TLS(tls_vkeys); SCO_TLS(tls_space); SCO_TLS(tls_shifted); SCO_TLS(tls_fast);
+
 void sco_default_config(sco_config *c)
 {   /* D.h:1308-1316 */
     c->num_ring = 20;
@@ -178,7 +190,7 @@ int sco_fast_align(int S, const double *vkey1, const double *vkey2)
 {
     int argmin_vkey_shift = 0;
     double min_diff_norm = 10000000;
-    double *shifted = (double *)malloc(sizeof(double) * (size_t)S);
+    double *shifted = tls_grow(&tls_align, &tls_align_cap, (size_t)S);
     for (int shift = 0; shift < S; shift++) {
         sco_circshift(1, S, vkey2, shift, shifted);               /* D.h:1498 */
         double ss = 0;
@@ -189,7 +201,6 @@ int sco_fast_align(int S, const double *vkey1, const double *vkey2)
         double cur = sqrt(ss);
         if (cur < min_diff_norm) { argmin_vkey_shift = shift; min_diff_norm = cur; }
     }
-    free(shifted);
     return argmin_vkey_shift;
 }
 
@@ -206,7 +217,7 @@ double sco_dist_direct(int R, int S, const double *sc1, const double *sc2)
 {
     int num_eff_cols = 0;
     double sum_sector_similarity = 0;
-    double *c1 = (double *)malloc(sizeof(double) * 2 * (size_t)R);
+    double *c1 = tls_grow(&tls_cols, &tls_cols_cap, 2 * (size_t)R);
     double *c2 = c1 + R;
     for (int col = 0; col < S; col++) {
         memcpy(c1, sc1 + (size_t)col * R, sizeof(double) * (size_t)R);     /* D.h:1520 */
@@ -218,7 +229,6 @@ double sco_dist_direct(int R, int S, const double *sc1, const double *sc2)
         sum_sector_similarity = sum_sector_similarity + sim;
         num_eff_cols = num_eff_cols + 1;
     }
-    free(c1);
     double sc_sim = sum_sector_similarity / num_eff_cols;                  /* 0/0 -> NaN */
     return 1.0 - sc_sim;
 }
@@ -239,16 +249,15 @@ void sco_distance(const sco_config *c, const double *sc1, const double *sc2,
                   double *dist, int *shift)
 {
     const int R = c->num_ring, S = c->num_sector;
-    double *vk1 = (double *)malloc(sizeof(double) * 2 * (size_t)S);
+    double *vk1 = tls_grow(&tls_vkeys, &tls_vkeys_cap, 2 * (size_t)S);
     double *vk2 = vk1 + S;
     sco_sectorkey(R, S, sc1, vk1);                                /* D.h:1541 */
     sco_sectorkey(R, S, sc2, vk2);                                /* D.h:1542 */
     int a = sco_fast_align(S, vk1, vk2);                          /* D.h:1543 */
-    free(vk1);
 
     const int SR = search_radius(c);
     int nsp = 1 + 2 * (SR > 0 ? SR : 0);
-    int *space = (int *)malloc(sizeof(int) * (size_t)nsp);
+    int *space = (int *)tls_grow(&tls_space, &tls_space_cap, ((size_t)nsp + 1) / 2);
     int m = 0;
     space[m++] = a;
     for (int ii = 1; ii < SR + 1; ii++) {                         /* D.h:1547-1551 */
@@ -259,15 +268,13 @@ void sco_distance(const sco_config *c, const double *sc1, const double *sc2,
 
     int argmin_shift = 0;
     double min_sc_dist = 10000000;
-    double *shifted = (double *)malloc(sizeof(double) * (size_t)R * S);
+    double *shifted = tls_grow(&tls_shifted, &tls_shifted_cap, (size_t)R * S);
     for (int t = 0; t < m; t++) {                                 /* D.h:1557-1566 */
         int num_shift = space[t];
         sco_circshift(R, S, sc2, num_shift, shifted);
         double cur = sco_dist_direct(R, S, sc1, shifted);
         if (cur < min_sc_dist) { argmin_shift = num_shift; min_sc_dist = cur; }
     }
-    free(shifted);
-    free(space);
     *dist = min_sc_dist;
     *shift = argmin_shift;
 }
@@ -279,7 +286,8 @@ void sco_distance_fast(const sco_config *c, const double *sc1, const double *sc2
                        double *dist, int *shift)
 {
     const int R = c->num_ring, S = c->num_sector;
-    double *buf = (double *)malloc(sizeof(double) * 4 * (size_t)S);
+    const int nsp_max = 1 + 2 * (search_radius(c) > 0 ? search_radius(c) : 0);
+    double *buf = tls_grow(&tls_fast, &tls_fast_cap, 4 * (size_t)S + ((size_t)nsp_max + 1) / 2);
     double *vk1 = buf, *vk2 = buf + S, *n1 = buf + 2 * S, *n2 = buf + 3 * S;
     sco_sectorkey(R, S, sc1, vk1);
     sco_sectorkey(R, S, sc2, vk2);
@@ -301,7 +309,7 @@ void sco_distance_fast(const sco_config *c, const double *sc1, const double *sc2
     }
     const int SR = search_radius(c);
     int nsp = 1 + 2 * (SR > 0 ? SR : 0);
-    int *space = (int *)malloc(sizeof(int) * (size_t)nsp);
+    int *space = (int *)(buf + 4 * (size_t)S);
     int m = 0;
     space[m++] = a;
     for (int ii = 1; ii < SR + 1; ii++) {
@@ -327,8 +335,7 @@ void sco_distance_fast(const sco_config *c, const double *sc1, const double *sc2
         double cur = 1.0 - sum / eff;
         if (cur < min_sc_dist) { argmin_shift = sh; min_sc_dist = cur; }
     }
-    free(space);
-    free(buf);
+    (void)nsp;
     *dist = min_sc_dist;
     *shift = argmin_shift;
 }
@@ -574,34 +581,117 @@ void sco_db_distance_batch(sco_db *db, int cur, const int *cand, int n,
     }
 }
 
-/* ---- CPU baseline variant B: the same reference-shaped evaluation, candidates split over threads ---- */
-typedef struct { sco_db *db; int cur; const int *cand; int lo, hi; double *dist; int *shift; int fast; } mt_job;
+/* ---- CPU baseline variant B: the same reference-shaped evaluation on every host core ----
+ * A pool of worker threads created ONCE (and re-made only when the requested count changes); a call publishes one job,
+ * the workers take candidates in blocks of 16 from a shared counter (first come first served: cores of a busy host are
+ * not equally fast) and the caller sleeps until the last block is done.  No thread is created and nothing is allocated
+ * per call, per pair, per shift or per column (the reference-shaped COPIES stay: sco_distance). */
+#define SCO_POOL_MAX 1024
+#define SCO_POOL_BLOCK 16
+typedef struct {
+    pthread_mutex_t mu;
+    pthread_cond_t cv_work, cv_done;
+    pthread_t th[SCO_POOL_MAX];
+    int n_threads;
+    unsigned long long generation;       /* bumped per job */
+    int stop;
+    /* the job */
+    sco_db *db; int cur; const int *cand; int n; double *dist; int *shift; int fast;
+    int next;                            /* next unclaimed candidate (atomic) */
+    int busy;                            /* workers still inside the job */
+} sco_pool;
+static sco_pool g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, 0, 0,
+                           NULL, 0, NULL, 0, NULL, NULL, 0, 0, 0 };
+static pthread_mutex_t g_pool_call = PTHREAD_MUTEX_INITIALIZER;   /* one job at a time */
 
-static void *mt_worker(void *arg)
+static void pool_run_blocks(sco_pool *p)
 {
-    mt_job *j = (mt_job *)arg;
-    for (int i = j->lo; i < j->hi; i++) {
-        int ci = j->cand ? j->cand[i] : i;
-        if (j->fast) sco_distance_fast(&j->db->cfg, sco_db_desc(j->db, j->cur), sco_db_desc(j->db, ci), &j->dist[i], &j->shift[i]);
-        else         sco_distance(&j->db->cfg, sco_db_desc(j->db, j->cur), sco_db_desc(j->db, ci), &j->dist[i], &j->shift[i]);
+    for (;;) {
+        const int lo = __atomic_fetch_add(&p->next, SCO_POOL_BLOCK, __ATOMIC_RELAXED);
+        if (lo >= p->n) break;
+        const int hi = lo + SCO_POOL_BLOCK < p->n ? lo + SCO_POOL_BLOCK : p->n;
+        for (int i = lo; i < hi; i++) {
+            const int ci = p->cand ? p->cand[i] : i;
+            if (p->fast) sco_distance_fast(&p->db->cfg, sco_db_desc(p->db, p->cur), sco_db_desc(p->db, ci), &p->dist[i], &p->shift[i]);
+            else         sco_distance(&p->db->cfg, sco_db_desc(p->db, p->cur), sco_db_desc(p->db, ci), &p->dist[i], &p->shift[i]);
+        }
     }
+}
+
+static void *pool_worker(void *arg)
+{
+    sco_pool *p = (sco_pool *)arg;
+    unsigned long long seen = 0;
+    pthread_mutex_lock(&p->mu);
+    for (;;) {
+        while (!p->stop && p->generation == seen) pthread_cond_wait(&p->cv_work, &p->mu);
+        if (p->stop) break;
+        seen = p->generation;
+        pthread_mutex_unlock(&p->mu);
+        pool_run_blocks(p);
+        pthread_mutex_lock(&p->mu);
+        if (--p->busy == 0) pthread_cond_signal(&p->cv_done);
+    }
+    pthread_mutex_unlock(&p->mu);
     return NULL;
+}
+
+static void pool_stop_locked_call(sco_pool *p)
+{
+    if (p->n_threads == 0) return;
+    pthread_mutex_lock(&p->mu);
+    p->stop = 1;
+    pthread_cond_broadcast(&p->cv_work);
+    pthread_mutex_unlock(&p->mu);
+    for (int t = 0; t < p->n_threads; t++) pthread_join(p->th[t], NULL);
+    p->n_threads = 0; p->stop = 0;
+}
+
+/* threads workers besides the caller's own share; returns the number actually running */
+static int pool_ensure(sco_pool *p, int threads)
+{
+    if (p->n_threads == threads) return threads;
+    pool_stop_locked_call(p);
+    pthread_attr_t at;
+    pthread_attr_init(&at);
+    pthread_attr_setstacksize(&at, 256 * 1024);
+    int made = 0;
+    for (int t = 0; t < threads; t++) {
+        if (pthread_create(&p->th[t], &at, pool_worker, p) != 0) break;
+        made++;
+    }
+    pthread_attr_destroy(&at);
+    p->n_threads = made;
+    return made;
+}
+
+void sco_pool_shutdown(void)
+{
+    pthread_mutex_lock(&g_pool_call);
+    pool_stop_locked_call(&g_pool);
+    pthread_mutex_unlock(&g_pool_call);
 }
 
 void sco_db_distance_batch_mt(sco_db *db, int cur, const int *cand, int n,
                               double *dist, int *shift, int fast, int threads)
 {
     if (threads < 1) threads = 1;
-    if (threads > 256) threads = 256;
-    pthread_t th[256];
-    mt_job jobs[256];
-    for (int t = 0; t < threads; t++) {
-        jobs[t].db = db; jobs[t].cur = cur; jobs[t].cand = cand; jobs[t].dist = dist; jobs[t].shift = shift; jobs[t].fast = fast;
-        jobs[t].lo = (int)((long long)n * t / threads);
-        jobs[t].hi = (int)((long long)n * (t + 1) / threads);
-        pthread_create(&th[t], NULL, mt_worker, &jobs[t]);
-    }
-    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    if (threads > SCO_POOL_MAX) threads = SCO_POOL_MAX;
+    sco_pool *p = &g_pool;
+    pthread_mutex_lock(&g_pool_call);
+    const int workers = pool_ensure(p, threads - 1);     /* the caller is the last thread of the team */
+    pthread_mutex_lock(&p->mu);
+    p->db = db; p->cur = cur; p->cand = cand; p->n = n; p->dist = dist; p->shift = shift; p->fast = fast;
+    __atomic_store_n(&p->next, 0, __ATOMIC_RELAXED);
+    p->busy = workers;
+    p->generation++;
+    pthread_cond_broadcast(&p->cv_work);
+    pthread_mutex_unlock(&p->mu);
+    pool_run_blocks(p);
+    pthread_mutex_lock(&p->mu);
+    while (p->busy > 0) pthread_cond_wait(&p->cv_done, &p->mu);
+    pthread_mutex_unlock(&p->mu);
+    pthread_mutex_unlock(&g_pool_call);
 }
 
 /* ---- Envelope of the parts that cannot be pinned offline (tests only) ------------------------------------------

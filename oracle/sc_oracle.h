@@ -94,9 +94,11 @@ void    sco_db_detect_full(sco_db *db, int cur, int *loop_id, int *nn_idx, int *
 void    sco_db_distance_batch(sco_db *db, int cur, const int *cand, int n,
                               double *dist, int *shift, int fast);
 
-/* the same batch split over `threads` pthreads (CPU baseline on all host cores) */
+/* the same batch on a team of `threads` threads (CPU baseline on all host cores): a persistent pool, made on the first
+ * call and re-made only when `threads` changes; candidates are dealt in blocks of 16, first come first served */
 void    sco_db_distance_batch_mt(sco_db *db, int cur, const int *cand, int n,
                                  double *dist, int *shift, int fast, int threads);
+void    sco_pool_shutdown(void);          /* joins the pool's threads (optional; the pool is re-made on demand) */
 
 /* envelope of what cannot be pinned offline (tests only; see sc_oracle.c) */
 void sco_ringkey_lanes(int R, int S, const double *desc, int lanes, float *key);

@@ -401,10 +401,26 @@ int scl_default_config(scl_config *c)
     return SCL_OK;
 }
 
+// Every environment switch the library reads selects a correct path, but a leftover one can cost an order of magnitude
+// (SCL_SCREEN=0 scores every pair with the exact kernel): the first engine of a process says which ones it found set.
+static void log_env_overrides_once()
+{
+    static std::atomic<bool> done{false};
+    if (done.exchange(true)) return;
+    static const char *const names[] = {"SCL_SCREEN", "SCL_SCREEN_FORM", "SCL_SCREEN_VARIANT", "SCL_SCREEN_PROBE", "SCL_SCREEN_V2_MIN", "SCL_SCREEN_TAIL",
+                                        "SCL_ALIGN_WGS", "SCL_ALIGN_SIDE", "SCL_ALIGN_FILTER", "SCL_SC_KERNEL", "SCL_SC_WAVES", "SCL_STAMP", "SCL_ABLATE",
+                                        "SCL_ALT_LANE", "SCL_ICP_REDUCE", "SCL_ICP_FUSED", "SCL_RCCL_MOCK"};
+    for (const char *n : names) {
+        const char *v = getenv(n);
+        if (v) fprintf(stderr, "scl_engine: environment override in effect: %s=%s\n", n, v);
+    }
+}
+
 int scl_create(const scl_config *cfg, scl_engine **out)
 {
     if (!cfg || !out) return SCL_ERR_INVALID_ARG;
     *out = nullptr;
+    log_env_overrides_once();
     if (cfg->num_ring < 1 || cfg->num_ring > 256 || cfg->num_sector < 1 || cfg->num_sector > 1024 ||
         cfg->num_candidates < 1 || cfg->num_candidates > kTopkMaxK || cfg->tree_making_period < 1 ||
         cfg->num_exclude_recent < 0 || !(cfg->max_radius > 0.0) || !(cfg->search_ratio >= 0.0))
@@ -482,6 +498,8 @@ int scl_create(const scl_config *cfg, scl_engine **out)
     if (hipEventCreateWithFlags(&e->ev_db, hipEventDisableTiming) != hipSuccess) return bail(SCL_ERR_HIP);
     if ((rc = dev_alloc(e, &e->d_align_fallbacks, (size_t)1))) return bail(rc);
     if (hipMemset(e->d_align_fallbacks, 0, sizeof(unsigned long long)) != hipSuccess) return bail(SCL_ERR_HIP);
+    if ((rc = dev_alloc(e, &e->d_surv_stats, (size_t)3))) return bail(rc);
+    if (hipMemset(e->d_surv_stats, 0, 3 * sizeof(unsigned long long)) != hipSuccess) return bail(SCL_ERR_HIP);
     if ((rc = ensure_pairs(e, 1024))) return bail(rc);
     e->screen = sc_screen_supported(db_view(e), e->SR) && cfg->num_candidates <= kTailTopMaxK;
     if ((rc = ensure_pinned(e, 1 << 16))) return bail(rc);
@@ -515,6 +533,12 @@ int scl_destroy(scl_engine *e)
     dev_free(e->d_dist); dev_free(e->d_shift); dev_free(e->d_cand); dev_free(e->d_ring_d2);
     dev_free(e->d_approx); dev_free(e->d_starts); dev_free(e->d_surv); dev_free(e->d_nsurv); dev_free(e->d_tmin); dev_free(e->d_part);
     dev_free(e->d_align_fallbacks);
+    if (e->d_mat_dist) (void)hipFree(e->d_mat_dist);
+    if (e->d_mat_shift) (void)hipFree(e->d_mat_shift);
+    if (e->h_mat) (void)hipHostFree(e->h_mat);
+    for (auto &ev : e->ev_mat_k) if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : e->ev_mat_c) if (ev) (void)hipEventDestroy(ev);
+    dev_free(e->d_surv_stats);
     dev_free(e->d_surv_part); dev_free(e->d_surv_done);
     if (e->d_surv_args) (void)hipFree(e->d_surv_args);
     if (e->h_surv_args) (void)hipHostFree(e->h_surv_args);
@@ -851,6 +875,79 @@ int scl_sc_distance_batch(scl_engine *e, int query, const int *cand, int n, doub
     return sync(e);
 }
 
+/* The exact distance matrix (north_star: "the column-shifted SC distance matrix over the keyframe database"): rows = queries,
+ * columns = keyframes lo .. hi-1, every entry the reference's distanceBtnScanContext (D.h:1538-1569) in fp64 with its shift.
+ * Up to kMaxQueryBatch rows per launch of the wave program; a launch's results travel to the host (pinned halves, second
+ * stream) while the next launch runs. */
+int scl_sc_distance_matrix(scl_engine *e, const int *queries, int nq, int lo, int hi, double *dist, int *shift)
+{
+    if (!e || nq < 0 || (nq > 0 && (!queries || !dist || !shift))) return SCL_ERR_INVALID_ARG;
+    if (nq == 0) return SCL_OK;
+    if (e->front) return front_sc_distance_matrix(e, queries, nq, lo, hi, dist, shift);
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    if (lo < 0 || hi > e->n || hi < lo) return fail(e, SCL_ERR_OUT_OF_RANGE, "keyframe range out of the database");
+    const int n = hi - lo;
+    if (n == 0) return SCL_OK;
+    std::vector<int> slots((size_t)nq);
+    for (int i = 0; i < nq; ++i) {
+        const int q = queries[i];
+        if (q >= e->n || q < -(int)scl_engine::kStage) return fail(e, SCL_ERR_OUT_OF_RANGE, "query keyframe out of range");
+        if (q < 0 && !e->staged[-1 - q]) return fail(e, SCL_ERR_INVALID_ARG, "no staged query in that slot");
+        slots[(size_t)i] = q >= 0 ? q : e->cap + (-1 - q);
+    }
+    constexpr int RB = kMaxQueryBatch;                                     // rows per launch
+    const size_t row = ((size_t)n + 63) & ~(size_t)63;
+    if (e->mat_cap < row) {
+        if (e->d_mat_dist) (void)hipFree(e->d_mat_dist);
+        if (e->d_mat_shift) (void)hipFree(e->d_mat_shift);
+        if (e->h_mat) (void)hipHostFree(e->h_mat);
+        e->d_mat_dist = nullptr; e->d_mat_shift = nullptr; e->h_mat = nullptr; e->mat_cap = 0;
+        if (hipMalloc((void **)&e->d_mat_dist, sizeof(double) * 2 * RB * row) != hipSuccess ||
+            hipMalloc((void **)&e->d_mat_shift, sizeof(int) * 2 * RB * row) != hipSuccess ||
+            hipHostMalloc(&e->h_mat, (sizeof(double) + sizeof(int)) * 2 * RB * row, hipHostMallocDefault) != hipSuccess)
+            return fail(e, SCL_ERR_NOMEM, "distance matrix buffers");
+        e->mat_cap = row;
+        for (int h = 0; h < 2; ++h) {
+            if (!e->ev_mat_k[h]) SCL_HIP(e, hipEventCreateWithFlags(&e->ev_mat_k[h], hipEventDisableTiming));
+            if (!e->ev_mat_c[h]) SCL_HIP(e, hipEventCreateWithFlags(&e->ev_mat_c[h], hipEventDisableTiming));
+        }
+    }
+    const size_t cap = e->mat_cap;
+    double *h_dist = static_cast<double *>(e->h_mat);
+    int *h_shift = reinterpret_cast<int *>(h_dist + 2 * RB * cap);
+    const int groups = (nq + RB - 1) / RB;
+    auto deliver = [&](int g) -> int {                                     // group g's rows: pinned half -> the caller's arrays
+        const int h = g & 1, r0 = g * RB, rows = nq - r0 < RB ? nq - r0 : RB;
+        SCL_HIP(e, hipEventSynchronize(e->ev_mat_c[h]));
+        for (int r = 0; r < rows; ++r) {
+            std::memcpy(dist + (size_t)(r0 + r) * n, h_dist + ((size_t)h * RB + r) * cap, sizeof(double) * (size_t)n);
+            std::memcpy(shift + (size_t)(r0 + r) * n, h_shift + ((size_t)h * RB + r) * cap, sizeof(int) * (size_t)n);
+        }
+        return SCL_OK;
+    };
+    int rc = SCL_OK;
+    for (int g = 0; g < groups; ++g) {
+        const int h = g & 1, r0 = g * RB, rows = nq - r0 < RB ? nq - r0 : RB;
+        if (g >= 2 && (rc = deliver(g - 2))) return rc;                    // (also: half h of the device buffers has been copied out)
+        {
+            ProfScope ps(e, P_SC);
+            SCL_HIP(e, launch_sc_distance_matrix(db_view(e), slots.data() + r0, rows, lo, n, e->SR, e->d_mat_dist + (size_t)h * RB * cap,
+                                                 e->d_mat_shift + (size_t)h * RB * cap, cap, e->num_cu, e->stream));
+            if (ps.active()) e->prof.sc_distance_pairs += (uint64_t)rows * (uint64_t)n;
+        }
+        SCL_HIP(e, hipEventRecord(e->ev_mat_k[h], e->stream));
+        SCL_HIP(e, hipStreamWaitEvent(e->stream2, e->ev_mat_k[h], 0));
+        SCL_HIP(e, hipMemcpyAsync(h_dist + (size_t)h * RB * cap, e->d_mat_dist + (size_t)h * RB * cap, sizeof(double) * (size_t)rows * cap, hipMemcpyDeviceToHost, e->stream2));
+        SCL_HIP(e, hipMemcpyAsync(h_shift + (size_t)h * RB * cap, e->d_mat_shift + (size_t)h * RB * cap, sizeof(int) * (size_t)rows * cap, hipMemcpyDeviceToHost, e->stream2));
+        SCL_HIP(e, hipEventRecord(e->ev_mat_c[h], e->stream2));
+    }
+    for (int g = groups >= 2 ? groups - 2 : 0; g < groups; ++g)
+        if ((rc = deliver(g))) return rc;
+    if (e->prof_on) collect_profile(e);
+    return SCL_OK;
+}
+
 namespace {
 
 // enqueue one full-DB pass; results land in pinned slot `sl` when ev_done[sl] has fired
@@ -905,7 +1002,7 @@ int launch_survivor_pass(scl_engine *e, const int *qslot, const int *lo, const i
     for (int j = 0; j < nq; ++j) { sp.slot[j] = qslot[j]; sp.base[j] = lo[j]; sp.n[j] = n[j]; sp.buf[j] = set0 + j; sp.out3[j] = out3[j]; }
     sp.pair_stride = e->set_stride;
     sp.approx = e->d_approx; sp.survivors = e->d_surv; sp.t_min = e->d_tmin; sp.out_dist = e->d_dist; sp.out_shift = e->d_shift;
-    sp.blk_part = e->d_surv_part; sp.done_counter = e->d_surv_done;
+    sp.blk_part = e->d_surv_part; sp.done_counter = e->d_surv_done; sp.surv_stats = e->d_surv_stats;
     sp.ring_d2 = e->d_ring_d2; sp.k = e->cfg.num_candidates; sp.exclude_eps = e->cfg.knn_exclude_eps; sp.topk_idx = e->d_topk_idx; sp.topk_d2 = e->d_topk_d2;
     const size_t region = (size_t)(region_in >= 0 ? (unsigned)region_in : survivor_arg_region(e)) * scl_engine::kScreenSets * kSurvivorArgBytes;   // 8 passes may be in flight
     sp.d_args = static_cast<char *>(e->d_surv_args) + region; sp.h_args = static_cast<char *>(e->h_surv_args) + region;
@@ -930,7 +1027,7 @@ int launch_survivor_pass_wide(scl_engine *e, const int *qslot, const int *lo, co
         for (int j = 0; j < w; ++j) { sb.slot[j] = qslot[g + j]; sb.base[j] = lo[g + j]; sb.n[j] = n[g + j]; sb.buf[j] = set0 + g + j; }
         sb.pair_stride = e->set_stride;
         sb.approx = e->d_approx; sb.starts = e->d_starts; sb.align_fallbacks = e->d_align_fallbacks; sb.ring_d2 = e->d_ring_d2;
-        sb.survivors = e->d_surv; sb.n_surv = e->d_nsurv; sb.t_min = e->d_tmin;
+        sb.survivors = e->d_surv; sb.n_surv = e->d_nsurv; sb.t_min = e->d_tmin; sb.surv_stats = e->d_surv_stats;
         sb.k = e->cfg.num_candidates; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
         SCL_HIP(e, launch_sc_select_batch(sb, stream));
         const int *sv[kWideExactBatch]; const int *ns[kWideExactBatch]; double *od[kWideExactBatch]; int *os[kWideExactBatch];
@@ -1499,6 +1596,8 @@ int scl_db_dump_file(scl_engine *e, const char *path)
     DbFileHeader h{};
     std::memcpy(h.magic, kDbMagic, 8);
     h.version = 1; h.num_ring = e->R; h.num_sector = e->S; h.count = n;
+    // state of detectInterLoopClosureID's periodic tree (D.h:1691-1703): reserved[0] = 1 marks the two words as present
+    if (!e->front) { std::lock_guard<std::mutex> lk(e->mu); h.reserved[0] = 1; h.reserved[1] = e->tree_counter; h.reserved[2] = e->tree_n; }
     int rc = SCL_OK;
     if (std::fwrite(&h, sizeof h, 1, f) != 1) rc = SCL_ERR_INVALID_ARG;
     const size_t cells = (size_t)e->R * e->S;
@@ -1527,31 +1626,48 @@ int scl_db_load_file(scl_engine *e, const char *path, int *n_loaded)
     if (!f) return fail(e, SCL_ERR_INVALID_ARG, "db_load: cannot open the file");
     DbFileHeader h{};
     int rc = SCL_OK;
+    const size_t cells = (size_t)e->R * e->S;
     if (std::fread(&h, sizeof h, 1, f) != 1 || std::memcmp(h.magic, kDbMagic, 8) != 0 || h.version != 1) rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: not a database dump of this engine");
     else if (h.num_ring != e->R || h.num_sector != e->S) rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: the dump was made for another grid (rings x sectors)");
     else if (h.count < 0) rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: corrupt header");
-    const size_t cells = (size_t)e->R * e->S;
-    std::vector<int8_t> robots; std::vector<int> indexs;
-    if (!rc) {
-        // the index map sits behind the descriptors: read it first, then stream the descriptors in chunks
-        robots.resize((size_t)h.count); indexs.resize((size_t)h.count);
-        if (std::fseek(f, (long)(sizeof h + sizeof(float) * cells * (size_t)h.count), SEEK_SET) != 0) rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: truncated file");
-        for (int k = 0; k < h.count && !rc; ++k) {
-            int32_t rec[2];
-            if (std::fread(rec, sizeof rec, 1, f) != 1) { rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: truncated index map"); break; }
-            robots[(size_t)k] = (int8_t)rec[0]; indexs[(size_t)k] = rec[1];
-        }
-        if (!rc && std::fseek(f, (long)sizeof h, SEEK_SET) != 0) rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: seek failed");
+    if (!rc) {   // the header is not trusted: the file must be exactly as long as the count says before anything is sized by it
+        const unsigned long long want = (unsigned long long)sizeof h + (unsigned long long)h.count * (sizeof(float) * cells + 2 * sizeof(int32_t));
+        long long have = -1;
+        if (fseeko(f, 0, SEEK_END) == 0) have = (long long)ftello(f);
+        if (have < 0 || (unsigned long long)have != want) rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: file length does not match the keyframe count of its header");
     }
-    const int chunk = 512;
-    std::vector<float> buf(cells * (size_t)chunk);
-    for (int done = 0; !rc && done < h.count; done += chunk) {
-        const int c = h.count - done < chunk ? h.count - done : chunk;
-        if (std::fread(buf.data(), sizeof(float) * cells, (size_t)c, f) != (size_t)c) { rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: truncated descriptors"); break; }
-        rc = scl_save_bulk(e, buf.data(), c, robots.data() + done, indexs.data() + done);
-        if (!rc && n_loaded) *n_loaded += c;
+    const int n_before = rc ? 0 : scl_get_size(e, -1);
+    try {
+        std::vector<int8_t> robots; std::vector<int> indexs;
+        if (!rc) {
+            // the index map sits behind the descriptors: read it first, then stream the descriptors in chunks
+            robots.resize((size_t)h.count); indexs.resize((size_t)h.count);
+            if (fseeko(f, (off_t)(sizeof h + sizeof(float) * cells * (size_t)h.count), SEEK_SET) != 0) rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: truncated file");
+            for (int k = 0; k < h.count && !rc; ++k) {
+                int32_t rec[2];
+                if (std::fread(rec, sizeof rec, 1, f) != 1) { rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: truncated index map"); break; }
+                robots[(size_t)k] = (int8_t)rec[0]; indexs[(size_t)k] = rec[1];
+            }
+            if (!rc && fseeko(f, (off_t)sizeof h, SEEK_SET) != 0) rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: seek failed");
+        }
+        const int chunk = 512;
+        std::vector<float> buf(rc ? 0 : cells * (size_t)chunk);
+        for (int done = 0; !rc && done < h.count; done += chunk) {
+            const int c = h.count - done < chunk ? h.count - done : chunk;
+            if (std::fread(buf.data(), sizeof(float) * cells, (size_t)c, f) != (size_t)c) { rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: truncated descriptors"); break; }
+            rc = scl_save_bulk(e, buf.data(), c, robots.data() + done, indexs.data() + done);
+            if (!rc && n_loaded) *n_loaded += c;
+        }
+    } catch (const std::bad_alloc &) {
+        rc = fail(e, SCL_ERR_NOMEM, "db_load: out of host memory");
     }
     std::fclose(f);
+    // an engine that was empty takes over the dump's inter-robot tree state too (D.h:1691-1703): the next
+    // detectInterLoopClosureID searches the range the dumped engine would have searched
+    if (!rc && n_before == 0 && !e->front && h.reserved[0] == 1) {
+        std::lock_guard<std::mutex> lk(e->mu);
+        e->tree_counter = h.reserved[1]; e->tree_n = h.reserved[2];
+    }
     return rc;
 }
 
@@ -2160,6 +2276,23 @@ int scl_alignment_stats(scl_engine *e, uint64_t *pairs, uint64_t *fallbacks, int
     return SCL_OK;
 }
 
+int scl_survivor_stats(scl_engine *e, uint64_t *queries, uint64_t *survivors, uint64_t *max_survivors, int reset)
+{
+    if (!e) return SCL_ERR_INVALID_ARG;
+    if (e->front) return front_survivor_stats(e, queries, survivors, max_survivors, reset);
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    unsigned long long s[3] = {0, 0, 0};
+    SCL_HIP(e, hipStreamSynchronize(e->stream));
+    if (e->stream_surv) SCL_HIP(e, hipStreamSynchronize(e->stream_surv));
+    SCL_HIP(e, hipMemcpy(s, e->d_surv_stats, sizeof s, hipMemcpyDeviceToHost));
+    if (survivors) *survivors = (uint64_t)s[0];
+    if (max_survivors) *max_survivors = (uint64_t)s[1];
+    if (queries) *queries = (uint64_t)s[2];
+    if (reset) SCL_HIP(e, hipMemset(e->d_surv_stats, 0, sizeof s));
+    return SCL_OK;
+}
+
 int scl_device_name(const scl_engine *e, char *buf, int buflen)
 {
     if (!e || !buf || buflen <= 0) return SCL_ERR_INVALID_ARG;
@@ -2243,6 +2376,17 @@ bool eng_would_regrow(const scl_engine *e, int count)
 {
     std::lock_guard<std::mutex> lk(e->mu);
     return e->n + count > e->cap;
+}
+
+// Drop the keyframes from n_keep on (the sharded front undoes a multi-shard append that failed on a later shard; the slots'
+// contents are simply overwritten by the next append).  Passes in flight must have been collected by the caller.
+int eng_truncate(scl_engine *e, int n_keep)
+{
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (n_keep < 0 || n_keep > e->n) return SCL_ERR_INVALID_ARG;
+    e->robots.resize((size_t)n_keep); e->indexs.resize((size_t)n_keep);
+    e->n = n_keep;
+    return SCL_OK;
 }
 
 const double *eng_ticket_record(const scl_engine *e, int ticket, int *slot_lo, bool *empty)

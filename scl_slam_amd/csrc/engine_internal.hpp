@@ -75,6 +75,7 @@ struct scl_engine {
     float *d_part = nullptr; size_t part_cap = 0;       // partial sums of the screening products' second form (one launch at a time)
     int *d_nsurv = nullptr; unsigned int *d_tmin = nullptr;
     unsigned long long *d_align_fallbacks = nullptr; uint64_t align_pairs = 0;   // statistics of the alignment kernel (scl_alignment_stats)
+    unsigned long long *d_surv_stats = nullptr;                                   // [3] survivors of the screening pass: sum, max, queries (scl_survivor_stats)
     size_t set_stride = 0;
     unsigned long long *d_surv_part = nullptr; unsigned int *d_surv_done = nullptr;        // tail of the exact pass
     void *d_surv_args = nullptr; void *h_surv_args = nullptr; unsigned surv_arg_tick = 0;   // argument sets of the exact pass (ring of 8 regions)
@@ -107,6 +108,9 @@ struct scl_engine {
     bool alt_lane = false;                                 // SCL_ALT_LANE=1: lowest latency per scan; kernels of the two lanes overlap,
                                                            // so per-kernel durations no longer measure one pass (default off)
     void *h_pinned = nullptr; size_t pinned_cap = 0;       // small result read-back
+    // scl_sc_distance_matrix: two halves of (rows of a launch) x (row length) device results and their pinned copies
+    double *d_mat_dist = nullptr; int *d_mat_shift = nullptr; void *h_mat = nullptr; size_t mat_cap = 0;
+    hipEvent_t ev_mat_k[2] = {nullptr, nullptr}, ev_mat_c[2] = {nullptr, nullptr};
 
     // inter-robot tree bookkeeping (descriptor.h:1691-1703, counter initialised: see DESIGN.md)
     int tree_counter = 0, tree_n = 0;
@@ -155,6 +159,7 @@ int eng_topk_finish(scl_engine *e, int k, bool have_dist, int *idx, float *d2, d
 int eng_sync_streams(scl_engine *e);
 // true when appending `count` keyframes would move the database arrays
 bool eng_would_regrow(const scl_engine *e, int count);
+int eng_truncate(scl_engine *e, int n_keep);
 // device-side exchange of full-DB winners: the pinned (device-visible) result record of a ticket, its range start,
 // the stream the pass runs on; release = free the ticket without reading it (the exchange has delivered it)
 const double *eng_ticket_record(const scl_engine *e, int ticket, int *slot_lo, bool *empty);
@@ -185,7 +190,9 @@ int front_icp_align_batch(scl_engine *e, const void *src, int n_src, const void 
 int front_profile_enable(scl_engine *e, int on);
 int front_profile_reset(scl_engine *e);
 int front_profile_get(scl_engine *e, scl_profile *out);
+int front_sc_distance_matrix(scl_engine *e, const int *queries, int nq, int lo, int hi, double *dist, int *shift);
 int front_alignment_stats(scl_engine *e, uint64_t *pairs, uint64_t *fallbacks, int reset);
+int front_survivor_stats(scl_engine *e, uint64_t *queries, uint64_t *survivors, uint64_t *max_survivors, int reset);
 scl_engine *front_primary(const scl_engine *e);            // the shard that runs unsharded work (geometry, keyframe store)
 
 }  // namespace scl

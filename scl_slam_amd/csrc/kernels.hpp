@@ -89,6 +89,11 @@ struct QueryBatch {
 };
 hipError_t launch_sc_distance_batch(const struct DbView &db, const QueryBatch &qb, int SR, double *out_dist, int *out_shift,
                                     float *out_ring_d2, const FullTail &tail, int num_cu, hipStream_t stream);
+// The exact distance MATRIX: nq <= kMaxQueryBatch query keyframes (database / staging slots) against the range [base, base + n),
+// every pair through the exact fp64 program; row i of the outputs at out_dist / out_shift + i * row_stride.  Grids with a wave
+// program score all rows in one launch (a row's workgroups take over CUs as the previous row's retire), the others row by row.
+hipError_t launch_sc_distance_matrix(const struct DbView &db, const int *slots, int nq, int base, int n, int SR,
+                                     double *out_dist, int *out_shift, size_t row_stride, int num_cu, hipStream_t stream);
 // ---- screening pass of the full-DB mode (sc_screen.hip; 64x120 grid) --------------------------------------------
 // Per query i: every keyframe of [base, base+n) gets approx[i*pair_stride + pos] = its reference distance within
 // +- sc_screen_eps() (fp16 matrix-core evaluation of the reference's own 13 shifts; -inf = must be scored exactly),
@@ -105,6 +110,7 @@ struct ScreenBatch {
     float *approx; float *ring_d2; int *survivors; int *n_surv; unsigned int *t_min;
     int *starts;                                // first shifts (alignment kernel -> screening kernel), like approx
     unsigned long long *align_fallbacks;        // optional counter: keyframes aligned by the exact evaluation
+    unsigned long long *surv_stats;             // optional (select launch): [0] += survivors, [1] = max(survivors), [2] += 1 per query
     int k; float exclude_eps; int *topk_idx; float *topk_d2;
     hipStream_t side; hipEvent_t ev_fork, ev_join;   // second form: stream and events for the next batch's alignment beside the products (nullptr: in line)
     float *part;                                // scratch of the second form of the 64 x 120 products: nq * pair_stride * 32 floats (nullptr: first form)
@@ -144,6 +150,7 @@ struct SurvivorPass {
     const float *approx; int *survivors; unsigned int *t_min; double *out_dist; int *out_shift;
     const float *ring_d2; int k; float exclude_eps; int *topk_idx; float *topk_d2;   // ring-key top-k of every range (workgroup 0 of the query)
     unsigned long long *blk_part; unsigned int *done_counter;
+    unsigned long long *surv_stats;             // optional: [0] += survivors, [1] = max(survivors), [2] += 1 per query scored
     void *d_args; void *h_args;
 };
 // phases: kSurvivorArgs = fill the argument sets and enqueue their copy to the device (may be done ahead of the event the

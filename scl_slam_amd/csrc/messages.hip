@@ -181,19 +181,30 @@ int scl_msg_cloud_from_xyzi(const void *points, uint32_t n_points, scl_msg_cloud
 }
 
 int scl_msg_cloud_xyz_layout(const scl_msg_cloud *cloud, int *stride_bytes, int *xyz_offset)
-{
+{   // the cloud was decoded from a peer's message: nothing in it is trusted
     if (!cloud || !stride_bytes || !xyz_offset) return SCL_ERR_INVALID_ARG;
-    int ox = -1, oy = -1, oz = -1;
+    if (cloud->n_fields && !cloud->fields) return SCL_ERR_INVALID_ARG;
+    int64_t off[3] = {-1, -1, -1};
     for (uint32_t i = 0; i < cloud->n_fields; ++i) {
         const scl_msg_point_field &f = cloud->fields[i];
-        if (f.datatype != 7 || f.name_len != 1) continue;
-        if (f.name[0] == 'x') ox = (int)f.offset;
-        if (f.name[0] == 'y') oy = (int)f.offset;
-        if (f.name[0] == 'z') oz = (int)f.offset;
+        if (f.name_len != 1 || !f.name) continue;
+        const int a = f.name[0] == 'x' ? 0 : f.name[0] == 'y' ? 1 : f.name[0] == 'z' ? 2 : -1;
+        if (a < 0) continue;
+        if (off[a] >= 0) return SCL_ERR_UNSUPPORTED;                              // a second x / y / z field: which one is meant?
+        if (f.datatype != 7 /* FLOAT32 */ || f.count != 1) return SCL_ERR_UNSUPPORTED;
+        off[a] = (int64_t)f.offset;
     }
-    if (ox < 0 || oy != ox + 4 || oz != ox + 8 || cloud->is_bigendian || cloud->point_step < 12 || (cloud->point_step & 3)) return SCL_ERR_UNSUPPORTED;
-    if ((uint64_t)cloud->point_step * cloud->width * cloud->height > cloud->n_data) return SCL_ERR_INVALID_ARG;
-    *stride_bytes = (int)cloud->point_step; *xyz_offset = ox;
+    const uint64_t step = cloud->point_step, n = (uint64_t)cloud->width * (uint64_t)cloud->height;
+    if (off[0] < 0 || off[1] != off[0] + 4 || off[2] != off[0] + 8 || cloud->is_bigendian || step < 12 || (step & 3) || (off[0] & 3) ||
+        step > 0x7fffffffu || (uint64_t)off[0] + 12 > step)                      // z must end inside the record
+        return SCL_ERR_UNSUPPORTED;
+    // rows: pcl::toROSMsg writes row_step = point_step * width; padded rows are not the engine's (pointer, count, stride) layout
+    if (cloud->row_step != 0 && (uint64_t)cloud->row_step != step * (uint64_t)cloud->width) return SCL_ERR_UNSUPPORTED;
+    if (n > 0x7fffffffu || step * n > (uint64_t)cloud->n_data) return SCL_ERR_INVALID_ARG;
+    // The engine's entry points read n * stride bytes from the pointer they are given (data + xyz_offset): with x not at the
+    // start of the record that runs xyz_offset bytes past the last record, so the buffer must hold them
+    if (n && (uint64_t)off[0] + step * n > (uint64_t)cloud->n_data) return SCL_ERR_UNSUPPORTED;
+    *stride_bytes = (int)step; *xyz_offset = (int)off[0];
     return SCL_OK;
 }
 

@@ -52,6 +52,7 @@ struct ScArgs {
     const float *approx; unsigned int *t_min; int range_n; float two_eps;
     const float *ring_d2;     // survivors pass: the ring-key metric of the range (from the screening pass), for the top-k
     int *sel_topk_idx; float *sel_topk_d2; int sel_topk_k; float sel_exclude_eps;
+    unsigned long long *surv_stats;   // survivors pass, optional: survivor count statistics (scl_survivor_stats)
     int S;
     int SR;
     int NW;   // waves per candidate
@@ -993,6 +994,11 @@ __global__ __launch_bounds__(MAXT) void sc_distance_survivors_kernel(const ScArg
     __syncthreads();
     int before = 0, total = 0;
     for (int w = 0; w < nwv; ++w) { const int t = wave_total[w]; if (w < wv) before += t; total += t; }
+    if (bid == 0 && threadIdx.x == 0 && a.surv_stats) {
+        atomicAdd(a.surv_stats, (unsigned long long)total);
+        atomicMax(a.surv_stats + 1, (unsigned long long)total);
+        atomicAdd(a.surv_stats + 2, 1ull);
+    }
     int *list = const_cast<int *>(a.cand);
     for (int base = wlo; base < whi; base += kWave) {
         const int i = base + lane;
@@ -1338,7 +1344,7 @@ hipError_t launch_sc_distance(const DbView &db, const QueryView &q, const int *c
     ScArgs a;
     a.desc = db.desc; a.vkey = db.vkey; a.norm = db.norm;
     a.q_desc = q.desc; a.q_vkey = q.vkey; a.q_norm = q.norm;
-    a.cand = cand; a.slot_base = slot_base; a.n = n; a.n_dev = nullptr; a.approx = nullptr; a.t_min = nullptr; a.range_n = 0; a.two_eps = 0.f; a.ring_d2 = nullptr; a.sel_topk_idx = nullptr; a.sel_topk_d2 = nullptr; a.sel_topk_k = 0; a.sel_exclude_eps = 0.f; a.S = db.S; a.SR = SR;
+    a.cand = cand; a.slot_base = slot_base; a.n = n; a.n_dev = nullptr; a.approx = nullptr; a.t_min = nullptr; a.range_n = 0; a.two_eps = 0.f; a.ring_d2 = nullptr; a.sel_topk_idx = nullptr; a.surv_stats = nullptr; a.sel_topk_d2 = nullptr; a.sel_topk_k = 0; a.sel_exclude_eps = 0.f; a.S = db.S; a.SR = SR;
     a.NW = (db.S + kWave - 1) / kWave; a.G = 1;
     a.ablate = ablate_flags();
     a.align_filter = align_filter_enabled();
@@ -1396,7 +1402,7 @@ hipError_t launch_sc_distance_batch(const DbView &db, const QueryBatch &qb, int 
         a.desc = db.desc; a.vkey = db.vkey; a.norm = db.norm;
         a.q_desc = db.desc + slot * (size_t)(db.RG * db.S); a.q_vkey = db.vkey + slot * db.S;
         a.q_norm = db.norm + slot * db.S; a.q_rkey = db.rkey + slot * (size_t)(4 * db.RG);
-        a.cand = nullptr; a.slot_base = qb.base[i]; a.n = qb.n[i]; a.n_dev = nullptr; a.approx = nullptr; a.t_min = nullptr; a.range_n = 0; a.two_eps = 0.f; a.ring_d2 = nullptr; a.sel_topk_idx = nullptr; a.sel_topk_d2 = nullptr; a.sel_topk_k = 0; a.sel_exclude_eps = 0.f; a.S = db.S; a.SR = SR;
+        a.cand = nullptr; a.slot_base = qb.base[i]; a.n = qb.n[i]; a.n_dev = nullptr; a.approx = nullptr; a.t_min = nullptr; a.range_n = 0; a.two_eps = 0.f; a.ring_d2 = nullptr; a.sel_topk_idx = nullptr; a.surv_stats = nullptr; a.sel_topk_d2 = nullptr; a.sel_topk_k = 0; a.sel_exclude_eps = 0.f; a.S = db.S; a.SR = SR;
         a.NW = (db.S + kWave - 1) / kWave; a.G = 1;
         a.ablate = ablate_flags(); a.stamps = nullptr; a.align_filter = align_filter_enabled();
         a.rkey4 = db.rkey4; a.rk_cap = db.cap;
@@ -1412,6 +1418,46 @@ hipError_t launch_sc_distance_batch(const DbView &db, const QueryBatch &qb, int 
     ab.nb = nmax;                                                      // launch_wave sizes the grid from it
     const int W = 2 * SR + 1;
     if (db.RG == 5 && W == 7 && db.S == 60) return launch_wave<5, 7, 5, 60>(ab, num_cu, stream);
+    return launch_wave<16, 13, 4, 120, 512>(ab, num_cu, stream);
+}
+
+hipError_t launch_sc_distance_matrix(const DbView &db, const int *slots, int nq, int base, int n, int SR,
+                                     double *out_dist, int *out_shift, size_t row_stride, int num_cu, hipStream_t stream)
+{
+    if (nq < 1 || nq > kMaxQueryBatch || n <= 0) return hipErrorInvalidValue;
+    const int W = 2 * SR + 1;
+    const bool wave_grid = ((db.RG == 5 && W == 7 && db.S == 60) || (db.RG == 16 && W == 13 && db.S == 120)) && (db.R % 4 == 0);
+    static const bool force_v1 = [] { const char *e = getenv("SCL_SC_KERNEL"); return e && e[0] == 'v' && e[1] == '1'; }();
+    if (!wave_grid || force_v1) {
+        for (int i = 0; i < nq; ++i) {
+            QueryView q{};
+            const size_t slot = (size_t)slots[i];
+            q.desc = db.desc + slot * (size_t)(db.RG * db.S); q.vkey = db.vkey + slot * db.S; q.norm = db.norm + slot * db.S;
+            q.rkey = db.rkey + slot * (size_t)(4 * db.RG);
+            hipError_t e = launch_sc_distance(db, q, nullptr, base, n, SR, out_dist + (size_t)i * row_stride, out_shift + (size_t)i * row_stride, num_cu, stream);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    ScBatchArgs ab{};
+    ab.nq = nq;
+    for (int i = 0; i < nq; ++i) {
+        ScArgs &a = ab.q[i];
+        const size_t slot = (size_t)slots[i];
+        a.desc = db.desc; a.vkey = db.vkey; a.norm = db.norm;
+        a.q_desc = db.desc + slot * (size_t)(db.RG * db.S); a.q_vkey = db.vkey + slot * db.S;
+        a.q_norm = db.norm + slot * db.S; a.q_rkey = db.rkey + slot * (size_t)(4 * db.RG);
+        a.cand = nullptr; a.slot_base = base; a.n = n; a.n_dev = nullptr; a.approx = nullptr; a.t_min = nullptr; a.range_n = 0; a.two_eps = 0.f; a.ring_d2 = nullptr;
+        a.sel_topk_idx = nullptr; a.surv_stats = nullptr; a.sel_topk_d2 = nullptr; a.sel_topk_k = 0; a.sel_exclude_eps = 0.f; a.S = db.S; a.SR = SR;
+        a.NW = (db.S + kWave - 1) / kWave; a.G = 1;
+        a.ablate = ablate_flags(); a.stamps = nullptr; a.align_filter = align_filter_enabled();
+        a.rkey4 = db.rkey4; a.rk_cap = db.cap; a.out_d2 = nullptr;
+        a.out_dist = out_dist + (size_t)i * row_stride; a.out_shift = out_shift + (size_t)i * row_stride;
+        a.blk_part = nullptr; a.done_counter = nullptr; a.out3 = nullptr; a.topk_idx = nullptr; a.topk_d2 = nullptr; a.topk_k = 0; a.exclude_eps = 0.0f;
+    }
+    for (int i = nq; i < kMaxQueryBatch; ++i) ab.q[i] = ab.q[0];
+    ab.nb = n;                                                         // launch_wave sizes the grid from it
+    if (db.RG == 5) return launch_wave<5, 7, 5, 60>(ab, num_cu, stream);
     return launch_wave<16, 13, 4, 120, 512>(ab, num_cu, stream);
 }
 
@@ -1440,6 +1486,7 @@ hipError_t launch_sc_distance_survivors(const DbView &db, const SurvivorPass &sp
         a.ring_d2 = sp.ring_d2 + (size_t)sp.buf[i] * sp.pair_stride;
         a.sel_topk_idx = sp.topk_idx + sp.buf[i] * kTailTopMaxK; a.sel_topk_d2 = sp.topk_d2 + sp.buf[i] * kTailTopMaxK;
         a.sel_topk_k = sp.k; a.sel_exclude_eps = sp.exclude_eps;
+        a.surv_stats = sp.surv_stats;
     }
     hipError_t e = hipSuccess;
     if (phases & kSurvivorArgs) {
@@ -1486,7 +1533,7 @@ hipError_t launch_sc_distance_survivors_wide(const DbView &db, int nq, const int
         a.q_rkey = db.rkey + slot * (size_t)(4 * db.RG);
         a.cand = survivors[j]; a.slot_base = slot_base[j]; a.n = 256;        // sizes nothing here; the kernel loops over *n_dev
         a.n_dev = n_surv[j]; a.approx = nullptr; a.t_min = nullptr; a.range_n = 0; a.two_eps = 0.f;
-        a.ring_d2 = nullptr; a.sel_topk_idx = nullptr; a.sel_topk_d2 = nullptr; a.sel_topk_k = 0; a.sel_exclude_eps = 0.f;
+        a.ring_d2 = nullptr; a.sel_topk_idx = nullptr; a.surv_stats = nullptr; a.sel_topk_d2 = nullptr; a.sel_topk_k = 0; a.sel_exclude_eps = 0.f;
         a.S = db.S; a.SR = SR; a.NW = (db.S + kWave - 1) / kWave; a.G = 1;
         a.ablate = 0; a.align_filter = 0; a.stamps = nullptr;
         a.rkey4 = db.rkey4; a.rk_cap = db.cap; a.out_d2 = nullptr;

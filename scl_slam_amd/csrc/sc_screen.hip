@@ -785,6 +785,7 @@ struct SelectArgs {
     const float *approx; const float *d2; int n; int slot_base;
     unsigned int *t_min; int *survivors; int *n_surv;       // survivors == nullptr: ring-key top-k only
     int k; float exclude_eps; int *topk_idx; float *topk_d2;
+    unsigned long long *surv_stats;
 };
 struct SelectBatchArgs { SelectArgs q[kMaxScreenBatch]; };
 
@@ -834,6 +835,11 @@ __global__ __launch_bounds__(1024) void sc_select_kernel(SelectBatchArgs sb)
             }
         }
         if (threadIdx.x == 0 && a.survivors) { *a.n_surv = total; *a.t_min = 0xffffffffu; }   // armed for the next launch (stream ordered)
+        if (threadIdx.x == 0 && a.survivors && a.surv_stats) {
+            atomicAdd(a.surv_stats, (unsigned long long)total);
+            atomicMax(a.surv_stats + 1, (unsigned long long)total);
+            atomicAdd(a.surv_stats + 2, 1ull);
+        }
     }
 
     const unsigned long long none = ~0ull;
@@ -888,6 +894,7 @@ hipError_t launch_sc_select_batch(const ScreenBatch &sb, hipStream_t stream)
         s.approx = sb.approx + (size_t)sb.buf[i] * sb.pair_stride; s.d2 = sb.ring_d2 + (size_t)sb.buf[i] * sb.pair_stride;
         s.n = sb.n[i]; s.slot_base = sb.base[i]; s.t_min = sb.t_min + sb.buf[i];
         s.survivors = sb.survivors ? sb.survivors + (size_t)sb.buf[i] * sb.pair_stride : nullptr; s.n_surv = sb.n_surv ? sb.n_surv + sb.buf[i] : nullptr;
+        s.surv_stats = sb.surv_stats;
         s.k = sb.k; s.exclude_eps = sb.exclude_eps; s.topk_idx = sb.topk_idx + sb.buf[i] * kTailTopMaxK; s.topk_d2 = sb.topk_d2 + sb.buf[i] * kTailTopMaxK;
     }
     hipLaunchKernelGGL(sc_select_kernel, dim3(sb.nq), dim3(1024), 0, stream, sel);

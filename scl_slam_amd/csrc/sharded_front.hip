@@ -84,6 +84,63 @@ Rccl *rccl()
     });
     return &r;
 }
+
+// Stand-in collective for tests (exchange = 3): the same function table, so the front runs the very control flow of the RCCL
+// exchange -- pack kernels, grouped all-reduce, select kernels, second all-reduce, one D2H -- with G > 1 ranks on boxes where
+// RCCL cannot (it refuses two ranks on one device, and a one-GPU box has only one).  A group's all-reduces are recorded
+// between GroupStart and GroupEnd; GroupEnd waits for every rank's stream, forms the element-wise minimum of the ranks'
+// input buffers on the host and writes it to every rank's output buffer.  Not a product path: nothing selects it but
+// scl_create_sharded(..., exchange = 3).
+struct MockComm { int rank, size; };
+struct MockOp { const void *in; void *out; size_t count; MockComm *comm; hipStream_t stream; };
+thread_local std::vector<MockOp> g_mock_ops;
+thread_local bool g_mock_open = false;
+
+ncclResult_t mock_comm_init_all(ncclComm_t *comms, int n, const int *)
+{
+    for (int c = 0; c < n; ++c) comms[c] = reinterpret_cast<ncclComm_t>(new MockComm{c, n});
+    return ncclSuccess;
+}
+ncclResult_t mock_comm_destroy(ncclComm_t c) { delete reinterpret_cast<MockComm *>(c); return ncclSuccess; }
+ncclResult_t mock_group_start() { g_mock_ops.clear(); g_mock_open = true; return ncclSuccess; }
+ncclResult_t mock_all_reduce(const void *in, void *out, size_t count, ncclDataType_t dt, ncclRedOp_t op, ncclComm_t comm, hipStream_t stream)
+{
+    if (!g_mock_open || dt != ncclUint64 || op != ncclMin) return ncclInvalidArgument;
+    g_mock_ops.push_back(MockOp{in, out, count, reinterpret_cast<MockComm *>(comm), stream});
+    return ncclSuccess;
+}
+ncclResult_t mock_group_end()
+{
+    g_mock_open = false;
+    if (g_mock_ops.empty()) return ncclSuccess;
+    const size_t count = g_mock_ops[0].count;
+    const int size = g_mock_ops[0].comm->size;
+    if ((int)g_mock_ops.size() != size) return ncclInvalidUsage;                 // every rank takes part exactly once
+    std::vector<unsigned long long> acc(count, ~0ull), tmp(count);
+    std::vector<char> seen((size_t)size, 0);
+    for (const MockOp &o : g_mock_ops) {
+        if (o.count != count || o.comm->size != size || seen[(size_t)o.comm->rank]) return ncclInvalidUsage;
+        seen[(size_t)o.comm->rank] = 1;
+        if (hipStreamSynchronize(o.stream) != hipSuccess) return ncclUnhandledCudaError;
+        if (hipMemcpy(tmp.data(), o.in, count * 8, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+        for (size_t i = 0; i < count; ++i) acc[i] = tmp[i] < acc[i] ? tmp[i] : acc[i];
+    }
+    for (const MockOp &o : g_mock_ops)
+        if (hipMemcpy(o.out, acc.data(), count * 8, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+    g_mock_ops.clear();
+    return ncclSuccess;
+}
+
+Rccl *mock_rccl()
+{
+    static Rccl m = [] {
+        Rccl t;
+        t.CommInitAll = mock_comm_init_all; t.CommDestroy = mock_comm_destroy; t.AllReduce = mock_all_reduce;
+        t.GroupStart = mock_group_start; t.GroupEnd = mock_group_end; t.ok = true;
+        return t;
+    }();
+    return &m;
+}
 #endif
 
 // ---- device side of the RCCL exchange ---------------------------------------------------------------------------
@@ -144,9 +201,10 @@ struct ShardedFront {
     int last_pass = -1;
 
     // device-side exchange (exchange == 2)
-    int exchange = 1;                                      // 1 host merge, 2 RCCL min all-reduce on packed keys
+    int exchange = 1;                                      // 1 host merge, 2 RCCL min all-reduce on packed keys, 3 the same through the tests' stand-in collective
 #ifdef SCL_HAVE_RCCL_HEADER
     ncclComm_t comm[kMaxShards] = {nullptr};
+    Rccl *coll = nullptr;                                  // the collective's function table: librccl, or the stand-in (exchange == 3)
 #endif
     unsigned long long *d_key[kMaxShards] = {nullptr};     // per shard: kFrontSlots groups x {key1, key2, min1, min2}[kMaxQueryBatch]
     unsigned long long *h_keys = nullptr;                  // pinned: kFrontSlots groups x {min1, min2}[kMaxQueryBatch]
@@ -236,7 +294,7 @@ int front_destroy(scl_engine *e)
         if (f->sh[c]) { (void)hipSetDevice(f->dev[c]); (void)eng_sync_streams(f->sh[c]); }
     }
 #ifdef SCL_HAVE_RCCL_HEADER
-    for (int c = 0; c < f->G; ++c) if (f->comm[c]) (void)rccl()->CommDestroy(f->comm[c]);
+    for (int c = 0; c < f->G; ++c) if (f->comm[c] && f->coll) (void)f->coll->CommDestroy(f->comm[c]);
 #endif
     for (int c = 0; c < f->G; ++c) {
         if (f->d_key[c]) { (void)hipSetDevice(f->dev[c]); (void)hipFree(f->d_key[c]); }
@@ -255,7 +313,7 @@ using namespace scl;
 
 extern "C" int scl_create_sharded(const scl_config *cfg, const int *devices, int n_devices, int exchange, scl_engine **out)
 {
-    if (!cfg || !devices || !out || n_devices < 1 || n_devices > kMaxShards || exchange < 0 || exchange > 2) return SCL_ERR_INVALID_ARG;
+    if (!cfg || !devices || !out || n_devices < 1 || n_devices > kMaxShards || exchange < 0 || exchange > 3) return SCL_ERR_INVALID_ARG;
     *out = nullptr;
     scl_engine *e = new (std::nothrow) scl_engine();
     ShardedFront *f = new (std::nothrow) ShardedFront();
@@ -277,16 +335,18 @@ extern "C" int scl_create_sharded(const scl_config *cfg, const int *devices, int
         if (rc) { front_destroy(e); return rc; }
     }
     // the exchange of full-DB winners: 0 = RCCL when it can be had (more than one shard, every shard on its own
-    // device), else the host merge; 1 = host merge; 2 = RCCL or fail
+    // device), else the host merge; 1 = host merge; 2 = RCCL or fail; 3 = the RCCL control flow through the tests' stand-in
+    // collective (any device list)
     f->exchange = 1;
-    if (exchange == 2 || (exchange == 0 && n_devices > 1 && distinct)) {
+    if (exchange >= 2 || (exchange == 0 && n_devices > 1 && distinct)) {
         int rc = SCL_ERR_UNSUPPORTED;
 #ifdef SCL_HAVE_RCCL_HEADER
-        Rccl *r = rccl();
-        if (r->ok && distinct) {
+        Rccl *r = exchange == 3 ? mock_rccl() : rccl();
+        if (r->ok && (distinct || exchange == 3)) {
             const ncclResult_t nr = r->CommInitAll(f->comm, n_devices, f->dev);
             rc = nr == ncclSuccess ? SCL_OK : SCL_ERR_HIP;
             if (rc) for (auto &cm : f->comm) cm = nullptr;
+            else f->coll = r;
         }
 #endif
         if (rc == SCL_OK) {
@@ -299,8 +359,8 @@ extern "C" int scl_create_sharded(const scl_config *cfg, const int *devices, int
             for (int g = 0; g < kFrontSlots && rc == SCL_OK; ++g)
                 if (hipEventCreateWithFlags(&f->ev_group[g], hipEventDisableTiming) != hipSuccess) rc = SCL_ERR_HIP;
         }
-        if (rc == SCL_OK) f->exchange = 2;
-        else if (exchange == 2) { front_destroy(e); return rc; }
+        if (rc == SCL_OK) f->exchange = exchange == 3 ? 3 : 2;
+        else if (exchange >= 2) { front_destroy(e); return rc; }
     }
     *out = e;
     return SCL_OK;
@@ -361,6 +421,11 @@ int front_save_bulk(scl_engine *e, const float *values, int count, const int8_t 
     } else {
         std::vector<float> buf;
         std::vector<int8_t> rb; std::vector<int> ib;
+        // A failure on shard c must not leave shards 0 .. c-1 longer than the front believes they are (global g lives in slot
+        // g / G of shard g % G): the shards that already appended are cut back to their old length
+        int n_old[kMaxShards];
+        for (int c = 0; c < f->G; ++c) n_old[c] = scl_get_size(f->sh[c], -1);
+        auto undo = [&](int upto) { for (int d = 0; d < upto; ++d) (void)eng_truncate(f->sh[d], n_old[d]); };
         for (int c = 0; c < f->G; ++c) {
             // descriptors i with (n + i) % G == c, in order
             int first = (c - f->n % f->G + f->G) % f->G;
@@ -374,9 +439,9 @@ int front_save_bulk(scl_engine *e, const float *values, int count, const int8_t 
                 ib[(size_t)j] = indexs ? indexs[i] : f->n + i;
             }
             int rc = quiesce_if_regrow(e, c, m);
-            if (rc) return rc;
+            if (rc) { undo(c); return rc; }
             rc = scl_save_bulk(f->sh[c], buf.data(), m, rb.data(), ib.data());
-            if (rc) return child_fail(e, f->sh[c], rc, "save on shard");
+            if (rc) { undo(c); return child_fail(e, f->sh[c], rc, "save on shard"); }
         }
     }
     for (int i = 0; i < count; ++i) {
@@ -542,6 +607,22 @@ int front_sc_distance_batch(scl_engine *e, int query, const int *cand, int n, do
     return SCL_OK;
 }
 
+int front_sc_distance_matrix(scl_engine *e, const int *queries, int nq, int lo, int hi, double *dist, int *shift)
+{   // row by row through the per-shard candidate lists (a diagnostic / bulk-export call on a sharded database)
+    int n_all;
+    { std::lock_guard<std::mutex> lk(e->mu); n_all = e->front->n; }
+    if (lo < 0 || hi > n_all || hi < lo) return ffail(e, SCL_ERR_OUT_OF_RANGE, "keyframe range out of the database");
+    const int n = hi - lo;
+    if (n == 0) return SCL_OK;
+    std::vector<int> cand((size_t)n);
+    for (int i = 0; i < n; ++i) cand[(size_t)i] = lo + i;
+    for (int r = 0; r < nq; ++r) {
+        const int rc = front_sc_distance_batch(e, queries[r], cand.data(), n, dist + (size_t)r * n, shift + (size_t)r * n);
+        if (rc) return rc;
+    }
+    return SCL_OK;
+}
+
 // ---- full-DB detection --------------------------------------------------------------------------------------------------
 
 namespace {
@@ -551,7 +632,7 @@ int enqueue_group_exchange(scl_engine *e, const int *front_tickets, int m)
 {
 #ifdef SCL_HAVE_RCCL_HEADER
     ShardedFront *f = e->front;
-    Rccl *r = rccl();
+    Rccl *r = f->coll;
     const int g = (int)(f->next_group % kFrontSlots);
     if (f->group[g].active) return ffail(e, SCL_ERR_INVALID_ARG, "too many full-DB passes in flight: collect first");
     const size_t goff = (size_t)g * 4 * kMaxQueryBatch;
@@ -641,9 +722,19 @@ int submit_many_locked(scl_engine *e, const int *queries, const int *lo, const i
     }
     f->next_pass += (unsigned)nq;
     f->last_pass = tickets[nq - 1];
-    if (f->exchange == 2) {
+    if (f->exchange >= 2) {
         const int rc = enqueue_group_exchange(e, tickets, nq);
-        if (rc) return rc;
+        if (rc) {
+            // the caller gets no tickets: wait for the passes the shards hold and give their slots back
+            const std::string why = e->last_error;
+            for (int i = 0; i < nq; ++i) {
+                ShardedFront::Pass &p = f->pass[tickets[i]];
+                for (int c = 0; c < f->G; ++c) { int a, b; double x; if (p.tk[c] >= 0) (void)scl_detect_full_collect(f->sh[c], p.tk[c], &a, &b, &x); }
+                p.busy = false; p.group = -1;
+            }
+            e->last_error = why;
+            return rc;
+        }
     }
     return SCL_OK;
 }
@@ -865,6 +956,21 @@ int front_alignment_stats(scl_engine *e, uint64_t *pairs, uint64_t *fallbacks, i
     }
     if (pairs) *pairs = p;
     if (fallbacks) *fallbacks = f;
+    return SCL_OK;
+}
+
+int front_survivor_stats(scl_engine *e, uint64_t *queries, uint64_t *survivors, uint64_t *max_survivors, int reset)
+{   // a scan is scored on every shard: survivors add up over the shards of a scan, `queries` counts (scan, shard) passes
+    uint64_t q = 0, s = 0, m = 0;
+    for (int c = 0; c < e->front->G; ++c) {
+        uint64_t qc = 0, sc = 0, mc = 0;
+        const int rc = scl_survivor_stats(e->front->sh[c], &qc, &sc, &mc, reset);
+        if (rc) return rc;
+        q += qc; s += sc; m = mc > m ? mc : m;
+    }
+    if (queries) *queries = q;
+    if (survivors) *survivors = s;
+    if (max_survivors) *max_survivors = m;
     return SCL_OK;
 }
 

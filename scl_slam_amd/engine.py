@@ -93,6 +93,7 @@ def _bind(lib):
         "scl_stage_query": (c_int, [P, fp]),
         "scl_ringkey_topk": (c_int, [P, c_int, c_int, c_int, c_int, ip, fp, ip]),
         "scl_sc_distance_batch": (c_int, [P, c_int, ip, c_int, dp, ip]),
+        "scl_sc_distance_matrix": (c_int, [P, ip, c_int, c_int, c_int, dp, ip]),
         "scl_detect_full": (c_int, [P, c_int, ip, ip, ip, dp]),
         "scl_detect_full_range": (c_int, [P, c_int, c_int, c_int, ip, ip, dp]),
         "scl_get_last_topk": (c_int, [P, c_int, ip, fp]),
@@ -127,6 +128,7 @@ def _bind(lib):
         "scl_profile_reset": (c_int, [P]),
         "scl_profile_get": (c_int, [P, POINTER(SclProfile)]),
         "scl_alignment_stats": (c_int, [P, POINTER(ctypes.c_uint64), POINTER(ctypes.c_uint64), c_int]),
+        "scl_survivor_stats": (c_int, [P, POINTER(ctypes.c_uint64), POINTER(ctypes.c_uint64), POINTER(ctypes.c_uint64), c_int]),
         "scl_device_name": (c_int, [P, c_char_p, c_int]),
     }
     for name, (res, args) in sig.items():
@@ -341,6 +343,15 @@ class ScanContextEngine:
         dist = np.empty(n, dtype=np.float64); shift = np.empty(n, dtype=np.int32)
         self._check(self._lib.scl_sc_distance_batch(self._h, query, cp, n, _ptr(dist, c_double),
                                                     _ptr(shift, c_int)), "scl_sc_distance_batch")
+        return dist, shift
+
+    def sc_distance_matrix(self, queries, lo, hi):
+        """exact fp64 distance and shift of every (queries[r], keyframe lo..hi-1) pair: two arrays of shape (len(queries), hi - lo)"""
+        q = np.ascontiguousarray(queries, dtype=np.int32)
+        n = max(0, int(hi) - int(lo))
+        dist = np.empty((q.size, n), dtype=np.float64); shift = np.empty((q.size, n), dtype=np.int32)
+        self._check(self._lib.scl_sc_distance_matrix(self._h, _ptr(q, c_int), q.size, int(lo), int(hi), _ptr(dist, c_double), _ptr(shift, c_int)),
+                    "scl_sc_distance_matrix")
         return dist, shift
 
     def detect_full(self, cur):
@@ -615,6 +626,12 @@ class ScanContextEngine:
         a, b = c_uint64(0), c_uint64(0)
         self._check(self._lib.scl_alignment_stats(self._h, byref(a), byref(b), int(bool(reset))), "scl_alignment_stats")
         return int(a.value), int(b.value)
+
+    def survivor_stats(self, reset=False):
+        """(scans through an exact pass, keyframes scored exactly for them, largest count of one scan) since the last reset"""
+        q, s, m = c_uint64(0), c_uint64(0), c_uint64(0)
+        self._check(self._lib.scl_survivor_stats(self._h, byref(q), byref(s), byref(m), int(bool(reset))), "scl_survivor_stats")
+        return int(q.value), int(s.value), int(m.value)
 
     def device_name(self):
         buf = ctypes.create_string_buffer(256)

@@ -192,6 +192,30 @@ def test_database_dump_and_load_reproduce_detections(tmp_path):
     open(str(tmp_path / "bad.scl"), "wb").write(b"not a dump")
     with pytest.raises(SclError):
         fresh.db_load(str(tmp_path / "bad.scl"))
+    # a header is not trusted.  A count the file cannot hold (here 2^31 - 1: tens of GB of index map if it were
+    # believed) and a truncated file are refused before anything is sized by them, and nothing is appended
+    raw = open(path, "rb").read()
+    import struct
+    hostile = raw[:8] + struct.pack("<iiii", 1, R, S, 2 ** 31 - 1) + raw[24:]
+    open(str(tmp_path / "hostile.scl"), "wb").write(hostile)
+    open(str(tmp_path / "short.scl"), "wb").write(raw[:len(raw) - 4096])
+    for name in ("hostile.scl", "short.scl"):
+        with pytest.raises(SclError):
+            fresh.db_load(str(tmp_path / name))
+    assert fresh.get_size() == n
+    # the inter-robot path's tree state (D.h:1691-1703: rebuilt every TREE_MAKING_PERIOD_ calls) travels with the dump: an
+    # engine that has answered some detectInterLoopClosureID calls and its reloaded copy give the same answers from there on
+    src = ScanContextEngine(num_ring=R, num_sector=S, initial_capacity=64)
+    src.save_bulk(descs[:700], robots[:700], indexs[:700])
+    for cur in (650, 651, 652):
+        src.detect_inter(cur)                                          # the tree now covers [0, 550), counter = 3
+    src.save_bulk(descs[700:], robots[700:], indexs[700:])
+    src.db_dump(str(tmp_path / "mid.scl"))
+    twin = ScanContextEngine(num_ring=R, num_sector=S, initial_capacity=16)
+    assert twin.db_load(str(tmp_path / "mid.scl")) == n
+    for cur in range(n - 1, n - 13, -1):                               # crosses the next rebuild (period 10) on both
+        assert twin.detect_inter(cur) == src.detect_inter(cur)
+    src.close(); twin.close()
     one.close(); fresh.close(); sharded.close()
 
 

@@ -45,6 +45,30 @@ def test_distance_batch_matches_oracle(R, S, n):
     eng.close()
 
 
+@pytest.mark.parametrize("R,S,n", [(20, 60, 300), (64, 120, 700), (80, 180, 60), (22, 50, 40)])
+def test_distance_matrix_matches_oracle(R, S, n):
+    """scl_sc_distance_matrix -- north_star's distance matrix: every (scan, keyframe) entry the exact fp64 evaluation.  Rows of
+    several launches (the results of one travel while the next runs), a sub-range of the database, a staged query."""
+    descs, eng, db = build(R, S, n, seed=300 + R)
+    qs = np.array([n - 1, 0, n // 2, n - 2, 3, n - 3, 5, 7, n - 9, 11, 1], dtype=np.int32)       # 11 rows: three launches of 4, 4, 3
+    for lo, hi in ((0, n), (7, n - 13), (n - 1, n)):
+        d, s = eng.sc_distance_matrix(qs, lo, hi)
+        assert d.shape == (len(qs), hi - lo)
+        for r, q in enumerate(qs):
+            d_cpu, s_cpu = db.distance_batch(int(q), cand=np.arange(lo, hi, dtype=np.int32), fast=True)
+            assert_same(d[r], s[r], d_cpu, s_cpu)
+    ext = synth_descriptors(1, R, S, seed=991)[0]
+    eng.stage_query(ext)
+    d, s = eng.sc_distance_matrix([-1, n - 1], 0, n)
+    db.save_bulk(ext[None])
+    d_cpu, s_cpu = db.distance_batch(n, n=n, fast=True)
+    assert_same(d[0], s[0], d_cpu, s_cpu)
+    assert eng.sc_distance_matrix([], 0, n)[0].shape == (0, n) and eng.sc_distance_matrix([1], 4, 4)[0].shape == (1, 0)
+    with pytest.raises(Exception):
+        eng.sc_distance_matrix([n], 0, n)
+    eng.close()
+
+
 def test_reference_shaped_oracle_agrees_on_sample():
     descs, eng, db = build(64, 120, 40, seed=8)
     d_gpu, s_gpu = eng.sc_distance_batch(39, n=40)

@@ -137,6 +137,50 @@ def test_rccl_exchange_single_shard():
     rc.close(); one.close()
 
 
+@pytest.mark.parametrize("G", [2, 8])
+def test_device_side_exchange_control_flow_with_several_ranks(G):
+    """exchange = 2's control flow -- pack kernel per rank, grouped all-reduce(uint64, min) on the distance keys,
+    select kernel, second all-reduce on (global index, shift), one D2H -- executed with G > 1 ranks.  RCCL refuses two ranks
+    on one device, so the collective itself is the tests' stand-in (exchange = 3: element-wise min of the ranks' buffers);
+    everything around it is the code a node runs.  Must equal the host merge (exchange = 1) and one unsharded database,
+    bit for bit -- duplicated keyframes on different shards (equal distances: the lowest GLOBAL index wins, which is what
+    the second reduction decides), ranges that leave some shards empty, a range with no candidate at all."""
+    R, S, n = 64, 120, 1800
+    descs = synth_descriptors(n, R, S, seed=78, revisit_frac=0.05)
+    rs = np.random.RandomState(4)
+    for i in range(40):                                                   # exact duplicates at other global indices: ties across shards
+        a, b = rs.randint(0, n - 300, 2)
+        descs[b] = descs[a]
+    for q in range(n - 40, n, 5):                                         # queries that are rolled copies of a duplicated pair
+        a = int(rs.randint(0, n - 300)); descs[(a + 1 + G // 2) % (n - 300)] = descs[a]
+        descs[q] = np.roll(descs[a], int(rs.randint(0, S)), axis=1)
+    one = ScanContextEngine(num_ring=R, num_sector=S, initial_capacity=n)
+    host = ScanContextEngine(num_ring=R, num_sector=S, initial_capacity=n, devices=[0] * G, exchange=1)
+    dev = ScanContextEngine(num_ring=R, num_sector=S, initial_capacity=n, devices=[0] * G, exchange=3)
+    assert dev.shard_info() == (G, 3) and host.shard_info() == (G, 1)
+    for e in (one, host, dev):
+        e.save_bulk(descs)
+    for cur in list(range(n - 1, n - 41, -1)):
+        x, y, z = dev.detect_full(cur), host.detect_full(cur), one.detect_full(cur)
+        assert x[:3] == y[:3] == z[:3] and _same_bits(x[3], y[3]) and _same_bits(x[3], z[3]), cur
+    # launch groups of several scans (one exchange per group), ragged and empty ranges
+    qs = [n - 1, n - 6, n - 11, n - 3]
+    for his in ([n - 101, n - 106, n - 111, n - 103], [G - 1, 1, 0, 3], [0, 0, 0, 0], [n - 101, 0, 2, n - 103]):
+        td = dev.detect_full_submit_many(qs, [0] * 4, his); th = host.detect_full_submit_many(qs, [0] * 4, his)
+        to = one.detect_full_submit_many(qs, [0] * 4, his)
+        for a, b, c in zip(td, th, to):
+            ra, rb, rc_ = dev.detect_full_collect(a), host.detect_full_collect(b), one.detect_full_collect(c)
+            assert ra[:2] == rb[:2] == rc_[:2] and _same_bits(ra[2], rb[2]) and _same_bits(ra[2], rc_[2]), (his, ra, rb, rc_)
+    # several groups in flight before the first collect
+    tick = [(dev.detect_full_submit_many([n - 1 - j, n - 2 - j], [0, 0], [n - 101 - j, n - 102 - j]),
+             one.detect_full_submit_many([n - 1 - j, n - 2 - j], [0, 0], [n - 101 - j, n - 102 - j])) for j in range(0, 6, 2)]
+    for td, to in tick:
+        for a, c in zip(td, to):
+            ra, rc_ = dev.detect_full_collect(a), one.detect_full_collect(c)
+            assert ra[:2] == rc_[:2] and _same_bits(ra[2], rc_[2])
+    dev.close(); host.close(); one.close()
+
+
 def test_candidates_of_one_scan_verified_across_shards():
     """scl_icp_align_batch on a sharded engine deals the loop candidates to the shards"""
     tgts = [synth_structured_cloud(3000 + 100 * c, seed=60 + c) for c in range(5)]
@@ -172,6 +216,23 @@ def test_configs3_100k_keyframes_sharded_equals_single_database(G):
         assert sh.detect_intra(cur) == one.detect_intra(cur)
         x, y = sh.detect_full(cur), one.detect_full(cur)
         assert x[:3] == y[:3] and _same_bits(x[3], y[3])
+    if G == 2:
+        # The checker at full size: two scans -- a planted revisit and an ordinary keyframe -- scored by
+        # the CPU restatement against ALL eligible keyframes of the 100k database (every core of the host), arg-min as the
+        # reference's loop takes it (strict <, ascending index), winner compared bit for bit with both engines.
+        allv = one.get_descriptors(0, n)
+        cfg = ob.make_config(R=R, S=S)
+        odb = ob.OracleDB(cfg); odb.save_bulk(allv)
+        del allv
+        threads = len(os.sched_getaffinity(0))
+        for cur in (n - 1, n - 2):
+            hist = cur - 100
+            dist, shift = odb.distance_batch_mt(cur, np.arange(hist, dtype=np.int32), True, threads)
+            best = int(np.flatnonzero(dist == np.nanmin(dist))[0])
+            x = sh.detect_full(cur)
+            assert x[1] == best and x[2] == int(shift[best]) and _same_bits(x[3], dist[best]), (cur, x, best, dist[best])
+            assert x[:3] == one.detect_full(cur)[:3]
+        odb.close()
     sh.close(); one.close()
 
 

@@ -112,6 +112,50 @@ def test_loop_info_and_service_messages():
     assert np.array_equal(back, pts)
 
 
+def test_cloud_layout_of_a_peer_message_is_checked_not_trusted():
+    """a decoded PointCloud2 comes from another robot.  Layouts whose x / y / z reads would leave the record or the
+    buffer -- or that are ambiguous -- are refused; the reference's own layout (pcl::toROSMsg of PointXYZI, DM.h:1329) passes."""
+    L = M.lib()
+    pts = np.zeros((5, 8), np.float32)
+    buf = (ctypes.c_uint8 * pts.nbytes).from_buffer_copy(pts.tobytes())
+
+    def layout(fields, point_step=32, row_step=None, n_data=None, width=5, height=1, bigendian=0):
+        fs = (M.PointField * max(1, len(fields)))()
+        for i, (name, off, dt, cnt) in enumerate(fields):
+            fs[i].name = name; fs[i].name_len = len(name); fs[i].offset = off; fs[i].datatype = dt; fs[i].count = cnt
+        c = M.Cloud()
+        c.height, c.width, c.fields, c.n_fields = height, width, fs, len(fields)
+        c.is_bigendian, c.point_step = bigendian, point_step
+        c.row_step = point_step * width if row_step is None else row_step
+        c.data = ctypes.cast(buf, ctypes.POINTER(ctypes.c_uint8)); c.n_data = pts.nbytes if n_data is None else n_data
+        stride, off = ctypes.c_int(-1), ctypes.c_int(-1)
+        return L.scl_msg_cloud_xyz_layout(ctypes.byref(c), ctypes.byref(stride), ctypes.byref(off)), stride.value, off.value
+
+    xyz = [(b"x", 0, 7, 1), (b"y", 4, 7, 1), (b"z", 8, 7, 1)]
+    assert layout(xyz + [(b"intensity", 16, 7, 1)]) == (0, 32, 0)
+    assert layout(xyz, point_step=12, n_data=60) == (0, 12, 0)
+    OK, INVALID, UNSUPPORTED = 0, -1, None
+    rc_unsupported = layout([(b"x", 0, 7, 1), (b"y", 8, 7, 1), (b"z", 4, 7, 1)])[0]          # not consecutive
+    assert rc_unsupported != 0
+    bad = {
+        "z runs past the record": layout([(b"x", 24, 7, 1), (b"y", 28, 7, 1), (b"z", 32, 7, 1)]),
+        "x late in the record, no slack behind the last record": layout([(b"x", 16, 7, 1), (b"y", 20, 7, 1), (b"z", 24, 7, 1)]),
+        "duplicate x": layout(xyz + [(b"x", 16, 7, 1)]),
+        "count 2": layout([(b"x", 0, 7, 2), (b"y", 4, 7, 1), (b"z", 8, 7, 1)]),
+        "float64 fields": layout([(b"x", 0, 8, 1), (b"y", 4, 8, 1), (b"z", 8, 8, 1)]),
+        "big endian": layout(xyz, bigendian=1),
+        "padded rows": layout(xyz, row_step=200),
+        "step not a multiple of four": layout(xyz, point_step=14, n_data=70),
+        "missing z": layout(xyz[:2]),
+    }
+    for why, (rc, _, _) in bad.items():
+        assert rc == rc_unsupported, why
+    assert layout(xyz, n_data=159)[0] not in (0, rc_unsupported)                              # data shorter than the records it declares
+    assert layout(xyz, width=1 << 20, height=1 << 12)[0] != 0
+    # x late in the record is fine when the buffer holds the bytes a whole-record read from data + offset touches
+    assert layout([(b"x", 16, 7, 1), (b"y", 20, 7, 1), (b"z", 24, 7, 1)], width=4) == (0, 32, 16)
+
+
 def test_transform_pose_conversions():
     rs = np.random.RandomState(3)
     for _ in range(200):
