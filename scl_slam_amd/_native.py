@@ -3,6 +3,11 @@ import ctypes
 import os
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libscl_engine.so")
+# SCL_ENGINE_LIB: another build of the same library (kernel experiments: scripts/build_variant.sh); said out loud when used
+if os.environ.get("SCL_ENGINE_LIB"):
+    LIB_PATH = os.path.abspath(os.environ["SCL_ENGINE_LIB"])
+    import sys
+    print(f"scl_slam_amd: loading the engine from SCL_ENGINE_LIB={LIB_PATH}", file=sys.stderr)
 
 
 class NativeLibraryError(RuntimeError):

@@ -110,7 +110,7 @@ DbView db_view(const scl_engine *e)
 {
     DbView v;
     v.desc = e->d_desc; v.vkey = e->d_vkey; v.norm = e->d_norm; v.rkey = e->d_rkey; v.rkey4 = e->d_rkey4;
-    v.hdesc = e->d_hdesc; v.kmask = e->d_kmask; v.hkey = e->d_hkey; v.hstride = e->hstride;
+    v.hdesc = e->d_hdesc; v.kmask = e->d_kmask; v.hkey = e->d_hkey; v.hstride = e->hstride; v.halign = e->d_halign;
     v.cap = e->cap; v.R = e->R; v.S = e->S; v.RG = e->RG;
     return v;
 }
@@ -139,7 +139,8 @@ int ensure_capacity(scl_engine *e, int need)
     while (ncap < need) ncap *= 2;
     const size_t tile = (size_t)e->RG * e->S;
     float4 *nd = nullptr; double *nv = nullptr; double *nn = nullptr; float *nr = nullptr; float4 *nr4 = nullptr;
-    uint2 *nh = nullptr; unsigned int *nk = nullptr; unsigned short *nhk = nullptr;
+    uint2 *nh = nullptr; unsigned int *nk = nullptr; unsigned short *nhk = nullptr; unsigned char *nha = nullptr;
+    const size_t hab = (size_t)halign_bytes(e->S);            // alignment images: database slots only
     int rc;
     const size_t nst = (size_t)ncap + scl_engine::kStage;     // database slots + the staging slots behind them
     if ((rc = dev_alloc(e, &nd, tile * nst))) return rc;
@@ -149,6 +150,7 @@ int ensure_capacity(scl_engine *e, int need)
     if ((rc = dev_alloc(e, &nh, (size_t)e->hstride * nst))) return rc;
     if ((rc = dev_alloc(e, &nk, (size_t)8 * nst))) return rc;
     if ((rc = dev_alloc(e, &nhk, (size_t)e->hkw * nst))) return rc;
+    if (hab && (rc = dev_alloc(e, &nha, hab * (size_t)ncap))) return rc;
     if ((rc = dev_alloc(e, &nr4, (size_t)e->RG * ncap))) return rc;
     SCL_HIP(e, hipMemsetAsync(nr4, 0, sizeof(float4) * (size_t)e->RG * ncap, e->stream));
     if (e->n > 0) {
@@ -159,6 +161,7 @@ int ensure_capacity(scl_engine *e, int need)
         SCL_HIP(e, hipMemcpyAsync(nh, e->d_hdesc, sizeof(uint2) * (size_t)e->hstride * e->n, hipMemcpyDeviceToDevice, e->stream));
         SCL_HIP(e, hipMemcpyAsync(nk, e->d_kmask, sizeof(unsigned int) * (size_t)8 * e->n, hipMemcpyDeviceToDevice, e->stream));
         SCL_HIP(e, hipMemcpyAsync(nhk, e->d_hkey, sizeof(unsigned short) * (size_t)e->hkw * e->n, hipMemcpyDeviceToDevice, e->stream));
+        if (hab) SCL_HIP(e, hipMemcpyAsync(nha, e->d_halign, hab * (size_t)e->n, hipMemcpyDeviceToDevice, e->stream));
         SCL_HIP(e, hipMemcpy2DAsync(nr4, sizeof(float4) * ncap, e->d_rkey4, sizeof(float4) * e->cap,
                                     sizeof(float4) * e->n, e->RG, hipMemcpyDeviceToDevice, e->stream));
     }
@@ -175,9 +178,9 @@ int ensure_capacity(scl_engine *e, int need)
     SCL_HIP(e, hipStreamSynchronize(e->stream));
     if (e->stream_alt) SCL_HIP(e, hipStreamSynchronize(e->stream_alt));   // passes still reading the old arrays
     dev_free(e->d_desc); dev_free(e->d_vkey); dev_free(e->d_norm); dev_free(e->d_rkey); dev_free(e->d_rkey4);
-    dev_free(e->d_hdesc); dev_free(e->d_kmask); dev_free(e->d_hkey);
+    dev_free(e->d_hdesc); dev_free(e->d_kmask); dev_free(e->d_hkey); dev_free(e->d_halign);
     e->d_desc = nd; e->d_vkey = nv; e->d_norm = nn; e->d_rkey = nr; e->d_rkey4 = nr4;
-    e->d_hdesc = nh; e->d_kmask = nk; e->d_hkey = nhk;
+    e->d_hdesc = nh; e->d_kmask = nk; e->d_hkey = nhk; e->d_halign = nha;
     e->cap = ncap;
     return SCL_OK;
 }
@@ -253,7 +256,7 @@ int ingest_from_vals(scl_engine *e, int count, int first_slot)
 {
     ProfScope ps(e, P_INGEST);
     SCL_HIP(e, launch_ingest(e->d_vals, count, first_slot, e->d_desc, e->d_vkey, e->d_norm, e->d_rkey,
-                             e->d_rkey4, e->d_hdesc, e->d_kmask, e->d_hkey, e->hstride, e->cap, e->R, e->S, e->stream));
+                             e->d_rkey4, e->d_hdesc, e->d_kmask, e->d_hkey, e->hstride, e->cap, e->R, e->S, e->stream, e->d_halign));
     e->db_version++;                                       // the alt lane orders itself behind this write
     return SCL_OK;
 }
@@ -434,7 +437,7 @@ int scl_create(const scl_config *cfg, scl_engine **out)
     e->R = cfg->num_ring; e->S = cfg->num_sector;
     e->RG = (e->R + 3) / 4; e->R4 = e->RG * 4;
     e->hstride = hdesc_stride(e->RG, e->S);
-    e->hkw = hkey_store_halfs(e->S);
+    e->hkw = hkey_row_halfs(e->S);
     e->SR = (int)std::round(0.5 * cfg->search_ratio * (double)e->S);   /* D.h:1545 */
     if (e->SR < 0) e->SR = 0;
     e->device = cfg->device;
@@ -528,7 +531,7 @@ int scl_destroy(scl_engine *e)
         if (e->icp_lane_stream[i]) (void)hipStreamDestroy(e->icp_lane_stream[i]);
     }
     dev_free(e->d_desc); dev_free(e->d_vkey); dev_free(e->d_norm); dev_free(e->d_rkey); dev_free(e->d_rkey4);
-    dev_free(e->d_hdesc); dev_free(e->d_kmask); dev_free(e->d_hkey);
+    dev_free(e->d_hdesc); dev_free(e->d_kmask); dev_free(e->d_hkey); dev_free(e->d_halign);
     dev_free(e->d_vals); dev_free(e->d_points); dev_free(e->d_tile);
     dev_free(e->d_dist); dev_free(e->d_shift); dev_free(e->d_cand); dev_free(e->d_ring_d2);
     dev_free(e->d_approx); dev_free(e->d_starts); dev_free(e->d_surv); dev_free(e->d_nsurv); dev_free(e->d_tmin); dev_free(e->d_part);

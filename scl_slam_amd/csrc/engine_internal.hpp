@@ -46,6 +46,7 @@ struct scl_engine {
     float4 *d_desc = nullptr; double *d_vkey = nullptr; double *d_norm = nullptr;
     float *d_rkey = nullptr; float4 *d_rkey4 = nullptr;
     uint2 *d_hdesc = nullptr; unsigned int *d_kmask = nullptr; int hstride = 0;
+    unsigned char *d_halign = nullptr;                      // alignment images of the database's keyframes (kernels.hpp: halign_bytes(S) each)
     unsigned short *d_hkey = nullptr; int hkw = 0;          // dense fp16 sector keys (+ norms), hkw halfs per slot   // the screening pass's fp16 copy + sector masks
     std::vector<int8_t> robots;
     std::vector<int> indexs;

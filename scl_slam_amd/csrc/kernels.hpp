@@ -10,6 +10,17 @@ constexpr double kBigDist = 10000000.0;   // D.h:1494,1556,1637,1705 initial min
 constexpr int hdesc_sector(int RG) { return ((RG * 8 + 63) / 64) * 8; }   // 8-byte elements per sector of hdesc: ring groups padded to whole 64-byte k-steps
 constexpr int hkey_halfs(int S) { return ((S + 31) / 32) * 32; }         // the unit-norm fp16 sector key behind the copy, zero padded to whole k-steps
 constexpr int hkey_store_halfs(int S) { return hkey_halfs(S) + 8; }      // ... followed by the key's norm as a float (and 12 spare bytes)
+constexpr int hkey_row_halfs(int S) { return 2 * hkey_halfs(S) + 8; }    // a row of the dense key table: the same, then the key's SECOND fp16 part fp16(2^11 (k - kh)), zero padded alike (stage 2 of the alignment's second form)
+// The alignment image of a keyframe (second form of the alignment, sc_screen.hip): P copies of the unit fp16 sector key, copy rho
+// rotated right by rho sectors -- X_rho[i] = key[(i - rho) mod S], i in [0, CP) with CP >= S + 8 (the first sectors repeat behind
+// the last: eight consecutive entries never wrap).  Layout of a slot: 16 bytes (the key's norm as a float, 12 spare), the P copies
+// of the key's first fp16 part kh, the P copies of its second part fp16(2^11 (k - kh)).  With P | S the correlation's matrix-core
+// operand (row sigma, phase rho: shift P sigma + rho) is whole, aligned chunks of P halfs of copy rho: P = 8 at S = 120 (16 B per
+// chunk), 4 at S = 180 (8 B).  0 bytes: no image for this grid.
+constexpr int halign_P(int S) { return S % 8 == 0 ? 8 : (S % 4 == 0 ? 4 : 0); }
+constexpr int halign_CP(int S) { return ((S + 8 + 31) / 32) * 32; }
+constexpr int halign_img_bytes(int S) { return halign_P(S) * halign_CP(S) * 2; }                      // one part
+constexpr int halign_bytes(int S) { return halign_P(S) ? 16 + 2 * halign_img_bytes(S) : 0; }
 // A second image of the copy sits behind the key, for the second form of the screening products (sc_screen.hip):
 // chunk-major -- [ring part h of 32 rings][16-byte chunk j][sector 0 .. S+15] x 16 B (rings 32h + 8j .. + 7 of sector s mod S), so
 // that the 16 consecutive sectors a matrix-core fragment needs per chunk are 256 consecutive bytes; offsets in 8-byte elements,
@@ -36,7 +47,7 @@ constexpr int hdesc_stride(int RG, int S) { return hdesc_stride_rgh(hdesc_sector
 //                                desc.  Behind it the sector key as a unit vector in fp16 (vkey / |vkey|, zero padded to a multiple of 32; all zero when the
 //                                norm is zero or not finite) and its norm as a float: the first stage of the alignment filter; behind that, 128-byte aligned, the
 //                                chunk-major image of the same values (hdesc2_offset / hdesc2_elems above).  hstride = hdesc_stride(RG, S) elements of 8 B.
-//   hkey   half   [cap][hkey_store_halfs(S)]  the fp16 sector key and its norm as stored behind hdesc's copy, in a table of its own: the alignment reads
+//   hkey   half   [cap][hkey_row_halfs(S)]  the fp16 sector key and its norm as stored behind hdesc's copy (+ the key's second fp16 part), in a table of its own: the alignment reads
 //                                nothing else of a keyframe, and 272 B at a stride of 33 KB cost it a DRAM page and a TLB entry per keyframe
 //   kmask  u32    [cap][8]       bit c of words 0..6 = column c has a non-zero norm; word 7 bit 0 = some column norm is outside [2^-60, 2^60] or non-finite (such keyframes are always scored exactly)
 struct DbView {
@@ -45,7 +56,8 @@ struct DbView {
     const double *norm;
     const uint2  *hdesc;
     const unsigned int *kmask;
-    const unsigned short *hkey;   // [cap][hkey_store_halfs(S)] the unit fp16 sector keys + norms once more, DENSE (272 B per keyframe at S = 120): what the alignment reads
+    const unsigned short *hkey;   // [cap][hkey_row_halfs(S)] the unit fp16 sector keys + norms once more, DENSE (272 B per keyframe at S = 120): what the alignment reads
+    const unsigned char *halign;  // [cap][halign_bytes(S)] the alignment images of the database's keyframes (no staging rows: a scan is the other operand); may be null
     int hstride;
     const float  *rkey;
     const float4 *rkey4;
@@ -192,7 +204,7 @@ hipError_t launch_ringkey_topk(const DbView &db, const float *qkey, int lo, int 
 hipError_t launch_ingest(const float *values, int count, int first_slot,
                          float4 *desc, double *vkey, double *norm, float *rkey, float4 *rkey4,
                          uint2 *hdesc, unsigned int *kmask, unsigned short *hkey, int hstride,
-                         int cap, int R, int S, hipStream_t stream);
+                         int cap, int R, int S, hipStream_t stream, unsigned char *halign = nullptr);
 // tiled -> row-major wire format (read back)
 hipError_t launch_untile(const float4 *desc_slot, int R, int S, float *values, hipStream_t stream);
 

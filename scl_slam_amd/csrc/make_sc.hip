@@ -82,7 +82,8 @@ __global__ void make_sc_finalize_kernel(const int *gtile, int cells, float *valu
 // One workgroup per descriptor.  values: [count][R*S] row-major floats.
 __global__ __launch_bounds__(256) void ingest_kernel(
     const float *values, int first_slot, float4 *desc, double *vkey, double *norm,
-    float *rkey, float4 *rkey4, uint2 *hdesc, unsigned int *kmask, unsigned short *hkey, int hstride, int cap, int R, int S)
+    float *rkey, float4 *rkey4, uint2 *hdesc, unsigned int *kmask, unsigned short *hkey, int hstride, int cap, int R, int S,
+    unsigned char *halign)
 {
     extern __shared__ float sv[];                 // [R][S+1], then the S reciprocal norms
     const int LS = S + 1;                         // odd-ish stride: column walks hit distinct banks
@@ -180,14 +181,38 @@ __global__ __launch_bounds__(256) void ingest_kernel(
         for (int c = 0; c < S; ++c) n2 = n2 + svk[c] * svk[c];            // every thread the same sequential sum
         const double nrm = sqrt(n2);
         const bool usable = nrm > 0.0 && nrm < 1.0e300;                   // zero, NaN, inf: all zero -> every shift ties -> exact evaluation
-        _Float16 *hd = reinterpret_cast<_Float16 *>(hkey + (size_t)slot * hkey_store_halfs(S));   // the dense table of the same keys
+        _Float16 *hd = reinterpret_cast<_Float16 *>(hkey + (size_t)slot * hkey_row_halfs(S));   // the dense table of the same keys
+        // second fp16 part of an entry: fp16(2^11 (u - kh)) -- scaled so that it is a normal number; u - kh is exact in fp64
+        auto parts = [&](int c, _Float16 *h, _Float16 *l) {
+            const double u = svk[c] / nrm;
+            const _Float16 kh = (_Float16)(float)u;
+            *h = kh; *l = (_Float16)(float)((u - (double)(float)kh) * 2048.0);
+        };
         for (int c = threadIdx.x; c < SK; c += blockDim.x) {
-            const _Float16 v = (c < S && usable) ? (_Float16)(float)(svk[c] / nrm) : (_Float16)0.0f;
-            hk[c] = v; hd[c] = v;
+            _Float16 v = (_Float16)0.0f, vl = (_Float16)0.0f;
+            if (c < S && usable) parts(c, &v, &vl);
+            hk[c] = v; hd[c] = v; hd[SK + 8 + c] = vl;
         }
         if (threadIdx.x == 0) {
             *reinterpret_cast<float *>(hk + SK) = usable ? (float)nrm : -1.0f;   // the filter's range check (negative: no decision)
             *reinterpret_cast<float *>(hd + SK) = usable ? (float)nrm : -1.0f;
+        }
+        // the alignment image (kernels.hpp: halign_*): norm, P rotated copies of either part; database slots only
+        const int P = halign_P(S), CP = halign_CP(S);
+        if (halign && P && slot < cap) {
+            unsigned char *img = halign + (size_t)slot * (size_t)halign_bytes(S);
+            _Float16 *x = reinterpret_cast<_Float16 *>(img + 16);
+            for (int i = threadIdx.x; i < P * CP; i += blockDim.x) {
+                const int rho = i / CP, k = i - rho * CP;
+                int c = (k - rho) % S; c = c < 0 ? c + S : c;
+                _Float16 v = (_Float16)0.0f, vl = (_Float16)0.0f;
+                if (usable) parts(c, &v, &vl);
+                x[i] = v; x[P * CP + i] = vl;
+            }
+            if (threadIdx.x == 0) {
+                float *head = reinterpret_cast<float *>(img);
+                head[0] = usable ? (float)nrm : -1.0f; head[1] = 0.f; head[2] = 0.f; head[3] = 0.f;
+            }
         }
     }
     if (threadIdx.x < 8) {
@@ -240,7 +265,7 @@ hipError_t launch_make_sc(const void *points, int n, int stride_bytes, int R, in
 hipError_t launch_ingest(const float *values, int count, int first_slot,
                          float4 *desc, double *vkey, double *norm, float *rkey, float4 *rkey4,
                          uint2 *hdesc, unsigned int *kmask, unsigned short *hkey, int hstride,
-                         int cap, int R, int S, hipStream_t stream)
+                         int cap, int R, int S, hipStream_t stream, unsigned char *halign)
 {
     if (count <= 0) return hipSuccess;
     if (S > 224) return hipErrorInvalidValue;              // kmask holds 7 words of sector bits
@@ -255,7 +280,7 @@ hipError_t launch_ingest(const float *values, int count, int first_slot,
         attr_set.store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(ingest_kernel, dim3(count), dim3(256), lds, stream,
-                       values, first_slot, desc, vkey, norm, rkey, rkey4, hdesc, kmask, hkey, hstride, cap, R, S);
+                       values, first_slot, desc, vkey, norm, rkey, rkey4, hdesc, kmask, hkey, hstride, cap, R, S, halign);
     return hipGetLastError();
 }
 

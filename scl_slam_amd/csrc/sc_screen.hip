@@ -498,6 +498,255 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// K0, second form: one KEYFRAME against the launch's scans per matrix-core tile (as the products' second form does).
+//   c_q[s] = sum_v q_q[v] k[(v - s) mod S]:   A[row][v] = k[(v - s_row) mod S]  (the keyframe),   B[v][q] = q_q[v]  (the scans)
+// so B -- the unit fp16 keys of the launch's scans, zero padded to whole k-steps -- is loaded ONCE per wave into registers and
+// stays there, and the keyframe's side is the only per-keyframe traffic.  A is a Toeplitz image of the key: lane (m, j) needs the
+// eight consecutive entries from (32 kk + 8 j - s_m) mod S.  With the shifts of a tile taken P apart -- row sigma of tile
+// (rho, tau) is shift P (16 tau + sigma) + rho, P | S -- that start is rho past a multiple of P for EVERY lane of the tile: the
+// fragment is one aligned chunk read of copy rho of the keyframe's alignment image (kernels.hpp: halign_*, written at ingest:
+// X_rho[i] = k[(i - rho) mod S]).  P = 8 at S = 120 (15 rows of 16 used, 8 tiles x 4 k-steps = 32 MFMAs per keyframe and launch,
+// ds_read_b128), P = 4 at S = 180 (45 rows = 3 x 16, 12 tiles x 6 k-steps, 8-byte aligned reads).
+// One wave per keyframe: the image goes from memory (16-byte loads, one keyframe ahead) into the wave's own LDS tile, the
+// fragments come out of it.  The filter has the two stages of sc_align_role, both in fp16 products:
+//   stage 1, always: kh . qh, the unit keys rounded to fp16.  |c~ - c| <= 9.9e-4 (see sc_align_role); a lead of kAlign16Margin decides.
+//   stage 2, when a scan of the launch is still open for this keyframe (half of the keyframes of the bench database; 4 % of its
+//     pairs): the keys split in two fp16 parts, k = kh + 2^-11 kl + rk with kl = fp16(2^11 (k - kh)) (scaled: a normal number, no
+//     subnormal is ever needed), |rk_v| <= 2^-22 |k_v|.  c~ = sum kh qh + 2^-11 (sum kh ql + kl qh): products of fp16 values are
+//     exact in fp32; the leading sum is taken as KS single MFMAs (32 products each, on a zero accumulator) joined by KS - 1
+//     additions, the cross sum as one chain whose error is scaled by 2^-11.  Against the correlation of the fp64 unit vectors:
+//       accumulation (32 + KS + 1) 2^-23 (every addition truncating)      <= 4.4e-6
+//       cross chain 2^-11 (64 KS + 2) 2^-23 x 2,  last fma 2^-24           <= 1.0e-7
+//       dropped 2^-22 sum kl ql,  |rq| + |rk|                              <= 7.2e-7
+//     kAlignSplitEps = 6e-6 bounds their sum; a shift that leads every other by more than 2 kAlignSplitEps is the arg-max of the
+//     exact correlation, i.e. the reference's arg-min (same range conditions on the norms as stage 1).  Values are compared
+//     untagged here: the tag's 1.5e-5 would be most of the margin.
+//   what neither stage decides (near ties: 5e-4 of the pairs) goes to the reference's own fp64 evaluation, align_keyframe_exact /
+//   _wide, one pair at a time -- the code of the exact kernel, ties included ("the lowest shift wins").
+// Per 16 scans and keyframe ~110 VALU instructions in stage 1 against 340 per (scan, 16 keyframes) of the first form, no per-scan
+// set-up in LDS, and the keyframe's bytes are fetched once per launch instead of once per scan.
+constexpr int kAlignUndecided = -1;            // first shift of a pair no alignment has decided (never written by this file's kernels now; the consumers honour it)
+constexpr float kAlignSplitEps = 6.0e-6f;      // stage 2: bound of |c~ - c| (see above)
+#ifndef SCL_A2_PROBE
+#define SCL_A2_PROBE 0                         // experiments only (scripts/build_variant.sh): 1 no stage 2 / exact (open pairs marked undecided)
+#endif
+
+template <int S>
+struct Align2Cfg {
+    static constexpr int P = halign_P(S), CP = halign_CP(S);
+    static constexpr int ROWS = P ? S / P : 0;                     // shifts per phase
+    static constexpr int NTAU = (ROWS + 15) / 16;
+    static constexpr int NT = P * NTAU;                            // tiles per keyframe
+    static constexpr int SK = hkey_halfs(S), KS = SK / 32;
+    static constexpr int TSTEP = 16 * P / 32;                      // a tile row block further on = this many k-steps back
+    static constexpr int ND = KS + TSTEP * (NTAU - 1);             // distinct fragment starts of a lane
+    static constexpr int IMG = halign_img_bytes(S);                // bytes of one part (hi or lo) of the image
+    static constexpr int NLD = (IMG + kWave * 16 - 1) / (kWave * 16);   // 16-byte loads per lane and part
+    static constexpr int LDS_WAVE = 2 * IMG > (2 * S + 2) * 8 ? 2 * IMG : ((2 * S + 2) * 8 + 15) / 16 * 16;   // both parts; the exact evaluation's scratch reuses it
+    static constexpr int OCC = KS <= 4 ? 4 : 3;                    // waves per SIMD the kernels are built for
+};
+
+template <int S, int W>
+__device__ __forceinline__ void sc_align2_role(const ScreenBatchArgs &ab, const unsigned char *halign, int u_lo, int u_n,
+                                               const int wave_global, const int waves_total, unsigned char *smem_wave)
+{
+    using C = Align2Cfg<S>;
+    constexpr int P = C::P, CP = C::CP, KS = C::KS, NTAU = C::NTAU, NT = C::NT, ND = C::ND, IMG = C::IMG, SK = C::SK, NLD = C::NLD;
+    static_assert(P == 4 || P == 8, "alignment image");
+    static_assert(S % P == 0 && (16 * P) % 32 == 0 && CP >= S + 8 && IMG % 16 == 0 && S <= 256 && NLD >= 1 && NLD <= 2, "tiling of the shifts");
+    constexpr int SR = (W - 1) / 2;
+    constexpr int HAB = halign_bytes(S);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int c16 = lane & 15, j4 = lane >> 4;                     // A: row sigma = c16; B / output: scan q = c16
+    const int cq = c16 < ab.nq ? c16 : 0;                          // columns past the launch's scans shadow scan 0 (never stored)
+    const ScreenQuery sq = ab.q[cq];
+    const bool q_live = c16 < ab.nq;
+    int *starts_q = ab.starts + (size_t)sq.buf * (size_t)ab.pair_stride;
+    // ---- B: this lane's part of scan q's key for every k-step (halfs 32 kk + 8 j .. + 7), both parts, and the scan's norm ----
+    const _Float16 *qk = reinterpret_cast<const _Float16 *>(ab.hkey) + (size_t)sq.slot * (size_t)ab.hkw;
+    h8 bq[KS], bql[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+        bq[kk] = *reinterpret_cast<const h8 *>(qk + 32 * kk + 8 * j4);
+        bql[kk] = *reinterpret_cast<const h8 *>(qk + SK + 8 + 32 * kk + 8 * j4);
+    }
+    const float qnorm = *reinterpret_cast<const float *>(qk + SK);
+    // ---- A: byte offsets of this lane's fragment starts inside a copy: (8 j - P sigma + 32 d) mod S, d = -TSTEP (NTAU - 1) .. KS - 1
+    unsigned int offs[ND];
+    {
+        int base0 = (8 * j4 - P * c16) % S; base0 = base0 < 0 ? base0 + S : base0;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            int x = (base0 + 32 * (d - C::TSTEP * (NTAU - 1))) % S; x = x < 0 ? x + S : x;
+            offs[d] = (unsigned int)(2 * x);
+        }
+    }
+    const bool use_filter = ab.align_filter != 0;
+    const float kNegInf = __int_as_float(0xff800000);
+    unsigned long long open_pairs = 0;
+    auto frag = [&](const unsigned char *ap) -> h8 {
+        if constexpr (P == 8) return *reinterpret_cast<const h8 *>(ap);
+        else {
+            const uint2 a0 = *reinterpret_cast<const uint2 *>(ap), a1 = *reinterpret_cast<const uint2 *>(ap + 8);
+            const u32x4 aw = {a0.x, a0.y, a1.x, a1.y};
+            return __builtin_bit_cast(h8, aw);
+        }
+    };
+    // the image's first part (kh) of the wave's next keyframe, requested one keyframe ahead (plain named registers: an array
+    // behind a lambda went to scratch memory, and the prefetch with it)
+    const unsigned int loff0 = (unsigned int)lane * 16u, loff1 = (unsigned int)(kWave + lane) * 16u;
+    const bool ld1 = NLD > 1 && loff1 < (unsigned int)IMG;
+    uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = make_uint4(0, 0, 0, 0);
+    float knorm_pre = 0.f;
+    auto image_of = [&](int idx) { idx = idx < u_n ? idx : u_n - 1; return halign + (size_t)(u_lo + idx) * (size_t)HAB; };
+    if (wave_global < u_n) {
+        const unsigned char *g = image_of(wave_global);
+        pre0 = *reinterpret_cast<const uint4 *>(g + 16 + loff0);
+        if (NLD > 1) pre1 = *reinterpret_cast<const uint4 *>(g + 16 + (ld1 ? loff1 : 0u));
+        knorm_pre = *reinterpret_cast<const float *>(g);
+    }
+    for (int idx = wave_global; idx < u_n; idx += waves_total) {
+        wave_fence();                                                            // the previous keyframe's fragment reads are done
+        *reinterpret_cast<uint4 *>(smem_wave + loff0) = pre0;
+        if (ld1) *reinterpret_cast<uint4 *>(smem_wave + loff1) = pre1;
+        const float knorm = knorm_pre;
+        wave_fence();
+        const unsigned char *g_cur = image_of(idx);
+        {
+            const unsigned char *g = image_of(idx + waves_total);
+            pre0 = *reinterpret_cast<const uint4 *>(g + 16 + loff0);
+            if (NLD > 1) pre1 = *reinterpret_cast<const uint4 *>(g + 16 + (ld1 ? loff1 : 0u));
+            knorm_pre = *reinterpret_cast<const float *>(g);
+        }
+        // ---- stage 1: the correlation tile by tile; the two largest values per scan with the largest's shift ----
+        // (the shift rides in the low 8 mantissa bits of its value: a perturbation of < 3.1e-5, which the margin test allows for;
+        //  pairs of values enter a running (hi, lo) through max3 / med3, two independent chains; the next tile's fragments are
+        //  requested before this tile's products)
+        float hi[2] = {kNegInf, kNegInf}, lo[2] = {kNegInf, kNegInf};
+        h8 af[2][KS];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) af[0][kk] = frag(smem_wave + offs[kk + C::TSTEP * (NTAU - 1)]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int rho = t / NTAU, tau = t - rho * NTAU;
+            if (t + 1 < NT) {
+                const int rn = (t + 1) / NTAU, tn = (t + 1) - rn * NTAU;
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) af[(t + 1) & 1][kk] = frag(smem_wave + rn * (CP * 2) + offs[kk + C::TSTEP * (NTAU - 1 - tn)]);
+            }
+            f4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[t & 1][kk], bq[kk], acc, 0, 0, 0);
+            const int ch = t & 1;
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+                // lane (q, j) holds rows 4 j + i of the tile: shift P (16 tau + 4 j + i) + rho
+                const int sg0 = 16 * tau + 4 * j4 + i, sg1 = sg0 + 1;
+                const float x = sg0 < C::ROWS ? __uint_as_float((__float_as_uint(acc[i]) & ~255u) | (unsigned int)(P * sg0 + rho)) : kNegInf;
+                const float y = sg1 < C::ROWS ? __uint_as_float((__float_as_uint(acc[i + 1]) & ~255u) | (unsigned int)(P * sg1 + rho)) : kNegInf;
+                lo[ch] = fmaxf(lo[ch], __builtin_amdgcn_fmed3f(hi[ch], x, y));
+                hi[ch] = fmaxf(fmaxf(hi[ch], x), y);
+            }
+        }
+        auto merge = [](float &h, float &l, float oh, float ol) { l = fmaxf(fmaxf(l, ol), fminf(h, oh)); h = fmaxf(h, oh); };
+        merge(hi[0], lo[0], hi[1], lo[1]);
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) merge(hi[0], lo[0], __shfl_xor(hi[0], off, kWave), __shfl_xor(lo[0], off, kWave));
+        const float v1 = hi[0], v2 = lo[0] + 7.0e-5f;                           // (the tags moved either value by < 3.1e-5)
+        int a1 = (int)(__float_as_uint(hi[0]) & 255u);
+        // the same range conditions as sc_align_role's first stage (see there)
+        const bool in_range = qnorm >= 1e-30f && qnorm <= 4.0e6f && knorm >= 1e-30f && knorm <= 4.0e6f &&
+                              qnorm <= 1.0e4f * knorm && knorm <= 1.0e4f * qnorm;
+        bool uniq = use_filter && in_range && (v1 == v1) && (v2 < v1 - kAlign16Margin);
+        const int ci = u_lo + idx - sq.base;
+        const bool mine = q_live && ci >= 0 && ci < sq.n;                        // (every lane of column q holds the same numbers)
+        unsigned long long amb = __builtin_amdgcn_ballot_w64(mine && !uniq) & 0xffffull;
+        // ---- stage 2 (some scan of the launch is still open for this keyframe): the split keys ----
+        if (SCL_A2_PROBE != 1 && use_filter && amb) {
+            // the image's second part (kl) into the second half of the wave's tile
+            const uint4 l0 = *reinterpret_cast<const uint4 *>(g_cur + 16 + IMG + loff0);
+            uint4 l1 = make_uint4(0, 0, 0, 0);
+            if (NLD > 1) l1 = *reinterpret_cast<const uint4 *>(g_cur + 16 + IMG + (ld1 ? loff1 : 0u));
+            *reinterpret_cast<uint4 *>(smem_wave + IMG + loff0) = l0;
+            if (ld1) *reinterpret_cast<uint4 *>(smem_wave + IMG + loff1) = l1;
+            wave_fence();
+            float h2 = kNegInf, l2 = kNegInf;
+            int g2 = 0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int rho = t / NTAU, tau = t - rho * NTAU;
+                const f4v zero = {0.f, 0.f, 0.f, 0.f};
+                f4v hh = zero, xx = zero;
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) {
+                    const unsigned char *ap = smem_wave + rho * (CP * 2) + offs[kk + C::TSTEP * (NTAU - 1 - tau)];
+                    const h8 ah = frag(ap), al = frag(ap + IMG);
+                    const f4v one = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bq[kk], zero, 0, 0, 0);   // 32 products on a zero accumulator
+                    hh = kk == 0 ? one : hh + one;
+                    xx = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bql[kk], xx, 0, 0, 0);
+                    xx = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bq[kk], xx, 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int sg = 16 * tau + 4 * j4 + i;
+                    const float c = sg < C::ROWS ? __builtin_fmaf(xx[i], 0x1p-11f, hh[i]) : kNegInf;     // (2^-11 xx is exact: fma == mul + add)
+                    l2 = fmaxf(l2, fminf(c, h2));
+                    g2 = c > h2 ? P * sg + rho : g2;
+                    h2 = fmaxf(h2, c);
+                }
+            }
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {
+                const float oh = __shfl_xor(h2, off, kWave), ol = __shfl_xor(l2, off, kWave);
+                const int og = __shfl_xor(g2, off, kWave);
+                l2 = fmaxf(fmaxf(l2, ol), fminf(h2, oh));
+                g2 = oh > h2 ? og : g2;
+                h2 = fmaxf(h2, oh);
+            }
+            if (!uniq && in_range && (h2 == h2) && (l2 < h2 - 2.0f * kAlignSplitEps)) { uniq = true; a1 = g2; }
+            amb = __builtin_amdgcn_ballot_w64(mine && !uniq) & 0xffffull;
+        }
+        if (mine && j4 == 0 && uniq) starts_q[ci] = wrapS(a1 - SR, S);
+        if (SCL_A2_PROBE == 1 && mine && j4 == 0 && !uniq) starts_q[ci] = kAlignUndecided;
+        open_pairs += (unsigned long long)__popcll(amb);
+        // ---- what the filter left open: the reference's own evaluation, one pair at a time ----
+        while (SCL_A2_PROBE != 1 && amb) {
+            const int qn = __ffsll((long long)amb) - 1;
+            amb &= amb - 1;
+            const ScreenQuery oq = ab.q[qn];                                      // (uniform index: scalar loads)
+            const double *vq = ab.vkey + (size_t)oq.slot * S;
+            const double *vkp = ab.vkey + (size_t)(u_lo + idx) * S;
+            double *vk2 = reinterpret_cast<double *>(smem_wave);                  // (the image is not needed any more)
+            int al;
+            if constexpr (S / 2 <= kWave) {
+                constexpr int L = S >> 1;
+                const int ll = lane < L ? lane : L - 1;
+                const double2 vk = *reinterpret_cast<const double2 *>(vkp + 2 * ll);
+                al = align_keyframe_exact<S>(vk, lane, vk2, vq);
+            } else {
+                constexpr int SPL = (S + kWave - 1) / kWave, LA = S / SPL;
+                const int ll = lane < LA ? lane : LA - 1;
+                double vk[SPL];
+#pragma unroll
+                for (int u = 0; u < SPL; ++u) vk[u] = vkp[SPL * ll + u];
+                al = align_keyframe_wide<S>(vk, lane, vk2, vq);
+            }
+            if (lane == 0) (ab.starts + (size_t)oq.buf * (size_t)ab.pair_stride)[u_lo + idx - oq.base] = wrapS(al - SR, S);
+        }
+    }
+    if (lane == 0 && open_pairs && ab.fallbacks) atomicAdd(ab.fallbacks, open_pairs);
+}
+
+template <int RG, int S, int W>
+__global__ __launch_bounds__(kScreenWaves * kWave, Align2Cfg<S>::OCC) void sc_align2_kernel(ScreenBatchArgs ab, const unsigned char *halign, int u_lo, int u_n)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_align2[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    sc_align2_role<S, W>(ab, halign, u_lo, u_n, (int)blockIdx.x * kScreenWaves + wave, (int)gridDim.x * kScreenWaves,
+                         smem_align2 + (size_t)wave * Align2Cfg<S>::LDS_WAVE);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // K1s: the screening products.
 // RGH = 8-byte elements per sector of hdesc (ring groups padded to whole k-steps: 16 at R = 64, 24 at R = 80);
 // D = k-steps of loads in flight per wave (1 KB each).
@@ -699,7 +948,9 @@ __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const 
 
         // ---- epilogue (wave 0): lane (n, q) holds shifts 16m + 4q .. 16m + 4q+3 of keyframe n ----------------------------
         if (wave == 0) {
-            const int b_n = __shfl(b_cur, 4 * n16, kWave);                       // lane 4n holds keyframe n's first shift
+            const int b_raw = __shfl(b_cur, 4 * n16, kWave);                     // lane 4n holds keyframe n's first shift
+            const bool b_open = b_raw < 0;                                       // kAlignUndecided: the exact pass aligns and scores this pair
+            const int b_n = b_open ? 0 : b_raw;
             float dmin = __int_as_float(0x7f800000);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -724,7 +975,7 @@ __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const 
             dmin = fminf(dmin, __shfl_xor(dmin, 16, kWave));
             dmin = fminf(dmin, __shfl_xor(dmin, 32, kWave));
             const bool mine = lane < kGroup && ci_n < a.n;
-            const bool exact_only = q_bad || kflag != 0 || !(dmin == dmin);
+            const bool exact_only = q_bad || kflag != 0 || b_open || !(dmin == dmin);
             if (mine) a.out_approx[ci_n] = exact_only ? __int_as_float(0xff800000) : dmin;
             float contrib = (mine && !exact_only) ? dmin : __int_as_float(0x7f800000);
 #pragma unroll
@@ -769,8 +1020,11 @@ __global__ __launch_bounds__(kScreenWaves * kWave, OCC) void sc_screen_kernel(Sc
     }
 }
 
+#ifndef SCL_ALIGN_OCC
+#define SCL_ALIGN_OCC 2
+#endif
 template <int RG, int S, int W>
-__global__ __launch_bounds__(kScreenWaves * kWave, 2) void sc_align_kernel(ScreenBatchArgs ab)
+__global__ __launch_bounds__(kScreenWaves * kWave, SCL_ALIGN_OCC) void sc_align_kernel(ScreenBatchArgs ab)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_align[];
     sc_align_role<RG, S, W>(ab, (int)blockIdx.x, smem_align);
@@ -1155,7 +1409,9 @@ __device__ __forceinline__ void sc_screen2_finish_body(const Screen2Args &fa, co
         for (int i = 0; i < MW; ++i) km[i] = *reinterpret_cast<const uint4 *>(kp + 4 * i);
         const unsigned int kflag = kp[7];
         if (MW == 2) km[MW - 1].w = 0u;                                          // word 7 is the flag, not sector bits
-        const int b0 = a.starts[ci];
+        const int b_raw = a.starts[ci];
+        const bool b_open = b_raw < 0;                                           // kAlignUndecided (sc_align2_role): scored by the exact pass
+        const int b0 = b_open ? 0 : b_raw;
         const f4v *pp = reinterpret_cast<const f4v *>(fa.part + ((size_t)qi * (size_t)ab.pair_stride + (size_t)ci) * (NP * NPASS * 16));
         float dmin = kInf;
 #pragma unroll
@@ -1182,7 +1438,7 @@ __device__ __forceinline__ void sc_screen2_finish_body(const Screen2Args &fa, co
                 }
             }
         }
-        const bool exact_only = q_bad || kflag != 0 || !(dmin == dmin);
+        const bool exact_only = q_bad || kflag != 0 || b_open || !(dmin == dmin);
         a.out_approx[ci] = exact_only ? __int_as_float(0xff800000) : dmin;
         contrib = exact_only ? kInf : dmin;
         // nanoflann's metric (nanoflann.hpp:383-408) for the ring-key top-k: four dimensions per step, fp32, groups accumulated in
@@ -1228,6 +1484,22 @@ __global__ __launch_bounds__(kScreenWaves * kWave, 2) void sc_screen2_tail_kerne
     sc_screen2_finish_body<RG, S, W>(fa, fb / chunks, fb - (fb / chunks) * chunks);
 }
 
+// ... with the alignment in its second form (one keyframe against the next batch's scans per wave)
+template <int RG, int S, int W>
+__global__ __launch_bounds__(kScreenWaves * kWave, Align2Cfg<S>::OCC) void sc_screen2_tail2_kernel(Screen2Args fa, ScreenBatchArgs nb, const unsigned char *halign, int u_lo, int u_n,
+                                                                                     int align_blocks, int chunks)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_tail2[];
+    const int b = (int)blockIdx.x;
+    if (b < align_blocks) {
+        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        sc_align2_role<S, W>(nb, halign, u_lo, u_n, b * kScreenWaves + wave, align_blocks * kScreenWaves, smem_tail2 + (size_t)wave * Align2Cfg<S>::LDS_WAVE);
+        return;
+    }
+    const int fb = b - align_blocks;
+    sc_screen2_finish_body<RG, S, W>(fa, fb / chunks, fb - (fb / chunks) * chunks);
+}
+
 static bool screen_second_form()
 {   // SCL_SCREEN_FORM=1 keeps the products' first form (keyframe rows per pair through the L2, alignment riding in the launch)
     static const int form = [] { const char *e = getenv("SCL_SCREEN_FORM"); return e ? atoi(e) : 2; }();
@@ -1245,7 +1517,7 @@ size_t sc_screen_scratch_floats(const DbView &db, int SR)
 // argument block of one batch; returns the largest range or -1
 static int fill_screen_args(const DbView &db, const ScreenBatch &sb, int align_filter, ScreenBatchArgs *ab)
 {
-    ab->vkey = db.vkey; ab->rkey = db.rkey; ab->hdesc = db.hdesc; ab->kmask = db.kmask; ab->rkey4 = db.rkey4; ab->hkey = db.hkey; ab->hkw = hkey_store_halfs(db.S);
+    ab->vkey = db.vkey; ab->rkey = db.rkey; ab->hdesc = db.hdesc; ab->kmask = db.kmask; ab->rkey4 = db.rkey4; ab->hkey = db.hkey; ab->hkw = hkey_row_halfs(db.S);
     ab->starts = sb.starts; ab->approx = sb.approx; ab->ring_d2 = sb.ring_d2; ab->t_min = sb.t_min; ab->fallbacks = sb.align_fallbacks;
     ab->pair_stride = (unsigned long long)sb.pair_stride;
     ab->S = db.S; ab->R4 = 4 * db.RG; ab->hstride = db.hstride; ab->rk_cap = db.cap; ab->align_filter = align_filter;
@@ -1326,10 +1598,33 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
     const bool use_v2 = second_form_for(sb);
     const bool next_v2 = next && second_form_for(*next);
     ab.skip_d2 = use_v2 ? 1 : 0;
+    // SCL_ALIGN_FORM=1 keeps the alignment's first form (one scan against 16 keyframes per tile, inline fp32 / fp64 fallbacks)
+    static const int align_form_env = [] { const char *e = getenv("SCL_ALIGN_FORM"); return e ? atoi(e) : 2; }();
+    const bool align2 = align_form_env != 1 && db.halign != nullptr && halign_bytes(S) > 0;
+    constexpr size_t lds_a2 = (size_t)kScreenWaves * Align2Cfg<S>::LDS_WAVE;
+    auto union_of = [](const ScreenBatch &b, int *lo_out, int *n_out) {
+        int lo = b.base[0], hi = b.base[0] + b.n[0];
+        for (int i = 1; i < b.nq; ++i) { lo = b.base[i] < lo ? b.base[i] : lo; hi = b.base[i] + b.n[i] > hi ? b.base[i] + b.n[i] : hi; }
+        *lo_out = lo; *n_out = hi - lo;
+    };
+    // workgroups of the alignment's second form: a wave per keyframe, several keyframes per wave (the next one's image in flight)
+    auto align2_blocks = [&](int u_n) {
+        static const int env = [] { const char *e = getenv("SCL_ALIGN2_WGS"); return e ? atoi(e) : 0; }();
+        int b = (u_n + kScreenWaves * 3 - 1) / (kScreenWaves * 3);
+        const int cap = env > 0 ? env : 2 * num_cu;
+        b = b > cap ? cap : b;
+        return b < 1 ? 1 : b;
+    };
     // the alignment of this batch, on its own (the first launch of a sequence, or a caller that has only one)
     if ((phases & kScreenAlign) && probe != 3) {
-        ab.nb = align_blocks(ngroups, sb.nq, false);
-        hipLaunchKernelGGL((sc_align_kernel<RG, S, W>), dim3(ab.nb * sb.nq), dim3(kScreenWaves * kWave), lds0, stream, ab);
+        if (align2 && use_v2) {                                  // (the products' first form takes the ring-key metric from the alignment's first form)
+            int ulo, un;
+            union_of(sb, &ulo, &un);
+            hipLaunchKernelGGL((sc_align2_kernel<RG, S, W>), dim3(align2_blocks(un)), dim3(kScreenWaves * kWave), lds_a2, stream, ab, db.halign, ulo, un);
+        } else {
+            ab.nb = align_blocks(ngroups, sb.nq, false);
+            hipLaunchKernelGGL((sc_align_kernel<RG, S, W>), dim3(ab.nb * sb.nq), dim3(kScreenWaves * kWave), lds0, stream, ab);
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -1365,6 +1660,12 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
                 const int nmax2 = fill_screen_args(db, *next, align_filter, &nb);
                 if (nmax2 < 0) return hipErrorInvalidValue;
                 nb.skip_d2 = next_v2 ? 1 : 0;
+                if (align2 && next_v2) {
+                    int ulo, un;
+                    union_of(*next, &ulo, &un);
+                    hipLaunchKernelGGL((sc_align2_kernel<RG, S, W>), dim3(align2_blocks(un)), dim3(kScreenWaves * kWave), lds_a2, as, nb, db.halign, ulo, un);
+                    return hipGetLastError();
+                }
                 const int ng2 = (nmax2 + kGroup - 1) / kGroup;
                 // persistent workgroups: three per CU (167 registers: three waves per SIMD; 128 spill and double the time) over the
                 // whole batch, every wave walks several groups with the next group's keys in flight
@@ -1394,13 +1695,24 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
                 const int nmax2 = fill_screen_args(db, *next, align_filter, &nb);
                 if (nmax2 < 0) return hipErrorInvalidValue;
                 nb.skip_d2 = next_v2 ? 1 : 0;
-                const int ng2 = (nmax2 + kGroup - 1) / kGroup;
-                int per_q = 3 * num_cu / next->nq;
-                per_q = per_q < 1 ? 1 : per_q;
-                nb.nb = (ng2 + kScreenWaves - 1) / kScreenWaves;
-                nb.nb = nb.nb > per_q ? per_q : nb.nb;
-                const int ablocks = nb.nb * next->nq, chunks = (nmax + 255) / 256;
-                hipLaunchKernelGGL((sc_screen2_tail_kernel<RG, S, W>), dim3(ablocks + chunks * sb.nq), dim3(kScreenWaves * kWave), lds0, stream, f2, nb, ablocks, chunks);
+                const int chunks = (nmax + 255) / 256;
+                if (align2 && next_v2) {
+                    // (the first form of the products forms the ring-key metric in its own alignment role: only batches that the
+                    //  second form will score take the alignment's second form here)
+                    int ulo, un;
+                    union_of(*next, &ulo, &un);
+                    const int ablocks = align2_blocks(un);
+                    hipLaunchKernelGGL((sc_screen2_tail2_kernel<RG, S, W>), dim3(ablocks + chunks * sb.nq), dim3(kScreenWaves * kWave), lds_a2, stream, f2, nb, db.halign, ulo, un,
+                                       ablocks, chunks);
+                } else {
+                    const int ng2 = (nmax2 + kGroup - 1) / kGroup;
+                    int per_q = 3 * num_cu / next->nq;
+                    per_q = per_q < 1 ? 1 : per_q;
+                    nb.nb = (ng2 + kScreenWaves - 1) / kScreenWaves;
+                    nb.nb = nb.nb > per_q ? per_q : nb.nb;
+                    const int ablocks = nb.nb * next->nq;
+                    hipLaunchKernelGGL((sc_screen2_tail_kernel<RG, S, W>), dim3(ablocks + chunks * sb.nq), dim3(kScreenWaves * kWave), lds0, stream, f2, nb, ablocks, chunks);
+                }
                 if ((e = hipGetLastError()) != hipSuccess) return e;
             } else {
                 hipLaunchKernelGGL((sc_screen2_finish_kernel<RG, S, W>), dim3((nmax + 255) / 256, sb.nq), dim3(256), 0, stream, f2);
