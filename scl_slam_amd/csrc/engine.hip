@@ -233,7 +233,7 @@ int ensure_sets(scl_engine *e, size_t n)
     int rc = ensure_pairs(e, stride * scl_engine::kScreenSets);
     if (rc) { e->set_stride = 0; return rc; }
     e->set_stride = stride;
-    const size_t need = stride * sc_screen_scratch_floats(db_view(e), e->SR);   // floats: ring parts x passes x 16 shifts per pair of a launch
+    const size_t need = 2 * stride * sc_screen_scratch_floats(db_view(e), e->SR);   // floats: ring parts x passes x 16 shifts per pair of a launch; two launches' worth (a launch's finishing rides in the next launch)
     if (need > e->part_cap) {
         dev_free(e->d_part); e->part_cap = 0;
         if ((rc = dev_alloc(e, &e->d_part, need))) { e->set_stride = 0; return rc; }
@@ -960,11 +960,11 @@ int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, c
 // One screening launch for up to four queries: slots qslot[i] against [lo[i], lo[i] + n[i]), results in buffer sets
 // set0 + i.  The event pair of the profile brackets this launch: it is the dominant kernel of a pass.
 // One screening launch group: queries qslot[0..nq) against [lo[i], lo[i] + n[i]), buffer sets set0 + i.
-struct ScreenGroup { const int *qslot, *lo, *n; int nq, set0; };
+struct ScreenGroup { const int *qslot, *lo, *n; int nq, set0; int part_half = 0; };   // part_half: which half of d_part holds the batch's partial sums
 // next (optional, nq > 0): the launch that will follow; its alignment rides in this one (the next call then passes
 // kScreenProducts only).
 int launch_screen_group(scl_engine *e, const ScreenGroup &cur, int phases = kScreenAlign | kScreenProducts,
-                        const ScreenGroup *next = nullptr, hipStream_t stream = nullptr)
+                        const ScreenGroup *next = nullptr, hipStream_t stream = nullptr, const ScreenGroup *prev = nullptr)
 {
     if (!stream) stream = e->stream;
     auto fill = [&](ScreenBatch &sb, const ScreenGroup &g) {
@@ -972,14 +972,21 @@ int launch_screen_group(scl_engine *e, const ScreenGroup &cur, int phases = kScr
         for (int j = 0; j < g.nq; ++j) { sb.slot[j] = g.qslot[j]; sb.base[j] = g.lo[j]; sb.n[j] = g.n[j]; sb.buf[j] = g.set0 + j; }
         sb.pair_stride = e->set_stride;
         sb.approx = e->d_approx; sb.starts = e->d_starts; sb.align_fallbacks = e->d_align_fallbacks; sb.ring_d2 = e->d_ring_d2;
-        sb.survivors = nullptr; sb.n_surv = nullptr; sb.t_min = e->d_tmin; sb.part = e->d_part;
+        sb.survivors = nullptr; sb.n_surv = nullptr; sb.t_min = e->d_tmin;
+        sb.part = e->d_part + (g.part_half ? e->part_cap / 2 : 0);
         sb.side = stream == e->stream ? e->stream_align : nullptr; sb.ev_fork = e->ev_afork; sb.ev_join = e->ev_ajoin;
         sb.k = e->cfg.num_candidates; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
     };
-    ScreenBatch sb{}, nx{};
+    ScreenBatch sb{}, nx{}, pv{};
     fill(sb, cur);
     const bool has_next = next && next->nq > 0;
     if (has_next) fill(nx, *next);
+    const bool has_prev = prev && prev->nq > 0;
+    if (has_prev) fill(pv, *prev);
+    if (phases == kScreenFinish) {                          // a deferred finishing on its own (the end of a stream)
+        SCL_HIP(e, launch_sc_screen_batch(db_view(e), sb, e->SR, sc_align_filter_enabled(), e->num_cu, stream, kScreenFinish, nullptr, nullptr));
+        return SCL_OK;
+    }
     if (phases & kScreenAlign) for (int j = 0; j < cur.nq; ++j) e->align_pairs += (uint64_t)cur.n[j];
     if (has_next) for (int j = 0; j < next->nq; ++j) e->align_pairs += (uint64_t)next->n[j];
     if ((phases & kScreenAlign) && (phases & kScreenProducts) && has_next) {   // a sequence's first launch: its own alignment outside the
@@ -987,7 +994,7 @@ int launch_screen_group(scl_engine *e, const ScreenGroup &cur, int phases = kScr
         phases = kScreenProducts;
     }
     ProfScope ps(e, P_SC, stream);
-    SCL_HIP(e, launch_sc_screen_batch(db_view(e), sb, e->SR, sc_align_filter_enabled(), e->num_cu, stream, phases, has_next ? &nx : nullptr));
+    SCL_HIP(e, launch_sc_screen_batch(db_view(e), sb, e->SR, sc_align_filter_enabled(), e->num_cu, stream, phases, has_next ? &nx : nullptr, has_prev ? &pv : nullptr));
     if (ps.active()) { for (int j = 0; j < cur.nq; ++j) e->prof.sc_distance_pairs += (uint64_t)cur.n[j]; }
     return SCL_OK;
 }
@@ -1260,6 +1267,35 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
     struct List { int qslot[CH], qlo[CH], qn[CH], pos[CH], m = 0; };     // the scans of a chunk that have something to score
     struct Chunk { int first = 0, count = 0; bool busy = false, aligned = false; std::vector<int> lo, empty; };
     Chunk ch[2];
+    // A launch's finishing (bound, flags, ring-key metric: what the exact pass reads) rides in the NEXT launch's extra waves
+    // (sc_screen.hip): `pend` is the launch whose finishing is still owed, `owed` the chunk whose exact pass waits for it.
+    struct Pending { int qslot[kMaxScreenBatch], lo[kMaxScreenBatch], n[kMaxScreenBatch], nq = 0, set0 = 0, half = 0; bool valid = false; } pend;
+    struct Owed { List L; int c = 0, region = 0; bool valid = false; } owed;
+    int part_half = 0;
+    auto pend_group = [&]() { ScreenGroup g{pend.qslot, pend.lo, pend.n, pend.nq, pend.set0}; g.part_half = pend.half; return g; };
+    // the exact pass of chunk `o.c` on the side stream, behind everything the main stream holds now
+    auto run_owed = [&]() -> int {
+        if (!owed.valid) return SCL_OK;
+        const int oc = owed.c;
+        double *out3[CH];
+        for (int j = 0; j < owed.L.m; ++j) out3[j] = e->h_stream_out + ((size_t)oc * NS + (size_t)owed.L.pos[j]) * 8;
+        SCL_HIP(e, hipEventRecord(e->ev_k1[oc], e->stream));
+        SCL_HIP(e, hipStreamWaitEvent(e->stream_surv, e->ev_k1[oc], 0));
+        int r2 = SCL_OK;
+        if (owed.L.m > 0) r2 = wide ? launch_survivor_pass_wide(e, owed.L.qslot, owed.L.qlo, owed.L.qn, owed.L.m, oc * CH, out3, e->stream_surv)
+                                    : launch_survivor_pass(e, owed.L.qslot, owed.L.qlo, owed.L.qn, owed.L.m, oc * CH, out3, e->stream_surv, kSurvivorKernel, owed.region);
+        if (r2) return r2;
+        SCL_HIP(e, hipEventRecord(e->ev_chunk[oc], e->stream_surv));
+        owed.valid = false;
+        return SCL_OK;
+    };
+    // the owed finishing as a launch of its own (nothing follows that could carry it)
+    auto flush_pending = [&]() -> int {
+        if (!pend.valid) return SCL_OK;
+        const ScreenGroup g = pend_group();
+        pend.valid = false;
+        return launch_screen_group(e, g, kScreenFinish);
+    };
     int nmax = 1;
     for (int i = 0; i < n_queries; ++i) {
         const int l = lo[i] < 0 ? 0 : lo[i], h = hi[i] > e->n ? e->n : hi[i];
@@ -1305,9 +1341,16 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
         const int region = (cur.m > 0 && !wide) ? (int)survivor_arg_region(e) : 0;
         if (cur.m > 0 && !wide && (rc = launch_survivor_pass(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, e->stream_surv, kSurvivorArgs, region))) return rc;
         bool next_aligned = false;
+        if (cur.m == 0) {                                    // nothing to launch: what earlier chunks are owed cannot ride along
+            if ((rc = flush_pending())) return rc;
+            if ((rc = run_owed())) return rc;
+        }
         for (int g = 0; g < cur.m; g += spl) {
             const int w = cur.m - g < spl ? cur.m - g : spl;
-            const ScreenGroup grp{cur.qslot + g, cur.qlo + g, cur.qn + g, w, set0 + g};
+            ScreenGroup grp{cur.qslot + g, cur.qlo + g, cur.qn + g, w, set0 + g};
+            grp.part_half = part_half;
+            const bool defer = sc_screen_can_defer(db_view(e), e->SR, w);
+            if (!defer && (rc = flush_pending())) return rc;   // (a batch the first form scores has no extra waves to carry it)
             ScreenGroup nx{nullptr, nullptr, nullptr, 0, 0};
             if (g + w < cur.m) {
                 const int wn = cur.m - g - w < spl ? cur.m - g - w : spl;
@@ -1318,12 +1361,31 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
                 if (ch[c ^ 1].busy) SCL_HIP(e, hipStreamWaitEvent(e->stream, e->ev_chunk[c ^ 1], 0));
                 next_aligned = true;
             }
-            const int phases = (g == 0 && !k.aligned) ? (kScreenAlign | kScreenProducts) : kScreenProducts;
-            if ((rc = launch_screen_group(e, grp, phases, nx.nq > 0 ? &nx : nullptr))) return rc;
+            const int phases = ((g == 0 && !k.aligned) ? (kScreenAlign | kScreenProducts) : kScreenProducts) | (defer ? kScreenDeferFinish : 0);
+            const ScreenGroup pv = pend_group();
+            if ((rc = launch_screen_group(e, grp, phases, nx.nq > 0 ? &nx : nullptr, nullptr, pend.valid ? &pv : nullptr))) return rc;
+            pend.valid = false;
+            if (defer) {
+                for (int j = 0; j < w; ++j) { pend.qslot[j] = grp.qslot[j]; pend.lo[j] = grp.lo[j]; pend.n[j] = grp.n[j]; }
+                pend.nq = w; pend.set0 = grp.set0; pend.half = part_half; pend.valid = true;
+                part_half ^= 1;
+            }
+            if (g == 0 && (rc = run_owed())) return rc;      // the chunk before this one is finished now: its exact pass may start
         }
         // The exact pass of a chunk runs beside the next chunk's products, on the side stream -- except the call's last one,
         // which nothing follows: it stays on the main stream (no hop between streams in front of it; its argument sets are
         // already on the device: wait for their copy only).
+        if (ncount > 0 && pend.valid) {
+            // this chunk's last finishing rides in the next chunk's first launch: the exact pass is owed until then
+            owed.L = cur; owed.c = c; owed.region = region; owed.valid = true;
+            k.busy = true;
+            k.aligned = false;
+            ch[c ^ 1].aligned = next_aligned;
+            e->last_pass_empty = cur.m == 0;
+            e->last_pass_alt = false;
+            return SCL_OK;
+        }
+        if ((rc = flush_pending())) return rc;
         hipStream_t xs = ncount > 0 ? e->stream_surv : e->stream;
         if (ncount > 0) {
             SCL_HIP(e, hipEventRecord(e->ev_k1[c], e->stream));

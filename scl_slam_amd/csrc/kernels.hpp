@@ -136,9 +136,14 @@ size_t sc_screen_scratch_floats(const struct DbView &db, int SR);   // partial-s
 // (which read sb.starts), 3 = both, one after the other on `stream`.  next (optional): the batch that follows; its
 // alignment rides in the launch of this batch's products (further workgroups of the same grid: one is matrix-core bound,
 // the other HBM bound), so the next call needs phase 2 only.
-constexpr int kScreenAlign = 1, kScreenProducts = 2;
+// kScreenDeferFinish (with kScreenProducts, second form only: sc_screen_can_defer): the batch's finishing -- bound d~, flags, ring-key
+// metric: what the exact pass reads -- is left to the extra waves of the NEXT launch, which gets this batch as `prev` (same buffer
+// sets, same sb.part, which therefore must not be the next launch's own), or to a last call with phases = kScreenFinish.
+// prev: the batch whose finishing rides in this launch.
+constexpr int kScreenAlign = 1, kScreenProducts = 2, kScreenDeferFinish = 4, kScreenFinish = 8;
 hipError_t launch_sc_screen_batch(const struct DbView &db, const ScreenBatch &sb, int SR, int align_filter, int num_cu, hipStream_t stream,
-                                  int phases = kScreenAlign | kScreenProducts, const ScreenBatch *next = nullptr);
+                                  int phases = kScreenAlign | kScreenProducts, const ScreenBatch *next = nullptr, const ScreenBatch *prev = nullptr);
+bool sc_screen_can_defer(const struct DbView &db, int SR, int nq);
 hipError_t launch_sc_select_batch(const ScreenBatch &sb, hipStream_t stream);
 // Exact pass over the survivors of nq screened queries (any number: the argument sets travel through device memory).
 // Query i: keyframe slot[i] against the range [base[i], base[i] + n[i]); its screening results live in buffer set

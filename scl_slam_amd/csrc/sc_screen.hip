@@ -527,6 +527,9 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
 // set-up in LDS, and the keyframe's bytes are fetched once per launch instead of once per scan.
 constexpr int kAlignUndecided = -1;            // first shift of a pair no alignment has decided (never written by this file's kernels now; the consumers honour it)
 constexpr float kAlignSplitEps = 6.0e-6f;      // stage 2: bound of |c~ - c| (see above)
+#ifndef SCL_A2_OCC
+#define SCL_A2_OCC 4
+#endif
 #ifndef SCL_A2_PROBE
 #define SCL_A2_PROBE 0                         // experiments only (scripts/build_variant.sh): 1 no stage 2 / exact (open pairs marked undecided)
 #endif
@@ -543,7 +546,7 @@ struct Align2Cfg {
     static constexpr int IMG = halign_img_bytes(S);                // bytes of one part (hi or lo) of the image
     static constexpr int NLD = (IMG + kWave * 16 - 1) / (kWave * 16);   // 16-byte loads per lane and part
     static constexpr int LDS_WAVE = 2 * IMG > (2 * S + 2) * 8 ? 2 * IMG : ((2 * S + 2) * 8 + 15) / 16 * 16;   // both parts; the exact evaluation's scratch reuses it
-    static constexpr int OCC = KS <= 4 ? 4 : 3;                    // waves per SIMD the kernels are built for
+    static constexpr int OCC = KS <= 4 ? SCL_A2_OCC : 3;           // waves per SIMD the kernels are built for
 };
 
 template <int S, int W>
@@ -564,12 +567,9 @@ __device__ __forceinline__ void sc_align2_role(const ScreenBatchArgs &ab, const 
     int *starts_q = ab.starts + (size_t)sq.buf * (size_t)ab.pair_stride;
     // ---- B: this lane's part of scan q's key for every k-step (halfs 32 kk + 8 j .. + 7), both parts, and the scan's norm ----
     const _Float16 *qk = reinterpret_cast<const _Float16 *>(ab.hkey) + (size_t)sq.slot * (size_t)ab.hkw;
-    h8 bq[KS], bql[KS];
+    h8 bq[KS];
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-        bq[kk] = *reinterpret_cast<const h8 *>(qk + 32 * kk + 8 * j4);
-        bql[kk] = *reinterpret_cast<const h8 *>(qk + SK + 8 + 32 * kk + 8 * j4);
-    }
+    for (int kk = 0; kk < KS; ++kk) bq[kk] = *reinterpret_cast<const h8 *>(qk + 32 * kk + 8 * j4);
     const float qnorm = *reinterpret_cast<const float *>(qk + SK);
     // ---- A: byte offsets of this lane's fragment starts inside a copy: (8 j - P sigma + 32 d) mod S, d = -TSTEP (NTAU - 1) .. KS - 1
     unsigned int offs[ND];
@@ -669,6 +669,9 @@ __device__ __forceinline__ void sc_align2_role(const ScreenBatchArgs &ab, const 
             if (NLD > 1) l1 = *reinterpret_cast<const uint4 *>(g_cur + 16 + IMG + (ld1 ? loff1 : 0u));
             *reinterpret_cast<uint4 *>(smem_wave + IMG + loff0) = l0;
             if (ld1) *reinterpret_cast<uint4 *>(smem_wave + IMG + loff1) = l1;
+            h8 bql[KS];                                                          // the scans' second parts: needed here only (4 % of the keyframes)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) bql[kk] = *reinterpret_cast<const h8 *>(qk + SK + 8 + 32 * kk + 8 * j4);
             wave_fence();
             float h2 = kNegInf, l2 = kNegInf;
             int g2 = 0;
@@ -1206,15 +1209,33 @@ hipError_t launch_sc_select_batch(const ScreenBatch &sb, hipStream_t stream)
 #ifndef S2WV_A
 #define S2WV_A 16
 #endif
+#ifndef S2WVF_A
+#define S2WVF_A 12
+#endif
+#ifndef S2XW_A
+#define S2XW_A 4
+#endif
+#ifndef S2XPRIO
+#define S2XPRIO 0
+#endif
+#ifndef S2XW_B
+#define S2XW_B 2
+#endif
 template <int RG, int S, int W> struct S2Cfg;
-template <> struct S2Cfg<16, 120, 13> { static constexpr int NP = 2, NPASS = 1, STEPS = 4, NQ = 16, RS = S2RS_A, WV = S2WV_A; };   // RS: ring slots of fragment loads (RS - 1 in flight);
-template <> struct S2Cfg<20, 180, 19> { static constexpr int NP = 3, NPASS = 2, STEPS = 4, NQ = 12, RS = 9, WV = 8; };    // S / STEPS iterations per keyframe = a multiple of RS
+// WV: waves of the products per workgroup; XW: EXTRA waves of the same workgroup that align the NEXT batch and finish the PREVIOUS
+// one beside the products (sc_screen2_kernel): the products leave two thirds of the vector and matrix-core issue slots idle
+template <> struct S2Cfg<16, 120, 13> { static constexpr int NP = 2, NPASS = 1, STEPS = 4, NQ = 16, RS = S2RS_A, WV = S2WV_A, WVF = S2WVF_A, XW = S2XW_A; };   // RS: ring slots of fragment loads (RS - 1 in flight);
+template <> struct S2Cfg<20, 180, 19> { static constexpr int NP = 3, NPASS = 2, STEPS = 4, NQ = 12, RS = 9, WV = 8, WVF = 8, XW = S2XW_B; };    // S / STEPS iterations per keyframe = a multiple of RS
 constexpr int kS2PassRows = 13;                    // shift rows per pass: row m of pass p = shift W - 1 - 13 p - m
 
 // LDS image of the scans (see above): quad stride in bytes, 2 mod 4 sixteen-byte slots
 constexpr int s2_quad(int S, int STEPS) { return (((S + STEPS - 1) * 256 / 16) % 4 == 2) ? (S + STEPS - 1) * 256 : (S + STEPS - 1) * 256 + 32; }
 template <int RG, int S, int W> constexpr size_t s2_lds() { return (size_t)(S2Cfg<RG, S, W>::NQ / 4) * s2_quad(S, S2Cfg<RG, S, W>::STEPS); }
 template <int RG, int S, int W> constexpr int s2_part_floats() { return S2Cfg<RG, S, W>::NP * S2Cfg<RG, S, W>::NPASS * 16; }   // partial sums per pair
+// LDS tile of one extra wave: the alignment image (both parts) / the exact evaluation's scratch, or the finishing's rotated masks
+template <int S> constexpr int s2_xlds() { return Align2Cfg<S>::LDS_WAVE > S * ((((S + 63) / 64) + 1) / 2) * 16 ? Align2Cfg<S>::LDS_WAVE : S * ((((S + 63) / 64) + 1) / 2) * 16; }
+template <int RG, int S, int W, bool FUSED> constexpr size_t s2_lds_total() { return s2_lds<RG, S, W>() + (FUSED ? (size_t)S2Cfg<RG, S, W>::XW * s2_xlds<S>() : 0); }
+template <int RG, int S, int W, bool FUSED> constexpr int s2_waves() { return FUSED ? S2Cfg<RG, S, W>::WVF + S2Cfg<RG, S, W>::XW : S2Cfg<RG, S, W>::WV; }
 
 struct Screen2Args {
     ScreenBatchArgs prod;
@@ -1224,8 +1245,20 @@ struct Screen2Args {
 };
 
 template <int RG, int S, int W>
-__global__ __launch_bounds__((S2Cfg<RG, S, W>::WV * kWave), 1) void sc_screen2_kernel(Screen2Args fa)
+__device__ __forceinline__ void sc_screen2_finish_waves(const Screen2Args &fa, const int nb64, const int unit0, const int unit_stride, unsigned char *lds_wave);
+
+// What the extra waves of a launch do: the alignment of the batch BEHIND this one (a_n > 0) and the finishing of the batch in
+// FRONT of it (f_nb64 > 0), whose products the launch before wrote.
+struct Screen2Extra {
+    ScreenBatchArgs next; const unsigned char *halign; int a_lo, a_n;
+    Screen2Args prev; int f_nb64;
+};
+
+// FUSED: the workgroup has XW extra waves behind its WVF product waves; otherwise WV product waves and nothing else
+template <int RG, int S, int W, bool FUSED>
+__global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_screen2_kernel(Screen2Args fa, Screen2Extra xa)
 {
+    constexpr int WVP = FUSED ? S2Cfg<RG, S, W>::WVF : S2Cfg<RG, S, W>::WV;
     using C = S2Cfg<RG, S, W>;
     constexpr int NP = C::NP, NPASS = C::NPASS, STEPS = C::STEPS, NQ = C::NQ;
     constexpr int RGH = hdesc_rgh(RG);
@@ -1244,8 +1277,8 @@ __global__ __launch_bounds__((S2Cfg<RG, S, W>::WV * kWave), 1) void sc_screen2_k
     const int b = (int)blockIdx.x, xcd = b & 7, jx = b >> 3;
     const int part = jx % NP;
     const int gi = (jx / NP) * 8 + xcd;                // 0 .. nwg / NP - 1
-    const int waves_part = (fa.nwg / NP) * C::WV;
-    const int gw = gi * C::WV + wave;
+    const int waves_part = (fa.nwg / NP) * WVP;
+    const int gw = gi * WVP + wave;
 
     // ---- stage the scans' ring part (the last STEPS - 1 sectors repeat the first) ----
     for (int idx = threadIdx.x; idx < NQ * ROWS * 4; idx += blockDim.x) {
@@ -1256,7 +1289,21 @@ __global__ __launch_bounds__((S2Cfg<RG, S, W>::WV * kWave), 1) void sc_screen2_k
         *reinterpret_cast<uint4 *>(smem2 + (size_t)(q >> 2) * QUAD + sx * 256 + (q & 3) * 64 + ch * 16) = *reinterpret_cast<const uint4 *>(src);
     }
     __syncthreads();
+    if (FUSED && wave >= WVP) {                        // ---- the extra waves: next batch's alignment, previous batch's finishing ----
+        const int xw = wave - WVP;
+        const int xg = b * C::XW + xw, xtotal = (int)gridDim.x * C::XW;
+#if S2XPRIO > 0
+        __builtin_amdgcn_s_setprio(S2XPRIO);           // few instructions, long dependent chains: issue them ahead of the products' waves
+#endif
+        unsigned char *xs = smem2 + s2_lds<RG, S, W>() + (size_t)xw * s2_xlds<S>();
+        if (xa.a_n > 0) sc_align2_role<S, W>(xa.next, xa.halign, xa.a_lo, xa.a_n, xg, xtotal, xs);
+        if (xa.f_nb64 > 0) sc_screen2_finish_waves<RG, S, W>(xa.prev, xa.f_nb64, xg, xtotal, xs);
+        return;
+    }
     if (gw >= fa.u_n) return;
+#ifdef S2_NO_PRODUCTS
+    return;                                            // experiment: what the extra waves take on their own
+#endif
 
     const int c16 = lane & 15, j4 = lane >> 4;         // A: row m = c16; B / output: scan q = c16
     // columns past the launch's scans shadow the column 12 below: the SAME address as a lane of the same ds_read_b128 group
@@ -1373,88 +1420,102 @@ __global__ __launch_bounds__((S2Cfg<RG, S, W>::WV * kWave), 1) void sc_screen2_k
 }
 
 // the ring parts of every pair meet: d~ = min_t (1 - sim[t] / n_eff[t]), flags, the launch's smallest d~ per scan
+// rotq[s] (LDS, built by the caller's threads): the scan's sector mask rotated right by s
+template <int S>
+__device__ __forceinline__ void build_rotq(const unsigned int *q_kmask, uint4 *rotq, int tid, int nthreads)
+{
+    constexpr int NW64 = (S + 63) / 64, MW = (NW64 + 1) / 2;
+    unsigned long long qm[NW64];
+#pragma unroll
+    for (int i = 0; i < NW64; ++i) qm[i] = (unsigned long long)q_kmask[2 * i] | ((unsigned long long)(2 * i + 1 < 7 ? q_kmask[2 * i + 1] : 0u) << 32);
+    for (int sft = tid; sft < S; sft += nthreads) {
+        unsigned long long rr[NW64];
+        rotate_mask<S>(qm, sft, rr);
+#pragma unroll
+        for (int i = 0; i < MW; ++i) {
+            const unsigned long long lo = rr[2 * i], hi = 2 * i + 1 < NW64 ? rr[2 * i + 1] : 0ull;
+            rotq[sft * MW + i] = make_uint4((unsigned int)lo, (unsigned int)(lo >> 32), (unsigned int)hi, (unsigned int)(hi >> 32));
+        }
+    }
+}
+
+// one pair (scan qi of the batch, position ci of its range): returns its contribution to the launch's smallest d~
 template <int RG, int S, int W>
-__device__ __forceinline__ void sc_screen2_finish_body(const Screen2Args &fa, const int qi, const int chunk)
+__device__ __forceinline__ float sc_screen2_finish_pair(const Screen2Args &fa, const ScreenArgs &a, const int qi, const int ci, const uint4 *rotq, const bool q_bad)
 {
     using C = S2Cfg<RG, S, W>;
     constexpr int NP = C::NP, NPASS = C::NPASS;
     constexpr int NW64 = (S + 63) / 64, MW = (NW64 + 1) / 2;
     const ScreenBatchArgs &ab = fa.prod;
-    const ScreenArgs a = screen_args_of(ab, qi);
-    __shared__ uint4 rotq[S * MW];
-    __shared__ float wmin[4];
-    {
-        unsigned long long qm[NW64];
+    const float kInf = __int_as_float(0x7f800000);
+    const unsigned int *kp = a.kmask + (size_t)(a.slot_base + ci) * 8;
+    uint4 km[MW];
 #pragma unroll
-        for (int i = 0; i < NW64; ++i) qm[i] = (unsigned long long)a.q_kmask[2 * i] | ((unsigned long long)(2 * i + 1 < 7 ? a.q_kmask[2 * i + 1] : 0u) << 32);
-        for (int sft = threadIdx.x; sft < S; sft += blockDim.x) {
-            unsigned long long rr[NW64];
-            rotate_mask<S>(qm, sft, rr);
+    for (int i = 0; i < MW; ++i) km[i] = *reinterpret_cast<const uint4 *>(kp + 4 * i);
+    const unsigned int kflag = kp[7];
+    if (MW == 2) km[MW - 1].w = 0u;                                          // word 7 is the flag, not sector bits
+    const int b_raw = a.starts[ci];
+    const bool b_open = b_raw < 0;                                           // kAlignUndecided: scored by the exact pass
+    const int b0 = b_open ? 0 : b_raw;
+    const f4v *pp = reinterpret_cast<const f4v *>(fa.part + ((size_t)qi * (size_t)ab.pair_stride + (size_t)ci) * (NP * NPASS * 16));
+    float dmin = kInf;
 #pragma unroll
-            for (int i = 0; i < MW; ++i) {
-                const unsigned long long lo = rr[2 * i], hi = 2 * i + 1 < NW64 ? rr[2 * i + 1] : 0ull;
-                rotq[sft * MW + i] = make_uint4((unsigned int)lo, (unsigned int)(lo >> 32), (unsigned int)hi, (unsigned int)(hi >> 32));
+    for (int p = 0; p < NPASS; ++p) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            f4v sm = pp[p * 4 + g4];                                         // part 0
+#pragma unroll
+            for (int h = 1; h < NP; ++h) sm += pp[(h * NPASS + p) * 4 + g4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 4 * g4 + r;                                    // row m of pass p = shift W - 1 - 13 p - m
+                const int t = W - 1 - kS2PassRows * p - m;
+                if (m >= kS2PassRows || t < 0) continue;
+                int ri = b0 + t; ri = ri >= S ? ri - S : ri;
+                int ne = 0;
+#pragma unroll
+                for (int i = 0; i < MW; ++i) {
+                    const uint4 rq = rotq[ri * MW + i];
+                    ne += __popc(rq.x & km[i].x) + __popc(rq.y & km[i].y) + __popc(rq.z & km[i].z) + __popc(rq.w & km[i].w);
+                }
+                const float d = 1.0f - sm[r] / (float)ne;
+                if (ne > 0 && d < dmin) dmin = d;
             }
         }
     }
+    const bool exact_only = q_bad || kflag != 0 || b_open || !(dmin == dmin);
+    a.out_approx[ci] = exact_only ? __int_as_float(0xff800000) : dmin;
+    // nanoflann's metric (nanoflann.hpp:383-408) for the ring-key top-k: four dimensions per step, fp32, groups accumulated in
+    // order -- the arithmetic of sc_align_role, here with consecutive threads on consecutive slots of the tiled key table
+    const int slot = a.slot_base + ci;
+    float result = 0.0f;
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+        const float4 bk = a.rkey4[(size_t)r * a.rk_cap + slot];
+        const float4 qk = *reinterpret_cast<const float4 *>(a.q_rkey + 4 * r);
+        const float d0 = qk.x - bk.x, d1 = qk.y - bk.y, d2 = qk.z - bk.z, d3 = qk.w - bk.w;
+        const float grp = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        result += grp;
+    }
+    a.out_d2[ci] = result;
+    return exact_only ? kInf : dmin;
+}
+
+template <int RG, int S, int W>
+__device__ __forceinline__ void sc_screen2_finish_body(const Screen2Args &fa, const int qi, const int chunk)
+{
+    constexpr int NW64 = (S + 63) / 64, MW = (NW64 + 1) / 2;
+    const ScreenBatchArgs &ab = fa.prod;
+    const ScreenArgs a = screen_args_of(ab, qi);
+    __shared__ uint4 rotq[S * MW];
+    __shared__ float wmin[4];
+    build_rotq<S>(a.q_kmask, rotq, (int)threadIdx.x, (int)blockDim.x);
     const bool q_bad = a.q_kmask[7] != 0;
     __syncthreads();
     const int ci = (int)(chunk * blockDim.x + threadIdx.x);
     const float kInf = __int_as_float(0x7f800000);
     float contrib = kInf;
-    if (ci < a.n) {
-        const unsigned int *kp = a.kmask + (size_t)(a.slot_base + ci) * 8;
-        uint4 km[MW];
-#pragma unroll
-        for (int i = 0; i < MW; ++i) km[i] = *reinterpret_cast<const uint4 *>(kp + 4 * i);
-        const unsigned int kflag = kp[7];
-        if (MW == 2) km[MW - 1].w = 0u;                                          // word 7 is the flag, not sector bits
-        const int b_raw = a.starts[ci];
-        const bool b_open = b_raw < 0;                                           // kAlignUndecided (sc_align2_role): scored by the exact pass
-        const int b0 = b_open ? 0 : b_raw;
-        const f4v *pp = reinterpret_cast<const f4v *>(fa.part + ((size_t)qi * (size_t)ab.pair_stride + (size_t)ci) * (NP * NPASS * 16));
-        float dmin = kInf;
-#pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                f4v sm = pp[p * 4 + g4];                                         // part 0
-#pragma unroll
-                for (int h = 1; h < NP; ++h) sm += pp[(h * NPASS + p) * 4 + g4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = 4 * g4 + r;                                    // row m of pass p = shift W - 1 - 13 p - m
-                    const int t = W - 1 - kS2PassRows * p - m;
-                    if (m >= kS2PassRows || t < 0) continue;
-                    int ri = b0 + t; ri = ri >= S ? ri - S : ri;
-                    int ne = 0;
-#pragma unroll
-                    for (int i = 0; i < MW; ++i) {
-                        const uint4 rq = rotq[ri * MW + i];
-                        ne += __popc(rq.x & km[i].x) + __popc(rq.y & km[i].y) + __popc(rq.z & km[i].z) + __popc(rq.w & km[i].w);
-                    }
-                    const float d = 1.0f - sm[r] / (float)ne;
-                    if (ne > 0 && d < dmin) dmin = d;
-                }
-            }
-        }
-        const bool exact_only = q_bad || kflag != 0 || b_open || !(dmin == dmin);
-        a.out_approx[ci] = exact_only ? __int_as_float(0xff800000) : dmin;
-        contrib = exact_only ? kInf : dmin;
-        // nanoflann's metric (nanoflann.hpp:383-408) for the ring-key top-k: four dimensions per step, fp32, groups accumulated in
-        // order -- the arithmetic of sc_align_role, here with consecutive threads on consecutive slots of the tiled key table
-        const int slot = a.slot_base + ci;
-        float result = 0.0f;
-#pragma unroll
-        for (int r = 0; r < RG; ++r) {
-            const float4 bk = a.rkey4[(size_t)r * a.rk_cap + slot];
-            const float4 qk = *reinterpret_cast<const float4 *>(a.q_rkey + 4 * r);
-            const float d0 = qk.x - bk.x, d1 = qk.y - bk.y, d2 = qk.z - bk.z, d3 = qk.w - bk.w;
-            const float grp = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-            result += grp;
-        }
-        a.out_d2[ci] = result;
-    }
+    if (ci < a.n) contrib = sc_screen2_finish_pair<RG, S, W>(fa, a, qi, ci, rotq, q_bad);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) contrib = fminf(contrib, __shfl_xor(contrib, off, kWave));
     if ((threadIdx.x & 63) == 0) wmin[threadIdx.x >> 6] = contrib;
@@ -1462,6 +1523,32 @@ __device__ __forceinline__ void sc_screen2_finish_body(const Screen2Args &fa, co
     if (threadIdx.x == 0) {
         const float m = fminf(fminf(wmin[0], wmin[1]), fminf(wmin[2], wmin[3]));
         if (m < kInf) atomicMin(a.t_min, float_to_ordered_u(m));
+    }
+}
+
+// ... by single waves (the extra waves of the products' launch): wave unit0, unit0 + stride, ... of the (scan, block of 64 pairs)
+// units of the batch; rotq in the wave's own LDS tile
+template <int RG, int S, int W>
+__device__ __forceinline__ void sc_screen2_finish_waves(const Screen2Args &fa, const int nb64, const int unit0, const int unit_stride, unsigned char *lds_wave)
+{
+    const ScreenBatchArgs &ab = fa.prod;
+    const int lane = threadIdx.x & (kWave - 1);
+    uint4 *rotq = reinterpret_cast<uint4 *>(lds_wave);
+    const float kInf = __int_as_float(0x7f800000);
+    for (int u = unit0; u < ab.nq * nb64; u += unit_stride) {
+        const int qi = u / nb64, blk = u - qi * nb64;
+        const ScreenArgs a = screen_args_of(ab, qi);
+        if (blk * kWave >= a.n) continue;                                        // (wave uniform)
+        wave_fence();
+        build_rotq<S>(a.q_kmask, rotq, lane, kWave);
+        const bool q_bad = a.q_kmask[7] != 0;
+        wave_fence();
+        const int ci = blk * kWave + lane;
+        float contrib = kInf;
+        if (ci < a.n) contrib = sc_screen2_finish_pair<RG, S, W>(fa, a, qi, ci, rotq, q_bad);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) contrib = fminf(contrib, __shfl_xor(contrib, off, kWave));
+        if (lane == 0 && contrib < kInf) atomicMin(a.t_min, float_to_ordered_u(contrib));
     }
 }
 
@@ -1490,7 +1577,12 @@ __global__ __launch_bounds__(kScreenWaves * kWave, Align2Cfg<S>::OCC) void sc_sc
                                                                                      int align_blocks, int chunks)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_tail2[];
+#ifdef SCL_TAIL_FINISH_FIRST
+    const int fblocks = (int)gridDim.x - align_blocks;
+    const int b = (int)blockIdx.x < fblocks ? (int)blockIdx.x + align_blocks : (int)blockIdx.x - fblocks;
+#else
     const int b = (int)blockIdx.x;
+#endif
     if (b < align_blocks) {
         const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         sc_align2_role<S, W>(nb, halign, u_lo, u_n, b * kScreenWaves + wave, align_blocks * kScreenWaves, smem_tail2 + (size_t)wave * Align2Cfg<S>::LDS_WAVE);
@@ -1535,7 +1627,7 @@ static int fill_screen_args(const DbView &db, const ScreenBatch &sb, int align_f
 // one grid: RG ring groups, S sectors, W shifts; OCC0 / OCC1 = waves per SIMD of the default kernel / of variant 1
 template <int RG, int S, int W, int OCC0, int OCC1>
 static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, int align_filter, int num_cu, hipStream_t stream, int phases,
-                                     const ScreenBatch *next)
+                                     const ScreenBatch *next, const ScreenBatch *prev)
 {
     constexpr int RGH = hdesc_rgh(RG);
     ScreenBatchArgs ab{};
@@ -1615,6 +1707,17 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
         b = b > cap ? cap : b;
         return b < 1 ? 1 : b;
     };
+    // SCL_SCREEN_FUSE=1 (experiment; measured slower): the next batch's alignment and the previous batch's
+    // finishing in extra waves inside the products' launch instead of a launch of their own behind it (sc_screen2_tail2_kernel)
+    static const int fuse_env = [] { const char *e = getenv("SCL_SCREEN_FUSE"); return e ? atoi(e) : 0; }();
+    const bool fuse = fuse_env != 0 && align2;
+    if (phases & kScreenFinish) {                                // this batch's finishing alone (the end of a sequence of deferred ones)
+        if (!use_v2) return hipErrorInvalidValue;
+        Screen2Args f2{};
+        f2.prod = ab; f2.part = sb.part;
+        hipLaunchKernelGGL((sc_screen2_finish_kernel<RG, S, W>), dim3((nmax + 255) / 256, sb.nq), dim3(256), 0, stream, f2);
+        return hipGetLastError();
+    }
     // the alignment of this batch, on its own (the first launch of a sequence, or a caller that has only one)
     if ((phases & kScreenAlign) && probe != 3) {
         if (align2 && use_v2) {                                  // (the products' first form takes the ring-key metric from the alignment's first form)
@@ -1634,7 +1737,8 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
             static std::atomic<bool> attr2_dev[64];
             std::atomic<bool> &attr2 = attr2_dev[dev_ & 63];
             if (!attr2.load(std::memory_order_acquire)) {
-                hipError_t e = hipFuncSetAttribute((const void *)sc_screen2_kernel<RG, S, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(s2_lds<RG, S, W>()));
+                hipError_t e = hipFuncSetAttribute((const void *)sc_screen2_kernel<RG, S, W, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(s2_lds_total<RG, S, W, true>()));
+                if (e == hipSuccess) e = hipFuncSetAttribute((const void *)sc_screen2_kernel<RG, S, W, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(s2_lds_total<RG, S, W, false>()));
                 if (e != hipSuccess) return e;
                 attr2.store(true, std::memory_order_release);
             }
@@ -1684,9 +1788,40 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
                 return r;
             };
             if (side == 2 && (e = fork()) != hipSuccess) return e;
-            constexpr size_t lds2 = s2_lds<RG, S, W>();
-            hipLaunchKernelGGL((sc_screen2_kernel<RG, S, W>), dim3(nwg), dim3(S2Cfg<RG, S, W>::WV * kWave), lds2, stream, f2);
+
+            // what the extra waves of this launch carry: the next batch's alignment, the previous batch's finishing
+            Screen2Extra xa{};
+            static const int parts_env = [] { const char *e = getenv("SCL_FUSE_PARTS"); return e ? atoi(e) : 3; }();   // experiments: 1 = only the alignment rides, 2 = only the finishing
+            const bool ride_align = fuse && side == 0 && next && next_v2 && (parts_env & 1);
+            if (ride_align) {
+                if (next->nq < 1 || next->nq > kMaxScreenBatch) return hipErrorInvalidValue;
+                if (fill_screen_args(db, *next, align_filter, &xa.next) < 0) return hipErrorInvalidValue;
+                xa.next.skip_d2 = 1;
+                xa.halign = db.halign;
+                union_of(*next, &xa.a_lo, &xa.a_n);
+            }
+            if (prev) {
+                if (!fuse || prev->nq < 1 || prev->nq > kMaxScreenBatch || !prev->part) return hipErrorInvalidValue;
+                const int pmax = fill_screen_args(db, *prev, align_filter, &xa.prev.prod);
+                if (pmax < 0) return hipErrorInvalidValue;
+                xa.prev.prod.skip_d2 = 1;
+                xa.prev.part = prev->part;
+                xa.f_nb64 = (pmax + kWave - 1) / kWave;
+            }
+            if (fuse) hipLaunchKernelGGL((sc_screen2_kernel<RG, S, W, true>), dim3(nwg), dim3(s2_waves<RG, S, W, true>() * kWave), (s2_lds_total<RG, S, W, true>()), stream, f2, xa);
+            else hipLaunchKernelGGL((sc_screen2_kernel<RG, S, W, false>), dim3(nwg), dim3(s2_waves<RG, S, W, false>() * kWave), (s2_lds_total<RG, S, W, false>()), stream, f2, xa);
             if ((e = hipGetLastError()) != hipSuccess) return e;
+            if (fuse && side == 0) {
+                // this batch's finishing: deferred to the next launch's extra waves (the caller passes this batch as its `prev`, or
+                // ends the sequence with phases = kScreenFinish), or now
+                if (!(phases & kScreenDeferFinish)) {
+                    hipLaunchKernelGGL((sc_screen2_finish_kernel<RG, S, W>), dim3((nmax + 255) / 256, sb.nq), dim3(256), 0, stream, f2);
+                    if ((e = hipGetLastError()) != hipSuccess) return e;
+                }
+                if (next && !ride_align && (e = launch_align(stream)) != hipSuccess) return e;   // (a batch the first form will score)
+                return hipSuccess;
+            }
+            if (prev || (phases & kScreenDeferFinish)) return hipErrorInvalidValue;
             if (side == 1 && (e = fork()) != hipSuccess) return e;
             static const int tail_env = [] { const char *e = getenv("SCL_SCREEN_TAIL"); return e ? atoi(e) : 1; }();   // 0: finish and alignment as two launches
             if (next && side == 0 && tail_env) {
@@ -1752,11 +1887,28 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
 }
 
 hipError_t launch_sc_screen_batch(const DbView &db, const ScreenBatch &sb, int SR, int align_filter, int num_cu, hipStream_t stream, int phases,
-                                  const ScreenBatch *next)
+                                  const ScreenBatch *next, const ScreenBatch *prev)
 {
     if (sb.nq < 1 || sb.nq > kMaxScreenBatch || !sc_screen_supported(db, SR)) return hipErrorInvalidValue;
-    if (sc_screen_is_wide(db, SR)) return launch_screen_grid<20, 180, 19, 2, 2>(db, sb, align_filter, num_cu, stream, phases, next);   // 80 x 180
-    return launch_screen_grid<16, 120, 13, 3, 2>(db, sb, align_filter, num_cu, stream, phases, next);                                   // 64 x 120
+    if (sc_screen_is_wide(db, SR)) return launch_screen_grid<20, 180, 19, 2, 2>(db, sb, align_filter, num_cu, stream, phases, next, prev);   // 80 x 180
+    return launch_screen_grid<16, 120, 13, 3, 2>(db, sb, align_filter, num_cu, stream, phases, next, prev);                                   // 64 x 120
+}
+
+// Can a batch of nq scans have its finishing deferred (second form of the products, extra waves available)?
+bool sc_screen_can_defer(const DbView &db, int SR, int nq)
+{
+    static const int fuse_env = [] { const char *e = getenv("SCL_SCREEN_FUSE"); return e ? atoi(e) : 0; }();
+    static const int align_form_env = [] { const char *e = getenv("SCL_ALIGN_FORM"); return e ? atoi(e) : 2; }();
+    static const int side_env = [] { const char *e = getenv("SCL_ALIGN_SIDE"); return e ? atoi(e) : 0; }();
+    static const int variant = [] { const char *e = getenv("SCL_SCREEN_VARIANT"); return e ? atoi(e) : 0; }();
+    static const int probe = [] { const char *e = getenv("SCL_SCREEN_PROBE"); return e ? atoi(e) : 0; }();
+    static const int parts_env = [] { const char *e = getenv("SCL_FUSE_PARTS"); return e ? atoi(e) : 3; }();
+    if (!(parts_env & 2)) return false;
+    if (!fuse_env || align_form_env == 1 || side_env != 0 || variant != 0 || probe != 0 || !screen_second_form() || !db.halign || !sc_screen_supported(db, SR)) return false;
+    const bool wide = sc_screen_is_wide(db, SR);
+    static const int v2_env = [] { const char *e = getenv("SCL_SCREEN_V2_MIN"); return e ? atoi(e) : 0; }();
+    const int v2_min = v2_env > 0 ? v2_env : (wide ? 2 : 4);
+    return nq >= v2_min && nq <= sc_screen_max_batch(db, SR);
 }
 
 }  // namespace scl
