@@ -77,6 +77,9 @@ def parse_args():
                          "them through an XCD's L2, so the database crosses HBM once per launch, not once per scan")
     ap.add_argument("--native-chunk", type=int, default=1024,
                     help="scans handed to the engine's native submit/collect pipeline per call (0: drive every scan from Python)")
+    ap.add_argument("--front", type=int, default=0,
+                    help="G > 0: measure the C-ABI sharded front instead (scl_create_sharded: ONE process, G shards of 12 500 keyframes dealt "
+                         "over the visible devices; the stream form and the single passes with their exchange).  Not the driver's contract line.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] geometric-verification measurement")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the 1-thread CPU sample (0 = auto ~10 s)")
@@ -111,6 +114,30 @@ def _cpu_model():
     except OSError:
         pass
     return "unknown"
+
+
+def _cgroup_cpu():
+    """CPU bandwidth the container may use (cgroup quota / period) and the throttling counters: a host that shows 256 cores in the
+    affinity mask but a quota of 16 runs 256 threads at 16 cores' worth -- the all-core figure then scales with the quota, not
+    with the thread count."""
+    out = {}
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        out["quota_cores"] = None if q == "max" else float(q) / float(p)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            out["quota_cores"] = None if q <= 0 else q / p
+        except Exception:
+            out["quota_cores"] = "unknown"
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            st = dict(l.split() for l in open(path).read().strip().splitlines())
+            out["nr_throttled"] = int(st.get("nr_throttled", 0)); out["throttled_usec"] = int(st.get("throttled_usec", st.get("throttled_time", 0)))
+            break
+        except Exception:
+            pass
+    return out
 
 
 def _native_oracle():
@@ -199,8 +226,18 @@ def cpu_baseline(descs, n_pairs_hint, budget_s=8.0):
                      f"reference-shaped sco_distance (per-shift matrix copy, double norm evaluation) "
                      f"+ ring-key scan per query, single thread, -O3 (no -march, as the reference builds)",
            "cpu_model": _cpu_model(), "host_cores_available": os.cpu_count(), "affinity_cores": threads}
+    cg0 = _cgroup_cpu()
+    t_sweep = time.perf_counter()
+    cpu0 = time.process_time()
     res["all_cores_reference_shaped"], res["all_cores_copy_free"] = sweep(db, 2.0)
+    cpu1, wall = time.process_time(), time.perf_counter() - t_sweep
+    cg1 = _cgroup_cpu()
     res["all_cores_over_one_thread"] = res["all_cores_reference_shaped"]["value"] / res["value"]
+    # why the all-core figure is not (threads x the one-thread figure): CPU time this process actually got during the sweep
+    res["host_cpu_share"] = {"cgroup_quota_cores": cg0.get("quota_cores"), "cores_worth_of_cpu_time_during_sweep": (cpu1 - cpu0) / wall,
+                             "cgroup_throttled_periods_during_sweep": (cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0)) if "nr_throttled" in cg0 else None,
+                             "cgroup_throttled_ms_during_sweep": ((cg1.get("throttled_usec", 0) - cg0.get("throttled_usec", 0)) / 1e3) if "throttled_usec" in cg0 else None,
+                             "note": "pairs/s per core-second of CPU time = all_cores value / cores_worth_of_cpu_time"}
     db.close()
     # the same figures from a -march=native build made on this host (BASELINE.md §2's flags)
     native = _native_oracle()
@@ -445,8 +482,55 @@ def secondary_livox_stream(device, n0=1000, n_scans=120):
 
 
 # ------------------------------------------------------------------------------------------------
+# the C-ABI sharded front (one process, all GPUs of the node): SURVEY 8(e) through scl_create_sharded
+# ------------------------------------------------------------------------------------------------
+def bench_front(G, steps, spl):
+    """BASELINE configs[3] through the C ABI: ONE engine over G shards (keyframe g on shard g % G; devices = the visible GPUs, round
+    robin, so on a one-GPU box the shards share the card and the exchange is the host merge or -- SCL_FRONT_EXCHANGE=3 -- the tests'
+    stand-in collective; with G distinct devices the two RCCL min all-reduces).  Stream form (per-shard streams + host merge of the
+    winners) and the single blocking pass (per-shard pass + exchange)."""
+    import torch
+    from scl_slam_amd import ScanContextEngine
+    from scl_slam_amd.synth import synth_descriptors
+    ndev = max(1, torch.cuda.device_count())
+    devices = [i % ndev for i in range(G)]
+    distinct = len(set(devices)) == G
+    exch = int(os.environ.get("SCL_FRONT_EXCHANGE", "2" if (distinct and G > 1) else "1"))
+    n = N_KEYFRAMES_SHARD * G
+    eng = ScanContextEngine(num_ring=R, num_sector=S, num_candidates=3, num_exclude_recent=N_EXCLUDE, initial_capacity=n + 64, devices=devices, exchange=exch)
+    for c in range(G):
+        eng.save_bulk(synth_descriptors(N_KEYFRAMES_SHARD, R, S, seed=1002 + 7919 * c, revisit_frac=0.0))
+    n_elig = n - N_EXCLUDE
+    scans = steps * spl
+    qs = (n_elig + (np.arange(scans) % N_EXCLUDE)).astype(np.int32)
+    eng.detect_full_stream(qs[:2 * spl], 0, n_elig, spl, 2)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        eng.detect_full_stream(qs, 0, n_elig, spl, 2)
+        ts.append(time.perf_counter() - t0)
+    dt = float(np.median(ts))
+    lat = []
+    for i in range(60):
+        t0 = time.perf_counter()
+        eng.detect_full_range(int(qs[i]), 0, n_elig)
+        if i >= 10:
+            lat.append((time.perf_counter() - t0) * 1e6)
+    info = eng.shard_info()
+    eng.close()
+    print(json.dumps({"metric": "loop-closure candidates/sec through the C-ABI sharded front (scl_create_sharded), one process", "value": n_elig * scans / dt,
+                      "unit": "pairs/s", "n_gpus": len(set(devices)), "shards": G, "devices": devices, "exchange": {1: "host merge", 2: "RCCL min all-reduce x2", 3: "stand-in collective (tests)"}.get(info[1], str(info[1])),
+                      "steps": steps, "ms_per_step": dt / steps * 1e3, "ms_per_scan": dt / scans * 1e3, "higher_is_better": True, "scaling": "weak",
+                      "config": {"workload": f"BASELINE configs[3]-shaped: {n} keyframes over {G} shards ({N_KEYFRAMES_SHARD} each), 64x120, {scans} scans through the front's stream form",
+                                 "scans_per_launch": spl},
+                      "blocking_pass_us": {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)),
+                                           "note": "one scan: per-shard passes enqueued on every device, winners reduced by the exchange above"}}), flush=True)
+
+
 def main():
     args = parse_args()
+    if args.front > 0:
+        return bench_front(args.front, args.steps, max(1, args.scans_per_launch))
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     world_env = os.environ.get("WORLD_SIZE")
@@ -631,6 +715,10 @@ def main():
                                                        "comparison with round 1's figures; not a rate of moved bytes"}},
             "device": eng.device_name(),
         }
+        if world > 1:
+            out["collective"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                                 "library": "RCCL (torch.distributed 'nccl' on ROCm)" if dist.get_backend() == "nccl" else "gloo (CPU rehearsal: SCL_BENCH_SHARE_GPU=1)",
+                                 "exchange": args.exchange, "devices_distinct": not share_gpu}
         if world == 1 and not args.no_secondary:
             out["secondary"] = {}
             for name, fn in (("exact_all_pairs", lambda: secondary_exact_all_pairs(eng, n_elig, n_query)),

@@ -47,9 +47,10 @@ struct IcpState {
     double fitness;
     int iter; int done; int converged; int n_corr;
     double sums[kNSum];
+    unsigned int ticket; unsigned int pad_;               // workgroups of the fused iteration that have delivered their partial sums
 };
 
-enum Buf { B_SRC = 0, B_TGT, B_WORK, B_TSORT, B_CSTART, B_CFILL, B_NNI, B_NND, B_PART, B_STATE, B_BBOX, B_SI, B_TI, B_OUT, B_MASK, B_HYP };
+enum Buf { B_SRC = 0, B_TGT, B_WORK, B_TSORT, B_CSTART, B_CFILL, B_NNI, B_NND, B_PART, B_STATE, B_BBOX, B_SI, B_TI, B_OUT, B_MASK, B_HYP, B_PROB };
 constexpr int B_NORM = B_OUT;             // target normals share the slot of the raw-transform output (never live together)
 
 int ensure(IcpWorkspace *ws, int k, size_t bytes, std::string *err)
@@ -308,16 +309,11 @@ __device__ __forceinline__ void nn_search_kernel_t_body(float4 *work, int n_src,
         }
         group_min<G>(best, bi);
     };
-    if (warm && bi >= 0) {                                       // the previous neighbour bounds the ball
-        ball_pass();
-        if (valid && sub == 0) {
-            nn_idx[i] = bi;
-            nn_d2[i] = best;
-        }
-        return;
-    }
+    const bool warm_start = warm && bi >= 0;                     // the previous neighbour bounds the ball
+    if (warm_start) ball_pass();
     // Cold search: shells until the first one that holds a point (its distance bounds the ball), then the ball once.
-    for (int r = 0; r <= maxdim; ++r) {
+    // (no early return above: this body is inlined in front of the fused iteration's reduction)
+    for (int r = 0; !warm_start && r <= maxdim; ++r) {
         const int lo0 = c[0] - r, hi0 = c[0] + r, lo1 = c[1] - r, hi1 = c[1] + r, lo2 = c[2] - r, hi2 = c[2] + r;
         const int z0 = max(lo2, 0), z1 = min(hi2, dz - 1), y0 = max(lo1, 0), y1 = min(hi1, dy - 1);
         const int ny = y1 - y0 + 1, nrows = (z1 - z0 + 1) * ny;
@@ -396,6 +392,17 @@ __global__ __launch_bounds__(256) void nn_search_kernel_t(float4 *work, int n_sr
     nn_search_kernel_t_body<G>(work, n_src, st, cell_start, sorted, nn_idx, nn_d2, check_done, apply_iter, tgt_raw, stride, warm);
 }
 
+// A workgroup's partial sums leave it either as plain stores (a reduction launch of its own: the solve is another launch) or,
+// inside the fused iteration, as agent-scope atomic stores (write-through to where every XCD sees them: the last workgroup to
+// arrive reads them back in the same launch)
+__device__ __forceinline__ void put_partial(double *dst, double v, bool atomic_out)
+{
+    if (atomic_out) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *dst = v;
+}
+// the range of correspondences a workgroup reduces: i = i0 + threadIdx.x, + step, ... < i1
+struct RedRange { int i0, step, i1; };
+
 // ---- K5 ----------------------------------------------------------------------------
 // sums of [p;1][q;1]^T (16) and of d2 over the accepted correspondences.
 // mode 0: pairs (i, nn_idx[i]) with d2 <= maxd2, p from `work`;  mode 1: explicit pairs (si[k], ti[k]).
@@ -403,13 +410,15 @@ __device__ __forceinline__ void corr_reduce_kernel_body(const float4 *work, cons
                                                           const unsigned char *tgt_raw, int stride, int n,
                                                           const int *nn_idx, const float *nn_d2, float maxd2,
                                                           const int *si, const int *ti, int mode,
-                                                          const IcpState *st, double *partials, int check_done)
+                                                          const IcpState *st, double *partials, int check_done,
+                                                          const RedRange *range = nullptr)
 {
     if (check_done && st->done) return;
     double acc[kNSum];
 #pragma unroll
     for (int k = 0; k < kNSum; ++k) acc[k] = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int r_i0 = range ? range->i0 : (int)(blockIdx.x * blockDim.x), r_step = range ? range->step : (int)(gridDim.x * blockDim.x), r_i1 = range ? range->i1 : n;
+    for (int i = r_i0 + (int)threadIdx.x; i < r_i1; i += r_step) {
         float3 p, q;
         float d2 = 0.f;
         if (mode == 0) {
@@ -442,7 +451,7 @@ __device__ __forceinline__ void corr_reduce_kernel_body(const float4 *work, cons
     if ((threadIdx.x & 63) == 0) for (int k = 0; k < kNSum; ++k) s[wv][k] = acc[k];
     __syncthreads();
     if (threadIdx.x < kNSum)
-        partials[blockIdx.x * kNSum + threadIdx.x] = ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x];
+        put_partial(partials + blockIdx.x * kNSum + threadIdx.x, ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x], range != nullptr);
 }
 
 __global__ __launch_bounds__(256) void corr_reduce_kernel(const float4 *work, const unsigned char *src_raw,
@@ -464,7 +473,8 @@ __device__ __forceinline__ void corr_reduce_mfma_kernel_body(const float4 *work,
                                                                const unsigned char *tgt_raw, int stride, int n,
                                                                const int *nn_idx, const float *nn_d2, float maxd2,
                                                                const int *si, const int *ti, int mode,
-                                                               const IcpState *st, double *partials, int check_done)
+                                                               const IcpState *st, double *partials, int check_done,
+                                                               const RedRange *range = nullptr)
 {
     if (check_done && st->done) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -472,12 +482,14 @@ __device__ __forceinline__ void corr_reduce_mfma_kernel_body(const float4 *work,
     const int wave_global = blockIdx.x * 4 + wv, nwaves = gridDim.x * 4;
     double acc0 = 0.0, acc1 = 0.0;
     double sum_d2 = 0.0;
-    for (int base = wave_global * 32; base < n; base += nwaves * 32) {
+    // (a range: this workgroup's own correspondences, 32 per wave and step)
+    const int b_first = range ? range->i0 + wv * 32 : wave_global * 32, b_step = range ? 4 * 32 : nwaves * 32, b_end = range ? range->i1 : n;
+    for (int base = b_first; base < b_end; base += b_step) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {                       // two independent accumulator chains
             const int i = base + half * 16 + 4 * blk + k;            // this lane's correspondence
             double av = 0.0, bv = 0.0;
-            if (i < n) {
+            if (i < b_end) {
                 bool ok = true;
                 int pi = i, qi;
                 float d2 = 0.f;
@@ -509,7 +521,7 @@ __device__ __forceinline__ void corr_reduce_mfma_kernel_body(const float4 *work,
     if (lane == 0) s[wv][16] = sum_d2;
     __syncthreads();
     if (threadIdx.x < kNSum)
-        partials[blockIdx.x * kNSum + threadIdx.x] = ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x];
+        put_partial(partials + blockIdx.x * kNSum + threadIdx.x, ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x], range != nullptr);
 }
 
 __global__ __launch_bounds__(256) void corr_reduce_mfma_kernel(const float4 *work, const unsigned char *src_raw,
@@ -528,7 +540,7 @@ __global__ __launch_bounds__(256) void corr_reduce_mfma_kernel(const float4 *wor
 // cofactor inverses instead of ~8 sweeps of a 4x4 Jacobi whose dependent fp64 divisions and square
 // roots cost ~40 us on one lane.  Returns false (caller falls back to Horn's quaternion) when S is
 // close to singular or improper -- e.g. the rank-2 matrices of the 3-point RANSAC fits.
-__device__ bool rotation_polar(const double S[3][3], double R[3][3])
+__device__ __forceinline__ bool rotation_polar(const double S[3][3], double R[3][3])
 {
     double X[3][3];
     double fro = 0.0;
@@ -584,7 +596,7 @@ __device__ bool rotation_polar(const double S[3][3], double R[3][3])
     return true;
 }
 
-__device__ void rotation_from_S(const double S[3][3], double R[3][3])
+__device__ __forceinline__ void rotation_from_S(const double S[3][3], double R[3][3])
 {
     if (rotation_polar(S, R)) return;
     double N[4][4], V[4][4];
@@ -643,7 +655,7 @@ __device__ void rotation_from_S(const double S[3][3], double R[3][3])
 }
 
 // final = T_inc * final, ++iter, pcl::registration::DefaultConvergenceCriteria
-__device__ void apply_increment(IcpState *st, const float *T, double sum_d2, double N, int max_iter,
+__device__ __forceinline__ void apply_increment(IcpState *st, const float *T, double sum_d2, double N, int max_iter,
                                 double trans_eps, double fit_eps)
 {
     float F[16];
@@ -687,14 +699,9 @@ __device__ __forceinline__ void reduce_partials(const double *partials, int nblo
 }
 
 // mode 0: ICP iteration (convergence bookkeeping); mode 1: one-shot rigid estimate; mode 2: fitness only
-__device__ __forceinline__ void icp_solve_kernel_body(IcpState *st, const double *partials, int nblocks, int mode,
-                                                       int max_iter, double trans_eps, double fit_eps)
+// one thread: the sums of an iteration -> increment, convergence bookkeeping
+__device__ __forceinline__ void icp_solve_from_sums(IcpState *st, const double *sums, int mode, int max_iter, double trans_eps, double fit_eps)
 {
-    __shared__ double sums[kNSum];
-    __shared__ double tmp[kNSum][64];
-    if (mode == 0 && st->done) return;
-    reduce_partials<kNSum>(partials, nblocks, sums, tmp);
-    if (threadIdx.x != 0) return;
     for (int k = 0; k < kNSum; ++k) st->sums[k] = sums[k];
     const double N = sums[15];
     st->n_corr = (int)N;
@@ -713,6 +720,17 @@ __device__ __forceinline__ void icp_solve_kernel_body(IcpState *st, const double
     for (int k = 0; k < 16; ++k) st->inc_T[k] = T[k];
     if (mode == 1) { for (int k = 0; k < 16; ++k) st->final_T[k] = T[k]; return; }
     apply_increment(st, T, sums[16], N, max_iter, trans_eps, fit_eps);
+}
+
+__device__ __forceinline__ void icp_solve_kernel_body(IcpState *st, const double *partials, int nblocks, int mode,
+                                                       int max_iter, double trans_eps, double fit_eps)
+{
+    __shared__ double sums[kNSum];
+    __shared__ double tmp[kNSum][64];
+    if (mode == 0 && st->done) return;
+    reduce_partials<kNSum>(partials, nblocks, sums, tmp);
+    if (threadIdx.x != 0) return;
+    icp_solve_from_sums(st, sums, mode, max_iter, trans_eps, fit_eps);
 }
 
 __global__ __launch_bounds__(64) void icp_solve_kernel(IcpState *st, const double *partials, int nblocks, int mode,
@@ -854,13 +872,15 @@ __global__ __launch_bounds__(256) void normals_kernel(const unsigned char *tgt, 
 
 __device__ __forceinline__ void plane_reduce_kernel_body(const float4 *work, const unsigned char *tgt_raw, int stride, int n,
                                                            const int *nn_idx, const float *nn_d2, float maxd2,
-                                                           const float4 *normals, const IcpState *st, double *partials)
+                                                           const float4 *normals, const IcpState *st, double *partials,
+                                                           const RedRange *range = nullptr)
 {
     if (st->done) return;
     double acc[kNPlane];
 #pragma unroll
     for (int k = 0; k < kNPlane; ++k) acc[k] = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int r_i0 = range ? range->i0 : (int)(blockIdx.x * blockDim.x), r_step = range ? range->step : (int)(gridDim.x * blockDim.x), r_i1 = range ? range->i1 : n;
+    for (int i = r_i0 + (int)threadIdx.x; i < r_i1; i += r_step) {
         const int j = nn_idx[i];
         const float d2 = nn_d2[i];
         if (j < 0 || !(d2 <= maxd2)) continue;
@@ -890,7 +910,7 @@ __device__ __forceinline__ void plane_reduce_kernel_body(const float4 *work, con
     if ((threadIdx.x & 63) == 0) for (int k = 0; k < kNPlane; ++k) s[wv][k] = acc[k];
     __syncthreads();
     if (threadIdx.x < kNPlane)
-        partials[blockIdx.x * kNPlane + threadIdx.x] = ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x];
+        put_partial(partials + blockIdx.x * kNPlane + threadIdx.x, ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x], range != nullptr);
 }
 
 __global__ __launch_bounds__(256) void plane_reduce_kernel(const float4 *work, const unsigned char *tgt_raw, int stride, int n,
@@ -900,13 +920,8 @@ __global__ __launch_bounds__(256) void plane_reduce_kernel(const float4 *work, c
     plane_reduce_kernel_body(work, tgt_raw, stride, n, nn_idx, nn_d2, maxd2, normals, st, partials);
 }
 
-__device__ __forceinline__ void plane_solve_kernel_body(IcpState *st, const double *partials, int nblocks, int max_iter, double trans_eps, double fit_eps)
+__device__ __forceinline__ void plane_solve_from_sums(IcpState *st, const double *sums, int max_iter, double trans_eps, double fit_eps)
 {
-    __shared__ double sums[kNPlane];
-    __shared__ double tmp[kNPlane][64];
-    if (st->done) return;
-    reduce_partials<kNPlane>(partials, nblocks, sums, tmp);
-    if (threadIdx.x != 0) return;
     const double N = sums[28];
     st->n_corr = (int)N;
     if (N < 3.0) { st->done = 1; st->converged = 0; return; }
@@ -934,6 +949,16 @@ __device__ __forceinline__ void plane_solve_kernel_body(IcpState *st, const doub
     T[12] = T[13] = T[14] = 0.f; T[15] = 1.f;
     for (int k = 0; k < 16; ++k) st->inc_T[k] = T[k];
     apply_increment(st, T, sums[27], N, max_iter, trans_eps, fit_eps);
+}
+
+__device__ __forceinline__ void plane_solve_kernel_body(IcpState *st, const double *partials, int nblocks, int max_iter, double trans_eps, double fit_eps)
+{
+    __shared__ double sums[kNPlane];
+    __shared__ double tmp[kNPlane][64];
+    if (st->done) return;
+    reduce_partials<kNPlane>(partials, nblocks, sums, tmp);
+    if (threadIdx.x != 0) return;
+    plane_solve_from_sums(st, sums, max_iter, trans_eps, fit_eps);
 }
 
 __global__ void plane_solve_kernel(IcpState *st, const double *partials, int nblocks, int max_iter, double trans_eps, double fit_eps)
@@ -995,7 +1020,7 @@ __global__ void state_init_kernel(IcpState *st)
     if (threadIdx.x == 0) {
         for (int k = 0; k < 16; ++k) { st->final_T[k] = (k % 5 == 0) ? 1.f : 0.f; st->inc_T[k] = (k % 5 == 0) ? 1.f : 0.f; }
         st->mse_prev = DBL_MAX; st->fitness = (double)FLT_MAX;
-        st->iter = 0; st->done = 0; st->converged = 0; st->n_corr = 0;
+        st->iter = 0; st->done = 0; st->converged = 0; st->n_corr = 0; st->ticket = 0u; st->pad_ = 0u;
     }
 }
 
@@ -1168,6 +1193,64 @@ __global__ void plane_solve_batch_kernel(const IcpProblem *pr, int nblocks, int 
     plane_solve_kernel_body(p.st, p.part, nblocks, max_iter, trans_eps, fit_eps);
 }
 
+// ---- one launch per ICP iteration -------------------------------------------------------------------------------------------
+// search (the previous solve's increment moves the working points first), this workgroup's own correspondences reduced to a
+// partial record, and -- in the workgroup that delivers the last record of its alignment -- the sum of the records in a fixed
+// order and the solve: what used to be three dependent launches (DM.h:1107-1121's loop body).  The records travel as agent-scope
+// atomic stores / loads (no cache write-back or invalidation: an agent-scope fence would write the L2 back), ordered by the ticket
+// counter in the alignment's state: a workgroup takes its ticket after its stores have been acknowledged.
+// mode 0: ICP iteration; 2: fitness pass (behind work_transform: the final transform on the original source; every correspondence
+// counts).  (The transform is not folded into this kernel: a source read in front of the inlined search crashes this compiler.)
+// est 0: point to point (covariance on the fp64 matrix cores when mfma != 0), 1: point to plane.
+template <int G>
+__global__ __launch_bounds__(256) void icp_fused_batch_kernel(const IcpProblem *pr, const unsigned char *src_raw, int n_src, int stride, int apply, int warm,
+                                                              float maxd2, int mfma, int mode, int est, int max_iter, double trans_eps, double fit_eps)
+{
+    const IcpProblem p = pr[blockIdx.y];
+    IcpState *st = p.st;
+    if (mode == 0 && st->done) return;                           // (set by an earlier launch's solve: the same for every workgroup)
+    nn_search_kernel_t_body<G>(p.work, n_src, st, p.cell_start, p.sorted, p.nni, p.nnd, 0, apply, p.tgt, stride, warm);
+    __threadfence_block();
+    __syncthreads();                                             // this workgroup's neighbours and moved points are in memory for its own lanes
+    constexpr int QW = 256 / G;                                  // queries of a workgroup
+    RedRange rr;
+    rr.i0 = (int)blockIdx.x * QW; rr.step = 256; rr.i1 = rr.i0 + QW < n_src ? rr.i0 + QW : n_src;
+    const int NS = est == 1 ? kNPlane : kNSum;
+    if (est == 1) plane_reduce_kernel_body(p.work, p.tgt, stride, n_src, p.nni, p.nnd, maxd2, p.normals, st, p.part, &rr);
+    else if (mfma) corr_reduce_mfma_kernel_body(p.work, src_raw, p.tgt, stride, n_src, p.nni, p.nnd, maxd2, nullptr, nullptr, 0, st, p.part, 0, &rr);
+    else corr_reduce_kernel_body(p.work, src_raw, p.tgt, stride, n_src, p.nni, p.nnd, maxd2, nullptr, nullptr, 0, st, p.part, 0, &rr);
+    // ---- ticket: the stores above must have been acknowledged before it is taken ----
+    __shared__ unsigned int s_ticket;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket != gridDim.x - 1) return;
+    // ---- the last workgroup: records summed in a fixed order (wave w takes entries w, w + 4, ...; lane l records l, l + 64, ...;
+    //      then the lanes in lane order), then the solve ----
+    __shared__ double f_tmp[kNPlane][64];
+    __shared__ double f_sums[kNPlane];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nblocks = (int)gridDim.x;
+    for (int k = wv; k < NS; k += 4) {
+        double acc = 0.0;
+        for (int b = lane; b < nblocks; b += 64) acc += __hip_atomic_load(p.part + (size_t)b * NS + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        f_tmp[k][lane] = acc;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < NS) {
+        double acc = 0.0;
+        for (int l = 0; l < 64; ++l) acc += f_tmp[threadIdx.x][l];
+        f_sums[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    st->ticket = 0u;                                             // armed for the next launch (stream ordered)
+    if (est == 1 && mode == 0) plane_solve_from_sums(st, f_sums, max_iter, trans_eps, fit_eps);
+    else if (est == 1) { const double N = f_sums[28]; st->n_corr = (int)N; st->fitness = N > 0.0 ? f_sums[27] / N : (double)FLT_MAX; }
+    else icp_solve_from_sums(st, f_sums, mode, max_iter, trans_eps, fit_eps);
+}
+
 __global__ void work_transform_batch_kernel(const IcpProblem *pr, const unsigned char *src, int n, int stride, int which)
 {
     const IcpProblem p = pr[blockIdx.y];
@@ -1175,6 +1258,21 @@ __global__ void work_transform_batch_kernel(const IcpProblem *pr, const unsigned
 }
 
 // ---- host helpers -------------------------------------------------------------------
+// records of the fused iteration: one per workgroup of the search, the cold search (kNnGroup lanes per query) has the most
+static size_t fused_part_bytes(int n_src)
+{
+    const size_t q = n_src > 0 ? (size_t)n_src : 1;
+    const size_t blocks = (q * 8 + 255) / 256 + 1;
+    return sizeof(double) * kNPlane * (blocks > (size_t)kRedBlocks ? blocks : (size_t)kRedBlocks);
+}
+static bool icp_fused_enabled()
+{
+    // SCL_ICP_FUSED=1: search + reduction + solve of an iteration in ONE launch (icp_fused_batch_kernel).  Correct (the same tests
+    // pass) but measured slower -- 15.0 against 10.8 ms per 25-candidate query: the solve's fp64 registers (126 + spills) halve the
+    // occupancy the search lives on (74 registers, six waves per SIMD) -- so the three launches stay the default.
+    static const bool v = [] { const char *e = getenv("SCL_ICP_FUSED"); return e && e[0] == '1'; }();
+    return v;
+}
 static bool use_mfma_reduce()
 {
     static const bool v = [] { const char *e = getenv("SCL_ICP_REDUCE"); return !(e && e[0] == 'v'); }();   // SCL_ICP_REDUCE=valu
@@ -1308,7 +1406,7 @@ int icp_align_staged(IcpWorkspace *ws, hipStream_t stream, int n_src, int n_tgt,
     if ((rc = ensure(ws, B_WORK, sizeof(float4) * (size_t)(n_src + 1), err))) return rc;
     if ((rc = ensure(ws, B_NNI, sizeof(int) * (size_t)(n_src + 1), err))) return rc;
     if ((rc = ensure(ws, B_NND, sizeof(float) * (size_t)(n_src + 1), err))) return rc;
-    if ((rc = ensure(ws, B_PART, sizeof(double) * kNPlane * kRedBlocks, err))) return rc;
+    if ((rc = ensure(ws, B_PART, fused_part_bytes(n_src), err))) return rc;
     if ((rc = build_grid(ws, stream, n_tgt, stride, err))) return rc;
     if ((rc = pinned(ws, sizeof(IcpState), err))) return rc;
     if (p.estimator == 1) {
@@ -1333,8 +1431,29 @@ int icp_align_staged(IcpWorkspace *ws, hipStream_t stream, int n_src, int n_tgt,
     hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(64), 0, stream, st);
     hipLaunchKernelGGL(work_init_kernel, dim3(pb), dim3(256), 0, stream, d_src, n_src, stride, work);
     IcpState *h = static_cast<IcpState *>(ws->pinned);
-    // one iteration = neighbour search (K6 of the previous iteration fused in) + reduction + solve
+    const bool fused = icp_fused_enabled();
+    const IcpProblem *dprob = nullptr;
+    const int mfma1 = use_mfma_reduce() ? 1 : 0;
+    const long long q1 = n_src > 0 ? n_src : 1;
+    if (fused) {                                             // the one-entry problem table of the fused launches
+        if ((rc = ensure(ws, B_PROB, sizeof(IcpProblem), err))) return rc;
+        if ((rc = pinned(ws, sizeof(IcpState) + sizeof(IcpProblem), err))) return rc;
+        h = static_cast<IcpState *>(ws->pinned);
+        IcpProblem *hp = reinterpret_cast<IcpProblem *>(h + 1);
+        hp->work = work; hp->st = st; hp->cell_start = (const int *)ws->buf[B_CSTART]; hp->sorted = (const float4 *)ws->buf[B_TSORT];
+        hp->nni = nni; hp->nnd = nnd; hp->part = part; hp->tgt = d_tgt; hp->normals = p.estimator == 1 ? (const float4 *)ws->buf[B_NORM] : nullptr;
+        ICP_HIP(hipMemcpyAsync(ws->buf[B_PROB], hp, sizeof(IcpProblem), hipMemcpyHostToDevice, stream));
+        dprob = static_cast<const IcpProblem *>(ws->buf[B_PROB]);
+    }
+    auto fused_launch = [&](bool cold, int apply, int warm, float md2, int mode, int est) {
+        if (cold) hipLaunchKernelGGL(icp_fused_batch_kernel<kNnGroup>, dim3((unsigned)((q1 * kNnGroup + 255) / 256), 1), dim3(256), 0, stream,
+                                     dprob, d_src, n_src, stride, apply, warm, md2, mfma1, mode, est, p.max_iterations, p.transformation_epsilon, p.euclidean_fitness_epsilon);
+        else hipLaunchKernelGGL(icp_fused_batch_kernel<kNnWarmGroup>, dim3((unsigned)((q1 * kNnWarmGroup + 255) / 256), 1), dim3(256), 0, stream,
+                                dprob, d_src, n_src, stride, apply, warm, md2, mfma1, mode, est, p.max_iterations, p.transformation_epsilon, p.euclidean_fitness_epsilon);
+    };
+    // one iteration = neighbour search (K6 of the previous iteration fused in) + reduction + solve: ONE launch
     auto enqueue_iteration = [&](bool cold) {
+        if (fused) { fused_launch(cold, cold ? -1 : 1, cold ? 0 : 1, maxd2, 0, p.estimator); return; }
         launch_nn_search(stream, work, n_src, st, (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], nni, nnd, 1,
                          cold ? -1 : 1, d_tgt, stride, cold ? 0 : 1);
         if (p.estimator == 1) {
@@ -1359,12 +1478,17 @@ int icp_align_staged(IcpWorkspace *ws, hipStream_t stream, int n_src, int n_tgt,
         }
     }
     // fitness: original source moved by the final transform, mean squared NN distance over all points
-    hipLaunchKernelGGL(work_transform_kernel, dim3(pb), dim3(256), 0, stream, work, d_src, n_src, stride, st, 1, 0);
-    launch_nn_search(stream, work, n_src, st,
-                       (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], nni, nnd, 0, -1, d_tgt, stride, 1);
-    LAUNCH_REDUCE(rb, stream, work, d_src, d_tgt, stride, n_src,
-                  nni, nnd, FLT_MAX, (const int *)nullptr, (const int *)nullptr, 0, st, part, 0);
-    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, stream, st, part, rb, 2, 0, 0.0, 0.0);
+    if (fused) {
+        hipLaunchKernelGGL(work_transform_kernel, dim3(pb), dim3(256), 0, stream, work, d_src, n_src, stride, st, 1, 0);
+        fused_launch(false, -1, 1, FLT_MAX, 2, 0);
+    } else {
+        hipLaunchKernelGGL(work_transform_kernel, dim3(pb), dim3(256), 0, stream, work, d_src, n_src, stride, st, 1, 0);
+        launch_nn_search(stream, work, n_src, st,
+                           (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], nni, nnd, 0, -1, d_tgt, stride, 1);
+        LAUNCH_REDUCE(rb, stream, work, d_src, d_tgt, stride, n_src,
+                      nni, nnd, FLT_MAX, (const int *)nullptr, (const int *)nullptr, 0, st, part, 0);
+        hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, stream, st, part, rb, 2, 0, 0.0, 0.0);
+    }
     ICP_HIP(hipGetLastError());
     ICP_HIP(hipMemcpyAsync(h, st, sizeof(IcpState), hipMemcpyDeviceToHost, stream));
     ICP_HIP(hipStreamSynchronize(stream));
@@ -1389,7 +1513,7 @@ int icp_batch_prepare(IcpWorkspace *ws, hipStream_t stream, const void *d_src, i
     if ((rc = ensure(ws, B_WORK, sizeof(float4) * (size_t)(n_src + 1), err))) return rc;
     if ((rc = ensure(ws, B_NNI, sizeof(int) * (size_t)(n_src + 1), err))) return rc;
     if ((rc = ensure(ws, B_NND, sizeof(float) * (size_t)(n_src + 1), err))) return rc;
-    if ((rc = ensure(ws, B_PART, sizeof(double) * kNPlane * kRedBlocks, err))) return rc;
+    if ((rc = ensure(ws, B_PART, fused_part_bytes(n_src), err))) return rc;
     if ((rc = build_grid(ws, stream, n_tgt, stride, err))) return rc;
     if (p.estimator == 1) {
         if ((rc = ensure(ws, B_NORM, sizeof(float4) * (size_t)(n_tgt + 1), err))) return rc;
@@ -1438,7 +1562,15 @@ int icp_batch_run(IcpWorkspace *const *wss, int nprob, IcpWorkspace *ctl, hipStr
         else hipLaunchKernelGGL(nn_search_batch_kernel<kNnWarmGroup>, dim3((unsigned)((q * kNnWarmGroup + 255) / 256), nprob), dim3(256), 0, stream,
                                 dp, n_src, check_done, 1, stride, 1);
     };
+    const bool fused = icp_fused_enabled();
+    auto fused_launch = [&](bool cold, int apply, int warm, float md2, int mode, int est) {
+        if (cold) hipLaunchKernelGGL(icp_fused_batch_kernel<kNnGroup>, dim3((unsigned)((q * kNnGroup + 255) / 256), nprob), dim3(256), 0, stream,
+                                     dp, src, n_src, stride, apply, warm, md2, mfma, mode, est, p.max_iterations, p.transformation_epsilon, p.euclidean_fitness_epsilon);
+        else hipLaunchKernelGGL(icp_fused_batch_kernel<kNnWarmGroup>, dim3((unsigned)((q * kNnWarmGroup + 255) / 256), nprob), dim3(256), 0, stream,
+                                dp, src, n_src, stride, apply, warm, md2, mfma, mode, est, p.max_iterations, p.transformation_epsilon, p.euclidean_fitness_epsilon);
+    };
     auto iteration = [&](bool cold) {
+        if (fused) { fused_launch(cold, cold ? -1 : 1, cold ? 0 : 1, maxd2, 0, p.estimator); return; }
         search(cold, 1);
         if (p.estimator == 1) {
             hipLaunchKernelGGL(plane_reduce_batch_kernel, dim3(rb, nprob), dim3(256), 0, stream, dp, stride, n_src, maxd2);
@@ -1467,11 +1599,16 @@ int icp_batch_run(IcpWorkspace *const *wss, int nprob, IcpWorkspace *ctl, hipStr
     }
     // fitness: the original source moved by each final transform, mean squared NN distance over all points (warm: the
     // last neighbour bounds the search)
-    hipLaunchKernelGGL(work_transform_batch_kernel, dim3(pb, nprob), dim3(256), 0, stream, dp, src, n_src, stride, 1);
-    hipLaunchKernelGGL(nn_search_batch_kernel<kNnWarmGroup>, dim3((unsigned)((q * kNnWarmGroup + 255) / 256), nprob), dim3(256), 0, stream,
-                       dp, n_src, 0, -1, stride, 1);
-    hipLaunchKernelGGL(corr_reduce_batch_kernel, dim3(rb, nprob), dim3(256), 0, stream, dp, src, stride, n_src, FLT_MAX, 0, mfma);
-    hipLaunchKernelGGL(icp_solve_batch_kernel, dim3(nprob), dim3(64), 0, stream, dp, rb, 2, 0, 0.0, 0.0);
+    if (fused) {
+        hipLaunchKernelGGL(work_transform_batch_kernel, dim3(pb, nprob), dim3(256), 0, stream, dp, src, n_src, stride, 1);
+        fused_launch(false, -1, 1, FLT_MAX, 2, 0);
+    } else {
+        hipLaunchKernelGGL(work_transform_batch_kernel, dim3(pb, nprob), dim3(256), 0, stream, dp, src, n_src, stride, 1);
+        hipLaunchKernelGGL(nn_search_batch_kernel<kNnWarmGroup>, dim3((unsigned)((q * kNnWarmGroup + 255) / 256), nprob), dim3(256), 0, stream,
+                           dp, n_src, 0, -1, stride, 1);
+        hipLaunchKernelGGL(corr_reduce_batch_kernel, dim3(rb, nprob), dim3(256), 0, stream, dp, src, stride, n_src, FLT_MAX, 0, mfma);
+        hipLaunchKernelGGL(icp_solve_batch_kernel, dim3(nprob), dim3(64), 0, stream, dp, rb, 2, 0, 0.0, 0.0);
+    }
     ICP_HIP(hipGetLastError());
     if ((rc = read_states())) return rc;
     for (int c = 0; c < nprob; ++c) {

@@ -10,8 +10,8 @@
 namespace scl {
 
 struct IcpWorkspace {
-    void *buf[16] = {nullptr};
-    size_t cap[16] = {0};
+    void *buf[20] = {nullptr};
+    size_t cap[20] = {0};
     void *pinned = nullptr;
     size_t pinned_cap = 0;
 };
