@@ -9,7 +9,10 @@
 //   becomes                    scanDescriptor = std::unique_ptr<scan_descriptor>(new lidar_iris_hip_descriptor(80, 360, N_SCAN, 0.4, ...));
 //
 // What differs from the reference's class, on purpose (scl_iris.h has the details):
-//   * compare() searches every column shift instead of the two five-shift windows around OpenCV's FFT estimate;
+//   * compare() follows the reference (FFT shift estimate, two five-shift Hamming windows, matchNum), but the estimate is OpenCV's
+//     algorithms restated, not OpenCV's binaries: an estimate within rounding of a whole column can fall on the other side and move
+//     a window by one column (parity unpinned).  shiftSearch = 1 searches every column shift instead -- then the distance is <= the
+//     reference's and distThres 0.32 accepts loops the reference would not: an opt-in, re-derive the threshold for it;
 //   * saveDescriptorAndKey decodes the wire vector with the reference's own indexing by default (wireDecode = 0,
 //     descriptor.h:1035 -- it shears the received image); wireDecode = 1 reads the layout makeAndSave emits.
 // Errors are written to stderr and mapped to "no loop" / empty results, as the reference only logs.
@@ -45,7 +48,8 @@ public:
         int thisID             = 0,
         int device             = 0,
         int wireDecode         = 0,
-        float knnExcludeEps    = FLT_EPSILON)
+        float knnExcludeEps    = FLT_EPSILON,
+        int shiftSearch        = 0)
     {
         scl_iris_config cfg;
         scl_iris_default_config(&cfg);
@@ -53,7 +57,7 @@ public:
         cfg.num_exclude_recent = numExcludeRecent; cfg.match_num = matchNum; cfg.num_candidates = numCandidates;
         cfg.nscale = nscale; cfg.min_wavelength = minWaveLength; cfg.mult = mult; cfg.sigma_onf = sigmaOnf;
         cfg.robot_num = robotNum; cfg.this_id = thisID; cfg.device = device; cfg.wire_decode = wireDecode;
-        cfg.knn_exclude_eps = knnExcludeEps;
+        cfg.knn_exclude_eps = knnExcludeEps; cfg.shift_search = shiftSearch;
         values_ = rows * cols + rows;
         const int rc = scl_iris_create(&cfg, &iris_);
         if (rc != SCL_OK) {

@@ -8,14 +8,16 @@
  * virtuals of the plugin (D.h:1026-1271: per-robot feature lists, local -> global index maps, intra- and inter-robot
  * detection).  The C++ adapter is include/scl/lidar_iris_hip_descriptor.hpp.
  *
- * NOT here: the shift estimate in front of the matching (logPolarFFTTemplateMatch, D.h:793-925 -- a chain of OpenCV
- * calls whose arithmetic cannot be restated bit for bit without OpenCV).  compare() (D.h:966-1022) evaluates the
- * Hamming distance in windows of five column shifts around that estimate (and around the estimate for the candidate
- * turned by half a revolution); the detection entry points here search EVERY column shift instead -- a superset of
- * both windows, so the distance is <= the reference's and equal to it whenever the reference's estimate is within two
- * columns of the best shift.  scl_iris_hamming takes an estimate from the caller for hosts that keep OpenCV's.
- * Parity: bit-identical to the CPU restatement under oracle/ (tests/test_gpu_iris.py); against the reference's binaries
- * the templates are unpinned (OpenCV's float FFT) -- see oracle/iris_oracle.h.
+ * The shift estimate in front of the matching (logPolarFFTTemplateMatch, D.h:793-925: forwardFFT, highpass, log-polar remap,
+ * two cv::phaseCorrelate, warpAffine) is restated from the algorithms OpenCV publishes -- direct DFTs with fp64 sums, the
+ * remaps in OpenCV's fixed point, the 5 x 5 weighted centroid -- and compare() (D.h:964-1024) evaluates the Hamming distance
+ * in the windows of five column shifts around it, for the candidate as it is and turned by 180 columns, as match_num says:
+ * the detections follow the reference's own procedure (scl_iris_fft_match, scl_iris_compare expose the steps).  What the
+ * restatement cannot reproduce is OpenCV's float rounding (its mixed-radix FFT, the packed spectra of phaseCorrelate's
+ * helpers): an estimate that OpenCV places within rounding of a whole number can fall on the other side here.
+ * cfg.shift_search = 1 searches every column shift instead (round 2's behaviour; an opt-in, see the field).
+ * Parity: bit-identical to the CPU restatement under oracle/ (tests/test_iris.py, tests/test_iris_fftmatch.py); against the
+ * reference's binaries templates and estimates are UNPINNED (no OpenCV in the image) -- see oracle/iris_oracle.h.
  * Conventions as in scl_engine.h (status codes, point clouds as pointer / count / stride, no CPU fallback).
  */
 #ifndef SCL_IRIS_H
@@ -44,8 +46,8 @@ typedef struct scl_iris_config {
     /* the plugin layer */
     double dist_thres;          /* 0.32: loop accepted below it (D.h:1140, 1245)            */
     int    num_exclude_recent;  /* 30:   newest keyframes of this robot kept out (D.h:1097)  */
-    int    match_num;           /* 2:    which windows compare() evaluates (D.h:968-1021); kept for the constructor's
-                                         signature -- the exhaustive shift search covers all three settings          */
+    int    match_num;           /* 2:    which passes compare() runs (D.h:968-1021): 2 both, 1 only the candidate turned by
+                                         180 columns, 0 only the first                                                */
     int    num_candidates;      /* 10:   row-key neighbours compared (D.h:1109)              */
     int    robot_num;           /* 1  */
     int    this_id;             /* 0  */
@@ -54,6 +56,12 @@ typedef struct scl_iris_config {
     int    wire_decode;         /* 0: saveDescriptorAndKey's own indexing iris[row*(cols+1)+col+1] (D.h:1030-1037: reads
                                       the image sheared by one more column per row, stays inside the buffer);
                                    1: the layout makeAndSaveDescriptorAndKey emits (row*cols+col, D.h:1067-1074)       */
+    int    shift_search;        /* 0 (default): compare() as the reference runs it (D.h:964-1024) -- the FFT shift estimate
+                                      logPolarFFTTemplateMatch (D.h:793-925), then the Hamming windows of five column shifts
+                                      around it, both passes as match_num says (even rows / cols);
+                                   1: EVERY column shift instead of the estimate + windows (an opt-in: the distance can only
+                                      be smaller than the reference's, so dist_thres 0.32 accepts loops the reference would
+                                      not; the returned shift is the first minimum over [0, cols)) */
 } scl_iris_config;
 
 int  scl_iris_default_config(scl_iris_config *cfg);
@@ -98,7 +106,14 @@ int  scl_iris_get_feature(scl_iris *h, int key, uint8_t *T, uint8_t *M);
 int  scl_iris_hamming(scl_iris *h, int key1, int key2, int scale, float *dis, int *bias);
 /* key1 against n candidates, each with its own shift estimate */
 int  scl_iris_hamming_batch(scl_iris *h, int key1, const int *cand, const int *scales, int n, float *dis, int *bias);
-/* every column shift 0 .. cols-1 (first minimum): stands in for estimate + window where no estimate is available */
+/* fftMatch(im0, im1) (D.h:927-932) with im0 = the image of key0 turned by roll0 columns (0, or 180 for compare()'s second pass)
+ * and im1 = the image of key1: *center_x = the RotatedRect's centre x as a float (compare() takes int(center_x - cols / 2) as its
+ * shift); *compatible (may be NULL) = 0 where the reference reports "Images are not compatible" (centre 0). */
+int  scl_iris_fft_match(scl_iris *h, int key0, int roll0, int key1, float *center_x, int *compatible);
+/* compare(key1, cand[i], &bias) for n candidates (D.h:964-1024, match_num as configured): distance (NaN where every window shift
+ * is fully masked) and shift */
+int  scl_iris_compare(scl_iris *h, int key1, const int *cand, int n, float *dis, int *bias);
+/* every column shift 0 .. cols-1 (first minimum): what cfg.shift_search = 1 uses */
 int  scl_iris_hamming_all_shifts(scl_iris *h, int key1, const int *cand, int n, float *dis, int *bias);
 
 #ifdef __cplusplus

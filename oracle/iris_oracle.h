@@ -7,7 +7,8 @@
  * they approximate (forward unscaled, inverse unscaled -- cv::idft without DFT_SCALE), cv::log / pow / exp on Mat1f as
  * float arithmetic.  PARITY UNPINNED against the reference's own binaries (OpenCV's float FFT rounds differently: a
  * template bit can differ where the filter response is within ~1e-3 relative of zero); the shift estimate
- * logPolarFFTTemplateMatch (D.h:793-925: cv::dft, remap, phaseCorrelate) is not restated at all.
+ * logPolarFFTTemplateMatch (D.h:793-925: cv::dft, remap, phaseCorrelate, warpAffine) is restated from the algorithms OpenCV
+ * publishes (iriso_fft_match), equally unpinned.
  */
 #ifndef IRIS_ORACLE_H
 #define IRIS_ORACLE_H
@@ -31,6 +32,15 @@ void iriso_responses(const iriso_config *c, const uint8_t *image, double *resp);
 void iriso_hamming(const iriso_config *c, const uint8_t *T1, const uint8_t *M1, const uint8_t *T2, const uint8_t *M2, int scale, float *dis, int *bias);
 /* every column shift 0 .. cols-1 (what the FFT estimate of D.h:793-925 narrows down): first minimum */
 void iriso_hamming_all(const iriso_config *c, const uint8_t *T1, const uint8_t *M1, const uint8_t *T2, const uint8_t *M2, float *dis, int *bias);
+
+/* fftMatch(im0, im1) = logPolarFFTTemplateMatch on copies (D.h:793-932), restated from OpenCV's published algorithms (see the
+ * .c file: PARITY UNPINNED): *center_x = the RotatedRect's centre x as a float; returns 1, 0 for "images are not compatible"
+ * (centre 0), -1 for sizes this restatement does not take (odd).  dbg (optional, 6 doubles): rotation_and_scale.x / .y, angle,
+ * scale, tr.x, tr.y */
+int iriso_fft_match(int rows, int cols, const uint8_t *im0, const uint8_t *im1, float *center_x, double *dbg);
+/* compare(img1, img2, &bias), D.h:964-1024: the Hamming windows of five shifts around the FFT estimate(s) */
+void iriso_compare(const iriso_config *c, int match_num, const uint8_t *img1, const uint8_t *T1, const uint8_t *M1,
+                   const uint8_t *img2, const uint8_t *T2, const uint8_t *M2, float *dis, int *bias, int *shifts_out);
 
 #ifdef __cplusplus
 }

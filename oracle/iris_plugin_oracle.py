@@ -7,8 +7,9 @@ C restatement of the building blocks (oracle/iris_oracle.c through tests/oracle_
 oracle/sc_oracle.c (sco_knn: exact search, libnabo's self-match rule behind exclude_eps).
 
 PARITY UNPINNED against the reference's binaries.  Where this restatement knowingly departs from them:
-  * compare() (D.h:966-1022) evaluates Hamming windows of five shifts around OpenCV's FFT estimate; here every column
-    shift is searched (iriso_hamming_all), a superset of those windows -- see include/scl_iris.h;
+  * compare() (D.h:964-1024) runs as the reference's does -- FFT estimate, Hamming windows of five shifts, both passes as
+    match_num says -- but the estimate (logPolarFFTTemplateMatch) is OpenCV's algorithms restated, not OpenCV's binaries
+    (oracle/iris_oracle.c: iriso_fft_match); shift_search=1 searches every column shift instead (iriso_hamming_all);
   * libnabo's kNN arithmetic is restated as the exact search in nanoflann's accumulation order (as for the ring keys).
 """
 import numpy as np
@@ -19,12 +20,13 @@ FLT_EPSILON = float(np.finfo(np.float32).eps)
 class IrisPluginOracle:
     def __init__(self, oi, ob, rows=80, cols=360, nscan=64, dist_thres=0.32, num_exclude_recent=30, match_num=2,
                  num_candidates=10, nscale=4, min_wavelength=18, mult=1.6, sigma_onf=0.75, robot_num=1, this_id=0,
-                 knn_exclude_eps=FLT_EPSILON, wire_decode=0):
+                 knn_exclude_eps=FLT_EPSILON, wire_decode=0, shift_search=0):
         self.oi, self.ob = oi, ob
         self.cfg = oi.config(rows, cols, nscan, nscale, min_wavelength, mult, sigma_onf)
         self.rows, self.cols = rows, cols
         self.dist_thres, self.num_exclude_recent, self.num_candidates = dist_thres, num_exclude_recent, num_candidates
         self.robot_num, self.this_id, self.eps, self.wire_decode = robot_num, this_id, knn_exclude_eps, wire_decode
+        self.match_num, self.shift_search = match_num, shift_search
         self.features = [[] for _ in range(robot_num)]          # irisFeatures, D.h:1289
         self.rowkeys = [[] for _ in range(robot_num)]           # irisFeatureRowKey, D.h:1290
         self.local2global = [[] for _ in range(robot_num)]      # D.h:1291
@@ -69,8 +71,11 @@ class IrisPluginOracle:
         for i in range(k):
             if idx[i] < 0 or idx[i] >= len(feats):
                 continue
-            _, T2, M2 = feats[idx[i]]
-            d, b = self.oi.hamming_all(self.cfg, cur_feat[1], cur_feat[2], T2, M2)
+            img2, T2, M2 = feats[idx[i]]
+            if self.shift_search == 1:
+                d, b = self.oi.hamming_all(self.cfg, cur_feat[1], cur_feat[2], T2, M2)
+            else:
+                d, b, _ = self.oi.compare(self.cfg, self.match_num, cur_feat[0], cur_feat[1], cur_feat[2], img2, T2, M2)   # D.h:1126
             if d < min_dis:                                                                     # NaN never wins
                 min_dis, min_pos, min_bias = np.float32(d), int(idx[i]), b
         return min_pos, float(min_dis), min_bias

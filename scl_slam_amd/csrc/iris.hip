@@ -127,19 +127,21 @@ __global__ void iris_unpack_kernel(const unsigned int *W, int N, int words, int 
 // one wave per (candidate, shift index); shift = shifts[job]
 __global__ __launch_bounds__(64) void iris_hamming_kernel(const unsigned int *T, const unsigned int *M, size_t feat_words /* per keyframe */,
                                                           int key1, const int *cand, const int *shifts, int shifts_per_cand,
-                                                          int N, int words, int trows, int *bits_diff, int *total_bits)
+                                                          int N, int words, int trows, int *bits_diff, int *total_bits, const int *rolls2)
 {
     const int job = blockIdx.x, c = job / shifts_per_cand;
     const int key2 = cand[c];
     int sh = shifts[job] % N; sh = sh < 0 ? sh + N : sh;
+    int r2 = rolls2 ? rolls2[c] % N : 0; r2 = r2 < 0 ? r2 + N : r2;           // the second keyframe turned: circShift(T2, 0, roll), D.h:976-977
     const unsigned int *T1 = T + (size_t)key1 * feat_words, *M1 = M + (size_t)key1 * feat_words;
     const unsigned int *T2 = T + (size_t)key2 * feat_words, *M2 = M + (size_t)key2 * feat_words;
     int diff = 0, masked = 0;
     for (int i = threadIdx.x; i < N * words; i += 64) {
         const int k = i / words, w = i - k * words;
         int src = k - sh; src = src < 0 ? src + N : src;                       // circColShift: dst(:, k) = src(:, k - shift), D.h:581-592
-        const unsigned int mask = M1[(size_t)src * words + w] | M2[(size_t)k * words + w];
-        const unsigned int x = (T1[(size_t)src * words + w] ^ T2[(size_t)k * words + w]) & ~mask;
+        int k2 = k - r2; k2 = k2 < 0 ? k2 + N : k2;
+        const unsigned int mask = M1[(size_t)src * words + w] | M2[(size_t)k2 * words + w];
+        const unsigned int x = (T1[(size_t)src * words + w] ^ T2[(size_t)k2 * words + w]) & ~mask;
         diff += __popc(x); masked += __popc(mask);
     }
 #pragma unroll
@@ -167,6 +169,146 @@ __global__ void iris_rowkey_d2_kernel(const float *rowkeys, int rows, int q, con
     d2[i] = result;
 }
 
+
+// ---- logPolarFFTTemplateMatch (D.h:793-925), the shift estimate in front of compare()'s Hamming windows -------------------------
+// Restated from the algorithms OpenCV publishes (oracle/iris_oracle.c: iriso_fft_match states every step; PARITY UNPINNED against
+// the reference's binaries).  Everything transcendental -- twiddles, the highpass, the log-polar map, the rotation matrix -- is
+// evaluated on the host with the C library the CPU restatement uses and shipped as tables; the device adds, multiplies, divides and
+// takes square roots, unfused, in the restatement's order: the two agree bit for bit.  J jobs (candidate, orientation) per launch.
+struct FftJob { int key0, roll0, key1; };                  // im0 = image of key0 turned by roll0 columns, im1 = image of key1
+
+// a[j][i] = (float)u8 * (float)(1 / 255)  (convertTo(CV_32FC1, 1.0 / 255.0), D.h:848-849)
+__global__ void fm_stage_kernel(const unsigned char *images, const FftJob *jobs, int R, int C, float *a0, float *a1)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    if (i >= R * C) return;
+    const FftJob jb = jobs[j];
+    const int r = i / C, c = i - r * C;
+    int s0 = (c - jb.roll0) % C; s0 = s0 < 0 ? s0 + C : s0;                    // circShift(img, 0, roll): dst(:, c) = src(:, c - roll)
+    const size_t n = (size_t)R * C;
+    a0[(size_t)j * n + i] = (float)images[(size_t)jb.key0 * n + (size_t)r * C + s0] * (float)(1.0 / 255.0);
+    a1[(size_t)j * n + i] = (float)images[(size_t)jb.key1 * n + i] * (float)(1.0 / 255.0);
+}
+
+__global__ void fm_to_complex_kernel(const float *src, double2 *dst, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[(size_t)blockIdx.y * n + i] = make_double2((double)src[(size_t)blockIdx.y * n + i], 0.0);
+}
+
+// out[l][k] = sum_m in[l][m] w^(k m): `lines` lines of n elements (element stride es, line stride ls); sgn -1 forward, +1 inverse.
+// One thread per output; consecutive threads run along the dimension that is contiguous in memory.
+__global__ __launch_bounds__(256) void fm_dft_lines_kernel(const double2 *in, double2 *out, int n, int es, int lines, int ls, int sgn,
+                                                           const double *wc, const double *ws, size_t job_stride)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * lines) return;
+    int k, l;
+    if (es == 1) { l = t / n; k = t - l * n; } else { k = t / lines; l = t - k * lines; }
+    const double2 *src = in + (size_t)blockIdx.y * job_stride + (size_t)l * ls;
+    double re = 0.0, im = 0.0;
+    int tw = 0;                                                                // (k * m) mod n
+    for (int m = 0; m < n; ++m) {
+        const double2 x = src[(size_t)m * es];
+        const double c = wc[tw], s = sgn < 0 ? -ws[tw] : ws[tw];
+        re = re + (x.x * c - x.y * s);
+        im = im + (x.x * s + x.y * c);
+        tw += k; tw = tw >= n ? tw - n : tw;
+    }
+    out[(size_t)blockIdx.y * job_stride + (size_t)l * ls + (size_t)k * es] = make_double2(re, im);
+}
+
+// recomb (quadrant swap), / (M N), magnitude on the float planes, highpass: f = |F| * h  (D.h:719-764, 856-872)
+__global__ void fm_mag_highpass_kernel(const double2 *F, const float *hp, int R, int C, float *f)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * C) return;
+    const int r = i / C, c = i - r * C;
+    const size_t n = (size_t)R * C;
+    const double2 v = F[(size_t)blockIdx.y * n + (size_t)((r + R / 2) % R) * C + (c + C / 2) % C];
+    const float mn = (float)(R * C);
+    const float re = (float)v.x / mn, im = (float)v.y / mn;
+    f[(size_t)blockIdx.y * n + i] = sqrtf(re * re + im * im) * hp[i];
+}
+
+__device__ __forceinline__ float fm_bilinear32(const float *src, int R, int C, int sx, int sy)
+{
+    const int ix = sx >> 5, iy = sy >> 5, fx = sx & 31, fy = sy & 31;
+    const float ax = (float)fx * (1.0f / 32.0f), ay = (float)fy * (1.0f / 32.0f);
+    const float w00 = (1.0f - ax) * (1.0f - ay), w01 = ax * (1.0f - ay), w10 = (1.0f - ax) * ay, w11 = ax * ay;
+    auto tap = [&](int yy, int xx) { return (yy >= 0 && yy < R && xx >= 0 && xx < C) ? src[(size_t)yy * C + xx] : 0.0f; };
+    return ((tap(iy, ix) * w00 + tap(iy, ix + 1) * w01) + tap(iy + 1, ix) * w10) + tap(iy + 1, ix + 1) * w11;
+}
+
+// cv::remap through the log-polar map (fixed-point source positions from the host)
+__global__ void fm_remap_kernel(const float *f, const int2 *map, int R, int C, float *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * C) return;
+    const size_t n = (size_t)R * C;
+    const int2 p = map[i];
+    out[(size_t)blockIdx.y * n + i] = fm_bilinear32(f + (size_t)blockIdx.y * n, R, C, p.x, p.y);
+}
+
+// F1 conj(F2) / (|F1 conj(F2)| + FLT_EPSILON)
+__global__ void fm_crosspower_kernel(const double2 *A, const double2 *B, double2 *out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double2 a = A[(size_t)blockIdx.y * n + i], b = B[(size_t)blockIdx.y * n + i];
+    const double pr = a.x * b.x + a.y * b.y, pi = a.y * b.x - a.x * b.y;
+    const double mag = sqrt(pr * pr + pi * pi) + (double)FLT_EPSILON;
+    out[(size_t)blockIdx.y * n + i] = make_double2(pr / mag, pi / mag);
+}
+
+// quadrant swap, first maximum in row-major order, 5 x 5 weighted centroid: one workgroup per job; out = (cols / 2 - cx, rows / 2 - cy)
+__global__ __launch_bounds__(256) void fm_peak_kernel(const double2 *Cr, int R, int C, double2 *out)
+{
+    const size_t n = (size_t)R * C;
+    const double2 *src = Cr + (size_t)blockIdx.x * n;
+    auto at = [&](int i, int j) { return (float)src[(size_t)((i + R / 2) % R) * C + (j + C / 2) % C].x; };
+    float best = -INFINITY; int bidx = 0x7fffffff;
+    for (int i = threadIdx.x; i < R * C; i += blockDim.x) {
+        const float v = at(i / C, i % C);
+        if (v > best) { best = v; bidx = i; }                                  // (ascending i per thread: the first maximum it meets)
+    }
+    __shared__ float sv[256]; __shared__ int si[256];
+    sv[threadIdx.x] = best; si[threadIdx.x] = bidx;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const float ov = sv[threadIdx.x + off]; const int oi = si[threadIdx.x + off];
+            if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) { sv[threadIdx.x] = ov; si[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    const int pr = si[0] == 0x7fffffff ? 0 : si[0] / C, pc = si[0] == 0x7fffffff ? 0 : si[0] % C;
+    int minr = pr - 2, maxr = pr + 2, minc = pc - 2, maxc = pc + 2;
+    minr = minr < 0 ? 0 : minr; minc = minc < 0 ? 0 : minc; maxr = maxr > R - 1 ? R - 1 : maxr; maxc = maxc > C - 1 ? C - 1 : maxc;
+    double sum = 0.0, cx = 0.0, cy = 0.0;
+    for (int y = minr; y <= maxr; ++y)
+        for (int x = minc; x <= maxc; ++x) {
+            const double v = (double)at(y, x);
+            cx += (double)x * v; cy += (double)y * v; sum += v;
+        }
+    cx /= sum; cy /= sum;
+    out[blockIdx.x] = make_double2((double)C / 2.0 - cx, (double)R / 2.0 - cy);
+}
+
+// cv::warpAffine with the inverted matrix in fixed point (AB_BITS 10, INTER_BITS 5): mats[j][6]
+__global__ void fm_warp_kernel(const float *src, const double *mats, int R, int C, float *dst)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * C) return;
+    const size_t n = (size_t)R * C;
+    const double *M = mats + (size_t)blockIdx.y * 6;
+    const int y = i / C, x = i - y * C;
+    const int X0 = __double2int_rn((M[1] * (double)y + M[2]) * 1024.0) + 16, Y0 = __double2int_rn((M[4] * (double)y + M[5]) * 1024.0) + 16;
+    const int X = (X0 + __double2int_rn(M[0] * (double)x * 1024.0)) >> 5, Y = (Y0 + __double2int_rn(M[3] * (double)x * 1024.0)) >> 5;
+    dst[(size_t)blockIdx.y * n + i] = fm_bilinear32(src + (size_t)blockIdx.y * n, R, C, X, Y);
+}
+
 }  // namespace
 
 struct scl_iris {
@@ -186,6 +328,13 @@ struct scl_iris {
     // the plugin layer (D.h:1289-1292): per robot the global keys of its keyframes in arrival order
     std::vector<std::vector<int>> local2global;
     int *d_list = nullptr; float *d_d2 = nullptr; size_t list_cap = 0;
+    // FFT shift estimate (logPolarFFTTemplateMatch): tables made at creation, work buffers for fm_cap jobs
+    double *d_wcR = nullptr, *d_wsR = nullptr, *d_wcC = nullptr, *d_wsC = nullptr; float *d_hp = nullptr; int2 *d_lpmap = nullptr; float log_base = 0.f;
+    bool fm_ok = false;                                        // even rows / cols (the restatement's quadrant swap)
+    size_t fm_cap = 0;
+    FftJob *d_fjobs = nullptr; float *d_fa0 = nullptr, *d_fa1 = nullptr, *d_ff = nullptr, *d_flp0 = nullptr, *d_flp1 = nullptr, *d_frs = nullptr;
+    double2 *d_fw0 = nullptr, *d_fw1 = nullptr, *d_fw2 = nullptr, *d_fres = nullptr; double *d_fmats = nullptr;
+    int *d_rolls = nullptr; size_t rolls_cap = 0;
 };
 
 namespace {
@@ -278,7 +427,7 @@ int append_locked(scl_iris *h, int8_t robot, int index)
     return SCL_OK;
 }
 
-int hamming_jobs_locked(scl_iris *h, int key1, const int *cand, const int *shifts, int n, int per, float *dis, int *bias, bool window)
+int hamming_jobs_locked(scl_iris *h, int key1, const int *cand, const int *shifts, int n, int per, float *dis, int *bias, bool window, const int *rolls2 = nullptr)
 {
     if (key1 < 0 || key1 >= h->n) return ifail(h, SCL_ERR_OUT_OF_RANGE, "key1 out of range");
     for (int i = 0; i < n; ++i) if (cand[i] < 0 || cand[i] >= h->n) return ifail(h, SCL_ERR_OUT_OF_RANGE, "candidate out of range");
@@ -292,9 +441,19 @@ int hamming_jobs_locked(scl_iris *h, int key1, const int *cand, const int *shift
     }
     IRIS_HIP(h, hipMemcpyAsync(h->d_cand, cand, sizeof(int) * n, hipMemcpyHostToDevice, h->stream));
     IRIS_HIP(h, hipMemcpyAsync(h->d_shifts, shifts, sizeof(int) * jobs, hipMemcpyHostToDevice, h->stream));
+    if (rolls2) {
+        if ((size_t)n > h->rolls_cap) {
+            if (h->d_rolls) (void)hipFree(h->d_rolls);
+            h->d_rolls = nullptr; h->rolls_cap = 0;
+            int rc = ialloc(h, &h->d_rolls, (size_t)n + 64);
+            if (rc) return rc;
+            h->rolls_cap = (size_t)n + 64;
+        }
+        IRIS_HIP(h, hipMemcpyAsync(h->d_rolls, rolls2, sizeof(int) * n, hipMemcpyHostToDevice, h->stream));
+    }
     const size_t fw = (size_t)h->cfg.cols * h->words;
     hipLaunchKernelGGL(iris_hamming_kernel, dim3((unsigned)jobs), dim3(64), 0, h->stream, h->d_T, h->d_M, fw, key1, h->d_cand, h->d_shifts, per,
-                       h->cfg.cols, h->words, h->trows, h->d_diff, h->d_total);
+                       h->cfg.cols, h->words, h->trows, h->d_diff, h->d_total, rolls2 ? h->d_rolls : (const int *)nullptr);
     IRIS_HIP(h, hipGetLastError());
     std::vector<int> diff(jobs), total(jobs);
     IRIS_HIP(h, hipMemcpyAsync(diff.data(), h->d_diff, sizeof(int) * jobs, hipMemcpyDeviceToHost, h->stream));
@@ -309,6 +468,130 @@ int hamming_jobs_locked(scl_iris *h, int key1, const int *cand, const int *shift
             if (cur < best || std::isnan(best)) { best = cur; b = shifts[job]; }
         }
         dis[c] = best; bias[c] = b;
+    }
+    return SCL_OK;
+}
+
+// fftMatch for J jobs: centre x of the RotatedRect as a float (D.h:927-932); ok[j] = 0 where the reference prints "Images are not
+// compatible" and returns an empty rectangle (centre 0).  Two round trips to the host: the rotation / scale of the log-polar stage
+// and the translation.
+int fft_match_jobs_locked(scl_iris *h, const FftJob *jobs, int J, float *center_x, int *ok_out)
+{
+    if (J <= 0) return SCL_OK;
+    if (!h->fm_ok) return ifail(h, SCL_ERR_UNSUPPORTED, "the FFT shift estimate takes even rows and columns only");
+    const int R = h->cfg.rows, C = h->cfg.cols;
+    const size_t n = (size_t)R * C;
+    if ((size_t)J > h->fm_cap) {
+        for (void **p : {(void **)&h->d_fjobs, (void **)&h->d_fa0, (void **)&h->d_fa1, (void **)&h->d_ff, (void **)&h->d_flp0, (void **)&h->d_flp1, (void **)&h->d_frs,
+                         (void **)&h->d_fw0, (void **)&h->d_fw1, (void **)&h->d_fw2, (void **)&h->d_fres, (void **)&h->d_fmats}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        h->fm_cap = 0;
+        const size_t cap = (size_t)J + 8;
+        int rc;
+        if ((rc = ialloc(h, &h->d_fjobs, cap)) || (rc = ialloc(h, &h->d_fa0, cap * n)) || (rc = ialloc(h, &h->d_fa1, cap * n)) || (rc = ialloc(h, &h->d_ff, cap * n)) ||
+            (rc = ialloc(h, &h->d_flp0, cap * n)) || (rc = ialloc(h, &h->d_flp1, cap * n)) || (rc = ialloc(h, &h->d_frs, cap * n)) || (rc = ialloc(h, &h->d_fw0, cap * n)) ||
+            (rc = ialloc(h, &h->d_fw1, cap * n)) || (rc = ialloc(h, &h->d_fw2, cap * n)) || (rc = ialloc(h, &h->d_fres, cap)) || (rc = ialloc(h, &h->d_fmats, cap * 6))) return rc;
+        h->fm_cap = cap;
+    }
+    hipStream_t st = h->stream;
+    const dim3 ge((unsigned)((n + 255) / 256), (unsigned)J), blk(256);
+    IRIS_HIP(h, hipMemcpyAsync(h->d_fjobs, jobs, sizeof(FftJob) * (size_t)J, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(fm_stage_kernel, ge, blk, 0, st, h->d_images, h->d_fjobs, R, C, h->d_fa0, h->d_fa1);
+    // 2-D DFT of a float image: rows, then columns; result in w_out, w_tmp as scratch
+    auto dft2 = [&](const float *src, double2 *w_out, double2 *w_tmp) {
+        hipLaunchKernelGGL(fm_to_complex_kernel, ge, blk, 0, st, src, w_tmp, (int)n);
+        hipLaunchKernelGGL(fm_dft_lines_kernel, ge, blk, 0, st, w_tmp, w_out, C, 1, R, C, -1, h->d_wcC, h->d_wsC, n);
+        hipLaunchKernelGGL(fm_dft_lines_kernel, ge, blk, 0, st, w_out, w_tmp, R, C, C, 1, -1, h->d_wcR, h->d_wsR, n);
+        (void)hipMemcpyAsync(w_out, w_tmp, sizeof(double2) * n * (size_t)J, hipMemcpyDeviceToDevice, st);
+    };
+    auto phase_correlate = [&](const float *s1, const float *s2) {             // -> d_fres[j] = (tx, ty)
+        dft2(s1, h->d_fw0, h->d_fw2);
+        dft2(s2, h->d_fw1, h->d_fw2);
+        hipLaunchKernelGGL(fm_crosspower_kernel, ge, blk, 0, st, h->d_fw0, h->d_fw1, h->d_fw2, (int)n);
+        hipLaunchKernelGGL(fm_dft_lines_kernel, ge, blk, 0, st, h->d_fw2, h->d_fw0, R, C, C, 1, +1, h->d_wcR, h->d_wsR, n);   // inverse: columns, then rows
+        hipLaunchKernelGGL(fm_dft_lines_kernel, ge, blk, 0, st, h->d_fw0, h->d_fw1, C, 1, R, C, +1, h->d_wcC, h->d_wsC, n);
+        hipLaunchKernelGGL(fm_peak_kernel, dim3((unsigned)J), blk, 0, st, h->d_fw1, R, C, h->d_fres);
+    };
+    auto logpolar = [&](const float *img, float *lp) {
+        dft2(img, h->d_fw0, h->d_fw1);
+        hipLaunchKernelGGL(fm_mag_highpass_kernel, ge, blk, 0, st, h->d_fw0, h->d_hp, R, C, h->d_ff);
+        hipLaunchKernelGGL(fm_remap_kernel, ge, blk, 0, st, h->d_ff, h->d_lpmap, R, C, lp);
+    };
+    logpolar(h->d_fa0, h->d_flp0);
+    logpolar(h->d_fa1, h->d_flp1);
+    phase_correlate(h->d_flp1, h->d_flp0);
+    IRIS_HIP(h, hipGetLastError());
+    std::vector<double2> res((size_t)J);
+    IRIS_HIP(h, hipMemcpyAsync(res.data(), h->d_fres, sizeof(double2) * (size_t)J, hipMemcpyDeviceToHost, st));
+    IRIS_HIP(h, hipStreamSynchronize(st));
+    // rotation and scale -> the inverted affine map of warpAffine (D.h:884-912; the expressions of iriso_fft_match)
+    std::vector<double> mats((size_t)J * 6);
+    std::vector<int> ok((size_t)J, 1);
+    for (int j = 0; j < J; ++j) {
+        const double rx = res[(size_t)j].x, ry = res[(size_t)j].y;
+        float angle = (float)(180.0 * ry / (double)R);
+        float scale = (float)std::pow((double)h->log_base, rx);
+        if (scale > 1.8f) {
+            angle = (float)(-180.0 * ry / (double)R);
+            scale = (float)(1.0 / std::pow((double)h->log_base, rx));
+            if (scale > 1.8f) ok[(size_t)j] = 0;
+        }
+        if (angle < -90.0f) angle += 180.0f; else if (angle > 90.0f) angle -= 180.0f;
+        const double ang = (double)angle * M_PI / 180.0, sc = 1.0 / (double)scale;
+        const double alpha = std::cos(ang) * sc, beta = std::sin(ang) * sc, pcx = (double)(float)(C / 2), pcy = (double)(float)(R / 2);
+        double M[6] = {alpha, beta, (1.0 - alpha) * pcx - beta * pcy, -beta, alpha, beta * pcx + (1.0 - alpha) * pcy};
+        double D = M[0] * M[4] - M[1] * M[3];
+        D = D != 0.0 ? 1.0 / D : 0.0;
+        const double A11 = M[4] * D, A22 = M[0] * D;
+        M[0] = A11; M[1] *= -D; M[3] *= -D; M[4] = A22;
+        const double b1 = -M[0] * M[2] - M[1] * M[5], b2 = -M[3] * M[2] - M[4] * M[5];
+        M[2] = b1; M[5] = b2;
+        for (int k = 0; k < 6; ++k) mats[(size_t)j * 6 + k] = M[k];
+    }
+    IRIS_HIP(h, hipMemcpyAsync(h->d_fmats, mats.data(), sizeof(double) * mats.size(), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(fm_warp_kernel, ge, blk, 0, st, h->d_fa1, h->d_fmats, R, C, h->d_frs);
+    phase_correlate(h->d_frs, h->d_fa0);
+    IRIS_HIP(h, hipGetLastError());
+    IRIS_HIP(h, hipMemcpyAsync(res.data(), h->d_fres, sizeof(double2) * (size_t)J, hipMemcpyDeviceToHost, st));
+    IRIS_HIP(h, hipStreamSynchronize(st));
+    for (int j = 0; j < J; ++j) {
+        center_x[j] = ok[(size_t)j] ? (float)(res[(size_t)j].x + (double)(C / 2)) : 0.0f;
+        if (ok_out) ok_out[j] = ok[(size_t)j];
+    }
+    return SCL_OK;
+}
+
+// compare(cur, candidate) for m candidates (D.h:964-1024): the FFT estimate(s), then the Hamming windows of five shifts around
+// them -- the first pass against the candidate as it is, the second against the candidate turned by 180 columns -- as match_num says
+int compare_jobs_locked(scl_iris *h, int cur, const int *cand, int m, float *dis, int *bias)
+{
+    const int mn = h->cfg.match_num, C = h->cfg.cols;
+    const bool first = mn == 2 || mn == 0, second = mn == 2 || mn == 1;
+    std::vector<FftJob> jobs;
+    for (int c = 0; c < m; ++c) {
+        if (first) jobs.push_back(FftJob{cand[c], 0, cur});
+        if (second) jobs.push_back(FftJob{cand[c], 180, cur});                     // circShift(img2.img, 0, 180), D.h:978
+    }
+    std::vector<float> cx(jobs.size());
+    int rc = fft_match_jobs_locked(h, jobs.data(), (int)jobs.size(), cx.data(), nullptr);
+    if (rc) return rc;
+    const int per = 5, J = (int)jobs.size();
+    std::vector<int> jc((size_t)J), jr((size_t)J), shifts((size_t)J * per), jb((size_t)J);
+    std::vector<float> jd((size_t)J);
+    for (int j = 0; j < J; ++j) {
+        jc[(size_t)j] = jobs[(size_t)j].key0; jr[(size_t)j] = jobs[(size_t)j].roll0;
+        const int est = (int)(cx[(size_t)j] - (float)(C / 2));                     // int = float - int, D.h:969 / 980
+        for (int t = 0; t < per; ++t) shifts[(size_t)j * per + t] = est - 2 + t;   // D.h:937
+    }
+    rc = hamming_jobs_locked(h, cur, jc.data(), shifts.data(), J, per, jd.data(), jb.data(), true, jr.data());
+    if (rc) return rc;
+    int j = 0;
+    for (int c = 0; c < m; ++c) {
+        float d1 = NAN, d2 = 0.0f; int b1 = -1, b2 = 0;
+        if (first) { d1 = jd[(size_t)j]; b1 = jb[(size_t)j]; ++j; }
+        if (second) { d2 = jd[(size_t)j]; b2 = jb[(size_t)j]; ++j; }
+        if (mn == 2) { if (d1 < d2) { dis[c] = d1; bias[c] = b1; } else { dis[c] = d2; bias[c] = (b2 + 180) % 360; } }   // D.h:986-997
+        else if (mn == 1) { dis[c] = d2; bias[c] = (b2 + 180) % 360; }
+        else { dis[c] = d1; bias[c] = b1; }
     }
     return SCL_OK;
 }
@@ -353,10 +636,17 @@ int detect_core_locked(scl_iris *h, int cur, const std::vector<int> &list, int *
     }
     if (pos.empty()) return SCL_OK;
     const int m = (int)pos.size(), N = h->cfg.cols;
-    std::vector<int> cand((size_t)m), shifts((size_t)m * N), bias((size_t)m);
+    std::vector<int> cand((size_t)m), bias((size_t)m);
     std::vector<float> dis((size_t)m);
-    for (int c = 0; c < m; ++c) { cand[(size_t)c] = list[(size_t)pos[(size_t)c]]; for (int j = 0; j < N; ++j) shifts[(size_t)c * N + j] = j; }
-    int rc = hamming_jobs_locked(h, cur, cand.data(), shifts.data(), m, N, dis.data(), bias.data(), false);
+    for (int c = 0; c < m; ++c) cand[(size_t)c] = list[(size_t)pos[(size_t)c]];
+    int rc;
+    if (h->cfg.shift_search == 1) {                                          // every column shift (a superset of compare()'s windows)
+        std::vector<int> shifts((size_t)m * N);
+        for (int c = 0; c < m; ++c) for (int j = 0; j < N; ++j) shifts[(size_t)c * N + j] = j;
+        rc = hamming_jobs_locked(h, cur, cand.data(), shifts.data(), m, N, dis.data(), bias.data(), false);
+    } else {
+        rc = compare_jobs_locked(h, cur, cand.data(), m, dis.data(), bias.data());   // compare(), D.h:964-1024
+    }
     if (rc) return rc;
     for (int c = 0; c < m; ++c)                                              // D.h:1112-1131: strict <, NaN never wins
         if (dis[(size_t)c] < *best_dis) { *best_dis = dis[(size_t)c]; *best_pos = pos[(size_t)c]; *best_bias = bias[(size_t)c]; }
@@ -372,7 +662,7 @@ int scl_iris_default_config(scl_iris_config *c)
     if (!c) return SCL_ERR_INVALID_ARG;
     c->rows = 80; c->cols = 360; c->nscan = 64; c->nscale = 4; c->min_wavelength = 18; c->mult = 1.6f; c->sigma_onf = 0.75f; c->device = 0;
     c->dist_thres = 0.32; c->num_exclude_recent = 30; c->match_num = 2; c->num_candidates = 10; c->robot_num = 1; c->this_id = 0;
-    c->knn_exclude_eps = FLT_EPSILON; c->wire_decode = 0;
+    c->knn_exclude_eps = FLT_EPSILON; c->wire_decode = 0; c->shift_search = 0;
     return SCL_OK;
 }
 
@@ -385,7 +675,8 @@ int scl_iris_create(const scl_iris_config *cfg, scl_iris **out)
     if (cfg->rows < 1 || cfg->rows > 512 || cfg->cols < 2 || cfg->cols > 2048 || cfg->nscale < 1 || cfg->nscale > 8 ||
         cfg->min_wavelength < 1 || !(cfg->mult > 0.f) || !(cfg->sigma_onf > 0.f) || cfg->sigma_onf == 1.0f ||
         cfg->robot_num < 1 || cfg->robot_num > 127 || cfg->this_id < 0 || cfg->this_id >= cfg->robot_num || cfg->num_candidates < 1 ||
-        cfg->num_candidates > 4096 || cfg->num_exclude_recent < 0 || cfg->match_num < 0 || cfg->match_num > 2 || !(cfg->knn_exclude_eps >= 0.0f))
+        cfg->num_candidates > 4096 || cfg->num_exclude_recent < 0 || cfg->match_num < 0 || cfg->match_num > 2 || !(cfg->knn_exclude_eps >= 0.0f) ||
+        cfg->shift_search < 0 || cfg->shift_search > 1)
         return SCL_ERR_INVALID_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SCL_ERR_NO_DEVICE;
@@ -437,6 +728,42 @@ int scl_iris_create(const scl_iris_config *cfg, scl_iris **out)
             }
         if (hipMemcpy(h->d_h, hh.data(), sizeof(double2) * hh.size(), hipMemcpyHostToDevice) != hipSuccess) return bail(SCL_ERR_HIP);
     }
+    // tables of the FFT shift estimate (logPolarFFTTemplateMatch, D.h:719-925): the expressions of oracle/iris_oracle.c's
+    // iriso_fft_match, evaluated here with the same C library -- twiddles, highpass, log-polar map in OpenCV's fixed point
+    h->fm_ok = !(cfg->rows & 1) && !(cfg->cols & 1) && cfg->rows >= 6 && cfg->cols >= 6;
+    if (h->fm_ok) {
+        const int R = cfg->rows, C = cfg->cols;
+        std::vector<double> wcR((size_t)R), wsR((size_t)R), wcC((size_t)C), wsC((size_t)C);
+        for (int k = 0; k < R; ++k) { wcR[(size_t)k] = std::cos(2.0 * M_PI * (double)k / (double)R); wsR[(size_t)k] = std::sin(2.0 * M_PI * (double)k / (double)R); }
+        for (int k = 0; k < C; ++k) { wcC[(size_t)k] = std::cos(2.0 * M_PI * (double)k / (double)C); wsC[(size_t)k] = std::sin(2.0 * M_PI * (double)k / (double)C); }
+        std::vector<float> a((size_t)R), b((size_t)C), hp(cells);
+        { const float step = (float)(M_PI / (double)R); float val = (float)(-M_PI * 0.5); for (int i = 0; i < R; ++i) { a[(size_t)i] = cosf(val); val += step; } }
+        { const float step = (float)(M_PI / (double)C); float val = (float)(-M_PI * 0.5); for (int j = 0; j < C; ++j) { b[(size_t)j] = cosf(val); val += step; } }
+        for (int i = 0; i < R; ++i)
+            for (int j = 0; j < C; ++j) { const float t = a[(size_t)i] * b[(size_t)j]; hp[(size_t)i * C + j] = (1.0f - t) * (2.0f - t); }
+        std::vector<int2> map(cells);
+        const float radii = (float)C, angles = (float)R, cxf = (float)(C / 2), cyf = (float)(R / 2);
+        const float ddx = (float)C - cxf, ddy = (float)R - cyf;
+        const float d = (float)std::sqrt((double)ddx * (double)ddx + (double)ddy * (double)ddy);
+        const float log_base = (float)std::pow(10.0, (double)(log10f(d) / radii));
+        const float d_theta = (float)(M_PI / (double)angles);
+        float theta = (float)(M_PI / 2.0);
+        for (int i = 0; i < R; ++i) {
+            for (int j = 0; j < C; ++j) {
+                const float radius = powf(log_base, (float)j);
+                const float x = radius * sinf(theta) + cxf, y = radius * cosf(theta) + cyf;
+                map[(size_t)i * C + j] = make_int2((int)lrint((double)x * 32.0), (int)lrint((double)y * 32.0));
+            }
+            theta += d_theta;
+        }
+        h->log_base = log_base;
+        if ((rc = ialloc(h, &h->d_wcR, (size_t)R)) || (rc = ialloc(h, &h->d_wsR, (size_t)R)) || (rc = ialloc(h, &h->d_wcC, (size_t)C)) || (rc = ialloc(h, &h->d_wsC, (size_t)C)) ||
+            (rc = ialloc(h, &h->d_hp, cells)) || (rc = ialloc(h, &h->d_lpmap, cells))) return bail(rc);
+        if (hipMemcpy(h->d_wcR, wcR.data(), sizeof(double) * R, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(h->d_wsR, wsR.data(), sizeof(double) * R, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(h->d_wcC, wcC.data(), sizeof(double) * C, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(h->d_wsC, wsC.data(), sizeof(double) * C, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(h->d_hp, hp.data(), sizeof(float) * cells, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(h->d_lpmap, map.data(), sizeof(int2) * cells, hipMemcpyHostToDevice) != hipSuccess)
+            return bail(SCL_ERR_HIP);
+    }
     *out = h;
     return SCL_OK;
 }
@@ -448,7 +775,9 @@ int scl_iris_destroy(scl_iris *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void *p : {(void *)h->d_images, (void *)h->d_rowkeys, (void *)h->d_T, (void *)h->d_M, (void *)h->d_h, (void *)h->d_cells, (void *)h->d_zmax,
                     (void *)h->d_points, (void *)h->d_img1, (void *)h->d_key1, (void *)h->d_unpack, (void *)h->d_cand, (void *)h->d_shifts,
-                    (void *)h->d_diff, (void *)h->d_total, (void *)h->d_list, (void *)h->d_d2})
+                    (void *)h->d_diff, (void *)h->d_total, (void *)h->d_list, (void *)h->d_d2, (void *)h->d_wcR, (void *)h->d_wsR, (void *)h->d_wcC, (void *)h->d_wsC,
+                    (void *)h->d_hp, (void *)h->d_lpmap, (void *)h->d_fjobs, (void *)h->d_fa0, (void *)h->d_fa1, (void *)h->d_ff, (void *)h->d_flp0, (void *)h->d_flp1,
+                    (void *)h->d_frs, (void *)h->d_fw0, (void *)h->d_fw1, (void *)h->d_fw2, (void *)h->d_fres, (void *)h->d_fmats, (void *)h->d_rolls})
         if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -643,6 +972,27 @@ int scl_iris_hamming_batch(scl_iris *h, int key1, const int *cand, const int *sc
 int scl_iris_hamming(scl_iris *h, int key1, int key2, int scale, float *dis, int *bias)
 {
     return scl_iris_hamming_batch(h, key1, &key2, &scale, 1, dis, bias);
+}
+
+int scl_iris_fft_match(scl_iris *h, int key0, int roll0, int key1, float *center_x, int *compatible)
+{
+    if (!h || !center_x) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    (void)hipSetDevice(h->device);
+    if (key0 < 0 || key0 >= h->n || key1 < 0 || key1 >= h->n) return ifail(h, SCL_ERR_OUT_OF_RANGE, "fft_match: key out of range");
+    const FftJob jb{key0, roll0, key1};
+    return fft_match_jobs_locked(h, &jb, 1, center_x, compatible);
+}
+
+int scl_iris_compare(scl_iris *h, int key1, const int *cand, int n, float *dis, int *bias)
+{
+    if (!h || (n > 0 && (!cand || !dis || !bias)) || n < 0) return SCL_ERR_INVALID_ARG;
+    if (n == 0) return SCL_OK;
+    std::lock_guard<std::mutex> lk(h->mu);
+    (void)hipSetDevice(h->device);
+    if (key1 < 0 || key1 >= h->n) return ifail(h, SCL_ERR_OUT_OF_RANGE, "compare: key1 out of range");
+    for (int i = 0; i < n; ++i) if (cand[i] < 0 || cand[i] >= h->n) return ifail(h, SCL_ERR_OUT_OF_RANGE, "compare: candidate out of range");
+    return compare_jobs_locked(h, key1, cand, n, dis, bias);
 }
 
 int scl_iris_hamming_all_shifts(scl_iris *h, int key1, const int *cand, int n, float *dis, int *bias)

@@ -12,7 +12,7 @@ class IrisConfig(ctypes.Structure):
     _fields_ = [("rows", c_int), ("cols", c_int), ("nscan", c_int), ("nscale", c_int), ("min_wavelength", c_int),
                 ("mult", c_float), ("sigma_onf", c_float), ("device", c_int),
                 ("dist_thres", c_double), ("num_exclude_recent", c_int), ("match_num", c_int), ("num_candidates", c_int),
-                ("robot_num", c_int), ("this_id", c_int), ("knn_exclude_eps", c_float), ("wire_decode", c_int)]
+                ("robot_num", c_int), ("this_id", c_int), ("knn_exclude_eps", c_float), ("wire_decode", c_int), ("shift_search", c_int)]
 
 
 _bound = None
@@ -44,6 +44,8 @@ def _lib():
         "scl_iris_hamming": (c_int, [P, c_int, c_int, c_int, fp, ip]),
         "scl_iris_hamming_batch": (c_int, [P, c_int, ip, ip, c_int, fp, ip]),
         "scl_iris_hamming_all_shifts": (c_int, [P, c_int, ip, c_int, fp, ip]),
+        "scl_iris_fft_match": (c_int, [P, c_int, c_int, c_int, fp, ip]),
+        "scl_iris_compare": (c_int, [P, c_int, ip, c_int, fp, ip]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name); fn.restype = res; fn.argtypes = args
@@ -57,14 +59,14 @@ class IrisEngine:
 
     def __init__(self, rows=80, cols=360, nscan=64, dist_thres=0.32, num_exclude_recent=30, match_num=2, num_candidates=10,
                  nscale=4, min_wavelength=18, mult=1.6, sigma_onf=0.75, robot_num=1, this_id=0, device=0,
-                 knn_exclude_eps=None, wire_decode=0):
+                 knn_exclude_eps=None, wire_decode=0, shift_search=0):
         self.L = _lib()
         cfg = IrisConfig()
         self._check_rc(self.L.scl_iris_default_config(byref(cfg)))
         cfg.rows, cfg.cols, cfg.nscan, cfg.nscale, cfg.min_wavelength = rows, cols, nscan, nscale, min_wavelength
         cfg.mult, cfg.sigma_onf, cfg.device = mult, sigma_onf, device
         cfg.dist_thres, cfg.num_exclude_recent, cfg.match_num, cfg.num_candidates = dist_thres, num_exclude_recent, match_num, num_candidates
-        cfg.robot_num, cfg.this_id, cfg.wire_decode = robot_num, this_id, wire_decode
+        cfg.robot_num, cfg.this_id, cfg.wire_decode, cfg.shift_search = robot_num, this_id, wire_decode, shift_search
         if knn_exclude_eps is not None:
             cfg.knn_exclude_eps = knn_exclude_eps
         self.cfg = cfg
@@ -179,4 +181,18 @@ class IrisEngine:
         d = np.empty(c.size, np.float32); b = np.empty(c.size, np.int32)
         self._check(self.L.scl_iris_hamming_all_shifts(self.h, key1, c.ctypes.data_as(POINTER(c_int)), c.size,
                                                        d.ctypes.data_as(POINTER(c_float)), b.ctypes.data_as(POINTER(c_int))), "scl_iris_hamming_all_shifts")
+        return d, b
+
+    def fft_match(self, key0, roll0, key1):
+        """fftMatch(image of key0 turned by roll0 columns, image of key1), descriptor.h:793-932: (centre x as float32, compatible)"""
+        cx, ok = c_float(), c_int()
+        self._check(self.L.scl_iris_fft_match(self.h, key0, roll0, key1, byref(cx), byref(ok)), "scl_iris_fft_match")
+        return np.float32(cx.value), bool(ok.value)
+
+    def compare(self, key1, cand):
+        """compare(key1, cand[i]) of descriptor.h:964-1024 (match_num as configured): distances and shifts"""
+        c = np.ascontiguousarray(cand, np.int32)
+        d = np.empty(c.size, np.float32); b = np.empty(c.size, np.int32)
+        self._check(self.L.scl_iris_compare(self.h, key1, c.ctypes.data_as(POINTER(c_int)), c.size,
+                                            d.ctypes.data_as(POINTER(c_float)), b.ctypes.data_as(POINTER(c_int))), "scl_iris_compare")
         return d, b

@@ -23,6 +23,9 @@ def _L():
     L.iriso_responses.argtypes = [POINTER(IrisoConfig), u8, POINTER(c_double)]
     L.iriso_hamming.argtypes = [POINTER(IrisoConfig), u8, u8, u8, u8, c_int, POINTER(c_float), POINTER(c_int)]
     L.iriso_hamming_all.argtypes = [POINTER(IrisoConfig), u8, u8, u8, u8, POINTER(c_float), POINTER(c_int)]
+    L.iriso_fft_match.restype = c_int
+    L.iriso_fft_match.argtypes = [c_int, c_int, u8, u8, POINTER(c_float), POINTER(c_double)]
+    L.iriso_compare.argtypes = [POINTER(IrisoConfig), c_int, u8, u8, u8, u8, u8, u8, POINTER(c_float), POINTER(c_int), POINTER(c_int)]
     return L
 
 
@@ -62,3 +65,20 @@ def hamming_all(cfg, T1, M1, T2, M2):
     d, b = c_float(), c_int()
     _L().iriso_hamming_all(byref(cfg), _p(T1), _p(M1), _p(T2), _p(M2), byref(d), byref(b))
     return d.value, b.value
+
+
+def fft_match(rows, cols, im0, im1):
+    """fftMatch(im0, im1): (centre x as float32, compatible, [rot_scale.x, .y, angle, scale, tr.x, tr.y])"""
+    a = np.ascontiguousarray(im0, np.uint8); b = np.ascontiguousarray(im1, np.uint8)
+    cx = c_float(); dbg = (c_double * 6)()
+    ok = _L().iriso_fft_match(rows, cols, _p(a), _p(b), byref(cx), dbg)
+    return np.float32(cx.value), ok, list(dbg)
+
+
+def compare(cfg, match_num, img1, T1, M1, img2, T2, M2):
+    """compare(img1, img2): (distance, bias, [first estimate, second estimate])"""
+    d, b = c_float(), c_int()
+    sh = (c_int * 2)()
+    arrs = [np.ascontiguousarray(x, np.uint8) for x in (img1, T1, M1, img2, T2, M2)]
+    _L().iriso_compare(byref(cfg), match_num, *[_p(x) for x in arrs], byref(d), byref(b), sh)
+    return d.value, b.value, [sh[0], sh[1]]

@@ -43,7 +43,10 @@ def test_plugin_restatement_finds_the_planted_revisit():
     # D.h:1092: too few keyframes behind the exclusion window -> no search
     assert po.detect_intra(10) == (-1, 0.0, 10000000.0)
     loop, bias, dis = po.detect_intra(12)
-    assert loop == 2 and dis < 0.32 and abs(bias - (360 - 41)) <= 1      # the revisit's columns sit 41 further: circShift(T1, 360 - 41) lines it up with keyframe 2
+    # the revisit's columns sit 41 further: circShift(T1, -41) lines it up with keyframe 2 -- compare() reports the window's own
+    # shift (bias1, which can be negative) or (bias2 + 180) % 360 (D.h:986-997): the same turn modulo 360
+    assert loop == 2 and dis < 0.32 and min((bias - (360 - 41)) % 360, (360 - 41 - bias) % 360) <= 1
+    dis_windows = dis
     loop13, _, dis13 = po.detect_intra(13)                                 # an unrelated place: candidates compared, none accepted
     assert loop13 == -1 and 0.32 <= dis13 < 1.0
     # a yaw-only revisit in image space (columns rolled, same row key): libnabo's self-match rule (d2 <= FLT_EPSILON) drops it
@@ -60,7 +63,13 @@ def test_plugin_restatement_finds_the_planted_revisit():
         if expect is None:
             assert loop != 2
         else:
-            assert (loop, bias, dis) == (2, 270.0, 0.0)                    # circShift(T of 12, 270) == T of 2
+            assert loop == 2 and bias % 360 == 270.0 and dis == 0.0          # circShift(T of 12, 270) == T of 2 (bias1 = -90 or (bias2 + 180) % 360 = 270)
+    # every column shift instead of compare()'s windows (shift_search = 1): the first minimum over [0, 360)
+    p3 = IrisPluginOracle(oi, ob, shift_search=1, **kw)
+    for k, s in enumerate(scans):
+        p3.make_and_save(s, 0, k)
+    loop, bias, dis3 = p3.detect_intra(12)
+    assert loop == 2 and abs(bias - (360 - 41)) <= 1 and dis3 <= dis_windows + 1e-7      # a superset of the windows: never larger
 
 
 def test_plugin_restatement_wire_and_inter_robot():
@@ -79,9 +88,9 @@ def test_plugin_restatement_wire_and_inter_robot():
     # with the emitted layout decoded as emitted, a received keyframe equals the sender's
     assert np.array_equal(po.features[1][3][0], sender.features[1][3][0]) and np.array_equal(po.features[1][3][1], sender.features[1][3][1])
     loop, bias, dis = po.detect_inter(9)                                   # received keyframe -> searched among this robot's
-    assert loop == 1 and dis < 0.32 and abs(bias - 23) <= 1
+    assert loop == 1 and dis < 0.32 and min((bias - 23) % 360, (23 - bias) % 360) <= 1
     loop, bias, dis = po.detect_inter(1)                                   # own keyframe -> searched among the other robots'
-    assert loop == 9 and dis < 0.32 and abs(bias - (360 - 23)) <= 1
+    assert loop == 9 and dis < 0.32 and min((bias - (360 - 23)) % 360, (360 - 23 - bias) % 360) <= 1
     # the reference's own decoder (D.h:1035) shears the image: row r starts r + 1 columns late; the last row ends in the row key
     pr = IrisPluginOracle(oi, ob, wire_decode=0, **kw)
     w = sender.make_and_save(remote[0], 1, 99)
