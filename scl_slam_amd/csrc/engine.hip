@@ -233,6 +233,12 @@ int ensure_sets(scl_engine *e, size_t n)
     int rc = ensure_pairs(e, stride * scl_engine::kScreenSets);
     if (rc) { e->set_stride = 0; return rc; }
     e->set_stride = stride;
+    // the shift masks follow the sets: the wide grid's exact pass reads them always, the 64 x 120 grid once a distance matrix has asked
+    if ((sc_screen_is_wide(db_view(e), e->SR) || e->d_smask) && e->smask_cap < stride * scl_engine::kScreenSets) {
+        dev_free(e->d_smask); e->d_smask = nullptr; e->smask_cap = 0;
+        if ((rc = dev_alloc(e, &e->d_smask, stride * scl_engine::kScreenSets))) { e->set_stride = 0; return rc; }
+        e->smask_cap = stride * scl_engine::kScreenSets;
+    }
     const size_t need = 2 * stride * sc_screen_scratch_floats(db_view(e), e->SR);   // floats: ring parts x passes x 16 shifts per pair of a launch; two launches' worth (a launch's finishing rides in the next launch)
     if (need > e->part_cap) {
         dev_free(e->d_part); e->part_cap = 0;
@@ -536,6 +542,7 @@ int scl_destroy(scl_engine *e)
     dev_free(e->d_dist); dev_free(e->d_shift); dev_free(e->d_cand); dev_free(e->d_ring_d2);
     dev_free(e->d_approx); dev_free(e->d_starts); dev_free(e->d_surv); dev_free(e->d_nsurv); dev_free(e->d_tmin); dev_free(e->d_part);
     dev_free(e->d_align_fallbacks);
+    dev_free(e->d_smask);
     if (e->d_mat_dist) (void)hipFree(e->d_mat_dist);
     if (e->d_mat_shift) (void)hipFree(e->d_mat_shift);
     if (e->h_mat) (void)hipHostFree(e->h_mat);
@@ -878,6 +885,8 @@ int scl_sc_distance_batch(scl_engine *e, int query, const int *cand, int n, doub
     return sync(e);
 }
 
+namespace { int matrix_screened_locked(scl_engine *e, const int *slots, int nq, int lo, int n, double *dist, int *shift); }
+
 /* The exact distance matrix (north_star: "the column-shifted SC distance matrix over the keyframe database"): rows = queries,
  * columns = keyframes lo .. hi-1, every entry the reference's distanceBtnScanContext (D.h:1538-1569) in fp64 with its shift.
  * Up to kMaxQueryBatch rows per launch of the wave program; a launch's results travel to the host (pinned halves, second
@@ -899,6 +908,8 @@ int scl_sc_distance_matrix(scl_engine *e, const int *queries, int nq, int lo, in
         if (q < 0 && !e->staged[-1 - q]) return fail(e, SCL_ERR_INVALID_ARG, "no staged query in that slot");
         slots[(size_t)i] = q >= 0 ? q : e->cap + (-1 - q);
     }
+    // the screened grids: alignment + screening of 16 rows at a time, then the exact evaluation of the shifts still open (sc_masked.hip)
+    if (e->screen && sc_masked_supported(db_view(e), e->SR) && !getenv("SCL_MATRIX_PLAIN")) return matrix_screened_locked(e, slots.data(), nq, lo, n, dist, shift);
     constexpr int RB = kMaxQueryBatch;                                     // rows per launch
     const size_t row = ((size_t)n + 63) & ~(size_t)63;
     if (e->mat_cap < row) {
@@ -973,6 +984,7 @@ int launch_screen_group(scl_engine *e, const ScreenGroup &cur, int phases = kScr
         sb.pair_stride = e->set_stride;
         sb.approx = e->d_approx; sb.starts = e->d_starts; sb.align_fallbacks = e->d_align_fallbacks; sb.ring_d2 = e->d_ring_d2;
         sb.survivors = nullptr; sb.n_surv = nullptr; sb.t_min = e->d_tmin;
+        sb.smask = e->d_smask;                              // (null until a caller of the masked exact kernel has asked for the masks)
         sb.part = e->d_part + (g.part_half ? e->part_cap / 2 : 0);
         sb.side = stream == e->stream ? e->stream_align : nullptr; sb.ev_fork = e->ev_afork; sb.ev_join = e->ev_ajoin;
         sb.k = e->cfg.num_candidates; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
@@ -1041,13 +1053,101 @@ int launch_survivor_pass_wide(scl_engine *e, const int *qslot, const int *lo, co
         sb.k = e->cfg.num_candidates; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
         SCL_HIP(e, launch_sc_select_batch(sb, stream));
         const int *sv[kWideExactBatch]; const int *ns[kWideExactBatch]; double *od[kWideExactBatch]; int *os[kWideExactBatch];
+        const int *st[kWideExactBatch]; const unsigned int *sm[kWideExactBatch];
         for (int j = 0; j < w; ++j) {
             const size_t set = (size_t)(set0 + g + j);
             sv[j] = e->d_surv + set * e->set_stride; ns[j] = e->d_nsurv + set;
             od[j] = e->d_dist + set * e->set_stride; os[j] = e->d_shift + set * e->set_stride;
+            st[j] = e->d_starts + set * e->set_stride; sm[j] = e->d_smask ? e->d_smask + set * e->set_stride : nullptr;
         }
-        SCL_HIP(e, launch_sc_distance_survivors_wide(db_view(e), w, qslot + g, lo + g, e->SR, sv, ns, od, os, out3 + g, e->num_cu, stream));
+        SCL_HIP(e, launch_sc_distance_survivors_wide(db_view(e), w, qslot + g, lo + g, e->SR, sv, ns, od, os, out3 + g, e->num_cu, stream,
+                                                     e->d_smask ? st : nullptr, e->d_smask ? sm : nullptr));
     }
+    return SCL_OK;
+}
+
+// The exact distance matrix on a screened grid.  Per group of up to `mb` rows (a screening launch's worth): alignment, screening
+// products and finishing -- which leaves, per pair, the first shift and the mask of the shifts within 2 eps of the pair's smallest
+// screened distance -- then sc_masked_kernel evaluates exactly those shifts in fp64.  Every entry is the reference's distance and
+// shift, bit for bit; the results of a group travel to the host while the next group runs.
+int matrix_screened_locked(scl_engine *e, const int *slots, int nq, int lo, int n, double *dist, int *shift)
+{
+    const int mb = sc_screen_max_batch(db_view(e), e->SR);
+    const bool wide = sc_screen_is_wide(db_view(e), e->SR);
+    const int v2_min = wide ? 2 : 4;                                        // smaller batches take the first form, which leaves no masks: padded
+    int rc = ensure_sets(e, (size_t)n);
+    if (rc) return rc;
+    const size_t need = e->set_stride * scl_engine::kScreenSets;
+    if (e->smask_cap < need) {
+        dev_free(e->d_smask); e->d_smask = nullptr; e->smask_cap = 0;
+        if ((rc = dev_alloc(e, &e->d_smask, need))) return rc;
+        e->smask_cap = need;
+    }
+    const size_t row = ((size_t)n + 63) & ~(size_t)63;
+    const int RB = kMaxScreenBatch;
+    if (e->mat_cap < row * (size_t)(RB / kMaxQueryBatch)) {                  // (the plain form sizes the halves for kMaxQueryBatch rows)
+        if (e->d_mat_dist) (void)hipFree(e->d_mat_dist);
+        if (e->d_mat_shift) (void)hipFree(e->d_mat_shift);
+        if (e->h_mat) (void)hipHostFree(e->h_mat);
+        e->d_mat_dist = nullptr; e->d_mat_shift = nullptr; e->h_mat = nullptr; e->mat_cap = 0;
+        const size_t cap_rows = (size_t)2 * RB;
+        if (hipMalloc((void **)&e->d_mat_dist, sizeof(double) * cap_rows * row) != hipSuccess ||
+            hipMalloc((void **)&e->d_mat_shift, sizeof(int) * cap_rows * row) != hipSuccess ||
+            hipHostMalloc(&e->h_mat, (sizeof(double) + sizeof(int)) * cap_rows * row, hipHostMallocDefault) != hipSuccess)
+            return fail(e, SCL_ERR_NOMEM, "distance matrix buffers");
+        e->mat_cap = row * (size_t)(RB / kMaxQueryBatch);
+        for (int h = 0; h < 2; ++h) {
+            if (!e->ev_mat_k[h]) SCL_HIP(e, hipEventCreateWithFlags(&e->ev_mat_k[h], hipEventDisableTiming));
+            if (!e->ev_mat_c[h]) SCL_HIP(e, hipEventCreateWithFlags(&e->ev_mat_c[h], hipEventDisableTiming));
+        }
+    }
+    const size_t cap = row;
+    double *h_dist = static_cast<double *>(e->h_mat);
+    int *h_shift = reinterpret_cast<int *>(h_dist + (size_t)2 * RB * cap);
+    const int groups = (nq + mb - 1) / mb;
+    auto deliver = [&](int g) -> int {
+        const int h = g & 1, r0 = g * mb, rows = nq - r0 < mb ? nq - r0 : mb;
+        SCL_HIP(e, hipEventSynchronize(e->ev_mat_c[h]));
+        for (int r = 0; r < rows; ++r) {
+            std::memcpy(dist + (size_t)(r0 + r) * n, h_dist + ((size_t)h * RB + r) * cap, sizeof(double) * (size_t)n);
+            std::memcpy(shift + (size_t)(r0 + r) * n, h_shift + ((size_t)h * RB + r) * cap, sizeof(int) * (size_t)n);
+        }
+        return SCL_OK;
+    };
+    for (int g = 0; g < groups; ++g) {
+        const int h = g & 1, r0 = g * mb, rows = nq - r0 < mb ? nq - r0 : mb;
+        if (g >= 2 && (rc = deliver(g - 2))) return rc;
+        int qs[kMaxScreenBatch], los[kMaxScreenBatch], ns[kMaxScreenBatch];
+        const int padded = rows < v2_min ? v2_min : rows;                   // (the padding rows repeat the last one; their results are dropped)
+        for (int j = 0; j < padded; ++j) { qs[j] = slots[r0 + (j < rows ? j : rows - 1)]; los[j] = lo; ns[j] = n; }
+        {
+            ProfScope ps(e, P_SC);
+            ScreenGroup grp{qs, los, ns, padded, 0};
+            const int prof_saved = e->prof_on;
+            e->prof_on = 0;                                                  // (one event pair around the whole group: this scope's)
+            rc = launch_screen_group(e, grp);
+            e->prof_on = prof_saved;
+            if (rc) return rc;
+            MaskedQuery mq[kMaxMaskedQueries];
+            for (int j = 0; j < rows; ++j) {
+                mq[j].qslot = qs[j]; mq[j].slot_base = lo; mq[j].n = n; mq[j].n_dev = nullptr; mq[j].cand = nullptr;
+                mq[j].starts = e->d_starts + (size_t)j * e->set_stride; mq[j].smask = e->d_smask + (size_t)j * e->set_stride;
+                mq[j].out_dist = e->d_mat_dist + ((size_t)h * RB + j) * cap; mq[j].out_shift = e->d_mat_shift + ((size_t)h * RB + j) * cap;
+            }
+            int parts = 2 * e->num_cu / rows; parts = parts < 1 ? 1 : parts;
+            const int max_parts = (n + 7) / 8; parts = parts > max_parts ? max_parts : parts;
+            SCL_HIP(e, launch_sc_masked(db_view(e), e->SR, mq, rows, parts, e->stream));
+            if (ps.active()) e->prof.sc_distance_pairs += (uint64_t)rows * (uint64_t)n;
+        }
+        SCL_HIP(e, hipEventRecord(e->ev_mat_k[h], e->stream));
+        SCL_HIP(e, hipStreamWaitEvent(e->stream2, e->ev_mat_k[h], 0));
+        SCL_HIP(e, hipMemcpyAsync(h_dist + (size_t)h * RB * cap, e->d_mat_dist + (size_t)h * RB * cap, sizeof(double) * (size_t)rows * cap, hipMemcpyDeviceToHost, e->stream2));
+        SCL_HIP(e, hipMemcpyAsync(h_shift + (size_t)h * RB * cap, e->d_mat_shift + (size_t)h * RB * cap, sizeof(int) * (size_t)rows * cap, hipMemcpyDeviceToHost, e->stream2));
+        SCL_HIP(e, hipEventRecord(e->ev_mat_c[h], e->stream2));
+    }
+    for (int g = groups >= 2 ? groups - 2 : 0; g < groups; ++g)
+        if ((rc = deliver(g))) return rc;
+    if (e->prof_on) collect_profile(e);
     return SCL_OK;
 }
 

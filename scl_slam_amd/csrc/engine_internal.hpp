@@ -73,6 +73,7 @@ struct scl_engine {
     // every chunk end for the exact pass of the chunk before, whose buffers the next alignment writes; 256 measured no better)
     static constexpr int kScreenSets = 128;
     float *d_approx = nullptr; int *d_starts = nullptr; int *d_surv = nullptr;
+    unsigned int *d_smask = nullptr; size_t smask_cap = 0;  // per pair the shifts still open after the screening (sc_masked.hip); allocated on first use
     float *d_part = nullptr; size_t part_cap = 0;       // partial sums of the screening products' second form (one launch at a time)
     int *d_nsurv = nullptr; unsigned int *d_tmin = nullptr;
     unsigned long long *d_align_fallbacks = nullptr; uint64_t align_pairs = 0;   // statistics of the alignment kernel (scl_alignment_stats)

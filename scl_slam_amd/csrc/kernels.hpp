@@ -106,6 +106,19 @@ hipError_t launch_sc_distance_batch(const struct DbView &db, const QueryBatch &q
 // program score all rows in one launch (a row's workgroups take over CUs as the previous row's retire), the others row by row.
 hipError_t launch_sc_distance_matrix(const struct DbView &db, const int *slots, int nq, int base, int n, int SR,
                                      double *out_dist, int *out_shift, size_t row_stride, int num_cu, hipStream_t stream);
+// ---- exact distances at the shifts the screening leaves open (sc_masked.hip) ------------------------------------------------------
+// Query i: keyframe qslot against the items of its list -- cand[item] (database slots, ascending) or, cand == nullptr, the range
+// slot_base + item -- n of them (n_dev != nullptr: counted on the device).  starts / smask are indexed by the slot's position in the
+// scan's range (slot - slot_base): the first searched shift and the bit mask of the shifts still open (bit t: shift (first + t) mod S).
+// out_dist / out_shift are indexed by item.  parts: workgroups per query (each takes every parts-th group of 8 items).
+constexpr int kMaxMaskedQueries = 16;
+struct MaskedQuery {
+    int qslot, slot_base, n; const int *n_dev; const int *cand; const int *starts; const unsigned int *smask;
+    double *out_dist; int *out_shift;
+};
+struct MaskedArgs { const float4 *desc; const double *norm; int nq, parts; MaskedQuery q[kMaxMaskedQueries]; };
+bool sc_masked_supported(const struct DbView &db, int SR);
+hipError_t launch_sc_masked(const struct DbView &db, int SR, const MaskedQuery *queries, int nq, int parts, hipStream_t stream);
 // ---- screening pass of the full-DB mode (sc_screen.hip; 64x120 grid) --------------------------------------------
 // Per query i: every keyframe of [base, base+n) gets approx[i*pair_stride + pos] = its reference distance within
 // +- sc_screen_eps() (fp16 matrix-core evaluation of the reference's own 13 shifts; -inf = must be scored exactly),
@@ -123,6 +136,8 @@ struct ScreenBatch {
     int *starts;                                // first shifts (alignment kernel -> screening kernel), like approx
     unsigned long long *align_fallbacks;        // optional counter: keyframes aligned by the exact evaluation
     unsigned long long *surv_stats;             // optional (select launch): [0] += survivors, [1] = max(survivors), [2] += 1 per query
+    unsigned int *smask;                        // optional, like approx: per pair the shifts whose screened distance is within 2 eps of the pair's smallest
+                                                // (bit t: shift (first + t) mod S; every shift for a pair the screening cannot bound): sc_masked.hip's input
     int k; float exclude_eps; int *topk_idx; float *topk_d2;
     hipStream_t side; hipEvent_t ev_fork, ev_join;   // second form: stream and events for the next batch's alignment beside the products (nullptr: in line)
     float *part;                                // scratch of the second form of the 64 x 120 products: nq * pair_stride * 32 floats (nullptr: first form)
@@ -177,7 +192,8 @@ hipError_t launch_sc_distance_survivors(const struct DbView &db, const SurvivorP
                                         int phases = kSurvivorArgs | kSurvivorKernel);
 hipError_t launch_sc_distance_survivors_wide(const struct DbView &db, int nq, const int *query_slot, const int *slot_base, int SR,
                                              const int *const *survivors, const int *const *n_surv, double *const *out_dist, int *const *out_shift,
-                                             double *const *out3, int num_cu, hipStream_t stream);
+                                             double *const *out3, int num_cu, hipStream_t stream,
+                                             const int *const *starts = nullptr, const unsigned int *const *smask = nullptr);
 int sc_align_filter_enabled();
 
 // out_ring_d2 (optional): also write the squared ring-key distance (nanoflann metric) of every scored

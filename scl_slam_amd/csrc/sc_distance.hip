@@ -1518,12 +1518,31 @@ hipError_t launch_sc_distance_survivors(const DbView &db, const SurvivorPass &sp
 // (blockIdx.y = query, the survivor counts stay on the device) and ONE arg-min launch; winners to out3[i].
 hipError_t launch_sc_distance_survivors_wide(const DbView &db, int nq, const int *query_slot, const int *slot_base, int SR,
                                              const int *const *survivors, const int *const *n_surv, double *const *out_dist, int *const *out_shift,
-                                             double *const *out3, int num_cu, hipStream_t stream)
+                                             double *const *out3, int num_cu, hipStream_t stream, const int *const *starts, const unsigned int *const *smask)
 {
     if (!(db.RG == 20 && db.S == 180 && SR == 9) || nq < 1 || nq > kWideExactBatch) return hipErrorInvalidValue;
     constexpr int RG = 20, W = 19, MAXT = 256;
     ScArgsBatch ab{};
     ArgminBatch mb{};
+    // The wave program of this grid (sc_masked.hip): every survivor's exact distance at the shifts its screening left open, the
+    // first shift taken from the screening's alignment -- instead of the one-sector-per-lane program below, whose workgroups each
+    // staged 126 KB of fp64 scan and re-aligned every pair (SCL_WIDE_EXACT=0 keeps it)
+    static const bool use_masked = [] { const char *e = getenv("SCL_WIDE_EXACT"); return !(e && e[0] == '0'); }();
+    if (use_masked && starts && smask && sc_masked_supported(db, SR)) {
+        MaskedQuery mq[kMaxMaskedQueries];
+        static_assert(kWideExactBatch <= kMaxMaskedQueries, "one masked launch per exact batch");
+        for (int i = 0; i < nq; ++i) {
+            mq[i].qslot = query_slot[i]; mq[i].slot_base = slot_base[i]; mq[i].n = 0; mq[i].n_dev = n_surv[i]; mq[i].cand = survivors[i];
+            mq[i].starts = starts[i]; mq[i].smask = smask[i]; mq[i].out_dist = out_dist[i]; mq[i].out_shift = out_shift[i];
+            mb.dist[i] = out_dist[i]; mb.shift[i] = out_shift[i]; mb.n_dev[i] = n_surv[i]; mb.cand[i] = survivors[i];
+            mb.slot_base[i] = slot_base[i]; mb.out3[i] = out3[i];
+        }
+        for (int i = nq; i < kWideExactBatch; ++i) { mb.dist[i] = mb.dist[0]; mb.shift[i] = mb.shift[0]; mb.n_dev[i] = mb.n_dev[0]; mb.cand[i] = mb.cand[0]; mb.slot_base[i] = mb.slot_base[0]; mb.out3[i] = mb.out3[0]; }
+        hipError_t e = launch_sc_masked(db, SR, mq, nq, 4, stream);           // four workgroups per scan: 32 survivors at once, more loop
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(argmin_survivors_batch_kernel, dim3(nq), dim3(1024), 0, stream, mb);
+        return hipGetLastError();
+    }
     for (int i = 0; i < kWideExactBatch; ++i) {
         const int j = i < nq ? i : 0;
         ScArgs &a = ab.q[i];

@@ -65,6 +65,7 @@ struct ScreenArgs {
     unsigned long long *fallbacks;   // keyframes whose first shift the filter could not decide (statistics; may be null)
     float *out_approx;        // [n] d~ ; -inf = must be scored exactly, +inf = no finite distance
     float *out_d2;            // [n] squared ring-key distance (nanoflann's metric), for the top-k
+    unsigned int *out_smask;  // [n] optional: the shifts of the pair that can still hold its minimum (second form's finishing)
     unsigned int *t_min;      // ordered image of min d~ over the screened keyframes (atomicMin; re-armed by the exact pass)
     int align_filter;
 };
@@ -74,7 +75,7 @@ struct ScreenArgs {
 struct ScreenQuery { int slot, base, n, buf; };
 struct ScreenBatchArgs {
     const double *vkey; const float *rkey; const uint2 *hdesc; const unsigned int *kmask; const float4 *rkey4; const unsigned short *hkey;
-    int *starts; float *approx; float *ring_d2; unsigned int *t_min; unsigned long long *fallbacks;
+    int *starts; float *approx; float *ring_d2; unsigned int *t_min; unsigned long long *fallbacks; unsigned int *smask;
     unsigned long long pair_stride;
     int S, R4, hstride, rk_cap, align_filter, hkw;
     int nq, nb;
@@ -93,7 +94,7 @@ __device__ __forceinline__ ScreenArgs screen_args_of(const ScreenBatchArgs &ab, 
     a.rkey4 = ab.rkey4; a.rk_cap = ab.rk_cap;
     a.slot_base = sq.base; a.n = sq.n;
     a.starts = ab.starts + off; a.fallbacks = ab.fallbacks;
-    a.out_approx = ab.approx + off; a.out_d2 = ab.ring_d2 + off;
+    a.out_approx = ab.approx + off; a.out_d2 = ab.ring_d2 + off; a.out_smask = ab.smask ? ab.smask + off : nullptr;
     a.t_min = ab.t_min + sq.buf; a.align_filter = ab.align_filter;
     return a;
 }
@@ -980,6 +981,7 @@ __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const 
             const bool mine = lane < kGroup && ci_n < a.n;
             const bool exact_only = q_bad || kflag != 0 || b_open || !(dmin == dmin);
             if (mine) a.out_approx[ci_n] = exact_only ? __int_as_float(0xff800000) : dmin;
+            if (mine && a.out_smask) a.out_smask[ci_n] = b_open ? 0u : (W >= 32 ? 0xffffffffu : ((1u << W) - 1u));   // (this form keeps no per-shift record: every shift stays open)
             float contrib = (mine && !exact_only) ? dmin : __int_as_float(0x7f800000);
 #pragma unroll
             for (int off = 8; off > 0; off >>= 1) contrib = fminf(contrib, __shfl_xor(contrib, off, kWave));
@@ -1459,6 +1461,9 @@ __device__ __forceinline__ float sc_screen2_finish_pair(const Screen2Args &fa, c
     const int b0 = b_open ? 0 : b_raw;
     const f4v *pp = reinterpret_cast<const f4v *>(fa.part + ((size_t)qi * (size_t)ab.pair_stride + (size_t)ci) * (NP * NPASS * 16));
     float dmin = kInf;
+    float dsh[W];                                                            // the screened distance of every shift (+inf: no effective sector)
+#pragma unroll
+    for (int t = 0; t < W; ++t) dsh[t] = kInf;
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
 #pragma unroll
@@ -1480,11 +1485,21 @@ __device__ __forceinline__ float sc_screen2_finish_pair(const Screen2Args &fa, c
                 }
                 const float d = 1.0f - sm[r] / (float)ne;
                 if (ne > 0 && d < dmin) dmin = d;
+                dsh[t] = ne > 0 ? d : kInf;
             }
         }
     }
     const bool exact_only = q_bad || kflag != 0 || b_open || !(dmin == dmin);
     a.out_approx[ci] = exact_only ? __int_as_float(0xff800000) : dmin;
+    if (a.out_smask) {
+        // a shift can hold (or tie for) the pair's exact minimum only if its screened distance is within 2 eps of the smallest
+        // (NaN sums compare false everywhere: such a pair is exact_only); an undecided alignment has no first shift: mask 0
+        unsigned int m = 0u;
+        const float lim = dmin + 2.0f * kScreenEps;
+#pragma unroll
+        for (int t = 0; t < W; ++t) m |= ((exact_only || dsh[t] <= lim) ? 1u : 0u) << t;
+        a.out_smask[ci] = b_open ? 0u : m;
+    }
     // nanoflann's metric (nanoflann.hpp:383-408) for the ring-key top-k: four dimensions per step, fp32, groups accumulated in
     // order -- the arithmetic of sc_align_role, here with consecutive threads on consecutive slots of the tiled key table
     const int slot = a.slot_base + ci;
@@ -1610,7 +1625,7 @@ size_t sc_screen_scratch_floats(const DbView &db, int SR)
 static int fill_screen_args(const DbView &db, const ScreenBatch &sb, int align_filter, ScreenBatchArgs *ab)
 {
     ab->vkey = db.vkey; ab->rkey = db.rkey; ab->hdesc = db.hdesc; ab->kmask = db.kmask; ab->rkey4 = db.rkey4; ab->hkey = db.hkey; ab->hkw = hkey_row_halfs(db.S);
-    ab->starts = sb.starts; ab->approx = sb.approx; ab->ring_d2 = sb.ring_d2; ab->t_min = sb.t_min; ab->fallbacks = sb.align_fallbacks;
+    ab->starts = sb.starts; ab->approx = sb.approx; ab->ring_d2 = sb.ring_d2; ab->t_min = sb.t_min; ab->fallbacks = sb.align_fallbacks; ab->smask = sb.smask;
     ab->pair_stride = (unsigned long long)sb.pair_stride;
     ab->S = db.S; ab->R4 = 4 * db.RG; ab->hstride = db.hstride; ab->rk_cap = db.cap; ab->align_filter = align_filter;
     ab->nq = sb.nq;

@@ -16,7 +16,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" 
   timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -o pmc -- python3 bench.py --steps 16 --warmup 2 --repeats 1 --no-cpu-baseline --no-secondary > $OUT/p$i.json 2> $OUT/p$i.err || echo "pmc group $i failed: $grp" >> $OUT/progress.txt
   echo "pmc $i done" >> $OUT/progress.txt
 done
-python3 profiles/summarize_pmc.py $OUT $OUT/pmc_summary.json ${K1_FILTER:-sc_screen2_kernel,sc_screen2_tail_kernel} > /dev/null
+python3 profiles/summarize_pmc.py $OUT $OUT/pmc_summary.json ${K1_FILTER:-sc_screen2_kernel,sc_screen2_tail2_kernel} > /dev/null
 python3 scripts/summarize_kernel_stats.py $(find $OUT/trace -name "*kernel_stats.csv" | head -1) > $OUT/kernel_stats_short.txt
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 python3 bench.py --steps $STEPS --warmup 2 --no-secondary > $OUT/bench.json 2> $OUT/bench.err

@@ -45,6 +45,43 @@ def test_distance_batch_matches_oracle(R, S, n):
     eng.close()
 
 
+def test_distance_matrix_on_adversarial_descriptors():
+    """The screened form of the matrix (64x120, 80x180: alignment + screening, then the exact evaluation of the shifts the
+    screening leaves open, sc_masked.hip) on what the screening cannot bound or barely separates: exact copies and near copies
+    (ties between shifts and between keyframes), flat sector keys (alignment ties), empty / half-empty / single-cell descriptors,
+    tiny and huge values, inf and NaN.  Every entry must be the checker's, bit for bit."""
+    for R, S, n in ((64, 120, 420), (80, 180, 90)):
+        rs = np.random.RandomState(R)
+        descs = synth_descriptors(n, R, S, seed=900 + R, revisit_frac=0.05)
+        base = descs[n - 1].copy()
+        for i, mag in enumerate([0.0, 1e-7, 1e-5, 1e-3, 1e-2]):
+            d = np.roll(base, int(rs.randint(0, S)), axis=1)
+            descs[10 + 3 * i] = np.clip(d + mag * rs.standard_normal(d.shape).astype(np.float32) * (d > 0), 0, None)
+        descs[30] = 0.0
+        descs[31][:, ::2] = 0.0
+        descs[32] = base * np.float32(1e-30)
+        descs[33] = base * np.float32(1e25)
+        descs[34] = base * np.float32(1e-38)
+        descs[35][3, 5] = np.inf
+        descs[36][0, 0] = np.nan
+        descs[37][:] = 0.0; descs[37][R // 4, S // 3] = 3.5
+        descs[38][:] = 1.0                                                # constant: every shift ties
+        descs[39] = np.tile(base[:, :S // 4], (1, 4))                    # periodic in the sectors: alignment and shifts tie
+        descs[40] = descs[39]
+        eng = ScanContextEngine(num_ring=R, num_sector=S, initial_capacity=64)
+        eng.save_bulk(descs)
+        db = ob.OracleDB(ob.make_config(R=R, S=S)); db.save_bulk(descs)
+        qs = np.array([n - 1, 30, 31, 33, 35, 36, 37, 38, 39, 10, 13, 16, 19, 22, 5, n - 2, n - 3], dtype=np.int32)   # 17 rows: two screening groups
+        d, s = eng.sc_distance_matrix(qs, 0, n)
+        for r, q in enumerate(qs):
+            d_cpu, s_cpu = db.distance_batch(int(q), n=n, fast=True)
+            assert_same(d[r], s[r], d_cpu, s_cpu)
+        d1, s1 = eng.sc_distance_matrix(qs[:1], 3, n - 5)                # one row (padded to a screening batch), a sub-range
+        d_cpu, s_cpu = db.distance_batch(int(qs[0]), cand=np.arange(3, n - 5, dtype=np.int32), fast=True)
+        assert_same(d1[0], s1[0], d_cpu, s_cpu)
+        eng.close(); db.close()
+
+
 @pytest.mark.parametrize("R,S,n", [(20, 60, 300), (64, 120, 700), (80, 180, 60), (22, 50, 40)])
 def test_distance_matrix_matches_oracle(R, S, n):
     """scl_sc_distance_matrix -- north_star's distance matrix: every (scan, keyframe) entry the exact fp64 evaluation.  Rows of
