@@ -47,10 +47,11 @@ N_EXCLUDE = 100                    # NUM_EXCLUDE_RECENT, descriptor.h:1314
 ALGO_BYTES_PER_PAIR = R * S * 4 + S * 4 + S * 4      # 31 680 B at 64x120 (fp32 descriptor + fp64 sector key)
 # What the screening launch group (products in their second form + the tail launch: finishing beside the next batch's alignment) reads per
 # KEYFRAME by design, once per launch whatever the number of scans: the chunk-major fp16 image of the
-# descriptor (2 halves x 4 chunks x (S + 16) sectors x 16 B = 17 408 B at 64x120: 13 % padding so that no fragment wraps), the unit
-# fp16 sector key + its norm (2 * 128 + 16), the tiled ring key (4 * 4 ceil(R/4)) and the 32-byte sector mask = 17 968 B -- not
-# SURVEY's 31 680 B (fp32 descriptor): the kernels must not get credit for bytes they do not move.
-KERNEL_BYTES_PER_KEYFRAME = 2 * 4 * (S + 16) * 16 + (2 * 128 + 16) + 4 * 4 * ((R + 3) // 4) + 32
+# descriptor (2 halves x 4 chunks x (S + 16) sectors x 16 B = 17 408 B at 64x120: 13 % padding so that no fragment wraps), the first
+# part of the alignment image (8 rotated copies of the unit fp16 sector key x 256 B + 16 B of norm = 2 064 B; the second part only for
+# the 4 % of the keyframes whose alignment needs the split stage), the tiled ring key (4 * 4 ceil(R/4)) and the 32-byte sector mask
+# = 19 760 B -- not SURVEY's 31 680 B (fp32 descriptor): the kernels must not get credit for bytes they do not move.
+KERNEL_BYTES_PER_KEYFRAME = 2 * 4 * (S + 16) * 16 + (8 * 128 * 2 + 16) + 4 * 4 * ((R + 3) // 4) + 32
 # ... and per PAIR, whatever stays on the chip or not: first shift (4 B written by the alignment, read by products and finish),
 # the two ring halves' partial sums (2 x 64 B written, read once), the bound d~ and the ring-key metric (4 B each)
 KERNEL_BYTES_PER_PAIR_IO = 4 + 2 * 4 + 2 * 128 + 4 + 4
@@ -320,11 +321,13 @@ def secondary_icp(eng, n_cand=25, n_pts=100000):
 # ------------------------------------------------------------------------------------------------
 # secondary: the EXACT all-pairs distance matrix (every pair through the fp64 kernel), one blocking scan, survivors
 # ------------------------------------------------------------------------------------------------
-def secondary_exact_all_pairs(eng, n_elig, n_query, queries=32):
-    """north_star's "column-shifted SC distance matrix over the keyframe database": every (scan, keyframe) pair gets the
-    reference's fp64 distance and shift (descriptor.h:1538-1569) from the exact wave kernel -- no screening.  Bit-identical
-    to the checker (tests/test_gpu_sc_distance.py compares uint64 views).  Priced at SURVEY 8(d)'s 31 680 B per pair."""
-    eng.sc_distance_matrix(n_elig + np.arange(4, dtype=np.int32), 0, n_elig)               # warm-up
+def secondary_exact_all_pairs(eng, n_elig, n_query, queries=64):
+    """north_star's "column-shifted SC distance matrix over the keyframe database": EVERY (scan, keyframe) pair gets the
+    reference's fp64 distance and shift (descriptor.h:1538-1569).  Per 16 rows: alignment + screening (which leaves, per pair, the
+    first shift and the shifts within 2 eps of the pair's smallest screened distance), then sc_masked_kernel evaluates exactly
+    those shifts in the reference's fp64 arithmetic.  Bit-identical to the checker (tests/test_gpu_sc_distance.py compares uint64
+    views, adversarial descriptors included).  Priced at SURVEY 8(d)'s 31 680 B per pair."""
+    eng.sc_distance_matrix(n_elig + np.arange(16, dtype=np.int32), 0, n_elig)              # warm-up
     eng.profile_reset(); eng.profile_enable(2)
     qs = (n_elig + (np.arange(queries) % n_query)).astype(np.int32)
     t0 = time.perf_counter()
@@ -341,9 +344,10 @@ def secondary_exact_all_pairs(eng, n_elig, n_query, queries=32):
                         f"results copied to the host)",
             "value": pairs / dt, "unit": "pairs/s", "ms_per_scan": dt / queries * 1e3, "dtype": "f64",
             "finite_distances": int(np.isfinite(dist).sum()),
-            "kernel_ms": {"sc_distance_wave_kernel_launch": k_ms, "pairs_per_launch": k_pairs},
+            "kernel_ms": {"group_of_rows": k_ms, "pairs_per_group": k_pairs},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "bytes_per_pair": ALGO_BYTES_PER_PAIR, "kernel": "sc_distance_wave_kernel<16,13,4,120> (exact fp64, one wave per pair); HIP events around every launch",
+                         "bytes_per_pair": ALGO_BYTES_PER_PAIR, "kernel": "per group of 16 rows: sc_align2_kernel + sc_screen2_kernel + sc_screen2_finish_kernel + sc_masked_kernel<16,120,13> "
+                                                                             "(exact fp64 at the open shifts, one wave per pair); HIP events around every group",
                          "fp64_vector_frac": (k_pairs * flops / (k_ms * 1e-3) / 1e12 / 78.6) if k_ms > 0 else 0.0,
                          "note": "SURVEY 8(d): 4 R S + 8 S bytes per pair, one scan per database pass; fp64_vector_frac = the reference's "
                                  "242 880 flop per pair against 78.6 TFLOP/s"}}
@@ -416,10 +420,10 @@ def secondary_80x180(device, n=10000, steps=512):
     eng.close()
     survey_pair = R2 * S2 * 4 + S2 * 4 + S2 * 4                                 # 59 040 B at 80x180
     # what the launch group (products in their second form + finish + next alignment) reads per keyframe by design, once per
-    # launch of 12 scans: the chunk-major fp16 image (3 ring thirds x 4 chunks x (S + 16) sectors x 16 B), the fp16 sector key + norm,
-    # the tiled ring key, the sector mask; per pair: first shift, the three thirds' two-pass partial sums (written and read), bound,
-    # ring-key metric
-    bytes_kf = 3 * 4 * (S2 + 16) * 16 + (2 * 192 + 16) + 4 * 4 * ((R2 + 3) // 4) + 32
+    # launch of 12 scans: the chunk-major fp16 image (3 ring thirds x 4 chunks x (S + 16) sectors x 16 B), the first part of the
+    # alignment image (4 rotated copies of the fp16 sector key x 384 B + norm), the tiled ring key, the sector mask; per pair: first
+    # shift, the three thirds' two-pass partial sums (written and read), bound, ring-key metric
+    bytes_kf = 3 * 4 * (S2 + 16) * 16 + (4 * 192 * 2 + 16) + 4 * 4 * ((R2 + 3) // 4) + 32
     bytes_pair_io = 4 + 2 * 4 + 2 * (3 * 2 * 16 * 4) + 4 + 4
     k_ms = prof["sc_distance_ms"] / max(1, prof["sc_distance_launches"])
     k_pairs = prof["sc_distance_pairs"] / max(1, prof["sc_distance_launches"])
@@ -697,12 +701,12 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": f"screening launch group of {k1_scans:.0f} scans x {n_elig} keyframes: sc_screen2_kernel (products: one keyframe "
-                                   f"against the launch's scans per matrix-core tile) + sc_screen2_tail_kernel (finishing beside the next batch's alignment); "
-                                   f"HIP events around the group",
+                                   f"against the launch's scans per matrix-core tile) + sc_screen2_tail2_kernel (finishing beside the next batch's alignment, "
+                                   f"itself one keyframe against the scans per tile); HIP events around the group",
                          "algorithmic_bytes_per_launch": per_launch,
                          "scans_per_launch": k1_scans, "pairs_per_launch": k1_pairs,
                          "pricing": "SURVEY 8(d), Q scans per database pass: DB bytes once per launch + per-scan bytes + per-pair intermediates "
-                                    f"({KERNEL_BYTES_PER_KEYFRAME} B per keyframe: chunk-major fp16 image, fp16 sector key, tiled ring key, mask; "
+                                    f"({KERNEL_BYTES_PER_KEYFRAME} B per keyframe: chunk-major fp16 image, alignment image, tiled ring key, mask; "
                                     f"{KERNEL_BYTES_PER_PAIR_IO} B per pair: first shift, partial sums, bound, ring-key metric)",
                          "note": "the database crosses HBM once per launch of Q scans; the per-pair operand (the scan rotated by the pair's first "
                                  "shift) comes out of LDS.  `single_scan_hbm_floor`: what any kernel that streams the database once per scan "
