@@ -721,6 +721,7 @@ def main():
         }
         if world > 1:
             out["collective"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                                 "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0,
                                  "library": "RCCL (torch.distributed 'nccl' on ROCm)" if dist.get_backend() == "nccl" else "gloo (CPU rehearsal: SCL_BENCH_SHARE_GPU=1)",
                                  "exchange": args.exchange, "devices_distinct": not share_gpu}
         if world == 1 and not args.no_secondary:

@@ -79,6 +79,30 @@ def test_screening_bound_and_survivors_on_the_bench_database():
     eng.close()
 
 
+def test_ranged_and_full_passes_interleaved():
+    """The call pattern of round 2's abort: the diagnostic entry point over a SUB-RANGE of the database between
+    full-range passes of the stream form (16 scans per launch: second form of the products, last-workgroup reductions, buffer
+    halves reused), ranges growing and shrinking, on one engine.  Every pass is compared with the checker."""
+    n = 2100
+    descs = synth_descriptors(n, R, S, seed=1011, revisit_frac=0.03)
+    eng = ScanContextEngine(num_ring=R, num_sector=S, initial_capacity=n)
+    db = ob.OracleDB(ob.make_config(R=R, S=S))
+    eng.save_bulk(descs); db.save_bulk(descs)
+    qs = np.arange(n - 1, n - 41, -1, dtype=np.int32)
+    want = [db.detect_full(int(q)) for q in qs]
+
+    def full():
+        nn, sh, dd = eng.detect_full_stream(qs, 0, qs - 100, 16, 2)
+        for i in range(len(qs)):
+            assert (nn[i], sh[i]) == (want[i][1], want[i][2]) and dd[i].view(np.uint64) == np.float64(want[i][3]).view(np.uint64)
+
+    for q, lo, hi in ((n - 1, 0, n - 100), (n - 2, 1900, 1990), (700, 0, 33), (n - 3, 5, 6), (n - 4, 0, n - 104), (40, 1000, 1017)):
+        full()
+        _check(eng, db, q, lo, hi)
+    full()
+    eng.close()
+
+
 def test_survivor_statistics_and_a_database_where_many_keyframes_survive():
     """scl_survivor_stats counts what the exact pass scores.  The headline rate depends on it (VERDICT r2 #1c): on the bench
     database a scan leaves a handful of survivors; with 5 % of the database within the screening margin of the winner the
