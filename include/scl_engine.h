@@ -177,8 +177,11 @@ int  scl_sc_distance_batch(scl_engine *e, int query, const int *cand, int n,
 /* The distance MATRIX of north_star ("the column-shifted SC distance matrix over the keyframe database"): row r =
  * distanceBtnScanContext (D.h:1538-1569) of keyframe queries[r] (or a staged query, -1 - slot) against the keyframes
  * lo .. hi-1; dist / shift are nq x (hi - lo), row-major.  Every entry is the exact fp64 evaluation (bit-identical to the
- * sequential CPU evaluation, as scl_sc_distance_batch): no screening.  Several rows share a launch and a launch's results
- * travel to the host while the next one runs. */
+ * sequential CPU evaluation, as scl_sc_distance_batch).  On the screened grids (64x120, 80x180) the screening pass first tells,
+ * per pair, which of the 2 SR + 1 shifts can still hold the minimum (a guaranteed bound: DESIGN.md section 4), and the fp64
+ * arithmetic of the reference is then carried out at those shifts only -- the result is the same number; the environment switch
+ * SCL_MATRIX_PLAIN=1 evaluates every shift of every pair.  Several rows share a launch and a launch's results travel to the
+ * host while the next one runs. */
 int  scl_sc_distance_matrix(scl_engine *e, const int *queries, int nq, int lo, int hi, double *dist, int *shift);
 /* BASELINE "full-DB" mode: ring-key top-k AND the shifted SC distance against
  * every eligible slot [0, hi) with hi = cur - num_exclude_recent (D.h:1627), then
