@@ -119,7 +119,7 @@ int query_view(const scl_engine *e, int query, QueryView *q)
 {
     if (query < 0) {                                       // staging slot j = -1 - query
         const int j = -1 - query;
-        if (j >= scl_engine::kStage || !e->staged[j]) return fail(e, SCL_ERR_INVALID_ARG, "no staged query (call scl_stage_query first)");
+        if (j >= e->stage_rows || !e->staged[j]) return fail(e, SCL_ERR_INVALID_ARG, "no staged query (call scl_stage_query first)");
         query = e->cap + j;
     } else if (query >= e->n) return fail(e, SCL_ERR_OUT_OF_RANGE, "query slot out of range");
     q->desc = e->d_desc + (size_t)query * e->RG * e->S;
@@ -142,7 +142,7 @@ int ensure_capacity(scl_engine *e, int need)
     uint2 *nh = nullptr; unsigned int *nk = nullptr; unsigned short *nhk = nullptr; unsigned char *nha = nullptr;
     const size_t hab = (size_t)halign_bytes(e->S);            // alignment images: database slots only
     int rc;
-    const size_t nst = (size_t)ncap + scl_engine::kStage;     // database slots + the staging slots behind them
+    const size_t nst = (size_t)ncap + (size_t)e->stage_rows;  // database slots + the staging (and mirror) rows behind them
     if ((rc = dev_alloc(e, &nd, tile * nst))) return rc;
     if ((rc = dev_alloc(e, &nv, (size_t)e->S * nst))) return rc;
     if ((rc = dev_alloc(e, &nn, (size_t)e->S * nst))) return rc;
@@ -166,7 +166,7 @@ int ensure_capacity(scl_engine *e, int need)
                                     sizeof(float4) * e->n, e->RG, hipMemcpyDeviceToDevice, e->stream));
     }
     if (e->cap > 0) {                                      // staged queries move with the arrays
-        const size_t k = scl_engine::kStage;
+        const size_t k = (size_t)e->stage_rows;
         SCL_HIP(e, hipMemcpyAsync(nd + tile * ncap, e->d_desc + tile * e->cap, sizeof(float4) * tile * k, hipMemcpyDeviceToDevice, e->stream));
         SCL_HIP(e, hipMemcpyAsync(nv + (size_t)e->S * ncap, e->d_vkey + (size_t)e->S * e->cap, sizeof(double) * e->S * k, hipMemcpyDeviceToDevice, e->stream));
         SCL_HIP(e, hipMemcpyAsync(nn + (size_t)e->S * ncap, e->d_norm + (size_t)e->S * e->cap, sizeof(double) * e->S * k, hipMemcpyDeviceToDevice, e->stream));
@@ -904,7 +904,7 @@ int scl_sc_distance_matrix(scl_engine *e, const int *queries, int nq, int lo, in
     std::vector<int> slots((size_t)nq);
     for (int i = 0; i < nq; ++i) {
         const int q = queries[i];
-        if (q >= e->n || q < -(int)scl_engine::kStage) return fail(e, SCL_ERR_OUT_OF_RANGE, "query keyframe out of range");
+        if (q >= e->n || q < -e->stage_rows) return fail(e, SCL_ERR_OUT_OF_RANGE, "query keyframe out of range");
         if (q < 0 && !e->staged[-1 - q]) return fail(e, SCL_ERR_INVALID_ARG, "no staged query in that slot");
         slots[(size_t)i] = q >= 0 ? q : e->cap + (-1 - q);
     }
@@ -1244,7 +1244,7 @@ int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, c
     for (int i = 0; i < nq && batchable; ++i) {
         const int q = queries[i];
         if (q >= 0) { batchable = q < e->n; qslot[i] = q; }
-        else { const int j = -1 - q; batchable = j < scl_engine::kStage && e->staged[j]; qslot[i] = e->cap + j; }
+        else { const int j = -1 - q; batchable = j < e->stage_rows && e->staged[j]; qslot[i] = e->cap + j; }
     }
     if (!batchable) {                                      // one pass per query
         for (int i = 0; i < nq; ++i) { int rc = submit_full_locked(e, queries[i], los[i], his[i], &tickets[i]); if (rc) return rc; }
@@ -1412,7 +1412,7 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
             const int q = queries[first + i];
             int slot;
             if (q >= 0) { if (q >= e->n) return fail(e, SCL_ERR_OUT_OF_RANGE, "query slot out of range"); slot = q; }
-            else { const int j = -1 - q; if (j >= scl_engine::kStage || !e->staged[j]) return fail(e, SCL_ERR_INVALID_ARG, "no staged query"); slot = e->cap + j; }
+            else { const int j = -1 - q; if (j >= e->stage_rows || !e->staged[j]) return fail(e, SCL_ERR_INVALID_ARG, "no staged query"); slot = e->cap + j; }
             const int l = lo[first + i] < 0 ? 0 : lo[first + i], h = hi[first + i] > e->n ? e->n : hi[first + i];
             if (k) k->lo[(size_t)i] = l;
             if (h - l <= 0) continue;
@@ -1631,7 +1631,7 @@ int scl_screen_distances(scl_engine *e, int query, int lo, int hi, float *approx
     if (!e->screen) return fail(e, SCL_ERR_UNSUPPORTED, "no screening pass for this grid (64x120 and 80x180 at search ratio 0.1 only)");
     int qslot;
     if (query >= 0) { if (query >= e->n) return fail(e, SCL_ERR_OUT_OF_RANGE, "query slot out of range"); qslot = query; }
-    else { const int j = -1 - query; if (j >= scl_engine::kStage || !e->staged[j]) return fail(e, SCL_ERR_INVALID_ARG, "no staged query"); qslot = e->cap + j; }
+    else { const int j = -1 - query; if (j >= e->stage_rows || !e->staged[j]) return fail(e, SCL_ERR_INVALID_ARG, "no staged query"); qslot = e->cap + j; }
     if (lo < 0) lo = 0;
     if (hi > e->n) hi = e->n;
     const int n = hi - lo;
@@ -2475,7 +2475,7 @@ namespace scl {
 
 int eng_stage_from_peer(scl_engine *dst, int j, scl_engine *src, int src_slot, int count)
 {
-    if (!dst || !src || count < 1 || j < 0 || j + count > scl_engine::kStage) return SCL_ERR_INVALID_ARG;
+    if (!dst || !src || count < 1 || j < 0 || j + count > dst->stage_rows) return SCL_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(dst->mu);
     if (src_slot < 0 || src_slot + count > src->n) return fail(dst, SCL_ERR_OUT_OF_RANGE, "stage_from_peer: source slot out of range");
     (void)hipSetDevice(dst->device);
@@ -2494,9 +2494,22 @@ int eng_stage_from_peer(scl_engine *dst, int j, scl_engine *src, int src_slot, i
     return SCL_OK;
 }
 
+int eng_set_stage_rows(scl_engine *e, int rows)
+{
+    if (!e || rows < scl_engine::kStage) return SCL_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->n > 0) return fail(e, SCL_ERR_INVALID_ARG, "stage rows are fixed once a keyframe is stored");
+    (void)hipSetDevice(e->device);
+    const int old_cap = e->cap;
+    e->stage_rows = rows;
+    e->staged.assign((size_t)rows, 0);
+    e->cap = 0;                                            // empty database: new arrays of the new shape, nothing to copy (the old ones are freed there)
+    return ensure_capacity(e, old_cap > 0 ? old_cap : 1);
+}
+
 int eng_stage_values(scl_engine *e, int j, const float *values)
 {
-    if (!e || !values || j < 0 || j >= scl_engine::kStage) return SCL_ERR_INVALID_ARG;
+    if (!e || !values || j < 0 || j >= e->stage_rows) return SCL_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     int rc;

@@ -58,8 +58,12 @@ struct scl_engine {
     // live on another device).
     // (0: the public staged query; 1..9: the sharded front's passes in flight and blocking calls; 12..75: the front's stream form, one
     // block of 64 scans whose keyframes live on another shard)
+    // Behind those, an engine that is a shard of a sharded front carries MIRROR rows (stage_rows > kStage; sharded_front.hip): the query-side
+    // rows of the newest keyframes of the OTHER shards, copied over when they are appended, so that a scan of a keyframe that lives on
+    // another device needs no copy when it is searched for.
     static constexpr int kStage = 76;
-    bool staged[kStage] = {false};
+    int stage_rows = kStage;                                // rows behind the database slots (>= kStage); fixed before the first allocation
+    std::vector<unsigned char> staged = std::vector<unsigned char>(kStage, 0);
 
     // scratch
     float *d_vals = nullptr; size_t vals_cap = 0;          // wire-format staging (floats)
@@ -151,6 +155,7 @@ namespace scl {
 
 // copy keyframe `src_slot` of `src` (descriptor tile, sector key, norms, ring key) into staging slot j of `dst`
 // (query id -1-j); device-to-device, ordered on dst's stream.  src == dst is allowed.
+int eng_set_stage_rows(scl_engine *e, int rows);            // before the first keyframe is stored: kStage + mirror rows
 int eng_stage_from_peer(scl_engine *dst, int j, scl_engine *src, int src_slot, int count = 1);   // count consecutive rows: slots src_slot.. to staging rows j..
 // wire descriptor -> staging slot j
 int eng_stage_values(scl_engine *e, int j, const float *values);

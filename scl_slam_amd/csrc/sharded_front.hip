@@ -42,7 +42,14 @@ constexpr int kMaxShards = 16;
 constexpr int kFrontSlots = 8;                             // full-DB passes in flight at the front (= the shards' slots)
 constexpr unsigned long long kNoKey = ~0ull;
 static_assert(1 + kFrontSlots < scl_engine::kStage, "staging slots: 0 public, 1..8 passes in flight, 9 blocking calls");
-constexpr int kStreamStage0 = 12, kStreamBlock = 64;       // staging rows of the stream form's block
+constexpr int kStreamStage0 = 12, kStreamBlock = 64;       // staging rows of the stream form's block (keyframes that are not mirrored)
+// Mirror rows: behind the staging rows every shard keeps the query-side rows (descriptor, keys, norms, fp16 copy,
+// masks) of the newest kMirrorPerOwner keyframes of EVERY other shard, copied device to device when the keyframe is appended.  A scan is
+// searched for right after it was appended, so the shards that do not own it find it in place: no copy at query time, whatever the
+// order of the queries.  Row of slot s of owner o: kStage + o kMirrorPerOwner + s mod kMirrorPerOwner (consecutive slots = consecutive
+// rows: a bulk append travels in one copy per array and destination).  Older keyframes still go through the staging rows.
+constexpr int kMirrorPerOwner = 1024;
+constexpr int kStreamCall = 1024;                          // scans per shard call of the stream form (a block ends earlier when its 64 staging rows are used up)
 static_assert(kStreamStage0 > 1 + kFrontSlots && kStreamStage0 + kStreamBlock <= scl_engine::kStage, "staging rows of the stream form");
 
 int local_count(int global_hi, int c, int G)
@@ -194,6 +201,8 @@ struct ShardedFront {
     std::vector<int> indexs;
     int tree_counter = 0, tree_n = 0;                      // D.h:1691-1703
     bool staged0 = false;                                  // scl_stage_query was called on the front
+    int mirror_lo[kMaxShards] = {0};                       // per owner: slots [mirror_lo, its size) have been copied to the other shards' mirror rows
+    bool mirror_on = false;
 
     struct Pass { bool busy = false; int tk[kMaxShards]; int group = -1; };
     Pass pass[kFrontSlots];
@@ -229,6 +238,42 @@ int child_fail(const scl_engine *e, const scl_engine *child, int rc, const char 
     return rc;
 }
 
+inline int mirror_row(int owner, int slot) { return scl_engine::kStage + owner * kMirrorPerOwner + slot % kMirrorPerOwner; }
+
+// is global keyframe g in the other shards' mirror rows?
+inline bool mirrored(const ShardedFront *f, int g)
+{
+    if (!f->mirror_on || g < 0 || g >= f->n) return false;
+    const int o = g % f->G, s = g / f->G;
+    return s >= f->mirror_lo[o] && s >= local_count(f->n, o, f->G) - kMirrorPerOwner;
+}
+
+// slots [s0, s0 + cnt) of owner o have just been appended (the owner's ingest has completed): copy their rows to the mirror rows of
+// every other shard.  A failure only switches the mirror off for what it could not copy: those keyframes take the staging rows.
+void mirror_appended(scl_engine *e, int o, int s0, int cnt)
+{
+    ShardedFront *f = e->front;
+    if (!f->mirror_on || cnt <= 0) return;
+    const int end = s0 + cnt;
+    if (cnt > kMirrorPerOwner) { s0 = end - kMirrorPerOwner; cnt = kMirrorPerOwner; }
+    bool in_flight = false;
+    for (int t = 0; t < kFrontSlots; ++t) in_flight |= f->pass[t].busy;
+    bool ok = true;
+    for (int c = 0; c < f->G && ok; ++c) {
+        if (c == o) continue;
+        // a pass in flight may still read the rows that are about to be replaced (its exact pass runs on a side stream)
+        if (in_flight && eng_sync_streams(f->sh[c])) { ok = false; break; }
+        for (int s = s0; s < end && ok; ) {
+            const int r = s % kMirrorPerOwner;
+            const int len = end - s < kMirrorPerOwner - r ? end - s : kMirrorPerOwner - r;
+            ok = eng_stage_from_peer(f->sh[c], mirror_row(o, s), f->sh[o], s, len) == SCL_OK;
+            s += len;
+        }
+    }
+    // (mirror_lo[o] <= the owner's old size always: a successful copy keeps [mirror_lo, end) contiguous)
+    if (!ok) f->mirror_lo[o] = end;                        // nothing of this owner up to here counts as mirrored
+}
+
 // make global keyframe / staged query `query` available on every shard; qid[c] = the id shard c uses for it.
 // stage_slot: which staging slot the non-owners use (1 + front pass for passes in flight, 1 for blocking calls).
 int place_query(scl_engine *e, int query, int stage_slot, int *qid)
@@ -241,8 +286,10 @@ int place_query(scl_engine *e, int query, int stage_slot, int *qid)
     }
     if (query >= f->n) return ffail(e, SCL_ERR_OUT_OF_RANGE, "query keyframe out of range");
     const int owner = query % f->G, slot = query / f->G;
+    const bool in_mirror = mirrored(f, query);
     for (int c = 0; c < f->G; ++c) {
         if (c == owner) { qid[c] = slot; continue; }
+        if (in_mirror) { qid[c] = -1 - mirror_row(owner, slot); continue; }
         const int rc = eng_stage_from_peer(f->sh[c], stage_slot, f->sh[owner], slot);
         if (rc) return child_fail(e, f->sh[c], rc, "stage query on shard");
         qid[c] = -1 - stage_slot;
@@ -331,9 +378,11 @@ extern "C" int scl_create_sharded(const scl_config *cfg, const int *devices, int
         scl_config cc = *cfg;
         cc.device = devices[c];
         cc.initial_capacity = cfg->initial_capacity > 0 ? (cfg->initial_capacity + n_devices - 1) / n_devices + 1 : cfg->initial_capacity;
-        const int rc = scl_create(&cc, &f->sh[c]);
+        int rc = scl_create(&cc, &f->sh[c]);
         if (rc) { front_destroy(e); return rc; }
+        if (n_devices > 1 && (rc = eng_set_stage_rows(f->sh[c], scl_engine::kStage + n_devices * kMirrorPerOwner))) { front_destroy(e); return rc; }
     }
+    f->mirror_on = n_devices > 1;
     // the exchange of full-DB winners: 0 = RCCL when it can be had (more than one shard, every shard on its own
     // device), else the host merge; 1 = host merge; 2 = RCCL or fail; 3 = the RCCL control flow through the tests' stand-in
     // collective (any device list)
@@ -404,6 +453,7 @@ int front_make_and_save(scl_engine *e, const void *points, int n_points, int str
                   : scl_make_and_save(f->sh[c], points, n_points, stride_bytes, robot, index, out_values);
     if (rc) return child_fail(e, f->sh[c], rc, "make_and_save on shard");
     f->robots.push_back(robot); f->indexs.push_back(index); f->n++;
+    mirror_appended(e, c, (f->n - 1) / f->G, 1);
     return SCL_OK;
 }
 
@@ -448,7 +498,12 @@ int front_save_bulk(scl_engine *e, const float *values, int count, const int8_t 
         f->robots.push_back(robots ? robots[i] : (int8_t)0);
         f->indexs.push_back(indexs ? indexs[i] : f->n + i);
     }
+    const int n_before = f->n;
     f->n += count;
+    for (int c = 0; c < f->G; ++c) {
+        const int s0 = local_count(n_before, c, f->G), s1 = local_count(f->n, c, f->G);
+        mirror_appended(e, c, s0, s1 - s0);
+    }
     return SCL_OK;
 }
 
@@ -804,22 +859,30 @@ int front_detect_full_stream(scl_engine *e, const int *queries, const int *lo, c
     for (int t = 0; t < kFrontSlots; ++t)
         if (f->pass[t].busy) return ffail(e, SCL_ERR_INVALID_ARG, "detect_full_stream: collect the passes in flight first");
     // Block form (winners merged on the host whatever the exchange mode of the single passes: the results of a stream go to host arrays
-    // anyway): the scans go to the shards in blocks of 64 -- the keyframes of a block are copied to the
-    // staging rows of the shards that do not hold them, then every shard runs its own stream form over the block (up to 16 scans per
+    // anyway): the scans go to the shards in blocks of up to kStreamCall.  A scan whose keyframe the other shards hold in their mirror
+    // rows (every recent keyframe: copied when it was appended) needs nothing; the others -- at most 64 per block -- are copied to the
+    // staging rows of the shards that do not hold them.  Then every shard runs its own stream form over the block (up to 16 scans per
     // launch, one exact pass per chunk: scl_detect_full_stream of the shard, one host thread per shard), and the per-shard winners of
     // the block are merged as one database's arg-min would (smallest distance, ties to the lowest global index).
     const int G = f->G;
     const int spl_s = scans_per_launch < 1 ? 1 : scans_per_launch;              // the shard clamps it to what its grid takes per launch
-    std::vector<int> q((size_t)G * kStreamBlock), l((size_t)G * kStreamBlock), h((size_t)G * kStreamBlock);
-    std::vector<int> nn((size_t)G * kStreamBlock), sh((size_t)G * kStreamBlock);
-    std::vector<double> dd((size_t)G * kStreamBlock);
-    for (int b0 = 0; b0 < n_queries; b0 += kStreamBlock) {
-        const int m = n_queries - b0 < kStreamBlock ? n_queries - b0 : kStreamBlock;
-        // Staging rows in the order (owner shard, position in the block): keyframes that follow each other on their owner -- the
-        // usual case, a backlog of the newest keyframes: global slots g, g + 1, ... are slots s, s + 1 on each owner -- land in
+    std::vector<int> q((size_t)G * kStreamCall), l((size_t)G * kStreamCall), h((size_t)G * kStreamCall);
+    std::vector<int> nn((size_t)G * kStreamCall), sh((size_t)G * kStreamCall);
+    std::vector<double> dd((size_t)G * kStreamCall);
+    std::vector<int> row_of((size_t)kStreamCall);
+    for (int b0 = 0, m = 0; b0 < n_queries; b0 += m) {
+        int n_copy = 0;
+        for (m = 0; b0 + m < n_queries && m < kStreamCall; ++m) {
+            const int g = queries[b0 + m];
+            const bool copy = G > 1 && g >= 0 && !mirrored(f, g);
+            if (copy && n_copy == kStreamBlock) break;
+            n_copy += copy ? 1 : 0;
+            row_of[(size_t)m] = -1;
+        }
+        // Staging rows in the order (owner shard, position in the block): keyframes that follow each other on their owner land in
         // consecutive rows, and a run of them travels to a shard in one copy per array instead of one per keyframe.
-        int row_of[kStreamBlock], next_row = kStreamStage0;
-        for (int o = 0; o < G; ++o) {
+        int next_row = kStreamStage0;
+        for (int o = 0; o < G && n_copy > 0; ++o) {
             int run_row = -1, run_slot = -1, run_len = 0;
             auto flush = [&]() -> int {
                 for (int c = 0; c < G && run_len > 0; ++c) {
@@ -832,14 +895,14 @@ int front_detect_full_stream(scl_engine *e, const int *queries, const int *lo, c
             };
             for (int i = 0; i < m; ++i) {
                 const int g = queries[b0 + i];
-                if (g < 0 || g % G != o) continue;
+                if (g < 0 || g % G != o || mirrored(f, g)) continue;
                 if (g >= f->n) return ffail(e, SCL_ERR_OUT_OF_RANGE, "query keyframe out of range");
                 const int slot = g / G;
-                row_of[i] = next_row++;
+                row_of[(size_t)i] = next_row++;
                 if (run_len > 0 && slot == run_slot + run_len) { ++run_len; continue; }
                 int rc = flush();
                 if (rc) return rc;
-                run_row = row_of[i]; run_slot = slot; run_len = 1;
+                run_row = row_of[(size_t)i]; run_slot = slot; run_len = 1;
             }
             const int rc = flush();
             if (rc) return rc;
@@ -849,14 +912,14 @@ int front_detect_full_stream(scl_engine *e, const int *queries, const int *lo, c
             if (g < 0 && (g != SCL_QUERY_STAGED || !f->staged0)) return ffail(e, SCL_ERR_INVALID_ARG, "no staged query (call scl_stage_query first)");
             const int glo = lo[b0 + i] < 0 ? 0 : lo[b0 + i], ghi = hi[b0 + i] > f->n ? f->n : hi[b0 + i];
             for (int c = 0; c < G; ++c) {
-                const size_t k = (size_t)c * kStreamBlock + (size_t)i;
-                q[k] = g < 0 ? SCL_QUERY_STAGED : (c == g % G ? g / G : -1 - row_of[i]);
+                const size_t k = (size_t)c * kStreamCall + (size_t)i;
+                q[k] = g < 0 ? SCL_QUERY_STAGED : (c == g % G ? g / G : -1 - (row_of[(size_t)i] >= 0 ? row_of[(size_t)i] : mirror_row(g % G, g / G)));
                 l[k] = local_count(glo, c, G); h[k] = local_count(ghi, c, G);
             }
         }
         int rcs[kMaxShards] = {0};
         auto run = [&](int c) {
-            const size_t k = (size_t)c * kStreamBlock;
+            const size_t k = (size_t)c * kStreamCall;
             rcs[c] = scl_detect_full_stream(f->sh[c], q.data() + k, l.data() + k, h.data() + k, m, spl_s, launches_in_flight,
                                             nn.data() + k, sh.data() + k, dd.data() + k);
         };
@@ -868,7 +931,7 @@ int front_detect_full_stream(scl_engine *e, const int *queries, const int *lo, c
         for (int i = 0; i < m; ++i) {
             int bi = -1, bs = 0; double bd = kBigDist;
             for (int c = 0; c < G; ++c) {
-                const size_t k = (size_t)c * kStreamBlock + (size_t)i;
+                const size_t k = (size_t)c * kStreamCall + (size_t)i;
                 if (nn[k] < 0) continue;
                 const int g = nn[k] * G + c;
                 if (dd[k] < bd || (dd[k] == bd && (bi < 0 || g < bi))) { bd = dd[k]; bi = g; bs = sh[k]; }

@@ -95,6 +95,52 @@ def test_sharded_engine_equals_single_engine_and_oracle(G):
     sh.close(); one.close()
 
 
+@pytest.mark.parametrize("G", [2, 3])
+def test_mirror_rows_of_recent_keyframes(G):
+    """The other shards' copies of the newest keyframes (made when a keyframe is appended: sharded_front.hip, mirror rows) serve
+    scattered queries without a copy at query time; keyframes that have left the mirror (more than 1024 newer ones on their owner)
+    go through the staging rows.  Ingest one by one and in bulk, across the ring's wrap and across a growth of the arrays; every
+    form of the pass equals one database bit for bit."""
+    R, S = 64, 120
+    n = 1024 * G + 700                                         # past the wrap of every owner's ring
+    descs = synth_descriptors(n, R, S, seed=1013, revisit_frac=0.04)
+    one = ScanContextEngine(num_ring=R, num_sector=S, initial_capacity=256)
+    sh = ScanContextEngine(num_ring=R, num_sector=S, initial_capacity=256, devices=[0] * G, exchange=1)
+    rs = np.random.RandomState(5)
+    done = 0
+
+    def check(count):
+        # scattered queries: newest first, random recent ones, some old ones (staging rows), repeated keyframes
+        qs = np.concatenate([np.arange(done - 1, max(done - 40, -1), -1), rs.randint(max(0, done - 900 * G), done, 70),
+                             rs.randint(0, done, 30), [done - 1, done - 1]]).astype(np.int32)[:count]
+        his = np.maximum(qs - 50, 0).astype(np.int32)
+        a = one.detect_full_stream(qs, 0, his, 16, 2)
+        b = sh.detect_full_stream(qs, 0, his, 16, 2)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2].view(np.uint64), b[2].view(np.uint64))
+        for q in (int(qs[0]), int(qs[45 % len(qs)])):           # blocking passes and the top-k take the same rows
+            assert _same_full(one.detect_full_range(q, 0, max(q - 50, 0)), sh.detect_full_range(q, 0, max(q - 50, 0)))
+            ia, da = one.ringkey_topk(q, 0, max(q - 50, 0), 5)[:2]
+            ib, db_ = sh.ringkey_topk(q, 0, max(q - 50, 0), 5)[:2]
+            assert np.array_equal(ia, ib) and np.array_equal(np.asarray(da).view(np.uint32), np.asarray(db_).view(np.uint32))
+
+    for step in (300, 1, 1, 1, 500, 1, 1300, 1, 1, n):         # bulk appends of several sizes (one larger than a ring) and single ones
+        m = min(step, n - done)
+        if m <= 0:
+            break
+        if m == 1:
+            one.save_from_wire(descs[done], 0, done); sh.save_from_wire(descs[done], 0, done)
+        else:
+            one.save_bulk(descs[done:done + m]); sh.save_bulk(descs[done:done + m])
+        done += m
+        check(142)
+    assert done == n
+    one.close(); sh.close()
+
+
+def _same_full(a, b):
+    return a[0] == b[0] and a[1] == b[1] and _same_bits(a[2], b[2])
+
+
 def test_sharded_engine_grows_under_passes_in_flight():
     """appends that move a shard's arrays while another shard's pass still reads a staged copy of a keyframe"""
     R, S = 20, 60
