@@ -95,6 +95,9 @@ int  scl_destroy(scl_engine *e);
  * exchange = 3 is for tests: the control flow of exchange = 2 (pack kernels, grouped all-reduce, select kernels, second
  * all-reduce, one device-to-host copy) with a stand-in for the collective that forms the ranks' element-wise minimum on the
  * host -- RCCL refuses two ranks on one device, so this is how the G > 1 flow runs on a one-GPU box.
+ * With more than one shard every shard also keeps the query-side rows of the newest 1024 keyframes of each OTHER shard (copied
+ * device to device when a keyframe is appended: 66 KB per keyframe at 64x120, n_devices x 1024 rows per shard), so that searching
+ * for a recent keyframe -- what detection does -- moves nothing between the devices; older keyframes are copied when asked for.
  * Geometric verification of one scan's candidates (scl_icp_align_batch) is spread over the shards by candidate;
  * other geometry calls and the keyframe store live on devices[0].  cfg->device is ignored. */
 int  scl_create_sharded(const scl_config *cfg, const int *devices, int n_devices, int exchange, scl_engine **out);
