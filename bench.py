@@ -83,6 +83,7 @@ def parse_args():
                          "over the visible devices; the stream form and the single passes with their exchange).  Not the driver's contract line.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] geometric-verification measurement")
+    ap.add_argument("--only-secondary", default="", help="comma-separated names: run only these secondary measurements (experiments)")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the 1-thread CPU sample (0 = auto ~10 s)")
     return ap.parse_args()
 
@@ -731,7 +732,9 @@ def main():
                              ("sc_distance_80x180", lambda: secondary_80x180(local_rank)),
                              ("adversarial_survivors", lambda: secondary_adversarial_survivors(local_rank, shard, queries, n_elig)),
                              ("icp_verification", lambda: secondary_icp(eng)),
-                                 ("livox_stream_80x180", lambda: secondary_livox_stream(local_rank))):
+                             ("livox_stream_80x180", lambda: secondary_livox_stream(local_rank))):
+                if args.only_secondary and name not in args.only_secondary.split(","):
+                    continue
                 try:
                     out["secondary"][name] = fn()
                 except Exception as ex:                      # never lose the headline line to a secondary measurement

@@ -1199,6 +1199,9 @@ hipError_t launch_sc_select_batch(const ScreenBatch &sb, hipStream_t stream)
 // Waves per workgroup (one workgroup per CU: the scans fill the LDS) and ring slots of the fragment loads; -D overrides for experiments.
 // 64 x 120: 113 registers -> 16 waves (four per SIMD) hide the chains that two per SIMD left open (products 54 -> 48 us per 16 scans;
 // six ring slots instead of ten: 1 us slower).  80 x 180: 156 registers; twelve waves measured the same as eight.
+#ifndef S2_FRAG_SHIFT
+#define S2_FRAG_SHIFT 1               // products, second form: three of four keyframe fragments by row shifts of loaded ones (0: every fragment loaded)
+#endif
 #ifndef S2RS_A
 #define S2RS_A 10
 #endif
@@ -1206,7 +1209,7 @@ hipError_t launch_sc_select_batch(const ScreenBatch &sb, hipStream_t stream)
 #define S2RS_B 9
 #endif
 #ifndef S2WV_B
-#define S2WV_B 8
+#define S2WV_B 12
 #endif
 #ifndef S2WV_A
 #define S2WV_A 16
@@ -1227,7 +1230,7 @@ template <int RG, int S, int W> struct S2Cfg;
 // WV: waves of the products per workgroup; XW: EXTRA waves of the same workgroup that align the NEXT batch and finish the PREVIOUS
 // one beside the products (sc_screen2_kernel): the products leave two thirds of the vector and matrix-core issue slots idle
 template <> struct S2Cfg<16, 120, 13> { static constexpr int NP = 2, NPASS = 1, STEPS = 4, NQ = 16, RS = S2RS_A, WV = S2WV_A, WVF = S2WVF_A, XW = S2XW_A; };   // RS: ring slots of fragment loads (RS - 1 in flight);
-template <> struct S2Cfg<20, 180, 19> { static constexpr int NP = 3, NPASS = 2, STEPS = 4, NQ = 12, RS = 9, WV = 8, WVF = 8, XW = S2XW_B; };    // S / STEPS iterations per keyframe = a multiple of RS
+template <> struct S2Cfg<20, 180, 19> { static constexpr int NP = 3, NPASS = 2, STEPS = 4, NQ = 12, RS = 9, WV = S2WV_B, WVF = 8, XW = S2XW_B; };    // S / STEPS iterations per keyframe = a multiple of RS
 constexpr int kS2PassRows = 13;                    // shift rows per pass: row m of pass p = shift W - 1 - 13 p - m
 
 // LDS image of the scans (see above): quad stride in bytes, 2 mod 4 sixteen-byte slots
@@ -1331,6 +1334,92 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
         return starts_q[ok ? ci : 0];
     };
     const int nk = (fa.u_n - gw + waves_part - 1) / waves_part;
+    const unsigned int q_lds = (unsigned int)((cq >> 2) * QUAD + (cq & 3) * 64 + j4 * 16);
+    const int up16 = ((lane + 16) & 63) * 4;           // ds_bpermute address of the lane that holds the next four rows of this column
+#if S2_FRAG_SHIFT
+    // The fragment of iteration i (keyframe sectors 4 i + m, m = 0 .. 15) shares twelve of its sixteen sectors with the one before: only
+    // every FOURTH fragment is loaded (sectors 16 g + m: the same 1 KB load, a quarter as many), the three between come out of two loaded
+    // ones by row shifts inside the rows of 16 lanes -- lane m of offset 4 o takes lane m + 4 o of load g, or lane m + 4 o - 16 of load
+    // g + 1 (two DPP moves per register).  The texture addresser, the busiest unit of this kernel (64 %), sees a quarter of the requests;
+    // three loads of 16 sectors are held (12 registers) instead of a ring of ten fragments (40).
+    constexpr int NGR = (NIT + 3) / 4;                  // groups of four iterations per keyframe (the last may be short)
+    constexpr int NL = ((NIT - 1) % 4 == 0) ? NGR : NGR + 1;   // loads per keyframe: the last group needs load NGR only if it has a derived fragment
+    static_assert(NL % 3 == 0, "three buffers, statically indexed across keyframes");
+    // lane (m, j4) of load g reads sector 16 g + m; the image's rows end at sector S + 15 (the last load's upper lanes stay inside)
+    auto load_off = [&](int g) -> unsigned int { const int sct = 16 * g + c16; return a_lane + (unsigned int)((sct <= S + 15 ? sct : S + 15) - c16) * 16u; };
+    u32x4 F[3];
+    const unsigned char *base_cur = kf_base(0), *base_nxt = kf_base(1);
+    F[0] = *reinterpret_cast<const u32x4 *>(base_cur + load_off(0));
+    F[1] = *reinterpret_cast<const u32x4 *>(base_cur + load_off(1));
+    int b_cur = first_shift(0), b_nxt = first_shift(1);
+    for (int k = 0; k < nk; ++k) {
+        // Scan sector that meets keyframe sector 0 in pass p: c0 = first shift + W - 1 - 13 p; iteration `it` reads sectors c0 + 4 it .. + 3
+        // (mod S; the image repeats STEPS - 1 sectors so that the reads of an iteration never wrap).  The lane's address is ONE of two
+        // fixed bases -- before and after its wrap -- plus a compile-time offset of 1 KB per iteration: a compare and a select per
+        // iteration and pass instead of the running pointer's five instructions (the vector issue port is what binds this kernel).
+        const unsigned char *preB[NPASS], *postB[NPASS];  // (pointers: the image's base address is added once per keyframe, not per read)
+        int wrapB[NPASS];                                // first iteration that reads from the wrapped base
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            int c0 = b_cur + (W - 1) - kS2PassRows * p;
+            c0 = c0 >= S ? c0 - S : c0;
+            preB[p] = smem2 + (q_lds + (unsigned int)c0 * 256u);
+            postB[p] = preB[p] - S * 256;
+            wrapB[p] = (S - c0 + STEPS - 1) / STEPS;     // smallest it with c0 + 4 it >= S
+        }
+        auto readB = [&](h8 (&dst)[NPASS][STEPS], const int it) {
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) {
+                const unsigned char *qp = (it < wrapB[p] ? preB[p] : postB[p]) + it * STEPS * 256;
+#pragma unroll
+                for (int u = 0; u < STEPS; ++u) dst[p][u] = *reinterpret_cast<const h8 *>(qp + 256 * u);
+            }
+        };
+        f4v acc[NPASS][STEPS];
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+            for (int u = 0; u < STEPS; ++u) acc[p][u] = f4v{0.f, 0.f, 0.f, 0.f};
+        h8 bfr[2][NPASS][STEPS];
+        readB(bfr[0], 0);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int g = it >> 2, o = it & 3;
+            if (o == 0) {                                // the load two groups ahead: from the next keyframe at this one's end
+                const int j = g + 2;
+                F[j % 3] = j < NL ? *reinterpret_cast<const u32x4 *>(base_cur + load_off(j))
+                                  : *reinterpret_cast<const u32x4 *>(base_nxt + load_off(j - NL));
+            }
+            if (it + 1 < NIT) readB(bfr[(it + 1) & 1], it + 1);   // the next iteration's B fragments
+            u32x4 fr = F[g % 3];
+            if (o != 0) {
+                const u32x4 f0 = F[g % 3], f1 = F[(g + 1) % 3];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    // lanes m >= 16 - 4 o: lane m - (16 - 4 o) of the next load; lanes below: lane m + 4 o of this one
+                    // (bound_ctrl on the first move: lanes without a source lane take 0 -- no register to initialise; the second keeps them)
+                    int t = o == 1 ? __builtin_amdgcn_update_dpp(0, (int)f1[d], 0x11C, 0xf, 0xf, true)        // row_shr:12
+                          : o == 2 ? __builtin_amdgcn_update_dpp(0, (int)f1[d], 0x118, 0xf, 0xf, true)        // row_shr:8
+                                   : __builtin_amdgcn_update_dpp(0, (int)f1[d], 0x114, 0xf, 0xf, true);       // row_shr:4
+                    t = o == 1 ? __builtin_amdgcn_update_dpp(t, (int)f0[d], 0x104, 0xf, 0xf, false)           // row_shl:4
+                      : o == 2 ? __builtin_amdgcn_update_dpp(t, (int)f0[d], 0x108, 0xf, 0xf, false)           // row_shl:8
+                               : __builtin_amdgcn_update_dpp(t, (int)f0[d], 0x10C, 0xf, 0xf, false);          // row_shl:12
+                    fr[d] = (unsigned int)t;
+                }
+            }
+            const h8 af = __builtin_bit_cast(h8, fr);
+#pragma unroll
+            for (int u = 0; u < STEPS; ++u)
+#pragma unroll
+                for (int p = 0; p < NPASS; ++p)
+                    acc[p][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfr[it & 1][p][u], acc[p][u], 0, 0, 0);
+#ifndef S2_NO_ITER_BARRIER
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+        // (S = 120: the loop reaches load 0 of the next keyframe only; its load 1 takes the buffer the last group has just left)
+        if constexpr (NL == NGR + 1) F[1] = *reinterpret_cast<const u32x4 *>(base_nxt + load_off(1));
+#else
     constexpr int RS = C::RS, DA = RS - 1;             // ring slots: iteration i consumes slot i % RS and refills slot (i - 1) % RS,
     constexpr int NB = RS % 2 == 0 ? 2 : 3;            // whose value died an iteration ago -- no register copies; B fragments one
     static_assert(NIT % RS == 0 && RS % NB == 0, "");  // iteration ahead in NB buffers that the unrolled ring indexes statically
@@ -1344,8 +1433,6 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
 #pragma unroll
     for (int sl = 0; sl < DA; ++sl) issueA(sl);
     int b_cur = first_shift(0), b_nxt = first_shift(1);
-    const unsigned int q_lds = (unsigned int)((cq >> 2) * QUAD + (cq & 3) * 64 + j4 * 16);
-    const int up16 = ((lane + 16) & 63) * 4;           // ds_bpermute address of the lane that holds the next four rows of this column
     for (int k = 0; k < nk; ++k) {
         // scan sector that meets keyframe sector 0 in pass p: first shift + W - 1 - 13 p
         unsigned int offB[NPASS];
@@ -1394,6 +1481,7 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#endif
         // ---- this keyframe's 16 x 16 tiles: lane (q, j) holds rows 4j .. 4j+3 of scan q ----
         {
             const int idx = gw + k * waves_part;
