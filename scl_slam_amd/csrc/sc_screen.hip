@@ -1391,6 +1391,10 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
                                   : *reinterpret_cast<const u32x4 *>(base_nxt + load_off(j - NL));
             }
             if (it + 1 < NIT) readB(bfr[(it + 1) & 1], it + 1);   // the next iteration's B fragments
+#ifndef S2_NO_READ_PIN
+            __builtin_amdgcn_sched_barrier(0);           // (pinned ahead of this iteration's products: left alone, the scheduler reuses the
+                                                         //  registers the products are reading and issues the reads behind the third of them)
+#endif
             u32x4 fr = F[g % 3];
             if (o != 0) {
                 const u32x4 f0 = F[g % 3], f1 = F[(g + 1) % 3];
