@@ -1202,6 +1202,12 @@ hipError_t launch_sc_select_batch(const ScreenBatch &sb, hipStream_t stream)
 #ifndef S2_FRAG_SHIFT
 #define S2_FRAG_SHIFT 1               // products, second form: three of four keyframe fragments by row shifts of loaded ones (0: every fragment loaded)
 #endif
+#ifndef S2NBUF_A
+#define S2NBUF_A 9                    // fragment buffers of the products' second form (loads per keyframe: 9 at S = 120, 12 at S = 180)
+#endif
+#ifndef S2NBUF_B
+#define S2NBUF_B 3
+#endif
 #ifndef S2RS_A
 #define S2RS_A 10
 #endif
@@ -1226,11 +1232,15 @@ hipError_t launch_sc_select_batch(const ScreenBatch &sb, hipStream_t stream)
 #ifndef S2XW_B
 #define S2XW_B 2
 #endif
+#ifdef S2_STAMP
+// experiments only (scripts/build_variant.sh): s_memtime of one wave of two workgroups at every iteration of its second keyframe
+__device__ unsigned long long g_s2_stamps[4 * 64];
+#endif
 template <int RG, int S, int W> struct S2Cfg;
 // WV: waves of the products per workgroup; XW: EXTRA waves of the same workgroup that align the NEXT batch and finish the PREVIOUS
 // one beside the products (sc_screen2_kernel): the products leave two thirds of the vector and matrix-core issue slots idle
-template <> struct S2Cfg<16, 120, 13> { static constexpr int NP = 2, NPASS = 1, STEPS = 4, NQ = 16, RS = S2RS_A, WV = S2WV_A, WVF = S2WVF_A, XW = S2XW_A; };   // RS: ring slots of fragment loads (RS - 1 in flight);
-template <> struct S2Cfg<20, 180, 19> { static constexpr int NP = 3, NPASS = 2, STEPS = 4, NQ = 12, RS = 9, WV = S2WV_B, WVF = 8, XW = S2XW_B; };    // S / STEPS iterations per keyframe = a multiple of RS
+template <> struct S2Cfg<16, 120, 13> { static constexpr int NP = 2, NPASS = 1, STEPS = 4, NQ = 16, RS = S2RS_A, WV = S2WV_A, WVF = S2WVF_A, XW = S2XW_A, NBUF = S2NBUF_A; };   // RS: ring slots of fragment loads (RS - 1 in flight);
+template <> struct S2Cfg<20, 180, 19> { static constexpr int NP = 3, NPASS = 2, STEPS = 4, NQ = 12, RS = 9, WV = S2WV_B, WVF = 8, XW = S2XW_B, NBUF = S2NBUF_B; };    // S / STEPS iterations per keyframe = a multiple of RS
 constexpr int kS2PassRows = 13;                    // shift rows per pass: row m of pass p = shift W - 1 - 13 p - m
 
 // LDS image of the scans (see above): quad stride in bytes, 2 mod 4 sixteen-byte slots
@@ -1285,31 +1295,13 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
     const int waves_part = (fa.nwg / NP) * WVP;
     const int gw = gi * WVP + wave;
 
-    // ---- stage the scans' ring part (the last STEPS - 1 sectors repeat the first) ----
-    for (int idx = threadIdx.x; idx < NQ * ROWS * 4; idx += blockDim.x) {
-        const int q = idx / (ROWS * 4), rem = idx - q * (ROWS * 4);
-        const int sx = rem >> 2, ch = rem & 3;
-        const int sct = sx < S ? sx : sx - S;
-        const unsigned char *src = reinterpret_cast<const unsigned char *>(ab.hdesc + (size_t)ab.q[q].slot * HS) + (size_t)sct * SB + part * 64 + ch * 16;
-        *reinterpret_cast<uint4 *>(smem2 + (size_t)(q >> 2) * QUAD + sx * 256 + (q & 3) * 64 + ch * 16) = *reinterpret_cast<const uint4 *>(src);
-    }
-    __syncthreads();
-    if (FUSED && wave >= WVP) {                        // ---- the extra waves: next batch's alignment, previous batch's finishing ----
-        const int xw = wave - WVP;
-        const int xg = b * C::XW + xw, xtotal = (int)gridDim.x * C::XW;
-#if S2XPRIO > 0
-        __builtin_amdgcn_s_setprio(S2XPRIO);           // few instructions, long dependent chains: issue them ahead of the products' waves
+#ifdef S2_STAMP
+#define S2_STAMP_AT(slot) do { if ((wave == 0 || wave == 5) && (b == 0 || b == 37) && lane == 0) g_s2_stamps[((b ? 2 : 0) + (wave ? 1 : 0)) * 64 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define S2_STAMP_AT(slot) do { } while (0)
 #endif
-        unsigned char *xs = smem2 + s2_lds<RG, S, W>() + (size_t)xw * s2_xlds<S>();
-        if (xa.a_n > 0) sc_align2_role<S, W>(xa.next, xa.halign, xa.a_lo, xa.a_n, xg, xtotal, xs);
-        if (xa.f_nb64 > 0) sc_screen2_finish_waves<RG, S, W>(xa.prev, xa.f_nb64, xg, xtotal, xs);
-        return;
-    }
-    if (gw >= fa.u_n) return;
-#ifdef S2_NO_PRODUCTS
-    return;                                            // experiment: what the extra waves take on their own
-#endif
-
+    S2_STAMP_AT(32);
+    const bool xwave = FUSED && wave >= WVP;           // an extra wave (alignment / finishing): no part in the products
     const int c16 = lane & 15, j4 = lane >> 4;         // A: row m = c16; B / output: scan q = c16
     // columns past the launch's scans shadow the column 12 below: the SAME address as a lane of the same ds_read_b128 group
     // (lanes 12-15 beside 0-3, 28-31 beside 16-19, ...): a broadcast.  (Shadowing column c - 4 put them on the slots of
@@ -1324,6 +1316,7 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
     auto kf_base = [&](int k) -> const unsigned char * {
         int idx = gw + k * waves_part;
         idx = idx < fa.u_n ? idx : fa.u_n - 1;
+        idx = idx < 0 ? 0 : idx;
         return hd + (size_t)(fa.u_lo + idx) * (size_t)(HS * 8);
     };
     auto first_shift = [&](int k) -> int {             // scan q's first shift for the wave's k-th keyframe (0 where it has none)
@@ -1333,71 +1326,148 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
         const bool ok = ci >= 0 && ci < sq.n;
         return starts_q[ok ? ci : 0];
     };
-    const int nk = (fa.u_n - gw + waves_part - 1) / waves_part;
+    const int nk = gw < fa.u_n ? (fa.u_n - gw + waves_part - 1) / waves_part : 0;
     const unsigned int q_lds = (unsigned int)((cq >> 2) * QUAD + (cq & 3) * 64 + j4 * 16);
     const int up16 = ((lane + 16) & 63) * 4;           // ds_bpermute address of the lane that holds the next four rows of this column
-#if S2_FRAG_SHIFT
     // The fragment of iteration i (keyframe sectors 4 i + m, m = 0 .. 15) shares twelve of its sixteen sectors with the one before: only
     // every FOURTH fragment is loaded (sectors 16 g + m: the same 1 KB load, a quarter as many), the three between come out of two loaded
     // ones by row shifts inside the rows of 16 lanes -- lane m of offset 4 o takes lane m + 4 o of load g, or lane m + 4 o - 16 of load
-    // g + 1 (two DPP moves per register).  The texture addresser, the busiest unit of this kernel (64 %), sees a quarter of the requests;
-    // three loads of 16 sectors are held (12 registers) instead of a ring of ten fragments (40).
+    // g + 1 (two DPP moves per register).  The texture addresser, the busiest unit of the kernel while every fragment was loaded
+    // (TA_BUSY = the kernel's duration), sees a quarter of the requests.
     constexpr int NGR = (NIT + 3) / 4;                  // groups of four iterations per keyframe (the last may be short)
     constexpr int NL = ((NIT - 1) % 4 == 0) ? NGR : NGR + 1;   // loads per keyframe: the last group needs load NGR only if it has a derived fragment
-    static_assert(NL % 3 == 0, "three buffers, statically indexed across keyframes");
+    // NBUF buffers, statically indexed across keyframes (NL % NBUF == 0): load j lives in F[j % NBUF] from its issue -- NBUF - 1 groups
+    // ahead of the group that multiplies it -- to the last fragment derived from it.  Measured with three buffers (two groups ahead):
+    // every fourth iteration waited 450-1000 cycles for its load (stamps: 250 cycles per iteration, 700-1300 where a group begins).
+    constexpr int NBUF = C::NBUF;
+    static_assert(NL % NBUF == 0 && NBUF >= 3, "fragment buffers");
     // lane (m, j4) of load g reads sector 16 g + m; the image's rows end at sector S + 15 (the last load's upper lanes stay inside)
     auto load_off = [&](int g) -> unsigned int { const int sct = 16 * g + c16; return a_lane + (unsigned int)((sct <= S + 15 ? sct : S + 15) - c16) * 16u; };
-    u32x4 F[3];
+    u32x4 F[NBUF];
     const unsigned char *base_cur = kf_base(0), *base_nxt = kf_base(1);
-    F[0] = *reinterpret_cast<const u32x4 *>(base_cur + load_off(0));
-    F[1] = *reinterpret_cast<const u32x4 *>(base_cur + load_off(1));
-    int b_cur = first_shift(0), b_nxt = first_shift(1);
-    for (int k = 0; k < nk; ++k) {
-        // Scan sector that meets keyframe sector 0 in pass p: c0 = first shift + W - 1 - 13 p; iteration `it` reads sectors c0 + 4 it .. + 3
-        // (mod S; the image repeats STEPS - 1 sectors so that the reads of an iteration never wrap).  The lane's address is ONE of two
-        // fixed bases -- before and after its wrap -- plus a compile-time offset of 1 KB per iteration: a compare and a select per
-        // iteration and pass instead of the running pointer's five instructions (the vector issue port is what binds this kernel).
-        const unsigned char *preB[NPASS], *postB[NPASS];  // (pointers: the image's base address is added once per keyframe, not per read)
-        int wrapB[NPASS];                                // first iteration that reads from the wrapped base
+    int b_cur = 0, b_nxt = 0;
+    // ---- stage the scans' ring part (the last STEPS - 1 sectors repeat the first).  Eight 16-byte pieces per thread are requested
+    // before the first is stored (one piece at a time, the loop paid a memory round trip per piece: 12.5 k cycles per workgroup, a fifth
+    // of the kernel).  Behind the LAST batch's requests and in front of its stores go the wave's first keyframe fragments and first
+    // shifts: they do not depend on the image, their round trip to HBM (6-9 k cycles when they followed the barrier) passes under the
+    // stores and the barrier, and -- loads return in order -- the scans' pieces, which come out of the L2, are not held up behind them ----
+    {
+        // One scan per wave and turn (16 scans, 16 waves): the scan -- its slot in the database, its place in the image -- is a scalar, a
+        // piece's sector and chunk are shifts of the lane index.  (Dealt out piece by piece over the workgroup's threads, every piece
+        // cost a division and a per-lane read of the launch's argument block for its scan's slot: the waves took 5-10 k cycles to ISSUE
+        // their requests, and the workgroup met at the barrier 15 k cycles into the kernel -- a quarter of it.)
+        constexpr int NWV = s2_waves<RG, S, W, FUSED>(), NPIECE = ROWS * 4, BATCH = 8;
+        constexpr int NBATCH = (NPIECE + BATCH * kWave - 1) / (BATCH * kWave);
+        static_assert(NBATCH <= 2 && NQ <= 2 * NWV, "staging turns");
+        // (named variables, straight-line code: as arrays -- behind lambdas or inside macros' loops -- the pieces were placed in scratch)
+        uint4 pc0, pc1, pc2, pc3, pc4, pc5, pc6, pc7;
+        unsigned int ds0, ds1, ds2, ds3, ds4, ds5, ds6, ds7;
+#define S2_STAGE_RQ(BASE, r, PC, DS)                                                                                                            \
+        {                                                                                                                                       \
+            const int idx0 = (BASE) + (r) * kWave + lane;                                                                                       \
+            const int idx = idx0 < NPIECE ? idx0 : NPIECE - 1;                                                                                  \
+            const int sx = idx >> 2, ch = idx & 3;                                                                                              \
+            const int sct = sx < S ? sx : sx - S;                                                                                               \
+            PC = *reinterpret_cast<const uint4 *>(sbase + (unsigned int)(sct * SB + ch * 16));                                                  \
+            DS = dbase + (unsigned int)(sx * 256 + ch * 16);                                                                                    \
+        }
+#define S2_STAGE_ST(BASE, r, PC, DS) if ((BASE) + (r) * kWave + lane < NPIECE) *reinterpret_cast<uint4 *>(smem2 + DS) = PC;
+#define S2_STAGE_REQUEST(BASE) S2_STAGE_RQ(BASE, 0, pc0, ds0) S2_STAGE_RQ(BASE, 1, pc1, ds1) S2_STAGE_RQ(BASE, 2, pc2, ds2) S2_STAGE_RQ(BASE, 3, pc3, ds3) \
+                               S2_STAGE_RQ(BASE, 4, pc4, ds4) S2_STAGE_RQ(BASE, 5, pc5, ds5) S2_STAGE_RQ(BASE, 6, pc6, ds6) S2_STAGE_RQ(BASE, 7, pc7, ds7)
+#define S2_STAGE_STORE(BASE) S2_STAGE_ST(BASE, 0, pc0, ds0) S2_STAGE_ST(BASE, 1, pc1, ds1) S2_STAGE_ST(BASE, 2, pc2, ds2) S2_STAGE_ST(BASE, 3, pc3, ds3) \
+                             S2_STAGE_ST(BASE, 4, pc4, ds4) S2_STAGE_ST(BASE, 5, pc5, ds5) S2_STAGE_ST(BASE, 6, pc6, ds6) S2_STAGE_ST(BASE, 7, pc7, ds7)
+        // (a second turn only where the workgroup has fewer waves than the launch has scans: the fused experiment's 12 + 4)
+        if (wave + NWV < NQ) {
+            const int q2 = wave + NWV;
+            const unsigned char *sbase = reinterpret_cast<const unsigned char *>(ab.hdesc + (size_t)ab.q[q2].slot * HS) + part * 64;
+            const unsigned int dbase = (unsigned int)((q2 >> 2) * QUAD + (q2 & 3) * 64);
+            if constexpr (NBATCH == 2) { S2_STAGE_REQUEST(0) S2_STAGE_STORE(0) }
+            S2_STAGE_REQUEST((NBATCH - 1) * BATCH * kWave)
+            S2_STAGE_STORE((NBATCH - 1) * BATCH * kWave)
+        }
+        const int q1 = wave < NQ ? wave : NQ - 1;
+        const unsigned char *sbase = reinterpret_cast<const unsigned char *>(ab.hdesc + (size_t)ab.q[q1].slot * HS) + part * 64;
+        const unsigned int dbase = (unsigned int)((q1 >> 2) * QUAD + (q1 & 3) * 64);
+        if constexpr (NBATCH == 2) { S2_STAGE_REQUEST(0) S2_STAGE_STORE(0) }
+        S2_STAGE_REQUEST((NBATCH - 1) * BATCH * kWave)
+        S2_STAMP_AT(61);
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int NPRE = NBUF - 1 < 4 ? NBUF - 1 : 4;     // (the pieces in flight + every fragment buffer would not fit the registers)
+        if (!xwave) {
+#pragma unroll
+            for (int j = 0; j < NPRE; ++j) F[j] = *reinterpret_cast<const u32x4 *>(base_cur + load_off(j));
+            b_cur = first_shift(0); b_nxt = first_shift(1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        S2_STAMP_AT(62);
+        if (wave < NQ) { S2_STAGE_STORE((NBATCH - 1) * BATCH * kWave) }
+        S2_STAMP_AT(63);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!xwave) {
+#pragma unroll
+            for (int j = NPRE; j < NBUF - 1; ++j) F[j] = *reinterpret_cast<const u32x4 *>(base_cur + load_off(j));
+        }
+    }
+    __syncthreads();
+    S2_STAMP_AT(33);
+    if (xwave) {                                       // ---- the extra waves: next batch's alignment, previous batch's finishing ----
+        const int xw = wave - WVP;
+        const int xg = b * C::XW + xw, xtotal = (int)gridDim.x * C::XW;
+#if S2XPRIO > 0
+        __builtin_amdgcn_s_setprio(S2XPRIO);           // few instructions, long dependent chains: issue them ahead of the products' waves
+#endif
+        unsigned char *xs = smem2 + s2_lds<RG, S, W>() + (size_t)xw * s2_xlds<S>();
+        if (xa.a_n > 0) sc_align2_role<S, W>(xa.next, xa.halign, xa.a_lo, xa.a_n, xg, xtotal, xs);
+        if (xa.f_nb64 > 0) sc_screen2_finish_waves<RG, S, W>(xa.prev, xa.f_nb64, xg, xtotal, xs);
+        return;
+    }
+    if (gw >= fa.u_n) return;
+#ifdef S2_NO_PRODUCTS
+    return;                                            // experiment: what the extra waves take on their own
+#endif
+    // Scan sector that meets keyframe sector 0 in pass p: c0 = first shift + W - 1 - 13 p; iteration `it` reads sectors c0 + 4 it .. + 3
+    // (mod S; the image repeats STEPS - 1 sectors so that the reads of an iteration never wrap).  The lane's address is ONE of two
+    // fixed bases -- before and after its wrap -- plus a compile-time offset of 1 KB per iteration: a compare and a select per
+    // iteration and pass instead of the running pointer's five instructions (the vector issue port is what binds this kernel).
+    const unsigned char *preB[NPASS], *postB[NPASS];      // (pointers: the image's base address is added once per keyframe, not per read)
+    int wrapB[NPASS];                                    // first iteration that reads from the wrapped base
+    auto scan_bases = [&](const int first) {
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
-            int c0 = b_cur + (W - 1) - kS2PassRows * p;
+            int c0 = first + (W - 1) - kS2PassRows * p;
             c0 = c0 >= S ? c0 - S : c0;
             preB[p] = smem2 + (q_lds + (unsigned int)c0 * 256u);
             postB[p] = preB[p] - S * 256;
             wrapB[p] = (S - c0 + STEPS - 1) / STEPS;     // smallest it with c0 + 4 it >= S
         }
-        auto readB = [&](h8 (&dst)[NPASS][STEPS], const int it) {
+    };
+    auto readB = [&](h8 (&dst)[NPASS][STEPS], const int it) {
 #pragma unroll
-            for (int p = 0; p < NPASS; ++p) {
-                const unsigned char *qp = (it < wrapB[p] ? preB[p] : postB[p]) + it * STEPS * 256;
+        for (int p = 0; p < NPASS; ++p) {
+            const unsigned char *qp = (it < wrapB[p] ? preB[p] : postB[p]) + it * STEPS * 256;
 #pragma unroll
-                for (int u = 0; u < STEPS; ++u) dst[p][u] = *reinterpret_cast<const h8 *>(qp + 256 * u);
-            }
-        };
+            for (int u = 0; u < STEPS; ++u) dst[p][u] = *reinterpret_cast<const h8 *>(qp + 256 * u);
+        }
+    };
+    h8 bfr[2][NPASS][STEPS];
+    scan_bases(b_cur);
+    readB(bfr[0], 0);
+    for (int k = 0; k < nk; ++k) {
         f4v acc[NPASS][STEPS];
 #pragma unroll
         for (int p = 0; p < NPASS; ++p)
 #pragma unroll
             for (int u = 0; u < STEPS; ++u) acc[p][u] = f4v{0.f, 0.f, 0.f, 0.f};
-        h8 bfr[2][NPASS][STEPS];
-        readB(bfr[0], 0);
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int g = it >> 2, o = it & 3;
-            if (o == 0) {                                // the load two groups ahead: from the next keyframe at this one's end
-                const int j = g + 2;
-                F[j % 3] = j < NL ? *reinterpret_cast<const u32x4 *>(base_cur + load_off(j))
-                                  : *reinterpret_cast<const u32x4 *>(base_nxt + load_off(j - NL));
-            }
-            if (it + 1 < NIT) readB(bfr[(it + 1) & 1], it + 1);   // the next iteration's B fragments
-#ifndef S2_NO_READ_PIN
-            __builtin_amdgcn_sched_barrier(0);           // (pinned ahead of this iteration's products: left alone, the scheduler reuses the
-                                                         //  registers the products are reading and issues the reads behind the third of them)
-#endif
-            u32x4 fr = F[g % 3];
+        if (k < 6) S2_STAMP_AT(34 + 3 * k);
+        // The fragment of iteration it + 1 is formed WHILE iteration it multiplies: its eight row-shift moves have no part in this
+        // iteration's products, so they are dealt out between them -- one matrix product, two moves, ... -- and fill the eight cycles in
+        // which a matrix product lets the SIMD issue other vector instructions; formed in front of the products they need, the moves
+        // were a serial stretch of every iteration.
+        auto fragment_of = [&](const int it2) -> u32x4 {
+            const int g = it2 >> 2, o = it2 & 3;
+            u32x4 fr = F[g % NBUF];
             if (o != 0) {
-                const u32x4 f0 = F[g % 3], f1 = F[(g + 1) % 3];
+                const u32x4 f0 = F[g % NBUF], f1 = F[(g + 1) % NBUF];
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     // lanes m >= 16 - 4 o: lane m - (16 - 4 o) of the next load; lanes below: lane m + 4 o of this one
@@ -1411,81 +1481,59 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
                     fr[d] = (unsigned int)t;
                 }
             }
-            const h8 af = __builtin_bit_cast(h8, fr);
+            return fr;
+        };
+        u32x4 fr_cur = F[0];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int g = it >> 2, o = it & 3;
+#ifdef S2_STAMP
+            if (k == 1 && (wave == 0 || wave == 5) && (b == 0 || b == 37) && lane == 0)
+                g_s2_stamps[((b ? 2 : 0) + (wave ? 1 : 0)) * 64 + it] = __builtin_amdgcn_s_memtime();
+#endif
+            if (o == 0) {                                // the load NBUF - 1 groups ahead: from the next keyframe towards this one's end
+                const int j = g + NBUF - 1;                  // (its buffer held load g - 1, whose last fragment was formed two iterations ago)
+                if (j < NL) F[j % NBUF] = *reinterpret_cast<const u32x4 *>(base_cur + load_off(j));
+                else if (j - NL < NBUF - 1) F[j % NBUF] = *reinterpret_cast<const u32x4 *>(base_nxt + load_off(j - NL));
+            }
+            if (it + 1 < NIT) readB(bfr[(it + 1) & 1], it + 1);   // the next iteration's B fragments
+#ifndef S2_NO_READ_PIN
+            __builtin_amdgcn_sched_barrier(0);           // (pinned ahead of this iteration's products: left alone, the scheduler reuses the
+                                                         //  registers the products are reading and issues the reads behind the third of them)
+#endif
+            u32x4 fr_nxt = fr_cur;
+            if (it + 1 < NIT) fr_nxt = fragment_of(it + 1);
+            const h8 af = __builtin_bit_cast(h8, fr_cur);
 #pragma unroll
             for (int u = 0; u < STEPS; ++u)
 #pragma unroll
                 for (int p = 0; p < NPASS; ++p)
                     acc[p][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfr[it & 1][p][u], acc[p][u], 0, 0, 0);
+#ifndef S2_NO_INTERLEAVE
+            if (it + 1 < NIT && ((it + 1) & 3) != 0) {
+#pragma unroll
+                for (int x = 0; x < STEPS * NPASS; ++x) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     // one matrix product
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8 / (STEPS * NPASS), 0);   // its share of the eight moves
+                }
+            }
+#endif
 #ifndef S2_NO_ITER_BARRIER
             __builtin_amdgcn_sched_barrier(0);
 #endif
+            fr_cur = fr_nxt;
         }
-        // (S = 120: the loop reaches load 0 of the next keyframe only; its load 1 takes the buffer the last group has just left)
-        if constexpr (NL == NGR + 1) F[1] = *reinterpret_cast<const u32x4 *>(base_nxt + load_off(1));
-#else
-    constexpr int RS = C::RS, DA = RS - 1;             // ring slots: iteration i consumes slot i % RS and refills slot (i - 1) % RS,
-    constexpr int NB = RS % 2 == 0 ? 2 : 3;            // whose value died an iteration ago -- no register copies; B fragments one
-    static_assert(NIT % RS == 0 && RS % NB == 0, "");  // iteration ahead in NB buffers that the unrolled ring indexes statically
-    u32x4 ringA[RS];
-    const unsigned char *base_cur = kf_base(0), *base_nxt = kf_base(1);
-    const unsigned char *pA = base_cur;                // wave-uniform: the keyframe's base + 16 STEPS bytes per iteration issued
-    auto issueA = [&](int sl) {
-        ringA[sl] = *reinterpret_cast<const u32x4 *>(pA + a_lane);
-        pA += 16 * STEPS;
-    };
+        if (k < 6) S2_STAMP_AT(35 + 3 * k);
+        // (the loads of the next keyframe that no group of this one reached: their buffers are free now)
 #pragma unroll
-    for (int sl = 0; sl < DA; ++sl) issueA(sl);
-    int b_cur = first_shift(0), b_nxt = first_shift(1);
-    for (int k = 0; k < nk; ++k) {
-        // scan sector that meets keyframe sector 0 in pass p: first shift + W - 1 - 13 p
-        unsigned int offB[NPASS];
-#pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
-            int c0 = b_cur + (W - 1) - kS2PassRows * p;
-            c0 = c0 >= S ? c0 - S : c0;
-            offB[p] = q_lds + (unsigned int)c0 * 256u;
-        }
-        auto readB = [&](h8 (&dst)[NPASS][STEPS]) {
-#pragma unroll
-            for (int p = 0; p < NPASS; ++p) {
-                const unsigned char *qp = smem2 + offB[p];
-#pragma unroll
-                for (int u = 0; u < STEPS; ++u) dst[p][u] = *reinterpret_cast<const h8 *>(qp + 256 * u);
-                offB[p] += (unsigned int)STEPS * 256u;
-                const unsigned int t = offB[p] - (unsigned int)(S * 256);
-                offB[p] = (int)t >= (int)q_lds ? t : offB[p];
-            }
-        };
-        f4v acc[NPASS][STEPS];
-#pragma unroll
-        for (int p = 0; p < NPASS; ++p)
-#pragma unroll
-            for (int u = 0; u < STEPS; ++u) acc[p][u] = f4v{0.f, 0.f, 0.f, 0.f};
-        h8 bfr[NB][NPASS][STEPS];
-        readB(bfr[0]);
-#pragma unroll 1
-        for (int r = 0; r < NIT / RS; ++r) {
-#pragma unroll
-            for (int xb = 0; xb < RS; ++xb) {
-                // the load DA iterations ahead: from the next keyframe for the last DA iterations of this one
-                if (xb == RS - DA) pA = (r == NIT / RS - 1) ? base_nxt : pA;
-                issueA((xb + RS - 1) % RS);
-                readB(bfr[(xb + 1) % NB]);                                       // the next iteration's B fragments (past the end: unused)
-                // The fragment is NOT rotated between the k-steps of an iteration: k-step u (scan sector 4 t + u) meets fragment row m =
-                // keyframe sector 4 t + m, so row m of acc[.][u] collects what the rotated fragment would have put in row m - u -- the
-                // same products in the same order, in another row; the rows are shifted back once per keyframe (below) instead of
-                // twelve DPP moves per iteration.
-                const h8 af = __builtin_bit_cast(h8, ringA[xb]);
-#pragma unroll
-                for (int u = 0; u < STEPS; ++u)
-#pragma unroll
-                    for (int p = 0; p < NPASS; ++p)
-                        acc[p][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfr[xb % NB][p][u], acc[p][u], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-#endif
+        for (int j = NGR + NBUF - 1 - NL; j < NBUF - 1; ++j)
+            if (j >= 0) F[j % NBUF] = *reinterpret_cast<const u32x4 *>(base_nxt + load_off(j));
+        // the next keyframe's first reads of the scans, ahead of this keyframe's tiles (the first buffer is free: the exchanges and
+        // stores below used to stand between a keyframe's last product and the next one's first read)
+        static_assert(NIT >= 2, "");
+        scan_bases(b_nxt);
+        if constexpr (((NIT - 1) & 1) == 0) __builtin_amdgcn_sched_barrier(0);   // (the last iteration multiplied out of the first buffer)
+        readB(bfr[0], 0);
         // ---- this keyframe's 16 x 16 tiles: lane (q, j) holds rows 4j .. 4j+3 of scan q ----
         {
             const int idx = gw + k * waves_part;
@@ -1510,7 +1558,9 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
         }
         base_cur = base_nxt; base_nxt = kf_base(k + 2);
         b_cur = b_nxt; b_nxt = first_shift(k + 2);
+        if (k < 6) S2_STAMP_AT(36 + 3 * k);
     }
+    S2_STAMP_AT(60);
 }
 
 // the ring parts of every pair meet: d~ = min_t (1 - sim[t] / n_eff[t]), flags, the launch's smallest d~ per scan
@@ -2019,3 +2069,10 @@ bool sc_screen_can_defer(const DbView &db, int SR, int nq)
 }
 
 }  // namespace scl
+
+#ifdef S2_STAMP
+extern "C" int scl_debug_s2_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(scl::g_s2_stamps), sizeof(unsigned long long) * 4 * 64);
+}
+#endif
