@@ -1342,7 +1342,9 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
     constexpr int NBUF = C::NBUF;
     static_assert(NL % NBUF == 0 && NBUF >= 3, "fragment buffers");
     // lane (m, j4) of load g reads sector 16 g + m; the image's rows end at sector S + 15 (the last load's upper lanes stay inside)
-    auto load_off = [&](int g) -> unsigned int { const int sct = 16 * g + c16; return a_lane + (unsigned int)((sct <= S + 15 ? sct : S + 15) - c16) * 16u; };
+    // (sectors past the keyframe's last are its first again: read where they were read before -- those lines are in the L2, the image's
+    //  16 repeated sectors per row would come from HBM: 1.5 KB per keyframe, 15 MB per launch)
+    auto load_off = [&](int g) -> unsigned int { const int sct = 16 * g + c16; return a_lane + (unsigned int)((sct < S ? sct : (sct - S < S ? sct - S : 0)) - c16) * 16u; };
     u32x4 F[NBUF];
     const unsigned char *base_cur = kf_base(0), *base_nxt = kf_base(1);
     int b_cur = 0, b_nxt = 0;
@@ -1583,25 +1585,50 @@ __device__ __forceinline__ void build_rotq(const unsigned int *q_kmask, uint4 *r
     }
 }
 
-// one pair (scan qi of the batch, position ci of its range): returns its contribution to the launch's smallest d~
+// one pair (scan qi of the batch, position ci of its range): returns its contribution to the launch's smallest d~.
+// In two steps: everything the pair reads from memory is REQUESTED first (one batch: the keyframe's mask, the first shift, the partial
+// sums, the keyframe's tiled ring key), then -- in the workgroup form behind the barrier that publishes the scan's rotated masks --
+// the distances are formed.  Written as one step the compiler waited for the loads two at a time: six memory round trips behind each
+// other in a kernel that is nothing but round trips (2.4 waves per SIMD, all resident at once).
 template <int RG, int S, int W>
-__device__ __forceinline__ float sc_screen2_finish_pair(const Screen2Args &fa, const ScreenArgs &a, const int qi, const int ci, const uint4 *rotq, const bool q_bad)
+struct FinishLoads {
+    static constexpr int NPF = S2Cfg<RG, S, W>::NP * S2Cfg<RG, S, W>::NPASS * 4;
+    static constexpr int MW = (((S + 63) / 64) + 1) / 2;
+    static constexpr bool kRingUpFront = NPF * 4 + RG * 4 <= 100;                // (registers: the 80 x 180 grid asks for its ring key later)
+    uint4 km[MW]; unsigned int kflag; int b_raw; f4v pv[NPF]; float4 bk[kRingUpFront ? RG : 1];
+};
+template <int RG, int S, int W>
+__device__ __forceinline__ FinishLoads<RG, S, W> sc_screen2_finish_request(const Screen2Args &fa, const ScreenArgs &a, const int qi, const int ci)
+{
+    using L = FinishLoads<RG, S, W>;
+    using C = S2Cfg<RG, S, W>;
+    const ScreenBatchArgs &ab = fa.prod;
+    L l;
+    const unsigned int *kp = a.kmask + (size_t)(a.slot_base + ci) * 8;
+#pragma unroll
+    for (int i = 0; i < L::MW; ++i) l.km[i] = *reinterpret_cast<const uint4 *>(kp + 4 * i);
+    l.kflag = kp[7];
+    l.b_raw = a.starts[ci];
+    const f4v *pp = reinterpret_cast<const f4v *>(fa.part + ((size_t)qi * (size_t)ab.pair_stride + (size_t)ci) * (C::NP * C::NPASS * 16));
+#pragma unroll
+    for (int i = 0; i < L::NPF; ++i) l.pv[i] = pp[i];
+    if constexpr (L::kRingUpFront) {
+        const int slot = a.slot_base + ci;
+#pragma unroll
+        for (int r = 0; r < RG; ++r) l.bk[r] = a.rkey4[(size_t)r * a.rk_cap + slot];
+    }
+    return l;
+}
+template <int RG, int S, int W>
+__device__ __forceinline__ float sc_screen2_finish_compute(const ScreenArgs &a, const int ci, const uint4 *rotq, const bool q_bad, FinishLoads<RG, S, W> &l)
 {
     using C = S2Cfg<RG, S, W>;
-    constexpr int NP = C::NP, NPASS = C::NPASS;
-    constexpr int NW64 = (S + 63) / 64, MW = (NW64 + 1) / 2;
-    const ScreenBatchArgs &ab = fa.prod;
+    using L = FinishLoads<RG, S, W>;
+    constexpr int NP = C::NP, NPASS = C::NPASS, MW = L::MW;
     const float kInf = __int_as_float(0x7f800000);
-    const unsigned int *kp = a.kmask + (size_t)(a.slot_base + ci) * 8;
-    uint4 km[MW];
-#pragma unroll
-    for (int i = 0; i < MW; ++i) km[i] = *reinterpret_cast<const uint4 *>(kp + 4 * i);
-    const unsigned int kflag = kp[7];
-    if (MW == 2) km[MW - 1].w = 0u;                                          // word 7 is the flag, not sector bits
-    const int b_raw = a.starts[ci];
-    const bool b_open = b_raw < 0;                                           // kAlignUndecided: scored by the exact pass
-    const int b0 = b_open ? 0 : b_raw;
-    const f4v *pp = reinterpret_cast<const f4v *>(fa.part + ((size_t)qi * (size_t)ab.pair_stride + (size_t)ci) * (NP * NPASS * 16));
+    if (MW == 2) l.km[MW - 1].w = 0u;                                        // word 7 is the flag, not sector bits
+    const bool b_open = l.b_raw < 0;                                         // kAlignUndecided: scored by the exact pass
+    const int b0 = b_open ? 0 : l.b_raw;
     float dmin = kInf;
     float dsh[W];                                                            // the screened distance of every shift (+inf: no effective sector)
 #pragma unroll
@@ -1610,9 +1637,9 @@ __device__ __forceinline__ float sc_screen2_finish_pair(const Screen2Args &fa, c
     for (int p = 0; p < NPASS; ++p) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            f4v sm = pp[p * 4 + g4];                                         // part 0
+            f4v sm = l.pv[p * 4 + g4];                                       // part 0
 #pragma unroll
-            for (int h = 1; h < NP; ++h) sm += pp[(h * NPASS + p) * 4 + g4];
+            for (int h = 1; h < NP; ++h) sm += l.pv[(h * NPASS + p) * 4 + g4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = 4 * g4 + r;                                    // row m of pass p = shift W - 1 - 13 p - m
@@ -1623,7 +1650,7 @@ __device__ __forceinline__ float sc_screen2_finish_pair(const Screen2Args &fa, c
 #pragma unroll
                 for (int i = 0; i < MW; ++i) {
                     const uint4 rq = rotq[ri * MW + i];
-                    ne += __popc(rq.x & km[i].x) + __popc(rq.y & km[i].y) + __popc(rq.z & km[i].z) + __popc(rq.w & km[i].w);
+                    ne += __popc(rq.x & l.km[i].x) + __popc(rq.y & l.km[i].y) + __popc(rq.z & l.km[i].z) + __popc(rq.w & l.km[i].w);
                 }
                 const float d = 1.0f - sm[r] / (float)ne;
                 if (ne > 0 && d < dmin) dmin = d;
@@ -1631,7 +1658,7 @@ __device__ __forceinline__ float sc_screen2_finish_pair(const Screen2Args &fa, c
             }
         }
     }
-    const bool exact_only = q_bad || kflag != 0 || b_open || !(dmin == dmin);
+    const bool exact_only = q_bad || l.kflag != 0 || b_open || !(dmin == dmin);
     a.out_approx[ci] = exact_only ? __int_as_float(0xff800000) : dmin;
     if (a.out_smask) {
         // a shift can hold (or tie for) the pair's exact minimum only if its screened distance is within 2 eps of the smallest
@@ -1648,7 +1675,8 @@ __device__ __forceinline__ float sc_screen2_finish_pair(const Screen2Args &fa, c
     float result = 0.0f;
 #pragma unroll
     for (int r = 0; r < RG; ++r) {
-        const float4 bk = a.rkey4[(size_t)r * a.rk_cap + slot];
+        float4 bk;
+        if constexpr (L::kRingUpFront) bk = l.bk[r]; else bk = a.rkey4[(size_t)r * a.rk_cap + slot];
         const float4 qk = *reinterpret_cast<const float4 *>(a.q_rkey + 4 * r);
         const float d0 = qk.x - bk.x, d1 = qk.y - bk.y, d2 = qk.z - bk.z, d3 = qk.w - bk.w;
         const float grp = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
@@ -1656,6 +1684,12 @@ __device__ __forceinline__ float sc_screen2_finish_pair(const Screen2Args &fa, c
     }
     a.out_d2[ci] = result;
     return exact_only ? kInf : dmin;
+}
+template <int RG, int S, int W>
+__device__ __forceinline__ float sc_screen2_finish_pair(const Screen2Args &fa, const ScreenArgs &a, const int qi, const int ci, const uint4 *rotq, const bool q_bad)
+{
+    FinishLoads<RG, S, W> l = sc_screen2_finish_request<RG, S, W>(fa, a, qi, ci);
+    return sc_screen2_finish_compute<RG, S, W>(a, ci, rotq, q_bad, l);
 }
 
 template <int RG, int S, int W>
@@ -1666,13 +1700,15 @@ __device__ __forceinline__ void sc_screen2_finish_body(const Screen2Args &fa, co
     const ScreenArgs a = screen_args_of(ab, qi);
     __shared__ uint4 rotq[S * MW];
     __shared__ float wmin[4];
+    const int ci = (int)(chunk * blockDim.x + threadIdx.x);
+    const bool live = ci < a.n;
+    FinishLoads<RG, S, W> ld = sc_screen2_finish_request<RG, S, W>(fa, a, qi, live ? ci : 0);   // (a.n >= 1 where a workgroup was launched for the scan)
     build_rotq<S>(a.q_kmask, rotq, (int)threadIdx.x, (int)blockDim.x);
     const bool q_bad = a.q_kmask[7] != 0;
     __syncthreads();
-    const int ci = (int)(chunk * blockDim.x + threadIdx.x);
     const float kInf = __int_as_float(0x7f800000);
     float contrib = kInf;
-    if (ci < a.n) contrib = sc_screen2_finish_pair<RG, S, W>(fa, a, qi, ci, rotq, q_bad);
+    if (live) contrib = sc_screen2_finish_compute<RG, S, W>(a, ci, rotq, q_bad, ld);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) contrib = fminf(contrib, __shfl_xor(contrib, off, kWave));
     if ((threadIdx.x & 63) == 0) wmin[threadIdx.x >> 6] = contrib;
