@@ -193,9 +193,28 @@ __global__ __launch_bounds__(256) void ingest_kernel(
             if (c < S && usable) parts(c, &v, &vl);
             hk[c] = v; hd[c] = v; hd[SK + 8 + c] = vl;
         }
+        // |u - kh|_2: how far the fp16 key is from the unit key it stands for, rounded UP (second float behind the key).  The
+        // alignment's first stage bounds its error by Cauchy-Schwarz on these ACTUAL norms (2.4e-4 as a rule) instead of the worst
+        // case of fp16 rounding (4.9e-4 per key): the lead it demands of the best shift falls from 3e-3 to ~1e-3, and fewer pairs go
+        // on to the second stage.  An entry below fp16's normal range counts with the larger of its rounding error and its value (a
+        // matrix core may take it for zero).  Every thread forms the same sequential sum.
+        float kerr = -1.0f;
+        if (usable) {
+            double e2 = 0.0;
+            for (int c = 0; c < S; ++c) {
+                const double u = svk[c] / nrm;
+                const double kh = (double)(float)(_Float16)(float)u;
+                double d = fabs(u - kh);
+                if (fabs(kh) < 6.103515625e-05) d = fmax(d, fabs(u));
+                e2 = e2 + d * d;
+            }
+            kerr = __double2float_ru(sqrt(e2) * (1.0 + 1e-6) + 1e-10);         // (> 0 always: 0 would read as "not recorded")
+        }
         if (threadIdx.x == 0) {
             *reinterpret_cast<float *>(hk + SK) = usable ? (float)nrm : -1.0f;   // the filter's range check (negative: no decision)
             *reinterpret_cast<float *>(hd + SK) = usable ? (float)nrm : -1.0f;
+            *reinterpret_cast<float *>(hk + SK + 2) = kerr;
+            *reinterpret_cast<float *>(hd + SK + 2) = kerr;
         }
         // the alignment image (kernels.hpp: halign_*): norm, P rotated copies of either part; database slots only
         const int P = halign_P(S), CP = halign_CP(S);
@@ -211,7 +230,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(
             }
             if (threadIdx.x == 0) {
                 float *head = reinterpret_cast<float *>(img);
-                head[0] = usable ? (float)nrm : -1.0f; head[1] = 0.f; head[2] = 0.f; head[3] = 0.f;
+                head[0] = usable ? (float)nrm : -1.0f; head[1] = kerr; head[2] = 0.f; head[3] = 0.f;
             }
         }
     }

@@ -572,6 +572,7 @@ __device__ __forceinline__ void sc_align2_role(const ScreenBatchArgs &ab, const 
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) bq[kk] = *reinterpret_cast<const h8 *>(qk + 32 * kk + 8 * j4);
     const float qnorm = *reinterpret_cast<const float *>(qk + SK);
+    const float qerr = *reinterpret_cast<const float *>(qk + SK + 2);          // |q - qh| of the scan's unit key, rounded up (make_sc.hip)
     // ---- A: byte offsets of this lane's fragment starts inside a copy: (8 j - P sigma + 32 d) mod S, d = -TSTEP (NTAU - 1) .. KS - 1
     unsigned int offs[ND];
     {
@@ -598,19 +599,20 @@ __device__ __forceinline__ void sc_align2_role(const ScreenBatchArgs &ab, const 
     const unsigned int loff0 = (unsigned int)lane * 16u, loff1 = (unsigned int)(kWave + lane) * 16u;
     const bool ld1 = NLD > 1 && loff1 < (unsigned int)IMG;
     uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = make_uint4(0, 0, 0, 0);
-    float knorm_pre = 0.f;
+    float knorm_pre = 0.f, kerr_pre = 0.f;
     auto image_of = [&](int idx) { idx = idx < u_n ? idx : u_n - 1; return halign + (size_t)(u_lo + idx) * (size_t)HAB; };
     if (wave_global < u_n) {
         const unsigned char *g = image_of(wave_global);
         pre0 = *reinterpret_cast<const uint4 *>(g + 16 + loff0);
         if (NLD > 1) pre1 = *reinterpret_cast<const uint4 *>(g + 16 + (ld1 ? loff1 : 0u));
         knorm_pre = *reinterpret_cast<const float *>(g);
+        kerr_pre = *reinterpret_cast<const float *>(g + 4);
     }
     for (int idx = wave_global; idx < u_n; idx += waves_total) {
         wave_fence();                                                            // the previous keyframe's fragment reads are done
         *reinterpret_cast<uint4 *>(smem_wave + loff0) = pre0;
         if (ld1) *reinterpret_cast<uint4 *>(smem_wave + loff1) = pre1;
-        const float knorm = knorm_pre;
+        const float knorm = knorm_pre, kerr = kerr_pre;
         wave_fence();
         const unsigned char *g_cur = image_of(idx);
         {
@@ -618,6 +620,7 @@ __device__ __forceinline__ void sc_align2_role(const ScreenBatchArgs &ab, const 
             pre0 = *reinterpret_cast<const uint4 *>(g + 16 + loff0);
             if (NLD > 1) pre1 = *reinterpret_cast<const uint4 *>(g + 16 + (ld1 ? loff1 : 0u));
             knorm_pre = *reinterpret_cast<const float *>(g);
+            kerr_pre = *reinterpret_cast<const float *>(g + 4);
         }
         // ---- stage 1: the correlation tile by tile; the two largest values per scan with the largest's shift ----
         // (the shift rides in the low 8 mantissa bits of its value: a perturbation of < 3.1e-5, which the margin test allows for;
@@ -658,7 +661,11 @@ __device__ __forceinline__ void sc_align2_role(const ScreenBatchArgs &ab, const 
         // the same range conditions as sc_align_role's first stage (see there)
         const bool in_range = qnorm >= 1e-30f && qnorm <= 4.0e6f && knorm >= 1e-30f && knorm <= 4.0e6f &&
                               qnorm <= 1.0e4f * knorm && knorm <= 1.0e4f * qnorm;
-        bool uniq = use_filter && in_range && (v1 == v1) && (v2 < v1 - kAlign16Margin);
+        // the lead the best shift must have: twice the error bound of a value.  |c~ - c| <= |q - qh| |kh| + |q| |k - kh| + the fp32
+        // accumulation of 128 exact products ((n - 1) 2^-24 sum |q k| <= 7.6e-6), with the keys' ACTUAL rounding-error norms as recorded
+        // at ingest (unit keys: |q| = 1, |kh| <= 1 + |k - kh|) -- never more than the worst case the constant stands for
+        const float lead = (qerr > 0.f && kerr > 0.f) ? fminf(kAlign16Margin, 2.0f * (qerr + kerr + qerr * kerr) * 1.0001f + 1.6e-5f) : kAlign16Margin;
+        bool uniq = use_filter && in_range && (v1 == v1) && (v2 < v1 - lead);
         const int ci = u_lo + idx - sq.base;
         const bool mine = q_live && ci >= 0 && ci < sq.n;                        // (every lane of column q holds the same numbers)
         unsigned long long amb = __builtin_amdgcn_ballot_w64(mine && !uniq) & 0xffffull;

@@ -115,3 +115,51 @@ def test_fp16_stage_error_and_accepted_shifts():
             assert int(order[0]) == ref, (int(order[0]), ref)
     print(f"fp16 stage: worst error {worst:.3e} (half margin 1.5e-3), {accepted} of {total} pairs accepted")
     assert accepted > total // 3
+
+
+def test_fp16_stage_bound_from_the_keys_own_rounding_errors():
+    """Round 3: the lead the first stage demands is twice |q - qh| (1 + |k - kh|) + |k - kh| + 7.6e-6 with the ACTUAL rounding-error
+    norms of the two unit keys (written at ingest, make_sc.hip) instead of the worst case of fp16 rounding.  The error of every
+    shift's value must stay inside that bound under the worst accumulation order, the bound must not exceed the constant it
+    replaces by more than the accumulation term for ordinary keys, and a shift accepted with the smaller lead must be the
+    checker's."""
+    L = ob.load()
+    worst_ratio, accepted, accepted_old, total = 0.0, 0, 0, 0
+    for q, k in cases():
+        nq, nk = np.linalg.norm(q), np.linalg.norm(k)
+        if not (nq > 0 and nk > 0):
+            continue
+        uq, uk = q / nq, k / nk
+        qh = uq.astype(np.float32).astype(np.float16).astype(np.float64)
+        kh = uk.astype(np.float32).astype(np.float16).astype(np.float64)
+
+        def err_norm(u, h):
+            d = np.abs(u - h)
+            sub = np.abs(h) < 2.0 ** -14                               # below fp16's normal range: may be taken for zero
+            d = np.where(sub, np.maximum(d, np.abs(u)), d)
+            return float(np.sqrt((d * d).sum())) * (1 + 1e-6) + 1e-10
+        eq, ek = err_norm(uq, qh), err_norm(uk, kh)
+        bound = eq + ek + eq * ek + 7.6e-6
+        s = np.arange(S)
+        for flush in (False, True):                                    # a matrix core that keeps subnormal inputs / takes them for zero
+            a = np.where(np.abs(qh) < 2.0 ** -14, 0.0, qh) if flush else qh
+            b = np.where(np.abs(kh) < 2.0 ** -14, 0.0, kh) if flush else kh
+            acc = np.zeros(S, np.float32)
+            for u in range(S):
+                acc = (acc + (a[(u + s) % S].astype(np.float32) * np.float32(b[u])).astype(np.float32)).astype(np.float32)
+            ce = corr_exact(q, k) / (np.longdouble(nq) * np.longdouble(nk))
+            err = float(np.max(np.abs(acc.astype(np.longdouble) - ce)))
+            assert err <= bound, (err, bound, eq, ek)
+            worst_ratio = max(worst_ratio, err / bound)
+        total += 1
+        in_range = 1e-30 <= nq <= 4e6 and 1e-30 <= nk <= 4e6 and nq <= 1e4 * nk and nk <= 1e4 * nq
+        order = np.argsort(-acc, kind="stable")
+        lead = min(3.0e-3, 2.0 * (eq + ek + eq * ek) * 1.0001 + 1.6e-5)
+        if in_range and acc[order[1]] < acc[order[0]] - np.float32(3.0e-3):
+            accepted_old += 1
+        if in_range and acc[order[1]] < acc[order[0]] - np.float32(lead):
+            accepted += 1
+            ref = L.sco_fast_align(S, ob._p(np.ascontiguousarray(q, np.float64), ob.c_double), ob._p(np.ascontiguousarray(k, np.float64), ob.c_double))
+            assert int(order[0]) == ref, (int(order[0]), ref, lead)
+    print(f"fp16 stage, per-pair bound: worst error / bound {worst_ratio:.3f}; accepted {accepted} (constant lead: {accepted_old}) of {total}")
+    assert accepted >= accepted_old and worst_ratio <= 1.0
