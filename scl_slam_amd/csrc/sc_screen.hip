@@ -1502,7 +1502,11 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
 #endif
             if (o == 0) {                                // the load NBUF - 1 groups ahead: from the next keyframe towards this one's end
                 const int j = g + NBUF - 1;                  // (its buffer held load g - 1, whose last fragment was formed two iterations ago)
-                if (j < NL) F[j % NBUF] = *reinterpret_cast<const u32x4 *>(base_cur + load_off(j));
+                // (the keyframe's last load serves the last derived fragment only: sectors up to 4 (NIT - 1) + 15; at S = 120 that is
+                //  four of its sixteen sectors -- the other lanes stay out of the request: 0.75 KB per keyframe and ring part less)
+                constexpr int kLastLanes = 4 * (NIT - 1) + 16 - 16 * (NL - 1);
+                if (j == NL - 1 && kLastLanes < 16) { if (c16 < kLastLanes) F[j % NBUF] = *reinterpret_cast<const u32x4 *>(base_cur + load_off(j)); }
+                else if (j < NL) F[j % NBUF] = *reinterpret_cast<const u32x4 *>(base_cur + load_off(j));
                 else if (j - NL < NBUF - 1) F[j % NBUF] = *reinterpret_cast<const u32x4 *>(base_nxt + load_off(j - NL));
             }
             if (it + 1 < NIT) readB(bfr[(it + 1) & 1], it + 1);   // the next iteration's B fragments
