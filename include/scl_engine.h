@@ -253,6 +253,11 @@ int  scl_icp_align_batch(scl_engine *e, const void *src, int n_src, const void *
  * exact 1-NN of every source point in the target (ties -> lowest target index). */
 int  scl_nn_correspondences(scl_engine *e, const void *src, int n_src, const void *tgt, int n_tgt,
                             int stride_bytes, int *nn_index, float *nn_dist2);
+/* The correspondences of the source moved by T (row-major 4x4, DM.h:247-249 arithmetic), searched from those of the
+ * unmoved source: the warm neighbour search of an ICP iteration (pcl::IterativeClosestPoint's loop body, DM.h:1119) on
+ * its own.  Results equal scl_nn_correspondences on the moved cloud. */
+int  scl_nn_correspondences_moved(scl_engine *e, const void *src, int n_src, const void *tgt, int n_tgt,
+                                  int stride_bytes, const float T[16], int *nn_index, float *nn_dist2);
 /* TransformationEstimationSVD::estimateRigidTransformation, DM.h:1228-1230,
  * over correspondence pairs (src_index[i], tgt_index[i]). */
 int  scl_rigid_svd(scl_engine *e, const void *src, int n_src, const void *tgt, int n_tgt,
@@ -346,6 +351,11 @@ int  scl_profile_enable(scl_engine *e, int on);   /* 0 off, 1 every kernel famil
                                                      between two back-to-back launches costs ~8 us of device time) */
 int  scl_profile_reset(scl_engine *e);
 int  scl_profile_get(scl_engine *e, scl_profile *out);
+/* Counters of the ICP loop's LDS-tiled neighbour search (icp.hip K4c) since the last reset, in builds made with
+ * -DSCL_DIAGNOSTICS (zeros otherwise): [0] rounds asked for, [1] rounds whose box did not fit, [2] lanes finished in memory,
+ * [3] table entries staged, [4] points staged, [5] row visits, [6] points compared; [8..14] 10 ns ticks of every workgroup's
+ * first thread per phase (up to the ball round, box, table, row scan, staging, the queries' walk, reduction).  Device-wide. */
+void scl_debug_icp_tile_stats(unsigned long long out[16], int reset);
 /* The full-database pass aligns every (scan, keyframe) pair (fastAlignUsingVkey, D.h:1491-1511) with an fp32 correlation
  * filter on the matrix cores and falls back to the reference's own fp64 evaluation wherever two shifts are closer than the
  * filter's error margin.  pairs = pairs aligned since the last reset, fallbacks = those decided by the fp64 evaluation (the

@@ -1992,7 +1992,23 @@ int scl_nn_correspondences(scl_engine *e, const void *src, int n_src, const void
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     std::string err;
-    int rc = icp_nn_correspondences(&e->icp_ws, e->stream, e->num_cu, src, n_src, tgt, n_tgt, stride_bytes,
+    int rc = icp_nn_correspondences(&e->icp_ws, e->stream, e->num_cu, src, n_src, tgt, n_tgt, stride_bytes, nullptr,
+                                    nn_index, nn_dist2, &err);
+    if (rc) e->last_error = err;
+    return rc;
+}
+
+void scl_debug_icp_tile_stats(unsigned long long out[16], int reset) { icp_tile_stats(out, reset != 0); }
+
+int scl_nn_correspondences_moved(scl_engine *e, const void *src, int n_src, const void *tgt, int n_tgt,
+                                 int stride_bytes, const float T[16], int *nn_index, float *nn_dist2)
+{
+    if (!e || !src || !tgt || !nn_index || !T) return SCL_ERR_INVALID_ARG;
+    if (e->front) e = front_primary(e);
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    std::string err;
+    int rc = icp_nn_correspondences(&e->icp_ws, e->stream, e->num_cu, src, n_src, tgt, n_tgt, stride_bytes, T,
                                     nn_index, nn_dist2, &err);
     if (rc) e->last_error = err;
     return rc;

@@ -50,7 +50,9 @@ struct IcpState {
     unsigned int ticket; unsigned int pad_;               // workgroups of the fused iteration that have delivered their partial sums
 };
 
-enum Buf { B_SRC = 0, B_TGT, B_WORK, B_TSORT, B_CSTART, B_CFILL, B_NNI, B_NND, B_PART, B_STATE, B_BBOX, B_SI, B_TI, B_OUT, B_MASK, B_HYP, B_PROB };
+enum Buf { B_SRC = 0, B_TGT, B_WORK, B_TSORT, B_CSTART, B_CFILL, B_NNI, B_NND, B_PART, B_STATE, B_BBOX, B_SI, B_TI, B_OUT, B_MASK, B_HYP, B_PROB,
+           B_NNQ, B_PERM, B_SORT, B_FLAG };
+static_assert(B_FLAG < (int)(sizeof(IcpWorkspace::buf) / sizeof(void *)), "IcpWorkspace::buf is too short");
 constexpr int B_NORM = B_OUT;             // target normals share the slot of the raw-transform output (never live together)
 
 int ensure(IcpWorkspace *ws, int k, size_t bytes, std::string *err)
@@ -208,29 +210,12 @@ __device__ __forceinline__ void group_min(float &d, int &j)
 // G = lanes per query: 8 for a cold search (whole shells to look at), 2 once the previous neighbour bounds the ball
 // (most queries are done after their own cell; eight lanes would mostly idle and only a quarter of the queries
 // would be resident at a time).
+// The search proper: the group's G lanes (sub = this lane's place in it) find the nearest target point of p, starting from
+// (best, bi) -- the previous neighbour's distance and index when warm_start, (FLT_MAX, -1) otherwise.
 template <int G>
-__device__ __forceinline__ void nn_search_kernel_t_body(float4 *work, int n_src, const IcpState *st,
-                                                          const int *cell_start, const float4 *sorted,
-                                                          int *nn_idx, float *nn_d2, int check_done, int apply_iter,
-                                                          const unsigned char *tgt_raw, int stride, int warm)
+__device__ __forceinline__ void nn_core(const float3 p, const IcpState *st, const int *cell_start, const float4 *sorted,
+                                        const int sub, const bool warm_start, float &best, int &bi)
 {
-    if (check_done && st->done) return;
-    if (n_src <= 0) return;
-    const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / G;
-    const int sub = threadIdx.x & (G - 1);
-    const bool valid = gid < n_src;
-    const int i = valid ? gid : n_src - 1;                       // surplus groups shadow the last query (all lanes stay in the exchanges)
-    float4 pw = work[i];
-    if (apply_iter >= 0 && valid) {                              // (surplus groups would re-apply it to the stored result)
-        const float *T = st->inc_T;
-        const float x = pw.x, y = pw.y, z = pw.z;
-        pw.x = T[0] * x + T[1] * y + T[2] * z + T[3];
-        pw.y = T[4] * x + T[5] * y + T[6] * z + T[7];
-        pw.z = T[8] * x + T[9] * y + T[10] * z + T[11];
-        pw.w = 0.f;
-        if (sub == 0) work[i] = pw;
-    }
-    const float3 p = make_float3(pw.x, pw.y, pw.z);
     int c[3];
     cell_index(st, p, c);
     const int dx = st->dim[0], dy = st->dim[1], dz = st->dim[2];
@@ -246,17 +231,6 @@ __device__ __forceinline__ void nn_search_kernel_t_body(float4 *work, int n_src,
         d = (d == d) ? d : 0.f;                                  // NaN coordinates: no help from this axis
         dout2[a] = d * d;
         dout_sum += dout2[a];
-    }
-    float best = FLT_MAX;
-    int bi = -1;
-    if (warm) {
-        const int j = nn_idx[i];
-        if (j >= 0) {
-            const float3 q = load_xyz(tgt_raw, j, stride);
-            const float ex = p.x - q.x, ey = p.y - q.y, ez = p.z - q.z;
-            const float d = (ex * ex + ey * ey) + ez * ez;       // the expression the scan uses: the same bits when the scan meets j again
-            if (d == d) { best = d; bi = j; }
-        }
     }
     const float gx0 = st->mn[0], gy0 = st->mn[1], gz0 = st->mn[2];
     // four points per step, their loads issued together (a load per step and a wait behind it left the lane
@@ -309,8 +283,7 @@ __device__ __forceinline__ void nn_search_kernel_t_body(float4 *work, int n_src,
         }
         group_min<G>(best, bi);
     };
-    const bool warm_start = warm && bi >= 0;                     // the previous neighbour bounds the ball
-    if (warm_start) ball_pass();
+    if (warm_start) ball_pass();                                 // the previous neighbour bounds the ball
     // Cold search: shells until the first one that holds a point (its distance bounds the ball), then the ball once.
     // (no early return above: this body is inlined in front of the fused iteration's reduction)
     for (int r = 0; !warm_start && r <= maxdim; ++r) {
@@ -377,6 +350,43 @@ __device__ __forceinline__ void nn_search_kernel_t_body(float4 *work, int n_src,
         if (bi >= 0 && best < bound2 * 0.9998f) break;
         if (bi >= 0 && best < FLT_MAX) { ball_pass(); break; }   // (every lane of the group holds the same best and bi here)
     }
+}
+
+template <int G>
+__device__ __forceinline__ void nn_search_kernel_t_body(float4 *work, int n_src, const IcpState *st,
+                                                          const int *cell_start, const float4 *sorted,
+                                                          int *nn_idx, float *nn_d2, int check_done, int apply_iter,
+                                                          const unsigned char *tgt_raw, int stride, int warm)
+{
+    if (check_done && st->done) return;
+    if (n_src <= 0) return;
+    const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int sub = threadIdx.x & (G - 1);
+    const bool valid = gid < n_src;
+    const int i = valid ? gid : n_src - 1;                       // surplus groups shadow the last query (all lanes stay in the exchanges)
+    float4 pw = work[i];
+    if (apply_iter >= 0 && valid) {                              // (surplus groups would re-apply it to the stored result)
+        const float *T = st->inc_T;
+        const float x = pw.x, y = pw.y, z = pw.z;
+        pw.x = T[0] * x + T[1] * y + T[2] * z + T[3];
+        pw.y = T[4] * x + T[5] * y + T[6] * z + T[7];
+        pw.z = T[8] * x + T[9] * y + T[10] * z + T[11];
+        pw.w = 0.f;
+        if (sub == 0) work[i] = pw;
+    }
+    const float3 p = make_float3(pw.x, pw.y, pw.z);
+    float best = FLT_MAX;
+    int bi = -1;
+    if (warm) {
+        const int j = nn_idx[i];
+        if (j >= 0) {
+            const float3 q = load_xyz(tgt_raw, j, stride);
+            const float ex = p.x - q.x, ey = p.y - q.y, ez = p.z - q.z;
+            const float d = (ex * ex + ey * ey) + ez * ez;       // the expression the scan uses: the same bits when the scan meets j again
+            if (d == d) { best = d; bi = j; }
+        }
+    }
+    nn_core<G>(p, st, cell_start, sorted, sub, warm && bi >= 0, best, bi);
     if (valid && sub == 0) {
         nn_idx[i] = bi;
         nn_d2[i] = best;
@@ -913,13 +923,6 @@ __device__ __forceinline__ void plane_reduce_kernel_body(const float4 *work, con
         put_partial(partials + blockIdx.x * kNPlane + threadIdx.x, ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x], range != nullptr);
 }
 
-__global__ __launch_bounds__(256) void plane_reduce_kernel(const float4 *work, const unsigned char *tgt_raw, int stride, int n,
-                                                           const int *nn_idx, const float *nn_d2, float maxd2,
-                                                           const float4 *normals, const IcpState *st, double *partials)
-{
-    plane_reduce_kernel_body(work, tgt_raw, stride, n, nn_idx, nn_d2, maxd2, normals, st, partials);
-}
-
 __device__ __forceinline__ void plane_solve_from_sums(IcpState *st, const double *sums, int max_iter, double trans_eps, double fit_eps)
 {
     const double N = sums[28];
@@ -961,43 +964,11 @@ __device__ __forceinline__ void plane_solve_kernel_body(IcpState *st, const doub
     plane_solve_from_sums(st, sums, max_iter, trans_eps, fit_eps);
 }
 
-__global__ void plane_solve_kernel(IcpState *st, const double *partials, int nblocks, int max_iter, double trans_eps, double fit_eps)
-{
-    plane_solve_kernel_body(st, partials, nblocks, max_iter, trans_eps, fit_eps);
-}
-
 // ---- K6 ----------------------------------------------------------------------------
 __global__ void work_init_kernel(const unsigned char *src, int n, int stride, float4 *work)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { const float3 p = load_xyz(src, i, stride); work[i] = make_float4(p.x, p.y, p.z, 0.f); }
-}
-
-// which: 0 = inc_T applied to work in place (ICP step); 1 = final_T applied to the raw source into work
-__device__ __forceinline__ void work_transform_kernel_body(float4 *work, const unsigned char *src, int n, int stride,
-                                      const IcpState *st, int which, int expect_iter)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float *T = which == 0 ? st->inc_T : st->final_T;
-    float x, y, z;
-    if (which == 0) {
-        if (st->iter != expect_iter) return;      // this iteration's solve did not run (finished earlier / failed)
-        const float4 p = work[i]; x = p.x; y = p.y; z = p.z;
-    } else {
-        const float3 p = load_xyz(src, i, stride); x = p.x; y = p.y; z = p.z;
-    }
-    // distributedMapping.h:247-249 (fp32, left-to-right, no FMA)
-    const float ox = T[0] * x + T[1] * y + T[2] * z + T[3];
-    const float oy = T[4] * x + T[5] * y + T[6] * z + T[7];
-    const float oz = T[8] * x + T[9] * y + T[10] * z + T[11];
-    work[i] = make_float4(ox, oy, oz, 0.f);
-}
-
-__global__ void work_transform_kernel(float4 *work, const unsigned char *src, int n, int stride,
-                                      const IcpState *st, int which, int expect_iter)
-{
-    work_transform_kernel_body(work, src, n, stride, st, which, expect_iter);
 }
 
 __global__ void raw_transform_kernel(const unsigned char *in, unsigned char *out, int n, int stride, const float *T)
@@ -1158,22 +1129,9 @@ __global__ void iota_pairs_kernel(const int *nn, int n, int *si, int *ti)
 struct IcpProblem {
     float4 *work; IcpState *st; const int *cell_start; const float4 *sorted; int *nni; float *nnd; double *part;
     const unsigned char *tgt; const float4 *normals;
+    float4 *nnq;                                             // every source's current neighbour: its coordinates and (in .w) its index
+    int *flag;                                               // per workgroup of the tile search: lanes left for icp_tile_finish_kernel
 };
-
-template <int G>
-__global__ __launch_bounds__(256) void nn_search_batch_kernel(const IcpProblem *pr, int n_src, int check_done, int apply_iter, int stride, int warm)
-{
-    const IcpProblem p = pr[blockIdx.y];
-    nn_search_kernel_t_body<G>(p.work, n_src, p.st, p.cell_start, p.sorted, p.nni, p.nnd, check_done, apply_iter, p.tgt, stride, warm);
-}
-
-__global__ __launch_bounds__(256) void corr_reduce_batch_kernel(const IcpProblem *pr, const unsigned char *src_raw, int stride, int n, float maxd2,
-                                                                int check_done, int mfma)
-{
-    const IcpProblem p = pr[blockIdx.y];
-    if (mfma) corr_reduce_mfma_kernel_body(p.work, src_raw, p.tgt, stride, n, p.nni, p.nnd, maxd2, nullptr, nullptr, 0, p.st, p.part, check_done);
-    else corr_reduce_kernel_body(p.work, src_raw, p.tgt, stride, n, p.nni, p.nnd, maxd2, nullptr, nullptr, 0, p.st, p.part, check_done);
-}
 
 __global__ __launch_bounds__(64) void icp_solve_batch_kernel(const IcpProblem *pr, int nblocks, int mode, int max_iter, double trans_eps, double fit_eps)
 {
@@ -1193,85 +1151,506 @@ __global__ void plane_solve_batch_kernel(const IcpProblem *pr, int nblocks, int 
     plane_solve_kernel_body(p.st, p.part, nblocks, max_iter, trans_eps, fit_eps);
 }
 
-// ---- one launch per ICP iteration -------------------------------------------------------------------------------------------
-// search (the previous solve's increment moves the working points first), this workgroup's own correspondences reduced to a
-// partial record, and -- in the workgroup that delivers the last record of its alignment -- the sum of the records in a fixed
-// order and the solve: what used to be three dependent launches (DM.h:1107-1121's loop body).  The records travel as agent-scope
-// atomic stores / loads (no cache write-back or invalidation: an agent-scope fence would write the L2 back), ordered by the ticket
-// counter in the alignment's state: a workgroup takes its ticket after its stores have been acknowledged.
-// mode 0: ICP iteration; 2: fitness pass (behind work_transform: the final transform on the original source; every correspondence
-// counts).  (The transform is not folded into this kernel: a source read in front of the inlined search crashes this compiler.)
-// est 0: point to point (covariance on the fp64 matrix cores when mfma != 0), 1: point to plane.
-template <int G>
-__global__ __launch_bounds__(256) void icp_fused_batch_kernel(const IcpProblem *pr, const unsigned char *src_raw, int n_src, int stride, int apply, int warm,
-                                                              float maxd2, int mfma, int mode, int est, int max_iter, double trans_eps, double fit_eps)
+// ---- K4c: the search of a loop iteration served from LDS ---------------------------------------------------------------------
+// The one-lane-per-query walk above spends its time waiting: previous neighbour -> cell table -> points are dependent round trips
+// to L2 / HBM for every query, 8.6 G queries/s however the lanes are grouped.  Here a workgroup takes kTileQ consecutive source
+// points -- the batch's sources are sorted along a Hilbert curve once per scan (source_order below), so they are a compact blob
+// --, forms the bounding box of the cells its queries' balls reach, stages that box's slice of the cell table and its points
+// in LDS with two rounds of coalesced loads, and every query then walks ITS cells out of LDS.  The arithmetic of a comparison, the
+// pruning margins and the (distance, index) order are those of nn_core: the neighbour found is the same point, bit for bit.
+// A round whose box does not fit (kTileRows rows, kTileTab table entries, kTilePts points) is served by nn_core<1> from
+// memory for the lanes that asked -- a blob torn by a jump of the curve, sources far away from the target.
+// Cold (first iteration, nothing known): round A looks at each query's own cell, round B at the 3 x 3 x 3 cells around it for
+// the queries whose cell was empty, what is still without a candidate walks shells in memory (nn_core<1>); then the ball.
+// do_reduce: the workgroup's correspondences are reduced on the spot (fp64 matrix cores, as corr_reduce_mfma_kernel_body) and
+// leave as one record of kNSum sums per workgroup: the iteration is this launch + the solve.
+#ifndef SCL_TILE_PTS
+#define SCL_TILE_PTS 2048
+#endif
+#ifndef SCL_TILE_TAB
+#define SCL_TILE_TAB 2048
+#endif
+constexpr int kTileQ = 256, kTilePts = SCL_TILE_PTS, kTileTab = SCL_TILE_TAB, kTileRows = 128;
+#ifdef SCL_DIAGNOSTICS
+// [0..6] (SCL_DIAGNOSTICS=1): rounds asked for, rounds that did not fit, lanes finished in memory, table entries / points staged, row
+// visits, points compared; [8..14] (SCL_DIAGNOSTICS=2, so that the counters' atomics do not sit in the phases they time): ticks of
+// thread 0 of every workgroup between the kernel's phases
+__device__ unsigned long long g_tile_stats[16];
+#endif
+#if defined(SCL_DIAGNOSTICS) && SCL_DIAGNOSTICS == 1
+#define TILE_STAT(k, v) atomicAdd(&g_tile_stats[k], (unsigned long long)(v))
+#else
+#define TILE_STAT(k, v) ((void)0)
+#endif
+#if defined(SCL_DIAGNOSTICS) && SCL_DIAGNOSTICS == 2
+#define TILE_STAMP(k) do { if (threadIdx.x == 0) { const unsigned long long now__ = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_tile_stats[k], now__ - tile_t0__); tile_t0__ = now__; } } while (0)
+#define TILE_STAMP_DECL unsigned long long tile_t0__ = __builtin_amdgcn_s_memrealtime()
+#define TILE_STAMP_ARG , unsigned long long &tile_t0__
+#define TILE_STAMP_PASS , tile_t0__
+#else
+#define TILE_STAMP(k) ((void)0)
+#define TILE_STAMP_DECL ((void)0)
+#define TILE_STAMP_ARG
+#define TILE_STAMP_PASS
+#endif
+
+struct TileLds {
+    float4 pts[kTilePts + 4];            // staged target points (x, y, z, index; a walk reads up to 3 past its range); reused as the reduction's staging area
+    int tab[kTileTab];                   // the box's slice of cell_start, row after row, as offsets into pts
+    int g0[kTileRows];                   // first point (in `sorted`) of every row of the box
+    int loff[kTileRows + 1];             // where the row's points start in pts; loff[nrows] = their number
+    int box[6];
+    unsigned char prow[kTilePts];        // the row of every staged point
+    double red[kTileQ / 64][kNSum];
+};
+static_assert(kTileRows <= 256 && kTilePts % (4 * kTileQ) == 0 && kTileTab % kTileQ == 0, "tile constants");
+
+struct TileGrid { float gx0, gy0, gz0, h, inv_h; int dx, dy, dz; };
+
+// minimum over the wave's 64 lanes, the same value in every lane (a scalar): four DPP steps inside the rows of 16, then the four rows
+__device__ __forceinline__ int wave_min_i32(int v)
 {
-    const IcpProblem p = pr[blockIdx.y];
-    IcpState *st = p.st;
-    if (mode == 0 && st->done) return;                           // (set by an earlier launch's solve: the same for every workgroup)
-    nn_search_kernel_t_body<G>(p.work, n_src, st, p.cell_start, p.sorted, p.nni, p.nnd, 0, apply, p.tgt, stride, warm);
-    __threadfence_block();
-    __syncthreads();                                             // this workgroup's neighbours and moved points are in memory for its own lanes
-    constexpr int QW = 256 / G;                                  // queries of a workgroup
-    RedRange rr;
-    rr.i0 = (int)blockIdx.x * QW; rr.step = 256; rr.i1 = rr.i0 + QW < n_src ? rr.i0 + QW : n_src;
-    const int NS = est == 1 ? kNPlane : kNSum;
-    if (est == 1) plane_reduce_kernel_body(p.work, p.tgt, stride, n_src, p.nni, p.nnd, maxd2, p.normals, st, p.part, &rr);
-    else if (mfma) corr_reduce_mfma_kernel_body(p.work, src_raw, p.tgt, stride, n_src, p.nni, p.nnd, maxd2, nullptr, nullptr, 0, st, p.part, 0, &rr);
-    else corr_reduce_kernel_body(p.work, src_raw, p.tgt, stride, n_src, p.nni, p.nnd, maxd2, nullptr, nullptr, 0, st, p.part, 0, &rr);
-    // ---- ticket: the stores above must have been acknowledged before it is taken ----
-    __shared__ unsigned int s_ticket;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (s_ticket != gridDim.x - 1) return;
-    // ---- the last workgroup: records summed in a fixed order (wave w takes entries w, w + 4, ...; lane l records l, l + 64, ...;
-    //      then the lanes in lane order), then the solve ----
-    __shared__ double f_tmp[kNPlane][64];
-    __shared__ double f_sums[kNPlane];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int nblocks = (int)gridDim.x;
-    for (int k = wv; k < NS; k += 4) {
-        double acc = 0.0;
-        for (int b = lane; b < nblocks; b += 64) acc += __hip_atomic_load(p.part + (size_t)b * NS + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        f_tmp[k][lane] = acc;
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < NS) {
-        double acc = 0.0;
-        for (int l = 0; l < 64; ++l) acc += f_tmp[threadIdx.x][l];
-        f_sums[threadIdx.x] = acc;
-    }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    st->ticket = 0u;                                             // armed for the next launch (stream ordered)
-    if (est == 1 && mode == 0) plane_solve_from_sums(st, f_sums, max_iter, trans_eps, fit_eps);
-    else if (est == 1) { const double N = f_sums[28]; st->n_corr = (int)N; st->fitness = N > 0.0 ? f_sums[27] / N : (double)FLT_MAX; }
-    else icp_solve_from_sums(st, f_sums, mode, max_iter, trans_eps, fit_eps);
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));     // quad_perm [1,0,3,2]
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));     // quad_perm [2,3,0,1]
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));    // row_half_mirror
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));    // row_mirror
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
-__global__ void work_transform_batch_kernel(const IcpProblem *pr, const unsigned char *src, int n, int stride, int which)
+__device__ __forceinline__ void tile_reach(float v, float g0, float h, int dim, float reach, int &a, int &b)
 {
-    const IcpProblem p = pr[blockIdx.y];
-    work_transform_kernel_body(p.work, src, n, stride, p.st, which, 0);
+    const float fa = floorf((v - reach - g0) / h), fb = floorf((v + reach - g0) / h);
+    a = 0; b = dim - 1;
+    if (fa == fa && fb == fb) {
+        const int ia = fa < -1.0e9f ? 0 : (fa > 1.0e9f ? dim : (int)fa), ib = fb < -1.0e9f ? -1 : (fb > 1.0e9f ? dim - 1 : (int)fb);
+        a = max(a, ia); b = min(b, ib);
+    }
 }
+
+// Staging: the lanes with req ask for the cells [xa, xb] x [ya, yb] x [za, zb] (non-empty ranges inside the grid); the box of all
+// requests -- its slice of the cell table as offsets into pts, its points -- is put in LDS.  Returns 0 when nobody asked, 1 when
+// the box is staged (B describes it), 2 when it does not fit (nothing usable in LDS).  The same value in every lane of the workgroup.
+struct TileBox { int X0, Y0, Z0, NY, W1; };
+__device__ __forceinline__ int tile_stage(TileLds &L, const TileGrid &g, const int *cell_start, const float4 *sorted, const bool req,
+                                          const int xa, const int xb, const int ya, const int yb, const int za, const int zb, TileBox &B TILE_STAMP_ARG)
+{
+    const int t = threadIdx.x, lane = t & 63;
+    int lo[3] = {req ? xa : INT_MAX, req ? ya : INT_MAX, req ? za : INT_MAX}, hi[3] = {req ? xb : -INT_MAX, req ? yb : -INT_MAX, req ? zb : -INT_MAX};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { lo[a] = wave_min_i32(lo[a]); hi[a] = -wave_min_i32(-hi[a]); }
+    if (t < 6) L.box[t] = t < 3 ? INT_MAX : INT_MIN;
+    __syncthreads();                                             // (also: every lane has left the previous round's LDS)
+    if (lane == 0 && lo[0] <= hi[0]) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { atomicMin(&L.box[a], lo[a]); atomicMax(&L.box[3 + a], hi[a]); }
+    }
+    __syncthreads();
+    const int X0 = L.box[0], Y0 = L.box[1], Z0 = L.box[2], X1 = L.box[3], Y1 = L.box[4], Z1 = L.box[5];
+    __syncthreads();                                             // (a lane that returns below may write the next round's box at once)
+    TILE_STAMP(9);
+    if (X0 > X1) return 0;
+    if (t == 0) TILE_STAT(0, 1);
+    const int W1 = X1 - X0 + 2, NY = Y1 - Y0 + 1, NZ = Z1 - Z0 + 1;    // W1 table entries per row: its cells' starts + the end of the last
+    if ((long long)NY * NZ > kTileRows || (long long)NY * NZ * W1 > kTileTab) { if (t == 0) TILE_STAT(1, 1); return 2; }
+    const int nrows = NY * NZ, nent = nrows * W1;
+    {                                                            // every load of the table in flight before the first is stored
+        int tv[kTileTab / kTileQ];
+#pragma unroll
+        for (int u = 0; u < kTileTab / kTileQ; ++u) {
+            const int e = t + u * kTileQ;
+            const int r = e / W1, k = e - r * W1, zz = r / NY;
+            tv[u] = e < nent ? cell_start[((Z0 + zz) * g.dy + (Y0 + (r - zz * NY))) * g.dx + X0 + k] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kTileTab / kTileQ; ++u) { const int e = t + u * kTileQ; if (e < nent) L.tab[e] = tv[u]; }
+    }
+    __syncthreads();
+    TILE_STAMP(10);
+    if (t < 64) {                                                // the rows' point counts and their exclusive scan: two rows per lane
+        constexpr int PER = kTileRows / 64;
+        int cnt[PER], tot = 0;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) { const int r = t * PER + u; cnt[u] = r < nrows ? L.tab[r * W1 + W1 - 1] - L.tab[r * W1] : 0; tot += cnt[u]; }
+        int incl = tot;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, kWave); if (lane >= off) incl += o; }
+        int base = incl - tot;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) { const int r = t * PER + u; if (r < nrows) { L.loff[r] = base; L.g0[r] = L.tab[r * W1]; } base += cnt[u]; }
+        if (t == 63) L.loff[nrows] = incl;
+    }
+    __syncthreads();
+    const int total = L.loff[nrows];
+    TILE_STAMP(11);
+    if (total > kTilePts) { if (t == 0) TILE_STAT(1, 1); return 2; }
+    if (t == 0) { TILE_STAT(3, nent); TILE_STAT(4, total); }
+    for (int e = t; e < nent; e += kTileQ) { const int r = e / W1; L.tab[e] = L.tab[e] - L.g0[r] + L.loff[r]; }
+    for (int r = t >> 4; r < nrows; r += kTileQ / 16) {          // which row every staged point belongs to (16 lanes per row, LDS only)
+        const int dst0 = L.loff[r], cnt = L.loff[r + 1] - dst0;
+        for (int k = t & 15; k < cnt; k += 16) L.prow[dst0 + k] = (unsigned char)r;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u0 = 0; u0 < kTilePts / kTileQ; u0 += 4) {          // the points: four loads per lane in flight, then their stores
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = t + (u0 + u) * kTileQ;
+            if (k < total) { const int r = L.prow[k]; v[u] = sorted[L.g0[r] + (k - L.loff[r])]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int k = t + (u0 + u) * kTileQ; if (k < total) L.pts[k] = v[u]; }
+    }
+    __syncthreads();
+    TILE_STAMP(12);
+    B.X0 = X0; B.Y0 = Y0; B.Z0 = Z0; B.NY = NY; B.W1 = W1;
+    return 1;
+}
+
+// One round of the neighbour search: staging, then every asking lane walks ITS cells out of LDS (best / bi / bq updated when 1 is
+// returned; 0 and 2 as tile_stage).
+__device__ __forceinline__ int tile_round(TileLds &L, const TileGrid &g, const int *cell_start, const float4 *sorted, const bool req,
+                                          const int xa, const int xb, const int ya, const int yb, const int za, const int zb,
+                                          const float3 p, float &best, int &bi, float3 &bq TILE_STAMP_ARG)
+{
+    TileBox B;
+    const int rc = tile_stage(L, g, cell_start, sorted, req, xa, xb, ya, yb, za, zb, B TILE_STAMP_PASS);
+    if (rc != 1) return rc;
+    const int X0 = B.X0, Y0 = B.Y0, Z0 = B.Z0, NY = B.NY, W1 = B.W1;
+    if (req) {
+        // (distance, index) as one 64-bit key: the bits of a distance >= 0 order like the distance, the index's sign bit is flipped so
+        // that -1 ("none") comes last among equal distances, as in nn_core; a NaN distance has the largest key and is never taken
+        unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | ((unsigned int)bi ^ 0x80000000u);
+        int kbest = -1;
+        for (int z = za; z <= zb; ++z)
+            for (int y = ya; y <= yb; ++y) {
+                // nn_core's row test: the distance from p to the row's (y, z) box, the box taken a hair smaller than the cells
+                const float ylo = g.gy0 + (float)y * g.h, zlo = g.gz0 + (float)z * g.h;
+                const float ddy = fmaxf(fmaxf(ylo - p.y, p.y - (ylo + g.h)), 0.f), ddz = fmaxf(fmaxf(zlo - p.z, p.z - (zlo + g.h)), 0.f);
+                const float dyz2 = (ddy * ddy + ddz * ddz) * 0.9995f;
+                const float bnow = __uint_as_float((unsigned int)(key >> 32));
+                if (dyz2 > bnow) continue;
+                int x0 = xa, x1 = xb;
+                if (bnow < FLT_MAX) {
+                    // the cells of the row the ball reaches: a product with 1 / h instead of nn_core's division, the reach widened by
+                    // what the two can differ by (2e-5 cells at 100 cells per axis; the 1.0005 covers the square root's last bit)
+                    const float reach = __builtin_amdgcn_sqrtf(bnow - dyz2) * 1.0005f + 2.1e-5f * g.h;
+                    const float fa = floorf((p.x - reach - g.gx0) * g.inv_h), fb = floorf((p.x + reach - g.gx0) * g.inv_h);
+                    if (fa == fa && fb == fb) {
+                        const int ia = fa < -1.0e9f ? 0 : (fa > 1.0e9f ? g.dx : (int)fa), ib = fb < -1.0e9f ? -1 : (fb > 1.0e9f ? g.dx - 1 : (int)fb);
+                        x0 = max(x0, ia); x1 = min(x1, ib);
+                    }
+                }
+                if (x0 > x1) continue;
+                const int row = ((z - Z0) * NY + (y - Y0)) * W1 - X0;
+                const int kb = L.tab[row + x0], ke = L.tab[row + x1 + 1];
+                TILE_STAT(5, 1); TILE_STAT(6, ke - kb);
+                for (int k = kb; k < ke; k += 4) {
+                    const float4 *qp = &L.pts[k];                // (reads past ke stay inside L: masked below)
+                    float4 q[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) q[u] = qp[u];
+                    const int rem = ke - k;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float ex = p.x - q[u].x, ey = p.y - q[u].y, ez = p.z - q[u].z;
+                        const float d = (ex * ex + ey * ey) + ez * ez;
+                        const unsigned long long ku = ((unsigned long long)__float_as_uint(d) << 32) | (__float_as_uint(q[u].w) ^ 0x80000000u);
+                        const bool take = (u < rem) & (ku < key);
+                        key = take ? ku : key;
+                        kbest = take ? k + u : kbest;
+                    }
+                }
+            }
+        best = __uint_as_float((unsigned int)(key >> 32));
+        bi = (int)((unsigned int)key ^ 0x80000000u);
+        if (kbest >= 0) { const float4 q = L.pts[kbest]; bq = make_float3(q.x, q.y, q.z); }
+    }
+    TILE_STAMP(13);
+    return 1;
+}
+
+// A workgroup's kTileQ correspondences (p, its neighbour q, ok) -> one record of kNSum sums: the operands meet in LDS in the layout
+// corr_reduce_mfma_kernel_body reads from memory, four fp64 matrix-core products per wave, the waves' sums added in wave order.
+__device__ __forceinline__ void tile_reduce(TileLds &L, const float3 p, const float3 q, const bool ok, const float d2, double *record)
+{
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    __syncthreads();                                             // every lane has left pts
+    float *pq = reinterpret_cast<float *>(L.pts) + t * 8;
+    const float okf = ok ? 1.0f : 0.0f;
+    pq[0] = ok ? p.x : 0.f; pq[1] = ok ? p.y : 0.f; pq[2] = ok ? p.z : 0.f; pq[3] = okf;
+    pq[4] = ok ? q.x : 0.f; pq[5] = ok ? q.y : 0.f; pq[6] = ok ? q.z : 0.f; pq[7] = okf;
+    double sum_d2 = ok ? (double)d2 : 0.0;
+    __syncthreads();
+    const int k = lane >> 4, blk = (lane >> 2) & 3, comp = lane & 3;
+    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+    for (int base = 0; base < 64; base += 32) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const float *e = reinterpret_cast<const float *>(L.pts) + (wv * 64 + base + half * 16 + 4 * blk + k) * 8;
+            const double av = (double)e[comp], bv = (double)e[4 + comp];
+            if (half == 0) acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, acc0, 0, 0, 0);
+            else           acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, acc1, 0, 0, 0);
+        }
+    }
+    double d = acc0 + acc1;                                      // lane 16i + 4b + j holds block b's D[i][j]
+    d += __shfl_xor(d, 4, kWave);
+    d += __shfl_xor(d, 8, kWave);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum_d2 += __shfl_xor(sum_d2, off, kWave);
+    if (blk == 0) L.red[wv][k * 4 + comp] = d;
+    if (lane == 0) L.red[wv][16] = sum_d2;
+    __syncthreads();
+    if (t < kNSum) record[t] = ((L.red[0][t] + L.red[1][t]) + L.red[2][t]) + L.red[3][t];
+}
+
+__global__ __launch_bounds__(kTileQ) void icp_tile_search_kernel(const IcpProblem *pr, int n_src, int check_done, int apply, int cold,
+                                                                  int stride, float maxd2, int do_reduce)
+{
+    __shared__ TileLds L;
+    const IcpProblem P = pr[blockIdx.y];
+    const IcpState *st = P.st;
+    if (check_done && st->done) return;
+    const int t = threadIdx.x, wv = t >> 6;
+    const int i = blockIdx.x * kTileQ + t;
+    const bool valid = i < n_src;
+    TileGrid g;
+    g.gx0 = st->mn[0]; g.gy0 = st->mn[1]; g.gz0 = st->mn[2]; g.h = st->h; g.inv_h = 1.0f / st->h; g.dx = st->dim[0]; g.dy = st->dim[1]; g.dz = st->dim[2];
+    float4 pw = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) {
+        pw = P.work[i];
+        if (apply) {                                             // K6: the previous solve's increment moves the working point first
+            const float *T = st->inc_T;
+            const float x = pw.x, y = pw.y, z = pw.z;
+            pw.x = T[0] * x + T[1] * y + T[2] * z + T[3];
+            pw.y = T[4] * x + T[5] * y + T[6] * z + T[7];
+            pw.z = T[8] * x + T[9] * y + T[10] * z + T[11];
+            pw.w = 0.f;
+            P.work[i] = pw;
+        }
+    }
+    const float3 p = make_float3(pw.x, pw.y, pw.z);
+    float best = FLT_MAX;
+    int bi = -1;
+    float3 bq = make_float3(0.f, 0.f, 0.f);
+    bool open = valid;                                           // this lane's search is not finished
+    bool deferred = false;                                       // ... and will be finished in memory by the launch behind this one
+    TILE_STAMP_DECL;
+    if (valid && !cold) {                                        // the previous neighbour bounds the ball
+        const float4 prev = P.nnq[i];
+        const int j = __float_as_int(prev.w);
+        if (j >= 0) {
+            const float ex = p.x - prev.x, ey = p.y - prev.y, ez = p.z - prev.z;
+            const float d = (ex * ex + ey * ey) + ez * ez;
+            if (d == d) { best = d; bi = j; bq = make_float3(prev.x, prev.y, prev.z); }
+        }
+    }
+    // Stages: 0 = the query's own cell, 1 = the 27 cells around it for the queries that found nothing (both only when cold), 2 = the
+    // ball of the best distance known.  A stage's box that does not fit is tried once more wave by wave (64 consecutive sources: a
+    // smaller box); what does not fit then, and the queries that reach stage 2 without a candidate, finish in memory: nn_core's
+    // own walk from whatever the lane knows.  (One loop, so that tile_round and nn_core are instantiated once: registers.)
+    int c[3] = {0, 0, 0};
+    if (cold) cell_index(st, p, c);
+#pragma unroll 1
+    for (int stage = cold ? 0 : 2; stage < 3; ++stage) {
+        int xa = 0, xb = -1, ya = 0, yb = -1, za = 0, zb = -1;
+        bool ask = false, to_memory = false;
+        if (stage == 0) { ask = open; xa = xb = c[0]; ya = yb = c[1]; za = zb = c[2]; }
+        else if (stage == 1) {
+            ask = open && bi < 0;
+            xa = max(c[0] - 1, 0); xb = min(c[0] + 1, g.dx - 1); ya = max(c[1] - 1, 0); yb = min(c[1] + 1, g.dy - 1); za = max(c[2] - 1, 0); zb = min(c[2] + 1, g.dz - 1);
+        } else {
+            to_memory = open && bi < 0;
+            if (open && bi >= 0) {
+                const float reach0 = sqrtf(best) * 1.0005f + 1e-6f * g.h;
+                tile_reach(p.x, g.gx0, g.h, g.dx, reach0, xa, xb);
+                tile_reach(p.y, g.gy0, g.h, g.dy, reach0, ya, yb);
+                tile_reach(p.z, g.gz0, g.h, g.dz, reach0, za, zb);
+                ask = xa <= xb && ya <= yb && za <= zb;
+            }
+        }
+#pragma unroll 1
+        for (int sub = -1; sub < kTileQ / 64; ++sub) {            // -1: the whole workgroup; 0..3: wave by wave after a box that did not fit
+            const bool mine = ask && (sub < 0 || wv == sub);
+            if (stage == 2 && sub < 0) TILE_STAMP(8);            // (everything up to the ball round: loads, seeds, a cold search's stages 0 and 1)
+            const int rc = tile_round(L, g, P.cell_start, P.sorted, mine, xa, xb, ya, yb, za, zb, p, best, bi, bq TILE_STAMP_PASS);
+            if ((rc == 2 && sub >= 0 && mine) || to_memory) {     // left to icp_tile_finish_kernel, with what the lane knows as its seed
+                TILE_STAT(2, 1);
+                deferred = true; open = false; ask = false; to_memory = false;
+            }
+            if (sub < 0 && rc != 2) break;
+        }
+    }
+    // a deferred lane leaves its seed in nnq and a negative distance as the mark; its workgroup's record is then the finish launch's
+    const int any_deferred = __syncthreads_or(deferred ? 1 : 0);
+    if (t == 0) P.flag[blockIdx.x] = any_deferred;
+    if (do_reduce && !any_deferred)
+        tile_reduce(L, p, bq, valid && bi >= 0 && (best <= maxd2), best, P.part + (size_t)blockIdx.x * kNSum);
+    if (valid) {                                                 // (behind the reduction: a barrier waits for the stores in front of it)
+        P.nnq[i] = make_float4(bq.x, bq.y, bq.z, __int_as_float(bi));
+        P.nni[i] = bi;
+        P.nnd[i] = deferred ? -1.0f : best;
+    }
+    TILE_STAMP(14);
+}
+
+// The lanes icp_tile_search_kernel could not serve from LDS (a box that did not fit twice; a query with no candidate near it): nn_core's
+// own walk through memory from the seed the lane left behind, then the workgroup's record.  One launch behind every tile search; a
+// workgroup whose flag is down leaves at once.  (A kernel of its own: inlined in the tile search, this walk's registers cost it two
+// of its five waves per SIMD.)
+__global__ __launch_bounds__(kTileQ) void icp_tile_finish_kernel(const IcpProblem *pr, int n_src, int check_done, int stride, float maxd2, int do_reduce)
+{
+    __shared__ TileLds L;
+    const IcpProblem P = pr[blockIdx.y];
+    const IcpState *st = P.st;
+    if (check_done && st->done) return;
+    if (!P.flag[blockIdx.x]) return;
+    const int t = threadIdx.x;
+    const int i = blockIdx.x * kTileQ + t;
+    const bool valid = i < n_src;
+    float3 p = make_float3(0.f, 0.f, 0.f), bq = make_float3(0.f, 0.f, 0.f);
+    float best = FLT_MAX;
+    int bi = -1;
+    if (valid) {
+        const float4 pw = P.work[i], nq = P.nnq[i];
+        p = make_float3(pw.x, pw.y, pw.z);
+        bq = make_float3(nq.x, nq.y, nq.z);
+        bi = __float_as_int(nq.w);
+        best = P.nnd[i];
+        if (best < 0.f) {                                        // marked: the seed's distance by the walk's own expression, then the walk
+            best = FLT_MAX;
+            if (bi >= 0) {
+                const float ex = p.x - bq.x, ey = p.y - bq.y, ez = p.z - bq.z;
+                const float d = (ex * ex + ey * ey) + ez * ez;
+                if (d == d) best = d; else bi = -1;
+            }
+            nn_core<1>(p, st, P.cell_start, P.sorted, 0, bi >= 0, best, bi);
+            if (bi >= 0) bq = load_xyz(P.tgt, bi, stride);
+            P.nnq[i] = make_float4(bq.x, bq.y, bq.z, __int_as_float(bi));
+            P.nni[i] = bi;
+            P.nnd[i] = best;
+        }
+    }
+    if (do_reduce) tile_reduce(L, p, bq, valid && bi >= 0 && (best <= maxd2), best, P.part + (size_t)blockIdx.x * kNSum);
+}
+
+// ---- the order the sources are worked in: along a Hilbert curve through their own bounding box ---------------------------------
+// key = the Hilbert index of the point's cell in a 1024^3 grid over the cloud's box (NaN -> cell 0); a stable radix sort of
+// (key, index) gives the permutation.  Consecutive cells of the curve share a face, so any run of consecutive sources is one
+// blob in space (a Z-order curve jumps: 7 % of the workgroups' boxes did not fit), for any target grid: the order is made once
+// per scan and shared by the alignments against all its candidates.
+__device__ __forceinline__ unsigned int spread10(unsigned int v)
+{
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void source_key_kernel(const unsigned char *src, int n, int stride, const float *part, int nparts,
+                                                         unsigned int *keys, int *vals)
+{
+    __shared__ float s_box[6];
+    if (threadIdx.x < 64) {                                      // the cloud's box from bbox_partial_kernel's records
+        float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (int b = threadIdx.x; b < nparts; b += 64)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], part[b * 6 + a]); mx[a] = fmaxf(mx[a], part[b * 6 + 3 + a]); }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, kWave)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, kWave)); }
+        if (threadIdx.x == 0) for (int a = 0; a < 3; ++a) { s_box[a] = mn[a]; s_box[3 + a] = mx[a]; }
+    }
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float ext = 0.f;
+    for (int a = 0; a < 3; ++a) ext = fmaxf(ext, s_box[3 + a] - s_box[a]);
+    const float scale = ext > 0.f ? 1023.0f / ext : 0.f;
+    const float3 p = load_xyz(src, i, stride);
+    const float v[3] = {p.x, p.y, p.z};
+    unsigned int X[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float f = (v[a] - s_box[a]) * scale;
+        X[a] = !(f > 0.f) ? 0u : (f >= 1023.f ? 1023u : (unsigned int)f);
+    }
+    // cell coordinates -> the "transposed" Hilbert index (J. Skilling, Programming the Hilbert curve, AIP Conf. Proc. 707, 2004)
+#pragma unroll 1
+    for (unsigned int Q = 512u; Q > 1u; Q >>= 1) {
+        const unsigned int Pm = Q - 1u;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (X[a] & Q) X[0] ^= Pm;
+            else { const unsigned int tt = (X[0] ^ X[a]) & Pm; X[0] ^= tt; X[a] ^= tt; }
+        }
+    }
+    X[1] ^= X[0]; X[2] ^= X[1];
+    unsigned int tt = 0;
+#pragma unroll 1
+    for (unsigned int Q = 512u; Q > 1u; Q >>= 1) if (X[2] & Q) tt ^= Q - 1u;
+    X[0] ^= tt; X[1] ^= tt; X[2] ^= tt;
+    keys[i] = (spread10(X[0]) << 2) | (spread10(X[1]) << 1) | spread10(X[2]);
+    vals[i] = i;
+}
+
+__global__ void work_init_batch_kernel(const IcpProblem *pr, const unsigned char *src, const int *perm, int n, int stride)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float3 p = load_xyz(src, perm[k], stride);
+    pr[blockIdx.y].work[k] = make_float4(p.x, p.y, p.z, 0.f);
+}
+
+// which == 1 only: the final transform applied to the raw source (in the sources' working order) into work
+__global__ void work_final_batch_kernel(const IcpProblem *pr, const unsigned char *src, const int *perm, int n, int stride)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const IcpProblem p = pr[blockIdx.y];
+    const float *T = p.st->final_T;
+    const float3 s = load_xyz(src, perm[k], stride);
+    // distributedMapping.h:247-249 (fp32, left-to-right, no FMA)
+    const float ox = T[0] * s.x + T[1] * s.y + T[2] * s.z + T[3];
+    const float oy = T[4] * s.x + T[5] * s.y + T[6] * s.z + T[7];
+    const float oz = T[8] * s.x + T[9] * s.y + T[10] * s.z + T[11];
+    p.work[k] = make_float4(ox, oy, oz, 0.f);
+}
+
+// results back in the caller's order
+__global__ void unpermute_nn_kernel(const int *perm, const int *nni, const float *nnd, int n, int *out_i, float *out_d)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) { out_i[perm[k]] = nni[k]; out_d[perm[k]] = nnd[k]; }
+}
+
+// the alignments' done flags and, at the end, their states side by side: one copy to the host instead of one per alignment
+__global__ void gather_done_kernel(const IcpProblem *pr, int nprob, int *out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < nprob) out[c] = pr[c].st->done;
+}
+__global__ void gather_states_kernel(const IcpProblem *pr, int nprob, IcpState *out)
+{
+    const int c = blockIdx.x;
+    const int words = (int)(sizeof(IcpState) / sizeof(int));
+    const int *s = reinterpret_cast<const int *>(pr[c].st);
+    int *d = reinterpret_cast<int *>(out + c);
+    for (int w = threadIdx.x; w < words; w += blockDim.x) d[w] = s[w];
+}
+
 
 // ---- host helpers -------------------------------------------------------------------
-// records of the fused iteration: one per workgroup of the search, the cold search (kNnGroup lanes per query) has the most
-static size_t fused_part_bytes(int n_src)
+// partial-sum records of an iteration: one per workgroup of the tile search (point to point), kRedBlocks of the plane reduction
+static size_t part_bytes(int n_src)
 {
     const size_t q = n_src > 0 ? (size_t)n_src : 1;
-    const size_t blocks = (q * 8 + 255) / 256 + 1;
+    const size_t blocks = (q + kTileQ - 1) / kTileQ + 1;
     return sizeof(double) * kNPlane * (blocks > (size_t)kRedBlocks ? blocks : (size_t)kRedBlocks);
-}
-static bool icp_fused_enabled()
-{
-    // SCL_ICP_FUSED=1: search + reduction + solve of an iteration in ONE launch (icp_fused_batch_kernel).  Correct (the same tests
-    // pass) but measured slower -- 15.0 against 10.8 ms per 25-candidate query: the solve's fp64 registers (126 + spills) halve the
-    // occupancy the search lives on (74 registers, six waves per SIMD) -- so the three launches stay the default.
-    static const bool v = [] { const char *e = getenv("SCL_ICP_FUSED"); return e && e[0] == '1'; }();
-    return v;
 }
 static bool use_mfma_reduce()
 {
@@ -1357,10 +1736,22 @@ int check_cloud_args(int n_src, int n_tgt, int stride, std::string *err)
 
 }  // namespace
 
+void icp_tile_stats(unsigned long long out[16], bool reset)
+{
+#ifdef SCL_DIAGNOSTICS
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_stats), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tile_stats), z, sizeof(z)); }
+#else
+    (void)reset;
+    for (int k = 0; k < 16; ++k) out[k] = 0;
+#endif
+}
+
 void icp_workspace_free(IcpWorkspace *ws)
 {
 
-    for (int i = 0; i < 16; ++i) if (ws->buf[i]) { (void)hipFree(ws->buf[i]); ws->buf[i] = nullptr; ws->cap[i] = 0; }
+    for (size_t i = 0; i < sizeof(ws->buf) / sizeof(ws->buf[0]); ++i) if (ws->buf[i]) { (void)hipFree(ws->buf[i]); ws->buf[i] = nullptr; ws->cap[i] = 0; }
+    for (int k = 0; k < 2; ++k) if (ws->ev[k]) { (void)hipEventDestroy(ws->ev[k]); ws->ev[k] = nullptr; }
     if (ws->pinned) { (void)hipHostFree(ws->pinned); ws->pinned = nullptr; ws->pinned_cap = 0; }
 }
 
@@ -1395,125 +1786,71 @@ int icp_stage_cloud(IcpWorkspace *ws, hipStream_t stream, bool target, const voi
     return SCL_OK;
 }
 
+int icp_batch_prepare(IcpWorkspace *ws, hipStream_t stream, const void *d_src, int n_src, int n_tgt, int stride,
+                      const scl_icp_params &p, std::string *err);
+int icp_batch_run(IcpWorkspace *const *wss, int nprob, IcpWorkspace *ctl, hipStream_t stream, const void *d_src, int n_src,
+                  int stride, const scl_icp_params &p, float *T, float *fitness, int *converged, int *iterations, std::string *err);
+
+// One alignment = a batch of one: the same launches, the same order of every sum (tests compare the two bit for bit).
 int icp_align_staged(IcpWorkspace *ws, hipStream_t stream, int n_src, int n_tgt, int stride, const scl_icp_params &p,
                      float T[16], float *fitness, int *converged, int *iterations, std::string *err)
 {
-    int rc = check_cloud_args(n_src, n_tgt, stride, err);
+    int rc = icp_batch_prepare(ws, stream, ws->buf[B_SRC], n_src, n_tgt, stride, p, err);
     if (rc) return rc;
-    if (p.estimator != 0 && p.estimator != 1) { if (err) *err = "unknown estimator"; return SCL_ERR_INVALID_ARG; }
-    if (p.estimator == 1 && !(p.normal_radius > 0.0)) { if (err) *err = "normal_radius must be > 0"; return SCL_ERR_INVALID_ARG; }
-    if (p.max_iterations < 1) { if (err) *err = "max_iterations < 1"; return SCL_ERR_INVALID_ARG; }
-    if ((rc = ensure(ws, B_WORK, sizeof(float4) * (size_t)(n_src + 1), err))) return rc;
-    if ((rc = ensure(ws, B_NNI, sizeof(int) * (size_t)(n_src + 1), err))) return rc;
-    if ((rc = ensure(ws, B_NND, sizeof(float) * (size_t)(n_src + 1), err))) return rc;
-    if ((rc = ensure(ws, B_PART, fused_part_bytes(n_src), err))) return rc;
-    if ((rc = build_grid(ws, stream, n_tgt, stride, err))) return rc;
-    if ((rc = pinned(ws, sizeof(IcpState), err))) return rc;
-    if (p.estimator == 1) {
-        if ((rc = ensure(ws, B_NORM, sizeof(float4) * (size_t)(n_tgt + 1), err))) return rc;
-        hipLaunchKernelGGL(normals_kernel, dim3(((size_t)n_tgt * kNormGroup + 255) / 256 > 0 ? (unsigned)(((size_t)n_tgt * kNormGroup + 255) / 256) : 1u), dim3(256), 0, stream,
-                           (const unsigned char *)ws->buf[B_TGT], n_tgt, stride, (const IcpState *)ws->buf[B_STATE],
-                           (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], p.normal_radius,
-                           (float4 *)ws->buf[B_NORM]);
-    }
-
-    IcpState *st = static_cast<IcpState *>(ws->buf[B_STATE]);
-    float4 *work = static_cast<float4 *>(ws->buf[B_WORK]);
-    const unsigned char *d_src = static_cast<const unsigned char *>(ws->buf[B_SRC]);
-    const unsigned char *d_tgt = static_cast<const unsigned char *>(ws->buf[B_TGT]);
-    int *nni = static_cast<int *>(ws->buf[B_NNI]);
-    float *nnd = static_cast<float *>(ws->buf[B_NND]);
-    double *part = static_cast<double *>(ws->buf[B_PART]);
-    const int pb = (n_src + 255) / 256 > 0 ? (n_src + 255) / 256 : 1;
-    int rb = pb < kRedBlocks ? pb : kRedBlocks;
-    const float maxd2 = (float)(p.max_correspondence_dist * p.max_correspondence_dist);
-
-    hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(64), 0, stream, st);
-    hipLaunchKernelGGL(work_init_kernel, dim3(pb), dim3(256), 0, stream, d_src, n_src, stride, work);
-    IcpState *h = static_cast<IcpState *>(ws->pinned);
-    const bool fused = icp_fused_enabled();
-    const IcpProblem *dprob = nullptr;
-    const int mfma1 = use_mfma_reduce() ? 1 : 0;
-    const long long q1 = n_src > 0 ? n_src : 1;
-    if (fused) {                                             // the one-entry problem table of the fused launches
-        if ((rc = ensure(ws, B_PROB, sizeof(IcpProblem), err))) return rc;
-        if ((rc = pinned(ws, sizeof(IcpState) + sizeof(IcpProblem), err))) return rc;
-        h = static_cast<IcpState *>(ws->pinned);
-        IcpProblem *hp = reinterpret_cast<IcpProblem *>(h + 1);
-        hp->work = work; hp->st = st; hp->cell_start = (const int *)ws->buf[B_CSTART]; hp->sorted = (const float4 *)ws->buf[B_TSORT];
-        hp->nni = nni; hp->nnd = nnd; hp->part = part; hp->tgt = d_tgt; hp->normals = p.estimator == 1 ? (const float4 *)ws->buf[B_NORM] : nullptr;
-        ICP_HIP(hipMemcpyAsync(ws->buf[B_PROB], hp, sizeof(IcpProblem), hipMemcpyHostToDevice, stream));
-        dprob = static_cast<const IcpProblem *>(ws->buf[B_PROB]);
-    }
-    auto fused_launch = [&](bool cold, int apply, int warm, float md2, int mode, int est) {
-        if (cold) hipLaunchKernelGGL(icp_fused_batch_kernel<kNnGroup>, dim3((unsigned)((q1 * kNnGroup + 255) / 256), 1), dim3(256), 0, stream,
-                                     dprob, d_src, n_src, stride, apply, warm, md2, mfma1, mode, est, p.max_iterations, p.transformation_epsilon, p.euclidean_fitness_epsilon);
-        else hipLaunchKernelGGL(icp_fused_batch_kernel<kNnWarmGroup>, dim3((unsigned)((q1 * kNnWarmGroup + 255) / 256), 1), dim3(256), 0, stream,
-                                dprob, d_src, n_src, stride, apply, warm, md2, mfma1, mode, est, p.max_iterations, p.transformation_epsilon, p.euclidean_fitness_epsilon);
-    };
-    // one iteration = neighbour search (K6 of the previous iteration fused in) + reduction + solve: ONE launch
-    auto enqueue_iteration = [&](bool cold) {
-        if (fused) { fused_launch(cold, cold ? -1 : 1, cold ? 0 : 1, maxd2, 0, p.estimator); return; }
-        launch_nn_search(stream, work, n_src, st, (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], nni, nnd, 1,
-                         cold ? -1 : 1, d_tgt, stride, cold ? 0 : 1);
-        if (p.estimator == 1) {
-            hipLaunchKernelGGL(plane_reduce_kernel, dim3(rb), dim3(256), 0, stream, work, d_tgt, stride, n_src, nni, nnd, maxd2,
-                               (const float4 *)ws->buf[B_NORM], st, part);
-            hipLaunchKernelGGL(plane_solve_kernel, dim3(1), dim3(64), 0, stream, st, part, rb, p.max_iterations,
-                               p.transformation_epsilon, p.euclidean_fitness_epsilon);
-        } else {
-            LAUNCH_REDUCE(rb, stream, work, d_src, d_tgt, stride, n_src,
-                          nni, nnd, maxd2, (const int *)nullptr, (const int *)nullptr, 0, st, part, 1);
-            hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, stream, st, part, rb, 0, p.max_iterations,
-                               p.transformation_epsilon, p.euclidean_fitness_epsilon);
-        }
-    };
-    enqueue_iteration(true);
-    for (int it = 1; it < p.max_iterations; ++it) {
-        enqueue_iteration(false);
-        if ((it & 7) == 7 && it + 1 < p.max_iterations) {      // peek at the device flag every 8 iterations
-            ICP_HIP(hipMemcpyAsync(h, st, sizeof(IcpState), hipMemcpyDeviceToHost, stream));
-            ICP_HIP(hipStreamSynchronize(stream));
-            if (h->done) break;
-        }
-    }
-    // fitness: original source moved by the final transform, mean squared NN distance over all points
-    if (fused) {
-        hipLaunchKernelGGL(work_transform_kernel, dim3(pb), dim3(256), 0, stream, work, d_src, n_src, stride, st, 1, 0);
-        fused_launch(false, -1, 1, FLT_MAX, 2, 0);
-    } else {
-        hipLaunchKernelGGL(work_transform_kernel, dim3(pb), dim3(256), 0, stream, work, d_src, n_src, stride, st, 1, 0);
-        launch_nn_search(stream, work, n_src, st,
-                           (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], nni, nnd, 0, -1, d_tgt, stride, 1);
-        LAUNCH_REDUCE(rb, stream, work, d_src, d_tgt, stride, n_src,
-                      nni, nnd, FLT_MAX, (const int *)nullptr, (const int *)nullptr, 0, st, part, 0);
-        hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, stream, st, part, rb, 2, 0, 0.0, 0.0);
-    }
-    ICP_HIP(hipGetLastError());
-    ICP_HIP(hipMemcpyAsync(h, st, sizeof(IcpState), hipMemcpyDeviceToHost, stream));
-    ICP_HIP(hipStreamSynchronize(stream));
-    std::memcpy(T, h->final_T, sizeof(float) * 16);
-    if (fitness) *fitness = (float)h->fitness;
-    if (converged) *converged = h->converged;
-    if (iterations) *iterations = h->iter;
+    IcpWorkspace *one[1] = {ws};
+    float fit = 0.f; int conv = 0, iters = 0;
+    rc = icp_batch_run(one, 1, ws, stream, ws->buf[B_SRC], n_src, stride, p, T, &fit, &conv, &iters, err);
+    if (rc) return rc;
+    if (fitness) *fitness = fit;
+    if (converged) *converged = conv;
+    if (iterations) *iterations = iters;
     return SCL_OK;
 }
 
-// ---- the alignments of one scan's loop candidates, fused (BASELINE configs[2]) -----------------------------------------
-// icp_batch_prepare: everything an alignment needs before its first iteration, for the target staged in ws (B_TGT) and
-// the batch's shared source d_src: buffers, NN grid, normals (point-to-plane), state and working cloud.
+// The order the batch's sources are worked in (B_PERM of ctl): see source_key_kernel.
+static int source_order(IcpWorkspace *ctl, hipStream_t stream, const void *d_src, int n_src, int stride, std::string *err)
+{
+    int rc;
+    const size_t n = n_src > 0 ? (size_t)n_src : 1;
+    if ((rc = ensure(ctl, B_PERM, sizeof(int) * (n + 1), err))) return rc;
+    if (n_src <= 0) return SCL_OK;
+    if ((rc = ensure(ctl, B_BBOX, sizeof(float) * 6 * 256, err))) return rc;
+    size_t tmp_bytes = 0;
+    unsigned int *nk = nullptr; int *nv = nullptr;
+    ICP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, nk, nk, nv, nv, n_src, 0, 30, stream));
+    const size_t arr = (sizeof(int) * n + 255) & ~(size_t)255;
+    if ((rc = ensure(ctl, B_SORT, 3 * arr + tmp_bytes + 256, err))) return rc;
+    unsigned char *base = static_cast<unsigned char *>(ctl->buf[B_SORT]);
+    unsigned int *keys_in = reinterpret_cast<unsigned int *>(base), *keys_out = reinterpret_cast<unsigned int *>(base + arr);
+    int *vals_in = reinterpret_cast<int *>(base + 2 * arr);
+    void *tmp = base + 3 * arr;
+    int nb = (n_src + 255) / 256; nb = nb > 256 ? 256 : nb;
+    hipLaunchKernelGGL(bbox_partial_kernel, dim3(nb), dim3(256), 0, stream, (const unsigned char *)d_src, n_src, stride, (float *)ctl->buf[B_BBOX]);
+    hipLaunchKernelGGL(source_key_kernel, dim3((n_src + 255) / 256), dim3(256), 0, stream, (const unsigned char *)d_src, n_src, stride,
+                       (const float *)ctl->buf[B_BBOX], nb, keys_in, vals_in);
+    ICP_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, (int *)ctl->buf[B_PERM], n_src, 0, 30, stream));
+    ICP_HIP(hipGetLastError());
+    return SCL_OK;
+}
+
+// ---- the alignments of one scan's loop candidates, every loop step one launch for all of them (BASELINE configs[2]) ------------
+// icp_batch_prepare: everything an alignment needs before its first iteration that depends on its target (staged in ws, B_TGT):
+// buffers, NN grid, normals (point-to-plane), state.  (The working clouds are set up by icp_batch_run, in the sources' working order.)
 int icp_batch_prepare(IcpWorkspace *ws, hipStream_t stream, const void *d_src, int n_src, int n_tgt, int stride,
                       const scl_icp_params &p, std::string *err)
 {
+    (void)d_src;
     int rc = check_cloud_args(n_src, n_tgt, stride, err);
     if (rc) return rc;
     if (p.estimator != 0 && p.estimator != 1) { if (err) *err = "unknown estimator"; return SCL_ERR_INVALID_ARG; }
     if (p.estimator == 1 && !(p.normal_radius > 0.0)) { if (err) *err = "normal_radius must be > 0"; return SCL_ERR_INVALID_ARG; }
     if (p.max_iterations < 1) { if (err) *err = "max_iterations < 1"; return SCL_ERR_INVALID_ARG; }
     if ((rc = ensure(ws, B_WORK, sizeof(float4) * (size_t)(n_src + 1), err))) return rc;
+    if ((rc = ensure(ws, B_NNQ, sizeof(float4) * (size_t)(n_src + 1), err))) return rc;
+    if ((rc = ensure(ws, B_FLAG, sizeof(int) * ((size_t)(n_src > n_tgt ? n_src : n_tgt) / kTileQ + 2), err))) return rc;
     if ((rc = ensure(ws, B_NNI, sizeof(int) * (size_t)(n_src + 1), err))) return rc;
     if ((rc = ensure(ws, B_NND, sizeof(float) * (size_t)(n_src + 1), err))) return rc;
-    if ((rc = ensure(ws, B_PART, fused_part_bytes(n_src), err))) return rc;
+    if ((rc = ensure(ws, B_PART, part_bytes(n_src), err))) return rc;
     if ((rc = build_grid(ws, stream, n_tgt, stride, err))) return rc;
     if (p.estimator == 1) {
         if ((rc = ensure(ws, B_NORM, sizeof(float4) * (size_t)(n_tgt + 1), err))) return rc;
@@ -1522,95 +1859,96 @@ int icp_batch_prepare(IcpWorkspace *ws, hipStream_t stream, const void *d_src, i
                            (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], p.normal_radius,
                            (float4 *)ws->buf[B_NORM]);
     }
-    const int pb = (n_src + 255) / 256 > 0 ? (n_src + 255) / 256 : 1;
     hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(64), 0, stream, (IcpState *)ws->buf[B_STATE]);
-    hipLaunchKernelGGL(work_init_kernel, dim3(pb), dim3(256), 0, stream, (const unsigned char *)d_src, n_src, stride, (float4 *)ws->buf[B_WORK]);
     ICP_HIP(hipGetLastError());
     return SCL_OK;
 }
 
+static void fill_problem(IcpProblem *hp, IcpWorkspace *ws, bool normals)
+{
+    hp->work = (float4 *)ws->buf[B_WORK]; hp->st = (IcpState *)ws->buf[B_STATE];
+    hp->cell_start = (const int *)ws->buf[B_CSTART]; hp->sorted = (const float4 *)ws->buf[B_TSORT];
+    hp->nni = (int *)ws->buf[B_NNI]; hp->nnd = (float *)ws->buf[B_NND]; hp->part = (double *)ws->buf[B_PART];
+    hp->tgt = (const unsigned char *)ws->buf[B_TGT]; hp->normals = normals ? (const float4 *)ws->buf[B_NORM] : nullptr;
+    hp->nnq = (float4 *)ws->buf[B_NNQ]; hp->flag = (int *)ws->buf[B_FLAG];
+}
+
 // icp_batch_run: the ICP loops and the fitness passes of nprob prepared alignments, every step one launch for all of
-// them.  ctl keeps the problem table (device) and the pinned read-back area.  Per-alignment results are those of
-// icp_align_staged on the same clouds.
+// them.  ctl keeps the sources' working order, the problem table (device) and the pinned read-back area (it may be the one
+// alignment's own workspace).  An iteration (DM.h:1107-1121's loop body) is two launches: icp_tile_search_kernel (the previous
+// increment applied, neighbours, this workgroup's sums) and the solve; point to plane keeps its reduction as a launch of its own.
 int icp_batch_run(IcpWorkspace *const *wss, int nprob, IcpWorkspace *ctl, hipStream_t stream, const void *d_src, int n_src,
                   int stride, const scl_icp_params &p, float *T, float *fitness, int *converged, int *iterations, std::string *err)
 {
     if (nprob <= 0) return SCL_OK;
     int rc;
+    constexpr int kPeek = 4;                                     // iterations between two looks at the done flags
+    const size_t flags_bytes = (sizeof(int) * (size_t)nprob + 255) & ~(size_t)255;
     if ((rc = ensure(ctl, B_MASK, sizeof(IcpProblem) * (size_t)nprob, err))) return rc;
-    if ((rc = pinned(ctl, (sizeof(IcpProblem) + sizeof(IcpState)) * (size_t)nprob, err))) return rc;
+    if ((rc = ensure(ctl, B_HYP, sizeof(IcpState) * (size_t)nprob + 2 * flags_bytes, err))) return rc;
+    if ((rc = pinned(ctl, (sizeof(IcpProblem) + sizeof(IcpState)) * (size_t)nprob + 2 * flags_bytes, err))) return rc;
+    for (int k = 0; k < 2; ++k) if (!ctl->ev[k]) ICP_HIP(hipEventCreateWithFlags(&ctl->ev[k], hipEventDisableTiming));
     IcpProblem *hp = static_cast<IcpProblem *>(ctl->pinned);
     IcpState *hs = reinterpret_cast<IcpState *>(hp + nprob);
-    for (int c = 0; c < nprob; ++c) {
-        IcpWorkspace *ws = wss[c];
-        hp[c].work = (float4 *)ws->buf[B_WORK]; hp[c].st = (IcpState *)ws->buf[B_STATE];
-        hp[c].cell_start = (const int *)ws->buf[B_CSTART]; hp[c].sorted = (const float4 *)ws->buf[B_TSORT];
-        hp[c].nni = (int *)ws->buf[B_NNI]; hp[c].nnd = (float *)ws->buf[B_NND]; hp[c].part = (double *)ws->buf[B_PART];
-        hp[c].tgt = (const unsigned char *)ws->buf[B_TGT]; hp[c].normals = p.estimator == 1 ? (const float4 *)ws->buf[B_NORM] : nullptr;
-    }
+    unsigned char *h_flags = reinterpret_cast<unsigned char *>(hs + nprob);
+    IcpState *d_states = static_cast<IcpState *>(ctl->buf[B_HYP]);
+    unsigned char *d_flags = reinterpret_cast<unsigned char *>(d_states + nprob);
+    if ((rc = source_order(ctl, stream, d_src, n_src, stride, err))) return rc;
+    for (int c = 0; c < nprob; ++c) fill_problem(&hp[c], wss[c], p.estimator == 1);
     const IcpProblem *dp = static_cast<const IcpProblem *>(ctl->buf[B_MASK]);
     ICP_HIP(hipMemcpyAsync(ctl->buf[B_MASK], hp, sizeof(IcpProblem) * (size_t)nprob, hipMemcpyHostToDevice, stream));
     const unsigned char *src = static_cast<const unsigned char *>(d_src);
+    const int *perm = static_cast<const int *>(ctl->buf[B_PERM]);
     const long long q = n_src > 0 ? n_src : 1;
-    const int pb = (int)((q + 255) / 256);
+    const int pb = (int)((q + 255) / 256), tb = (int)((q + kTileQ - 1) / kTileQ);
     const int rb = pb < kRedBlocks ? pb : kRedBlocks;
     const float maxd2 = (float)(p.max_correspondence_dist * p.max_correspondence_dist);
-    const int mfma = use_mfma_reduce() ? 1 : 0;
-    auto search = [&](bool cold, int check_done) {
-        if (cold) hipLaunchKernelGGL(nn_search_batch_kernel<kNnGroup>, dim3((unsigned)((q * kNnGroup + 255) / 256), nprob), dim3(256), 0, stream,
-                                     dp, n_src, check_done, -1, stride, 0);
-        else hipLaunchKernelGGL(nn_search_batch_kernel<kNnWarmGroup>, dim3((unsigned)((q * kNnWarmGroup + 255) / 256), nprob), dim3(256), 0, stream,
-                                dp, n_src, check_done, 1, stride, 1);
-    };
-    const bool fused = icp_fused_enabled();
-    auto fused_launch = [&](bool cold, int apply, int warm, float md2, int mode, int est) {
-        if (cold) hipLaunchKernelGGL(icp_fused_batch_kernel<kNnGroup>, dim3((unsigned)((q * kNnGroup + 255) / 256), nprob), dim3(256), 0, stream,
-                                     dp, src, n_src, stride, apply, warm, md2, mfma, mode, est, p.max_iterations, p.transformation_epsilon, p.euclidean_fitness_epsilon);
-        else hipLaunchKernelGGL(icp_fused_batch_kernel<kNnWarmGroup>, dim3((unsigned)((q * kNnWarmGroup + 255) / 256), nprob), dim3(256), 0, stream,
-                                dp, src, n_src, stride, apply, warm, md2, mfma, mode, est, p.max_iterations, p.transformation_epsilon, p.euclidean_fitness_epsilon);
-    };
+    hipLaunchKernelGGL(work_init_batch_kernel, dim3(pb, nprob), dim3(256), 0, stream, dp, src, perm, n_src, stride);
     auto iteration = [&](bool cold) {
-        if (fused) { fused_launch(cold, cold ? -1 : 1, cold ? 0 : 1, maxd2, 0, p.estimator); return; }
-        search(cold, 1);
+        hipLaunchKernelGGL(icp_tile_search_kernel, dim3(tb, nprob), dim3(kTileQ), 0, stream, dp, n_src, 1, cold ? 0 : 1, cold ? 1 : 0, stride, maxd2,
+                           p.estimator == 0 ? 1 : 0);
+        hipLaunchKernelGGL(icp_tile_finish_kernel, dim3(tb, nprob), dim3(kTileQ), 0, stream, dp, n_src, 1, stride, maxd2, p.estimator == 0 ? 1 : 0);
         if (p.estimator == 1) {
             hipLaunchKernelGGL(plane_reduce_batch_kernel, dim3(rb, nprob), dim3(256), 0, stream, dp, stride, n_src, maxd2);
             hipLaunchKernelGGL(plane_solve_batch_kernel, dim3(nprob), dim3(64), 0, stream, dp, rb, p.max_iterations, p.transformation_epsilon,
                                p.euclidean_fitness_epsilon);
         } else {
-            hipLaunchKernelGGL(corr_reduce_batch_kernel, dim3(rb, nprob), dim3(256), 0, stream, dp, src, stride, n_src, maxd2, 1, mfma);
-            hipLaunchKernelGGL(icp_solve_batch_kernel, dim3(nprob), dim3(64), 0, stream, dp, rb, 0, p.max_iterations, p.transformation_epsilon,
+            hipLaunchKernelGGL(icp_solve_batch_kernel, dim3(nprob), dim3(64), 0, stream, dp, tb, 0, p.max_iterations, p.transformation_epsilon,
                                p.euclidean_fitness_epsilon);
         }
     };
-    auto read_states = [&]() -> int {
-        for (int c = 0; c < nprob; ++c) ICP_HIP(hipMemcpyAsync(&hs[c], hp[c].st, sizeof(IcpState), hipMemcpyDeviceToHost, stream));
-        ICP_HIP(hipStreamSynchronize(stream));
-        return SCL_OK;
-    };
+    // The done flags travel to the host every kPeek iterations and are looked at one period later, when they have long arrived:
+    // the host never waits for the device to drain (a finished alignment's workgroups leave at once, so the iterations enqueued in
+    // the meantime cost a launch each)
+    int slot = 0, pending = -1;
     iteration(true);
     for (int it = 1; it < p.max_iterations; ++it) {
         iteration(false);
-        if ((it & 7) == 7 && it + 1 < p.max_iterations) {      // peek at the done flags every 8 iterations
-            if ((rc = read_states())) return rc;
-            bool all = true;
-            for (int c = 0; c < nprob; ++c) all &= hs[c].done != 0;
-            if (all) break;
+        if ((it % kPeek) == kPeek - 1 && it + 1 < p.max_iterations) {
+            if (pending >= 0) {
+                ICP_HIP(hipEventSynchronize(ctl->ev[pending]));
+                const int *f = reinterpret_cast<const int *>(h_flags + (size_t)pending * flags_bytes);
+                bool all = true;
+                for (int c = 0; c < nprob; ++c) all &= f[c] != 0;
+                if (all) break;
+            }
+            hipLaunchKernelGGL(gather_done_kernel, dim3((nprob + 63) / 64), dim3(64), 0, stream, dp, nprob, (int *)(d_flags + (size_t)slot * flags_bytes));
+            ICP_HIP(hipMemcpyAsync(h_flags + (size_t)slot * flags_bytes, d_flags + (size_t)slot * flags_bytes, sizeof(int) * (size_t)nprob,
+                                   hipMemcpyDeviceToHost, stream));
+            ICP_HIP(hipEventRecord(ctl->ev[slot], stream));
+            pending = slot; slot ^= 1;
         }
     }
-    // fitness: the original source moved by each final transform, mean squared NN distance over all points (warm: the
-    // last neighbour bounds the search)
-    if (fused) {
-        hipLaunchKernelGGL(work_transform_batch_kernel, dim3(pb, nprob), dim3(256), 0, stream, dp, src, n_src, stride, 1);
-        fused_launch(false, -1, 1, FLT_MAX, 2, 0);
-    } else {
-        hipLaunchKernelGGL(work_transform_batch_kernel, dim3(pb, nprob), dim3(256), 0, stream, dp, src, n_src, stride, 1);
-        hipLaunchKernelGGL(nn_search_batch_kernel<kNnWarmGroup>, dim3((unsigned)((q * kNnWarmGroup + 255) / 256), nprob), dim3(256), 0, stream,
-                           dp, n_src, 0, -1, stride, 1);
-        hipLaunchKernelGGL(corr_reduce_batch_kernel, dim3(rb, nprob), dim3(256), 0, stream, dp, src, stride, n_src, FLT_MAX, 0, mfma);
-        hipLaunchKernelGGL(icp_solve_batch_kernel, dim3(nprob), dim3(64), 0, stream, dp, rb, 2, 0, 0.0, 0.0);
-    }
+    // fitness: the original source moved by each final transform, mean squared NN distance over all points (the last
+    // neighbour bounds the search)
+    hipLaunchKernelGGL(work_final_batch_kernel, dim3(pb, nprob), dim3(256), 0, stream, dp, src, perm, n_src, stride);
+    hipLaunchKernelGGL(icp_tile_search_kernel, dim3(tb, nprob), dim3(kTileQ), 0, stream, dp, n_src, 0, 0, 0, stride, FLT_MAX, 1);
+    hipLaunchKernelGGL(icp_tile_finish_kernel, dim3(tb, nprob), dim3(kTileQ), 0, stream, dp, n_src, 0, stride, FLT_MAX, 1);
+    hipLaunchKernelGGL(icp_solve_batch_kernel, dim3(nprob), dim3(64), 0, stream, dp, tb, 2, 0, 0.0, 0.0);
+    hipLaunchKernelGGL(gather_states_kernel, dim3(nprob), dim3(64), 0, stream, dp, nprob, d_states);
     ICP_HIP(hipGetLastError());
-    if ((rc = read_states())) return rc;
+    ICP_HIP(hipMemcpyAsync(hs, d_states, sizeof(IcpState) * (size_t)nprob, hipMemcpyDeviceToHost, stream));
+    ICP_HIP(hipStreamSynchronize(stream));
     for (int c = 0; c < nprob; ++c) {
         std::memcpy(T + 16 * (size_t)c, hs[c].final_T, sizeof(float) * 16);
         if (fitness) fitness[c] = (float)hs[c].fitness;
@@ -1620,28 +1958,49 @@ int icp_batch_run(IcpWorkspace *const *wss, int nprob, IcpWorkspace *ctl, hipStr
     return SCL_OK;
 }
 
+// T_move == nullptr: every source point's nearest target point (a cold search).  T_move: the correspondences of the source moved
+// by T_move, searched from those of the unmoved source -- the warm search of a loop iteration, on its own.
 int icp_nn_correspondences(IcpWorkspace *ws, hipStream_t stream, int num_cu, const void *src, int n_src,
-                           const void *tgt, int n_tgt, int stride, int *nn_index, float *nn_dist2, std::string *err)
+                           const void *tgt, int n_tgt, int stride, const float *T_move, int *nn_index, float *nn_dist2, std::string *err)
 {
     (void)num_cu;
     int rc = check_cloud_args(n_src, n_tgt, stride, err);
     if (rc) return rc;
+    if (n_src == 0) return SCL_OK;
     if ((rc = upload(ws, B_SRC, src, (size_t)n_src * stride, stream, err))) return rc;
     if ((rc = upload(ws, B_TGT, tgt, (size_t)n_tgt * stride, stream, err))) return rc;
     if ((rc = ensure(ws, B_WORK, sizeof(float4) * (size_t)(n_src + 1), err))) return rc;
+    if ((rc = ensure(ws, B_NNQ, sizeof(float4) * (size_t)(n_src + 1), err))) return rc;
+    if ((rc = ensure(ws, B_FLAG, sizeof(int) * ((size_t)(n_src > 0 ? n_src : 1) / kTileQ + 2), err))) return rc;
     if ((rc = ensure(ws, B_NNI, sizeof(int) * (size_t)(n_src + 1), err))) return rc;
     if ((rc = ensure(ws, B_NND, sizeof(float) * (size_t)(n_src + 1), err))) return rc;
+    if ((rc = ensure(ws, B_PART, part_bytes(n_src), err))) return rc;
+    if ((rc = ensure(ws, B_SI, sizeof(int) * (size_t)(n_src + 1), err))) return rc;
+    if ((rc = ensure(ws, B_TI, sizeof(float) * (size_t)(n_src + 1), err))) return rc;
+    if ((rc = ensure(ws, B_MASK, sizeof(IcpProblem), err))) return rc;
+    if ((rc = pinned(ws, sizeof(IcpProblem) + sizeof(IcpState), err))) return rc;
     if ((rc = build_grid(ws, stream, n_tgt, stride, err))) return rc;
-    IcpState *st = static_cast<IcpState *>(ws->buf[B_STATE]);
-    const int pb = (n_src + 255) / 256 > 0 ? (n_src + 255) / 256 : 1;
-    hipLaunchKernelGGL(work_init_kernel, dim3(pb), dim3(256), 0, stream, (const unsigned char *)ws->buf[B_SRC], n_src, stride,
-                       (float4 *)ws->buf[B_WORK]);
-    launch_nn_search(stream, (float4 *)ws->buf[B_WORK], n_src, st,
-                       (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], (int *)ws->buf[B_NNI],
-                       (float *)ws->buf[B_NND], 0, -1, (const unsigned char *)ws->buf[B_TGT], stride, 0);
+    if ((rc = source_order(ws, stream, ws->buf[B_SRC], n_src, stride, err))) return rc;
+    IcpProblem *hp = static_cast<IcpProblem *>(ws->pinned);
+    fill_problem(hp, ws, false);
+    ICP_HIP(hipMemcpyAsync(ws->buf[B_MASK], hp, sizeof(IcpProblem), hipMemcpyHostToDevice, stream));
+    const IcpProblem *dp = static_cast<const IcpProblem *>(ws->buf[B_MASK]);
+    const int pb = (n_src + 255) / 256, tb = (n_src + kTileQ - 1) / kTileQ;
+    hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(64), 0, stream, (IcpState *)ws->buf[B_STATE]);
+    hipLaunchKernelGGL(work_init_batch_kernel, dim3(pb, 1), dim3(256), 0, stream, dp, (const unsigned char *)ws->buf[B_SRC], (const int *)ws->buf[B_PERM], n_src, stride);
+    hipLaunchKernelGGL(icp_tile_search_kernel, dim3(tb, 1), dim3(kTileQ), 0, stream, dp, n_src, 0, 0, 1, stride, FLT_MAX, 0);
+    hipLaunchKernelGGL(icp_tile_finish_kernel, dim3(tb, 1), dim3(kTileQ), 0, stream, dp, n_src, 0, stride, FLT_MAX, 0);
+    if (T_move) {
+        IcpState *st = static_cast<IcpState *>(ws->buf[B_STATE]);
+        ICP_HIP(hipMemcpyAsync(st->inc_T, T_move, sizeof(float) * 16, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(icp_tile_search_kernel, dim3(tb, 1), dim3(kTileQ), 0, stream, dp, n_src, 0, 1, 0, stride, FLT_MAX, 0);
+        hipLaunchKernelGGL(icp_tile_finish_kernel, dim3(tb, 1), dim3(kTileQ), 0, stream, dp, n_src, 0, stride, FLT_MAX, 0);
+    }
+    hipLaunchKernelGGL(unpermute_nn_kernel, dim3(pb), dim3(256), 0, stream, (const int *)ws->buf[B_PERM], (const int *)ws->buf[B_NNI], (const float *)ws->buf[B_NND],
+                       n_src, (int *)ws->buf[B_SI], (float *)ws->buf[B_TI]);
     ICP_HIP(hipGetLastError());
-    ICP_HIP(hipMemcpyAsync(nn_index, ws->buf[B_NNI], sizeof(int) * (size_t)n_src, hipMemcpyDeviceToHost, stream));
-    if (nn_dist2) ICP_HIP(hipMemcpyAsync(nn_dist2, ws->buf[B_NND], sizeof(float) * (size_t)n_src, hipMemcpyDeviceToHost, stream));
+    ICP_HIP(hipMemcpyAsync(nn_index, ws->buf[B_SI], sizeof(int) * (size_t)n_src, hipMemcpyDeviceToHost, stream));
+    if (nn_dist2) ICP_HIP(hipMemcpyAsync(nn_dist2, ws->buf[B_TI], sizeof(float) * (size_t)n_src, hipMemcpyDeviceToHost, stream));
     ICP_HIP(hipStreamSynchronize(stream));
     return SCL_OK;
 }

@@ -10,13 +10,16 @@
 namespace scl {
 
 struct IcpWorkspace {
-    void *buf[20] = {nullptr};
-    size_t cap[20] = {0};
+    void *buf[24] = {nullptr};
+    size_t cap[24] = {0};
     void *pinned = nullptr;
     size_t pinned_cap = 0;
+    hipEvent_t ev[2] = {nullptr, nullptr};     // the batch loop's two looks at the done flags in flight
 };
 
 void icp_workspace_free(IcpWorkspace *ws);
+// counters of the tile search (builds with -DSCL_DIAGNOSTICS; zeros otherwise): scripts/probe_icp_tiles.py
+void icp_tile_stats(unsigned long long out[16], bool reset);
 
 int icp_align(IcpWorkspace *ws, hipStream_t stream, int num_cu, const void *src, int n_src,
               const void *tgt, int n_tgt, int stride_bytes, const scl_icp_params &p,
@@ -36,7 +39,7 @@ int icp_batch_prepare(IcpWorkspace *ws, hipStream_t stream, const void *d_src, i
 int icp_batch_run(IcpWorkspace *const *wss, int nprob, IcpWorkspace *ctl, hipStream_t stream, const void *d_src, int n_src,
                   int stride, const scl_icp_params &p, float *T, float *fitness, int *converged, int *iterations, std::string *err);
 int icp_nn_correspondences(IcpWorkspace *ws, hipStream_t stream, int num_cu, const void *src, int n_src,
-                           const void *tgt, int n_tgt, int stride_bytes, int *nn_index, float *nn_dist2,
+                           const void *tgt, int n_tgt, int stride_bytes, const float *T_move, int *nn_index, float *nn_dist2,
                            std::string *err);
 int icp_rigid_svd(IcpWorkspace *ws, hipStream_t stream, int num_cu, const void *src, int n_src,
                   const void *tgt, int n_tgt, int stride_bytes, const int *src_index, const int *tgt_index,

@@ -107,6 +107,7 @@ def _bind(lib):
         "scl_icp_align": (c_int, [P, P, c_int, P, c_int, c_int, POINTER(IcpParams), fp, fp, ip, ip]),
         "scl_icp_align_batch": (c_int, [P, P, c_int, POINTER(c_void_p), ip, c_int, c_int, POINTER(IcpParams), fp, fp, ip, ip]),
         "scl_nn_correspondences": (c_int, [P, P, c_int, P, c_int, c_int, ip, fp]),
+        "scl_nn_correspondences_moved": (c_int, [P, P, c_int, P, c_int, c_int, fp, ip, fp]),
         "scl_rigid_svd": (c_int, [P, P, c_int, P, c_int, c_int, ip, ip, c_int, fp]),
         "scl_transform_cloud": (c_int, [P, P, c_int, c_int, fp, P]),
         "scl_voxel_grid": (c_int, [P, P, c_int, c_int, c_float, P, c_int, ip]),
@@ -466,6 +467,19 @@ class ScanContextEngine:
         self._check(self._lib.scl_nn_correspondences(self._h, s.ctypes.data_as(c_void_p), ns,
                                                      t.ctypes.data_as(c_void_p), nt, stride,
                                                      _ptr(idx, c_int), _ptr(d2, c_float)), "scl_nn_correspondences")
+        return idx, d2
+
+    def nn_correspondences_moved(self, src, tgt, T):
+        """Correspondences of `src` moved by the 4x4 `T`, searched warm from those of the unmoved cloud."""
+        s, ns, stride = _cloud(src)
+        t, nt, stride_t = _cloud(tgt)
+        if stride != stride_t:
+            raise ValueError("source and target must share a record layout")
+        Tm = np.ascontiguousarray(T, dtype=np.float32).reshape(16)
+        idx = np.empty(ns, dtype=np.int32); d2 = np.empty(ns, dtype=np.float32)
+        self._check(self._lib.scl_nn_correspondences_moved(self._h, s.ctypes.data_as(c_void_p), ns,
+                                                           t.ctypes.data_as(c_void_p), nt, stride, _ptr(Tm, c_float),
+                                                           _ptr(idx, c_int), _ptr(d2, c_float)), "scl_nn_correspondences_moved")
         return idx, d2
 
     def rigid_svd(self, src, tgt, src_index, tgt_index):

@@ -50,7 +50,11 @@ else:
         print(f"--- phase {bi}: {len(b)} kernels, span {span:.0f} us, device busy {busy / 1e3:.0f} us")
         agg = defaultdict(lambda: [0, 0])
         for s, e, n in b:
-            short = n.split("(anonymous namespace)::")[-1].split("(")[0][:44]
+            short = n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].split("<")[0].split("::")[-1][:44] or n[:44]
             agg[short][0] += 1; agg[short][1] += e - s
         for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
             print(f"   {n:44s} calls {c:4d} total {t / 1e3:8.1f} us  avg {t / c / 1e3:7.1f}")
+        tile = [(s - b[0][0], e - s) for s, e, n in b if "icp_tile_search_kernel" in n.split("(")[0] + n.split("(anonymous namespace)::")[1 if "(anonymous namespace)::" in n else 0].split("(")[0]]
+        if tile:
+            print("   icp_tile_search_kernel, start (us after the phase's first kernel) : duration (us):")
+            print("      " + "  ".join(f"{s / 1e3:.0f}:{d / 1e3:.0f}" for s, d in tile))

@@ -30,6 +30,38 @@ def test_nn_correspondences_bit_exact(eng, n_src, n_tgt):
     assert np.array_equal(gd.view(np.uint32), od.view(np.uint32))
 
 
+@pytest.mark.parametrize("n_src,n_tgt,shift", [(1500, 5000, 0.05), (60000, 100000, 0.3), (20000, 30000, 3.0), (300, 1000, 40.0), (1, 10, 0.1)])
+def test_nn_correspondences_of_the_moved_source_bit_exact(eng, n_src, n_tgt, shift):
+    """The warm search of a loop iteration (LDS tiles seeded by the previous neighbours, icp.hip K4c): the source moved by T,
+    searched from the unmoved source's correspondences == a cold search of the moved cloud (checker), small and large moves
+    (the large ones overflow the tiles and finish in memory)."""
+    tgt = synth_structured_cloud(n_tgt, seed=2 + n_tgt)
+    src = synth_structured_cloud(n_src, seed=3 + n_src)
+    src[: max(1, n_src // 50), :3] += 250.0
+    T = rigid_transform(0.003, -0.002, 0.01, shift, -0.5 * shift, 0.1 * shift).astype(np.float32)
+    gi, gd = eng.nn_correspondences_moved(src, tgt, T)
+    oi_, od = oi.nn(oi.transform(src, T), tgt, use_grid=True)
+    assert np.array_equal(gi, oi_)
+    assert np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+
+
+def test_nn_correspondences_large_and_degenerate_clouds(eng):
+    """100 k x 100 k (configs[2]'s size), a target that is one point, a target on a line, sources with NaN coordinates."""
+    tgt = synth_structured_cloud(100000, seed=41, extent=60.0)
+    src = synth_structured_cloud(100000, seed=42, extent=60.0)
+    gi, gd = eng.nn_correspondences(src, tgt)
+    oi_, od = oi.nn(src, tgt, use_grid=True)
+    assert np.array_equal(gi, oi_) and np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+    one = tgt[:1].copy()
+    gi, gd = eng.nn_correspondences(src[:1000], one)
+    oi_, od = oi.nn(src[:1000], one, use_grid=True)
+    assert np.array_equal(gi, oi_) and np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+    line = np.zeros((500, 8), np.float32); line[:, 0] = np.linspace(-30, 30, 500)
+    gi, gd = eng.nn_correspondences(src[:3000], line)
+    oi_, od = oi.nn(src[:3000], line, use_grid=True)
+    assert np.array_equal(gi, oi_) and np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+
+
 def test_nn_ties_lowest_index(eng):
     tgt = np.zeros((6, 8), np.float32); tgt[:, 0] = [1, 1, 1, 5, 5, 1]
     src = np.zeros((2, 8), np.float32); src[1, 0] = 5
