@@ -1372,11 +1372,12 @@ __device__ __forceinline__ int tile_round(TileLds &L, const TileGrid &g, const i
 
 // A workgroup's kTileQ correspondences (p, its neighbour q, ok) -> one record of kNSum sums: the operands meet in LDS in the layout
 // corr_reduce_mfma_kernel_body reads from memory, four fp64 matrix-core products per wave, the waves' sums added in wave order.
-__device__ __forceinline__ void tile_reduce(TileLds &L, const float3 p, const float3 q, const bool ok, const float d2, double *record)
+__device__ __forceinline__ void tile_reduce(float *pq_area /* kTileQ x 8 floats of LDS */, double (*red)[kNSum] /* [kTileQ / 64] in LDS */,
+                                            const float3 p, const float3 q, const bool ok, const float d2, double *record)
 {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    __syncthreads();                                             // every lane has left pts
-    float *pq = reinterpret_cast<float *>(L.pts) + t * 8;
+    __syncthreads();                                             // every lane has left the area
+    float *pq = pq_area + t * 8;
     const float okf = ok ? 1.0f : 0.0f;
     pq[0] = ok ? p.x : 0.f; pq[1] = ok ? p.y : 0.f; pq[2] = ok ? p.z : 0.f; pq[3] = okf;
     pq[4] = ok ? q.x : 0.f; pq[5] = ok ? q.y : 0.f; pq[6] = ok ? q.z : 0.f; pq[7] = okf;
@@ -1388,7 +1389,7 @@ __device__ __forceinline__ void tile_reduce(TileLds &L, const float3 p, const fl
     for (int base = 0; base < 64; base += 32) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            const float *e = reinterpret_cast<const float *>(L.pts) + (wv * 64 + base + half * 16 + 4 * blk + k) * 8;
+            const float *e = pq_area + (wv * 64 + base + half * 16 + 4 * blk + k) * 8;
             const double av = (double)e[comp], bv = (double)e[4 + comp];
             if (half == 0) acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, acc0, 0, 0, 0);
             else           acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, acc1, 0, 0, 0);
@@ -1399,10 +1400,10 @@ __device__ __forceinline__ void tile_reduce(TileLds &L, const float3 p, const fl
     d += __shfl_xor(d, 8, kWave);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sum_d2 += __shfl_xor(sum_d2, off, kWave);
-    if (blk == 0) L.red[wv][k * 4 + comp] = d;
-    if (lane == 0) L.red[wv][16] = sum_d2;
+    if (blk == 0) red[wv][k * 4 + comp] = d;
+    if (lane == 0) red[wv][16] = sum_d2;
     __syncthreads();
-    if (t < kNSum) record[t] = ((L.red[0][t] + L.red[1][t]) + L.red[2][t]) + L.red[3][t];
+    if (t < kNSum) record[t] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
 }
 
 __global__ __launch_bounds__(kTileQ) void icp_tile_search_kernel(const IcpProblem *pr, int n_src, int check_done, int apply, int cold,
@@ -1486,7 +1487,7 @@ __global__ __launch_bounds__(kTileQ) void icp_tile_search_kernel(const IcpProble
     const int any_deferred = __syncthreads_or(deferred ? 1 : 0);
     if (t == 0) P.flag[blockIdx.x] = any_deferred;
     if (do_reduce && !any_deferred)
-        tile_reduce(L, p, bq, valid && bi >= 0 && (best <= maxd2), best, P.part + (size_t)blockIdx.x * kNSum);
+        tile_reduce(reinterpret_cast<float *>(L.pts), L.red, p, bq, valid && bi >= 0 && (best <= maxd2), best, P.part + (size_t)blockIdx.x * kNSum);
     if (valid) {                                                 // (behind the reduction: a barrier waits for the stores in front of it)
         P.nnq[i] = make_float4(bq.x, bq.y, bq.z, __int_as_float(bi));
         P.nni[i] = bi;
@@ -1532,7 +1533,40 @@ __global__ __launch_bounds__(kTileQ) void icp_tile_finish_kernel(const IcpProble
             P.nnd[i] = best;
         }
     }
-    if (do_reduce) tile_reduce(L, p, bq, valid && bi >= 0 && (best <= maxd2), best, P.part + (size_t)blockIdx.x * kNSum);
+    if (do_reduce) tile_reduce(reinterpret_cast<float *>(L.pts), L.red, p, bq, valid && bi >= 0 && (best <= maxd2), best, P.part + (size_t)blockIdx.x * kNSum);
+}
+
+// ---- the same iteration for launches too small to fill the chip with tiles (one alignment, a few small ones) --------------------
+// A tile workgroup lives through four dependent rounds of loads; with one workgroup per CU nothing hides them (a lone alignment of
+// 50 k points: 30 us per search against 18).  Below kTileMinQueries queries per launch the neighbours are searched in memory, two
+// lanes per query (nn_search_kernel_t_body, in the sources' working order), and chunk_reduce_batch_kernel forms the SAME records
+// from the SAME values (exact neighbours, tile_reduce on kTileQ consecutive sources): which path a launch takes changes no bit of
+// the result, so an alignment on its own still equals the same alignment inside a batch.
+constexpr long long kTileMinQueries = 300000;
+template <int G>
+__global__ __launch_bounds__(256) void nn_search_batch_kernel(const IcpProblem *pr, int n_src, int check_done, int apply_iter, int stride, int warm)
+{
+    const IcpProblem p = pr[blockIdx.y];
+    nn_search_kernel_t_body<G>(p.work, n_src, p.st, p.cell_start, p.sorted, p.nni, p.nnd, check_done, apply_iter, p.tgt, stride, warm);
+}
+
+__global__ __launch_bounds__(kTileQ) void chunk_reduce_batch_kernel(const IcpProblem *pr, int n_src, int check_done, int stride, float maxd2)
+{
+    __shared__ float pq[kTileQ * 8];
+    __shared__ double red[kTileQ / 64][kNSum];
+    const IcpProblem P = pr[blockIdx.y];
+    if (check_done && P.st->done) return;
+    const int i = blockIdx.x * kTileQ + threadIdx.x;
+    float3 p = make_float3(0.f, 0.f, 0.f), q = make_float3(0.f, 0.f, 0.f);
+    float d2 = FLT_MAX;
+    int j = -1;
+    if (i < n_src) {
+        const float4 pw = P.work[i];
+        p = make_float3(pw.x, pw.y, pw.z);
+        j = P.nni[i]; d2 = P.nnd[i];
+        if (j >= 0) q = load_xyz(P.tgt, j, stride);
+    }
+    tile_reduce(pq, red, p, q, i < n_src && j >= 0 && (d2 <= maxd2), d2, P.part + (size_t)blockIdx.x * kNSum);
 }
 
 // ---- the order the sources are worked in: along a Hilbert curve through their own bounding box ---------------------------------
@@ -1904,10 +1938,22 @@ int icp_batch_run(IcpWorkspace *const *wss, int nprob, IcpWorkspace *ctl, hipStr
     const int rb = pb < kRedBlocks ? pb : kRedBlocks;
     const float maxd2 = (float)(p.max_correspondence_dist * p.max_correspondence_dist);
     hipLaunchKernelGGL(work_init_batch_kernel, dim3(pb, nprob), dim3(256), 0, stream, dp, src, perm, n_src, stride);
+    const bool tiles = (long long)nprob * q >= kTileMinQueries;   // (no bit of the result depends on it: see chunk_reduce_batch_kernel)
+    // neighbours (the previous increment applied first) and, point to point, the records of the workgroups' sums
+    auto search_and_sums = [&](bool cold, int check_done, int apply, float md2, bool sums) {
+        if (tiles) {
+            hipLaunchKernelGGL(icp_tile_search_kernel, dim3(tb, nprob), dim3(kTileQ), 0, stream, dp, n_src, check_done, apply, cold ? 1 : 0, stride, md2, sums ? 1 : 0);
+            hipLaunchKernelGGL(icp_tile_finish_kernel, dim3(tb, nprob), dim3(kTileQ), 0, stream, dp, n_src, check_done, stride, md2, sums ? 1 : 0);
+            return;
+        }
+        if (cold) hipLaunchKernelGGL(nn_search_batch_kernel<kNnGroup>, dim3((unsigned)((q * kNnGroup + 255) / 256), nprob), dim3(256), 0, stream,
+                                     dp, n_src, check_done, apply ? 1 : -1, stride, 0);
+        else hipLaunchKernelGGL(nn_search_batch_kernel<kNnWarmGroup>, dim3((unsigned)((q * kNnWarmGroup + 255) / 256), nprob), dim3(256), 0, stream,
+                                dp, n_src, check_done, apply ? 1 : -1, stride, 1);
+        if (sums) hipLaunchKernelGGL(chunk_reduce_batch_kernel, dim3(tb, nprob), dim3(kTileQ), 0, stream, dp, n_src, check_done, stride, md2);
+    };
     auto iteration = [&](bool cold) {
-        hipLaunchKernelGGL(icp_tile_search_kernel, dim3(tb, nprob), dim3(kTileQ), 0, stream, dp, n_src, 1, cold ? 0 : 1, cold ? 1 : 0, stride, maxd2,
-                           p.estimator == 0 ? 1 : 0);
-        hipLaunchKernelGGL(icp_tile_finish_kernel, dim3(tb, nprob), dim3(kTileQ), 0, stream, dp, n_src, 1, stride, maxd2, p.estimator == 0 ? 1 : 0);
+        search_and_sums(cold, 1, cold ? 0 : 1, maxd2, p.estimator == 0);
         if (p.estimator == 1) {
             hipLaunchKernelGGL(plane_reduce_batch_kernel, dim3(rb, nprob), dim3(256), 0, stream, dp, stride, n_src, maxd2);
             hipLaunchKernelGGL(plane_solve_batch_kernel, dim3(nprob), dim3(64), 0, stream, dp, rb, p.max_iterations, p.transformation_epsilon,
@@ -1942,8 +1988,7 @@ int icp_batch_run(IcpWorkspace *const *wss, int nprob, IcpWorkspace *ctl, hipStr
     // fitness: the original source moved by each final transform, mean squared NN distance over all points (the last
     // neighbour bounds the search)
     hipLaunchKernelGGL(work_final_batch_kernel, dim3(pb, nprob), dim3(256), 0, stream, dp, src, perm, n_src, stride);
-    hipLaunchKernelGGL(icp_tile_search_kernel, dim3(tb, nprob), dim3(kTileQ), 0, stream, dp, n_src, 0, 0, 0, stride, FLT_MAX, 1);
-    hipLaunchKernelGGL(icp_tile_finish_kernel, dim3(tb, nprob), dim3(kTileQ), 0, stream, dp, n_src, 0, stride, FLT_MAX, 1);
+    search_and_sums(false, 0, 0, FLT_MAX, true);
     hipLaunchKernelGGL(icp_solve_batch_kernel, dim3(nprob), dim3(64), 0, stream, dp, tb, 2, 0, 0.0, 0.0);
     hipLaunchKernelGGL(gather_states_kernel, dim3(nprob), dim3(64), 0, stream, dp, nprob, d_states);
     ICP_HIP(hipGetLastError());
