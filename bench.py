@@ -37,6 +37,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP spreads a process's streams over this many hardware queues (default 4), decided when the runtime initialises: the engine has
+# five streams of its own and the verification prepares a scan's candidates on eight more (INTEGRATION.md asks a host application
+# for the same export).  Recorded in the line as config.hip_hw_queues.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 
@@ -683,6 +687,7 @@ def main():
                        "scans_per_step": spl, "scans_timed": timed_scans,
                        "keyframes_per_gpu": n_local, "eligible_per_query": n_elig, "rings": R, "sectors": S,
                        "shifts_per_pair": 13, "scans_per_launch": args.scans_per_launch, "launches_in_flight": args.pipeline, "native_chunk": args.native_chunk,
+                       "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "4 (HIP's default)"),
                        "sharding": (f"keyframe-index shards x{world}; exchange = {args.exchange} "
                                     f"({'two 8-byte min all-reduces' if args.exchange == 'allreduce' else 'one 24-byte all-gather'} "
                                     f"per scan, batched over {args.native_chunk or args.merge_every} scans, asynchronous)") if world > 1 else "none (one GPU)"},

@@ -130,7 +130,7 @@ struct scl_engine {
 
     scl::IcpWorkspace icp_ws;
     scl::IcpWorkspace vox_ws;
-    static constexpr int kIcpLanes = 4;                    // concurrent alignments of scl_icp_align_batch
+    static constexpr int kIcpLanes = 8;                    // streams (and host threads) that prepare the candidates of a batch side by side: 8 measured best (4: 4.9 ms of preparation per 25 candidates from the store, 8: 3.6, 3.1 with GPU_MAX_HW_QUEUES=8, 16: 4.1)
     scl::IcpWorkspace icp_lane_ws[kIcpLanes];
     scl::IcpWorkspace vox_lane_ws[kIcpLanes];              // submap assembly (voxel filter) of the candidates of a batch, one per lane
     // scl_icp_align_batch: one workspace per loop candidate (their ICP loops run fused, every step one launch for the
