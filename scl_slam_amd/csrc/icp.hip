@@ -810,16 +810,21 @@ __global__ __launch_bounds__(256) void normals_kernel(const unsigned char *tgt, 
     const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / kNormGroup;
     const int sub = threadIdx.x & (kNormGroup - 1);
     const bool valid = gid < n_tgt;
-    const int i = valid ? gid : n_tgt - 1;                    // surplus groups shadow the last point (all lanes stay in the exchanges)
-    const float3 p = load_xyz(tgt, i, stride);
+    // the points are taken in the grid's order (sorted[]: coordinates and, in .w, the point's index in the cloud): the groups of a
+    // workgroup then walk the same rows of cells, whatever order the cloud came in
+    const float4 me = sorted[valid ? gid : n_tgt - 1];        // surplus groups shadow the last point (all lanes stay in the exchanges)
+    const int i = __float_as_int(me.w);
+    const float3 p = make_float3(me.x, me.y, me.z);
     const float pv[3] = {p.x, p.y, p.z};
     // Cells the ball can reach, per axis: a point within `radius` of p lies in [p - radius, p + radius]; the grid bins points
     // with an fp32 division (cell_index), which can be off by ~1e-4 of a cell for grids of a thousand cells per axis -- the
     // interval is widened by a hundredth of a cell, not by a whole cell on either side (that box held 18 x the ball's volume).
-    const double hh = (double)st->h, kCellSlack = 0.01;
+    // (a product with 1 / h where a quotient stood: the two differ by 1e-14 of a cell, the slack is 1e-2; every point of the cells
+    //  looked at is tested against the radius in fp64 below, so a cell too many changes nothing)
+    const double hh = (double)st->h, inv_hh = 1.0 / hh, kCellSlack = 0.01;
     auto cells = [&](double v, double reach, int a, int &c0, int &c1) {
-        const double l = floor((v - reach - (double)st->mn[a]) / hh - kCellSlack);
-        const double h = floor((v + reach - (double)st->mn[a]) / hh + kCellSlack);
+        const double l = floor((v - reach - (double)st->mn[a]) * inv_hh - kCellSlack);
+        const double h = floor((v + reach - (double)st->mn[a]) * inv_hh + kCellSlack);
         c0 = !(l >= 0.0) ? 0 : (l >= (double)st->dim[a] ? st->dim[a] : (int)l);
         c1 = !(h < (double)st->dim[a]) ? st->dim[a] - 1 : (h < 0.0 ? -1 : (int)h);
     };
@@ -839,7 +844,7 @@ __global__ __launch_bounds__(256) void normals_kernel(const unsigned char *tgt, 
         const double dyz2 = (ddy > 0.0 ? ddy * ddy : 0.0) + (ddz > 0.0 ? ddz * ddz : 0.0);
         if (dyz2 > r2) continue;
         int xa, xb;
-        cells((double)p.x, sqrt(r2 - dyz2), 0, xa, xb);
+        cells((double)p.x, (double)(__builtin_amdgcn_sqrtf((float)(r2 - dyz2)) * 1.0001f), 0, xa, xb);   // (an fp32 root taken a hair longer: a superset)
         if (xa > xb) continue;
         const int kb = cell_start[(z * st->dim[1] + y) * st->dim[0] + xa];
         const int ke = cell_start[(z * st->dim[1] + y) * st->dim[0] + xb + 1];          // cells along x are contiguous
@@ -863,7 +868,30 @@ __global__ __launch_bounds__(256) void normals_kernel(const unsigned char *tgt, 
 #pragma unroll
     for (int a = 0; a < 6; ++a) sq[a] = group_sum8(sq[a]);
     cnt = (int)group_sum8((double)cnt);
-    if (!valid || sub != 0) return;
+    // The eigenvectors: one lane per point, and the workgroup's 32 points side by side in ONE wave -- with the first lane of every
+    // group of eight the Jacobi sweeps ran in all four waves at an eighth of their lanes, and they are most of this kernel's
+    // instructions.  Same arithmetic per point, so the same normals.
+    __shared__ double s_sums[256 / kNormGroup][10];
+    __shared__ int s_idx[256 / kNormGroup];
+    if (sub == 0) {
+        double *d = s_sums[threadIdx.x / kNormGroup];
+        d[0] = sum[0]; d[1] = sum[1]; d[2] = sum[2];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) d[3 + a] = sq[a];
+        d[9] = (double)cnt;
+        s_idx[threadIdx.x / kNormGroup] = valid ? i : -1;
+    }
+    __syncthreads();
+    if (threadIdx.x >= 256 / kNormGroup) return;
+    {
+        const double *d = s_sums[threadIdx.x];
+        sum[0] = d[0]; sum[1] = d[1]; sum[2] = d[2];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) sq[a] = d[3 + a];
+        cnt = (int)d[9];
+    }
+    const int out_i = s_idx[threadIdx.x];
+    if (out_i < 0) return;
     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
     if (cnt >= 3) {
         const double N = (double)cnt, m0 = sum[0] / N, m1 = sum[1] / N, m2 = sum[2] / N;
@@ -877,7 +905,7 @@ __global__ __launch_bounds__(256) void normals_kernel(const unsigned char *tgt, 
         for (int a = 1; a < 3; ++a) if (C[a][a] < low) { low = C[a][a]; n0 = V[0][a]; n1 = V[1][a]; n2 = V[2][a]; }
         out = make_float4((float)n0, (float)n1, (float)n2, 0.f);
     }
-    normals[i] = out;
+    normals[out_i] = out;
 }
 
 __device__ __forceinline__ void plane_reduce_kernel_body(const float4 *work, const unsigned char *tgt_raw, int stride, int n,
