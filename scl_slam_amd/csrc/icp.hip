@@ -35,8 +35,11 @@ namespace scl {
 
 namespace {
 
-constexpr int kGridDiv = 96;             // cells along the longest bbox edge
-constexpr int kMaxCells = 97 * 97 * 97;
+#ifndef SCL_GRID_DIV
+#define SCL_GRID_DIV 96
+#endif
+constexpr int kGridDiv = SCL_GRID_DIV;   // cells along the longest bbox edge
+constexpr int kMaxCells = (kGridDiv + 1) * (kGridDiv + 1) * (kGridDiv + 1);
 constexpr int kRedBlocks = 256;
 constexpr int kNSum = 17;                // 16 entries of sum [p;1][q;1]^T + sum d2
 
@@ -1245,9 +1248,22 @@ __device__ __forceinline__ int wave_min_i32(int v)
     return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
-__device__ __forceinline__ void tile_reach(float v, float g0, float h, int dim, float reach, int &a, int &b)
+// n / d and n % d for 0 <= n < 2^20, 0 < d < 2^12 through the reciprocal inv = 1.0f / d (an integer division by a variable is some
+// forty instructions; the staging loops did two per table entry): the float quotient is off by at most one, which the remainder tells
+__device__ __forceinline__ void fast_divmod(const int n, const int d, const float inv, int &q, int &r)
 {
-    const float fa = floorf((v - reach - g0) / h), fb = floorf((v + reach - g0) / h);
+    q = (int)((float)n * inv);
+    r = n - q * d;
+    if (r < 0) { --q; r += d; }
+    else if (r >= d) { ++q; r -= d; }
+}
+
+// the cells [a, b] of one axis that the interval [v - reach, v + reach] meets, clamped to the grid (empty: a > b).  A product with 1 / h
+// where nn_core divides: the reach is widened by what the two can differ by (2e-5 cells at a hundred cells per axis)
+__device__ __forceinline__ void tile_reach(float v, float g0, float h, float inv_h, int dim, float reach, int &a, int &b)
+{
+    reach += 2.1e-5f * h;
+    const float fa = floorf((v - reach - g0) * inv_h), fb = floorf((v + reach - g0) * inv_h);
     a = 0; b = dim - 1;
     if (fa == fa && fb == fb) {
         const int ia = fa < -1.0e9f ? 0 : (fa > 1.0e9f ? dim : (int)fa), ib = fb < -1.0e9f ? -1 : (fb > 1.0e9f ? dim - 1 : (int)fb);
@@ -1281,13 +1297,16 @@ __device__ __forceinline__ int tile_stage(TileLds &L, const TileGrid &g, const i
     const int W1 = X1 - X0 + 2, NY = Y1 - Y0 + 1, NZ = Z1 - Z0 + 1;    // W1 table entries per row: its cells' starts + the end of the last
     if ((long long)NY * NZ > kTileRows || (long long)NY * NZ * W1 > kTileTab) { if (t == 0) TILE_STAT(1, 1); return 2; }
     const int nrows = NY * NZ, nent = nrows * W1;
+    const float inv_W1 = 1.0f / (float)W1, inv_NY = 1.0f / (float)NY;
     {                                                            // every load of the table in flight before the first is stored
         int tv[kTileTab / kTileQ];
 #pragma unroll
         for (int u = 0; u < kTileTab / kTileQ; ++u) {
             const int e = t + u * kTileQ;
-            const int r = e / W1, k = e - r * W1, zz = r / NY;
-            tv[u] = e < nent ? cell_start[((Z0 + zz) * g.dy + (Y0 + (r - zz * NY))) * g.dx + X0 + k] : 0;
+            int r, k, zz, yy;
+            fast_divmod(e, W1, inv_W1, r, k);
+            fast_divmod(r, NY, inv_NY, zz, yy);
+            tv[u] = e < nent ? cell_start[((Z0 + zz) * g.dy + (Y0 + yy)) * g.dx + X0 + k] : 0;
         }
 #pragma unroll
         for (int u = 0; u < kTileTab / kTileQ; ++u) { const int e = t + u * kTileQ; if (e < nent) L.tab[e] = tv[u]; }
@@ -1312,7 +1331,7 @@ __device__ __forceinline__ int tile_stage(TileLds &L, const TileGrid &g, const i
     TILE_STAMP(11);
     if (total > kTilePts) { if (t == 0) TILE_STAT(1, 1); return 2; }
     if (t == 0) { TILE_STAT(3, nent); TILE_STAT(4, total); }
-    for (int e = t; e < nent; e += kTileQ) { const int r = e / W1; L.tab[e] = L.tab[e] - L.g0[r] + L.loff[r]; }
+    for (int e = t; e < nent; e += kTileQ) { int r, k; fast_divmod(e, W1, inv_W1, r, k); L.tab[e] = L.tab[e] - L.g0[r] + L.loff[r]; }
     for (int r = t >> 4; r < nrows; r += kTileQ / 16) {          // which row every staged point belongs to (16 lanes per row, LDS only)
         const int dst0 = L.loff[r], cnt = L.loff[r + 1] - dst0;
         for (int k = t & 15; k < cnt; k += 16) L.prow[dst0 + k] = (unsigned char)r;
@@ -1492,10 +1511,10 @@ __global__ __launch_bounds__(kTileQ) void icp_tile_search_kernel(const IcpProble
         } else {
             to_memory = open && bi < 0;
             if (open && bi >= 0) {
-                const float reach0 = sqrtf(best) * 1.0005f + 1e-6f * g.h;
-                tile_reach(p.x, g.gx0, g.h, g.dx, reach0, xa, xb);
-                tile_reach(p.y, g.gy0, g.h, g.dy, reach0, ya, yb);
-                tile_reach(p.z, g.gz0, g.h, g.dz, reach0, za, zb);
+                const float reach0 = __builtin_amdgcn_sqrtf(best) * 1.0005f + 1e-6f * g.h;
+                tile_reach(p.x, g.gx0, g.h, g.inv_h, g.dx, reach0, xa, xb);
+                tile_reach(p.y, g.gy0, g.h, g.inv_h, g.dy, reach0, ya, yb);
+                tile_reach(p.z, g.gz0, g.h, g.inv_h, g.dz, reach0, za, zb);
                 ask = xa <= xb && ya <= yb && za <= zb;
             }
         }
