@@ -418,7 +418,7 @@ static void log_env_overrides_once()
     if (done.exchange(true)) return;
     static const char *const names[] = {"SCL_SCREEN", "SCL_SCREEN_FORM", "SCL_SCREEN_VARIANT", "SCL_SCREEN_PROBE", "SCL_SCREEN_V2_MIN", "SCL_SCREEN_TAIL",
                                         "SCL_ALIGN_WGS", "SCL_ALIGN_SIDE", "SCL_ALIGN_FILTER", "SCL_SC_KERNEL", "SCL_SC_WAVES", "SCL_STAMP", "SCL_ABLATE",
-                                        "SCL_ALT_LANE", "SCL_ICP_REDUCE", "SCL_ICP_FUSED", "SCL_RCCL_MOCK"};
+                                        "SCL_ALT_LANE", "SCL_ICP_REDUCE", "SCL_RCCL_MOCK"};
     for (const char *n : names) {
         const char *v = getenv(n);
         if (v) fprintf(stderr, "scl_engine: environment override in effect: %s=%s\n", n, v);

@@ -18,7 +18,7 @@ lib = eng._lib
 stats = (ctypes.c_ulonglong * 16)()
 names = ["rounds", "rounds_overflowed", "lanes_in_memory", "table_entries", "points_staged", "row_visits", "points_compared", "-",
          "t_until_ball", "t_box", "t_table", "t_rowscan", "t_staging", "t_walk", "t_reduce", "-"]
-for est in ((0,) if os.environ.get("PROBE_P2P_ONLY") else (0, 1)):
+for est in ((0,) if os.environ.get("PROBE_P2P_ONLY") else (0, 1)):   # PROBE_P2P_ONLY: scripts/profile_icp.sh
     pp = eng.icp_default_params(); pp.max_iterations = 30; pp.estimator = est; pp.normal_radius = 1.0
     eng.icp_align_batch(src0, tgts, pp)
     lib.scl_debug_icp_tile_stats(stats, 1)

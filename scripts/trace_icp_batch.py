@@ -58,3 +58,9 @@ else:
         if tile:
             print("   icp_tile_search_kernel, start (us after the phase's first kernel) : duration (us):")
             print("      " + "  ".join(f"{s / 1e3:.0f}:{d / 1e3:.0f}" for s, d in tile))
+    if os.environ.get("DUMP"):
+        b = blocks[-1]
+        t0 = b[0][0]
+        for s, e, n in b[:int(os.environ["DUMP"])]:
+            short = n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].split("<")[0].split("::")[-1][:40] or n[:40]
+            print(f"{(s - t0) / 1e3:9.1f} {(e - s) / 1e3:7.1f}  {short}")
