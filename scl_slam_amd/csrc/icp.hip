@@ -1201,6 +1201,9 @@ __global__ void plane_solve_batch_kernel(const IcpProblem *pr, int nblocks, int 
 #ifndef SCL_TILE_TAB
 #define SCL_TILE_TAB 2048
 #endif
+#ifndef SCL_TILE_ABLATE
+#define SCL_TILE_ABLATE 0                // experiments only (results invalid): 1 no walk, 2 no reduction, 4 no staging of the points
+#endif
 constexpr int kTileQ = 256, kTilePts = SCL_TILE_PTS, kTileTab = SCL_TILE_TAB, kTileRows = 128;
 #ifdef SCL_DIAGNOSTICS
 // [0..6] (SCL_DIAGNOSTICS=1): rounds asked for, rounds that did not fit, lanes finished in memory, table entries / points staged, row
@@ -1338,7 +1341,7 @@ __device__ __forceinline__ int tile_stage(TileLds &L, const TileGrid &g, const i
     }
     __syncthreads();
 #pragma unroll
-    for (int u0 = 0; u0 < kTilePts / kTileQ; u0 += 4) {          // the points: four loads per lane in flight, then their stores
+    for (int u0 = 0; u0 < ((SCL_TILE_ABLATE & 4) ? 0 : kTilePts / kTileQ); u0 += 4) {   // the points: four loads per lane in flight, then their stores
         float4 v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -1364,7 +1367,7 @@ __device__ __forceinline__ int tile_round(TileLds &L, const TileGrid &g, const i
     const int rc = tile_stage(L, g, cell_start, sorted, req, xa, xb, ya, yb, za, zb, B TILE_STAMP_PASS);
     if (rc != 1) return rc;
     const int X0 = B.X0, Y0 = B.Y0, Z0 = B.Z0, NY = B.NY, W1 = B.W1;
-    if (req) {
+    if (req && !(SCL_TILE_ABLATE & 1)) {
         // (distance, index) as one 64-bit key: the bits of a distance >= 0 order like the distance, the index's sign bit is flipped so
         // that -1 ("none") comes last among equal distances, as in nn_core; a NaN distance has the largest key and is never taken
         unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | ((unsigned int)bi ^ 0x80000000u);
@@ -1533,7 +1536,7 @@ __global__ __launch_bounds__(kTileQ) void icp_tile_search_kernel(const IcpProble
     // a deferred lane leaves its seed in nnq and a negative distance as the mark; its workgroup's record is then the finish launch's
     const int any_deferred = __syncthreads_or(deferred ? 1 : 0);
     if (t == 0) P.flag[blockIdx.x] = any_deferred;
-    if (do_reduce && !any_deferred)
+    if (do_reduce && !any_deferred && !(SCL_TILE_ABLATE & 2))
         tile_reduce(reinterpret_cast<float *>(L.pts), L.red, p, bq, valid && bi >= 0 && (best <= maxd2), best, P.part + (size_t)blockIdx.x * kNSum);
     if (valid) {                                                 // (behind the reduction: a barrier waits for the stores in front of it)
         P.nnq[i] = make_float4(bq.x, bq.y, bq.z, __int_as_float(bi));
