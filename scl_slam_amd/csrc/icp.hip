@@ -1196,15 +1196,21 @@ __global__ void plane_solve_batch_kernel(const IcpProblem *pr, int nblocks, int 
 // do_reduce: the workgroup's correspondences are reduced on the spot (fp64 matrix cores, as corr_reduce_mfma_kernel_body) and
 // leave as one record of kNSum sums per workgroup: the iteration is this launch + the solve.
 #ifndef SCL_TILE_PTS
-#define SCL_TILE_PTS 2048
+#define SCL_TILE_PTS 1536
 #endif
 #ifndef SCL_TILE_TAB
-#define SCL_TILE_TAB 2048
+#define SCL_TILE_TAB 1024
 #endif
 #ifndef SCL_TILE_ABLATE
 #define SCL_TILE_ABLATE 0                // experiments only (results invalid): 1 no walk, 2 no reduction, 4 no staging of the points
 #endif
-constexpr int kTileQ = 256, kTilePts = SCL_TILE_PTS, kTileTab = SCL_TILE_TAB, kTileRows = 128;
+#ifndef SCL_TILE_Q
+#define SCL_TILE_Q 256
+#endif
+#ifndef SCL_TILE_ROWS
+#define SCL_TILE_ROWS 128
+#endif
+constexpr int kTileQ = SCL_TILE_Q, kTilePts = SCL_TILE_PTS, kTileTab = SCL_TILE_TAB, kTileRows = SCL_TILE_ROWS;
 #ifdef SCL_DIAGNOSTICS
 // [0..6] (SCL_DIAGNOSTICS=1): rounds asked for, rounds that did not fit, lanes finished in memory, table entries / points staged, row
 // visits, points compared; [8..14] (SCL_DIAGNOSTICS=2, so that the counters' atomics do not sit in the phases they time): ticks of
@@ -1237,7 +1243,7 @@ struct TileLds {
     unsigned char prow[kTilePts];        // the row of every staged point
     double red[kTileQ / 64][kNSum];
 };
-static_assert(kTileRows <= 256 && kTilePts % (4 * kTileQ) == 0 && kTileTab % kTileQ == 0, "tile constants");
+static_assert(kTileRows <= 256 && kTileRows % 64 == 0 && kTileQ % 64 == 0 && kTilePts % kTileQ == 0 && kTileTab % kTileQ == 0, "tile constants");
 
 struct TileGrid { float gx0, gy0, gz0, h, inv_h; int dx, dy, dz; };
 
@@ -1453,7 +1459,12 @@ __device__ __forceinline__ void tile_reduce(float *pq_area /* kTileQ x 8 floats 
     if (blk == 0) red[wv][k * 4 + comp] = d;
     if (lane == 0) red[wv][16] = sum_d2;
     __syncthreads();
-    if (t < kNSum) record[t] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+    if (t < kNSum) {
+        double v = red[0][t];
+#pragma unroll
+        for (int w = 1; w < kTileQ / 64; ++w) v += red[w][t];        // (the waves' sums in wave order)
+        record[t] = v;
+    }
 }
 
 __global__ __launch_bounds__(kTileQ) void icp_tile_search_kernel(const IcpProblem *pr, int n_src, int check_done, int apply, int cold,
