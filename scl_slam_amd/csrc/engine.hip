@@ -2283,17 +2283,6 @@ int scl_loop_icp_batch_from_store(scl_engine *e, int robot, int key_cur, const f
     const int stride = e->kf_stride ? e->kf_stride : 16;
     std::vector<const void *> clouds; std::vector<int> counts; std::vector<float> Tw;
     std::string err;
-    int ns = 0;
-    const void *d_res = nullptr;
-    // source: loopFindNearKeyframes(cur, 0), DM.h:1105 -- once for all candidates
-    int rc = kf_window(e, robot, key_cur, 0, pose_cur, &clouds, &counts, &Tw);
-    if (rc) return rc;
-    rc = assemble_submap_ex(&e->vox_ws, e->stream, clouds.data(), counts.data(), Tw.data(), (int)clouds.size(), stride, leaf,
-                            true, nullptr, 0, &d_res, &ns, &err);
-    if (rc) { e->last_error = err; return rc; }
-    if ((rc = ensure_points(e, (size_t)ns * stride + 16))) return rc;
-    if (ns) SCL_HIP(e, hipMemcpyAsync(e->d_points, d_res, (size_t)ns * stride, hipMemcpyDeviceToDevice, e->stream));
-    if (n_src) *n_src = ns;
     const int win = 2 * search_num + 1;
     for (int c = 0; c < n_candidates; ++c) {
         for (int i = 0; i < 16; ++i) T[16 * (size_t)c + i] = (i % 5 == 0) ? 1.0f : 0.0f;
@@ -2302,39 +2291,59 @@ int scl_loop_icp_batch_from_store(scl_engine *e, int robot, int key_cur, const f
         if (iterations) iterations[c] = 0;
         if (n_tgts) n_tgts[c] = 0;
     }
+    if (n_src) *n_src = 0;
     const int lanes = n_candidates < scl_engine::kIcpLanes ? n_candidates : scl_engine::kIcpLanes;
     for (int l = 0; l < lanes; ++l) {
         if (!e->icp_lane_stream[l]) SCL_HIP(e, hipStreamCreateWithFlags(&e->icp_lane_stream[l], hipStreamNonBlocking));
         if (!e->ev_lane[l]) SCL_HIP(e, hipEventCreateWithFlags(&e->ev_lane[l], hipEventDisableTiming));
     }
-    SCL_HIP(e, hipStreamSynchronize(e->stream));                                     // the source is in d_points
-    for (int first = 0; first < n_candidates; first += scl_engine::kIcpBatch) {
+    int rc = SCL_OK;
+    for (int first = 0; first < n_candidates || first == 0; first += scl_engine::kIcpBatch) {
         const int m = n_candidates - first < scl_engine::kIcpBatch ? n_candidates - first : scl_engine::kIcpBatch;
-        // targets: loopFindNearKeyframes(pre, historyKeyframeSearchNum), DM.h:1107, from the store -- submap assembly (voxel
-        // filter: a radix sort per candidate), staging and search-grid build are independent per candidate: a few host
-        // threads issue them onto the lane streams, each with its own filter workspace
+        // The submaps of a round -- the scan's own (loopFindNearKeyframes(cur, 0), DM.h:1105) in front, then the candidates'
+        // (loopFindNearKeyframes(pre, historyKeyframeSearchNum), DM.h:1107) -- are assembled and filtered TOGETHER: every step of the
+        // voxel filter is one launch over all of them (voxel.hip, assemble_submaps_batch), where each used to be a chain of ~20 short
+        // launches on its lane.  (The scan's submap is redone per round of kIcpBatch candidates: rounds beyond the first are rare.)
+        std::vector<const void *> cl_all; std::vector<int> cn_all, first_of; std::vector<float> tw_all;
+        first_of.push_back(0);
+        {
+            clouds.clear(); counts.clear(); Tw.clear();
+            if ((rc = kf_window(e, robot, key_cur, 0, pose_cur, &clouds, &counts, &Tw))) return rc;
+            cl_all.insert(cl_all.end(), clouds.begin(), clouds.end()); cn_all.insert(cn_all.end(), counts.begin(), counts.end()); tw_all.insert(tw_all.end(), Tw.begin(), Tw.end());
+            first_of.push_back((int)cl_all.size());
+        }
+        for (int c = 0; c < m; ++c) {
+            clouds.clear(); counts.clear(); Tw.clear();
+            if ((rc = kf_window(e, robot, keys_pre[first + c], search_num, poses_pre + (size_t)(first + c) * win * 16, &clouds, &counts, &Tw))) return rc;
+            cl_all.insert(cl_all.end(), clouds.begin(), clouds.end()); cn_all.insert(cn_all.end(), counts.begin(), counts.end()); tw_all.insert(tw_all.end(), Tw.begin(), Tw.end());
+            first_of.push_back((int)cl_all.size());
+        }
+        std::vector<const void *> d_sub((size_t)m + 1); std::vector<int> n_sub((size_t)m + 1);
+        rc = assemble_submaps_batch(&e->vox_ws, e->stream, cl_all.data(), cn_all.data(), tw_all.data(), first_of.data(), m + 1, stride, leaf,
+                                    d_sub.data(), n_sub.data(), &err);
+        if (rc) { e->last_error = err; return rc; }
+        const int ns = n_sub[0];
+        const void *d_src = d_sub[0];                                                    // (stays in the filter's workspace until the round is over)
+        if (n_src) *n_src = ns;
+        if (m <= 0) break;
+        // staging and search-grid build (+ normals) are independent per candidate: a few host threads issue them onto the lane streams
         std::atomic<int> next{0};
         std::atomic<int> first_rc{SCL_OK};
         std::string errs[scl_engine::kIcpLanes];
-        int nts[scl_engine::kIcpBatch]; bool ok[scl_engine::kIcpBatch];
+        bool ok[scl_engine::kIcpBatch];
         auto worker = [&](int l) {
             (void)hipSetDevice(e->device);
             hipStream_t st = e->icp_lane_stream[l];
-            std::vector<const void *> cl; std::vector<int> cn; std::vector<float> tw;
             for (;;) {
                 const int c = next.fetch_add(1);
                 if (c >= m) break;
-                nts[c] = 0; ok[c] = false;
-                const void *d_sub = nullptr;
-                int nt = 0;
-                int rc2 = kf_window(e, robot, keys_pre[first + c], search_num, poses_pre + (size_t)(first + c) * win * 16, &cl, &cn, &tw);
-                if (!rc2) rc2 = assemble_submap_ex(&e->vox_lane_ws[l], st, cl.data(), cn.data(), tw.data(), (int)cl.size(), stride, leaf,
-                                                   true, nullptr, 0, &d_sub, &nt, &errs[l]);
-                nts[c] = nt;
-                if (!rc2 && !(ns < min_src_points || nt < min_tgt_points)) {        // DM.h:1108: too small, no alignment attempted
+                ok[c] = false;
+                const int nt = n_sub[(size_t)c + 1];
+                int rc2 = SCL_OK;
+                if (!(ns < min_src_points || nt < min_tgt_points)) {                     // DM.h:1108: too small, no alignment attempted
                     IcpWorkspace *ws = &e->icp_batch_ws[c];
-                    rc2 = icp_stage_cloud(ws, st, true, d_sub, nt, stride, &errs[l]);
-                    if (!rc2) rc2 = icp_batch_prepare(ws, st, e->d_points, ns, nt, stride, *p, &errs[l]);
+                    rc2 = icp_stage_cloud(ws, st, true, d_sub[(size_t)c + 1], nt, stride, &errs[l]);
+                    if (!rc2) rc2 = icp_batch_prepare(ws, st, d_src, ns, nt, stride, *p, &errs[l]);
                     ok[c] = !rc2;
                 }
                 if (rc2) { int expect = SCL_OK; first_rc.compare_exchange_strong(expect, rc2); }
@@ -2351,12 +2360,12 @@ int scl_loop_icp_batch_from_store(scl_engine *e, int robot, int key_cur, const f
         for (int l = 0; l < nl; ++l) SCL_HIP(e, hipStreamWaitEvent(e->stream, e->ev_lane[l], 0));
         IcpWorkspace *wss[scl_engine::kIcpBatch]; int which[scl_engine::kIcpBatch]; int live = 0;
         for (int c = 0; c < m; ++c) {
-            if (n_tgts) n_tgts[first + c] = nts[c];
+            if (n_tgts) n_tgts[first + c] = n_sub[(size_t)c + 1];
             if (ok[c]) { wss[live] = &e->icp_batch_ws[c]; which[live] = first + c; ++live; }
         }
         if (live == 0) continue;
         std::vector<float> Tl(16 * (size_t)live), fl((size_t)live); std::vector<int> cl((size_t)live), il((size_t)live);
-        rc = icp_batch_run(wss, live, &e->icp_batch_ctl, e->stream, e->d_points, ns, stride, *p, Tl.data(), fl.data(), cl.data(), il.data(), &err);
+        rc = icp_batch_run(wss, live, &e->icp_batch_ctl, e->stream, d_src, ns, stride, *p, Tl.data(), fl.data(), cl.data(), il.data(), &err);
         if (rc) { e->last_error = err; return rc; }
         for (int j = 0; j < live; ++j) {
             std::memcpy(T + 16 * (size_t)which[j], Tl.data() + 16 * (size_t)j, 16 * sizeof(float));

@@ -70,6 +70,10 @@ int assemble_submap(IcpWorkspace *ws, hipStream_t stream, const void *const *clo
                     const float *transforms, int n_clouds, int stride, float leaf, void *out, int out_capacity,
                     int *n_out, std::string *err);
 
+// the same for n_jobs submaps at once, every step one launch over all of them; job j = clouds [first[j], first[j + 1]) (device pointers)
+int assemble_submaps_batch(IcpWorkspace *ws, hipStream_t stream, const void *const *clouds, const int *counts, const float *transforms,
+                           const int *first, int n_jobs, int stride, float leaf, const void **d_results, int *n_out, std::string *err);
+
 int assemble_submap_ex(IcpWorkspace *ws, hipStream_t stream, const void *const *clouds, const int *counts,
                        const float *transforms, int n_clouds, int stride, float leaf, bool clouds_on_device,
                        void *out, int out_capacity, const void **d_result, int *n_out, std::string *err);

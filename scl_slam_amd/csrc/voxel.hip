@@ -14,6 +14,7 @@
 
 #include <cfloat>
 #include <cstring>
+#include <vector>
 
 #include "device_common.hpp"
 #include "icp.hpp"
@@ -67,7 +68,7 @@ __global__ void vox_bbox_partial_kernel(const unsigned char *pts, int n, int str
     }
 }
 
-__global__ __launch_bounds__(64) void vox_setup_kernel(const float *part, const int *cnt, int nblocks, float inv, VoxState *st)
+__device__ __forceinline__ void vox_setup_kernel_body(const float *part, const int *cnt, int nblocks, float inv, VoxState *st)
 {
     // one wave: lane l folds the partial boxes l, l+64, ..., then a butterfly (min / max / integer sum: order independent)
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
@@ -91,6 +92,11 @@ __global__ __launch_bounds__(64) void vox_setup_kernel(const float *part, const 
         st->divb[a] = tot ? (long long)floorf(mx[a] * inv) - st->minb[a] + 1 : 1;
     }
     if (st->divb[0] * st->divb[1] * st->divb[2] > 2147483647LL) st->overflow = 1;
+}
+
+__global__ __launch_bounds__(64) void vox_setup_kernel(const float *part, const int *cnt, int nblocks, float inv, VoxState *st)
+{
+    vox_setup_kernel_body(part, cnt, nblocks, inv, st);
 }
 
 constexpr unsigned kNoVoxel = 0xffffffffu;                             // non-finite points sort to the end
@@ -156,6 +162,138 @@ __global__ void transform_append_kernel(const unsigned char *in, int n, int stri
     o[0] = T[0] * x + T[1] * y + T[2] * z + T[3];
     o[1] = T[4] * x + T[5] * y + T[6] * z + T[7];
     o[2] = T[8] * x + T[9] * y + T[10] * z + T[11];
+}
+
+// ---- the submaps of one scan's loop candidates, assembled and filtered TOGETHER --------------------------------------------------
+// loopFindNearKeyframes for 26 clouds (the scan's own submap + 25 candidates, BASELINE configs[2]) was 26 chains of ~20 short
+// launches, ten of them a radix sort of 100 k pairs each.  Here the raw submaps lie behind each other in one buffer and every step is
+// ONE launch over all of them: the sort orders (job << 32 | voxel, point) pairs of all jobs at once -- a stable LSD radix sort keeps a
+// voxel's points in input order inside its job, so every centroid is the same sum as in the one-by-one form, bit for bit.
+struct VoxPiece { const unsigned char *src; int n; int dst_off; int t_index; };   // one keyframe of one job -> its place in the raw buffer
+struct VoxJob { int off, n; };                                                    // a job's range of the raw buffer (and of its output)
+constexpr int kVoxMaxJobs = 64;
+
+__global__ void transform_pieces_kernel(const VoxPiece *pieces, const float *T_all, int stride, unsigned char *raw)
+{
+    const VoxPiece pc = pieces[blockIdx.y];
+    const float *T = T_all + 16 * pc.t_index;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pc.n; i += gridDim.x * blockDim.x) {
+        const float *f = reinterpret_cast<const float *>(pc.src + (size_t)i * stride);
+        float *o = reinterpret_cast<float *>(raw + (size_t)(pc.dst_off + i) * stride);
+        const float x = f[0], y = f[1], z = f[2];
+        for (int k = 3; k < stride / 4; ++k) o[k] = f[k];
+        // distributedMapping.h:247-249 (fp32, left to right, no FMA)
+        o[0] = T[0] * x + T[1] * y + T[2] * z + T[3];
+        o[1] = T[4] * x + T[5] * y + T[6] * z + T[7];
+        o[2] = T[8] * x + T[9] * y + T[10] * z + T[11];
+    }
+}
+
+// blockIdx.y = job; partial boxes of the job's raw points at part[(job * 256 + block) * 6], finite counts beside them
+__global__ void vox_bbox_partial_batch_kernel(const unsigned char *raw, const VoxJob *jobs, int stride, float *part, int *cnt)
+{
+    const VoxJob jb = jobs[blockIdx.y];
+    const unsigned char *pts = raw + (size_t)jb.off * stride;
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    int c = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < jb.n; i += gridDim.x * blockDim.x) {
+        const float *f = reinterpret_cast<const float *>(pts + (size_t)i * stride);
+        const float x = f[0], y = f[1], z = f[2];
+        if (!finite3(x, y, z)) continue;
+        mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
+        mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
+        ++c;
+    }
+    __shared__ float s[6][4];
+    __shared__ int sc[4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, kWave));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, kWave));
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, kWave);
+    const int wv = threadIdx.x / kWave;
+    if ((threadIdx.x & 63) == 0) { for (int a = 0; a < 3; ++a) { s[a][wv] = mn[a]; s[3 + a][wv] = mx[a]; } sc[wv] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int slot = blockIdx.y * gridDim.x + blockIdx.x;
+        int tot = 0;
+        for (int w = 0; w < 4; ++w) tot += sc[w];
+        for (int a = 0; a < 3; ++a) {
+            float m = s[a][0], M = s[3 + a][0];
+            for (int w = 1; w < 4; ++w) { m = fminf(m, s[a][w]); M = fmaxf(M, s[3 + a][w]); }
+            part[slot * 6 + a] = m; part[slot * 6 + 3 + a] = M;
+        }
+        cnt[slot] = tot;
+    }
+}
+
+__global__ __launch_bounds__(64) void vox_setup_batch_kernel(const float *part, const int *cnt, int nblocks, float inv, VoxState *st)
+{
+    vox_setup_kernel_body(part + (size_t)blockIdx.x * nblocks * 6, cnt + (size_t)blockIdx.x * nblocks, nblocks, inv, st + blockIdx.x);
+}
+
+// one thread per raw point of any job: the job of point i by bisection of the jobs' offsets (in LDS)
+__global__ void vox_keys_batch_kernel(const unsigned char *raw, int n_total, const VoxJob *jobs, int n_jobs, int stride, float inv, const VoxState *st,
+                                      unsigned long long *keys, unsigned *idx)
+{
+    __shared__ int s_off[kVoxMaxJobs + 1];
+    if ((int)threadIdx.x <= n_jobs) s_off[threadIdx.x] = (int)threadIdx.x < n_jobs ? jobs[threadIdx.x].off : n_total;
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_total) return;
+    int a = 0, b = n_jobs;                                             // the last job whose offset is <= i (empty jobs share an offset with the next)
+    while (b - a > 1) { const int m = (a + b) >> 1; if (s_off[m] <= i) a = m; else b = m; }
+    const VoxState *js = st + a;
+    const float *f = reinterpret_cast<const float *>(raw + (size_t)i * stride);
+    const float x = f[0], y = f[1], z = f[2];
+    unsigned key = kNoVoxel;
+    if (finite3(x, y, z) && !js->overflow) {
+        const long long i0 = (long long)floorf(x * inv) - js->minb[0];
+        const long long i1 = (long long)floorf(y * inv) - js->minb[1];
+        const long long i2 = (long long)floorf(z * inv) - js->minb[2];
+        key = (unsigned)(i0 + i1 * js->divb[0] + i2 * js->divb[0] * js->divb[1]);   // < 2^31 (overflow is flagged)
+    }
+    keys[i] = ((unsigned long long)(unsigned)a << 32) | key;
+    idx[i] = (unsigned)i;
+}
+
+__global__ void vox_heads_batch_kernel(const unsigned long long *keys, int n, int *head)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long k = keys[i];
+    head[i] = ((unsigned)k != kNoVoxel && (i == 0 || keys[i - 1] != k)) ? 1 : 0;
+}
+
+// one thread per voxel: the centroid of its points in input order, written to the job's own output range [off, off + nout)
+__global__ void vox_centroid_batch_kernel(const unsigned char *raw, int stride, const unsigned long long *keys, const unsigned *idx, const int *head,
+                                          const int *pos /*exclusive scan of head over all jobs*/, int n, const VoxJob *jobs, unsigned char *out, VoxState *st)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !head[i]) return;
+    const unsigned long long v = keys[i];
+    const int job = (int)(v >> 32);
+    const VoxJob jb = jobs[job];
+    float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+    const bool has_i = stride >= 20;
+    int b = i;
+    while (b < n && keys[b] == v) {
+        const float *f = reinterpret_cast<const float *>(raw + (size_t)idx[b] * stride);
+        sx += f[0]; sy += f[1]; sz += f[2];
+        if (has_i) si += f[4];
+        ++b;
+    }
+    const float cnt = (float)(b - i);
+    const int local = pos[i] - pos[jb.off];                             // (the job's first sorted element is its first head, or the job has no head at all)
+    float *o = reinterpret_cast<float *>(out + (size_t)(jb.off + local) * stride);
+    for (int k = 0; k < stride / 4; ++k) o[k] = 0.f;
+    o[0] = sx / cnt; o[1] = sy / cnt; o[2] = sz / cnt;
+    if (has_i) o[4] = si / cnt;
+    if (b >= n || (int)(keys[b] >> 32) != job || (unsigned)keys[b] == kNoVoxel) st[job].nout = local + 1;   // the job's last head publishes its count
 }
 
 enum VBuf { V_IN = 0, V_KEYS, V_KEYS2, V_HEAD, V_POS, V_TMP, V_OUT, V_STATE, V_PART, V_T };
@@ -310,6 +448,101 @@ int assemble_submap_ex(IcpWorkspace *ws, hipStream_t stream, const void *const *
     }
     VOX_HIP(hipStreamSynchronize(stream));
     *n_out = m;
+    return SCL_OK;
+}
+
+// n_jobs submaps at once (see the batched kernels above): job j = the clouds [first[j], first[j + 1]) of `clouds` (device pointers:
+// the keyframe store), each moved by its transform.  d_results[j] / n_out[j]: the filtered submap of job j, left in the workspace
+// (valid until the workspace is used again); a job whose voxel index would overflow keeps its unfiltered points (PCL's behaviour).
+int assemble_submaps_batch(IcpWorkspace *ws, hipStream_t stream, const void *const *clouds, const int *counts, const float *transforms,
+                           const int *first, int n_jobs, int stride, float leaf, const void **d_results, int *n_out, std::string *err)
+{
+    if (n_jobs < 0 || n_jobs > kVoxMaxJobs || stride < 12 || (stride & 3) || !(leaf > 0.f)) { if (err) *err = "assemble_submaps_batch: bad arguments"; return SCL_ERR_INVALID_ARG; }
+    if (n_jobs == 0) return SCL_OK;
+    const int n_pieces = first[n_jobs];
+    size_t total = 0;
+    int max_piece = 0, max_job = 0;
+    std::vector<VoxJob> jobs((size_t)n_jobs);
+    std::vector<VoxPiece> pieces((size_t)(n_pieces > 0 ? n_pieces : 1));
+    for (int j = 0; j < n_jobs; ++j) {
+        jobs[(size_t)j].off = (int)total;
+        for (int c = first[j]; c < first[j + 1]; ++c) {
+            if (counts[c] < 0) { if (err) *err = "negative count"; return SCL_ERR_INVALID_ARG; }
+            pieces[(size_t)c] = VoxPiece{static_cast<const unsigned char *>(clouds[c]), counts[c], (int)total, c};
+            total += (size_t)counts[c];
+            if (total > 0x7fffffffull) { if (err) *err = "submaps too large"; return SCL_ERR_INVALID_ARG; }
+            max_piece = counts[c] > max_piece ? counts[c] : max_piece;
+        }
+        jobs[(size_t)j].n = (int)total - jobs[(size_t)j].off;
+        max_job = jobs[(size_t)j].n > max_job ? jobs[(size_t)j].n : max_job;
+        d_results[j] = nullptr; n_out[j] = 0;
+    }
+    if (total == 0) return SCL_OK;
+    const int n = (int)total;
+    int rc;
+    int nb = (max_job + 255) / 256; nb = nb < 1 ? 1 : (nb > 256 ? 256 : nb);
+    const size_t tab_bytes = sizeof(float) * 16 * (size_t)(n_pieces > 0 ? n_pieces : 1) + sizeof(VoxPiece) * pieces.size() + sizeof(VoxJob) * jobs.size();
+    if ((rc = vensure(ws, V_IN, total * stride + 16, err))) return rc;
+    if ((rc = vensure(ws, V_OUT, total * stride + 16, err))) return rc;
+    if ((rc = vensure(ws, V_KEYS, (sizeof(unsigned long long) + sizeof(unsigned)) * total + 16, err))) return rc;
+    if ((rc = vensure(ws, V_KEYS2, (sizeof(unsigned long long) + sizeof(unsigned)) * total + 16, err))) return rc;
+    if ((rc = vensure(ws, V_HEAD, sizeof(int) * total, err))) return rc;
+    if ((rc = vensure(ws, V_POS, sizeof(int) * total, err))) return rc;
+    if ((rc = vensure(ws, V_STATE, sizeof(VoxState) * (size_t)n_jobs, err))) return rc;
+    if ((rc = vensure(ws, V_PART, (sizeof(float) * 6 + sizeof(int)) * (size_t)nb * (size_t)n_jobs, err))) return rc;
+    if ((rc = vensure(ws, V_T, tab_bytes + 64, err))) return rc;
+    const size_t pin_bytes = tab_bytes > sizeof(VoxState) * (size_t)n_jobs ? tab_bytes : sizeof(VoxState) * (size_t)n_jobs;
+    if (!ws->pinned || ws->pinned_cap < pin_bytes) {
+        if (ws->pinned) { (void)hipHostFree(ws->pinned); ws->pinned = nullptr; ws->pinned_cap = 0; }
+        VOX_HIP(hipHostMalloc(&ws->pinned, pin_bytes + 4096, hipHostMallocDefault));
+        ws->pinned_cap = pin_bytes + 4096;
+    }
+    // the tables: transforms, pieces, jobs -- one copy
+    unsigned char *hp = static_cast<unsigned char *>(ws->pinned);
+    const size_t o_pieces = sizeof(float) * 16 * (size_t)(n_pieces > 0 ? n_pieces : 1), o_jobs = o_pieces + sizeof(VoxPiece) * pieces.size();
+    if (n_pieces) std::memcpy(hp, transforms, sizeof(float) * 16 * (size_t)n_pieces);
+    std::memcpy(hp + o_pieces, pieces.data(), sizeof(VoxPiece) * pieces.size());
+    std::memcpy(hp + o_jobs, jobs.data(), sizeof(VoxJob) * jobs.size());
+    VOX_HIP(hipMemcpyAsync(ws->buf[V_T], hp, tab_bytes, hipMemcpyHostToDevice, stream));
+    const float *d_T = static_cast<const float *>(ws->buf[V_T]);
+    const VoxPiece *d_pieces = reinterpret_cast<const VoxPiece *>(static_cast<unsigned char *>(ws->buf[V_T]) + o_pieces);
+    const VoxJob *d_jobs = reinterpret_cast<const VoxJob *>(static_cast<unsigned char *>(ws->buf[V_T]) + o_jobs);
+    unsigned char *raw = static_cast<unsigned char *>(ws->buf[V_IN]);
+    unsigned long long *keys_in = static_cast<unsigned long long *>(ws->buf[V_KEYS]), *keys_out = static_cast<unsigned long long *>(ws->buf[V_KEYS2]);
+    unsigned *idx_in = reinterpret_cast<unsigned *>(keys_in + total), *idx_out = reinterpret_cast<unsigned *>(keys_out + total);
+    VoxState *st = static_cast<VoxState *>(ws->buf[V_STATE]);
+    float *part = static_cast<float *>(ws->buf[V_PART]);
+    int *pcnt = reinterpret_cast<int *>(part + 6 * (size_t)nb * (size_t)n_jobs);
+    const float inv = 1.0f / leaf;
+    const int pb = (n + 255) / 256;
+    int ebits = 32;
+    while ((1 << (ebits - 32)) < n_jobs) ++ebits;                      // the sort looks at the voxel's 32 bits and the job's
+    if (n_pieces) {
+        int gb = (max_piece + 255) / 256; gb = gb < 1 ? 1 : (gb > 512 ? 512 : gb);
+        hipLaunchKernelGGL(transform_pieces_kernel, dim3(gb, n_pieces), dim3(256), 0, stream, d_pieces, d_T, stride, raw);
+    }
+    hipLaunchKernelGGL(vox_bbox_partial_batch_kernel, dim3(nb, n_jobs), dim3(256), 0, stream, raw, d_jobs, stride, part, pcnt);
+    hipLaunchKernelGGL(vox_setup_batch_kernel, dim3(n_jobs), dim3(64), 0, stream, part, pcnt, nb, inv, st);
+    hipLaunchKernelGGL(vox_keys_batch_kernel, dim3(pb), dim3(256), 0, stream, raw, n, d_jobs, n_jobs, stride, inv, st, keys_in, idx_in);
+    size_t tmp_sort = 0, tmp_scan = 0;
+    VOX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, keys_in, keys_out, idx_in, idx_out, n, 0, ebits, stream));
+    VOX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, (int *)ws->buf[V_HEAD], (int *)ws->buf[V_POS], n, stream));
+    const size_t tmp = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
+    if ((rc = vensure(ws, V_TMP, tmp + 256, err))) return rc;
+    VOX_HIP(hipcub::DeviceRadixSort::SortPairs(ws->buf[V_TMP], tmp_sort, keys_in, keys_out, idx_in, idx_out, n, 0, ebits, stream));
+    hipLaunchKernelGGL(vox_heads_batch_kernel, dim3(pb), dim3(256), 0, stream, keys_out, n, (int *)ws->buf[V_HEAD]);
+    VOX_HIP(hipcub::DeviceScan::ExclusiveSum(ws->buf[V_TMP], tmp_scan, (int *)ws->buf[V_HEAD], (int *)ws->buf[V_POS], n, stream));
+    hipLaunchKernelGGL(vox_centroid_batch_kernel, dim3(pb), dim3(256), 0, stream, raw, stride, keys_out, idx_out, (const int *)ws->buf[V_HEAD],
+                       (const int *)ws->buf[V_POS], n, d_jobs, (unsigned char *)ws->buf[V_OUT], st);
+    VOX_HIP(hipGetLastError());
+    VOX_HIP(hipMemcpyAsync(ws->pinned, st, sizeof(VoxState) * (size_t)n_jobs, hipMemcpyDeviceToHost, stream));
+    VOX_HIP(hipStreamSynchronize(stream));
+    const VoxState *h = static_cast<const VoxState *>(ws->pinned);
+    for (int j = 0; j < n_jobs; ++j) {
+        const bool unfiltered = h[j].overflow != 0;                     // DM.h:1183-1185 through PCL: leaf too small for the cloud's extent
+        d_results[j] = (unfiltered ? static_cast<unsigned char *>(ws->buf[V_IN]) : static_cast<unsigned char *>(ws->buf[V_OUT])) + (size_t)jobs[(size_t)j].off * stride;
+        n_out[j] = unfiltered ? jobs[(size_t)j].n : h[j].nout;
+    }
     return SCL_OK;
 }
 
