@@ -2292,11 +2292,6 @@ int scl_loop_icp_batch_from_store(scl_engine *e, int robot, int key_cur, const f
         if (n_tgts) n_tgts[c] = 0;
     }
     if (n_src) *n_src = 0;
-    const int lanes = n_candidates < scl_engine::kIcpLanes ? n_candidates : scl_engine::kIcpLanes;
-    for (int l = 0; l < lanes; ++l) {
-        if (!e->icp_lane_stream[l]) SCL_HIP(e, hipStreamCreateWithFlags(&e->icp_lane_stream[l], hipStreamNonBlocking));
-        if (!e->ev_lane[l]) SCL_HIP(e, hipEventCreateWithFlags(&e->ev_lane[l], hipEventDisableTiming));
-    }
     int rc = SCL_OK;
     for (int first = 0; first < n_candidates || first == 0; first += scl_engine::kIcpBatch) {
         const int m = n_candidates - first < scl_engine::kIcpBatch ? n_candidates - first : scl_engine::kIcpBatch;
@@ -2326,44 +2321,19 @@ int scl_loop_icp_batch_from_store(scl_engine *e, int robot, int key_cur, const f
         const void *d_src = d_sub[0];                                                    // (stays in the filter's workspace until the round is over)
         if (n_src) *n_src = ns;
         if (m <= 0) break;
-        // staging and search-grid build (+ normals) are independent per candidate: a few host threads issue them onto the lane streams
-        std::atomic<int> next{0};
-        std::atomic<int> first_rc{SCL_OK};
-        std::string errs[scl_engine::kIcpLanes];
-        bool ok[scl_engine::kIcpBatch];
-        auto worker = [&](int l) {
-            (void)hipSetDevice(e->device);
-            hipStream_t st = e->icp_lane_stream[l];
-            for (;;) {
-                const int c = next.fetch_add(1);
-                if (c >= m) break;
-                ok[c] = false;
-                const int nt = n_sub[(size_t)c + 1];
-                int rc2 = SCL_OK;
-                if (!(ns < min_src_points || nt < min_tgt_points)) {                     // DM.h:1108: too small, no alignment attempted
-                    IcpWorkspace *ws = &e->icp_batch_ws[c];
-                    rc2 = icp_stage_cloud(ws, st, true, d_sub[(size_t)c + 1], nt, stride, &errs[l]);
-                    if (!rc2) rc2 = icp_batch_prepare(ws, st, d_src, ns, nt, stride, *p, &errs[l]);
-                    ok[c] = !rc2;
-                }
-                if (rc2) { int expect = SCL_OK; first_rc.compare_exchange_strong(expect, rc2); }
-            }
-            (void)hipEventRecord(e->ev_lane[l], st);
-        };
-        const int nl = m < lanes ? m : lanes;
-        std::vector<std::thread> pool;
-        for (int l = 1; l < nl; ++l) pool.emplace_back(worker, l);
-        worker(0);
-        for (auto &t : pool) t.join();
-        rc = first_rc.load();
-        if (rc) { for (auto &msg : errs) if (!msg.empty()) { e->last_error = msg; break; } (void)hipDeviceSynchronize(); return rc; }
-        for (int l = 0; l < nl; ++l) SCL_HIP(e, hipStreamWaitEvent(e->stream, e->ev_lane[l], 0));
+        // search grids (+ normals) of the candidates that are large enough (DM.h:1108), their submaps read where the filter left them:
+        // one launch per step over all of them (icp.hip, icp_batch_prepare_all), on the engine's stream
         IcpWorkspace *wss[scl_engine::kIcpBatch]; int which[scl_engine::kIcpBatch]; int live = 0;
+        const void *tg[scl_engine::kIcpBatch]; int tn[scl_engine::kIcpBatch];
         for (int c = 0; c < m; ++c) {
-            if (n_tgts) n_tgts[first + c] = n_sub[(size_t)c + 1];
-            if (ok[c]) { wss[live] = &e->icp_batch_ws[c]; which[live] = first + c; ++live; }
+            const int nt = n_sub[(size_t)c + 1];
+            if (n_tgts) n_tgts[first + c] = nt;
+            if (ns < min_src_points || nt < min_tgt_points) continue;
+            wss[live] = &e->icp_batch_ws[c]; which[live] = first + c; tg[live] = d_sub[(size_t)c + 1]; tn[live] = nt; ++live;
         }
         if (live == 0) continue;
+        rc = icp_batch_prepare_all(wss, live, &e->icp_batch_ctl, e->stream, ns, tg, tn, stride, *p, &err);
+        if (rc) { e->last_error = err; return rc; }
         std::vector<float> Tl(16 * (size_t)live), fl((size_t)live); std::vector<int> cl((size_t)live), il((size_t)live);
         rc = icp_batch_run(wss, live, &e->icp_batch_ctl, e->stream, d_src, ns, stride, *p, Tl.data(), fl.data(), cl.data(), il.data(), &err);
         if (rc) { e->last_error = err; return rc; }

@@ -28,6 +28,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "device_common.hpp"
 
@@ -81,7 +82,7 @@ __device__ __forceinline__ float3 load_xyz(const unsigned char *base, int i, int
 }
 
 // ---- K4a ---------------------------------------------------------------------------
-__global__ void bbox_partial_kernel(const unsigned char *pts, int n, int stride, float *part)
+__device__ __forceinline__ void bbox_partial_body(const unsigned char *pts, int n, int stride, float *part)
 {
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -109,8 +110,9 @@ __global__ void bbox_partial_kernel(const unsigned char *pts, int n, int stride,
         }
     }
 }
+__global__ void bbox_partial_kernel(const unsigned char *pts, int n, int stride, float *part) { bbox_partial_body(pts, n, stride, part); }
 
-__global__ void grid_setup_kernel(const float *part, int nblocks, int n, IcpState *st, int *cell_start)
+__device__ __forceinline__ void grid_setup_body(const float *part, int nblocks, int n, IcpState *st, int *cell_start)
 {
     // one wave: lane l folds the partial boxes l, l+64, ..., then a butterfly (min/max are order independent)
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
@@ -137,6 +139,7 @@ __global__ void grid_setup_kernel(const float *part, int nblocks, int n, IcpStat
     }
     (void)cell_start;                                      // zeroed by the caller (hipMemsetAsync of the whole table)
 }
+__global__ void grid_setup_kernel(const float *part, int nblocks, int n, IcpState *st, int *cell_start) { grid_setup_body(part, nblocks, n, st, cell_start); }
 
 __device__ __forceinline__ int cell_index(const IcpState *st, float3 p, int c[3])
 {
@@ -150,7 +153,7 @@ __device__ __forceinline__ int cell_index(const IcpState *st, float3 p, int c[3]
     return (c[2] * st->dim[1] + c[1]) * st->dim[0] + c[0];
 }
 
-__global__ void grid_count_kernel(const unsigned char *pts, int n, int stride, const IcpState *st, int *cell_start)
+__device__ __forceinline__ void grid_count_body(const unsigned char *pts, int n, int stride, const IcpState *st, int *cell_start)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         int c[3];
@@ -159,8 +162,10 @@ __global__ void grid_count_kernel(const unsigned char *pts, int n, int stride, c
     }
 }
 
-__global__ void grid_scatter_kernel(const unsigned char *pts, int n, int stride, const IcpState *st,
-                                    int *cell_fill, float4 *sorted)
+__global__ void grid_count_kernel(const unsigned char *pts, int n, int stride, const IcpState *st, int *cell_start) { grid_count_body(pts, n, stride, st, cell_start); }
+
+__device__ __forceinline__ void grid_scatter_body(const unsigned char *pts, int n, int stride, const IcpState *st,
+                                                  int *cell_fill, float4 *sorted)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         int c[3];
@@ -169,6 +174,10 @@ __global__ void grid_scatter_kernel(const unsigned char *pts, int n, int stride,
         const int pos = atomicAdd(&cell_fill[cell], 1);
         sorted[pos] = make_float4(p.x, p.y, p.z, __int_as_float(i));
     }
+}
+__global__ void grid_scatter_kernel(const unsigned char *pts, int n, int stride, const IcpState *st, int *cell_fill, float4 *sorted)
+{
+    grid_scatter_body(pts, n, stride, st, cell_fill, sorted);
 }
 
 // ---- K4b ---------------------------------------------------------------------------
@@ -806,8 +815,7 @@ __device__ __forceinline__ double group_sum8(double v)
     return v;
 }
 
-__global__ __launch_bounds__(256) void normals_kernel(const unsigned char *tgt, int n_tgt, int stride, const IcpState *st,
-                                                      const int *cell_start, const float4 *sorted, double radius, float4 *normals)
+__device__ __forceinline__ void normals_body(int n_tgt, const IcpState *st, const int *cell_start, const float4 *sorted, double radius, float4 *normals)
 {
     if (n_tgt <= 0) return;
     const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / kNormGroup;
@@ -909,6 +917,12 @@ __global__ __launch_bounds__(256) void normals_kernel(const unsigned char *tgt, 
         out = make_float4((float)n0, (float)n1, (float)n2, 0.f);
     }
     normals[out_i] = out;
+}
+__global__ __launch_bounds__(256) void normals_kernel(const unsigned char *tgt, int n_tgt, int stride, const IcpState *st,
+                                                      const int *cell_start, const float4 *sorted, double radius, float4 *normals)
+{
+    (void)tgt; (void)stride;
+    normals_body(n_tgt, st, cell_start, sorted, radius, normals);
 }
 
 __device__ __forceinline__ void plane_reduce_kernel_body(const float4 *work, const unsigned char *tgt_raw, int stride, int n,
@@ -1017,7 +1031,7 @@ __global__ void raw_transform_kernel(const unsigned char *in, unsigned char *out
     o[2] = T[8] * x + T[9] * y + T[10] * z + T[11];
 }
 
-__global__ void state_init_kernel(IcpState *st)
+__device__ __forceinline__ void state_init_body(IcpState *st)
 {
     if (threadIdx.x == 0) {
         for (int k = 0; k < 16; ++k) { st->final_T[k] = (k % 5 == 0) ? 1.f : 0.f; st->inc_T[k] = (k % 5 == 0) ? 1.f : 0.f; }
@@ -1025,6 +1039,62 @@ __global__ void state_init_kernel(IcpState *st)
         st->iter = 0; st->done = 0; st->converged = 0; st->n_corr = 0; st->ticket = 0u; st->pad_ = 0u;
     }
 }
+
+__global__ void state_init_kernel(IcpState *st) { state_init_body(st); }
+
+// ---- everything an alignment needs from its TARGET, for the candidates of one scan at once (blockIdx.y = candidate) ------------
+// The search grid of a target is seven short launches (box, set-up, zero, count, scan, scatter, state) and its normals an eighth;
+// for 25 candidates on eight lanes that was 1.6 ms of a query's preparation.  Here every step is one launch over all candidates.
+// The prefix sum of a target's cell counts -- only the cells+1 entries its grid has, not the table's capacity -- is one
+// workgroup per target (4 096 entries per trip).
+struct GridJob { const unsigned char *tgt; int n; IcpState *st; int *cstart; int *cfill; float4 *tsort; float *bbox; float4 *normals; };
+
+__global__ void bbox_partial_batch_kernel(const GridJob *jobs, int stride) { const GridJob j = jobs[blockIdx.y]; bbox_partial_body(j.tgt, j.n, stride, j.bbox); }
+__global__ void grid_setup_batch_kernel(const GridJob *jobs, int nblocks) { const GridJob j = jobs[blockIdx.x]; grid_setup_body(j.bbox, nblocks, j.n, j.st, j.cstart); }
+__global__ void grid_zero_batch_kernel(const GridJob *jobs)
+{
+    const GridJob j = jobs[blockIdx.y];
+    const int n = j.st->cells + 2;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) j.cstart[i] = 0;
+}
+__global__ void grid_count_batch_kernel(const GridJob *jobs, int stride) { const GridJob j = jobs[blockIdx.y]; grid_count_body(j.tgt, j.n, stride, j.st, j.cstart); }
+__global__ __launch_bounds__(1024) void grid_scan_batch_kernel(const GridJob *jobs)
+{
+    // counts sit in cstart[cell + 1]; the inclusive sum of entries 0 .. cells turns them into the cells' start offsets; cfill = a copy
+    const GridJob j = jobs[blockIdx.x];
+    const int n = j.st->cells + 1;
+    __shared__ int s_wave[16];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    int carry = 0;
+    for (int base = 0; base < n; base += 4096) {
+        const int i0 = base + 4 * t;
+        int v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = i0 + u < n ? j.cstart[i0 + u] : 0;
+        const int mine = (v[0] + v[1]) + (v[2] + v[3]);
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, kWave); if (lane >= off) incl += o; }
+        if (lane == 63) s_wave[wv] = incl;
+        __syncthreads();
+        int before = carry, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const int x = s_wave[w]; before += w < wv ? x : 0; total += x; }
+        int run = before + incl - mine;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { run += v[u]; if (i0 + u < n) { j.cstart[i0 + u] = run; j.cfill[i0 + u] = run; } }
+        carry += total;
+        __syncthreads();
+    }
+}
+__global__ void grid_scatter_batch_kernel(const GridJob *jobs, int stride) { const GridJob j = jobs[blockIdx.y]; grid_scatter_body(j.tgt, j.n, stride, j.st, j.cfill, j.tsort); }
+__global__ __launch_bounds__(256) void normals_batch_kernel(const GridJob *jobs, double radius)
+{
+    const GridJob j = jobs[blockIdx.y];
+    if ((long long)blockIdx.x * (256 / kNormGroup) >= j.n) return;         // (a workgroup is 32 points; the grid is sized for the largest target)
+    normals_body(j.n, j.st, j.cstart, j.tsort, radius, j.normals);
+}
+__global__ void state_init_batch_kernel(const GridJob *jobs) { state_init_body(jobs[blockIdx.x].st); }
 
 // ---- RANSAC correspondence rejection (CorrespondenceRejectorSampleConsensus, DM.h:1218-1225) ----------
 // Deterministic restatement (see oracle/icp_oracle.h): hypothesis h = 3 distinct correspondences drawn
@@ -1935,6 +2005,7 @@ int icp_batch_prepare(IcpWorkspace *ws, hipStream_t stream, const void *d_src, i
                       const scl_icp_params &p, std::string *err)
 {
     (void)d_src;
+    ws->ext_tgt = nullptr;                                       // the target is the one staged in B_TGT
     int rc = check_cloud_args(n_src, n_tgt, stride, err);
     if (rc) return rc;
     if (p.estimator != 0 && p.estimator != 1) { if (err) *err = "unknown estimator"; return SCL_ERR_INVALID_ARG; }
@@ -1959,12 +2030,63 @@ int icp_batch_prepare(IcpWorkspace *ws, hipStream_t stream, const void *d_src, i
     return SCL_OK;
 }
 
+// icp_batch_prepare for n alignments at once, their targets already on the device (d_tgts[c], n_tgts[c] points: read in place, not
+// copied): every step one launch over all of them, on one stream.  ctl keeps the table of the jobs.
+int icp_batch_prepare_all(IcpWorkspace *const *wss, int n, IcpWorkspace *ctl, hipStream_t stream, int n_src, const void *const *d_tgts,
+                          const int *n_tgts, int stride, const scl_icp_params &p, std::string *err)
+{
+    if (n <= 0) return SCL_OK;
+    if (p.estimator != 0 && p.estimator != 1) { if (err) *err = "unknown estimator"; return SCL_ERR_INVALID_ARG; }
+    if (p.estimator == 1 && !(p.normal_radius > 0.0)) { if (err) *err = "normal_radius must be > 0"; return SCL_ERR_INVALID_ARG; }
+    if (p.max_iterations < 1) { if (err) *err = "max_iterations < 1"; return SCL_ERR_INVALID_ARG; }
+    int rc, max_n = 0;
+    std::vector<GridJob> jobs((size_t)n);
+    for (int c = 0; c < n; ++c) {
+        IcpWorkspace *ws = wss[c];
+        const int n_tgt = n_tgts[c];
+        if ((rc = check_cloud_args(n_src, n_tgt, stride, err))) return rc;
+        if ((rc = ensure(ws, B_WORK, sizeof(float4) * (size_t)(n_src + 1), err))) return rc;
+        if ((rc = ensure(ws, B_NNQ, sizeof(float4) * (size_t)(n_src + 1), err))) return rc;
+        if ((rc = ensure(ws, B_FLAG, sizeof(int) * ((size_t)(n_src > n_tgt ? n_src : n_tgt) / kTileQ + 2), err))) return rc;
+        if ((rc = ensure(ws, B_NNI, sizeof(int) * (size_t)(n_src + 1), err))) return rc;
+        if ((rc = ensure(ws, B_NND, sizeof(float) * (size_t)(n_src + 1), err))) return rc;
+        if ((rc = ensure(ws, B_PART, part_bytes(n_src), err))) return rc;
+        if ((rc = ensure(ws, B_TSORT, sizeof(float4) * (size_t)(n_tgt + 1), err))) return rc;
+        if ((rc = ensure(ws, B_CSTART, sizeof(int) * (size_t)(kMaxCells + 2), err))) return rc;
+        if ((rc = ensure(ws, B_CFILL, sizeof(int) * (size_t)(kMaxCells + 2), err))) return rc;
+        if ((rc = ensure(ws, B_BBOX, sizeof(float) * 6 * 256, err))) return rc;
+        if ((rc = ensure(ws, B_STATE, sizeof(IcpState), err))) return rc;
+        if (p.estimator == 1 && (rc = ensure(ws, B_NORM, sizeof(float4) * (size_t)(n_tgt + 1), err))) return rc;
+        ws->ext_tgt = d_tgts[c];
+        GridJob &j = jobs[(size_t)c];
+        j.tgt = static_cast<const unsigned char *>(d_tgts[c]); j.n = n_tgt; j.st = (IcpState *)ws->buf[B_STATE];
+        j.cstart = (int *)ws->buf[B_CSTART]; j.cfill = (int *)ws->buf[B_CFILL]; j.tsort = (float4 *)ws->buf[B_TSORT];
+        j.bbox = (float *)ws->buf[B_BBOX]; j.normals = p.estimator == 1 ? (float4 *)ws->buf[B_NORM] : nullptr;
+        max_n = n_tgt > max_n ? n_tgt : max_n;
+    }
+    if ((rc = ensure(ctl, B_PROB, sizeof(GridJob) * (size_t)n, err))) return rc;
+    ICP_HIP(hipMemcpyAsync(ctl->buf[B_PROB], jobs.data(), sizeof(GridJob) * (size_t)n, hipMemcpyHostToDevice, stream));   // (pageable: staged before the call returns)
+    const GridJob *dj = static_cast<const GridJob *>(ctl->buf[B_PROB]);
+    int gb = (max_n + 255) / 256; gb = gb < 1 ? 1 : (gb > 2048 ? 2048 : gb);
+    hipLaunchKernelGGL(bbox_partial_batch_kernel, dim3(256, n), dim3(256), 0, stream, dj, stride);
+    hipLaunchKernelGGL(grid_setup_batch_kernel, dim3(n), dim3(64), 0, stream, dj, 256);
+    hipLaunchKernelGGL(grid_zero_batch_kernel, dim3(64, n), dim3(256), 0, stream, dj);
+    hipLaunchKernelGGL(grid_count_batch_kernel, dim3(gb, n), dim3(256), 0, stream, dj, stride);
+    hipLaunchKernelGGL(grid_scan_batch_kernel, dim3(n), dim3(1024), 0, stream, dj);
+    hipLaunchKernelGGL(grid_scatter_batch_kernel, dim3(gb, n), dim3(256), 0, stream, dj, stride);
+    if (p.estimator == 1 && max_n > 0)
+        hipLaunchKernelGGL(normals_batch_kernel, dim3((unsigned)(((size_t)max_n * kNormGroup + 255) / 256), n), dim3(256), 0, stream, dj, p.normal_radius);
+    hipLaunchKernelGGL(state_init_batch_kernel, dim3(n), dim3(64), 0, stream, dj);
+    ICP_HIP(hipGetLastError());
+    return SCL_OK;
+}
+
 static void fill_problem(IcpProblem *hp, IcpWorkspace *ws, bool normals)
 {
     hp->work = (float4 *)ws->buf[B_WORK]; hp->st = (IcpState *)ws->buf[B_STATE];
     hp->cell_start = (const int *)ws->buf[B_CSTART]; hp->sorted = (const float4 *)ws->buf[B_TSORT];
     hp->nni = (int *)ws->buf[B_NNI]; hp->nnd = (float *)ws->buf[B_NND]; hp->part = (double *)ws->buf[B_PART];
-    hp->tgt = (const unsigned char *)ws->buf[B_TGT]; hp->normals = normals ? (const float4 *)ws->buf[B_NORM] : nullptr;
+    hp->tgt = (const unsigned char *)(ws->ext_tgt ? ws->ext_tgt : ws->buf[B_TGT]); hp->normals = normals ? (const float4 *)ws->buf[B_NORM] : nullptr;
     hp->nnq = (float4 *)ws->buf[B_NNQ]; hp->flag = (int *)ws->buf[B_FLAG];
 }
 
@@ -2073,6 +2195,7 @@ int icp_nn_correspondences(IcpWorkspace *ws, hipStream_t stream, int num_cu, con
     int rc = check_cloud_args(n_src, n_tgt, stride, err);
     if (rc) return rc;
     if (n_src == 0) return SCL_OK;
+    ws->ext_tgt = nullptr;
     if ((rc = upload(ws, B_SRC, src, (size_t)n_src * stride, stream, err))) return rc;
     if ((rc = upload(ws, B_TGT, tgt, (size_t)n_tgt * stride, stream, err))) return rc;
     if ((rc = ensure(ws, B_WORK, sizeof(float4) * (size_t)(n_src + 1), err))) return rc;

@@ -15,6 +15,7 @@ struct IcpWorkspace {
     void *pinned = nullptr;
     size_t pinned_cap = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};     // the batch loop's two looks at the done flags in flight
+    const void *ext_tgt = nullptr;             // the alignment's target when it is read in place (icp_batch_prepare_all) instead of staged in the workspace
 };
 
 void icp_workspace_free(IcpWorkspace *ws);
@@ -36,6 +37,9 @@ int icp_align_staged(IcpWorkspace *ws, hipStream_t stream, int n_src, int n_tgt,
 // the alignments of one scan's loop candidates, every loop step one launch for all of them (icp.hip)
 int icp_batch_prepare(IcpWorkspace *ws, hipStream_t stream, const void *d_src, int n_src, int n_tgt, int stride,
                       const scl_icp_params &p, std::string *err);
+// the same for n alignments whose targets are already on the device (read in place), every step one launch over all of them
+int icp_batch_prepare_all(IcpWorkspace *const *wss, int n, IcpWorkspace *ctl, hipStream_t stream, int n_src, const void *const *d_tgts,
+                          const int *n_tgts, int stride, const scl_icp_params &p, std::string *err);
 int icp_batch_run(IcpWorkspace *const *wss, int nprob, IcpWorkspace *ctl, hipStream_t stream, const void *d_src, int n_src,
                   int stride, const scl_icp_params &p, float *T, float *fitness, int *converged, int *iterations, std::string *err);
 int icp_nn_correspondences(IcpWorkspace *ws, hipStream_t stream, int num_cu, const void *src, int n_src,
