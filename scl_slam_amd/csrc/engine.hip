@@ -1948,7 +1948,8 @@ int scl_icp_align_batch(scl_engine *e, const void *src, int n_src, const void *c
     for (int first = 0; first < n_targets; first += scl_engine::kIcpBatch) {
         const int m = n_targets - first < scl_engine::kIcpBatch ? n_targets - first : scl_engine::kIcpBatch;
         // stage the targets and build their search grids (normals): independent per candidate, issued from a few host
-        // threads onto the lane streams
+        // threads onto the lane streams, so that one candidate's kernels run under another's PCIe copy (the batched chain of
+        // scl_loop_icp_batch_from_store behind ALL the copies was measured slower here: 8.3 against 8.1 ms, 6.2 against 5.1 point to plane)
         std::atomic<int> next{0};
         std::atomic<int> first_rc{SCL_OK};
         std::string errs[scl_engine::kIcpLanes];
