@@ -1631,40 +1631,46 @@ __global__ __launch_bounds__(kTileQ) void icp_tile_search_kernel(const IcpProble
 // own walk through memory from the seed the lane left behind, then the workgroup's record.  One launch behind every tile search; a
 // workgroup whose flag is down leaves at once.  (A kernel of its own: inlined in the tile search, this walk's registers cost it two
 // of its five waves per SIMD.)
-__global__ __launch_bounds__(kTileQ) void icp_tile_finish_kernel(const IcpProblem *pr, int n_src, int check_done, int stride, float maxd2, int do_reduce)
+// A workgroup of the grid looks at the flags of the tiles w = blockIdx.x, + gridDim.x, ...: the launch is at most kFinishBlocks workgroups per
+// alignment, not one per tile (a launch of 9 775 workgroups that read a flag and leave took 16-22 us of every iteration).
+constexpr int kFinishBlocks = 128;
+__global__ __launch_bounds__(kTileQ) void icp_tile_finish_kernel(const IcpProblem *pr, int n_src, int n_tiles, int check_done, int stride, float maxd2, int do_reduce)
 {
-    __shared__ TileLds L;
+    __shared__ float pq[kTileQ * 8];
+    __shared__ double red[kTileQ / 64][kNSum];
     const IcpProblem P = pr[blockIdx.y];
     const IcpState *st = P.st;
     if (check_done && st->done) return;
-    if (!P.flag[blockIdx.x]) return;
     const int t = threadIdx.x;
-    const int i = blockIdx.x * kTileQ + t;
-    const bool valid = i < n_src;
-    float3 p = make_float3(0.f, 0.f, 0.f), bq = make_float3(0.f, 0.f, 0.f);
-    float best = FLT_MAX;
-    int bi = -1;
-    if (valid) {
-        const float4 pw = P.work[i], nq = P.nnq[i];
-        p = make_float3(pw.x, pw.y, pw.z);
-        bq = make_float3(nq.x, nq.y, nq.z);
-        bi = __float_as_int(nq.w);
-        best = P.nnd[i];
-        if (best < 0.f) {                                        // marked: the seed's distance by the walk's own expression, then the walk
-            best = FLT_MAX;
-            if (bi >= 0) {
-                const float ex = p.x - bq.x, ey = p.y - bq.y, ez = p.z - bq.z;
-                const float d = (ex * ex + ey * ey) + ez * ez;
-                if (d == d) best = d; else bi = -1;
+    for (int w = blockIdx.x; w < n_tiles; w += gridDim.x) {
+        if (!P.flag[w]) continue;                                // (the same for every lane of the workgroup)
+        const int i = w * kTileQ + t;
+        const bool valid = i < n_src;
+        float3 p = make_float3(0.f, 0.f, 0.f), bq = make_float3(0.f, 0.f, 0.f);
+        float best = FLT_MAX;
+        int bi = -1;
+        if (valid) {
+            const float4 pw = P.work[i], nq = P.nnq[i];
+            p = make_float3(pw.x, pw.y, pw.z);
+            bq = make_float3(nq.x, nq.y, nq.z);
+            bi = __float_as_int(nq.w);
+            best = P.nnd[i];
+            if (best < 0.f) {                                    // marked: the seed's distance by the walk's own expression, then the walk
+                best = FLT_MAX;
+                if (bi >= 0) {
+                    const float ex = p.x - bq.x, ey = p.y - bq.y, ez = p.z - bq.z;
+                    const float d = (ex * ex + ey * ey) + ez * ez;
+                    if (d == d) best = d; else bi = -1;
+                }
+                nn_core<1>(p, st, P.cell_start, P.sorted, 0, bi >= 0, best, bi);
+                if (bi >= 0) bq = load_xyz(P.tgt, bi, stride);
+                P.nnq[i] = make_float4(bq.x, bq.y, bq.z, __int_as_float(bi));
+                P.nni[i] = bi;
+                P.nnd[i] = best;
             }
-            nn_core<1>(p, st, P.cell_start, P.sorted, 0, bi >= 0, best, bi);
-            if (bi >= 0) bq = load_xyz(P.tgt, bi, stride);
-            P.nnq[i] = make_float4(bq.x, bq.y, bq.z, __int_as_float(bi));
-            P.nni[i] = bi;
-            P.nnd[i] = best;
         }
+        if (do_reduce) tile_reduce(pq, red, p, bq, valid && bi >= 0 && (best <= maxd2), best, P.part + (size_t)w * kNSum);
     }
-    if (do_reduce) tile_reduce(reinterpret_cast<float *>(L.pts), L.red, p, bq, valid && bi >= 0 && (best <= maxd2), best, P.part + (size_t)blockIdx.x * kNSum);
 }
 
 // ---- the same iteration for launches too small to fill the chip with tiles (one alignment, a few small ones) --------------------
@@ -2126,7 +2132,7 @@ int icp_batch_run(IcpWorkspace *const *wss, int nprob, IcpWorkspace *ctl, hipStr
     auto search_and_sums = [&](bool cold, int check_done, int apply, float md2, bool sums) {
         if (tiles) {
             hipLaunchKernelGGL(icp_tile_search_kernel, dim3(tb, nprob), dim3(kTileQ), 0, stream, dp, n_src, check_done, apply, cold ? 1 : 0, stride, md2, sums ? 1 : 0);
-            hipLaunchKernelGGL(icp_tile_finish_kernel, dim3(tb, nprob), dim3(kTileQ), 0, stream, dp, n_src, check_done, stride, md2, sums ? 1 : 0);
+            hipLaunchKernelGGL(icp_tile_finish_kernel, dim3(tb < kFinishBlocks ? tb : kFinishBlocks, nprob), dim3(kTileQ), 0, stream, dp, n_src, tb, check_done, stride, md2, sums ? 1 : 0);
             return;
         }
         if (cold) hipLaunchKernelGGL(nn_search_batch_kernel<kNnGroup>, dim3((unsigned)((q * kNnGroup + 255) / 256), nprob), dim3(256), 0, stream,
@@ -2218,12 +2224,12 @@ int icp_nn_correspondences(IcpWorkspace *ws, hipStream_t stream, int num_cu, con
     hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(64), 0, stream, (IcpState *)ws->buf[B_STATE]);
     hipLaunchKernelGGL(work_init_batch_kernel, dim3(pb, 1), dim3(256), 0, stream, dp, (const unsigned char *)ws->buf[B_SRC], (const int *)ws->buf[B_PERM], n_src, stride);
     hipLaunchKernelGGL(icp_tile_search_kernel, dim3(tb, 1), dim3(kTileQ), 0, stream, dp, n_src, 0, 0, 1, stride, FLT_MAX, 0);
-    hipLaunchKernelGGL(icp_tile_finish_kernel, dim3(tb, 1), dim3(kTileQ), 0, stream, dp, n_src, 0, stride, FLT_MAX, 0);
+    hipLaunchKernelGGL(icp_tile_finish_kernel, dim3(tb < kFinishBlocks ? tb : kFinishBlocks, 1), dim3(kTileQ), 0, stream, dp, n_src, tb, 0, stride, FLT_MAX, 0);
     if (T_move) {
         IcpState *st = static_cast<IcpState *>(ws->buf[B_STATE]);
         ICP_HIP(hipMemcpyAsync(st->inc_T, T_move, sizeof(float) * 16, hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(icp_tile_search_kernel, dim3(tb, 1), dim3(kTileQ), 0, stream, dp, n_src, 0, 1, 0, stride, FLT_MAX, 0);
-        hipLaunchKernelGGL(icp_tile_finish_kernel, dim3(tb, 1), dim3(kTileQ), 0, stream, dp, n_src, 0, stride, FLT_MAX, 0);
+        hipLaunchKernelGGL(icp_tile_finish_kernel, dim3(tb < kFinishBlocks ? tb : kFinishBlocks, 1), dim3(kTileQ), 0, stream, dp, n_src, tb, 0, stride, FLT_MAX, 0);
     }
     hipLaunchKernelGGL(unpermute_nn_kernel, dim3(pb), dim3(256), 0, stream, (const int *)ws->buf[B_PERM], (const int *)ws->buf[B_NNI], (const float *)ws->buf[B_NND],
                        n_src, (int *)ws->buf[B_SI], (float *)ws->buf[B_TI]);
