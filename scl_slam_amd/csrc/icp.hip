@@ -798,6 +798,7 @@ __device__ __forceinline__ void jacobi_eig3(double (&A)[3][3], double (&V)[3][3]
 // the ball's bounding box are dealt round robin to the lanes (one thread per point left 1.5 waves per SIMD chasing dependent
 // loads row after row), the ten fp64 sums meet by DPP exchanges in a fixed order.
 constexpr int kNormGroup = 8;
+constexpr int kNormBlock = 512;           // threads per workgroup: 64 points, whose eigenvectors fill ONE wave (256 threads: half a wave)
 __device__ __forceinline__ double group_sum8(double v)
 {
     // xor 1, xor 2 (quad permutes), then mirror inside each half row (lane i <-> 7 - i): all 8 lanes end with the same sum
@@ -845,32 +846,53 @@ __device__ __forceinline__ void normals_body(int n_tgt, const IcpState *st, cons
     double sum[3] = {0, 0, 0}, sq[6] = {0, 0, 0, 0, 0, 0};
     int cnt = 0;
     const int ny = hi[1] - lo[1] + 1, nrows = (hi[2] >= lo[2] && ny > 0) ? (hi[2] - lo[2] + 1) * ny : 0;
-    for (int t = sub; t < nrows; t += kNormGroup) {
-        const int zz = t / ny;
-        const int z = lo[2] + zz, y = lo[1] + (t - zz * ny);
-        // the row's cells along x that the ball reaches: distance from p to the row's (y, z) box, taken a hair smaller
-        const double ylo = (double)st->mn[1] + (double)y * hh, zlo = (double)st->mn[2] + (double)z * hh;
-        const double ddy = fmax(fmax(ylo - (double)p.y, (double)p.y - (ylo + hh)), 0.0) - kCellSlack * hh;
-        const double ddz = fmax(fmax(zlo - (double)p.z, (double)p.z - (zlo + hh)), 0.0) - kCellSlack * hh;
-        const double dyz2 = (ddy > 0.0 ? ddy * ddy : 0.0) + (ddz > 0.0 ? ddz * ddz : 0.0);
-        if (dyz2 > r2) continue;
-        int xa, xb;
-        cells((double)p.x, (double)(__builtin_amdgcn_sqrtf((float)(r2 - dyz2)) * 1.0001f), 0, xa, xb);   // (an fp32 root taken a hair longer: a superset)
-        if (xa > xb) continue;
-        const int kb = cell_start[(z * st->dim[1] + y) * st->dim[0] + xa];
-        const int ke = cell_start[(z * st->dim[1] + y) * st->dim[0] + xb + 1];          // cells along x are contiguous
-        for (int k = kb; k < ke; k += 4) {                     // four loads in flight per step
-            float4 qq[4];
+    // Rows are taken eight at a time: lane s of the group finds the range of `sorted` that row t0 + s contributes (its cells along x that
+    // the ball reaches), then ALL eight lanes share the points of each of those ranges, lane s taking points s, s + 8, ... -- with a
+    // whole row per lane the nine rows of a typical ball left one lane with two rows and every lane with its own row's density, and a
+    // wave runs as long as its busiest lane.  A point is first placed by its fp32 squared distance; only when that lies within 1e-5 of
+    // r^2 does the fp64 test decide (the same verdict for every point as the fp64 test alone: fp32 errs by 1e-6 at most here).
+    const float r2f = (float)r2, r2_lo = r2f * (1.0f - 1e-5f), r2_hi = r2f * (1.0f + 1e-5f);
+    const int gbase = (int)(threadIdx.x & 63u) & ~(kNormGroup - 1);
+    for (int t0 = 0; t0 < nrows; t0 += kNormGroup) {
+        int kb = 0, ke = 0;
+        const int t = t0 + sub;
+        if (t < nrows) {
+            const int zz = t / ny;
+            const int z = lo[2] + zz, y = lo[1] + (t - zz * ny);
+            // the row's cells along x that the ball reaches: distance from p to the row's (y, z) box, taken a hair smaller
+            const double ylo = (double)st->mn[1] + (double)y * hh, zlo = (double)st->mn[2] + (double)z * hh;
+            const double ddy = fmax(fmax(ylo - (double)p.y, (double)p.y - (ylo + hh)), 0.0) - kCellSlack * hh;
+            const double ddz = fmax(fmax(zlo - (double)p.z, (double)p.z - (zlo + hh)), 0.0) - kCellSlack * hh;
+            const double dyz2 = (ddy > 0.0 ? ddy * ddy : 0.0) + (ddz > 0.0 ? ddz * ddz : 0.0);
+            if (!(dyz2 > r2)) {
+                int xa, xb;
+                cells((double)p.x, (double)(__builtin_amdgcn_sqrtf((float)(r2 - dyz2)) * 1.0001f), 0, xa, xb);   // (an fp32 root taken a hair longer: a superset)
+                if (xa <= xb) {
+                    kb = cell_start[(z * st->dim[1] + y) * st->dim[0] + xa];
+                    ke = cell_start[(z * st->dim[1] + y) * st->dim[0] + xb + 1];          // cells along x are contiguous
+                }
+            }
+        }
+#pragma unroll 1
+        for (int j = 0; j < kNormGroup; ++j) {
+            const int rb = __shfl(kb, gbase + j, kWave), re = __shfl(ke, gbase + j, kWave);
+            for (int k = rb + sub; k < re; k += 4 * kNormGroup) {         // four loads in flight per step
+                float4 qq[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) qq[u] = sorted[k + u < ke ? k + u : ke - 1];
+                for (int u = 0; u < 4; ++u) { const int kk = k + u * kNormGroup; qq[u] = sorted[kk < re ? kk : re - 1]; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float4 q = qq[u];
-                const double dx = (double)q.x - (double)p.x, dy = (double)q.y - (double)p.y, dz = (double)q.z - (double)p.z;
-                if (k + u >= ke || dx * dx + dy * dy + dz * dz > r2) continue;
-                sum[0] += dx; sum[1] += dy; sum[2] += dz;
-                sq[0] += dx * dx; sq[1] += dx * dy; sq[2] += dx * dz; sq[3] += dy * dy; sq[4] += dy * dz; sq[5] += dz * dz;
-                ++cnt;
+                for (int u = 0; u < 4; ++u) {
+                    const float4 q = qq[u];
+                    if (k + u * kNormGroup >= re) continue;
+                    const float fx = q.x - p.x, fy = q.y - p.y, fz = q.z - p.z;
+                    const float d2f = fx * fx + fy * fy + fz * fz;
+                    if (d2f > r2_hi) continue;
+                    const double dx = (double)q.x - (double)p.x, dy = (double)q.y - (double)p.y, dz = (double)q.z - (double)p.z;
+                    if (!(d2f < r2_lo) && dx * dx + dy * dy + dz * dz > r2) continue;
+                    sum[0] += dx; sum[1] += dy; sum[2] += dz;
+                    sq[0] += dx * dx; sq[1] += dx * dy; sq[2] += dx * dz; sq[3] += dy * dy; sq[4] += dy * dz; sq[5] += dz * dz;
+                    ++cnt;
+                }
             }
         }
     }
@@ -879,11 +901,11 @@ __device__ __forceinline__ void normals_body(int n_tgt, const IcpState *st, cons
 #pragma unroll
     for (int a = 0; a < 6; ++a) sq[a] = group_sum8(sq[a]);
     cnt = (int)group_sum8((double)cnt);
-    // The eigenvectors: one lane per point, and the workgroup's 32 points side by side in ONE wave -- with the first lane of every
+    // The eigenvectors: one lane per point, and the workgroup's 64 points side by side in ONE wave -- with the first lane of every
     // group of eight the Jacobi sweeps ran in all four waves at an eighth of their lanes, and they are most of this kernel's
     // instructions.  Same arithmetic per point, so the same normals.
-    __shared__ double s_sums[256 / kNormGroup][10];
-    __shared__ int s_idx[256 / kNormGroup];
+    __shared__ double s_sums[kNormBlock / kNormGroup][10];
+    __shared__ int s_idx[kNormBlock / kNormGroup];
     if (sub == 0) {
         double *d = s_sums[threadIdx.x / kNormGroup];
         d[0] = sum[0]; d[1] = sum[1]; d[2] = sum[2];
@@ -893,7 +915,7 @@ __device__ __forceinline__ void normals_body(int n_tgt, const IcpState *st, cons
         s_idx[threadIdx.x / kNormGroup] = valid ? i : -1;
     }
     __syncthreads();
-    if (threadIdx.x >= 256 / kNormGroup) return;
+    if (threadIdx.x >= kNormBlock / kNormGroup) return;
     {
         const double *d = s_sums[threadIdx.x];
         sum[0] = d[0]; sum[1] = d[1]; sum[2] = d[2];
@@ -918,7 +940,7 @@ __device__ __forceinline__ void normals_body(int n_tgt, const IcpState *st, cons
     }
     normals[out_i] = out;
 }
-__global__ __launch_bounds__(256) void normals_kernel(const unsigned char *tgt, int n_tgt, int stride, const IcpState *st,
+__global__ __launch_bounds__(kNormBlock) void normals_kernel(const unsigned char *tgt, int n_tgt, int stride, const IcpState *st,
                                                       const int *cell_start, const float4 *sorted, double radius, float4 *normals)
 {
     (void)tgt; (void)stride;
@@ -1088,10 +1110,10 @@ __global__ __launch_bounds__(1024) void grid_scan_batch_kernel(const GridJob *jo
     }
 }
 __global__ void grid_scatter_batch_kernel(const GridJob *jobs, int stride) { const GridJob j = jobs[blockIdx.y]; grid_scatter_body(j.tgt, j.n, stride, j.st, j.cfill, j.tsort); }
-__global__ __launch_bounds__(256) void normals_batch_kernel(const GridJob *jobs, double radius)
+__global__ __launch_bounds__(kNormBlock) void normals_batch_kernel(const GridJob *jobs, double radius)
 {
     const GridJob j = jobs[blockIdx.y];
-    if ((long long)blockIdx.x * (256 / kNormGroup) >= j.n) return;         // (a workgroup is 32 points; the grid is sized for the largest target)
+    if ((long long)blockIdx.x * (kNormBlock / kNormGroup) >= j.n) return;  // (a workgroup is 64 points; the grid is sized for the largest target)
     normals_body(j.n, j.st, j.cstart, j.tsort, radius, j.normals);
 }
 __global__ void state_init_batch_kernel(const GridJob *jobs) { state_init_body(jobs[blockIdx.x].st); }
@@ -2026,7 +2048,7 @@ int icp_batch_prepare(IcpWorkspace *ws, hipStream_t stream, const void *d_src, i
     if ((rc = build_grid(ws, stream, n_tgt, stride, err))) return rc;
     if (p.estimator == 1) {
         if ((rc = ensure(ws, B_NORM, sizeof(float4) * (size_t)(n_tgt + 1), err))) return rc;
-        hipLaunchKernelGGL(normals_kernel, dim3(((size_t)n_tgt * kNormGroup + 255) / 256 > 0 ? (unsigned)(((size_t)n_tgt * kNormGroup + 255) / 256) : 1u), dim3(256), 0, stream,
+        hipLaunchKernelGGL(normals_kernel, dim3(n_tgt > 0 ? (unsigned)(((size_t)n_tgt * kNormGroup + kNormBlock - 1) / kNormBlock) : 1u), dim3(kNormBlock), 0, stream,
                            (const unsigned char *)ws->buf[B_TGT], n_tgt, stride, (const IcpState *)ws->buf[B_STATE],
                            (const int *)ws->buf[B_CSTART], (const float4 *)ws->buf[B_TSORT], p.normal_radius,
                            (float4 *)ws->buf[B_NORM]);
@@ -2081,7 +2103,7 @@ int icp_batch_prepare_all(IcpWorkspace *const *wss, int n, IcpWorkspace *ctl, hi
     hipLaunchKernelGGL(grid_scan_batch_kernel, dim3(n), dim3(1024), 0, stream, dj);
     hipLaunchKernelGGL(grid_scatter_batch_kernel, dim3(gb, n), dim3(256), 0, stream, dj, stride);
     if (p.estimator == 1 && max_n > 0)
-        hipLaunchKernelGGL(normals_batch_kernel, dim3((unsigned)(((size_t)max_n * kNormGroup + 255) / 256), n), dim3(256), 0, stream, dj, p.normal_radius);
+        hipLaunchKernelGGL(normals_batch_kernel, dim3((unsigned)(((size_t)max_n * kNormGroup + kNormBlock - 1) / kNormBlock), n), dim3(kNormBlock), 0, stream, dj, p.normal_radius);
     hipLaunchKernelGGL(state_init_batch_kernel, dim3(n), dim3(64), 0, stream, dj);
     ICP_HIP(hipGetLastError());
     return SCL_OK;
