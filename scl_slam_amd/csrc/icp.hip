@@ -704,18 +704,19 @@ __device__ __forceinline__ void apply_increment(IcpState *st, const float *T, do
 template <int NS>
 __device__ __forceinline__ void reduce_partials(const double *partials, int nblocks, double *sums, double (*tmp)[64])
 {
-    const int lane = threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < NS; ++k) {
+    // (the workgroup's waves share the entries: wave w takes k = w, w + waves, ... -- every (entry, lane) sum and the order of the
+    //  final additions are those of a single wave, so the result does not depend on the number of waves)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
+    for (int k = wv; k < NS; k += nw) {
         double s = 0.0;
         for (int b = lane; b < nblocks; b += 64) s += partials[b * NS + k];
         tmp[k][lane] = s;
     }
     __syncthreads();
-    if (lane < NS) {
+    if ((int)threadIdx.x < NS) {
         double s = 0.0;
-        for (int l = 0; l < 64; ++l) s += tmp[lane][l];
-        sums[lane] = s;
+        for (int l = 0; l < 64; ++l) s += tmp[threadIdx.x][l];
+        sums[threadIdx.x] = s;
     }
     __syncthreads();
 }
@@ -1256,7 +1257,7 @@ struct IcpProblem {
     int *flag;                                               // per workgroup of the tile search: lanes left for icp_tile_finish_kernel
 };
 
-__global__ __launch_bounds__(64) void icp_solve_batch_kernel(const IcpProblem *pr, int nblocks, int mode, int max_iter, double trans_eps, double fit_eps)
+__global__ __launch_bounds__(256) void icp_solve_batch_kernel(const IcpProblem *pr, int nblocks, int mode, int max_iter, double trans_eps, double fit_eps)
 {
     const IcpProblem p = pr[blockIdx.x];
     icp_solve_kernel_body(p.st, p.part, nblocks, mode, max_iter, trans_eps, fit_eps);
@@ -1268,7 +1269,7 @@ __global__ __launch_bounds__(256) void plane_reduce_batch_kernel(const IcpProble
     plane_reduce_kernel_body(p.work, p.tgt, stride, n, p.nni, p.nnd, maxd2, p.normals, p.st, p.part);
 }
 
-__global__ void plane_solve_batch_kernel(const IcpProblem *pr, int nblocks, int max_iter, double trans_eps, double fit_eps)
+__global__ __launch_bounds__(256) void plane_solve_batch_kernel(const IcpProblem *pr, int nblocks, int max_iter, double trans_eps, double fit_eps)
 {
     const IcpProblem p = pr[blockIdx.x];
     plane_solve_kernel_body(p.st, p.part, nblocks, max_iter, trans_eps, fit_eps);
@@ -2167,10 +2168,10 @@ int icp_batch_run(IcpWorkspace *const *wss, int nprob, IcpWorkspace *ctl, hipStr
         search_and_sums(cold, 1, cold ? 0 : 1, maxd2, p.estimator == 0);
         if (p.estimator == 1) {
             hipLaunchKernelGGL(plane_reduce_batch_kernel, dim3(rb, nprob), dim3(256), 0, stream, dp, stride, n_src, maxd2);
-            hipLaunchKernelGGL(plane_solve_batch_kernel, dim3(nprob), dim3(64), 0, stream, dp, rb, p.max_iterations, p.transformation_epsilon,
+            hipLaunchKernelGGL(plane_solve_batch_kernel, dim3(nprob), dim3(256), 0, stream, dp, rb, p.max_iterations, p.transformation_epsilon,
                                p.euclidean_fitness_epsilon);
         } else {
-            hipLaunchKernelGGL(icp_solve_batch_kernel, dim3(nprob), dim3(64), 0, stream, dp, tb, 0, p.max_iterations, p.transformation_epsilon,
+            hipLaunchKernelGGL(icp_solve_batch_kernel, dim3(nprob), dim3(256), 0, stream, dp, tb, 0, p.max_iterations, p.transformation_epsilon,
                                p.euclidean_fitness_epsilon);
         }
     };
@@ -2200,7 +2201,7 @@ int icp_batch_run(IcpWorkspace *const *wss, int nprob, IcpWorkspace *ctl, hipStr
     // neighbour bounds the search)
     hipLaunchKernelGGL(work_final_batch_kernel, dim3(pb, nprob), dim3(256), 0, stream, dp, src, perm, n_src, stride);
     search_and_sums(false, 0, 0, FLT_MAX, true);
-    hipLaunchKernelGGL(icp_solve_batch_kernel, dim3(nprob), dim3(64), 0, stream, dp, tb, 2, 0, 0.0, 0.0);
+    hipLaunchKernelGGL(icp_solve_batch_kernel, dim3(nprob), dim3(256), 0, stream, dp, tb, 2, 0, 0.0, 0.0);
     hipLaunchKernelGGL(gather_states_kernel, dim3(nprob), dim3(64), 0, stream, dp, nprob, d_states);
     ICP_HIP(hipGetLastError());
     ICP_HIP(hipMemcpyAsync(hs, d_states, sizeof(IcpState) * (size_t)nprob, hipMemcpyDeviceToHost, stream));
