@@ -1946,6 +1946,8 @@ void icp_workspace_free(IcpWorkspace *ws)
 
     for (size_t i = 0; i < sizeof(ws->buf) / sizeof(ws->buf[0]); ++i) if (ws->buf[i]) { (void)hipFree(ws->buf[i]); ws->buf[i] = nullptr; ws->cap[i] = 0; }
     for (int k = 0; k < 2; ++k) if (ws->ev[k]) { (void)hipEventDestroy(ws->ev[k]); ws->ev[k] = nullptr; }
+    for (int k = 0; k < 2; ++k) if (ws->ev_side[k]) { (void)hipEventDestroy(ws->ev_side[k]); ws->ev_side[k] = nullptr; }
+    if (ws->side) { (void)hipStreamDestroy(ws->side); ws->side = nullptr; }
     if (ws->pinned) { (void)hipHostFree(ws->pinned); ws->pinned = nullptr; ws->pinned_cap = 0; }
 }
 
@@ -2103,8 +2105,18 @@ int icp_batch_prepare_all(IcpWorkspace *const *wss, int n, IcpWorkspace *ctl, hi
     hipLaunchKernelGGL(grid_count_batch_kernel, dim3(gb, n), dim3(256), 0, stream, dj, stride);
     hipLaunchKernelGGL(grid_scan_batch_kernel, dim3(n), dim3(1024), 0, stream, dj);
     hipLaunchKernelGGL(grid_scatter_batch_kernel, dim3(gb, n), dim3(256), 0, stream, dj, stride);
-    if (p.estimator == 1 && max_n > 0)
-        hipLaunchKernelGGL(normals_batch_kernel, dim3((unsigned)(((size_t)max_n * kNormGroup + kNormBlock - 1) / kNormBlock), n), dim3(kNormBlock), 0, stream, dj, p.normal_radius);
+    ctl->normals_pending = false;
+    if (p.estimator == 1 && max_n > 0) {
+        // the normals are first needed by the plane reduction behind the cold search: they run on a side stream beside the sources'
+        // ordering and that search (icp_batch_run waits for ev_side[1] in front of its first plane reduction)
+        if (!ctl->side) ICP_HIP(hipStreamCreateWithFlags(&ctl->side, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) if (!ctl->ev_side[k]) ICP_HIP(hipEventCreateWithFlags(&ctl->ev_side[k], hipEventDisableTiming));
+        ICP_HIP(hipEventRecord(ctl->ev_side[0], stream));
+        ICP_HIP(hipStreamWaitEvent(ctl->side, ctl->ev_side[0], 0));
+        hipLaunchKernelGGL(normals_batch_kernel, dim3((unsigned)(((size_t)max_n * kNormGroup + kNormBlock - 1) / kNormBlock), n), dim3(kNormBlock), 0, ctl->side, dj, p.normal_radius);
+        ICP_HIP(hipEventRecord(ctl->ev_side[1], ctl->side));
+        ctl->normals_pending = true;
+    }
     hipLaunchKernelGGL(state_init_batch_kernel, dim3(n), dim3(64), 0, stream, dj);
     ICP_HIP(hipGetLastError());
     return SCL_OK;
@@ -2167,6 +2179,7 @@ int icp_batch_run(IcpWorkspace *const *wss, int nprob, IcpWorkspace *ctl, hipStr
     auto iteration = [&](bool cold) {
         search_and_sums(cold, 1, cold ? 0 : 1, maxd2, p.estimator == 0);
         if (p.estimator == 1) {
+            if (ctl->normals_pending) { (void)hipStreamWaitEvent(stream, ctl->ev_side[1], 0); ctl->normals_pending = false; }
             hipLaunchKernelGGL(plane_reduce_batch_kernel, dim3(rb, nprob), dim3(256), 0, stream, dp, stride, n_src, maxd2);
             hipLaunchKernelGGL(plane_solve_batch_kernel, dim3(nprob), dim3(256), 0, stream, dp, rb, p.max_iterations, p.transformation_epsilon,
                                p.euclidean_fitness_epsilon);
