@@ -45,6 +45,20 @@ def test_nn_correspondences_of_the_moved_source_bit_exact(eng, n_src, n_tgt, shi
     assert np.array_equal(gd.view(np.uint32), od.view(np.uint32))
 
 
+@pytest.mark.parametrize("n_src,n_tgt,move", [(60000, 100000, 2e-4), (60000, 100000, 3e-3), (20000, 30000, 1e-2), (100000, 100000, 5e-5)])
+def test_nn_correspondences_after_a_tiny_move_bit_exact(eng, n_src, n_tgt, move):
+    """Moves as small as a late ICP iteration's (the previous neighbour is almost always still the nearest, the ball around it
+    hugs the query): indices and distance bits still equal a cold search of the moved cloud by the checker."""
+    tgt = synth_structured_cloud(n_tgt, seed=12 + n_tgt, extent=60.0)
+    src = synth_structured_cloud(n_src, seed=13 + n_src, extent=60.0)
+    T = np.eye(4, dtype=np.float32); T[:3, 3] = [move, -0.7 * move, 0.4 * move]
+    T[0, 1] = -1e-6; T[1, 0] = 1e-6                                   # (a hair of rotation: the movement differs from point to point)
+    gi, gd = eng.nn_correspondences_moved(src, tgt, T)
+    oi_, od = oi.nn(oi.transform(src, T), tgt, use_grid=True)
+    assert np.array_equal(gi, oi_)
+    assert np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+
+
 def test_nn_correspondences_large_and_degenerate_clouds(eng):
     """100 k x 100 k (configs[2]'s size), a target that is one point, a target on a line, sources with NaN coordinates."""
     tgt = synth_structured_cloud(100000, seed=41, extent=60.0)
