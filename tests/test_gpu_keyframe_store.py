@@ -150,6 +150,13 @@ def test_loop_icp_batch_from_store_equals_one_by_one():
             assert (ns, ntb[c]) == (ns1, nt1) and cb[c] == c1 and ib[c] == i1
             assert np.array_equal(Tb[c].view(np.uint32), T1.view(np.uint32)) and fb[c] == np.float32(f1)
         assert cb.all()
+        # point to plane: the candidates' normals by the batched launch on the side stream == one target at a time
+        pq = e.icp_default_params(); pq.max_iterations = 30; pq.estimator = 1; pq.normal_radius = 1.5
+        Tb, fb, cb, ib, ns, ntb = e.loop_icp_batch_from_store(0, 12, ident, keys, sn, poses, leaf, pq)
+        for c, k in enumerate(keys):
+            T1, f1, c1, i1, ns1, nt1 = e.loop_icp_from_store(0, 12, ident, k, sn, _window([ident] * 13, k, sn), leaf, pq)
+            assert (ns, ntb[c]) == (ns1, nt1) and cb[c] == c1 and ib[c] == i1
+            assert np.array_equal(Tb[c].view(np.uint32), T1.view(np.uint32)) and fb[c] == np.float32(f1)
         # size gate: nothing attempted
         T0, f0, c0, i0, _, _ = e.loop_icp_batch_from_store(0, 12, ident, keys[:2], sn, poses[:2], leaf, pp, min_tgt_points=10 ** 7)
         assert not c0.any() and not i0.any() and np.array_equal(T0[1], ident)
