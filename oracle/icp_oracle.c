@@ -268,7 +268,8 @@ static void jacobi_eig3(double A[3][3], double V[3][3])
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) V[i][j] = (i == j);
     for (int sweep = 0; sweep < 32; sweep++) {
         const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
-        if (off < 1e-300) break;
+        const double dia = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+        if (off < 1e-300 || off <= 1e-34 * dia) break;      /* (below 1e-17 of the diagonal a rotation changes no bit: icp.hip jacobi_eig3) */
         for (int p = 0; p < 2; p++) for (int q = p + 1; q < 3; q++) {
             if (A[p][q] == 0.0) continue;
             const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
