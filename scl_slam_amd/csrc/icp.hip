@@ -1298,7 +1298,7 @@ __global__ __launch_bounds__(256) void plane_solve_batch_kernel(const IcpProblem
 #define SCL_TILE_TAB 1024
 #endif
 #ifndef SCL_TILE_ABLATE
-#define SCL_TILE_ABLATE 0                // experiments only (results invalid): 1 no walk, 2 no reduction, 4 no staging of the points
+#define SCL_TILE_ABLATE 0                // experiments only (results invalid): 1 no walk, 2 no reduction, 4 no staging of the points, 8 no rounds at all
 #endif
 #ifndef SCL_TILE_Q
 #define SCL_TILE_Q 256
@@ -1611,7 +1611,7 @@ __global__ __launch_bounds__(kTileQ) void icp_tile_search_kernel(const IcpProble
     int c[3] = {0, 0, 0};
     if (cold) cell_index(st, p, c);
 #pragma unroll 1
-    for (int stage = cold ? 0 : 2; stage < 3; ++stage) {
+    for (int stage = (SCL_TILE_ABLATE & 8) ? 3 : (cold ? 0 : 2); stage < 3; ++stage) {
         int xa = 0, xb = -1, ya = 0, yb = -1, za = 0, zb = -1;
         bool ask = false, to_memory = false;
         if (stage == 0) { ask = open; xa = xb = c[0]; ya = yb = c[1]; za = zb = c[2]; }
