@@ -1333,9 +1333,9 @@ __device__ unsigned long long g_tile_stats[16];
 struct TileLds {
     float4 pts[kTilePts + 4];            // staged target points (x, y, z, index; a walk reads up to 3 past its range); reused as the reduction's staging area
     int tab[kTileTab];                   // the box's slice of cell_start, row after row, as offsets into pts
-    int g0[kTileRows];                   // first point (in `sorted`) of every row of the box
+    int delta[kTileRows];                // per row of the box: (where its points start in pts) - (where they start in `sorted`)
     int loff[kTileRows + 1];             // where the row's points start in pts; loff[nrows] = their number
-    int box[6];
+    int box[2][6];                       // the requests' bounding box, two rounds' worth (a round prepares the next one's)
     unsigned char prow[kTilePts];        // the row of every staged point
     double red[kTileQ / 64][kNSum];
 };
@@ -1376,26 +1376,38 @@ __device__ __forceinline__ void tile_reach(float v, float g0, float h, float inv
     }
 }
 
+// LDS operations of one wave execute in issue order; only the compiler must not move them across this point
+__device__ __forceinline__ void wave_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Staging: the lanes with req ask for the cells [xa, xb] x [ya, yb] x [za, zb] (non-empty ranges inside the grid); the box of all
 // requests -- its slice of the cell table as offsets into pts, its points -- is put in LDS.  Returns 0 when nobody asked, 1 when
 // the box is staged (B describes it), 2 when it does not fit (nothing usable in LDS).  The same value in every lane of the workgroup.
 struct TileBox { int X0, Y0, Z0, NY, W1; };
 __device__ __forceinline__ int tile_stage(TileLds &L, const TileGrid &g, const int *cell_start, const float4 *sorted, const bool req,
-                                          const int xa, const int xb, const int ya, const int yb, const int za, const int zb, TileBox &B TILE_STAMP_ARG)
+                                          const int xa, const int xb, const int ya, const int yb, const int za, const int zb, TileBox &B, int &par TILE_STAMP_ARG)
 {
+    // Barriers of a round: the box is complete | the table is in LDS | every point knows its row | the points are in LDS.  (The box
+    // of round n + 1 is initialised by round n in the other of two buffers; the rows' prefix sum is done by every wave for itself --
+    // the same values from every wave -- and the table keeps its raw entries, a per-row delta turning them into offsets at use: each of
+    // the three took a barrier of its own.)  L.box[par] holds INT_MAX / INT_MIN on entry.
     const int t = threadIdx.x, lane = t & 63;
     int lo[3] = {req ? xa : INT_MAX, req ? ya : INT_MAX, req ? za : INT_MAX}, hi[3] = {req ? xb : -INT_MAX, req ? yb : -INT_MAX, req ? zb : -INT_MAX};
 #pragma unroll
     for (int a = 0; a < 3; ++a) { lo[a] = wave_min_i32(lo[a]); hi[a] = -wave_min_i32(-hi[a]); }
-    if (t < 6) L.box[t] = t < 3 ? INT_MAX : INT_MIN;
-    __syncthreads();                                             // (also: every lane has left the previous round's LDS)
+    int *box = L.box[par];
     if (lane == 0 && lo[0] <= hi[0]) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { atomicMin(&L.box[a], lo[a]); atomicMax(&L.box[3 + a], hi[a]); }
+        for (int a = 0; a < 3; ++a) { atomicMin(&box[a], lo[a]); atomicMax(&box[3 + a], hi[a]); }
     }
-    __syncthreads();
-    const int X0 = L.box[0], Y0 = L.box[1], Z0 = L.box[2], X1 = L.box[3], Y1 = L.box[4], Z1 = L.box[5];
-    __syncthreads();                                             // (a lane that returns below may write the next round's box at once)
+    __syncthreads();                                             // (also: every lane has left the previous round's table and points)
+    const int X0 = box[0], Y0 = box[1], Z0 = box[2], X1 = box[3], Y1 = box[4], Z1 = box[5];
+    par ^= 1;
+    if (t < 6) L.box[par][t] = t < 3 ? INT_MAX : INT_MIN;        // the next round's (nobody has touched this buffer since the round before last)
     TILE_STAMP(9);
     if (X0 > X1) return 0;
     if (t == 0) TILE_STAT(0, 1);
@@ -1418,25 +1430,29 @@ __device__ __forceinline__ int tile_stage(TileLds &L, const TileGrid &g, const i
     }
     __syncthreads();
     TILE_STAMP(10);
-    if (t < 64) {                                                // the rows' point counts and their exclusive scan: two rows per lane
+    {                                                            // the rows' point counts and their exclusive scan, by every wave: two rows per lane
         constexpr int PER = kTileRows / 64;
-        int cnt[PER], tot = 0;
+        int cnt[PER], first[PER], tot = 0;
 #pragma unroll
-        for (int u = 0; u < PER; ++u) { const int r = t * PER + u; cnt[u] = r < nrows ? L.tab[r * W1 + W1 - 1] - L.tab[r * W1] : 0; tot += cnt[u]; }
+        for (int u = 0; u < PER; ++u) {
+            const int r = lane * PER + u;
+            first[u] = r < nrows ? L.tab[r * W1] : 0;
+            cnt[u] = r < nrows ? L.tab[r * W1 + W1 - 1] - first[u] : 0;
+            tot += cnt[u];
+        }
         int incl = tot;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, kWave); if (lane >= off) incl += o; }
         int base = incl - tot;
 #pragma unroll
-        for (int u = 0; u < PER; ++u) { const int r = t * PER + u; if (r < nrows) { L.loff[r] = base; L.g0[r] = L.tab[r * W1]; } base += cnt[u]; }
-        if (t == 63) L.loff[nrows] = incl;
+        for (int u = 0; u < PER; ++u) { const int r = lane * PER + u; if (r < nrows) { L.loff[r] = base; L.delta[r] = base - first[u]; } base += cnt[u]; }
+        if (lane == 63) L.loff[nrows] = incl;
     }
-    __syncthreads();
+    wave_fence();                                                // (this wave's own writes: the other waves write the same values)
     const int total = L.loff[nrows];
     TILE_STAMP(11);
     if (total > kTilePts) { if (t == 0) TILE_STAT(1, 1); return 2; }
     if (t == 0) { TILE_STAT(3, nent); TILE_STAT(4, total); }
-    for (int e = t; e < nent; e += kTileQ) { int r, k; fast_divmod(e, W1, inv_W1, r, k); L.tab[e] = L.tab[e] - L.g0[r] + L.loff[r]; }
     for (int r = t >> 4; r < nrows; r += kTileQ / 16) {          // which row every staged point belongs to (16 lanes per row, LDS only)
         const int dst0 = L.loff[r], cnt = L.loff[r + 1] - dst0;
         for (int k = t & 15; k < cnt; k += 16) L.prow[dst0 + k] = (unsigned char)r;
@@ -1448,7 +1464,7 @@ __device__ __forceinline__ int tile_stage(TileLds &L, const TileGrid &g, const i
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int k = t + (u0 + u) * kTileQ;
-            if (k < total) { const int r = L.prow[k]; v[u] = sorted[L.g0[r] + (k - L.loff[r])]; }
+            if (k < total) v[u] = sorted[k - L.delta[L.prow[k]]];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) { const int k = t + (u0 + u) * kTileQ; if (k < total) L.pts[k] = v[u]; }
@@ -1463,10 +1479,10 @@ __device__ __forceinline__ int tile_stage(TileLds &L, const TileGrid &g, const i
 // returned; 0 and 2 as tile_stage).
 __device__ __forceinline__ int tile_round(TileLds &L, const TileGrid &g, const int *cell_start, const float4 *sorted, const bool req,
                                           const int xa, const int xb, const int ya, const int yb, const int za, const int zb,
-                                          const float3 p, float &best, int &bi, float3 &bq TILE_STAMP_ARG)
+                                          const float3 p, float &best, int &bi, float3 &bq, int &par TILE_STAMP_ARG)
 {
     TileBox B;
-    const int rc = tile_stage(L, g, cell_start, sorted, req, xa, xb, ya, yb, za, zb, B TILE_STAMP_PASS);
+    const int rc = tile_stage(L, g, cell_start, sorted, req, xa, xb, ya, yb, za, zb, B, par TILE_STAMP_PASS);
     if (rc != 1) return rc;
     const int X0 = B.X0, Y0 = B.Y0, Z0 = B.Z0, NY = B.NY, W1 = B.W1;
     if (req && !(SCL_TILE_ABLATE & 1)) {
@@ -1494,8 +1510,8 @@ __device__ __forceinline__ int tile_round(TileLds &L, const TileGrid &g, const i
                     }
                 }
                 if (x0 > x1) continue;
-                const int row = ((z - Z0) * NY + (y - Y0)) * W1 - X0;
-                const int kb = L.tab[row + x0], ke = L.tab[row + x1 + 1];
+                const int rr = (z - Z0) * NY + (y - Y0), row = rr * W1 - X0, dl = L.delta[rr];
+                const int kb = L.tab[row + x0] + dl, ke = L.tab[row + x1 + 1] + dl;
                 TILE_STAT(5, 1); TILE_STAT(6, ke - kb);
                 for (int k = kb; k < ke; k += 4) {
                     const float4 *qp = &L.pts[k];                // (reads past ke stay inside L: masked below)
@@ -1592,6 +1608,9 @@ __global__ __launch_bounds__(kTileQ) void icp_tile_search_kernel(const IcpProble
     float best = FLT_MAX;
     int bi = -1;
     float3 bq = make_float3(0.f, 0.f, 0.f);
+    int par = 0;                                                 // which of the two boxes the next round fills
+    if (t < 6) L.box[0][t] = t < 3 ? INT_MAX : INT_MIN;
+    __syncthreads();
     bool open = valid;                                           // this lane's search is not finished
     bool deferred = false;                                       // ... and will be finished in memory by the launch behind this one
     TILE_STAMP_DECL;
@@ -1632,7 +1651,7 @@ __global__ __launch_bounds__(kTileQ) void icp_tile_search_kernel(const IcpProble
         for (int sub = -1; sub < kTileQ / 64; ++sub) {            // -1: the whole workgroup; 0..3: wave by wave after a box that did not fit
             const bool mine = ask && (sub < 0 || wv == sub);
             if (stage == 2 && sub < 0) TILE_STAMP(8);            // (everything up to the ball round: loads, seeds, a cold search's stages 0 and 1)
-            const int rc = tile_round(L, g, P.cell_start, P.sorted, mine, xa, xb, ya, yb, za, zb, p, best, bi, bq TILE_STAMP_PASS);
+            const int rc = tile_round(L, g, P.cell_start, P.sorted, mine, xa, xb, ya, yb, za, zb, p, best, bi, bq, par TILE_STAMP_PASS);
             if ((rc == 2 && sub >= 0 && mine) || to_memory) {     // left to icp_tile_finish_kernel, with what the lane knows as its seed
                 TILE_STAT(2, 1);
                 deferred = true; open = false; ask = false; to_memory = false;
