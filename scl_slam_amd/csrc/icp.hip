@@ -51,7 +51,7 @@ struct IcpState {
     double fitness;
     int iter; int done; int converged; int n_corr;
     double sums[kNSum];
-    unsigned int ticket; unsigned int pad_;               // workgroups of the fused iteration that have delivered their partial sums
+    unsigned int pad_[2];
 };
 
 enum Buf { B_SRC = 0, B_TGT, B_WORK, B_TSORT, B_CSTART, B_CFILL, B_NNI, B_NND, B_PART, B_STATE, B_BBOX, B_SI, B_TI, B_OUT, B_MASK, B_HYP, B_PROB,
@@ -208,7 +208,7 @@ __device__ __forceinline__ void group_min(float &d, int &j)
 #undef SCL_GMIN_STEP
 }
 
-// apply_iter >= 0: K6 fused in -- the increment of the previous iteration's solve (st->inc_T) moves the working point
+// apply_iter >= 0: K6 folded in -- the increment of the previous iteration's solve (st->inc_T) moves the working point
 // first, and the moved point is written back for the reduction that follows (distributedMapping.h:247-249
 // arithmetic: fp32, no FMA).  Every search of the loop follows exactly one solve; a solve that fails or converges sets
 // st->done, on which this kernel returns at once -- so no iteration number has to travel with the launch, and the same
@@ -297,7 +297,6 @@ __device__ __forceinline__ void nn_core(const float3 p, const IcpState *st, cons
     };
     if (warm_start) ball_pass();                                 // the previous neighbour bounds the ball
     // Cold search: shells until the first one that holds a point (its distance bounds the ball), then the ball once.
-    // (no early return above: this body is inlined in front of the fused iteration's reduction)
     for (int r = 0; !warm_start && r <= maxdim; ++r) {
         const int lo0 = c[0] - r, hi0 = c[0] + r, lo1 = c[1] - r, hi1 = c[1] + r, lo2 = c[2] - r, hi2 = c[2] + r;
         const int z0 = max(lo2, 0), z1 = min(hi2, dz - 1), y0 = max(lo1, 0), y1 = min(hi1, dy - 1);
@@ -414,17 +413,6 @@ __global__ __launch_bounds__(256) void nn_search_kernel_t(float4 *work, int n_sr
     nn_search_kernel_t_body<G>(work, n_src, st, cell_start, sorted, nn_idx, nn_d2, check_done, apply_iter, tgt_raw, stride, warm);
 }
 
-// A workgroup's partial sums leave it either as plain stores (a reduction launch of its own: the solve is another launch) or,
-// inside the fused iteration, as agent-scope atomic stores (write-through to where every XCD sees them: the last workgroup to
-// arrive reads them back in the same launch)
-__device__ __forceinline__ void put_partial(double *dst, double v, bool atomic_out)
-{
-    if (atomic_out) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *dst = v;
-}
-// the range of correspondences a workgroup reduces: i = i0 + threadIdx.x, + step, ... < i1
-struct RedRange { int i0, step, i1; };
-
 // ---- K5 ----------------------------------------------------------------------------
 // sums of [p;1][q;1]^T (16) and of d2 over the accepted correspondences.
 // mode 0: pairs (i, nn_idx[i]) with d2 <= maxd2, p from `work`;  mode 1: explicit pairs (si[k], ti[k]).
@@ -432,14 +420,13 @@ __device__ __forceinline__ void corr_reduce_kernel_body(const float4 *work, cons
                                                           const unsigned char *tgt_raw, int stride, int n,
                                                           const int *nn_idx, const float *nn_d2, float maxd2,
                                                           const int *si, const int *ti, int mode,
-                                                          const IcpState *st, double *partials, int check_done,
-                                                          const RedRange *range = nullptr)
+                                                          const IcpState *st, double *partials, int check_done)
 {
     if (check_done && st->done) return;
     double acc[kNSum];
 #pragma unroll
     for (int k = 0; k < kNSum; ++k) acc[k] = 0.0;
-    const int r_i0 = range ? range->i0 : (int)(blockIdx.x * blockDim.x), r_step = range ? range->step : (int)(gridDim.x * blockDim.x), r_i1 = range ? range->i1 : n;
+    const int r_i0 = (int)(blockIdx.x * blockDim.x), r_step = (int)(gridDim.x * blockDim.x), r_i1 = n;
     for (int i = r_i0 + (int)threadIdx.x; i < r_i1; i += r_step) {
         float3 p, q;
         float d2 = 0.f;
@@ -473,7 +460,7 @@ __device__ __forceinline__ void corr_reduce_kernel_body(const float4 *work, cons
     if ((threadIdx.x & 63) == 0) for (int k = 0; k < kNSum; ++k) s[wv][k] = acc[k];
     __syncthreads();
     if (threadIdx.x < kNSum)
-        put_partial(partials + blockIdx.x * kNSum + threadIdx.x, ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x], range != nullptr);
+        partials[blockIdx.x * kNSum + threadIdx.x] = ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void corr_reduce_kernel(const float4 *work, const unsigned char *src_raw,
@@ -495,8 +482,7 @@ __device__ __forceinline__ void corr_reduce_mfma_kernel_body(const float4 *work,
                                                                const unsigned char *tgt_raw, int stride, int n,
                                                                const int *nn_idx, const float *nn_d2, float maxd2,
                                                                const int *si, const int *ti, int mode,
-                                                               const IcpState *st, double *partials, int check_done,
-                                                               const RedRange *range = nullptr)
+                                                               const IcpState *st, double *partials, int check_done)
 {
     if (check_done && st->done) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -504,8 +490,7 @@ __device__ __forceinline__ void corr_reduce_mfma_kernel_body(const float4 *work,
     const int wave_global = blockIdx.x * 4 + wv, nwaves = gridDim.x * 4;
     double acc0 = 0.0, acc1 = 0.0;
     double sum_d2 = 0.0;
-    // (a range: this workgroup's own correspondences, 32 per wave and step)
-    const int b_first = range ? range->i0 + wv * 32 : wave_global * 32, b_step = range ? 4 * 32 : nwaves * 32, b_end = range ? range->i1 : n;
+    const int b_first = wave_global * 32, b_step = nwaves * 32, b_end = n;
     for (int base = b_first; base < b_end; base += b_step) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {                       // two independent accumulator chains
@@ -543,7 +528,7 @@ __device__ __forceinline__ void corr_reduce_mfma_kernel_body(const float4 *work,
     if (lane == 0) s[wv][16] = sum_d2;
     __syncthreads();
     if (threadIdx.x < kNSum)
-        put_partial(partials + blockIdx.x * kNSum + threadIdx.x, ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x], range != nullptr);
+        partials[blockIdx.x * kNSum + threadIdx.x] = ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void corr_reduce_mfma_kernel(const float4 *work, const unsigned char *src_raw,
@@ -953,14 +938,13 @@ __global__ __launch_bounds__(kNormBlock) void normals_kernel(const unsigned char
 
 __device__ __forceinline__ void plane_reduce_kernel_body(const float4 *work, const unsigned char *tgt_raw, int stride, int n,
                                                            const int *nn_idx, const float *nn_d2, float maxd2,
-                                                           const float4 *normals, const IcpState *st, double *partials,
-                                                           const RedRange *range = nullptr)
+                                                           const float4 *normals, const IcpState *st, double *partials)
 {
     if (st->done) return;
     double acc[kNPlane];
 #pragma unroll
     for (int k = 0; k < kNPlane; ++k) acc[k] = 0.0;
-    const int r_i0 = range ? range->i0 : (int)(blockIdx.x * blockDim.x), r_step = range ? range->step : (int)(gridDim.x * blockDim.x), r_i1 = range ? range->i1 : n;
+    const int r_i0 = (int)(blockIdx.x * blockDim.x), r_step = (int)(gridDim.x * blockDim.x), r_i1 = n;
     for (int i = r_i0 + (int)threadIdx.x; i < r_i1; i += r_step) {
         const int j = nn_idx[i];
         const float d2 = nn_d2[i];
@@ -991,7 +975,7 @@ __device__ __forceinline__ void plane_reduce_kernel_body(const float4 *work, con
     if ((threadIdx.x & 63) == 0) for (int k = 0; k < kNPlane; ++k) s[wv][k] = acc[k];
     __syncthreads();
     if (threadIdx.x < kNPlane)
-        put_partial(partials + blockIdx.x * kNPlane + threadIdx.x, ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x], range != nullptr);
+        partials[blockIdx.x * kNPlane + threadIdx.x] = ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x];
 }
 
 __device__ __forceinline__ void plane_solve_from_sums(IcpState *st, const double *sums, int max_iter, double trans_eps, double fit_eps)
@@ -1062,7 +1046,7 @@ __device__ __forceinline__ void state_init_body(IcpState *st)
     if (threadIdx.x == 0) {
         for (int k = 0; k < 16; ++k) { st->final_T[k] = (k % 5 == 0) ? 1.f : 0.f; st->inc_T[k] = (k % 5 == 0) ? 1.f : 0.f; }
         st->mse_prev = DBL_MAX; st->fitness = (double)FLT_MAX;
-        st->iter = 0; st->done = 0; st->converged = 0; st->n_corr = 0; st->ticket = 0u; st->pad_ = 0u;
+        st->iter = 0; st->done = 0; st->converged = 0; st->n_corr = 0; st->pad_[0] = 0u; st->pad_[1] = 0u;
     }
 }
 
