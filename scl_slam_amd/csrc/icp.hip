@@ -6,20 +6,27 @@
 //   TransformationEstimationSVD::estimateRigidTransformation  distributedMapping.h:1228-1230
 //   paramsServer::transformPointCloud                      distributedMapping.h:234-253
 //
-// Kernels (all HBM-bound; bytes per iteration ~ (n_src + n_tgt) * 16):
-//   K4a grid build   target cloud -> uniform grid (bbox, count, scan, scatter as float4 xyz+index)
-//   K4b nn search    one thread per source point, shell expansion over grid cells until the best
-//                    distance beats every unsearched cell; fp32 distances ((dx*dx+dy*dy)+dz*dz),
-//                    ties -> lowest target index (a total order: the result does not depend on the
-//                    order points were scattered into a cell)
+// Kernels (SURVEY 8(d) prices an iteration at (n_src + n_tgt) * 16 bytes; an EXACT nearest-neighbour search is bound by its
+// comparisons and gathers, not by those bytes: DESIGN.md section 4, K4-K6):
+//   K4a grid build   target cloud -> uniform grid (bbox, count, scan, scatter as float4 xyz+index); for the candidates of one scan
+//                    as one chain of batched launches (icp_batch_prepare_all)
+//   K4b nn search    in memory: lanes of a group share the rows of a shell / of the ball around the previous neighbour (nn_core);
+//                    fp32 distances ((dx*dx+dy*dy)+dz*dz), ties -> lowest target index (a total order: the result does not
+//                    depend on the order points were scattered into a cell).  Small launches and what the tiles leave over.
+//   K4c tile search  the loop's search for large launches: 256 Hilbert-ordered sources per workgroup, the box of the cells their
+//                    balls reach staged in LDS, every query walks its cells there; the same neighbours bit for bit; the
+//                    workgroup's correspondences reduced in the same launch (icp_tile_search_kernel, icp_tile_finish_kernel)
 //   K5  reduce       fp64 sums of the augmented outer product [p;1][q;1]^T over correspondences
 //                    (gives the cross-covariance, both centroids and the count in one pass) + sum d2;
-//                    on the matrix cores: one v_mfma_f64_4x4x4_4b_f64 per 16 correspondences
-//   K5b solve        one wave: centred covariance, closed-form rotation (Horn quaternion, cyclic
-//                    Jacobi, fp64), incremental transform, PCL's convergence criteria, final = T*final
-//   K6  transform    working source cloud <- T_inc * cloud (fp32, no FMA)
-// The whole ICP loop is enqueued without host round trips: every kernel looks at a device-side
-// `done` flag, the host peeks at it every few iterations.
+//                    on the matrix cores: one v_mfma_f64_4x4x4_4b_f64 per 16 correspondences (tile_reduce: one record per 256
+//                    sources, the same records whichever search found the neighbours)
+//   K5b solve        the records summed in a fixed order, then one thread: centred covariance, closed-form rotation (polar factor;
+//                    Horn quaternion + cyclic Jacobi for near-singular cases, fp64), incremental transform, PCL's convergence
+//                    criteria, final = T*final
+//   K6  transform    working source cloud <- T_inc * cloud (fp32, no FMA), folded into the next search
+//   normals          point to plane: PCA of the neighbours within a radius through the same grid (normals_body)
+// The whole ICP loop is enqueued without host round trips: every kernel looks at a device-side `done` flag; the flags travel to the
+// host every four iterations and are looked at one period later.
 #include "icp.hpp"
 
 #include <hipcub/hipcub.hpp>
