@@ -85,6 +85,9 @@ def parse_args():
     ap.add_argument("--front", type=int, default=0,
                     help="G > 0: measure the C-ABI sharded front instead (scl_create_sharded: ONE process, G shards of 12 500 keyframes dealt "
                          "over the visible devices; the stream form and the single passes with their exchange).  Not the driver's contract line.")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="print the rank command line `--gpus N` / the device list `--front G` would use, check that the node shows that many "
+                         "GPUs (torch.cuda.device_count(): does not initialise HIP) and exit -- 0 when the run could start, 3 otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] geometric-verification measurement")
     ap.add_argument("--only-secondary", default="", help="comma-separated names: run only these secondary measurements (experiments)")
@@ -95,18 +98,51 @@ def parse_args():
 # ------------------------------------------------------------------------------------------------
 # self-launch: `python bench.py --gpus N` with no torchrun environment
 # ------------------------------------------------------------------------------------------------
+def rank_command(args, port):
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--dry-run"]
+
+
+def rank_env():
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return env
+
+
 def launch_ranks(args):
     """Start the N ranks as a fresh child (`python -m torch.distributed.run`).  This parent has not imported torch
     or touched HIP; it only relays the child's output (rank 0 prints the JSON line) and exit code."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.call(cmd, env=env)
+    return subprocess.call(rank_command(args, port), env=rank_env())
+
+
+def dry_run(args):
+    """What `--gpus N` (or `--front G`) would start, and whether this node can: the GPU count comes from
+    torch.cuda.device_count(), which does not initialise HIP on this image, so nothing touches a device."""
+    import torch
+    have = torch.cuda.device_count()
+    need = args.front if args.front > 0 else args.gpus
+    plan = {"dry_run": True, "gpus_visible": have, "gpus_needed": need,
+            "env": {k: rank_env().get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "OMP_NUM_THREADS", "GPU_MAX_HW_QUEUES")}}
+    if args.front > 0:
+        plan["mode"] = "C-ABI sharded front: one process, scl_create_sharded over the device list"
+        plan["devices"] = [i % max(1, have) for i in range(args.front)]
+        plan["exchange"] = "RCCL min all-reduce x2 (exchange = 2)" if have >= args.front and args.front > 1 else "host merge (exchange = 1): shards share a card"
+        plan["command"] = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--dry-run"]
+    else:
+        plan["mode"] = "one process per GPU over RCCL (torch.distributed 'nccl')" if args.gpus > 1 else "one process, one GPU"
+        plan["command"] = rank_command(args, "<free port>") if args.gpus > 1 else [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--dry-run"]
+        plan["keyframes_per_gpu"] = args.keyframes or (N_KEYFRAMES_1GPU if args.gpus == 1 else N_KEYFRAMES_SHARD)
+    ok = have >= need and need >= 1
+    plan["ok"] = ok
+    if not ok:
+        plan["error"] = (f"this node shows {have} GPU(s) (torch.cuda.device_count()), the run needs {need}: "
+                         f"{'the shards of --front would share cards (plumbing, not scaling)' if args.front > 0 else 'one rank per GPU, RCCL refuses two ranks on one device'}")
+    print(json.dumps(plan), flush=True)
+    return 0 if ok else 3
 
 
 # ------------------------------------------------------------------------------------------------
@@ -271,23 +307,73 @@ def cpu_baseline(descs, n_pairs_hint, budget_s=8.0):
 # ------------------------------------------------------------------------------------------------
 # secondary: BASELINE configs[2] -- geometric verification of the top-25 candidates of one scan
 # ------------------------------------------------------------------------------------------------
-def secondary_icp(eng, n_cand=25, n_pts=100000):
-    """One scan against its 25 loop candidates (~100 k points per cloud, point-to-plane, 30 iterations max:
-    configs[2]; and point-to-point, the reference's estimator, DM.h:1108), verified together by
-    scl_icp_align_batch.  Outside the headline's timed region.  The ICP roofline follows SURVEY 8(d):
-    (n_src + n_tgt) * 16 B per iteration against the HBM peak."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+def _icp_clouds(n_cand, n_pts):
+    """configs[2]'s synthetic verification problem: `n_cand` structured clouds (the loop candidates' submaps) and the scan = a
+    moved, noisy copy of candidate 0 (the one true loop; the other 24 do not match, as for a real top-25 list)."""
     from scl_slam_amd.synth import rigid_transform, synth_structured_cloud
     tgts, src0 = [], None
     for c in range(n_cand):
         tgt = synth_structured_cloud(n_pts, seed=100 + c, extent=60.0)
         tgts.append(tgt)
-        if c == 0:                                            # the scan = a moved, noisy copy of candidate 0
+        if c == 0:
             T = rigid_transform(0.004, -0.006, 0.02, 0.25, -0.15, 0.05)
             rs = np.random.RandomState(3)
             src0 = tgt.copy()
             p = tgt[:, :3].astype(np.float64) @ T[:3, :3].T + T[:3, 3]
             src0[:, :3] = (p + 0.01 * rs.standard_normal(p.shape)).astype(np.float32)
+    return tgts, src0
+
+
+def cpu_baseline_icp(n_cand=25, n_pts=100000, one_thread_sample=6):
+    """The ICP half of north_star's denominator ("the reference nanoflann+CPU SC-distance+ICP path"; BASELINE.md section 2 variant B:
+    "thread pool over candidates / ICP problems"): oracle/icp_oracle.c's restatement of pcl::IterativeClosestPoint::align +
+    getFitnessScore (DM.h:1107-1121; exact 1-NN through a uniform grid, fp64 Umeyama) on the SAME 25 x 100 k problems as
+    secondary.icp_verification, both estimators.  (A) one thread, as the reference runs it (loopClosureThread, DM.h:1078-1141), on
+    the first `one_thread_sample` candidates (the matching one + non-matching ones; the query figure is scaled to 25 and says so);
+    (B) a pool over the 25 problems on the host cores this process may use.  Clouds are host buffers (no voxel filter: compare
+    with 'host_buffers', or with 'from_store' whose 0.05 m filter keeps ~99 % of the points)."""
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_icp_binding as oi                       # (ctypes releases the GIL inside icpo_icp_align: the pool's threads run in parallel)
+    tgts, src0 = _icp_clouds(n_cand, n_pts)
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    pool_threads = max(1, min(n_cand, threads))
+    cg = _cgroup_cpu()
+    out = {"kind": "port", "cpu_model": _cpu_model(), "affinity_cores": threads, "cgroup_quota_cores": cg.get("quota_cores"),
+           "workload": f"{n_cand} alignments of a {n_pts}-point scan against {n_pts}-point candidates, max 30 iterations (oracle/icp_oracle.c: "
+                       f"icpo_icp_align, grid NN; -O3, no -march, as the reference builds)"}
+    for est, name in ((1, "point_to_plane"), (0, "point_to_point")):
+        def one(c, est=est):
+            pp = oi.default_params(max_iterations=30, estimator=est, normal_radius=1.0)
+            T, fit, conv, it = oi.icp_align(src0, tgts[c], pp)
+            return it, fit, conv
+        k = max(1, min(one_thread_sample, n_cand))
+        t0 = time.perf_counter()
+        r1 = [one(c) for c in range(k)]
+        dt1 = time.perf_counter() - t0
+        cpu0, t0 = time.process_time(), time.perf_counter()
+        with ThreadPoolExecutor(pool_threads) as ex:
+            rp = list(ex.map(one, range(n_cand)))
+        dtp = time.perf_counter() - t0
+        cores_used = (time.process_time() - cpu0) / dtp
+        out[name] = {
+            "one_thread": {"value": k / dt1, "unit": "ICP problems/s", "cores": 1, "ms_per_candidate": dt1 * 1e3 / k,
+                           "ms_per_query_of_25_scaled": dt1 * 1e3 / k * n_cand, "iterations_mean": float(np.mean([r[0] for r in r1])),
+                           "sample": f"candidates 0..{k - 1} of the {n_cand} (candidate 0 is the match), {dt1:.1f} s; the per-query figure is this "
+                                     f"mean x {n_cand}"},
+            "pool_over_problems": {"value": n_cand / dtp, "unit": "ICP problems/s", "cores": pool_threads, "ms_per_query": dtp * 1e3,
+                                   "cores_worth_of_cpu_time": cores_used, "iterations_mean": float(np.mean([r[0] for r in rp])),
+                                   "matching_candidate_fitness": float(rp[0][1]), "converged": int(sum(1 for r in rp if r[2])),
+                                   "sample": f"all {n_cand} problems, one per thread of a {pool_threads}-thread pool, {dtp:.1f} s"}}
+    return out
+
+
+def secondary_icp(eng, n_cand=25, n_pts=100000):
+    """One scan against its 25 loop candidates (~100 k points per cloud, point-to-plane, 30 iterations max:
+    configs[2]; and point-to-point, the reference's estimator, DM.h:1108), verified together by
+    scl_icp_align_batch.  Outside the headline's timed region.  The ICP roofline follows SURVEY 8(d):
+    (n_src + n_tgt) * 16 B per iteration against the HBM peak."""
+    tgts, src0 = _icp_clouds(n_cand, n_pts)
     out = {"workload": f"BASELINE configs[2]: one scan vs its {n_cand} loop candidates, {n_pts} points per cloud, max 30 iterations; "
                        f"'from_store': clouds resident in the on-device keyframe store (scl_loop_icp_batch_from_store: submap assembly + "
                        f"fused ICP loops, nothing but poses crosses PCIe); 'host_buffers': the same alignments with every cloud handed "
@@ -538,6 +624,8 @@ def bench_front(G, steps, spl):
 
 def main():
     args = parse_args()
+    if args.dry_run:
+        sys.exit(dry_run(args))
     if args.front > 0:
         return bench_front(args.front, args.steps, max(1, args.scans_per_launch))
     if args.gpus < 1:
@@ -746,6 +834,17 @@ def main():
                     out["secondary"][name] = {"error": repr(ex)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(shard, args.cpu_pairs)
+            icp_gpu = out.get("secondary", {}).get("icp_verification")
+            if isinstance(icp_gpu, dict) and "error" not in icp_gpu:        # the ICP half of the denominator, beside the GPU figures it belongs to
+                try:
+                    icp_cpu = cpu_baseline_icp()
+                    for name in ("point_to_plane", "point_to_point"):
+                        g = icp_gpu[name]["from_store"]["ms_per_query"]
+                        icp_cpu[name]["gpu_from_store_speedup_vs_pool"] = icp_cpu[name]["pool_over_problems"]["ms_per_query"] / g
+                        icp_cpu[name]["gpu_from_store_speedup_vs_one_thread"] = icp_cpu[name]["one_thread"]["ms_per_query_of_25_scaled"] / g
+                    icp_gpu["cpu_baseline"] = icp_cpu
+                except Exception as ex:
+                    icp_gpu["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:

@@ -49,7 +49,7 @@ constexpr int hdesc_stride(int RG, int S) { return hdesc_stride_rgh(hdesc_sector
 //                                chunk-major image of the same values (hdesc2_offset / hdesc2_elems above).  hstride = hdesc_stride(RG, S) elements of 8 B.
 //   hkey   half   [cap][hkey_row_halfs(S)]  the fp16 sector key and its norm as stored behind hdesc's copy (+ the key's second fp16 part), in a table of its own: the alignment reads
 //                                nothing else of a keyframe, and 272 B at a stride of 33 KB cost it a DRAM page and a TLB entry per keyframe
-//   kmask  u32    [cap][8]       bit c of words 0..6 = column c has a non-zero norm; word 7 bit 0 = some column norm is outside [2^-60, 2^60] or non-finite (such keyframes are always scored exactly)
+//   kmask  u32    [cap][8]       bit c of words 0..6 = column c has a non-zero norm (grids of up to 192 sectors: word 6 = float E, the summed fp16 rounding-error norms of the screening copy's unit columns, rounded up -- make_sc.hip); word 7 bit 0 = some column norm is outside [2^-60, 2^60] or non-finite (such keyframes are always scored exactly)
 struct DbView {
     const float4 *desc;
     const double *vkey;

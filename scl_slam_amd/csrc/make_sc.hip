@@ -234,9 +234,37 @@ __global__ __launch_bounds__(256) void ingest_kernel(
             }
         }
     }
+    // How far the fp16 unit columns of the screening copy are from the unit columns they stand for: E = sum over the columns of
+    // |h_c - x_c / norm_c|_2, rounded up.  By Cauchy-Schwarz the screened cosine of a column pair is off by at most |e_q| + |e_k| +
+    // |e_q||e_k|, so the screened distance of a (scan, keyframe, shift) is within (E_q + E_k)(1 + 1e-3) / n_eff (+ accumulation) of
+    // the reference's -- on the ACTUAL rounding errors (2e-4 per column as a rule) instead of fp16's worst case (4.9e-4): the
+    // finishing kernel's shift masks (sc_screen.hip) get their margin from it.  An entry below fp16's normal range counts with the
+    // larger of its rounding error and its value (a matrix core may take it for zero).  Kept in word 6 of the sector mask, which
+    // holds no sector bits on grids of up to 192 sectors.
+    __syncthreads();                                                 // (svk, the sector key, is no longer read)
+    for (int c = threadIdx.x; c < S; c += blockDim.x) {
+        const float iv = siv[c];
+        double e2 = 0.0;
+        if (iv == iv && iv != 0.0f) {
+            const double nrm = norm[(size_t)slot * S + c];
+            for (int r = 0; r < R; ++r) {
+                const float x = sv[r * LS + c];
+                const double h = (double)(float)(_Float16)(x * iv), u = (double)x / nrm;
+                double d = fabs(h - u);
+                if (fabs(h) < 6.103515625e-05) d = fmax(d, fabs(u));
+                e2 = e2 + d * d;
+            }
+        }
+        svk[c] = sqrt(e2);
+    }
+    __syncthreads();
     if (threadIdx.x < 8) {
         unsigned int w = 0;
-        if (threadIdx.x < 7) {
+        if (threadIdx.x == 6 && S <= 192) {
+            double E = 0.0;
+            for (int c = 0; c < S; ++c) E = E + svk[c];
+            w = (unsigned int)__float_as_int(__double2float_ru(E * (1.0 + 1e-6) + 1e-12));
+        } else if (threadIdx.x < 7) {
             for (int b = 0; b < 32; ++b) {
                 const int c = 32 * (int)threadIdx.x + b;
                 if (c < S && siv[c] != 0.0f) w |= 1u << b;               // NaN counts as non-zero

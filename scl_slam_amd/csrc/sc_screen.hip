@@ -178,6 +178,12 @@ __device__ __forceinline__ int align_keyframe_exact(const double2 vk, int lane, 
 }
 
 constexpr float kScreenEps = 1.5e-3f;          // see the error budget at the top of this file
+// ... its part that does not come from the fp16 rounding of the operands, for the products' SECOND form: an accumulator's chain of S / 4
+// matrix-core products of 32 terms each, every term's addition truncating (|error| <= 2^-23 of the sum of the terms' magnitudes, which
+// is at most n_eff (1 + 1e-3): unit columns), the accumulators and ring parts joined by at most 16 further additions; 2e-6 for the fp32
+// scaling of the unit columns (3.6e-7), the finishing kernel's fp32 quotient and difference and this bound's own rounding.
+// 1.19e-4 at 64 x 120 (chains of 960 terms), 1.76e-4 at 80 x 180 (1 440).
+template <int S> constexpr float screen2_acc_eps() { return (float)((S / 4) * 32 + 16) * 1.1920929e-7f * 1.002f + 2.0e-6f; }
 constexpr int kScreenWaves = 4;
 constexpr int kGroup = 16;                     // keyframes per matrix product (the MFMA's N)
 constexpr int kTileStride = 64;                // bytes per keyframe in a wave's transposition tile (32 fp16); the 16-byte chunk j of keyframe n
@@ -1606,7 +1612,7 @@ struct FinishLoads {
     static constexpr int NPF = S2Cfg<RG, S, W>::NP * S2Cfg<RG, S, W>::NPASS * 4;
     static constexpr int MW = (((S + 63) / 64) + 1) / 2;
     static constexpr bool kRingUpFront = NPF * 4 + RG * 4 <= 100;                // (registers: the 80 x 180 grid asks for its ring key later)
-    uint4 km[MW]; unsigned int kflag; int b_raw; f4v pv[NPF]; float4 bk[kRingUpFront ? RG : 1];
+    uint4 km[MW]; unsigned int kflag; float kerr; int b_raw; f4v pv[NPF]; float4 bk[kRingUpFront ? RG : 1];
 };
 template <int RG, int S, int W>
 __device__ __forceinline__ FinishLoads<RG, S, W> sc_screen2_finish_request(const Screen2Args &fa, const ScreenArgs &a, const int qi, const int ci)
@@ -1618,7 +1624,10 @@ __device__ __forceinline__ FinishLoads<RG, S, W> sc_screen2_finish_request(const
     const unsigned int *kp = a.kmask + (size_t)(a.slot_base + ci) * 8;
 #pragma unroll
     for (int i = 0; i < L::MW; ++i) l.km[i] = *reinterpret_cast<const uint4 *>(kp + 4 * i);
-    l.kflag = kp[7];
+    {
+        const uint2 ef = *reinterpret_cast<const uint2 *>(kp + 6);              // word 6: the keyframe's summed rounding-error norms E; word 7: the flag
+        l.kerr = __uint_as_float(ef.x); l.kflag = ef.y;
+    }
     l.b_raw = a.starts[ci];
     const f4v *pp = reinterpret_cast<const f4v *>(fa.part + ((size_t)qi * (size_t)ab.pair_stride + (size_t)ci) * (C::NP * C::NPASS * 16));
 #pragma unroll
@@ -1631,19 +1640,26 @@ __device__ __forceinline__ FinishLoads<RG, S, W> sc_screen2_finish_request(const
     return l;
 }
 template <int RG, int S, int W>
-__device__ __forceinline__ float sc_screen2_finish_compute(const ScreenArgs &a, const int ci, const uint4 *rotq, const bool q_bad, FinishLoads<RG, S, W> &l)
+__device__ __forceinline__ float sc_screen2_finish_compute(const ScreenArgs &a, const int ci, const uint4 *rotq, const bool q_bad, const float q_err, FinishLoads<RG, S, W> &l)
 {
     using C = S2Cfg<RG, S, W>;
     using L = FinishLoads<RG, S, W>;
     constexpr int NP = C::NP, NPASS = C::NPASS, MW = L::MW;
     const float kInf = __int_as_float(0x7f800000);
-    if (MW == 2) l.km[MW - 1].w = 0u;                                        // word 7 is the flag, not sector bits
+    if (MW == 2) { l.km[MW - 1].z = 0u; l.km[MW - 1].w = 0u; }               // words 6 and 7 are E and the flag, not sector bits
     const bool b_open = l.b_raw < 0;                                         // kAlignUndecided: scored by the exact pass
     const int b0 = b_open ? 0 : l.b_raw;
     float dmin = kInf;
     float dsh[W];                                                            // the screened distance of every shift (+inf: no effective sector)
+    // ... and how far it can be from the reference's distance of that shift: (E_q + E_k)(1 + 1e-3) / n_eff for the fp16 rounding of the
+    // two descriptors' unit columns on their recorded error norms (make_sc.hip), screen2_acc_eps for the accumulation and the fp32
+    // scaling / quotient / difference; never more than the worst-case kScreenEps
+    const float e_pair = (q_err + l.kerr) * 1.002f;
+    const bool e_ok = e_pair >= 0.0f && e_pair < 1.0f;                       // (NaN / absurd values: the worst-case bound)
+    float hi_min = kInf;                                                     // the smallest upper bound of a shift's exact distance
+    float dlo[W];
 #pragma unroll
-    for (int t = 0; t < W; ++t) dsh[t] = kInf;
+    for (int t = 0; t < W; ++t) { dsh[t] = kInf; dlo[t] = kInf; }
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
 #pragma unroll
@@ -1666,18 +1682,20 @@ __device__ __forceinline__ float sc_screen2_finish_compute(const ScreenArgs &a, 
                 const float d = 1.0f - sm[r] / (float)ne;
                 if (ne > 0 && d < dmin) dmin = d;
                 dsh[t] = ne > 0 ? d : kInf;
+                const float et = e_ok ? fminf(e_pair / (float)ne + screen2_acc_eps<S>(), kScreenEps) : kScreenEps;
+                if (ne > 0) { dlo[t] = d - et; hi_min = fminf(hi_min, d + et); }
             }
         }
     }
     const bool exact_only = q_bad || l.kflag != 0 || b_open || !(dmin == dmin);
     a.out_approx[ci] = exact_only ? __int_as_float(0xff800000) : dmin;
     if (a.out_smask) {
-        // a shift can hold (or tie for) the pair's exact minimum only if its screened distance is within 2 eps of the smallest
-        // (NaN sums compare false everywhere: such a pair is exact_only); an undecided alignment has no first shift: mask 0
+        // a shift can hold (or tie for) the pair's exact minimum only if the lower end of its interval does not lie above the
+        // smallest upper end (NaN sums compare false everywhere: such a pair is exact_only); an undecided alignment has no first
+        // shift: mask 0
         unsigned int m = 0u;
-        const float lim = dmin + 2.0f * kScreenEps;
 #pragma unroll
-        for (int t = 0; t < W; ++t) m |= ((exact_only || dsh[t] <= lim) ? 1u : 0u) << t;
+        for (int t = 0; t < W; ++t) m |= ((exact_only || dlo[t] <= hi_min) ? 1u : 0u) << t;
         a.out_smask[ci] = b_open ? 0u : m;
     }
     // nanoflann's metric (nanoflann.hpp:383-408) for the ring-key top-k: four dimensions per step, fp32, groups accumulated in
@@ -1700,7 +1718,7 @@ template <int RG, int S, int W>
 __device__ __forceinline__ float sc_screen2_finish_pair(const Screen2Args &fa, const ScreenArgs &a, const int qi, const int ci, const uint4 *rotq, const bool q_bad)
 {
     FinishLoads<RG, S, W> l = sc_screen2_finish_request<RG, S, W>(fa, a, qi, ci);
-    return sc_screen2_finish_compute<RG, S, W>(a, ci, rotq, q_bad, l);
+    return sc_screen2_finish_compute<RG, S, W>(a, ci, rotq, q_bad, __uint_as_float(a.q_kmask[6]), l);
 }
 
 template <int RG, int S, int W>
@@ -1719,7 +1737,7 @@ __device__ __forceinline__ void sc_screen2_finish_body(const Screen2Args &fa, co
     __syncthreads();
     const float kInf = __int_as_float(0x7f800000);
     float contrib = kInf;
-    if (live) contrib = sc_screen2_finish_compute<RG, S, W>(a, ci, rotq, q_bad, ld);
+    if (live) contrib = sc_screen2_finish_compute<RG, S, W>(a, ci, rotq, q_bad, __uint_as_float(a.q_kmask[6]), ld);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) contrib = fminf(contrib, __shfl_xor(contrib, off, kWave));
     if ((threadIdx.x & 63) == 0) wmin[threadIdx.x >> 6] = contrib;

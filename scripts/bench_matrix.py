@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The exact distance matrix (scl_sc_distance_matrix) on BASELINE configs[1]'s database: rows x 9 900 keyframes, 64x120 -- and on
-configs[4]'s grid (80x180).  usage: bench_matrix.py [rows]"""
+configs[4]'s grid (80x180).  usage: bench_matrix.py [rows] [64x120|80x180]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,8 +9,11 @@ from scl_slam_amd import ScanContextEngine
 from scl_slam_amd.synth import synth_descriptors
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+only = sys.argv[2] if len(sys.argv) > 2 else None
 out = {}
 for R, S, seed in ((64, 120, 1002), (80, 180, 1005)):
+    if only and only != f"{R}x{S}":
+        continue
     n = 10000
     eng = ScanContextEngine(num_ring=R, num_sector=S, initial_capacity=n + 64)
     eng.save_bulk(synth_descriptors(n, R, S, seed=seed, revisit_frac=0.01))
