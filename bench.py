@@ -417,7 +417,8 @@ def secondary_exact_all_pairs(eng, n_elig, n_query, queries=64):
     reference's fp64 distance and shift (descriptor.h:1538-1569).  Per 16 rows: alignment + screening (which leaves, per pair, the
     first shift and the shifts within 2 eps of the pair's smallest screened distance), then sc_masked_kernel evaluates exactly
     those shifts in the reference's fp64 arithmetic.  Bit-identical to the checker (tests/test_gpu_sc_distance.py compares uint64
-    views, adversarial descriptors included).  Priced at SURVEY 8(d)'s 31 680 B per pair."""
+    views, adversarial descriptors included).  `roofline.frac` prices the bytes a group of rows MOVES (the database once per group);
+    SURVEY 8(d)'s per-pair price is kept as `survey_equivalent`."""
     eng.sc_distance_matrix(n_elig + np.arange(16, dtype=np.int32), 0, n_elig)              # warm-up
     eng.profile_reset(); eng.profile_enable(2)
     qs = (n_elig + (np.arange(queries) % n_query)).astype(np.int32)
@@ -429,19 +430,50 @@ def secondary_exact_all_pairs(eng, n_elig, n_query, queries=64):
     pairs = queries * n_elig
     k_ms = prof["sc_distance_ms"] / max(1, prof["sc_distance_launches"])
     k_pairs = prof["sc_distance_pairs"] / max(1, prof["sc_distance_launches"])
-    ach = k_pairs * ALGO_BYTES_PER_PAIR / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    k_rows = k_pairs / n_elig
+    # Bytes one group of rows MOVES by design (SURVEY 8(d)'s rule for Q scans per database pass -- "DB_bytes / Q + per-query bytes;
+    # never count bytes that were not moved"): every keyframe's fp32 rows + fp64 column norms ONCE per group (the workgroups of the
+    # group's scan pairs share a keyframe through an XCD's L2), the screening group's bytes per keyframe (fp16 image, alignment image,
+    # ring key, mask), the same per scan, and per pair the screening intermediates, the shift mask (written, read), the first shift
+    # (read again) and the result (fp64 distance + shift).
+    exact_kf = R * S * 4 + S * 8
+    per_pair_io = KERNEL_BYTES_PER_PAIR_IO + 4 + 4 + 4 + 12
+    moved = (n_elig + k_rows) * (exact_kf + KERNEL_BYTES_PER_KEYFRAME) + k_pairs * per_pair_io
+    ach = moved / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    survey = k_pairs * ALGO_BYTES_PER_PAIR / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    # what crosses L2 -> CU by design: a keyframe's fp32 rows and norms once per PAIR of scans (a workgroup of the exact kernel holds
+    # two scans), the screening image once per launch
+    l2_bytes = n_elig * ((k_rows + 1) // 2) * exact_kf + (n_elig + k_rows) * KERNEL_BYTES_PER_KEYFRAME + k_pairs * per_pair_io
+    l2 = l2_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     flops = 3 * S * S + 13 * S * 2 * R                                                      # 242 880 per pair
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_matrix.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))                      # PMC run of scripts/bench_matrix.py (scripts/profile_matrix.sh): HBM bytes per group of 16 rows
+            if abs(k_rows - tj.get("rows_per_group", 0)) < 0.5:
+                traffic = tj["hbm_bytes_per_group"] * n_elig / tj["eligible_keyframes"]
+        except Exception:
+            traffic = None
     return {"workload": f"{queries} scans x {n_elig} keyframes, 64x120: the fp64 distance and shift of EVERY pair (scl_sc_distance_matrix, "
                         f"results copied to the host)",
             "value": pairs / dt, "unit": "pairs/s", "ms_per_scan": dt / queries * 1e3, "dtype": "f64",
             "finite_distances": int(np.isfinite(dist).sum()),
             "kernel_ms": {"group_of_rows": k_ms, "pairs_per_group": k_pairs},
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "bytes_per_pair": ALGO_BYTES_PER_PAIR, "kernel": "per group of 16 rows: sc_align2_kernel + sc_screen2_kernel + sc_screen2_finish_kernel + sc_masked_kernel<16,120,13> "
-                                                                             "(exact fp64 at the open shifts, one wave per pair); HIP events around every group",
-                         "fp64_vector_frac": (k_pairs * flops / (k_ms * 1e-3) / 1e12 / 78.6) if k_ms > 0 else 0.0,
-                         "note": "SURVEY 8(d): 4 R S + 8 S bytes per pair, one scan per database pass; fp64_vector_frac = the reference's "
-                                 "242 880 flop per pair against 78.6 TFLOP/s"}}
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_group": moved, "rows_per_group": k_rows,
+                         "pricing": f"moved bytes: per keyframe {exact_kf} B (fp32 rows + fp64 norms, once per group of rows) + {KERNEL_BYTES_PER_KEYFRAME} B "
+                                    f"(screening group), per pair {per_pair_io} B (screening intermediates, mask, first shift, result)",
+                         "kernel": "per group of 16 rows: sc_align2_kernel + sc_screen2_kernel + sc_screen2_finish_kernel (masks from the recorded fp16 "
+                                   "rounding-error norms) + sc_matrix_kernel<16,120,13> (exact fp64 at the open shifts: a workgroup holds two scans, a wave "
+                                   "scores one keyframe against both); HIP events around every group",
+                         "l2_delivery": {"achieved": l2, "peak": L2_RATE_GBS, "frac": l2 / L2_RATE_GBS, "bytes_per_group": l2_bytes},
+                         "single_scan_hbm_floor": {"pairs_per_s": HBM_PEAK_GBS * 1e9 / ALGO_BYTES_PER_PAIR, "value_over_floor": (pairs / dt) / (HBM_PEAK_GBS * 1e9 / ALGO_BYTES_PER_PAIR),
+                                                   "note": "a kernel that streams the fp32 database once per SCAN at 8 TB/s (SURVEY 8(d)'s Q = 1 floor)"},
+                         "survey_equivalent": {"bytes_per_pair": ALGO_BYTES_PER_PAIR, "achieved": survey, "frac": survey / HBM_PEAK_GBS,
+                                               "fp64_vector_frac": (k_pairs * flops / (k_ms * 1e-3) / 1e12 / 78.6) if k_ms > 0 else 0.0,
+                                               "note": "SURVEY 8(d)'s single-scan price (4 R S + 8 S bytes and 242 880 flop per pair) x pairs / time: "
+                                                       "round 3's `frac`; NOT a rate of moved bytes or of evaluated flops (1-3 of the 13 shifts are evaluated)"}}}
 
 
 def secondary_blocking_scan(eng, n_elig, n_query, scans=300):
@@ -581,8 +613,8 @@ def secondary_livox_stream(device, n0=1000, n_scans=120):
 # ------------------------------------------------------------------------------------------------
 def bench_front(G, steps, spl):
     """BASELINE configs[3] through the C ABI: ONE engine over G shards (keyframe g on shard g % G; devices = the visible GPUs, round
-    robin, so on a one-GPU box the shards share the card and the exchange is the host merge or -- SCL_FRONT_EXCHANGE=3 -- the tests'
-    stand-in collective; with G distinct devices the two RCCL min all-reduces).  Stream form (per-shard streams + host merge of the
+    robin, so on a one-GPU box the shards share the card and the exchange is the host merge -- or, SCL_FRONT_EXCHANGE=2 with
+    SCL_RCCL_LIB=tests/cpp/libmock_rccl.so, the tests' stand-in collective; with G distinct devices the two RCCL min all-reduces).  Stream form (per-shard streams + host merge of the
     winners) and the single blocking pass (per-shard pass + exchange)."""
     import torch
     from scl_slam_amd import ScanContextEngine
@@ -614,7 +646,7 @@ def bench_front(G, steps, spl):
     info = eng.shard_info()
     eng.close()
     print(json.dumps({"metric": "loop-closure candidates/sec through the C-ABI sharded front (scl_create_sharded), one process", "value": n_elig * scans / dt,
-                      "unit": "pairs/s", "n_gpus": len(set(devices)), "shards": G, "devices": devices, "exchange": {1: "host merge", 2: "RCCL min all-reduce x2", 3: "stand-in collective (tests)"}.get(info[1], str(info[1])),
+                      "unit": "pairs/s", "n_gpus": len(set(devices)), "shards": G, "devices": devices, "exchange": {1: "host merge", 2: "min all-reduce x2 through " + (os.environ.get("SCL_RCCL_LIB") or "librccl")}.get(info[1], str(info[1])),
                       "steps": steps, "ms_per_step": dt / steps * 1e3, "ms_per_scan": dt / scans * 1e3, "higher_is_better": True, "scaling": "weak",
                       "config": {"workload": f"BASELINE configs[3]-shaped: {n} keyframes over {G} shards ({N_KEYFRAMES_SHARD} each), 64x120, {scans} scans through the front's stream form",
                                  "scans_per_launch": spl},

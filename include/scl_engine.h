@@ -92,16 +92,16 @@ int  scl_destroy(scl_engine *e);
  * keys (exchange = 2; needs every shard on its own device), or on the host from pinned memory (exchange = 1);
  * exchange = 0 picks RCCL when n_devices > 1 and the devices are distinct, else the host merge.  The same device
  * may be listed more than once (several shards on one GPU: rehearsal of the multi-GPU path on a one-GPU box).
- * exchange = 3 is for tests: the control flow of exchange = 2 (pack kernels, grouped all-reduce, select kernels, second
- * all-reduce, one device-to-host copy) with a stand-in for the collective that forms the ranks' element-wise minimum on the
- * host -- RCCL refuses two ranks on one device, so this is how the G > 1 flow runs on a one-GPU box.
+ * The collective library is librccl unless the environment names another one (SCL_RCCL_LIB=/path/to/lib: a newer RCCL build, or
+ * the stand-in the tests link -- tests/cpp/mock_rccl.cpp, the ranks' element-wise minimum formed on the host --, which is how the
+ * G > 1 control flow of exchange = 2 runs on a one-GPU box: RCCL itself refuses two ranks on one device).
  * With more than one shard every shard also keeps the query-side rows of the newest 1024 keyframes of each OTHER shard (copied
  * device to device when a keyframe is appended: 66 KB per keyframe at 64x120, n_devices x 1024 rows per shard), so that searching
  * for a recent keyframe -- what detection does -- moves nothing between the devices; older keyframes are copied when asked for.
  * Geometric verification of one scan's candidates (scl_icp_align_batch) is spread over the shards by candidate;
  * other geometry calls and the keyframe store live on devices[0].  cfg->device is ignored. */
 int  scl_create_sharded(const scl_config *cfg, const int *devices, int n_devices, int exchange, scl_engine **out);
-/* number of shards (1 for scl_create) and the exchange in use (0 none, 1 host merge, 2 RCCL, 3 the tests' stand-in); either may be NULL */
+/* number of shards (1 for scl_create) and the exchange in use (0 none, 1 host merge, 2 min all-reduces through the collective library); either may be NULL */
 int  scl_shard_info(const scl_engine *e, int *n_shards, int *exchange);
 
 /* ---- the six virtuals of scan_descriptor (D.h:21-36) ----------------------- */

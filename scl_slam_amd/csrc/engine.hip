@@ -416,13 +416,24 @@ static void log_env_overrides_once()
 {
     static std::atomic<bool> done{false};
     if (done.exchange(true)) return;
-    static const char *const names[] = {"SCL_SCREEN", "SCL_SCREEN_FORM", "SCL_SCREEN_VARIANT", "SCL_SCREEN_PROBE", "SCL_SCREEN_V2_MIN", "SCL_SCREEN_TAIL",
-                                        "SCL_ALIGN_WGS", "SCL_ALIGN_SIDE", "SCL_ALIGN_FILTER", "SCL_SC_KERNEL", "SCL_SC_WAVES", "SCL_STAMP", "SCL_ABLATE",
-                                        "SCL_ALT_LANE", "SCL_ICP_REDUCE", "SCL_RCCL_MOCK"};
+    static const char *const names[] = {"SCL_SCREEN", "SCL_SCREEN_FORM", "SCL_SCREEN_V2_MIN", "SCL_RCCL_LIB",
+                                        // experiments: read by a diagnostics build only (kernels.hpp: scl_lab_int)
+                                        "SCL_SCREEN_VARIANT", "SCL_SCREEN_PROBE", "SCL_SCREEN_TAIL", "SCL_SCREEN_FUSE", "SCL_FUSE_PARTS", "SCL_ALIGN_FORM", "SCL_ALIGN_WGS",
+                                        "SCL_ALIGN2_WGS", "SCL_ALIGN_SIDE", "SCL_ALIGN_FILTER", "SCL_SC_KERNEL", "SCL_SC_WAVES", "SCL_STAMP", "SCL_ABLATE", "SCL_ALT_LANE",
+                                        "SCL_ICP_REDUCE", "SCL_MATRIX_PLAIN", "SCL_MATRIX_KERNEL", "SCL_MATRIX_KR", "SCL_WIDE_EXACT"};
+    constexpr int kProduct = 4;
+    int i = 0;
     for (const char *n : names) {
         const char *v = getenv(n);
-        if (v) fprintf(stderr, "scl_engine: environment override in effect: %s=%s\n", n, v);
+#ifdef SCL_DIAGNOSTICS
+        if (v) fprintf(stderr, "scl_engine (diagnostics build): environment override in effect: %s=%s\n", n, v);
+#else
+        if (v && i < kProduct) fprintf(stderr, "scl_engine: environment override in effect: %s=%s\n", n, v);
+        else if (v) fprintf(stderr, "scl_engine: %s=%s is an experiment's switch: ignored by this build (make EXTRA=-DSCL_DIAGNOSTICS builds them in)\n", n, v);
+#endif
+        ++i;
     }
+    (void)kProduct;
 }
 
 int scl_create(const scl_config *cfg, scl_engine **out)
@@ -503,7 +514,7 @@ int scl_create(const scl_config *cfg, scl_engine **out)
     if ((rc = dev_alloc(e, &e->a_topk_idx, (size_t)kTopkMaxK))) return bail(rc);
     if ((rc = dev_alloc(e, &e->a_topk_d2, (size_t)kTopkMaxK))) return bail(rc);
     if (hipStreamCreateWithFlags(&e->stream_alt, hipStreamNonBlocking) != hipSuccess) return bail(SCL_ERR_HIP);
-    { const char *env = getenv("SCL_ALT_LANE"); e->alt_lane = env && env[0] == '1'; }
+    e->alt_lane = scl_lab_int("SCL_ALT_LANE", 0) == 1;
     if (hipEventCreateWithFlags(&e->ev_db, hipEventDisableTiming) != hipSuccess) return bail(SCL_ERR_HIP);
     if ((rc = dev_alloc(e, &e->d_align_fallbacks, (size_t)1))) return bail(rc);
     if (hipMemset(e->d_align_fallbacks, 0, sizeof(unsigned long long)) != hipSuccess) return bail(SCL_ERR_HIP);
@@ -909,7 +920,7 @@ int scl_sc_distance_matrix(scl_engine *e, const int *queries, int nq, int lo, in
         slots[(size_t)i] = q >= 0 ? q : e->cap + (-1 - q);
     }
     // the screened grids: alignment + screening of 16 rows at a time, then the exact evaluation of the shifts still open (sc_masked.hip)
-    if (e->screen && sc_masked_supported(db_view(e), e->SR) && !getenv("SCL_MATRIX_PLAIN")) return matrix_screened_locked(e, slots.data(), nq, lo, n, dist, shift);
+    if (e->screen && sc_masked_supported(db_view(e), e->SR) && !scl_lab_int("SCL_MATRIX_PLAIN", 0)) return matrix_screened_locked(e, slots.data(), nq, lo, n, dist, shift);
     constexpr int RB = kMaxQueryBatch;                                     // rows per launch
     const size_t row = ((size_t)n + 63) & ~(size_t)63;
     if (e->mat_cap < row) {
@@ -1066,6 +1077,16 @@ int launch_survivor_pass_wide(scl_engine *e, const int *qslot, const int *lo, co
     return SCL_OK;
 }
 
+// experiments (diagnostics builds only): SCL_MATRIX_KERNEL=masked keeps round 3's one-wave-per-pair kernel, SCL_MATRIX_KR = keyframes per workgroup
+static bool matrix_masked_kernel()
+{
+    return scl_lab_is("SCL_MATRIX_KERNEL", "m");
+}
+static int matrix_kr()
+{
+    return scl_lab_int("SCL_MATRIX_KR", 0);
+}
+
 // The exact distance matrix on a screened grid.  Per group of up to `mb` rows (a screening launch's worth): alignment, screening
 // products and finishing -- which leaves, per pair, the first shift and the mask of the shifts within 2 eps of the pair's smallest
 // screened distance -- then sc_masked_kernel evaluates exactly those shifts in fp64.  Every entry is the reference's distance and
@@ -1116,7 +1137,6 @@ int matrix_screened_locked(scl_engine *e, const int *slots, int nq, int lo, int 
     };
     for (int g = 0; g < groups; ++g) {
         const int h = g & 1, r0 = g * mb, rows = nq - r0 < mb ? nq - r0 : mb;
-        if (g >= 2 && (rc = deliver(g - 2))) return rc;
         int qs[kMaxScreenBatch], los[kMaxScreenBatch], ns[kMaxScreenBatch];
         const int padded = rows < v2_min ? v2_min : rows;                   // (the padding rows repeat the last one; their results are dropped)
         for (int j = 0; j < padded; ++j) { qs[j] = slots[r0 + (j < rows ? j : rows - 1)]; los[j] = lo; ns[j] = n; }
@@ -1134,9 +1154,14 @@ int matrix_screened_locked(scl_engine *e, const int *slots, int nq, int lo, int 
                 mq[j].starts = e->d_starts + (size_t)j * e->set_stride; mq[j].smask = e->d_smask + (size_t)j * e->set_stride;
                 mq[j].out_dist = e->d_mat_dist + ((size_t)h * RB + j) * cap; mq[j].out_shift = e->d_mat_shift + ((size_t)h * RB + j) * cap;
             }
-            int parts = 2 * e->num_cu / rows; parts = parts < 1 ? 1 : parts;
-            const int max_parts = (n + 7) / 8; parts = parts > max_parts ? max_parts : parts;
-            SCL_HIP(e, launch_sc_masked(db_view(e), e->SR, mq, rows, parts, e->stream));
+            if (sc_matrix_supported(db_view(e), e->SR) && !matrix_masked_kernel()) {
+                SCL_HIP(e, launch_sc_matrix(db_view(e), e->SR, qs, rows, lo, n, e->d_starts, e->d_smask, e->set_stride,
+                                            e->d_mat_dist + (size_t)h * RB * cap, e->d_mat_shift + (size_t)h * RB * cap, cap, matrix_kr(), e->stream));
+            } else {
+                int parts = 2 * e->num_cu / rows; parts = parts < 1 ? 1 : parts;
+                const int max_parts = (n + 7) / 8; parts = parts > max_parts ? max_parts : parts;
+                SCL_HIP(e, launch_sc_masked(db_view(e), e->SR, mq, rows, parts, e->stream));
+            }
             if (ps.active()) e->prof.sc_distance_pairs += (uint64_t)rows * (uint64_t)n;
         }
         SCL_HIP(e, hipEventRecord(e->ev_mat_k[h], e->stream));
@@ -1144,9 +1169,11 @@ int matrix_screened_locked(scl_engine *e, const int *slots, int nq, int lo, int 
         SCL_HIP(e, hipMemcpyAsync(h_dist + (size_t)h * RB * cap, e->d_mat_dist + (size_t)h * RB * cap, sizeof(double) * (size_t)rows * cap, hipMemcpyDeviceToHost, e->stream2));
         SCL_HIP(e, hipMemcpyAsync(h_shift + (size_t)h * RB * cap, e->d_mat_shift + (size_t)h * RB * cap, sizeof(int) * (size_t)rows * cap, hipMemcpyDeviceToHost, e->stream2));
         SCL_HIP(e, hipEventRecord(e->ev_mat_c[h], e->stream2));
+        // group g is enqueued: hand over group g - 1 now (its copy ends while g runs; the half it leaves is g + 1's) -- only the last
+        // group's copy and hand-over are left behind the last kernel
+        if (g >= 1 && (rc = deliver(g - 1))) return rc;
     }
-    for (int g = groups >= 2 ? groups - 2 : 0; g < groups; ++g)
-        if ((rc = deliver(g))) return rc;
+    if ((rc = deliver(groups - 1))) return rc;
     if (e->prof_on) collect_profile(e);
     return SCL_OK;
 }

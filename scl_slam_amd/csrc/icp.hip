@@ -1861,7 +1861,7 @@ static size_t part_bytes(int n_src)
 }
 static bool use_mfma_reduce()
 {
-    static const bool v = [] { const char *e = getenv("SCL_ICP_REDUCE"); return !(e && e[0] == 'v'); }();   // SCL_ICP_REDUCE=valu
+    static const bool v = !scl_lab_is("SCL_ICP_REDUCE", "v");   // SCL_ICP_REDUCE=valu
     return v;
 }
 

@@ -4,7 +4,23 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 namespace scl {
+
+// ---- switches of experiments ---------------------------------------------------------------------------------------------------
+// A product build (plain `make`) reads three environment variables, all of which select shipped, tested paths: SCL_SCREEN (0: the
+// exact kernel on every pair), SCL_SCREEN_FORM (1: the products' first form on every batch), SCL_SCREEN_V2_MIN (smallest batch the
+// second form scores) -- plus SCL_RCCL_LIB (which collective library the sharded front loads).  Every other SCL_* switch selects a
+// measured alternative or an ablation and exists only in a diagnostics build (make EXTRA=-DSCL_DIAGNOSTICS): here it is its default,
+// a constant, and the code it would select is not compiled in.
+#ifdef SCL_DIAGNOSTICS
+inline int scl_lab_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+inline bool scl_lab_is(const char *name, const char *value) { const char *e = getenv(name); if (!e) return false; while (*value) if (*e++ != *value++) return false; return true; }
+#else
+constexpr int scl_lab_int(const char *, int dflt) { return dflt; }
+constexpr bool scl_lab_is(const char *, const char *) { return false; }
+#endif
 
 constexpr double kBigDist = 10000000.0;   // D.h:1494,1556,1637,1705 initial minima
 constexpr int hdesc_sector(int RG) { return ((RG * 8 + 63) / 64) * 8; }   // 8-byte elements per sector of hdesc: ring groups padded to whole 64-byte k-steps
@@ -117,6 +133,12 @@ struct MaskedQuery {
     double *out_dist; int *out_shift;
 };
 struct MaskedArgs { const float4 *desc; const double *norm; int nq, parts; MaskedQuery q[kMaxMaskedQueries]; };
+// ---- the exact distance MATRIX on the screened grids (sc_matrix.hip): scans qslots[0 .. nq) against the keyframes [lo, lo + n), every pair at
+// the shifts its mask leaves open.  starts / smask of scan i at i * set_stride + position in the range, results of row i at i * row_stride +
+// position.  kr: keyframes per workgroup (0: the default).
+bool sc_matrix_supported(const struct DbView &db, int SR);
+hipError_t launch_sc_matrix(const struct DbView &db, int SR, const int *qslots, int nq, int lo, int n, const int *starts, const unsigned int *smask,
+                            size_t set_stride, double *out_dist, int *out_shift, size_t row_stride, int kr, hipStream_t stream);
 bool sc_masked_supported(const struct DbView &db, int SR);
 hipError_t launch_sc_masked(const struct DbView &db, int SR, const MaskedQuery *queries, int nq, int parts, hipStream_t stream);
 // ---- screening pass of the full-DB mode (sc_screen.hip; 64x120 grid) --------------------------------------------

@@ -1066,7 +1066,7 @@ hipError_t launch_wave(const ScBatchArgs &batch_in, int num_cu, hipStream_t stre
     int waves = (int)((lds_cap - fixed - 16) / per_wave);
     if (waves > MAXT / kWave) waves = MAXT / kWave;
 #ifdef SCL_DIAGNOSTICS
-    static const int wave_cap = [] { const char *e = getenv("SCL_SC_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1 << 20; }();
+    static const int wave_cap = [] { const int v = scl_lab_int("SCL_SC_WAVES", 0); return v > 0 ? v : 1 << 20; }();
     if (waves > wave_cap) waves = wave_cap;               // diagnostic: fewer waves per CU
 #endif
     if (waves < 1) return hipErrorInvalidValue;
@@ -1322,7 +1322,7 @@ hipError_t launch_fast(const ScArgs &args_in, int num_cu, hipStream_t stream)
 int ablate_flags()
 {
 #ifdef SCL_DIAGNOSTICS
-    static const int f = [] { const char *e = getenv("SCL_ABLATE"); return e ? atoi(e) : 0; }();
+    static const int f = scl_lab_int("SCL_ABLATE", 0);
     return f;
 #else
     return 0;
@@ -1331,7 +1331,7 @@ int ablate_flags()
 
 int align_filter_enabled()
 {
-    static const int on = [] { const char *e = getenv("SCL_ALIGN_FILTER"); return (e && e[0] == '0') ? 0 : 1; }();
+    static const int on = scl_lab_int("SCL_ALIGN_FILTER", 1) != 0 ? 1 : 0;
     return on;
 }
 
@@ -1354,7 +1354,7 @@ hipError_t launch_sc_distance(const DbView &db, const QueryView &q, const int *c
     a.topk_k = 0; a.exclude_eps = 0.0f;
     a.out_dist = out_dist; a.out_shift = out_shift;
     const int W = 2 * SR + 1;
-    static const bool force_v1 = [] { const char *e = getenv("SCL_SC_KERNEL"); return e && e[0] == 'v' && e[1] == '1'; }();
+    static const bool force_v1 = scl_lab_is("SCL_SC_KERNEL", "v1");
     const bool wave_ok = !force_v1;
     const bool wave_grid = wave_ok && ((db.RG == 5 && W == 7 && db.S == 60) || (db.RG == 16 && W == 13 && db.S == 120)) && (db.R % 4 == 0);
     if (wave_grid && out_ring_d2) {
@@ -1368,8 +1368,8 @@ hipError_t launch_sc_distance(const DbView &db, const QueryView &q, const int *c
     one.q[0] = a; one.nq = 1; one.nb = 0;
     if (wave_ok && db.RG == 5 && W == 7 && db.S == 60)   return launch_wave<5, 7, 5, 60>(one, num_cu, stream);
 #ifdef SCL_DIAGNOSTICS
-    static const bool stamp = [] { const char *e = getenv("SCL_STAMP"); return e && e[0] == '1'; }();
-    static const int occ = [] { const char *e = getenv("SCL_SC_WAVES"); return e ? atoi(e) : 8; }();
+    static const bool stamp = scl_lab_int("SCL_STAMP", 0) == 1;
+    static const int occ = scl_lab_int("SCL_SC_WAVES", 8);
 #else
     constexpr bool stamp = false;
     constexpr int occ = 8;
@@ -1427,7 +1427,7 @@ hipError_t launch_sc_distance_matrix(const DbView &db, const int *slots, int nq,
     if (nq < 1 || nq > kMaxQueryBatch || n <= 0) return hipErrorInvalidValue;
     const int W = 2 * SR + 1;
     const bool wave_grid = ((db.RG == 5 && W == 7 && db.S == 60) || (db.RG == 16 && W == 13 && db.S == 120)) && (db.R % 4 == 0);
-    static const bool force_v1 = [] { const char *e = getenv("SCL_SC_KERNEL"); return e && e[0] == 'v' && e[1] == '1'; }();
+    static const bool force_v1 = scl_lab_is("SCL_SC_KERNEL", "v1");
     if (!wave_grid || force_v1) {
         for (int i = 0; i < nq; ++i) {
             QueryView q{};
@@ -1527,7 +1527,7 @@ hipError_t launch_sc_distance_survivors_wide(const DbView &db, int nq, const int
     // The wave program of this grid (sc_masked.hip): every survivor's exact distance at the shifts its screening left open, the
     // first shift taken from the screening's alignment -- instead of the one-sector-per-lane program below, whose workgroups each
     // staged 126 KB of fp64 scan and re-aligned every pair (SCL_WIDE_EXACT=0 keeps it)
-    static const bool use_masked = [] { const char *e = getenv("SCL_WIDE_EXACT"); return !(e && e[0] == '0'); }();
+    static const bool use_masked = scl_lab_int("SCL_WIDE_EXACT", 1) != 0;
     if (use_masked && starts && smask && sc_masked_supported(db, SR)) {
         MaskedQuery mq[kMaxMaskedQueries];
         static_assert(kWideExactBatch <= kMaxMaskedQueries, "one masked launch per exact batch");
@@ -1585,8 +1585,7 @@ int sc_align_filter_enabled() { return align_filter_enabled(); }
 bool sc_distance_fuses_ring(const DbView &db, int SR)
 {
     const int W = 2 * SR + 1;
-    const char *e = getenv("SCL_SC_KERNEL");
-    if (e && e[0] == 'v' && e[1] == '1') return false;
+    if (scl_lab_is("SCL_SC_KERNEL", "v1")) return false;
     return ((db.RG == 5 && W == 7 && db.S == 60) || (db.RG == 16 && W == 13 && db.S == 120)) && (db.R % 4 == 0);
 }
 

@@ -1819,6 +1819,11 @@ static bool screen_second_form()
     static const int form = [] { const char *e = getenv("SCL_SCREEN_FORM"); return e ? atoi(e) : 2; }();
     return form != 1;
 }
+static int screen_v2_min_env()
+{   // SCL_SCREEN_V2_MIN: the smallest batch the second form scores (0 / unset: the grid's own; tests: 1 = always the second form)
+    static const int v = [] { const char *e = getenv("SCL_SCREEN_V2_MIN"); return e ? atoi(e) : 0; }();
+    return v;
+}
 int sc_screen_max_batch(const DbView &db, int SR)
 {
     return (sc_screen_is_wide(db, SR) && screen_second_form()) ? S2Cfg<20, 180, 19>::NQ : kMaxScreenBatch;
@@ -1861,12 +1866,12 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
     int dev_ = 0; (void)hipGetDevice(&dev_);
     std::atomic<bool> &attr_set = attr_set_dev[dev_ & 63];
     // variants (SCL_SCREEN_VARIANT): 0 = 15 k-steps in flight; 1 = the other register budget; 2 = 5 k-steps in flight
-    static const int variant = [] { const char *e = getenv("SCL_SCREEN_VARIANT"); return e ? atoi(e) : 0; }();
+    static const int variant = scl_lab_int("SCL_SCREEN_VARIANT", 0);
     void (*kern)(ScreenFusedArgs) = sc_screen_kernel<RG, S, W, 15, OCC0>;
+#ifdef SCL_DIAGNOSTICS
     if (variant == 1) kern = sc_screen_kernel<RG, S, W, 15, OCC1>;
     if (variant == 2) kern = sc_screen_kernel<RG, S, W, 5, OCC0>;
-#ifdef SCL_DIAGNOSTICS
-    static const int probe = [] { const char *e = getenv("SCL_SCREEN_PROBE"); return e ? atoi(e) : 0; }();
+    static const int probe = scl_lab_int("SCL_SCREEN_PROBE", 0);
     if (probe == 2) kern = sc_screen_kernel<RG, S, W, 15, OCC0, 2>;
 #else
     const int probe = 0;
@@ -1877,14 +1882,12 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
     const size_t lds1 = (size_t)QSX * (RGH * 8 + 32) + (size_t)S * MW * 16 + (size_t)kScreenWaves * kGroup * kTileStride +
                         (size_t)(2 * kScreenWaves * MT) * kWave * 16;
     if (!attr_set.load(std::memory_order_acquire)) {
-        for (auto k : {(void (*)(ScreenFusedArgs))sc_screen_kernel<RG, S, W, 15, OCC0>, (void (*)(ScreenFusedArgs))sc_screen_kernel<RG, S, W, 15, OCC1>,
-                       (void (*)(ScreenFusedArgs))sc_screen_kernel<RG, S, W, 5, OCC0>}) {
-            hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            if (e != hipSuccess) return e;
-        }
-        hipError_t e = hipFuncSetAttribute((const void *)sc_align_kernel<RG, S, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void *)sc_screen_kernel<RG, S, W, 15, OCC0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)sc_align_kernel<RG, S, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (e != hipSuccess) return e;
 #ifdef SCL_DIAGNOSTICS
+        (void)hipFuncSetAttribute((const void *)sc_screen_kernel<RG, S, W, 15, OCC1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipFuncSetAttribute((const void *)sc_screen_kernel<RG, S, W, 5, OCC0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         (void)hipFuncSetAttribute((const void *)sc_screen_kernel<RG, S, W, 15, OCC0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
 #endif
         attr_set.store(true, std::memory_order_release);
@@ -1893,7 +1896,7 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
     // batch (measured beside the products: 128 per query for four queries on 256 CUs is the best point; 136 and more cost 5 %)
     auto align_blocks = [&](int groups, int nq, bool beside_products) {
         int b = (groups + kScreenWaves - 1) / kScreenWaves;
-        static const int cap_env = [] { const char *e = getenv("SCL_ALIGN_WGS"); return e ? atoi(e) : 0; }();
+        static const int cap_env = scl_lab_int("SCL_ALIGN_WGS", 0);
         int cap = cap_env > 0 ? cap_env : (beside_products ? 2 * num_cu / (nq > 0 ? nq : 1) : num_cu);   // on its own: one wave per group
         if (cap < 1) cap = 1;
         return b > cap ? cap : b;
@@ -1905,7 +1908,7 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
     // (one on 80 x 180) -- blocking single-scan calls, short remainders -- take the first form.  A batch's alignment is
     // launched by the batch in front of it and leaves the ring-key metric to the second form's finishing kernel, so the
     // decision is made per batch from its own size.
-    static const int v2_min = [] { const char *e = getenv("SCL_SCREEN_V2_MIN"); return e ? atoi(e) : (S <= 128 ? 4 : 2); }();   // (tests: 1 = always the second form)
+    const int v2_min = screen_v2_min_env() > 0 ? screen_v2_min_env() : (S <= 128 ? 4 : 2);
     auto second_form_for = [&](const ScreenBatch &b) {
         return screen_second_form() && b.part && probe == 0 && variant == 0 && b.nq >= v2_min && b.nq <= S2Cfg<RG, S, W>::NQ;
     };
@@ -1913,7 +1916,7 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
     const bool next_v2 = next && second_form_for(*next);
     ab.skip_d2 = use_v2 ? 1 : 0;
     // SCL_ALIGN_FORM=1 keeps the alignment's first form (one scan against 16 keyframes per tile, inline fp32 / fp64 fallbacks)
-    static const int align_form_env = [] { const char *e = getenv("SCL_ALIGN_FORM"); return e ? atoi(e) : 2; }();
+    static const int align_form_env = scl_lab_int("SCL_ALIGN_FORM", 2);
     const bool align2 = align_form_env != 1 && db.halign != nullptr && halign_bytes(S) > 0;
     constexpr size_t lds_a2 = (size_t)kScreenWaves * Align2Cfg<S>::LDS_WAVE;
     auto union_of = [](const ScreenBatch &b, int *lo_out, int *n_out) {
@@ -1923,7 +1926,7 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
     };
     // workgroups of the alignment's second form: a wave per keyframe, several keyframes per wave (the next one's image in flight)
     auto align2_blocks = [&](int u_n) {
-        static const int env = [] { const char *e = getenv("SCL_ALIGN2_WGS"); return e ? atoi(e) : 0; }();
+        static const int env = scl_lab_int("SCL_ALIGN2_WGS", 0);
         int b = (u_n + kScreenWaves * 3 - 1) / (kScreenWaves * 3);
         const int cap = env > 0 ? env : 2 * num_cu;
         b = b > cap ? cap : b;
@@ -1931,7 +1934,7 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
     };
     // SCL_SCREEN_FUSE=1 (experiment; measured slower): the next batch's alignment and the previous batch's
     // finishing in extra waves inside the products' launch instead of a launch of their own behind it (sc_screen2_tail2_kernel)
-    static const int fuse_env = [] { const char *e = getenv("SCL_SCREEN_FUSE"); return e ? atoi(e) : 0; }();
+    static const int fuse_env = scl_lab_int("SCL_SCREEN_FUSE", 0);
     const bool fuse = fuse_env != 0 && align2;
     if (phases & kScreenFinish) {                                // this batch's finishing alone (the end of a sequence of deferred ones)
         if (!use_v2) return hipErrorInvalidValue;
@@ -1959,8 +1962,10 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
             static std::atomic<bool> attr2_dev[64];
             std::atomic<bool> &attr2 = attr2_dev[dev_ & 63];
             if (!attr2.load(std::memory_order_acquire)) {
-                hipError_t e = hipFuncSetAttribute((const void *)sc_screen2_kernel<RG, S, W, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(s2_lds_total<RG, S, W, true>()));
-                if (e == hipSuccess) e = hipFuncSetAttribute((const void *)sc_screen2_kernel<RG, S, W, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(s2_lds_total<RG, S, W, false>()));
+                hipError_t e = hipFuncSetAttribute((const void *)sc_screen2_kernel<RG, S, W, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(s2_lds_total<RG, S, W, false>()));
+#ifdef SCL_DIAGNOSTICS
+                if (e == hipSuccess) e = hipFuncSetAttribute((const void *)sc_screen2_kernel<RG, S, W, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(s2_lds_total<RG, S, W, true>()));
+#endif
                 if (e != hipSuccess) return e;
                 attr2.store(true, std::memory_order_release);
             }
@@ -1977,7 +1982,7 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
             // kernel; 1: on the low-priority side stream from the end of this batch's products, beside the finishing kernel; 2: from
             // the start of the products.  Measured: 1.45 G pairs/s in line, 0.51 G (1) and 0.67 G (2) -- the two event hops between
             // the queues per launch cost more than the alignment itself.
-            static const int side_env = [] { const char *e = getenv("SCL_ALIGN_SIDE"); return e ? atoi(e) : 0; }();
+            static const int side_env = scl_lab_int("SCL_ALIGN_SIDE", 0);
             const int side = (next && sb.side) ? side_env : 0;
             hipError_t e = hipSuccess;
             auto launch_align = [&](hipStream_t as) -> hipError_t {
@@ -2013,7 +2018,7 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
 
             // what the extra waves of this launch carry: the next batch's alignment, the previous batch's finishing
             Screen2Extra xa{};
-            static const int parts_env = [] { const char *e = getenv("SCL_FUSE_PARTS"); return e ? atoi(e) : 3; }();   // experiments: 1 = only the alignment rides, 2 = only the finishing
+            static const int parts_env = scl_lab_int("SCL_FUSE_PARTS", 3);   // experiments: 1 = only the alignment rides, 2 = only the finishing
             const bool ride_align = fuse && side == 0 && next && next_v2 && (parts_env & 1);
             if (ride_align) {
                 if (next->nq < 1 || next->nq > kMaxScreenBatch) return hipErrorInvalidValue;
@@ -2030,8 +2035,11 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
                 xa.prev.part = prev->part;
                 xa.f_nb64 = (pmax + kWave - 1) / kWave;
             }
+#ifdef SCL_DIAGNOSTICS
             if (fuse) hipLaunchKernelGGL((sc_screen2_kernel<RG, S, W, true>), dim3(nwg), dim3(s2_waves<RG, S, W, true>() * kWave), (s2_lds_total<RG, S, W, true>()), stream, f2, xa);
-            else hipLaunchKernelGGL((sc_screen2_kernel<RG, S, W, false>), dim3(nwg), dim3(s2_waves<RG, S, W, false>() * kWave), (s2_lds_total<RG, S, W, false>()), stream, f2, xa);
+            else
+#endif
+            hipLaunchKernelGGL((sc_screen2_kernel<RG, S, W, false>), dim3(nwg), dim3(s2_waves<RG, S, W, false>() * kWave), (s2_lds_total<RG, S, W, false>()), stream, f2, xa);
             if ((e = hipGetLastError()) != hipSuccess) return e;
             if (fuse && side == 0) {
                 // this batch's finishing: deferred to the next launch's extra waves (the caller passes this batch as its `prev`, or
@@ -2045,7 +2053,7 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
             }
             if (prev || (phases & kScreenDeferFinish)) return hipErrorInvalidValue;
             if (side == 1 && (e = fork()) != hipSuccess) return e;
-            static const int tail_env = [] { const char *e = getenv("SCL_SCREEN_TAIL"); return e ? atoi(e) : 1; }();   // 0: finish and alignment as two launches
+            static const int tail_env = scl_lab_int("SCL_SCREEN_TAIL", 1);   // 0: finish and alignment as two launches
             if (next && side == 0 && tail_env) {
                 if (next->nq < 1 || next->nq > kMaxScreenBatch) return hipErrorInvalidValue;
                 ScreenBatchArgs nb{};
@@ -2119,17 +2127,16 @@ hipError_t launch_sc_screen_batch(const DbView &db, const ScreenBatch &sb, int S
 // Can a batch of nq scans have its finishing deferred (second form of the products, extra waves available)?
 bool sc_screen_can_defer(const DbView &db, int SR, int nq)
 {
-    static const int fuse_env = [] { const char *e = getenv("SCL_SCREEN_FUSE"); return e ? atoi(e) : 0; }();
-    static const int align_form_env = [] { const char *e = getenv("SCL_ALIGN_FORM"); return e ? atoi(e) : 2; }();
-    static const int side_env = [] { const char *e = getenv("SCL_ALIGN_SIDE"); return e ? atoi(e) : 0; }();
-    static const int variant = [] { const char *e = getenv("SCL_SCREEN_VARIANT"); return e ? atoi(e) : 0; }();
-    static const int probe = [] { const char *e = getenv("SCL_SCREEN_PROBE"); return e ? atoi(e) : 0; }();
-    static const int parts_env = [] { const char *e = getenv("SCL_FUSE_PARTS"); return e ? atoi(e) : 3; }();
+    static const int fuse_env = scl_lab_int("SCL_SCREEN_FUSE", 0);
+    static const int align_form_env = scl_lab_int("SCL_ALIGN_FORM", 2);
+    static const int side_env = scl_lab_int("SCL_ALIGN_SIDE", 0);
+    static const int variant = scl_lab_int("SCL_SCREEN_VARIANT", 0);
+    static const int probe = scl_lab_int("SCL_SCREEN_PROBE", 0);
+    static const int parts_env = scl_lab_int("SCL_FUSE_PARTS", 3);
     if (!(parts_env & 2)) return false;
     if (!fuse_env || align_form_env == 1 || side_env != 0 || variant != 0 || probe != 0 || !screen_second_form() || !db.halign || !sc_screen_supported(db, SR)) return false;
     const bool wide = sc_screen_is_wide(db, SR);
-    static const int v2_env = [] { const char *e = getenv("SCL_SCREEN_V2_MIN"); return e ? atoi(e) : 0; }();
-    const int v2_min = v2_env > 0 ? v2_env : (wide ? 2 : 4);
+    const int v2_min = screen_v2_min_env() > 0 ? screen_v2_min_env() : (wide ? 2 : 4);
     return nq >= v2_min && nq <= sc_screen_max_batch(db, SR);
 }
 

@@ -69,6 +69,7 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
+    bool shared_devices_ok = false;                        // the library says it can run several ranks on one device (RCCL cannot; the tests' stand-in can)
 };
 
 Rccl *rccl()
@@ -76,11 +77,19 @@ Rccl *rccl()
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (r.lib) break;
+        // SCL_RCCL_LIB: the collective library to load instead of the system's librccl (a newer build of it -- or the stand-in the tests
+        // link, tests/cpp/mock_rccl.cpp, which forms the ranks' element-wise minimum on the host so that the G > 1 control flow of the
+        // exchange runs on a one-GPU box).  If it is set and cannot be loaded there is no fallback.
+        if (const char *path = getenv("SCL_RCCL_LIB")) {
+            r.lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        } else {
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (r.lib) break;
+            }
         }
         if (!r.lib) return;
+        r.shared_devices_ok = dlsym(r.lib, "scl_collective_allows_shared_devices") != nullptr;
         r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(r.lib, "ncclCommInitAll"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
         r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
@@ -92,62 +101,6 @@ Rccl *rccl()
     return &r;
 }
 
-// Stand-in collective for tests (exchange = 3): the same function table, so the front runs the very control flow of the RCCL
-// exchange -- pack kernels, grouped all-reduce, select kernels, second all-reduce, one D2H -- with G > 1 ranks on boxes where
-// RCCL cannot (it refuses two ranks on one device, and a one-GPU box has only one).  A group's all-reduces are recorded
-// between GroupStart and GroupEnd; GroupEnd waits for every rank's stream, forms the element-wise minimum of the ranks'
-// input buffers on the host and writes it to every rank's output buffer.  Not a product path: nothing selects it but
-// scl_create_sharded(..., exchange = 3).
-struct MockComm { int rank, size; };
-struct MockOp { const void *in; void *out; size_t count; MockComm *comm; hipStream_t stream; };
-thread_local std::vector<MockOp> g_mock_ops;
-thread_local bool g_mock_open = false;
-
-ncclResult_t mock_comm_init_all(ncclComm_t *comms, int n, const int *)
-{
-    for (int c = 0; c < n; ++c) comms[c] = reinterpret_cast<ncclComm_t>(new MockComm{c, n});
-    return ncclSuccess;
-}
-ncclResult_t mock_comm_destroy(ncclComm_t c) { delete reinterpret_cast<MockComm *>(c); return ncclSuccess; }
-ncclResult_t mock_group_start() { g_mock_ops.clear(); g_mock_open = true; return ncclSuccess; }
-ncclResult_t mock_all_reduce(const void *in, void *out, size_t count, ncclDataType_t dt, ncclRedOp_t op, ncclComm_t comm, hipStream_t stream)
-{
-    if (!g_mock_open || dt != ncclUint64 || op != ncclMin) return ncclInvalidArgument;
-    g_mock_ops.push_back(MockOp{in, out, count, reinterpret_cast<MockComm *>(comm), stream});
-    return ncclSuccess;
-}
-ncclResult_t mock_group_end()
-{
-    g_mock_open = false;
-    if (g_mock_ops.empty()) return ncclSuccess;
-    const size_t count = g_mock_ops[0].count;
-    const int size = g_mock_ops[0].comm->size;
-    if ((int)g_mock_ops.size() != size) return ncclInvalidUsage;                 // every rank takes part exactly once
-    std::vector<unsigned long long> acc(count, ~0ull), tmp(count);
-    std::vector<char> seen((size_t)size, 0);
-    for (const MockOp &o : g_mock_ops) {
-        if (o.count != count || o.comm->size != size || seen[(size_t)o.comm->rank]) return ncclInvalidUsage;
-        seen[(size_t)o.comm->rank] = 1;
-        if (hipStreamSynchronize(o.stream) != hipSuccess) return ncclUnhandledCudaError;
-        if (hipMemcpy(tmp.data(), o.in, count * 8, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
-        for (size_t i = 0; i < count; ++i) acc[i] = tmp[i] < acc[i] ? tmp[i] : acc[i];
-    }
-    for (const MockOp &o : g_mock_ops)
-        if (hipMemcpy(o.out, acc.data(), count * 8, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
-    g_mock_ops.clear();
-    return ncclSuccess;
-}
-
-Rccl *mock_rccl()
-{
-    static Rccl m = [] {
-        Rccl t;
-        t.CommInitAll = mock_comm_init_all; t.CommDestroy = mock_comm_destroy; t.AllReduce = mock_all_reduce;
-        t.GroupStart = mock_group_start; t.GroupEnd = mock_group_end; t.ok = true;
-        return t;
-    }();
-    return &m;
-}
 #endif
 
 // ---- device side of the RCCL exchange ---------------------------------------------------------------------------
@@ -210,10 +163,10 @@ struct ShardedFront {
     int last_pass = -1;
 
     // device-side exchange (exchange == 2)
-    int exchange = 1;                                      // 1 host merge, 2 RCCL min all-reduce on packed keys, 3 the same through the tests' stand-in collective
+    int exchange = 1;                                      // 1 host merge, 2 RCCL min all-reduce on packed keys
 #ifdef SCL_HAVE_RCCL_HEADER
     ncclComm_t comm[kMaxShards] = {nullptr};
-    Rccl *coll = nullptr;                                  // the collective's function table: librccl, or the stand-in (exchange == 3)
+    Rccl *coll = nullptr;                                  // the collective's function table (librccl, or what SCL_RCCL_LIB names)
 #endif
     unsigned long long *d_key[kMaxShards] = {nullptr};     // per shard: kFrontSlots groups x {key1, key2, min1, min2}[kMaxQueryBatch]
     unsigned long long *h_keys = nullptr;                  // pinned: kFrontSlots groups x {min1, min2}[kMaxQueryBatch]
@@ -360,7 +313,7 @@ using namespace scl;
 
 extern "C" int scl_create_sharded(const scl_config *cfg, const int *devices, int n_devices, int exchange, scl_engine **out)
 {
-    if (!cfg || !devices || !out || n_devices < 1 || n_devices > kMaxShards || exchange < 0 || exchange > 3) return SCL_ERR_INVALID_ARG;
+    if (!cfg || !devices || !out || n_devices < 1 || n_devices > kMaxShards || exchange < 0 || exchange > 2) return SCL_ERR_INVALID_ARG;
     *out = nullptr;
     scl_engine *e = new (std::nothrow) scl_engine();
     ShardedFront *f = new (std::nothrow) ShardedFront();
@@ -384,14 +337,13 @@ extern "C" int scl_create_sharded(const scl_config *cfg, const int *devices, int
     }
     f->mirror_on = n_devices > 1;
     // the exchange of full-DB winners: 0 = RCCL when it can be had (more than one shard, every shard on its own
-    // device), else the host merge; 1 = host merge; 2 = RCCL or fail; 3 = the RCCL control flow through the tests' stand-in
-    // collective (any device list)
+    // device), else the host merge; 1 = host merge; 2 = RCCL or fail
     f->exchange = 1;
     if (exchange >= 2 || (exchange == 0 && n_devices > 1 && distinct)) {
         int rc = SCL_ERR_UNSUPPORTED;
 #ifdef SCL_HAVE_RCCL_HEADER
-        Rccl *r = exchange == 3 ? mock_rccl() : rccl();
-        if (r->ok && (distinct || exchange == 3)) {
+        Rccl *r = rccl();
+        if (r->ok && (distinct || r->shared_devices_ok)) {
             const ncclResult_t nr = r->CommInitAll(f->comm, n_devices, f->dev);
             rc = nr == ncclSuccess ? SCL_OK : SCL_ERR_HIP;
             if (rc) for (auto &cm : f->comm) cm = nullptr;
@@ -408,7 +360,7 @@ extern "C" int scl_create_sharded(const scl_config *cfg, const int *devices, int
             for (int g = 0; g < kFrontSlots && rc == SCL_OK; ++g)
                 if (hipEventCreateWithFlags(&f->ev_group[g], hipEventDisableTiming) != hipSuccess) rc = SCL_ERR_HIP;
         }
-        if (rc == SCL_OK) f->exchange = exchange == 3 ? 3 : 2;
+        if (rc == SCL_OK) f->exchange = 2;
         else if (exchange >= 2) { front_destroy(e); return rc; }
     }
     *out = e;

@@ -187,10 +187,22 @@ def test_rccl_exchange_single_shard():
 def test_device_side_exchange_control_flow_with_several_ranks(G):
     """exchange = 2's control flow -- pack kernel per rank, grouped all-reduce(uint64, min) on the distance keys,
     select kernel, second all-reduce on (global index, shift), one D2H -- executed with G > 1 ranks.  RCCL refuses two ranks
-    on one device, so the collective itself is the tests' stand-in (exchange = 3: element-wise min of the ranks' buffers);
-    everything around it is the code a node runs.  Must equal the host merge (exchange = 1) and one unsharded database,
-    bit for bit -- duplicated keyframes on different shards (equal distances: the lowest GLOBAL index wins, which is what
-    the second reduction decides), ranges that leave some shards empty, a range with no candidate at all."""
+    on one device, so the collective library is the tests' stand-in (tests/cpp/libmock_rccl.so, loaded through SCL_RCCL_LIB:
+    element-wise min of the ranks' buffers on the host); everything around it is the product's code, unchanged.  The library is
+    chosen once per process, so the body runs in a child interpreter (`_exchange_control_flow_body`)."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    mock = os.path.join(here, "cpp", "libmock_rccl.so")
+    assert os.path.exists(mock), "make builds tests/cpp/libmock_rccl.so"
+    code = f"import sys; sys.path.insert(0, {here!r}); sys.path.insert(0, {os.path.dirname(here)!r}); import test_gpu_sharded as t; t._exchange_control_flow_body({G})"
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SCL_RCCL_LIB=mock), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def _exchange_control_flow_body(G):
+    """Must equal the host merge (exchange = 1) and one unsharded database, bit for bit -- duplicated keyframes on different
+    shards (equal distances: the lowest GLOBAL index wins, which is what the second reduction decides), ranges that leave some
+    shards empty, a range with no candidate at all."""
     R, S, n = 64, 120, 1800
     descs = synth_descriptors(n, R, S, seed=78, revisit_frac=0.05)
     rs = np.random.RandomState(4)
@@ -202,8 +214,8 @@ def test_device_side_exchange_control_flow_with_several_ranks(G):
         descs[q] = np.roll(descs[a], int(rs.randint(0, S)), axis=1)
     one = ScanContextEngine(num_ring=R, num_sector=S, initial_capacity=n)
     host = ScanContextEngine(num_ring=R, num_sector=S, initial_capacity=n, devices=[0] * G, exchange=1)
-    dev = ScanContextEngine(num_ring=R, num_sector=S, initial_capacity=n, devices=[0] * G, exchange=3)
-    assert dev.shard_info() == (G, 3) and host.shard_info() == (G, 1)
+    dev = ScanContextEngine(num_ring=R, num_sector=S, initial_capacity=n, devices=[0] * G, exchange=2)
+    assert dev.shard_info() == (G, 2) and host.shard_info() == (G, 1)
     for e in (one, host, dev):
         e.save_bulk(descs)
     for cur in list(range(n - 1, n - 41, -1)):
