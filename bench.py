@@ -477,16 +477,32 @@ def secondary_exact_all_pairs(eng, n_elig, n_query, queries=64):
 
 
 def secondary_blocking_scan(eng, n_elig, n_query, scans=300):
-    """one incoming scan, blocking: scl_detect_full_range call -> result on the host (ring-key top-k + screening + exact pass)"""
-    lat = []
-    for i in range(scans + 20):
-        t0 = time.perf_counter()
-        eng.detect_full_range(int(n_elig + i % n_query), 0, n_elig)
-        if i >= 20:
-            lat.append((time.perf_counter() - t0) * 1e6)
-    lat = np.array(lat)
-    return {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)), "mean": float(lat.mean()), "scans": scans,
-            "pairs_per_s_at_p50": n_elig / (float(np.percentile(lat, 50)) * 1e-6),
+    """SURVEY 8(d)'s headline shape and the reference's own call pattern (descriptor.h:1613-1674 from distributedMapping.h:1078): ONE
+    incoming scan, blocking -- scl_detect_full_range call -> result on the host.  Two launches: the products in their first form with
+    the workgroups aligning their own groups (fastAlignUsingVkey exactly + fp16 matrix-core screening of the 13 shifts: the database
+    streamed once), then one workgroup that lists the keyframes within the margin, scores them at their open shifts in fp64, forms the
+    ring-key top-k and writes the winner to pinned memory.  Also the reference-faithful call (ring-key top-3 -> 3 SC distances ->
+    threshold: scl_detect_intra), as the loop-closure thread makes it."""
+    def run(fn, reps):
+        lat = []
+        for i in range(reps + 20):
+            t0 = time.perf_counter()
+            fn(i)
+            if i >= 20:
+                lat.append((time.perf_counter() - t0) * 1e6)
+        return np.array(lat)
+    lat = run(lambda i: eng.detect_full_range(int(n_elig + i % n_query), 0, n_elig), scans)
+    li = run(lambda i: eng.detect_intra(int(n_elig + i % n_query)), scans)
+    p50 = float(np.percentile(lat, 50))
+    moved = n_elig * SINGLE_SCAN_BYTES_PER_PAIR                      # the fp16 copy, keys, ring key and mask of every keyframe, once
+    return {"p50": p50, "p99": float(np.percentile(lat, 99)), "mean": float(lat.mean()), "scans": scans,
+            "pairs_per_s_at_p50": n_elig / (p50 * 1e-6),
+            "roofline": {"bound": "hbm", "achieved": moved / (p50 * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": moved / (p50 * 1e-6) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": moved, "bytes_per_pair": SINGLE_SCAN_BYTES_PER_PAIR,
+                         "hbm_floor_us": moved / (HBM_PEAK_GBS * 1e9) * 1e6,
+                         "note": "wall clock of the blocking call (launch latency, two kernels, result pick-up) against the bytes one scan's pass streams"},
+            "detect_intra_us": {"p50": float(np.percentile(li, 50)), "p99": float(np.percentile(li, 99)),
+                                "note": "the reference-faithful call through the six virtuals: ring-key top-3, 3 exact SC distances, threshold (D.h:1613-1674)"},
             "note": "microseconds per blocking one-scan call over the whole database (no batch to share the database pass with)"}
 
 
@@ -535,11 +551,13 @@ def secondary_80x180(device, n=10000, steps=512):
     qs = (n_elig + (np.arange(steps) % N_EXCLUDE)).astype(np.int32)
     eng.detect_full_stream(qs[:8], 0, n_elig, 16, 2)
     eng.profile_reset(); eng.profile_enable(3)
+    eng.survivor_stats(reset=True)
     t0 = time.perf_counter()
     nn, sh, dd = eng.detect_full_stream(qs, 0, n_elig, 16, 2)
     dt = time.perf_counter() - t0
     eng.profile_enable(0)
     prof = eng.profile()
+    sv_q, sv_sum, sv_max = eng.survivor_stats()
     eng.close()
     survey_pair = R2 * S2 * 4 + S2 * 4 + S2 * 4                                 # 59 040 B at 80x180
     # what the launch group (products in their second form + finish + next alignment) reads per keyframe by design, once per
@@ -557,6 +575,7 @@ def secondary_80x180(device, n=10000, steps=512):
                         f"over the whole DB per scan, {steps} scans",
             "value": n_elig * steps / dt, "unit": "pairs/s", "ms_per_scan": dt / steps * 1e3,
             "kernel_ms": {"screening_launch_group": k_ms},
+            "survivors_per_scan": {"mean": sv_sum / max(1, sv_q), "max": sv_max, "scans": sv_q},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": per_launch, "scans_per_launch": k_scans,
                          "bytes_per_keyframe": bytes_kf, "bytes_per_pair_intermediates": bytes_pair_io, "survey_bytes_per_pair": survey_pair,

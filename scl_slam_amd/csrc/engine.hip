@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -15,6 +16,7 @@
 #include <new>
 #include <string>
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -176,7 +178,10 @@ int ensure_capacity(scl_engine *e, int need)
         SCL_HIP(e, hipMemcpyAsync(nhk + (size_t)e->hkw * ncap, e->d_hkey + (size_t)e->hkw * e->cap, sizeof(unsigned short) * e->hkw * k, hipMemcpyDeviceToDevice, e->stream));
     }
     SCL_HIP(e, hipStreamSynchronize(e->stream));
-    if (e->stream_alt) SCL_HIP(e, hipStreamSynchronize(e->stream_alt));   // passes still reading the old arrays
+    // passes still reading the old arrays: the exact pass of a stream's chunk on the side stream, the ring-key scan, the alternate lane
+    // (an append may now run between the chunks of a stream call: stream_screened_locked)
+    for (hipStream_t s2 : {e->stream_alt, e->stream_surv, e->stream_align, e->stream2})
+        if (s2) SCL_HIP(e, hipStreamSynchronize(s2));
     dev_free(e->d_desc); dev_free(e->d_vkey); dev_free(e->d_norm); dev_free(e->d_rkey); dev_free(e->d_rkey4);
     dev_free(e->d_hdesc); dev_free(e->d_kmask); dev_free(e->d_hkey); dev_free(e->d_halign);
     e->d_desc = nd; e->d_vkey = nv; e->d_norm = nn; e->d_rkey = nr; e->d_rkey4 = nr4;
@@ -233,8 +238,8 @@ int ensure_sets(scl_engine *e, size_t n)
     int rc = ensure_pairs(e, stride * scl_engine::kScreenSets);
     if (rc) { e->set_stride = 0; return rc; }
     e->set_stride = stride;
-    // the shift masks follow the sets: the wide grid's exact pass reads them always, the 64 x 120 grid once a distance matrix has asked
-    if ((sc_screen_is_wide(db_view(e), e->SR) || e->d_smask) && e->smask_cap < stride * scl_engine::kScreenSets) {
+    // the shift masks follow the sets (the exact passes evaluate the open shifts only: sc_masked.hip, sc_matrix.hip)
+    if (e->smask_cap < stride * scl_engine::kScreenSets) {
         dev_free(e->d_smask); e->d_smask = nullptr; e->smask_cap = 0;
         if ((rc = dev_alloc(e, &e->d_smask, stride * scl_engine::kScreenSets))) { e->set_stride = 0; return rc; }
         e->smask_cap = stride * scl_engine::kScreenSets;
@@ -689,6 +694,7 @@ int scl_stage_query(scl_engine *e, const float *values)
 {
     if (!e || !values) return SCL_ERR_INVALID_ARG;
     if (e->front) return front_stage_query(e, values);
+    std::lock_guard<std::mutex> pk(e->pass_mu);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     int rc;
@@ -710,6 +716,7 @@ int scl_detect_intra(scl_engine *e, int cur, int *loop_id, float *shift, double 
 {
     if (!e || !loop_id || !shift) return SCL_ERR_INVALID_ARG;
     if (e->front) return front_detect_intra(e, cur, loop_id, shift, dist);
+    std::lock_guard<std::mutex> pk(e->pass_mu);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     *loop_id = -1; *shift = 0.0f;                                         /* D.h:1615 */
@@ -743,6 +750,7 @@ int scl_detect_inter(scl_engine *e, int cur, int *loop_id, float *yaw_rad, doubl
 {
     if (!e || !loop_id || !yaw_rad) return SCL_ERR_INVALID_ARG;
     if (e->front) return front_detect_inter(e, cur, loop_id, yaw_rad, dist);
+    std::lock_guard<std::mutex> pk(e->pass_mu);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     *loop_id = -1; *yaw_rad = 0.0f;                                       /* D.h:1678,1686 */
@@ -857,6 +865,7 @@ int scl_ringkey_topk(scl_engine *e, int query, int lo, int hi, int k, int *idx, 
 {
     if (!e || !idx || !d2) return SCL_ERR_INVALID_ARG;
     if (e->front) return front_topk(e, query, lo, hi, k, idx, d2, nullptr, nullptr, found);
+    std::lock_guard<std::mutex> pk(e->pass_mu);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     return topk_with_distance_locked(e, query, lo, hi, k, e->cfg.knn_exclude_eps, idx, d2, nullptr, nullptr, found);
@@ -867,6 +876,7 @@ int scl_topk_with_distance(scl_engine *e, int query, int lo, int hi, int k,
 {
     if (!e || !idx || !d2 || !dist || !shift) return SCL_ERR_INVALID_ARG;
     if (e->front) return front_topk(e, query, lo, hi, k, idx, d2, dist, shift, found);
+    std::lock_guard<std::mutex> pk(e->pass_mu);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     return topk_with_distance_locked(e, query, lo, hi, k, e->cfg.knn_exclude_eps, idx, d2, dist, shift, found);
@@ -877,6 +887,7 @@ int scl_sc_distance_batch(scl_engine *e, int query, const int *cand, int n, doub
     if (!e || n < 0 || !dist || !shift) return SCL_ERR_INVALID_ARG;
     if (n == 0) return SCL_OK;
     if (e->front) return front_sc_distance_batch(e, query, cand, n, dist, shift);
+    std::lock_guard<std::mutex> pk(e->pass_mu);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     QueryView q;
@@ -907,6 +918,7 @@ int scl_sc_distance_matrix(scl_engine *e, const int *queries, int nq, int lo, in
     if (!e || nq < 0 || (nq > 0 && (!queries || !dist || !shift))) return SCL_ERR_INVALID_ARG;
     if (nq == 0) return SCL_OK;
     if (e->front) return front_sc_distance_matrix(e, queries, nq, lo, hi, dist, shift);
+    std::lock_guard<std::mutex> pk(e->pass_mu);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     if (lo < 0 || hi > e->n || hi < lo) return fail(e, SCL_ERR_OUT_OF_RANGE, "keyframe range out of the database");
@@ -1308,6 +1320,21 @@ int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, c
             if ((rc = launch_screen_group(e, ScreenGroup{qb.slot, qb.base, qb.n, qb.nq, 0}))) return rc;
             if (wide) {
                 if ((rc = launch_survivor_pass_wide(e, qb.slot, qb.base, qb.n, qb.nq, 0, qb.out3, e->stream))) return rc;
+            } else if (sc_small_exact_supported(db_view(e), e->SR) && e->d_smask && !scl_lab_int("SCL_SMALL_EXACT_OFF", 0)) {
+                // a blocking call's handful of scans: one workgroup per scan selects, scores the open shifts, forms the top-k and
+                // writes the winner (sc_masked.hip) -- one launch, no argument copy
+                SmallExactArgs sa{};
+                sa.nq = qb.nq; sa.k = k; sa.exclude_eps = e->cfg.knn_exclude_eps; sa.two_eps = 2.0f * sc_screen_eps(); sa.surv_stats = e->d_surv_stats;
+                for (int j = 0; j < qb.nq; ++j) {
+                    const size_t off = (size_t)j * e->set_stride;
+                    SmallExactQuery &sq = sa.q[j];
+                    sq.qslot = qb.slot[j]; sq.base = qb.base[j]; sq.n = qb.n[j];
+                    sq.approx = e->d_approx + off; sq.starts = e->d_starts + off; sq.smask = e->d_smask + off; sq.ring_d2 = e->d_ring_d2 + off;
+                    sq.t_min = e->d_tmin + j; sq.list = e->d_surv + off; sq.out3 = qb.out3[j];
+                    sq.topk_idx = e->d_topk_idx + j * kTailTopMaxK; sq.topk_d2 = e->d_topk_d2 + j * kTailTopMaxK;
+                }
+                ProfScope ps(e, P_ARGMIN);
+                SCL_HIP(e, launch_sc_small_exact(db_view(e), e->SR, sa, e->stream));
             } else if ((rc = launch_survivor_pass(e, qb.slot, qb.base, qb.n, qb.nq, 0, qb.out3))) return rc;
         } else {
             ProfScope ps(e, P_SC);
@@ -1331,7 +1358,16 @@ int collect_full_locked(scl_engine *e, int ticket, int *nn_idx, int *shift, doub
 {
     if (ticket < 0 || ticket >= scl_engine::kSlots || !e->slot_busy[ticket])
         return fail(e, SCL_ERR_INVALID_ARG, "unknown ticket");
-    SCL_HIP(e, hipEventSynchronize(e->ev_done[e->slot_ev[ticket]]));
+    {
+        // a pass of one or a few scans ends within tens of microseconds: poll for that long (a blocking wait wakes up tens of
+        // microseconds late -- a fifth of a blocking one-scan call), then sleep in the runtime
+        hipEvent_t ev = e->ev_done[e->slot_ev[ticket]];
+        hipError_t q = hipErrorNotReady;
+        const auto t0 = std::chrono::steady_clock::now();
+        while ((q = hipEventQuery(ev)) == hipErrorNotReady)
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) { q = hipEventSynchronize(ev); break; }
+        SCL_HIP(e, q);
+    }
     collect_profile(e);
     e->slot_busy[ticket] = false;
     *nn_idx = -1; *shift = 0; *dist = kBigDist;
@@ -1349,6 +1385,7 @@ int scl_detect_full_submit(scl_engine *e, int query, int lo, int hi, int *ticket
 {
     if (!e || !ticket) return SCL_ERR_INVALID_ARG;
     if (e->front) return front_submit_many(e, &query, &lo, &hi, 1, ticket);
+    std::lock_guard<std::mutex> pk(e->pass_mu);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     return submit_full_locked(e, query, lo, hi, ticket);
@@ -1365,6 +1402,7 @@ int scl_detect_full_submit_many(scl_engine *e, const int *queries, const int *lo
         }
         return SCL_OK;
     }
+    std::lock_guard<std::mutex> pk(e->pass_mu);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     for (int i = 0; i < n_queries; i += kMaxQueryBatch) {
@@ -1381,9 +1419,15 @@ namespace {
 // (spl scans per launch, one buffer set per scan), then ONE exact pass over the survivors of the whole chunk, one
 // event.  Two chunks are kept enqueued (their results land in the two halves of h_stream_out), so the device never
 // waits for the host between chunks.
-int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, const int *hi, int n_queries, int spl,
+// `db`: the caller's lock on the database (e->mu).  The call scores the database it was started on -- n0 keyframes -- and gives the
+// lock up while it waits for a chunk's results: appends (which take e->mu only) get in there, behind the launches already enqueued on
+// the stream; a capacity doubling waits for every stream of the engine before it frees the old arrays (grow_to), and the launches
+// enqueued after it read the new ones (db_view is formed per launch).  pass_mu, held by the caller throughout, keeps every other
+// scoring entry point out of the buffer sets.
+int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, const int *queries, const int *lo, const int *hi, int n_queries, int spl,
                            int *nn_idx, int *shift, double *dist)
 {
+    const int n0 = e->n;                                     // the database this call scores
     constexpr int NS = scl_engine::kScreenSets;
     constexpr int CH = NS / 2;                               // scans per chunk at most: the two chunks in flight use the two halves of the buffer sets
     // ... and a whole number of launches (80 x 180 takes 12 scans per launch: 64 would end every chunk with a launch of four,
@@ -1425,7 +1469,7 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
     };
     int nmax = 1;
     for (int i = 0; i < n_queries; ++i) {
-        const int l = lo[i] < 0 ? 0 : lo[i], h = hi[i] > e->n ? e->n : hi[i];
+        const int l = lo[i] < 0 ? 0 : lo[i], h = hi[i] > n0 ? n0 : hi[i];
         if (h - l > nmax) nmax = h - l;
     }
     int rc = ensure_sets(e, (size_t)nmax);
@@ -1438,9 +1482,9 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
         for (int i = 0; i < count; ++i) {
             const int q = queries[first + i];
             int slot;
-            if (q >= 0) { if (q >= e->n) return fail(e, SCL_ERR_OUT_OF_RANGE, "query slot out of range"); slot = q; }
+            if (q >= 0) { if (q >= n0) return fail(e, SCL_ERR_OUT_OF_RANGE, "query slot out of range"); slot = q; }
             else { const int j = -1 - q; if (j >= e->stage_rows || !e->staged[j]) return fail(e, SCL_ERR_INVALID_ARG, "no staged query"); slot = e->cap + j; }
-            const int l = lo[first + i] < 0 ? 0 : lo[first + i], h = hi[first + i] > e->n ? e->n : hi[first + i];
+            const int l = lo[first + i] < 0 ? 0 : lo[first + i], h = hi[first + i] > n0 ? n0 : hi[first + i];
             if (k) k->lo[(size_t)i] = l;
             if (h - l <= 0) continue;
             if (k) k->empty[(size_t)i] = 0;
@@ -1537,6 +1581,14 @@ int stream_screened_locked(scl_engine *e, const int *queries, const int *lo, con
             hipError_t q;
             while ((q = hipEventQuery(e->ev_chunk[c])) == hipErrorNotReady) { }
             SCL_HIP(e, q);
+        } else if (!owed.valid && !pend.valid) {
+            // more to submit behind this wait: the database lock is free meanwhile (appends get in; nothing of this call's state
+            // names a slot or a pointer that a capacity doubling could move: the chunks in flight are enqueued, the next one is
+            // built after the lock is back)
+            db.unlock();
+            const hipError_t w = hipEventSynchronize(e->ev_chunk[c]);
+            db.lock();
+            SCL_HIP(e, w);
         } else {
             SCL_HIP(e, hipEventSynchronize(e->ev_chunk[c]));
         }
@@ -1583,7 +1635,8 @@ int scl_detect_full_stream(scl_engine *e, const int *queries, const int *lo, con
 {
     if (!e || !queries || !lo || !hi || !nn_idx || !shift || !dist || n_queries < 0) return SCL_ERR_INVALID_ARG;
     if (e->front) return front_detect_full_stream(e, queries, lo, hi, n_queries, scans_per_launch, launches_in_flight, nn_idx, shift, dist);
-    std::lock_guard<std::mutex> lk(e->mu);
+    std::lock_guard<std::mutex> pk(e->pass_mu);
+    std::unique_lock<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     for (int i = 0; i < scl_engine::kSlots; ++i)
         if (e->slot_busy[i]) return fail(e, SCL_ERR_INVALID_ARG, "detect_full_stream: collect the passes in flight first");
@@ -1592,7 +1645,7 @@ int scl_detect_full_stream(scl_engine *e, const int *queries, const int *lo, con
         // keyframe line through the L2 (sc_screen.hip), so more scans per launch read less per scan from HBM
         const int mb = sc_screen_max_batch(db_view(e), e->SR);
         const int spl_s = scans_per_launch < 1 ? 1 : (scans_per_launch > mb ? mb : scans_per_launch);
-        return stream_screened_locked(e, queries, lo, hi, n_queries, spl_s, nn_idx, shift, dist);
+        return stream_screened_locked(e, lk, queries, lo, hi, n_queries, spl_s, nn_idx, shift, dist);
     }
     const int spl = scans_per_launch < 1 ? 1 : (scans_per_launch > kMaxQueryBatch ? kMaxQueryBatch : scans_per_launch);
     int depth = launches_in_flight < 1 ? 1 : launches_in_flight;
@@ -1626,6 +1679,7 @@ int scl_detect_full_collect(scl_engine *e, int ticket, int *nn_idx, int *shift, 
 {
     if (!e || !nn_idx || !shift || !dist) return SCL_ERR_INVALID_ARG;
     if (e->front) return front_collect(e, ticket, nn_idx, shift, dist);
+    std::lock_guard<std::mutex> pk(e->pass_mu);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     return collect_full_locked(e, ticket, nn_idx, shift, dist);
@@ -1639,6 +1693,7 @@ int scl_detect_full_range(scl_engine *e, int query, int lo, int hi, int *nn_idx,
         const int rc = front_submit_many(e, &query, &lo, &hi, 1, &t);
         return rc ? rc : front_collect(e, t, nn_idx, shift, dist);
     }
+    std::lock_guard<std::mutex> pk(e->pass_mu);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     *nn_idx = -1; *shift = 0; *dist = kBigDist;
@@ -1652,6 +1707,7 @@ int scl_screen_distances(scl_engine *e, int query, int lo, int hi, float *approx
 {
     if (!e || !approx) return SCL_ERR_INVALID_ARG;
     if (e->front) return fail(e, SCL_ERR_UNSUPPORTED, "screen_distances: call it on a one-GPU engine");
+    std::lock_guard<std::mutex> pk(e->pass_mu);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     if (eps) *eps = sc_screen_eps();
@@ -1697,6 +1753,7 @@ int scl_get_last_topk(scl_engine *e, int k, int *idx, float *d2)
 {
     if (!e || !idx || !d2 || k < 1 || k > kTopkMaxK) return SCL_ERR_INVALID_ARG;
     if (e->front) return front_get_last_topk(e, k, idx, d2);
+    std::lock_guard<std::mutex> pk(e->pass_mu);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     if (e->last_pass_empty) {                              // the last pass had an empty range: no neighbours

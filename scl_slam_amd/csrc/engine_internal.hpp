@@ -38,7 +38,13 @@ struct scl_engine {
     int slot_lo[kSlots] = {0}; bool slot_busy[kSlots] = {false}; bool slot_empty[kSlots] = {false};
     int slot_ev[kSlots] = {0};                             // which slot's event completes this one (batched launches share one)
     unsigned next_slot = 0;
+    // Two locks.  `mu` guards the database -- the arrays, n / cap, the (robot, index) map, the scratch of an append -- and is held by
+    // every entry point for as long as it touches them.  `pass_mu` guards what a detection PASS works in (buffer sets, slots, pinned
+    // results, the streams' bookkeeping) and is taken first, by every entry point that scores anything; appends take `mu` only.  The
+    // stream form keeps pass_mu for the whole call but gives `mu` up while it waits for a chunk (engine.hip: stream_screened_locked),
+    // so the LIO thread's appends (DM.h:1001-1003) get in between the chunks of a long stream instead of behind all of it.
     mutable std::mutex mu;
+    mutable std::mutex pass_mu;
     mutable std::string last_error;
 
     // database (layout: kernels.hpp)

@@ -139,6 +139,21 @@ struct MaskedArgs { const float4 *desc; const double *norm; int nq, parts; Maske
 bool sc_matrix_supported(const struct DbView &db, int SR);
 hipError_t launch_sc_matrix(const struct DbView &db, int SR, const int *qslots, int nq, int lo, int n, const int *starts, const unsigned int *smask,
                             size_t set_stride, double *out_dist, int *out_shift, size_t row_stride, int kr, hipStream_t stream);
+// ---- the exact pass of a small batch of screened scans (sc_masked.hip: sc_small_exact_kernel) -- one workgroup per scan lists the
+// keyframes within the margin of the smallest screened distance, scores them at their open shifts, forms the ring-key top-k and writes
+// the winner {distance, position in the range or -1, shift} to out3 (pinned).  list: scratch of n ints; t_min is re-armed.
+struct SmallExactQuery {
+    int qslot, base, n;
+    const float *approx; const int *starts; const unsigned int *smask; const float *ring_d2; unsigned int *t_min;
+    int *list; double *out3; int *topk_idx; float *topk_d2;
+};
+struct SmallExactArgs {
+    const float4 *desc; const double *norm; const double *vkey;               // (filled by the launcher)
+    int nq, k; float exclude_eps, two_eps; unsigned long long *surv_stats;
+    SmallExactQuery q[kMaxQueryBatch];
+};
+bool sc_small_exact_supported(const struct DbView &db, int SR);
+hipError_t launch_sc_small_exact(const struct DbView &db, int SR, const SmallExactArgs &args, hipStream_t stream);
 bool sc_masked_supported(const struct DbView &db, int SR);
 hipError_t launch_sc_masked(const struct DbView &db, int SR, const MaskedQuery *queries, int nq, int parts, hipStream_t stream);
 // ---- screening pass of the full-DB mode (sc_screen.hip; 64x120 grid) --------------------------------------------

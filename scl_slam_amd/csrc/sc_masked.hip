@@ -20,6 +20,7 @@
 // pass over the survivors of the 80 x 180 grid (the wave program that grid lacked).
 #include <atomic>
 
+#include "align_exact.hpp"
 #include "device_common.hpp"
 #include "kernels.hpp"
 
@@ -56,11 +57,135 @@ struct MaskedCfg {
     static constexpr size_t LDS = LDS_Q + LDS_N + WAVES * LDS_WAVE;
 };
 
+// The exact distance of ONE pair at the shifts of `mask` (bit t: shift (first + t) mod S), by one wave: the scan staged in LDS (Qs:
+// column-major fp32 with QCOLS columns, nq: its norms extended alike), the candidate's fp32 rows kd and norms kn from memory, simrow:
+// the wave's TM rows of S similarities.  best / bshift: the smallest distance and its shift VALUE (ties: the lowest), kInf / INT_MAX
+// when no shift has a finite distance.
+template <int RG, int S, int W, int PD = MASKED_PD>
+__device__ __forceinline__ void masked_pair(const unsigned char *Qs, const double *nq, double *simrow, const float4 *kd, const double *kn,
+                                            const int first, unsigned int mask, const int lane, double &best, int &bshift)
+{
+    using C = MaskedCfg<RG, S, W>;
+    constexpr int CPL = C::CPL, PITCH = C::PITCH, TM = kMaskTMax;
+    const bool active = lane < kMaskLanes;
+    const int ll = active ? lane : kMaskLanes - 1;
+    const double kInf = __longlong_as_double(0x7ff0000000000000LL);
+    // candidate columns of this lane and their norms
+    int yc[CPL];
+    double nk[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) { int y = ll + kMaskLanes * j - first; y = y < 0 ? y + S : y; yc[j] = y; nk[j] = kn[y]; }
+    best = kInf; bshift = 0x7fffffff;
+    while (mask) {
+        // the next up to TM open shifts of the pair
+        int ts[TM]; int nt = 0;
+#pragma unroll
+        for (int u = 0; u < TM; ++u) { ts[u] = 0; if (mask) { ts[u] = __ffs((int)mask) - 1; mask &= mask - 1; nt = u + 1; } }
+        double acc[TM][CPL];
+#pragma unroll
+        for (int u = 0; u < TM; ++u)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) acc[u][j] = 0.0;
+        // ---- ring-order dots: the candidate's ring groups (one ahead), the scan's from LDS ----
+        // (PD ring groups in flight: one group ahead left the wave waiting a memory round trip per group)
+        float4 kbuf[PD][CPL];
+#pragma unroll
+        for (int d = 0; d < PD; ++d)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) kbuf[d][j] = kd[(size_t)(d < RG ? d : RG - 1) * S + yc[j]];
+        static_assert(RG % PD == 0, "ring groups in whole prefetch rounds");
+#pragma unroll 1
+        for (int r0 = 0; r0 < RG; r0 += PD) {
+#pragma unroll
+          for (int dd = 0; dd < PD; ++dd) {
+            const int rg = r0 + dd;
+            float4 kv[CPL];
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) kv[j] = kbuf[dd][j];
+            {   // the slot is refilled with the group PD further on (past the end: the last group again, unused)
+                const int rn = rg + PD < RG ? rg + PD : RG - 1;
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) kbuf[dd][j] = kd[(size_t)rn * S + yc[j]];
+            }
+#pragma unroll
+            for (int u = 0; u < TM; ++u) {
+                if (u < nt) {                                               // (wave uniform)
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        const float4 qv = *reinterpret_cast<const float4 *>(Qs + (size_t)(ll + kMaskLanes * j + ts[u]) * PITCH + rg * 16);
+                        acc[u][j] = fma((double)kv[j].x, (double)qv.x, acc[u][j]);
+                        acc[u][j] = fma((double)kv[j].y, (double)qv.y, acc[u][j]);
+                        acc[u][j] = fma((double)kv[j].z, (double)qv.z, acc[u][j]);
+                        acc[u][j] = fma((double)kv[j].w, (double)qv.w, acc[u][j]);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        // ---- cosine similarity per (shift, scan column), into the wave's rows by scan column ----
+        wave_fence_lds();
+#pragma unroll
+        for (int u = 0; u < TM; ++u) {
+            if (u < nt && active) {
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    const int cx = ll + kMaskLanes * j + ts[u];             // < S + W - 1
+                    const int c = cx >= S ? cx - S : cx;
+                    const double nqc = nq[cx];
+                    const bool skip = (nqc == 0.0) | (nk[j] == 0.0);        // D.h:1523
+                    // a skipped column contributes +0.0 to the sum, which is bit-equivalent to leaving it out
+                    simrow[u * S + c] = skip ? 0.0 : acc[u][j] / (nqc * nk[j]);
+                }
+            }
+        }
+        // effective columns per shift (both norms non-zero), counted over the lanes
+        int eff[TM];
+#pragma unroll
+        for (int u = 0; u < TM; ++u) {
+            int e = 0;
+            if (u < nt) {
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    const int cx = ll + kMaskLanes * j + ts[u];
+                    const bool use = active && !((nq[cx] == 0.0) | (nk[j] == 0.0));
+                    e += __popcll(__builtin_amdgcn_ballot_w64(use));
+                }
+            }
+            eff[u] = e;
+        }
+        wave_fence_lds();
+        // ---- the sum over the scan's columns in ascending order (D.h:1518-1532), one lane per shift ----
+        double d = kInf; int sh = 0x7fffffff;
+        if (lane < nt) {
+            const double *row = simrow + lane * S;
+            double sum = 0.0;
+#pragma unroll 8
+            for (int c = 0; c < S; ++c) sum = sum + row[c];
+            int e = eff[0], t = ts[0];
+#pragma unroll
+            for (int u = 1; u < TM; ++u) if (lane == u) { e = eff[u]; t = ts[u]; }
+            const double dd = 1.0 - sum / (double)e;                         // 0 / 0 -> NaN, never wins
+            int st = first + t; st = st >= S ? st - S : st;
+            if (dd < kBigDist) { d = dd; sh = st; }
+        }
+        // smallest distance, ties to the lowest shift VALUE (the reference walks the sorted shift space with strict <)
+#pragma unroll
+        for (int off = 1; off < TM; off <<= 1) {
+            const double od = __shfl_xor(d, off, kWave); const int os = __shfl_xor(sh, off, kWave);
+            const bool take = (od < d) | ((od == d) & (os < sh));
+            d = take ? od : d; sh = take ? os : sh;
+        }
+        d = readlane_f64(d, 0); sh = __builtin_amdgcn_readfirstlane(sh);
+        if ((d < best) | ((d == best) & (sh < bshift))) { best = d; bshift = sh; }
+    }
+}
+
 template <int RG, int S, int W>
 __global__ __launch_bounds__((MaskedCfg<RG, S, W>::WAVES * kWave)) void sc_masked_kernel(MaskedArgs ma)
 {
     using C = MaskedCfg<RG, S, W>;
-    constexpr int CPL = C::CPL, PITCH = C::PITCH, QCOLS = C::QCOLS, TM = kMaskTMax;
+    constexpr int CPL = C::CPL, PITCH = C::PITCH, QCOLS = C::QCOLS;
     static_assert(S % kMaskLanes == 0 && CPL >= 1 && CPL <= 3 && W <= 32, "tiling");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_m[];
     unsigned char *Qs = smem_m;
@@ -92,9 +217,6 @@ __global__ __launch_bounds__((MaskedCfg<RG, S, W>::WAVES * kWave)) void sc_maske
     }
     __syncthreads();
 
-    const bool active = lane < kMaskLanes;
-    const int ll = active ? lane : kMaskLanes - 1;
-    const double kInf = __longlong_as_double(0x7ff0000000000000LL);
     const int stride_items = ma.parts * C::WAVES;
     for (int item = part * C::WAVES + wave; item < n_items; item += stride_items) {
         // ---- the pair: candidate slot, first searched shift, the shifts still open ----
@@ -105,118 +227,10 @@ __global__ __launch_bounds__((MaskedCfg<RG, S, W>::WAVES * kWave)) void sc_maske
         const unsigned int all = W >= 32 ? 0xffffffffu : ((1u << W) - 1u);
         if (first < 0 || first >= S) { first = 0; mask = 0u; }                  // (an undecided alignment never reaches this kernel: guard only)
         mask &= all;
-        // candidate columns of this lane and their norms
-        int yc[CPL];
-        double nk[CPL];
         const double *kn = ma.norm + (size_t)slot * S;
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) { int y = ll + kMaskLanes * j - first; y = y < 0 ? y + S : y; yc[j] = y; nk[j] = kn[y]; }
         const float4 *kd = ma.desc + (size_t)slot * (size_t)(RG * S);
-        double best = kInf; int bshift = 0x7fffffff;
-        while (mask) {
-            // the next up to TM open shifts of the pair
-            int ts[TM]; int nt = 0;
-#pragma unroll
-            for (int u = 0; u < TM; ++u) { ts[u] = 0; if (mask) { ts[u] = __ffs((int)mask) - 1; mask &= mask - 1; nt = u + 1; } }
-            double acc[TM][CPL];
-#pragma unroll
-            for (int u = 0; u < TM; ++u)
-#pragma unroll
-                for (int j = 0; j < CPL; ++j) acc[u][j] = 0.0;
-            // ---- ring-order dots: the candidate's ring groups (one ahead), the scan's from LDS ----
-            // (PD ring groups in flight: one group ahead left the wave waiting a memory round trip per group)
-            constexpr int PD = MASKED_PD;
-            float4 kbuf[PD][CPL];
-#pragma unroll
-            for (int d = 0; d < PD; ++d)
-#pragma unroll
-                for (int j = 0; j < CPL; ++j) kbuf[d][j] = kd[(size_t)(d < RG ? d : RG - 1) * S + yc[j]];
-            static_assert(RG % PD == 0, "ring groups in whole prefetch rounds");
-#pragma unroll 1
-            for (int r0 = 0; r0 < RG; r0 += PD) {
-#pragma unroll
-              for (int dd = 0; dd < PD; ++dd) {
-                const int rg = r0 + dd;
-                float4 kv[CPL];
-#pragma unroll
-                for (int j = 0; j < CPL; ++j) kv[j] = kbuf[dd][j];
-                {   // the slot is refilled with the group PD further on (past the end: the last group again, unused)
-                    const int rn = rg + PD < RG ? rg + PD : RG - 1;
-#pragma unroll
-                    for (int j = 0; j < CPL; ++j) kbuf[dd][j] = kd[(size_t)rn * S + yc[j]];
-                }
-#pragma unroll
-                for (int u = 0; u < TM; ++u) {
-                    if (u < nt) {                                               // (wave uniform)
-#pragma unroll
-                        for (int j = 0; j < CPL; ++j) {
-                            const float4 qv = *reinterpret_cast<const float4 *>(Qs + (size_t)(ll + kMaskLanes * j + ts[u]) * PITCH + rg * 16);
-                            acc[u][j] = fma((double)kv[j].x, (double)qv.x, acc[u][j]);
-                            acc[u][j] = fma((double)kv[j].y, (double)qv.y, acc[u][j]);
-                            acc[u][j] = fma((double)kv[j].z, (double)qv.z, acc[u][j]);
-                            acc[u][j] = fma((double)kv[j].w, (double)qv.w, acc[u][j]);
-                        }
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-              }
-            }
-            // ---- cosine similarity per (shift, scan column), into the wave's rows by scan column ----
-            wave_fence_lds();
-#pragma unroll
-            for (int u = 0; u < TM; ++u) {
-                if (u < nt && active) {
-#pragma unroll
-                    for (int j = 0; j < CPL; ++j) {
-                        const int cx = ll + kMaskLanes * j + ts[u];             // < S + W - 1
-                        const int c = cx >= S ? cx - S : cx;
-                        const double nqc = nq[cx];
-                        const bool skip = (nqc == 0.0) | (nk[j] == 0.0);        // D.h:1523
-                        // a skipped column contributes +0.0 to the sum, which is bit-equivalent to leaving it out
-                        simrow[u * S + c] = skip ? 0.0 : acc[u][j] / (nqc * nk[j]);
-                    }
-                }
-            }
-            // effective columns per shift (both norms non-zero), counted over the lanes
-            int eff[TM];
-#pragma unroll
-            for (int u = 0; u < TM; ++u) {
-                int e = 0;
-                if (u < nt) {
-#pragma unroll
-                    for (int j = 0; j < CPL; ++j) {
-                        const int cx = ll + kMaskLanes * j + ts[u];
-                        const bool use = active && !((nq[cx] == 0.0) | (nk[j] == 0.0));
-                        e += __popcll(__builtin_amdgcn_ballot_w64(use));
-                    }
-                }
-                eff[u] = e;
-            }
-            wave_fence_lds();
-            // ---- the sum over the scan's columns in ascending order (D.h:1518-1532), one lane per shift ----
-            double d = kInf; int sh = 0x7fffffff;
-            if (lane < nt) {
-                const double *row = simrow + lane * S;
-                double sum = 0.0;
-#pragma unroll 8
-                for (int c = 0; c < S; ++c) sum = sum + row[c];
-                int e = eff[0], t = ts[0];
-#pragma unroll
-                for (int u = 1; u < TM; ++u) if (lane == u) { e = eff[u]; t = ts[u]; }
-                const double dd = 1.0 - sum / (double)e;                         // 0 / 0 -> NaN, never wins
-                int st = first + t; st = st >= S ? st - S : st;
-                if (dd < kBigDist) { d = dd; sh = st; }
-            }
-            // smallest distance, ties to the lowest shift VALUE (the reference walks the sorted shift space with strict <)
-#pragma unroll
-            for (int off = 1; off < TM; off <<= 1) {
-                const double od = __shfl_xor(d, off, kWave); const int os = __shfl_xor(sh, off, kWave);
-                const bool take = (od < d) | ((od == d) & (os < sh));
-                d = take ? od : d; sh = take ? os : sh;
-            }
-            d = readlane_f64(d, 0); sh = __builtin_amdgcn_readfirstlane(sh);
-            if ((d < best) | ((d == best) & (sh < bshift))) { best = d; bshift = sh; }
-        }
+        double best; int bshift;
+        masked_pair<RG, S, W>(Qs, nq, simrow, kd, kn, first, mask, lane, best, bshift);
         if (lane == 0) {
             const bool ok = best < kBigDist;
             mq.out_dist[item] = ok ? best : kBigDist;
@@ -242,6 +256,225 @@ hipError_t launch_masked(const MaskedArgs &ma, hipStream_t stream)
     return hipGetLastError();
 }
 
+
+// ---- the exact pass of a SMALL batch of screened scans (one to four: a blocking call over the whole database) --------------------
+// One workgroup per scan does everything the big survivors' pass spreads over launches and workgroups: it reads the smallest
+// screened distance, lists the keyframes within the margin of it, scores those few at their open shifts (masked_pair: the first
+// shift is the alignment's, the mask the screening's), forms the ring-key top-k from the metric the screening stored, and writes
+// the winner to pinned host memory -- one launch, arguments in the kernel-argument segment (the
+// survivors' pass of a chunk uploads its argument sets with a copy of its own: 5 us of a blocking call).  A pair that reaches
+// it without a first shift (nothing writes kAlignUndecided now; the consumers honour it) is aligned here by the reference's own
+// fp64 evaluation and scored at every shift.
+constexpr int kSmallWaves = 8;                  // (512 threads: registers for kSmallPD ring groups in flight)
+constexpr int kSmallPD = 4;                     // ring groups in flight per wave (8 spill)
+constexpr int kSmallList = 1024;                // listed keyframes kept in LDS with their first shift and mask (more: through memory)
+constexpr int kSmallTop = 4;                    // ring-key candidates the barrier-free top-k tracks per wave
+template <int RG, int S, int W>
+struct SmallCfg {
+    using M = MaskedCfg<RG, S, W>;
+    static constexpr size_t LDS_Q = M::LDS_Q, LDS_N = M::LDS_N;
+    static constexpr size_t LDS_WAVE = M::LDS_WAVE > (size_t)(2 * S + 2) * 8 ? M::LDS_WAVE : (size_t)(2 * S + 2) * 8;   // TM rows, or the doubled key of the slow path
+    static constexpr size_t LDS_VQ = (size_t)S * 8;                  // the scan's sector key (slow path)
+    static constexpr size_t LDS_REC = (size_t)kSmallWaves * 16 + (size_t)kSmallWaves * kSmallTop * 8;   // a wave's best (distance, position << 8 | shift); its kSmallTop nearest ring keys
+    static constexpr size_t LDS_LIST = (size_t)kSmallList * 12;
+    static constexpr size_t LDS = LDS_Q + LDS_N + kSmallWaves * LDS_WAVE + LDS_VQ + LDS_REC + 16 + LDS_LIST;
+};
+
+template <int RG, int S, int W>
+__global__ __launch_bounds__(kSmallWaves * kWave) void sc_small_exact_kernel(SmallExactArgs sa)
+{
+    using C = MaskedCfg<RG, S, W>;
+    using SC = SmallCfg<RG, S, W>;
+    constexpr int PITCH = C::PITCH, QCOLS = C::QCOLS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
+    unsigned char *Qs = smem_s;
+    double *nq = reinterpret_cast<double *>(smem_s + SC::LDS_Q);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    double *wrow = reinterpret_cast<double *>(smem_s + SC::LDS_Q + SC::LDS_N + (size_t)wave * SC::LDS_WAVE);
+    double *vq = reinterpret_cast<double *>(smem_s + SC::LDS_Q + SC::LDS_N + (size_t)kSmallWaves * SC::LDS_WAVE);
+    unsigned long long *rec = reinterpret_cast<unsigned long long *>(smem_s + SC::LDS_Q + SC::LDS_N + (size_t)kSmallWaves * SC::LDS_WAVE + SC::LDS_VQ);
+    unsigned long long *tkw = rec + 2 * kSmallWaves;                             // [kSmallWaves][kSmallTop]
+    int *n_list = reinterpret_cast<int *>(tkw + kSmallWaves * kSmallTop);
+    int *llist = n_list + 4;                                                     // [kSmallList][3]: position, first shift, mask
+    const SmallExactQuery q = sa.q[blockIdx.x];
+    const double kInf = __longlong_as_double(0x7ff0000000000000LL);
+
+    // ---- threshold, then the scan's rows and norms on their way while the list is made ----
+    const unsigned int tm = *q.t_min;
+    float thr = __int_as_float(0xff800000);                                      // nothing screened: only the "score exactly" marks pass
+    if (tm != 0xffffffffu) {
+        const unsigned int b = (tm >> 31) ? (tm & 0x7fffffffu) : ~tm;            // inverse of the ordered image
+        thr = __int_as_float((int)b) + sa.two_eps;
+    }
+    if (threadIdx.x == 0) *n_list = 0;
+    {
+        const float4 *qd = sa.desc + (size_t)q.qslot * (size_t)(RG * S);
+        for (int idx = threadIdx.x; idx < RG * QCOLS; idx += blockDim.x) {
+            const int rg = idx / QCOLS, cx = idx - rg * QCOLS;
+            const int c = cx < S ? cx : cx - S;
+            *reinterpret_cast<float4 *>(Qs + (size_t)cx * PITCH + rg * 16) = qd[(size_t)rg * S + c];
+        }
+        const double *qn = sa.norm + (size_t)q.qslot * S;
+        for (int cx = threadIdx.x; cx < QCOLS; cx += blockDim.x) nq[cx] = qn[cx < S ? cx : cx - S];
+        const double *qv = sa.vkey + (size_t)q.qslot * S;
+        for (int c = threadIdx.x; c < S; c += blockDim.x) vq[c] = qv[c];
+    }
+    __syncthreads();
+    // ---- one sweep over the range, every thread's loads in flight together (a loop that waited for each load took 100 us here):
+    // the keyframes that can still hold the minimum go on the list (positions in the range; any order: the winner is the smallest
+    // (distance, position)); the ring-key metric stays in registers for the top-k rounds ----
+    constexpr int U = 20, NT = kSmallWaves * kWave;                             // 10 240 positions per sweep
+    const unsigned long long none = ~0ull;
+    const int sweeps = (q.n + U * NT - 1) / (U * NT);
+    unsigned long long tk_prev = 0ull;                                           // (top-k over several sweeps: the rounds below re-read memory)
+    float rv[U];
+    for (int sw = 0; sw < sweeps; ++sw) {
+        float av[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = sw * U * NT + u * NT + (int)threadIdx.x;
+            av[u] = i < q.n ? q.approx[i] : __int_as_float(0x7f800000);
+            rv[u] = i < q.n ? q.ring_d2[i] : 3.402823466e+38f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = sw * U * NT + u * NT + (int)threadIdx.x;
+            if (i < q.n && av[u] <= thr) {                                      // -inf (score exactly) always passes
+                const int at = atomicAdd(n_list, 1);
+                if (at < kSmallList) { llist[3 * at] = i; llist[3 * at + 1] = q.starts[i]; llist[3 * at + 2] = q.smask ? (int)q.smask[i] : 0; }
+                else q.list[at] = i;
+            }
+        }
+    }
+    // ---- the ring-key top-k of the range over the metric the screening stored; keys (d2 bits << 32 | position) are unique.  One sweep
+    // (n <= 10 240) and k <= kSmallTop: every wave picks ITS k smallest out of the registers (k rounds of a wave minimum, no barrier),
+    // thread 0 merges the waves' picks behind the one barrier below.  Otherwise: k rounds over the whole workgroup, from memory ----
+    const bool topk_fast = sa.k > 0 && sa.k <= kSmallTop && sweeps == 1;
+    if (topk_fast) {
+        unsigned long long prev = 0ull;
+        bool first = true;
+        for (int round = 0; round < sa.k; ++round) {
+            unsigned long long mine = none;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = u * NT + (int)threadIdx.x;
+                const float r = rv[u];
+                const bool excluded = (sa.exclude_eps > 0.0f) && (r <= sa.exclude_eps);
+                const unsigned long long key = ((unsigned long long)(unsigned)__float_as_int(r) << 32) | (unsigned)i;
+                if (!excluded && (r < 3.402823466e+38f) && (first || key > prev) && key < mine) mine = key;
+            }
+            mine = wave_min_u64(mine);
+            if (lane == 0) tkw[wave * kSmallTop + round] = mine;
+            prev = mine; first = false;                                          // (none: every further round finds none as well)
+            if (mine == none) { for (int r2 = round + 1; r2 < sa.k; ++r2) if (lane == 0) tkw[wave * kSmallTop + r2] = none; break; }
+        }
+    } else if (sa.k > 0) {
+        bool first = true;
+        for (int round = 0; round < sa.k; ++round) {
+            unsigned long long mine = none;
+            for (int i = (int)threadIdx.x; i < q.n; i += NT) {
+                const float r = q.ring_d2[i];
+                const bool excluded = (sa.exclude_eps > 0.0f) && (r <= sa.exclude_eps);
+                const unsigned long long key = ((unsigned long long)(unsigned)__float_as_int(r) << 32) | (unsigned)i;
+                if (!excluded && (r < 3.402823466e+38f) && (first || key > tk_prev) && key < mine) mine = key;
+            }
+            mine = wave_min_u64(mine);
+            __syncthreads();                                                     // (the round before has been read)
+            if (lane == 0) rec[wave] = mine;
+            __syncthreads();
+            unsigned long long m = rec[0];
+#pragma unroll
+            for (int w = 1; w < kSmallWaves; ++w) m = rec[w] < m ? rec[w] : m;
+            if (threadIdx.x == 0) {
+                if (m == none) { q.topk_idx[round] = -1; q.topk_d2[round] = 3.402823466e+38f; }
+                else { q.topk_idx[round] = q.base + (int)(unsigned)(m & 0xffffffffull); q.topk_d2[round] = __int_as_float((int)(m >> 32)); }
+            }
+            if (m == none) {
+                for (int r2 = round + 1 + (int)threadIdx.x; r2 < sa.k; r2 += NT) { q.topk_idx[r2] = -1; q.topk_d2[r2] = 3.402823466e+38f; }
+                break;
+            }
+            tk_prev = m; first = false;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int total = *n_list;
+    if (topk_fast && threadIdx.x == 0) {                                         // the k smallest of the waves' k smallest (each list ascending)
+        int head[kSmallWaves];
+#pragma unroll
+        for (int w = 0; w < kSmallWaves; ++w) head[w] = 0;
+        for (int round = 0; round < sa.k; ++round) {
+            unsigned long long m = none; int mw = -1;
+#pragma unroll
+            for (int w = 0; w < kSmallWaves; ++w) {
+                const unsigned long long c = head[w] < sa.k ? tkw[w * kSmallTop + head[w]] : none;
+                if (c < m) { m = c; mw = w; }
+            }
+            if (mw < 0) { q.topk_idx[round] = -1; q.topk_d2[round] = 3.402823466e+38f; continue; }
+#pragma unroll
+            for (int w = 0; w < kSmallWaves; ++w) if (w == mw) ++head[w];
+            q.topk_idx[round] = q.base + (int)(unsigned)(m & 0xffffffffull); q.topk_d2[round] = __int_as_float((int)(m >> 32));
+        }
+    }
+
+    // ---- the listed keyframes, one wave each at a time ----
+    unsigned long long my_d = ~0ull, my_ps = ~0ull;                              // this wave's best: ordered image of the distance, position << 8 | shift
+    for (int it = wave; it < total; it += kSmallWaves) {
+        int pos, first; unsigned int mask;
+        if (it < kSmallList) { pos = llist[3 * it]; first = llist[3 * it + 1]; mask = (unsigned int)llist[3 * it + 2]; }
+        else { pos = q.list[it]; first = q.starts[pos]; mask = q.smask ? q.smask[pos] : 0u; }
+        const int slot = q.base + pos;
+        const unsigned int all = W >= 32 ? 0xffffffffu : ((1u << W) - 1u);
+        const double *kn = sa.norm + (size_t)slot * S;
+        const float4 *kd = sa.desc + (size_t)slot * (size_t)(RG * S);
+        if (first < 0 || first >= S || !q.smask) {
+            // no first shift (or no masks at all): the reference's own alignment (fastAlignUsingVkey, D.h:1491-1511), every shift open
+            if (first < 0 || first >= S) {
+                const int ll2 = lane < (S >> 1) ? lane : (S >> 1) - 1;
+                const double2 vk = *reinterpret_cast<const double2 *>(sa.vkey + (size_t)slot * S + 2 * ll2);
+                const int a0 = align_keyframe_exact<S>(vk, lane, wrow, vq);
+                // D.h:1545-1551: the searched shifts start SEARCH_RADIUS below the aligned one
+                first = a0 - (W - 1) / 2; first = first < 0 ? first + S : first;
+                wave_fence_lds();
+            }
+            mask = all;
+        }
+        mask &= all;
+        double best; int bshift;
+        masked_pair<RG, S, W, kSmallPD>(Qs, nq, wrow, kd, kn, first, mask, lane, best, bshift);   // (a lone wave: every round trip counts)
+        if (best < kBigDist) {
+            const unsigned long long b = (unsigned long long)__double_as_longlong(best);
+            const unsigned long long od = (b >> 63) ? ~b : (b | 0x8000000000000000ull);     // IEEE order -> unsigned order
+            const unsigned long long ps = ((unsigned long long)(unsigned)pos << 8) | (unsigned long long)(bshift & 0xff);
+            if (od < my_d || (od == my_d && ps < my_ps)) { my_d = od; my_ps = ps; }
+        }
+    }
+    __syncthreads();                                                             // (rec: the top-k rounds' words have been read)
+    if (lane == 0) { rec[2 * wave] = my_d; rec[2 * wave + 1] = my_ps; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long bd = ~0ull, bp = ~0ull;
+        for (int w = 0; w < kSmallWaves; ++w) {
+            const unsigned long long d = rec[2 * w], p = rec[2 * w + 1];
+            if (d < bd || (d == bd && p < bp)) { bd = d; bp = p; }
+        }
+        volatile double *o = q.out3;
+        if (bd == ~0ull) { o[0] = kBigDist; o[1] = -1.0; o[2] = 0.0; }
+        else {
+            const unsigned long long b = (bd >> 63) ? (bd & 0x7fffffffffffffffull) : ~bd;
+            o[0] = __longlong_as_double((long long)b); o[1] = (double)(int)(bp >> 8); o[2] = (double)(int)(bp & 0xff);
+        }
+        *q.t_min = 0xffffffffu;                                                  // re-armed for the next screening pass of this buffer set
+        if (sa.surv_stats) {
+            atomicAdd(sa.surv_stats, (unsigned long long)total);
+            atomicMax(sa.surv_stats + 1, (unsigned long long)total);
+            atomicAdd(sa.surv_stats + 2, 1ull);
+        }
+    }
+    (void)kInf;
+}
+
 }  // namespace
 
 bool sc_masked_supported(const DbView &db, int SR)
@@ -258,6 +491,28 @@ hipError_t launch_sc_masked(const DbView &db, int SR, const MaskedQuery *queries
     for (int i = 0; i < nq; ++i) ma.q[i] = queries[i];
     if (db.S == 120) return launch_masked<16, 120, 13>(ma, stream);
     return launch_masked<20, 180, 19>(ma, stream);
+}
+
+
+bool sc_small_exact_supported(const DbView &db, int SR) { return db.RG == 16 && db.S == 120 && 2 * SR + 1 == 13; }
+
+hipError_t launch_sc_small_exact(const DbView &db, int SR, const SmallExactArgs &args_in, hipStream_t stream)
+{
+    if (args_in.nq < 1 || args_in.nq > kMaxQueryBatch || !sc_small_exact_supported(db, SR)) return hipErrorInvalidValue;
+    using SC = SmallCfg<16, 120, 13>;
+    static_assert(SC::LDS <= 160 * 1024, "LDS");
+    static std::atomic<bool> attr_set_dev[64];
+    int dev_ = 0; (void)hipGetDevice(&dev_);
+    std::atomic<bool> &attr_set = attr_set_dev[dev_ & 63];
+    if (!attr_set.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute((const void *)sc_small_exact_kernel<16, 120, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC::LDS);
+        if (e != hipSuccess) return e;
+        attr_set.store(true, std::memory_order_release);
+    }
+    SmallExactArgs sa = args_in;
+    sa.desc = db.desc; sa.norm = db.norm; sa.vkey = db.vkey;
+    hipLaunchKernelGGL((sc_small_exact_kernel<16, 120, 13>), dim3(sa.nq), dim3(kSmallWaves * kWave), SC::LDS, stream, sa);
+    return hipGetLastError();
 }
 
 }  // namespace scl

@@ -39,7 +39,7 @@ constexpr int kMatLanes = 60;                  // active lanes: S / 60 keyframe 
 #define MAT_A 2, 16, 6, 2
 #endif
 #ifndef MAT_B
-#define MAT_B 1, 16, 4, 2
+#define MAT_B 1, 12, 4, 2
 #endif
 
 template <int RG_, int S_, int W_, int NS_, int WAVES_, int P_, int PD_>

@@ -39,6 +39,7 @@
 #include <atomic>
 #include <type_traits>
 
+#include "align_exact.hpp"
 #include "device_common.hpp"
 #include "kernels.hpp"
 
@@ -80,6 +81,7 @@ struct ScreenBatchArgs {
     int S, R4, hstride, rk_cap, align_filter, hkw;
     int nq, nb;
     int skip_d2;              // the alignment role leaves the ring-key metric to sc_screen2_finish_kernel
+    int self_align;           // first form, a batch nobody aligned in advance (a blocking call of one to three scans): every products workgroup aligns its OWN groups first
     ScreenQuery q[kMaxScreenBatch];
 };
 __device__ __forceinline__ ScreenArgs screen_args_of(const ScreenBatchArgs &ab, int qi)
@@ -105,76 +107,10 @@ __device__ __forceinline__ int wrapS(int x, int S)
     return x >= S ? x - S : x;
 }
 
-__device__ __forceinline__ void wave_fence()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-__device__ __forceinline__ void pin3(double &a, double &b, double &c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c) :: "memory"); }
-
 __device__ __forceinline__ unsigned int float_to_ordered_u(float f)
 {
     const unsigned int b = (unsigned int)__float_as_int(f);
     return (b >> 31) ? ~b : (b | 0x80000000u);
-}
-
-// fastAlignUsingVkey (D.h:1491-1511) for one keyframe, wave-wide, in the reference's own fp64 arithmetic; returns the
-// reference's arg-min shift.  vk = the keyframe's sector key at sectors 2*ll, 2*ll+1 (ll = min(lane, S/2 - 1)).  Same
-// arithmetic as the exact evaluation in the alignment phase of sc_distance_wave_kernel (tie rules included).
-template <int S>
-__device__ __forceinline__ int align_keyframe_exact(const double2 vk, int lane, double *vk2, const double *vq)
-{
-    constexpr int L = S >> 1;
-    const bool active = lane < L;
-    const int ll = active ? lane : L - 1;
-    const int j0 = 2 * ll;
-    const double kInf = __longlong_as_double(0x7ff0000000000000LL);
-    wave_fence();
-    *reinterpret_cast<double2 *>(vk2 + j0) = vk;
-    *reinterpret_cast<double2 *>(vk2 + j0 + S) = vk;
-    wave_fence();
-    double best = kInf;
-    int bshift = 0x7fffffff;
-    {
-        const double *p = vk2 + S - j0;
-        const double2 *pp = reinterpret_cast<const double2 *>(p);
-        double prev = p[-1];
-        double ss0 = 0.0, ss1 = 0.0;
-        constexpr int npair = S >> 1;
-        constexpr int BT = 3;                              // (5 in sc_distance.hip; here the path is rare and registers are short)
-        static_assert(npair % BT == 0, "alignment batches must tile the sector pairs");
-        const double2 *qq = reinterpret_cast<const double2 *>(vq);
-        double2 pb[2][BT], qb[2][BT];
-#pragma unroll
-        for (int v = 0; v < BT; ++v) { pb[0][v] = pp[v]; qb[0][v] = qq[v]; }
-#pragma unroll
-        for (int bt = 0; bt < npair / BT; ++bt) {
-            if (bt + 1 < npair / BT) {
-#pragma unroll
-                for (int v = 0; v < BT; ++v) { pb[(bt + 1) & 1][v] = pp[(bt + 1) * BT + v]; qb[(bt + 1) & 1][v] = qq[(bt + 1) * BT + v]; }
-            }
-            pin3(ss0, ss1, prev);
-#pragma unroll
-            for (int v = 0; v < BT; ++v) {
-                const double2 pv = pb[bt & 1][v];
-                const double qx = qb[bt & 1][v].x, qy = qb[bt & 1][v].y;
-                const double d0 = qx - pv.x, d1 = qx - prev;
-                ss0 = ss0 + d0 * d0;
-                ss1 = ss1 + d1 * d1;
-                const double e0 = qy - pv.y, e1 = qy - pv.x;
-                ss0 = ss0 + e0 * e0;
-                ss1 = ss1 + e1 * e1;
-                prev = pv.y;
-            }
-            pin3(ss0, ss1, prev);
-        }
-        const double n0 = sqrt(ss0), n1 = sqrt(ss1);
-        if (active && n0 < kBigDist) { best = n0; bshift = j0; }
-        if (active && n1 < kBigDist && n1 < best) { best = n1; bshift = j0 + 1; }
-    }
-    wave_argmin_dpp(best, bshift);
-    return __builtin_amdgcn_readfirstlane(best < kBigDist ? bshift : 0);
 }
 
 constexpr float kScreenEps = 1.5e-3f;          // see the error budget at the top of this file
@@ -256,8 +192,10 @@ constexpr int hdesc_rgh(int RG) { return ((RG * 8 + 63) / 64) * 8; }   // 8-byte
 constexpr float kAlign16Margin = 3.0e-3f;      // lead the fp16 stage demands of the best shift (normalised correlation; bound below: 2 x 9.9e-4)
 constexpr int kAlignFp32From = 3;              // ambiguous keyframes in a group from which the fp32 stage runs before the exact evaluation
 
+// own_groups: the workgroup aligns the groups the PRODUCTS role of the same (query, block) will walk -- bid, bid + nb, ...: wave w takes
+// every NWV-th of them -- instead of its share of a launch of its own (bid NWV + wave, + nb NWV, ...): sc_screen_role calls it so.
 template <int RG, int S, int W, int NWV = kScreenWaves>
-__device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const int block, unsigned char *smem_raw)
+__device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const int block, unsigned char *smem_raw, const bool own_groups = false)
 {
     constexpr int L = S >> 1;
     constexpr int MT = (S + 15) / 16;                  // tiles of 16 shifts
@@ -301,7 +239,7 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
         for (int kk = 0; kk < KS; ++kk) pre[kk] = *reinterpret_cast<const uint4 *>(kp + (4 * kk + k4) * 16);
         knorm_pre = *reinterpret_cast<const float *>(reinterpret_cast<const _Float16 *>(kp) + SK);
     };
-    const int g_first = bid * NWV + wave;
+    const int g_first = own_groups ? bid + wave * nbk : bid * NWV + wave;
     if (g_first < ngroups) fetch(g_first);
     {   // every global read of the set-up first, then the LDS stores: three loops of load -> store were three memory round trips
         constexpr int T = NWV * kWave;
@@ -837,6 +775,7 @@ __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const 
             *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(a.q_hdesc) + (size_t)c * SB + ch * 16);
     }
     const bool q_bad = a.q_kmask[7] != 0;
+    const float q_err = __uint_as_float(a.q_kmask[6]);                           // the scan's summed rounding-error norms (make_sc.hip)
     {
         unsigned long long qm[NW64];
 #pragma unroll
@@ -859,7 +798,7 @@ __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const 
     // first shifts (K0's output) of this group's keyframe n4, and of the next group's: requested one group ahead
     auto start_of = [&](int grp) {
         const int ci = grp * kGroup + n4;
-        return a.starts[ci < a.n ? ci : a.n - 1];
+        return a.starts[ci < a.n ? ci : a.n - 1];                                // (self-aligned batch: written by this workgroup a moment ago)
     };
     int b_nxt = start_of(bid < ngroups ? bid : 0);
     __syncthreads();
@@ -891,12 +830,14 @@ __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const 
 #pragma unroll
         for (int i = 0; i < MW; ++i) km[i] = make_uint4(0u, 0u, 0u, 0u);
         unsigned int kflag = 0;
-        if (wave == 0) {                                                         // the epilogue's operands: sector mask and flag of keyframe n
+        float kerr = 0.0f;
+        if (wave == 0) {                                                         // the epilogue's operands: sector mask, rounding-error norm and flag of keyframe n
             const unsigned int *kp = a.kmask + (size_t)(first_slot + (n16 < last_rel ? n16 : last_rel)) * 8;
-            kflag = kp[7];
+            const uint2 ef = *reinterpret_cast<const uint2 *>(kp + 6);
+            kerr = __uint_as_float(ef.x); kflag = ef.y;
 #pragma unroll
             for (int i = 0; i < MW; ++i) km[i] = *reinterpret_cast<const uint4 *>(kp + 4 * i);
-            if (MW == 2) km[1].w = 0u;                                           // word 7 is the flag, not sector bits
+            if (MW == 2) { km[1].z = 0u; km[1].w = 0u; }                         // words 6 and 7 are E and the flag, not sector bits
         }
         u32x4 ring[D];
         int cw_iss = cw0;                                                        // byte offset of the next step inside the keyframe
@@ -969,6 +910,13 @@ __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const 
             const bool b_open = b_raw < 0;                                       // kAlignUndecided: the exact pass aligns and scores this pair
             const int b_n = b_open ? 0 : b_raw;
             float dmin = __int_as_float(0x7f800000);
+            // per shift the interval the reference's distance lies in (as the second form's finishing: the two descriptors' recorded
+            // rounding-error norms over n_eff + this form's accumulation -- a wave's chain of NST products of 32 terms, NWV partials)
+            const float kInfF = __int_as_float(0x7f800000);
+            const float e_pair = (q_err + kerr) * 1.002f;
+            const bool e_ok = e_pair >= 0.0f && e_pair < 1.0f;
+            constexpr float kAcc1 = (float)(NST * 32 + NWV + 4) * 1.1920929e-7f * 1.002f + 2.0e-6f;
+            float dlo[MT][4], hi_min = kInfF;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 f4v s = part_cur[m * kWave + lane];
@@ -987,14 +935,33 @@ __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const 
                     }
                     const float d = 1.0f - s[r] / (float)ne;
                     if (t < W && ne > 0 && d < dmin) dmin = d;                   // n_eff = 0: 0/0 in the reference, never wins
+                    const float et = e_ok ? fminf(e_pair / (float)ne + kAcc1, kScreenEps) : kScreenEps;
+                    dlo[m][r] = kInfF;
+                    if (t < W && ne > 0) { dlo[m][r] = d - et; hi_min = fminf(hi_min, d + et); }
                 }
             }
             dmin = fminf(dmin, __shfl_xor(dmin, 16, kWave));
             dmin = fminf(dmin, __shfl_xor(dmin, 32, kWave));
+            hi_min = fminf(hi_min, __shfl_xor(hi_min, 16, kWave));
+            hi_min = fminf(hi_min, __shfl_xor(hi_min, 32, kWave));
             const bool mine = lane < kGroup && ci_n < a.n;
             const bool exact_only = q_bad || kflag != 0 || b_open || !(dmin == dmin);
             if (mine) a.out_approx[ci_n] = exact_only ? __int_as_float(0xff800000) : dmin;
-            if (mine && a.out_smask) a.out_smask[ci_n] = b_open ? 0u : (W >= 32 ? 0xffffffffu : ((1u << W) - 1u));   // (this form keeps no per-shift record: every shift stays open)
+            if (a.out_smask) {
+                // the shifts that can still hold (or tie for) the pair's exact minimum: the lower end of the interval not above the
+                // smallest upper end; every shift for a pair the screening cannot bound
+                unsigned int mb = 0u;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int t = 16 * m + 4 * j4 + r;
+                        if (t < W && (exact_only || dlo[m][r] <= hi_min)) mb |= 1u << t;
+                    }
+                mb |= __shfl_xor(mb, 16, kWave);
+                mb |= __shfl_xor(mb, 32, kWave);
+                if (mine) a.out_smask[ci_n] = b_open ? 0u : mb;
+            }
             float contrib = (mine && !exact_only) ? dmin : __int_as_float(0x7f800000);
 #pragma unroll
             for (int off = 8; off > 0; off >>= 1) contrib = fminf(contrib, __shfl_xor(contrib, off, kWave));
@@ -1030,7 +997,20 @@ __global__ __launch_bounds__(kScreenWaves * kWave, OCC) void sc_screen_kernel(Sc
         const int xcd = b & 7, j = b >> 3;
         const int grp = j / cyc_len, cyc = j - grp * cyc_len;
         const int idx = grp * 8 + xcd;
-        if (cyc < nq) { if (idx < nbk) sc_screen_role<hdesc_rgh(RG), S, W, D, PROBE>(fa.prod, cyc, idx, smem_fused); }
+        if (cyc < nq) {
+            if (idx < nbk) {
+                if (fa.prod.self_align) {
+                    // a batch nobody aligned in advance (a blocking call): the workgroup aligns the groups it is about to walk -- a
+                    // phase of one group per wave instead of a launch of 10-13 us in front of this one.  Its first shifts pass through
+                    // memory inside the workgroup: one CU, one L1 -- a workgroup-scope fence and the barrier order them (an agent-scope
+                    // fence writes the XCD's L2 back: 33 us per launch, measured)
+                    sc_align_role<RG, S, W>(fa.prod, cyc * nbk + idx, smem_fused, true);
+                    __threadfence_block();
+                    __syncthreads();
+                }
+                sc_screen_role<hdesc_rgh(RG), S, W, D, PROBE>(fa.prod, cyc, idx, smem_fused);
+            }
+        }
         else if (idx < X) sc_align_role<RG, S, W>(fa.next, idx, smem_fused);
     } else {
         const int idx = 8 * ((nbk + 7) >> 3) + (b - patterned);             // more alignment workgroups than pattern slots
@@ -1943,8 +1923,11 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
         hipLaunchKernelGGL((sc_screen2_finish_kernel<RG, S, W>), dim3((nmax + 255) / 256, sb.nq), dim3(256), 0, stream, f2);
         return hipGetLastError();
     }
+    // a batch of the first form that has to align for itself and has a products launch coming (a blocking call of one to three
+    // scans): the products' workgroups align their own groups (sc_screen_kernel), no launch in front of them
+    const bool self_align = (phases & kScreenAlign) && (phases & kScreenProducts) && !use_v2 && probe == 0 && !scl_lab_int("SCL_SELF_ALIGN_OFF", 0);
     // the alignment of this batch, on its own (the first launch of a sequence, or a caller that has only one)
-    if ((phases & kScreenAlign) && probe != 3) {
+    if ((phases & kScreenAlign) && probe != 3 && !self_align) {
         if (align2 && use_v2) {                                  // (the products' first form takes the ring-key metric from the alignment's first form)
             int ulo, un;
             union_of(sb, &ulo, &un);
@@ -2095,6 +2078,7 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
     if (blocks > ngroups) blocks = ngroups;
     if (blocks > kScreenMaxBlocks) blocks = kScreenMaxBlocks;
     fa.prod.nb = blocks;
+    fa.prod.self_align = self_align ? 1 : 0;
     int extra = 0;
     if (next && probe != 3) {
         if (next->nq < 1 || next->nq > kMaxScreenBatch) return hipErrorInvalidValue;
@@ -2107,7 +2091,7 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
         if (probe == 5 || probe == 6) fa.next.align_filter = probe == 5 ? 2 : 3;
 #endif
     }
-    const size_t lds = extra && lds0 > lds1 ? lds0 : lds1;
+    const size_t lds = (extra || self_align) && lds0 > lds1 ? lds0 : lds1;
     fa.align_blocks = extra;
     const int patterned = fused_patterned_blocks(sb.nq, blocks, extra);
     const int slots = 8 * ((blocks + 7) >> 3);                               // alignment slots inside the pattern
