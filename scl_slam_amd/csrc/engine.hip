@@ -493,9 +493,11 @@ int scl_create(const scl_config *cfg, scl_engine **out)
     {
         constexpr int NS = scl_engine::kScreenSets;
         if ((rc = dev_alloc(e, &e->d_nsurv, (size_t)NS))) return bail(rc);
-        if ((rc = dev_alloc(e, &e->d_tmin, (size_t)NS))) return bail(rc);
+        static_assert(NS <= kTminEpsOffset, "the launch's largest bound sits kTminEpsOffset words behind its t_min word");
+        if ((rc = dev_alloc(e, &e->d_tmin, (size_t)NS + kTminEpsOffset))) return bail(rc);
         if (hipMemset(e->d_nsurv, 0, sizeof(int) * NS) != hipSuccess) return bail(SCL_ERR_HIP);
         if (hipMemset(e->d_tmin, 0xff, sizeof(unsigned int) * NS) != hipSuccess) return bail(SCL_ERR_HIP);
+        if (hipMemset(e->d_tmin + NS, 0, sizeof(unsigned int) * kTminEpsOffset) != hipSuccess) return bail(SCL_ERR_HIP);
         if ((rc = dev_alloc(e, &e->d_surv_part, (size_t)NS * kSurvivorBlocks * kTailRec))) return bail(rc);
         if ((rc = dev_alloc(e, &e->d_surv_done, (size_t)NS))) return bail(rc);
         if (hipMemset(e->d_surv_done, 0, sizeof(unsigned int) * NS) != hipSuccess) return bail(SCL_ERR_HIP);
@@ -994,7 +996,8 @@ int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, c
 // One screening launch for up to four queries: slots qslot[i] against [lo[i], lo[i] + n[i]), results in buffer sets
 // set0 + i.  The event pair of the profile brackets this launch: it is the dominant kernel of a pass.
 // One screening launch group: queries qslot[0..nq) against [lo[i], lo[i] + n[i]), buffer sets set0 + i.
-struct ScreenGroup { const int *qslot, *lo, *n; int nq, set0; int part_half = 0; };   // part_half: which half of d_part holds the batch's partial sums
+struct ScreenGroup { const int *qslot, *lo, *n; int nq, set0; int part_half = 0; bool masks = false; };   // part_half: which half of d_part holds the batch's partial sums;
+                                                                                                             // masks: the batch's exact pass evaluates the open shifts only (the shift masks are formed and written)
 // next (optional, nq > 0): the launch that will follow; its alignment rides in this one (the next call then passes
 // kScreenProducts only).
 int launch_screen_group(scl_engine *e, const ScreenGroup &cur, int phases = kScreenAlign | kScreenProducts,
@@ -1007,7 +1010,7 @@ int launch_screen_group(scl_engine *e, const ScreenGroup &cur, int phases = kScr
         sb.pair_stride = e->set_stride;
         sb.approx = e->d_approx; sb.starts = e->d_starts; sb.align_fallbacks = e->d_align_fallbacks; sb.ring_d2 = e->d_ring_d2;
         sb.survivors = nullptr; sb.n_surv = nullptr; sb.t_min = e->d_tmin;
-        sb.smask = e->d_smask;                              // (null until a caller of the masked exact kernel has asked for the masks)
+        sb.smask = (g.masks || sc_screen_is_wide(db_view(e), e->SR)) ? e->d_smask : nullptr;   // (the 64 x 120 stream's exact pass scores all 13 shifts of its few survivors: no masks)
         sb.part = e->d_part + (g.part_half ? e->part_cap / 2 : 0);
         sb.side = stream == e->stream ? e->stream_align : nullptr; sb.ev_fork = e->ev_afork; sb.ev_join = e->ev_ajoin;
         sb.k = e->cfg.num_candidates; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
@@ -1155,6 +1158,7 @@ int matrix_screened_locked(scl_engine *e, const int *slots, int nq, int lo, int 
         {
             ProfScope ps(e, P_SC);
             ScreenGroup grp{qs, los, ns, padded, 0};
+            grp.masks = true;
             const int prof_saved = e->prof_on;
             e->prof_on = 0;                                                  // (one event pair around the whole group: this scope's)
             rc = launch_screen_group(e, grp);
@@ -1317,10 +1321,12 @@ int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, c
             // screening pass (fp16 matrix-core bounds around every reference distance) -> the exact fp64 kernel on the
             // survivors only; the winner is the reference's, bit for bit (sc_screen.hip)
             if ((rc = ensure_sets(e, (size_t)nmax))) return rc;
-            if ((rc = launch_screen_group(e, ScreenGroup{qb.slot, qb.base, qb.n, qb.nq, 0}))) return rc;
+            ScreenGroup sg{qb.slot, qb.base, qb.n, qb.nq, 0};
+            sg.masks = !wide && sc_small_exact_supported(db_view(e), e->SR);
+            if ((rc = launch_screen_group(e, sg))) return rc;
             if (wide) {
                 if ((rc = launch_survivor_pass_wide(e, qb.slot, qb.base, qb.n, qb.nq, 0, qb.out3, e->stream))) return rc;
-            } else if (sc_small_exact_supported(db_view(e), e->SR) && e->d_smask && !scl_lab_int("SCL_SMALL_EXACT_OFF", 0)) {
+            } else if (sg.masks && e->d_smask && !scl_lab_int("SCL_SMALL_EXACT_OFF", 0)) {
                 // a blocking call's handful of scans: one workgroup per scan selects, scores the open shifts, forms the top-k and
                 // writes the winner (sc_masked.hip) -- one launch, no argument copy
                 SmallExactArgs sa{};

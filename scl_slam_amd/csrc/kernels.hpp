@@ -22,7 +22,12 @@ constexpr int scl_lab_int(const char *, int dflt) { return dflt; }
 constexpr bool scl_lab_is(const char *, const char *) { return false; }
 #endif
 
-constexpr double kBigDist = 10000000.0;   // D.h:1494,1556,1637,1705 initial minima
+constexpr double kBigDist = 10000000.0;
+// The screening pass keeps, kTminEpsOffset words behind a buffer set's t_min word (the smallest screened distance of the launch), the
+// LARGEST per-pair bound of the launch as float bits: eps_max = max over the screened pairs of (E_q + E_k)(1 + 2e-3) / n_eff + accumulation
+// (sc_screen.hip).  Every screened distance of the launch is within eps_max of the reference's, so the keyframes that can hold the minimum
+// are those within 2 eps_max of the smallest -- not 2 kScreenEps (the worst case of fp16 rounding).  Zero: nothing recorded.
+constexpr int kTminEpsOffset = 256;   // D.h:1494,1556,1637,1705 initial minima
 constexpr int hdesc_sector(int RG) { return ((RG * 8 + 63) / 64) * 8; }   // 8-byte elements per sector of hdesc: ring groups padded to whole 64-byte k-steps
 constexpr int hkey_halfs(int S) { return ((S + 31) / 32) * 32; }         // the unit-norm fp16 sector key behind the copy, zero padded to whole k-steps
 constexpr int hkey_store_halfs(int S) { return hkey_halfs(S) + 8; }      // ... followed by the key's norm as a float (and 12 spare bytes)

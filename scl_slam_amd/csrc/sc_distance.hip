@@ -946,7 +946,7 @@ __device__ __forceinline__ void sc_wave_body(const ScArgs &a, const int bid, con
             prev = m; first = false;
         }
         if (lane == 0) *a.done_counter = 0u;            // armed for the next launch (stream ordered)
-        if (lane == 0 && a.t_min) *a.t_min = 0xffffffffu;   // survivors pass: every workgroup has read the minimum by now
+        if (lane == 0 && a.t_min) { *a.t_min = 0xffffffffu; a.t_min[kTminEpsOffset] = 0u; }   // survivors pass: every workgroup has read the minimum (and the bound) by now
     }
 }
 
@@ -975,7 +975,9 @@ __global__ __launch_bounds__(MAXT) void sc_distance_survivors_kernel(const ScArg
     float thr = __int_as_float(0xff800000);                                      // nothing screened: only the "score exactly" marks pass
     if (tm != 0xffffffffu) {
         const unsigned int b = (tm >> 31) ? (tm & 0x7fffffffu) : ~tm;            // inverse of the ordered image
-        thr = __int_as_float((int)b) + a.two_eps;
+        const unsigned int ew = a.t_min[kTminEpsOffset];                       // the launch's largest per-pair bound (0: not recorded)
+        const float two_eps = ew ? fminf(2.0f * __uint_as_float(ew) * 1.0001f, a.two_eps) : a.two_eps;
+        thr = __int_as_float((int)b) + two_eps;
     }
     // Every wave owns a contiguous part of the range and walks it 64 entries at a time (coalesced reads; a thread-owned
     // chunk made every load a 64-line gather): count, prefix over the waves, then the same walk writes the list --

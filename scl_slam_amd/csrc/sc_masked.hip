@@ -305,7 +305,8 @@ __global__ __launch_bounds__(kSmallWaves * kWave) void sc_small_exact_kernel(Sma
     float thr = __int_as_float(0xff800000);                                      // nothing screened: only the "score exactly" marks pass
     if (tm != 0xffffffffu) {
         const unsigned int b = (tm >> 31) ? (tm & 0x7fffffffu) : ~tm;            // inverse of the ordered image
-        thr = __int_as_float((int)b) + sa.two_eps;
+        const unsigned int ew = q.t_min[kTminEpsOffset];                       // the launch's largest per-pair bound (0: not recorded)
+        thr = __int_as_float((int)b) + (ew ? fminf(2.0f * __uint_as_float(ew) * 1.0001f, sa.two_eps) : sa.two_eps);
     }
     if (threadIdx.x == 0) *n_list = 0;
     {
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(kSmallWaves * kWave) void sc_small_exact_kernel(Sma
             const unsigned long long b = (bd >> 63) ? (bd & 0x7fffffffffffffffull) : ~bd;
             o[0] = __longlong_as_double((long long)b); o[1] = (double)(int)(bp >> 8); o[2] = (double)(int)(bp & 0xff);
         }
-        *q.t_min = 0xffffffffu;                                                  // re-armed for the next screening pass of this buffer set
+        *q.t_min = 0xffffffffu; q.t_min[kTminEpsOffset] = 0u;                    // re-armed for the next screening pass of this buffer set
         if (sa.surv_stats) {
             atomicAdd(sa.surv_stats, (unsigned long long)total);
             atomicMax(sa.surv_stats + 1, (unsigned long long)total);

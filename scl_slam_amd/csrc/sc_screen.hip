@@ -795,6 +795,7 @@ __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const 
     const int n4 = lane >> 2, jl = lane & 3;             // load layout: four consecutive lanes = 64 consecutive bytes of keyframe n
     const int ngroups = (a.n + kGroup - 1) / kGroup;
     float run_min = __int_as_float(0x7f800000);                                  // wave 0: min d~ over screened keyframes
+    float run_eps = 0.0f;                                                        // ... and the largest per-pair bound
     // first shifts (K0's output) of this group's keyframe n4, and of the next group's: requested one group ahead
     auto start_of = [&](int grp) {
         const int ci = grp * kGroup + n4;
@@ -913,10 +914,12 @@ __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const 
             // per shift the interval the reference's distance lies in (as the second form's finishing: the two descriptors' recorded
             // rounding-error norms over n_eff + this form's accumulation -- a wave's chain of NST products of 32 terms, NWV partials)
             const float kInfF = __int_as_float(0x7f800000);
+            const bool want_mask = a.out_smask != nullptr;
             const float e_pair = (q_err + kerr) * 1.002f;
             const bool e_ok = e_pair >= 0.0f && e_pair < 1.0f;
             constexpr float kAcc1 = (float)(NST * 32 + NWV + 4) * 1.1920929e-7f * 1.002f + 2.0e-6f;
             float dlo[MT][4], hi_min = kInfF;
+            int ne_min = 0x7fffffff;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 f4v s = part_cur[m * kWave + lane];
@@ -935,9 +938,12 @@ __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const 
                     }
                     const float d = 1.0f - s[r] / (float)ne;
                     if (t < W && ne > 0 && d < dmin) dmin = d;                   // n_eff = 0: 0/0 in the reference, never wins
-                    const float et = e_ok ? fminf(e_pair / (float)ne + kAcc1, kScreenEps) : kScreenEps;
+                    if (t < W && ne > 0) ne_min = ne < ne_min ? ne : ne_min;
                     dlo[m][r] = kInfF;
-                    if (t < W && ne > 0) { dlo[m][r] = d - et; hi_min = fminf(hi_min, d + et); }
+                    if (want_mask && t < W && ne > 0) {
+                        const float et = e_ok ? fminf(e_pair / (float)ne + kAcc1, kScreenEps) : kScreenEps;
+                        dlo[m][r] = d - et; hi_min = fminf(hi_min, d + et);
+                    }
                 }
             }
             dmin = fminf(dmin, __shfl_xor(dmin, 16, kWave));
@@ -963,12 +969,18 @@ __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const 
                 if (mine) a.out_smask[ci_n] = b_open ? 0u : mb;
             }
             float contrib = (mine && !exact_only) ? dmin : __int_as_float(0x7f800000);
+            // the pair's bound on |d~ - d| (fewest effective sectors of its shifts), into the launch's largest
+            ne_min = min(ne_min, __shfl_xor(ne_min, 16, kWave));
+            ne_min = min(ne_min, __shfl_xor(ne_min, 32, kWave));
+            float peps = (mine && !exact_only && ne_min != 0x7fffffff) ? (e_ok ? fminf(e_pair / (float)ne_min + kAcc1, kScreenEps) : kScreenEps) : 0.0f;
 #pragma unroll
-            for (int off = 8; off > 0; off >>= 1) contrib = fminf(contrib, __shfl_xor(contrib, off, kWave));
+            for (int off = 8; off > 0; off >>= 1) { contrib = fminf(contrib, __shfl_xor(contrib, off, kWave)); peps = fmaxf(peps, __shfl_xor(peps, off, kWave)); }
             run_min = fminf(run_min, __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(contrib))));
+            run_eps = fmaxf(run_eps, __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(peps))));
         }
     }
     if (wave == 0 && lane == 0 && run_min < __int_as_float(0x7f800000)) atomicMin(a.t_min, float_to_ordered_u(run_min));
+    if (wave == 0 && lane == 0 && run_eps > 0.0f) atomicMax(a.t_min + kTminEpsOffset, __float_as_uint(run_eps));
 }
 
 // One launch = the screening products of a batch of scans and, in further workgroups of the same grid, the alignment of
@@ -1051,7 +1063,9 @@ __global__ __launch_bounds__(1024) void sc_select_kernel(SelectBatchArgs sb)
     float thr;
     {
         const unsigned int b = (tm >> 31) ? (tm & 0x7fffffffu) : ~tm;            // inverse of float_to_ordered_u
-        thr = tm == 0xffffffffu ? __int_as_float(0xff800000) : __int_as_float((int)b) + 2.0f * kScreenEps;
+        const unsigned int ew = a.t_min[kTminEpsOffset];                       // the launch's largest per-pair bound (0: not recorded)
+        const float two_eps = ew ? fminf(2.0f * __uint_as_float(ew) * 1.0001f, 2.0f * kScreenEps) : 2.0f * kScreenEps;
+        thr = tm == 0xffffffffu ? __int_as_float(0xff800000) : __int_as_float((int)b) + two_eps;
     }
     // Every wave owns a contiguous part of the range and walks it 4 x 64 entries at a time (four independent loads in flight,
     // one barrier in all: the walk in steps of the whole workgroup paid a load's latency and three barriers per step): count,
@@ -1086,7 +1100,7 @@ __global__ __launch_bounds__(1024) void sc_select_kernel(SelectBatchArgs sb)
                 before += __popcll(m);
             }
         }
-        if (threadIdx.x == 0 && a.survivors) { *a.n_surv = total; *a.t_min = 0xffffffffu; }   // armed for the next launch (stream ordered)
+        if (threadIdx.x == 0 && a.survivors) { *a.n_surv = total; *a.t_min = 0xffffffffu; a.t_min[kTminEpsOffset] = 0u; }   // armed for the next launch (stream ordered)
         if (threadIdx.x == 0 && a.survivors && a.surv_stats) {
             atomicAdd(a.surv_stats, (unsigned long long)total);
             atomicMax(a.surv_stats + 1, (unsigned long long)total);
@@ -1619,8 +1633,10 @@ __device__ __forceinline__ FinishLoads<RG, S, W> sc_screen2_finish_request(const
     }
     return l;
 }
-template <int RG, int S, int W>
-__device__ __forceinline__ float sc_screen2_finish_compute(const ScreenArgs &a, const int ci, const uint4 *rotq, const bool q_bad, const float q_err, FinishLoads<RG, S, W> &l)
+// MASKS = false: an instance for launches that ask for no shift masks (the 64 x 120 stream's tail launch): no per-shift interval ends
+// are kept -- thirteen registers that the tail launch, built for four waves per SIMD beside the alignment, does not have
+template <int RG, int S, int W, bool MASKS = true>
+__device__ __forceinline__ float sc_screen2_finish_compute(const ScreenArgs &a, const int ci, const uint4 *rotq, const bool q_bad, const float q_err, FinishLoads<RG, S, W> &l, float &pair_eps)
 {
     using C = S2Cfg<RG, S, W>;
     using L = FinishLoads<RG, S, W>;
@@ -1634,12 +1650,14 @@ __device__ __forceinline__ float sc_screen2_finish_compute(const ScreenArgs &a, 
     // ... and how far it can be from the reference's distance of that shift: (E_q + E_k)(1 + 1e-3) / n_eff for the fp16 rounding of the
     // two descriptors' unit columns on their recorded error norms (make_sc.hip), screen2_acc_eps for the accumulation and the fp32
     // scaling / quotient / difference; never more than the worst-case kScreenEps
+    const bool want_mask = MASKS && a.out_smask != nullptr;
     const float e_pair = (q_err + l.kerr) * 1.002f;
     const bool e_ok = e_pair >= 0.0f && e_pair < 1.0f;                       // (NaN / absurd values: the worst-case bound)
     float hi_min = kInf;                                                     // the smallest upper bound of a shift's exact distance
-    float dlo[W];
+    int ne_min = 0x7fffffff;                                                 // fewest effective sectors over the pair's shifts
+    float dlo[MASKS ? W : 1];
 #pragma unroll
-    for (int t = 0; t < W; ++t) { dsh[t] = kInf; dlo[t] = kInf; }
+    for (int t = 0; t < W; ++t) { dsh[t] = kInf; if (MASKS) dlo[MASKS ? t : 0] = kInf; }
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
 #pragma unroll
@@ -1661,21 +1679,26 @@ __device__ __forceinline__ float sc_screen2_finish_compute(const ScreenArgs &a, 
                 }
                 const float d = 1.0f - sm[r] / (float)ne;
                 if (ne > 0 && d < dmin) dmin = d;
+                if (ne > 0) ne_min = ne < ne_min ? ne : ne_min;
                 dsh[t] = ne > 0 ? d : kInf;
-                const float et = e_ok ? fminf(e_pair / (float)ne + screen2_acc_eps<S>(), kScreenEps) : kScreenEps;
-                if (ne > 0) { dlo[t] = d - et; hi_min = fminf(hi_min, d + et); }
+                if (want_mask && ne > 0) {                                   // (wave uniform: the stream form of 64 x 120 asks for no masks)
+                    const float et = e_ok ? fminf(e_pair / (float)ne + screen2_acc_eps<S>(), kScreenEps) : kScreenEps;
+                    dlo[MASKS ? t : 0] = d - et; hi_min = fminf(hi_min, d + et);
+                }
             }
         }
     }
     const bool exact_only = q_bad || l.kflag != 0 || b_open || !(dmin == dmin);
     a.out_approx[ci] = exact_only ? __int_as_float(0xff800000) : dmin;
-    if (a.out_smask) {
+    // this pair's bound on |d~ - d| (every shift's is at most this): into the launch's largest (kTminEpsOffset)
+    pair_eps = (exact_only || ne_min == 0x7fffffff) ? 0.0f : (e_ok ? fminf(e_pair / (float)ne_min + screen2_acc_eps<S>(), kScreenEps) : kScreenEps);
+    if (MASKS && a.out_smask) {
         // a shift can hold (or tie for) the pair's exact minimum only if the lower end of its interval does not lie above the
         // smallest upper end (NaN sums compare false everywhere: such a pair is exact_only); an undecided alignment has no first
         // shift: mask 0
         unsigned int m = 0u;
 #pragma unroll
-        for (int t = 0; t < W; ++t) m |= ((exact_only || dlo[t] <= hi_min) ? 1u : 0u) << t;
+        for (int t = 0; t < W; ++t) m |= ((exact_only || dlo[MASKS ? t : 0] <= hi_min) ? 1u : 0u) << t;
         a.out_smask[ci] = b_open ? 0u : m;
     }
     // nanoflann's metric (nanoflann.hpp:383-408) for the ring-key top-k: four dimensions per step, fp32, groups accumulated in
@@ -1695,20 +1718,20 @@ __device__ __forceinline__ float sc_screen2_finish_compute(const ScreenArgs &a, 
     return exact_only ? kInf : dmin;
 }
 template <int RG, int S, int W>
-__device__ __forceinline__ float sc_screen2_finish_pair(const Screen2Args &fa, const ScreenArgs &a, const int qi, const int ci, const uint4 *rotq, const bool q_bad)
+__device__ __forceinline__ float sc_screen2_finish_pair(const Screen2Args &fa, const ScreenArgs &a, const int qi, const int ci, const uint4 *rotq, const bool q_bad, float &pair_eps)
 {
     FinishLoads<RG, S, W> l = sc_screen2_finish_request<RG, S, W>(fa, a, qi, ci);
-    return sc_screen2_finish_compute<RG, S, W>(a, ci, rotq, q_bad, __uint_as_float(a.q_kmask[6]), l);
+    return sc_screen2_finish_compute<RG, S, W>(a, ci, rotq, q_bad, __uint_as_float(a.q_kmask[6]), l, pair_eps);
 }
 
-template <int RG, int S, int W>
+template <int RG, int S, int W, bool MASKS = true>
 __device__ __forceinline__ void sc_screen2_finish_body(const Screen2Args &fa, const int qi, const int chunk)
 {
     constexpr int NW64 = (S + 63) / 64, MW = (NW64 + 1) / 2;
     const ScreenBatchArgs &ab = fa.prod;
     const ScreenArgs a = screen_args_of(ab, qi);
     __shared__ uint4 rotq[S * MW];
-    __shared__ float wmin[4];
+    __shared__ float wmin[4], wmax[4];
     const int ci = (int)(chunk * blockDim.x + threadIdx.x);
     const bool live = ci < a.n;
     FinishLoads<RG, S, W> ld = sc_screen2_finish_request<RG, S, W>(fa, a, qi, live ? ci : 0);   // (a.n >= 1 where a workgroup was launched for the scan)
@@ -1716,15 +1739,18 @@ __device__ __forceinline__ void sc_screen2_finish_body(const Screen2Args &fa, co
     const bool q_bad = a.q_kmask[7] != 0;
     __syncthreads();
     const float kInf = __int_as_float(0x7f800000);
-    float contrib = kInf;
-    if (live) contrib = sc_screen2_finish_compute<RG, S, W>(a, ci, rotq, q_bad, __uint_as_float(a.q_kmask[6]), ld);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) contrib = fminf(contrib, __shfl_xor(contrib, off, kWave));
-    if ((threadIdx.x & 63) == 0) wmin[threadIdx.x >> 6] = contrib;
+    float contrib = kInf, peps = 0.0f;
+    if (live) contrib = sc_screen2_finish_compute<RG, S, W, MASKS>(a, ci, rotq, q_bad, __uint_as_float(a.q_kmask[6]), ld, peps);
+    // (wave minimum / maximum by DPP row exchanges: twelve ds_bpermute round trips per thread otherwise)
+    contrib = -wave_max_f32_dpp(-contrib);
+    peps = wave_max_f32_dpp(peps);
+    if ((threadIdx.x & 63) == 0) { wmin[threadIdx.x >> 6] = contrib; wmax[threadIdx.x >> 6] = peps; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const float m = fminf(fminf(wmin[0], wmin[1]), fminf(wmin[2], wmin[3]));
         if (m < kInf) atomicMin(a.t_min, float_to_ordered_u(m));
+        const float pe = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        if (pe > 0.0f) atomicMax(a.t_min + kTminEpsOffset, __float_as_uint(pe));      // (positive floats order like their bits)
     }
 }
 
@@ -1746,11 +1772,12 @@ __device__ __forceinline__ void sc_screen2_finish_waves(const Screen2Args &fa, c
         const bool q_bad = a.q_kmask[7] != 0;
         wave_fence();
         const int ci = blk * kWave + lane;
-        float contrib = kInf;
-        if (ci < a.n) contrib = sc_screen2_finish_pair<RG, S, W>(fa, a, qi, ci, rotq, q_bad);
+        float contrib = kInf, peps = 0.0f;
+        if (ci < a.n) contrib = sc_screen2_finish_pair<RG, S, W>(fa, a, qi, ci, rotq, q_bad, peps);
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) contrib = fminf(contrib, __shfl_xor(contrib, off, kWave));
+        for (int off = 32; off > 0; off >>= 1) { contrib = fminf(contrib, __shfl_xor(contrib, off, kWave)); peps = fmaxf(peps, __shfl_xor(peps, off, kWave)); }
         if (lane == 0 && contrib < kInf) atomicMin(a.t_min, float_to_ordered_u(contrib));
+        if (lane == 0 && peps > 0.0f) atomicMax(a.t_min + kTminEpsOffset, __float_as_uint(peps));
     }
 }
 
@@ -1774,7 +1801,7 @@ __global__ __launch_bounds__(kScreenWaves * kWave, 2) void sc_screen2_tail_kerne
 }
 
 // ... with the alignment in its second form (one keyframe against the next batch's scans per wave)
-template <int RG, int S, int W>
+template <int RG, int S, int W, bool MASKS = true>
 __global__ __launch_bounds__(kScreenWaves * kWave, Align2Cfg<S>::OCC) void sc_screen2_tail2_kernel(Screen2Args fa, ScreenBatchArgs nb, const unsigned char *halign, int u_lo, int u_n,
                                                                                      int align_blocks, int chunks)
 {
@@ -1791,7 +1818,7 @@ __global__ __launch_bounds__(kScreenWaves * kWave, Align2Cfg<S>::OCC) void sc_sc
         return;
     }
     const int fb = b - align_blocks;
-    sc_screen2_finish_body<RG, S, W>(fa, fb / chunks, fb - (fb / chunks) * chunks);
+    sc_screen2_finish_body<RG, S, W, MASKS>(fa, fb / chunks, fb - (fb / chunks) * chunks);
 }
 
 static bool screen_second_form()
@@ -2050,8 +2077,10 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
                     int ulo, un;
                     union_of(*next, &ulo, &un);
                     const int ablocks = align2_blocks(un);
-                    hipLaunchKernelGGL((sc_screen2_tail2_kernel<RG, S, W>), dim3(ablocks + chunks * sb.nq), dim3(kScreenWaves * kWave), lds_a2, stream, f2, nb, db.halign, ulo, un,
-                                       ablocks, chunks);
+                    if (sb.smask) hipLaunchKernelGGL((sc_screen2_tail2_kernel<RG, S, W, true>), dim3(ablocks + chunks * sb.nq), dim3(kScreenWaves * kWave), lds_a2, stream, f2, nb, db.halign, ulo, un,
+                                                     ablocks, chunks);
+                    else hipLaunchKernelGGL((sc_screen2_tail2_kernel<RG, S, W, false>), dim3(ablocks + chunks * sb.nq), dim3(kScreenWaves * kWave), lds_a2, stream, f2, nb, db.halign, ulo, un,
+                                            ablocks, chunks);
                 } else {
                     const int ng2 = (nmax2 + kGroup - 1) / kGroup;
                     int per_q = 3 * num_cu / next->nq;
