@@ -17,7 +17,7 @@ from scl_slam_amd.synth import synth_descriptors  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 t_end = time.time() + budget
-seed, pairs, wins, streams = 0, 0, 0, 0
+seed, pairs, wins, streams, mats = 0, 0, 0, 0, 0
 while time.time() < t_end:
     seed += 1
     rs = np.random.RandomState(seed)
@@ -56,6 +56,17 @@ while time.time() < t_end:
         nn1, sh1, d1 = eng.detect_full_range(int(qs[i]), int(los[i]), int(his[i]))
         assert (int(nn_s[i]), int(sh_s[i])) == (nn1, sh1) and np.float64(d_s[i]).view(np.uint64) == np.float64(d1).view(np.uint64), (seed, i, qs[i], los[i], his[i])
         streams += 1
+    # the exact distance matrix (screened grids: alignment + screening + shift masks, then the open shifts in fp64): 1 to 19 rows over a
+    # random sub-range against the 13-shift kernel of the sampled pairs' path above (another program), entry for entry
+    if S != 60:
+        rows = rs.randint(0, n, size=int(rs.randint(1, 20))).astype(np.int32)
+        lo_m = int(rs.randint(0, n - 1)); hi_m = int(rs.randint(lo_m + 1, n + 1))
+        dm, sm = eng.sc_distance_matrix(rows, lo_m, hi_m)
+        for r, q in enumerate(rows):
+            d1, s1 = eng.sc_distance_batch(int(q), cand=np.arange(lo_m, hi_m, dtype=np.int32))
+            assert np.array_equal(dm[r].view(np.uint64), d1.view(np.uint64)) and np.array_equal(sm[r], s1), (seed, int(q), lo_m, hi_m)
+            mats += hi_m - lo_m
     eng.close()
-    print(f"seed {seed}: {R}x{S} n={n} contrast={contrast}: ok ({pairs} pairs, {wins} winners, {streams} streamed scans so far)", flush=True)
-print(f"soak done: {seed} databases, {pairs} pairs bit-identical, {wins} full-DB winners consistent, {streams} streamed scans equal to their one-scan calls")
+    print(f"seed {seed}: {R}x{S} n={n} contrast={contrast}: ok ({pairs} pairs, {wins} winners, {streams} streamed scans, {mats} matrix entries so far)", flush=True)
+print(f"soak done: {seed} databases, {pairs} pairs bit-identical, {wins} full-DB winners consistent, {streams} streamed scans equal to their one-scan calls, "
+      f"{mats} distance-matrix entries equal to the 13-shift kernel's")

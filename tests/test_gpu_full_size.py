@@ -68,3 +68,25 @@ def test_ring_shift_of_the_query_shifts_the_answer(world):
         e.stage_query(np.roll(q, s, axis=1))
         nn, sh, d = e.detect_full_range(-1, 0, N - 100)
         assert nn == nn0 and sh == (sh0 + s) % S and abs(d - d0) < 1e-12
+
+
+def test_distance_matrix_equals_the_13_shift_kernel_on_the_whole_database(world):
+    """scl_sc_distance_matrix at BASELINE configs[1]'s size: alignment + screening + shift masks from the recorded rounding-error norms,
+    then sc_matrix_kernel at the open shifts -- against scl_sc_distance_batch, the exact kernel that evaluates all 13 shifts of
+    every pair (another program: one wave per pair, the candidate rotating under the staged scan).  Every entry of 23 rows x 9 900
+    keyframes must agree bit for bit (23 = a group of 16, one of 7: odd, so a workgroup with one scan; ranges that are not a whole
+    number of workgroups), and the checker confirms a sample."""
+    e, descs, planted = world
+    cfg = ob.make_config(R=R, S=S)
+    rs = np.random.RandomState(9)
+    qs = np.array([N - 1 - i for i in range(20)] + [17, 4242, N - 40], dtype=np.int32)
+    for lo, hi in ((0, N - 100), (1234, 1234 + 4097)):
+        dist, sh = e.sc_distance_matrix(qs, lo, hi)
+        assert dist.shape == (len(qs), hi - lo)
+        for r, q in enumerate(qs):
+            d1, s1 = e.sc_distance_batch(int(q), cand=np.arange(lo, hi, dtype=np.int32))
+            assert np.array_equal(dist[r].view(np.uint64), d1.view(np.uint64)) and np.array_equal(sh[r], s1), (q, lo, hi)
+        for r in (0, 21):
+            for c in rs.randint(lo, hi, 12):
+                dc, sc = ob.distance(cfg, descs[qs[r]], descs[int(c)], fast=True)
+                assert sc == sh[r][c - lo] and np.float64(dc).view(np.uint64) == dist[r][c - lo:c - lo + 1].view(np.uint64)[0]
