@@ -172,9 +172,6 @@ __global__ __launch_bounds__(C::WAVES * kWave) void sc_matrix_kernel(MatrixArgs 
 
     int item = wave;                                                            // (wave uniform)
     if (item >= r_n) return;
-#ifdef MAT_TOUCH
-    int sink = 0;
-#endif
     // what an item needs from memory, requested one item ahead: first shifts and masks of its pairs, the keyframe's norms
     int pf_first[NS]; unsigned int pf_mask[NS]; double pf_nk[CPL];
     auto request = [&](const int it) {
@@ -221,17 +218,6 @@ __global__ __launch_bounds__(C::WAVES * kWave) void sc_matrix_kernel(MatrixArgs 
         next_item = __builtin_amdgcn_readfirstlane(next_item);
         const bool has_next = next_item < r_n;
         const float4 *knext_item = ma.desc + (size_t)(ma.lo + r_lo + (has_next ? next_item : item)) * kf_floats4;
-#ifdef MAT_TOUCH
-        // The NEXT keyframe's cache lines, touched a whole item ahead (the ring groups themselves are requested PD groups ahead -- enough
-        // for an L2 hit, not for a miss): the workgroups of a range walk the same keyframes, so each touches every NG-th line and together
-        // they bring the keyframe into their XCD's L2.  One load per item; its value is folded into a sink at the item's end.
-        int touched = 0;
-        {
-            constexpr int kLines = RG * S * 16 / 128;
-            const int line = g + NG * lane;
-            if (has_next && line < kLines) touched = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(knext_item) + (size_t)line * 128);
-        }
-#endif
 
         double best[NS]; int bshift[NS];
 #pragma unroll
@@ -342,14 +328,8 @@ __global__ __launch_bounds__(C::WAVES * kWave) void sc_matrix_kernel(MatrixArgs 
                 }
             }
         }
-#ifdef MAT_TOUCH
-        sink += touched;
-#endif
         item = has_next ? next_item : r_n;
     }
-#ifdef MAT_TOUCH
-    if (sink == 0x5a5a5a5a && (int)blockIdx.x < 0) ma.out_shift[0] = sink;      // (never: keeps the touches alive)
-#endif
 }
 
 template <class C>
