@@ -96,6 +96,21 @@ int sync(scl_engine *e)
     return SCL_OK;
 }
 
+// The end of a SHORT blocking call (tens of microseconds of device time): an event behind its last launch, polled for up to 300 us,
+// then a sleep in the runtime -- hipStreamSynchronize wakes up tens of microseconds late, a fifth of such a call.
+int sync_short(scl_engine *e)
+{
+    if (!e->ev_call) SCL_HIP(e, hipEventCreateWithFlags(&e->ev_call, hipEventDisableTiming));
+    SCL_HIP(e, hipEventRecord(e->ev_call, e->stream));
+    hipError_t q = hipErrorNotReady;
+    const auto t0 = std::chrono::steady_clock::now();
+    while ((q = hipEventQuery(e->ev_call)) == hipErrorNotReady)
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) { q = hipEventSynchronize(e->ev_call); break; }
+    SCL_HIP(e, q);
+    collect_profile(e);
+    return SCL_OK;
+}
+
 template <class T>
 int dev_alloc(scl_engine *e, T **p, size_t count)
 {
@@ -331,29 +346,27 @@ int topk_enqueue_locked(scl_engine *e, int query, int lo, int hi, int k, float e
     if ((rc = ensure_pairs(e, (size_t)k))) return rc;
     if ((rc = launch_topk(e, q, lo, hi, k, eps))) return rc;
     *have_dist = hi > lo && want_dist;
+    const size_t need = (size_t)k * (sizeof(int) * 2 + sizeof(float) + sizeof(double));
+    if ((rc = ensure_pinned(e, need))) return rc;
+    if (*have_dist && k <= 16 && sc_cand_exact_supported(db_view(e), e->SR) && !scl_lab_int("SCL_CAND_EXACT_OFF", 0)) {
+        // the reference-faithful detection's k (3) candidates: one workgroup aligns and scores them and writes the block (sc_masked.hip)
+        ProfScope ps(e, P_SC);
+        SCL_HIP(e, launch_sc_cand_exact(db_view(e), q, e->SR, k, e->d_topk_idx, e->d_topk_d2, e->h_pinned, e->stream));
+        if (ps.active()) e->prof.sc_distance_pairs += (uint64_t)k;
+        return SCL_OK;
+    }
     if (*have_dist) {
         if ((rc = launch_distance(e, q, e->d_topk_idx, 0, k))) return rc;
     }
-    const size_t need = (size_t)k * (sizeof(int) * 2 + sizeof(float) + sizeof(double));
-    if ((rc = ensure_pinned(e, need))) return rc;
-    char *h = static_cast<char *>(e->h_pinned);
-    int *h_idx = reinterpret_cast<int *>(h);
-    float *h_d2 = reinterpret_cast<float *>(h + sizeof(int) * k);
-    double *h_dist = reinterpret_cast<double *>(h + (sizeof(int) + sizeof(float)) * k);
-    int *h_shift = reinterpret_cast<int *>(h + (sizeof(int) + sizeof(float) + sizeof(double)) * k);
-    SCL_HIP(e, hipMemcpyAsync(h_idx, e->d_topk_idx, sizeof(int) * k, hipMemcpyDeviceToHost, e->stream));
-    SCL_HIP(e, hipMemcpyAsync(h_d2, e->d_topk_d2, sizeof(float) * k, hipMemcpyDeviceToHost, e->stream));
-    if (*have_dist) {
-        SCL_HIP(e, hipMemcpyAsync(h_dist, e->d_dist, sizeof(double) * k, hipMemcpyDeviceToHost, e->stream));
-        SCL_HIP(e, hipMemcpyAsync(h_shift, e->d_shift, sizeof(int) * k, hipMemcpyDeviceToHost, e->stream));
-    }
+    // the k results travel as ONE block written by a kernel into pinned memory (four copies of a few bytes cost more than the search)
+    SCL_HIP(e, launch_topk_pack(e->d_topk_idx, e->d_topk_d2, e->d_dist, e->d_shift, k, *have_dist, e->h_pinned, e->stream));
     return SCL_OK;
 }
 
 int topk_finish_locked(scl_engine *e, int k, bool have_dist, int *idx, float *d2, double *dist, int *shift, int *found)
 {
     int rc;
-    if ((rc = sync(e))) return rc;
+    if ((rc = sync_short(e))) return rc;
     char *h = static_cast<char *>(e->h_pinned);
     const int *h_idx = reinterpret_cast<int *>(h);
     const float *h_d2 = reinterpret_cast<float *>(h + sizeof(int) * k);
@@ -586,6 +599,7 @@ int scl_destroy(scl_engine *e)
     if (e->stream_alt) { (void)hipStreamSynchronize(e->stream_alt); (void)hipStreamDestroy(e->stream_alt); }
     if (e->h_pinned) (void)hipHostFree(e->h_pinned);
     if (e->h_out3) (void)hipHostFree(e->h_out3);
+    if (e->ev_call) (void)hipEventDestroy(e->ev_call);
     for (int i = 0; i < scl_engine::kSlots; ++i) if (e->ev_done[i]) (void)hipEventDestroy(e->ev_done[i]);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);

@@ -35,6 +35,7 @@ struct scl_engine {
     double *h_out3 = nullptr;                              // pinned, device-visible: the arg-min kernel writes it directly
     static constexpr int kSlots = 8;                       // full-DB passes in flight (submit/collect)
     hipEvent_t ev_done[kSlots] = {nullptr};
+    hipEvent_t ev_call = nullptr;                          // end of a short blocking call's launches: polled (sync_short)
     int slot_lo[kSlots] = {0}; bool slot_busy[kSlots] = {false}; bool slot_empty[kSlots] = {false};
     int slot_ev[kSlots] = {0};                             // which slot's event completes this one (batched launches share one)
     unsigned next_slot = 0;

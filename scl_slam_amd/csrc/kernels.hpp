@@ -157,6 +157,14 @@ struct SmallExactArgs {
     int nq, k; float exclude_eps, two_eps; unsigned long long *surv_stats;
     SmallExactQuery q[kMaxQueryBatch];
 };
+// ---- the k candidates of a ring-key search, scored by one workgroup (sc_masked.hip: sc_cand_exact_kernel): candidate cand_idx[i] (-1:
+// none -> (1e7, 0)) against the query; idx[k] | d2[k] | dist[k] | shift[k] written to pinned_out ----
+struct CandExactArgs {
+    const float4 *desc; const double *norm; const double *vkey; const float4 *q_desc; const double *q_norm; const double *q_vkey;
+    int k; const int *cand_idx; const float *cand_d2; char *out;
+};
+bool sc_cand_exact_supported(const struct DbView &db, int SR);
+hipError_t launch_sc_cand_exact(const struct DbView &db, const struct QueryView &q, int SR, int k, const int *cand_idx, const float *cand_d2, void *pinned_out, hipStream_t stream);
 bool sc_small_exact_supported(const struct DbView &db, int SR);
 hipError_t launch_sc_small_exact(const struct DbView &db, int SR, const SmallExactArgs &args, hipStream_t stream);
 bool sc_masked_supported(const struct DbView &db, int SR);
@@ -259,6 +267,8 @@ hipError_t launch_full_epilogue(const double *dist, const int *shift, const floa
 constexpr int kTopkMaxBlocks = 256;
 constexpr int kTopkMaxK = 64;
 static_assert(kTopkMaxK == kTailTopMaxK, "top-k sets share one size");
+// idx[k] | d2[k] | dist[k] | shift[k] into one block of pinned host memory (k results of a top-k and their SC distances)
+hipError_t launch_topk_pack(const int *idx, const float *d2, const double *dist, const int *shift, int k, bool have_dist, void *pinned_out, hipStream_t stream);
 hipError_t launch_ringkey_topk(const DbView &db, const float *qkey, int lo, int hi, int k,
                                float exclude_eps, unsigned long long *scratch,
                                int *out_idx, float *out_d2, hipStream_t stream);

@@ -61,12 +61,15 @@ struct MaskedCfg {
 // column-major fp32 with QCOLS columns, nq: its norms extended alike), the candidate's fp32 rows kd and norms kn from memory, simrow:
 // the wave's TM rows of S similarities.  best / bshift: the smallest distance and its shift VALUE (ties: the lowest), kInf / INT_MAX
 // when no shift has a finite distance.
-template <int RG, int S, int W, int PD = MASKED_PD>
+// ALL: the caller opens every one of TM = W shifts (mask = all ones: slot u is shift first + u): the dots then run without branches, the
+// scan's LDS reads one slot ahead of the products that use them, every address a base register + an immediate -- for a lone wave
+// (sc_cand_exact_kernel: one wave per candidate, nothing else on the CU) the read latency is otherwise paid 26 times per ring group.
+template <int RG, int S, int W, int PD = MASKED_PD, int TM = kMaskTMax, bool ALL = false>
 __device__ __forceinline__ void masked_pair(const unsigned char *Qs, const double *nq, double *simrow, const float4 *kd, const double *kn,
                                             const int first, unsigned int mask, const int lane, double &best, int &bshift)
 {
     using C = MaskedCfg<RG, S, W>;
-    constexpr int CPL = C::CPL, PITCH = C::PITCH, TM = kMaskTMax;
+    constexpr int CPL = C::CPL, PITCH = C::PITCH;
     const bool active = lane < kMaskLanes;
     const int ll = active ? lane : kMaskLanes - 1;
     const double kInf = __longlong_as_double(0x7ff0000000000000LL);
@@ -94,6 +97,57 @@ __device__ __forceinline__ void masked_pair(const unsigned char *Qs, const doubl
 #pragma unroll
             for (int j = 0; j < CPL; ++j) kbuf[d][j] = kd[(size_t)(d < RG ? d : RG - 1) * S + yc[j]];
         static_assert(RG % PD == 0, "ring groups in whole prefetch rounds");
+        if constexpr (ALL) {
+            const unsigned char *qb[CPL];                                       // the scan's column that meets this lane's at slot 0
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) qb[j] = Qs + (size_t)(ll + kMaskLanes * j) * PITCH;
+            float4 qv[2][CPL];
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) qv[0][j] = *reinterpret_cast<const float4 *>(qb[j]);
+#pragma unroll 1
+            for (int r0 = 0; r0 < RG; r0 += PD) {
+#pragma unroll
+                for (int dd = 0; dd < PD; ++dd) {
+                    const int rg = r0 + dd;
+                    double kx[CPL][4];
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        const float4 kv = kbuf[dd][j];
+                        kx[j][0] = (double)kv.x; kx[j][1] = (double)kv.y; kx[j][2] = (double)kv.z; kx[j][3] = (double)kv.w;
+                    }
+                    {
+                        const int rn = rg + PD < RG ? rg + PD : RG - 1;
+#pragma unroll
+                        for (int j = 0; j < CPL; ++j) kbuf[dd][j] = kd[(size_t)rn * S + yc[j]];
+                    }
+#pragma unroll
+                    for (int u = 0; u < TM; ++u) {
+                        const int cur = (dd * TM + u) & 1, nxt = cur ^ 1;     // (compile time: a block starts with its first slot in set 0)
+                        // the slot that follows: the next shift of this ring group, or the first shift of the next ring group (past the
+                        // last group: the column's padding, unused)
+                        const int un = u + 1 < TM ? u + 1 : 0, off = un * PITCH + (u + 1 < TM ? dd : dd + 1) * 16;
+#pragma unroll
+                        for (int j = 0; j < CPL; ++j) qv[nxt][j] = *reinterpret_cast<const float4 *>(qb[j] + off);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < CPL; ++j) {
+                            const float4 q = qv[cur][j];
+                            acc[u][j] = fma(kx[j][0], (double)q.x, acc[u][j]);
+                            acc[u][j] = fma(kx[j][1], (double)q.y, acc[u][j]);
+                            acc[u][j] = fma(kx[j][2], (double)q.z, acc[u][j]);
+                            acc[u][j] = fma(kx[j][3], (double)q.w, acc[u][j]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if ((PD * TM) & 1) {                                            // an odd number of slots per block: the prefetched one moves to set 0
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) qv[0][j] = qv[1][j];
+                }
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) qb[j] += PD * 16;
+            }
+        } else {
 #pragma unroll 1
         for (int r0 = 0; r0 < RG; r0 += PD) {
 #pragma unroll
@@ -122,6 +176,7 @@ __device__ __forceinline__ void masked_pair(const unsigned char *Qs, const doubl
             }
             __builtin_amdgcn_sched_barrier(0);
           }
+        }
         }
         // ---- cosine similarity per (shift, scan column), into the wave's rows by scan column ----
         wave_fence_lds();
@@ -476,6 +531,70 @@ __global__ __launch_bounds__(kSmallWaves * kWave) void sc_small_exact_kernel(Sma
     (void)kInf;
 }
 
+
+// ---- the k candidates of a ring-key search, scored (the reference-faithful detection: D.h:1642-1659, 1710-1737) ----------------
+// One workgroup: the scan staged once, one wave per candidate -- the reference's own alignment (fastAlignUsingVkey: align_keyframe_exact),
+// then all W shifts in ONE pass over the candidate (masked_pair with W slots) -- and the k results written straight into pinned host
+// memory beside the candidates' indices and ring-key distances (idx[k] | d2[k] | dist[k] | shift[k]).  It replaces the 13-shift wave
+// program's launch (126 KB of fp64 scan staged for three candidates: 19-20 us) and the packing launch behind it (4 us).
+constexpr int kCandWaves = 8;
+template <int RG, int S, int W>
+struct CandCfg {
+    using M = MaskedCfg<RG, S, W>;
+    static constexpr size_t LDS_Q = M::LDS_Q, LDS_N = M::LDS_N;
+    static constexpr size_t LDS_WAVE = (size_t)W * S * 8 > (size_t)(2 * S + 2) * 8 ? (size_t)W * S * 8 : (size_t)(2 * S + 2) * 8;   // W rows; the alignment's doubled key first
+    static constexpr size_t LDS = LDS_Q + LDS_N + kCandWaves * LDS_WAVE + (size_t)S * 8;
+};
+
+template <int RG, int S, int W>
+__global__ __launch_bounds__(kCandWaves * kWave) void sc_cand_exact_kernel(CandExactArgs ca)
+{
+    using C = MaskedCfg<RG, S, W>;
+    using CC = CandCfg<RG, S, W>;
+    constexpr int PITCH = C::PITCH, QCOLS = C::QCOLS, SR = (W - 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_c[];
+    unsigned char *Qs = smem_c;
+    double *nq = reinterpret_cast<double *>(smem_c + CC::LDS_Q);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    double *wrow = reinterpret_cast<double *>(smem_c + CC::LDS_Q + CC::LDS_N + (size_t)wave * CC::LDS_WAVE);
+    double *vq = reinterpret_cast<double *>(smem_c + CC::LDS_Q + CC::LDS_N + (size_t)kCandWaves * CC::LDS_WAVE);
+    int *o_idx = reinterpret_cast<int *>(ca.out);
+    float *o_d2 = reinterpret_cast<float *>(ca.out + sizeof(int) * ca.k);
+    double *o_dist = reinterpret_cast<double *>(ca.out + (sizeof(int) + sizeof(float)) * ca.k);
+    int *o_shift = reinterpret_cast<int *>(ca.out + (sizeof(int) + sizeof(float) + sizeof(double)) * ca.k);
+    // the candidates first (a dependent load otherwise), then the scan
+    int my_slot = -1;
+    if (wave < ca.k) my_slot = ca.cand_idx[wave];
+    for (int idx = threadIdx.x; idx < RG * QCOLS; idx += blockDim.x) {
+        const int rg = idx / QCOLS, cx = idx - rg * QCOLS;
+        const int c = cx < S ? cx : cx - S;
+        *reinterpret_cast<float4 *>(Qs + (size_t)cx * PITCH + rg * 16) = ca.q_desc[(size_t)rg * S + c];
+    }
+    for (int cx = threadIdx.x; cx < QCOLS; cx += blockDim.x) nq[cx] = ca.q_norm[cx < S ? cx : cx - S];
+    for (int c = threadIdx.x; c < S; c += blockDim.x) vq[c] = ca.q_vkey[c];
+    if ((int)threadIdx.x < ca.k) { o_idx[threadIdx.x] = ca.cand_idx[threadIdx.x]; o_d2[threadIdx.x] = ca.cand_d2[threadIdx.x]; }
+    __syncthreads();
+    for (int c = wave; c < ca.k; c += kCandWaves) {
+        const int slot = c == wave ? my_slot : ca.cand_idx[c];
+        double best = kBigDist; int bshift = 0;
+        if (slot >= 0) {                                                         // (wave uniform; a slot the search left unfilled: (1e7, 0) like launch_sc_distance)
+            constexpr int L = S >> 1;
+            const int ll2 = lane < L ? lane : L - 1;
+            const double2 vk = *reinterpret_cast<const double2 *>(ca.vkey + (size_t)slot * S + 2 * ll2);
+            const int a0 = align_keyframe_exact<S>(vk, lane, wrow, vq);
+            int first = a0 - SR; first = first < 0 ? first + S : first;          // D.h:1545-1551: the searched shifts start SEARCH_RADIUS below
+            wave_fence_lds();
+            double b; int bs;
+            constexpr int PDC = RG % 4 == 0 ? 4 : RG;                            // ring groups in flight (a lone wave: every round trip counts)
+            masked_pair<RG, S, W, PDC, W, true>(Qs, nq, wrow, ca.desc + (size_t)slot * (size_t)(RG * S), ca.norm + (size_t)slot * S, first,
+                                               W >= 32 ? 0xffffffffu : ((1u << W) - 1u), lane, b, bs);
+            if (b < kBigDist) { best = b; bshift = bs; }
+        }
+        if (lane == 0) { o_dist[c] = best; o_shift[c] = bshift; }
+    }
+}
+
 }  // namespace
 
 bool sc_masked_supported(const DbView &db, int SR)
@@ -514,6 +633,40 @@ hipError_t launch_sc_small_exact(const DbView &db, int SR, const SmallExactArgs 
     sa.desc = db.desc; sa.norm = db.norm; sa.vkey = db.vkey;
     hipLaunchKernelGGL((sc_small_exact_kernel<16, 120, 13>), dim3(sa.nq), dim3(kSmallWaves * kWave), SC::LDS, stream, sa);
     return hipGetLastError();
+}
+
+
+bool sc_cand_exact_supported(const DbView &db, int SR)
+{
+    const int W = 2 * SR + 1;
+    return (db.RG == 16 && db.S == 120 && W == 13) || (db.RG == 5 && db.S == 60 && W == 7 && db.R == 20);
+}
+
+template <int RG, int S, int W>
+static hipError_t launch_cand_t(const CandExactArgs &ca, hipStream_t stream)
+{
+    using CC = CandCfg<RG, S, W>;
+    static_assert(CC::LDS <= 160 * 1024, "LDS");
+    static std::atomic<bool> attr_set_dev[64];
+    int dev_ = 0; (void)hipGetDevice(&dev_);
+    std::atomic<bool> &attr_set = attr_set_dev[dev_ & 63];
+    if (!attr_set.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute((const void *)sc_cand_exact_kernel<RG, S, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CC::LDS);
+        if (e != hipSuccess) return e;
+        attr_set.store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((sc_cand_exact_kernel<RG, S, W>), dim3(1), dim3(kCandWaves * kWave), CC::LDS, stream, ca);
+    return hipGetLastError();
+}
+
+hipError_t launch_sc_cand_exact(const DbView &db, const QueryView &q, int SR, int k, const int *cand_idx, const float *cand_d2, void *pinned_out, hipStream_t stream)
+{
+    if (k < 1 || k > kTopkMaxK || !sc_cand_exact_supported(db, SR) || !pinned_out) return hipErrorInvalidValue;
+    CandExactArgs ca{};
+    ca.desc = db.desc; ca.norm = db.norm; ca.vkey = db.vkey; ca.q_desc = q.desc; ca.q_norm = q.norm; ca.q_vkey = q.vkey;
+    ca.k = k; ca.cand_idx = cand_idx; ca.cand_d2 = cand_d2; ca.out = static_cast<char *>(pinned_out);
+    if (db.S == 120) return launch_cand_t<16, 120, 13>(ca, stream);
+    return launch_cand_t<5, 60, 7>(ca, stream);
 }
 
 }  // namespace scl

@@ -17,6 +17,12 @@ if sys.argv[1] == "run":
         t0 = time.perf_counter(); eng.detect_full_range(N - 1 - (i % 50), 0, N - 100); ts.append((time.perf_counter() - t0) * 1e6)
         time.sleep(0.0005)
     print("blocking call us: p50 %.1f  min %.1f" % (float(np.percentile(ts[10:], 50)), min(ts[10:])))
+    time.sleep(0.01)
+    ts = []
+    for i in range(60):                                   # ... and the reference-faithful call (top-3 + 3 distances + threshold)
+        t0 = time.perf_counter(); eng.detect_intra(N - 1 - (i % 50)); ts.append((time.perf_counter() - t0) * 1e6)
+        time.sleep(0.0005)
+    print("detect_intra call us: p50 %.1f  min %.1f" % (float(np.percentile(ts[10:], 50)), min(ts[10:])))
     eng.close()
     sys.exit(0)
 rows = list(csv.DictReader(open(sys.argv[1])))
