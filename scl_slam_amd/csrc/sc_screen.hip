@@ -936,7 +936,7 @@ __device__ __forceinline__ void sc_screen_role(const ScreenBatchArgs &ab, const 
                         const uint4 rq = rotq[ri * MW + i];
                         ne += __popc(rq.x & km[i].x) + __popc(rq.y & km[i].y) + __popc(rq.z & km[i].z) + __popc(rq.w & km[i].w);
                     }
-                    const float d = 1.0f - s[r] / (float)ne;
+                    const float d = 1.0f - s[r] * __builtin_amdgcn_rcpf((float)ne);   // (v_rcp_f32, 1 ulp: a screened value; the bound's 2e-6 covers it -- the IEEE quotient is ten instructions, thirteen times per pair)
                     if (t < W && ne > 0 && d < dmin) dmin = d;                   // n_eff = 0: 0/0 in the reference, never wins
                     if (t < W && ne > 0) ne_min = ne < ne_min ? ne : ne_min;
                     dlo[m][r] = kInfF;
@@ -1677,7 +1677,7 @@ __device__ __forceinline__ float sc_screen2_finish_compute(const ScreenArgs &a, 
                     const uint4 rq = rotq[ri * MW + i];
                     ne += __popc(rq.x & l.km[i].x) + __popc(rq.y & l.km[i].y) + __popc(rq.z & l.km[i].z) + __popc(rq.w & l.km[i].w);
                 }
-                const float d = 1.0f - sm[r] / (float)ne;
+                const float d = 1.0f - sm[r] * __builtin_amdgcn_rcpf((float)ne);      // (v_rcp_f32, 1 ulp: a screened value; the bound's 2e-6 covers it -- the IEEE quotient is ten instructions, thirteen times per pair)
                 if (ne > 0 && d < dmin) dmin = d;
                 if (ne > 0) ne_min = ne < ne_min ? ne : ne_min;
                 dsh[t] = ne > 0 ? d : kInf;
