@@ -1010,8 +1010,9 @@ int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, c
 // One screening launch for up to four queries: slots qslot[i] against [lo[i], lo[i] + n[i]), results in buffer sets
 // set0 + i.  The event pair of the profile brackets this launch: it is the dominant kernel of a pass.
 // One screening launch group: queries qslot[0..nq) against [lo[i], lo[i] + n[i]), buffer sets set0 + i.
-struct ScreenGroup { const int *qslot, *lo, *n; int nq, set0; int part_half = 0; bool masks = false; };   // part_half: which half of d_part holds the batch's partial sums;
+struct ScreenGroup { const int *qslot, *lo, *n; int nq, set0; int part_half = 0; bool masks = false; bool keys_later = false; };   // part_half: which half of d_part holds the batch's partial sums;
                                                                                                              // masks: the batch's exact pass evaluates the open shifts only (the shift masks are formed and written)
+                                                                                                             // keys_later: ScreenBatch::no_ring_metric
 // next (optional, nq > 0): the launch that will follow; its alignment rides in this one (the next call then passes
 // kScreenProducts only).
 int launch_screen_group(scl_engine *e, const ScreenGroup &cur, int phases = kScreenAlign | kScreenProducts,
@@ -1026,6 +1027,7 @@ int launch_screen_group(scl_engine *e, const ScreenGroup &cur, int phases = kScr
         sb.survivors = nullptr; sb.n_surv = nullptr; sb.t_min = e->d_tmin;
         sb.smask = (g.masks || sc_screen_is_wide(db_view(e), e->SR)) ? e->d_smask : nullptr;   // (the 64 x 120 stream's exact pass scores all 13 shifts of its few survivors: no masks)
         sb.part = e->d_part + (g.part_half ? e->part_cap / 2 : 0);
+        sb.no_ring_metric = g.keys_later;
         sb.side = stream == e->stream ? e->stream_align : nullptr; sb.ev_fork = e->ev_afork; sb.ev_join = e->ev_ajoin;
         sb.k = e->cfg.num_candidates; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
     };
@@ -1056,11 +1058,11 @@ int launch_screen_group(scl_engine *e, const ScreenGroup &cur, int phases = kScr
 // survivor_arg_region) to both halves
 unsigned survivor_arg_region(scl_engine *e) { return e->surv_arg_tick++ & 7u; }
 int launch_survivor_pass(scl_engine *e, const int *qslot, const int *lo, const int *n, int nq, int set0, double *const *out3, hipStream_t stream = nullptr,
-                         int phases = kSurvivorArgs | kSurvivorKernel, int region_in = -1)
+                         int phases = kSurvivorArgs | kSurvivorKernel, int region_in = -1, bool ring_from_keys = false)
 {
     if (!stream) stream = e->stream;
     SurvivorPass sp{};
-    sp.nq = nq;
+    sp.nq = nq; sp.ring_from_keys = ring_from_keys ? 1 : 0;
     for (int j = 0; j < nq; ++j) { sp.slot[j] = qslot[j]; sp.base[j] = lo[j]; sp.n[j] = n[j]; sp.buf[j] = set0 + j; sp.out3[j] = out3[j]; }
     sp.pair_stride = e->set_stride;
     sp.approx = e->d_approx; sp.survivors = e->d_surv; sp.t_min = e->d_tmin; sp.out_dist = e->d_dist; sp.out_shift = e->d_shift;
@@ -1463,7 +1465,8 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
     struct Pending { int qslot[kMaxScreenBatch], lo[kMaxScreenBatch], n[kMaxScreenBatch], nq = 0, set0 = 0, half = 0; bool valid = false; } pend;
     struct Owed { List L; int c = 0, region = 0; bool valid = false; } owed;
     int part_half = 0;
-    auto pend_group = [&]() { ScreenGroup g{pend.qslot, pend.lo, pend.n, pend.nq, pend.set0}; g.part_half = pend.half; return g; };
+    const bool keys_later = !wide;                          // the exact pass of a chunk forms the ring-key metric of its ranges (beside the next chunk's products)
+    auto pend_group = [&]() { ScreenGroup g{pend.qslot, pend.lo, pend.n, pend.nq, pend.set0}; g.part_half = pend.half; g.keys_later = keys_later; return g; };
     // the exact pass of chunk `o.c` on the side stream, behind everything the main stream holds now
     auto run_owed = [&]() -> int {
         if (!owed.valid) return SCL_OK;
@@ -1474,7 +1477,7 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
         SCL_HIP(e, hipStreamWaitEvent(e->stream_surv, e->ev_k1[oc], 0));
         int r2 = SCL_OK;
         if (owed.L.m > 0) r2 = wide ? launch_survivor_pass_wide(e, owed.L.qslot, owed.L.qlo, owed.L.qn, owed.L.m, oc * CH, out3, e->stream_surv)
-                                    : launch_survivor_pass(e, owed.L.qslot, owed.L.qlo, owed.L.qn, owed.L.m, oc * CH, out3, e->stream_surv, kSurvivorKernel, owed.region);
+                                    : launch_survivor_pass(e, owed.L.qslot, owed.L.qlo, owed.L.qn, owed.L.m, oc * CH, out3, e->stream_surv, kSurvivorKernel, owed.region, keys_later);
         if (r2) return r2;
         SCL_HIP(e, hipEventRecord(e->ev_chunk[oc], e->stream_surv));
         owed.valid = false;
@@ -1530,7 +1533,7 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
         // for it there (it finished long ago).  Only the very first launch aligns for itself.
         // the exact pass's argument sets go to the device now, ahead of the products it has to wait for
         const int region = (cur.m > 0 && !wide) ? (int)survivor_arg_region(e) : 0;
-        if (cur.m > 0 && !wide && (rc = launch_survivor_pass(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, e->stream_surv, kSurvivorArgs, region))) return rc;
+        if (cur.m > 0 && !wide && (rc = launch_survivor_pass(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, e->stream_surv, kSurvivorArgs, region, keys_later))) return rc;
         bool next_aligned = false;
         if (cur.m == 0) {                                    // nothing to launch: what earlier chunks are owed cannot ride along
             if ((rc = flush_pending())) return rc;
@@ -1539,16 +1542,18 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
         for (int g = 0; g < cur.m; g += spl) {
             const int w = cur.m - g < spl ? cur.m - g : spl;
             ScreenGroup grp{cur.qslot + g, cur.qlo + g, cur.qn + g, w, set0 + g};
-            grp.part_half = part_half;
+            grp.part_half = part_half; grp.keys_later = keys_later;
             const bool defer = sc_screen_can_defer(db_view(e), e->SR, w);
             if (!defer && (rc = flush_pending())) return rc;   // (a batch the first form scores has no extra waves to carry it)
             ScreenGroup nx{nullptr, nullptr, nullptr, 0, 0};
             if (g + w < cur.m) {
                 const int wn = cur.m - g - w < spl ? cur.m - g - w : spl;
                 nx = ScreenGroup{cur.qslot + g + w, cur.qlo + g + w, cur.qn + g + w, wn, set0 + g + w};
+                nx.keys_later = keys_later;
             } else if (ncount > 0 && nxt.m > 0) {
                 const int wn = nxt.m < spl ? nxt.m : spl;
                 nx = ScreenGroup{nxt.qslot, nxt.qlo, nxt.qn, wn, nset0};
+                nx.keys_later = keys_later;
                 if (ch[c ^ 1].busy) SCL_HIP(e, hipStreamWaitEvent(e->stream, e->ev_chunk[c ^ 1], 0));
                 next_aligned = true;
             }
@@ -1586,7 +1591,7 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
             SCL_HIP(e, hipStreamWaitEvent(e->stream, e->ev_k1[c], 0));
         }
         if (cur.m > 0 && (rc = wide ? launch_survivor_pass_wide(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, xs)
-                                    : launch_survivor_pass(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, xs, kSurvivorKernel, region))) return rc;
+                                    : launch_survivor_pass(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, xs, kSurvivorKernel, region, keys_later))) return rc;
         SCL_HIP(e, hipEventRecord(e->ev_chunk[c], xs));
         k.busy = true;
         k.aligned = false;

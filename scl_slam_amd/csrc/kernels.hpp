@@ -191,6 +191,9 @@ struct ScreenBatch {
     int k; float exclude_eps; int *topk_idx; float *topk_d2;
     hipStream_t side; hipEvent_t ev_fork, ev_join;   // second form: stream and events for the next batch's alignment beside the products (nullptr: in line)
     float *part;                                // scratch of the second form of the 64 x 120 products: nq * pair_stride * 32 floats (nullptr: first form)
+    bool no_ring_metric;                        // the caller's exact pass forms the ring-key metric itself (SurvivorPass::ring_from_keys) or has no use for
+                                                // it (the distance matrix): the second form's tail launch leaves ring_d2 alone (the first form and the
+                                                // last group's plain finish still write it -- the same values)
 };
 bool sc_screen_supported(const struct DbView &db, int SR);
 bool sc_screen_is_wide(const struct DbView &db, int SR);      // 80 x 180: screening by sc_screen_wide_kernel, exact pass by the one-sector-per-lane kernel
@@ -234,6 +237,8 @@ struct SurvivorPass {
     unsigned long long *blk_part; unsigned int *done_counter;
     unsigned long long *surv_stats;             // optional: [0] += survivors, [1] = max(survivors), [2] += 1 per query scored
     void *d_args; void *h_args;
+    int ring_from_keys;                         // 1: ring_d2 is scratch the top-k workgroup of every range fills from the tiled ring keys first
+                                                // (ScreenBatch::no_ring_metric: the screening launches did not)
 };
 // phases: kSurvivorArgs = fill the argument sets and enqueue their copy to the device (may be done ahead of the event the
 // kernel has to wait for), kSurvivorKernel = the kernel; both by default

@@ -51,6 +51,7 @@ struct ScArgs {
     // image of the minimum, re-armed by the last workgroup), slots written to `cand` in ascending order
     const float *approx; unsigned int *t_min; int range_n; float two_eps;
     const float *ring_d2;     // survivors pass: the ring-key metric of the range (from the screening pass), for the top-k
+    int ring_from_keys;       // survivors pass: ... formed here from the tiled ring keys instead (the screening pass left it out)
     int *sel_topk_idx; float *sel_topk_d2; int sel_topk_k; float sel_exclude_eps;
     unsigned long long *surv_stats;   // survivors pass, optional: survivor count statistics (scl_survivor_stats)
     int S;
@@ -1020,6 +1021,28 @@ __global__ __launch_bounds__(MAXT) void sc_distance_survivors_kernel(const ScArg
         const unsigned long long none = ~0ull;
         unsigned long long prev = 0ull;
         bool first = true;
+        if (a.ring_from_keys) {
+            // nanoflann's metric (nanoflann.hpp:383-408) of every keyframe of the range, the arithmetic of sc_screen2_finish_compute:
+            // four dimensions per step, fp32, groups accumulated in order; consecutive threads on consecutive slots of the tiled keys
+            float *rd = const_cast<float *>(a.ring_d2);
+            for (int i = (int)threadIdx.x; i < a.range_n; i += (int)blockDim.x) {
+                const int slot = a.slot_base + i;
+                float4 bk[RG];
+#pragma unroll
+                for (int r = 0; r < RG; ++r) bk[r] = a.rkey4[(size_t)r * a.rk_cap + slot];
+                float result = 0.0f;
+#pragma unroll
+                for (int r = 0; r < RG; ++r) {
+                    const float4 qk = *reinterpret_cast<const float4 *>(a.q_rkey + 4 * r);
+                    const float d0 = qk.x - bk[r].x, d1 = qk.y - bk[r].y, d2 = qk.z - bk[r].z, d3 = qk.w - bk[r].w;
+                    const float grp = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+                    result += grp;
+                }
+                rd[i] = result;
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
         for (int round = 0; round < a.sel_topk_k; ++round) {
             unsigned long long mine = none;
             for (int i = (int)threadIdx.x; i < a.range_n; i += (int)blockDim.x) {
@@ -1346,7 +1369,7 @@ hipError_t launch_sc_distance(const DbView &db, const QueryView &q, const int *c
     ScArgs a;
     a.desc = db.desc; a.vkey = db.vkey; a.norm = db.norm;
     a.q_desc = q.desc; a.q_vkey = q.vkey; a.q_norm = q.norm;
-    a.cand = cand; a.slot_base = slot_base; a.n = n; a.n_dev = nullptr; a.approx = nullptr; a.t_min = nullptr; a.range_n = 0; a.two_eps = 0.f; a.ring_d2 = nullptr; a.sel_topk_idx = nullptr; a.surv_stats = nullptr; a.sel_topk_d2 = nullptr; a.sel_topk_k = 0; a.sel_exclude_eps = 0.f; a.S = db.S; a.SR = SR;
+    a.cand = cand; a.slot_base = slot_base; a.n = n; a.n_dev = nullptr; a.approx = nullptr; a.t_min = nullptr; a.range_n = 0; a.two_eps = 0.f; a.ring_d2 = nullptr; a.ring_from_keys = 0; a.sel_topk_idx = nullptr; a.surv_stats = nullptr; a.sel_topk_d2 = nullptr; a.sel_topk_k = 0; a.sel_exclude_eps = 0.f; a.S = db.S; a.SR = SR;
     a.NW = (db.S + kWave - 1) / kWave; a.G = 1;
     a.ablate = ablate_flags();
     a.align_filter = align_filter_enabled();
@@ -1404,7 +1427,7 @@ hipError_t launch_sc_distance_batch(const DbView &db, const QueryBatch &qb, int 
         a.desc = db.desc; a.vkey = db.vkey; a.norm = db.norm;
         a.q_desc = db.desc + slot * (size_t)(db.RG * db.S); a.q_vkey = db.vkey + slot * db.S;
         a.q_norm = db.norm + slot * db.S; a.q_rkey = db.rkey + slot * (size_t)(4 * db.RG);
-        a.cand = nullptr; a.slot_base = qb.base[i]; a.n = qb.n[i]; a.n_dev = nullptr; a.approx = nullptr; a.t_min = nullptr; a.range_n = 0; a.two_eps = 0.f; a.ring_d2 = nullptr; a.sel_topk_idx = nullptr; a.surv_stats = nullptr; a.sel_topk_d2 = nullptr; a.sel_topk_k = 0; a.sel_exclude_eps = 0.f; a.S = db.S; a.SR = SR;
+        a.cand = nullptr; a.slot_base = qb.base[i]; a.n = qb.n[i]; a.n_dev = nullptr; a.approx = nullptr; a.t_min = nullptr; a.range_n = 0; a.two_eps = 0.f; a.ring_d2 = nullptr; a.ring_from_keys = 0; a.sel_topk_idx = nullptr; a.surv_stats = nullptr; a.sel_topk_d2 = nullptr; a.sel_topk_k = 0; a.sel_exclude_eps = 0.f; a.S = db.S; a.SR = SR;
         a.NW = (db.S + kWave - 1) / kWave; a.G = 1;
         a.ablate = ablate_flags(); a.stamps = nullptr; a.align_filter = align_filter_enabled();
         a.rkey4 = db.rkey4; a.rk_cap = db.cap;
@@ -1449,7 +1472,7 @@ hipError_t launch_sc_distance_matrix(const DbView &db, const int *slots, int nq,
         a.desc = db.desc; a.vkey = db.vkey; a.norm = db.norm;
         a.q_desc = db.desc + slot * (size_t)(db.RG * db.S); a.q_vkey = db.vkey + slot * db.S;
         a.q_norm = db.norm + slot * db.S; a.q_rkey = db.rkey + slot * (size_t)(4 * db.RG);
-        a.cand = nullptr; a.slot_base = base; a.n = n; a.n_dev = nullptr; a.approx = nullptr; a.t_min = nullptr; a.range_n = 0; a.two_eps = 0.f; a.ring_d2 = nullptr;
+        a.cand = nullptr; a.slot_base = base; a.n = n; a.n_dev = nullptr; a.approx = nullptr; a.t_min = nullptr; a.range_n = 0; a.two_eps = 0.f; a.ring_d2 = nullptr; a.ring_from_keys = 0;
         a.sel_topk_idx = nullptr; a.surv_stats = nullptr; a.sel_topk_d2 = nullptr; a.sel_topk_k = 0; a.sel_exclude_eps = 0.f; a.S = db.S; a.SR = SR;
         a.NW = (db.S + kWave - 1) / kWave; a.G = 1;
         a.ablate = ablate_flags(); a.stamps = nullptr; a.align_filter = align_filter_enabled();
@@ -1485,7 +1508,7 @@ hipError_t launch_sc_distance_survivors(const DbView &db, const SurvivorPass &sp
         a.blk_part = sp.blk_part + (size_t)i * kSurvivorBlocks * kTailRec; a.done_counter = sp.done_counter + i;
         a.out3 = sp.out3[i];
         a.topk_idx = nullptr; a.topk_d2 = nullptr; a.topk_k = 0; a.exclude_eps = 0.0f;
-        a.ring_d2 = sp.ring_d2 + (size_t)sp.buf[i] * sp.pair_stride;
+        a.ring_d2 = sp.ring_d2 + (size_t)sp.buf[i] * sp.pair_stride; a.ring_from_keys = sp.ring_from_keys;
         a.sel_topk_idx = sp.topk_idx + sp.buf[i] * kTailTopMaxK; a.sel_topk_d2 = sp.topk_d2 + sp.buf[i] * kTailTopMaxK;
         a.sel_topk_k = sp.k; a.sel_exclude_eps = sp.exclude_eps;
         a.surv_stats = sp.surv_stats;
@@ -1554,7 +1577,7 @@ hipError_t launch_sc_distance_survivors_wide(const DbView &db, int nq, const int
         a.q_rkey = db.rkey + slot * (size_t)(4 * db.RG);
         a.cand = survivors[j]; a.slot_base = slot_base[j]; a.n = 256;        // sizes nothing here; the kernel loops over *n_dev
         a.n_dev = n_surv[j]; a.approx = nullptr; a.t_min = nullptr; a.range_n = 0; a.two_eps = 0.f;
-        a.ring_d2 = nullptr; a.sel_topk_idx = nullptr; a.surv_stats = nullptr; a.sel_topk_d2 = nullptr; a.sel_topk_k = 0; a.sel_exclude_eps = 0.f;
+        a.ring_d2 = nullptr; a.ring_from_keys = 0; a.sel_topk_idx = nullptr; a.surv_stats = nullptr; a.sel_topk_d2 = nullptr; a.sel_topk_k = 0; a.sel_exclude_eps = 0.f;
         a.S = db.S; a.SR = SR; a.NW = (db.S + kWave - 1) / kWave; a.G = 1;
         a.ablate = 0; a.align_filter = 0; a.stamps = nullptr;
         a.rkey4 = db.rkey4; a.rk_cap = db.cap; a.out_d2 = nullptr;

@@ -1246,13 +1246,27 @@ __device__ unsigned long long g_s2_stamps[4 * 64];
 template <int RG, int S, int W> struct S2Cfg;
 // WV: waves of the products per workgroup; XW: EXTRA waves of the same workgroup that align the NEXT batch and finish the PREVIOUS
 // one beside the products (sc_screen2_kernel): the products leave two thirds of the vector and matrix-core issue slots idle
-template <> struct S2Cfg<16, 120, 13> { static constexpr int NP = 2, NPASS = 1, STEPS = 4, NQ = 16, RS = S2RS_A, WV = S2WV_A, WVF = S2WVF_A, XW = S2XW_A, NBUF = S2NBUF_A; };   // RS: ring slots of fragment loads (RS - 1 in flight);
-template <> struct S2Cfg<20, 180, 19> { static constexpr int NP = 3, NPASS = 2, STEPS = 4, NQ = 12, RS = 9, WV = S2WV_B, WVF = 8, XW = S2XW_B, NBUF = S2NBUF_B; };    // S / STEPS iterations per keyframe = a multiple of RS
+// NP ring parts, NPASS passes of 13 shift rows, STEPS k-steps per iteration (= per keyframe fragment), SPK sectors per k-step:
+// a k-step's 32 products are 32 rings of one sector (SPK = 1) or 16 rings of two consecutive sectors (SPK = 2)
+template <> struct S2Cfg<16, 120, 13> { static constexpr int NP = 2, NPASS = 1, STEPS = 4, SPK = 1, NQ = 16, RS = S2RS_A, WV = S2WV_A, WVF = S2WVF_A, XW = S2XW_A, NBUF = S2NBUF_A; };
+#ifdef S2_WIDE_THIRDS
+// (rounds 3-4: 96 padded rings as three thirds of 32, twelve scans per launch -- 141 KB of LDS; 37 % of the matrix-core work useful)
+template <> struct S2Cfg<20, 180, 19> { static constexpr int NP = 3, NPASS = 2, STEPS = 4, SPK = 1, NQ = 12, RS = 9, WV = S2WV_B, WVF = 8, XW = S2XW_B, NBUF = S2NBUF_B; };
+#else
+// 80 rings as five slices of 16, two sectors per k-step: no padded rings, sixteen scans per launch (16 x 183 sectors x 32 B = 94 KB)
+template <> struct S2Cfg<20, 180, 19> { static constexpr int NP = 5, NPASS = 2, STEPS = 2, SPK = 2, NQ = 16, RS = 9, WV = S2WV_B, WVF = 8, XW = S2XW_B, NBUF = S2NBUF_B; };
+#endif
 constexpr int kS2PassRows = 13;                    // shift rows per pass: row m of pass p = shift W - 1 - 13 p - m
 
 // LDS image of the scans (see above): quad stride in bytes, 2 mod 4 sixteen-byte slots
-constexpr int s2_quad(int S, int STEPS) { return (((S + STEPS - 1) * 256 / 16) % 4 == 2) ? (S + STEPS - 1) * 256 : (S + STEPS - 1) * 256 + 32; }
-template <int RG, int S, int W> constexpr size_t s2_lds() { return (size_t)(S2Cfg<RG, S, W>::NQ / 4) * s2_quad(S, S2Cfg<RG, S, W>::STEPS); }
+// (SECT = sectors per iteration; SPK = 2: eight scans of 32 B share a row, a lane's slot is 2 (q & 7) + (j & 1) whatever its sector:
+//  whole rows per block of eight scans)
+constexpr int s2_quad(int S, int SECT, int SPK) { return SPK == 2 ? (S + SECT - 1) * 256 : ((((S + SECT - 1) * 256 / 16) % 4 == 2) ? (S + SECT - 1) * 256 : (S + SECT - 1) * 256 + 32); }
+template <int RG, int S, int W> constexpr size_t s2_lds()
+{
+    using C = S2Cfg<RG, S, W>;
+    return (size_t)(C::NQ / (4 * C::SPK)) * s2_quad(S, C::STEPS * C::SPK, C::SPK);
+}
 template <int RG, int S, int W> constexpr int s2_part_floats() { return S2Cfg<RG, S, W>::NP * S2Cfg<RG, S, W>::NPASS * 16; }   // partial sums per pair
 // LDS tile of one extra wave: the alignment image (both parts) / the exact evaluation's scratch, or the finishing's rotated masks
 template <int S> constexpr int s2_xlds() { return Align2Cfg<S>::LDS_WAVE > S * ((((S + 63) / 64) + 1) / 2) * 16 ? Align2Cfg<S>::LDS_WAVE : S * ((((S + 63) / 64) + 1) / 2) * 16; }
@@ -1282,15 +1296,18 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
 {
     constexpr int WVP = FUSED ? S2Cfg<RG, S, W>::WVF : S2Cfg<RG, S, W>::WV;
     using C = S2Cfg<RG, S, W>;
-    constexpr int NP = C::NP, NPASS = C::NPASS, STEPS = C::STEPS, NQ = C::NQ;
+    constexpr int NP = C::NP, NPASS = C::NPASS, STEPS = C::STEPS, NQ = C::NQ, SPK = C::SPK;
     constexpr int RGH = hdesc_rgh(RG);
     constexpr int SB = RGH * 8;                        // bytes of one sector in hdesc (all rings, fp16)
     constexpr int HS = hdesc_stride(RG, S);
-    constexpr int NIT = S / STEPS;                     // iterations (of STEPS k-steps) per keyframe
-    constexpr int ROWS = S + STEPS - 1;                // sectors per scan in LDS: the reads of an iteration never wrap
-    constexpr int QUAD = s2_quad(S, STEPS);
-    static_assert(SB == 64 * NP && S % STEPS == 0 && kS2PassRows + STEPS - 1 <= 16 && W <= NPASS * kS2PassRows && NQ % 4 == 0 && NQ <= kMaxScreenBatch, "second form");
-    static_assert((QUAD / 16) % 4 == 2, "bank slots of the quads");
+    constexpr int SECT = STEPS * SPK;                  // sectors per iteration
+    constexpr int NIT = S / SECT;                      // iterations (of STEPS k-steps) per keyframe
+    constexpr int ROWS = S + SECT - 1;                 // sectors per scan in LDS: the reads of an iteration never wrap
+    constexpr int QUAD = s2_quad(S, SECT, SPK);        // bytes of a block of SPR scans in the image
+    constexpr int SPR = 4 * SPK, SCB = 64 / SPK;       // scans per 256-byte row of the image; a scan's bytes in it (its ring part of one sector)
+    static_assert(SB >= SCB * NP && SB == 64 * ((NP * SCB + 63) / 64) && S % SECT == 0 && SECT == 4 && kS2PassRows + SPK * (STEPS - 1) <= 16 && W <= NPASS * kS2PassRows
+                  && NQ % SPR == 0 && NQ <= kMaxScreenBatch && (SPK == 1 || SPK == 2), "second form");
+    static_assert(SPK == 2 ? QUAD % 256 == 0 : (QUAD / 16) % 4 == 2, "bank slots of the image's blocks");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
     const ScreenBatchArgs &ab = fa.prod;
     const int lane = threadIdx.x & (kWave - 1);
@@ -1318,7 +1335,10 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
     const int *starts_q = ab.starts + (size_t)sq.buf * (size_t)ab.pair_stride;
     const bool q_live = c16 < ab.nq && c16 < NQ;
     // A side: row m of the fragment of step y is sector y + m of the chunk-major image (no wrap: 16 sectors repeat at its end)
-    const unsigned int a_lane = (unsigned int)(hdesc2_offset(RG, S) * 8 + ((part * 4 + j4) * (S + 16) + c16) * 16);
+    // (SPK = 2: the fragment's 32 products are chunks 2 part, 2 part + 1 of sector y + m and of sector y + m + 1: lanes j4 = 2, 3 read one
+    //  sector further on -- the same 256 consecutive bytes per 16 lanes)
+    const int lsec = c16 + (SPK == 2 ? (j4 >> 1) : 0);
+    const unsigned int a_lane = (unsigned int)(hdesc2_offset(RG, S) * 8 + (((SPK == 2 ? part * 2 + (j4 & 1) : part * 4 + j4)) * (S + 16) + lsec) * 16);
     const unsigned char *hd = reinterpret_cast<const unsigned char *>(ab.hdesc);
     auto kf_base = [&](int k) -> const unsigned char * {
         int idx = gw + k * waves_part;
@@ -1334,7 +1354,7 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
         return starts_q[ok ? ci : 0];
     };
     const int nk = gw < fa.u_n ? (fa.u_n - gw + waves_part - 1) / waves_part : 0;
-    const unsigned int q_lds = (unsigned int)((cq >> 2) * QUAD + (cq & 3) * 64 + j4 * 16);
+    const unsigned int q_lds = (unsigned int)((cq / SPR) * QUAD + (cq % SPR) * SCB + (SPK == 2 ? (j4 & 1) * 16 + (j4 >> 1) * 256 : j4 * 16));
     const int up16 = ((lane + 16) & 63) * 4;           // ds_bpermute address of the lane that holds the next four rows of this column
     // The fragment of iteration i (keyframe sectors 4 i + m, m = 0 .. 15) shares twelve of its sixteen sectors with the one before: only
     // every FOURTH fragment is loaded (sectors 16 g + m: the same 1 KB load, a quarter as many), the three between come out of two loaded
@@ -1351,7 +1371,7 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
     // lane (m, j4) of load g reads sector 16 g + m; the image's rows end at sector S + 15 (the last load's upper lanes stay inside)
     // (sectors past the keyframe's last are its first again: read where they were read before -- those lines are in the L2, the image's
     //  16 repeated sectors per row would come from HBM: 1.5 KB per keyframe, 15 MB per launch)
-    auto load_off = [&](int g) -> unsigned int { const int sct = 16 * g + c16; return a_lane + (unsigned int)((sct < S ? sct : (sct - S < S ? sct - S : 0)) - c16) * 16u; };
+    auto load_off = [&](int g) -> unsigned int { const int sct = 16 * g + lsec; return a_lane + (unsigned int)((sct < S ? sct : (sct - S < S ? sct - S : 0)) - lsec) * 16u; };
     u32x4 F[NBUF];
     const unsigned char *base_cur = kf_base(0), *base_nxt = kf_base(1);
     int b_cur = 0, b_nxt = 0;
@@ -1365,7 +1385,8 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
         // piece's sector and chunk are shifts of the lane index.  (Dealt out piece by piece over the workgroup's threads, every piece
         // cost a division and a per-lane read of the launch's argument block for its scan's slot: the waves took 5-10 k cycles to ISSUE
         // their requests, and the workgroup met at the barrier 15 k cycles into the kernel -- a quarter of it.)
-        constexpr int NWV = s2_waves<RG, S, W, FUSED>(), NPIECE = ROWS * 4, BATCH = 8;
+        constexpr int PPS = 4 / SPK;                           // 16-byte pieces of a scan per sector
+        constexpr int NWV = s2_waves<RG, S, W, FUSED>(), NPIECE = ROWS * PPS, BATCH = 8;
         constexpr int NBATCH = (NPIECE + BATCH * kWave - 1) / (BATCH * kWave);
         static_assert(NBATCH <= 2 && NQ <= 2 * NWV, "staging turns");
         // (named variables, straight-line code: as arrays -- behind lambdas or inside macros' loops -- the pieces were placed in scratch)
@@ -1375,7 +1396,7 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
         {                                                                                                                                       \
             const int idx0 = (BASE) + (r) * kWave + lane;                                                                                       \
             const int idx = idx0 < NPIECE ? idx0 : NPIECE - 1;                                                                                  \
-            const int sx = idx >> 2, ch = idx & 3;                                                                                              \
+            const int sx = idx / PPS, ch = idx % PPS;                                                                                           \
             const int sct = sx < S ? sx : sx - S;                                                                                               \
             PC = *reinterpret_cast<const uint4 *>(sbase + (unsigned int)(sct * SB + ch * 16));                                                  \
             DS = dbase + (unsigned int)(sx * 256 + ch * 16);                                                                                    \
@@ -1388,15 +1409,15 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
         // (a second turn only where the workgroup has fewer waves than the launch has scans: the fused experiment's 12 + 4)
         if (wave + NWV < NQ) {
             const int q2 = wave + NWV;
-            const unsigned char *sbase = reinterpret_cast<const unsigned char *>(ab.hdesc + (size_t)ab.q[q2].slot * HS) + part * 64;
-            const unsigned int dbase = (unsigned int)((q2 >> 2) * QUAD + (q2 & 3) * 64);
+            const unsigned char *sbase = reinterpret_cast<const unsigned char *>(ab.hdesc + (size_t)ab.q[q2].slot * HS) + part * SCB;
+            const unsigned int dbase = (unsigned int)((q2 / SPR) * QUAD + (q2 % SPR) * SCB);
             if constexpr (NBATCH == 2) { S2_STAGE_REQUEST(0) S2_STAGE_STORE(0) }
             S2_STAGE_REQUEST((NBATCH - 1) * BATCH * kWave)
             S2_STAGE_STORE((NBATCH - 1) * BATCH * kWave)
         }
         const int q1 = wave < NQ ? wave : NQ - 1;
-        const unsigned char *sbase = reinterpret_cast<const unsigned char *>(ab.hdesc + (size_t)ab.q[q1].slot * HS) + part * 64;
-        const unsigned int dbase = (unsigned int)((q1 >> 2) * QUAD + (q1 & 3) * 64);
+        const unsigned char *sbase = reinterpret_cast<const unsigned char *>(ab.hdesc + (size_t)ab.q[q1].slot * HS) + part * SCB;
+        const unsigned int dbase = (unsigned int)((q1 / SPR) * QUAD + (q1 % SPR) * SCB);
         if constexpr (NBATCH == 2) { S2_STAGE_REQUEST(0) S2_STAGE_STORE(0) }
         S2_STAGE_REQUEST((NBATCH - 1) * BATCH * kWave)
         S2_STAMP_AT(61);
@@ -1447,15 +1468,15 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
             c0 = c0 >= S ? c0 - S : c0;
             preB[p] = smem2 + (q_lds + (unsigned int)c0 * 256u);
             postB[p] = preB[p] - S * 256;
-            wrapB[p] = (S - c0 + STEPS - 1) / STEPS;     // smallest it with c0 + 4 it >= S
+            wrapB[p] = (S - c0 + SECT - 1) / SECT;       // smallest it with c0 + 4 it >= S
         }
     };
     auto readB = [&](h8 (&dst)[NPASS][STEPS], const int it) {
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
-            const unsigned char *qp = (it < wrapB[p] ? preB[p] : postB[p]) + it * STEPS * 256;
+            const unsigned char *qp = (it < wrapB[p] ? preB[p] : postB[p]) + it * SECT * 256;
 #pragma unroll
-            for (int u = 0; u < STEPS; ++u) dst[p][u] = *reinterpret_cast<const h8 *>(qp + 256 * u);
+            for (int u = 0; u < STEPS; ++u) dst[p][u] = *reinterpret_cast<const h8 *>(qp + 256 * SPK * u);
         }
     };
     h8 bfr[2][NPASS][STEPS];
@@ -1504,7 +1525,7 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
                 const int j = g + NBUF - 1;                  // (its buffer held load g - 1, whose last fragment was formed two iterations ago)
                 // (the keyframe's last load serves the last derived fragment only: sectors up to 4 (NIT - 1) + 15; at S = 120 that is
                 //  four of its sixteen sectors -- the other lanes stay out of the request: 0.75 KB per keyframe and ring part less)
-                constexpr int kLastLanes = 4 * (NIT - 1) + 16 - 16 * (NL - 1);
+                constexpr int kLastLanes = SPK == 2 ? 16 : 4 * (NIT - 1) + 16 - 16 * (NL - 1);
                 if (j == NL - 1 && kLastLanes < 16) { if (c16 < kLastLanes) F[j % NBUF] = *reinterpret_cast<const u32x4 *>(base_cur + load_off(j)); }
                 else if (j < NL) F[j % NBUF] = *reinterpret_cast<const u32x4 *>(base_cur + load_off(j));
                 else if (j - NL < NBUF - 1) F[j % NBUF] = *reinterpret_cast<const u32x4 *>(base_nxt + load_off(j - NL));
@@ -1554,17 +1575,19 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
             const bool ok = q_live && ci >= 0 && ci < sq.n;
 #pragma unroll
             for (int p = 0; p < NPASS; ++p) {
-                // row s of the tile = sum over u of row s + u of acc[p][u]: rows 4 j + i + u of this lane while i + u <= 3, of the lane
-                // 16 further on (rows 4 (j + 1) ..) beyond; rows 13 .. 15 are not shifts (W - 1 - 13 p - m < 0 there) and take whatever comes
+                // row s of the tile = sum over u of row s + SPK u of acc[p][u]: rows 4 j + i + SPK u of this lane while i + SPK u <= 3, of the
+                // lane 16 further on (rows 4 (j + 1) ..) beyond; rows 13 .. 15 are not shifts (W - 1 - 13 p - m < 0 there) and take whatever comes
                 f4v sum = acc[p][0];
 #pragma unroll
                 for (int u = 1; u < STEPS; ++u) {
-                    float nx[STEPS - 1];
+                    constexpr int kMaxSh = SPK * (STEPS - 1);
+                    const int sh = SPK * u;
+                    float nx[4];
 #pragma unroll
-                    for (int e2 = 0; e2 < u; ++e2)
-                        nx[e2] = __int_as_float(__builtin_amdgcn_ds_bpermute(up16, __float_as_int(acc[p][u][e2])));
+                    for (int e2 = 0; e2 < kMaxSh; ++e2)
+                        if (e2 < sh) nx[e2] = __int_as_float(__builtin_amdgcn_ds_bpermute(up16, __float_as_int(acc[p][u][e2])));
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) sum[i] += (i + u <= 3) ? acc[p][u][(i + u) & 3] : nx[(i + u - 4) & 3];
+                    for (int i = 0; i < 4; ++i) sum[i] += (i + sh <= 3) ? acc[p][u][(i + sh) & 3] : nx[(i + sh - 4) & 3];
                 }
                 if (ok) *reinterpret_cast<f4v *>(fa.part + ((((size_t)c16 * (size_t)ab.pair_stride + (size_t)ci) * NP + part) * NPASS + p) * 16 + 4 * j4) = sum;
             }
@@ -1601,17 +1624,19 @@ __device__ __forceinline__ void build_rotq(const unsigned int *q_kmask, uint4 *r
 // sums, the keyframe's tiled ring key), then -- in the workgroup form behind the barrier that publishes the scan's rotated masks --
 // the distances are formed.  Written as one step the compiler waited for the loads two at a time: six memory round trips behind each
 // other in a kernel that is nothing but round trips (2.4 waves per SIMD, all resident at once).
-template <int RG, int S, int W>
+template <int RG, int S, int W, bool D2 = true>
 struct FinishLoads {
-    static constexpr int NPF = S2Cfg<RG, S, W>::NP * S2Cfg<RG, S, W>::NPASS * 4;
+    static constexpr int NPA = S2Cfg<RG, S, W>::NP <= 3 ? S2Cfg<RG, S, W>::NP : 3;   // ring parts whose sums are requested up front (registers: the others follow
+                                                                                    //  once these are added up)
+    static constexpr int NPF = NPA * S2Cfg<RG, S, W>::NPASS * 4;
     static constexpr int MW = (((S + 63) / 64) + 1) / 2;
     static constexpr bool kRingUpFront = NPF * 4 + RG * 4 <= 100;                // (registers: the 80 x 180 grid asks for its ring key later)
-    uint4 km[MW]; unsigned int kflag; float kerr; int b_raw; f4v pv[NPF]; float4 bk[kRingUpFront ? RG : 1];
+    uint4 km[MW]; unsigned int kflag; float kerr; int b_raw; f4v pv[NPF]; const f4v *rest; float4 bk[(D2 && kRingUpFront) ? RG : 1];
 };
-template <int RG, int S, int W>
-__device__ __forceinline__ FinishLoads<RG, S, W> sc_screen2_finish_request(const Screen2Args &fa, const ScreenArgs &a, const int qi, const int ci)
+template <int RG, int S, int W, bool D2 = true>
+__device__ __forceinline__ FinishLoads<RG, S, W, D2> sc_screen2_finish_request(const Screen2Args &fa, const ScreenArgs &a, const int qi, const int ci)
 {
-    using L = FinishLoads<RG, S, W>;
+    using L = FinishLoads<RG, S, W, D2>;
     using C = S2Cfg<RG, S, W>;
     const ScreenBatchArgs &ab = fa.prod;
     L l;
@@ -1626,7 +1651,8 @@ __device__ __forceinline__ FinishLoads<RG, S, W> sc_screen2_finish_request(const
     const f4v *pp = reinterpret_cast<const f4v *>(fa.part + ((size_t)qi * (size_t)ab.pair_stride + (size_t)ci) * (C::NP * C::NPASS * 16));
 #pragma unroll
     for (int i = 0; i < L::NPF; ++i) l.pv[i] = pp[i];
-    if constexpr (L::kRingUpFront) {
+    l.rest = pp + L::NPF;
+    if constexpr (D2 && L::kRingUpFront) {
         const int slot = a.slot_base + ci;
 #pragma unroll
         for (int r = 0; r < RG; ++r) l.bk[r] = a.rkey4[(size_t)r * a.rk_cap + slot];
@@ -1634,12 +1660,15 @@ __device__ __forceinline__ FinishLoads<RG, S, W> sc_screen2_finish_request(const
     return l;
 }
 // MASKS = false: an instance for launches that ask for no shift masks (the 64 x 120 stream's tail launch): no per-shift interval ends
-// are kept -- thirteen registers that the tail launch, built for four waves per SIMD beside the alignment, does not have
-template <int RG, int S, int W, bool MASKS = true>
-__device__ __forceinline__ float sc_screen2_finish_compute(const ScreenArgs &a, const int ci, const uint4 *rotq, const bool q_bad, const float q_err, FinishLoads<RG, S, W> &l, float &pair_eps)
+// are kept -- thirteen registers that the tail launch, built for four waves per SIMD beside the alignment, does not have.
+// D2 = false: the ring-key metric of the pair is left to the exact pass of the range (sc_distance_survivors_kernel forms it in
+// front of its top-k, on the side stream): sixteen float4 loads and sixty-four registers per pair that the stream's tail launch
+// neither waits for nor holds
+template <int RG, int S, int W, bool MASKS = true, bool D2 = true>
+__device__ __forceinline__ float sc_screen2_finish_compute(const ScreenArgs &a, const int ci, const uint4 *rotq, const bool q_bad, const float q_err, FinishLoads<RG, S, W, D2> &l, float &pair_eps)
 {
     using C = S2Cfg<RG, S, W>;
-    using L = FinishLoads<RG, S, W>;
+    using L = FinishLoads<RG, S, W, D2>;
     constexpr int NP = C::NP, NPASS = C::NPASS, MW = L::MW;
     const float kInf = __int_as_float(0x7f800000);
     if (MW == 2) { l.km[MW - 1].z = 0u; l.km[MW - 1].w = 0u; }               // words 6 and 7 are E and the flag, not sector bits
@@ -1658,13 +1687,42 @@ __device__ __forceinline__ float sc_screen2_finish_compute(const ScreenArgs &a, 
     float dlo[MASKS ? W : 1];
 #pragma unroll
     for (int t = 0; t < W; ++t) { dsh[t] = kInf; if (MASKS) dlo[MASKS ? t : 0] = kInf; }
+    // the ring parts' sums of a tile row, in the order of the parts; the tiles' rows that are shifts: 13 of pass 0, W - 13 of pass 1
+    constexpr int NPA = L::NPA;
+    f4v psum[NPASS][4];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            if (4 * g4 >= kS2PassRows || W - 1 - kS2PassRows * p - 4 * g4 < 0) continue;
+            f4v sm = l.pv[p * 4 + g4];                                       // part 0
+#pragma unroll
+            for (int h = 1; h < NPA; ++h) sm += l.pv[(h * NPASS + p) * 4 + g4];
+            psum[p][g4] = sm;
+        }
+    if constexpr (NP > NPA) {
+        f4v rv[NP - NPA][NPASS][4];
+#pragma unroll
+        for (int h = NPA; h < NP; ++h)
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+                    if (4 * g4 < kS2PassRows && W - 1 - kS2PassRows * p - 4 * g4 >= 0) rv[h - NPA][p][g4] = l.rest[((h - NPA) * NPASS + p) * 4 + g4];
+#pragma unroll
+        for (int h = NPA; h < NP; ++h)
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+                    if (4 * g4 < kS2PassRows && W - 1 - kS2PassRows * p - 4 * g4 >= 0) psum[p][g4] += rv[h - NPA][p][g4];
+    }
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            f4v sm = l.pv[p * 4 + g4];                                       // part 0
-#pragma unroll
-            for (int h = 1; h < NP; ++h) sm += l.pv[(h * NPASS + p) * 4 + g4];
+            if (4 * g4 >= kS2PassRows || W - 1 - kS2PassRows * p - 4 * g4 < 0) continue;
+            const f4v sm = psum[p][g4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = 4 * g4 + r;                                    // row m of pass p = shift W - 1 - 13 p - m
@@ -1703,18 +1761,20 @@ __device__ __forceinline__ float sc_screen2_finish_compute(const ScreenArgs &a, 
     }
     // nanoflann's metric (nanoflann.hpp:383-408) for the ring-key top-k: four dimensions per step, fp32, groups accumulated in
     // order -- the arithmetic of sc_align_role, here with consecutive threads on consecutive slots of the tiled key table
-    const int slot = a.slot_base + ci;
-    float result = 0.0f;
+    if constexpr (D2) {
+        const int slot = a.slot_base + ci;
+        float result = 0.0f;
 #pragma unroll
-    for (int r = 0; r < RG; ++r) {
-        float4 bk;
-        if constexpr (L::kRingUpFront) bk = l.bk[r]; else bk = a.rkey4[(size_t)r * a.rk_cap + slot];
-        const float4 qk = *reinterpret_cast<const float4 *>(a.q_rkey + 4 * r);
-        const float d0 = qk.x - bk.x, d1 = qk.y - bk.y, d2 = qk.z - bk.z, d3 = qk.w - bk.w;
-        const float grp = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-        result += grp;
+        for (int r = 0; r < RG; ++r) {
+            float4 bk;
+            if constexpr (L::kRingUpFront) bk = l.bk[r]; else bk = a.rkey4[(size_t)r * a.rk_cap + slot];
+            const float4 qk = *reinterpret_cast<const float4 *>(a.q_rkey + 4 * r);
+            const float d0 = qk.x - bk.x, d1 = qk.y - bk.y, d2 = qk.z - bk.z, d3 = qk.w - bk.w;
+            const float grp = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            result += grp;
+        }
+        a.out_d2[ci] = result;
     }
-    a.out_d2[ci] = result;
     return exact_only ? kInf : dmin;
 }
 template <int RG, int S, int W>
@@ -1724,7 +1784,7 @@ __device__ __forceinline__ float sc_screen2_finish_pair(const Screen2Args &fa, c
     return sc_screen2_finish_compute<RG, S, W>(a, ci, rotq, q_bad, __uint_as_float(a.q_kmask[6]), l, pair_eps);
 }
 
-template <int RG, int S, int W, bool MASKS = true>
+template <int RG, int S, int W, bool MASKS = true, bool D2 = true>
 __device__ __forceinline__ void sc_screen2_finish_body(const Screen2Args &fa, const int qi, const int chunk)
 {
     constexpr int NW64 = (S + 63) / 64, MW = (NW64 + 1) / 2;
@@ -1734,13 +1794,13 @@ __device__ __forceinline__ void sc_screen2_finish_body(const Screen2Args &fa, co
     __shared__ float wmin[4], wmax[4];
     const int ci = (int)(chunk * blockDim.x + threadIdx.x);
     const bool live = ci < a.n;
-    FinishLoads<RG, S, W> ld = sc_screen2_finish_request<RG, S, W>(fa, a, qi, live ? ci : 0);   // (a.n >= 1 where a workgroup was launched for the scan)
+    FinishLoads<RG, S, W, D2> ld = sc_screen2_finish_request<RG, S, W, D2>(fa, a, qi, live ? ci : 0);   // (a.n >= 1 where a workgroup was launched for the scan)
     build_rotq<S>(a.q_kmask, rotq, (int)threadIdx.x, (int)blockDim.x);
     const bool q_bad = a.q_kmask[7] != 0;
     __syncthreads();
     const float kInf = __int_as_float(0x7f800000);
     float contrib = kInf, peps = 0.0f;
-    if (live) contrib = sc_screen2_finish_compute<RG, S, W, MASKS>(a, ci, rotq, q_bad, __uint_as_float(a.q_kmask[6]), ld, peps);
+    if (live) contrib = sc_screen2_finish_compute<RG, S, W, MASKS, D2>(a, ci, rotq, q_bad, __uint_as_float(a.q_kmask[6]), ld, peps);
     // (wave minimum / maximum by DPP row exchanges: twelve ds_bpermute round trips per thread otherwise)
     contrib = -wave_max_f32_dpp(-contrib);
     peps = wave_max_f32_dpp(peps);
@@ -1801,7 +1861,7 @@ __global__ __launch_bounds__(kScreenWaves * kWave, 2) void sc_screen2_tail_kerne
 }
 
 // ... with the alignment in its second form (one keyframe against the next batch's scans per wave)
-template <int RG, int S, int W, bool MASKS = true>
+template <int RG, int S, int W, bool MASKS = true, bool D2 = true>
 __global__ __launch_bounds__(kScreenWaves * kWave, Align2Cfg<S>::OCC) void sc_screen2_tail2_kernel(Screen2Args fa, ScreenBatchArgs nb, const unsigned char *halign, int u_lo, int u_n,
                                                                                      int align_blocks, int chunks)
 {
@@ -1818,7 +1878,7 @@ __global__ __launch_bounds__(kScreenWaves * kWave, Align2Cfg<S>::OCC) void sc_sc
         return;
     }
     const int fb = b - align_blocks;
-    sc_screen2_finish_body<RG, S, W, MASKS>(fa, fb / chunks, fb - (fb / chunks) * chunks);
+    sc_screen2_finish_body<RG, S, W, MASKS, D2>(fa, fb / chunks, fb - (fb / chunks) * chunks);
 }
 
 static bool screen_second_form()
@@ -2077,10 +2137,12 @@ static hipError_t launch_screen_grid(const DbView &db, const ScreenBatch &sb, in
                     int ulo, un;
                     union_of(*next, &ulo, &un);
                     const int ablocks = align2_blocks(un);
-                    if (sb.smask) hipLaunchKernelGGL((sc_screen2_tail2_kernel<RG, S, W, true>), dim3(ablocks + chunks * sb.nq), dim3(kScreenWaves * kWave), lds_a2, stream, f2, nb, db.halign, ulo, un,
-                                                     ablocks, chunks);
-                    else hipLaunchKernelGGL((sc_screen2_tail2_kernel<RG, S, W, false>), dim3(ablocks + chunks * sb.nq), dim3(kScreenWaves * kWave), lds_a2, stream, f2, nb, db.halign, ulo, un,
-                                            ablocks, chunks);
+                    const dim3 tgrid(ablocks + chunks * sb.nq), tblock(kScreenWaves * kWave);
+                    const bool d2 = !sb.no_ring_metric;                       // (left to the exact pass of the range: kernels.hpp)
+                    if (sb.smask && d2) hipLaunchKernelGGL((sc_screen2_tail2_kernel<RG, S, W, true, true>), tgrid, tblock, lds_a2, stream, f2, nb, db.halign, ulo, un, ablocks, chunks);
+                    else if (sb.smask) hipLaunchKernelGGL((sc_screen2_tail2_kernel<RG, S, W, true, false>), tgrid, tblock, lds_a2, stream, f2, nb, db.halign, ulo, un, ablocks, chunks);
+                    else if (d2) hipLaunchKernelGGL((sc_screen2_tail2_kernel<RG, S, W, false, true>), tgrid, tblock, lds_a2, stream, f2, nb, db.halign, ulo, un, ablocks, chunks);
+                    else hipLaunchKernelGGL((sc_screen2_tail2_kernel<RG, S, W, false, false>), tgrid, tblock, lds_a2, stream, f2, nb, db.halign, ulo, un, ablocks, chunks);
                 } else {
                     const int ng2 = (nmax2 + kGroup - 1) / kGroup;
                     int per_q = 3 * num_cu / next->nq;
