@@ -519,6 +519,7 @@ int scl_create(const scl_config *cfg, scl_engine **out)
         if (hipHostMalloc((void **)&e->h_stream_out, (size_t)2 * NS * 64, hipHostMallocDefault) != hipSuccess) return bail(SCL_ERR_HIP);
         for (auto &ev : e->ev_chunk) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return bail(SCL_ERR_HIP);
         for (auto &ev : e->ev_k1) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return bail(SCL_ERR_HIP);
+        for (auto &ev : e->ev_sub0) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return bail(SCL_ERR_HIP);
         if (hipEventCreateWithFlags(&e->ev_align_gate, hipEventDisableTiming) != hipSuccess) return bail(SCL_ERR_HIP);
         {   // lowest priority: its workgroups take the slots the products leave, not the other way round
             int lo_p = 0, hi_p = 0;
@@ -590,6 +591,7 @@ int scl_destroy(scl_engine *e)
     if (e->ev_afork) (void)hipEventDestroy(e->ev_afork);
     if (e->ev_ajoin) (void)hipEventDestroy(e->ev_ajoin);
     for (auto ev : e->ev_k1) if (ev) (void)hipEventDestroy(ev);
+    for (auto ev : e->ev_sub0) if (ev) (void)hipEventDestroy(ev);
     if (e->ev_align_gate) (void)hipEventDestroy(e->ev_align_gate);
     dev_free(e->d_topk_scratch); dev_free(e->d_topk_idx); dev_free(e->d_topk_d2); dev_free(e->d_out3);
     dev_free(e->d_blk_part); dev_free(e->d_done_counter);
@@ -1081,7 +1083,8 @@ int launch_survivor_pass(scl_engine *e, const int *qslot, const int *lo, const i
 
 // The exact pass of the 80 x 180 grid over the screened queries of buffer sets set0 .. set0 + nq - 1: per group of up to four
 // queries the select launch (survivor lists + ring-key top-k), the one-sector-per-lane program on the survivors and the arg-min.
-int launch_survivor_pass_wide(scl_engine *e, const int *qslot, const int *lo, const int *n, int nq, int set0, double *const *out3, hipStream_t stream)
+// first_done (optional): recorded behind the pass's first group of kWideExactBatch scans
+int launch_survivor_pass_wide(scl_engine *e, const int *qslot, const int *lo, const int *n, int nq, int set0, double *const *out3, hipStream_t stream, hipEvent_t first_done = nullptr)
 {
     ProfScope ps(e, P_ARGMIN, stream);
     for (int g = 0; g < nq; g += kWideExactBatch) {
@@ -1104,6 +1107,7 @@ int launch_survivor_pass_wide(scl_engine *e, const int *qslot, const int *lo, co
         }
         SCL_HIP(e, launch_sc_distance_survivors_wide(db_view(e), w, qslot + g, lo + g, e->SR, sv, ns, od, os, out3 + g, e->num_cu, stream,
                                                      e->d_smask ? st : nullptr, e->d_smask ? sm : nullptr));
+        if (g == 0 && first_done) SCL_HIP(e, hipEventRecord(first_done, stream));
     }
     return SCL_OK;
 }
@@ -1465,6 +1469,7 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
     struct Pending { int qslot[kMaxScreenBatch], lo[kMaxScreenBatch], n[kMaxScreenBatch], nq = 0, set0 = 0, half = 0; bool valid = false; } pend;
     struct Owed { List L; int c = 0, region = 0; bool valid = false; } owed;
     int part_half = 0;
+    bool sub0_valid[2] = {false, false};                    // ev_sub0[c] was recorded by the exact pass that ev_chunk[c] ends
     const bool keys_later = !wide;                          // the exact pass of a chunk forms the ring-key metric of its ranges (beside the next chunk's products)
     auto pend_group = [&]() { ScreenGroup g{pend.qslot, pend.lo, pend.n, pend.nq, pend.set0}; g.part_half = pend.half; g.keys_later = keys_later; return g; };
     // the exact pass of chunk `o.c` on the side stream, behind everything the main stream holds now
@@ -1476,9 +1481,10 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
         SCL_HIP(e, hipEventRecord(e->ev_k1[oc], e->stream));
         SCL_HIP(e, hipStreamWaitEvent(e->stream_surv, e->ev_k1[oc], 0));
         int r2 = SCL_OK;
-        if (owed.L.m > 0) r2 = wide ? launch_survivor_pass_wide(e, owed.L.qslot, owed.L.qlo, owed.L.qn, owed.L.m, oc * CH, out3, e->stream_surv)
+        if (owed.L.m > 0) r2 = wide ? launch_survivor_pass_wide(e, owed.L.qslot, owed.L.qlo, owed.L.qn, owed.L.m, oc * CH, out3, e->stream_surv, e->ev_sub0[oc])
                                     : launch_survivor_pass(e, owed.L.qslot, owed.L.qlo, owed.L.qn, owed.L.m, oc * CH, out3, e->stream_surv, kSurvivorKernel, owed.region, keys_later);
         if (r2) return r2;
+        sub0_valid[oc] = wide && owed.L.m > 0;
         SCL_HIP(e, hipEventRecord(e->ev_chunk[oc], e->stream_surv));
         owed.valid = false;
         return SCL_OK;
@@ -1554,7 +1560,9 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
                 const int wn = nxt.m < spl ? nxt.m : spl;
                 nx = ScreenGroup{nxt.qslot, nxt.qlo, nxt.qn, wn, nset0};
                 nx.keys_later = keys_later;
-                if (ch[c ^ 1].busy) SCL_HIP(e, hipStreamWaitEvent(e->stream, e->ev_chunk[c ^ 1], 0));
+                // (80 x 180: the exact pass of a chunk is several launch groups, one per kWideExactBatch buffer sets, and nearly as
+                //  long as the next chunk's screening: this launch's alignment writes the first group's sets only and waits for those)
+                if (ch[c ^ 1].busy) SCL_HIP(e, hipStreamWaitEvent(e->stream, (wide && sub0_valid[c ^ 1] && wn <= kWideExactBatch) ? e->ev_sub0[c ^ 1] : e->ev_chunk[c ^ 1], 0));
                 next_aligned = true;
             }
             const int phases = ((g == 0 && !k.aligned) ? (kScreenAlign | kScreenProducts) : kScreenProducts) | (defer ? kScreenDeferFinish : 0);
@@ -1590,7 +1598,8 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
             SCL_HIP(e, hipEventRecord(e->ev_k1[c], e->stream_surv));         // behind the copy of the argument sets
             SCL_HIP(e, hipStreamWaitEvent(e->stream, e->ev_k1[c], 0));
         }
-        if (cur.m > 0 && (rc = wide ? launch_survivor_pass_wide(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, xs)
+        sub0_valid[c] = wide && cur.m > 0;
+        if (cur.m > 0 && (rc = wide ? launch_survivor_pass_wide(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, xs, e->ev_sub0[c])
                                     : launch_survivor_pass(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, xs, kSurvivorKernel, region, keys_later))) return rc;
         SCL_HIP(e, hipEventRecord(e->ev_chunk[c], xs));
         k.busy = true;
@@ -1602,20 +1611,27 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
     };
     auto collect = [&](int c, bool last) -> int {
         Chunk &k = ch[c];
-        if (last) {   // nothing left to submit, the caller waits for this: poll (a blocking wait wakes up tens of microseconds late)
+        // A chunk's event is polled (for up to 20 ms, then the runtime's blocking wait): the blocking wait wakes up late -- tens of
+        // microseconds as a rule, but the next chunk's launches are enqueued only after it, and on the 80 x 180 grid, whose exact
+        // pass ends late in the following chunk's screening, the main stream ran dry for 100-120 us of every chunk (a tenth)
+        auto wait_chunk = [&]() -> hipError_t {
             hipError_t q;
-            while ((q = hipEventQuery(e->ev_chunk[c])) == hipErrorNotReady) { }
-            SCL_HIP(e, q);
-        } else if (!owed.valid && !pend.valid) {
+            const auto t0 = std::chrono::steady_clock::now();
+            int spins = 0;
+            while ((q = hipEventQuery(e->ev_chunk[c])) == hipErrorNotReady)
+                if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) return hipEventSynchronize(e->ev_chunk[c]);
+            return q;
+        };
+        if (last || owed.valid || pend.valid) {
+            SCL_HIP(e, wait_chunk());
+        } else {
             // more to submit behind this wait: the database lock is free meanwhile (appends get in; nothing of this call's state
             // names a slot or a pointer that a capacity doubling could move: the chunks in flight are enqueued, the next one is
             // built after the lock is back)
             db.unlock();
-            const hipError_t w = hipEventSynchronize(e->ev_chunk[c]);
+            const hipError_t w = wait_chunk();
             db.lock();
             SCL_HIP(e, w);
-        } else {
-            SCL_HIP(e, hipEventSynchronize(e->ev_chunk[c]));
         }
         collect_profile(e);
         for (int i = 0; i < k.count; ++i) {

@@ -175,7 +175,7 @@ hipError_t launch_sc_masked(const struct DbView &db, int SR, const MaskedQuery *
 // ring_d2 = its ring-key metric (the exact pass forms the top-k from it).  launch_sc_select_batch (diagnostics only):
 // survivors = the database slots (ascending) that can still hold the minimum.
 // t_min: one word per query, 0xffffffff before the first launch (the select launch re-arms it).
-constexpr int kWideExactBatch = 12;         // queries per launch of the 80 x 180 grid's exact pass (select, one-sector-per-lane program, arg-min): a screening launch's worth
+constexpr int kWideExactBatch = 16;         // queries per launch of the 80 x 180 grid's exact pass (select, one-sector-per-lane program, arg-min): a screening launch's worth
 constexpr int kMaxScreenBatch = 16;         // scans per screening launch (the fused exact kernel of the 20 x 60 grid keeps kMaxQueryBatch)
 struct ScreenBatch {
     int nq;

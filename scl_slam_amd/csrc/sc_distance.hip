@@ -241,8 +241,9 @@ __global__ __launch_bounds__(MAXT) void sc_distance_kernel(ScArgs a)
     sc_distance_body<RG, W, MAXT>(a, smem);
 }
 
-// the same program for the survivor lists of up to kWideExactBatch queries in one launch: blockIdx.y = query
-struct ScArgsBatch { ScArgs q[kWideExactBatch]; };
+// the same program for the survivor lists of up to kWideLegacyBatch queries in one launch: blockIdx.y = query
+constexpr int kWideLegacyBatch = 12;         // (twelve argument sets are what the launch's argument block holds)
+struct ScArgsBatch { ScArgs q[kWideLegacyBatch]; };
 static_assert(sizeof(ScArgsBatch) <= 4096, "kernel arguments end at 4 KB");
 template <int RG, int W, int MAXT>
 __global__ __launch_bounds__(MAXT) void sc_distance_batch4_kernel(ScArgsBatch ab)
@@ -1568,7 +1569,14 @@ hipError_t launch_sc_distance_survivors_wide(const DbView &db, int nq, const int
         hipLaunchKernelGGL(argmin_survivors_batch_kernel, dim3(nq), dim3(1024), 0, stream, mb);
         return hipGetLastError();
     }
-    for (int i = 0; i < kWideExactBatch; ++i) {
+    if (nq > kWideLegacyBatch) {                                // (SCL_WIDE_EXACT=0 / no shift masks: two launches of the older program)
+        hipError_t e = launch_sc_distance_survivors_wide(db, kWideLegacyBatch, query_slot, slot_base, SR, survivors, n_surv, out_dist, out_shift, out3, num_cu, stream, starts, smask);
+        if (e != hipSuccess) return e;
+        const int o = kWideLegacyBatch;
+        return launch_sc_distance_survivors_wide(db, nq - o, query_slot + o, slot_base + o, SR, survivors + o, n_surv + o, out_dist + o, out_shift + o, out3 + o, num_cu, stream,
+                                                 starts ? starts + o : nullptr, smask ? smask + o : nullptr);
+    }
+    for (int i = 0; i < kWideLegacyBatch; ++i) {
         const int j = i < nq ? i : 0;
         ScArgs &a = ab.q[i];
         const size_t slot = (size_t)query_slot[j];

@@ -1222,7 +1222,7 @@ hipError_t launch_sc_select_batch(const ScreenBatch &sb, hipStream_t stream)
 #define S2RS_B 9
 #endif
 #ifndef S2WV_B
-#define S2WV_B 12
+#define S2WV_B 16
 #endif
 #ifndef S2WV_A
 #define S2WV_A 16
