@@ -1248,15 +1248,21 @@ template <int RG, int S, int W> struct S2Cfg;
 // one beside the products (sc_screen2_kernel): the products leave two thirds of the vector and matrix-core issue slots idle
 // NP ring parts, NPASS passes of 13 shift rows, STEPS k-steps per iteration (= per keyframe fragment), SPK sectors per k-step:
 // a k-step's 32 products are 32 rings of one sector (SPK = 1) or 16 rings of two consecutive sectors (SPK = 2)
-template <> struct S2Cfg<16, 120, 13> { static constexpr int NP = 2, NPASS = 1, STEPS = 4, SPK = 1, NQ = 16, RS = S2RS_A, WV = S2WV_A, WVF = S2WVF_A, XW = S2XW_A, NBUF = S2NBUF_A; };
+template <> struct S2Cfg<16, 120, 13> { static constexpr int NP = 2, NPASS = 1, STEPS = 4, SPK = 1, PS = 13, NQ = 16, RS = S2RS_A, WV = S2WV_A, WVF = S2WVF_A, XW = S2XW_A, NBUF = S2NBUF_A; };
 #ifdef S2_WIDE_THIRDS
 // (rounds 3-4: 96 padded rings as three thirds of 32, twelve scans per launch -- 141 KB of LDS; 37 % of the matrix-core work useful)
-template <> struct S2Cfg<20, 180, 19> { static constexpr int NP = 3, NPASS = 2, STEPS = 4, SPK = 1, NQ = 12, RS = 9, WV = S2WV_B, WVF = 8, XW = S2XW_B, NBUF = S2NBUF_B; };
+template <> struct S2Cfg<20, 180, 19> { static constexpr int NP = 3, NPASS = 2, STEPS = 4, SPK = 1, PS = 13, NQ = 12, RS = 9, WV = S2WV_B, WVF = 8, XW = S2XW_B, NBUF = S2NBUF_B; };
 #else
 // 80 rings as five slices of 16, two sectors per k-step: no padded rings, sixteen scans per launch (16 x 183 sectors x 32 B = 94 KB)
-template <> struct S2Cfg<20, 180, 19> { static constexpr int NP = 5, NPASS = 2, STEPS = 2, SPK = 2, NQ = 16, RS = 9, WV = S2WV_B, WVF = 8, XW = S2XW_B, NBUF = S2NBUF_B; };
+// PS = 12: the two passes share the scans' fragments -- pass 1 (shifts 5 .. 0 in rows 1 .. 6) multiplies the keyframe fragment of this
+// iteration, pass 0 (shifts 18 .. 6) the fragment of three iterations (12 sectors) ago: one LDS read per TWO matrix products (with PS = 13
+// each pass read the scan at its own offset, and the LDS array was as busy as the matrix cores)
+#ifndef S2_WIDE_PS
+#define S2_WIDE_PS 12
 #endif
-constexpr int kS2PassRows = 13;                    // shift rows per pass: row m of pass p = shift W - 1 - 13 p - m
+template <> struct S2Cfg<20, 180, 19> { static constexpr int NP = 5, NPASS = 2, STEPS = 2, SPK = 2, PS = S2_WIDE_PS, NQ = 16, RS = 9, WV = S2WV_B, WVF = 8, XW = S2XW_B, NBUF = S2NBUF_B; };
+#endif
+constexpr int kS2PassRows = 13;                    // shift rows per pass: row m of pass p = shift W - 1 - PS p - m (PS = 13; 12: row 0 of pass 1 repeats row 12 of pass 0)
 
 // LDS image of the scans (see above): quad stride in bytes, 2 mod 4 sixteen-byte slots
 // (SECT = sectors per iteration; SPK = 2: eight scans of 32 B share a row, a lane's slot is 2 (q & 7) + (j & 1) whatever its sector:
@@ -1296,7 +1302,10 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
 {
     constexpr int WVP = FUSED ? S2Cfg<RG, S, W>::WVF : S2Cfg<RG, S, W>::WV;
     using C = S2Cfg<RG, S, W>;
-    constexpr int NP = C::NP, NPASS = C::NPASS, STEPS = C::STEPS, NQ = C::NQ, SPK = C::SPK;
+    constexpr int NP = C::NP, NPASS = C::NPASS, STEPS = C::STEPS, NQ = C::NQ, SPK = C::SPK, PS = C::PS;
+    constexpr bool AOFF = PS != kS2PassRows;           // the passes share the scans' fragments (see S2Cfg)
+    constexpr int NB = AOFF ? 1 : NPASS;               // fragment sets of the scans per iteration
+    constexpr int LAG = AOFF ? PS / 4 : 0;             // iterations between the keyframe fragments of pass 0 and pass 1
     constexpr int RGH = hdesc_rgh(RG);
     constexpr int SB = RGH * 8;                        // bytes of one sector in hdesc (all rings, fp16)
     constexpr int HS = hdesc_stride(RG, S);
@@ -1305,7 +1314,7 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
     constexpr int ROWS = S + SECT - 1;                 // sectors per scan in LDS: the reads of an iteration never wrap
     constexpr int QUAD = s2_quad(S, SECT, SPK);        // bytes of a block of SPR scans in the image
     constexpr int SPR = 4 * SPK, SCB = 64 / SPK;       // scans per 256-byte row of the image; a scan's bytes in it (its ring part of one sector)
-    static_assert(SB >= SCB * NP && SB == 64 * ((NP * SCB + 63) / 64) && S % SECT == 0 && SECT == 4 && kS2PassRows + SPK * (STEPS - 1) <= 16 && W <= NPASS * kS2PassRows
+    static_assert(SB >= SCB * NP && SB == 64 * ((NP * SCB + 63) / 64) && S % SECT == 0 && SECT == 4 && kS2PassRows + SPK * (STEPS - 1) <= 16 && W <= PS * (NPASS - 1) + kS2PassRows && (!AOFF || (NPASS == 2 && PS == 12))
                   && NQ % SPR == 0 && NQ <= kMaxScreenBatch && (SPK == 1 || SPK == 2), "second form");
     static_assert(SPK == 2 ? QUAD % 256 == 0 : (QUAD / 16) % 4 == 2, "bank slots of the image's blocks");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
@@ -1459,27 +1468,27 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
     // (mod S; the image repeats STEPS - 1 sectors so that the reads of an iteration never wrap).  The lane's address is ONE of two
     // fixed bases -- before and after its wrap -- plus a compile-time offset of 1 KB per iteration: a compare and a select per
     // iteration and pass instead of the running pointer's five instructions (the vector issue port is what binds this kernel).
-    const unsigned char *preB[NPASS], *postB[NPASS];      // (pointers: the image's base address is added once per keyframe, not per read)
-    int wrapB[NPASS];                                    // first iteration that reads from the wrapped base
+    const unsigned char *preB[NB], *postB[NB];            // (pointers: the image's base address is added once per keyframe, not per read)
+    int wrapB[NB];                                       // first iteration that reads from the wrapped base
     auto scan_bases = [&](const int first) {
 #pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
-            int c0 = first + (W - 1) - kS2PassRows * p;
+        for (int p = 0; p < NB; ++p) {
+            int c0 = first + (W - 1) - PS * (AOFF ? 1 : p);   // (shared fragments: the scan where pass 1 wants it)
             c0 = c0 >= S ? c0 - S : c0;
             preB[p] = smem2 + (q_lds + (unsigned int)c0 * 256u);
             postB[p] = preB[p] - S * 256;
             wrapB[p] = (S - c0 + SECT - 1) / SECT;       // smallest it with c0 + 4 it >= S
         }
     };
-    auto readB = [&](h8 (&dst)[NPASS][STEPS], const int it) {
+    auto readB = [&](h8 (&dst)[NB][STEPS], const int it) {
 #pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
+        for (int p = 0; p < NB; ++p) {
             const unsigned char *qp = (it < wrapB[p] ? preB[p] : postB[p]) + it * SECT * 256;
 #pragma unroll
             for (int u = 0; u < STEPS; ++u) dst[p][u] = *reinterpret_cast<const h8 *>(qp + 256 * SPK * u);
         }
     };
-    h8 bfr[2][NPASS][STEPS];
+    h8 bfr[2][NB][STEPS];
     scan_bases(b_cur);
     readB(bfr[0], 0);
     for (int k = 0; k < nk; ++k) {
@@ -1514,6 +1523,7 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
             return fr;
         };
         u32x4 fr_cur = F[0];
+        u32x4 fr_h1 = fr_cur, fr_h2 = fr_cur, fr_h3 = fr_cur;   // (shared fragments) the keyframe fragments of the last three iterations
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int g = it >> 2, o = it & 3;
@@ -1538,24 +1548,56 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
             u32x4 fr_nxt = fr_cur;
             if (it + 1 < NIT) fr_nxt = fragment_of(it + 1);
             const h8 af = __builtin_bit_cast(h8, fr_cur);
+            const int nmm = (AOFF && it < LAG) ? STEPS : STEPS * NPASS;                    // matrix products of this iteration
+            if constexpr (AOFF) {
+                const h8 ah = __builtin_bit_cast(h8, fr_h3);
 #pragma unroll
-            for (int u = 0; u < STEPS; ++u)
+                for (int u = 0; u < STEPS; ++u) {
+                    acc[1][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfr[it & 1][0][u], acc[1][u], 0, 0, 0);
+                    if (it >= LAG) acc[0][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bfr[it & 1][0][u], acc[0][u], 0, 0, 0);
+                }
+            } else {
 #pragma unroll
-                for (int p = 0; p < NPASS; ++p)
-                    acc[p][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfr[it & 1][p][u], acc[p][u], 0, 0, 0);
+                for (int u = 0; u < STEPS; ++u)
+#pragma unroll
+                    for (int p = 0; p < NPASS; ++p)
+                        acc[p][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfr[it & 1][p][u], acc[p][u], 0, 0, 0);
+            }
 #ifndef S2_NO_INTERLEAVE
             if (it + 1 < NIT && ((it + 1) & 3) != 0) {
+                if (nmm == STEPS * NPASS) {
 #pragma unroll
-                for (int x = 0; x < STEPS * NPASS; ++x) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     // one matrix product
-                    __builtin_amdgcn_sched_group_barrier(0x002, 8 / (STEPS * NPASS), 0);   // its share of the eight moves
+                    for (int x = 0; x < STEPS * NPASS; ++x) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     // one matrix product
+                        __builtin_amdgcn_sched_group_barrier(0x002, 8 / (STEPS * NPASS), 0);   // its share of the eight moves
+                    }
+                } else {
+#pragma unroll
+                    for (int x = 0; x < STEPS; ++x) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 8 / STEPS, 0);
+                    }
                 }
             }
 #endif
 #ifndef S2_NO_ITER_BARRIER
             __builtin_amdgcn_sched_barrier(0);
 #endif
+            if constexpr (AOFF) { fr_h3 = fr_h2; fr_h2 = fr_h1; fr_h1 = fr_cur; }
             fr_cur = fr_nxt;
+        }
+        if constexpr (AOFF) {
+            // pass 0's products of the first LAG iterations' scan fragments: with the keyframe's LAST fragments (the sectors wrap), which are
+            // at hand only now; the scan fragments are read once more
+            h8 bx[LAG][NB][STEPS];
+#pragma unroll
+            for (int x = 0; x < LAG; ++x) readB(bx[x], x);
+#pragma unroll
+            for (int x = 0; x < LAG; ++x) {
+                const h8 ah = __builtin_bit_cast(h8, x == 0 ? fr_h3 : (x == 1 ? fr_h2 : fr_h1));
+#pragma unroll
+                for (int u = 0; u < STEPS; ++u) acc[0][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bx[x][0][u], acc[0][u], 0, 0, 0);
+            }
         }
         if (k < 6) S2_STAMP_AT(35 + 3 * k);
         // (the loads of the next keyframe that no group of this one reached: their buffers are free now)
@@ -1669,7 +1711,7 @@ __device__ __forceinline__ float sc_screen2_finish_compute(const ScreenArgs &a, 
 {
     using C = S2Cfg<RG, S, W>;
     using L = FinishLoads<RG, S, W, D2>;
-    constexpr int NP = C::NP, NPASS = C::NPASS, MW = L::MW;
+    constexpr int NP = C::NP, NPASS = C::NPASS, MW = L::MW, PS = C::PS;
     const float kInf = __int_as_float(0x7f800000);
     if (MW == 2) { l.km[MW - 1].z = 0u; l.km[MW - 1].w = 0u; }               // words 6 and 7 are E and the flag, not sector bits
     const bool b_open = l.b_raw < 0;                                         // kAlignUndecided: scored by the exact pass
@@ -1694,7 +1736,7 @@ __device__ __forceinline__ float sc_screen2_finish_compute(const ScreenArgs &a, 
     for (int p = 0; p < NPASS; ++p)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            if (4 * g4 >= kS2PassRows || W - 1 - kS2PassRows * p - 4 * g4 < 0) continue;
+            if (4 * g4 >= kS2PassRows || W - 1 - PS * p - 4 * g4 < 0) continue;
             f4v sm = l.pv[p * 4 + g4];                                       // part 0
 #pragma unroll
             for (int h = 1; h < NPA; ++h) sm += l.pv[(h * NPASS + p) * 4 + g4];
@@ -1708,26 +1750,26 @@ __device__ __forceinline__ float sc_screen2_finish_compute(const ScreenArgs &a, 
             for (int p = 0; p < NPASS; ++p)
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4)
-                    if (4 * g4 < kS2PassRows && W - 1 - kS2PassRows * p - 4 * g4 >= 0) rv[h - NPA][p][g4] = l.rest[((h - NPA) * NPASS + p) * 4 + g4];
+                    if (4 * g4 < kS2PassRows && W - 1 - PS * p - 4 * g4 >= 0) rv[h - NPA][p][g4] = l.rest[((h - NPA) * NPASS + p) * 4 + g4];
 #pragma unroll
         for (int h = NPA; h < NP; ++h)
 #pragma unroll
             for (int p = 0; p < NPASS; ++p)
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4)
-                    if (4 * g4 < kS2PassRows && W - 1 - kS2PassRows * p - 4 * g4 >= 0) psum[p][g4] += rv[h - NPA][p][g4];
+                    if (4 * g4 < kS2PassRows && W - 1 - PS * p - 4 * g4 >= 0) psum[p][g4] += rv[h - NPA][p][g4];
     }
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            if (4 * g4 >= kS2PassRows || W - 1 - kS2PassRows * p - 4 * g4 < 0) continue;
+            if (4 * g4 >= kS2PassRows || W - 1 - PS * p - 4 * g4 < 0) continue;
             const f4v sm = psum[p][g4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = 4 * g4 + r;                                    // row m of pass p = shift W - 1 - 13 p - m
-                const int t = W - 1 - kS2PassRows * p - m;
-                if (m >= kS2PassRows || t < 0) continue;
+                const int t = W - 1 - PS * p - m;
+                if (m >= kS2PassRows || t < 0 || (p > 0 && t >= W - 1 - PS * (p - 1) - (kS2PassRows - 1))) continue;   // (a shift the pass in front holds)
                 int ri = b0 + t; ri = ri >= S ? ri - S : ri;
                 int ne = 0;
 #pragma unroll
