@@ -524,7 +524,11 @@ int scl_create(const scl_config *cfg, scl_engine **out)
         {   // lowest priority: its workgroups take the slots the products leave, not the other way round
             int lo_p = 0, hi_p = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
-            if (hipStreamCreateWithPriority(&e->stream_surv, hipStreamNonBlocking, lo_p) != hipSuccess) return bail(SCL_ERR_HIP);
+            // (80 x 180: the exact pass is a dozen short launches per chunk with a handful of survivors each, and the next-but-one chunk is
+            //  submitted when it has ended: starved by the products -- 150-180 us per masked launch instead of 35 -- it ended when the
+            //  next chunk's screening did and the main stream ran dry for 60 us per chunk.  There it goes FIRST.)
+            const bool wide_grid = e->S == 180 && e->RG == 20;
+            if (hipStreamCreateWithPriority(&e->stream_surv, hipStreamNonBlocking, wide_grid ? hi_p : lo_p) != hipSuccess) return bail(SCL_ERR_HIP);
             if (hipStreamCreateWithPriority(&e->stream_align, hipStreamNonBlocking, lo_p) != hipSuccess) return bail(SCL_ERR_HIP);
             if (hipEventCreateWithFlags(&e->ev_afork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_ajoin, hipEventDisableTiming) != hipSuccess) return bail(SCL_ERR_HIP);
         }

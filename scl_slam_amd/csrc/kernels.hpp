@@ -137,7 +137,7 @@ struct MaskedQuery {
     int qslot, slot_base, n; const int *n_dev; const int *cand; const int *starts; const unsigned int *smask;
     double *out_dist; int *out_shift;
 };
-struct MaskedArgs { const float4 *desc; const double *norm; int nq, parts; MaskedQuery q[kMaxMaskedQueries]; };
+struct MaskedArgs { const float4 *desc; const double *norm; int nq, parts, spread; MaskedQuery q[kMaxMaskedQueries]; };
 // ---- the exact distance MATRIX on the screened grids (sc_matrix.hip): scans qslots[0 .. nq) against the keyframes [lo, lo + n), every pair at
 // the shifts its mask leaves open.  starts / smask of scan i at i * set_stride + position in the range, results of row i at i * row_stride +
 // position.  kr: keyframes per workgroup (0: the default).
@@ -168,7 +168,9 @@ hipError_t launch_sc_cand_exact(const struct DbView &db, const struct QueryView 
 bool sc_small_exact_supported(const struct DbView &db, int SR);
 hipError_t launch_sc_small_exact(const struct DbView &db, int SR, const SmallExactArgs &args, hipStream_t stream);
 bool sc_masked_supported(const struct DbView &db, int SR);
-hipError_t launch_sc_masked(const struct DbView &db, int SR, const MaskedQuery *queries, int nq, int parts, hipStream_t stream);
+// spread: short survivor lists (only part 0 of a query has work, as a rule): the queries' workgroups go round the XCDs -- the mapping for
+// long lists puts every part 0 on XCD 0, and beside a launch that leaves two CUs per XCD free they ran eight behind each other
+hipError_t launch_sc_masked(const struct DbView &db, int SR, const MaskedQuery *queries, int nq, int parts, hipStream_t stream, bool spread = false);
 // ---- screening pass of the full-DB mode (sc_screen.hip; 64x120 grid) --------------------------------------------
 // Per query i: every keyframe of [base, base+n) gets approx[i*pair_stride + pos] = its reference distance within
 // +- sc_screen_eps() (fp16 matrix-core evaluation of the reference's own 13 shifts; -inf = must be scored exactly),

@@ -1564,7 +1564,7 @@ hipError_t launch_sc_distance_survivors_wide(const DbView &db, int nq, const int
             mb.slot_base[i] = slot_base[i]; mb.out3[i] = out3[i];
         }
         for (int i = nq; i < kWideExactBatch; ++i) { mb.dist[i] = mb.dist[0]; mb.shift[i] = mb.shift[0]; mb.n_dev[i] = mb.n_dev[0]; mb.cand[i] = mb.cand[0]; mb.slot_base[i] = mb.slot_base[0]; mb.out3[i] = mb.out3[0]; }
-        hipError_t e = launch_sc_masked(db, SR, mq, nq, 4, stream);           // four workgroups per scan: 32 survivors at once, more loop
+        hipError_t e = launch_sc_masked(db, SR, mq, nq, 4, stream, true);     // four workgroups per scan: 32 survivors at once, more loop; the scans go round the XCDs
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(argmin_survivors_batch_kernel, dim3(nq), dim3(1024), 0, stream, mb);
         return hipGetLastError();

@@ -252,8 +252,8 @@ __global__ __launch_bounds__((MaskedCfg<RG, S, W>::WAVES * kWave)) void sc_maske
     // workgroup -> (query, part): the workgroups of a launch's queries that walk the same part of the range sit next to each other on
     // one XCD (index & 7) and start together: all but the first find the keyframes' rows in that XCD's L2
     const int b = (int)blockIdx.x, xcd = b & 7, jx = b >> 3;
-    const int qi = jx % ma.nq;
-    const int part = (jx / ma.nq) * 8 + xcd;
+    const int qi = ma.spread ? b % ma.nq : jx % ma.nq;
+    const int part = ma.spread ? b / ma.nq : (jx / ma.nq) * 8 + xcd;
     if (part >= ma.parts) return;
     const MaskedQuery mq = ma.q[qi];
     const int n_items = mq.n_dev ? *mq.n_dev : mq.n;
@@ -306,7 +306,7 @@ hipError_t launch_masked(const MaskedArgs &ma, hipStream_t stream)
         if (e != hipSuccess) return e;
         attr_set.store(true, std::memory_order_release);
     }
-    const int grid = 8 * ((ma.parts + 7) / 8) * ma.nq;
+    const int grid = ma.spread ? ma.parts * ma.nq : 8 * ((ma.parts + 7) / 8) * ma.nq;
     hipLaunchKernelGGL((sc_masked_kernel<RG, S, W>), dim3(grid), dim3(C::WAVES * kWave), C::LDS, stream, ma);
     return hipGetLastError();
 }
@@ -603,11 +603,11 @@ bool sc_masked_supported(const DbView &db, int SR)
     return (db.RG == 16 && db.S == 120 && W == 13) || (db.RG == 20 && db.S == 180 && W == 19);
 }
 
-hipError_t launch_sc_masked(const DbView &db, int SR, const MaskedQuery *queries, int nq, int parts, hipStream_t stream)
+hipError_t launch_sc_masked(const DbView &db, int SR, const MaskedQuery *queries, int nq, int parts, hipStream_t stream, bool spread)
 {
     if (nq < 1 || nq > kMaxMaskedQueries || parts < 1 || !sc_masked_supported(db, SR)) return hipErrorInvalidValue;
     MaskedArgs ma{};
-    ma.desc = db.desc; ma.norm = db.norm; ma.nq = nq; ma.parts = parts;
+    ma.desc = db.desc; ma.norm = db.norm; ma.nq = nq; ma.parts = parts; ma.spread = spread ? 1 : 0;
     for (int i = 0; i < nq; ++i) ma.q[i] = queries[i];
     if (db.S == 120) return launch_masked<16, 120, 13>(ma, stream);
     return launch_masked<20, 180, 19>(ma, stream);

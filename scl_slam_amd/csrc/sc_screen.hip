@@ -1213,7 +1213,7 @@ hipError_t launch_sc_select_batch(const ScreenBatch &sb, hipStream_t stream)
 #define S2NBUF_A 9                    // fragment buffers of the products' second form (loads per keyframe: 9 at S = 120, 12 at S = 180)
 #endif
 #ifndef S2NBUF_B
-#define S2NBUF_B 3
+#define S2NBUF_B 6
 #endif
 #ifndef S2RS_A
 #define S2RS_A 10
@@ -1273,7 +1273,13 @@ template <int RG, int S, int W> constexpr size_t s2_lds()
     using C = S2Cfg<RG, S, W>;
     return (size_t)(C::NQ / (4 * C::SPK)) * s2_quad(S, C::STEPS * C::SPK, C::SPK);
 }
-template <int RG, int S, int W> constexpr int s2_part_floats() { return S2Cfg<RG, S, W>::NP * S2Cfg<RG, S, W>::NPASS * 16; }   // partial sums per pair
+// The partial sums of a pair and ring part: per pass the groups of four tile rows that hold shifts (rows 4 g .. 4 g + 3 of pass p: shifts
+// W - 1 - PS p - 4 g - i), packed -- at 80 x 180 the second pass has six shifts in its sixteen rows: 24 floats per part instead of 32
+template <int RG, int S, int W> constexpr bool s2_group_used(int p, int g4) { return 4 * g4 < kS2PassRows && W - 1 - S2Cfg<RG, S, W>::PS * p - 4 * g4 >= 0; }
+template <int RG, int S, int W> constexpr int s2_pass_f4(int p) { int n = 0; for (int g = 0; g < 4; ++g) n += s2_group_used<RG, S, W>(p, g) ? 1 : 0; return n; }
+template <int RG, int S, int W> constexpr int s2_pass_off(int p) { int o = 0; for (int q = 0; q < p; ++q) o += s2_pass_f4<RG, S, W>(q); return o; }   // in float4
+template <int RG, int S, int W> constexpr int s2_part_f4() { return s2_pass_off<RG, S, W>(S2Cfg<RG, S, W>::NPASS); }
+template <int RG, int S, int W> constexpr int s2_part_floats() { return S2Cfg<RG, S, W>::NP * s2_part_f4<RG, S, W>() * 4; }   // partial sums per pair
 // LDS tile of one extra wave: the alignment image (both parts) / the exact evaluation's scratch, or the finishing's rotated masks
 template <int S> constexpr int s2_xlds() { return Align2Cfg<S>::LDS_WAVE > S * ((((S + 63) / 64) + 1) / 2) * 16 ? Align2Cfg<S>::LDS_WAVE : S * ((((S + 63) / 64) + 1) / 2) * 16; }
 template <int RG, int S, int W, bool FUSED> constexpr size_t s2_lds_total() { return s2_lds<RG, S, W>() + (FUSED ? (size_t)S2Cfg<RG, S, W>::XW * s2_xlds<S>() : 0); }
@@ -1631,7 +1637,8 @@ __global__ __launch_bounds__((s2_waves<RG, S, W, FUSED>() * kWave), 1) void sc_s
 #pragma unroll
                     for (int i = 0; i < 4; ++i) sum[i] += (i + sh <= 3) ? acc[p][u][(i + sh) & 3] : nx[(i + sh - 4) & 3];
                 }
-                if (ok) *reinterpret_cast<f4v *>(fa.part + ((((size_t)c16 * (size_t)ab.pair_stride + (size_t)ci) * NP + part) * NPASS + p) * 16 + 4 * j4) = sum;
+                if (ok && j4 < s2_pass_f4<RG, S, W>(p))
+                    *reinterpret_cast<f4v *>(fa.part + (((size_t)c16 * (size_t)ab.pair_stride + (size_t)ci) * NP + part) * (s2_part_f4<RG, S, W>() * 4) + (s2_pass_off<RG, S, W>(p) + j4) * 4) = sum;
             }
         }
         base_cur = base_nxt; base_nxt = kf_base(k + 2);
@@ -1670,7 +1677,8 @@ template <int RG, int S, int W, bool D2 = true>
 struct FinishLoads {
     static constexpr int NPA = S2Cfg<RG, S, W>::NP <= 3 ? S2Cfg<RG, S, W>::NP : 3;   // ring parts whose sums are requested up front (registers: the others follow
                                                                                     //  once these are added up)
-    static constexpr int NPF = NPA * S2Cfg<RG, S, W>::NPASS * 4;
+    static constexpr int PF4 = s2_part_f4<RG, S, W>();                               // float4 per ring part
+    static constexpr int NPF = NPA * PF4;
     static constexpr int MW = (((S + 63) / 64) + 1) / 2;
     static constexpr bool kRingUpFront = NPF * 4 + RG * 4 <= 100;                // (registers: the 80 x 180 grid asks for its ring key later)
     uint4 km[MW]; unsigned int kflag; float kerr; int b_raw; f4v pv[NPF]; const f4v *rest; float4 bk[(D2 && kRingUpFront) ? RG : 1];
@@ -1690,7 +1698,7 @@ __device__ __forceinline__ FinishLoads<RG, S, W, D2> sc_screen2_finish_request(c
         l.kerr = __uint_as_float(ef.x); l.kflag = ef.y;
     }
     l.b_raw = a.starts[ci];
-    const f4v *pp = reinterpret_cast<const f4v *>(fa.part + ((size_t)qi * (size_t)ab.pair_stride + (size_t)ci) * (C::NP * C::NPASS * 16));
+    const f4v *pp = reinterpret_cast<const f4v *>(fa.part + ((size_t)qi * (size_t)ab.pair_stride + (size_t)ci) * (size_t)s2_part_floats<RG, S, W>());
 #pragma unroll
     for (int i = 0; i < L::NPF; ++i) l.pv[i] = pp[i];
     l.rest = pp + L::NPF;
@@ -1736,10 +1744,10 @@ __device__ __forceinline__ float sc_screen2_finish_compute(const ScreenArgs &a, 
     for (int p = 0; p < NPASS; ++p)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            if (4 * g4 >= kS2PassRows || W - 1 - PS * p - 4 * g4 < 0) continue;
-            f4v sm = l.pv[p * 4 + g4];                                       // part 0
+            if (!s2_group_used<RG, S, W>(p, g4)) continue;
+            f4v sm = l.pv[s2_pass_off<RG, S, W>(p) + g4];                    // part 0
 #pragma unroll
-            for (int h = 1; h < NPA; ++h) sm += l.pv[(h * NPASS + p) * 4 + g4];
+            for (int h = 1; h < NPA; ++h) sm += l.pv[h * L::PF4 + s2_pass_off<RG, S, W>(p) + g4];
             psum[p][g4] = sm;
         }
     if constexpr (NP > NPA) {
@@ -1750,20 +1758,20 @@ __device__ __forceinline__ float sc_screen2_finish_compute(const ScreenArgs &a, 
             for (int p = 0; p < NPASS; ++p)
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4)
-                    if (4 * g4 < kS2PassRows && W - 1 - PS * p - 4 * g4 >= 0) rv[h - NPA][p][g4] = l.rest[((h - NPA) * NPASS + p) * 4 + g4];
+                    if (s2_group_used<RG, S, W>(p, g4)) rv[h - NPA][p][g4] = l.rest[(h - NPA) * L::PF4 + s2_pass_off<RG, S, W>(p) + g4];
 #pragma unroll
         for (int h = NPA; h < NP; ++h)
 #pragma unroll
             for (int p = 0; p < NPASS; ++p)
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4)
-                    if (4 * g4 < kS2PassRows && W - 1 - PS * p - 4 * g4 >= 0) psum[p][g4] += rv[h - NPA][p][g4];
+                    if (s2_group_used<RG, S, W>(p, g4)) psum[p][g4] += rv[h - NPA][p][g4];
     }
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            if (4 * g4 >= kS2PassRows || W - 1 - PS * p - 4 * g4 < 0) continue;
+            if (!s2_group_used<RG, S, W>(p, g4)) continue;
             const f4v sm = psum[p][g4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
