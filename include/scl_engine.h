@@ -217,6 +217,9 @@ int  scl_detect_full_collect(scl_engine *e, int ticket, int *nn_idx, int *shift,
  * winner; this call exists so that tests can check the bound on the hardware.  survivors (n entries), n_survivors
  * and eps may be NULL.  SCL_ERR_UNSUPPORTED on other grids. */
 int  scl_screen_distances(scl_engine *e, int query, int lo, int hi, float *approx, int *survivors, int *n_survivors, float *eps);
+/* ... of up to 16 scans in ONE screening launch (the stream form's batch: the products' second form, every column of its matrix
+ * products): approx[i * n + k] = scan queries[i] against slot lo + k, n = the clipped range's length.  No survivor lists. */
+int  scl_screen_distances_many(scl_engine *e, const int *queries, int n_queries, int lo, int hi, float *approx, float *eps);
 /* The ring-key top-k (num_candidates entries) computed as part of the last scl_detect_full[_range]. */
 int  scl_get_last_topk(scl_engine *e, int k, int *idx, float *d2);
 /* Reference-faithful candidates for the sharded driver: local ring-key top-k in

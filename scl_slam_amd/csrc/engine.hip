@@ -1794,6 +1794,49 @@ int scl_screen_distances(scl_engine *e, int query, int lo, int hi, float *approx
     return SCL_OK;
 }
 
+int scl_screen_distances_many(scl_engine *e, const int *queries, int n_queries, int lo, int hi, float *approx, float *eps)
+{
+    if (!e || !queries || !approx || n_queries < 1 || n_queries > kMaxScreenBatch) return SCL_ERR_INVALID_ARG;
+    if (e->front) return fail(e, SCL_ERR_UNSUPPORTED, "screen_distances_many: call it on a one-GPU engine");
+    std::lock_guard<std::mutex> pk(e->pass_mu);
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    if (eps) *eps = sc_screen_eps();
+    if (!e->screen) return fail(e, SCL_ERR_UNSUPPORTED, "no screening pass for this grid (64x120 and 80x180 at search ratio 0.1 only)");
+    if (n_queries > sc_screen_max_batch(db_view(e), e->SR)) return fail(e, SCL_ERR_INVALID_ARG, "more scans than a screening launch takes");
+    if (lo < 0) lo = 0;
+    if (hi > e->n) hi = e->n;
+    const int n = hi - lo;
+    if (n <= 0) return SCL_OK;
+    int rc;
+    if ((rc = ensure_pairs(e, (size_t)n * (size_t)n_queries))) return rc;
+    {
+        const size_t per_pair = sc_screen_scratch_floats(db_view(e), e->SR) / (size_t)sc_screen_max_batch(db_view(e), e->SR);
+        const size_t want = (size_t)n * (size_t)n_queries * per_pair + 1024;
+        if (want > e->part_cap) {
+            dev_free(e->d_part); e->part_cap = 0;
+            if ((rc = dev_alloc(e, &e->d_part, want))) return rc;
+            e->part_cap = want;
+        }
+    }
+    ScreenBatch sb{};
+    sb.part = e->d_part;
+    sb.nq = n_queries; sb.pair_stride = (size_t)n;
+    for (int i = 0; i < n_queries; ++i) {
+        const int q = queries[i];
+        if (q >= 0) { if (q >= e->n) return fail(e, SCL_ERR_OUT_OF_RANGE, "query slot out of range"); sb.slot[i] = q; }
+        else { const int j = -1 - q; if (j >= e->stage_rows || !e->staged[j]) return fail(e, SCL_ERR_INVALID_ARG, "no staged query"); sb.slot[i] = e->cap + j; }
+        sb.base[i] = lo; sb.n[i] = n; sb.buf[i] = i;
+    }
+    sb.approx = e->d_approx; sb.starts = e->d_starts; sb.align_fallbacks = e->d_align_fallbacks; sb.ring_d2 = e->d_ring_d2; sb.survivors = e->d_surv; sb.n_surv = e->d_nsurv; sb.t_min = e->d_tmin;
+    sb.k = e->cfg.num_candidates; sb.exclude_eps = e->cfg.knn_exclude_eps; sb.topk_idx = e->d_topk_idx; sb.topk_d2 = e->d_topk_d2;
+    SCL_HIP(e, launch_sc_screen_batch(db_view(e), sb, e->SR, sc_align_filter_enabled(), e->num_cu, e->stream));
+    SCL_HIP(e, hipMemsetAsync(e->d_tmin, 0xff, sizeof(unsigned int) * (size_t)n_queries, e->stream));          // (no select launch re-arms the words)
+    SCL_HIP(e, hipMemsetAsync(e->d_tmin + kTminEpsOffset, 0, sizeof(unsigned int) * (size_t)n_queries, e->stream));
+    SCL_HIP(e, hipMemcpyAsync(approx, e->d_approx, sizeof(float) * (size_t)n * (size_t)n_queries, hipMemcpyDeviceToHost, e->stream));
+    return sync(e);
+}
+
 int scl_get_last_topk(scl_engine *e, int k, int *idx, float *d2)
 {
     if (!e || !idx || !d2 || k < 1 || k > kTopkMaxK) return SCL_ERR_INVALID_ARG;

@@ -98,6 +98,7 @@ def _bind(lib):
         "scl_detect_full_range": (c_int, [P, c_int, c_int, c_int, ip, ip, dp]),
         "scl_get_last_topk": (c_int, [P, c_int, ip, fp]),
         "scl_screen_distances": (c_int, [P, c_int, c_int, c_int, fp, ip, ip, fp]),
+        "scl_screen_distances_many": (c_int, [P, ip, c_int, c_int, c_int, fp, fp]),
         "scl_detect_full_submit": (c_int, [P, c_int, c_int, c_int, ip]),
         "scl_detect_full_collect": (c_int, [P, c_int, ip, ip, dp]),
         "scl_detect_full_submit_many": (c_int, [P, ip, ip, ip, c_int, ip]),
@@ -400,6 +401,15 @@ class ScanContextEngine:
         self._check(self._lib.scl_detect_full_collect(self._h, ticket, byref(nn), byref(sh), byref(d)),
                     "scl_detect_full_collect")
         return nn.value, sh.value, d.value
+
+    def screen_distances_many(self, queries, lo, hi):
+        """diagnostic: the screening pass of up to 16 scans in one launch over slots lo..hi-1 -> (approx [nq, n], eps)"""
+        q = np.ascontiguousarray(queries, dtype=np.int32)
+        n = max(0, min(hi, self.get_size()) - max(lo, 0))
+        approx = np.empty((q.shape[0], max(n, 1)), np.float32); eps = c_float()
+        self._check(self._lib.scl_screen_distances_many(self._h, _ptr(q, c_int), q.shape[0], lo, hi, _ptr(approx, c_float), byref(eps)),
+                    "scl_screen_distances_many")
+        return approx.reshape(-1)[:q.shape[0] * n].reshape(q.shape[0], n), eps.value
 
     def screen_distances(self, query, lo, hi):
         """diagnostic: (approximate distances of slots lo..hi-1, surviving slots, eps) of the screening pass"""

@@ -64,6 +64,43 @@ def _check(eng, db, query, lo, hi):
     return err.max() if err.size else 0.0, len(surv)
 
 
+@pytest.mark.parametrize("R2,S2,n", [(64, 120, 900), (80, 180, 700)])
+def test_every_column_of_a_screening_launch_meets_the_bound(R2, S2, n):
+    """The products' second form scores up to sixteen scans per launch, one per column of its matrix products (80 x 180: five ring
+    slices of 16, two sectors per k-step, the second pass on the keyframe fragment of three iterations ago, columns 8 .. 15 in the
+    second block of the scans' LDS image).  Every scan of launches of 2 .. 16 scans -- each rotated differently, so that every
+    column has its own first shift against every keyframe -- is compared with the checker's fp64 distance: inside the bound, and
+    the all-zero / NaN / huge keyframes flagged for the exact pass."""
+    descs = synth_descriptors(n, R2, S2, seed=2024, revisit_frac=0.05)
+    rs = np.random.RandomState(5)
+    descs[30] = 0.0; descs[31][:, ::3] = 0.0; descs[32] = descs[n - 1] * np.float32(1e25); descs[33][5, 7] = np.nan
+    for i in range(16):                                        # the scans: rotated, perturbed copies of keyframes all over the database
+        src = descs[int(rs.randint(40, n - 40))]
+        d = np.roll(src, int(rs.randint(0, S2)), axis=1)
+        descs[n - 16 + i] = np.clip(d + np.float32(10.0 ** -(i % 4 + 2)) * rs.standard_normal(d.shape).astype(np.float32) * (d > 0), 0, None)
+    eng = ScanContextEngine(num_ring=R2, num_sector=S2, initial_capacity=n)
+    db = ob.OracleDB(ob.make_config(R=R2, S=S2))
+    eng.save_bulk(descs); db.save_bulk(descs)
+    worst = 0.0
+    for nq, lo, hi in ((16, 0, n - 16), (9, 3, n - 50), (5, 17, 300), (2, 0, 131), (12, 200, 217), (16, 0, 5)):
+        qs = np.arange(n - nq, n, dtype=np.int32)
+        approx, eps = eng.screen_distances_many(qs, lo, hi)
+        assert approx.shape == (nq, hi - lo)
+        for i, q in enumerate(qs):
+            d_ref, _ = db.distance_batch(int(q), cand=np.arange(lo, hi, dtype=np.int32))
+            a = approx[i]
+            finite = np.isfinite(a)
+            ok = d_ref < 1e7
+            assert np.all(a[~ok & ~np.isneginf(a)] == np.inf), (nq, i)
+            err = np.abs(a[finite & ok].astype(np.float64) - d_ref[finite & ok])
+            assert err.size == 0 or err.max() <= eps, (nq, i, float(err.max()), eps)
+            assert finite[ok].mean() > 0.9 or ok.sum() < 8, (nq, i)     # the bound is met by values, not by flagging everything
+            worst = max(worst, float(err.max()) if err.size else 0.0)
+    print(f"{R2}x{S2}: worst |d~ - d| over all columns = {worst:.3e}")
+    assert worst < 4e-4
+    eng.close()
+
+
 def test_screening_bound_and_survivors_on_the_bench_database():
     n = 3000
     descs = synth_descriptors(n, R, S, seed=1002, revisit_frac=0.02)
