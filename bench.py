@@ -538,8 +538,8 @@ def secondary_adversarial_survivors(device, shard, queries, n_elig, frac=0.05, s
 # secondary: the SC-distance pass on BASELINE configs[4]'s grid (80 x 180), 10k keyframes
 # ------------------------------------------------------------------------------------------------
 def secondary_80x180(device, n=10000, steps=512):
-    """pairs/s of the full-DB pass on the 80x180 grid of configs[4] (Livox): alignment kernel + screening products (two M
-    tiles, W = 19) + exact pass on the survivors, four scans per launch group."""
+    """pairs/s of the full-DB pass on the 80x180 grid of configs[4] (Livox): alignment + screening products (W = 19 shifts in two
+    passes) + exact pass on the survivors, sixteen scans per launch group."""
     from scl_slam_amd import ScanContextEngine
     from scl_slam_amd.synth import synth_descriptors
     R2, S2 = 80, 180
@@ -561,11 +561,12 @@ def secondary_80x180(device, n=10000, steps=512):
     eng.close()
     survey_pair = R2 * S2 * 4 + S2 * 4 + S2 * 4                                 # 59 040 B at 80x180
     # what the launch group (products in their second form + finish + next alignment) reads per keyframe by design, once per
-    # launch of 12 scans: the chunk-major fp16 image (3 ring thirds x 4 chunks x (S + 16) sectors x 16 B), the first part of the
-    # alignment image (4 rotated copies of the fp16 sector key x 384 B + norm), the tiled ring key, the sector mask; per pair: first
-    # shift, the three thirds' two-pass partial sums (written and read), bound, ring-key metric
-    bytes_kf = 3 * 4 * (S2 + 16) * 16 + (4 * 192 * 2 + 16) + 4 * 4 * ((R2 + 3) // 4) + 32
-    bytes_pair_io = 4 + 2 * 4 + 2 * (3 * 2 * 16 * 4) + 4 + 4
+    # launch of 16 scans: the chunk-major fp16 image (5 ring slices of 16 x 2 chunks x S sectors x 16 B: the 80 rings, no padding;
+    # the sectors a fragment load repeats past the last come out of the L2), the first part of the alignment image (4 rotated copies of
+    # the fp16 sector key x 384 B + norm), the tiled ring key, the sector mask; per pair: first shift, the five slices' packed
+    # partial sums (13 + 6 shift rows in 16 + 8 floats, written and read), bound, ring-key metric
+    bytes_kf = 5 * 2 * S2 * 16 + (4 * 192 * 2 + 16) + 4 * 4 * ((R2 + 3) // 4) + 32
+    bytes_pair_io = 4 + 2 * 4 + 2 * (5 * 24 * 4) + 4 + 4
     k_ms = prof["sc_distance_ms"] / max(1, prof["sc_distance_launches"])
     k_pairs = prof["sc_distance_pairs"] / max(1, prof["sc_distance_launches"])
     k_scans = k_pairs / n_elig
@@ -579,8 +580,9 @@ def secondary_80x180(device, n=10000, steps=512):
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": per_launch, "scans_per_launch": k_scans,
                          "bytes_per_keyframe": bytes_kf, "bytes_per_pair_intermediates": bytes_pair_io, "survey_bytes_per_pair": survey_pair,
-                         "kernel": "screening launch group of the 80x180 grid: sc_screen2_kernel<20,180,19> (three ring thirds, 19 shifts in two "
-                                   "passes, 12 scans per launch) + finish + alignment of the next group; one group in seven sampled"}}
+                         "kernel": "screening launch group of the 80x180 grid: sc_screen2_kernel<20,180,19> (five ring slices of 16, two sectors per "
+                                   "k-step, 19 shifts in two passes that share the scans' fragments, 16 scans per launch) + finish + alignment of "
+                                   "the next group; one group in seven sampled"}}
 
 
 # ------------------------------------------------------------------------------------------------

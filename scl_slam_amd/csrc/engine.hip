@@ -1085,6 +1085,38 @@ int launch_survivor_pass(scl_engine *e, const int *qslot, const int *lo, const i
     return SCL_OK;
 }
 
+// The same pass by sc_small_exact_kernel (sc_masked.hip): ONE workgroup per scan lists the scan's survivors, scores them (every shift:
+// the stream's launches form no shift masks), forms the ring-key top-k and writes the winner.  Where the survivors' kernel above holds
+// 128 workgroups of 160 KB of LDS for 130 us beside the screening launches -- whose products need every CU: the launch that met them took
+// 63 us instead of 38, once per chunk -- this one holds 64 CUs for a fifth of that.  Argument sets through the same regions.
+int launch_small_exact_chunk(scl_engine *e, const int *qslot, const int *lo, const int *n, int nq, int set0, double *const *out3, hipStream_t stream,
+                             int phases, int region_in)
+{
+    static_assert(sizeof(SmallExactQuery) <= kSurvivorArgBytes && kMaxSmallExactQueries <= scl_engine::kScreenSets, "argument regions");
+    if (nq < 1 || nq > kMaxSmallExactQueries) return fail(e, SCL_ERR_INVALID_ARG, "exact pass: too many scans for one launch");
+    const size_t region = (size_t)(region_in >= 0 ? (unsigned)region_in : survivor_arg_region(e)) * scl_engine::kScreenSets * kSurvivorArgBytes;
+    SmallExactQuery *h = reinterpret_cast<SmallExactQuery *>(static_cast<char *>(e->h_surv_args) + region);
+    SmallExactQuery *d = reinterpret_cast<SmallExactQuery *>(static_cast<char *>(e->d_surv_args) + region);
+    if (phases & kSurvivorArgs) {
+        for (int j = 0; j < nq; ++j) {
+            const size_t set = (size_t)(set0 + j), off = set * e->set_stride;
+            SmallExactQuery &sq = h[j];
+            sq.qslot = qslot[j]; sq.base = lo[j]; sq.n = n[j];
+            sq.approx = e->d_approx + off; sq.starts = e->d_starts + off; sq.smask = nullptr; sq.ring_d2 = e->d_ring_d2 + off;
+            sq.t_min = e->d_tmin + set; sq.list = e->d_surv + off; sq.out3 = out3[j];
+            sq.topk_idx = e->d_topk_idx + set * kTailTopMaxK; sq.topk_d2 = e->d_topk_d2 + set * kTailTopMaxK;
+        }
+        SCL_HIP(e, hipMemcpyAsync(d, h, sizeof(SmallExactQuery) * (size_t)nq, hipMemcpyHostToDevice, stream));
+    }
+    if (!(phases & kSurvivorKernel)) return SCL_OK;
+    SmallExactArgs sa{};
+    sa.nq = nq; sa.k = e->cfg.num_candidates; sa.exclude_eps = e->cfg.knn_exclude_eps; sa.two_eps = 2.0f * sc_screen_eps(); sa.surv_stats = e->d_surv_stats;
+    sa.q_dev = d;
+    ProfScope ps(e, P_ARGMIN, stream);
+    SCL_HIP(e, launch_sc_small_exact(db_view(e), e->SR, sa, stream));
+    return SCL_OK;
+}
+
 // The exact pass of the 80 x 180 grid over the screened queries of buffer sets set0 .. set0 + nq - 1: per group of up to four
 // queries the select launch (survivor lists + ring-key top-k), the one-sector-per-lane program on the survivors and the arg-min.
 // first_done (optional): recorded behind the pass's first group of kWideExactBatch scans
@@ -1474,7 +1506,10 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
     struct Owed { List L; int c = 0, region = 0; bool valid = false; } owed;
     int part_half = 0;
     bool sub0_valid[2] = {false, false};                    // ev_sub0[c] was recorded by the exact pass that ev_chunk[c] ends
-    const bool keys_later = !wide;                          // the exact pass of a chunk forms the ring-key metric of its ranges (beside the next chunk's products)
+    // 64 x 120: the chunk's exact pass by one workgroup per scan (SCL_STREAM_EXACT=survivors keeps round 3's kernel, which also forms the
+    // ring-key metric of its ranges -- keys_later)
+    const bool small_exact = !wide && sc_small_exact_supported(db_view(e), e->SR) && !scl_lab_is("SCL_STREAM_EXACT", "s");
+    const bool keys_later = !wide && !small_exact;
     auto pend_group = [&]() { ScreenGroup g{pend.qslot, pend.lo, pend.n, pend.nq, pend.set0}; g.part_half = pend.half; g.keys_later = keys_later; return g; };
     // the exact pass of chunk `o.c` on the side stream, behind everything the main stream holds now
     auto run_owed = [&]() -> int {
@@ -1486,6 +1521,7 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
         SCL_HIP(e, hipStreamWaitEvent(e->stream_surv, e->ev_k1[oc], 0));
         int r2 = SCL_OK;
         if (owed.L.m > 0) r2 = wide ? launch_survivor_pass_wide(e, owed.L.qslot, owed.L.qlo, owed.L.qn, owed.L.m, oc * CH, out3, e->stream_surv, e->ev_sub0[oc])
+                      : small_exact ? launch_small_exact_chunk(e, owed.L.qslot, owed.L.qlo, owed.L.qn, owed.L.m, oc * CH, out3, e->stream_surv, kSurvivorKernel, owed.region)
                                     : launch_survivor_pass(e, owed.L.qslot, owed.L.qlo, owed.L.qn, owed.L.m, oc * CH, out3, e->stream_surv, kSurvivorKernel, owed.region, keys_later);
         if (r2) return r2;
         sub0_valid[oc] = wide && owed.L.m > 0;
@@ -1543,7 +1579,8 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
         // for it there (it finished long ago).  Only the very first launch aligns for itself.
         // the exact pass's argument sets go to the device now, ahead of the products it has to wait for
         const int region = (cur.m > 0 && !wide) ? (int)survivor_arg_region(e) : 0;
-        if (cur.m > 0 && !wide && (rc = launch_survivor_pass(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, e->stream_surv, kSurvivorArgs, region, keys_later))) return rc;
+        if (cur.m > 0 && !wide && (rc = small_exact ? launch_small_exact_chunk(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, e->stream_surv, kSurvivorArgs, region)
+                                                    : launch_survivor_pass(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, e->stream_surv, kSurvivorArgs, region, keys_later))) return rc;
         bool next_aligned = false;
         if (cur.m == 0) {                                    // nothing to launch: what earlier chunks are owed cannot ride along
             if ((rc = flush_pending())) return rc;
@@ -1604,6 +1641,7 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
         }
         sub0_valid[c] = wide && cur.m > 0;
         if (cur.m > 0 && (rc = wide ? launch_survivor_pass_wide(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, xs, e->ev_sub0[c])
+                      : small_exact ? launch_small_exact_chunk(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, xs, kSurvivorKernel, region)
                                     : launch_survivor_pass(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, xs, kSurvivorKernel, region, keys_later))) return rc;
         SCL_HIP(e, hipEventRecord(e->ev_chunk[c], xs));
         k.busy = true;

@@ -155,8 +155,11 @@ struct SmallExactQuery {
 struct SmallExactArgs {
     const float4 *desc; const double *norm; const double *vkey;               // (filled by the launcher)
     int nq, k; float exclude_eps, two_eps; unsigned long long *surv_stats;
+    const SmallExactQuery *q_dev;                                             // the queries in device memory (a chunk of the stream form: up to
+                                                                              // kMaxSmallExactQueries) instead of q[] (nq <= kMaxQueryBatch)
     SmallExactQuery q[kMaxQueryBatch];
 };
+constexpr int kMaxSmallExactQueries = 64;
 // ---- the k candidates of a ring-key search, scored by one workgroup (sc_masked.hip: sc_cand_exact_kernel): candidate cand_idx[i] (-1:
 // none -> (1e7, 0)) against the query; idx[k] | d2[k] | dist[k] | shift[k] written to pinned_out ----
 struct CandExactArgs {

@@ -323,7 +323,7 @@ hipError_t launch_masked(const MaskedArgs &ma, hipStream_t stream)
 constexpr int kSmallWaves = 8;                  // (512 threads: registers for kSmallPD ring groups in flight)
 constexpr int kSmallPD = 4;                     // ring groups in flight per wave (8 spill)
 constexpr int kSmallList = 1024;                // listed keyframes kept in LDS with their first shift and mask (more: through memory)
-constexpr int kSmallTop = 4;                    // ring-key candidates the barrier-free top-k tracks per wave
+constexpr int kSmallTop = 16;                   // ring-key candidates the barrier-free top-k tracks per wave
 template <int RG, int S, int W>
 struct SmallCfg {
     using M = MaskedCfg<RG, S, W>;
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(kSmallWaves * kWave) void sc_small_exact_kernel(Sma
     unsigned long long *tkw = rec + 2 * kSmallWaves;                             // [kSmallWaves][kSmallTop]
     int *n_list = reinterpret_cast<int *>(tkw + kSmallWaves * kSmallTop);
     int *llist = n_list + 4;                                                     // [kSmallList][3]: position, first shift, mask
-    const SmallExactQuery q = sa.q[blockIdx.x];
+    const SmallExactQuery q = sa.q_dev ? sa.q_dev[blockIdx.x] : sa.q[blockIdx.x];
     const double kInf = __longlong_as_double(0x7ff0000000000000LL);
 
     // ---- threshold, then the scan's rows and norms on their way while the list is made ----
@@ -618,7 +618,7 @@ bool sc_small_exact_supported(const DbView &db, int SR) { return db.RG == 16 && 
 
 hipError_t launch_sc_small_exact(const DbView &db, int SR, const SmallExactArgs &args_in, hipStream_t stream)
 {
-    if (args_in.nq < 1 || args_in.nq > kMaxQueryBatch || !sc_small_exact_supported(db, SR)) return hipErrorInvalidValue;
+    if (args_in.nq < 1 || args_in.nq > (args_in.q_dev ? kMaxSmallExactQueries : kMaxQueryBatch) || !sc_small_exact_supported(db, SR)) return hipErrorInvalidValue;
     using SC = SmallCfg<16, 120, 13>;
     static_assert(SC::LDS <= 160 * 1024, "LDS");
     static std::atomic<bool> attr_set_dev[64];

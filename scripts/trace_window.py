@@ -13,5 +13,5 @@ qs = {}
 for s, e, q, n in ks:
     if s < t0 or s > t0 + win * 1e3: continue
     qi = qs.setdefault(q, len(qs))
-    nm = n.split('(')[0].replace('void ', '').replace('scl::', '')
+    nm = n.replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '').replace('scl::', '')
     print(f"{(s - t0) / 1e3:9.1f}  {(e - s) / 1e3:8.1f}  q{qi}  {' ' * (28 * qi)}{nm[:44]}")
