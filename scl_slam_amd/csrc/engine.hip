@@ -1498,12 +1498,12 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
     static_assert(CH <= kMaxSurvivorQueries, "one exact pass takes the survivors of a whole chunk");
     const bool wide = sc_screen_is_wide(db_view(e), e->SR);  // 80 x 180: same launches, its own exact pass
     struct List { int qslot[CH], qlo[CH], qn[CH], pos[CH], m = 0; };     // the scans of a chunk that have something to score
-    struct Chunk { int first = 0, count = 0; bool busy = false, aligned = false; std::vector<int> lo, empty; };
+    struct Chunk { int first = 0, count = 0; bool busy = false, aligned = false, small = false; std::vector<int> lo, empty; };
     Chunk ch[2];
     // A launch's finishing (bound, flags, ring-key metric: what the exact pass reads) rides in the NEXT launch's extra waves
     // (sc_screen.hip): `pend` is the launch whose finishing is still owed, `owed` the chunk whose exact pass waits for it.
     struct Pending { int qslot[kMaxScreenBatch], lo[kMaxScreenBatch], n[kMaxScreenBatch], nq = 0, set0 = 0, half = 0; bool valid = false; } pend;
-    struct Owed { List L; int c = 0, region = 0; bool valid = false; } owed;
+    struct Owed { List L; int c = 0, region = 0; bool valid = false, small = false; } owed;
     int part_half = 0;
     bool sub0_valid[2] = {false, false};                    // ev_sub0[c] was recorded by the exact pass that ev_chunk[c] ends
     // 64 x 120: the chunk's exact pass by one workgroup per scan (SCL_STREAM_EXACT=survivors keeps round 3's kernel, which also forms the
@@ -1521,7 +1521,7 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
         SCL_HIP(e, hipStreamWaitEvent(e->stream_surv, e->ev_k1[oc], 0));
         int r2 = SCL_OK;
         if (owed.L.m > 0) r2 = wide ? launch_survivor_pass_wide(e, owed.L.qslot, owed.L.qlo, owed.L.qn, owed.L.m, oc * CH, out3, e->stream_surv, e->ev_sub0[oc])
-                      : small_exact ? launch_small_exact_chunk(e, owed.L.qslot, owed.L.qlo, owed.L.qn, owed.L.m, oc * CH, out3, e->stream_surv, kSurvivorKernel, owed.region)
+                       : owed.small ? launch_small_exact_chunk(e, owed.L.qslot, owed.L.qlo, owed.L.qn, owed.L.m, oc * CH, out3, e->stream_surv, kSurvivorKernel, owed.region)
                                     : launch_survivor_pass(e, owed.L.qslot, owed.L.qlo, owed.L.qn, owed.L.m, oc * CH, out3, e->stream_surv, kSurvivorKernel, owed.region, keys_later);
         if (r2) return r2;
         sub0_valid[oc] = wide && owed.L.m > 0;
@@ -1579,7 +1579,10 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
         // for it there (it finished long ago).  Only the very first launch aligns for itself.
         // the exact pass's argument sets go to the device now, ahead of the products it has to wait for
         const int region = (cur.m > 0 && !wide) ? (int)survivor_arg_region(e) : 0;
-        if (cur.m > 0 && !wide && (rc = small_exact ? launch_small_exact_chunk(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, e->stream_surv, kSurvivorArgs, region)
+        // one workgroup per scan scores its survivors at every shift: right for the handful a scan leaves as a rule; dozens per scan (what
+        // the chunks collected last reported) go to the survivors' kernel
+        k.small = small_exact && !e->exact_heavy;
+        if (cur.m > 0 && !wide && (rc = k.small ? launch_small_exact_chunk(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, e->stream_surv, kSurvivorArgs, region)
                                                     : launch_survivor_pass(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, e->stream_surv, kSurvivorArgs, region, keys_later))) return rc;
         bool next_aligned = false;
         if (cur.m == 0) {                                    // nothing to launch: what earlier chunks are owed cannot ride along
@@ -1622,7 +1625,7 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
         // already on the device: wait for their copy only).
         if (ncount > 0 && pend.valid) {
             // this chunk's last finishing rides in the next chunk's first launch: the exact pass is owed until then
-            owed.L = cur; owed.c = c; owed.region = region; owed.valid = true;
+            owed.L = cur; owed.c = c; owed.region = region; owed.valid = true; owed.small = k.small;
             k.busy = true;
             k.aligned = false;
             ch[c ^ 1].aligned = next_aligned;
@@ -1641,7 +1644,7 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
         }
         sub0_valid[c] = wide && cur.m > 0;
         if (cur.m > 0 && (rc = wide ? launch_survivor_pass_wide(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, xs, e->ev_sub0[c])
-                      : small_exact ? launch_small_exact_chunk(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, xs, kSurvivorKernel, region)
+                          : k.small ? launch_small_exact_chunk(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, xs, kSurvivorKernel, region)
                                     : launch_survivor_pass(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, xs, kSurvivorKernel, region, keys_later))) return rc;
         SCL_HIP(e, hipEventRecord(e->ev_chunk[c], xs));
         k.busy = true;
@@ -1676,14 +1679,20 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
             SCL_HIP(e, w);
         }
         collect_profile(e);
+        double listed = 0.0; int scored = 0;
         for (int i = 0; i < k.count; ++i) {
             const int o_i = k.first + i;
             nn_idx[o_i] = -1; shift[o_i] = 0; dist[o_i] = kBigDist;
             if (k.empty[(size_t)i]) continue;
             const volatile double *o = e->h_stream_out + ((size_t)c * NS + (size_t)i) * 8;
+            listed += o[3]; ++scored;
             dist[o_i] = o[0];
             nn_idx[o_i] = o[1] < 0 ? -1 : k.lo[(size_t)i] + (int)o[1];
             shift[o_i] = (int)o[2];
+        }
+        if (small_exact && scored > 0) {                      // (with hysteresis: 32 survivors per scan and more, 16 and fewer)
+            const double mean = listed / (double)scored;
+            if (mean > 32.0) e->exact_heavy = true; else if (mean < 16.0) e->exact_heavy = false;
         }
         k.busy = false;
         return SCL_OK;

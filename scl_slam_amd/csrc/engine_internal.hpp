@@ -94,6 +94,7 @@ struct scl_engine {
     void *d_surv_args = nullptr; void *h_surv_args = nullptr; unsigned surv_arg_tick = 0;   // argument sets of the exact pass (ring of 8 regions)
     double *h_stream_out = nullptr;                        // pinned: 2 x kScreenSets result records of the stream form
     hipEvent_t ev_chunk[2] = {nullptr, nullptr};
+    bool exact_heavy = false;                     // 64 x 120 stream: the last chunks left dozens of survivors per scan -> the survivors' kernel scores the next ones
     hipEvent_t ev_sub0[2] = {nullptr, nullptr};   // 80 x 180: behind the FIRST launch group of a chunk's exact pass (the buffer sets the next-but-one chunk's first alignment writes)
     // stream form: the exact pass over a chunk's survivors (small, latency bound) runs on its own low-priority stream
     // beside the screening products of the next chunk; the main stream carries the products back to back.

@@ -998,6 +998,7 @@ __global__ __launch_bounds__(MAXT) void sc_distance_survivors_kernel(const ScArg
     __syncthreads();
     int before = 0, total = 0;
     for (int w = 0; w < nwv; ++w) { const int t = wave_total[w]; if (w < wv) before += t; total += t; }
+    if (bid == 0 && threadIdx.x == 0 && a.out3) a.out3[3] = (double)total;      // (the stream form looks at it: which exact pass the next chunks take)
     if (bid == 0 && threadIdx.x == 0 && a.surv_stats) {
         atomicAdd(a.surv_stats, (unsigned long long)total);
         atomicMax(a.surv_stats + 1, (unsigned long long)total);
