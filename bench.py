@@ -582,7 +582,7 @@ def secondary_80x180(device, n=10000, steps=512):
                          "bytes_per_keyframe": bytes_kf, "bytes_per_pair_intermediates": bytes_pair_io, "survey_bytes_per_pair": survey_pair,
                          "kernel": "screening launch group of the 80x180 grid: sc_screen2_kernel<20,180,19> (five ring slices of 16, two sectors per "
                                    "k-step, 19 shifts in two passes that share the scans' fragments, 16 scans per launch) + finish + alignment of "
-                                   "the next group; one group in seven sampled"}}
+                                   "the next group; one group in thirteen sampled"}}
 
 
 # ------------------------------------------------------------------------------------------------

@@ -46,7 +46,11 @@ struct ProfScope {
     ProfScope(scl_engine *e_, int kind_, hipStream_t s_ = nullptr) : e(e_), kind(kind_), s(s_ ? s_ : e_->stream)
     {
         if (!e->prof_on || (e->prof_on >= 2 && kind != P_SC)) return;
-        if (e->prof_on == 3 && (e->prof_tick++ % 7) != 0) return;     // sampled: one launch in seven (not a divisor of the launches per chunk)
+#ifndef SCL_PROF_SAMPLE
+#define SCL_PROF_SAMPLE 13
+#endif
+        if (e->prof_on == 3 && (e->prof_tick++ % SCL_PROF_SAMPLE) != 0) return;   // sampled: one launch in thirteen (not a divisor of the launches per chunk;
+                                                                                 //  an event pair keeps two launches back by 4-6 us each)
         auto get = [&]() {
             hipEvent_t ev = nullptr;
             if (!e->event_pool.empty()) { ev = e->event_pool.back(); e->event_pool.pop_back(); }
@@ -1494,9 +1498,12 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
     constexpr int CH = NS / 2;                               // scans per chunk at most: the two chunks in flight use the two halves of the buffer sets
     // ... and a whole number of launches (80 x 180 takes 12 scans per launch: 64 would end every chunk with a launch of four,
     // which costs the same pass over the database as one of twelve)
-    const int chn = spl >= 1 && spl <= CH ? (CH / spl) * spl : CH;
     static_assert(CH <= kMaxSurvivorQueries, "one exact pass takes the survivors of a whole chunk");
     const bool wide = sc_screen_is_wide(db_view(e), e->SR);  // 80 x 180: same launches, its own exact pass
+    // (80 x 180: chunks of 64 -- its exact pass is a chain of launches per 16 scans that runs beside the NEXT chunk's screening, and the
+    //  host submits the chunk after that only when it has ended: chunks of 128 measured 3 % slower there, 4 % faster on 64 x 120)
+    const int chmax = wide && CH > 64 ? 64 : CH;
+    const int chn = spl >= 1 && spl <= chmax ? (chmax / spl) * spl : chmax;
     struct List { int qslot[CH], qlo[CH], qn[CH], pos[CH], m = 0; };     // the scans of a chunk that have something to score
     struct Chunk { int first = 0, count = 0; bool busy = false, aligned = false, small = false; std::vector<int> lo, empty; };
     Chunk ch[2];

@@ -80,9 +80,13 @@ struct scl_engine {
     // screening pass of the full-DB mode (sc_screen.hip): approximate distances, survivors, their counts, min d~ words
     // Buffers come in kScreenSets sets of `set_stride` entries (one set per query of a chunk of the stream form; the
     // submit / collect form uses sets 0..3): approx, ring_d2, survivors, dist, shift at set * set_stride.
-    // (128: chunks of 64 scans = four launches of 16, five of 12 on 80 x 180 -- with chunks of 32 the 80 x 180 products waited 85 us at
-    // every chunk end for the exact pass of the chunk before, whose buffers the next alignment writes; 256 measured no better)
-    static constexpr int kScreenSets = 128;
+    // (256: chunks of 128 scans = eight launches of 16.  A chunk costs the main stream one event record and one wait for another stream's
+    // event, and either keeps the next launch back by 4-6 us (scripts/probes/probe_dispatch_gap.hip): with chunks of 64 that was 4 % of
+    // the stream's time.  With chunks of 32 the 80 x 180 products waited 85 us at every chunk end for the exact pass of the chunk before.)
+#ifndef SCL_SCREEN_SETS
+#define SCL_SCREEN_SETS 256
+#endif
+    static constexpr int kScreenSets = SCL_SCREEN_SETS;
     float *d_approx = nullptr; int *d_starts = nullptr; int *d_surv = nullptr;
     unsigned int *d_smask = nullptr; size_t smask_cap = 0;  // per pair the shifts still open after the screening (sc_masked.hip); allocated on first use
     float *d_part = nullptr; size_t part_cap = 0;       // partial sums of the screening products' second form (one launch at a time)

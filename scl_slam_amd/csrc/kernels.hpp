@@ -159,7 +159,7 @@ struct SmallExactArgs {
                                                                               // kMaxSmallExactQueries) instead of q[] (nq <= kMaxQueryBatch)
     SmallExactQuery q[kMaxQueryBatch];
 };
-constexpr int kMaxSmallExactQueries = 64;
+constexpr int kMaxSmallExactQueries = 128;
 // ---- the k candidates of a ring-key search, scored by one workgroup (sc_masked.hip: sc_cand_exact_kernel): candidate cand_idx[i] (-1:
 // none -> (1e7, 0)) against the query; idx[k] | d2[k] | dist[k] | shift[k] written to pinned_out ----
 struct CandExactArgs {
@@ -231,7 +231,7 @@ hipError_t launch_sc_select_batch(const ScreenBatch &sb, hipStream_t stream);
 // the overlap of top-k and scoring.
 constexpr int kSurvivorBlocks = 2;
 constexpr int kSurvivorArgBytes = 384;
-constexpr int kMaxSurvivorQueries = 64;
+constexpr int kMaxSurvivorQueries = 128;
 struct SurvivorPass {
     int nq;
     int slot[kMaxSurvivorQueries], base[kMaxSurvivorQueries], n[kMaxSurvivorQueries], buf[kMaxSurvivorQueries];
