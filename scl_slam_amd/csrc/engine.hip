@@ -1329,7 +1329,7 @@ int submit_full_locked(scl_engine *e, int query, int lo, int hi, int *ticket)
     }
     e->last_pass_empty = n <= 0;                            // nothing ran: the top-k buffers still hold an older pass
     SCL_HIP(e, hipEventRecord(e->ev_done[sl], use_alt ? e->stream_alt : e->stream));
-    e->slot_ev[sl] = sl;
+    e->slot_ev[sl] = sl; e->slot_seq[sl] = 0;
     e->slot_busy[sl] = true;
     e->next_slot++;
     *ticket = sl;
@@ -1357,6 +1357,7 @@ int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, c
         if (e->slot_busy[(e->next_slot + (unsigned)i) % scl_engine::kSlots])
             return fail(e, SCL_ERR_INVALID_ARG, "too many full-DB passes in flight: collect first");
     QueryBatch qb{};
+    unsigned int seq_of_launch = 0;                        // (the small exact pass: the number it writes behind every result record)
     int first = -1, nmax = 0;
     int lo_of[kMaxQueryBatch]; bool empty_of[kMaxQueryBatch];
     for (int i = 0; i < nq; ++i) {
@@ -1399,6 +1400,10 @@ int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, c
                     sq.t_min = e->d_tmin + j; sq.list = e->d_surv + off; sq.out3 = qb.out3[j];
                     sq.topk_idx = e->d_topk_idx + j * kTailTopMaxK; sq.topk_d2 = e->d_topk_d2 + j * kTailTopMaxK;
                 }
+                if (++e->out_seq == 0) ++e->out_seq;
+#ifndef SCL_NO_SEQ
+                sa.seq = seq_of_launch = e->out_seq;
+#endif
                 ProfScope ps(e, P_ARGMIN);
                 SCL_HIP(e, launch_sc_small_exact(db_view(e), e->SR, sa, e->stream));
             } else if ((rc = launch_survivor_pass(e, qb.slot, qb.base, qb.n, qb.nq, 0, qb.out3))) return rc;
@@ -1415,6 +1420,7 @@ int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, c
     for (int i = 0; i < nq; ++i) {
         e->slot_lo[tickets[i]] = lo_of[i]; e->slot_empty[tickets[i]] = empty_of[i];
         e->slot_ev[tickets[i]] = first; e->slot_busy[tickets[i]] = true;
+        e->slot_seq[tickets[i]] = empty_of[i] ? 0u : seq_of_launch;
     }
     e->next_slot += (unsigned)nq;
     return SCL_OK;
@@ -1430,8 +1436,19 @@ int collect_full_locked(scl_engine *e, int ticket, int *nn_idx, int *shift, doub
         hipEvent_t ev = e->ev_done[e->slot_ev[ticket]];
         hipError_t q = hipErrorNotReady;
         const auto t0 = std::chrono::steady_clock::now();
-        while ((q = hipEventQuery(ev)) == hipErrorNotReady)
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) { q = hipEventSynchronize(ev); break; }
+        const unsigned int seq = e->slot_empty[ticket] ? 0u : e->slot_seq[ticket];
+        if (seq) {
+            // the exact pass's workgroup writes this launch's number behind the record in pinned memory: seen here 4-6 us before the
+            // event's packet fires.  (The launches behind it on the stream are ordered by the stream; nothing else of this pass is read here.)
+            const volatile double *o = e->h_out3 + (size_t)ticket * 8;
+            int spins = 0;
+            q = hipSuccess;
+            while (o[4] != (double)seq)
+                if ((++spins & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) { q = hipEventSynchronize(ev); break; }
+        } else {
+            while ((q = hipEventQuery(ev)) == hipErrorNotReady)
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) { q = hipEventSynchronize(ev); break; }
+        }
         SCL_HIP(e, q);
     }
     collect_profile(e);

@@ -521,7 +521,9 @@ __global__ __launch_bounds__(kSmallWaves * kWave) void sc_small_exact_kernel(Sma
             const unsigned long long b = (bd >> 63) ? (bd & 0x7fffffffffffffffull) : ~bd;
             o[0] = __longlong_as_double((long long)b); o[1] = (double)(int)(bp >> 8); o[2] = (double)(int)(bp & 0xff);
         }
-        if (sa.q_dev) o[3] = (double)total;                                      // (the stream form's result records have eight words: the list's length for the host)
+        if (sa.q_dev) o[3] = (double)total;
+        if (sa.seq) { __threadfence_system(); o[4] = (double)sa.seq; }             // (the record is complete in host memory before its sequence number)
+                                             // (the stream form's result records have eight words: the list's length for the host)
         *q.t_min = 0xffffffffu; q.t_min[kTminEpsOffset] = 0u;                    // re-armed for the next screening pass of this buffer set
         if (sa.surv_stats) {
             atomicAdd(sa.surv_stats, (unsigned long long)total);
