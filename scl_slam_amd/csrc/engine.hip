@@ -350,12 +350,15 @@ int topk_enqueue_locked(scl_engine *e, int query, int lo, int hi, int k, float e
     if ((rc = ensure_pairs(e, (size_t)k))) return rc;
     if ((rc = launch_topk(e, q, lo, hi, k, eps))) return rc;
     *have_dist = hi > lo && want_dist;
-    const size_t need = (size_t)k * (sizeof(int) * 2 + sizeof(float) + sizeof(double));
+    const size_t need = cand_seq_offset(k) + 16;
     if ((rc = ensure_pinned(e, need))) return rc;
+    e->pinned_seq = 0;
     if (*have_dist && k <= 16 && sc_cand_exact_supported(db_view(e), e->SR) && !scl_lab_int("SCL_CAND_EXACT_OFF", 0)) {
         // the reference-faithful detection's k (3) candidates: one workgroup aligns and scores them and writes the block (sc_masked.hip)
         ProfScope ps(e, P_SC);
-        SCL_HIP(e, launch_sc_cand_exact(db_view(e), q, e->SR, k, e->d_topk_idx, e->d_topk_d2, e->h_pinned, e->stream));
+        if (++e->out_seq == 0) ++e->out_seq;
+        e->pinned_seq = e->out_seq;
+        SCL_HIP(e, launch_sc_cand_exact(db_view(e), q, e->SR, k, e->d_topk_idx, e->d_topk_d2, e->h_pinned, e->stream, e->pinned_seq));
         if (ps.active()) e->prof.sc_distance_pairs += (uint64_t)k;
         return SCL_OK;
     }
@@ -370,8 +373,19 @@ int topk_enqueue_locked(scl_engine *e, int query, int lo, int hi, int k, float e
 int topk_finish_locked(scl_engine *e, int k, bool have_dist, int *idx, float *d2, double *dist, int *shift, int *found)
 {
     int rc;
-    if ((rc = sync_short(e))) return rc;
     char *h = static_cast<char *>(e->h_pinned);
+    bool seen = false;
+    if (e->pinned_seq) {
+        // the candidates' kernel writes this call's number behind the block: seen here 4-6 us before an event behind the launch would fire
+        const volatile unsigned int *w = reinterpret_cast<const volatile unsigned int *>(h + cand_seq_offset(k));
+        const auto t0 = std::chrono::steady_clock::now();
+        int spins = 0;
+        seen = true;
+        while (*w != e->pinned_seq)
+            if ((++spins & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) { seen = false; break; }
+        if (seen) collect_profile(e);
+    }
+    if (!seen && (rc = sync_short(e))) return rc;
     const int *h_idx = reinterpret_cast<int *>(h);
     const float *h_d2 = reinterpret_cast<float *>(h + sizeof(int) * k);
     const double *h_dist = reinterpret_cast<double *>(h + (sizeof(int) + sizeof(float)) * k);

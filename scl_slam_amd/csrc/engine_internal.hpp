@@ -37,6 +37,7 @@ struct scl_engine {
     hipEvent_t ev_done[kSlots] = {nullptr};
     hipEvent_t ev_call = nullptr;                          // end of a short blocking call's launches: polled (sync_short)
     int slot_lo[kSlots] = {0}; bool slot_busy[kSlots] = {false}; bool slot_empty[kSlots] = {false};
+    unsigned int pinned_seq = 0;                            // != 0: the number the candidates' kernel writes behind the block in h_pinned (topk_finish polls it)
     unsigned int slot_seq[kSlots] = {0}; unsigned int out_seq = 0;   // != 0: the exact pass writes this number behind the slot's result record (polled)
     int slot_ev[kSlots] = {0};                             // which slot's event completes this one (batched launches share one)
     unsigned next_slot = 0;

@@ -167,9 +167,12 @@ constexpr int kMaxSmallExactQueries = 128;
 struct CandExactArgs {
     const float4 *desc; const double *norm; const double *vkey; const float4 *q_desc; const double *q_norm; const double *q_vkey;
     int k; const int *cand_idx; const float *cand_d2; char *out;
+    unsigned int seq;                  // != 0: written to out + cand_seq_offset(k) when the block is complete (the caller polls it instead of an event)
 };
+constexpr size_t cand_seq_offset(int k) { return (((size_t)k * (sizeof(int) * 2 + sizeof(float) + sizeof(double))) + 15) / 16 * 16; }
 bool sc_cand_exact_supported(const struct DbView &db, int SR);
-hipError_t launch_sc_cand_exact(const struct DbView &db, const struct QueryView &q, int SR, int k, const int *cand_idx, const float *cand_d2, void *pinned_out, hipStream_t stream);
+hipError_t launch_sc_cand_exact(const struct DbView &db, const struct QueryView &q, int SR, int k, const int *cand_idx, const float *cand_d2, void *pinned_out, hipStream_t stream,
+                                unsigned int seq = 0);
 bool sc_small_exact_supported(const struct DbView &db, int SR);
 hipError_t launch_sc_small_exact(const struct DbView &db, int SR, const SmallExactArgs &args, hipStream_t stream);
 bool sc_masked_supported(const struct DbView &db, int SR);

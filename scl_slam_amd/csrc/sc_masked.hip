@@ -596,6 +596,11 @@ __global__ __launch_bounds__(kCandWaves * kWave) void sc_cand_exact_kernel(CandE
         }
         if (lane == 0) { o_dist[c] = best; o_shift[c] = bshift; }
     }
+    if (ca.seq) {                                                                // the block is complete in host memory before its sequence number
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) *reinterpret_cast<volatile unsigned int *>(ca.out + cand_seq_offset(ca.k)) = ca.seq;
+    }
 }
 
 }  // namespace
@@ -662,12 +667,12 @@ static hipError_t launch_cand_t(const CandExactArgs &ca, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_sc_cand_exact(const DbView &db, const QueryView &q, int SR, int k, const int *cand_idx, const float *cand_d2, void *pinned_out, hipStream_t stream)
+hipError_t launch_sc_cand_exact(const DbView &db, const QueryView &q, int SR, int k, const int *cand_idx, const float *cand_d2, void *pinned_out, hipStream_t stream, unsigned int seq)
 {
     if (k < 1 || k > kTopkMaxK || !sc_cand_exact_supported(db, SR) || !pinned_out) return hipErrorInvalidValue;
     CandExactArgs ca{};
     ca.desc = db.desc; ca.norm = db.norm; ca.vkey = db.vkey; ca.q_desc = q.desc; ca.q_norm = q.norm; ca.q_vkey = q.vkey;
-    ca.k = k; ca.cand_idx = cand_idx; ca.cand_d2 = cand_d2; ca.out = static_cast<char *>(pinned_out);
+    ca.k = k; ca.cand_idx = cand_idx; ca.cand_d2 = cand_d2; ca.out = static_cast<char *>(pinned_out); ca.seq = seq;
     if (db.S == 120) return launch_cand_t<16, 120, 13>(ca, stream);
     return launch_cand_t<5, 60, 7>(ca, stream);
 }
