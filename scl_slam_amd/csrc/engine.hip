@@ -1527,8 +1527,7 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
     const int n0 = e->n;                                     // the database this call scores
     constexpr int NS = scl_engine::kScreenSets;
     constexpr int CH = NS / 2;                               // scans per chunk at most: the two chunks in flight use the two halves of the buffer sets
-    // ... and a whole number of launches (80 x 180 takes 12 scans per launch: 64 would end every chunk with a launch of four,
-    // which costs the same pass over the database as one of twelve)
+    // ... and a whole number of launches (a short launch costs the same pass over the database as a full one)
     static_assert(CH <= kMaxSurvivorQueries, "one exact pass takes the survivors of a whole chunk");
     const bool wide = sc_screen_is_wide(db_view(e), e->SR);  // 80 x 180: same launches, its own exact pass
     // (80 x 180: chunks of 64 -- its exact pass is a chain of launches per 16 scans that runs beside the NEXT chunk's screening, and the

@@ -1200,12 +1200,16 @@ hipError_t launch_sc_select_batch(const ScreenBatch &sb, hipStream_t stream)
 // QUAD / 16 = 2 mod 4.  (Scan-major rows of 64 B put the eight same-chunk lanes of a group on two slots: 4-way conflicts,
 // 99 us per launch instead of ...)
 // Shapes of the second form.  64 x 120: two ring halves, 13 shifts in one pass, four k-steps per fragment load (13 + 3 rows),
-// 16 scans per launch.  80 x 180 (96 padded rings, 19 shifts): three ring thirds, the shifts in two passes of 13 and 6 rows that
-// share the keyframe's fragment (pass p reads the scan 13 p sectors further back), 12 scans per launch (12 x 183 sectors x 64 B =
-// 141 KB of LDS).
+// 16 scans per launch.  80 x 180 (80 rings, 19 shifts): FIVE ring slices of 16, a k-step's 32 products being 16 rings of TWO consecutive
+// sectors (SPK = 2): lane (m, j) of the keyframe fragment reads chunk 2 slice + (j & 1) of sector y + m + (j >> 1) -- the same chunk-major
+// image --, the scan fragment is 64 consecutive bytes of a row pair of an image that holds eight scans of 32 B per 256-byte row (a lane's
+// slot 2 (q & 7) + (j & 1) whatever its sector: conflict free), an iteration is two k-steps (four sectors, row shift two between them);
+// the shifts in two passes of 13 and 6 rows that share the SCAN's fragment (PS = 12: pass 1 on this iteration's keyframe fragment, pass 0 on
+// the one of three iterations ago); 16 scans per launch (16 x 183 sectors x 32 B = 94 KB of LDS).  Until the middle of round 4: 96 padded
+// rings as three thirds of 32, twelve scans per launch, each pass reading the scan at its own offset (S2_WIDE_THIRDS).
 // Waves per workgroup (one workgroup per CU: the scans fill the LDS) and ring slots of the fragment loads; -D overrides for experiments.
 // 64 x 120: 113 registers -> 16 waves (four per SIMD) hide the chains that two per SIMD left open (products 54 -> 48 us per 16 scans;
-// six ring slots instead of ten: 1 us slower).  80 x 180: 156 registers; twelve waves measured the same as eight.
+// six ring slots instead of ten: 1 us slower).  80 x 180: 108 registers, sixteen waves, six fragment buffers.
 #ifndef S2_FRAG_SHIFT
 #define S2_FRAG_SHIFT 1               // products, second form: three of four keyframe fragments by row shifts of loaded ones (0: every fragment loaded)
 #endif
