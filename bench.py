@@ -743,9 +743,20 @@ def main():
         """`count` steps.  Each step = one scan's full pass over this rank's shard (ring-key top-k + SC distance
         + arg-min, one launch); `--pipeline` passes are in flight, and for N > 1 the per-rank winners of a chunk
         of scans travel in one asynchronous exchange (RCCL), merged one batch later."""
+        q = (n_elig + ((first + np.arange(count)) % n_query)).astype(np.int32)
+        if world == 1 and args.native_chunk > 0:
+            # one GPU: the C ABI's own stream call, arrays of scans in, arrays of winners out (scl_detect_full_stream), `native_chunk`
+            # scans per call -- FullScanStream, the merge of several shards' winners, has nothing to merge here, and turning 320
+            # winners into Python tuples cost the driver's 20-step run 3 % of its time
+            out = []
+            for s0 in range(0, count, args.native_chunk):
+                nn, sh, dd = eng.detect_full_stream(q[s0:s0 + args.native_chunk], 0, n_elig, args.scans_per_launch, args.pipeline)
+                out.append((dd, nn, sh))
+            assert sum(len(o[1]) for o in out) == count
+            return out
         st = FullScanStream(eng, rank, world, device=coll_dev, depth=args.pipeline, merge_every=args.merge_every,
                             scans_per_launch=args.scans_per_launch, native_chunk=args.native_chunk, exchange=args.exchange)
-        st.submit_many(n_elig + ((first + np.arange(count)) % n_query), 0, n_elig)
+        st.submit_many(q, 0, n_elig)
         res = st.drain()
         assert len(res) == count
         return res
@@ -775,6 +786,11 @@ def main():
         times.append(elapsed)
         # outside the timed region: every planted revisit (query 4j = a rolled copy of one of rank 0's keyframes) must
         # have been found by the merged result, on every rank
+        if timed_results and isinstance(timed_results[0][0], np.ndarray):      # the one-GPU form's arrays, call by call
+            flat = []
+            for dd_, nn_, sh_ in timed_results:
+                flat.extend(zip(dd_.tolist(), nn_.tolist(), sh_.tolist()))
+            timed_results = flat
         for i, (d, g, sh) in enumerate(timed_results):
             if os.environ.get("SCL_ABLATE"):             # diagnostic build with phases switched off: results are wrong on purpose
                 break

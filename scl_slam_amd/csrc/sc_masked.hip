@@ -328,7 +328,7 @@ template <int RG, int S, int W>
 struct SmallCfg {
     using M = MaskedCfg<RG, S, W>;
     static constexpr size_t LDS_Q = M::LDS_Q, LDS_N = M::LDS_N;
-    static constexpr size_t LDS_WAVE = M::LDS_WAVE > (size_t)(2 * S + 2) * 8 ? M::LDS_WAVE : (size_t)(2 * S + 2) * 8;   // TM rows, or the doubled key of the slow path
+    static constexpr size_t LDS_WAVE = (size_t)W * S * 8 > (size_t)(2 * S + 2) * 8 ? (size_t)W * S * 8 : (size_t)(2 * S + 2) * 8;   // W rows (every shift in one pass), or the doubled key of the slow path
     static constexpr size_t LDS_VQ = (size_t)S * 8;                  // the scan's sector key (slow path)
     static constexpr size_t LDS_REC = (size_t)kSmallWaves * 16 + (size_t)kSmallWaves * kSmallTop * 8;   // a wave's best (distance, position << 8 | shift); its kSmallTop nearest ring keys
     static constexpr size_t LDS_LIST = (size_t)kSmallList * 12;
@@ -498,7 +498,11 @@ __global__ __launch_bounds__(kSmallWaves * kWave) void sc_small_exact_kernel(Sma
         }
         mask &= all;
         double best; int bshift;
-        masked_pair<RG, S, W, kSmallPD>(Qs, nq, wrow, kd, kn, first, mask, lane, best, bshift);   // (a lone wave: every round trip counts)
+        // every shift open (the stream form's launches form no masks; an undecided alignment): all W shifts in ONE pass over the keyframe,
+        // the branch-free form of the candidates' kernel -- in passes of four shift slots a survivor of the stream cost its rows four times
+        // (44 us per chunk's launch on its own instead of 25)
+        if (mask == all) masked_pair<RG, S, W, kSmallPD, W, true>(Qs, nq, wrow, kd, kn, first, mask, lane, best, bshift);
+        else masked_pair<RG, S, W, kSmallPD>(Qs, nq, wrow, kd, kn, first, mask, lane, best, bshift);   // (a lone wave: every round trip counts)
         if (best < kBigDist) {
             const unsigned long long b = (unsigned long long)__double_as_longlong(best);
             const unsigned long long od = (b >> 63) ? ~b : (b | 0x8000000000000000ull);     // IEEE order -> unsigned order
