@@ -1700,8 +1700,10 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
             hipError_t q;
             const auto t0 = std::chrono::steady_clock::now();
             int spins = 0;
-            while ((q = hipEventQuery(e->ev_chunk[c])) == hipErrorNotReady)
-                if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) return hipEventSynchronize(e->ev_chunk[c]);
+            while ((q = hipEventQuery(e->ev_chunk[c])) == hipErrorNotReady) {
+                for (int p = 0; p < 32; ++p) __builtin_ia32_pause();          // (a thread that appends meanwhile goes through the same runtime)
+                if ((++spins & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) return hipEventSynchronize(e->ev_chunk[c]);
+            }
             return q;
         };
         if (last || owed.valid || pend.valid) {
