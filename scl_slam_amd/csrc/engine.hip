@@ -1621,6 +1621,7 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
         k.small = small_exact && !e->exact_heavy;
         if (cur.m > 0 && !wide && (rc = k.small ? launch_small_exact_chunk(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, e->stream_surv, kSurvivorArgs, region)
                                                     : launch_survivor_pass(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, e->stream_surv, kSurvivorArgs, region, keys_later))) return rc;
+        if (ncount == 0 && cur.m > 0) SCL_HIP(e, hipEventRecord(e->ev_k1[c], e->stream_surv));   // the call's last chunk: its exact pass runs on the main stream, behind this copy
         bool next_aligned = false;
         if (cur.m == 0) {                                    // nothing to launch: what earlier chunks are owed cannot ride along
             if ((rc = flush_pending())) return rc;
@@ -1676,8 +1677,10 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
             SCL_HIP(e, hipEventRecord(e->ev_k1[c], e->stream));
             SCL_HIP(e, hipStreamWaitEvent(e->stream_surv, e->ev_k1[c], 0));
         } else if (cur.m > 0) {
-            SCL_HIP(e, hipEventRecord(e->ev_k1[c], e->stream_surv));         // behind the copy of the argument sets
-            SCL_HIP(e, hipStreamWaitEvent(e->stream, e->ev_k1[c], 0));
+            // behind the copy of the argument sets, enqueued on the side stream before this chunk's launches: long done as a rule, and a
+            // wait for a pending event keeps the main stream's next launch back by 5 us -- asked for only if the copy is still on its way
+            // (the event was recorded behind the copy, at the start of this chunk's submission)
+            if (hipEventQuery(e->ev_k1[c]) != hipSuccess) SCL_HIP(e, hipStreamWaitEvent(e->stream, e->ev_k1[c], 0));
         }
         sub0_valid[c] = wide && cur.m > 0;
         if (cur.m > 0 && (rc = wide ? launch_survivor_pass_wide(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, xs, e->ev_sub0[c])
