@@ -1115,12 +1115,13 @@ int launch_small_exact_chunk(scl_engine *e, const int *qslot, const int *lo, con
     const size_t region = (size_t)(region_in >= 0 ? (unsigned)region_in : survivor_arg_region(e)) * scl_engine::kScreenSets * kSurvivorArgBytes;
     SmallExactQuery *h = reinterpret_cast<SmallExactQuery *>(static_cast<char *>(e->h_surv_args) + region);
     SmallExactQuery *d = reinterpret_cast<SmallExactQuery *>(static_cast<char *>(e->d_surv_args) + region);
+    const bool wide_masks = sc_screen_is_wide(db_view(e), e->SR) && e->d_smask;   // (80 x 180: every launch forms the shift masks)
     if (phases & kSurvivorArgs) {
         for (int j = 0; j < nq; ++j) {
             const size_t set = (size_t)(set0 + j), off = set * e->set_stride;
             SmallExactQuery &sq = h[j];
             sq.qslot = qslot[j]; sq.base = lo[j]; sq.n = n[j];
-            sq.approx = e->d_approx + off; sq.starts = e->d_starts + off; sq.smask = nullptr; sq.ring_d2 = e->d_ring_d2 + off;
+            sq.approx = e->d_approx + off; sq.starts = e->d_starts + off; sq.smask = wide_masks ? e->d_smask + off : nullptr; sq.ring_d2 = e->d_ring_d2 + off;
             sq.t_min = e->d_tmin + set; sq.list = e->d_surv + off; sq.out3 = out3[j];
             sq.topk_idx = e->d_topk_idx + set * kTailTopMaxK; sq.topk_d2 = e->d_topk_d2 + set * kTailTopMaxK;
         }
@@ -1399,9 +1400,10 @@ int submit_full_many_locked(scl_engine *e, const int *queries, const int *los, c
             ScreenGroup sg{qb.slot, qb.base, qb.n, qb.nq, 0};
             sg.masks = !wide && sc_small_exact_supported(db_view(e), e->SR);
             if ((rc = launch_screen_group(e, sg))) return rc;
-            if (wide) {
+            const bool small_pass = (sg.masks || wide) && sc_small_exact_supported(db_view(e), e->SR) && e->d_smask && !scl_lab_int("SCL_SMALL_EXACT_OFF", 0);
+            if (wide && !small_pass) {
                 if ((rc = launch_survivor_pass_wide(e, qb.slot, qb.base, qb.n, qb.nq, 0, qb.out3, e->stream))) return rc;
-            } else if (sg.masks && e->d_smask && !scl_lab_int("SCL_SMALL_EXACT_OFF", 0)) {
+            } else if (small_pass) {
                 // a blocking call's handful of scans: one workgroup per scan selects, scores the open shifts, forms the top-k and
                 // writes the winner (sc_masked.hip) -- one launch, no argument copy
                 SmallExactArgs sa{};
@@ -1532,7 +1534,10 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
     const bool wide = sc_screen_is_wide(db_view(e), e->SR);  // 80 x 180: same launches, its own exact pass
     // (80 x 180: chunks of 64 -- its exact pass is a chain of launches per 16 scans that runs beside the NEXT chunk's screening, and the
     //  host submits the chunk after that only when it has ended: chunks of 128 measured 3 % slower there, 4 % faster on 64 x 120)
-    const int chmax = wide && CH > 64 ? 64 : CH;
+#ifndef SCL_WIDE_CHUNK
+#define SCL_WIDE_CHUNK 64
+#endif
+    const int chmax = wide && CH > SCL_WIDE_CHUNK ? SCL_WIDE_CHUNK : CH;
     const int chn = spl >= 1 && spl <= chmax ? (chmax / spl) * spl : chmax;
     struct List { int qslot[CH], qlo[CH], qn[CH], pos[CH], m = 0; };     // the scans of a chunk that have something to score
     struct Chunk { int first = 0, count = 0; bool busy = false, aligned = false, small = false; std::vector<int> lo, empty; };
@@ -1545,7 +1550,7 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
     bool sub0_valid[2] = {false, false};                    // ev_sub0[c] was recorded by the exact pass that ev_chunk[c] ends
     // 64 x 120: the chunk's exact pass by one workgroup per scan (SCL_STREAM_EXACT=survivors keeps round 3's kernel, which also forms the
     // ring-key metric of its ranges -- keys_later)
-    const bool small_exact = !wide && sc_small_exact_supported(db_view(e), e->SR) && !scl_lab_is("SCL_STREAM_EXACT", "s");
+    const bool small_exact = sc_small_exact_supported(db_view(e), e->SR) && (!wide || e->d_smask) && !scl_lab_is("SCL_STREAM_EXACT", "s");
     const bool keys_later = !wide && !small_exact;
     auto pend_group = [&]() { ScreenGroup g{pend.qslot, pend.lo, pend.n, pend.nq, pend.set0}; g.part_half = pend.half; g.keys_later = keys_later; return g; };
     // the exact pass of chunk `o.c` on the side stream, behind everything the main stream holds now
@@ -1557,11 +1562,11 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
         SCL_HIP(e, hipEventRecord(e->ev_k1[oc], e->stream));
         SCL_HIP(e, hipStreamWaitEvent(e->stream_surv, e->ev_k1[oc], 0));
         int r2 = SCL_OK;
-        if (owed.L.m > 0) r2 = wide ? launch_survivor_pass_wide(e, owed.L.qslot, owed.L.qlo, owed.L.qn, owed.L.m, oc * CH, out3, e->stream_surv, e->ev_sub0[oc])
-                       : owed.small ? launch_small_exact_chunk(e, owed.L.qslot, owed.L.qlo, owed.L.qn, owed.L.m, oc * CH, out3, e->stream_surv, kSurvivorKernel, owed.region)
+        if (owed.L.m > 0) r2 = owed.small ? launch_small_exact_chunk(e, owed.L.qslot, owed.L.qlo, owed.L.qn, owed.L.m, oc * CH, out3, e->stream_surv, kSurvivorKernel, owed.region)
+                               : wide ? launch_survivor_pass_wide(e, owed.L.qslot, owed.L.qlo, owed.L.qn, owed.L.m, oc * CH, out3, e->stream_surv, e->ev_sub0[oc])
                                     : launch_survivor_pass(e, owed.L.qslot, owed.L.qlo, owed.L.qn, owed.L.m, oc * CH, out3, e->stream_surv, kSurvivorKernel, owed.region, keys_later);
         if (r2) return r2;
-        sub0_valid[oc] = wide && owed.L.m > 0;
+        sub0_valid[oc] = wide && !owed.small && owed.L.m > 0;
         SCL_HIP(e, hipEventRecord(e->ev_chunk[oc], e->stream_surv));
         owed.valid = false;
         return SCL_OK;
@@ -1615,11 +1620,11 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
         // launch, whose buffer sets the exact pass of the chunk before this one may still be reading: the main stream waits
         // for it there (it finished long ago).  Only the very first launch aligns for itself.
         // the exact pass's argument sets go to the device now, ahead of the products it has to wait for
-        const int region = (cur.m > 0 && !wide) ? (int)survivor_arg_region(e) : 0;
         // one workgroup per scan scores its survivors at every shift: right for the handful a scan leaves as a rule; dozens per scan (what
         // the chunks collected last reported) go to the survivors' kernel
         k.small = small_exact && !e->exact_heavy;
-        if (cur.m > 0 && !wide && (rc = k.small ? launch_small_exact_chunk(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, e->stream_surv, kSurvivorArgs, region)
+        const int region = (cur.m > 0 && (k.small || !wide)) ? (int)survivor_arg_region(e) : 0;
+        if (cur.m > 0 && (k.small || !wide) && (rc = k.small ? launch_small_exact_chunk(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, e->stream_surv, kSurvivorArgs, region)
                                                     : launch_survivor_pass(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, e->stream_surv, kSurvivorArgs, region, keys_later))) return rc;
         if (ncount == 0 && cur.m > 0) SCL_HIP(e, hipEventRecord(e->ev_k1[c], e->stream_surv));   // the call's last chunk: its exact pass runs on the main stream, behind this copy
         bool next_aligned = false;
@@ -1682,9 +1687,9 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
             // (the event was recorded behind the copy, at the start of this chunk's submission)
             if (hipEventQuery(e->ev_k1[c]) != hipSuccess) SCL_HIP(e, hipStreamWaitEvent(e->stream, e->ev_k1[c], 0));
         }
-        sub0_valid[c] = wide && cur.m > 0;
-        if (cur.m > 0 && (rc = wide ? launch_survivor_pass_wide(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, xs, e->ev_sub0[c])
-                          : k.small ? launch_small_exact_chunk(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, xs, kSurvivorKernel, region)
+        sub0_valid[c] = wide && !k.small && cur.m > 0;
+        if (cur.m > 0 && (rc = k.small ? launch_small_exact_chunk(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, xs, kSurvivorKernel, region)
+                             : wide ? launch_survivor_pass_wide(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, xs, e->ev_sub0[c])
                                     : launch_survivor_pass(e, cur.qslot, cur.qlo, cur.qn, cur.m, set0, out3, xs, kSurvivorKernel, region, keys_later))) return rc;
         SCL_HIP(e, hipEventRecord(e->ev_chunk[c], xs));
         k.busy = true;

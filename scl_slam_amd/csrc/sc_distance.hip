@@ -1307,6 +1307,7 @@ __global__ __launch_bounds__(1024) void argmin_survivors_batch_kernel(ArgminBatc
         out3[0] = ok ? best : kBigDist;
         out3[1] = ok ? (double)(cand[bi] - b.slot_base[q]) : -1.0;
         out3[2] = ok ? (double)shift[bi] : 0.0;
+        out3[3] = (double)n;                             // (the list's length: the stream form looks at it, as in the one-workgroup-per-scan pass)
     }
 }
 

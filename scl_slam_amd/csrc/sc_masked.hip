@@ -328,7 +328,11 @@ template <int RG, int S, int W>
 struct SmallCfg {
     using M = MaskedCfg<RG, S, W>;
     static constexpr size_t LDS_Q = M::LDS_Q, LDS_N = M::LDS_N;
-    static constexpr size_t LDS_WAVE = (size_t)W * S * 8 > (size_t)(2 * S + 2) * 8 ? (size_t)W * S * 8 : (size_t)(2 * S + 2) * 8;   // W rows (every shift in one pass), or the doubled key of the slow path
+    // every shift of a survivor in one pass needs W rows of sums per wave: 64 x 120 has the room (150 KB in all), 80 x 180 has not (its
+    // launches always form shift masks: passes of kMaskTMax open shifts)
+    static constexpr bool kAll = LDS_Q + LDS_N + (size_t)kSmallWaves * W * S * 8 + (size_t)kSmallList * 12 + 4096 <= 160 * 1024;
+    static constexpr size_t ROWS_WAVE = kAll ? (size_t)W * S * 8 : M::LDS_WAVE;
+    static constexpr size_t LDS_WAVE = ROWS_WAVE > (size_t)(2 * S + 2) * 8 ? ROWS_WAVE : (size_t)(2 * S + 2) * 8;   // rows of sums, or the doubled key of the slow path
     static constexpr size_t LDS_VQ = (size_t)S * 8;                  // the scan's sector key (slow path)
     static constexpr size_t LDS_REC = (size_t)kSmallWaves * 16 + (size_t)kSmallWaves * kSmallTop * 8;   // a wave's best (distance, position << 8 | shift); its kSmallTop nearest ring keys
     static constexpr size_t LDS_LIST = (size_t)kSmallList * 12;
@@ -487,9 +491,19 @@ __global__ __launch_bounds__(kSmallWaves * kWave) void sc_small_exact_kernel(Sma
         if (first < 0 || first >= S || !q.smask) {
             // no first shift (or no masks at all): the reference's own alignment (fastAlignUsingVkey, D.h:1491-1511), every shift open
             if (first < 0 || first >= S) {
-                const int ll2 = lane < (S >> 1) ? lane : (S >> 1) - 1;
-                const double2 vk = *reinterpret_cast<const double2 *>(sa.vkey + (size_t)slot * S + 2 * ll2);
-                const int a0 = align_keyframe_exact<S>(vk, lane, wrow, vq);
+                int a0;
+                if constexpr (S / 2 <= kWave) {
+                    const int ll2 = lane < (S >> 1) ? lane : (S >> 1) - 1;
+                    const double2 vk = *reinterpret_cast<const double2 *>(sa.vkey + (size_t)slot * S + 2 * ll2);
+                    a0 = align_keyframe_exact<S>(vk, lane, wrow, vq);
+                } else {
+                    constexpr int SPL = (S + kWave - 1) / kWave, LA = S / SPL;
+                    const int ll2 = lane < LA ? lane : LA - 1;
+                    double vk[SPL];
+#pragma unroll
+                    for (int u = 0; u < SPL; ++u) vk[u] = sa.vkey[(size_t)slot * S + SPL * ll2 + u];
+                    a0 = align_keyframe_wide<S>(vk, lane, wrow, vq);
+                }
                 // D.h:1545-1551: the searched shifts start SEARCH_RADIUS below the aligned one
                 first = a0 - (W - 1) / 2; first = first < 0 ? first + S : first;
                 wave_fence_lds();
@@ -501,8 +515,11 @@ __global__ __launch_bounds__(kSmallWaves * kWave) void sc_small_exact_kernel(Sma
         // every shift open (the stream form's launches form no masks; an undecided alignment): all W shifts in ONE pass over the keyframe,
         // the branch-free form of the candidates' kernel -- in passes of four shift slots a survivor of the stream cost its rows four times
         // (44 us per chunk's launch on its own instead of 25)
-        if (mask == all) masked_pair<RG, S, W, kSmallPD, W, true>(Qs, nq, wrow, kd, kn, first, mask, lane, best, bshift);
-        else masked_pair<RG, S, W, kSmallPD>(Qs, nq, wrow, kd, kn, first, mask, lane, best, bshift);   // (a lone wave: every round trip counts)
+        constexpr int PDS = C::CPL >= 3 ? 2 : kSmallPD;                           // (three columns per lane, 80 x 180: four ring groups in flight spill)
+        if constexpr (SC::kAll) {
+            if (mask == all) masked_pair<RG, S, W, PDS, W, true>(Qs, nq, wrow, kd, kn, first, mask, lane, best, bshift);
+            else masked_pair<RG, S, W, PDS>(Qs, nq, wrow, kd, kn, first, mask, lane, best, bshift);   // (a lone wave: every round trip counts)
+        } else masked_pair<RG, S, W, PDS>(Qs, nq, wrow, kd, kn, first, mask, lane, best, bshift);
         if (best < kBigDist) {
             const unsigned long long b = (unsigned long long)__double_as_longlong(best);
             const unsigned long long od = (b >> 63) ? ~b : (b | 0x8000000000000000ull);     // IEEE order -> unsigned order
@@ -626,25 +643,32 @@ hipError_t launch_sc_masked(const DbView &db, int SR, const MaskedQuery *queries
 }
 
 
-bool sc_small_exact_supported(const DbView &db, int SR) { return db.RG == 16 && db.S == 120 && 2 * SR + 1 == 13; }
-
-hipError_t launch_sc_small_exact(const DbView &db, int SR, const SmallExactArgs &args_in, hipStream_t stream)
+template <int RG, int S, int W>
+static hipError_t launch_small_t(const SmallExactArgs &sa, hipStream_t stream)
 {
-    if (args_in.nq < 1 || args_in.nq > (args_in.q_dev ? kMaxSmallExactQueries : kMaxQueryBatch) || !sc_small_exact_supported(db, SR)) return hipErrorInvalidValue;
-    using SC = SmallCfg<16, 120, 13>;
+    using SC = SmallCfg<RG, S, W>;
     static_assert(SC::LDS <= 160 * 1024, "LDS");
     static std::atomic<bool> attr_set_dev[64];
     int dev_ = 0; (void)hipGetDevice(&dev_);
     std::atomic<bool> &attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set.load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void *)sc_small_exact_kernel<16, 120, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC::LDS);
+        hipError_t e = hipFuncSetAttribute((const void *)sc_small_exact_kernel<RG, S, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC::LDS);
         if (e != hipSuccess) return e;
         attr_set.store(true, std::memory_order_release);
     }
+    hipLaunchKernelGGL((sc_small_exact_kernel<RG, S, W>), dim3(sa.nq), dim3(kSmallWaves * kWave), SC::LDS, stream, sa);
+    return hipGetLastError();
+}
+
+bool sc_small_exact_supported(const DbView &db, int SR) { return (db.RG == 16 && db.S == 120 && 2 * SR + 1 == 13) || (db.RG == 20 && db.S == 180 && 2 * SR + 1 == 19); }
+
+hipError_t launch_sc_small_exact(const DbView &db, int SR, const SmallExactArgs &args_in, hipStream_t stream)
+{
+    if (args_in.nq < 1 || args_in.nq > (args_in.q_dev ? kMaxSmallExactQueries : kMaxQueryBatch) || !sc_small_exact_supported(db, SR)) return hipErrorInvalidValue;
     SmallExactArgs sa = args_in;
     sa.desc = db.desc; sa.norm = db.norm; sa.vkey = db.vkey;
-    hipLaunchKernelGGL((sc_small_exact_kernel<16, 120, 13>), dim3(sa.nq), dim3(kSmallWaves * kWave), SC::LDS, stream, sa);
-    return hipGetLastError();
+    if (db.S == 120) return launch_small_t<16, 120, 13>(sa, stream);
+    return launch_small_t<20, 180, 19>(sa, stream);
 }
 
 

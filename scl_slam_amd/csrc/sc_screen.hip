@@ -126,49 +126,6 @@ constexpr int kTileStride = 64;                // bytes per keyframe in a wave's
                                                // sits at chunk j ^ ((n >> 1) & 2): stores and loads both conflict-free
 constexpr int kScreenMaxBlocks = 768;          // workgroups per query (3 per CU at most)
 
-// The same evaluation for grids with more than two sectors per lane (80 x 180: three shifts per lane).
-template <int S>
-__device__ __forceinline__ int align_keyframe_wide(const double (&vk)[(S + kWave - 1) / kWave], int lane, double *vk2, const double *vq)
-{
-    constexpr int SPL = (S + kWave - 1) / kWave;           // shifts (and sectors) per lane
-    constexpr int LA = S / SPL;                            // active lanes
-    static_assert(S % SPL == 0 && LA <= kWave, "shifts must tile the lanes");
-    const double kInf = __longlong_as_double(0x7ff0000000000000LL);
-    wave_fence();
-    if (lane < LA) {
-#pragma unroll
-        for (int u = 0; u < SPL; ++u) { vk2[SPL * lane + u] = vk[u]; vk2[SPL * lane + u + S] = vk[u]; }
-    }
-    if (lane == 0) { vk2[2 * S] = vk[0]; }                 // one past the doubled key: read by the last slide, never used
-    wave_fence();
-    // lane owns shifts s_k = SPL * lane + k; the key shifted by s at sector t is vk[(t - s) mod S] = p[t - k], p = vk2 + S - SPL * lane
-    const int ll = lane < LA ? lane : LA - 1;
-    const double *p = vk2 + S - SPL * ll;
-    double ss[SPL], w[SPL];
-#pragma unroll
-    for (int k = 0; k < SPL; ++k) { ss[k] = 0.0; w[k] = p[-k]; }
-#pragma unroll 4
-    for (int t = 0; t < S; ++t) {                          // sector order, as the reference's norm (D.h:1500-1502)
-        const double q = vq[t];
-        const double nxt = p[t + 1];
-#pragma unroll
-        for (int k = 0; k < SPL; ++k) { const double d = q - w[k]; ss[k] = ss[k] + d * d; }
-#pragma unroll
-        for (int k = SPL - 1; k > 0; --k) w[k] = w[k - 1];
-        w[0] = nxt;
-    }
-    double best = kInf;
-    int bshift = 0x7fffffff;
-#pragma unroll
-    for (int k = 0; k < SPL; ++k) {                        // ascending shifts, strict <: ties keep the lower shift
-        const double nk = sqrt(ss[k]);
-        if (lane < LA && nk < kBigDist && nk < best) { best = nk; bshift = SPL * lane + k; }
-    }
-    wave_argmin_dpp(best, bshift);
-    return __builtin_amdgcn_readfirstlane(best < kBigDist ? bshift : 0);
-}
-
-
 // ---------------------------------------------------------------------------------------------------------------------
 // K0: the first shift of every (query, keyframe) pair -- fastAlignUsingVkey (D.h:1491-1511) -- and nanoflann's ring-key
 // metric, ahead of the screening products.  One wave per 16 keyframes.
