@@ -771,7 +771,7 @@ def main():
     run(0, warm_scans)
     eng.profile_reset()
     eng.survivor_stats(reset=True)
-    eng.profile_enable(3)          # HIP events around the dominant kernel, one launch in eight (an event pair per launch costs ~8 us)
+    eng.profile_enable(3)          # HIP events around the dominant kernel, one launch in thirteen (an event pair keeps two launches back by 4-6 us each)
     times = []
     for rep in range(max(1, args.repeats)):
         fence()
