@@ -584,7 +584,7 @@ def secondary_80x180(device, n=10000, steps=512):
                          "bytes_per_keyframe": bytes_kf, "bytes_per_pair_intermediates": bytes_pair_io, "survey_bytes_per_pair": survey_pair,
                          "kernel": "screening launch group of the 80x180 grid: sc_screen2_kernel<20,180,19> (five ring slices of 16, two sectors per "
                                    "k-step, 19 shifts in two passes that share the scans' fragments, 16 scans per launch) + finish + alignment of "
-                                   "the next group; one group in thirteen sampled"}}
+                                   "the next group; one event pair around every second chunk's launch groups, its time divided by their number"}}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -867,7 +867,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": f"screening launch group of {k1_scans:.0f} scans x {n_elig} keyframes: sc_screen2_kernel (products: one keyframe "
                                    f"against the launch's scans per matrix-core tile) + sc_screen2_tail2_kernel (finishing beside the next batch's alignment, "
-                                   f"itself one keyframe against the scans per tile); HIP events around the group",
+                                   f"itself one keyframe against the scans per tile); HIP events around the launch groups of every second chunk of the stream (eight groups), "
+                                   f"their time divided by the groups' number",
                          "algorithmic_bytes_per_launch": per_launch,
                          "scans_per_launch": k1_scans, "pairs_per_launch": k1_pairs,
                          "pricing": "SURVEY 8(d), Q scans per database pass: DB bytes once per launch + per-scan bytes + per-pair intermediates "

@@ -350,8 +350,9 @@ int  scl_geometric_verification_from_store(scl_engine *e, const void *src, int n
 
 /* ---- measurement ----------------------------------------------------------- */
 int  scl_profile_enable(scl_engine *e, int on);   /* 0 off, 1 every kernel family, 2 SC distance only,
-                                                     3 SC distance only, one launch in thirteen (an event pair
-                                                     keeps the two launches behind its events back by 4-6 us each) */
+                                                     3 SC distance only, sampled: one launch in thirteen -- in the stream form one
+                                                     pair around every second chunk's launch groups, counted as that many launches
+                                                     (an event keeps the launch behind it back by 4-6 us) */
 int  scl_profile_reset(scl_engine *e);
 int  scl_profile_get(scl_engine *e, scl_profile *out);
 /* Counters of the ICP loop's LDS-tiled neighbour search (icp.hip K4c) since the last reset, in builds made with

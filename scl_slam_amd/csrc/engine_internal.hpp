@@ -17,7 +17,7 @@ namespace scl {
 
 enum ProfKind { P_SC = 0, P_TOPK, P_ARGMIN, P_MAKESC, P_INGEST, P_ICPNN, P_ICPRED, P_COUNT };
 
-struct PendingEvent { hipEvent_t start, stop; int kind; };
+struct PendingEvent { hipEvent_t start, stop; int kind; int launches = 1; };   // launches: what the pair brackets (a chunk's screening: its launch groups)
 
 struct ShardedFront;                                       // sharded_front.hip
 
