@@ -1131,6 +1131,7 @@ int launch_small_exact_chunk(scl_engine *e, const int *qslot, const int *lo, con
     SmallExactArgs sa{};
     sa.nq = nq; sa.k = e->cfg.num_candidates; sa.exclude_eps = e->cfg.knn_exclude_eps; sa.two_eps = 2.0f * sc_screen_eps(); sa.surv_stats = e->d_surv_stats;
     sa.q_dev = d;
+    sa.every_shift = wide_masks ? 0 : 1;
     ProfScope ps(e, P_ARGMIN, stream);
     SCL_HIP(e, launch_sc_small_exact(db_view(e), e->SR, sa, stream));
     return SCL_OK;

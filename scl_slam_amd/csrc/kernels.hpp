@@ -155,6 +155,7 @@ struct SmallExactQuery {
 struct SmallExactArgs {
     const float4 *desc; const double *norm; const double *vkey;               // (filled by the launcher)
     int nq, k; float exclude_eps, two_eps; unsigned long long *surv_stats;
+    int every_shift;                                                          // the scans' survivors come without shift masks: the instance that scores every shift in one pass
     unsigned int seq;                                                         // != 0: written to out3[4] behind the winner (a blocking call polls the pinned record
                                                                               // instead of an event: the event's packet fires 4-6 us behind the kernel)
     const SmallExactQuery *q_dev;                                             // the queries in device memory (a chunk of the stream form: up to

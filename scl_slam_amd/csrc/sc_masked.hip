@@ -324,13 +324,17 @@ constexpr int kSmallWaves = 8;                  // (512 threads: registers for k
 constexpr int kSmallPD = 4;                     // ring groups in flight per wave (8 spill)
 constexpr int kSmallList = 1024;                // listed keyframes kept in LDS with their first shift and mask (more: through memory)
 constexpr int kSmallTop = 16;                   // ring-key candidates the barrier-free top-k tracks per wave
-template <int RG, int S, int W>
+// EVERY: the instance for scans whose survivors come without shift masks (the 64 x 120 stream): W rows of sums per wave, every shift in one
+// pass.  The blocking call's instance (masks, a handful of open shifts) keeps the small rows: with both bodies in one kernel the blocking
+// scan took 5 us longer (150 KB of LDS to allocate, twice the code for a launch that runs once).
+template <int RG, int S, int W, bool EVERY = false>
 struct SmallCfg {
     using M = MaskedCfg<RG, S, W>;
     static constexpr size_t LDS_Q = M::LDS_Q, LDS_N = M::LDS_N;
     // every shift of a survivor in one pass needs W rows of sums per wave: 64 x 120 has the room (150 KB in all), 80 x 180 has not (its
     // launches always form shift masks: passes of kMaskTMax open shifts)
-    static constexpr bool kAll = LDS_Q + LDS_N + (size_t)kSmallWaves * W * S * 8 + (size_t)kSmallList * 12 + 4096 <= 160 * 1024;
+    static constexpr bool kFits = LDS_Q + LDS_N + (size_t)kSmallWaves * W * S * 8 + (size_t)kSmallList * 12 + 4096 <= 160 * 1024;
+    static constexpr bool kAll = EVERY && kFits;
     static constexpr size_t ROWS_WAVE = kAll ? (size_t)W * S * 8 : M::LDS_WAVE;
     static constexpr size_t LDS_WAVE = ROWS_WAVE > (size_t)(2 * S + 2) * 8 ? ROWS_WAVE : (size_t)(2 * S + 2) * 8;   // rows of sums, or the doubled key of the slow path
     static constexpr size_t LDS_VQ = (size_t)S * 8;                  // the scan's sector key (slow path)
@@ -339,11 +343,11 @@ struct SmallCfg {
     static constexpr size_t LDS = LDS_Q + LDS_N + kSmallWaves * LDS_WAVE + LDS_VQ + LDS_REC + 16 + LDS_LIST;
 };
 
-template <int RG, int S, int W>
+template <int RG, int S, int W, bool EVERY>
 __global__ __launch_bounds__(kSmallWaves * kWave) void sc_small_exact_kernel(SmallExactArgs sa)
 {
     using C = MaskedCfg<RG, S, W>;
-    using SC = SmallCfg<RG, S, W>;
+    using SC = SmallCfg<RG, S, W, EVERY>;
     constexpr int PITCH = C::PITCH, QCOLS = C::QCOLS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
     unsigned char *Qs = smem_s;
@@ -643,20 +647,20 @@ hipError_t launch_sc_masked(const DbView &db, int SR, const MaskedQuery *queries
 }
 
 
-template <int RG, int S, int W>
+template <int RG, int S, int W, bool EVERY>
 static hipError_t launch_small_t(const SmallExactArgs &sa, hipStream_t stream)
 {
-    using SC = SmallCfg<RG, S, W>;
+    using SC = SmallCfg<RG, S, W, EVERY>;
     static_assert(SC::LDS <= 160 * 1024, "LDS");
     static std::atomic<bool> attr_set_dev[64];
     int dev_ = 0; (void)hipGetDevice(&dev_);
     std::atomic<bool> &attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set.load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void *)sc_small_exact_kernel<RG, S, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC::LDS);
+        hipError_t e = hipFuncSetAttribute((const void *)sc_small_exact_kernel<RG, S, W, EVERY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC::LDS);
         if (e != hipSuccess) return e;
         attr_set.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((sc_small_exact_kernel<RG, S, W>), dim3(sa.nq), dim3(kSmallWaves * kWave), SC::LDS, stream, sa);
+    hipLaunchKernelGGL((sc_small_exact_kernel<RG, S, W, EVERY>), dim3(sa.nq), dim3(kSmallWaves * kWave), SC::LDS, stream, sa);
     return hipGetLastError();
 }
 
@@ -667,8 +671,8 @@ hipError_t launch_sc_small_exact(const DbView &db, int SR, const SmallExactArgs 
     if (args_in.nq < 1 || args_in.nq > (args_in.q_dev ? kMaxSmallExactQueries : kMaxQueryBatch) || !sc_small_exact_supported(db, SR)) return hipErrorInvalidValue;
     SmallExactArgs sa = args_in;
     sa.desc = db.desc; sa.norm = db.norm; sa.vkey = db.vkey;
-    if (db.S == 120) return launch_small_t<16, 120, 13>(sa, stream);
-    return launch_small_t<20, 180, 19>(sa, stream);
+    if (db.S == 120) return sa.every_shift ? launch_small_t<16, 120, 13, true>(sa, stream) : launch_small_t<16, 120, 13, false>(sa, stream);
+    return launch_small_t<20, 180, 19, false>(sa, stream);
 }
 
 

@@ -36,7 +36,9 @@ for k in ks[1:]:
         cur.append(k)
 blocks.append(cur)
 import re
-for b in blocks[-3:]:
+full = [b for b in blocks if any("small_exact" in k[2] or "survivors" in k[2] for k in b)][-3:]          # blocking full-database scans
+intra = [b for b in blocks if any("cand_exact" in k[2] or "topk_pack" in k[2] for k in b)][-3:]            # reference-faithful detection calls
+for b in full + intra:
     t0 = b[0][0]; prev_end = t0
     print(f"--- call of {len(b)} kernels, {(max(e for _, e, _ in b) - t0) / 1e3:.1f} us from first start to last end")
     for s, e, n in b:
