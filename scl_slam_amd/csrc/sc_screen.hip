@@ -2207,7 +2207,9 @@ hipError_t launch_sc_screen_batch(const DbView &db, const ScreenBatch &sb, int S
 {
     if (sb.nq < 1 || sb.nq > kMaxScreenBatch || !sc_screen_supported(db, SR)) return hipErrorInvalidValue;
     if (sc_screen_is_wide(db, SR)) return launch_screen_grid<20, 180, 19, 2, 2>(db, sb, align_filter, num_cu, stream, phases, next, prev);   // 80 x 180
-    return launch_screen_grid<16, 120, 13, 3, 2>(db, sb, align_filter, num_cu, stream, phases, next, prev);                                   // 64 x 120
+    // (64 x 120: the first form scores batches of one to three scans -- blocking calls -- and the kernel built for two waves per SIMD takes
+    //  4 us less of a one-scan call than the one for three, which was the better one when the first form still scored batches of four)
+    return launch_screen_grid<16, 120, 13, 2, 3>(db, sb, align_filter, num_cu, stream, phases, next, prev);                                   // 64 x 120
 }
 
 // Can a batch of nq scans have its finishing deferred (second form of the products, extra waves available)?
