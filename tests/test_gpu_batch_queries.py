@@ -80,3 +80,24 @@ def test_long_stream_crosses_chunks_with_empty_and_ragged_ranges():
                 assert (a[0], a[1]) == (g, s_) and a[2] == dd, (count, i)
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("R,S,n", [(64, 120, 600), (80, 180, 400), (20, 60, 500)])
+def test_stream_calls_of_one_to_four_scans_equal_the_blocking_calls(R, S, n):
+    """scl_detect_full_stream hands up to four scans to the blocking form's launch group (on the screened grids); whatever the path, the
+    winners are those of scl_detect_full_range -- ragged and empty ranges included."""
+    descs = synth_descriptors(n, R, S, seed=77, revisit_frac=0.05)
+    eng = ScanContextEngine(num_ring=R, num_sector=S, initial_capacity=n)
+    eng.save_bulk(descs)
+    rs = np.random.RandomState(4)
+    for m in (1, 2, 3, 4, 5):
+        for rep in range(3):
+            qs = rs.randint(0, n, size=m).astype(np.int32)
+            los = rs.randint(0, n // 2, size=m).astype(np.int32)
+            his = (los + rs.randint(0, n // 2, size=m)).astype(np.int32)
+            if rep == 2: his[0] = los[0]                                   # an empty range among them
+            nn, sh, dd = eng.detect_full_stream(qs, los, his, 16, 2)
+            for i in range(m):
+                one = eng.detect_full_range(int(qs[i]), int(los[i]), int(his[i]))
+                assert (nn[i], sh[i]) == (one[0], one[1]) and dd[i].view(np.uint64) == np.float64(one[2]).view(np.uint64), (m, rep, i)
+    eng.close()
