@@ -456,7 +456,8 @@ static void log_env_overrides_once()
                                         // experiments: read by a diagnostics build only (kernels.hpp: scl_lab_int)
                                         "SCL_SCREEN_VARIANT", "SCL_SCREEN_PROBE", "SCL_SCREEN_TAIL", "SCL_SCREEN_FUSE", "SCL_FUSE_PARTS", "SCL_ALIGN_FORM", "SCL_ALIGN_WGS",
                                         "SCL_ALIGN2_WGS", "SCL_ALIGN_SIDE", "SCL_ALIGN_FILTER", "SCL_SC_KERNEL", "SCL_SC_WAVES", "SCL_STAMP", "SCL_ABLATE", "SCL_ALT_LANE",
-                                        "SCL_ICP_REDUCE", "SCL_MATRIX_PLAIN", "SCL_MATRIX_KERNEL", "SCL_MATRIX_KR", "SCL_WIDE_EXACT"};
+                                        "SCL_ICP_REDUCE", "SCL_MATRIX_PLAIN", "SCL_MATRIX_KERNEL", "SCL_MATRIX_KR", "SCL_WIDE_EXACT", "SCL_STREAM_EXACT", "SCL_SMALL_EXACT_OFF",
+                                        "SCL_SELF_ALIGN_OFF", "SCL_CAND_EXACT_OFF"};
     constexpr int kProduct = 4;
     int i = 0;
     for (const char *n : names) {
