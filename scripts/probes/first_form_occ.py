@@ -9,7 +9,7 @@ from scl_slam_amd.synth import synth_descriptors
 R, S, N = 64, 120, 10000
 eng = ScanContextEngine(num_ring=R, num_sector=S, num_candidates=3, num_exclude_recent=100, initial_capacity=N + 8)
 eng.save_bulk(synth_descriptors(N, R, S, seed=1002))
-for nq in (1, 2, 3):
+for nq in (1, 2, 3, 4):
     ts = []
     for i in range(80):
         q = np.arange(N - 1 - (i % 40), N - 1 - (i % 40) - nq, -1, dtype=np.int32)
