@@ -429,8 +429,12 @@ __device__ __forceinline__ void sc_align_role(const ScreenBatchArgs &ab, const i
 // set-up in LDS, and the keyframe's bytes are fetched once per launch instead of once per scan.
 constexpr int kAlignUndecided = -1;            // first shift of a pair no alignment has decided (never written by this file's kernels now; the consumers honour it)
 constexpr float kAlignSplitEps = 6.0e-6f;      // stage 2: bound of |c~ - c| (see above)
+#ifndef SCL_A2_OCC_WIDE
+#define SCL_A2_OCC_WIDE 2            // (80 x 180: +2-5 % on the stream against the build for three waves, which spilled 56 bytes)
+#endif
 #ifndef SCL_A2_OCC
-#define SCL_A2_OCC 4
+#define SCL_A2_OCC 2                 // (built for two waves per SIMD the tail launch takes 166 registers and spills nothing: three waves per SIMD in fact, and
+                                     //  2 us less per launch than the 128-register build for four, which spilled 40 bytes: +3-4 % on the stream)
 #endif
 #ifndef SCL_A2_PROBE
 #define SCL_A2_PROBE 0                         // experiments only (scripts/build_variant.sh): 1 no stage 2 / exact (open pairs marked undecided)
@@ -448,7 +452,7 @@ struct Align2Cfg {
     static constexpr int IMG = halign_img_bytes(S);                // bytes of one part (hi or lo) of the image
     static constexpr int NLD = (IMG + kWave * 16 - 1) / (kWave * 16);   // 16-byte loads per lane and part
     static constexpr int LDS_WAVE = 2 * IMG > (2 * S + 2) * 8 ? 2 * IMG : ((2 * S + 2) * 8 + 15) / 16 * 16;   // both parts; the exact evaluation's scratch reuses it
-    static constexpr int OCC = KS <= 4 ? SCL_A2_OCC : 3;           // waves per SIMD the kernels are built for
+    static constexpr int OCC = KS <= 4 ? SCL_A2_OCC : SCL_A2_OCC_WIDE;   // waves per SIMD the kernels are built for
 };
 
 template <int S, int W>
