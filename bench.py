@@ -870,7 +870,7 @@ def main():
             # what the exact fp64 pass scored: the rate above depends on it (worst case -- every keyframe survives -- is
             # secondary.exact_all_pairs' rate; secondary.adversarial_survivors is a database with 5 % of the keyframes inside the margin)
             "survivors_per_scan": {"mean": sv_sum / max(1, sv_q), "max": sv_max, "scans": sv_q,
-                                   "screening_margin": "d~ <= min d~ + 2 x 1.5e-3"},
+                                   "screening_margin": "d~ <= min d~ + 2 x the launch's largest per-pair bound (<= 1.5e-3; ~6e-4 on this database)"},
             "semantics": "value = pairs through arg-min detection (winner index / shift / f64 distance bit-identical to the CPU restatement); "
                          "NOT every pair's f64 distance -- that is secondary.exact_all_pairs; a step is 16 scans that arrive together, "
                          "secondary.detect_full_blocking_us is one scan on its own",
