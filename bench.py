@@ -537,6 +537,136 @@ def secondary_adversarial_survivors(device, shard, queries, n_elig, frac=0.05, s
 
 
 # ------------------------------------------------------------------------------------------------
+# secondary: the front half of the per-incoming-scan path -- raw points -> descriptor -> database slot (K3), ring-key scan (K2)
+# ------------------------------------------------------------------------------------------------
+def _h2d_rate_gbs(mb=64, reps=8):
+    """what a pinned host buffer reaches on this box's PCIe link, through the same runtime (one big hipMemcpyAsync at a time)"""
+    import torch
+    x = torch.empty(mb << 20, dtype=torch.uint8).pin_memory()
+    y = torch.empty(mb << 20, dtype=torch.uint8, device="cuda")
+    y.copy_(x, non_blocking=True); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        y.copy_(x, non_blocking=True)
+    e1.record(); torch.cuda.synchronize()
+    return reps * (mb << 20) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def _p50_us(fn, reps, warm=3):
+    lat = []
+    for i in range(reps + warm):
+        t0 = time.perf_counter()
+        fn()
+        if i >= warm:
+            lat.append((time.perf_counter() - t0) * 1e6)
+    return float(np.percentile(lat, 50))
+
+
+def secondary_ingest_per_scan(device, shapes=((64, 120, 120000), (80, 180, 240000)), batch=16):
+    """K3 (makeScancontext D.h:1404-1461 + save D.h:1587-1602) per incoming scan of 16-byte point records: device time of the two
+    launches a batch of 16 scans costs (HIP events around the scatter over all 16 clouds and around the ingest of their 16 slots),
+    the call's wall clock from pageable and from pinned host memory, one scan at a time (scl_make_and_save) and sixteen
+    (scl_make_and_save_many).  Roofline by SURVEY 8(d): n x 16 B in + R x S x 4 B out per scan over the kernels' time."""
+    from scl_slam_amd import ScanContextEngine
+    from scl_slam_amd.synth import synth_scan
+    out = {}
+    for (R2, S2, npts) in shapes:
+        eng = ScanContextEngine(num_ring=R2, num_sector=S2, device=device, initial_capacity=8192)
+        clouds = [np.ascontiguousarray(synth_scan(npts, seed=300 + i, stride_floats=4)) for i in range(batch)]
+        pinned = []
+        for c in clouds:
+            a = eng.host_alloc(c.shape); a[:] = c; pinned.append(a)
+        one_pageable = _p50_us(lambda: eng.make_and_save(clouds[0], 0, 0), 30)
+        one_pinned = _p50_us(lambda: eng.make_and_save(pinned[0], 0, 0), 30)
+        many_pageable = _p50_us(lambda: eng.make_and_save_many(clouds, want_values=False), 8, 2)
+        many_pinned = _p50_us(lambda: eng.make_and_save_many(pinned, want_values=False), 12, 2)
+        eng.profile_reset(); eng.profile_enable(1)
+        for _ in range(10):
+            eng.make_and_save_many(pinned, want_values=False)
+        eng.profile_enable(0)
+        prof = eng.profile()
+        sc_us = prof["make_sc_ms"] / max(1, prof["make_sc_launches"]) * 1e3
+        ing_us = prof["ingest_ms"] / max(1, prof["ingest_launches"]) * 1e3
+        dev_us = sc_us + ing_us
+        algo = batch * (npts * 16 + R2 * S2 * 4)
+        ach = algo / (dev_us * 1e-6) / 1e9 if dev_us > 0 else 0.0
+        ach_sc = batch * npts * 16 / (sc_us * 1e-6) / 1e9 if sc_us > 0 else 0.0
+        eng.close()
+        out[f"{R2}x{S2}_{npts // 1000}k_points"] = {
+            "device_us_per_scan_in_a_batch_of_16": dev_us / batch, "device_us_per_batch": {"scatter_16_clouds": sc_us, "ingest_16_slots": ing_us},
+            "call_us_per_scan": {"one_scan_pageable": one_pageable, "one_scan_pinned": one_pinned,
+                                 "batch_of_16_pageable": many_pageable / batch, "batch_of_16_pinned": many_pinned / batch},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_batch": algo, "scatter_only": {"achieved": ach_sc, "frac": ach_sc / HBM_PEAK_GBS},
+                         "pricing": "SURVEY 8(d) K3: n_pts x 16 B in + R x S x 4 B out per scan, x 16 scans, over scatter + ingest (HIP events on the engine's stream)",
+                         "kernel": "make_sc_batch_scatter_kernel (workgroup = 4 096 points of one cloud, private LDS polar tile, atomicMax merge) + "
+                                   "ingest_kernel (one workgroup per scan: finalize, keys, norms, fp32 / fp16 / alignment images of the slot)"}}
+    return out
+
+
+def secondary_ringkey_topk(eng, n_elig, n_query, reps=60):
+    """K2: the exact ring-key scan (nanoflann's metric, NF:383-408) over the eligible keyframes -- ONE launch (distance + per-workgroup
+    top-k + last-workgroup merge).  Roofline by SURVEY 8(d): N x R x 4 B per query."""
+    res = {}
+    for k in (3, 25):
+        for i in range(5):
+            eng.ringkey_topk(int(n_elig + i), 0, n_elig, k)
+        eng.profile_reset(); eng.profile_enable(1)
+        for i in range(reps):
+            eng.ringkey_topk(int(n_elig + i % n_query), 0, n_elig, k)
+        eng.profile_enable(0)
+        prof = eng.profile()
+        us = prof["ringkey_topk_ms"] / max(1, prof["ringkey_topk_launches"]) * 1e3
+        call = _p50_us(lambda: eng.ringkey_topk(int(n_elig + 7), 0, n_elig, k), 40)
+        algo = n_elig * R * 4
+        ach = algo / (us * 1e-6) / 1e9 if us > 0 else 0.0
+        res[f"k{k}"] = {"device_us": us, "call_us_p50": call,
+                        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes": algo,
+                                     "hbm_floor_us": algo / (HBM_PEAK_GBS * 1e9) * 1e6,
+                                     "note": "2.5 MB per query: a launch is latency bound (one wave per 64 slots, sixteen 16-byte loads in flight per lane)"}}
+    return res
+
+
+def secondary_stream_from_points(device, n=N_KEYFRAMES_1GPU, npts=120000, n_scans=256, batch=16):
+    """The per-incoming-scan pipeline from raw points in one call (scl_stream_from_points): per scan 120 k points of 16 B from PINNED
+    host memory -> descriptor -> database slot -> full-database arg-min detection over [0, key - 100), on a 10k-keyframe database.
+    PCIe is the floor: the clouds of group g + 1 are copied while group g is binned, ingested and searched for."""
+    from scl_slam_amd import ScanContextEngine
+    from scl_slam_amd.synth import synth_descriptors, synth_scan
+    eng = ScanContextEngine(num_ring=R, num_sector=S, num_candidates=3, num_exclude_recent=N_EXCLUDE, device=device, initial_capacity=n + 2 * n_scans + 64)
+    eng.save_bulk(synth_descriptors(n, R, S, seed=1002))
+    pinned = []
+    for i in range(batch):
+        c = synth_scan(npts, seed=500 + i, stride_floats=4)
+        a = eng.host_alloc(c.shape); a[:] = c; pinned.append(a)
+    pageable = [np.array(a) for a in pinned]
+    seq = [pinned[i % batch] for i in range(n_scans)]
+    eng.stream_from_points(seq[:2 * batch])                                  # warm-up: buffers, streams, the stream form's sets
+    n_before = eng.get_size()
+    t0 = time.perf_counter()
+    nn, sh, dd = eng.stream_from_points(seq)
+    dt = time.perf_counter() - t0
+    pairs = int(sum(max(0, n_before + i - N_EXCLUDE) for i in range(n_scans)))
+    seq_p = [pageable[i % batch] for i in range(4 * batch)]
+    t0 = time.perf_counter()
+    eng.stream_from_points(seq_p)
+    dt_p = time.perf_counter() - t0
+    h2d = _h2d_rate_gbs()
+    bytes_scan = npts * 16
+    floor_us = bytes_scan / (h2d * 1e9) * 1e6
+    eng.close()
+    return {"workload": f"{n_scans} scans of {npts} points (16-byte records, pinned host memory) through scl_stream_from_points on a {n}-keyframe 64x120 database: "
+                        f"descriptor + append + full-database detection per scan, groups of {batch}",
+            "scans_per_s": n_scans / dt, "us_per_scan": dt / n_scans * 1e6, "value": pairs / dt, "unit": "pairs/s",
+            "winners_found": int((nn >= 0).sum()),
+            "pcie": {"h2d_GBps_measured": h2d, "bytes_per_scan": bytes_scan, "floor_us_per_scan": floor_us, "us_per_scan_over_floor": dt / n_scans * 1e6 / floor_us,
+                     "note": "floor = bytes per scan / the rate one large pinned hipMemcpyAsync reaches on this box"},
+            "pageable_host_memory": {"us_per_scan": dt_p / len(seq_p) * 1e6, "scans": len(seq_p),
+                                     "note": "the same call from ordinary (pageable) buffers: the runtime stages every copy through its own pinned memory"}}
+
+
+# ------------------------------------------------------------------------------------------------
 # secondary: the SC-distance pass on BASELINE configs[4]'s grid (80 x 180), 10k keyframes
 # ------------------------------------------------------------------------------------------------
 def secondary_80x180(device, n=10000, steps=512):
@@ -905,6 +1035,9 @@ def main():
             out["secondary"] = {}
             for name, fn in (("exact_all_pairs", lambda: secondary_exact_all_pairs(eng, n_elig, n_query)),
                              ("detect_full_blocking_us", lambda: secondary_blocking_scan(eng, n_elig, n_query)),
+                             ("ringkey_topk", lambda: secondary_ringkey_topk(eng, n_elig, n_query)),
+                             ("ingest_per_scan", lambda: secondary_ingest_per_scan(local_rank)),
+                             ("stream_from_points", lambda: secondary_stream_from_points(local_rank)),
                              ("sc_distance_80x180", lambda: secondary_80x180(local_rank)),
                              ("adversarial_survivors", lambda: secondary_adversarial_survivors(local_rank, shard, queries, n_elig)),
                              ("icp_verification", lambda: secondary_icp(eng)),

@@ -29,6 +29,7 @@
 #ifndef SCL_ENGINE_H
 #define SCL_ENGINE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -131,6 +132,29 @@ int  scl_get_size(const scl_engine *e, int id);
  * points after the filter.  Same descriptor, key and database state as scl_voxel_grid + scl_make_and_save. */
 int  scl_make_and_save_filtered(scl_engine *e, const void *points, int n_points, int stride_bytes, float leaf,
                                 int8_t robot, int index, float *out_values, int *n_filtered);
+/* makeDescriptors for a BATCH of keyframes (DM.h:988-1025 runs once per keyframe; a robot team's keyframes arrive together, and a
+ * map that is loaded or replayed arrives all at once): `count` clouds -> `count` descriptors appended in order, as `count` calls of
+ * scl_make_and_save would (same descriptors, keys and database state, bit for bit).  Groups of up to 16 scans cost two kernel
+ * launches each (one scatter over all the clouds, one ingest that writes every array of their slots); a group's clouds travel to
+ * the device while the group before is processed -- by DMA when the buffers are pinned (scl_host_alloc / scl_host_register).
+ * robots / indexs may be NULL (robot 0, index = slot); out_values may be NULL, else count x R*S floats (the wire format of
+ * global_descriptor.values, D.h:1446-1456, per scan). */
+int  scl_make_and_save_many(scl_engine *e, const void *const *clouds, const int *n_points, int count, int stride_bytes,
+                            const int8_t *robots, const int *indexs, float *out_values);
+/* The per-incoming-scan pipeline from raw points in one call: for scan i, makeAndSaveDescriptorAndKey (DM.h:1002; keyframe
+ * key_i = size before the call + i) and then the full-database detection of that keyframe over [0, key_i - NUM_EXCLUDE_RECENT)
+ * (D.h:1627; scl_detect_full's rule): nn_idx[i] = arg-min keyframe (-1: empty range), shift[i], dist[i] = its fp64 SC distance --
+ * what scl_make_and_save + scl_detect_full_range give scan by scan, bit for bit.  Same grouping and copy overlap as
+ * scl_make_and_save_many; the caller applies the threshold (dist < dist_thres, D.h:1662). */
+int  scl_stream_from_points(scl_engine *e, const void *const *clouds, const int *n_points, int n_scans, int stride_bytes,
+                            const int8_t *robots, const int *indexs, int *nn_idx, int *shift, double *dist, float *out_values);
+/* Pinned host memory for point clouds: a cloud handed over from such a buffer goes to the device by DMA, without the runtime's
+ * staging copy, and overlaps the kernels of the scans before it.  scl_host_alloc buffers are freed by scl_host_free or with the
+ * engine; scl_host_register pins memory the caller owns (e.g. a pcl::PointCloud's points) until scl_host_unregister. */
+int  scl_host_alloc(scl_engine *e, size_t bytes, void **out);
+int  scl_host_free(scl_engine *e, void *p);
+int  scl_host_register(scl_engine *e, void *p, size_t bytes);
+int  scl_host_unregister(scl_engine *e, void *p);
 /* makeScancontext only (D.h:1404-1461), nothing is stored. */
 int  scl_make_descriptor(scl_engine *e, const void *points, int n_points, int stride_bytes,
                          float *out_values);
@@ -372,6 +396,11 @@ int  scl_alignment_stats(scl_engine *e, uint64_t *pairs, uint64_t *fallbacks, in
  * pointer may be NULL; reset != 0 clears the counters. */
 int  scl_survivor_stats(scl_engine *e, uint64_t *queries, uint64_t *survivors, uint64_t *max_survivors, int reset);
 int  scl_device_name(const scl_engine *e, char *buf, int buflen);
+/* Self test of the device's float atan -- xy2theta (D.h:1352-1374) calls std::atan(float), here glibc's atanf restated in fp32
+ * (csrc/device_common.hpp) --: checksums[b] = sum mod 2^64 over the 2^24 float bit patterns of block first_block + b of
+ * splitmix64((bits << 32) | result bits), NaN results counted as 0x7fc00000.  tests/golden/atanf_blocks.json holds the 256 values
+ * of libm's atanf (oracle/tools/atanf_exhaustive.c). */
+int  scl_selftest_atanf_blocks(scl_engine *e, int first_block, int n_blocks, uint64_t *checksums);
 
 #ifdef __cplusplus
 }

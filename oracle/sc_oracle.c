@@ -42,12 +42,61 @@ void sco_default_config(sco_config *c)
 
 /* ---------------------------------------------------------------------------
  * atan.  The reference calls std::atan(float) (D.h:1357 via `using namespace
- * std`, D.h:19), i.e. the platform's atanf, whose last bit is not specified.
- * The restatement fixes it: atanf(x) := (float) A(x) where A is the classic
- * argument-reduction + odd-polynomial double atan below (< 1 ulp in double,
- * so the float result is the correctly rounded one except ~2^-29 of inputs).
- * Only +,-,*,/ in a fixed order -> the same bits on any IEEE machine.
+ * std`, D.h:19), i.e. the platform's atanf.  On the x86-64 glibc the reference
+ * is built against (2.35 in this image; the same file since glibc 2.0) that is
+ * sysdeps/ieee754/flt-32/s_atanf.c: fdlibm's float atan -- argument reduction
+ * into five intervals, an 11-term polynomial split into odd and even halves,
+ * every operation in fp32, no FMA (objdump of libm.so.6: mulss / addss / subss /
+ * divss only, a plain FUNC without IFUNC variants).  Restated here operation by
+ * operation; oracle/tools/atanf_exhaustive.c compares it with libm's atanf over
+ * ALL 2^32 inputs in the build container (0 differences) and writes the block
+ * checksums of tests/golden/atanf_blocks.json, which the device's copy
+ * (csrc/device_common.hpp: atanf_glibc) is tested against on the GPU.
+ * Constants are glibc's, given by their bit patterns.
  * ------------------------------------------------------------------------ */
+static inline float f32_from_bits(unsigned int u) { float f; memcpy(&f, &u, 4); return f; }
+static inline unsigned int f32_bits(float f) { unsigned int u; memcpy(&u, &f, 4); return u; }
+
+float sco_atanf_glibc(float x)
+{
+    static const unsigned int HI[4] = { 0x3eed6338u, 0x3f490fdau, 0x3f7b985eu, 0x3fc90fdau };   /* atan(0.5), atan(1), atan(1.5), atan(inf): high parts */
+    static const unsigned int LO[4] = { 0x31ac3769u, 0x33222168u, 0x33140fb4u, 0x33a22168u };   /* ... low parts */
+    static const unsigned int AT[11] = { 0x3eaaaaabu, 0xbe4ccccdu, 0x3e124925u, 0xbde38e38u, 0x3dba2e6eu, 0xbd9d8795u,
+                                         0x3d886b35u, 0xbd6ef16bu, 0x3d4bda59u, 0xbd15a221u, 0x3c8569d7u };
+    const unsigned int hx = f32_bits(x), ix = hx & 0x7fffffffu;
+    int id;
+    if (ix >= 0x4c000000u) {                              /* |x| >= 2^25 */
+        if (ix > 0x7f800000u) return x + x;               /* NaN */
+        const float r = f32_from_bits(HI[3]) + f32_from_bits(LO[3]);
+        return (hx >> 31) ? -r : r;
+    }
+    if (ix < 0x3ee00000u) {                               /* |x| < 0.4375 */
+        if (ix < 0x31000000u) return x;                   /* |x| < 2^-29 */
+        id = -1;
+    } else {
+        x = fabsf(x);
+        if (ix < 0x3f980000u) {                           /* |x| < 1.1875 */
+            if (ix < 0x3f300000u) { id = 0; x = (2.0f * x - 1.0f) / (2.0f + x); }      /* 7/16 <= |x| < 11/16 */
+            else                  { id = 1; x = (x - 1.0f) / (x + 1.0f); }             /* 11/16 <= |x| < 19/16 */
+        } else {
+            if (ix < 0x401c0000u) { id = 2; x = (x - 1.5f) / (1.0f + 1.5f * x); }      /* |x| < 2.4375 */
+            else                  { id = 3; x = -1.0f / x; }                           /* 2.4375 <= |x| < 2^25 */
+        }
+    }
+    const float z = x * x;
+    const float w = z * z;
+#define A(i) f32_from_bits(AT[i])
+    const float s1 = z * (A(0) + w * (A(2) + w * (A(4) + w * (A(6) + w * (A(8) + w * A(10))))));
+    const float s2 = w * (A(1) + w * (A(3) + w * (A(5) + w * (A(7) + w * A(9)))));
+#undef A
+    if (id < 0) return x - x * (s1 + s2);
+    const float r = f32_from_bits(HI[id]) - ((x * (s1 + s2) - f32_from_bits(LO[id])) - x);
+    return (hx >> 31) ? -r : r;
+}
+
+/* Rounds 1-4 used this fp64 argument-reduction + polynomial atan narrowed to float on both sides (the platform's atanf
+ * "unspecified in the last bit"); kept for the record of tests/test_oracle_envelope.py: its sector bin differs from the
+ * platform's for 2 points in 10^8. */
 static const double ATAN_HI[4] = {
     4.63647609000806093515e-01, /* atan(0.5) */
     7.85398163397448278999e-01, /* atan(1.0) */
@@ -94,7 +143,25 @@ double sco_atan_pos(double x)
     return ATAN_HI[id] - ((x * (s1 + s2) - ATAN_LO[id]) - x);
 }
 
-static float sco_atanf(float x) { return (float)sco_atan_pos((double)x); }
+static float sco_atanf(float x) { return sco_atanf_glibc(x); }
+
+/* Checksum of sco_atanf_glibc over block `block` (0..255) of 2^24 consecutive float bit patterns: sum mod 2^64 of
+ * splitmix64((bits << 32) | result bits), NaN results counted as 0x7fc00000 -- tests/golden/atanf_blocks.json holds the 256
+ * values (written by oracle/tools/atanf_exhaustive.c, where every result is also compared with libm's atanf). */
+unsigned long long sco_atanf_block_checksum(int block)
+{
+    unsigned long long h = 0;
+    for (unsigned int i = 0; i < (1u << 24); i++) {
+        const unsigned int bits = ((unsigned int)block << 24) | i;
+        const float a = sco_atanf_glibc(f32_from_bits(bits));
+        unsigned long long z = ((unsigned long long)bits << 32) | (a != a ? 0x7fc00000u : f32_bits(a));
+        z += 0x9e3779b97f4a7c15ull;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        h += z ^ (z >> 31);
+    }
+    return h;
+}
 
 /* D.h:1352-1374.  180/M_PI is a double; atan(float) is float; the result is
  * narrowed to float on return.  Non-short-circuit '&' has no side effects. */

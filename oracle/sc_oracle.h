@@ -41,7 +41,9 @@ typedef struct sco_config {
 void   sco_default_config(sco_config *c);
 
 /* scalar helpers */
-double sco_atan_pos(double x);                       /* deterministic fp64 atan, x >= 0 */
+double sco_atan_pos(double x);                       /* rounds 1-4's fp64 atan, x >= 0 (kept for the envelope record) */
+unsigned long long sco_atanf_block_checksum(int block);   /* see tests/golden/atanf_blocks.json */
+float  sco_atanf_glibc(float x);                     /* glibc's float atanf restated (fp32 ops only); == libm over all 2^32 inputs */
 float  sco_xy2theta(float x, float y);               /* D.h:1352-1374 */
 
 /* descriptor + keys.  Every `double *desc/sc` is an R x S matrix stored

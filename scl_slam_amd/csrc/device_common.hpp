@@ -27,8 +27,47 @@ __device__ __forceinline__ float ordered_to_float(int o)
     return __int_as_float(o >= 0 ? o : (o ^ 0x7fffffff));
 }
 
-// ---- deterministic atan (x >= 0): identical operation sequence to the CPU
-// checker's restatement; only + - * / in a fixed order, no libm --------------
+// ---- atanf as the reference's platform computes it (D.h:1357-1372 call std::atan(float)): glibc's float atanf
+// (sysdeps/ieee754/flt-32/s_atanf.c, fdlibm's algorithm) restated operation by operation -- fp32 only, no contraction
+// (-ffp-contract=off), IEEE division (-fhip-fp32-correctly-rounded-divide-sqrt).  The same restatement in oracle/sc_oracle.c
+// equals libm's atanf on all 2^32 inputs in the build container (oracle/tools/atanf_exhaustive.c); this copy is checked on the
+// device against the block checksums of tests/golden/atanf_blocks.json (tests/test_gpu_make_sc.py).  Constants by bit pattern.
+__device__ __forceinline__ float atanf_glibc(float x)
+{
+    const unsigned int hx = (unsigned int)__float_as_int(x), ix = hx & 0x7fffffffu;
+    float hi = 0.0f, lo = 0.0f;
+    int id;
+    if (ix >= 0x4c000000u) {                              // |x| >= 2^25
+        if (ix > 0x7f800000u) return x + x;               // NaN
+        const float r = __int_as_float(0x3fc90fda) + __int_as_float(0x33a22168);
+        return (hx >> 31) ? -r : r;
+    }
+    if (ix < 0x3ee00000u) {                               // |x| < 0.4375
+        if (ix < 0x31000000u) return x;                   // |x| < 2^-29
+        id = -1;
+    } else {
+        x = fabsf(x);
+        if (ix < 0x3f980000u) {                           // |x| < 1.1875
+            if (ix < 0x3f300000u) { id = 0; hi = __int_as_float(0x3eed6338); lo = __int_as_float(0x31ac3769); x = (2.0f * x - 1.0f) / (2.0f + x); }
+            else                  { id = 1; hi = __int_as_float(0x3f490fda); lo = __int_as_float(0x33222168); x = (x - 1.0f) / (x + 1.0f); }
+        } else {
+            if (ix < 0x401c0000u) { id = 2; hi = __int_as_float(0x3f7b985e); lo = __int_as_float(0x33140fb4); x = (x - 1.5f) / (1.0f + 1.5f * x); }
+            else                  { id = 3; hi = __int_as_float(0x3fc90fda); lo = __int_as_float(0x33a22168); x = -1.0f / x; }
+        }
+    }
+    const float z = x * x;
+    const float w = z * z;
+    const float s1 = z * (__int_as_float(0x3eaaaaab) + w * (__int_as_float(0x3e124925) + w * (__int_as_float(0x3dba2e6e) +
+                     w * (__int_as_float(0x3d886b35) + w * (__int_as_float(0x3d4bda59) + w * __int_as_float(0x3c8569d7))))));
+    const float s2 = w * (__int_as_float(0xbe4ccccd) + w * (__int_as_float(0xbde38e38) + w * (__int_as_float(0xbd9d8795) +
+                     w * (__int_as_float(0xbd6ef16b) + w * __int_as_float(0xbd15a221)))));
+    if (id < 0) return x - x * (s1 + s2);
+    const float r = hi - ((x * (s1 + s2) - lo) - x);
+    return (hx >> 31) ? -r : r;
+}
+
+// ---- fixed fp64 atan (x >= 0) behind LiDAR-Iris's atan2 (iris.hip; rounds 1-4 also used it for xy2theta): identical operation
+// sequence to the CPU checker's restatement; only + - * / in a fixed order, no libm --------------
 __device__ __forceinline__ double atan_pos(double x)
 {
     const double hi0 = 4.63647609000806093515e-01, lo0 = 2.26987774529616870924e-17;
@@ -61,16 +100,15 @@ __device__ __forceinline__ double atan_pos(double x)
     return hi - ((x * (s1 + s2) - lo) - x);
 }
 
-__device__ __forceinline__ float atanf_fixed(float x) { return (float)atan_pos((double)x); }
 
 // xy2theta, D.h:1352-1374
 __device__ __forceinline__ float xy2theta(float x, float y)
 {
     const double k = 180.0 / 3.14159265358979323846;
-    if ((x >= 0) & (y >= 0)) return (float)(k * (double)atanf_fixed(y / x));
-    if ((x < 0) & (y >= 0))  return (float)(180.0 - (k * (double)atanf_fixed(y / (-x))));
-    if ((x < 0) & (y < 0))   return (float)(180.0 + (k * (double)atanf_fixed(y / x)));
-    if ((x >= 0) & (y < 0))  return (float)(360.0 - (k * (double)atanf_fixed((-y) / x)));
+    if ((x >= 0) & (y >= 0)) return (float)(k * (double)atanf_glibc(y / x));
+    if ((x < 0) & (y >= 0))  return (float)(180.0 - (k * (double)atanf_glibc(y / (-x))));
+    if ((x < 0) & (y < 0))   return (float)(180.0 + (k * (double)atanf_glibc(y / x)));
+    if ((x >= 0) & (y < 0))  return (float)(360.0 - (k * (double)atanf_glibc((-y) / x)));
     return __int_as_float(0x7fc00000);
 }
 

@@ -35,6 +35,18 @@ namespace {
         }                                                                              \
     } while (0)
 
+// one spin of a polling loop, on whatever the host is (the engine's host code also builds for aarch64 robots)
+inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__) || defined(__arm__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::this_thread::yield();
+#endif
+}
+
 int fail(const scl_engine *e, int code, const char *msg)
 {
     if (e) e->last_error = msg;
@@ -277,6 +289,7 @@ int ensure_pinned(scl_engine *e, size_t bytes)
     if (bytes <= e->pinned_cap) return SCL_OK;
     if (e->h_pinned) { (void)hipHostFree(e->h_pinned); e->h_pinned = nullptr; e->pinned_cap = 0; }
     SCL_HIP(e, hipHostMalloc(&e->h_pinned, bytes, hipHostMallocDefault));
+    memset(e->h_pinned, 0, bytes);                          // (a polled sequence word must never start out as somebody's old number)
     e->pinned_cap = bytes;
     return SCL_OK;
 }
@@ -299,23 +312,78 @@ int append_meta(scl_engine *e, int8_t robot, int index)
     return SCL_OK;
 }
 
-// points (host) -> e->d_vals[0 .. R*S) on device
-int make_sc_to_vals(scl_engine *e, const void *points, int n_points, int stride_bytes)
+// the batch scatter's tiles (make_sc.hip): kMaxScBatch polar images in their initial state between calls
+int ensure_tiles(scl_engine *e, hipStream_t s)
+{
+    int rc;
+    if (!e->d_tiles) {
+        if ((rc = dev_alloc(e, &e->d_tiles, (size_t)kMaxScBatch * e->R * e->S))) return rc;
+        e->tiles_clean = false;
+    }
+    if (!e->tiles_clean) {                                   // first use, or a call that failed between scatter and consumer
+        SCL_HIP(e, launch_make_sc_tiles_init(e->d_tiles, kMaxScBatch, e->R, e->S, s));
+        e->tiles_clean = true;
+    }
+    return SCL_OK;
+}
+
+int check_cloud(scl_engine *e, const void *points, int n_points, int stride_bytes)
 {
     if (n_points < 0 || stride_bytes < 12 || (stride_bytes & 3)) return fail(e, SCL_ERR_INVALID_ARG, "bad point layout");
     if (n_points > 0 && !points) return fail(e, SCL_ERR_INVALID_ARG, "null points");
+    return SCL_OK;
+}
+
+// K3 for up to kMaxScBatch clouds ALREADY ON THE DEVICE (dptr[i], n[i] points of `stride` bytes): one scatter launch over all of
+// them into the tiles.  What consumes the tiles follows: group_ingest (append) or group_values (descriptor only).
+int group_scatter(scl_engine *e, const unsigned char *const *dptr, const int *n, int count, int stride, hipStream_t s)
+{
     int rc;
+    if (count < 1 || count > kMaxScBatch) return fail(e, SCL_ERR_INVALID_ARG, "batch of 1..16 scans");
+    if ((rc = ensure_tiles(e, s))) return rc;
+    if ((rc = ensure_vals(e, (size_t)e->R * e->S * (size_t)kMaxScBatch))) return rc;
+    ScanBatch b{};
+    b.count = count;
+    uint64_t pts = 0;
+    for (int i = 0; i < count; ++i) { b.points[i] = dptr[i]; b.n[i] = n[i]; pts += (uint64_t)n[i]; }
+    e->tiles_clean = false;
+    ProfScope ps(e, P_MAKESC, s);
+    SCL_HIP(e, launch_make_sc_batch(b, stride, e->R, e->S, e->cfg.lidar_height, e->cfg.max_radius, e->d_tiles,
+                                    scl_lab_int("SCL_SC_SLICE", kScPointsPerWorkgroup), e->num_cu, s));
+    e->prof.make_sc_points += e->prof_on ? pts : 0;
+    return SCL_OK;
+}
+
+// ... tiles -> database slots [first_slot, first_slot + count) (every array of the slot) + wire-format values in e->d_vals; the tiles
+// are initial again afterwards
+int group_ingest(scl_engine *e, int count, int first_slot, hipStream_t s)
+{
+    ProfScope ps(e, P_INGEST, s);
+    SCL_HIP(e, launch_ingest(nullptr, count, first_slot, e->d_desc, e->d_vkey, e->d_norm, e->d_rkey, e->d_rkey4, e->d_hdesc, e->d_kmask,
+                             e->d_hkey, e->hstride, e->cap, e->R, e->S, s, e->d_halign, e->d_tiles, e->d_vals));
+    e->tiles_clean = true;
+    e->db_version++;                                       // the alt lane orders itself behind this write
+    return SCL_OK;
+}
+
+// ... tiles -> wire-format values in e->d_vals only (nothing is stored)
+int group_values(scl_engine *e, int count, hipStream_t s)
+{
+    SCL_HIP(e, launch_make_sc_finalize(e->d_tiles, count, e->R, e->S, e->d_vals, s));
+    e->tiles_clean = true;
+    return SCL_OK;
+}
+
+// one cloud from the host into e->d_points, then the scatter
+int scatter_host_cloud(scl_engine *e, const void *points, int n_points, int stride_bytes)
+{
+    int rc;
+    if ((rc = check_cloud(e, points, n_points, stride_bytes))) return rc;
     const size_t bytes = (size_t)n_points * (size_t)stride_bytes;
     if ((rc = ensure_points(e, bytes + 16))) return rc;
-    if ((rc = ensure_vals(e, (size_t)e->R * e->S))) return rc;
     if (bytes) SCL_HIP(e, hipMemcpyAsync(e->d_points, points, bytes, hipMemcpyHostToDevice, e->stream));
-    {
-        ProfScope ps(e, P_MAKESC);
-        SCL_HIP(e, launch_make_sc(e->d_points, n_points, stride_bytes, e->R, e->S, e->cfg.lidar_height,
-                                  e->cfg.max_radius, e->d_tile, e->d_vals, e->num_cu, e->stream));
-    }
-    e->prof.make_sc_points += e->prof_on ? (uint64_t)n_points : 0;
-    return SCL_OK;
+    const unsigned char *dp = e->d_points;
+    return group_scatter(e, &dp, &n_points, 1, stride_bytes, e->stream);
 }
 
 int launch_distance(scl_engine *e, const QueryView &q, const int *d_cand, int slot_base, int n)
@@ -358,6 +426,9 @@ int topk_enqueue_locked(scl_engine *e, int query, int lo, int hi, int k, float e
         ProfScope ps(e, P_SC);
         if (++e->out_seq == 0) ++e->out_seq;
         e->pinned_seq = e->out_seq;
+        // the word sits at an offset that depends on k: a call with a larger k left idx[] / d2[] data there -- cleared before the launch
+        *reinterpret_cast<volatile unsigned int *>(static_cast<char *>(e->h_pinned) + cand_seq_offset(k)) = 0u;
+        std::atomic_thread_fence(std::memory_order_release);
         SCL_HIP(e, launch_sc_cand_exact(db_view(e), q, e->SR, k, e->d_topk_idx, e->d_topk_d2, e->h_pinned, e->stream, e->pinned_seq));
         if (ps.active()) e->prof.sc_distance_pairs += (uint64_t)k;
         return SCL_OK;
@@ -383,6 +454,7 @@ int topk_finish_locked(scl_engine *e, int k, bool have_dist, int *idx, float *d2
         seen = true;
         while (*w != e->pinned_seq)
             if ((++spins & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) { seen = false; break; }
+        std::atomic_thread_fence(std::memory_order_acquire);      // the block behind the word is read below through plain pointers
         if (seen) collect_profile(e);
     }
     if (!seen && (rc = sync_short(e))) return rc;
@@ -510,11 +582,12 @@ int scl_create(const scl_config *cfg, scl_engine **out)
     if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) return bail(SCL_ERR_HIP);
     if (hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) return bail(SCL_ERR_HIP);
     if (hipHostMalloc((void **)&e->h_out3, 64 * scl_engine::kSlots, hipHostMallocDefault) != hipSuccess) return bail(SCL_ERR_HIP);
+    memset(e->h_out3, 0, 64 * scl_engine::kSlots);          // o[4] of a record is a polled sequence number
     for (int i = 0; i < scl_engine::kSlots; ++i)
         if (hipEventCreateWithFlags(&e->ev_done[i], hipEventDisableTiming) != hipSuccess) return bail(SCL_ERR_HIP);
     if ((rc = ensure_capacity(e, 1))) return bail(rc);
-    if ((rc = dev_alloc(e, &e->d_tile, (size_t)e->R * e->S))) return bail(rc);
-    if ((rc = dev_alloc(e, &e->d_topk_scratch, (size_t)kTopkMaxBlocks * kTopkMaxK))) return bail(rc);
+    if ((rc = dev_alloc(e, &e->d_topk_scratch, (size_t)kTopkMaxBlocks * kTopkMaxK + 2))) return bail(rc);   // partial lists + the scan's ticket counter
+    if (hipMemset(e->d_topk_scratch, 0, sizeof(unsigned long long) * ((size_t)kTopkMaxBlocks * kTopkMaxK + 2)) != hipSuccess) return bail(SCL_ERR_HIP);
     if ((rc = dev_alloc(e, &e->d_topk_idx, (size_t)kTopkMaxK * scl_engine::kScreenSets))) return bail(rc);
     if ((rc = dev_alloc(e, &e->d_topk_d2, (size_t)kTopkMaxK * scl_engine::kScreenSets))) return bail(rc);
     if ((rc = dev_alloc(e, &e->d_out3, (size_t)4))) return bail(rc);
@@ -593,7 +666,14 @@ int scl_destroy(scl_engine *e)
     }
     dev_free(e->d_desc); dev_free(e->d_vkey); dev_free(e->d_norm); dev_free(e->d_rkey); dev_free(e->d_rkey4);
     dev_free(e->d_hdesc); dev_free(e->d_kmask); dev_free(e->d_hkey); dev_free(e->d_halign);
-    dev_free(e->d_vals); dev_free(e->d_points); dev_free(e->d_tile);
+    dev_free(e->d_vals); dev_free(e->d_points); dev_free(e->d_tiles);
+    for (int b = 0; b < 3; ++b) {
+        dev_free(e->d_pbuf[b]);
+        if (e->ev_copied[b]) (void)hipEventDestroy(e->ev_copied[b]);
+        if (e->ev_consumed[b]) (void)hipEventDestroy(e->ev_consumed[b]);
+    }
+    if (e->stream_copy) { (void)hipStreamSynchronize(e->stream_copy); (void)hipStreamDestroy(e->stream_copy); }
+    for (void *hp : e->host_allocs) (void)hipHostFree(hp);
     dev_free(e->d_dist); dev_free(e->d_shift); dev_free(e->d_cand); dev_free(e->d_ring_d2);
     dev_free(e->d_approx); dev_free(e->d_starts); dev_free(e->d_surv); dev_free(e->d_nsurv); dev_free(e->d_tmin); dev_free(e->d_part);
     dev_free(e->d_align_fallbacks);
@@ -645,8 +725,8 @@ int scl_make_and_save(scl_engine *e, const void *points, int n_points, int strid
     (void)hipSetDevice(e->device);
     int rc;
     if ((rc = ensure_capacity(e, e->n + 1))) return rc;
-    if ((rc = make_sc_to_vals(e, points, n_points, stride_bytes))) return rc;
-    if ((rc = ingest_from_vals(e, 1, e->n))) return rc;
+    if ((rc = scatter_host_cloud(e, points, n_points, stride_bytes))) return rc;
+    if ((rc = group_ingest(e, 1, e->n, e->stream))) return rc;
     if (out_values)
         SCL_HIP(e, hipMemcpyAsync(out_values, e->d_vals, sizeof(float) * (size_t)e->R * e->S,
                                   hipMemcpyDeviceToHost, e->stream));
@@ -661,24 +741,18 @@ int scl_make_and_save_filtered(scl_engine *e, const void *points, int n_points, 
     if (e->front) return front_make_and_save(e, points, n_points, stride_bytes, robot, index, out_values, true, leaf, n_filtered);
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
-    if (n_points < 0 || stride_bytes < 12 || (stride_bytes & 3)) return fail(e, SCL_ERR_INVALID_ARG, "bad point layout");
-    if (n_points > 0 && !points) return fail(e, SCL_ERR_INVALID_ARG, "null points");
     int rc;
+    if ((rc = check_cloud(e, points, n_points, stride_bytes))) return rc;
     if ((rc = ensure_capacity(e, e->n + 1))) return rc;
-    if ((rc = ensure_vals(e, (size_t)e->R * e->S))) return rc;
     // makeDescriptors, DM.h:996-1002: VoxelGrid(descriptLeafSize) then makeAndSaveDescriptorAndKey -- the filtered cloud
     // never leaves the device
     std::string err;
     const void *d_cloud = nullptr;
     int m = 0;
     if ((rc = voxel_grid_to_device(&e->vox_ws, e->stream, points, n_points, stride_bytes, leaf, &d_cloud, &m, &err))) { e->last_error = err; return rc; }
-    {
-        ProfScope ps(e, P_MAKESC);
-        SCL_HIP(e, launch_make_sc(d_cloud, m, stride_bytes, e->R, e->S, e->cfg.lidar_height,
-                                  e->cfg.max_radius, e->d_tile, e->d_vals, e->num_cu, e->stream));
-    }
-    e->prof.make_sc_points += e->prof_on ? (uint64_t)m : 0;
-    if ((rc = ingest_from_vals(e, 1, e->n))) return rc;
+    const unsigned char *dp = static_cast<const unsigned char *>(d_cloud);
+    if ((rc = group_scatter(e, &dp, &m, 1, stride_bytes, e->stream))) return rc;
+    if ((rc = group_ingest(e, 1, e->n, e->stream))) return rc;
     if (out_values)
         SCL_HIP(e, hipMemcpyAsync(out_values, e->d_vals, sizeof(float) * (size_t)e->R * e->S,
                                   hipMemcpyDeviceToHost, e->stream));
@@ -694,7 +768,8 @@ int scl_make_descriptor(scl_engine *e, const void *points, int n_points, int str
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     int rc;
-    if ((rc = make_sc_to_vals(e, points, n_points, stride_bytes))) return rc;
+    if ((rc = scatter_host_cloud(e, points, n_points, stride_bytes))) return rc;
+    if ((rc = group_values(e, 1, e->stream))) return rc;
     SCL_HIP(e, hipMemcpyAsync(out_values, e->d_vals, sizeof(float) * (size_t)e->R * e->S,
                               hipMemcpyDeviceToHost, e->stream));
     return sync(e);
@@ -1468,6 +1543,7 @@ int collect_full_locked(scl_engine *e, int ticket, int *nn_idx, int *shift, doub
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) { q = hipEventSynchronize(ev); break; }
         }
         SCL_HIP(e, q);
+        std::atomic_thread_fence(std::memory_order_acquire);
     }
     collect_profile(e);
     e->slot_busy[ticket] = false;
@@ -1735,7 +1811,7 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
             const auto t0 = std::chrono::steady_clock::now();
             int spins = 0;
             while ((q = hipEventQuery(e->ev_chunk[c])) == hipErrorNotReady) {
-                for (int p = 0; p < 32; ++p) __builtin_ia32_pause();          // (a thread that appends meanwhile goes through the same runtime)
+                for (int p = 0; p < 32; ++p) cpu_relax();          // (a thread that appends meanwhile goes through the same runtime)
                 if ((++spins & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) return hipEventSynchronize(e->ev_chunk[c]);
             }
             return q;
@@ -1795,14 +1871,12 @@ int stream_screened_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
 
 }  // namespace
 
-int scl_detect_full_stream(scl_engine *e, const int *queries, const int *lo, const int *hi, int n_queries,
-                           int scans_per_launch, int launches_in_flight, int *nn_idx, int *shift, double *dist)
+namespace {
+
+// scl_detect_full_stream behind its locks (pass_mu held, `lk` = the database lock): also the detection half of scl_stream_from_points
+int detect_full_stream_locked(scl_engine *e, std::unique_lock<std::mutex> &lk, const int *queries, const int *lo, const int *hi, int n_queries,
+                              int scans_per_launch, int launches_in_flight, int *nn_idx, int *shift, double *dist)
 {
-    if (!e || !queries || !lo || !hi || !nn_idx || !shift || !dist || n_queries < 0) return SCL_ERR_INVALID_ARG;
-    if (e->front) return front_detect_full_stream(e, queries, lo, hi, n_queries, scans_per_launch, launches_in_flight, nn_idx, shift, dist);
-    std::lock_guard<std::mutex> pk(e->pass_mu);
-    std::unique_lock<std::mutex> lk(e->mu);
-    (void)hipSetDevice(e->device);
     for (int i = 0; i < scl_engine::kSlots; ++i)
         if (e->slot_busy[i]) return fail(e, SCL_ERR_INVALID_ARG, "detect_full_stream: collect the passes in flight first");
     if (n_queries >= 1 && n_queries <= kMaxQueryBatch && e->screen) {
@@ -1856,6 +1930,236 @@ int scl_detect_full_stream(scl_engine *e, const int *queries, const int *lo, con
         ++collected;
         if (rc) { drain(); return rc; }
     }
+    return SCL_OK;
+}
+
+}  // namespace
+
+int scl_detect_full_stream(scl_engine *e, const int *queries, const int *lo, const int *hi, int n_queries,
+                           int scans_per_launch, int launches_in_flight, int *nn_idx, int *shift, double *dist)
+{
+    if (!e || !queries || !lo || !hi || !nn_idx || !shift || !dist || n_queries < 0) return SCL_ERR_INVALID_ARG;
+    if (e->front) return front_detect_full_stream(e, queries, lo, hi, n_queries, scans_per_launch, launches_in_flight, nn_idx, shift, dist);
+    std::lock_guard<std::mutex> pk(e->pass_mu);
+    std::unique_lock<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    return detect_full_stream_locked(e, lk, queries, lo, hi, n_queries, scans_per_launch, launches_in_flight, nn_idx, shift, dist);
+}
+
+namespace {
+
+// The per-incoming-scan pipeline from raw points (DM.h:988-1025 makeDescriptors once per keyframe, then DM.h:1078 detection):
+// the scans go through in GROUPS of up to kMaxScBatch.  A group's clouds are copied into one of three device buffers on the copy
+// stream -- by DMA when the caller's buffers are pinned (scl_host_alloc / scl_host_register) -- while the group before is binned (one
+// scatter launch), ingested (one launch: every array of its database slots), and, `detect`, searched for over the whole database
+// ([0, key - NUM_EXCLUDE_RECENT), D.h:1627) by the stream form's launch group.  PCIe is the floor of this path (n x stride bytes per
+// scan against ~10 us of kernels), so the only thing that matters is that the copy engine never waits: group g + 1's copy is
+// enqueued before group g's kernels, and the host blocks only on group g's results.
+// pass_mu (detect) and `db` = e->mu are held by the caller; the database lock is given up while a group's detection waits.
+int points_pipeline_locked(scl_engine *e, std::unique_lock<std::mutex> &db, const void *const *clouds, const int *n_points, int n_scans,
+                           int stride_bytes, const int8_t *robots, const int *indexs, float *out_values,
+                           bool detect, int *nn_idx, int *shift, double *dist)
+{
+    int rc;
+    for (int i = 0; i < n_scans; ++i)
+        if ((rc = check_cloud(e, clouds[i], n_points[i], stride_bytes))) return rc;
+    if (n_scans == 0) return SCL_OK;
+    constexpr int G = kMaxScBatch;
+    const int ng = (n_scans + G - 1) / G;
+    const size_t cells = (size_t)e->R * e->S;
+    // every group's clouds at 256-byte aligned offsets of one buffer: the largest group sizes the three buffers
+    auto group_bytes = [&](int g, size_t *off) {
+        size_t at = 0;
+        for (int i = g * G; i < n_scans && i < (g + 1) * G; ++i) {
+            if (off) off[i - g * G] = at;
+            at += (((size_t)n_points[i] * (size_t)stride_bytes + 16) + 255) & ~(size_t)255;
+        }
+        return at;
+    };
+    size_t need = 0;
+    for (int g = 0; g < ng; ++g) { const size_t b = group_bytes(g, nullptr); need = b > need ? b : need; }
+    const int nbuf = ng < 3 ? ng : 3;
+    if (!e->stream_copy) SCL_HIP(e, hipStreamCreateWithFlags(&e->stream_copy, hipStreamNonBlocking));
+    for (int b = 0; b < 3; ++b) {
+        if (!e->ev_copied[b]) SCL_HIP(e, hipEventCreateWithFlags(&e->ev_copied[b], hipEventDisableTiming));
+        if (!e->ev_consumed[b]) SCL_HIP(e, hipEventCreateWithFlags(&e->ev_consumed[b], hipEventDisableTiming));
+    }
+    if (need > e->pbuf_cap || !e->d_pbuf[nbuf - 1]) {      // (nothing of an earlier call is in flight: every call ends with its last group consumed)
+        const size_t nb = need > e->pbuf_cap ? need + need / 4 + 4096 : e->pbuf_cap;
+        for (int b = 0; b < 3; ++b) {
+            if (need > e->pbuf_cap) { dev_free(e->d_pbuf[b]); e->d_pbuf[b] = nullptr; }
+            if (b < nbuf && !e->d_pbuf[b] && (rc = dev_alloc(e, &e->d_pbuf[b], nb))) { e->pbuf_cap = 0; return rc; }
+        }
+        e->pbuf_cap = nb;
+    }
+    if ((rc = ensure_capacity(e, e->n + n_scans))) return rc;     // the slots of every scan of the call: no regrow between groups
+
+    auto enqueue_copy = [&](int g) -> int {
+        const int b = g % 3;
+        size_t off[G];
+        group_bytes(g, off);
+        if (g >= 3) SCL_HIP(e, hipStreamWaitEvent(e->stream_copy, e->ev_consumed[b], 0));     // the group that was binned out of this buffer
+        for (int i = g * G; i < n_scans && i < (g + 1) * G; ++i) {
+            const size_t bytes = (size_t)n_points[i] * (size_t)stride_bytes;
+            if (bytes) SCL_HIP(e, hipMemcpyAsync(e->d_pbuf[b] + off[i - g * G], clouds[i], bytes, hipMemcpyHostToDevice, e->stream_copy));
+        }
+        SCL_HIP(e, hipEventRecord(e->ev_copied[b], e->stream_copy));
+        return SCL_OK;
+    };
+    // error path: nothing may still read the caller's buffers or write the point buffers when the call returns
+    auto bail = [&](int code) { const std::string first = e->last_error; (void)hipStreamSynchronize(e->stream_copy); (void)hipStreamSynchronize(e->stream); e->last_error = first; return code; };
+
+    if ((rc = enqueue_copy(0))) return bail(rc);
+    const int excl = e->cfg.num_exclude_recent;
+    for (int g = 0; g < ng; ++g) {
+        if (g + 1 < ng && (rc = enqueue_copy(g + 1))) return bail(rc);
+        const int b = g % 3, i0 = g * G, m = n_scans - i0 < G ? n_scans - i0 : G;
+        size_t off[G];
+        group_bytes(g, off);
+        const unsigned char *dptr[G];
+        for (int j = 0; j < m; ++j) dptr[j] = e->d_pbuf[b] + off[j];
+        if (hipStreamWaitEvent(e->stream, e->ev_copied[b], 0) != hipSuccess) return bail(fail(e, SCL_ERR_HIP, "hipStreamWaitEvent(copied)"));
+        if ((rc = group_scatter(e, dptr, n_points + i0, m, stride_bytes, e->stream))) return bail(rc);
+        if (hipEventRecord(e->ev_consumed[b], e->stream) != hipSuccess) return bail(fail(e, SCL_ERR_HIP, "hipEventRecord(consumed)"));
+        if ((rc = ensure_capacity(e, e->n + m))) return bail(rc);   // (no-op unless another thread appended while a group's detection waited)
+        const int first_slot = e->n;
+        if ((rc = group_ingest(e, m, first_slot, e->stream))) return bail(rc);
+        if (out_values && hipMemcpyAsync(out_values + (size_t)i0 * cells, e->d_vals, sizeof(float) * cells * (size_t)m, hipMemcpyDeviceToHost, e->stream) != hipSuccess)
+            return bail(fail(e, SCL_ERR_HIP, "descriptor values to the host"));
+        for (int j = 0; j < m; ++j) {
+            e->robots.push_back(robots ? robots[i0 + j] : (int8_t)0);
+            e->indexs.push_back(indexs ? indexs[i0 + j] : first_slot + j);
+        }
+        e->n += m;                                          // (stream order: whatever scores these slots is enqueued behind their ingest)
+        if (detect) {
+            int q[G], lo[G], hi[G];
+            for (int j = 0; j < m; ++j) { q[j] = first_slot + j; lo[j] = 0; hi[j] = first_slot + j - excl; if (hi[j] < 0) hi[j] = 0; }
+            if ((rc = detect_full_stream_locked(e, db, q, lo, hi, m, G, 2, nn_idx + i0, shift + i0, dist + i0))) return bail(rc);
+            if (!db.owns_lock()) db.lock();
+        } else if (g + 1 == ng || out_values) {
+            if ((rc = sync(e))) return bail(rc);            // (d_vals is rewritten by the next group)
+        }
+    }
+    if ((rc = sync(e))) return bail(rc);
+    return SCL_OK;
+}
+
+}  // namespace
+
+/* ---- pinned host buffers ----------------------------------------------------------- */
+
+int scl_host_alloc(scl_engine *e, size_t bytes, void **out)
+{
+    if (!e || !out || bytes == 0) return SCL_ERR_INVALID_ARG;
+    scl_engine *t = e->front ? front_primary(e) : e;
+    std::lock_guard<std::mutex> lk(t->mu);
+    (void)hipSetDevice(t->device);
+    void *p = nullptr;
+    SCL_HIP(e, hipHostMalloc(&p, bytes, hipHostMallocPortable));
+    t->host_allocs.push_back(p);
+    *out = p;
+    return SCL_OK;
+}
+
+int scl_host_free(scl_engine *e, void *p)
+{
+    if (!e) return SCL_ERR_INVALID_ARG;
+    if (!p) return SCL_OK;
+    scl_engine *t = e->front ? front_primary(e) : e;
+    std::lock_guard<std::mutex> lk(t->mu);
+    for (size_t i = 0; i < t->host_allocs.size(); ++i)
+        if (t->host_allocs[i] == p) {
+            t->host_allocs.erase(t->host_allocs.begin() + (long)i);
+            (void)hipSetDevice(t->device);
+            SCL_HIP(e, hipHostFree(p));
+            return SCL_OK;
+        }
+    return fail(e, SCL_ERR_INVALID_ARG, "scl_host_free: not a buffer of scl_host_alloc on this engine");
+}
+
+int scl_host_register(scl_engine *e, void *p, size_t bytes)
+{
+    if (!e || !p || bytes == 0) return SCL_ERR_INVALID_ARG;
+    scl_engine *t = e->front ? front_primary(e) : e;
+    (void)hipSetDevice(t->device);
+    SCL_HIP(e, hipHostRegister(p, bytes, hipHostRegisterPortable));
+    return SCL_OK;
+}
+
+int scl_host_unregister(scl_engine *e, void *p)
+{
+    if (!e || !p) return SCL_ERR_INVALID_ARG;
+    scl_engine *t = e->front ? front_primary(e) : e;
+    (void)hipSetDevice(t->device);
+    SCL_HIP(e, hipHostUnregister(p));
+    return SCL_OK;
+}
+
+/* ---- batches of scans from raw points ------------------------------------------------ */
+
+int scl_make_and_save_many(scl_engine *e, const void *const *clouds, const int *n_points, int count, int stride_bytes,
+                           const int8_t *robots, const int *indexs, float *out_values)
+{
+    if (!e || count < 0 || (count > 0 && (!clouds || !n_points))) return SCL_ERR_INVALID_ARG;
+    if (e->front) {                                        // sharded: keyframe by keyframe through the owners (correct, not tuned)
+        const size_t cells = (size_t)e->R * e->S;
+        for (int i = 0; i < count; ++i) {
+            const int rc = scl_make_and_save(e, clouds[i], n_points[i], stride_bytes, robots ? robots[i] : (int8_t)0,
+                                             indexs ? indexs[i] : scl_get_size(e, -1), out_values ? out_values + (size_t)i * cells : nullptr);
+            if (rc) return rc;
+        }
+        return SCL_OK;
+    }
+    std::unique_lock<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    return points_pipeline_locked(e, lk, clouds, n_points, count, stride_bytes, robots, indexs, out_values, false, nullptr, nullptr, nullptr);
+}
+
+int scl_stream_from_points(scl_engine *e, const void *const *clouds, const int *n_points, int n_scans, int stride_bytes,
+                           const int8_t *robots, const int *indexs, int *nn_idx, int *shift, double *dist, float *out_values)
+{
+    if (!e || n_scans < 0 || (n_scans > 0 && (!clouds || !n_points || !nn_idx || !shift || !dist))) return SCL_ERR_INVALID_ARG;
+    if (e->front) {
+        const size_t cells = (size_t)e->R * e->S;
+        const int excl = e->cfg.num_exclude_recent;
+        for (int i0 = 0; i0 < n_scans; i0 += kMaxScBatch) {
+            const int m = n_scans - i0 < kMaxScBatch ? n_scans - i0 : kMaxScBatch;
+            int q[kMaxScBatch], lo[kMaxScBatch], hi[kMaxScBatch];
+            for (int j = 0; j < m; ++j) {
+                const int key = scl_get_size(e, -1);
+                if (key < 0) return key;
+                const int rc = scl_make_and_save(e, clouds[i0 + j], n_points[i0 + j], stride_bytes, robots ? robots[i0 + j] : (int8_t)0,
+                                                 indexs ? indexs[i0 + j] : key, out_values ? out_values + (size_t)(i0 + j) * cells : nullptr);
+                if (rc) return rc;
+                q[j] = key; lo[j] = 0; hi[j] = key - excl < 0 ? 0 : key - excl;
+            }
+            const int rc = scl_detect_full_stream(e, q, lo, hi, m, kMaxScBatch, 2, nn_idx + i0, shift + i0, dist + i0);
+            if (rc) return rc;
+        }
+        return SCL_OK;
+    }
+    std::lock_guard<std::mutex> pk(e->pass_mu);
+    std::unique_lock<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    return points_pipeline_locked(e, lk, clouds, n_points, n_scans, stride_bytes, robots, indexs, out_values, true, nn_idx, shift, dist);
+}
+
+/* test hook: the device's atanf (xy2theta, D.h:1352-1374) over blocks of 2^24 float bit patterns, as the checksums of
+ * tests/golden/atanf_blocks.json */
+int scl_selftest_atanf_blocks(scl_engine *e, int first_block, int n_blocks, uint64_t *checksums)
+{
+    if (!e || !checksums || first_block < 0 || n_blocks < 1 || first_block + n_blocks > 256) return SCL_ERR_INVALID_ARG;
+    if (e->front) e = front_primary(e);
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    unsigned long long *d = nullptr;
+    int rc = dev_alloc(e, &d, (size_t)n_blocks);
+    if (rc) return rc;
+    hipError_t he = launch_atanf_block_checksums(first_block, n_blocks, d, e->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(checksums, d, sizeof(uint64_t) * (size_t)n_blocks, hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    dev_free(d);
+    SCL_HIP(e, he);
     return SCL_OK;
 }
 

@@ -293,13 +293,26 @@ hipError_t launch_ringkey_topk(const DbView &db, const float *qkey, int lo, int 
 hipError_t launch_ingest(const float *values, int count, int first_slot,
                          float4 *desc, double *vkey, double *norm, float *rkey, float4 *rkey4,
                          uint2 *hdesc, unsigned int *kmask, unsigned short *hkey, int hstride,
-                         int cap, int R, int S, hipStream_t stream, unsigned char *halign = nullptr);
+                         int cap, int R, int S, hipStream_t stream, unsigned char *halign = nullptr,
+                         int *tiles = nullptr, float *vals_out = nullptr);   // tiles: descriptors from the batch scatter's tiles (values may be nullptr)
 // tiled -> row-major wire format (read back)
 hipError_t launch_untile(const float4 *desc_slot, int R, int S, float *values, hipStream_t stream);
 
-// K3: makeScancontext.  tile = R*S ints (ordered-int max-z image), values = R*S floats.
-hipError_t launch_make_sc(const void *points, int n, int stride_bytes, int R, int S,
-                          double lidar_height, double max_radius, int *tile, float *values,
-                          int num_cu, hipStream_t stream);
+// K3 for a batch of scans: one scatter launch over all of them, then launch_ingest(tiles = ...) -- two launches per batch.
+constexpr int kMaxScBatch = 16;
+constexpr int kScPointsPerWorkgroup = 4096;    // points of a cloud per scatter workgroup (its private LDS tile is merged with <= R*S atomics)
+struct ScanBatch {
+    const unsigned char *points[kMaxScBatch];      // device pointers
+    int n[kMaxScBatch];
+    int first_wg[kMaxScBatch + 1];                 // filled by launch_make_sc_batch
+    int count;
+};
+hipError_t launch_make_sc_tiles_init(int *tiles, int count, int R, int S, hipStream_t stream);
+// descriptor only: tiles -> values[count][R*S] (row-major wire format), tiles back to their initial state
+hipError_t launch_make_sc_finalize(int *tiles, int count, int R, int S, float *values, hipStream_t stream);
+hipError_t launch_make_sc_batch(ScanBatch b, int stride_bytes, int R, int S, double lidar_height, double max_radius,
+                                int *tiles, int points_per_wg, int num_cu, hipStream_t stream);
+// test hook: checksums of the device's atanf over blocks of 2^24 float bit patterns (tests/golden/atanf_blocks.json)
+hipError_t launch_atanf_block_checksums(int first_block, int n_blocks, unsigned long long *d_out, hipStream_t stream);
 
 }  // namespace scl

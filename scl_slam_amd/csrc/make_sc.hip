@@ -8,11 +8,15 @@
 //
 // Descriptor construction is a max-z scatter into an R x S polar image.  Taking the
 // maximum is order independent (NaN z never wins `desc < z`, D.h:1438), so the serial
-// loop parallelises exactly: every workgroup streams a contiguous slice of the cloud
+// loop parallelises exactly: every workgroup streams a contiguous slice of one cloud
 // (one 16-byte load per point record: x,y,z,+pad), bins it with the reference's
 // mixed fp32/fp64 arithmetic, and keeps a private polar tile in LDS updated with
 // integer atomicMax on an order-preserving float encoding; tiles are merged into the
-// global image with one atomicMax per touched cell.  HBM-bound: n*16 B in, R*S*4 out.
+// scan's global image with one atomicMax per touched cell.  HBM-bound: n*16 B in,
+// R*S*4 out.  A BATCH of up to 16 scans is two launches: the scatter over all of
+// them, and ingest_kernel (one workgroup per scan), which finalizes on the way in,
+// writes every array of the database slot and leaves the tiles in their initial
+// state for the next batch (round 4: init, scatter, finalize, ingest per scan).
 #include <atomic>
 
 #include "device_common.hpp"
@@ -24,42 +28,58 @@ namespace {
 
 constexpr int kScThreads = 256;
 
-__global__ __launch_bounds__(kScThreads) void make_sc_scatter_kernel(
-    const unsigned char *points, int n, int stride, int R, int S,
-    double lidar_height, double max_radius, int *gtile)
+// The same scatter for a BATCH of scans in one launch (the keyframes of a robot team that arrive together, DM.h:988-1025 once per
+// keyframe): workgroup -> (scan, slice of its cloud), a private LDS tile per workgroup, merged into the scan's global tile with one
+// atomicMax per touched cell.  The global tiles are in their initial state when the launch starts and are put back into it by the
+// kernel that consumes them (ingest_kernel), so a batch costs two launches whatever its size.  Four points per thread are in flight.
+__global__ __launch_bounds__(kScThreads) void make_sc_batch_scatter_kernel(ScanBatch b, int stride, int R, int S,
+                                                                           double lidar_height, double max_radius, int *gtiles)
 {
     extern __shared__ int tile[];
     const int cells = R * S;
     const int init = float_to_ordered((float)kNoPoint);
     for (int i = threadIdx.x; i < cells; i += blockDim.x) tile[i] = init;
-    __syncthreads();
-
-    const int per_block = (n + gridDim.x - 1) / gridDim.x;
-    const int begin = blockIdx.x * per_block;
+    int s = 0;
+#pragma unroll
+    for (int j = 1; j < kMaxScBatch; ++j) s += (j < b.count && (int)blockIdx.x >= b.first_wg[j]) ? 1 : 0;
+    const int slices = b.first_wg[s + 1] - b.first_wg[s];
+    const int slice = (int)blockIdx.x - b.first_wg[s];
+    const int n = b.n[s];
+    const unsigned char *points = b.points[s];
+    const int per_block = (n + slices - 1) / slices;
+    const int begin = slice * per_block;
     int end = begin + per_block; end = end > n ? n : end;
-    for (int p = begin + threadIdx.x; p < end; p += blockDim.x) {
-        const unsigned char *rec = points + (size_t)p * (size_t)stride;
-        float px, py, pzraw;
-        if ((stride & 15) == 0) {                       // pcl::PointXYZI and friends: one dwordx4
-            const float4 v = *reinterpret_cast<const float4 *>(rec);
-            px = v.x; py = v.y; pzraw = v.z;
-        } else {
-            const float *f = reinterpret_cast<const float *>(rec);
-            px = f[0]; py = f[1]; pzraw = f[2];
+    __syncthreads();
+    const bool vec = (stride & 15) == 0;
+    for (int p0 = begin + (int)threadIdx.x; p0 < end; p0 += 4 * kScThreads) {
+        float px[4], py[4], pzr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * kScThreads;
+            px[u] = 0.0f; py[u] = 0.0f; pzr[u] = __int_as_float(0x7fc00000);     // past the slice: NaN z never enters a cell
+            if (p < end) {
+                const unsigned char *rec = points + (size_t)p * (size_t)stride;
+                if (vec) { const float4 v = *reinterpret_cast<const float4 *>(rec); px[u] = v.x; py[u] = v.y; pzr[u] = v.z; }
+                else { const float *f = reinterpret_cast<const float *>(rec); px[u] = f[0]; py[u] = f[1]; pzr[u] = f[2]; }
+            }
         }
-        const float pz = (float)((double)pzraw + lidar_height);        // D.h:1422
-        const float azim_range = sqrtf(px * px + py * py);             // D.h:1425
-        const float azim_angle = xy2theta(px, py);                     // D.h:1426
-        if ((double)azim_range > max_radius) continue;                 // D.h:1429
-        const int ring = max(min(R, ceil_to_int_x86(((double)azim_range / max_radius) * R)), 1);   // D.h:1434
-        const int sect = max(min(S, ceil_to_int_x86(((double)azim_angle / 360.0) * S)), 1);        // D.h:1435
-        if (pz != pz) continue;                                        // NaN never passes `<` (D.h:1438)
-        atomicMax(&tile[(ring - 1) * S + (sect - 1)], float_to_ordered(pz));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float pz = (float)((double)pzr[u] + lidar_height);            // D.h:1422
+            const float azim_range = sqrtf(px[u] * px[u] + py[u] * py[u]);       // D.h:1425
+            const float azim_angle = xy2theta(px[u], py[u]);                     // D.h:1426
+            if ((double)azim_range > max_radius) continue;                       // D.h:1429
+            const int ring = max(min(R, ceil_to_int_x86(((double)azim_range / max_radius) * R)), 1);   // D.h:1434
+            const int sect = max(min(S, ceil_to_int_x86(((double)azim_angle / 360.0) * S)), 1);        // D.h:1435
+            if (pz != pz) continue;                                              // NaN never passes `<` (D.h:1438)
+            atomicMax(&tile[(ring - 1) * S + (sect - 1)], float_to_ordered(pz));
+        }
     }
     __syncthreads();
+    int *g = gtiles + (size_t)s * cells;
     for (int i = threadIdx.x; i < cells; i += blockDim.x) {
         const int v = tile[i];
-        if (v != init) atomicMax(&gtile[i], v);
+        if (v != init) atomicMax(&g[i], v);
     }
 }
 
@@ -69,32 +89,51 @@ __global__ void make_sc_init_kernel(int *gtile, int cells)
     if (i < cells) gtile[i] = float_to_ordered((float)kNoPoint);
 }
 
-__global__ void make_sc_finalize_kernel(const int *gtile, int cells, float *values)
+// descriptor only (scl_make_descriptor: nothing is stored): tiles -> wire-format values, tiles back to their initial state
+__global__ void make_sc_finalize_kernel(int *gtile, int cells, float *values)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < cells) {
         float v = ordered_to_float(gtile[i]);
         if (v == (float)kNoPoint) v = 0.0f;                            // D.h:1450-1453
         values[i] = v;                                                 // row-major == vT order, D.h:1454
+        gtile[i] = float_to_ordered((float)kNoPoint);
     }
 }
 
 // One workgroup per descriptor.  values: [count][R*S] row-major floats.
+// tiles != nullptr: the descriptors come straight from the scatter's global tiles (ordered-int max-z images, one per workgroup):
+// finalize (D.h:1446-1456: NO_POINT -> 0, row-major floats) happens on the way into LDS, the wire-format values go to vals_out
+// (what makeAndSaveDescriptorAndKey returns, D.h:1604-1611) and the tile is put back into its initial state for the next batch.
 __global__ __launch_bounds__(256) void ingest_kernel(
     const float *values, int first_slot, float4 *desc, double *vkey, double *norm,
     float *rkey, float4 *rkey4, uint2 *hdesc, unsigned int *kmask, unsigned short *hkey, int hstride, int cap, int R, int S,
-    unsigned char *halign)
+    unsigned char *halign, int *tiles, float *vals_out)
 {
     extern __shared__ float sv[];                 // [R][S+1], then the S reciprocal norms
     const int LS = S + 1;                         // odd-ish stride: column walks hit distinct banks
     const int RG = (R + 3) >> 2;
     const int slot = first_slot + blockIdx.x;
-    const float *src = values + (size_t)blockIdx.x * R * S;
+    const float *src = values ? values + (size_t)blockIdx.x * R * S : nullptr;
     float *siv = sv + R * LS;
     double *svk = reinterpret_cast<double *>(sv + ((R * LS + S + 1) & ~1));     // [S] the sector key, for its norm
-    for (int i = threadIdx.x; i < R * S; i += blockDim.x) {
-        const int r = i / S, c = i - r * S;
-        sv[r * LS + c] = src[i];
+    if (tiles) {
+        int *t = tiles + (size_t)blockIdx.x * R * S;
+        float *vo = vals_out ? vals_out + (size_t)blockIdx.x * R * S : nullptr;
+        const int init = float_to_ordered((float)kNoPoint);
+        for (int i = threadIdx.x; i < R * S; i += blockDim.x) {
+            const int r = i / S, c = i - r * S;
+            float v = ordered_to_float(t[i]);
+            if (v == (float)kNoPoint) v = 0.0f;                        // D.h:1450-1453
+            sv[r * LS + c] = v;
+            if (vo) vo[i] = v;                                         // row-major == vT order, D.h:1454
+            t[i] = init;
+        }
+    } else {
+        for (int i = threadIdx.x; i < R * S; i += blockDim.x) {
+            const int r = i / S, c = i - r * S;
+            sv[r * LS + c] = src[i];
+        }
     }
     __syncthreads();
 
@@ -276,6 +315,26 @@ __global__ __launch_bounds__(256) void ingest_kernel(
     }
 }
 
+// test hook (tests/test_gpu_make_sc.py): the device's atanf_glibc over whole blocks of 2^24 consecutive float bit patterns, reduced to the
+// order-independent checksum of oracle/tools/atanf_exhaustive.c -- sum mod 2^64 of splitmix64((bits << 32) | result bits), NaN as 0x7fc00000
+__global__ __launch_bounds__(256) void atanf_checksum_kernel(int first_block, unsigned long long *out)
+{
+    const unsigned int blk = (unsigned int)first_block + blockIdx.y;
+    unsigned long long h = 0;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < (1u << 24); i += gridDim.x * blockDim.x) {
+        const unsigned int bits = (blk << 24) | i;
+        const float a = atanf_glibc(__int_as_float((int)bits));
+        unsigned long long z = ((unsigned long long)bits << 32) | (a != a ? 0x7fc00000u : (unsigned int)__float_as_int(a));
+        z += 0x9e3779b97f4a7c15ull;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        h += z ^ (z >> 31);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) h += __shfl_xor(h, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) atomicAdd(&out[blockIdx.y], h);
+}
+
 __global__ void untile_kernel(const float4 *dslot, int R, int S, float *values)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -288,31 +347,55 @@ __global__ void untile_kernel(const float4 *dslot, int R, int S, float *values)
 
 }  // namespace
 
-hipError_t launch_make_sc(const void *points, int n, int stride_bytes, int R, int S,
-                          double lidar_height, double max_radius, int *tile, float *values,
-                          int num_cu, hipStream_t stream)
+hipError_t launch_make_sc_finalize(int *tiles, int count, int R, int S, float *values, hipStream_t stream)
 {
-    const int cells = R * S;
-    hipLaunchKernelGGL(make_sc_init_kernel, dim3((cells + 255) / 256), dim3(256), 0, stream, tile, cells);
-    if (n > 0) {
-        // ~2k points per workgroup keeps the private-tile merge (cells atomics) amortised
-        int blocks = (n + 2047) / 2048;
-        if (blocks > 2 * num_cu) blocks = 2 * num_cu;
-        if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(make_sc_scatter_kernel, dim3(blocks), dim3(kScThreads),
-                           sizeof(int) * (size_t)cells, stream,
-                           (const unsigned char *)points, n, stride_bytes, R, S,
-                           lidar_height, max_radius, tile);
+    const int cells = R * S * count;
+    if (cells <= 0) return hipSuccess;
+    hipLaunchKernelGGL(make_sc_finalize_kernel, dim3((cells + 255) / 256), dim3(256), 0, stream, tiles, cells, values);
+    return hipGetLastError();
+}
+
+hipError_t launch_make_sc_tiles_init(int *tiles, int count, int R, int S, hipStream_t stream)
+{
+    const int cells = R * S * count;
+    if (cells <= 0) return hipSuccess;
+    hipLaunchKernelGGL(make_sc_init_kernel, dim3((cells + 255) / 256), dim3(256), 0, stream, tiles, cells);
+    return hipGetLastError();
+}
+
+// scatter of a batch of clouds (device pointers in b.points, b.n; b.first_wg is filled here) into tiles[count][R*S]
+hipError_t launch_make_sc_batch(ScanBatch b, int stride_bytes, int R, int S, double lidar_height, double max_radius,
+                                int *tiles, int points_per_wg, int num_cu, hipStream_t stream)
+{
+    if (b.count <= 0) return hipSuccess;
+    if (b.count > kMaxScBatch || points_per_wg < 256) return hipErrorInvalidValue;
+    int total = 0;
+    for (int i = 0; i < b.count; ++i) {
+        b.first_wg[i] = total;
+        if (b.n[i] < 0 || (b.n[i] > 0 && !b.points[i])) return hipErrorInvalidValue;
+        total += (b.n[i] + points_per_wg - 1) / points_per_wg;           // an empty cloud has no workgroup: its tile stays initial
     }
-    hipLaunchKernelGGL(make_sc_finalize_kernel, dim3((cells + 255) / 256), dim3(256), 0, stream,
-                       tile, cells, values);
+    for (int i = b.count; i <= kMaxScBatch; ++i) b.first_wg[i] = total;
+    if (total == 0) return hipSuccess;
+    const size_t lds = sizeof(int) * (size_t)R * S;
+    static std::atomic<bool> attr_set_dev[64];
+    int dev_ = 0; (void)hipGetDevice(&dev_);
+    std::atomic<bool> &attr_set = attr_set_dev[dev_ & 63];
+    if (!attr_set.load(std::memory_order_acquire) && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)make_sc_batch_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set.store(true, std::memory_order_release);
+    }
+    (void)num_cu;
+    hipLaunchKernelGGL(make_sc_batch_scatter_kernel, dim3(total), dim3(kScThreads), lds, stream, b, stride_bytes, R, S,
+                       lidar_height, max_radius, tiles);
     return hipGetLastError();
 }
 
 hipError_t launch_ingest(const float *values, int count, int first_slot,
                          float4 *desc, double *vkey, double *norm, float *rkey, float4 *rkey4,
                          uint2 *hdesc, unsigned int *kmask, unsigned short *hkey, int hstride,
-                         int cap, int R, int S, hipStream_t stream, unsigned char *halign)
+                         int cap, int R, int S, hipStream_t stream, unsigned char *halign, int *tiles, float *vals_out)
 {
     if (count <= 0) return hipSuccess;
     if (S > 224) return hipErrorInvalidValue;              // kmask holds 7 words of sector bits
@@ -327,7 +410,16 @@ hipError_t launch_ingest(const float *values, int count, int first_slot,
         attr_set.store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(ingest_kernel, dim3(count), dim3(256), lds, stream,
-                       values, first_slot, desc, vkey, norm, rkey, rkey4, hdesc, kmask, hkey, hstride, cap, R, S, halign);
+                       values, first_slot, desc, vkey, norm, rkey, rkey4, hdesc, kmask, hkey, hstride, cap, R, S, halign, tiles, vals_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_atanf_block_checksums(int first_block, int n_blocks, unsigned long long *d_out, hipStream_t stream)
+{
+    if (first_block < 0 || n_blocks < 1 || first_block + n_blocks > 256) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(d_out, 0, sizeof(unsigned long long) * (size_t)n_blocks, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(atanf_checksum_kernel, dim3(64, n_blocks), dim3(256), 0, stream, first_block, d_out);
     return hipGetLastError();
 }
 

@@ -31,21 +31,23 @@ constexpr int kTopkThreads = 256;
 constexpr int kTopkPerThread = 4;                       // slots per thread per workgroup
 constexpr int kTopkChunk = kTopkThreads * kTopkPerThread;
 
+template <int T>
 __device__ __forceinline__ unsigned long long block_min_u64(unsigned long long k, unsigned long long *sred)
 {
     k = wave_min_u64(k);
+    if (T == kWave) return k;                             // one wave: nothing to exchange
     const int wv = threadIdx.x / kWave;
     __syncthreads();
     if ((threadIdx.x & (kWave - 1)) == 0) sred[wv] = k;
     __syncthreads();
     unsigned long long m = sred[0];
 #pragma unroll
-    for (int w = 1; w < kTopkThreads / kWave; ++w) m = sred[w] < m ? sred[w] : m;
+    for (int w = 1; w < T / kWave; ++w) m = sred[w] < m ? sred[w] : m;
     return m;
 }
 
 // k rounds of (block min, remove).  keys[] are this thread's private keys.
-template <int NK>
+template <int T, int NK>
 __device__ __forceinline__ void extract_topk(unsigned long long (&keys)[NK], int k,
                                              unsigned long long *out, unsigned long long *sred)
 {
@@ -53,10 +55,10 @@ __device__ __forceinline__ void extract_topk(unsigned long long (&keys)[NK], int
         unsigned long long mine = keys[0];
 #pragma unroll
         for (int i = 1; i < NK; ++i) mine = keys[i] < mine ? keys[i] : mine;
-        const unsigned long long m = block_min_u64(mine, sred);
+        const unsigned long long m = block_min_u64<T>(mine, sred);
         if (threadIdx.x == 0) out[round] = m;
         if (m == kNoKey) {               // exhausted: fill the rest and stop (uniform)
-            for (int r2 = round + 1 + (int)threadIdx.x; r2 < k; r2 += blockDim.x) out[r2] = kNoKey;
+            for (int r2 = round + 1 + (int)threadIdx.x; r2 < k; r2 += T) out[r2] = kNoKey;
             break;
         }
 #pragma unroll
@@ -64,25 +66,33 @@ __device__ __forceinline__ void extract_topk(unsigned long long (&keys)[NK], int
     }
 }
 
-__global__ __launch_bounds__(kTopkThreads) void ringkey_dist_topk_kernel(
+// ONE launch: T threads x SPT slots per workgroup and chunk; every workgroup keeps its k best (srun) and writes them to `partial`; the
+// workgroup that draws the last ticket merges the lists and writes the result (round 4: a second launch of one workgroup, 4.7 us
+// behind the 8.9 us of a scan that ran on ten CUs -- 1 024 slots per workgroup).  At 10k keyframes a workgroup is ONE wave with one
+// slot per lane (155 workgroups, sixteen 16-byte loads in flight per lane), the k rounds of the selection are wave reductions without
+// a barrier, and the merge reads 155 x k keys.
+template <int T, int SPT>
+__global__ __launch_bounds__(T) void ringkey_dist_topk_kernel(
     const float4 *rkey4, int cap, const float *qkey, int R, int lo, int hi, int k,
-    float exclude_eps, unsigned long long *partial)
+    float exclude_eps, unsigned long long *partial, unsigned int *done, int *out_idx, float *out_d2)
 {
-    __shared__ unsigned long long sred[kTopkThreads / kWave];
+    __shared__ unsigned long long sred[T / kWave];
     __shared__ unsigned long long srun[kTopkMaxK];      // this workgroup's running k best
     __shared__ float sq[256];
-    for (int r = threadIdx.x; r < R; r += blockDim.x) sq[r] = qkey[r];
-    for (int i = threadIdx.x; i < kTopkMaxK; i += blockDim.x) srun[i] = kNoKey;
+    __shared__ unsigned int s_ticket;
+    for (int r = threadIdx.x; r < R; r += T) sq[r] = qkey[r];
+    for (int i = threadIdx.x; i < kTopkMaxK; i += T) srun[i] = kNoKey;
     __syncthreads();
 
+    constexpr int CHUNK = T * SPT;
     const int RGfull = R >> 2;          // full groups of four
     const int tail = R & 3;
-    const int nchunks = (hi - lo + kTopkChunk - 1) / kTopkChunk;
+    const int nchunks = (hi - lo + CHUNK - 1) / CHUNK;
     for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        unsigned long long keys[kTopkPerThread + 1];
+        unsigned long long keys[SPT + 1];
 #pragma unroll
-        for (int u = 0; u < kTopkPerThread; ++u) {
-            const int slot = lo + chunk * kTopkChunk + u * kTopkThreads + threadIdx.x;
+        for (int u = 0; u < SPT; ++u) {
+            const int slot = lo + chunk * CHUNK + u * T + threadIdx.x;
             unsigned long long key = kNoKey;
             if (slot < hi) {
                 float result = 0.0f;
@@ -108,33 +118,41 @@ __global__ __launch_bounds__(kTopkThreads) void ringkey_dist_topk_kernel(
             }
             keys[u] = key;
         }
-        keys[kTopkPerThread] = (int)threadIdx.x < k ? srun[threadIdx.x] : kNoKey;
-        extract_topk(keys, k, srun, sred);   // first write to srun happens behind a barrier
+        keys[SPT] = (int)threadIdx.x < k ? srun[threadIdx.x] : kNoKey;
+        __syncthreads();                     // srun is rewritten by the rounds below
+        extract_topk<T>(keys, k, srun, sred);
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < k; i += blockDim.x) partial[(size_t)blockIdx.x * k + i] = srun[i];
-}
-
-// merge of the per-workgroup lists; NK keys per thread (4/16/64 by list count)
-template <int NK>
-__global__ __launch_bounds__(kTopkThreads) void topk_merge_small_kernel(
-    const unsigned long long *partial, int count, int k, int *out_idx, float *out_d2)
-{
-    __shared__ unsigned long long sred[kTopkThreads / kWave];
-    __shared__ unsigned long long sout[kTopkMaxK];
-    unsigned long long keys[NK];
-#pragma unroll
-    for (int i = 0; i < NK; ++i) {
-        const int p = i * kTopkThreads + threadIdx.x;
-        keys[i] = p < count ? partial[p] : kNoKey;
-    }
-    extract_topk(keys, k, sout, sred);
+    for (int i = threadIdx.x; i < k; i += T) partial[(size_t)blockIdx.x * k + i] = srun[i];
+    __threadfence();                                       // release: this workgroup's list, before its ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int i = threadIdx.x; i < k; i += blockDim.x) {
-        const unsigned long long m = sout[i];
+    if (threadIdx.x == 0) s_ticket = atomicAdd(done, 1u);
+    __syncthreads();
+    if (s_ticket != gridDim.x - 1) return;
+    __threadfence();                                       // acquire: the other workgroups' lists
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int i = threadIdx.x; i < kTopkMaxK; i += T) srun[i] = kNoKey;
+    __syncthreads();
+    const int count = (int)gridDim.x * k;
+    for (int base = 0; base < count; base += 4 * T) {
+        unsigned long long keys[5];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = base + u * T + (int)threadIdx.x;
+            keys[u] = p < count ? __builtin_nontemporal_load(partial + p) : kNoKey;
+        }
+        keys[4] = (int)threadIdx.x < k ? srun[threadIdx.x] : kNoKey;
+        __syncthreads();
+        extract_topk<T>(keys, k, srun, sred);
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < k; i += T) {
+        const unsigned long long m = srun[i];
         if (m == kNoKey) { out_idx[i] = -1; out_d2[i] = FLT_MAX; }
         else { out_idx[i] = (int)(unsigned)(m & 0xffffffffull); out_d2[i] = __int_as_float((int)(m >> 32)); }
     }
+    if (threadIdx.x == 0) *done = 0u;                      // armed for the next launch (stream ordered)
 }
 
 __global__ void topk_fill_empty_kernel(int k, int *out_idx, float *out_d2)
@@ -175,21 +193,21 @@ hipError_t launch_ringkey_topk(const DbView &db, const float *qkey, int lo, int 
         hipLaunchKernelGGL(topk_fill_empty_kernel, dim3(1), dim3(64), 0, stream, k, out_idx, out_d2);
         return hipGetLastError();
     }
-    int blocks = (n + kTopkChunk - 1) / kTopkChunk;
-    if (blocks > kTopkMaxBlocks) blocks = kTopkMaxBlocks;    // workgroups stride over the chunks
+    // scratch: kTopkMaxBlocks * kTopkMaxK partial keys, then the ticket counter (zero between launches)
     unsigned long long *partial = scratch;
-    hipLaunchKernelGGL(ringkey_dist_topk_kernel, dim3(blocks), dim3(kTopkThreads), 0, stream,
-                       db.rkey4, db.cap, qkey, db.R, lo, hi, k, exclude_eps, partial);
-    const int count = blocks * k;
-    if (count <= 4 * kTopkThreads)
-        hipLaunchKernelGGL((topk_merge_small_kernel<4>), dim3(1), dim3(kTopkThreads), 0, stream,
-                           partial, count, k, out_idx, out_d2);
-    else if (count <= 16 * kTopkThreads)
-        hipLaunchKernelGGL((topk_merge_small_kernel<16>), dim3(1), dim3(kTopkThreads), 0, stream,
-                           partial, count, k, out_idx, out_d2);
-    else
-        hipLaunchKernelGGL((topk_merge_small_kernel<64>), dim3(1), dim3(kTopkThreads), 0, stream,
-                           partial, count, k, out_idx, out_d2);
+    unsigned int *done = reinterpret_cast<unsigned int *>(scratch + (size_t)kTopkMaxBlocks * kTopkMaxK);
+    if (k <= 4 && n <= kWave * kTopkMaxBlocks) {
+        hipLaunchKernelGGL((ringkey_dist_topk_kernel<kWave, 1>), dim3((n + kWave - 1) / kWave), dim3(kWave), 0, stream,
+                           db.rkey4, db.cap, qkey, db.R, lo, hi, k, exclude_eps, partial, done, out_idx, out_d2);
+    } else if (n <= kTopkThreads * kTopkMaxBlocks) {
+        hipLaunchKernelGGL((ringkey_dist_topk_kernel<kTopkThreads, 1>), dim3((n + kTopkThreads - 1) / kTopkThreads), dim3(kTopkThreads), 0, stream,
+                           db.rkey4, db.cap, qkey, db.R, lo, hi, k, exclude_eps, partial, done, out_idx, out_d2);
+    } else {
+        int blocks = (n + kTopkChunk - 1) / kTopkChunk;
+        if (blocks > kTopkMaxBlocks) blocks = kTopkMaxBlocks;    // workgroups stride over the chunks
+        hipLaunchKernelGGL((ringkey_dist_topk_kernel<kTopkThreads, kTopkPerThread>), dim3(blocks), dim3(kTopkThreads), 0, stream,
+                           db.rkey4, db.cap, qkey, db.R, lo, hi, k, exclude_eps, partial, done, out_idx, out_d2);
+    }
     return hipGetLastError();
 }
 

@@ -132,6 +132,13 @@ def _bind(lib):
         "scl_alignment_stats": (c_int, [P, POINTER(ctypes.c_uint64), POINTER(ctypes.c_uint64), c_int]),
         "scl_survivor_stats": (c_int, [P, POINTER(ctypes.c_uint64), POINTER(ctypes.c_uint64), POINTER(ctypes.c_uint64), c_int]),
         "scl_device_name": (c_int, [P, c_char_p, c_int]),
+        "scl_make_and_save_many": (c_int, [P, POINTER(c_void_p), ip, c_int, c_int, POINTER(c_int8), ip, fp]),
+        "scl_stream_from_points": (c_int, [P, POINTER(c_void_p), ip, c_int, c_int, POINTER(c_int8), ip, ip, ip, dp, fp]),
+        "scl_host_alloc": (c_int, [P, ctypes.c_size_t, POINTER(c_void_p)]),
+        "scl_host_free": (c_int, [P, c_void_p]),
+        "scl_host_register": (c_int, [P, c_void_p, ctypes.c_size_t]),
+        "scl_host_unregister": (c_int, [P, c_void_p]),
+        "scl_selftest_atanf_blocks": (c_int, [P, c_int, c_int, POINTER(ctypes.c_uint64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -176,6 +183,7 @@ class ScanContextEngine:
         cfg.device, cfg.initial_capacity = device, initial_capacity
         self.cfg = cfg
         self.R, self.S = num_ring, num_sector
+        self._pinned = {}
         self._h = c_void_p()
         if devices is not None:
             devs = np.ascontiguousarray(devices, dtype=np.int32)
@@ -229,6 +237,65 @@ class ScanContextEngine:
         self._check(self._lib.scl_make_and_save_filtered(self._h, a.ctypes.data_as(c_void_p), n, stride, leaf,
                                                          robot, index, _ptr(out, c_float), byref(m)), "scl_make_and_save_filtered")
         return out, m.value
+
+    def _cloud_list(self, clouds):
+        arrs, ptrs, counts, stride = [], [], [], None
+        for c in clouds:
+            a, n, st = _cloud(c)
+            if stride is None:
+                stride = st
+            elif st != stride:
+                raise ValueError("the clouds of a batch share one point stride")
+            arrs.append(a); ptrs.append(a.ctypes.data); counts.append(n)
+        m = len(arrs)
+        return arrs, (c_void_p * max(1, m))(*ptrs), np.asarray(counts, dtype=np.int32), m, (stride or 16)
+
+    def make_and_save_many(self, clouds, robots=None, indexs=None, want_values=True):
+        """scl_make_and_save_many: the clouds' descriptors appended in order; returns the wire-format values [count, R*S] (or None)"""
+        arrs, ptrs, counts, m, stride = self._cloud_list(clouds)
+        out = np.empty((m, self.R * self.S), dtype=np.float32) if want_values else None
+        rb = None if robots is None else np.ascontiguousarray(robots, dtype=np.int8)
+        ib = None if indexs is None else np.ascontiguousarray(indexs, dtype=np.int32)
+        self._check(self._lib.scl_make_and_save_many(self._h, ptrs, _ptr(counts, c_int), m, stride,
+                                                     None if rb is None else _ptr(rb, c_int8), None if ib is None else _ptr(ib, c_int),
+                                                     None if out is None else _ptr(out, c_float)), "scl_make_and_save_many")
+        return out
+
+    def stream_from_points(self, clouds, robots=None, indexs=None, want_values=False):
+        """scl_stream_from_points: per scan descriptor + append + full-database detection; returns (nn_idx, shift, dist[, values])"""
+        arrs, ptrs, counts, m, stride = self._cloud_list(clouds)
+        nn = np.empty(m, dtype=np.int32); sh = np.empty(m, dtype=np.int32); dd = np.empty(m, dtype=np.float64)
+        out = np.empty((m, self.R * self.S), dtype=np.float32) if want_values else None
+        rb = None if robots is None else np.ascontiguousarray(robots, dtype=np.int8)
+        ib = None if indexs is None else np.ascontiguousarray(indexs, dtype=np.int32)
+        self._check(self._lib.scl_stream_from_points(self._h, ptrs, _ptr(counts, c_int), m, stride,
+                                                     None if rb is None else _ptr(rb, c_int8), None if ib is None else _ptr(ib, c_int),
+                                                     _ptr(nn, c_int), _ptr(sh, c_int), _ptr(dd, c_double),
+                                                     None if out is None else _ptr(out, c_float)), "scl_stream_from_points")
+        return (nn, sh, dd, out) if want_values else (nn, sh, dd)
+
+    def host_alloc(self, shape, dtype=np.float32):
+        """a numpy array over pinned host memory (scl_host_alloc): clouds handed over from it travel by DMA.  Freed with the engine
+        (or host_free(array)); the array must not be used after that."""
+        shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = c_void_p()
+        self._check(self._lib.scl_host_alloc(self._h, max(1, nbytes), byref(p)), "scl_host_alloc")
+        buf = (ctypes.c_char * max(1, nbytes)).from_address(p.value)
+        a = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self._pinned[a.ctypes.data] = p.value
+        return a
+
+    def host_free(self, array):
+        p = self._pinned.pop(array.ctypes.data, None)
+        if p is not None:
+            self._check(self._lib.scl_host_free(self._h, c_void_p(p)), "scl_host_free")
+
+    def selftest_atanf_blocks(self, first_block, n_blocks):
+        out = np.zeros(n_blocks, dtype=np.uint64)
+        self._check(self._lib.scl_selftest_atanf_blocks(self._h, first_block, n_blocks, out.ctypes.data_as(POINTER(ctypes.c_uint64))),
+                    "scl_selftest_atanf_blocks")
+        return out
 
     def save_from_wire(self, values, robot=0, index=0):
         v = _f32(values).reshape(-1)

@@ -77,3 +77,133 @@ def test_filtered_make_and_save_equals_two_calls():
         assert np.array_equal(e1.get_ringkey(0).view(np.uint32), e2.get_ringkey(0).view(np.uint32))
         assert np.array_equal(e1.get_sectorkey(0).view(np.uint64), e2.get_sectorkey(0).view(np.uint64))
         e1.close(); e2.close()
+
+
+def test_device_atanf_equals_libm_on_all_2_to_32_inputs():
+    """xy2theta (D.h:1352-1374) calls std::atan(float): the device's restatement of glibc's atanf, evaluated on ALL 2^32 float bit
+    patterns, against the 256 block checksums of tests/golden/atanf_blocks.json -- written in the build container by
+    oracle/tools/atanf_exhaustive.c, which compares the same restatement with libm's atanf input by input (0 differences)."""
+    import json, os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "atanf_blocks.json")))
+    assert gold["differences_vs_libm"] == 0
+    eng = ScanContextEngine()
+    got = np.concatenate([eng.selftest_atanf_blocks(b, 64) for b in range(0, 256, 64)])
+    eng.close()
+    bad = [b for b in range(256) if f"{int(got[b]):016x}" != gold["blocks"][b]]
+    assert not bad, f"blocks (of 2^24 inputs, by top byte) whose device atanf differs from libm: {[hex(b) for b in bad]}"
+
+
+def _ragged_clouds(sizes, stride, seed):
+    return [np.ascontiguousarray(synth_scan(n, seed=seed + 31 * i, stride_floats=stride)) if n else np.zeros((0, stride), np.float32)
+            for i, n in enumerate(sizes)]
+
+
+@pytest.mark.parametrize("R,S,sizes,stride", [
+    (64, 120, [120000, 0, 1, 77777, 4096, 4097, 15, 120000, 30000, 0, 5, 8191, 8192, 8193, 60000, 99999], 8),   # one full group, ragged, empty clouds
+    (20, 60, [15000] * 3 + [0, 9000], 4),                                                                      # a short group, 16-byte records
+    (80, 180, [240000, 100, 0, 180000] + [20000] * 33, 8),                                                     # three groups (16 + 16 + 5)
+    (64, 120, [5000] * 40, 3),                                                                                 # 12-byte records (scalar loads)
+])
+def test_make_and_save_many_equals_the_checker_scan_by_scan(R, S, sizes, stride):
+    """scl_make_and_save_many: groups of up to 16 clouds, two launches per group.  Every scan's wire values, ring key, sector key
+    and (robot, index) equal the checker's makeAndSaveDescriptorAndKey (D.h:1604-1611) bit for bit, and the database is the one
+    scan-by-scan calls build (a second engine)."""
+    clouds = _ragged_clouds(sizes, stride, seed=R + len(sizes))
+    eng = ScanContextEngine(num_ring=R, num_sector=S, initial_capacity=8)              # grows inside the call
+    one = ScanContextEngine(num_ring=R, num_sector=S)
+    db = ob.OracleDB(ob.make_config(R=R, S=S))
+    robots = [(i * 3) % 5 for i in range(len(sizes))]; indexs = [100 + 2 * i for i in range(len(sizes))]
+    vals = eng.make_and_save_many(clouds, robots, indexs)
+    assert eng.get_size() == len(sizes)
+    for i, c in enumerate(clouds):
+        v_cpu = db.make_and_save(c, robots[i], indexs[i])
+        v_one = one.make_and_save(c, robots[i], indexs[i])
+        assert np.array_equal(vals[i].view(np.uint32), v_cpu.view(np.uint32)), i
+        assert np.array_equal(v_one.view(np.uint32), v_cpu.view(np.uint32)), i
+        assert np.array_equal(eng.get_ringkey(i).view(np.uint32), db.ringkey(i).view(np.uint32)), i
+        assert np.array_equal(eng.get_sectorkey(i).view(np.uint64), one.get_sectorkey(i).view(np.uint64)), i
+        assert eng.get_index(i) == (robots[i], indexs[i]) == db.get_index(i)
+    # the derived images the screening pass reads were written by the same launch: a full-database pass agrees with the scan-by-scan engine
+    if (R, S) in ((64, 120), (80, 180)) and len(sizes) >= 16:
+        q = len(sizes) - 1
+        assert eng.detect_full_range(q, 0, q - 2) == one.detect_full_range(q, 0, q - 2)
+    # a second call appends behind the first (tiles were left in their initial state)
+    vals2 = eng.make_and_save_many(clouds[:3], want_values=True)
+    for i in range(3):
+        assert np.array_equal(vals2[i].view(np.uint32), vals[i].view(np.uint32))
+    assert eng.get_size() == len(sizes) + 3 and eng.get_index(len(sizes) + 1) == (0, len(sizes) + 1)
+    eng.close(); one.close()
+
+
+def test_make_and_save_many_from_pinned_buffers_and_empty_batch():
+    R, S = 64, 120
+    eng = ScanContextEngine(num_ring=R, num_sector=S)
+    db = ob.OracleDB(ob.make_config(R=R, S=S))
+    assert eng.make_and_save_many([]).shape == (0, R * S) and eng.get_size() == 0
+    sizes = [50000, 120000, 7]
+    src = _ragged_clouds(sizes, 4, seed=9)
+    pinned = []
+    for c in src:
+        a = eng.host_alloc(c.shape if c.size else (1, 4)); a[:c.shape[0]] = c
+        pinned.append(a[:c.shape[0]])
+    vals = eng.make_and_save_many(pinned, want_values=True)
+    for i, c in enumerate(src):
+        assert np.array_equal(vals[i].view(np.uint32), db.make_and_save(c, 0, i).view(np.uint32))
+    eng.close()
+
+
+def test_bad_clouds_are_status_codes_and_leave_the_engine_usable():
+    from scl_slam_amd import SclError
+    R, S = 20, 60
+    eng = ScanContextEngine(num_ring=R, num_sector=S)
+    good = synth_scan(3000, seed=1)
+    lib, h = eng._lib, eng._h
+    import ctypes
+    ptrs = (ctypes.c_void_p * 2)(good.ctypes.data, None)
+    counts = np.array([3000, 5], dtype=np.int32)
+    rc = lib.scl_make_and_save_many(h, ptrs, counts.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), 2, 32, None, None, None)
+    assert rc == -1 and eng.get_size() == 0                                            # SCL_ERR_INVALID_ARG: null cloud with points
+    rc = lib.scl_make_and_save_many(h, ptrs, counts.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), 1, 10, None, None, None)
+    assert rc == -1                                                                    # stride below 12 bytes
+    v = eng.make_and_save_many([good])
+    assert np.array_equal(v[0], ob.make_scancontext(ob.make_config(R=R, S=S), good))
+    eng.close()
+
+
+@pytest.mark.parametrize("R,S,n0,n_scans,excl", [(64, 120, 300, 37, 100), (80, 180, 150, 20, 30), (20, 60, 130, 18, 100), (64, 120, 0, 20, 5)])
+def test_stream_from_points_equals_scan_by_scan_calls_and_the_checker(R, S, n0, n_scans, excl):
+    """scl_stream_from_points = per scan makeAndSaveDescriptorAndKey (DM.h:1002) + full-database detection over [0, key - exclude)
+    (D.h:1627): winners / shifts / fp64 distances equal scl_make_and_save + scl_detect_full_range on a second engine AND the checker's
+    detect_full, bit for bit; revisits of earlier scans (the same cloud rotated about z by whole sectors) are found at distance ~0."""
+    from scl_slam_amd.synth import synth_descriptors
+    base = synth_descriptors(n0, R, S, seed=R + n0) if n0 else np.zeros((0, R, S), np.float32)
+    eng = ScanContextEngine(num_ring=R, num_sector=S, num_exclude_recent=excl, initial_capacity=max(8, n0))
+    one = ScanContextEngine(num_ring=R, num_sector=S, num_exclude_recent=excl)
+    db = ob.OracleDB(ob.make_config(R=R, S=S, exclude_recent=excl))
+    if n0:
+        eng.save_bulk(base); one.save_bulk(base); db.save_bulk(base)
+    clouds = []
+    for i in range(n_scans):
+        c = synth_scan(6000 + 500 * (i % 7), seed=1000 + i)
+        if i >= excl + 2 and i % 3 == 0:                                   # a revisit of scan i - excl - 2, turned by 7 sectors
+            src = clouds[i - excl - 2].copy()
+            a = np.deg2rad(7 * 360.0 / S)
+            x, y = src[:, 0].astype(np.float64), src[:, 1].astype(np.float64)
+            src[:, 0] = (x * np.cos(a) - y * np.sin(a)).astype(np.float32); src[:, 1] = (x * np.sin(a) + y * np.cos(a)).astype(np.float32)
+            c = src
+        clouds.append(c)
+    nn, sh, dd, vals = eng.stream_from_points(clouds, want_values=True)
+    for i, c in enumerate(clouds):
+        key = n0 + i
+        v1 = one.make_and_save(c, 0, key)
+        vc = db.make_and_save(c, 0, key)
+        assert np.array_equal(vals[i].view(np.uint32), vc.view(np.uint32)) and np.array_equal(v1.view(np.uint32), vc.view(np.uint32))
+        g = one.detect_full_range(key, 0, max(0, key - excl))
+        o_lid, o_nn, o_sh, o_dist = db.detect_full(key)
+        assert (int(nn[i]), int(sh[i])) == (g[0], g[1]) and np.float64(dd[i]).view(np.uint64) == np.float64(g[2]).view(np.uint64), (i, nn[i], sh[i], dd[i], g)
+        if o_nn >= 0:
+            assert (int(nn[i]), int(sh[i])) == (o_nn, o_sh) and np.float64(dd[i]).view(np.uint64) == np.float64(o_dist).view(np.uint64), (i, o_nn, o_sh, o_dist)
+        else:
+            assert nn[i] == -1
+    assert eng.get_size() == n0 + n_scans
+    eng.close(); one.close()

@@ -73,3 +73,25 @@ def test_topk_self_match_exclusion_switch():
     o_idx, o_d2, o_found = ob.knn(keys, keys[123], 3, exclude_eps=float(np.finfo(np.float32).eps))
     assert 123 not in idx and list(idx) == list(o_idx)
     eng.close()
+
+
+def test_alternating_k_never_returns_the_previous_calls_block():
+    """The k candidates leave as one block in pinned memory with a polled sequence word BEHIND the block, at an offset that depends on
+    k: a call with k = 20 leaves idx[] / d2[] data where a k = 3 (byte 64) or k = 1 (byte 32) call polls.  The word is cleared before
+    every launch, so a stale keyframe index that happens to equal the next sequence number cannot end the poll early."""
+    from scl_slam_amd.synth import synth_descriptors
+    R, S, n = 20, 60, 700
+    descs = synth_descriptors(n, R, S, seed=77, revisit_frac=0.05)
+    eng = ScanContextEngine(num_ring=R, num_sector=S, num_candidates=3, initial_capacity=1024)
+    db = ob.OracleDB(ob.make_config(R=R, S=S))
+    eng.save_bulk(descs); db.save_bulk(descs)
+    keys = db.ringkeys()
+    for rep in range(120):
+        for k in (20, 3, 9, 1, 16, 3):
+            q = 300 + (rep * 7 + k) % 390
+            idx, d2, dist, shift, found = eng.topk_with_distance(q, 0, q - 100, k)
+            o_idx, o_d2, o_found = ob.knn(keys[:q - 100], keys[q], k)
+            assert found == o_found and list(idx[:found]) == [int(x) for x in o_idx[:o_found]], (rep, k, q)
+            o_dist, o_shift = db.distance_batch(q, cand=np.asarray(idx[:found], dtype=np.int32))
+            assert np.array_equal(dist[:found].view(np.uint64), o_dist.view(np.uint64)) and np.array_equal(shift[:found], o_shift), (rep, k, q)
+    eng.close()
