@@ -34,8 +34,36 @@ tests/cpp/adapter_check: tests/cpp/adapter_check.cpp tests/cpp/pcl_types_for_ada
 tests/cpp/libmock_rccl.so: tests/cpp/mock_rccl.cpp
 	$(HIPCC) -x hip --offload-arch=$(ARCH) -O2 -std=c++17 -fPIC -shared -o $@ $<
 
+# Sanitizers + fuzzing over everything that builds without a GPU (log: profiles/rNN/sanitize.txt):
+#   1. the CPU checker under ASan + UBSan: the whole `-m "not gpu"` suite against oracle/liboracle_asan.so
+#   2. the checker's worker pool under TSan (oracle/tools/tsan_pool_driver)
+#   3. libFuzzer + ASan + UBSan over the host-only parsers of untrusted bytes: the ROS wire decoders (messages.hip, compiled as host
+#      C++) and the database dump parser (db_file.hpp) -- FUZZ_SECONDS (600) of mutation from tests/cpp/fuzz_seeds.py's corpus
+CLANGXX ?= /opt/rocm/lib/llvm/bin/clang++
+FUZZ_SECONDS ?= 600
+SAN_LOG ?= profiles/r05/sanitize.txt
+tests/cpp/fuzz_host: tests/cpp/fuzz_host.cpp $(CSRC)/messages.hip $(CSRC)/db_file.hpp include/scl_messages.h include/scl_engine.h
+	$(CLANGXX) -std=c++17 -O1 -g -fno-omit-frame-pointer -fsanitize=fuzzer,address,undefined -fno-sanitize-recover=undefined \
+	    -Iinclude -I$(CSRC) -o $@ tests/cpp/fuzz_host.cpp -x c++ $(CSRC)/messages.hip
+
+sanitize: tests/cpp/fuzz_host
+	$(MAKE) -C oracle liboracle_asan.so tools/tsan_pool_driver
+	@mkdir -p $(dir $(SAN_LOG)) /tmp/scl_fuzz_corpus
+	@echo "== make sanitize: $$(date -u +%Y-%m-%dT%H:%MZ), $$(gcc --version | head -1), $$($(CLANGXX) --version | head -1)" > $(SAN_LOG)
+	@echo "== 1. CPU tests against oracle/liboracle_asan.so (-fsanitize=address,undefined, libasan preloaded into python)" >> $(SAN_LOG)
+	SCL_ORACLE_LIB=oracle/liboracle_asan.so LD_PRELOAD=$$(gcc -print-file-name=libasan.so):$$(gcc -print-file-name=libubsan.so) \
+	    ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
+	    python -m pytest tests -x -q -m "not gpu" -p no:cacheprovider 2>&1 | tail -4 >> $(SAN_LOG)
+	@echo "== 2. worker pool under ThreadSanitizer (oracle/tools/tsan_pool_driver)" >> $(SAN_LOG)
+	TSAN_OPTIONS=halt_on_error=1 oracle/tools/tsan_pool_driver >> $(SAN_LOG) 2>&1
+	@echo "== 3. libFuzzer + ASan + UBSan: wire decoders (messages.hip) and dump parser (db_file.hpp), $(FUZZ_SECONDS) s" >> $(SAN_LOG)
+	python tests/cpp/fuzz_seeds.py /tmp/scl_fuzz_corpus
+	tests/cpp/fuzz_host -max_total_time=$(FUZZ_SECONDS) -max_len=4096 -print_final_stats=1 /tmp/scl_fuzz_corpus 2>&1 | grep -E "stat::|ERROR|SUMMARY|Done|cov:" | tail -12 >> $(SAN_LOG)
+	@echo "== done: no finding above means none was reported (every tool stops at its first)" >> $(SAN_LOG)
+	@cat $(SAN_LOG)
+
 clean:
 	rm -f $(OBJS) $(LIBDIR)/libscl_engine.so tests/cpp/adapter_check tests/cpp/libmock_rccl.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean sanitize

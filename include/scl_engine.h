@@ -396,6 +396,9 @@ int  scl_alignment_stats(scl_engine *e, uint64_t *pairs, uint64_t *fallbacks, in
  * pointer may be NULL; reset != 0 clears the counters. */
 int  scl_survivor_stats(scl_engine *e, uint64_t *queries, uint64_t *survivors, uint64_t *max_survivors, int reset);
 int  scl_device_name(const scl_engine *e, char *buf, int buflen);
+/* GB/s of `reps` copies of `bytes` from pinned host memory to the device, one after the other on the engine's copy stream (HIP events):
+ * the link's rate, i.e. the floor of scl_stream_from_points per byte of point cloud. */
+int  scl_host_copy_rate(scl_engine *e, size_t bytes, int reps, double *gbytes_per_s);
 /* Self test of the device's float atan -- xy2theta (D.h:1352-1374) calls std::atan(float), here glibc's atanf restated in fp32
  * (csrc/device_common.hpp) --: checksums[b] = sum mod 2^64 over the 2^24 float bit patterns of block first_block + b of
  * splitmix64((bits << 32) | result bits), NaN results counted as 0x7fc00000.  tests/golden/atanf_blocks.json holds the 256 values

@@ -32,38 +32,40 @@ __device__ __forceinline__ float ordered_to_float(int o)
 // (-ffp-contract=off), IEEE division (-fhip-fp32-correctly-rounded-divide-sqrt).  The same restatement in oracle/sc_oracle.c
 // equals libm's atanf on all 2^32 inputs in the build container (oracle/tools/atanf_exhaustive.c); this copy is checked on the
 // device against the block checksums of tests/golden/atanf_blocks.json (tests/test_gpu_make_sc.py).  Constants by bit pattern.
+//
+// Written WITHOUT divergent branches: the five intervals of the argument reduction differ only in the operands of ONE division
+// (id -1: x / 1 = x exactly), so the interval selects numerator, denominator and the hi / lo constants, every lane divides once and
+// evaluates the one polynomial, and the special ranges (|x| >= 2^25, NaN, |x| < 2^-29) are selected at the end.  The branchy form cost
+// the descriptor scatter a division per interval AND per quadrant of xy2theta under divergence (an IEEE fp32 division is ~15
+// instructions): the kernel was bound by vector instructions, not by HBM.
 __device__ __forceinline__ float atanf_glibc(float x)
 {
     const unsigned int hx = (unsigned int)__float_as_int(x), ix = hx & 0x7fffffffu;
-    float hi = 0.0f, lo = 0.0f;
-    int id;
-    if (ix >= 0x4c000000u) {                              // |x| >= 2^25
-        if (ix > 0x7f800000u) return x + x;               // NaN
-        const float r = __int_as_float(0x3fc90fda) + __int_as_float(0x33a22168);
-        return (hx >> 31) ? -r : r;
-    }
-    if (ix < 0x3ee00000u) {                               // |x| < 0.4375
-        if (ix < 0x31000000u) return x;                   // |x| < 2^-29
-        id = -1;
-    } else {
-        x = fabsf(x);
-        if (ix < 0x3f980000u) {                           // |x| < 1.1875
-            if (ix < 0x3f300000u) { id = 0; hi = __int_as_float(0x3eed6338); lo = __int_as_float(0x31ac3769); x = (2.0f * x - 1.0f) / (2.0f + x); }
-            else                  { id = 1; hi = __int_as_float(0x3f490fda); lo = __int_as_float(0x33222168); x = (x - 1.0f) / (x + 1.0f); }
-        } else {
-            if (ix < 0x401c0000u) { id = 2; hi = __int_as_float(0x3f7b985e); lo = __int_as_float(0x33140fb4); x = (x - 1.5f) / (1.0f + 1.5f * x); }
-            else                  { id = 3; hi = __int_as_float(0x3fc90fda); lo = __int_as_float(0x33a22168); x = -1.0f / x; }
-        }
-    }
-    const float z = x * x;
+    const float ax = fabsf(x);
+    const bool small = ix < 0x3ee00000u;                  // |x| < 0.4375: no reduction, sign kept
+    const bool i0 = ix < 0x3f300000u, i1 = ix < 0x3f980000u, i2 = ix < 0x401c0000u;
+    // numerator / denominator of the reduced argument (id 0: (2x-1)/(2+x), 1: (x-1)/(x+1), 2: (x-1.5)/(1+1.5x), 3: -1/x)
+    const float num = small ? x : (i0 ? 2.0f * ax - 1.0f : (i1 ? ax - 1.0f : (i2 ? ax - 1.5f : -1.0f)));
+    const float den = small ? 1.0f : (i0 ? 2.0f + ax : (i1 ? ax + 1.0f : (i2 ? 1.0f + 1.5f * ax : ax)));
+    const float hi = __int_as_float(i0 ? 0x3eed6338 : (i1 ? 0x3f490fda : (i2 ? 0x3f7b985e : 0x3fc90fda)));
+    const float lo = __int_as_float(i0 ? 0x31ac3769 : (i1 ? 0x33222168 : (i2 ? 0x33140fb4 : 0x33a22168)));
+    const float t = num / den;
+    const float z = t * t;
     const float w = z * z;
     const float s1 = z * (__int_as_float(0x3eaaaaab) + w * (__int_as_float(0x3e124925) + w * (__int_as_float(0x3dba2e6e) +
                      w * (__int_as_float(0x3d886b35) + w * (__int_as_float(0x3d4bda59) + w * __int_as_float(0x3c8569d7))))));
     const float s2 = w * (__int_as_float(0xbe4ccccd) + w * (__int_as_float(0xbde38e38) + w * (__int_as_float(0xbd9d8795) +
                      w * (__int_as_float(0xbd6ef16b) + w * __int_as_float(0xbd15a221)))));
-    if (id < 0) return x - x * (s1 + s2);
-    const float r = hi - ((x * (s1 + s2) - lo) - x);
-    return (hx >> 31) ? -r : r;
+    const float p = t * (s1 + s2);
+    const float r_small = t - p;                          // id < 0: x - x*(s1+s2)
+    const float r_red = hi - ((p - lo) - t);
+    float r = small ? r_small : ((hx >> 31) ? -r_red : r_red);
+    if (ix < 0x31000000u) r = x;                          // |x| < 2^-29
+    if (ix >= 0x4c000000u) {                              // |x| >= 2^25 (inf included): +-(hi3 + lo3); NaN: x + x
+        const float big = __int_as_float(0x3fc90fda) + __int_as_float(0x33a22168);
+        r = ix > 0x7f800000u ? x + x : ((hx >> 31) ? -big : big);
+    }
+    return r;
 }
 
 // ---- fixed fp64 atan (x >= 0) behind LiDAR-Iris's atan2 (iris.hip; rounds 1-4 also used it for xy2theta): identical operation
@@ -101,15 +103,22 @@ __device__ __forceinline__ double atan_pos(double x)
 }
 
 
-// xy2theta, D.h:1352-1374
+// xy2theta, D.h:1352-1374.  The four quadrant branches of the reference differ in the operands of the division (y / x, y / (-x), y / x,
+// (-y) / x) and in how the angle is placed (k a, 180 - k a, 180 + k a, 360 - k a): operands and placement are selected, every lane
+// divides once.  The conditions are the reference's own (x = -0.0 counts as x >= 0: y / -0.0 = -inf and the angle is -90 or 450 --
+// kept); a NaN coordinate fails all four and yields NaN (the reference falls off the end).
 __device__ __forceinline__ float xy2theta(float x, float y)
 {
     const double k = 180.0 / 3.14159265358979323846;
-    if ((x >= 0) & (y >= 0)) return (float)(k * (double)atanf_glibc(y / x));
-    if ((x < 0) & (y >= 0))  return (float)(180.0 - (k * (double)atanf_glibc(y / (-x))));
-    if ((x < 0) & (y < 0))   return (float)(180.0 + (k * (double)atanf_glibc(y / x)));
-    if ((x >= 0) & (y < 0))  return (float)(360.0 - (k * (double)atanf_glibc((-y) / x)));
-    return __int_as_float(0x7fc00000);
+    const bool xp = x >= 0, xn = x < 0, yp = y >= 0, yn = y < 0;
+    const bool q2 = xn & yp, q3 = xn & yn, q4 = xp & yn;
+    const float a = atanf_glibc((q4 ? -y : y) / (q2 ? -x : x));
+    const double ka = k * (double)a;
+    double r = ka;                                        // x >= 0, y >= 0
+    r = q2 ? 180.0 - ka : r;
+    r = q3 ? 180.0 + ka : r;
+    r = q4 ? 360.0 - ka : r;
+    return ((xp | xn) & (yp | yn)) ? (float)r : __int_as_float(0x7fc00000);
 }
 
 // int(ceil(v)) the way the reference's x86-64 build evaluates it (NaN -> INT_MIN)

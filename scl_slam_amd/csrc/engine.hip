@@ -20,6 +20,7 @@
 #include <thread>
 #include <vector>
 
+#include "db_file.hpp"
 #include "engine_internal.hpp"
 
 using namespace scl;
@@ -407,6 +408,8 @@ int launch_topk(scl_engine *e, const QueryView &q, int lo, int hi, int k, float 
 // top-k in [lo,hi) followed by the SC distance of those k candidates; enqueue puts the launches and the copies
 // into pinned memory on the engine's stream, finish waits for them and unpacks (the sharded front enqueues on
 // every device before it waits on any).
+// The ring-key scan leaves per-workgroup lists; the kernel that consumes the k nearest merges them in its prologue
+// (topk_merge.hpp): the candidates' kernel of the reference-faithful detection, or the merge + pack kernel of the bare search.
 int topk_enqueue_locked(scl_engine *e, int query, int lo, int hi, int k, float eps, bool want_dist, bool *have_dist)
 {
     if (k <= 0 || k > kTopkMaxK) return fail(e, SCL_ERR_INVALID_ARG, "k out of range (1..64)");
@@ -416,28 +419,40 @@ int topk_enqueue_locked(scl_engine *e, int query, int lo, int hi, int k, float e
     if (lo < 0) lo = 0;
     if (hi > e->n) hi = e->n;
     if ((rc = ensure_pairs(e, (size_t)k))) return rc;
-    if ((rc = launch_topk(e, q, lo, hi, k, eps))) return rc;
+    int n_lists = 0;
+    {
+        ProfScope ps(e, P_TOPK);
+        SCL_HIP(e, launch_ringkey_lists(db_view(e), q.rkey, lo, hi, k, eps, e->d_topk_scratch, &n_lists, e->stream));
+    }
     *have_dist = hi > lo && want_dist;
     const size_t need = cand_seq_offset(k) + 16;
     if ((rc = ensure_pinned(e, need))) return rc;
     e->pinned_seq = 0;
     if (*have_dist && k <= 16 && sc_cand_exact_supported(db_view(e), e->SR) && !scl_lab_int("SCL_CAND_EXACT_OFF", 0)) {
-        // the reference-faithful detection's k (3) candidates: one workgroup aligns and scores them and writes the block (sc_masked.hip)
+        // the reference-faithful detection's k (3) candidates: one workgroup merges the scan's lists, aligns and scores the candidates
+        // and writes the block (sc_masked.hip)
+        const bool fused = n_lists * k <= kCandMergeMaxKeys;
+        if (!fused) SCL_HIP(e, launch_topk_merge(e->d_topk_scratch, n_lists, k, e->d_topk_idx, e->d_topk_d2, nullptr, e->stream));
         ProfScope ps(e, P_SC);
         if (++e->out_seq == 0) ++e->out_seq;
         e->pinned_seq = e->out_seq;
         // the word sits at an offset that depends on k: a call with a larger k left idx[] / d2[] data there -- cleared before the launch
         *reinterpret_cast<volatile unsigned int *>(static_cast<char *>(e->h_pinned) + cand_seq_offset(k)) = 0u;
         std::atomic_thread_fence(std::memory_order_release);
-        SCL_HIP(e, launch_sc_cand_exact(db_view(e), q, e->SR, k, e->d_topk_idx, e->d_topk_d2, e->h_pinned, e->stream, e->pinned_seq));
+        SCL_HIP(e, launch_sc_cand_exact(db_view(e), q, e->SR, k, e->d_topk_idx, e->d_topk_d2, e->h_pinned, e->stream, e->pinned_seq,
+                                        fused ? e->d_topk_scratch : nullptr, n_lists, e->d_topk_idx, e->d_topk_d2));
         if (ps.active()) e->prof.sc_distance_pairs += (uint64_t)k;
         return SCL_OK;
     }
     if (*have_dist) {
+        SCL_HIP(e, launch_topk_merge(e->d_topk_scratch, n_lists, k, e->d_topk_idx, e->d_topk_d2, nullptr, e->stream));
         if ((rc = launch_distance(e, q, e->d_topk_idx, 0, k))) return rc;
+        // the k results travel as ONE block written by a kernel into pinned memory (four copies of a few bytes cost more than the search)
+        SCL_HIP(e, launch_topk_pack(e->d_topk_idx, e->d_topk_d2, e->d_dist, e->d_shift, k, true, e->h_pinned, e->stream));
+        return SCL_OK;
     }
-    // the k results travel as ONE block written by a kernel into pinned memory (four copies of a few bytes cost more than the search)
-    SCL_HIP(e, launch_topk_pack(e->d_topk_idx, e->d_topk_d2, e->d_dist, e->d_shift, k, *have_dist, e->h_pinned, e->stream));
+    // the bare search: merge and block in one launch
+    SCL_HIP(e, launch_topk_merge(e->d_topk_scratch, n_lists, k, e->d_topk_idx, e->d_topk_d2, e->h_pinned, e->stream));
     return SCL_OK;
 }
 
@@ -670,9 +685,11 @@ int scl_destroy(scl_engine *e)
     for (int b = 0; b < 3; ++b) {
         dev_free(e->d_pbuf[b]);
         if (e->ev_copied[b]) (void)hipEventDestroy(e->ev_copied[b]);
+        if (e->ev_copied2[b]) (void)hipEventDestroy(e->ev_copied2[b]);
         if (e->ev_consumed[b]) (void)hipEventDestroy(e->ev_consumed[b]);
     }
     if (e->stream_copy) { (void)hipStreamSynchronize(e->stream_copy); (void)hipStreamDestroy(e->stream_copy); }
+    if (e->stream_copy2) { (void)hipStreamSynchronize(e->stream_copy2); (void)hipStreamDestroy(e->stream_copy2); }
     for (void *hp : e->host_allocs) (void)hipHostFree(hp);
     dev_free(e->d_dist); dev_free(e->d_shift); dev_free(e->d_cand); dev_free(e->d_ring_d2);
     dev_free(e->d_approx); dev_free(e->d_starts); dev_free(e->d_surv); dev_free(e->d_nsurv); dev_free(e->d_tmin); dev_free(e->d_part);
@@ -730,7 +747,7 @@ int scl_make_and_save(scl_engine *e, const void *points, int n_points, int strid
     if (out_values)
         SCL_HIP(e, hipMemcpyAsync(out_values, e->d_vals, sizeof(float) * (size_t)e->R * e->S,
                                   hipMemcpyDeviceToHost, e->stream));
-    if ((rc = sync(e))) return rc;
+    if ((rc = sync_short(e))) return rc;                    // (tens of microseconds of device time: polled, not slept on)
     return append_meta(e, robot, index);
 }
 
@@ -1980,8 +1997,13 @@ int points_pipeline_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
     for (int g = 0; g < ng; ++g) { const size_t b = group_bytes(g, nullptr); need = b > need ? b : need; }
     const int nbuf = ng < 3 ? ng : 3;
     if (!e->stream_copy) SCL_HIP(e, hipStreamCreateWithFlags(&e->stream_copy, hipStreamNonBlocking));
+    // a second copy stream: a cloud is one copy of a megabyte or two, and the copies of ONE stream run strictly one after the other,
+    // each with its own start-up; two streams keep a second DMA engine's copy in flight while the first one's is being set up
+    const int ncs = scl_lab_int("SCL_COPY_STREAMS", 2);
+    if (ncs > 1 && !e->stream_copy2) SCL_HIP(e, hipStreamCreateWithFlags(&e->stream_copy2, hipStreamNonBlocking));
     for (int b = 0; b < 3; ++b) {
         if (!e->ev_copied[b]) SCL_HIP(e, hipEventCreateWithFlags(&e->ev_copied[b], hipEventDisableTiming));
+        if (!e->ev_copied2[b]) SCL_HIP(e, hipEventCreateWithFlags(&e->ev_copied2[b], hipEventDisableTiming));
         if (!e->ev_consumed[b]) SCL_HIP(e, hipEventCreateWithFlags(&e->ev_consumed[b], hipEventDisableTiming));
     }
     if (need > e->pbuf_cap || !e->d_pbuf[nbuf - 1]) {      // (nothing of an earlier call is in flight: every call ends with its last group consumed)
@@ -1998,16 +2020,28 @@ int points_pipeline_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
         const int b = g % 3;
         size_t off[G];
         group_bytes(g, off);
-        if (g >= 3) SCL_HIP(e, hipStreamWaitEvent(e->stream_copy, e->ev_consumed[b], 0));     // the group that was binned out of this buffer
+        if (g >= 3) {                                        // the group that was binned out of this buffer
+            SCL_HIP(e, hipStreamWaitEvent(e->stream_copy, e->ev_consumed[b], 0));
+            if (ncs > 1) SCL_HIP(e, hipStreamWaitEvent(e->stream_copy2, e->ev_consumed[b], 0));
+        }
         for (int i = g * G; i < n_scans && i < (g + 1) * G; ++i) {
             const size_t bytes = (size_t)n_points[i] * (size_t)stride_bytes;
-            if (bytes) SCL_HIP(e, hipMemcpyAsync(e->d_pbuf[b] + off[i - g * G], clouds[i], bytes, hipMemcpyHostToDevice, e->stream_copy));
+            hipStream_t cs = (ncs > 1 && (i & 1)) ? e->stream_copy2 : e->stream_copy;
+            if (bytes) SCL_HIP(e, hipMemcpyAsync(e->d_pbuf[b] + off[i - g * G], clouds[i], bytes, hipMemcpyHostToDevice, cs));
         }
         SCL_HIP(e, hipEventRecord(e->ev_copied[b], e->stream_copy));
+        if (ncs > 1) SCL_HIP(e, hipEventRecord(e->ev_copied2[b], e->stream_copy2));
         return SCL_OK;
     };
     // error path: nothing may still read the caller's buffers or write the point buffers when the call returns
-    auto bail = [&](int code) { const std::string first = e->last_error; (void)hipStreamSynchronize(e->stream_copy); (void)hipStreamSynchronize(e->stream); e->last_error = first; return code; };
+    auto bail = [&](int code) {
+        const std::string first = e->last_error;
+        (void)hipStreamSynchronize(e->stream_copy);
+        if (e->stream_copy2) (void)hipStreamSynchronize(e->stream_copy2);
+        (void)hipStreamSynchronize(e->stream);
+        e->last_error = first;
+        return code;
+    };
 
     if ((rc = enqueue_copy(0))) return bail(rc);
     const int excl = e->cfg.num_exclude_recent;
@@ -2019,6 +2053,7 @@ int points_pipeline_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
         const unsigned char *dptr[G];
         for (int j = 0; j < m; ++j) dptr[j] = e->d_pbuf[b] + off[j];
         if (hipStreamWaitEvent(e->stream, e->ev_copied[b], 0) != hipSuccess) return bail(fail(e, SCL_ERR_HIP, "hipStreamWaitEvent(copied)"));
+        if (ncs > 1 && hipStreamWaitEvent(e->stream, e->ev_copied2[b], 0) != hipSuccess) return bail(fail(e, SCL_ERR_HIP, "hipStreamWaitEvent(copied2)"));
         if ((rc = group_scatter(e, dptr, n_points + i0, m, stride_bytes, e->stream))) return bail(rc);
         if (hipEventRecord(e->ev_consumed[b], e->stream) != hipSuccess) return bail(fail(e, SCL_ERR_HIP, "hipEventRecord(consumed)"));
         if ((rc = ensure_capacity(e, e->n + m))) return bail(rc);   // (no-op unless another thread appended while a group's detection waited)
@@ -2142,6 +2177,36 @@ int scl_stream_from_points(scl_engine *e, const void *const *clouds, const int *
     std::unique_lock<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     return points_pipeline_locked(e, lk, clouds, n_points, n_scans, stride_bytes, robots, indexs, out_values, true, nn_idx, shift, dist);
+}
+
+/* measurement: what ONE large copy from pinned host memory reaches on this box's link (the floor of scl_stream_from_points) */
+int scl_host_copy_rate(scl_engine *e, size_t bytes, int reps, double *gbytes_per_s)
+{
+    if (!e || !gbytes_per_s || bytes == 0 || reps < 1) return SCL_ERR_INVALID_ARG;
+    if (e->front) e = front_primary(e);
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    void *h = nullptr; unsigned char *d = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t he = hipHostMalloc(&h, bytes, hipHostMallocDefault);
+    if (he == hipSuccess) { memset(h, 1, bytes); he = hipMalloc((void **)&d, bytes); }
+    if (he == hipSuccess) he = hipEventCreate(&e0);
+    if (he == hipSuccess) he = hipEventCreate(&e1);
+    if (!e->stream_copy && he == hipSuccess) he = hipStreamCreateWithFlags(&e->stream_copy, hipStreamNonBlocking);
+    float ms = 0.f;
+    if (he == hipSuccess) he = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, e->stream_copy);       // warm
+    if (he == hipSuccess) he = hipEventRecord(e0, e->stream_copy);
+    for (int i = 0; i < reps && he == hipSuccess; ++i) he = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, e->stream_copy);
+    if (he == hipSuccess) he = hipEventRecord(e1, e->stream_copy);
+    if (he == hipSuccess) he = hipEventSynchronize(e1);
+    if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (d) (void)hipFree(d);
+    if (h) (void)hipHostFree(h);
+    SCL_HIP(e, he);
+    *gbytes_per_s = ms > 0.f ? (double)bytes * reps / (ms * 1e-3) / 1e9 : 0.0;
+    return SCL_OK;
 }
 
 /* test hook: the device's atanf (xy2theta, D.h:1352-1374) over blocks of 2^24 float bit patterns, as the checksums of
@@ -2357,15 +2422,6 @@ int scl_find_key(const scl_engine *e, int8_t robot, int index, int *key)
     return SCL_OK;
 }
 
-namespace {
-struct DbFileHeader {
-    char magic[8];                                          // "SCLDB\0\0\1"
-    int32_t version, num_ring, num_sector, count;
-    int32_t reserved[4];
-};
-const char kDbMagic[8] = {'S', 'C', 'L', 'D', 'B', 0, 0, 1};
-}  // namespace
-
 int scl_db_dump_file(scl_engine *e, const char *path)
 {
     if (!e || !path) return SCL_ERR_INVALID_ARG;
@@ -2404,51 +2460,27 @@ int scl_db_load_file(scl_engine *e, const char *path, int *n_loaded)
     if (n_loaded) *n_loaded = 0;
     FILE *f = std::fopen(path, "rb");
     if (!f) return fail(e, SCL_ERR_INVALID_ARG, "db_load: cannot open the file");
+    const int n_before = scl_get_size(e, -1);
     DbFileHeader h{};
-    int rc = SCL_OK;
-    const size_t cells = (size_t)e->R * e->S;
-    if (std::fread(&h, sizeof h, 1, f) != 1 || std::memcmp(h.magic, kDbMagic, 8) != 0 || h.version != 1) rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: not a database dump of this engine");
-    else if (h.num_ring != e->R || h.num_sector != e->S) rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: the dump was made for another grid (rings x sectors)");
-    else if (h.count < 0) rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: corrupt header");
-    if (!rc) {   // the header is not trusted: the file must be exactly as long as the count says before anything is sized by it
-        const unsigned long long want = (unsigned long long)sizeof h + (unsigned long long)h.count * (sizeof(float) * cells + 2 * sizeof(int32_t));
-        long long have = -1;
-        if (fseeko(f, 0, SEEK_END) == 0) have = (long long)ftello(f);
-        if (have < 0 || (unsigned long long)have != want) rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: file length does not match the keyframe count of its header");
-    }
-    const int n_before = rc ? 0 : scl_get_size(e, -1);
-    try {
-        std::vector<int8_t> robots; std::vector<int> indexs;
-        if (!rc) {
-            // the index map sits behind the descriptors: read it first, then stream the descriptors in chunks
-            robots.resize((size_t)h.count); indexs.resize((size_t)h.count);
-            if (fseeko(f, (off_t)(sizeof h + sizeof(float) * cells * (size_t)h.count), SEEK_SET) != 0) rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: truncated file");
-            for (int k = 0; k < h.count && !rc; ++k) {
-                int32_t rec[2];
-                if (std::fread(rec, sizeof rec, 1, f) != 1) { rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: truncated index map"); break; }
-                robots[(size_t)k] = (int8_t)rec[0]; indexs[(size_t)k] = rec[1];
-            }
-            if (!rc && fseeko(f, (off_t)sizeof h, SEEK_SET) != 0) rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: seek failed");
-        }
-        const int chunk = 512;
-        std::vector<float> buf(rc ? 0 : cells * (size_t)chunk);
-        for (int done = 0; !rc && done < h.count; done += chunk) {
-            const int c = h.count - done < chunk ? h.count - done : chunk;
-            if (std::fread(buf.data(), sizeof(float) * cells, (size_t)c, f) != (size_t)c) { rc = fail(e, SCL_ERR_INVALID_ARG, "db_load: truncated descriptors"); break; }
-            rc = scl_save_bulk(e, buf.data(), c, robots.data() + done, indexs.data() + done);
-            if (!rc && n_loaded) *n_loaded += c;
-        }
-    } catch (const std::bad_alloc &) {
-        rc = fail(e, SCL_ERR_NOMEM, "db_load: out of host memory");
-    }
+    int sink_rc = 0;
+    // the parser (db_file.hpp: host code, fuzzed under ASan / UBSan by `make sanitize`) proves the file's length against its header before
+    // anything is sized by it, and hands the descriptors over in chunks
+    const int st = db_file_parse(f, e->R, e->S, &h, [&](const float *vals, int c, const int8_t *robots, const int *indexs) {
+        const int rc = scl_save_bulk(e, vals, c, robots, indexs);
+        if (!rc && n_loaded) *n_loaded += c;
+        return rc;
+    }, &sink_rc);
     std::fclose(f);
+    if (st == DBF_SINK) return sink_rc;                     // (scl_save_bulk left its own message)
+    if (st == DBF_NOMEM) return fail(e, SCL_ERR_NOMEM, db_file_status_string(st));
+    if (st != DBF_OK) return fail(e, SCL_ERR_INVALID_ARG, db_file_status_string(st));
     // an engine that was empty takes over the dump's inter-robot tree state too (D.h:1691-1703): the next
     // detectInterLoopClosureID searches the range the dumped engine would have searched
-    if (!rc && n_before == 0 && !e->front && h.reserved[0] == 1) {
+    if (n_before == 0 && !e->front && h.reserved[0] == 1) {
         std::lock_guard<std::mutex> lk(e->mu);
         e->tree_counter = h.reserved[1]; e->tree_n = h.reserved[2];
     }
-    return rc;
+    return SCL_OK;
 }
 
 /* ---- pose algebra behind the ICP block (DM.h:1130-1141, 1249-1259) ------------------------ */
@@ -3139,6 +3171,7 @@ int eng_stage_values(scl_engine *e, int j, const float *values)
 
 int eng_topk_enqueue(scl_engine *e, int query, int lo, int hi, int k, float eps, bool want_dist, bool *have_dist)
 {
+    std::lock_guard<std::mutex> pk(e->pass_mu);            // pass state (pinned results, slots, buffer sets): pass_mu first, like every scoring entry point
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     return topk_enqueue_locked(e, query, lo, hi, k, eps, want_dist, have_dist);
@@ -3146,6 +3179,7 @@ int eng_topk_enqueue(scl_engine *e, int query, int lo, int hi, int k, float eps,
 
 int eng_topk_finish(scl_engine *e, int k, bool have_dist, int *idx, float *d2, double *dist, int *shift, int *found)
 {
+    std::lock_guard<std::mutex> pk(e->pass_mu);            // pass state (pinned results, slots, buffer sets): pass_mu first, like every scoring entry point
     std::lock_guard<std::mutex> lk(e->mu);
     (void)hipSetDevice(e->device);
     return topk_finish_locked(e, k, have_dist, idx, d2, dist, shift, found);
@@ -3180,6 +3214,7 @@ int eng_truncate(scl_engine *e, int n_keep)
 
 const double *eng_ticket_record(const scl_engine *e, int ticket, int *slot_lo, bool *empty)
 {
+    std::lock_guard<std::mutex> pk(e->pass_mu);
     std::lock_guard<std::mutex> lk(e->mu);
     if (ticket < 0 || ticket >= scl_engine::kSlots || !e->slot_busy[ticket]) return nullptr;
     *slot_lo = e->slot_lo[ticket];
@@ -3191,6 +3226,7 @@ hipStream_t eng_stream(const scl_engine *e) { return e->stream; }
 
 int eng_release_ticket(scl_engine *e, int ticket)
 {
+    std::lock_guard<std::mutex> pk(e->pass_mu);            // pass state (pinned results, slots, buffer sets): pass_mu first, like every scoring entry point
     std::lock_guard<std::mutex> lk(e->mu);
     if (ticket < 0 || ticket >= scl_engine::kSlots || !e->slot_busy[ticket]) return fail(e, SCL_ERR_INVALID_ARG, "unknown ticket");
     e->slot_busy[ticket] = false;

@@ -168,12 +168,15 @@ constexpr int kMaxSmallExactQueries = 128;
 struct CandExactArgs {
     const float4 *desc; const double *norm; const double *vkey; const float4 *q_desc; const double *q_norm; const double *q_vkey;
     int k; const int *cand_idx; const float *cand_d2; char *out;
+    const unsigned long long *lists; int n_lists;   // lists != nullptr: the ring-key scan's per-workgroup lists -- the kernel merges them first (topk_merge.hpp) and
+    int *cand_idx_out; float *cand_d2_out;          // leaves the k candidates here as well (scl_get_last_topk); cand_idx / cand_d2 are not read then
     unsigned int seq;                  // != 0: written to out + cand_seq_offset(k) when the block is complete (the caller polls it instead of an event)
 };
 constexpr size_t cand_seq_offset(int k) { return (((size_t)k * (sizeof(int) * 2 + sizeof(float) + sizeof(double))) + 15) / 16 * 16; }
 bool sc_cand_exact_supported(const struct DbView &db, int SR);
 hipError_t launch_sc_cand_exact(const struct DbView &db, const struct QueryView &q, int SR, int k, const int *cand_idx, const float *cand_d2, void *pinned_out, hipStream_t stream,
-                                unsigned int seq = 0);
+                                unsigned int seq = 0, const unsigned long long *lists = nullptr, int n_lists = 0, int *cand_idx_out = nullptr, float *cand_d2_out = nullptr);
+constexpr int kCandMergeMaxKeys = 1024;   // lists x k the candidates' kernel merges itself (LDS of its wave rows); more: launch_topk_merge first
 bool sc_small_exact_supported(const struct DbView &db, int SR);
 hipError_t launch_sc_small_exact(const struct DbView &db, int SR, const SmallExactArgs &args, hipStream_t stream);
 bool sc_masked_supported(const struct DbView &db, int SR);
@@ -285,6 +288,11 @@ constexpr int kTopkMaxK = 64;
 static_assert(kTopkMaxK == kTailTopMaxK, "top-k sets share one size");
 // idx[k] | d2[k] | dist[k] | shift[k] into one block of pinned host memory (k results of a top-k and their SC distances)
 hipError_t launch_topk_pack(const int *idx, const float *d2, const double *dist, const int *shift, int k, bool have_dist, void *pinned_out, hipStream_t stream);
+// the scan alone: per-workgroup lists of k keys in `scratch` (*n_lists of them; 0 = empty range), merged by the consumer (topk_merge.hpp) or by
+// launch_topk_merge (-> out_idx / out_d2 in device memory and, pinned_out != nullptr, the block idx[k] | d2[k] the host reads)
+hipError_t launch_ringkey_lists(const DbView &db, const float *qkey, int lo, int hi, int k, float exclude_eps,
+                                unsigned long long *scratch, int *n_lists, hipStream_t stream);
+hipError_t launch_topk_merge(const unsigned long long *scratch, int n_lists, int k, int *out_idx, float *out_d2, void *pinned_out, hipStream_t stream);
 hipError_t launch_ringkey_topk(const DbView &db, const float *qkey, int lo, int hi, int k,
                                float exclude_eps, unsigned long long *scratch,
                                int *out_idx, float *out_d2, hipStream_t stream);

@@ -102,6 +102,11 @@ __global__ void make_sc_finalize_kernel(int *gtile, int cells, float *values)
 }
 
 // One workgroup per descriptor.  values: [count][R*S] row-major floats.
+// floor(n / d) for n, d < 2^16 by one multiply-high with M = ceil(2^32 / d) (exact in that range): the index splits of the loops
+// below (i -> row, column) were integer divisions by a runtime S -- ~40 instructions each, a third of this kernel's time
+__device__ __forceinline__ unsigned int fastdiv_magic(int d) { return 0xffffffffu / (unsigned int)d + 1u; }
+__device__ __forceinline__ int fastdiv(int n, unsigned int magic) { return (int)__umulhi((unsigned int)n, magic); }
+
 // tiles != nullptr: the descriptors come straight from the scatter's global tiles (ordered-int max-z images, one per workgroup):
 // finalize (D.h:1446-1456: NO_POINT -> 0, row-major floats) happens on the way into LDS, the wire-format values go to vals_out
 // (what makeAndSaveDescriptorAndKey returns, D.h:1604-1611) and the tile is put back into its initial state for the next batch.
@@ -113,16 +118,18 @@ __global__ __launch_bounds__(256) void ingest_kernel(
     extern __shared__ float sv[];                 // [R][S+1], then the S reciprocal norms
     const int LS = S + 1;                         // odd-ish stride: column walks hit distinct banks
     const int RG = (R + 3) >> 2;
+    const unsigned int mS = fastdiv_magic(S);
     const int slot = first_slot + blockIdx.x;
     const float *src = values ? values + (size_t)blockIdx.x * R * S : nullptr;
     float *siv = sv + R * LS;
     double *svk = reinterpret_cast<double *>(sv + ((R * LS + S + 1) & ~1));     // [S] the sector key, for its norm
+    double *sdd = svk + S;                                                      // [S] squared rounding errors of the fp16 sector key
     if (tiles) {
         int *t = tiles + (size_t)blockIdx.x * R * S;
         float *vo = vals_out ? vals_out + (size_t)blockIdx.x * R * S : nullptr;
         const int init = float_to_ordered((float)kNoPoint);
         for (int i = threadIdx.x; i < R * S; i += blockDim.x) {
-            const int r = i / S, c = i - r * S;
+            const int r = fastdiv(i, mS), c = i - r * S;
             float v = ordered_to_float(t[i]);
             if (v == (float)kNoPoint) v = 0.0f;                        // D.h:1450-1453
             sv[r * LS + c] = v;
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(
         }
     } else {
         for (int i = threadIdx.x; i < R * S; i += blockDim.x) {
-            const int r = i / S, c = i - r * S;
+            const int r = fastdiv(i, mS), c = i - r * S;
             sv[r * LS + c] = src[i];
         }
     }
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(
     // tiled copy: element (rg, c) = rows 4rg..4rg+3 of column c
     float4 *dslot = desc + (size_t)slot * RG * S;
     for (int i = threadIdx.x; i < RG * S; i += blockDim.x) {
-        const int rg = i / S, c = i - rg * S;
+        const int rg = fastdiv(i, mS), c = i - rg * S;
         float v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -183,8 +190,9 @@ __global__ __launch_bounds__(256) void ingest_kernel(
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     h4 *hslot = reinterpret_cast<h4 *>(hdesc + (size_t)slot * hstride);
     const int RGH = hdesc_sector(RG);                        // ring groups of the copy: rows >= R are zero
+    const unsigned int mRGH = fastdiv_magic(RGH);
     for (int i = threadIdx.x; i < S * RGH; i += blockDim.x) {
-        const int c = i / RGH, rg = i - c * RGH;
+        const int c = fastdiv(i, mRGH), rg = i - c * RGH;
         const float iv = siv[c];
         h4 hv;
 #pragma unroll
@@ -199,8 +207,9 @@ __global__ __launch_bounds__(256) void ingest_kernel(
         typedef _Float16 h8v __attribute__((ext_vector_type(8)));
         h8v *h2 = reinterpret_cast<h8v *>(hdesc + (size_t)slot * hstride + (size_t)hdesc2_offset(RG, S));
         const int n2 = hdesc2_elems(RG, S) / 2;                                 // entries of 16 B: ring parts x 4 chunks x (S + 16) sectors
+        const unsigned int mS16 = fastdiv_magic(S + 16);
         for (int i = threadIdx.x; i < n2; i += blockDim.x) {
-            const int hj = i / (S + 16), sx = i - hj * (S + 16);
+            const int hj = fastdiv(i, mS16), sx = i - hj * (S + 16);
             const int c = sx < S ? sx : sx - S;
             const float iv = siv[c];
             h8v hv;
@@ -220,10 +229,11 @@ __global__ __launch_bounds__(256) void ingest_kernel(
         for (int c = 0; c < S; ++c) n2 = n2 + svk[c] * svk[c];            // every thread the same sequential sum
         const double nrm = sqrt(n2);
         const bool usable = nrm > 0.0 && nrm < 1.0e300;                   // zero, NaN, inf: all zero -> every shift ties -> exact evaluation
+        const double rnrm = 1.0 / nrm;                                    // unit key u = k * (1 / |k|): one division per thread, not one per entry
         _Float16 *hd = reinterpret_cast<_Float16 *>(hkey + (size_t)slot * hkey_row_halfs(S));   // the dense table of the same keys
         // second fp16 part of an entry: fp16(2^11 (u - kh)) -- scaled so that it is a normal number; u - kh is exact in fp64
         auto parts = [&](int c, _Float16 *h, _Float16 *l) {
-            const double u = svk[c] / nrm;
+            const double u = svk[c] * rnrm;
             const _Float16 kh = (_Float16)(float)u;
             *h = kh; *l = (_Float16)(float)((u - (double)(float)kh) * 2048.0);
         };
@@ -236,17 +246,23 @@ __global__ __launch_bounds__(256) void ingest_kernel(
         // alignment's first stage bounds its error by Cauchy-Schwarz on these ACTUAL norms (2.4e-4 as a rule) instead of the worst
         // case of fp16 rounding (4.9e-4 per key): the lead it demands of the best shift falls from 3e-3 to ~1e-3, and fewer pairs go
         // on to the second stage.  An entry below fp16's normal range counts with the larger of its rounding error and its value (a
-        // matrix core may take it for zero).  Every thread forms the same sequential sum.
-        float kerr = -1.0f;
-        if (usable) {
-            double e2 = 0.0;
-            for (int c = 0; c < S; ++c) {
-                const double u = svk[c] / nrm;
+        // matrix core may take it for zero).  The squares are formed in parallel (sdd), thread 0 adds them up in sector order.
+        // (u as stored differs from k / |k| by two roundings, 2.3e-16 |u|: inside the 1e-10 the bound is raised by.)
+        for (int c = threadIdx.x; c < S; c += blockDim.x) {
+            double d = 0.0;
+            if (usable) {
+                const double u = svk[c] * rnrm;
                 const double kh = (double)(float)(_Float16)(float)u;
-                double d = fabs(u - kh);
+                d = fabs(u - kh);
                 if (fabs(kh) < 6.103515625e-05) d = fmax(d, fabs(u));
-                e2 = e2 + d * d;
             }
+            sdd[c] = d * d;
+        }
+        __syncthreads();
+        float kerr = -1.0f;
+        if (usable && threadIdx.x == 0) {
+            double e2 = 0.0;
+            for (int c = 0; c < S; ++c) e2 = e2 + sdd[c];
             kerr = __double2float_ru(sqrt(e2) * (1.0 + 1e-6) + 1e-10);         // (> 0 always: 0 would read as "not recorded")
         }
         if (threadIdx.x == 0) {
@@ -260,9 +276,11 @@ __global__ __launch_bounds__(256) void ingest_kernel(
         if (halign && P && slot < cap) {
             unsigned char *img = halign + (size_t)slot * (size_t)halign_bytes(S);
             _Float16 *x = reinterpret_cast<_Float16 *>(img + 16);
+            const unsigned int mCP = fastdiv_magic(CP);
             for (int i = threadIdx.x; i < P * CP; i += blockDim.x) {
-                const int rho = i / CP, k = i - rho * CP;
-                int c = (k - rho) % S; c = c < 0 ? c + S : c;
+                const int rho = fastdiv(i, mCP), k = i - rho * CP;
+                int c = k - rho + S;                                    // (k - rho) mod S, k - rho in [-P, CP)
+                c -= fastdiv(c, mS) * S;
                 _Float16 v = (_Float16)0.0f, vl = (_Float16)0.0f;
                 if (usable) parts(c, &v, &vl);
                 x[i] = v; x[P * CP + i] = vl;
@@ -285,10 +303,10 @@ __global__ __launch_bounds__(256) void ingest_kernel(
         const float iv = siv[c];
         double e2 = 0.0;
         if (iv == iv && iv != 0.0f) {
-            const double nrm = norm[(size_t)slot * S + c];
+            const double rn = 1.0 / norm[(size_t)slot * S + c];   // (x * (1 / norm): two roundings from x / norm, covered by the bound's 1e-6)
             for (int r = 0; r < R; ++r) {
                 const float x = sv[r * LS + c];
-                const double h = (double)(float)(_Float16)(x * iv), u = (double)x / nrm;
+                const double h = (double)(float)(_Float16)(x * iv), u = (double)x * rn;
                 double d = fabs(h - u);
                 if (fabs(h) < 6.103515625e-05) d = fmax(d, fabs(u));
                 e2 = e2 + d * d;
@@ -399,7 +417,7 @@ hipError_t launch_ingest(const float *values, int count, int first_slot,
 {
     if (count <= 0) return hipSuccess;
     if (S > 224) return hipErrorInvalidValue;              // kmask holds 7 words of sector bits
-    const size_t lds = sizeof(float) * ((size_t)R * (S + 1) + S + 2) + sizeof(double) * (size_t)S;
+    const size_t lds = sizeof(float) * ((size_t)R * (S + 1) + S + 2) + sizeof(double) * 2 * (size_t)S;
     static std::atomic<bool> attr_set_dev[64];   // per device; engines on different threads may race here: atomic flag,
     int dev_ = 0; (void)hipGetDevice(&dev_);     // and setting the attribute twice is harmless
     std::atomic<bool> &attr_set = attr_set_dev[dev_ & 63];

@@ -21,12 +21,13 @@
 
 #include "device_common.hpp"
 #include "kernels.hpp"
+#include "topk_merge.hpp"
 
 namespace scl {
 
 namespace {
 
-constexpr unsigned long long kNoKey = ~0ull;
+constexpr unsigned long long kNoKey = kTopkNoKey;
 constexpr int kTopkThreads = 256;
 constexpr int kTopkPerThread = 4;                       // slots per thread per workgroup
 constexpr int kTopkChunk = kTopkThreads * kTopkPerThread;
@@ -66,81 +67,160 @@ __device__ __forceinline__ void extract_topk(unsigned long long (&keys)[NK], int
     }
 }
 
-// ONE launch: T threads x SPT slots per workgroup and chunk; every workgroup keeps its k best (srun) and writes them to `partial`; the
-// workgroup that draws the last ticket merges the lists and writes the result (round 4: a second launch of one workgroup, 4.7 us
-// behind the 8.9 us of a scan that ran on ten CUs -- 1 024 slots per workgroup).  At 10k keyframes a workgroup is ONE wave with one
-// slot per lane (155 workgroups, sixteen 16-byte loads in flight per lane), the k rounds of the selection are wave reductions without
-// a barrier, and the merge reads 155 x k keys.
-template <int T, int SPT>
-__global__ __launch_bounds__(T) void ringkey_dist_topk_kernel(
-    const float4 *rkey4, int cap, const float *qkey, int R, int lo, int hi, int k,
-    float exclude_eps, unsigned long long *partial, unsigned int *done, int *out_idx, float *out_d2)
+// nanoflann's metric of one slot (NF:391-406: four dimensions per step, sequential tail; no FMA).  The loads of up to sixteen ring
+// groups are issued before the first of them is used: the accumulation is one dependent chain, and a load per link of it cost the
+// one-wave form of this kernel 16 memory latencies (12 us for 2.5 MB).
+__device__ __forceinline__ float ringkey_metric(const float4 *rkey4, int cap, int slot, const float *sq, int RGfull, int tail)
 {
-    __shared__ unsigned long long sred[T / kWave];
-    __shared__ unsigned long long srun[kTopkMaxK];      // this workgroup's running k best
-    __shared__ float sq[256];
-    __shared__ unsigned int s_ticket;
-    for (int r = threadIdx.x; r < R; r += T) sq[r] = qkey[r];
-    for (int i = threadIdx.x; i < kTopkMaxK; i += T) srun[i] = kNoKey;
-    __syncthreads();
-
-    constexpr int CHUNK = T * SPT;
-    const int RGfull = R >> 2;          // full groups of four
-    const int tail = R & 3;
-    const int nchunks = (hi - lo + CHUNK - 1) / CHUNK;
-    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        unsigned long long keys[SPT + 1];
+    float result = 0.0f;
+    for (int g0 = 0; g0 < RGfull; g0 += 16) {
+        float4 b[16];
 #pragma unroll
-        for (int u = 0; u < SPT; ++u) {
-            const int slot = lo + chunk * CHUNK + u * T + threadIdx.x;
-            unsigned long long key = kNoKey;
-            if (slot < hi) {
-                float result = 0.0f;
-                for (int g = 0; g < RGfull; ++g) {
-                    const float4 b = rkey4[(size_t)g * cap + slot];
-                    const float d0 = sq[4 * g + 0] - b.x;
-                    const float d1 = sq[4 * g + 1] - b.y;
-                    const float d2 = sq[4 * g + 2] - b.z;
-                    const float d3 = sq[4 * g + 3] - b.w;
-                    result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-                }
-                if (tail) {
-                    const float4 b = rkey4[(size_t)RGfull * cap + slot];
-                    const float bv[4] = {b.x, b.y, b.z, b.w};
-                    for (int i = 0; i < tail; ++i) {
-                        const float d0 = sq[4 * RGfull + i] - bv[i];
-                        result += d0 * d0;
-                    }
-                }
-                const bool excluded = (exclude_eps > 0.0f) && (result <= exclude_eps);
-                if (!excluded && (result < FLT_MAX))
-                    key = ((unsigned long long)(unsigned)__float_as_int(result) << 32) | (unsigned)slot;
+        for (int j = 0; j < 16; ++j)
+            if (g0 + j < RGfull) b[j] = rkey4[(size_t)(g0 + j) * cap + slot];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (g0 + j < RGfull) {
+                const int g = g0 + j;
+                const float d0 = sq[4 * g + 0] - b[j].x;
+                const float d1 = sq[4 * g + 1] - b[j].y;
+                const float d2 = sq[4 * g + 2] - b[j].z;
+                const float d3 = sq[4 * g + 3] - b[j].w;
+                result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
             }
-            keys[u] = key;
         }
-        keys[SPT] = (int)threadIdx.x < k ? srun[threadIdx.x] : kNoKey;
-        __syncthreads();                     // srun is rewritten by the rounds below
-        extract_topk<T>(keys, k, srun, sred);
-        __syncthreads();
     }
-    for (int i = threadIdx.x; i < k; i += T) partial[(size_t)blockIdx.x * k + i] = srun[i];
-    __threadfence();                                       // release: this workgroup's list, before its ticket
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tail) {
+        const float4 b = rkey4[(size_t)RGfull * cap + slot];
+        const float bv[4] = {b.x, b.y, b.z, b.w};
+        for (int i = 0; i < tail; ++i) {
+            const float d0 = sq[4 * RGfull + i] - bv[i];
+            result += d0 * d0;
+        }
+    }
+    return result;
+}
+
+__device__ __forceinline__ unsigned long long ringkey_key(float result, int slot, float exclude_eps)
+{
+    const bool excluded = (exclude_eps > 0.0f) && (result <= exclude_eps);
+    if (!excluded && (result < FLT_MAX))
+        return ((unsigned long long)(unsigned)__float_as_int(result) << 32) | (unsigned)slot;
+    return kNoKey;
+}
+
+// The scan for up to 65 536 slots: 256 slots per workgroup, one per thread (39 workgroups at 10k keyframes).  Every thread counts the
+// keys of the workgroup that are smaller than its own (256 broadcast reads of LDS, all independent; keys are unique -- the slot is
+// their low word) and the keys of rank < k go to position rank of the workgroup's list: sorted, no rounds, whatever k is (round 4: k
+// rounds of a block-wide minimum with two barriers each, 1 024 slots per workgroup on ten CUs).  The rows are requested BEFORE the
+// query's ring key: one memory round trip instead of two.  The lists are merged by the kernel that consumes the result (topk_merge.hpp).
+__global__ __launch_bounds__(kTopkThreads) void ringkey_lists_kernel(
+    const float4 *rkey4, int cap, const float *qkey, int R, int lo, int hi, int k, float exclude_eps, unsigned long long *partial)
+{
+    constexpr int T = kTopkThreads;
+    __shared__ unsigned long long skey[T];
+    __shared__ float sq[256];
+    const int slot = lo + (int)blockIdx.x * T + (int)threadIdx.x;
+    const int RGfull = R >> 2, tail = R & 3;
+    unsigned long long mine = kNoKey;
+    if (RGfull <= 16 && tail == 0) {
+        // (the grids in use: 20, 64, 80 rings) every row of the slot in flight, then the query's key
+        float4 b[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < RGfull && slot < hi) b[j] = rkey4[(size_t)j * cap + slot];
+        for (int r = threadIdx.x; r < R; r += T) sq[r] = qkey[r];
+        __syncthreads();
+        if (slot < hi) {
+            float result = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (j < RGfull) {
+                    const float d0 = sq[4 * j + 0] - b[j].x;
+                    const float d1 = sq[4 * j + 1] - b[j].y;
+                    const float d2 = sq[4 * j + 2] - b[j].z;
+                    const float d3 = sq[4 * j + 3] - b[j].w;
+                    result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;     // NF:391-397
+                }
+            }
+            mine = ringkey_key(result, slot, exclude_eps);
+        }
+    } else {
+        for (int r = threadIdx.x; r < R; r += T) sq[r] = qkey[r];
+        __syncthreads();
+        if (slot < hi) mine = ringkey_key(ringkey_metric(rkey4, cap, slot, sq, RGfull, tail), slot, exclude_eps);
+    }
+    unsigned long long *list = partial + (size_t)blockIdx.x * k;
+    if (k <= 8) {
+        // the reference's k (3): k rounds of a wave minimum over registers -- a key is a non-negative finite double by its bit pattern
+        // (distance bits in the high word: exponent field <= 0x7f7), "no key" = +inf, so the DPP minimum of device_common.hpp applies
+        // and nothing goes through LDS (the 256-key rank count below: 2-3 us of LDS reads) -- then the four waves' lists (4k keys) are
+        // ranked by the first wave
+        const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+        const double inf = __longlong_as_double(0x7ff0000000000000ll);
+        double mk = mine == kNoKey ? inf : __longlong_as_double((long long)mine);
+        for (int r = 0; r < k; ++r) {
+            const double m = wave_min_f64_dpp(mk);
+            if (lane == 0) skey[wv * 8 + r] = m == inf ? kNoKey : (unsigned long long)__double_as_longlong(m);
+            mk = mk == m ? inf : mk;                       // keys are unique: exactly one lane held it (or none: all inf)
+        }
+        __syncthreads();
+        if (wv == 0) {
+            const int nk = (T / kWave) * k;                // <= 32 keys
+            const int w2 = lane / k, r2 = lane - w2 * k;
+            const unsigned long long x = lane < nk ? skey[w2 * 8 + r2] : kNoKey;
+            int rank = 0, valid = 0;
+            for (int j = 0; j < nk; ++j) {
+                const int wj = j / k;
+                const unsigned long long y = skey[wj * 8 + (j - wj * k)];
+                rank += y < x ? 1 : 0;
+                valid += y != kNoKey ? 1 : 0;
+            }
+            if (x != kNoKey && rank < k) list[rank] = x;
+            if (lane >= valid && lane < k) list[lane] = kNoKey;      // behind the valid keys
+        }
+        return;
+    }
+    skey[threadIdx.x] = mine;
     __syncthreads();
-    if (threadIdx.x == 0) s_ticket = atomicAdd(done, 1u);
-    __syncthreads();
-    if (s_ticket != gridDim.x - 1) return;
-    __threadfence();                                       // acquire: the other workgroups' lists
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int rank = 0;
+#pragma unroll 8
+    for (int j = 0; j < T; ++j) rank += skey[j] < mine ? 1 : 0;
+    const int valid = __syncthreads_count(mine != kNoKey);
+    if (mine != kNoKey && rank < k) list[rank] = mine;
+    for (int i = valid + (int)threadIdx.x; i < k; i += T) list[i] = kNoKey;      // behind the valid keys
+}
+
+// The bare search's consumer (scl_ringkey_topk, and every path that needs the merged result in device memory before its next launch):
+// one workgroup merges the lists and writes idx / d2 -- and, pinned_out != nullptr, the same as the block idx[k] | d2[k] the host reads.
+__global__ __launch_bounds__(kTopkThreads) void topk_merge_pack_kernel(const unsigned long long *lists, int L, int k, int *out_idx, float *out_d2, char *pinned_out)
+{
+    __shared__ unsigned long long skey[kTopkMergeLds];
+    __shared__ unsigned long long scand[kTopkMergeLds];
+    __shared__ TopkMergeShared sh;
+    __shared__ int r_idx[kTopkMaxK];
+    __shared__ float r_d2[kTopkMaxK];
+    topk_merge_lists(lists, L, k, skey, scand, &sh, r_idx, r_d2);
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        out_idx[i] = r_idx[i]; out_d2[i] = r_d2[i];
+        if (pinned_out) { reinterpret_cast<int *>(pinned_out)[i] = r_idx[i]; reinterpret_cast<float *>(pinned_out + sizeof(int) * k)[i] = r_d2[i]; }
+    }
+}
+
+// ... more lists than a workgroup holds in LDS (k large on a large range): rounds of block-wide minima over the lists
+__global__ __launch_bounds__(kTopkThreads) void topk_merge_rounds_kernel(const unsigned long long *partial, int count, int k, int *out_idx, float *out_d2)
+{
+    constexpr int T = kTopkThreads;
+    __shared__ unsigned long long sred[T / kWave];
+    __shared__ unsigned long long srun[kTopkMaxK];
     for (int i = threadIdx.x; i < kTopkMaxK; i += T) srun[i] = kNoKey;
     __syncthreads();
-    const int count = (int)gridDim.x * k;
     for (int base = 0; base < count; base += 4 * T) {
         unsigned long long keys[5];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int p = base + u * T + (int)threadIdx.x;
-            keys[u] = p < count ? __builtin_nontemporal_load(partial + p) : kNoKey;
+            keys[u] = p < count ? partial[p] : kNoKey;
         }
         keys[4] = (int)threadIdx.x < k ? srun[threadIdx.x] : kNoKey;
         __syncthreads();
@@ -152,12 +232,36 @@ __global__ __launch_bounds__(T) void ringkey_dist_topk_kernel(
         if (m == kNoKey) { out_idx[i] = -1; out_d2[i] = FLT_MAX; }
         else { out_idx[i] = (int)(unsigned)(m & 0xffffffffull); out_d2[i] = __int_as_float((int)(m >> 32)); }
     }
-    if (threadIdx.x == 0) *done = 0u;                      // armed for the next launch (stream ordered)
 }
 
-__global__ void topk_fill_empty_kernel(int k, int *out_idx, float *out_d2)
+// More than 65 536 slots: T threads x SPT slots per workgroup and chunk, the workgroups stride over the chunks and keep their k best
+// by rounds of block-wide minima (ascending, kNoKey behind the valid keys: the same lists).
+template <int T, int SPT>
+__global__ __launch_bounds__(T) void ringkey_lists_chunked_kernel(
+    const float4 *rkey4, int cap, const float *qkey, int R, int lo, int hi, int k, float exclude_eps, unsigned long long *partial)
 {
-    for (int i = threadIdx.x; i < k; i += blockDim.x) { out_idx[i] = -1; out_d2[i] = FLT_MAX; }
+    __shared__ unsigned long long sred[T / kWave];
+    __shared__ unsigned long long srun[kTopkMaxK];      // this workgroup's running k best
+    __shared__ float sq[256];
+    for (int r = threadIdx.x; r < R; r += T) sq[r] = qkey[r];
+    for (int i = threadIdx.x; i < kTopkMaxK; i += T) srun[i] = kNoKey;
+    __syncthreads();
+
+    constexpr int CHUNK = T * SPT;
+    const int nchunks = (hi - lo + CHUNK - 1) / CHUNK;
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        unsigned long long keys[SPT + 1];
+#pragma unroll
+        for (int u = 0; u < SPT; ++u) {
+            const int slot = lo + chunk * CHUNK + u * T + threadIdx.x;
+            keys[u] = slot < hi ? ringkey_key(ringkey_metric(rkey4, cap, slot, sq, R >> 2, R & 3), slot, exclude_eps) : kNoKey;
+        }
+        keys[SPT] = (int)threadIdx.x < k ? srun[threadIdx.x] : kNoKey;
+        __syncthreads();                     // srun is rewritten by the rounds below
+        extract_topk<T>(keys, k, srun, sred);
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < k; i += T) partial[(size_t)blockIdx.x * k + i] = srun[i];
 }
 
 // the k results of a top-k (+ the SC distances of those k) into ONE block of pinned host memory, laid out idx[k] | d2[k] | dist[k] |
@@ -183,32 +287,50 @@ hipError_t launch_topk_pack(const int *idx, const float *d2, const double *dist,
     return hipGetLastError();
 }
 
+// the scan: per-workgroup lists in `scratch` (*n_lists of them, k keys each; 0: empty range)
+hipError_t launch_ringkey_lists(const DbView &db, const float *qkey, int lo, int hi, int k, float exclude_eps,
+                                unsigned long long *scratch, int *n_lists, hipStream_t stream)
+{
+    if (k <= 0 || k > kTopkMaxK || db.R > 256 || !n_lists) return hipErrorInvalidValue;
+    const int n = hi - lo;
+    *n_lists = 0;
+    if (n <= 0) return hipSuccess;
+    if (n <= kTopkThreads * kTopkMaxBlocks) {
+        const int blocks = (n + kTopkThreads - 1) / kTopkThreads;
+        hipLaunchKernelGGL(ringkey_lists_kernel, dim3(blocks), dim3(kTopkThreads), 0, stream,
+                           db.rkey4, db.cap, qkey, db.R, lo, hi, k, exclude_eps, scratch);
+        *n_lists = blocks;
+    } else {
+        int blocks = (n + kTopkChunk - 1) / kTopkChunk;
+        if (blocks > kTopkMaxBlocks) blocks = kTopkMaxBlocks;    // workgroups stride over the chunks
+        hipLaunchKernelGGL((ringkey_lists_chunked_kernel<kTopkThreads, kTopkPerThread>), dim3(blocks), dim3(kTopkThreads), 0, stream,
+                           db.rkey4, db.cap, qkey, db.R, lo, hi, k, exclude_eps, scratch);
+        *n_lists = blocks;
+    }
+    return hipGetLastError();
+}
+
+// the lists merged into out_idx / out_d2 (device), and, pinned_out != nullptr, into the block idx[k] | d2[k] there as well
+hipError_t launch_topk_merge(const unsigned long long *scratch, int n_lists, int k, int *out_idx, float *out_d2, void *pinned_out, hipStream_t stream)
+{
+    if (k <= 0 || k > kTopkMaxK || n_lists < 0 || n_lists > kTopkMaxBlocks) return hipErrorInvalidValue;
+    if (n_lists * k <= kTopkMergeLds) {
+        hipLaunchKernelGGL(topk_merge_pack_kernel, dim3(1), dim3(kTopkThreads), 0, stream, scratch, n_lists, k, out_idx, out_d2, static_cast<char *>(pinned_out));
+    } else {
+        hipLaunchKernelGGL(topk_merge_rounds_kernel, dim3(1), dim3(kTopkThreads), 0, stream, scratch, n_lists * k, k, out_idx, out_d2);
+        if (pinned_out) hipLaunchKernelGGL(topk_pack_kernel, dim3(1), dim3(64), 0, stream, out_idx, out_d2, (const double *)nullptr, (const int *)nullptr, k, 0, static_cast<char *>(pinned_out));
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_ringkey_topk(const DbView &db, const float *qkey, int lo, int hi, int k,
                                float exclude_eps, unsigned long long *scratch,
                                int *out_idx, float *out_d2, hipStream_t stream)
 {
-    if (k <= 0 || k > kTopkMaxK || db.R > 256) return hipErrorInvalidValue;
-    const int n = hi - lo;
-    if (n <= 0) {
-        hipLaunchKernelGGL(topk_fill_empty_kernel, dim3(1), dim3(64), 0, stream, k, out_idx, out_d2);
-        return hipGetLastError();
-    }
-    // scratch: kTopkMaxBlocks * kTopkMaxK partial keys, then the ticket counter (zero between launches)
-    unsigned long long *partial = scratch;
-    unsigned int *done = reinterpret_cast<unsigned int *>(scratch + (size_t)kTopkMaxBlocks * kTopkMaxK);
-    if (k <= 4 && n <= kWave * kTopkMaxBlocks) {
-        hipLaunchKernelGGL((ringkey_dist_topk_kernel<kWave, 1>), dim3((n + kWave - 1) / kWave), dim3(kWave), 0, stream,
-                           db.rkey4, db.cap, qkey, db.R, lo, hi, k, exclude_eps, partial, done, out_idx, out_d2);
-    } else if (n <= kTopkThreads * kTopkMaxBlocks) {
-        hipLaunchKernelGGL((ringkey_dist_topk_kernel<kTopkThreads, 1>), dim3((n + kTopkThreads - 1) / kTopkThreads), dim3(kTopkThreads), 0, stream,
-                           db.rkey4, db.cap, qkey, db.R, lo, hi, k, exclude_eps, partial, done, out_idx, out_d2);
-    } else {
-        int blocks = (n + kTopkChunk - 1) / kTopkChunk;
-        if (blocks > kTopkMaxBlocks) blocks = kTopkMaxBlocks;    // workgroups stride over the chunks
-        hipLaunchKernelGGL((ringkey_dist_topk_kernel<kTopkThreads, kTopkPerThread>), dim3(blocks), dim3(kTopkThreads), 0, stream,
-                           db.rkey4, db.cap, qkey, db.R, lo, hi, k, exclude_eps, partial, done, out_idx, out_d2);
-    }
-    return hipGetLastError();
+    int L = 0;
+    hipError_t e = launch_ringkey_lists(db, qkey, lo, hi, k, exclude_eps, scratch, &L, stream);
+    if (e != hipSuccess) return e;
+    return launch_topk_merge(scratch, L, k, out_idx, out_d2, nullptr, stream);
 }
 
 }  // namespace scl

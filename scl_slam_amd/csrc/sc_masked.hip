@@ -23,6 +23,7 @@
 #include "align_exact.hpp"
 #include "device_common.hpp"
 #include "kernels.hpp"
+#include "topk_merge.hpp"
 
 namespace scl {
 
@@ -592,8 +593,27 @@ __global__ __launch_bounds__(kCandWaves * kWave) void sc_cand_exact_kernel(CandE
     double *o_dist = reinterpret_cast<double *>(ca.out + (sizeof(int) + sizeof(float)) * ca.k);
     int *o_shift = reinterpret_cast<int *>(ca.out + (sizeof(int) + sizeof(float) + sizeof(double)) * ca.k);
     // the candidates first (a dependent load otherwise), then the scan
-    int my_slot = -1;
-    if (wave < ca.k) my_slot = ca.cand_idx[wave];
+    int my_slot = -1, my_slot2 = -1;                                             // candidates wave and wave + kCandWaves (k <= 16)
+    if (ca.lists) {
+        // the ring-key scan left its per-workgroup lists: merged here (topk_merge.hpp), in the LDS of the waves' rows, which nothing uses yet
+        unsigned long long *skey = reinterpret_cast<unsigned long long *>(smem_c + CC::LDS_Q + CC::LDS_N);
+        unsigned long long *scand = skey + kCandMergeMaxKeys;
+        TopkMergeShared *msh = reinterpret_cast<TopkMergeShared *>(scand + kCandMergeMaxKeys);
+        int *r_idx = reinterpret_cast<int *>(msh + 1);
+        float *r_d2 = reinterpret_cast<float *>(r_idx + 16);
+        topk_merge_lists(ca.lists, ca.n_lists, ca.k, skey, scand, msh, r_idx, r_d2);
+        if (wave < ca.k) my_slot = r_idx[wave];
+        if (wave + kCandWaves < ca.k) my_slot2 = r_idx[wave + kCandWaves];
+        if ((int)threadIdx.x < ca.k) {
+            const int ci = r_idx[threadIdx.x]; const float cd = r_d2[threadIdx.x];
+            o_idx[threadIdx.x] = ci; o_d2[threadIdx.x] = cd;
+            ca.cand_idx_out[threadIdx.x] = ci; ca.cand_d2_out[threadIdx.x] = cd;
+        }
+        __syncthreads();                                                         // (the rows' LDS is free again)
+    } else {
+        if (wave < ca.k) my_slot = ca.cand_idx[wave];
+        if (wave + kCandWaves < ca.k) my_slot2 = ca.cand_idx[wave + kCandWaves];
+    }
     for (int idx = threadIdx.x; idx < RG * QCOLS; idx += blockDim.x) {
         const int rg = idx / QCOLS, cx = idx - rg * QCOLS;
         const int c = cx < S ? cx : cx - S;
@@ -601,10 +621,10 @@ __global__ __launch_bounds__(kCandWaves * kWave) void sc_cand_exact_kernel(CandE
     }
     for (int cx = threadIdx.x; cx < QCOLS; cx += blockDim.x) nq[cx] = ca.q_norm[cx < S ? cx : cx - S];
     for (int c = threadIdx.x; c < S; c += blockDim.x) vq[c] = ca.q_vkey[c];
-    if ((int)threadIdx.x < ca.k) { o_idx[threadIdx.x] = ca.cand_idx[threadIdx.x]; o_d2[threadIdx.x] = ca.cand_d2[threadIdx.x]; }
+    if (!ca.lists && (int)threadIdx.x < ca.k) { o_idx[threadIdx.x] = ca.cand_idx[threadIdx.x]; o_d2[threadIdx.x] = ca.cand_d2[threadIdx.x]; }
     __syncthreads();
     for (int c = wave; c < ca.k; c += kCandWaves) {
-        const int slot = c == wave ? my_slot : ca.cand_idx[c];
+        const int slot = c == wave ? my_slot : my_slot2;
         double best = kBigDist; int bshift = 0;
         if (slot >= 0) {                                                         // (wave uniform; a slot the search left unfilled: (1e7, 0) like launch_sc_distance)
             constexpr int L = S >> 1;
@@ -687,6 +707,7 @@ static hipError_t launch_cand_t(const CandExactArgs &ca, hipStream_t stream)
 {
     using CC = CandCfg<RG, S, W>;
     static_assert(CC::LDS <= 160 * 1024, "LDS");
+    static_assert((size_t)kCandWaves * CC::LDS_WAVE >= 2 * (size_t)kCandMergeMaxKeys * 8 + sizeof(TopkMergeShared) + 16 * 8, "the merge of the scan's lists works in the waves' rows");
     static std::atomic<bool> attr_set_dev[64];
     int dev_ = 0; (void)hipGetDevice(&dev_);
     std::atomic<bool> &attr_set = attr_set_dev[dev_ & 63];
@@ -699,10 +720,13 @@ static hipError_t launch_cand_t(const CandExactArgs &ca, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_sc_cand_exact(const DbView &db, const QueryView &q, int SR, int k, const int *cand_idx, const float *cand_d2, void *pinned_out, hipStream_t stream, unsigned int seq)
+hipError_t launch_sc_cand_exact(const DbView &db, const QueryView &q, int SR, int k, const int *cand_idx, const float *cand_d2, void *pinned_out, hipStream_t stream, unsigned int seq,
+                                const unsigned long long *lists, int n_lists, int *cand_idx_out, float *cand_d2_out)
 {
-    if (k < 1 || k > kTopkMaxK || !sc_cand_exact_supported(db, SR) || !pinned_out) return hipErrorInvalidValue;
+    if (k < 1 || k > 2 * kCandWaves || !sc_cand_exact_supported(db, SR) || !pinned_out) return hipErrorInvalidValue;
+    if (lists && (n_lists < 0 || n_lists * k > kCandMergeMaxKeys || !cand_idx_out || !cand_d2_out)) return hipErrorInvalidValue;
     CandExactArgs ca{};
+    ca.lists = lists; ca.n_lists = n_lists; ca.cand_idx_out = cand_idx_out; ca.cand_d2_out = cand_d2_out;
     ca.desc = db.desc; ca.norm = db.norm; ca.vkey = db.vkey; ca.q_desc = q.desc; ca.q_norm = q.norm; ca.q_vkey = q.vkey;
     ca.k = k; ca.cand_idx = cand_idx; ca.cand_d2 = cand_d2; ca.out = static_cast<char *>(pinned_out); ca.seq = seq;
     if (db.S == 120) return launch_cand_t<16, 120, 13>(ca, stream);

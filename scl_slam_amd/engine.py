@@ -139,6 +139,7 @@ def _bind(lib):
         "scl_host_register": (c_int, [P, c_void_p, ctypes.c_size_t]),
         "scl_host_unregister": (c_int, [P, c_void_p]),
         "scl_selftest_atanf_blocks": (c_int, [P, c_int, c_int, POINTER(ctypes.c_uint64)]),
+        "scl_host_copy_rate": (c_int, [P, ctypes.c_size_t, c_int, dp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -290,6 +291,11 @@ class ScanContextEngine:
         p = self._pinned.pop(array.ctypes.data, None)
         if p is not None:
             self._check(self._lib.scl_host_free(self._h, c_void_p(p)), "scl_host_free")
+
+    def host_copy_rate(self, nbytes=64 << 20, reps=8):
+        g = c_double()
+        self._check(self._lib.scl_host_copy_rate(self._h, nbytes, reps, byref(g)), "scl_host_copy_rate")
+        return g.value
 
     def selftest_atanf_blocks(self, first_block, n_blocks):
         out = np.zeros(n_blocks, dtype=np.uint64)

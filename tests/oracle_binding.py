@@ -9,6 +9,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+# SCL_ORACLE_LIB: another build of the checker -- `make sanitize` runs the CPU tests against oracle/liboracle_asan.so (ASan + UBSan)
+if os.environ.get("SCL_ORACLE_LIB"):
+    LIB = os.path.abspath(os.environ["SCL_ORACLE_LIB"])
 REF_LIB = os.path.join(ORACLE_DIR, "_ref", "libnanoflann_ref.so")
 
 

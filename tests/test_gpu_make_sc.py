@@ -24,7 +24,10 @@ def test_edge_points_and_strides():
     R, S = 20, 60
     pts = np.array([[0, 0, 1.0], [80.0, 0, 2.0], [80.00001, 0, 9.0], [10, 10, -5.0], [10, 10, -2000.0],
                     [0, 5, 1.0], [-5, 0, 1.0], [0, -5, 1.0], [np.nan, 1, 1], [1, 1, np.nan], [np.inf, 0, 3],
-                    [1e-30, 1e-30, 0.5], [-1e-3, -1e-3, 0.25], [79.999, -0.0001, 4.0]], dtype=np.float32)
+                    [1e-30, 1e-30, 0.5], [-1e-3, -1e-3, 0.25], [79.999, -0.0001, 4.0],
+                    [-0.0, 3.0, 1.5], [-0.0, -3.0, 1.25], [3.0, -0.0, 1.75], [-3.0, -0.0, 0.75], [-0.0, -0.0, 2.5], [0.0, -0.0, 2.25],
+                    [np.inf, np.inf, 1.0], [-np.inf, 2.0, 1.0], [1e-40, 1e-42, 0.6], [-1e-40, 3e-41, 0.7], [30.0, 30.0, 1.0], [30.0, 13.125, 1.1],
+                    [30.0, 20.625, 1.2], [30.0, 35.625, 1.3], [30.0, 73.125, 1.4], [1.0, 4e7, 1.5], [-2.0, 7e7, 1.6]], dtype=np.float32)
     cfg = ob.make_config(R=R, S=S)
     for stride in (3, 4, 8):
         cloud = np.zeros((len(pts), stride), np.float32); cloud[:, :3] = pts
