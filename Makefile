@@ -53,12 +53,13 @@ sanitize: tests/cpp/fuzz_host
 	@echo "== 1. CPU tests against oracle/liboracle_asan.so (-fsanitize=address,undefined, libasan preloaded into python)" >> $(SAN_LOG)
 	SCL_ORACLE_LIB=oracle/liboracle_asan.so LD_PRELOAD=$$(gcc -print-file-name=libasan.so):$$(gcc -print-file-name=libubsan.so) \
 	    ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
-	    python -m pytest tests -x -q -m "not gpu" -p no:cacheprovider 2>&1 | tail -4 >> $(SAN_LOG)
+	    python -m pytest tests -x -q -m "not gpu" -p no:cacheprovider > /tmp/scl_san_tests.log 2>&1; \
+	    grep -E "runtime error|ERROR: AddressSanitizer|SUMMARY" /tmp/scl_san_tests.log | head -5 >> $(SAN_LOG); tail -2 /tmp/scl_san_tests.log >> $(SAN_LOG)
 	@echo "== 2. worker pool under ThreadSanitizer (oracle/tools/tsan_pool_driver)" >> $(SAN_LOG)
 	TSAN_OPTIONS=halt_on_error=1 oracle/tools/tsan_pool_driver >> $(SAN_LOG) 2>&1
 	@echo "== 3. libFuzzer + ASan + UBSan: wire decoders (messages.hip) and dump parser (db_file.hpp), $(FUZZ_SECONDS) s" >> $(SAN_LOG)
 	python tests/cpp/fuzz_seeds.py /tmp/scl_fuzz_corpus
-	tests/cpp/fuzz_host -max_total_time=$(FUZZ_SECONDS) -max_len=4096 -print_final_stats=1 /tmp/scl_fuzz_corpus 2>&1 | grep -E "stat::|ERROR|SUMMARY|Done|cov:" | tail -12 >> $(SAN_LOG)
+	ASAN_OPTIONS=detect_odr_violation=0 tests/cpp/fuzz_host -max_total_time=$(FUZZ_SECONDS) -max_len=4096 -print_final_stats=1 /tmp/scl_fuzz_corpus 2>&1 | grep -E "stat::|ERROR|SUMMARY|Done|cov:" | tail -12 >> $(SAN_LOG)
 	@echo "== done: no finding above means none was reported (every tool stops at its first)" >> $(SAN_LOG)
 	@cat $(SAN_LOG)
 

@@ -404,6 +404,11 @@ int  scl_host_copy_rate(scl_engine *e, size_t bytes, int reps, double *gbytes_pe
  * splitmix64((bits << 32) | result bits), NaN results counted as 0x7fc00000.  tests/golden/atanf_blocks.json holds the 256 values
  * of libm's atanf (oracle/tools/atanf_exhaustive.c). */
 int  scl_selftest_atanf_blocks(scl_engine *e, int first_block, int n_blocks, uint64_t *checksums);
+/* Self test of the descriptor kernel's two ways to a point's (ring, sector, dropped?) -- the reference's chain (D.h:1425-1435) and the
+ * cheap approximations that stand in for it wherever they are provably the same integers (csrc/device_common.hpp) -- on n_points
+ * generated points of the engine's grid (mode 0: uniform; 1: on ring boundaries; 2: on sector boundaries; 3: zeros, denormals, huge,
+ * inf, NaN): *sure = points the fast path answered, *disagreements = those of them where the chain says otherwise (must be 0). */
+int  scl_selftest_bin_paths(scl_engine *e, int mode, uint64_t seed, uint64_t n_points, uint64_t *disagreements, uint64_t *sure);
 
 #ifdef __cplusplus
 }

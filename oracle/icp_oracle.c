@@ -568,10 +568,15 @@ int icpo_voxel_grid(const void *in, int n, int stride, float leaf, void *out)
     if (nfinite == 0) return 0;
     long long minb[3], divb[3];
     for (int a = 0; a < 3; a++) {
-        minb[a] = (long long)floorf(mn[a] * inv);
-        divb[a] = (long long)floorf(mx[a] * inv) - minb[a] + 1;
+        /* a bound outside int32 (PCL casts it to int: undefined) counts as "too large for the leaf", and the voxel count is formed
+         * without wrapping (UBSan, make sanitize: 999999874000003969 * 999999937 overflowed here) */
+        const float lo = floorf(mn[a] * inv), hi = floorf(mx[a] * inv);
+        if (!(lo >= -2147483648.f && hi <= 2147483520.f)) return -1;
+        minb[a] = (long long)lo;
+        divb[a] = (long long)hi - minb[a] + 1;
+        if (divb[a] > 2147483647LL) return -1;
     }
-    if (divb[0] * divb[1] * divb[2] > 2147483647LL) return -1;
+    if (divb[0] * divb[1] > 2147483647LL || divb[0] * divb[1] * divb[2] > 2147483647LL) return -1;
     vox_key *keys = (vox_key *)malloc(sizeof(vox_key) * (size_t)nfinite);
     int m = 0;
     for (int i = 0; i < n; i++) {

@@ -129,6 +129,65 @@ __device__ __forceinline__ int ceil_to_int_x86(double v)
     return (int)c;
 }
 
+// ---- the descriptor's bins of a point, two ways (make_sc.hip) -------------------------------------------------------------------
+// The descriptor depends on a point only through (ring, sector, dropped?).  sc_bin_exact is the reference's chain (D.h:1425-1435):
+// IEEE sqrtf, xy2theta with glibc's atanf, the double quotients, ceil -- ~220 vector instructions, four IEEE divisions among them: the
+// scatter kernel was bound by them, not by HBM.  sc_bin_fast computes the SAME integers from cheap approximations and says whether it
+// is sure: with q~ an approximation of the exact chain's q = range / max_radius * R (resp. theta / 360 * S) and |q~ - q| <= E,
+// ceil(q~) = ceil(q) whenever q~ is farther than E from every integer; the guards below are four times the E derived here, and a
+// point inside a guard band (2-3 in 10 000) takes the exact chain.  Errors:
+//   ring:   s = x*x + y*y is the chain's own float arithmetic; v_sqrt_f32 is within 1 ulp where the chain's sqrtf is correctly
+//           rounded (1.5 ulp apart), the product with fl32(R / max_radius) adds two roundings: |q~ - q| <= 3e-7 q <= 2.4e-5 (R <= 80).
+//   sector: the chain's float angle is within 4e-5 degrees of the true one (atanf < 1 ulp, the quotient's half ulp, and the final
+//           rounding of an angle up to 360: half of 3.05e-5); here: v_rcp_f32 (1 ulp), a degree-17 odd polynomial for atan on [0, 1]
+//           (Abramowitz & Stegun 4.4.49, |error| <= 1.4e-8; 9.3e-8 as evaluated in fp32), the octant placement (pi's rounding, one
+//           rounding at <= 2 pi: 2.9e-7 rad), the product with fl32(S / 2 pi) (two roundings at <= 180: 2.2e-5): together 6e-5 sectors
+//           at S = 180.
+//   x or y zero, NaN, or the larger coordinate outside [1e-18, 1e18]: not sure (the chain's quirks live there: y / -0.0, 0 / 0).
+// scl_selftest_bin_paths (tests/test_gpu_make_sc.py) compares the two on 2^30 random, boundary-hugging and special points: no
+// disagreement where the fast path is sure.
+constexpr float kBinGuardRing = 1.0e-4f;
+constexpr float kBinGuardSect = 2.5e-4f;
+
+__device__ __forceinline__ void sc_bin_exact(float px, float py, int R, int S, double max_radius, int &ring, int &sect, bool &drop)
+{
+    const float azim_range = sqrtf(px * px + py * py);             // D.h:1425
+    const float azim_angle = xy2theta(px, py);                     // D.h:1426
+    drop = (double)azim_range > max_radius;                        // D.h:1429
+    ring = max(min(R, ceil_to_int_x86(((double)azim_range / max_radius) * R)), 1);   // D.h:1434
+    sect = max(min(S, ceil_to_int_x86(((double)azim_angle / 360.0) * S)), 1);        // D.h:1435
+}
+
+__device__ __forceinline__ bool sc_bin_fast(float x, float y, int R, int S, float c_ring, float c_sect, int &ring, int &sect, bool &drop)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float hi = fmaxf(ax, ay), lo = fminf(ax, ay);
+    bool sure = (x == x) & (y == y) & (lo > 0.0f) & (hi >= 1.0e-18f) & (hi <= 1.0e18f);
+    const float s = x * x + y * y;                                 // the chain's own operations (no contraction)
+    const float qr = __builtin_amdgcn_sqrtf(s) * c_ring;
+    sure &= fabsf(qr - rintf(qr)) > kBinGuardRing;
+    drop = qr > (float)R;
+    ring = max(min((int)ceilf(qr), R), 1);
+    const float a = lo * __builtin_amdgcn_rcpf(hi);                // in (0, 1]
+    const float z = a * a;
+    float p = fmaf(z, 0.0028662257f, -0.0161657367f);
+    p = fmaf(z, p, 0.0429096138f);
+    p = fmaf(z, p, -0.0752896400f);
+    p = fmaf(z, p, 0.1065626393f);
+    p = fmaf(z, p, -0.1420889944f);
+    p = fmaf(z, p, 0.1999355085f);
+    p = fmaf(z, p, -0.3333314528f);
+    p = fmaf(z, p, 1.0f);
+    float t = a * p;                                               // atan(lo / hi), [0, pi / 4]
+    t = ay > ax ? 1.57079632679f - t : t;
+    t = x < 0.0f ? 3.14159265359f - t : t;
+    t = y < 0.0f ? 6.28318530718f - t : t;
+    const float qs = t * c_sect;
+    sure &= fabsf(qs - rintf(qs)) > kBinGuardSect;
+    sect = max(min((int)ceilf(qs), S), 1);
+    return sure;
+}
+
 // ---- wave-level lexicographic arg-min on (double value, int tag) -----------
 __device__ __forceinline__ void wave_argmin(double &v, int &tag)
 {

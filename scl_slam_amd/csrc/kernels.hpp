@@ -322,5 +322,7 @@ hipError_t launch_make_sc_batch(ScanBatch b, int stride_bytes, int R, int S, dou
                                 int *tiles, int points_per_wg, int num_cu, hipStream_t stream);
 // test hook: checksums of the device's atanf over blocks of 2^24 float bit patterns (tests/golden/atanf_blocks.json)
 hipError_t launch_atanf_block_checksums(int first_block, int n_blocks, unsigned long long *d_out, hipStream_t stream);
+// test hook: the scatter's fast binning against the reference's chain on n generated points: d_out2[0] = disagreements where the fast path was sure, [1] = sure
+hipError_t launch_bin_paths_selftest(int mode, unsigned long long seed, unsigned long long n, int R, int S, double max_radius, unsigned long long *d_out2, hipStream_t stream);
 
 }  // namespace scl

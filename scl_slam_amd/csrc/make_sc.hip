@@ -33,10 +33,12 @@ constexpr int kScThreads = 256;
 // atomicMax per touched cell.  The global tiles are in their initial state when the launch starts and are put back into it by the
 // kernel that consumes them (ingest_kernel), so a batch costs two launches whatever its size.  Four points per thread are in flight.
 __global__ __launch_bounds__(kScThreads) void make_sc_batch_scatter_kernel(ScanBatch b, int stride, int R, int S,
-                                                                           double lidar_height, double max_radius, int *gtiles)
+                                                                           double lidar_height, double max_radius, int *gtiles, int lab)
 {
+    const bool exact_only = lab & 1;                       // (diagnostics builds: 1 = the reference's chain for every point, 2 / 4 = ablations)
     extern __shared__ int tile[];
     const int cells = R * S;
+    const float c_ring = (float)((double)R / max_radius), c_sect = (float)((double)S / 6.283185307179586);
     const int init = float_to_ordered((float)kNoPoint);
     for (int i = threadIdx.x; i < cells; i += blockDim.x) tile[i] = init;
     int s = 0;
@@ -51,32 +53,45 @@ __global__ __launch_bounds__(kScThreads) void make_sc_batch_scatter_kernel(ScanB
     int end = begin + per_block; end = end > n ? n : end;
     __syncthreads();
     const bool vec = (stride & 15) == 0;
-    for (int p0 = begin + (int)threadIdx.x; p0 < end; p0 += 4 * kScThreads) {
-        float px[4], py[4], pzr[4];
+    // SIXTEEN points per thread and round, every record of the round requested before the first is binned: the loop is bound by
+    // memory round trips, not by bytes or arithmetic (measured: four points per round, 14.5 us for 30.7 MB whether or not the next
+    // round's loads were issued ahead -- two waves per SIMD hide nothing, and a round's arithmetic is a sixth of its latency)
+    constexpr int U = 16;
+    const int p_end = (lab & 4) ? begin : end;
+    for (int p0 = begin + (int)threadIdx.x; p0 < p_end; p0 += U * kScThreads) {
+        float px[U], py[U], pzr[U];
+        // (unconditional loads from a clamped index: a load inside `if (p < end)` is a block of its own, and the compiler ended every
+        //  such block with s_waitcnt vmcnt(0) -- sixteen dependent round trips per round, however the source was arranged)
+        if (vec) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int p = p0 + u * kScThreads;
-            px[u] = 0.0f; py[u] = 0.0f; pzr[u] = __int_as_float(0x7fc00000);     // past the slice: NaN z never enters a cell
-            if (p < end) {
-                const unsigned char *rec = points + (size_t)p * (size_t)stride;
-                if (vec) { const float4 v = *reinterpret_cast<const float4 *>(rec); px[u] = v.x; py[u] = v.y; pzr[u] = v.z; }
-                else { const float *f = reinterpret_cast<const float *>(rec); px[u] = f[0]; py[u] = f[1]; pzr[u] = f[2]; }
+            for (int u = 0; u < U; ++u) {
+                const int p = p0 + u * kScThreads;
+                const float4 v = *reinterpret_cast<const float4 *>(points + (size_t)(p < end ? p : end - 1) * (size_t)stride);
+                px[u] = v.x; py[u] = v.y; pzr[u] = p < end ? v.z : __int_as_float(0x7fc00000);    // past the slice: NaN z never enters a cell
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int p = p0 + u * kScThreads;
+                const float *f = reinterpret_cast<const float *>(points + (size_t)(p < end ? p : end - 1) * (size_t)stride);
+                px[u] = f[0]; py[u] = f[1]; pzr[u] = p < end ? f[2] : __int_as_float(0x7fc00000);
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const float pz = (float)((double)pzr[u] + lidar_height);            // D.h:1422
-            const float azim_range = sqrtf(px[u] * px[u] + py[u] * py[u]);       // D.h:1425
-            const float azim_angle = xy2theta(px[u], py[u]);                     // D.h:1426
-            if ((double)azim_range > max_radius) continue;                       // D.h:1429
-            const int ring = max(min(R, ceil_to_int_x86(((double)azim_range / max_radius) * R)), 1);   // D.h:1434
-            const int sect = max(min(S, ceil_to_int_x86(((double)azim_angle / 360.0) * S)), 1);        // D.h:1435
+            int ring, sect; bool drop;
+            // the bins from cheap approximations where those are sure of them (device_common.hpp), the reference's chain otherwise
+            const bool sure = !exact_only && sc_bin_fast(px[u], py[u], R, S, c_ring, c_sect, ring, sect, drop);
+            if (!sure) sc_bin_exact(px[u], py[u], R, S, max_radius, ring, sect, drop);      // D.h:1425-1435
+            if (drop) continue;                                                  // D.h:1429
             if (pz != pz) continue;                                              // NaN never passes `<` (D.h:1438)
             atomicMax(&tile[(ring - 1) * S + (sect - 1)], float_to_ordered(pz));
         }
     }
     __syncthreads();
     int *g = gtiles + (size_t)s * cells;
+    if (lab & 2) return;
     for (int i = threadIdx.x; i < cells; i += blockDim.x) {
         const int v = tile[i];
         if (v != init) atomicMax(&g[i], v);
@@ -353,6 +368,50 @@ __global__ __launch_bounds__(256) void atanf_checksum_kernel(int first_block, un
     if ((threadIdx.x & (kWave - 1)) == 0) atomicAdd(&out[blockIdx.y], h);
 }
 
+// test hook (tests/test_gpu_make_sc.py): sc_bin_fast against sc_bin_exact on generated points -- out[0] += points on which the fast path
+// was sure AND differed from the reference's chain (must stay 0), out[1] += points on which it was sure.
+//   mode 0: uniform in the square of +-1.125 max_radius; 1: on ring boundaries, a few float steps either side; 2: on sector boundaries,
+//   micro-degrees either side; 3: zeros, signed zeros, denormals, huge values, infinities, NaNs and plain values, all pairs
+__global__ __launch_bounds__(256) void bin_paths_selftest_kernel(int mode, unsigned long long seed, unsigned long long n, int R, int S, double max_radius,
+                                                                 unsigned long long *out)
+{
+    const float c_ring = (float)((double)R / max_radius), c_sect = (float)((double)S / 6.283185307179586);
+    unsigned long long bad = 0, sure_n = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        unsigned long long z = seed + i * 0x9e3779b97f4a7c15ull;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; z ^= z >> 31;
+        const double u0 = (double)(z >> 40) * (1.0 / 16777216.0), u1 = (double)((z >> 16) & 0xffffffull) * (1.0 / 16777216.0);
+        const int kk = (int)(z & 31ull) - 16;
+        float x, y;
+        if (mode == 0) {
+            x = (float)((2.0 * u0 - 1.0) * 1.125 * max_radius); y = (float)((2.0 * u1 - 1.0) * 1.125 * max_radius);
+        } else if (mode == 1) {
+            const int ring = 1 + (int)(u0 * R);
+            const double r0 = (double)ring * max_radius / R, ang = 6.283185307179586 * u1;
+            const float fx = (float)(r0 * cos(ang)), fy = (float)(r0 * sin(ang));
+            x = __int_as_float(__float_as_int(fx) + ((kk >> 2) * (fx != 0.f))); y = __int_as_float(__float_as_int(fy) + ((kk & 3) - 1) * (fy != 0.f));
+        } else if (mode == 2) {
+            const int sec = (int)(u0 * (S + 1));
+            const double ang = (sec * (360.0 / S) + kk * 1.0e-6) * (3.14159265358979323846 / 180.0), r0 = 0.25 + u1 * 1.05 * max_radius;
+            x = (float)(r0 * cos(ang)); y = (float)(r0 * sin(ang));
+        } else {
+            const float tab[16] = {0.0f, -0.0f, 1.0e-42f, -1.0e-42f, 1.0e-20f, -1.0e-20f, 1.0e20f, -1.0e20f, __int_as_float(0x7f800000), __int_as_float((int)0xff800000u),
+                                   __int_as_float(0x7fc00000), 1.0f, -1.0f, (float)max_radius, 3.0e-5f, -37.5f};
+            x = tab[(z >> 8) & 15]; y = tab[(z >> 12) & 15];
+        }
+        int rf, sf, re, se; bool df, de;
+        const bool sure = sc_bin_fast(x, y, R, S, c_ring, c_sect, rf, sf, df);
+        sc_bin_exact(x, y, R, S, max_radius, re, se, de);
+        if (sure) {
+            sure_n++;
+            if (df != de || (!de && (rf != re || sf != se))) bad++;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { bad += __shfl_xor(bad, off, kWave); sure_n += __shfl_xor(sure_n, off, kWave); }
+    if ((threadIdx.x & (kWave - 1)) == 0) { atomicAdd(&out[0], bad); atomicAdd(&out[1], sure_n); }
+}
+
 __global__ void untile_kernel(const float4 *dslot, int R, int S, float *values)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -406,7 +465,7 @@ hipError_t launch_make_sc_batch(ScanBatch b, int stride_bytes, int R, int S, dou
     }
     (void)num_cu;
     hipLaunchKernelGGL(make_sc_batch_scatter_kernel, dim3(total), dim3(kScThreads), lds, stream, b, stride_bytes, R, S,
-                       lidar_height, max_radius, tiles);
+                       lidar_height, max_radius, tiles, scl_lab_int("SCL_SC_LAB", 0));
     return hipGetLastError();
 }
 
@@ -438,6 +497,14 @@ hipError_t launch_atanf_block_checksums(int first_block, int n_blocks, unsigned 
     hipError_t e = hipMemsetAsync(d_out, 0, sizeof(unsigned long long) * (size_t)n_blocks, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(atanf_checksum_kernel, dim3(64, n_blocks), dim3(256), 0, stream, first_block, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_bin_paths_selftest(int mode, unsigned long long seed, unsigned long long n, int R, int S, double max_radius, unsigned long long *d_out2, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(d_out2, 0, 2 * sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(bin_paths_selftest_kernel, dim3(2048), dim3(256), 0, stream, mode, seed, n, R, S, max_radius, d_out2);
     return hipGetLastError();
 }
 

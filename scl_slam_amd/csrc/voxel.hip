@@ -86,12 +86,23 @@ __device__ __forceinline__ void vox_setup_kernel_body(const float *part, const i
     }
     if (threadIdx.x != 0) return;
     st->nfinite = tot; st->overflow = 0; st->nout = 0;
+    // PCL: min_b = int(floor(min * inv)), the voxel count dx dy dz against int32's range in 64 bits.  A bound outside int32 (a stray
+    // point at 1e12 m, a leaf of 1e-9) makes the cast undefined there and the 64-bit product wrap here: found by UBSan in the checker's
+    // copy of this test (make sanitize) -- such a cloud is "too large for the leaf" like any other (the input comes back unfiltered)
+    bool big = false;
     for (int a = 0; a < 3; ++a) {
         st->mn[a] = mn[a]; st->mx[a] = mx[a];
-        st->minb[a] = tot ? (long long)floorf(mn[a] * inv) : 0;
-        st->divb[a] = tot ? (long long)floorf(mx[a] * inv) - st->minb[a] + 1 : 1;
+        const float lo = tot ? floorf(mn[a] * inv) : 0.f, hi = tot ? floorf(mx[a] * inv) : 0.f;
+        const bool in_range = lo >= -2147483648.f && hi <= 2147483520.f;      // (NaN fails)
+        big |= !in_range;
+        st->minb[a] = in_range ? (long long)lo : 0;
+        st->divb[a] = in_range ? (long long)hi - st->minb[a] + 1 : 1;
     }
-    if (st->divb[0] * st->divb[1] * st->divb[2] > 2147483647LL) st->overflow = 1;
+    if (big || st->divb[0] > 2147483647LL || st->divb[1] > 2147483647LL || st->divb[2] > 2147483647LL) st->overflow = 1;
+    else {
+        const long long xy = st->divb[0] * st->divb[1];                         // < 2^62
+        if (xy > 2147483647LL || xy * st->divb[2] > 2147483647LL) st->overflow = 1;
+    }
 }
 
 __global__ __launch_bounds__(64) void vox_setup_kernel(const float *part, const int *cnt, int nblocks, float inv, VoxState *st)

@@ -140,6 +140,7 @@ def _bind(lib):
         "scl_host_unregister": (c_int, [P, c_void_p]),
         "scl_selftest_atanf_blocks": (c_int, [P, c_int, c_int, POINTER(ctypes.c_uint64)]),
         "scl_host_copy_rate": (c_int, [P, ctypes.c_size_t, c_int, dp]),
+        "scl_selftest_bin_paths": (c_int, [P, c_int, c_uint64, c_uint64, POINTER(ctypes.c_uint64), POINTER(ctypes.c_uint64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -296,6 +297,11 @@ class ScanContextEngine:
         g = c_double()
         self._check(self._lib.scl_host_copy_rate(self._h, nbytes, reps, byref(g)), "scl_host_copy_rate")
         return g.value
+
+    def selftest_bin_paths(self, mode, seed, n_points):
+        bad, sure = ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self._lib.scl_selftest_bin_paths(self._h, mode, seed, n_points, byref(bad), byref(sure)), "scl_selftest_bin_paths")
+        return bad.value, sure.value
 
     def selftest_atanf_blocks(self, first_block, n_blocks):
         out = np.zeros(n_blocks, dtype=np.uint64)

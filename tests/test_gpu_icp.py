@@ -172,6 +172,12 @@ def test_voxel_grid_bit_exact(eng, n, leaf, stride):
 def test_voxel_grid_overflow_returns_input(eng):
     huge = np.zeros((2, 8), np.float32); huge[1, :3] = 1e6
     assert np.array_equal(eng.voxel_grid(huge, 0.001), huge)
+    # bounds outside int32 / a voxel count that wraps 64 bits (UBSan found the wrap in the checker: make sanitize): a stray point far
+    # out, three axes of ~2^22 voxels (2^66 in all), float extremes -- all "too large for the leaf", the input comes back
+    for far, leaf in ((1e12, 0.4), (4.2e3, 0.001), (3e38, 0.4), (-3e38, 1e-3)):
+        c = synth_structured_cloud(500, seed=3); c[17, :3] = far
+        assert oi.voxel_grid(c, leaf) is None
+        assert np.array_equal(eng.voxel_grid(c, leaf).view(np.uint32), c.view(np.uint32))
 
 
 def test_submap_assembly_matches_oracle(eng):

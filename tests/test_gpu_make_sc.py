@@ -210,3 +210,20 @@ def test_stream_from_points_equals_scan_by_scan_calls_and_the_checker(R, S, n0, 
             assert nn[i] == -1
     assert eng.get_size() == n0 + n_scans
     eng.close(); one.close()
+
+
+@pytest.mark.parametrize("R,S", [(20, 60), (64, 120), (80, 180)])
+def test_fast_binning_never_disagrees_with_the_references_chain(R, S):
+    """The scatter takes a point's (ring, sector, dropped?) from cheap approximations wherever those are provably the reference's
+    integers (csrc/device_common.hpp: sc_bin_fast, guards = four times the derived error) and from the reference's chain
+    (D.h:1425-1435) elsewhere.  On the device: 2^28 uniform points, 2^26 points hugging ring boundaries to a few float steps, 2^26
+    hugging sector boundaries to micro-degrees and every pair of special values -- wherever the fast path answers, the chain agrees."""
+    eng = ScanContextEngine(num_ring=R, num_sector=S)
+    total_sure = 0
+    for mode, n in ((0, 1 << 28), (1, 1 << 26), (2, 1 << 26), (3, 1 << 16)):
+        bad, sure = eng.selftest_bin_paths(mode, 20260105 + mode, n)
+        assert bad == 0, (mode, bad, sure)
+        total_sure += sure
+        if mode == 0:
+            assert sure > 0.995 * n              # ... and it answers nearly always
+    eng.close()

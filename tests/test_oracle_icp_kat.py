@@ -135,6 +135,9 @@ def test_voxel_grid_known_answers():
     assert oi.voxel_grid(np.zeros((0, 8), np.float32), 0.2).shape[0] == 0
     huge = np.zeros((2, 8), np.float32); huge[1, :3] = 1e6
     assert oi.voxel_grid(huge, 0.001) is None              # index range overflows int32: PCL refuses
+    for far, leaf in ((1e12, 0.4), (4.2e3, 0.001), (3e38, 0.4)):   # bounds outside int32, a voxel count past 2^63: refused without wrapping (UBSan)
+        huge[1, :3] = far
+        assert oi.voxel_grid(huge, leaf) is None
 
 
 def test_voxel_grid_reduces_and_preserves_mean():
