@@ -17,6 +17,9 @@
 #include "scl_engine.h"
 #include "scl_messages.h"
 
+// the codec itself, in this translation unit (host C++: the file has no device code)
+#include "messages.hip"
+
 static volatile uint64_t g_sink;
 
 static void touch(const void *p, size_t n)
