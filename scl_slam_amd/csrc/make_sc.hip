@@ -139,22 +139,41 @@ __global__ __launch_bounds__(256) void ingest_kernel(
     float *siv = sv + R * LS;
     double *svk = reinterpret_cast<double *>(sv + ((R * LS + S + 1) & ~1));     // [S] the sector key, for its norm
     double *sdd = svk + S;                                                      // [S] squared rounding errors of the fp16 sector key
+    // (eight loads of a thread in flight before the first is used, from a clamped index: a load per loop step, with the stores that
+    //  depend on it behind it, was thirty memory round trips one after the other -- most of this kernel's time)
+    constexpr int LU = 8;
+    const int cells = R * S;
     if (tiles) {
-        int *t = tiles + (size_t)blockIdx.x * R * S;
-        float *vo = vals_out ? vals_out + (size_t)blockIdx.x * R * S : nullptr;
+        int *t = tiles + (size_t)blockIdx.x * cells;
+        float *vo = vals_out ? vals_out + (size_t)blockIdx.x * cells : nullptr;
         const int init = float_to_ordered((float)kNoPoint);
-        for (int i = threadIdx.x; i < R * S; i += blockDim.x) {
-            const int r = fastdiv(i, mS), c = i - r * S;
-            float v = ordered_to_float(t[i]);
-            if (v == (float)kNoPoint) v = 0.0f;                        // D.h:1450-1453
-            sv[r * LS + c] = v;
-            if (vo) vo[i] = v;                                         // row-major == vT order, D.h:1454
-            t[i] = init;
+        for (int i0 = threadIdx.x; i0 < cells; i0 += LU * (int)blockDim.x) {
+            int o[LU];
+#pragma unroll
+            for (int u = 0; u < LU; ++u) { const int i = i0 + u * (int)blockDim.x; o[u] = t[i < cells ? i : cells - 1]; }
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const int i = i0 + u * (int)blockDim.x;
+                if (i < cells) {
+                    const int r = fastdiv(i, mS), c = i - r * S;
+                    float v = ordered_to_float(o[u]);
+                    if (v == (float)kNoPoint) v = 0.0f;                // D.h:1450-1453
+                    sv[r * LS + c] = v;
+                    if (vo) vo[i] = v;                                 // row-major == vT order, D.h:1454
+                    t[i] = init;
+                }
+            }
         }
     } else {
-        for (int i = threadIdx.x; i < R * S; i += blockDim.x) {
-            const int r = fastdiv(i, mS), c = i - r * S;
-            sv[r * LS + c] = src[i];
+        for (int i0 = threadIdx.x; i0 < cells; i0 += LU * (int)blockDim.x) {
+            float o[LU];
+#pragma unroll
+            for (int u = 0; u < LU; ++u) { const int i = i0 + u * (int)blockDim.x; o[u] = src[i < cells ? i : cells - 1]; }
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const int i = i0 + u * (int)blockDim.x;
+                if (i < cells) { const int r = fastdiv(i, mS), c = i - r * S; sv[r * LS + c] = o[u]; }
+            }
         }
     }
     __syncthreads();
@@ -172,6 +191,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(
         dslot[i] = make_float4(v[0], v[1], v[2], v[3]);
     }
     // sector key (column mean, D.h:1482-1486) and column norm (D.h:1523), sequential over rings
+    double my_norm = 0.0;
     for (int c = threadIdx.x; c < S; c += blockDim.x) {
         double sum = 0.0, ss = 0.0;
         for (int r = 0; r < R; ++r) {
@@ -183,6 +203,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(
         svk[c] = sum / (double)R;
         const double nrm = sqrt(ss);
         norm[(size_t)slot * S + c] = nrm;
+        my_norm = nrm;                                   // (S <= blockDim: a thread owns at most one column, in this loop and in the bound's below)
         // screening pass operand (sc_screen.hip): fp32 reciprocal norm; 0 = all-zero column, NaN = score this keyframe exactly
         float iv = __int_as_float(0x7fc00000);
         if (nrm == 0.0) iv = 0.0f;
@@ -318,7 +339,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(
         const float iv = siv[c];
         double e2 = 0.0;
         if (iv == iv && iv != 0.0f) {
-            const double rn = 1.0 / norm[(size_t)slot * S + c];   // (x * (1 / norm): two roundings from x / norm, covered by the bound's 1e-6)
+            const double rn = 1.0 / my_norm;   // (x * (1 / norm): two roundings from x / norm, covered by the bound's 1e-6)
             for (int r = 0; r < R; ++r) {
                 const float x = sv[r * LS + c];
                 const double h = (double)(float)(_Float16)(x * iv), u = (double)x * rn;

@@ -396,11 +396,20 @@ __global__ __launch_bounds__(kSmallWaves * kWave) void sc_small_exact_kernel(Sma
     float rv[U];
     for (int sw = 0; sw < sweeps; ++sw) {
         float av[U];
+        // (UNCONDITIONAL loads from a clamped position, the out-of-range values substituted afterwards: `i < n ? load : constant` made
+        //  every load a block of its own that ended with s_waitcnt vmcnt(0) -- forty dependent round trips where this comment's first
+        //  line promised all of them in flight, most of the kernel's 22 us; round 5, found in the descriptor scatter first)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = sw * U * NT + u * NT + (int)threadIdx.x, ic = i < q.n ? i : q.n - 1;
+            av[u] = q.approx[ic];
+            rv[u] = q.ring_d2[ic];
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = sw * U * NT + u * NT + (int)threadIdx.x;
-            av[u] = i < q.n ? q.approx[i] : __int_as_float(0x7f800000);
-            rv[u] = i < q.n ? q.ring_d2[i] : 3.402823466e+38f;
+            av[u] = i < q.n ? av[u] : __int_as_float(0x7f800000);
+            rv[u] = i < q.n ? rv[u] : 3.402823466e+38f;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {

@@ -104,3 +104,49 @@ def test_appends_get_in_between_the_chunks_of_a_long_stream_call():
             assert g[:3] == o[:3] and np.float64(g[3]).view(np.uint64) == np.float64(o[3]).view(np.uint64), (cur, g, o)
     finally:
         e.close(); db.close()
+
+
+def test_staged_queries_survive_a_capacity_doubling_between_the_chunks_of_a_stream_call():
+    """a staged query (id -1) lives in a row BEHIND the database slots (index cap + j), so its slot number changes when an
+    append doubles the capacity while a stream call waits for a chunk: the next chunk's alignment was enqueued with the old slot, its
+    products are built with the new one.  The stream's scans alternate between the staged query and a keyframe holding the SAME
+    descriptor; with appends doubling the capacity twice inside the call every staged scan must still equal its keyframe twin."""
+    R, S, n0, extra = 64, 120, 1500, 1700
+    descs = synth_descriptors(n0 + extra, R, S, seed=12, revisit_frac=0.05)
+    e = ScanContextEngine(num_ring=R, num_sector=S, num_candidates=3, num_exclude_recent=100, initial_capacity=n0 + 8)   # 1508 -> 3016 -> 6032
+    try:
+        e.save_bulk(descs[:n0])
+        twin = n0 - 7
+        e.stage_query(descs[twin])
+        scans = 6144
+        qs = np.where(np.arange(scans) % 2 == 0, -1, twin).astype(np.int32)
+        his = np.full(scans, n0 - 100, dtype=np.int32)
+        alone = e.detect_full_stream(qs, 0, his, 16, 2)
+        assert np.array_equal(alone[0][0::2], alone[0][1::2]) and np.array_equal(alone[2][0::2].view(np.uint64), alone[2][1::2].view(np.uint64))
+        errors, started, span = [], threading.Event(), {}
+
+        def appender():
+            try:
+                started.wait()
+                for i in range(n0, n0 + extra):
+                    e.save_from_wire(descs[i], 0, i)
+            except Exception as ex:                              # noqa: BLE001
+                errors.append(ex)
+
+        def streamer():
+            try:
+                started.set()
+                span["res"] = e.detect_full_stream(qs, 0, his, 16, 2)
+            except Exception as ex:                              # noqa: BLE001
+                errors.append(ex)
+
+        ta, ts = threading.Thread(target=appender), threading.Thread(target=streamer)
+        ta.start(); ts.start(); ts.join(); ta.join()
+        assert not errors, errors
+        got = span["res"]
+        assert np.array_equal(got[0], alone[0]) and np.array_equal(got[1], alone[1]) and np.array_equal(got[2].view(np.uint64), alone[2].view(np.uint64))
+        assert e.get_size() == n0 + extra
+        # the staged query is still where the engine says it is
+        assert e.detect_full_range(-1, 0, n0 - 100) == e.detect_full_range(twin, 0, n0 - 100)
+    finally:
+        e.close()
