@@ -687,12 +687,11 @@ int scl_destroy(scl_engine *e)
     dev_free(e->d_vals); dev_free(e->d_points); dev_free(e->d_tiles);
     for (int b = 0; b < 3; ++b) {
         dev_free(e->d_pbuf[b]);
-        if (e->ev_copied[b]) (void)hipEventDestroy(e->ev_copied[b]);
-        if (e->ev_copied2[b]) (void)hipEventDestroy(e->ev_copied2[b]);
+        for (int c = 0; c < scl_engine::kCopyStreams; ++c) if (e->ev_copied[c][b]) (void)hipEventDestroy(e->ev_copied[c][b]);
         if (e->ev_consumed[b]) (void)hipEventDestroy(e->ev_consumed[b]);
     }
     if (e->stream_copy) { (void)hipStreamSynchronize(e->stream_copy); (void)hipStreamDestroy(e->stream_copy); }
-    if (e->stream_copy2) { (void)hipStreamSynchronize(e->stream_copy2); (void)hipStreamDestroy(e->stream_copy2); }
+    for (hipStream_t cs : e->stream_copy_x) if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
     for (void *hp : e->host_allocs) (void)hipHostFree(hp);
     dev_free(e->d_dist); dev_free(e->d_shift); dev_free(e->d_cand); dev_free(e->d_ring_d2);
     dev_free(e->d_approx); dev_free(e->d_starts); dev_free(e->d_surv); dev_free(e->d_nsurv); dev_free(e->d_tmin); dev_free(e->d_part);
@@ -1968,6 +1967,8 @@ int scl_detect_full_stream(scl_engine *e, const int *queries, const int *lo, con
 
 namespace {
 
+constexpr int kDefaultCopyStreams = 2;
+
 // The per-incoming-scan pipeline from raw points (DM.h:988-1025 makeDescriptors once per keyframe, then DM.h:1078 detection):
 // the scans go through in GROUPS of up to kMaxScBatch.  A group's clouds are copied into one of three device buffers on the copy
 // stream -- by DMA when the caller's buffers are pinned (scl_host_alloc / scl_host_register) -- while the group before is binned (one
@@ -2000,13 +2001,16 @@ int points_pipeline_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
     for (int g = 0; g < ng; ++g) { const size_t b = group_bytes(g, nullptr); need = b > need ? b : need; }
     const int nbuf = ng < 3 ? ng : 3;
     if (!e->stream_copy) SCL_HIP(e, hipStreamCreateWithFlags(&e->stream_copy, hipStreamNonBlocking));
-    // a second copy stream: a cloud is one copy of a megabyte or two, and the copies of ONE stream run strictly one after the other,
-    // each with its own start-up; two streams keep a second DMA engine's copy in flight while the first one's is being set up
-    const int ncs = scl_lab_int("SCL_COPY_STREAMS", 2);
-    if (ncs > 1 && !e->stream_copy2) SCL_HIP(e, hipStreamCreateWithFlags(&e->stream_copy2, hipStreamNonBlocking));
+    // several copy streams: a cloud is one copy of a megabyte or two, and the copies of ONE stream run strictly one after the other,
+    // each with its own start-up (17 us: 44.8 GB/s for cloud-sized copies against 56.8 for one large copy); with the clouds of a group
+    // dealt over several streams another copy is in flight while one is being set up
+    const int ncs = std::min(std::max(scl_lab_int("SCL_COPY_STREAMS", kDefaultCopyStreams), 1), (int)scl_engine::kCopyStreams);
+    auto cstream = [&](int c) { return c == 0 ? e->stream_copy : e->stream_copy_x[c - 1]; };
+    for (int c = 1; c < ncs; ++c)
+        if (!e->stream_copy_x[c - 1]) SCL_HIP(e, hipStreamCreateWithFlags(&e->stream_copy_x[c - 1], hipStreamNonBlocking));
     for (int b = 0; b < 3; ++b) {
-        if (!e->ev_copied[b]) SCL_HIP(e, hipEventCreateWithFlags(&e->ev_copied[b], hipEventDisableTiming));
-        if (!e->ev_copied2[b]) SCL_HIP(e, hipEventCreateWithFlags(&e->ev_copied2[b], hipEventDisableTiming));
+        for (int c = 0; c < ncs; ++c)
+            if (!e->ev_copied[c][b]) SCL_HIP(e, hipEventCreateWithFlags(&e->ev_copied[c][b], hipEventDisableTiming));
         if (!e->ev_consumed[b]) SCL_HIP(e, hipEventCreateWithFlags(&e->ev_consumed[b], hipEventDisableTiming));
     }
     if (need > e->pbuf_cap || !e->d_pbuf[nbuf - 1]) {      // (nothing of an earlier call is in flight: every call ends with its last group consumed)
@@ -2023,24 +2027,19 @@ int points_pipeline_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
         const int b = g % 3;
         size_t off[G];
         group_bytes(g, off);
-        if (g >= 3) {                                        // the group that was binned out of this buffer
-            SCL_HIP(e, hipStreamWaitEvent(e->stream_copy, e->ev_consumed[b], 0));
-            if (ncs > 1) SCL_HIP(e, hipStreamWaitEvent(e->stream_copy2, e->ev_consumed[b], 0));
-        }
+        if (g >= 3)                                          // the group that was binned out of this buffer
+            for (int c = 0; c < ncs; ++c) SCL_HIP(e, hipStreamWaitEvent(cstream(c), e->ev_consumed[b], 0));
         for (int i = g * G; i < n_scans && i < (g + 1) * G; ++i) {
             const size_t bytes = (size_t)n_points[i] * (size_t)stride_bytes;
-            hipStream_t cs = (ncs > 1 && (i & 1)) ? e->stream_copy2 : e->stream_copy;
-            if (bytes) SCL_HIP(e, hipMemcpyAsync(e->d_pbuf[b] + off[i - g * G], clouds[i], bytes, hipMemcpyHostToDevice, cs));
+            if (bytes) SCL_HIP(e, hipMemcpyAsync(e->d_pbuf[b] + off[i - g * G], clouds[i], bytes, hipMemcpyHostToDevice, cstream(i % ncs)));
         }
-        SCL_HIP(e, hipEventRecord(e->ev_copied[b], e->stream_copy));
-        if (ncs > 1) SCL_HIP(e, hipEventRecord(e->ev_copied2[b], e->stream_copy2));
+        for (int c = 0; c < ncs; ++c) SCL_HIP(e, hipEventRecord(e->ev_copied[c][b], cstream(c)));
         return SCL_OK;
     };
     // error path: nothing may still read the caller's buffers or write the point buffers when the call returns
     auto bail = [&](int code) {
         const std::string first = e->last_error;
-        (void)hipStreamSynchronize(e->stream_copy);
-        if (e->stream_copy2) (void)hipStreamSynchronize(e->stream_copy2);
+        for (int c = 0; c < ncs; ++c) (void)hipStreamSynchronize(cstream(c));
         (void)hipStreamSynchronize(e->stream);
         e->last_error = first;
         return code;
@@ -2055,8 +2054,8 @@ int points_pipeline_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
         group_bytes(g, off);
         const unsigned char *dptr[G];
         for (int j = 0; j < m; ++j) dptr[j] = e->d_pbuf[b] + off[j];
-        if (hipStreamWaitEvent(e->stream, e->ev_copied[b], 0) != hipSuccess) return bail(fail(e, SCL_ERR_HIP, "hipStreamWaitEvent(copied)"));
-        if (ncs > 1 && hipStreamWaitEvent(e->stream, e->ev_copied2[b], 0) != hipSuccess) return bail(fail(e, SCL_ERR_HIP, "hipStreamWaitEvent(copied2)"));
+        for (int c = 0; c < ncs; ++c)
+            if (hipStreamWaitEvent(e->stream, e->ev_copied[c][b], 0) != hipSuccess) return bail(fail(e, SCL_ERR_HIP, "hipStreamWaitEvent(copied)"));
         if ((rc = group_scatter(e, dptr, n_points + i0, m, stride_bytes, e->stream))) return bail(rc);
         if (hipEventRecord(e->ev_consumed[b], e->stream) != hipSuccess) return bail(fail(e, SCL_ERR_HIP, "hipEventRecord(consumed)"));
         if ((rc = ensure_capacity(e, e->n + m))) return bail(rc);   // (no-op unless another thread appended while a group's detection waited)

@@ -82,8 +82,10 @@ struct scl_engine {
     // the pipelined forms (scl_make_and_save_many, scl_stream_from_points): three device buffers for a group's clouds, filled by the
     // copy stream while the group before is binned, ingested and searched for
     unsigned char *d_pbuf[3] = {nullptr, nullptr, nullptr}; size_t pbuf_cap = 0;
-    hipStream_t stream_copy = nullptr, stream_copy2 = nullptr;
-    hipEvent_t ev_copied[3] = {nullptr, nullptr, nullptr}, ev_copied2[3] = {nullptr, nullptr, nullptr}, ev_consumed[3] = {nullptr, nullptr, nullptr};
+    static constexpr int kCopyStreams = 4;
+    hipStream_t stream_copy = nullptr;                      // copy stream 0 (also scl_host_copy_rate's)
+    hipStream_t stream_copy_x[kCopyStreams - 1] = {nullptr, nullptr, nullptr};   // copy streams 1..
+    hipEvent_t ev_copied[kCopyStreams][3] = {}, ev_consumed[3] = {nullptr, nullptr, nullptr};
     std::vector<void *> host_allocs;                       // scl_host_alloc (pinned), freed with the engine at the latest
     double *d_dist = nullptr; int *d_shift = nullptr; int *d_cand = nullptr; float *d_ring_d2 = nullptr; size_t pair_cap = 0;
     // screening pass of the full-DB mode (sc_screen.hip): approximate distances, survivors, their counts, min d~ words
