@@ -550,6 +550,16 @@ def secondary_adversarial_survivors(device, shard, queries, n_elig, frac=0.05, s
 # ------------------------------------------------------------------------------------------------
 # secondary: the front half of the per-incoming-scan path -- raw points -> descriptor -> database slot (K3), ring-key scan (K2)
 # ------------------------------------------------------------------------------------------------
+def _distinct_scan(base, i):
+    """scan i of a stream: a base cloud with its own heights on a third of the points -- a different descriptor (scans that repeat are
+    exact duplicates of keyframes already in the database: dozens of survivors at distance 0 per scan, the adversarial case)"""
+    rs = np.random.RandomState(9000 + i)
+    c = base.copy()
+    m = rs.rand(c.shape[0]) < 0.3
+    c[m, 2] += rs.uniform(0.0, 3.0, int(m.sum())).astype(np.float32)
+    return c
+
+
 def _p50_us(fn, reps, warm=3):
     lat = []
     for i in range(reps + warm):
@@ -631,21 +641,21 @@ def secondary_stream_from_points(device, n=N_KEYFRAMES_1GPU, npts=120000, n_scan
     PCIe is the floor: the clouds of group g + 1 are copied while group g is binned, ingested and searched for."""
     from scl_slam_amd import ScanContextEngine
     from scl_slam_amd.synth import synth_descriptors, synth_scan
-    eng = ScanContextEngine(num_ring=R, num_sector=S, num_candidates=3, num_exclude_recent=N_EXCLUDE, device=device, initial_capacity=n + 2 * n_scans + 64)
+    eng = ScanContextEngine(num_ring=R, num_sector=S, num_candidates=3, num_exclude_recent=N_EXCLUDE, device=device, initial_capacity=n + 2 * n_scans + 256)
     eng.save_bulk(synth_descriptors(n, R, S, seed=1002))
+    bases = [synth_scan(npts, seed=500 + i, stride_floats=4) for i in range(batch)]
     pinned = []
-    for i in range(batch):
-        c = synth_scan(npts, seed=500 + i, stride_floats=4)
-        a = eng.host_alloc(c.shape); a[:] = c; pinned.append(a)
-    pageable = [np.array(a) for a in pinned]
-    seq = [pinned[i % batch] for i in range(n_scans)]
-    eng.stream_from_points(seq[:2 * batch])                                  # warm-up: buffers, streams, the stream form's sets
+    for i in range(n_scans + 2 * batch):                                     # every scan its own cloud, its own pinned buffer
+        a = eng.host_alloc(bases[0].shape); a[:] = _distinct_scan(bases[i % batch], i); pinned.append(a)
+    pageable = [np.array(a) for a in pinned[:4 * batch]]
+    warm, seq = pinned[n_scans:], pinned[:n_scans]
+    eng.stream_from_points(warm)                                             # warm-up: buffers, streams, the stream form's sets
     n_before = eng.get_size()
     t0 = time.perf_counter()
     nn, sh, dd = eng.stream_from_points(seq)
     dt = time.perf_counter() - t0
     pairs = int(sum(max(0, n_before + i - N_EXCLUDE) for i in range(n_scans)))
-    seq_p = [pageable[i % batch] for i in range(4 * batch)]
+    seq_p = pageable
     t0 = time.perf_counter()
     eng.stream_from_points(seq_p)
     dt_p = time.perf_counter() - t0
@@ -662,6 +672,42 @@ def secondary_stream_from_points(device, n=N_KEYFRAMES_1GPU, npts=120000, n_scan
                      "note": "floor = bytes per scan / the rate one large pinned hipMemcpyAsync reaches on this box"},
             "pageable_host_memory": {"us_per_scan": dt_p / len(seq_p) * 1e6, "scans": len(seq_p),
                                      "note": "the same call from ordinary (pageable) buffers: the runtime stages every copy through its own pinned memory"}}
+
+
+def secondary_stream_from_resident_points(device, n=N_KEYFRAMES_1GPU, npts=120000, n_scans=512):
+    """The per-incoming-scan path of BASELINE configs[1] with its INPUTS RESIDENT IN HBM (the clouds in the on-device keyframe store):
+    per scan descriptor build (K3) + append + ring-key scan (K2) + shifted SC distance against every eligible keyframe + arg-min (K1),
+    through scl_stream_from_store.  This is the rate `value` would be if its timed region started at the raw points instead of at the
+    ingested keyframe."""
+    from scl_slam_amd import ScanContextEngine
+    from scl_slam_amd.synth import synth_descriptors, synth_scan
+    eng = ScanContextEngine(num_ring=R, num_sector=S, num_candidates=3, num_exclude_recent=N_EXCLUDE, device=device, initial_capacity=n + 3 * n_scans + 128)
+    eng.save_bulk(synth_descriptors(n, R, S, seed=1002))
+    bases = [np.ascontiguousarray(synth_scan(npts, seed=700 + i, stride_floats=4)) for i in range(16)]
+    for i in range(2 * n_scans + 64):
+        eng.keyframe_put(0, i, _distinct_scan(bases[i % 16], i))         # every keyframe its own cloud
+    eng.stream_from_store(0, 0, n_scans)                                    # warm-up (buffers, the stream form's sets)
+    n_before = eng.get_size()
+    t0 = time.perf_counter()
+    nn, sh, dd = eng.stream_from_store(0, n_scans, n_scans)
+    dt = time.perf_counter() - t0
+    eng.profile_reset(); eng.profile_enable(1)                              # the front's share by HIP events, in a call of its own (an event pair per launch slows the call)
+    eng.stream_from_store(0, 2 * n_scans, 64)
+    eng.profile_enable(0)
+    prof = eng.profile()
+    eng.close()
+    pairs = int(sum(max(0, n_before + i - N_EXCLUDE) for i in range(n_scans)))
+    front_us = (prof["make_sc_ms"] + prof["ingest_ms"]) * 1e3 / 64
+    # bytes by SURVEY 8(d): K3 per scan + K1's launch groups (the database once per 16 scans) + K2 per scan
+    groups = n_scans / 16.0
+    algo = n_scans * (npts * 16 + R * S * 4) + groups * (n + n_scans / 2) * KERNEL_BYTES_PER_KEYFRAME + pairs * KERNEL_BYTES_PER_PAIR_IO
+    return {"workload": f"{n_scans} scans of {npts} points resident in HBM (keyframe store) through scl_stream_from_store on a {n}-keyframe 64x120 database: "
+                        f"descriptor + append + full-database detection per scan",
+            "scans_per_s": n_scans / dt, "us_per_scan": dt / n_scans * 1e6, "value": pairs / dt, "unit": "pairs/s", "winners_found": int((nn >= 0).sum()),
+            "front_device_us_per_scan": front_us,
+            "roofline": {"bound": "hbm", "achieved": algo / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / dt / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": algo,
+                         "pricing": "SURVEY 8(d): K3 n x 16 + R x S x 4 B per scan, + the screening launch groups' bytes (the database once per 16 scans, per-pair "
+                                    "intermediates) over the wall clock of the whole call"}}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1007,7 +1053,8 @@ def main():
                          "front stage (raw points -> descriptor -> slot) is secondary.ingest_per_scan (device time and roofline, K3), the ring-key "
                          "scan on its own secondary.ringkey_topk (K2), and the whole path from host point clouds -- PCIe inclusive, descriptor + "
                          "append + full-database detection per scan -- is secondary.stream_from_points, an order of magnitude below value because "
-                         "a scan's 1.9 MB cross PCIe in 34 us",
+                         "a scan's 1.9 MB cross PCIe in 34 us; the same path with the raw points resident in HBM (K3 + K2 + K1 per scan, nothing "
+                         "but results over PCIe) is secondary.stream_from_resident_points",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": f"screening launch group of {k1_scans:.0f} scans x {n_elig} keyframes: sc_screen2_kernel (products: one keyframe "
@@ -1048,7 +1095,8 @@ def main():
                              #  3.8 ms per point-to-plane query)
                              ("ringkey_topk", lambda: secondary_ringkey_topk(eng, n_elig, n_query)),
                              ("ingest_per_scan", lambda: secondary_ingest_per_scan(local_rank)),
-                             ("stream_from_points", lambda: secondary_stream_from_points(local_rank))):
+                             ("stream_from_points", lambda: secondary_stream_from_points(local_rank)),
+                             ("stream_from_resident_points", lambda: secondary_stream_from_resident_points(local_rank))):
                 if args.only_secondary and name not in args.only_secondary.split(","):
                     continue
                 try:
@@ -1087,6 +1135,8 @@ def main():
             "ringkey_topk_k3_device_us": pick(sec, "ringkey_topk", "k3", "device_us"),
             "ingest_device_us_per_scan_64x120_120k": pick(sec, "ingest_per_scan", "64x120_120k_points", "device_us_per_scan_in_a_batch_of_16"),
             "ingest_roofline_frac_64x120_120k": pick(sec, "ingest_per_scan", "64x120_120k_points", "roofline", "frac"),
+            "resident_points_pairs_per_s": pick(sec, "stream_from_resident_points", "value"),
+            "resident_points_us_per_scan": pick(sec, "stream_from_resident_points", "us_per_scan"),
             "stream_from_points_scans_per_s": pick(sec, "stream_from_points", "scans_per_s"),
             "stream_from_points_pairs_per_s": pick(sec, "stream_from_points", "value"),
             "stream_from_points_over_pcie_floor": pick(sec, "stream_from_points", "pcie", "us_per_scan_over_floor"),

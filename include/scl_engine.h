@@ -148,6 +148,12 @@ int  scl_make_and_save_many(scl_engine *e, const void *const *clouds, const int 
  * scl_make_and_save_many; the caller applies the threshold (dist < dist_thres, D.h:1662). */
 int  scl_stream_from_points(scl_engine *e, const void *const *clouds, const int *n_points, int n_scans, int stride_bytes,
                             const int8_t *robots, const int *indexs, int *nn_idx, int *shift, double *dist, float *out_values);
+/* The same for keyframes whose clouds are already in the on-device keyframe store (scl_keyframe_put, DM.h:674): keyframes
+ * first_index .. first_index + count - 1 of `robot` get their descriptors built from the stored clouds and are appended as
+ * (robot, index); then each is searched for over [0, key - NUM_EXCLUDE_RECENT).  Nothing crosses PCIe but the results (and the
+ * descriptor values when out_values is given): the path's rate with its inputs resident in HBM.  Same results as
+ * scl_stream_from_points on the same clouds. */
+int  scl_stream_from_store(scl_engine *e, int robot, int first_index, int count, int *nn_idx, int *shift, double *dist, float *out_values);
 /* Pinned host memory for point clouds: a cloud handed over from such a buffer goes to the device by DMA, without the runtime's
  * staging copy, and overlaps the kernels of the scans before it.  scl_host_alloc buffers are freed by scl_host_free or with the
  * engine; scl_host_register pins memory the caller owns (e.g. a pcl::PointCloud's points) until scl_host_unregister. */

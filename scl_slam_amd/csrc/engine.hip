@@ -318,11 +318,11 @@ int ensure_tiles(scl_engine *e, hipStream_t s)
 {
     int rc;
     if (!e->d_tiles) {
-        if ((rc = dev_alloc(e, &e->d_tiles, (size_t)kMaxScBatch * e->R * e->S))) return rc;
+        if ((rc = dev_alloc(e, &e->d_tiles, (size_t)2 * kMaxScBatch * e->R * e->S))) return rc;   // two sets: the resident path scatters group g + 1 beside the ingest of group g
         e->tiles_clean = false;
     }
     if (!e->tiles_clean) {                                   // first use, or a call that failed between scatter and consumer
-        SCL_HIP(e, launch_make_sc_tiles_init(e->d_tiles, kMaxScBatch, e->R, e->S, s));
+        SCL_HIP(e, launch_make_sc_tiles_init(e->d_tiles, 2 * kMaxScBatch, e->R, e->S, s));
         e->tiles_clean = true;
     }
     return SCL_OK;
@@ -2082,6 +2082,94 @@ int points_pipeline_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
 }
 
 }  // namespace
+
+namespace {
+
+// The same path for clouds that are ALREADY on the device (the keyframe store): with no copy to hide, the groups' two launches go
+// back to back on the stream (16 scans each), and the detection of all the new keyframes is ONE call of the stream form -- whose
+// launch groups overlap (a group's finishing rides beside the next group's alignment), which separate calls per group of 16 cannot.
+int device_points_pipeline_locked(scl_engine *e, std::unique_lock<std::mutex> &db, const unsigned char *const *d_clouds, const int *n_points,
+                                  int n_scans, int stride_bytes, const int8_t *robots, const int *indexs, float *out_values,
+                                  int *nn_idx, int *shift, double *dist)
+{
+    int rc;
+    if (n_scans == 0) return SCL_OK;
+    constexpr int G = kMaxScBatch;
+    const size_t cells = (size_t)e->R * e->S;
+    if ((rc = ensure_capacity(e, e->n + n_scans))) return rc;
+    const int first_key = e->n;
+    if ((rc = ensure_tiles(e, e->stream))) return rc;
+    if ((rc = ensure_vals(e, cells * (size_t)(2 * G)))) return rc;
+    for (int i = 0; i < n_scans; ++i)
+        if (n_points[i] < 0 || (n_points[i] > 0 && !d_clouds[i])) return fail(e, SCL_ERR_INVALID_ARG, "stored cloud without points");
+    // launch g = [ingest of group g - 1 out of tile set (g - 1) & 1] + [scatter of group g into tile set g & 1]: ng + 1 launches back to back
+    const int ng = (n_scans + G - 1) / G;
+    const int slice = scl_lab_int("SCL_SC_SLICE", e->R * e->S > 10000 ? 2 * kScPointsPerWorkgroup : kScPointsPerWorkgroup);
+    e->tiles_clean = false;
+    for (int g = 0; g <= ng; ++g) {
+        ScanBatch b{};
+        if (g < ng) {
+            const int i0 = g * G;
+            b.count = n_scans - i0 < G ? n_scans - i0 : G;
+            for (int j = 0; j < b.count; ++j) { b.points[j] = d_clouds[i0 + j]; b.n[j] = n_points[i0 + j]; }
+        }
+        IngestArgs ia{};
+        int n_ingest = 0;
+        ia.R = e->R; ia.S = e->S;
+        if (g > 0) {
+            const int i0 = (g - 1) * G;
+            n_ingest = n_scans - i0 < G ? n_scans - i0 : G;
+            ia = IngestArgs{nullptr, first_key + i0, e->d_desc, e->d_vkey, e->d_norm, e->d_rkey, e->d_rkey4, e->d_hdesc, e->d_kmask, e->d_hkey, e->hstride, e->cap,
+                            e->R, e->S, e->d_halign, e->d_tiles + (size_t)((g - 1) & 1) * G * cells, e->d_vals + (size_t)((g - 1) & 1) * G * cells};
+        }
+        {
+            ProfScope ps(e, P_MAKESC);
+            SCL_HIP(e, launch_front_fused(b, stride_bytes, e->cfg.lidar_height, e->cfg.max_radius, e->d_tiles + (size_t)(g & 1) * G * cells, slice, ia, n_ingest, e->stream));
+        }
+        if (g > 0 && out_values) {
+            const int i0 = (g - 1) * G;
+            SCL_HIP(e, hipMemcpyAsync(out_values + (size_t)i0 * cells, e->d_vals + (size_t)((g - 1) & 1) * G * cells, sizeof(float) * cells * (size_t)n_ingest,
+                                      hipMemcpyDeviceToHost, e->stream));
+        }
+    }
+    e->tiles_clean = true;
+    e->db_version++;
+    for (int i = 0; i < n_scans; ++i) {
+        e->robots.push_back(robots ? robots[i] : (int8_t)0);
+        e->indexs.push_back(indexs ? indexs[i] : first_key + i);
+    }
+    e->prof.make_sc_points += e->prof_on ? [&] { uint64_t t = 0; for (int i = 0; i < n_scans; ++i) t += (uint64_t)n_points[i]; return t; }() : 0;
+    e->n += n_scans;
+    std::vector<int> q((size_t)n_scans), lo((size_t)n_scans, 0), hi((size_t)n_scans);
+    const int excl = e->cfg.num_exclude_recent;
+    for (int i = 0; i < n_scans; ++i) { q[(size_t)i] = first_key + i; hi[(size_t)i] = first_key + i - excl < 0 ? 0 : first_key + i - excl; }
+    if ((rc = detect_full_stream_locked(e, db, q.data(), lo.data(), hi.data(), n_scans, G, 2, nn_idx, shift, dist))) return rc;
+    if (!db.owns_lock()) db.lock();
+    return sync(e);
+}
+
+}  // namespace
+
+/* makeDescriptors + full-database detection for keyframes whose clouds are in the on-device keyframe store (scl_keyframe_put) */
+int scl_stream_from_store(scl_engine *e, int robot, int first_index, int count, int *nn_idx, int *shift, double *dist, float *out_values)
+{
+    if (!e || robot < 0 || first_index < 0 || count < 0 || (count > 0 && (!nn_idx || !shift || !dist))) return SCL_ERR_INVALID_ARG;
+    if (e->front) return fail(e, SCL_ERR_UNSUPPORTED, "stream_from_store: the keyframe store lives on one engine; call it on a one-GPU engine");
+    std::lock_guard<std::mutex> pk(e->pass_mu);
+    std::unique_lock<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    if ((size_t)robot >= e->kf.size() || (size_t)first_index + (size_t)count > e->kf[(size_t)robot].size())
+        return fail(e, SCL_ERR_OUT_OF_RANGE, "stream_from_store: keyframes not in the store");
+    std::vector<const unsigned char *> d((size_t)count);
+    std::vector<int> n((size_t)count), idx((size_t)count);
+    std::vector<int8_t> rb((size_t)count, (int8_t)robot);
+    for (int i = 0; i < count; ++i) {
+        const auto &c = e->kf[(size_t)robot][(size_t)(first_index + i)];
+        if (c.n < 0) return fail(e, SCL_ERR_OUT_OF_RANGE, "stream_from_store: a keyframe of the range was never stored");
+        d[(size_t)i] = c.d; n[(size_t)i] = c.n; idx[(size_t)i] = first_index + i;
+    }
+    return device_points_pipeline_locked(e, lk, d.data(), n.data(), count, e->kf_stride, rb.data(), idx.data(), out_values, nn_idx, shift, dist);
+}
 
 /* ---- pinned host buffers ----------------------------------------------------------- */
 

@@ -315,6 +315,13 @@ struct ScanBatch {
     int first_wg[kMaxScBatch + 1];                 // filled by launch_make_sc_batch
     int count;
 };
+struct IngestArgs {
+    const float *values; int first_slot; float4 *desc; double *vkey; double *norm; float *rkey; float4 *rkey4; uint2 *hdesc; unsigned int *kmask;
+    unsigned short *hkey; int hstride, cap, R, S; unsigned char *halign; int *tiles; float *vals_out;
+};
+// ingest of n_ingest scans (ia.tiles: the previous group's tiles) beside the scatter of batch b into gtiles, in ONE launch
+hipError_t launch_front_fused(ScanBatch b, int stride_bytes, double lidar_height, double max_radius, int *gtiles, int points_per_wg,
+                              const IngestArgs &ia, int n_ingest, hipStream_t stream);
 hipError_t launch_make_sc_tiles_init(int *tiles, int count, int R, int S, hipStream_t stream);
 // descriptor only: tiles -> values[count][R*S] (row-major wire format), tiles back to their initial state
 hipError_t launch_make_sc_finalize(int *tiles, int count, int R, int S, float *values, hipStream_t stream);

@@ -32,20 +32,19 @@ constexpr int kScThreads = 256;
 // keyframe): workgroup -> (scan, slice of its cloud), a private LDS tile per workgroup, merged into the scan's global tile with one
 // atomicMax per touched cell.  The global tiles are in their initial state when the launch starts and are put back into it by the
 // kernel that consumes them (ingest_kernel), so a batch costs two launches whatever its size.  Four points per thread are in flight.
-__global__ __launch_bounds__(kScThreads) void make_sc_batch_scatter_kernel(ScanBatch b, int stride, int R, int S,
-                                                                           double lidar_height, double max_radius, int *gtiles, int lab)
+__device__ __forceinline__ void scatter_body(const ScanBatch &b, const int wg, int stride, int R, int S,
+                                             double lidar_height, double max_radius, int *gtiles, int lab, int *tile /* R*S ints of LDS */)
 {
     const bool exact_only = lab & 1;                       // (diagnostics builds: 1 = the reference's chain for every point, 2 / 4 = ablations)
-    extern __shared__ int tile[];
     const int cells = R * S;
     const float c_ring = (float)((double)R / max_radius), c_sect = (float)((double)S / 6.283185307179586);
     const int init = float_to_ordered((float)kNoPoint);
     for (int i = threadIdx.x; i < cells; i += blockDim.x) tile[i] = init;
     int s = 0;
 #pragma unroll
-    for (int j = 1; j < kMaxScBatch; ++j) s += (j < b.count && (int)blockIdx.x >= b.first_wg[j]) ? 1 : 0;
+    for (int j = 1; j < kMaxScBatch; ++j) s += (j < b.count && wg >= b.first_wg[j]) ? 1 : 0;
     const int slices = b.first_wg[s + 1] - b.first_wg[s];
-    const int slice = (int)blockIdx.x - b.first_wg[s];
+    const int slice = wg - b.first_wg[s];
     const int n = b.n[s];
     const unsigned char *points = b.points[s];
     const int per_block = (n + slices - 1) / slices;
@@ -98,6 +97,13 @@ __global__ __launch_bounds__(kScThreads) void make_sc_batch_scatter_kernel(ScanB
     }
 }
 
+__global__ __launch_bounds__(kScThreads) void make_sc_batch_scatter_kernel(ScanBatch b, int stride, int R, int S,
+                                                                           double lidar_height, double max_radius, int *gtiles, int lab)
+{
+    extern __shared__ int tile[];
+    scatter_body(b, (int)blockIdx.x, stride, R, S, lidar_height, max_radius, gtiles, lab, tile);
+}
+
 __global__ void make_sc_init_kernel(int *gtile, int cells)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -125,17 +131,16 @@ __device__ __forceinline__ int fastdiv(int n, unsigned int magic) { return (int)
 // tiles != nullptr: the descriptors come straight from the scatter's global tiles (ordered-int max-z images, one per workgroup):
 // finalize (D.h:1446-1456: NO_POINT -> 0, row-major floats) happens on the way into LDS, the wire-format values go to vals_out
 // (what makeAndSaveDescriptorAndKey returns, D.h:1604-1611) and the tile is put back into its initial state for the next batch.
-__global__ __launch_bounds__(256) void ingest_kernel(
-    const float *values, int first_slot, float4 *desc, double *vkey, double *norm,
-    float *rkey, float4 *rkey4, uint2 *hdesc, unsigned int *kmask, unsigned short *hkey, int hstride, int cap, int R, int S,
-    unsigned char *halign, int *tiles, float *vals_out)
+__device__ __forceinline__ void ingest_body(const IngestArgs &ia, const int wg, float *sv /* LDS: [R][S+1], then the S reciprocal norms, ... */)
 {
-    extern __shared__ float sv[];                 // [R][S+1], then the S reciprocal norms
+    const float *values = ia.values; const int first_slot = ia.first_slot; float4 *desc = ia.desc; double *vkey = ia.vkey; double *norm = ia.norm;
+    float *rkey = ia.rkey; float4 *rkey4 = ia.rkey4; uint2 *hdesc = ia.hdesc; unsigned int *kmask = ia.kmask; unsigned short *hkey = ia.hkey;
+    const int hstride = ia.hstride, cap = ia.cap, R = ia.R, S = ia.S; unsigned char *halign = ia.halign; int *tiles = ia.tiles; float *vals_out = ia.vals_out;
     const int LS = S + 1;                         // odd-ish stride: column walks hit distinct banks
     const int RG = (R + 3) >> 2;
     const unsigned int mS = fastdiv_magic(S);
-    const int slot = first_slot + blockIdx.x;
-    const float *src = values ? values + (size_t)blockIdx.x * R * S : nullptr;
+    const int slot = first_slot + wg;
+    const float *src = values ? values + (size_t)wg * R * S : nullptr;
     float *siv = sv + R * LS;
     double *svk = reinterpret_cast<double *>(sv + ((R * LS + S + 1) & ~1));     // [S] the sector key, for its norm
     double *sdd = svk + S;                                                      // [S] squared rounding errors of the fp16 sector key
@@ -144,8 +149,8 @@ __global__ __launch_bounds__(256) void ingest_kernel(
     constexpr int LU = 8;
     const int cells = R * S;
     if (tiles) {
-        int *t = tiles + (size_t)blockIdx.x * cells;
-        float *vo = vals_out ? vals_out + (size_t)blockIdx.x * cells : nullptr;
+        int *t = tiles + (size_t)wg * cells;
+        float *vo = vals_out ? vals_out + (size_t)wg * cells : nullptr;
         const int init = float_to_ordered((float)kNoPoint);
         for (int i0 = threadIdx.x; i0 < cells; i0 += LU * (int)blockDim.x) {
             int o[LU];
@@ -369,6 +374,24 @@ __global__ __launch_bounds__(256) void ingest_kernel(
     }
 }
 
+__global__ __launch_bounds__(256) void ingest_kernel(IngestArgs ia)
+{
+    extern __shared__ float sv_k[];
+    ingest_body(ia, (int)blockIdx.x, sv_k);
+}
+
+// A group's ingest and the NEXT group's scatter in one launch (the clouds already on the device: nothing to wait for between the groups):
+// the ingest is one workgroup per scan, sixteen CUs busy for as long as the scatter of sixteen clouds takes on all of them -- side by
+// side they cost what the longer one costs.  Workgroups 0 .. n_ingest-1 (dispatched first: the long ones) ingest the previous group's
+// tiles, the others scatter into the other set of tiles.
+__global__ __launch_bounds__(256) void front_fused_kernel(ScanBatch b, int stride, double lidar_height, double max_radius, int *gtiles, int lab,
+                                                          IngestArgs ia, int n_ingest)
+{
+    extern __shared__ float sv_f[];
+    if ((int)blockIdx.x < n_ingest) ingest_body(ia, (int)blockIdx.x, sv_f);
+    else scatter_body(b, (int)blockIdx.x - n_ingest, stride, ia.R, ia.S, lidar_height, max_radius, gtiles, lab, reinterpret_cast<int *>(sv_f));
+}
+
 // test hook (tests/test_gpu_make_sc.py): the device's atanf_glibc over whole blocks of 2^24 consecutive float bit patterns, reduced to the
 // order-independent checksum of oracle/tools/atanf_exhaustive.c -- sum mod 2^64 of splitmix64((bits << 32) | result bits), NaN as 0x7fc00000
 __global__ __launch_bounds__(256) void atanf_checksum_kernel(int first_block, unsigned long long *out)
@@ -490,6 +513,8 @@ hipError_t launch_make_sc_batch(ScanBatch b, int stride_bytes, int R, int S, dou
     return hipGetLastError();
 }
 
+static size_t ingest_lds_bytes(int R, int S) { return sizeof(float) * ((size_t)R * (S + 1) + S + 2) + sizeof(double) * 2 * (size_t)S; }
+
 hipError_t launch_ingest(const float *values, int count, int first_slot,
                          float4 *desc, double *vkey, double *norm, float *rkey, float4 *rkey4,
                          uint2 *hdesc, unsigned int *kmask, unsigned short *hkey, int hstride,
@@ -497,7 +522,7 @@ hipError_t launch_ingest(const float *values, int count, int first_slot,
 {
     if (count <= 0) return hipSuccess;
     if (S > 224) return hipErrorInvalidValue;              // kmask holds 7 words of sector bits
-    const size_t lds = sizeof(float) * ((size_t)R * (S + 1) + S + 2) + sizeof(double) * 2 * (size_t)S;
+    const size_t lds = ingest_lds_bytes(R, S);
     static std::atomic<bool> attr_set_dev[64];   // per device; engines on different threads may race here: atomic flag,
     int dev_ = 0; (void)hipGetDevice(&dev_);     // and setting the attribute twice is harmless
     std::atomic<bool> &attr_set = attr_set_dev[dev_ & 63];
@@ -507,8 +532,36 @@ hipError_t launch_ingest(const float *values, int count, int first_slot,
         if (e != hipSuccess) return e;
         attr_set.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL(ingest_kernel, dim3(count), dim3(256), lds, stream,
-                       values, first_slot, desc, vkey, norm, rkey, rkey4, hdesc, kmask, hkey, hstride, cap, R, S, halign, tiles, vals_out);
+    IngestArgs ia{values, first_slot, desc, vkey, norm, rkey, rkey4, hdesc, kmask, hkey, hstride, cap, R, S, halign, tiles, vals_out};
+    hipLaunchKernelGGL(ingest_kernel, dim3(count), dim3(256), lds, stream, ia);
+    return hipGetLastError();
+}
+
+// ingest of n_ingest scans (ia: tiles of the previous group) + scatter of the batch b into gtiles, one launch (either part may be empty)
+hipError_t launch_front_fused(ScanBatch b, int stride_bytes, double lidar_height, double max_radius, int *gtiles, int points_per_wg,
+                              const IngestArgs &ia, int n_ingest, hipStream_t stream)
+{
+    if (b.count < 0 || b.count > kMaxScBatch || n_ingest < 0 || n_ingest > kMaxScBatch || points_per_wg < 256 || ia.S > 224) return hipErrorInvalidValue;
+    int total = 0;
+    for (int i = 0; i < b.count; ++i) {
+        b.first_wg[i] = total;
+        if (b.n[i] < 0 || (b.n[i] > 0 && !b.points[i])) return hipErrorInvalidValue;
+        total += (b.n[i] + points_per_wg - 1) / points_per_wg;
+    }
+    for (int i = b.count; i <= kMaxScBatch; ++i) b.first_wg[i] = total;
+    if (total + n_ingest == 0) return hipSuccess;
+    const size_t lds_i = n_ingest ? ingest_lds_bytes(ia.R, ia.S) : 0, lds_s = sizeof(int) * (size_t)ia.R * ia.S;
+    const size_t lds = lds_i > lds_s ? lds_i : lds_s;
+    static std::atomic<bool> attr_set_dev[64];
+    int dev_ = 0; (void)hipGetDevice(&dev_);
+    std::atomic<bool> &attr_set = attr_set_dev[dev_ & 63];
+    if (!attr_set.load(std::memory_order_acquire) && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)front_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set.store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(front_fused_kernel, dim3(total + n_ingest), dim3(256), lds, stream, b, stride_bytes, lidar_height, max_radius, gtiles,
+                       scl_lab_int("SCL_SC_LAB", 0), ia, n_ingest);
     return hipGetLastError();
 }
 

@@ -134,6 +134,7 @@ def _bind(lib):
         "scl_device_name": (c_int, [P, c_char_p, c_int]),
         "scl_make_and_save_many": (c_int, [P, POINTER(c_void_p), ip, c_int, c_int, POINTER(c_int8), ip, fp]),
         "scl_stream_from_points": (c_int, [P, POINTER(c_void_p), ip, c_int, c_int, POINTER(c_int8), ip, ip, ip, dp, fp]),
+        "scl_stream_from_store": (c_int, [P, c_int, c_int, c_int, ip, ip, dp, fp]),
         "scl_host_alloc": (c_int, [P, ctypes.c_size_t, POINTER(c_void_p)]),
         "scl_host_free": (c_int, [P, c_void_p]),
         "scl_host_register": (c_int, [P, c_void_p, ctypes.c_size_t]),
@@ -274,6 +275,14 @@ class ScanContextEngine:
                                                      None if rb is None else _ptr(rb, c_int8), None if ib is None else _ptr(ib, c_int),
                                                      _ptr(nn, c_int), _ptr(sh, c_int), _ptr(dd, c_double),
                                                      None if out is None else _ptr(out, c_float)), "scl_stream_from_points")
+        return (nn, sh, dd, out) if want_values else (nn, sh, dd)
+
+    def stream_from_store(self, robot, first_index, count, want_values=False):
+        """scl_stream_from_store: descriptors from the stored keyframes' clouds + append + full-database detection"""
+        nn = np.empty(count, dtype=np.int32); sh = np.empty(count, dtype=np.int32); dd = np.empty(count, dtype=np.float64)
+        out = np.empty((count, self.R * self.S), dtype=np.float32) if want_values else None
+        self._check(self._lib.scl_stream_from_store(self._h, robot, first_index, count, _ptr(nn, c_int), _ptr(sh, c_int), _ptr(dd, c_double),
+                                                    None if out is None else _ptr(out, c_float)), "scl_stream_from_store")
         return (nn, sh, dd, out) if want_values else (nn, sh, dd)
 
     def host_alloc(self, shape, dtype=np.float32):

@@ -27,4 +27,6 @@ if what in ("all", "topk"):
     eng.close()
 if what in ("all", "stream"):
     out["stream_from_points"] = bench.secondary_stream_from_points(0)
+if what in ("all", "resident"):
+    out["stream_from_resident_points"] = bench.secondary_stream_from_resident_points(0)
 print(json.dumps(out))

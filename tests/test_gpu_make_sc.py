@@ -227,3 +227,30 @@ def test_fast_binning_never_disagrees_with_the_references_chain(R, S):
         if mode == 0:
             assert sure > 0.995 * n              # ... and it answers nearly always
     eng.close()
+
+
+@pytest.mark.parametrize("R,S,n0,n_scans,stride", [(64, 120, 250, 45, 8), (80, 180, 0, 20, 4), (20, 60, 140, 17, 8)])
+def test_stream_from_store_equals_stream_from_points(R, S, n0, n_scans, stride):
+    """scl_stream_from_store: the same pipeline with the clouds already on the device (scl_keyframe_put) -- every group's two
+    launches back to back, one stream call for the detection of all the new keyframes: descriptors, winners, shifts and fp64
+    distances equal those of scl_stream_from_points on the same clouds, bit for bit."""
+    from scl_slam_amd.synth import synth_descriptors
+    excl = 30
+    a = ScanContextEngine(num_ring=R, num_sector=S, num_exclude_recent=excl, initial_capacity=16)
+    b = ScanContextEngine(num_ring=R, num_sector=S, num_exclude_recent=excl)
+    if n0:
+        base = synth_descriptors(n0, R, S, seed=7 * R); a.save_bulk(base); b.save_bulk(base)
+    clouds = [synth_scan(3000 + 997 * (i % 5), seed=4000 + i, stride_floats=stride) for i in range(n_scans)]
+    clouds[3] = np.zeros((0, stride), np.float32)                         # an empty keyframe
+    for i in range(excl + 1, n_scans, 4):
+        clouds[i] = clouds[i - excl - 1]                                   # revisits
+    for i, c in enumerate(clouds):
+        a.keyframe_put(2, 5 + i, c)
+    nn, sh, dd, vals = a.stream_from_store(2, 5, n_scans, want_values=True)
+    nn2, sh2, dd2, vals2 = b.stream_from_points(clouds, robots=[2] * n_scans, indexs=list(range(5, 5 + n_scans)), want_values=True)
+    assert np.array_equal(vals.view(np.uint32), vals2.view(np.uint32))
+    assert np.array_equal(nn, nn2) and np.array_equal(sh, sh2) and np.array_equal(dd.view(np.uint64), dd2.view(np.uint64))
+    assert a.get_size() == n0 + n_scans and a.get_index(n0 + 4) == (2, 9) == b.get_index(n0 + 4)
+    with pytest.raises(Exception):
+        a.stream_from_store(2, 5, n_scans + 1)                             # past the stored keyframes
+    a.close(); b.close()
