@@ -644,9 +644,14 @@ def secondary_stream_from_points(device, n=N_KEYFRAMES_1GPU, npts=120000, n_scan
     eng = ScanContextEngine(num_ring=R, num_sector=S, num_candidates=3, num_exclude_recent=N_EXCLUDE, device=device, initial_capacity=n + 2 * n_scans + 256)
     eng.save_bulk(synth_descriptors(n, R, S, seed=1002))
     bases = [synth_scan(npts, seed=500 + i, stride_floats=4) for i in range(batch)]
-    pinned = []
-    for i in range(n_scans + 2 * batch):                                     # every scan its own cloud, its own pinned buffer
-        a = eng.host_alloc(bases[0].shape); a[:] = _distinct_scan(bases[i % batch], i); pinned.append(a)
+    # every scan its own cloud, one behind the other in ONE pinned arena (a ring of incoming scans): a group of 16 then travels as one copy
+    arena = eng.host_alloc((n_scans + 2 * batch, npts, 4))
+    for i in range(n_scans + 2 * batch):
+        arena[i] = _distinct_scan(bases[i % batch], i)
+    pinned = [arena[i] for i in range(n_scans + 2 * batch)]
+    separate = []                                                            # ... and 64 scans in pinned buffers of their own (one copy per cloud, two copy streams)
+    for i in range(4 * batch):
+        a = eng.host_alloc(bases[0].shape); a[:] = arena[i]; separate.append(a)
     pageable = [np.array(a) for a in pinned[:4 * batch]]
     warm, seq = pinned[n_scans:], pinned[:n_scans]
     eng.stream_from_points(warm)                                             # warm-up: buffers, streams, the stream form's sets
@@ -659,17 +664,23 @@ def secondary_stream_from_points(device, n=N_KEYFRAMES_1GPU, npts=120000, n_scan
     t0 = time.perf_counter()
     eng.stream_from_points(seq_p)
     dt_p = time.perf_counter() - t0
+    eng.stream_from_points(separate[:2 * batch])
+    t0 = time.perf_counter()
+    eng.stream_from_points(separate)
+    dt_s = time.perf_counter() - t0
     h2d = eng.host_copy_rate(64 << 20, 8)            # one large pinned copy at a time, HIP events on the engine's copy stream
     h2d_cloud = eng.host_copy_rate(npts * 16, 64)    # ... and copies of one cloud's size back to back on ONE stream
     bytes_scan = npts * 16
     floor_us = bytes_scan / (h2d * 1e9) * 1e6
     eng.close()
-    return {"workload": f"{n_scans} scans of {npts} points (16-byte records, pinned host memory) through scl_stream_from_points on a {n}-keyframe 64x120 database: "
+    return {"workload": f"{n_scans} scans of {npts} points (16-byte records, one behind the other in a pinned arena) through scl_stream_from_points on a {n}-keyframe 64x120 database: "
                         f"descriptor + append + full-database detection per scan, groups of {batch}",
             "scans_per_s": n_scans / dt, "us_per_scan": dt / n_scans * 1e6, "value": pairs / dt, "unit": "pairs/s",
             "winners_found": int((nn >= 0).sum()),
             "pcie": {"h2d_GBps_measured": h2d, "h2d_GBps_cloud_sized_copies_one_stream": h2d_cloud, "bytes_per_scan": bytes_scan, "floor_us_per_scan": floor_us, "us_per_scan_over_floor": dt / n_scans * 1e6 / floor_us,
                      "note": "floor = bytes per scan / the rate one large pinned hipMemcpyAsync reaches on this box"},
+            "pinned_buffer_per_cloud": {"us_per_scan": dt_s / len(separate) * 1e6, "scans": len(separate), "us_per_scan_over_floor": dt_s / len(separate) * 1e6 / floor_us,
+                                        "note": "every cloud in a pinned allocation of its own: one copy per cloud (17 us of start-up each), dealt over two copy streams"},
             "pageable_host_memory": {"us_per_scan": dt_p / len(seq_p) * 1e6, "scans": len(seq_p),
                                      "note": "the same call from ordinary (pageable) buffers: the runtime stages every copy through its own pinned memory"}}
 

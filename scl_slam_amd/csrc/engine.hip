@@ -1989,10 +1989,28 @@ int points_pipeline_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
     const int ng = (n_scans + G - 1) / G;
     const size_t cells = (size_t)e->R * e->S;
     // every group's clouds at 256-byte aligned offsets of one buffer: the largest group sizes the three buffers
-    auto group_bytes = [&](int g, size_t *off) {
+    // ... unless the group's clouds lie one behind the other in ONE host allocation (a ring of incoming scans, an arena the host
+    // assembles its clouds in): ascending addresses, 16-byte aligned distances, gaps of at most a page.  Such a group travels as ONE copy
+    // of its whole span -- at the link's rate for large copies (56.8 GB/s) instead of sixteen start-ups (44.8 GB/s on one stream) -- and
+    // lies on the device as it lay on the host (*merged; off = the clouds' distances from the first).
+    auto group_bytes = [&](int g, size_t *off, bool *merged_out = nullptr) {
+        const int i0 = g * G, i1 = (g + 1) * G < n_scans ? (g + 1) * G : n_scans;
+        bool merged = i1 - i0 >= 2;
+        const unsigned char *base = static_cast<const unsigned char *>(clouds[i0]), *end = base;
+        for (int i = i0; merged && i < i1; ++i) {
+            const unsigned char *c = static_cast<const unsigned char *>(clouds[i]);
+            const size_t bytes = (size_t)n_points[i] * (size_t)stride_bytes;
+            if (!c || bytes == 0 || c < end || (size_t)(c - end) >= 4096 || ((size_t)(c - base) & 15)) merged = false;   // (a gap below a page lies in pages the clouds themselves touch)
+            else end = c + bytes;
+        }
+        if (merged_out) *merged_out = merged;
+        if (merged) {
+            for (int i = i0; off && i < i1; ++i) off[i - i0] = (size_t)(static_cast<const unsigned char *>(clouds[i]) - base);
+            return (size_t)(end - base) + 16;
+        }
         size_t at = 0;
-        for (int i = g * G; i < n_scans && i < (g + 1) * G; ++i) {
-            if (off) off[i - g * G] = at;
+        for (int i = i0; i < i1; ++i) {
+            if (off) off[i - i0] = at;
             at += (((size_t)n_points[i] * (size_t)stride_bytes + 16) + 255) & ~(size_t)255;
         }
         return at;
@@ -2026,10 +2044,12 @@ int points_pipeline_locked(scl_engine *e, std::unique_lock<std::mutex> &db, cons
     auto enqueue_copy = [&](int g) -> int {
         const int b = g % 3;
         size_t off[G];
-        group_bytes(g, off);
+        bool merged = false;
+        const size_t span = group_bytes(g, off, &merged);
         if (g >= 3)                                          // the group that was binned out of this buffer
             for (int c = 0; c < ncs; ++c) SCL_HIP(e, hipStreamWaitEvent(cstream(c), e->ev_consumed[b], 0));
-        for (int i = g * G; i < n_scans && i < (g + 1) * G; ++i) {
+        if (merged) SCL_HIP(e, hipMemcpyAsync(e->d_pbuf[b], clouds[g * G], span - 16, hipMemcpyHostToDevice, cstream(0)));
+        else for (int i = g * G; i < n_scans && i < (g + 1) * G; ++i) {
             const size_t bytes = (size_t)n_points[i] * (size_t)stride_bytes;
             if (bytes) SCL_HIP(e, hipMemcpyAsync(e->d_pbuf[b] + off[i - g * G], clouds[i], bytes, hipMemcpyHostToDevice, cstream(i % ncs)));
         }

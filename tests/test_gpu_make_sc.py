@@ -254,3 +254,33 @@ def test_stream_from_store_equals_stream_from_points(R, S, n0, n_scans, stride):
     with pytest.raises(Exception):
         a.stream_from_store(2, 5, n_scans + 1)                             # past the stored keyframes
     a.close(); b.close()
+
+
+def test_clouds_in_one_arena_travel_as_one_copy_and_give_the_same_database():
+    """A group whose clouds lie one behind the other in one allocation (a pinned ring of incoming scans) is copied as ONE span and
+    addressed on the device as it lay on the host; ragged sizes (gaps between the clouds), a second group that is not contiguous,
+    and the same clouds from separate buffers must all give the checker's descriptors."""
+    R, S, stride = 64, 120, 4
+    eng = ScanContextEngine(num_ring=R, num_sector=S)
+    db = ob.OracleDB(ob.make_config(R=R, S=S))
+    sizes = [20000, 17000, 5, 20000, 12345] + [9000] * 15                       # 20 clouds: a full group of 16 + 4
+    slot = 20000
+    arena = eng.host_alloc((len(sizes), slot, stride))
+    clouds, views = [], []
+    for i, n in enumerate(sizes):
+        c = synth_scan(n, seed=77 + i, stride_floats=stride)
+        arena[i, :n] = c
+        clouds.append(c); views.append(arena[i, :n])                            # gaps of (slot - n) records between the clouds: some below a page, most above
+    views[17], views[18] = views[18], views[17]; clouds[17], clouds[18] = clouds[18], clouds[17]   # the second group: not ascending
+    vals = eng.make_and_save_many(views)
+    tight = eng.host_alloc((sum(sizes[:16]), stride))                            # ... and a group packed without gaps
+    at, tv = 0, []
+    for i in range(16):
+        tight[at:at + sizes[i]] = clouds[i]; tv.append(tight[at:at + sizes[i]]); at += sizes[i]
+    vals_t = eng.make_and_save_many(tv)
+    for i, c in enumerate(clouds):
+        v = db.make_and_save(c, 0, i)
+        assert np.array_equal(vals[i].view(np.uint32), v.view(np.uint32)), i
+        if i < 16:
+            assert np.array_equal(vals_t[i].view(np.uint32), v.view(np.uint32)), i
+    eng.close()
