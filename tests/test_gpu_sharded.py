@@ -366,3 +366,28 @@ def test_two_processes_share_the_database_over_gloo():
         assert len(arrays) == len(want_arrays)
         for (d, g, shf), w in zip(arrays, want_arrays):
             assert (g, shf) == (w[0], w[1]) and _same_bits(d, w[2])
+
+
+@pytest.mark.parametrize("G", [2, 3])
+def test_points_entry_points_on_a_sharded_engine_equal_the_single_engine(G):
+    """scl_make_and_save_many / scl_stream_from_points on a sharded front (keyframe g on shard g % G; the front goes keyframe by
+    keyframe through the owners and searches group by group through its stream form): descriptors, winners, shifts and fp64 distances
+    equal the one-GPU engine's, bit for bit."""
+    from scl_slam_amd.synth import synth_descriptors, synth_scan
+    R, S, n0, excl = 64, 120, 180, 20
+    base = synth_descriptors(n0, R, S, seed=31)
+    one = ScanContextEngine(num_ring=R, num_sector=S, num_exclude_recent=excl)
+    sh = ScanContextEngine(num_ring=R, num_sector=S, num_exclude_recent=excl, initial_capacity=64, devices=[0] * G, exchange=1)
+    one.save_bulk(base); sh.save_bulk(base)
+    clouds = [synth_scan(4000 + 300 * (i % 4), seed=600 + i, stride_floats=4) for i in range(21)]
+    for i in range(excl + 1, len(clouds), 3):
+        clouds[i] = clouds[i - excl - 1]
+    v1 = one.make_and_save_many(clouds[:5], robots=[1] * 5, indexs=list(range(5)))
+    v2 = sh.make_and_save_many(clouds[:5], robots=[1] * 5, indexs=list(range(5)))
+    assert np.array_equal(v1.view(np.uint32), v2.view(np.uint32)) and sh.get_size() == n0 + 5 and sh.get_index(n0 + 3) == (1, 3)
+    a = one.stream_from_points(clouds[5:], want_values=True)
+    b = sh.stream_from_points(clouds[5:], want_values=True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2].view(np.uint64), b[2].view(np.uint64))
+    assert np.array_equal(a[3].view(np.uint32), b[3].view(np.uint32))
+    assert (a[0] >= 0).sum() >= 1 and sh.get_size() == one.get_size() == n0 + len(clouds)
+    one.close(); sh.close()
