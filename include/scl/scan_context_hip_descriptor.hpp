@@ -150,6 +150,44 @@ public:
         return vT;
     }
 
+    // Not part of scan_descriptor: makeAndSaveDescriptorAndKey for the keyframes that arrive together (DM.h:988-1025 once per keyframe),
+    // in order -- groups of 16 cost two kernel launches each, the next group's clouds travel meanwhile (pinned buffers: scl_host_alloc /
+    // scl_host_register).  values[i] = what makeAndSaveDescriptorAndKey(*scans[i], robots[i], indexs[i]) returns.
+    std::vector<std::vector<float>> makeAndSaveDescriptorsAndKeys(const std::vector<const pcl::PointCloud<pcl::PointXYZI> *> &scans,
+                                                                  const std::vector<int8_t> &robots, const std::vector<int> &indexs)
+    {
+        const size_t n = scans.size();
+        std::vector<const void *> clouds(n); std::vector<int> counts(n);
+        for (size_t i = 0; i < n; ++i) { clouds[i] = scans[i]->points.data(); counts[i] = static_cast<int>(scans[i]->points.size()); }
+        std::vector<float> flat(n * static_cast<size_t>(cells_), 0.0f);
+        std::vector<std::vector<float>> out;
+        if (robots.size() != n || indexs.size() != n ||
+            !report(scl_make_and_save_many(engine_, clouds.data(), counts.data(), static_cast<int>(n), static_cast<int>(sizeof(pcl::PointXYZI)),
+                                           robots.data(), indexs.data(), flat.data()), "makeAndSaveDescriptorsAndKeys"))
+            return out;
+        for (size_t i = 0; i < n; ++i) out.emplace_back(flat.begin() + static_cast<long>(i * cells_), flat.begin() + static_cast<long>((i + 1) * cells_));
+        return out;
+    }
+
+    // ... and, in the same call, the full-database detection of every new keyframe over [0, key - NUM_EXCLUDE_RECENT) (descriptor.h:1627):
+    // loops[i] = {keyframe index or -1 (threshold SC_DIST_THRES applied, descriptor.h:1662), ring shift as float} like detectIntraLoopClosureID
+    std::vector<std::pair<int, float>> makeSaveAndDetect(const std::vector<const pcl::PointCloud<pcl::PointXYZI> *> &scans,
+                                                         const std::vector<int8_t> &robots, const std::vector<int> &indexs, double distThres = 0.14)
+    {
+        const size_t n = scans.size();
+        std::vector<const void *> clouds(n); std::vector<int> counts(n), nn(n, -1), shift(n, 0);
+        std::vector<double> dist(n, 1e7);
+        for (size_t i = 0; i < n; ++i) { clouds[i] = scans[i]->points.data(); counts[i] = static_cast<int>(scans[i]->points.size()); }
+        std::vector<std::pair<int, float>> out(n, std::pair<int, float>(-1, 0.0f));
+        if (robots.size() != n || indexs.size() != n ||
+            !report(scl_stream_from_points(engine_, clouds.data(), counts.data(), static_cast<int>(n), static_cast<int>(sizeof(pcl::PointXYZI)),
+                                           robots.data(), indexs.data(), nn.data(), shift.data(), dist.data(), nullptr), "makeSaveAndDetect"))
+            return out;
+        for (size_t i = 0; i < n; ++i)
+            if (nn[i] >= 0 && dist[i] < distThres) out[i] = std::pair<int, float>(nn[i], static_cast<float>(shift[i]));
+        return out;
+    }
+
 private:
     void init(int numRing, int numSector, int numCandidates, double distThres, double lidarHeight, double maxRadius,
               int numExcludeRecent, int treeMakingPeriod, double searchRatio, float knnExcludeEps,

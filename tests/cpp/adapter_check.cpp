@@ -32,6 +32,7 @@ int main(int argc, char **argv)
     std::vector<std::array<float, 4>> boxes;
     for (int b = 0; b < 300; ++b) boxes.push_back({(float)uni(-200, 200), (float)uni(-200, 200), (float)uni(2, 8), (float)uni(1, 10)});
     std::vector<std::vector<float>> published;
+    std::vector<pcl::PointCloud<pcl::PointXYZI>> all_clouds;
     for (int kf = 0; kf < n_keyframes; ++kf) {
         const int pos = kf % (n_keyframes / 2);
         const float cx = 150.0f * std::cos(0.048f * pos), cy = 150.0f * std::sin(0.048f * pos);
@@ -45,6 +46,7 @@ int main(int argc, char **argv)
             p.intensity = 1.0f;
             cloud.points.push_back(p);
         }
+        all_clouds.push_back(cloud);
         std::vector<float> v = scanDescriptor->makeAndSaveDescriptorAndKey(cloud, 0, kf);
         if ((int)v.size() != 20 * 60) { std::printf("FAIL vT size\n"); return 1; }
         published.push_back(v);
@@ -73,6 +75,25 @@ int main(int argc, char **argv)
     for (int kf = 0; kf < n_keyframes; ++kf) remote->saveDescriptorAndKey(published[kf].data(), 1, kf);
     for (int cur = n_keyframes - 30; cur < n_keyframes; ++cur) {
         if (remote->detectIntraLoopClosureID(cur) != scanDescriptor->detectIntraLoopClosureID(cur)) { std::printf("FAIL wire parity\n"); return 1; }
+    }
+    // the keyframes that arrive together (round 5): the batch call returns what the virtual returned keyframe by keyframe, and the
+    // one-call pipeline (descriptor + append + full-database detection per keyframe) finds the revisits
+    {
+        scan_context_hip_descriptor *batch_impl = make(), *pipe_impl = make();
+        std::unique_ptr<scan_descriptor> batch(batch_impl), pipe(pipe_impl);
+        std::vector<const pcl::PointCloud<pcl::PointXYZI> *> scans;
+        std::vector<int8_t> robots((size_t)n_keyframes, 0); std::vector<int> indexs;
+        for (int kf = 0; kf < n_keyframes; ++kf) { scans.push_back(&all_clouds[(size_t)kf]); indexs.push_back(kf); }
+        const std::vector<std::vector<float>> vals = batch_impl->makeAndSaveDescriptorsAndKeys(scans, robots, indexs);
+        if (vals != published || batch->getSize() != n_keyframes) { std::printf("FAIL batch descriptors\n"); return 1; }
+        for (int cur = n_keyframes - 20; cur < n_keyframes; ++cur)
+            if (batch->detectIntraLoopClosureID(cur) != scanDescriptor->detectIntraLoopClosureID(cur)) { std::printf("FAIL batch database\n"); return 1; }
+        const std::vector<std::pair<int, float>> found = pipe_impl->makeSaveAndDetect(scans, robots, indexs);
+        int ploops = 0, pcorrect = 0;
+        for (int cur = 0; cur < n_keyframes; ++cur)
+            if (found[(size_t)cur].first >= 0) { ++ploops; if (std::abs(found[(size_t)cur].first - (cur - n_keyframes / 2)) <= 2) ++pcorrect; }
+        std::printf("one-call pipeline: loops found %d, at the revisited place %d\n", ploops, pcorrect);
+        if (pipe->getSize() != n_keyframes || ploops < 20 || pcorrect * 10 < ploops * 8) { std::printf("FAIL pipeline loops\n"); return 1; }
     }
     // makeDescriptors in one call (filter + descriptor on the device) == scl_voxel_grid followed by the virtual
     {
