@@ -23,6 +23,10 @@
 #include "db_file.hpp"
 #include "engine_internal.hpp"
 
+#ifdef SCL_DIAGNOSTICS
+namespace scl { void ingest_stamps_print(); }       // make_sc.hip: the ingest's phase stamps (SCL_INGEST_STAMPS=1)
+#endif
+
 using namespace scl;
 
 namespace {
@@ -665,6 +669,9 @@ int scl_create(const scl_config *cfg, scl_engine **out)
 
 int scl_destroy(scl_engine *e)
 {
+#ifdef SCL_DIAGNOSTICS
+    if (e && !e->front && scl_lab_int("SCL_INGEST_STAMPS", 0)) { (void)hipSetDevice(e->device); scl::ingest_stamps_print(); }
+#endif
     if (!e) return SCL_OK;
     if (e->front) return front_destroy(e);
     (void)hipSetDevice(e->device);

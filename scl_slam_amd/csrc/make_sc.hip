@@ -18,6 +18,7 @@
 // writes every array of the database slot and leaves the tiles in their initial
 // state for the next batch (round 4: init, scatter, finalize, ingest per scan).
 #include <atomic>
+#include <cstdio>
 
 #include "device_common.hpp"
 #include "kernels.hpp"
@@ -128,11 +129,30 @@ __global__ void make_sc_finalize_kernel(int *gtile, int cells, float *values)
 __device__ __forceinline__ unsigned int fastdiv_magic(int d) { return 0xffffffffu / (unsigned int)d + 1u; }
 __device__ __forceinline__ int fastdiv(int n, unsigned int magic) { return (int)__umulhi((unsigned int)n, magic); }
 
+// sum over a wave of one double per lane (xor exchanges: every lane ends with the same value; a wave that runs it on the same data gets
+// the same bits).  For the quantities whose summation ORDER nothing depends on: norms and error bounds of the screening's operands.
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
 // tiles != nullptr: the descriptors come straight from the scatter's global tiles (ordered-int max-z images, one per workgroup):
 // finalize (D.h:1446-1456: NO_POINT -> 0, row-major floats) happens on the way into LDS, the wire-format values go to vals_out
 // (what makeAndSaveDescriptorAndKey returns, D.h:1604-1611) and the tile is put back into its initial state for the next batch.
+#ifdef SCL_DIAGNOSTICS
+__device__ unsigned long long g_ingest_stamps[16];     // ticks (100 MHz) of workgroup 0 between the ingest's phases; [15] = launches (scl_lab: SCL_INGEST_STAMPS=1 prints them)
+#define ING_STAMP(k) do { if (wg == 0 && threadIdx.x == 0) { const unsigned long long now__ = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_ingest_stamps[k], now__ - ing_t0__); ing_t0__ = now__; } } while (0)
+#else
+#define ING_STAMP(k) ((void)0)
+#endif
 __device__ __forceinline__ void ingest_body(const IngestArgs &ia, const int wg, float *sv /* LDS: [R][S+1], then the S reciprocal norms, ... */)
 {
+#ifdef SCL_DIAGNOSTICS
+    unsigned long long ing_t0__ = __builtin_amdgcn_s_memrealtime();
+    if (wg == 0 && threadIdx.x == 0) atomicAdd(&g_ingest_stamps[15], 1ull);
+#endif
     const float *values = ia.values; const int first_slot = ia.first_slot; float4 *desc = ia.desc; double *vkey = ia.vkey; double *norm = ia.norm;
     float *rkey = ia.rkey; float4 *rkey4 = ia.rkey4; uint2 *hdesc = ia.hdesc; unsigned int *kmask = ia.kmask; unsigned short *hkey = ia.hkey;
     const int hstride = ia.hstride, cap = ia.cap, R = ia.R, S = ia.S; unsigned char *halign = ia.halign; int *tiles = ia.tiles; float *vals_out = ia.vals_out;
@@ -144,6 +164,7 @@ __device__ __forceinline__ void ingest_body(const IngestArgs &ia, const int wg, 
     float *siv = sv + R * LS;
     double *svk = reinterpret_cast<double *>(sv + ((R * LS + S + 1) & ~1));     // [S] the sector key, for its norm
     double *sdd = svk + S;                                                      // [S] squared rounding errors of the fp16 sector key
+    double *snorm = sdd + S;                                                    // [S] the columns' fp64 norms (the bound's loop reads them with two lanes per column)
     // (eight loads of a thread in flight before the first is used, from a clamped index: a load per loop step, with the stores that
     //  depend on it behind it, was thirty memory round trips one after the other -- most of this kernel's time)
     constexpr int LU = 8;
@@ -182,6 +203,7 @@ __device__ __forceinline__ void ingest_body(const IngestArgs &ia, const int wg, 
         }
     }
     __syncthreads();
+    ING_STAMP(0);
 
     // tiled copy: element (rg, c) = rows 4rg..4rg+3 of column c
     float4 *dslot = desc + (size_t)slot * RG * S;
@@ -195,8 +217,8 @@ __device__ __forceinline__ void ingest_body(const IngestArgs &ia, const int wg, 
         }
         dslot[i] = make_float4(v[0], v[1], v[2], v[3]);
     }
+    ING_STAMP(1);
     // sector key (column mean, D.h:1482-1486) and column norm (D.h:1523), sequential over rings
-    double my_norm = 0.0;
     for (int c = threadIdx.x; c < S; c += blockDim.x) {
         double sum = 0.0, ss = 0.0;
         for (int r = 0; r < R; ++r) {
@@ -208,13 +230,14 @@ __device__ __forceinline__ void ingest_body(const IngestArgs &ia, const int wg, 
         svk[c] = sum / (double)R;
         const double nrm = sqrt(ss);
         norm[(size_t)slot * S + c] = nrm;
-        my_norm = nrm;                                   // (S <= blockDim: a thread owns at most one column, in this loop and in the bound's below)
+        snorm[c] = nrm;
         // screening pass operand (sc_screen.hip): fp32 reciprocal norm; 0 = all-zero column, NaN = score this keyframe exactly
         float iv = __int_as_float(0x7fc00000);
         if (nrm == 0.0) iv = 0.0f;
         else if (nrm >= 0x1p-60 && nrm <= 0x1p60) iv = (float)(1.0 / nrm);
         siv[c] = iv;
     }
+    ING_STAMP(2);
     // ring key (row mean narrowed to float, D.h:1468-1472), sequential over sectors
     for (int r = threadIdx.x; r < 4 * RG; r += blockDim.x) {
         float key = 0.0f;
@@ -226,8 +249,10 @@ __device__ __forceinline__ void ingest_body(const IngestArgs &ia, const int wg, 
         rkey[(size_t)slot * 4 * RG + r] = key;
         if (rkey4) reinterpret_cast<float *>(rkey4)[((size_t)(r >> 2) * cap + slot) * 4 + (r & 3)] = key;   // nullptr: staging slot
     }
+    ING_STAMP(3);
     // the screening pass's copy (sc_screen.hip): x * inv in fp32, rounded to nearest fp16; sector-major
     __syncthreads();
+    ING_STAMP(4);
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     h4 *hslot = reinterpret_cast<h4 *>(hdesc + (size_t)slot * hstride);
     const int RGH = hdesc_sector(RG);                        // ring groups of the copy: rows >= R are zero
@@ -243,6 +268,7 @@ __device__ __forceinline__ void ingest_body(const IngestArgs &ia, const int wg, 
         }
         hslot[i] = hv;
     }
+    ING_STAMP(5);
     // the chunk-major image of the same values: [ring part][chunk][sector 0 .. S+15], 8 rings = 16 B per entry
     if (hdesc2_elems(RG, S)) {
         typedef _Float16 h8v __attribute__((ext_vector_type(8)));
@@ -262,12 +288,17 @@ __device__ __forceinline__ void ingest_body(const IngestArgs &ia, const int wg, 
             h2[i] = hv;
         }
     }
+    ING_STAMP(6);
     // the sector key as a unit vector in fp16, behind the copy (first stage of the alignment filter, sc_screen.hip)
     {
         const int SK = hkey_halfs(S);
         _Float16 *hk = reinterpret_cast<_Float16 *>(hdesc + (size_t)slot * hstride + (size_t)RGH * S);
+        // |k|^2 of the sector key: lane partial sums + a wave reduction, by every wave for itself (the same bits in every wave).  Not the
+        // reference's arithmetic -- the unit key only feeds the alignment FILTER, whose bounds do not depend on this sum's order; the
+        // serial sum by every thread was 120 dependent fp64 additions.
         double n2 = 0.0;
-        for (int c = 0; c < S; ++c) n2 = n2 + svk[c] * svk[c];            // every thread the same sequential sum
+        for (int c = (int)(threadIdx.x & (kWave - 1)); c < S; c += kWave) n2 = n2 + svk[c] * svk[c];
+        n2 = wave_sum_f64(n2);
         const double nrm = sqrt(n2);
         const bool usable = nrm > 0.0 && nrm < 1.0e300;                   // zero, NaN, inf: all zero -> every shift ties -> exact evaluation
         const double rnrm = 1.0 / nrm;                                    // unit key u = k * (1 / |k|): one division per thread, not one per entry
@@ -301,10 +332,11 @@ __device__ __forceinline__ void ingest_body(const IngestArgs &ia, const int wg, 
         }
         __syncthreads();
         float kerr = -1.0f;
-        if (usable && threadIdx.x == 0) {
+        if (threadIdx.x < kWave) {                                        // the first wave adds them up (any order: a bound, rounded up)
             double e2 = 0.0;
-            for (int c = 0; c < S; ++c) e2 = e2 + sdd[c];
-            kerr = __double2float_ru(sqrt(e2) * (1.0 + 1e-6) + 1e-10);         // (> 0 always: 0 would read as "not recorded")
+            for (int c = (int)threadIdx.x; c < S; c += kWave) e2 = e2 + sdd[c];
+            e2 = wave_sum_f64(e2);
+            if (usable) kerr = __double2float_ru(sqrt(e2) * (1.0 + 1e-6) + 1e-10);   // (> 0 always: 0 would read as "not recorded")
         }
         if (threadIdx.x == 0) {
             *reinterpret_cast<float *>(hk + SK) = usable ? (float)nrm : -1.0f;   // the filter's range check (negative: no decision)
@@ -312,6 +344,7 @@ __device__ __forceinline__ void ingest_body(const IngestArgs &ia, const int wg, 
             *reinterpret_cast<float *>(hk + SK + 2) = kerr;
             *reinterpret_cast<float *>(hd + SK + 2) = kerr;
         }
+        ING_STAMP(7);
         // the alignment image (kernels.hpp: halign_*): norm, P rotated copies of either part; database slots only
         const int P = halign_P(S), CP = halign_CP(S);
         if (halign && P && slot < cap) {
@@ -332,6 +365,7 @@ __device__ __forceinline__ void ingest_body(const IngestArgs &ia, const int wg, 
             }
         }
     }
+    ING_STAMP(8);
     // How far the fp16 unit columns of the screening copy are from the unit columns they stand for: E = sum over the columns of
     // |h_c - x_c / norm_c|_2, rounded up.  By Cauchy-Schwarz the screened cosine of a column pair is off by at most |e_q| + |e_k| +
     // |e_q||e_k|, so the screened distance of a (scan, keyframe, shift) is within (E_q + E_k)(1 + 1e-3) / n_eff (+ accumulation) of
@@ -340,38 +374,46 @@ __device__ __forceinline__ void ingest_body(const IngestArgs &ia, const int wg, 
     // larger of its rounding error and its value (a matrix core may take it for zero).  Kept in word 6 of the sector mask, which
     // holds no sector bits on grids of up to 192 sectors.
     __syncthreads();                                                 // (svk, the sector key, is no longer read)
-    for (int c = threadIdx.x; c < S; c += blockDim.x) {
-        const float iv = siv[c];
+    ING_STAMP(10);
+    // (two lanes per column where the workgroup has them -- even and odd rings, joined by one exchange --; the bound's sum by a wave
+    //  reduction, the mask words by ballots: the serial forms were 6 of the kernel's 22 us)
+    {
+        const int TPC = 2 * S <= (int)blockDim.x ? 2 : 1;
+        const int c = (int)threadIdx.x / TPC, half = (int)threadIdx.x - c * TPC;
         double e2 = 0.0;
-        if (iv == iv && iv != 0.0f) {
-            const double rn = 1.0 / my_norm;   // (x * (1 / norm): two roundings from x / norm, covered by the bound's 1e-6)
-            for (int r = 0; r < R; ++r) {
-                const float x = sv[r * LS + c];
-                const double h = (double)(float)(_Float16)(x * iv), u = (double)x * rn;
-                double d = fabs(h - u);
-                if (fabs(h) < 6.103515625e-05) d = fmax(d, fabs(u));
-                e2 = e2 + d * d;
+        if (c < S) {
+            const float iv = siv[c];
+            if (iv == iv && iv != 0.0f) {
+                const double rn = 1.0 / snorm[c];   // (x * (1 / norm): two roundings from x / norm, covered by the bound's 1e-6)
+                for (int r = half; r < R; r += TPC) {
+                    const float x = sv[r * LS + c];
+                    const double h = (double)(float)(_Float16)(x * iv), u = (double)x * rn;
+                    double d = fabs(h - u);
+                    if (fabs(h) < 6.103515625e-05) d = fmax(d, fabs(u));
+                    e2 = e2 + d * d;
+                }
             }
         }
-        svk[c] = sqrt(e2);
+        if (TPC == 2) e2 += __shfl_xor(e2, 1, kWave);                  // (every lane of the workgroup takes part)
+        if (c < S && half == 0) svk[c] = sqrt(e2);
     }
-    __syncthreads();
-    if (threadIdx.x < 8) {
-        unsigned int w = 0;
-        if (threadIdx.x == 6 && S <= 192) {
-            double E = 0.0;
-            for (int c = 0; c < S; ++c) E = E + svk[c];
-            w = (unsigned int)__float_as_int(__double2float_ru(E * (1.0 + 1e-6) + 1e-12));
-        } else if (threadIdx.x < 7) {
-            for (int b = 0; b < 32; ++b) {
-                const int c = 32 * (int)threadIdx.x + b;
-                if (c < S && siv[c] != 0.0f) w |= 1u << b;               // NaN counts as non-zero
-            }
-        } else {
-            for (int c = 0; c < S; ++c) if (siv[c] != siv[c]) w = 1u;
+    const bool col = (int)threadIdx.x < S;                             // S <= 224 < blockDim: thread c looks at column c
+    const float ivc = col ? siv[threadIdx.x] : 0.0f;
+    const int any_nan = __syncthreads_or(col && ivc != ivc);           // (also the barrier behind the columns' bounds)
+    const unsigned long long nzb = __ballot(col && ivc != 0.0f);       // NaN counts as non-zero
+    const int wv = (int)(threadIdx.x >> 6), ln = (int)(threadIdx.x & 63);
+    if (wv < 3) {
+        if (ln == 0) { kmask[(size_t)slot * 8 + 2 * wv] = (unsigned int)nzb; kmask[(size_t)slot * 8 + 2 * wv + 1] = (unsigned int)(nzb >> 32); }
+    } else if (wv == 3) {
+        double E = 0.0;
+        for (int cc = ln; cc < S; cc += kWave) E = E + svk[cc];
+        E = wave_sum_f64(E);
+        if (ln == 0) {
+            kmask[(size_t)slot * 8 + 6] = S <= 192 ? (unsigned int)__float_as_int(__double2float_ru(E * (1.0 + 1e-6) + 1e-12)) : (unsigned int)nzb;
+            kmask[(size_t)slot * 8 + 7] = any_nan ? 1u : 0u;
         }
-        kmask[(size_t)slot * 8 + threadIdx.x] = w;
     }
+    ING_STAMP(9);
 }
 
 __global__ __launch_bounds__(256) void ingest_kernel(IngestArgs ia)
@@ -513,7 +555,7 @@ hipError_t launch_make_sc_batch(ScanBatch b, int stride_bytes, int R, int S, dou
     return hipGetLastError();
 }
 
-static size_t ingest_lds_bytes(int R, int S) { return sizeof(float) * ((size_t)R * (S + 1) + S + 2) + sizeof(double) * 2 * (size_t)S; }
+static size_t ingest_lds_bytes(int R, int S) { return sizeof(float) * ((size_t)R * (S + 1) + S + 2) + sizeof(double) * 3 * (size_t)S; }
 
 hipError_t launch_ingest(const float *values, int count, int first_slot,
                          float4 *desc, double *vkey, double *norm, float *rkey, float4 *rkey4,
@@ -523,14 +565,15 @@ hipError_t launch_ingest(const float *values, int count, int first_slot,
     if (count <= 0) return hipSuccess;
     if (S > 224) return hipErrorInvalidValue;              // kmask holds 7 words of sector bits
     const size_t lds = ingest_lds_bytes(R, S);
-    static std::atomic<bool> attr_set_dev[64];   // per device; engines on different threads may race here: atomic flag,
-    int dev_ = 0; (void)hipGetDevice(&dev_);     // and setting the attribute twice is harmless
-    std::atomic<bool> &attr_set = attr_set_dev[dev_ & 63];
-    if (!attr_set.load(std::memory_order_acquire) && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)ingest_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // (the attribute is raised to what the launch needs, not to the CU's 160 KB: the kernel has a few bytes of static LDS of its own --
+    //  __syncthreads_or -- and static + dynamic must fit.  Per device; engines on different threads may race here: setting it twice is harmless)
+    static std::atomic<size_t> attr_lds_dev[64];
+    int dev_ = 0; (void)hipGetDevice(&dev_);
+    std::atomic<size_t> &attr_lds = attr_lds_dev[dev_ & 63];
+    if (lds > 48 * 1024 && lds > attr_lds.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute((const void *)ingest_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set.store(true, std::memory_order_release);
+        attr_lds.store(lds, std::memory_order_release);
     }
     IngestArgs ia{values, first_slot, desc, vkey, norm, rkey, rkey4, hdesc, kmask, hkey, hstride, cap, R, S, halign, tiles, vals_out};
     hipLaunchKernelGGL(ingest_kernel, dim3(count), dim3(256), lds, stream, ia);
@@ -552,18 +595,30 @@ hipError_t launch_front_fused(ScanBatch b, int stride_bytes, double lidar_height
     if (total + n_ingest == 0) return hipSuccess;
     const size_t lds_i = n_ingest ? ingest_lds_bytes(ia.R, ia.S) : 0, lds_s = sizeof(int) * (size_t)ia.R * ia.S;
     const size_t lds = lds_i > lds_s ? lds_i : lds_s;
-    static std::atomic<bool> attr_set_dev[64];
+    static std::atomic<size_t> attr_lds_dev[64];
     int dev_ = 0; (void)hipGetDevice(&dev_);
-    std::atomic<bool> &attr_set = attr_set_dev[dev_ & 63];
-    if (!attr_set.load(std::memory_order_acquire) && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)front_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    std::atomic<size_t> &attr_lds = attr_lds_dev[dev_ & 63];
+    if (lds > 48 * 1024 && lds > attr_lds.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute((const void *)front_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set.store(true, std::memory_order_release);
+        attr_lds.store(lds, std::memory_order_release);
     }
     hipLaunchKernelGGL(front_fused_kernel, dim3(total + n_ingest), dim3(256), lds, stream, b, stride_bytes, lidar_height, max_radius, gtiles,
                        scl_lab_int("SCL_SC_LAB", 0), ia, n_ingest);
     return hipGetLastError();
 }
+
+#ifdef SCL_DIAGNOSTICS
+void ingest_stamps_print()
+{
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ingest_stamps), sizeof h) != hipSuccess || !h[15]) return;
+    static const char *names[11] = {"load + finalize", "tiled copy", "sector key + norms", "ring key", "barrier", "hdesc", "h2 image", "unit key, kerr", "halign", "E sum + masks", "E columns' barrier"};
+    fprintf(stderr, "ingest stamps (workgroup 0, %llu launches, us per launch):", h[15]);
+    for (int k = 0; k < 11; ++k) fprintf(stderr, " %s %.2f;", names[k], (double)h[k] / (double)h[15] / 100.0);
+    fprintf(stderr, "\n");
+}
+#endif
 
 hipError_t launch_atanf_block_checksums(int first_block, int n_blocks, unsigned long long *d_out, hipStream_t stream)
 {
