@@ -90,3 +90,46 @@ def test_distance_matrix_equals_the_13_shift_kernel_on_the_whole_database(world)
             for c in rs.randint(lo, hi, 12):
                 dc, sc = ob.distance(cfg, descs[qs[r]], descs[int(c)], fast=True)
                 assert sc == sh[r][c - lo] and np.float64(dc).view(np.uint64) == dist[r][c - lo:c - lo + 1].view(np.uint64)[0]
+
+
+def test_points_pipeline_at_full_size_agrees_three_ways(world):
+    """BASELINE configs[1]'s per-incoming-scan path at its stated size -- 120 k-point scans into the 10 k-keyframe database -- through the
+    three forms: scl_stream_from_points (host clouds, groups of 16), scl_stream_from_store (the same clouds resident in HBM) and the
+    reference's own call pattern, scl_make_and_save + scl_detect_full_range per keyframe.  Size-independent properties: the three
+    agree on every descriptor, winner, shift and fp64 distance bit for bit; a scan that is an earlier scan turned about z by whole
+    sectors is found at that scan with that shift and distance ~0; descriptors of a sample equal the checker's."""
+    from scl_slam_amd.synth import synth_scan
+    _, descs, _ = world
+    n_scans, npts, excl = 36, 120000, 100
+    engines = [ScanContextEngine(num_ring=R, num_sector=S, num_exclude_recent=excl, initial_capacity=N + 64) for _ in range(3)]
+    for e in engines:
+        e.save_bulk(descs)
+    clouds = [np.ascontiguousarray(synth_scan(npts, seed=9100 + i, stride_floats=4)) for i in range(n_scans)]
+    # scan 20 = scan 3 turned about z by 11 sectors (36 scans behind an exclusion window of 100: a scan never finds another scan of
+    # the call, so the rotation is checked on the descriptors, below)
+    a = np.deg2rad(11 * 360.0 / S)
+    src = clouds[3].copy()
+    x, y = src[:, 0].astype(np.float64), src[:, 1].astype(np.float64)
+    src[:, 0] = (x * np.cos(a) - y * np.sin(a)).astype(np.float32); src[:, 1] = (x * np.sin(a) + y * np.cos(a)).astype(np.float32)
+    clouds[20] = src
+    nn, sh, dd, vals = engines[0].stream_from_points(clouds, want_values=True)
+    for i, c in enumerate(clouds):
+        engines[1].keyframe_put(0, i, c)
+    nn1, sh1, dd1, vals1 = engines[1].stream_from_store(0, 0, n_scans, want_values=True)
+    assert np.array_equal(vals.view(np.uint32), vals1.view(np.uint32))
+    assert np.array_equal(nn, nn1) and np.array_equal(sh, sh1) and np.array_equal(dd.view(np.uint64), dd1.view(np.uint64))
+    for i, c in enumerate(clouds):
+        v = engines[2].make_and_save(c, 0, N + i)
+        g = engines[2].detect_full_range(N + i, 0, N + i - excl)
+        assert np.array_equal(v.view(np.uint32), vals[i].view(np.uint32)), i
+        assert (int(nn[i]), int(sh[i])) == (g[0], g[1]) and np.float64(dd[i]).view(np.uint64) == np.float64(g[2]).view(np.uint64), i
+    assert (nn >= 0).all() and (nn < N + n_scans - excl).all()
+    # the rotation property (D.h:1376-1395 on a cloud turned about z): most cells of scan 20's descriptor are scan 3's, 11 sectors on
+    d3, d20 = vals[3].reshape(R, S), vals[20].reshape(R, S)
+    same = (np.roll(d3, 11, axis=1) == d20).mean()
+    assert same > 0.9, same                                             # (points on bin edges move to a neighbouring cell under the float rotation)
+    cfg = ob.make_config(R=R, S=S)
+    for i in (0, 20, 35):
+        assert np.array_equal(vals[i].view(np.uint32), ob.make_scancontext(cfg, clouds[i]).view(np.uint32)), i
+    for e in engines:
+        e.close()
