@@ -6,20 +6,45 @@
 #include <stdlib.h>
 #include <string.h>
 
-double sco_atan_pos(double x);      /* sc_oracle.c: the fixed atan shared with the GPU */
-
-/* atan2 for the two uses of D.h:547-549: float arguments, float result (std::atan2(float, float)), evaluated through
- * the fixed fp64 atan so that CPU and GPU agree on every bin (the platform's atan2f differs in the last bit) */
-static float iriso_atan2f(float y, float x)
+/* atan2 for the two uses of D.h:547-549: float arguments, float result -- std::atan2(float, float) = the platform's atan2f.  On the
+ * x86-64 glibc the reference is built against (2.35 here) that is sysdeps/ieee754/flt-32/e_atan2f.c: fdlibm's case analysis around
+ * atanf(|y / x|) -- the float atan restated and pinned in sc_oracle.c (equal to libm on all 2^32 inputs) -- with the pi / pi_lo
+ * corrections of the second and third quadrants, fp32 throughout.  Restated here operation by operation; oracle/tools/atan2f_check.c
+ * compares it with libm's atan2f on 4e9 pairs (random bit patterns, every pair of special values, realistic coordinates): 0
+ * differences; tests/test_iris.py checks a sample on every run.  (Rounds 2-4 evaluated both uses through one fp64 polynomial.) */
+float sco_atanf_glibc(float x);     /* sc_oracle.c */
+static inline unsigned int iris_f32_bits(float f) { unsigned int u; memcpy(&u, &f, 4); return u; }
+static inline float iris_f32_from_bits(unsigned int u) { float f; memcpy(&f, &u, 4); return f; }
+float iriso_atan2f(float y, float x)
 {
-    const double PI = 3.14159265358979323846;
-    if (x != x || y != y) return NAN;
-    if (y == 0.0f) return (x < 0.0f || (x == 0.0f && signbit(x))) ? (signbit(y) ? -(float)PI : (float)PI) : y;
-    if (x == 0.0f) return y > 0.0f ? (float)(PI / 2) : (float)(-PI / 2);
-    const double ay = fabs((double)y), ax = fabs((double)x);
-    double a = isinf(ay) ? (isinf(ax) ? PI / 4 : PI / 2) : (isinf(ax) ? 0.0 : sco_atan_pos(ay / ax));
-    if (x < 0.0f) a = PI - a;
-    return (float)(y < 0.0f ? -a : a);
+    const float tiny = 1.0e-30f, zero = 0.0f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    float z;
+    const int hx = (int)iris_f32_bits(x), ix = hx & 0x7fffffff, hy = (int)iris_f32_bits(y), iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;                 /* x or y is NaN */
+    if (hx == 0x3f800000) return sco_atanf_glibc(y);                      /* x = 1.0 */
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);                    /* 2 sign(x) + sign(y) */
+    if (iy == 0) {                                                        /* y = 0 */
+        switch (m) { case 0: case 1: return y; case 2: return pi + tiny; default: return -pi - tiny; }
+    }
+    if (ix == 0) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;        /* x = 0 */
+    if (ix == 0x7f800000) {                                               /* x is inf */
+        if (iy == 0x7f800000) {
+            switch (m) { case 0: return pi_o_4 + tiny; case 1: return -pi_o_4 - tiny; case 2: return 3.0f * pi_o_4 + tiny; default: return -3.0f * pi_o_4 - tiny; }
+        } else {
+            switch (m) { case 0: return zero; case 1: return -zero; case 2: return pi + tiny; default: return -pi - tiny; }
+        }
+    }
+    if (iy == 0x7f800000) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;   /* y is inf */
+    const int k = (iy - ix) >> 23;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;                                /* |y / x| > 2^60 */
+    else if (hx < 0 && k < -60) z = 0.0f;                                 /* |y| / x < -2^60 */
+    else z = sco_atanf_glibc(fabsf(y / x));
+    switch (m) {
+    case 0: return z;                                                     /* atan(+, +) */
+    case 1: return iris_f32_from_bits(iris_f32_bits(z) ^ 0x80000000u);    /* atan(-, +) */
+    case 2: return pi - (z - pi_lo);                                      /* atan(+, -) */
+    default: return (z - pi_lo) - pi;                                     /* atan(-, -) */
+    }
 }
 
 static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }

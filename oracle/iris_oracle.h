@@ -23,6 +23,8 @@ typedef struct iriso_config {
 } iriso_config;
 
 /* getIris, D.h:532-598: image rows*cols bytes (row-major), rowkey rows floats */
+/* glibc's float atan2f restated (fp32 ops; equal to libm on 4e9 pairs: oracle/tools/atan2f_check.c) -- std::atan2(float, float) of D.h:547-549 */
+float iriso_atan2f(float y, float x);
 void iriso_make_image(const iriso_config *c, const void *pts, int n, int stride_bytes, uint8_t *image, float *rowkey);
 /* logFeatureEncode, D.h:661-680: T and M, (2*nscale*rows) x cols bytes each, 0 / 255 */
 void iriso_encode(const iriso_config *c, const uint8_t *image, uint8_t *T, uint8_t *M);

@@ -68,41 +68,6 @@ __device__ __forceinline__ float atanf_glibc(float x)
     return r;
 }
 
-// ---- fixed fp64 atan (x >= 0) behind LiDAR-Iris's atan2 (iris.hip; rounds 1-4 also used it for xy2theta): identical operation
-// sequence to the CPU checker's restatement; only + - * / in a fixed order, no libm --------------
-__device__ __forceinline__ double atan_pos(double x)
-{
-    const double hi0 = 4.63647609000806093515e-01, lo0 = 2.26987774529616870924e-17;
-    const double hi1 = 7.85398163397448278999e-01, lo1 = 3.06161699786838301793e-17;
-    const double hi2 = 9.82793723247329054082e-01, lo2 = 1.39033110312309984516e-17;
-    const double hi3 = 1.57079632679489655800e+00, lo3 = 6.12323399573676603587e-17;
-    if (x != x) return x;
-    if (x >= 7.378697629483821e19) return hi3 + lo3;
-    int id;
-    double hi = 0.0, lo = 0.0;
-    if (x < 0.4375) {
-        if (x < 1.862645149230957e-09) return x;
-        id = -1;
-    } else if (x < 1.1875) {
-        if (x < 0.6875) { id = 0; hi = hi0; lo = lo0; x = (2.0 * x - 1.0) / (2.0 + x); }
-        else            { id = 1; hi = hi1; lo = lo1; x = (x - 1.0) / (x + 1.0); }
-    } else {
-        if (x < 2.4375) { id = 2; hi = hi2; lo = lo2; x = (x - 1.5) / (1.0 + 1.5 * x); }
-        else            { id = 3; hi = hi3; lo = lo3; x = -1.0 / x; }
-    }
-    const double z = x * x;
-    const double w = z * z;
-    const double s1 = z * (3.33333333333329318027e-01 + w * (1.42857142725034663711e-01 +
-                      w * (9.09088713343650656196e-02 + w * (6.66107313738753120669e-02 +
-                      w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));
-    const double s2 = w * (-1.99999999998764832476e-01 + w * (-1.11111104054623557880e-01 +
-                      w * (-7.69187620504482999495e-02 + w * (-5.83357013379057348645e-02 +
-                      w * -3.65315727442169155270e-02))));
-    if (id < 0) return x - x * (s1 + s2);
-    return hi - ((x * (s1 + s2) - lo) - x);
-}
-
-
 // xy2theta, D.h:1352-1374.  The four quadrant branches of the reference differ in the operands of the division (y / x, y / (-x), y / x,
 // (-y) / x) and in how the angle is placed (k a, 180 - k a, 180 + k a, 360 - k a): operands and placement are selected, every lane
 // divides once.  The conditions are the reference's own (x = -0.0 counts as x >= 0: y / -0.0 = -inf and the angle is -90 or 450 --

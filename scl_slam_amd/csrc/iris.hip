@@ -33,16 +33,29 @@ using namespace scl;
 namespace {
 
 __device__ __forceinline__ float iris_atan2f(float y, float x)
-{   // the fixed fp64 atan of device_common.hpp behind std::atan2(float, float): same bits as oracle/iris_oracle.c
-    const double PI = 3.14159265358979323846;
-    if (x != x || y != y) return __int_as_float(0x7fc00000);
-    if (y == 0.0f) return (x < 0.0f || (x == 0.0f && (__float_as_int(x) < 0))) ? ((__float_as_int(y) < 0) ? -(float)PI : (float)PI) : y;
-    if (x == 0.0f) return y > 0.0f ? (float)(PI / 2) : (float)(-PI / 2);
-    const double ay = fabs((double)y), ax = fabs((double)x);
-    const bool iy = ay > 1.7976931348623157e308, ix = ax > 1.7976931348623157e308;
-    double a = iy ? (ix ? PI / 4 : PI / 2) : (ix ? 0.0 : atan_pos(ay / ax));
-    if (x < 0.0f) a = PI - a;
-    return (float)(y < 0.0f ? -a : a);
+{   // std::atan2(float, float) of D.h:547-549 = glibc's atan2f (fdlibm's case analysis around atanf(|y / x|), fp32 throughout): the same
+    // restatement as oracle/iris_oracle.c's, which equals libm on 4e9 pairs; atanf_glibc: device_common.hpp (all 2^32 inputs)
+    const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const int hx = __float_as_int(x), ix = hx & 0x7fffffff, hy = __float_as_int(y), iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
+    if (hx == 0x3f800000) return atanf_glibc(y);
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    if (iy == 0) return m < 2 ? y : (m == 2 ? pi + tiny : -pi - tiny);
+    if (ix == 0) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) return m == 0 ? pi_o_4 + tiny : (m == 1 ? -pi_o_4 - tiny : (m == 2 ? 3.0f * pi_o_4 + tiny : -3.0f * pi_o_4 - tiny));
+        return m == 0 ? 0.0f : (m == 1 ? -0.0f : (m == 2 ? pi + tiny : -pi - tiny));
+    }
+    if (iy == 0x7f800000) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int k = (iy - ix) >> 23;
+    float z;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60) z = 0.0f;
+    else z = atanf_glibc(fabsf(y / x));
+    if (m == 0) return z;
+    if (m == 1) return __int_as_float(__float_as_int(z) ^ (int)0x80000000u);
+    if (m == 2) return pi - (z - pi_lo);
+    return (z - pi_lo) - pi;
 }
 
 __device__ __forceinline__ int floor_to_int_x86(double v)

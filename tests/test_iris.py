@@ -112,3 +112,23 @@ def test_iris_on_the_gpu_equals_the_restatement():
     d_all, b_all = eng.hamming_all_shifts(0, np.array([1, 2, 3, 4, 5], np.int32))
     assert int(np.argmin(d_all)) == 4 and abs(int(b_all[4]) - 37) <= 1 and d_all[4] < 0.5 * np.delete(d_all, 4).min()
     eng.close()
+
+
+def test_restated_atan2f_equals_libm_on_a_sample():
+    """D.h:547-549 call std::atan2(float, float) = the platform's atan2f; the checker (and, bit for bit, the device: the image tests
+    below compare the two) restates glibc's.  `make -C oracle atan2f-check` compares it with libm on 4e9 pairs (0 differences); here:
+    every pair of special values and 60 000 random pairs, without a GPU."""
+    import ctypes
+    import oracle_binding as ob
+    L = ob.load()
+    L.iriso_atan2f.restype = ctypes.c_float; L.iriso_atan2f.argtypes = [ctypes.c_float, ctypes.c_float]
+    libm = ctypes.CDLL("libm.so.6"); libm.atan2f.restype = ctypes.c_float; libm.atan2f.argtypes = [ctypes.c_float, ctypes.c_float]
+    special = np.array([0, 0x80000000, 1, 0x80000001, 0x007fffff, 0x00800000, 0x3f800000, 0xbf800000, 0x7f800000, 0xff800000, 0x7fc00000,
+                        0x7f7fffff, 0xff7fffff, 0x3f000000, 0x40490fdb, 0x1e3ce508], dtype=np.uint32).view(np.float32)
+    rs = np.random.RandomState(11)
+    rnd = rs.randint(0, 2 ** 32, size=(20000, 2), dtype=np.uint64).astype(np.uint32).view(np.float32)
+    coords = (rs.uniform(-100, 100, size=(40000, 2))).astype(np.float32)
+    pairs = [(float(a), float(b)) for a in special for b in special] + [tuple(map(float, p)) for p in rnd] + [tuple(map(float, p)) for p in coords]
+    for y, x in pairs:
+        a, b = L.iriso_atan2f(y, x), libm.atan2f(y, x)
+        assert (a != a and b != b) or np.float32(a).view(np.uint32) == np.float32(b).view(np.uint32), (y, x, a, b)
