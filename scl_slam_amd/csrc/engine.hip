@@ -24,7 +24,7 @@
 #include "engine_internal.hpp"
 
 #ifdef SCL_DIAGNOSTICS
-namespace scl { void ingest_stamps_print(); }       // make_sc.hip: the ingest's phase stamps (SCL_INGEST_STAMPS=1)
+namespace scl { void ingest_stamps_print(); void cand_stamps_print(); }   // make_sc.hip / sc_masked.hip: phase stamps (SCL_INGEST_STAMPS=1)
 #endif
 
 using namespace scl;
@@ -670,7 +670,7 @@ int scl_create(const scl_config *cfg, scl_engine **out)
 int scl_destroy(scl_engine *e)
 {
 #ifdef SCL_DIAGNOSTICS
-    if (e && !e->front && scl_lab_int("SCL_INGEST_STAMPS", 0)) { (void)hipSetDevice(e->device); scl::ingest_stamps_print(); }
+    if (e && !e->front && scl_lab_int("SCL_INGEST_STAMPS", 0)) { (void)hipSetDevice(e->device); scl::ingest_stamps_print(); scl::cand_stamps_print(); }
 #endif
     if (!e) return SCL_OK;
     if (e->front) return front_destroy(e);

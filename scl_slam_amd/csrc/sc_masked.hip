@@ -19,6 +19,7 @@
 // Callers: the exact distance MATRIX (scl_sc_distance_matrix on the screened grids: every pair of a batch of scans), and the exact
 // pass over the survivors of the 80 x 180 grid (the wave program that grid lacked).
 #include <atomic>
+#include <cstdio>
 
 #include "align_exact.hpp"
 #include "device_common.hpp"
@@ -584,9 +585,19 @@ struct CandCfg {
     static constexpr size_t LDS = LDS_Q + LDS_N + kCandWaves * LDS_WAVE + (size_t)S * 8;
 };
 
+#ifdef SCL_DIAGNOSTICS
+__device__ unsigned long long g_cand_stamps[16];      // ticks (100 MHz) of thread 0 between the candidates' kernel's phases; [15] = launches
+#define CAND_STAMP(k) do { if (threadIdx.x == 0) { const unsigned long long now__ = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_cand_stamps[k], now__ - cand_t0__); cand_t0__ = now__; } } while (0)
+#else
+#define CAND_STAMP(k) ((void)0)
+#endif
 template <int RG, int S, int W>
 __global__ __launch_bounds__(kCandWaves * kWave) void sc_cand_exact_kernel(CandExactArgs ca)
 {
+#ifdef SCL_DIAGNOSTICS
+    unsigned long long cand_t0__ = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) atomicAdd(&g_cand_stamps[15], 1ull);
+#endif
     using C = MaskedCfg<RG, S, W>;
     using CC = CandCfg<RG, S, W>;
     constexpr int PITCH = C::PITCH, QCOLS = C::QCOLS, SR = (W - 1) / 2;
@@ -619,6 +630,7 @@ __global__ __launch_bounds__(kCandWaves * kWave) void sc_cand_exact_kernel(CandE
             ca.cand_idx_out[threadIdx.x] = ci; ca.cand_d2_out[threadIdx.x] = cd;
         }
         __syncthreads();                                                         // (the rows' LDS is free again)
+        CAND_STAMP(0);
     } else {
         if (wave < ca.k) my_slot = ca.cand_idx[wave];
         if (wave + kCandWaves < ca.k) my_slot2 = ca.cand_idx[wave + kCandWaves];
@@ -632,6 +644,7 @@ __global__ __launch_bounds__(kCandWaves * kWave) void sc_cand_exact_kernel(CandE
     for (int c = threadIdx.x; c < S; c += blockDim.x) vq[c] = ca.q_vkey[c];
     if (!ca.lists && (int)threadIdx.x < ca.k) { o_idx[threadIdx.x] = ca.cand_idx[threadIdx.x]; o_d2[threadIdx.x] = ca.cand_d2[threadIdx.x]; }
     __syncthreads();
+    CAND_STAMP(1);
     for (int c = wave; c < ca.k; c += kCandWaves) {
         const int slot = c == wave ? my_slot : my_slot2;
         double best = kBigDist; int bshift = 0;
@@ -640,6 +653,7 @@ __global__ __launch_bounds__(kCandWaves * kWave) void sc_cand_exact_kernel(CandE
             const int ll2 = lane < L ? lane : L - 1;
             const double2 vk = *reinterpret_cast<const double2 *>(ca.vkey + (size_t)slot * S + 2 * ll2);
             const int a0 = align_keyframe_exact<S>(vk, lane, wrow, vq);
+            CAND_STAMP(2);
             int first = a0 - SR; first = first < 0 ? first + S : first;          // D.h:1545-1551: the searched shifts start SEARCH_RADIUS below
             wave_fence_lds();
             double b; int bs;
@@ -647,6 +661,7 @@ __global__ __launch_bounds__(kCandWaves * kWave) void sc_cand_exact_kernel(CandE
             masked_pair<RG, S, W, PDC, W, true>(Qs, nq, wrow, ca.desc + (size_t)slot * (size_t)(RG * S), ca.norm + (size_t)slot * S, first,
                                                W >= 32 ? 0xffffffffu : ((1u << W) - 1u), lane, b, bs);
             if (b < kBigDist) { best = b; bshift = bs; }
+            CAND_STAMP(3);
         }
         if (lane == 0) { o_dist[c] = best; o_shift[c] = bshift; }
     }
@@ -655,9 +670,22 @@ __global__ __launch_bounds__(kCandWaves * kWave) void sc_cand_exact_kernel(CandE
         __syncthreads();
         if (threadIdx.x == 0) *reinterpret_cast<volatile unsigned int *>(ca.out + cand_seq_offset(ca.k)) = ca.seq;
     }
+    CAND_STAMP(4);
 }
 
 }  // namespace
+
+#ifdef SCL_DIAGNOSTICS
+void cand_stamps_print()
+{
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_cand_stamps), sizeof h) != hipSuccess || !h[15]) return;
+    static const char *names[5] = {"merge of the scan's lists", "scan staged", "alignment (wave 0's candidate)", "13 shifts", "results out"};
+    fprintf(stderr, "candidates' kernel stamps (thread 0, %llu launches, us per launch):", h[15]);
+    for (int k = 0; k < 5; ++k) fprintf(stderr, " %s %.2f;", names[k], (double)h[k] / (double)h[15] / 100.0);
+    fprintf(stderr, "\n");
+}
+#endif
 
 bool sc_masked_supported(const DbView &db, int SR)
 {
