@@ -614,6 +614,36 @@ __global__ __launch_bounds__(kCandWaves * kWave) void sc_cand_exact_kernel(CandE
     int *o_shift = reinterpret_cast<int *>(ca.out + (sizeof(int) + sizeof(float) + sizeof(double)) * ca.k);
     // the candidates first (a dependent load otherwise), then the scan
     int my_slot = -1, my_slot2 = -1;                                             // candidates wave and wave + kCandWaves (k <= 16)
+    // Every global read of the prologue first -- the scan (desc, norms, sector key) and the ring-key scan's lists --, then the LDS stores
+    // and the merge: one memory round trip where "merge, then stage" was two (phase stamps: 3.4 + 2.3 us of the kernel's 25).
+    constexpr int NT = kCandWaves * kWave, NL = (RG * QCOLS + NT - 1) / NT;
+    static_assert(QCOLS <= NT && S <= NT && kCandMergeMaxKeys <= 2 * NT, "one norm, one key entry and two list keys per thread");
+    float4 sqv[NL];
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+        int idx = (int)threadIdx.x + u * NT; idx = idx < RG * QCOLS ? idx : RG * QCOLS - 1;
+        const int rg = idx / QCOLS, cx = idx - rg * QCOLS;
+        sqv[u] = ca.q_desc[(size_t)rg * S + (cx < S ? cx : cx - S)];
+    }
+    const int cxn = (int)threadIdx.x < QCOLS ? (int)threadIdx.x : QCOLS - 1;
+    const double nqv = ca.q_norm[cxn < S ? cxn : cxn - S];
+    const double vqv = ca.q_vkey[(int)threadIdx.x < S ? (int)threadIdx.x : S - 1];
+    const int n_keys = ca.lists ? ca.n_lists * ca.k : 0;
+    unsigned long long lk0 = ~0ull, lk1 = ~0ull;
+    if (n_keys > 0) {
+        lk0 = ca.lists[(int)threadIdx.x < n_keys ? (int)threadIdx.x : n_keys - 1];
+        lk1 = ca.lists[(int)threadIdx.x + NT < n_keys ? (int)threadIdx.x + NT : n_keys - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+        const int idx = (int)threadIdx.x + u * NT;
+        if (idx < RG * QCOLS) {
+            const int rg = idx / QCOLS, cx = idx - rg * QCOLS;
+            *reinterpret_cast<float4 *>(Qs + (size_t)cx * PITCH + rg * 16) = sqv[u];
+        }
+    }
+    if ((int)threadIdx.x < QCOLS) nq[threadIdx.x] = nqv;
+    if ((int)threadIdx.x < S) vq[threadIdx.x] = vqv;
     if (ca.lists) {
         // the ring-key scan left its per-workgroup lists: merged here (topk_merge.hpp), in the LDS of the waves' rows, which nothing uses yet
         unsigned long long *skey = reinterpret_cast<unsigned long long *>(smem_c + CC::LDS_Q + CC::LDS_N);
@@ -621,7 +651,9 @@ __global__ __launch_bounds__(kCandWaves * kWave) void sc_cand_exact_kernel(CandE
         TopkMergeShared *msh = reinterpret_cast<TopkMergeShared *>(scand + kCandMergeMaxKeys);
         int *r_idx = reinterpret_cast<int *>(msh + 1);
         float *r_d2 = reinterpret_cast<float *>(r_idx + 16);
-        topk_merge_lists(ca.lists, ca.n_lists, ca.k, skey, scand, msh, r_idx, r_d2);
+        if ((int)threadIdx.x < n_keys) skey[threadIdx.x] = lk0;
+        if ((int)threadIdx.x + NT < n_keys) skey[threadIdx.x + NT] = lk1;
+        topk_merge_lists(ca.lists, ca.n_lists, ca.k, skey, scand, msh, r_idx, r_d2, true);
         if (wave < ca.k) my_slot = r_idx[wave];
         if (wave + kCandWaves < ca.k) my_slot2 = r_idx[wave + kCandWaves];
         if ((int)threadIdx.x < ca.k) {
@@ -629,19 +661,11 @@ __global__ __launch_bounds__(kCandWaves * kWave) void sc_cand_exact_kernel(CandE
             o_idx[threadIdx.x] = ci; o_d2[threadIdx.x] = cd;
             ca.cand_idx_out[threadIdx.x] = ci; ca.cand_d2_out[threadIdx.x] = cd;
         }
-        __syncthreads();                                                         // (the rows' LDS is free again)
         CAND_STAMP(0);
     } else {
         if (wave < ca.k) my_slot = ca.cand_idx[wave];
         if (wave + kCandWaves < ca.k) my_slot2 = ca.cand_idx[wave + kCandWaves];
     }
-    for (int idx = threadIdx.x; idx < RG * QCOLS; idx += blockDim.x) {
-        const int rg = idx / QCOLS, cx = idx - rg * QCOLS;
-        const int c = cx < S ? cx : cx - S;
-        *reinterpret_cast<float4 *>(Qs + (size_t)cx * PITCH + rg * 16) = ca.q_desc[(size_t)rg * S + c];
-    }
-    for (int cx = threadIdx.x; cx < QCOLS; cx += blockDim.x) nq[cx] = ca.q_norm[cx < S ? cx : cx - S];
-    for (int c = threadIdx.x; c < S; c += blockDim.x) vq[c] = ca.q_vkey[c];
     if (!ca.lists && (int)threadIdx.x < ca.k) { o_idx[threadIdx.x] = ca.cand_idx[threadIdx.x]; o_d2[threadIdx.x] = ca.cand_d2[threadIdx.x]; }
     __syncthreads();
     CAND_STAMP(1);

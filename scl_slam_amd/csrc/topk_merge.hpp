@@ -26,12 +26,13 @@ struct TopkMergeShared { unsigned long long tau; unsigned int nc; };
 //   3. every candidate counts the candidates below it (keys are unique: the slot is their low word): rank < k -> output[rank].
 // (A merge by binary search per (key, list) was built first: 39 x 5 DEPENDENT LDS reads per key -- 40 us at k = 25.)
 // Ends with a barrier: the outputs are visible to the block.
+// keys_in_lds: the caller has put the L * k keys into skey already (its own loads, issued beside others: the candidates' kernel).
 __device__ __forceinline__ void topk_merge_lists(const unsigned long long *lists, int L, int k, unsigned long long *skey, unsigned long long *scand,
-                                                 TopkMergeShared *sh, int *out_idx, float *out_d2)
+                                                 TopkMergeShared *sh, int *out_idx, float *out_d2, const bool keys_in_lds = false)
 {
     const int T = (int)blockDim.x, tid = (int)threadIdx.x;
     const int count = L * k;
-    for (int p = tid; p < count; p += T) skey[p] = lists[p];
+    if (!keys_in_lds) for (int p = tid; p < count; p += T) skey[p] = lists[p];
     for (int i = tid; i < k; i += T) { out_idx[i] = -1; out_d2[i] = FLT_MAX; }
     if (tid == 0) { sh->tau = kTopkNoKey; sh->nc = 0u; }
     __syncthreads();
