@@ -10,7 +10,7 @@ CSRC    := scl_slam_amd/csrc
 LIBDIR  := scl_slam_amd/lib
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
             -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-result -Iinclude -I$(CSRC) $(EXTRA)
-SRCS    := $(CSRC)/engine.hip $(CSRC)/sc_distance.hip $(CSRC)/ringkey_topk.hip $(CSRC)/make_sc.hip $(CSRC)/icp.hip $(CSRC)/voxel.hip $(CSRC)/sharded_front.hip $(CSRC)/sc_screen.hip $(CSRC)/sc_masked.hip $(CSRC)/sc_matrix.hip $(CSRC)/messages.hip $(CSRC)/iris.hip
+SRCS    := $(CSRC)/engine.hip $(CSRC)/sc_distance.hip $(CSRC)/ringkey_topk.hip $(CSRC)/make_sc.hip $(CSRC)/icp.hip $(CSRC)/voxel.hip $(CSRC)/sharded_front.hip $(CSRC)/sc_screen.hip $(CSRC)/sc_masked.hip $(CSRC)/sc_matrix.hip $(CSRC)/messages.hip $(CSRC)/iris.hip $(CSRC)/device_sort.hip
 OBJS    := $(SRCS:.hip=.o)
 
 all: $(LIBDIR)/libscl_engine.so oracle tests/cpp/adapter_check tests/cpp/libmock_rccl.so

@@ -416,6 +416,14 @@ int  scl_selftest_atanf_blocks(scl_engine *e, int first_block, int n_blocks, uin
  * inf, NaN): *sure = points the fast path answered, *disagreements = those of them where the chain says otherwise (must be 0). */
 int  scl_selftest_bin_paths(scl_engine *e, int mode, uint64_t seed, uint64_t n_points, uint64_t *disagreements, uint64_t *sure);
 
+/* Self test of the verification path's own stable radix sort (csrc/device_sort.hip; it replaced hipCUB's): the n (key, value) pairs
+ * sorted on the key bits [0, bits), equal keys in their input order.  key_bytes 4 or 8; n_segments > 1 (8-byte keys): every segment
+ * [segment_offsets[s], segment_offsets[s + 1]) sorted on its own, as the 26 submaps of a query are (DM.h:1183-1185 through PCL's VoxelGrid). */
+int  scl_selftest_sort_pairs(scl_engine *e, int key_bytes, const void *keys, const uint32_t *values, int n, int bits, const int *segment_offsets,
+                             int n_segments, void *keys_out, uint32_t *values_out);
+/* ... and of its prefix sums (cell counts -> cell starts): out[i] = in[0] + ... + in[i - 1], + in[i] when inclusive != 0 */
+int  scl_selftest_prefix_sum(scl_engine *e, const int32_t *in, int n, int inclusive, int32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,7 @@
 
 #include "db_file.hpp"
 #include "engine_internal.hpp"
+#include "device_sort.hpp"
 
 #ifdef SCL_DIAGNOSTICS
 namespace scl { void ingest_stamps_print(); void cand_stamps_print(); }   // make_sc.hip / sc_masked.hip: phase stamps (SCL_INGEST_STAMPS=1)
@@ -2343,6 +2344,64 @@ int scl_selftest_bin_paths(scl_engine *e, int mode, uint64_t seed, uint64_t n_po
     dev_free(d);
     SCL_HIP(e, he);
     *disagreements = h[0]; *sure = h[1];
+    return SCL_OK;
+}
+
+/* test hook: csrc/device_sort.hip's stable radix sort on the key bits [0, bits) -- key_bytes 4 or 8; n_segments > 1: every segment
+ * [segment_offsets[s], segment_offsets[s + 1]) on its own -- as the verification path uses it (voxel.hip, icp.hip) */
+int scl_selftest_sort_pairs(scl_engine *e, int key_bytes, const void *keys, const uint32_t *values, int n, int bits, const int *segment_offsets,
+                            int n_segments, void *keys_out, uint32_t *values_out)
+{
+    if (!e || n < 0 || (key_bytes != 4 && key_bytes != 8) || (n > 0 && (!keys || !values || !keys_out || !values_out))) return SCL_ERR_INVALID_ARG;
+    if (n_segments < 0 || n_segments > kSortMaxSegments || (n_segments > 1 && (!segment_offsets || key_bytes != 8))) return SCL_ERR_INVALID_ARG;
+    if (n == 0) return SCL_OK;
+    if (e->front) e = front_primary(e);
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    SortSegments seg{};
+    seg.nseg = n_segments > 1 ? n_segments : 1; seg.off[0] = 0; seg.off[1] = n;
+    if (n_segments > 1) {
+        for (int s = 0; s <= n_segments; ++s) seg.off[s] = segment_offsets[s];
+        if (seg.off[0] != 0 || seg.off[n_segments] != n) return SCL_ERR_INVALID_ARG;
+    }
+    unsigned char *d = nullptr;
+    const size_t kb = (size_t)key_bytes * (size_t)n, vb = sizeof(uint32_t) * (size_t)n, kpad = (kb + 255) & ~(size_t)255, vpad = (vb + 255) & ~(size_t)255;
+    const size_t sb = sort_scratch_bytes((size_t)n, seg.nseg);
+    int rc = dev_alloc(e, &d, 2 * kpad + 2 * vpad + sb);
+    if (rc) return rc;
+    unsigned char *k0 = d, *k1 = d + kpad, *v0 = d + 2 * kpad, *v1 = v0 + vpad, *scratch = v1 + vpad;
+    hipError_t he = hipMemcpyAsync(k0, keys, kb, hipMemcpyHostToDevice, e->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(v0, values, vb, hipMemcpyHostToDevice, e->stream);
+    if (he == hipSuccess) {
+        if (key_bytes == 4) he = sort_pairs_u32(scratch, (unsigned int *)k0, (unsigned int *)k1, (unsigned int *)v0, (unsigned int *)v1, n, bits, e->stream);
+        else he = sort_pairs_u64_segmented(scratch, (unsigned long long *)k0, (unsigned long long *)k1, (unsigned int *)v0, (unsigned int *)v1, seg, bits, e->stream);
+    }
+    if (he == hipSuccess) he = hipMemcpyAsync(keys_out, k1, kb, hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(values_out, v1, vb, hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    dev_free(d);
+    SCL_HIP(e, he);
+    return SCL_OK;
+}
+
+/* test hook: csrc/device_sort.hip's prefix sum of n ints (in place on the device, as the cell table's is) */
+int scl_selftest_prefix_sum(scl_engine *e, const int32_t *in, int n, int inclusive, int32_t *out)
+{
+    if (!e || n < 0 || (n > 0 && (!in || !out))) return SCL_ERR_INVALID_ARG;
+    if (n == 0) return SCL_OK;
+    if (e->front) e = front_primary(e);
+    std::lock_guard<std::mutex> lk(e->mu);
+    (void)hipSetDevice(e->device);
+    unsigned char *d = nullptr;
+    const size_t nb = (sizeof(int32_t) * (size_t)n + 255) & ~(size_t)255;
+    int rc = dev_alloc(e, &d, nb + scan_scratch_bytes((size_t)n));
+    if (rc) return rc;
+    hipError_t he = hipMemcpyAsync(d, in, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, e->stream);
+    if (he == hipSuccess) he = prefix_sum_i32(d + nb, (const int *)d, (int *)d, n, inclusive != 0, e->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(out, d, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    dev_free(d);
+    SCL_HIP(e, he);
     return SCL_OK;
 }
 

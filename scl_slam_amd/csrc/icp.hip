@@ -28,8 +28,8 @@
 // The whole ICP loop is enqueued without host round trips: every kernel looks at a device-side `done` flag; the flags travel to the
 // host every four iterations and are looked at one period later.
 #include "icp.hpp"
+#include "device_sort.hpp"
 
-#include <hipcub/hipcub.hpp>
 
 #include <cfloat>
 #include <cmath>
@@ -1299,8 +1299,8 @@ __global__ __launch_bounds__(256) void plane_solve_batch_kernel(const IcpProblem
 #endif
 constexpr int kTileQ = SCL_TILE_Q, kTilePts = SCL_TILE_PTS, kTileTab = SCL_TILE_TAB, kTileRows = SCL_TILE_ROWS;
 #ifdef SCL_DIAGNOSTICS
-// [0..6] (SCL_DIAGNOSTICS=1): rounds asked for, rounds that did not fit, lanes finished in memory, table entries / points staged, row
-// visits, points compared; [8..14] (SCL_DIAGNOSTICS=2, so that the counters' atomics do not sit in the phases they time): ticks of
+// [0..7] (SCL_DIAGNOSTICS=1): rounds asked for, rounds that did not fit, lanes finished in memory, table entries / points staged, row
+// visits, points compared, tiles left to the finish launch; [8..14] (SCL_DIAGNOSTICS=2, so that the counters' atomics do not sit in the phases they time): ticks of
 // thread 0 of every workgroup between the kernel's phases
 __device__ unsigned long long g_tile_stats[16];
 #endif
@@ -1570,30 +1570,42 @@ __device__ __forceinline__ void tile_reduce(float *pq_area /* kTileQ x 8 floats 
     }
 }
 
+#ifdef SCL_TILE_WAVES
+__attribute__((amdgpu_waves_per_eu(SCL_TILE_WAVES, SCL_TILE_WAVES)))
+#endif
 __global__ __launch_bounds__(kTileQ) void icp_tile_search_kernel(const IcpProblem *pr, int n_src, int check_done, int apply, int cold,
                                                                   int stride, float maxd2, int do_reduce)
 {
     __shared__ TileLds L;
     const IcpProblem P = pr[blockIdx.y];
     const IcpState *st = P.st;
-    if (check_done && st->done) return;
     const int t = threadIdx.x, wv = t >> 6;
     const int i = blockIdx.x * kTileQ + t;
     const bool valid = i < n_src;
+    // Every read the prologue needs is issued here, back to back, from addresses that exist for every lane (the last source stands in
+    // for the lanes past the end; nnq holds n_src + 1 entries, whatever is in them before the first search), and masked afterwards: a
+    // read inside a branch is a basic block of its own that ends in a wait -- the done flag, the grid, the working point, the
+    // increment, the previous neighbour's index and its coordinates were six round trips in a row in the life of every workgroup.
+    const int ic = valid ? i : (n_src > 0 ? n_src - 1 : 0);
+    float4 pw = P.work[ic];
+    const float4 prev = P.nnq[ic];
+    const int done = st->done;
     TileGrid g;
-    g.gx0 = st->mn[0]; g.gy0 = st->mn[1]; g.gz0 = st->mn[2]; g.h = st->h; g.inv_h = 1.0f / st->h; g.dx = st->dim[0]; g.dy = st->dim[1]; g.dz = st->dim[2];
-    float4 pw = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) {
-        pw = P.work[i];
-        if (apply) {                                             // K6: the previous solve's increment moves the working point first
-            const float *T = st->inc_T;
-            const float x = pw.x, y = pw.y, z = pw.z;
-            pw.x = T[0] * x + T[1] * y + T[2] * z + T[3];
-            pw.y = T[4] * x + T[5] * y + T[6] * z + T[7];
-            pw.z = T[8] * x + T[9] * y + T[10] * z + T[11];
-            pw.w = 0.f;
-            P.work[i] = pw;
-        }
+    g.gx0 = st->mn[0]; g.gy0 = st->mn[1]; g.gz0 = st->mn[2]; g.h = st->h; g.dx = st->dim[0]; g.dy = st->dim[1]; g.dz = st->dim[2];
+    float T[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T[k] = st->inc_T[k];
+    asm volatile("" :: "v"(pw.x), "v"(prev.x), "v"(done), "v"(g.h), "v"(T[0]));   // (all of them have arrived before the first branch)
+    if (check_done && done) return;
+    g.inv_h = 1.0f / g.h;
+    if (!valid) pw = make_float4(0.f, 0.f, 0.f, 0.f);
+    else if (apply) {                                            // K6: the previous solve's increment moves the working point first
+        const float x = pw.x, y = pw.y, z = pw.z;
+        pw.x = T[0] * x + T[1] * y + T[2] * z + T[3];
+        pw.y = T[4] * x + T[5] * y + T[6] * z + T[7];
+        pw.z = T[8] * x + T[9] * y + T[10] * z + T[11];
+        pw.w = 0.f;
+        P.work[i] = pw;
     }
     const float3 p = make_float3(pw.x, pw.y, pw.z);
     float best = FLT_MAX;
@@ -1606,7 +1618,6 @@ __global__ __launch_bounds__(kTileQ) void icp_tile_search_kernel(const IcpProble
     bool deferred = false;                                       // ... and will be finished in memory by the launch behind this one
     TILE_STAMP_DECL;
     if (valid && !cold) {                                        // the previous neighbour bounds the ball
-        const float4 prev = P.nnq[i];
         const int j = __float_as_int(prev.w);
         if (j >= 0) {
             const float ex = p.x - prev.x, ey = p.y - prev.y, ez = p.z - prev.z;
@@ -1619,7 +1630,15 @@ __global__ __launch_bounds__(kTileQ) void icp_tile_search_kernel(const IcpProble
     // smaller box); what does not fit then, and the queries that reach stage 2 without a candidate, finish in memory: nn_core's
     // own walk from whatever the lane knows.  (One loop, so that tile_round and nn_core are instantiated once: registers.)
     int c[3] = {0, 0, 0};
-    if (cold) cell_index(st, p, c);
+    if (cold) {                                                  // cell_index's expressions on the grid already loaded
+        const float v[3] = {p.x, p.y, p.z}, mn[3] = {g.gx0, g.gy0, g.gz0};
+        const int dim[3] = {g.dx, g.dy, g.dz};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float f = floorf((v[a] - mn[a]) / g.h);
+            c[a] = (f != f) ? 0 : (f < 0.f ? 0 : (f >= (float)dim[a] ? dim[a] - 1 : (int)f));
+        }
+    }
 #pragma unroll 1
     for (int stage = (SCL_TILE_ABLATE & 8) ? 3 : (cold ? 0 : 2); stage < 3; ++stage) {
         int xa = 0, xb = -1, ya = 0, yb = -1, za = 0, zb = -1;
@@ -1652,7 +1671,7 @@ __global__ __launch_bounds__(kTileQ) void icp_tile_search_kernel(const IcpProble
     }
     // a deferred lane leaves its seed in nnq and a negative distance as the mark; its workgroup's record is then the finish launch's
     const int any_deferred = __syncthreads_or(deferred ? 1 : 0);
-    if (t == 0) P.flag[blockIdx.x] = any_deferred;
+    if (t == 0) { P.flag[blockIdx.x] = any_deferred; TILE_STAT(7, any_deferred ? 1 : 0); }
     if (do_reduce && !any_deferred && !(SCL_TILE_ABLATE & 2))
         tile_reduce(reinterpret_cast<float *>(L.pts), L.red, p, bq, valid && bi >= 0 && (best <= maxd2), best, P.part + (size_t)blockIdx.x * kNSum);
     if (valid) {                                                 // (behind the reduction: a barrier waits for the stores in front of it)
@@ -1670,10 +1689,12 @@ __global__ __launch_bounds__(kTileQ) void icp_tile_search_kernel(const IcpProble
 // A workgroup of the grid looks at the flags of the tiles w = blockIdx.x, + gridDim.x, ...: the launch is at most kFinishBlocks workgroups per
 // alignment, not one per tile (a launch of 9 775 workgroups that read a flag and leave took 16-22 us of every iteration).
 constexpr int kFinishBlocks = 128;
+constexpr int kFinishGroup = 8;                                  // lanes that share one left-over query's walk
 __global__ __launch_bounds__(kTileQ) void icp_tile_finish_kernel(const IcpProblem *pr, int n_src, int n_tiles, int check_done, int stride, float maxd2, int do_reduce)
 {
     __shared__ float pq[kTileQ * 8];
     __shared__ double red[kTileQ / 64][kNSum];
+    __shared__ int s_count, s_list[kTileQ];
     const IcpProblem P = pr[blockIdx.y];
     const IcpState *st = P.st;
     if (check_done && st->done) return;
@@ -1682,28 +1703,48 @@ __global__ __launch_bounds__(kTileQ) void icp_tile_finish_kernel(const IcpProble
         if (!P.flag[w]) continue;                                // (the same for every lane of the workgroup)
         const int i = w * kTileQ + t;
         const bool valid = i < n_src;
-        float3 p = make_float3(0.f, 0.f, 0.f), bq = make_float3(0.f, 0.f, 0.f);
-        float best = FLT_MAX;
-        int bi = -1;
-        if (valid) {
-            const float4 pw = P.work[i], nq = P.nnq[i];
-            p = make_float3(pw.x, pw.y, pw.z);
-            bq = make_float3(nq.x, nq.y, nq.z);
-            bi = __float_as_int(nq.w);
-            best = P.nnd[i];
-            if (best < 0.f) {                                    // marked: the seed's distance by the walk's own expression, then the walk
-                best = FLT_MAX;
-                if (bi >= 0) {
-                    const float ex = p.x - bq.x, ey = p.y - bq.y, ez = p.z - bq.z;
-                    const float d = (ex * ex + ey * ey) + ez * ez;
-                    if (d == d) best = d; else bi = -1;
-                }
-                nn_core<1>(p, st, P.cell_start, P.sorted, 0, bi >= 0, best, bi);
-                if (bi >= 0) bq = load_xyz(P.tgt, bi, stride);
-                P.nnq[i] = make_float4(bq.x, bq.y, bq.z, __int_as_float(bi));
-                P.nni[i] = bi;
-                P.nnd[i] = best;
+        const int ic = valid ? i : (n_src > 0 ? n_src - 1 : 0);
+        const float4 pw = P.work[ic], nq = P.nnq[ic];            // (unconditional, from a position that exists: both in flight together)
+        float best = P.nnd[ic];
+        const float3 p = make_float3(pw.x, pw.y, pw.z);
+        float3 bq = make_float3(nq.x, nq.y, nq.z);
+        int bi = __float_as_int(nq.w);
+        const bool marked = valid && best < 0.f;
+        // The marked queries of the tile -- one or two as a rule, each a long walk through memory -- are taken by groups of
+        // kFinishGroup lanes (nn_core's own sharing of a walk: the rows of a shell or ball dealt round robin, the minimum over
+        // (distance, index) order independent): with one lane per query the launch lasted as long as the longest single walk,
+        // 30-45 us of every iteration.  The seed travels through the reduction's staging area (free until tile_reduce below).
+        if (t == 0) s_count = 0;
+        __syncthreads();
+        if (marked) {
+            s_list[atomicAdd(&s_count, 1)] = t;                  // (any order: a query's result does not depend on who walks it)
+            pq[t * 8 + 0] = p.x; pq[t * 8 + 1] = p.y; pq[t * 8 + 2] = p.z; pq[t * 8 + 3] = nq.w;
+            pq[t * 8 + 4] = bq.x; pq[t * 8 + 5] = bq.y; pq[t * 8 + 6] = bq.z;
+        }
+        __syncthreads();
+        const int n_marked = s_count;
+        for (int e = t / kFinishGroup; e < n_marked; e += kTileQ / kFinishGroup) {
+            const int owner = s_list[e];
+            const float *o = pq + owner * 8;
+            const float3 qp = make_float3(o[0], o[1], o[2]), qb = make_float3(o[4], o[5], o[6]);
+            int qi = __float_as_int(o[3]);
+            float qd = FLT_MAX;                                  // the seed's distance by the walk's own expression, then the walk
+            if (qi >= 0) {
+                const float ex = qp.x - qb.x, ey = qp.y - qb.y, ez = qp.z - qb.z;
+                const float d = (ex * ex + ey * ey) + ez * ez;
+                if (d == d) qd = d; else qi = -1;
             }
+            nn_core<kFinishGroup>(qp, st, P.cell_start, P.sorted, t & (kFinishGroup - 1), qi >= 0, qd, qi);
+            if ((t & (kFinishGroup - 1)) == 0) { pq[owner * 8 + 3] = __int_as_float(qi); pq[owner * 8 + 7] = qd; }
+        }
+        __syncthreads();
+        if (marked) {
+            bi = __float_as_int(pq[t * 8 + 3]);
+            best = pq[t * 8 + 7];
+            if (bi >= 0) bq = load_xyz(P.tgt, bi, stride);
+            P.nnq[i] = make_float4(bq.x, bq.y, bq.z, __int_as_float(bi));
+            P.nni[i] = bi;
+            P.nnd[i] = best;
         }
         if (do_reduce) tile_reduce(pq, red, p, bq, valid && bi >= 0 && (best <= maxd2), best, P.part + (size_t)w * kNSum);
     }
@@ -1898,10 +1939,8 @@ int build_grid(IcpWorkspace *ws, hipStream_t stream, int n_tgt, int stride, std:
     hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(64), 0, stream, (const float *)ws->buf[B_BBOX], nb, n_tgt, st, cstart);
     int gb = (n_tgt + 255) / 256; gb = gb < 1 ? 1 : (gb > 2048 ? 2048 : gb);
     hipLaunchKernelGGL(grid_count_kernel, dim3(gb), dim3(256), 0, stream, tgt, n_tgt, stride, st, cstart);
-    size_t scan_tmp = 0;
-    ICP_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, scan_tmp, cstart, cstart, kMaxCells + 1, stream));
-    if (scan_tmp > ws->cap[B_CFILL]) { if (err) *err = "icp: scan scratch larger than the cell table"; return SCL_ERR_NOMEM; }
-    ICP_HIP(hipcub::DeviceScan::InclusiveSum(ws->buf[B_CFILL], scan_tmp, cstart, cstart, kMaxCells + 1, stream));   // cell_fill doubles as scratch
+    if (scan_scratch_bytes((size_t)kMaxCells + 1) > ws->cap[B_CFILL]) { if (err) *err = "icp: scan scratch larger than the cell table"; return SCL_ERR_NOMEM; }
+    ICP_HIP(prefix_sum_i32(ws->buf[B_CFILL], cstart, cstart, kMaxCells + 1, true, stream));   // cell_fill doubles as scratch
     ICP_HIP(hipMemcpyAsync(ws->buf[B_CFILL], cstart, sizeof(int) * (size_t)(kMaxCells + 1), hipMemcpyDeviceToDevice, stream));
     hipLaunchKernelGGL(grid_scatter_kernel, dim3(gb), dim3(256), 0, stream, tgt, n_tgt, stride, st, (int *)ws->buf[B_CFILL],
                        (float4 *)ws->buf[B_TSORT]);
@@ -2024,9 +2063,7 @@ static int source_order(IcpWorkspace *ctl, hipStream_t stream, const void *d_src
     if ((rc = ensure(ctl, B_PERM, sizeof(int) * (n + 1), err))) return rc;
     if (n_src <= 0) return SCL_OK;
     if ((rc = ensure(ctl, B_BBOX, sizeof(float) * 6 * 256, err))) return rc;
-    size_t tmp_bytes = 0;
-    unsigned int *nk = nullptr; int *nv = nullptr;
-    ICP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, nk, nk, nv, nv, n_src, 0, 30, stream));
+    const size_t tmp_bytes = sort_scratch_bytes(n, 1);
     const size_t arr = (sizeof(int) * n + 255) & ~(size_t)255;
     if ((rc = ensure(ctl, B_SORT, 3 * arr + tmp_bytes + 256, err))) return rc;
     unsigned char *base = static_cast<unsigned char *>(ctl->buf[B_SORT]);
@@ -2037,7 +2074,7 @@ static int source_order(IcpWorkspace *ctl, hipStream_t stream, const void *d_src
     hipLaunchKernelGGL(bbox_partial_kernel, dim3(nb), dim3(256), 0, stream, (const unsigned char *)d_src, n_src, stride, (float *)ctl->buf[B_BBOX]);
     hipLaunchKernelGGL(source_key_kernel, dim3((n_src + 255) / 256), dim3(256), 0, stream, (const unsigned char *)d_src, n_src, stride,
                        (const float *)ctl->buf[B_BBOX], nb, keys_in, vals_in);
-    ICP_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, (int *)ctl->buf[B_PERM], n_src, 0, 30, stream));
+    ICP_HIP(sort_pairs_u32(tmp, keys_in, keys_out, (unsigned int *)vals_in, (unsigned int *)ctl->buf[B_PERM], n_src, 30, stream));
     ICP_HIP(hipGetLastError());
     return SCL_OK;
 }

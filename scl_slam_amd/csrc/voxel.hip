@@ -10,7 +10,6 @@
 // rocPRIM's radix sort (through hipCUB; LSD radix sort is stable, so the points of a voxel stay in input
 // order), run heads flagged and scanned, then ONE thread per voxel adds its points in that order -- the same
 // fp32 sums as the serial restatement, bit for bit.  HBM-bound: n * (stride + 4 * 4) bytes; the sort dominates.
-#include <hipcub/hipcub.hpp>
 
 #include <cfloat>
 #include <cstring>
@@ -18,6 +17,7 @@
 
 #include "device_common.hpp"
 #include "icp.hpp"
+#include "device_sort.hpp"
 
 namespace scl {
 
@@ -351,14 +351,13 @@ int voxel_device(IcpWorkspace *ws, hipStream_t stream, int n, int stride, float 
     hipLaunchKernelGGL(vox_bbox_partial_kernel, dim3(nb), dim3(256), 0, stream, in, n, stride, part, pcnt);
     hipLaunchKernelGGL(vox_setup_kernel, dim3(1), dim3(64), 0, stream, part, pcnt, nb, inv, st);
     hipLaunchKernelGGL(vox_keys_kernel, dim3(pb), dim3(256), 0, stream, in, n, stride, inv, st, vox_in, idx_in);
-    size_t tmp_sort = 0, tmp_scan = 0;
-    VOX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, vox_in, vox_out, idx_in, idx_out, n, 0, 32, stream));
-    VOX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, (int *)ws->buf[V_HEAD], (int *)ws->buf[V_POS], n, stream));
+    // (voxel, point) pairs by voxel, equal voxels in the cloud's order (csrc/device_sort.hip: three passes of eleven bits)
+    const size_t tmp_sort = sort_scratch_bytes((size_t)n, 1), tmp_scan = scan_scratch_bytes((size_t)n);
     const size_t tmp = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
     if ((rc = vensure(ws, V_TMP, tmp + 256, err))) return rc;
-    VOX_HIP(hipcub::DeviceRadixSort::SortPairs(ws->buf[V_TMP], tmp_sort, vox_in, vox_out, idx_in, idx_out, n, 0, 32, stream));
+    VOX_HIP(sort_pairs_u32(ws->buf[V_TMP], vox_in, vox_out, idx_in, idx_out, n, 32, stream));
     hipLaunchKernelGGL(vox_heads_kernel, dim3(pb), dim3(256), 0, stream, vox_out, n, (int *)ws->buf[V_HEAD]);
-    VOX_HIP(hipcub::DeviceScan::ExclusiveSum(ws->buf[V_TMP], tmp_scan, (int *)ws->buf[V_HEAD], (int *)ws->buf[V_POS], n, stream));
+    VOX_HIP(prefix_sum_i32(ws->buf[V_TMP], (const int *)ws->buf[V_HEAD], (int *)ws->buf[V_POS], n, false, stream));
     hipLaunchKernelGGL(vox_centroid_kernel, dim3(pb), dim3(256), 0, stream, in, stride, vox_out, idx_out, (const int *)ws->buf[V_HEAD],
                        (const int *)ws->buf[V_POS], n, (unsigned char *)ws->buf[V_OUT], st);
     VOX_HIP(hipGetLastError());
@@ -535,14 +534,22 @@ int assemble_submaps_batch(IcpWorkspace *ws, hipStream_t stream, const void *con
     hipLaunchKernelGGL(vox_bbox_partial_batch_kernel, dim3(nb, n_jobs), dim3(256), 0, stream, raw, d_jobs, stride, part, pcnt);
     hipLaunchKernelGGL(vox_setup_batch_kernel, dim3(n_jobs), dim3(64), 0, stream, part, pcnt, nb, inv, st);
     hipLaunchKernelGGL(vox_keys_batch_kernel, dim3(pb), dim3(256), 0, stream, raw, n, d_jobs, n_jobs, stride, inv, st, keys_in, idx_in);
-    size_t tmp_sort = 0, tmp_scan = 0;
-    VOX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, keys_in, keys_out, idx_in, idx_out, n, 0, ebits, stream));
-    VOX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, (int *)ws->buf[V_HEAD], (int *)ws->buf[V_POS], n, stream));
+    // ((job, voxel), point) pairs by job and voxel, equal keys in the submap's order.  The jobs lie behind each other in the buffer: up to
+    // kSortMaxSegments of them are sorted each on its own 32 voxel bits (three passes), more than that all together on (job, voxel)
+    const bool segmented = n_jobs <= kSortMaxSegments;
+    SortSegments seg{};
+    if (segmented) {
+        seg.nseg = n_jobs;
+        for (int j = 0; j < n_jobs; ++j) seg.off[j] = jobs[(size_t)j].off;
+        seg.off[n_jobs] = n;
+    }
+    const size_t tmp_sort = sort_scratch_bytes((size_t)n, segmented ? n_jobs : 1), tmp_scan = scan_scratch_bytes((size_t)n);
     const size_t tmp = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
     if ((rc = vensure(ws, V_TMP, tmp + 256, err))) return rc;
-    VOX_HIP(hipcub::DeviceRadixSort::SortPairs(ws->buf[V_TMP], tmp_sort, keys_in, keys_out, idx_in, idx_out, n, 0, ebits, stream));
+    if (segmented) VOX_HIP(sort_pairs_u64_segmented(ws->buf[V_TMP], keys_in, keys_out, idx_in, idx_out, seg, 32, stream));
+    else VOX_HIP(sort_pairs_u64(ws->buf[V_TMP], keys_in, keys_out, idx_in, idx_out, n, ebits, stream));
     hipLaunchKernelGGL(vox_heads_batch_kernel, dim3(pb), dim3(256), 0, stream, keys_out, n, (int *)ws->buf[V_HEAD]);
-    VOX_HIP(hipcub::DeviceScan::ExclusiveSum(ws->buf[V_TMP], tmp_scan, (int *)ws->buf[V_HEAD], (int *)ws->buf[V_POS], n, stream));
+    VOX_HIP(prefix_sum_i32(ws->buf[V_TMP], (const int *)ws->buf[V_HEAD], (int *)ws->buf[V_POS], n, false, stream));
     hipLaunchKernelGGL(vox_centroid_batch_kernel, dim3(pb), dim3(256), 0, stream, raw, stride, keys_out, idx_out, (const int *)ws->buf[V_HEAD],
                        (const int *)ws->buf[V_POS], n, d_jobs, (unsigned char *)ws->buf[V_OUT], st);
     VOX_HIP(hipGetLastError());

@@ -142,6 +142,8 @@ def _bind(lib):
         "scl_selftest_atanf_blocks": (c_int, [P, c_int, c_int, POINTER(ctypes.c_uint64)]),
         "scl_host_copy_rate": (c_int, [P, ctypes.c_size_t, c_int, dp]),
         "scl_selftest_bin_paths": (c_int, [P, c_int, c_uint64, c_uint64, POINTER(ctypes.c_uint64), POINTER(ctypes.c_uint64)]),
+        "scl_selftest_sort_pairs": (c_int, [P, c_int, c_void_p, POINTER(ctypes.c_uint32), c_int, c_int, POINTER(c_int), c_int, c_void_p, POINTER(ctypes.c_uint32)]),
+        "scl_selftest_prefix_sum": (c_int, [P, POINTER(ctypes.c_int32), c_int, c_int, POINTER(ctypes.c_int32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -311,6 +313,22 @@ class ScanContextEngine:
         bad, sure = ctypes.c_uint64(), ctypes.c_uint64()
         self._check(self._lib.scl_selftest_bin_paths(self._h, mode, seed, n_points, byref(bad), byref(sure)), "scl_selftest_bin_paths")
         return bad.value, sure.value
+
+    def selftest_sort_pairs(self, keys, values, bits, segment_offsets=None):
+        """(keys, values) stably sorted on the key bits [0, bits) by csrc/device_sort.hip; keys uint32 or uint64"""
+        keys = np.ascontiguousarray(keys); values = np.ascontiguousarray(values, dtype=np.uint32)
+        assert keys.dtype in (np.uint32, np.uint64) and keys.shape == values.shape
+        ko, vo = np.empty_like(keys), np.empty_like(values)
+        seg = None if segment_offsets is None else np.ascontiguousarray(segment_offsets, dtype=np.int32)
+        self._check(self._lib.scl_selftest_sort_pairs(self._h, keys.dtype.itemsize, c_void_p(keys.ctypes.data), _ptr(values, ctypes.c_uint32), keys.size, bits,
+                                                      None if seg is None else _ptr(seg, c_int), 0 if seg is None else seg.size - 1,
+                                                      c_void_p(ko.ctypes.data), _ptr(vo, ctypes.c_uint32)), "scl_selftest_sort_pairs")
+        return ko, vo
+
+    def selftest_prefix_sum(self, values, inclusive=False):
+        v = np.ascontiguousarray(values, dtype=np.int32); out = np.empty_like(v)
+        self._check(self._lib.scl_selftest_prefix_sum(self._h, _ptr(v, ctypes.c_int32), v.size, 1 if inclusive else 0, _ptr(out, ctypes.c_int32)), "scl_selftest_prefix_sum")
+        return out
 
     def selftest_atanf_blocks(self, first_block, n_blocks):
         out = np.zeros(n_blocks, dtype=np.uint64)

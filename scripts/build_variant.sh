@@ -11,7 +11,7 @@ OUT=$ROOT/scl_slam_amd/lib/variants
 mkdir -p $OUT /tmp/scl_variant_$NAME
 HIPFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-result -I$ROOT/include -I$CSRC"
 OBJS=""
-for f in engine sc_distance ringkey_topk make_sc icp voxel sharded_front sc_screen sc_masked sc_matrix messages iris; do
+for f in engine sc_distance ringkey_topk make_sc icp voxel sharded_front sc_screen sc_masked sc_matrix messages iris device_sort; do
   if echo " $* " | grep -q " $f.hip "; then
     /opt/rocm/bin/hipcc $HIPFLAGS $FLAGS -c $CSRC/$f.hip -o /tmp/scl_variant_$NAME/$f.o
     OBJS="$OBJS /tmp/scl_variant_$NAME/$f.o"

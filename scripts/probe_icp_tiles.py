@@ -16,7 +16,7 @@ p = tgts[0][:, :3].astype(np.float64) @ T[:3, :3].T + T[:3, 3]
 src0[:, :3] = (p + 0.01 * rs.standard_normal(p.shape)).astype(np.float32)
 lib = eng._lib
 stats = (ctypes.c_ulonglong * 16)()
-names = ["rounds", "rounds_overflowed", "lanes_in_memory", "table_entries", "points_staged", "row_visits", "points_compared", "-",
+names = ["rounds", "rounds_overflowed", "lanes_in_memory", "table_entries", "points_staged", "row_visits", "points_compared", "tiles_flagged",
          "t_until_ball", "t_box", "t_table", "t_rowscan", "t_staging", "t_walk", "t_reduce", "-"]
 for est in ((0,) if os.environ.get("PROBE_P2P_ONLY") else (0, 1)):   # PROBE_P2P_ONLY: scripts/profile_icp.sh
     pp = eng.icp_default_params(); pp.max_iterations = 30; pp.estimator = est; pp.normal_radius = 1.0
