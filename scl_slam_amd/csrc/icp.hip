@@ -1251,10 +1251,30 @@ struct IcpProblem {
     int *flag;                                               // per workgroup of the tile search: lanes left for icp_tile_finish_kernel
 };
 
-__global__ __launch_bounds__(256) void icp_solve_batch_kernel(const IcpProblem *pr, int nblocks, int mode, int max_iter, double trans_eps, double fit_eps)
+// How far a part of a batch has got, for the host that enqueues its iterations (icp_batch_run): the last alignment to leave a solve
+// launch writes (launches of the part finished so far << 16 | alignments of the part that are done) into pinned host memory.
+struct PartSync {
+    int *counters;                       // device: [0] arrivals at the current launch's end, [1] alignments done
+    unsigned int *host_word;             // pinned; nullptr: nobody is watching
+    unsigned int seq;                    // this launch's number within the part (the cold iteration's solve is 1)
+};
+__device__ __forceinline__ void part_sync_arrive(const PartSync &ps, const bool newly_done)
+{
+    if (newly_done) atomicAdd(&ps.counters[1], 1);
+    __threadfence();
+    if (atomicAdd(&ps.counters[0], 1) == (int)gridDim.x - 1) {   // every alignment of the launch has been here: the next launch starts behind this one
+        ps.counters[0] = 0;
+        const unsigned int nd = (unsigned int)atomicAdd(&ps.counters[1], 0);
+        __hip_atomic_store(ps.host_word, (ps.seq << 16) | (nd & 0xffffu), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+__global__ __launch_bounds__(256) void icp_solve_batch_kernel(const IcpProblem *pr, int nblocks, int mode, int max_iter, double trans_eps, double fit_eps, PartSync ps)
 {
     const IcpProblem p = pr[blockIdx.x];
+    const bool was_done = ps.host_word && threadIdx.x == 0 && p.st->done != 0;
     icp_solve_kernel_body(p.st, p.part, nblocks, mode, max_iter, trans_eps, fit_eps);
+    if (ps.host_word && threadIdx.x == 0) part_sync_arrive(ps, !was_done && p.st->done != 0);
 }
 
 __global__ __launch_bounds__(256) void plane_reduce_batch_kernel(const IcpProblem *pr, int stride, int n, float maxd2)
@@ -1263,10 +1283,12 @@ __global__ __launch_bounds__(256) void plane_reduce_batch_kernel(const IcpProble
     plane_reduce_kernel_body(p.work, p.tgt, stride, n, p.nni, p.nnd, maxd2, p.normals, p.st, p.part);
 }
 
-__global__ __launch_bounds__(256) void plane_solve_batch_kernel(const IcpProblem *pr, int nblocks, int max_iter, double trans_eps, double fit_eps)
+__global__ __launch_bounds__(256) void plane_solve_batch_kernel(const IcpProblem *pr, int nblocks, int max_iter, double trans_eps, double fit_eps, PartSync ps)
 {
     const IcpProblem p = pr[blockIdx.x];
+    const bool was_done = ps.host_word && threadIdx.x == 0 && p.st->done != 0;
     plane_solve_kernel_body(p.st, p.part, nblocks, max_iter, trans_eps, fit_eps);
+    if (ps.host_word && threadIdx.x == 0) part_sync_arrive(ps, !was_done && p.st->done != 0);
 }
 
 // ---- K4c: the search of a loop iteration served from LDS ---------------------------------------------------------------------
@@ -1688,6 +1710,12 @@ __global__ __launch_bounds__(kTileQ) void icp_tile_search_kernel(const IcpProble
 // of its five waves per SIMD.)
 // A workgroup of the grid looks at the flags of the tiles w = blockIdx.x, + gridDim.x, ...: the launch is at most kFinishBlocks workgroups per
 // alignment, not one per tile (a launch of 9 775 workgroups that read a flag and leave took 16-22 us of every iteration).
+#ifndef SCL_ICP_AHEAD
+#define SCL_ICP_AHEAD 2
+#endif
+#ifndef SCL_ICP_PARTS
+#define SCL_ICP_PARTS 3                  // parts a large batch runs as (icp_batch_run; 2: 5.9 ms, 3: 5.7-5.9, 4 on four hardware queues: 7.3)
+#endif
 constexpr int kFinishBlocks = 128;
 constexpr int kFinishGroup = 8;                                  // lanes that share one left-over query's walk
 __global__ __launch_bounds__(kTileQ) void icp_tile_finish_kernel(const IcpProblem *pr, int n_src, int n_tiles, int check_done, int stride, float maxd2, int do_reduce)
@@ -1877,11 +1905,6 @@ __global__ void unpermute_nn_kernel(const int *perm, const int *nni, const float
 }
 
 // the alignments' done flags and, at the end, their states side by side: one copy to the host instead of one per alignment
-__global__ void gather_done_kernel(const IcpProblem *pr, int nprob, int *out)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < nprob) out[c] = pr[c].st->done;
-}
 __global__ void gather_states_kernel(const IcpProblem *pr, int nprob, IcpState *out)
 {
     const int c = blockIdx.x;
@@ -1948,6 +1971,18 @@ int build_grid(IcpWorkspace *ws, hipStream_t stream, int n_tgt, int stride, std:
     return SCL_OK;
 }
 
+// one spin of the host's polling loop (icp_batch_run), on whatever the host is
+inline void cpu_pause()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__) || defined(__arm__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::this_thread::yield();
+#endif
+}
+
 int pinned(IcpWorkspace *ws, size_t bytes, std::string *err)
 {
     if (bytes <= ws->pinned_cap) return SCL_OK;
@@ -1997,9 +2032,13 @@ void icp_workspace_free(IcpWorkspace *ws)
 {
 
     for (size_t i = 0; i < sizeof(ws->buf) / sizeof(ws->buf[0]); ++i) if (ws->buf[i]) { (void)hipFree(ws->buf[i]); ws->buf[i] = nullptr; ws->cap[i] = 0; }
-    for (int k = 0; k < 2; ++k) if (ws->ev[k]) { (void)hipEventDestroy(ws->ev[k]); ws->ev[k] = nullptr; }
     for (int k = 0; k < 2; ++k) if (ws->ev_side[k]) { (void)hipEventDestroy(ws->ev_side[k]); ws->ev_side[k] = nullptr; }
     if (ws->side) { (void)hipStreamDestroy(ws->side); ws->side = nullptr; }
+    for (int k = 0; k < IcpWorkspace::kMaxParts - 1; ++k) {
+        if (ws->part_stream[k]) { (void)hipStreamDestroy(ws->part_stream[k]); ws->part_stream[k] = nullptr; }
+        if (ws->ev_join[k]) { (void)hipEventDestroy(ws->ev_join[k]); ws->ev_join[k] = nullptr; }
+    }
+    if (ws->ev_fork) { (void)hipEventDestroy(ws->ev_fork); ws->ev_fork = nullptr; }
     if (ws->pinned) { (void)hipHostFree(ws->pinned); ws->pinned = nullptr; ws->pinned_cap = 0; }
 }
 
@@ -2190,20 +2229,22 @@ int icp_batch_run(IcpWorkspace *const *wss, int nprob, IcpWorkspace *ctl, hipStr
 {
     if (nprob <= 0) return SCL_OK;
     int rc;
-    constexpr int kPeek = 4;                                     // iterations between two looks at the done flags
-    const size_t flags_bytes = (sizeof(int) * (size_t)nprob + 255) & ~(size_t)255;
+    constexpr int kAhead = SCL_ICP_AHEAD;                        // iterations the host may be ahead of what a part has finished
+    constexpr int kMaxParts = IcpWorkspace::kMaxParts;
+    constexpr size_t kWordPitch = 64;                            // a part's progress word has a cache line of pinned memory to itself
     if ((rc = ensure(ctl, B_MASK, sizeof(IcpProblem) * (size_t)nprob, err))) return rc;
-    if ((rc = ensure(ctl, B_HYP, sizeof(IcpState) * (size_t)nprob + 2 * flags_bytes, err))) return rc;
-    if ((rc = pinned(ctl, (sizeof(IcpProblem) + sizeof(IcpState)) * (size_t)nprob + 2 * flags_bytes, err))) return rc;
-    for (int k = 0; k < 2; ++k) if (!ctl->ev[k]) ICP_HIP(hipEventCreateWithFlags(&ctl->ev[k], hipEventDisableTiming));
+    if ((rc = ensure(ctl, B_HYP, sizeof(IcpState) * (size_t)nprob + 2 * sizeof(int) * kMaxParts, err))) return rc;
+    if ((rc = pinned(ctl, (sizeof(IcpProblem) + sizeof(IcpState)) * (size_t)nprob + 64 + kWordPitch * kMaxParts, err))) return rc;
     IcpProblem *hp = static_cast<IcpProblem *>(ctl->pinned);
     IcpState *hs = reinterpret_cast<IcpState *>(hp + nprob);
-    unsigned char *h_flags = reinterpret_cast<unsigned char *>(hs + nprob);
+    unsigned char *h_words = reinterpret_cast<unsigned char *>(((uintptr_t)(hs + nprob) + 63) & ~(uintptr_t)63);
     IcpState *d_states = static_cast<IcpState *>(ctl->buf[B_HYP]);
-    unsigned char *d_flags = reinterpret_cast<unsigned char *>(d_states + nprob);
+    int *d_counters = reinterpret_cast<int *>(d_states + nprob);
+    for (int k = 0; k < kMaxParts; ++k) *reinterpret_cast<volatile unsigned int *>(h_words + kWordPitch * (size_t)k) = 0u;
+    ICP_HIP(hipMemsetAsync(d_counters, 0, 2 * sizeof(int) * kMaxParts, stream));
     if ((rc = source_order(ctl, stream, d_src, n_src, stride, err))) return rc;
     for (int c = 0; c < nprob; ++c) fill_problem(&hp[c], wss[c], p.estimator == 1);
-    const IcpProblem *dp = static_cast<const IcpProblem *>(ctl->buf[B_MASK]);
+    const IcpProblem *dp_all = static_cast<const IcpProblem *>(ctl->buf[B_MASK]);
     ICP_HIP(hipMemcpyAsync(ctl->buf[B_MASK], hp, sizeof(IcpProblem) * (size_t)nprob, hipMemcpyHostToDevice, stream));
     const unsigned char *src = static_cast<const unsigned char *>(d_src);
     const int *perm = static_cast<const int *>(ctl->buf[B_PERM]);
@@ -2211,61 +2252,114 @@ int icp_batch_run(IcpWorkspace *const *wss, int nprob, IcpWorkspace *ctl, hipStr
     const int pb = (int)((q + 255) / 256), tb = (int)((q + kTileQ - 1) / kTileQ);
     const int rb = pb < kRedBlocks ? pb : kRedBlocks;
     const float maxd2 = (float)(p.max_correspondence_dist * p.max_correspondence_dist);
-    hipLaunchKernelGGL(work_init_batch_kernel, dim3(pb, nprob), dim3(256), 0, stream, dp, src, perm, n_src, stride);
+    hipLaunchKernelGGL(work_init_batch_kernel, dim3(pb, nprob), dim3(256), 0, stream, dp_all, src, perm, n_src, stride);
     const bool tiles = (long long)nprob * q >= kTileMinQueries;   // (no bit of the result depends on it: see chunk_reduce_batch_kernel)
+    // The alignments are independent, and an iteration is a chain -- search, finish, solve -- whose last two links are short launches
+    // that leave the chip almost idle (38-48 of an iteration's 280 us; the search's own last workgroups likewise).  So a batch that is
+    // large enough runs as kParts parts, each the same chain over its share of the alignments on a stream of its own: one part's
+    // finish and solve run under another part's search.  Which part an alignment is in changes no bit of its result (every launch
+    // treats blockIdx.y's alignment on its own); a part keeps at least kTileMinQueries queries, so that it searches as the whole would.
+    int parts = 1;
+    if (tiles) {
+        parts = SCL_ICP_PARTS;
+        while (parts > 1 && ((long long)(nprob / parts) * q < kTileMinQueries || nprob / parts < 4)) --parts;
+    }
+    struct Part { int first, n; hipStream_t s; int next_it; bool finished; PartSync sync; };
+    Part part[kMaxParts];
+    for (int k = 0; k < parts; ++k) {
+        part[k].first = (int)((long long)nprob * k / parts);
+        part[k].n = (int)((long long)nprob * (k + 1) / parts) - part[k].first;
+        part[k].next_it = 1; part[k].finished = false;
+        part[k].s = stream;
+        part[k].sync.counters = d_counters + 2 * k;
+        part[k].sync.host_word = reinterpret_cast<unsigned int *>(h_words + kWordPitch * (size_t)k);
+        part[k].sync.seq = 0;
+    }
+    if (parts > 1) {
+        if (!ctl->ev_fork) ICP_HIP(hipEventCreateWithFlags(&ctl->ev_fork, hipEventDisableTiming));
+        ICP_HIP(hipEventRecord(ctl->ev_fork, stream));
+        for (int k = 1; k < parts; ++k) {
+            if (!ctl->part_stream[k - 1]) ICP_HIP(hipStreamCreateWithFlags(&ctl->part_stream[k - 1], hipStreamNonBlocking));
+            if (!ctl->ev_join[k - 1]) ICP_HIP(hipEventCreateWithFlags(&ctl->ev_join[k - 1], hipEventDisableTiming));
+            part[k].s = ctl->part_stream[k - 1];
+            ICP_HIP(hipStreamWaitEvent(part[k].s, ctl->ev_fork, 0));
+        }
+    }
+    const bool wait_normals = ctl->normals_pending;
+    ctl->normals_pending = false;
     // neighbours (the previous increment applied first) and, point to point, the records of the workgroups' sums
-    auto search_and_sums = [&](bool cold, int check_done, int apply, float md2, bool sums) {
+    auto search_and_sums = [&](const Part &P, bool cold, int check_done, int apply, float md2, bool sums) {
+        const IcpProblem *dp = dp_all + P.first;
         if (tiles) {
-            hipLaunchKernelGGL(icp_tile_search_kernel, dim3(tb, nprob), dim3(kTileQ), 0, stream, dp, n_src, check_done, apply, cold ? 1 : 0, stride, md2, sums ? 1 : 0);
-            hipLaunchKernelGGL(icp_tile_finish_kernel, dim3(tb < kFinishBlocks ? tb : kFinishBlocks, nprob), dim3(kTileQ), 0, stream, dp, n_src, tb, check_done, stride, md2, sums ? 1 : 0);
+            hipLaunchKernelGGL(icp_tile_search_kernel, dim3(tb, P.n), dim3(kTileQ), 0, P.s, dp, n_src, check_done, apply, cold ? 1 : 0, stride, md2, sums ? 1 : 0);
+            hipLaunchKernelGGL(icp_tile_finish_kernel, dim3(tb < kFinishBlocks ? tb : kFinishBlocks, P.n), dim3(kTileQ), 0, P.s, dp, n_src, tb, check_done, stride, md2, sums ? 1 : 0);
             return;
         }
-        if (cold) hipLaunchKernelGGL(nn_search_batch_kernel<kNnGroup>, dim3((unsigned)((q * kNnGroup + 255) / 256), nprob), dim3(256), 0, stream,
+        if (cold) hipLaunchKernelGGL(nn_search_batch_kernel<kNnGroup>, dim3((unsigned)((q * kNnGroup + 255) / 256), P.n), dim3(256), 0, P.s,
                                      dp, n_src, check_done, apply ? 1 : -1, stride, 0);
-        else hipLaunchKernelGGL(nn_search_batch_kernel<kNnWarmGroup>, dim3((unsigned)((q * kNnWarmGroup + 255) / 256), nprob), dim3(256), 0, stream,
+        else hipLaunchKernelGGL(nn_search_batch_kernel<kNnWarmGroup>, dim3((unsigned)((q * kNnWarmGroup + 255) / 256), P.n), dim3(256), 0, P.s,
                                 dp, n_src, check_done, apply ? 1 : -1, stride, 1);
-        if (sums) hipLaunchKernelGGL(chunk_reduce_batch_kernel, dim3(tb, nprob), dim3(kTileQ), 0, stream, dp, n_src, check_done, stride, md2);
+        if (sums) hipLaunchKernelGGL(chunk_reduce_batch_kernel, dim3(tb, P.n), dim3(kTileQ), 0, P.s, dp, n_src, check_done, stride, md2);
     };
-    auto iteration = [&](bool cold) {
-        search_and_sums(cold, 1, cold ? 0 : 1, maxd2, p.estimator == 0);
+    auto iteration = [&](Part &P, bool cold) {
+        const IcpProblem *dp = dp_all + P.first;
+        P.sync.seq += 1;
+        search_and_sums(P, cold, 1, cold ? 0 : 1, maxd2, p.estimator == 0);
         if (p.estimator == 1) {
-            if (ctl->normals_pending) { (void)hipStreamWaitEvent(stream, ctl->ev_side[1], 0); ctl->normals_pending = false; }
-            hipLaunchKernelGGL(plane_reduce_batch_kernel, dim3(rb, nprob), dim3(256), 0, stream, dp, stride, n_src, maxd2);
-            hipLaunchKernelGGL(plane_solve_batch_kernel, dim3(nprob), dim3(256), 0, stream, dp, rb, p.max_iterations, p.transformation_epsilon,
-                               p.euclidean_fitness_epsilon);
+            if (cold && wait_normals) (void)hipStreamWaitEvent(P.s, ctl->ev_side[1], 0);   // the candidates' normals (icp_batch_prepare_all's side stream)
+            hipLaunchKernelGGL(plane_reduce_batch_kernel, dim3(rb, P.n), dim3(256), 0, P.s, dp, stride, n_src, maxd2);
+            hipLaunchKernelGGL(plane_solve_batch_kernel, dim3(P.n), dim3(256), 0, P.s, dp, rb, p.max_iterations, p.transformation_epsilon,
+                               p.euclidean_fitness_epsilon, P.sync);
         } else {
-            hipLaunchKernelGGL(icp_solve_batch_kernel, dim3(nprob), dim3(256), 0, stream, dp, tb, 0, p.max_iterations, p.transformation_epsilon,
-                               p.euclidean_fitness_epsilon);
+            hipLaunchKernelGGL(icp_solve_batch_kernel, dim3(P.n), dim3(256), 0, P.s, dp, tb, 0, p.max_iterations, p.transformation_epsilon,
+                               p.euclidean_fitness_epsilon, P.sync);
         }
     };
-    // The done flags travel to the host every kPeek iterations and are looked at one period later, when they have long arrived:
-    // the host never waits for the device to drain (a finished alignment's workgroups leave at once, so the iterations enqueued in
-    // the meantime cost a launch each)
-    int slot = 0, pending = -1;
-    iteration(true);
-    for (int it = 1; it < p.max_iterations; ++it) {
-        iteration(false);
-        if ((it % kPeek) == kPeek - 1 && it + 1 < p.max_iterations) {
-            if (pending >= 0) {
-                ICP_HIP(hipEventSynchronize(ctl->ev[pending]));
-                const int *f = reinterpret_cast<const int *>(h_flags + (size_t)pending * flags_bytes);
-                bool all = true;
-                for (int c = 0; c < nprob; ++c) all &= f[c] != 0;
-                if (all) break;
+    // The host stays kAhead iterations ahead of what a part has FINISHED (the progress word its solve launches write into pinned
+    // memory: launches finished, alignments done): the device always has the next iteration queued, and a part whose alignments are
+    // all done costs kAhead empty iterations (a finished alignment's workgroups leave at once), not the four to eight of a look at
+    // copied flags every fourth iteration -- 0.26 of a 25-candidate query's 5.8 ms.  The parts are served as they become ready.
+    for (int k = 0; k < parts; ++k) iteration(part[k], true);
+    for (unsigned long long idle = 0;;) {
+        bool open = false, progress = false;
+        for (int k = 0; k < parts; ++k) {
+            Part &P = part[k];
+            if (P.finished || P.next_it >= p.max_iterations) continue;
+            open = true;
+            const int want = P.next_it - kAhead;                 // the solve launch of the part that must have finished (the cold one is 1)
+            if (want >= 1) {
+                const unsigned int w = __atomic_load_n(P.sync.host_word, __ATOMIC_ACQUIRE);
+                if ((int)(w >> 16) < want) continue;
+                if ((int)(w & 0xffffu) >= P.n) { P.finished = true; progress = true; continue; }
             }
-            hipLaunchKernelGGL(gather_done_kernel, dim3((nprob + 63) / 64), dim3(64), 0, stream, dp, nprob, (int *)(d_flags + (size_t)slot * flags_bytes));
-            ICP_HIP(hipMemcpyAsync(h_flags + (size_t)slot * flags_bytes, d_flags + (size_t)slot * flags_bytes, sizeof(int) * (size_t)nprob,
-                                   hipMemcpyDeviceToHost, stream));
-            ICP_HIP(hipEventRecord(ctl->ev[slot], stream));
-            pending = slot; slot ^= 1;
+            iteration(P, false);
+            P.next_it += 1;
+            progress = true;
         }
+        if (!open) break;
+        if (progress) { idle = 0; continue; }
+        if ((++idle & 0xfffffull) == 0) {                        // nothing moved for a while: has a stream died, or drained without its word?
+            for (int k = 0; k < parts; ++k) {
+                const hipError_t qe = hipStreamQuery(part[k].s);
+                if (qe != hipSuccess && qe != hipErrorNotReady) { if (err) *err = std::string("icp_batch_run: ") + hipGetErrorString(qe); return SCL_ERR_HIP; }
+            }
+            if (idle > (1ull << 34)) { if (err) *err = "icp_batch_run: no progress word from the device"; return SCL_ERR_HIP; }
+        }
+        cpu_pause();
     }
     // fitness: the original source moved by each final transform, mean squared NN distance over all points (the last
     // neighbour bounds the search)
-    hipLaunchKernelGGL(work_final_batch_kernel, dim3(pb, nprob), dim3(256), 0, stream, dp, src, perm, n_src, stride);
-    search_and_sums(false, 0, 0, FLT_MAX, true);
-    hipLaunchKernelGGL(icp_solve_batch_kernel, dim3(nprob), dim3(256), 0, stream, dp, tb, 2, 0, 0.0, 0.0);
-    hipLaunchKernelGGL(gather_states_kernel, dim3(nprob), dim3(64), 0, stream, dp, nprob, d_states);
+    for (int k = 0; k < parts; ++k) {
+        const Part &P = part[k];
+        hipLaunchKernelGGL(work_final_batch_kernel, dim3(pb, P.n), dim3(256), 0, P.s, dp_all + P.first, src, perm, n_src, stride);
+        search_and_sums(P, false, 0, 0, FLT_MAX, true);
+        hipLaunchKernelGGL(icp_solve_batch_kernel, dim3(P.n), dim3(256), 0, P.s, dp_all + P.first, tb, 2, 0, 0.0, 0.0, PartSync{nullptr, nullptr, 0u});
+        if (k > 0) {
+            ICP_HIP(hipEventRecord(ctl->ev_join[k - 1], P.s));
+            ICP_HIP(hipStreamWaitEvent(stream, ctl->ev_join[k - 1], 0));
+        }
+    }
+    hipLaunchKernelGGL(gather_states_kernel, dim3(nprob), dim3(64), 0, stream, dp_all, nprob, d_states);
     ICP_HIP(hipGetLastError());
     ICP_HIP(hipMemcpyAsync(hs, d_states, sizeof(IcpState) * (size_t)nprob, hipMemcpyDeviceToHost, stream));
     ICP_HIP(hipStreamSynchronize(stream));

@@ -14,11 +14,14 @@ struct IcpWorkspace {
     size_t cap[24] = {0};
     void *pinned = nullptr;
     size_t pinned_cap = 0;
-    hipEvent_t ev[2] = {nullptr, nullptr};     // the batch loop's two looks at the done flags in flight
     const void *ext_tgt = nullptr;             // the alignment's target when it is read in place (icp_batch_prepare_all) instead of staged in the workspace
     hipStream_t side = nullptr;                // icp_batch_prepare_all: the candidates' normals run beside the batch's cold search
     hipEvent_t ev_side[2] = {nullptr, nullptr};
     bool normals_pending = false;              // ev_side[1] marks the end of the normals that icp_batch_run's first plane reduction needs
+    // icp_batch_run: a batch's alignments run as parts on streams of their own (one part's solve under another part's search)
+    static constexpr int kMaxParts = 4;
+    hipStream_t part_stream[kMaxParts - 1] = {nullptr, nullptr, nullptr};   // (part 0 runs on the caller's stream)
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxParts - 1] = {nullptr, nullptr, nullptr};
 };
 
 void icp_workspace_free(IcpWorkspace *ws);
