@@ -1592,9 +1592,11 @@ __device__ __forceinline__ void tile_reduce(float *pq_area /* kTileQ x 8 floats 
     }
 }
 
-#ifdef SCL_TILE_WAVES
-__attribute__((amdgpu_waves_per_eu(SCL_TILE_WAVES, SCL_TILE_WAVES)))
+#ifndef SCL_TILE_WAVES
+#define SCL_TILE_WAVES 5                 // built for five waves per SIMD (what 32 KB of LDS per workgroup allow): 95 registers instead of 116, the
+                                         // same 80 bytes of scratch; 5.71-5.84 against 5.84-5.91 ms per point-to-point query of 25 x 100 k
 #endif
+__attribute__((amdgpu_waves_per_eu(SCL_TILE_WAVES, SCL_TILE_WAVES)))
 __global__ __launch_bounds__(kTileQ) void icp_tile_search_kernel(const IcpProblem *pr, int n_src, int check_done, int apply, int cold,
                                                                   int stride, float maxd2, int do_reduce)
 {
@@ -1714,7 +1716,7 @@ __global__ __launch_bounds__(kTileQ) void icp_tile_search_kernel(const IcpProble
 #define SCL_ICP_AHEAD 2
 #endif
 #ifndef SCL_ICP_PARTS
-#define SCL_ICP_PARTS 3                  // parts a large batch runs as (icp_batch_run; 2: 5.9 ms, 3: 5.7-5.9, 4 on four hardware queues: 7.3)
+#define SCL_ICP_PARTS 2                  // parts a large batch runs as (icp_batch_run).  Point to point, 25 x 100 k: 1 part 6.8 ms, 2 parts 5.85 (with HIP's four hardware queues and with eight), 3 parts 5.6 with four queues but 7.6 with eight, 4 parts 7.3
 #endif
 constexpr int kFinishBlocks = 128;
 constexpr int kFinishGroup = 8;                                  // lanes that share one left-over query's walk
