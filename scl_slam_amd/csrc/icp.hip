@@ -1105,12 +1105,6 @@ __global__ __launch_bounds__(1024) void grid_scan_batch_kernel(const GridJob *jo
     }
 }
 __global__ void grid_scatter_batch_kernel(const GridJob *jobs, int stride) { const GridJob j = jobs[blockIdx.y]; grid_scatter_body(j.tgt, j.n, stride, j.st, j.cfill, j.tsort); }
-__global__ __launch_bounds__(kNormBlock) void normals_batch_kernel(const GridJob *jobs, double radius)
-{
-    const GridJob j = jobs[blockIdx.y];
-    if ((long long)blockIdx.x * (kNormBlock / kNormGroup) >= j.n) return;  // (a workgroup is 64 points; the grid is sized for the largest target)
-    normals_body(j.n, j.st, j.cstart, j.tsort, radius, j.normals);
-}
 __global__ void state_init_batch_kernel(const GridJob *jobs) { state_init_body(jobs[blockIdx.x].st); }
 
 // ---- RANSAC correspondence rejection (CorrespondenceRejectorSampleConsensus, DM.h:1218-1225) ----------
@@ -1249,6 +1243,7 @@ struct IcpProblem {
     const unsigned char *tgt; const float4 *normals;
     float4 *nnq;                                             // every source's current neighbour: its coordinates and (in .w) its index
     int *flag;                                               // per workgroup of the tile search: lanes left for icp_tile_finish_kernel
+    int n_tgt;
 };
 
 // How far a part of a batch has got, for the host that enqueues its iterations (icp_batch_run): the last alignment to leave a solve
@@ -1289,6 +1284,14 @@ __global__ __launch_bounds__(256) void plane_solve_batch_kernel(const IcpProblem
     const bool was_done = ps.host_word && threadIdx.x == 0 && p.st->done != 0;
     plane_solve_kernel_body(p.st, p.part, nblocks, max_iter, trans_eps, fit_eps);
     if (ps.host_word && threadIdx.x == 0) part_sync_arrive(ps, !was_done && p.st->done != 0);
+}
+
+// the normals of the targets of a batch's alignments (icp_batch_run: beside the cold searches)
+__global__ __launch_bounds__(kNormBlock) void normals_problems_kernel(const IcpProblem *pr, double radius)
+{
+    const IcpProblem j = pr[blockIdx.y];
+    if ((long long)blockIdx.x * (kNormBlock / kNormGroup) >= j.n_tgt) return;  // (a workgroup is 64 points; the grid is sized for the largest target)
+    normals_body(j.n_tgt, j.st, j.cell_start, j.sorted, radius, const_cast<float4 *>(j.normals));
 }
 
 // ---- K4c: the search of a loop iteration served from LDS ---------------------------------------------------------------------
@@ -2034,12 +2037,12 @@ void icp_workspace_free(IcpWorkspace *ws)
 {
 
     for (size_t i = 0; i < sizeof(ws->buf) / sizeof(ws->buf[0]); ++i) if (ws->buf[i]) { (void)hipFree(ws->buf[i]); ws->buf[i] = nullptr; ws->cap[i] = 0; }
-    for (int k = 0; k < 2; ++k) if (ws->ev_side[k]) { (void)hipEventDestroy(ws->ev_side[k]); ws->ev_side[k] = nullptr; }
     if (ws->side) { (void)hipStreamDestroy(ws->side); ws->side = nullptr; }
     for (int k = 0; k < IcpWorkspace::kMaxParts - 1; ++k) {
         if (ws->part_stream[k]) { (void)hipStreamDestroy(ws->part_stream[k]); ws->part_stream[k] = nullptr; }
         if (ws->ev_join[k]) { (void)hipEventDestroy(ws->ev_join[k]); ws->ev_join[k] = nullptr; }
     }
+    for (int k = 0; k < IcpWorkspace::kMaxParts; ++k) if (ws->ev_norm[k]) { (void)hipEventDestroy(ws->ev_norm[k]); ws->ev_norm[k] = nullptr; }
     if (ws->ev_fork) { (void)hipEventDestroy(ws->ev_fork); ws->ev_fork = nullptr; }
     if (ws->pinned) { (void)hipHostFree(ws->pinned); ws->pinned = nullptr; ws->pinned_cap = 0; }
 }
@@ -2139,6 +2142,7 @@ int icp_batch_prepare(IcpWorkspace *ws, hipStream_t stream, const void *d_src, i
     if ((rc = ensure(ws, B_NNI, sizeof(int) * (size_t)(n_src + 1), err))) return rc;
     if ((rc = ensure(ws, B_NND, sizeof(float) * (size_t)(n_src + 1), err))) return rc;
     if ((rc = ensure(ws, B_PART, part_bytes(n_src), err))) return rc;
+    ws->n_tgt = n_tgt;
     if ((rc = build_grid(ws, stream, n_tgt, stride, err))) return rc;
     if (p.estimator == 1) {
         if ((rc = ensure(ws, B_NORM, sizeof(float4) * (size_t)(n_tgt + 1), err))) return rc;
@@ -2180,6 +2184,7 @@ int icp_batch_prepare_all(IcpWorkspace *const *wss, int n, IcpWorkspace *ctl, hi
         if ((rc = ensure(ws, B_STATE, sizeof(IcpState), err))) return rc;
         if (p.estimator == 1 && (rc = ensure(ws, B_NORM, sizeof(float4) * (size_t)(n_tgt + 1), err))) return rc;
         ws->ext_tgt = d_tgts[c];
+        ws->n_tgt = n_tgt;
         GridJob &j = jobs[(size_t)c];
         j.tgt = static_cast<const unsigned char *>(d_tgts[c]); j.n = n_tgt; j.st = (IcpState *)ws->buf[B_STATE];
         j.cstart = (int *)ws->buf[B_CSTART]; j.cfill = (int *)ws->buf[B_CFILL]; j.tsort = (float4 *)ws->buf[B_TSORT];
@@ -2196,18 +2201,10 @@ int icp_batch_prepare_all(IcpWorkspace *const *wss, int n, IcpWorkspace *ctl, hi
     hipLaunchKernelGGL(grid_count_batch_kernel, dim3(gb, n), dim3(256), 0, stream, dj, stride);
     hipLaunchKernelGGL(grid_scan_batch_kernel, dim3(n), dim3(1024), 0, stream, dj);
     hipLaunchKernelGGL(grid_scatter_batch_kernel, dim3(gb, n), dim3(256), 0, stream, dj, stride);
-    ctl->normals_pending = false;
-    if (p.estimator == 1 && max_n > 0) {
-        // the normals are first needed by the plane reduction behind the cold search: they run on a side stream beside the sources'
-        // ordering and that search (icp_batch_run waits for ev_side[1] in front of its first plane reduction)
-        if (!ctl->side) ICP_HIP(hipStreamCreateWithFlags(&ctl->side, hipStreamNonBlocking));
-        for (int k = 0; k < 2; ++k) if (!ctl->ev_side[k]) ICP_HIP(hipEventCreateWithFlags(&ctl->ev_side[k], hipEventDisableTiming));
-        ICP_HIP(hipEventRecord(ctl->ev_side[0], stream));
-        ICP_HIP(hipStreamWaitEvent(ctl->side, ctl->ev_side[0], 0));
-        hipLaunchKernelGGL(normals_batch_kernel, dim3((unsigned)(((size_t)max_n * kNormGroup + kNormBlock - 1) / kNormBlock), n), dim3(kNormBlock), 0, ctl->side, dj, p.normal_radius);
-        ICP_HIP(hipEventRecord(ctl->ev_side[1], ctl->side));
-        ctl->normals_pending = true;
-    }
+    // the normals (point to plane) are first needed by the plane reduction behind the cold search: icp_batch_run launches them beside
+    // the cold searches of its parts
+    ctl->normals_pending = p.estimator == 1 && max_n > 0;
+    ctl->normals_radius = p.normal_radius;
     hipLaunchKernelGGL(state_init_batch_kernel, dim3(n), dim3(64), 0, stream, dj);
     ICP_HIP(hipGetLastError());
     return SCL_OK;
@@ -2220,6 +2217,7 @@ static void fill_problem(IcpProblem *hp, IcpWorkspace *ws, bool normals)
     hp->nni = (int *)ws->buf[B_NNI]; hp->nnd = (float *)ws->buf[B_NND]; hp->part = (double *)ws->buf[B_PART];
     hp->tgt = (const unsigned char *)(ws->ext_tgt ? ws->ext_tgt : ws->buf[B_TGT]); hp->normals = normals ? (const float4 *)ws->buf[B_NORM] : nullptr;
     hp->nnq = (float4 *)ws->buf[B_NNQ]; hp->flag = (int *)ws->buf[B_FLAG];
+    hp->n_tgt = ws->n_tgt;
 }
 
 // icp_batch_run: the ICP loops and the fitness passes of nprob prepared alignments, every step one launch for all of
@@ -2287,8 +2285,31 @@ int icp_batch_run(IcpWorkspace *const *wss, int nprob, IcpWorkspace *ctl, hipStr
             ICP_HIP(hipStreamWaitEvent(part[k].s, ctl->ev_fork, 0));
         }
     }
-    const bool wait_normals = ctl->normals_pending;
+    // Point to plane, the targets' normals still to be computed (icp_batch_prepare_all): a kernel bound by its vector instructions, 1.1-1.4 ms
+    // for 25 x 100 k points, beside cold searches that wait for memory.  With two parts and TWO streams: part 1's stream computes part 0's
+    // normals and then searches, part 0's stream searches and then computes part 1's normals -- one search and one half of the normals
+    // on the chip at any time, and each part's first plane reduction waits for the event behind its normals on the other stream.  (On a
+    // side stream of their own the normals shared a hardware queue with a part's stream on some runs, and that part's cold search then
+    // started when they ended: 1.2 ms late.)  One part: the side stream as before.
+    const bool normals_todo = ctl->normals_pending && p.estimator == 1;
     ctl->normals_pending = false;
+    int max_tgt = 0;
+    for (int c = 0; c < nprob; ++c) max_tgt = wss[c]->n_tgt > max_tgt ? wss[c]->n_tgt : max_tgt;
+    auto launch_normals = [&](const Part &of, hipStream_t on) {
+        hipLaunchKernelGGL(normals_problems_kernel, dim3((unsigned)(((size_t)max_tgt * kNormGroup + kNormBlock - 1) / kNormBlock), of.n), dim3(kNormBlock), 0, on,
+                           dp_all + of.first, ctl->normals_radius);
+    };
+    if (normals_todo) {
+        for (int k = 0; k < parts; ++k) if (!ctl->ev_norm[k]) ICP_HIP(hipEventCreateWithFlags(&ctl->ev_norm[k], hipEventDisableTiming));
+        if (parts == 1) {
+            if (!ctl->side) ICP_HIP(hipStreamCreateWithFlags(&ctl->side, hipStreamNonBlocking));
+            if (!ctl->ev_fork) ICP_HIP(hipEventCreateWithFlags(&ctl->ev_fork, hipEventDisableTiming));
+            ICP_HIP(hipEventRecord(ctl->ev_fork, stream));
+            ICP_HIP(hipStreamWaitEvent(ctl->side, ctl->ev_fork, 0));
+            launch_normals(part[0], ctl->side);
+            ICP_HIP(hipEventRecord(ctl->ev_norm[0], ctl->side));
+        }
+    }
     // neighbours (the previous increment applied first) and, point to point, the records of the workgroups' sums
     auto search_and_sums = [&](const Part &P, bool cold, int check_done, int apply, float md2, bool sums) {
         const IcpProblem *dp = dp_all + P.first;
@@ -2303,12 +2324,26 @@ int icp_batch_run(IcpWorkspace *const *wss, int nprob, IcpWorkspace *ctl, hipStr
                                 dp, n_src, check_done, apply ? 1 : -1, stride, 1);
         if (sums) hipLaunchKernelGGL(chunk_reduce_batch_kernel, dim3(tb, P.n), dim3(kTileQ), 0, P.s, dp, n_src, check_done, stride, md2);
     };
+    bool cold_wait[kMaxParts] = {false, false, false, false};
     auto iteration = [&](Part &P, bool cold) {
         const IcpProblem *dp = dp_all + P.first;
+        const int k = (int)(&P - part);
         P.sync.seq += 1;
+        if (cold && normals_todo && parts > 1 && (k & 1)) {      // an odd part's stream: the normals of the part before it, then its own search
+            launch_normals(part[k - 1], P.s);
+            (void)hipEventRecord(ctl->ev_norm[k - 1], P.s);
+        }
         search_and_sums(P, cold, 1, cold ? 0 : 1, maxd2, p.estimator == 0);
         if (p.estimator == 1) {
-            if (cold && wait_normals) (void)hipStreamWaitEvent(P.s, ctl->ev_side[1], 0);   // the candidates' normals (icp_batch_prepare_all's side stream)
+            if (cold && normals_todo) {
+                if (parts > 1 && !(k & 1)) {                     // an even part's stream: its own search, then the normals of the part behind it (its own, if it is the last)
+                    const int of = k + 1 < parts ? k + 1 : k;
+                    launch_normals(part[of], P.s);
+                    (void)hipEventRecord(ctl->ev_norm[of], P.s);
+                }
+                cold_wait[k] = true;                             // (the wait is enqueued when every part's normals have their event: below)
+                return;
+            }
             hipLaunchKernelGGL(plane_reduce_batch_kernel, dim3(rb, P.n), dim3(256), 0, P.s, dp, stride, n_src, maxd2);
             hipLaunchKernelGGL(plane_solve_batch_kernel, dim3(P.n), dim3(256), 0, P.s, dp, rb, p.max_iterations, p.transformation_epsilon,
                                p.euclidean_fitness_epsilon, P.sync);
@@ -2321,7 +2356,15 @@ int icp_batch_run(IcpWorkspace *const *wss, int nprob, IcpWorkspace *ctl, hipStr
     // memory: launches finished, alignments done): the device always has the next iteration queued, and a part whose alignments are
     // all done costs kAhead empty iterations (a finished alignment's workgroups leave at once), not the four to eight of a look at
     // copied flags every fourth iteration -- 0.26 of a 25-candidate query's 5.8 ms.  The parts are served as they become ready.
-    for (int k = 0; k < parts; ++k) iteration(part[k], true);
+    for (int k = parts - 1; k >= 0; --k) iteration(part[k], true);       // (odd parts first: their streams start with the normals the even parts wait for)
+    for (int k = 0; k < parts; ++k) {
+        if (!cold_wait[k]) continue;                             // point to plane, cold: the rest of the iteration behind the part's normals
+        const Part &P = part[k];
+        (void)hipStreamWaitEvent(P.s, ctl->ev_norm[k], 0);
+        hipLaunchKernelGGL(plane_reduce_batch_kernel, dim3(rb, P.n), dim3(256), 0, P.s, dp_all + P.first, stride, n_src, maxd2);
+        hipLaunchKernelGGL(plane_solve_batch_kernel, dim3(P.n), dim3(256), 0, P.s, dp_all + P.first, rb, p.max_iterations, p.transformation_epsilon,
+                           p.euclidean_fitness_epsilon, P.sync);
+    }
     for (unsigned long long idle = 0;;) {
         bool open = false, progress = false;
         for (int k = 0; k < parts; ++k) {

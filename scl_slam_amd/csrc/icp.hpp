@@ -16,12 +16,14 @@ struct IcpWorkspace {
     size_t pinned_cap = 0;
     const void *ext_tgt = nullptr;             // the alignment's target when it is read in place (icp_batch_prepare_all) instead of staged in the workspace
     hipStream_t side = nullptr;                // icp_batch_prepare_all: the candidates' normals run beside the batch's cold search
-    hipEvent_t ev_side[2] = {nullptr, nullptr};
-    bool normals_pending = false;              // ev_side[1] marks the end of the normals that icp_batch_run's first plane reduction needs
+    bool normals_pending = false;              // icp_batch_prepare_all: the targets' normals are still to be computed (icp_batch_run launches them beside its cold searches)
+    double normals_radius = 0.0;
+    int n_tgt = 0;                             // the alignment's target as prepared
     // icp_batch_run: a batch's alignments run as parts on streams of their own (one part's solve under another part's search)
     static constexpr int kMaxParts = 4;
     hipStream_t part_stream[kMaxParts - 1] = {nullptr, nullptr, nullptr};   // (part 0 runs on the caller's stream)
     hipEvent_t ev_fork = nullptr, ev_join[kMaxParts - 1] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_norm[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};   // the normals of a part's targets are done
 };
 
 void icp_workspace_free(IcpWorkspace *ws);
