@@ -1722,7 +1722,7 @@ __global__ __launch_bounds__(kTileQ) void icp_tile_search_kernel(const IcpProble
 #define SCL_ICP_PARTS 2                  // parts a large batch runs as (icp_batch_run).  Point to point, 25 x 100 k: 1 part 6.8 ms, 2 parts 5.85 (with HIP's four hardware queues and with eight), 3 parts 5.6 with four queues but 7.6 with eight, 4 parts 7.3
 #endif
 constexpr int kFinishBlocks = 128;
-constexpr int kFinishGroup = 8;                                  // lanes that share one left-over query's walk
+constexpr int kFinishGroup = 4;                                  // lanes that share one left-over query's walk (a deferred wave's 64 queries go through in one round; 2 and 8 measured slower)
 __global__ __launch_bounds__(kTileQ) void icp_tile_finish_kernel(const IcpProblem *pr, int n_src, int n_tiles, int check_done, int stride, float maxd2, int do_reduce)
 {
     __shared__ float pq[kTileQ * 8];
@@ -1730,10 +1730,21 @@ __global__ __launch_bounds__(kTileQ) void icp_tile_finish_kernel(const IcpProble
     __shared__ int s_count, s_list[kTileQ];
     const IcpProblem P = pr[blockIdx.y];
     const IcpState *st = P.st;
-    if (check_done && st->done) return;
     const int t = threadIdx.x;
-    for (int w = blockIdx.x; w < n_tiles; w += gridDim.x) {
-        if (!P.flag[w]) continue;                                // (the same for every lane of the workgroup)
+    // the done flag and the flags of this workgroup's tiles, all in flight together (one after the other: a round trip each)
+    constexpr int kFlagsPer = 8;
+    unsigned int flagged = 0u;
+    {
+        const int done = st->done;
+        int fl[kFlagsPer];
+#pragma unroll
+        for (int u = 0; u < kFlagsPer; ++u) { const int w = blockIdx.x + u * (int)gridDim.x; fl[u] = P.flag[w < n_tiles ? w : n_tiles - 1]; }
+#pragma unroll
+        for (int u = 0; u < kFlagsPer; ++u) flagged |= (fl[u] != 0 ? 1u : 0u) << u;
+        if (check_done && done) return;
+    }
+    for (int w = blockIdx.x, u = 0; w < n_tiles; w += gridDim.x, ++u) {
+        if (!(u < kFlagsPer ? (int)((flagged >> u) & 1u) : P.flag[w])) continue;   // (the same for every lane of the workgroup)
         const int i = w * kTileQ + t;
         const bool valid = i < n_src;
         const int ic = valid ? i : (n_src > 0 ? n_src - 1 : 0);
