@@ -745,6 +745,14 @@ def secondary_80x180(device, n=10000, steps=512):
     eng.profile_enable(0)
     prof = eng.profile()
     sv_q, sv_sum, sv_max = eng.survivor_stats()
+    # every pair's exact fp64 distance and shift on this grid (scl_sc_distance_matrix: 64 scans against the database, as
+    # secondary.exact_all_pairs on 64x120), median of three calls
+    mq = qs[:64]
+    eng.sc_distance_matrix(mq[:16], 0, n_elig)
+    mts = []
+    for _ in range(3):
+        t0 = time.perf_counter(); eng.sc_distance_matrix(mq, 0, n_elig); mts.append(time.perf_counter() - t0)
+    matrix_pairs_per_s = len(mq) * n_elig / sorted(mts)[1]
     eng.close()
     survey_pair = R2 * S2 * 4 + S2 * 4 + S2 * 4                                 # 59 040 B at 80x180
     # what the launch group (products in their second form + finish + next alignment) reads per keyframe by design, once per
@@ -764,6 +772,8 @@ def secondary_80x180(device, n=10000, steps=512):
             "value": n_elig * steps / dt, "unit": "pairs/s", "ms_per_scan": dt / steps * 1e3,
             "kernel_ms": {"screening_launch_group": k_ms},
             "survivors_per_scan": {"mean": sv_sum / max(1, sv_q), "max": sv_max, "scans": sv_q},
+            "exact_all_pairs": {"value": matrix_pairs_per_s, "unit": "pairs/s", "rows": int(len(mq)),
+                                "note": "scl_sc_distance_matrix through the call, results in host memory; groups of 16 rows alternate between two streams"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": per_launch, "scans_per_launch": k_scans,
                          "bytes_per_keyframe": bytes_kf, "bytes_per_pair_intermediates": bytes_pair_io, "survey_bytes_per_pair": survey_pair,
@@ -1152,6 +1162,7 @@ def main():
             "stream_from_points_pairs_per_s": pick(sec, "stream_from_points", "value"),
             "stream_from_points_over_pcie_floor": pick(sec, "stream_from_points", "pcie", "us_per_scan_over_floor"),
             "sc_distance_80x180_pairs_per_s": pick(sec, "sc_distance_80x180", "value"),
+            "exact_all_pairs_80x180_per_s": pick(sec, "sc_distance_80x180", "exact_all_pairs", "value"),
             "icp_p2plane_ms_per_query": pick(sec, "icp_verification", "point_to_plane", "from_store", "ms_per_query"),
             "icp_p2p_ms_per_query": pick(sec, "icp_verification", "point_to_point", "from_store", "ms_per_query"),
             "livox_stream_p50_ms": pick(sec, "livox_stream_80x180", "latency_ms", "p50"),

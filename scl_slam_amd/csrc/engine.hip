@@ -1329,37 +1329,51 @@ int matrix_screened_locked(scl_engine *e, const int *slots, int nq, int lo, int 
         }
         return SCL_OK;
     };
+    // Consecutive groups alternate between the engine's stream and its second lane (buffer sets, partial sums and output halves of their
+    // own) on the 80 x 180 grid: a group is alignment, products and finishing -- launches that each ramp up and drain -- in front of the exact
+    // kernel, and on one stream the chip went through them with nothing beside them; now they run under the group before's exact kernel:
+    // 97-104 -> 108-116 M pairs/s.  On 64 x 120 the same measured 206-214 -> 194-196 M at 64 rows and nothing at 256: there the exact kernel
+    // lives off its keyframes staying in the XCDs' L2s (sc_matrix.hip), which a products launch beside it streams the database through.
     for (int g = 0; g < groups; ++g) {
         const int h = g & 1, r0 = g * mb, rows = nq - r0 < mb ? nq - r0 : mb;
+        const int lane = (groups > 1 && wide) ? h : 0, set0 = lane * mb;   // (64 x 120: one lane -- see above)
+        hipStream_t ks = lane ? e->stream_alt : e->stream;
+        if (lane && e->alt_seen_version != e->db_version) {                  // descriptors written on `stream` since the last pass on the second lane
+            SCL_HIP(e, hipEventRecord(e->ev_db, e->stream));
+            SCL_HIP(e, hipStreamWaitEvent(e->stream_alt, e->ev_db, 0));
+            e->alt_seen_version = e->db_version;
+        }
         int qs[kMaxScreenBatch], los[kMaxScreenBatch], ns[kMaxScreenBatch];
         const int padded = rows < v2_min ? v2_min : rows;                   // (the padding rows repeat the last one; their results are dropped)
         for (int j = 0; j < padded; ++j) { qs[j] = slots[r0 + (j < rows ? j : rows - 1)]; los[j] = lo; ns[j] = n; }
         {
-            ProfScope ps(e, P_SC);
-            ScreenGroup grp{qs, los, ns, padded, 0};
-            grp.masks = true;
+            ProfScope ps(e, P_SC, ks);
+            ScreenGroup grp{qs, los, ns, padded, set0};
+            grp.masks = true; grp.part_half = lane;
             const int prof_saved = e->prof_on;
             e->prof_on = 0;                                                  // (one event pair around the whole group: this scope's)
-            rc = launch_screen_group(e, grp);
+            rc = launch_screen_group(e, grp, kScreenAlign | kScreenProducts, nullptr, ks);
             e->prof_on = prof_saved;
             if (rc) return rc;
+            const int *g_starts = e->d_starts + (size_t)set0 * e->set_stride;
+            const unsigned int *g_smask = e->d_smask + (size_t)set0 * e->set_stride;
             MaskedQuery mq[kMaxMaskedQueries];
             for (int j = 0; j < rows; ++j) {
                 mq[j].qslot = qs[j]; mq[j].slot_base = lo; mq[j].n = n; mq[j].n_dev = nullptr; mq[j].cand = nullptr;
-                mq[j].starts = e->d_starts + (size_t)j * e->set_stride; mq[j].smask = e->d_smask + (size_t)j * e->set_stride;
+                mq[j].starts = g_starts + (size_t)j * e->set_stride; mq[j].smask = g_smask + (size_t)j * e->set_stride;
                 mq[j].out_dist = e->d_mat_dist + ((size_t)h * RB + j) * cap; mq[j].out_shift = e->d_mat_shift + ((size_t)h * RB + j) * cap;
             }
             if (sc_matrix_supported(db_view(e), e->SR) && !matrix_masked_kernel()) {
-                SCL_HIP(e, launch_sc_matrix(db_view(e), e->SR, qs, rows, lo, n, e->d_starts, e->d_smask, e->set_stride,
-                                            e->d_mat_dist + (size_t)h * RB * cap, e->d_mat_shift + (size_t)h * RB * cap, cap, matrix_kr(), e->stream));
+                SCL_HIP(e, launch_sc_matrix(db_view(e), e->SR, qs, rows, lo, n, g_starts, g_smask, e->set_stride,
+                                            e->d_mat_dist + (size_t)h * RB * cap, e->d_mat_shift + (size_t)h * RB * cap, cap, matrix_kr(), ks));
             } else {
                 int parts = 2 * e->num_cu / rows; parts = parts < 1 ? 1 : parts;
                 const int max_parts = (n + 7) / 8; parts = parts > max_parts ? max_parts : parts;
-                SCL_HIP(e, launch_sc_masked(db_view(e), e->SR, mq, rows, parts, e->stream));
+                SCL_HIP(e, launch_sc_masked(db_view(e), e->SR, mq, rows, parts, ks));
             }
             if (ps.active()) e->prof.sc_distance_pairs += (uint64_t)rows * (uint64_t)n;
         }
-        SCL_HIP(e, hipEventRecord(e->ev_mat_k[h], e->stream));
+        SCL_HIP(e, hipEventRecord(e->ev_mat_k[h], ks));
         SCL_HIP(e, hipStreamWaitEvent(e->stream2, e->ev_mat_k[h], 0));
         SCL_HIP(e, hipMemcpyAsync(h_dist + (size_t)h * RB * cap, e->d_mat_dist + (size_t)h * RB * cap, sizeof(double) * (size_t)rows * cap, hipMemcpyDeviceToHost, e->stream2));
         SCL_HIP(e, hipMemcpyAsync(h_shift + (size_t)h * RB * cap, e->d_mat_shift + (size_t)h * RB * cap, sizeof(int) * (size_t)rows * cap, hipMemcpyDeviceToHost, e->stream2));
