@@ -247,3 +247,23 @@ def test_configs2_point_to_plane_batch_25_candidates_of_100k_points(eng):
     for c in (0, 5, 24):                                            # fused == one by one, bit for bit
         T1, f1, c1, i1 = eng.icp_align(src, tgts[c], p)
         assert np.array_equal(Tb[c].view(np.uint32), T1.view(np.uint32)) and fb[c] == f1 and bool(cb[c]) == c1 and ib[c] == i1
+
+
+@pytest.mark.parametrize("estimator", [0, 1])
+@pytest.mark.parametrize("max_iterations", [1, 2, 3, 4, 9])
+def test_batch_in_parts_at_iteration_caps_equals_one_by_one(eng, estimator, max_iterations):
+    """A batch large enough to run as two parts on two streams (icp_batch_run: >= 300 k queries per part, >= 4 alignments) with the
+    iteration cap below, at and above the host's run-ahead of two iterations, alignments that converge at different iterations (one
+    of them at once: the scan against itself) and parts of unequal size: every alignment bit for bit the one-by-one call's."""
+    n_pts, n_cand = 80000, 9
+    base = synth_structured_cloud(n_pts, seed=901, extent=40.0)
+    src = moved_copy(base, rigid_transform(0.003, -0.004, 0.01, 0.12, -0.08, 0.03), keep_every=1, noise=0.005, seed=5)
+    tgts = [base, src.copy()] + [synth_structured_cloud(n_pts - 3000 * c, seed=910 + c, extent=40.0) for c in range(n_cand - 2)]
+    p = eng.icp_default_params(); p.max_iterations = max_iterations; p.estimator = estimator; p.normal_radius = 1.0
+    Tb, fb, cb, ib = eng.icp_align_batch(src, tgts, p)
+    assert ib.max() <= max_iterations
+    for c in (0, 1, 4, 5, 8):
+        T1, f1, c1, i1 = eng.icp_align(src, tgts[c], p)
+        assert np.array_equal(Tb[c].view(np.uint32), T1.view(np.uint32)) and fb[c] == f1 and bool(cb[c]) == c1 and ib[c] == i1, (c, ib[c], i1)
+    Tb2, fb2, cb2, ib2 = eng.icp_align_batch(src, tgts, p)             # and the same again: nothing of the first call is left in the workspaces
+    assert np.array_equal(Tb.view(np.uint32), Tb2.view(np.uint32)) and np.array_equal(fb, fb2) and np.array_equal(ib, ib2)
