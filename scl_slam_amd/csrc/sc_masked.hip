@@ -656,6 +656,7 @@ __global__ __launch_bounds__(kCandWaves * kWave) void sc_cand_exact_kernel(CandE
         topk_merge_lists(ca.lists, ca.n_lists, ca.k, skey, scand, msh, r_idx, r_d2, true);
         if (wave < ca.k) my_slot = r_idx[wave];
         if (wave + kCandWaves < ca.k) my_slot2 = r_idx[wave + kCandWaves];
+        if (ca.k <= kCandWaves / 2 && wave >= kCandWaves / 2 && wave - kCandWaves / 2 < ca.k) my_slot = r_idx[wave - kCandWaves / 2];   // (two waves per candidate: below)
         if ((int)threadIdx.x < ca.k) {
             const int ci = r_idx[threadIdx.x]; const float cd = r_d2[threadIdx.x];
             o_idx[threadIdx.x] = ci; o_d2[threadIdx.x] = cd;
@@ -665,10 +666,54 @@ __global__ __launch_bounds__(kCandWaves * kWave) void sc_cand_exact_kernel(CandE
     } else {
         if (wave < ca.k) my_slot = ca.cand_idx[wave];
         if (wave + kCandWaves < ca.k) my_slot2 = ca.cand_idx[wave + kCandWaves];
+        if (ca.k <= kCandWaves / 2 && wave >= kCandWaves / 2 && wave - kCandWaves / 2 < ca.k) my_slot = ca.cand_idx[wave - kCandWaves / 2];
     }
     if (!ca.lists && (int)threadIdx.x < ca.k) { o_idx[threadIdx.x] = ca.cand_idx[threadIdx.x]; o_d2[threadIdx.x] = ca.cand_d2[threadIdx.x]; }
     __syncthreads();
     CAND_STAMP(1);
+    constexpr int PDC = RG % 4 == 0 ? 4 : RG;                                    // ring groups in flight (a lone wave: every round trip counts)
+    if (ca.k <= kCandWaves / 2) {
+        // Up to four candidates (the reference's three, D.h:1319): TWO waves per candidate.  One wave's 13 shifts were 14 of the kernel's
+        // 25 us -- 1 664 fp64 products and as many conversions per candidate on ONE SIMD's fp64 pipe, with half of the workgroup's waves
+        // idle.  Wave c aligns candidate c (the reference's own alignment) and scores its first seven shifts, wave c + 4 the other six;
+        // the smaller (distance, shift value) of the two is the pair's -- masked_pair's own tie rule (the lowest shift value).
+        constexpr int H = kCandWaves / 2, TA = (W + 1) / 2, TB = W - TA;
+        __shared__ int s_first[H];
+        __shared__ double s_b[kCandWaves];
+        __shared__ int s_bs[kCandWaves];
+        const int c = wave < H ? wave : wave - H;
+        const bool mine = c < ca.k && my_slot >= 0;
+        if (mine && wave < H) {
+            constexpr int L = S >> 1;
+            const int ll2 = lane < L ? lane : L - 1;
+            const double2 vk = *reinterpret_cast<const double2 *>(ca.vkey + (size_t)my_slot * S + 2 * ll2);
+            const int a0 = align_keyframe_exact<S>(vk, lane, wrow, vq);
+            int first = a0 - SR; first = first < 0 ? first + S : first;          // D.h:1545-1551: the searched shifts start SEARCH_RADIUS below
+            if (lane == 0) s_first[c] = first;
+            wave_fence_lds();
+        }
+        CAND_STAMP(2);
+        __syncthreads();
+        double b = __longlong_as_double(0x7ff0000000000000LL); int bs = 0x7fffffff;
+        if (mine) {
+            int first = s_first[c];
+            const float4 *kd = ca.desc + (size_t)my_slot * (size_t)(RG * S);
+            const double *kn = ca.norm + (size_t)my_slot * S;
+            if (wave < H) masked_pair<RG, S, W, PDC, TA, true>(Qs, nq, wrow, kd, kn, first, (1u << TA) - 1u, lane, b, bs);
+            else { first += TA; first = first >= S ? first - S : first; masked_pair<RG, S, W, PDC, TB, true>(Qs, nq, wrow, kd, kn, first, (1u << TB) - 1u, lane, b, bs); }
+        }
+        if (lane == 0) { s_b[wave] = b; s_bs[wave] = bs; }
+        CAND_STAMP(3);
+        __syncthreads();
+        if (wave < H && c < ca.k && lane == 0) {
+            double best = kBigDist; int bshift = 0;
+            double b0 = s_b[wave]; int bs0 = s_bs[wave];
+            const double b1 = s_b[wave + H]; const int bs1 = s_bs[wave + H];
+            if (b1 < b0 || (b1 == b0 && bs1 < bs0)) { b0 = b1; bs0 = bs1; }
+            if (my_slot >= 0 && b0 < kBigDist) { best = b0; bshift = bs0; }
+            o_dist[c] = best; o_shift[c] = bshift;
+        }
+    } else
     for (int c = wave; c < ca.k; c += kCandWaves) {
         const int slot = c == wave ? my_slot : my_slot2;
         double best = kBigDist; int bshift = 0;
@@ -681,7 +726,6 @@ __global__ __launch_bounds__(kCandWaves * kWave) void sc_cand_exact_kernel(CandE
             int first = a0 - SR; first = first < 0 ? first + S : first;          // D.h:1545-1551: the searched shifts start SEARCH_RADIUS below
             wave_fence_lds();
             double b; int bs;
-            constexpr int PDC = RG % 4 == 0 ? 4 : RG;                            // ring groups in flight (a lone wave: every round trip counts)
             masked_pair<RG, S, W, PDC, W, true>(Qs, nq, wrow, ca.desc + (size_t)slot * (size_t)(RG * S), ca.norm + (size_t)slot * S, first,
                                                W >= 32 ? 0xffffffffu : ((1u << W) - 1u), lane, b, bs);
             if (b < kBigDist) { best = b; bshift = bs; }
