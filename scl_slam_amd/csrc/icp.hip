@@ -1247,10 +1247,10 @@ struct IcpProblem {
 };
 
 // How far a part of a batch has got, for the host that enqueues its iterations (icp_batch_run): the last alignment to leave a solve
-// launch writes (launches of the part finished so far << 16 | alignments of the part that are done) into pinned host memory.
+// launch writes (launches of the part finished so far << 32 | alignments of the part that are done) into pinned host memory.
 struct PartSync {
     int *counters;                       // device: [0] arrivals at the current launch's end, [1] alignments done
-    unsigned int *host_word;             // pinned; nullptr: nobody is watching
+    unsigned long long *host_word;       // pinned; nullptr: nobody is watching
     unsigned int seq;                    // this launch's number within the part (the cold iteration's solve is 1)
 };
 __device__ __forceinline__ void part_sync_arrive(const PartSync &ps, const bool newly_done)
@@ -1260,7 +1260,7 @@ __device__ __forceinline__ void part_sync_arrive(const PartSync &ps, const bool 
     if (atomicAdd(&ps.counters[0], 1) == (int)gridDim.x - 1) {   // every alignment of the launch has been here: the next launch starts behind this one
         ps.counters[0] = 0;
         const unsigned int nd = (unsigned int)atomicAdd(&ps.counters[1], 0);
-        __hip_atomic_store(ps.host_word, (ps.seq << 16) | (nd & 0xffffu), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(ps.host_word, ((unsigned long long)ps.seq << 32) | (unsigned long long)nd, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -2251,7 +2251,7 @@ int icp_batch_run(IcpWorkspace *const *wss, int nprob, IcpWorkspace *ctl, hipStr
     unsigned char *h_words = reinterpret_cast<unsigned char *>(((uintptr_t)(hs + nprob) + 63) & ~(uintptr_t)63);
     IcpState *d_states = static_cast<IcpState *>(ctl->buf[B_HYP]);
     int *d_counters = reinterpret_cast<int *>(d_states + nprob);
-    for (int k = 0; k < kMaxParts; ++k) *reinterpret_cast<volatile unsigned int *>(h_words + kWordPitch * (size_t)k) = 0u;
+    for (int k = 0; k < kMaxParts; ++k) *reinterpret_cast<volatile unsigned long long *>(h_words + kWordPitch * (size_t)k) = 0ull;
     ICP_HIP(hipMemsetAsync(d_counters, 0, 2 * sizeof(int) * kMaxParts, stream));
     if ((rc = source_order(ctl, stream, d_src, n_src, stride, err))) return rc;
     for (int c = 0; c < nprob; ++c) fill_problem(&hp[c], wss[c], p.estimator == 1);
@@ -2283,7 +2283,7 @@ int icp_batch_run(IcpWorkspace *const *wss, int nprob, IcpWorkspace *ctl, hipStr
         part[k].next_it = 1; part[k].finished = false;
         part[k].s = stream;
         part[k].sync.counters = d_counters + 2 * k;
-        part[k].sync.host_word = reinterpret_cast<unsigned int *>(h_words + kWordPitch * (size_t)k);
+        part[k].sync.host_word = reinterpret_cast<unsigned long long *>(h_words + kWordPitch * (size_t)k);
         part[k].sync.seq = 0;
     }
     if (parts > 1) {
@@ -2384,9 +2384,9 @@ int icp_batch_run(IcpWorkspace *const *wss, int nprob, IcpWorkspace *ctl, hipStr
             open = true;
             const int want = P.next_it - kAhead;                 // the solve launch of the part that must have finished (the cold one is 1)
             if (want >= 1) {
-                const unsigned int w = __atomic_load_n(P.sync.host_word, __ATOMIC_ACQUIRE);
-                if ((int)(w >> 16) < want) continue;
-                if ((int)(w & 0xffffu) >= P.n) { P.finished = true; progress = true; continue; }
+                const unsigned long long w = __atomic_load_n(P.sync.host_word, __ATOMIC_ACQUIRE);
+                if ((long long)(w >> 32) < (long long)want) continue;
+                if ((long long)(w & 0xffffffffull) >= (long long)P.n) { P.finished = true; progress = true; continue; }
             }
             iteration(P, false);
             P.next_it += 1;
