@@ -38,19 +38,24 @@ struct SortPlan {                                // passed by value: lives in th
     int nseg;
     int off[kSortMaxSegments + 1];               // first element of each segment; off[nseg] = n
     int blk[kSortMaxSegments + 1];               // first tile of each segment; blk[nseg] = tiles
+    unsigned int hi[kSortMaxSegments];           // packed passes: the high word every key of the segment has
 };
 
 // the segment tile b belongs to: its elements [e0, e1), its tiles [b0, b1).  Static indices only: the plan stays in scalar registers.
-__device__ __forceinline__ void sort_locate(const SortPlan &pl, const int b, int &e0, int &e1, int &b0, int &b1)
+__device__ __forceinline__ void sort_locate(const SortPlan &pl, const int b, int &e0, int &e1, int &b0, int &b1, unsigned int *hi = nullptr)
 {
     e0 = pl.off[0]; e1 = pl.off[1]; b0 = pl.blk[0]; b1 = pl.blk[1];
-    if (pl.nseg == 1) return;
+    unsigned int h = pl.hi[0];
+    if (pl.nseg > 1) {
 #pragma unroll
-    for (int s = 1; s < kSortMaxSegments; ++s) {
-        const bool here = s < pl.nseg && b >= pl.blk[s];
-        e0 = here ? pl.off[s] : e0; e1 = here ? pl.off[s + 1] : e1;
-        b0 = here ? pl.blk[s] : b0; b1 = here ? pl.blk[s + 1] : b1;
+        for (int s = 1; s < kSortMaxSegments; ++s) {
+            const bool here = s < pl.nseg && b >= pl.blk[s];
+            e0 = here ? pl.off[s] : e0; e1 = here ? pl.off[s + 1] : e1;
+            b0 = here ? pl.blk[s] : b0; b1 = here ? pl.blk[s + 1] : b1;
+            h = here ? pl.hi[s] : h;
+        }
     }
+    if (hi) *hi = h;
 }
 
 template <typename K, int RB, int ITEMS>
@@ -115,17 +120,23 @@ __global__ __launch_bounds__(kSortThreads) void sort_colscan_kernel(int *H, cons
     }
 }
 
-template <typename K, int RB, int ITEMS>
+// MODE (64-bit keys whose high word is the same throughout a segment, sorted on their low word): 0 keys and values in arrays of their own,
+// in and out; 1 in: as 0, out: ONE 8-byte record per pair (value << 32 | low word of the key); 2 records in and out; 3 records in, out as
+// 0 with the segment's high word back in the key.  A pair of a middle pass is then one 8-byte write where it was an 8- and a 4-byte
+// write to two arrays -- with 2 048 destinations per tile of 4 096 every write is a transaction of its own.
+template <typename K, int RB, int ITEMS, int MODE = 0>
 __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const K *kin, K *kout, const unsigned int *vin, unsigned int *vout,
                                                                     const SortPlan pl, const int shift, const unsigned int mask, const int *E)
 {
+    static_assert(MODE == 0 || sizeof(K) == 8, "packed records are 64-bit keys'");
     constexpr int NB = 1 << RB, DPT = NB / kSortThreads;
     static_assert(RB >= 8 && RB <= kSortMaxDigit, "digit");
     __shared__ int cnt[kSortWaves][NB];
     __shared__ int wtot[kSortWaves];
     const int b = blockIdx.x, t = threadIdx.x, lane = t & (kSortWave - 1), w = t >> 6;
     int e0, e1, b0, b1;
-    sort_locate(pl, b, e0, e1, b0, b1);
+    unsigned int seg_hi = 0u;
+    sort_locate(pl, b, e0, e1, b0, b1, &seg_hi);
     // the tile in the order that has to survive: wave w takes pairs [w * 64 ITEMS, (w + 1) * 64 ITEMS), round u the next 64 of them
     const int wave0 = e0 + (b - b0) * (kSortThreads * ITEMS) + w * (kSortWave * ITEMS);
     K kv[ITEMS];
@@ -134,7 +145,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const K *kin
     for (int u = 0; u < ITEMS; ++u) {
         const int idx = wave0 + u * kSortWave + lane, ic = idx < e1 ? idx : e1 - 1;
         kv[u] = kin[ic];
-        vv[u] = vin[ic];
+        if constexpr (MODE <= 1) vv[u] = vin[ic]; else vv[u] = 0u;
     }
     // this thread's DPT consecutive digits of the three rows of E
     int eb[DPT], es0[DPT], es1[DPT];
@@ -191,8 +202,10 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const K *kin
         if (wave0 + u * kSortWave + lane < e1) {
             const unsigned int digit = (unsigned int)(kv[u] >> shift) & mask;
             const int pos = cnt[w][digit] + rank[u];
-            kout[pos] = kv[u];
-            vout[pos] = vv[u];
+            if constexpr (MODE == 0) { kout[pos] = kv[u]; vout[pos] = vv[u]; }
+            else if constexpr (MODE == 1) kout[pos] = (K)(((unsigned long long)vv[u] << 32) | ((unsigned long long)kv[u] & 0xffffffffull));
+            else if constexpr (MODE == 2) kout[pos] = kv[u];
+            else { kout[pos] = (K)(((unsigned long long)seg_hi << 32) | ((unsigned long long)kv[u] & 0xffffffffull)); vout[pos] = (unsigned int)((unsigned long long)kv[u] >> 32); }
         }
     }
 }
@@ -201,30 +214,38 @@ inline int sort_items(size_t n) { return n >= kSortBigN ? kSortBigItems : kSortS
 
 template <typename K, int RB, int ITEMS>
 hipError_t sort_pass(const K *kin, K *kout, const unsigned int *vin, unsigned int *vout, const SortPlan &pl, int tiles, int shift,
-                     unsigned int mask, int *H, hipStream_t stream)
+                     unsigned int mask, int *H, hipStream_t stream, int mode)
 {
     constexpr int NB = 1 << RB;
     hipLaunchKernelGGL((sort_hist_kernel<K, RB, ITEMS>), dim3(tiles), dim3(kSortThreads), 0, stream, kin, pl, shift, mask, H);
     hipLaunchKernelGGL(sort_colscan_kernel, dim3(NB / 16), dim3(kSortThreads), 0, stream, H, tiles, NB);
-    hipLaunchKernelGGL((sort_scatter_kernel<K, RB, ITEMS>), dim3(tiles), dim3(kSortThreads), 0, stream, kin, kout, vin, vout, pl, shift, mask, (const int *)H);
+    const dim3 g(tiles), t(kSortThreads);
+    if constexpr (sizeof(K) == 8) {
+        if (mode == 1) hipLaunchKernelGGL((sort_scatter_kernel<K, RB, ITEMS, 1>), g, t, 0, stream, kin, kout, vin, vout, pl, shift, mask, (const int *)H);
+        else if (mode == 2) hipLaunchKernelGGL((sort_scatter_kernel<K, RB, ITEMS, 2>), g, t, 0, stream, kin, kout, vin, vout, pl, shift, mask, (const int *)H);
+        else if (mode == 3) hipLaunchKernelGGL((sort_scatter_kernel<K, RB, ITEMS, 3>), g, t, 0, stream, kin, kout, vin, vout, pl, shift, mask, (const int *)H);
+        else hipLaunchKernelGGL((sort_scatter_kernel<K, RB, ITEMS, 0>), g, t, 0, stream, kin, kout, vin, vout, pl, shift, mask, (const int *)H);
+    } else {
+        hipLaunchKernelGGL((sort_scatter_kernel<K, RB, ITEMS, 0>), g, t, 0, stream, kin, kout, vin, vout, pl, shift, mask, (const int *)H);
+    }
     return hipGetLastError();
 }
 
 template <typename K, int ITEMS>
 hipError_t sort_pass_rb(int rb, const K *kin, K *kout, const unsigned int *vin, unsigned int *vout, const SortPlan &pl, int tiles, int shift,
-                        unsigned int mask, int *H, hipStream_t stream)
+                        unsigned int mask, int *H, hipStream_t stream, int mode)
 {
     switch (rb) {
-    case 11: return sort_pass<K, 11, ITEMS>(kin, kout, vin, vout, pl, tiles, shift, mask, H, stream);
-    case 10: return sort_pass<K, 10, ITEMS>(kin, kout, vin, vout, pl, tiles, shift, mask, H, stream);
-    case 9: return sort_pass<K, 9, ITEMS>(kin, kout, vin, vout, pl, tiles, shift, mask, H, stream);
-    default: return sort_pass<K, 8, ITEMS>(kin, kout, vin, vout, pl, tiles, shift, mask, H, stream);
+    case 11: return sort_pass<K, 11, ITEMS>(kin, kout, vin, vout, pl, tiles, shift, mask, H, stream, mode);
+    case 10: return sort_pass<K, 10, ITEMS>(kin, kout, vin, vout, pl, tiles, shift, mask, H, stream, mode);
+    case 9: return sort_pass<K, 9, ITEMS>(kin, kout, vin, vout, pl, tiles, shift, mask, H, stream, mode);
+    default: return sort_pass<K, 8, ITEMS>(kin, kout, vin, vout, pl, tiles, shift, mask, H, stream, mode);
     }
 }
 
 template <typename K>
 hipError_t sort_run(void *scratch, K *keys_in, K *keys_out, unsigned int *vals_in, unsigned int *vals_out, const SortSegments &seg, int bits,
-                    hipStream_t stream)
+                    hipStream_t stream, const unsigned int *seg_hi = nullptr)
 {
     if (seg.nseg < 1 || seg.nseg > kSortMaxSegments || bits < 0 || bits > (int)(8 * sizeof(K)) || seg.off[0] != 0) return hipErrorInvalidValue;
     const int n = seg.off[seg.nseg];
@@ -242,6 +263,7 @@ hipError_t sort_run(void *scratch, K *keys_in, K *keys_out, unsigned int *vals_i
     }
     pl.off[seg.nseg] = n; pl.blk[seg.nseg] = tiles;
     for (int s = seg.nseg + 1; s <= kSortMaxSegments; ++s) { pl.off[s] = n; pl.blk[s] = tiles; }
+    for (int s = 0; s < seg.nseg; ++s) pl.hi[s] = seg_hi ? seg_hi[s] : 0u;
     // an odd number of passes of at most eleven bits
     int passes = (bits + kSortMaxDigit - 1) / kSortMaxDigit;
     if (passes < 1) passes = 1;
@@ -254,8 +276,11 @@ hipError_t sort_run(void *scratch, K *keys_in, K *keys_out, unsigned int *vals_i
         const K *kin = (p & 1) ? keys_out : keys_in; K *kout = (p & 1) ? keys_in : keys_out;
         const unsigned int *vin = (p & 1) ? vals_out : vals_in; unsigned int *vout = (p & 1) ? vals_in : vals_out;
         const int sh = shift < (int)(8 * sizeof(K)) ? shift : 0;                 // (a pass with no bits left: mask 0, a stable copy)
-        hipError_t e = items == kSortBigItems ? sort_pass_rb<K, kSortBigItems>(rb, kin, kout, vin, vout, pl, tiles, sh, mask, H, stream)
-                                              : sort_pass_rb<K, kSortSmallItems>(rb, kin, kout, vin, vout, pl, tiles, sh, mask, H, stream);
+        // 64-bit keys that differ in their low word only within a segment: 8-byte records between the first and the last pass
+        const bool packed = sizeof(K) == 8 && seg_hi && bits <= 32 && passes >= 3;
+        const int mode = !packed ? 0 : (p == 0 ? 1 : (p == passes - 1 ? 3 : 2));
+        hipError_t e = items == kSortBigItems ? sort_pass_rb<K, kSortBigItems>(rb, kin, kout, vin, vout, pl, tiles, sh, mask, H, stream, mode)
+                                              : sort_pass_rb<K, kSortSmallItems>(rb, kin, kout, vin, vout, pl, tiles, sh, mask, H, stream, mode);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -356,9 +381,9 @@ hipError_t sort_pairs_u64(void *scratch, unsigned long long *keys_in, unsigned l
 }
 
 hipError_t sort_pairs_u64_segmented(void *scratch, unsigned long long *keys_in, unsigned long long *keys_out, unsigned int *vals_in,
-                                    unsigned int *vals_out, const SortSegments &seg, int bits, hipStream_t stream)
+                                    unsigned int *vals_out, const SortSegments &seg, int bits, hipStream_t stream, const unsigned int *seg_hi)
 {
-    return sort_run<unsigned long long>(scratch, keys_in, keys_out, vals_in, vals_out, seg, bits, stream);
+    return sort_run<unsigned long long>(scratch, keys_in, keys_out, vals_in, vals_out, seg, bits, stream, seg_hi);
 }
 
 size_t scan_scratch_bytes(size_t) { return sizeof(int) * (size_t)kScanMaxChunks; }

@@ -27,9 +27,12 @@ hipError_t sort_pairs_u32(void *scratch, unsigned int *keys_in, unsigned int *ke
                           int n, int bits, hipStream_t stream);
 hipError_t sort_pairs_u64(void *scratch, unsigned long long *keys_in, unsigned long long *keys_out, unsigned int *vals_in,
                           unsigned int *vals_out, int n, int bits, hipStream_t stream);
-// every segment sorted on its own on the key bits [0, bits) (the whole 64-bit key travels)
+// every segment sorted on its own on the key bits [0, bits) (the whole 64-bit key travels).  seg_hi (optional, bits <= 32): the caller
+// says that every key of segment s has the high word seg_hi[s] -- the passes then move 8-byte records (value, low word) instead of a
+// key and a value in two arrays, and the last one puts the high word back.
 hipError_t sort_pairs_u64_segmented(void *scratch, unsigned long long *keys_in, unsigned long long *keys_out, unsigned int *vals_in,
-                                    unsigned int *vals_out, const SortSegments &seg, int bits, hipStream_t stream);
+                                    unsigned int *vals_out, const SortSegments &seg, int bits, hipStream_t stream,
+                                    const unsigned int *seg_hi = nullptr);
 
 // bytes of scratch a prefix sum of n values needs
 size_t scan_scratch_bytes(size_t n);

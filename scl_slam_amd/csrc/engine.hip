@@ -2388,7 +2388,18 @@ int scl_selftest_sort_pairs(scl_engine *e, int key_bytes, const void *keys, cons
     if (he == hipSuccess) he = hipMemcpyAsync(v0, values, vb, hipMemcpyHostToDevice, e->stream);
     if (he == hipSuccess) {
         if (key_bytes == 4) he = sort_pairs_u32(scratch, (unsigned int *)k0, (unsigned int *)k1, (unsigned int *)v0, (unsigned int *)v1, n, bits, e->stream);
-        else he = sort_pairs_u64_segmented(scratch, (unsigned long long *)k0, (unsigned long long *)k1, (unsigned int *)v0, (unsigned int *)v1, seg, bits, e->stream);
+        else {
+            // keys whose high word is the same throughout every segment take the 8-byte records of voxel.hip's batch (device_sort.hpp)
+            unsigned int seg_hi[kSortMaxSegments];
+            bool uniform = bits <= 32;
+            const unsigned long long *hk = static_cast<const unsigned long long *>(keys);
+            for (int s = 0; s < seg.nseg && uniform; ++s) {
+                seg_hi[s] = seg.off[s] < seg.off[s + 1] ? (unsigned int)(hk[seg.off[s]] >> 32) : 0u;
+                for (int i = seg.off[s]; i < seg.off[s + 1]; ++i) if ((unsigned int)(hk[i] >> 32) != seg_hi[s]) { uniform = false; break; }
+            }
+            he = sort_pairs_u64_segmented(scratch, (unsigned long long *)k0, (unsigned long long *)k1, (unsigned int *)v0, (unsigned int *)v1, seg, bits, e->stream,
+                                          uniform ? seg_hi : nullptr);
+        }
     }
     if (he == hipSuccess) he = hipMemcpyAsync(keys_out, k1, kb, hipMemcpyDeviceToHost, e->stream);
     if (he == hipSuccess) he = hipMemcpyAsync(values_out, v1, vb, hipMemcpyDeviceToHost, e->stream);

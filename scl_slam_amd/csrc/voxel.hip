@@ -546,7 +546,9 @@ int assemble_submaps_batch(IcpWorkspace *ws, hipStream_t stream, const void *con
     const size_t tmp_sort = sort_scratch_bytes((size_t)n, segmented ? n_jobs : 1), tmp_scan = scan_scratch_bytes((size_t)n);
     const size_t tmp = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
     if ((rc = vensure(ws, V_TMP, tmp + 256, err))) return rc;
-    if (segmented) VOX_HIP(sort_pairs_u64_segmented(ws->buf[V_TMP], keys_in, keys_out, idx_in, idx_out, seg, 32, stream));
+    unsigned int seg_hi[kSortMaxSegments];                               // vox_keys_batch_kernel's keys: job << 32 | voxel
+    for (int j = 0; j < n_jobs && j < kSortMaxSegments; ++j) seg_hi[j] = (unsigned int)j;
+    if (segmented) VOX_HIP(sort_pairs_u64_segmented(ws->buf[V_TMP], keys_in, keys_out, idx_in, idx_out, seg, 32, stream, seg_hi));
     else VOX_HIP(sort_pairs_u64(ws->buf[V_TMP], keys_in, keys_out, idx_in, idx_out, n, ebits, stream));
     hipLaunchKernelGGL(vox_heads_batch_kernel, dim3(pb), dim3(256), 0, stream, keys_out, n, (int *)ws->buf[V_HEAD]);
     VOX_HIP(prefix_sum_i32(ws->buf[V_TMP], (const int *)ws->buf[V_HEAD], (int *)ws->buf[V_POS], n, false, stream));

@@ -94,3 +94,16 @@ def test_prefix_sum_is_numpys_cumsum(eng, n, inclusive):
     c = np.cumsum(v.astype(np.int64))
     want = c if inclusive else np.concatenate([[0], c[:-1]])
     assert np.array_equal(out, want.astype(np.int32))
+
+
+def test_sort_u64_one_segment_with_a_common_high_word_takes_the_record_passes(eng):
+    """keys that share their high word within every segment go through 8-byte records between the first and the last pass (the hook says
+    so to the sort when it sees it): one segment of 1.3 M pairs (big tiles) and of 5 000 (small tiles), bits 32 and 20"""
+    for n, bits in ((1_300_000, 32), (5000, 32), (70_000, 20)):
+        rs = np.random.RandomState(n + bits)
+        keys = (np.uint64(7) << np.uint64(32)) | rs.randint(0, 2 ** 32, size=n, dtype=np.uint64)
+        keys[::3] = keys[0]
+        vals = rs.randint(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
+        ko, vo = eng.selftest_sort_pairs(keys, vals, bits, segment_offsets=np.array([0, n], dtype=np.int32))
+        order = _expect(keys, bits)
+        assert np.array_equal(vo, vals[order]) and np.array_equal(ko, keys[order])
